@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — KKT assemble+factor+solve iterations/sec (fp64) on MI355X.
+
+Workload at N=1 (BASELINE.json `metric`, configs[2] — the configuration the metric is quoted on):
+  "NlpMDS_ex4 Newton, n_sparse=1e5 n_dense=4096 m=4096": the condensed mixed-dense-sparse KKT system
+  of hiopKKTLinSysCompressedMDSXYcYd (N = n_dense + m = 8192) on the generalised MdsEx1 problem
+  (oracle/problems.py::mds_ex1_g, SURVEY.md §8d "MdsEx1-g").
+One "step" = one IPM iteration's worth of KKT work, inputs already resident in HBM:
+  1 x build_kkt_matrix  (zero N^2, scatter dense blocks, 3 sparse Schur row-builds, diagonals)
+  1 x factorizeWithCurvCheck (blocked no-pivot LDL^T on fp64 MFMA + inertia, returned to the host)
+  3 x solveCompressed  (rhs reduction, forward/backward substitution, recovery of the sparse part)
+(the 1+1+3 split is SURVEY.md §8d's "ideal C3 iteration": initial solve + one BiCGStab refinement
+iteration = 2 preconditioner solves).
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run): the MDS path does not shard (the reference's
+MDS interface is explicitly single-rank, src/Interface/hiopInterface.hpp:582-584) -> "replicas only":
+every rank runs the same workload on its own GPU, value = N * steps / max-over-ranks time, scaling weak.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak (dense), SURVEY.md §8d
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ns", type=int, default=50000, help="x (and s) sparse variables: n_sparse = 2*ns")
+    ap.add_argument("--nd", type=int, default=4096)
+    ap.add_argument("--neq", type=int, default=4093)
+    ap.add_argument("--solves", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(p, Dx, Dd, rhs, nsolves, steps):
+    """The oracle's restatement of the same step (numpy + scipy-OpenBLAS LAPACK DSYTRF/DSYTRS, i.e. the
+    reference's CPU path, src/LinAlg/hiopLinSolverSymDenseLapack.hpp) on the host cores, bounded sample."""
+    from oracle import hiop_oracle as ho
+    k = ho.KKTLinSysCompressedMDSXYcYd(p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j),
+                                       (p.Hss_i, p.Hss_j))
+    k.set_values(p.Jcs_v, p.Jds_v, p.Hss_v, p.Jcd, p.Jdd, p.Hdd, Dx, Dd)
+    rx, ryc, ryd = rhs
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        k.build_kkt_matrix(0.0, 0.0, 0.0, 0.0)
+        nneg = k.factorize_with_curv_check()
+        assert nneg == p.neq + p.nineq
+        for _ in range(nsolves):
+            k.solve_compressed(rx, ryc, ryd)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    return dict(value=steps / dt, unit="KKT iterations/s", cores=int(thr), kind="port",
+                sample=f"{steps} steps of the same workload (N={p.N}; build + DSYTRF + {nsolves}x DSYTRS), "
+                       f"{dt:.1f} s on the host via oracle/hiop_oracle.py (numpy + scipy-OpenBLAS LAPACK)")
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: no HIP device visible (there is no CPU product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from hiop_amd.runtime import Context, dev
+    from hiop_amd.kkt import mds_from_problem
+    from hiop_amd._lib import lib
+    import ctypes as C
+    from oracle import problems as pr
+
+    p = pr.mds_ex1_g(a.ns, a.nd, a.neq)
+    Dx, Dd = pr.barrier_diagonals(p)
+    rhs = pr.random_rhs(p)
+    ctx = Context(local_rank)
+    kg, dv = mds_from_problem(ctx, p)
+    dv["Dx"], dv["Dd"] = dev(Dx), dev(Dd)
+    kg.set_values(dv["Jcs_v"], dv["Jds_v"], dv["Hss_v"], dv["Jcd"], dv["Jdd"], dv["Hdd"], dv["Dx"], dv["Dd"])
+    rx, ryc, ryd0 = dev(rhs[0]), dev(rhs[1]), dev(rhs[2])
+    ryd = ryd0.clone()
+    dx, dyc, dyd = torch.zeros_like(rx), torch.zeros_like(ryc), torch.zeros_like(ryd)
+    torch.cuda.synchronize()
+    L = lib()
+    expected_neg = p.neq + p.nineq
+
+    def step():
+        kg.build_kkt_matrix(0.0, 0.0, 0.0, 0.0)
+        nneg = kg.factorize_with_curv_check()
+        if nneg != expected_neg:
+            raise RuntimeError(f"wrong inertia {nneg} != {expected_neg}")
+        for _ in range(a.solves):
+            L.hiopamd_copy_d2d(ctx.h, C.c_void_p(ryd.data_ptr()), C.c_void_p(ryd0.data_ptr()), ryd.numel() * 8)
+            kg.solve_compressed(rx, ryc, ryd, dx, dyc, dyd)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline pass: the same K steps with HIP events around every launch of the dominant kernel
+    ls = C.c_void_p(L.hiopamd_kkt_mds_linsolver(kg.h))
+    L.hiopamd_linsolver_profile(ls, 1)
+    for _ in range(a.steps):
+        step()
+    ctx.sync()
+    ums, ufl, ul = C.c_double(0), C.c_double(0), C.c_int64(0)
+    L.hiopamd_linsolver_profile_read(ls, C.byref(ums), C.byref(ufl), C.byref(ul))
+    L.hiopamd_linsolver_profile(ls, 0)
+    launches = max(int(ul.value), 1)
+    flops_per_launch = ufl.value / launches
+    ms_per_launch = ums.value / launches
+    achieved = (flops_per_launch / (ms_per_launch * 1e-3)) / 1e12 if ms_per_launch > 0 else 0.0
+    roofline = dict(bound="mfma", kernel="ldlt_update_kernel (rank-K trailing update, v_mfma_f64_16x16x4_f64)",
+                    achieved=achieved, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
+                    traffic=None, launches_per_step=launches / a.steps, avg_launch_ms=ms_per_launch,
+                    algorithmic_flops_per_launch=flops_per_launch,
+                    update_ms_per_step=ums.value / a.steps)
+
+    # ---- parity spot check of the last solve against the oracle's residual definition (not timed)
+    from oracle import hiop_oracle as ho
+    ko = ho.KKTLinSysCompressedMDSXYcYd(p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j),
+                                        (p.Hss_i, p.Hss_j))
+    ko.set_values(p.Jcs_v, p.Jds_v, p.Hss_v, p.Jcd, p.Jdd, p.Hdd, Dx, Dd)
+    res = ho.kkt_mds_full_residual(ko, (0.0, 0.0, 0.0, 0.0), rhs[0], rhs[1], rhs[2], dx.cpu().numpy(), dyc.cpu().numpy(),
+                                   dyd.cpu().numpy())
+
+    out = None
+    if rank == 0:
+        value = world * a.steps / dt
+        out = {
+            "metric": "KKT assemble+factor+solve iters/sec (fp64)",
+            "value": value, "unit": "KKT iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"NlpMDS condensed KKT (MdsEx1-g): n_sparse={p.nxs} n_dense={p.nxd} m={p.neq + p.nineq} "
+                                   f"N={p.N}; step = 1 assemble + 1 LDL^T factor(+inertia) + {a.solves} solveCompressed",
+                       "parallelism": "single GPU" if world == 1 else f"replicas only x{world} (MDS path does not shard)"},
+            "roofline": roofline,
+            "check": {"kkt_residual_rel_inf": max(res), "inertia_neg": expected_neg},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p, Dx, Dd, rhs, a.solves, a.cpu_steps)
+        print(json.dumps(out), flush=True)
+    kg.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

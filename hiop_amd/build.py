@@ -1,0 +1,93 @@
+"""Build the gfx950 shared library `hiop_amd/lib/libhiopamd.so` in-tree with hipcc.
+
+One translation unit per kernel family (compiled in parallel), linked against RCCL.  There is no
+CPU build and no fallback: if hipcc is missing this raises.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+LIBDIR = ROOT / "lib"
+LIB = LIBDIR / "libhiopamd.so"
+OBJDIR = ROOT / "build"
+
+SOURCES = [
+    "context.hip",
+    "vector_kernels.hip",
+    "dense_kernels.hip",
+    "sparse_kernels.hip",
+    "gram.hip",
+    "ldlt.hip",
+    "small_solvers.hip",
+    "kkt_mds.hip",
+    "lowrank.hip",
+]
+
+ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-ffp-contract=on"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: hiop_amd has no CPU build")
+    return exe
+
+
+def _deps() -> list[Path]:
+    hdrs = list(CSRC.glob("*.hpp")) + list((ROOT.parent / "include").glob("*.h"))
+    return hdrs
+
+
+def _needs(obj: Path, src: Path) -> bool:
+    if not obj.exists():
+        return True
+    t = obj.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in [src, *_deps()])
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    hipcc = _hipcc()
+    OBJDIR.mkdir(exist_ok=True)
+    LIBDIR.mkdir(exist_ok=True)
+    srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
+    jobs = []
+    for src in srcs:
+        obj = OBJDIR / (src.stem + ".o")
+        if force or _needs(obj, src):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc, *CXXFLAGS, "-c", str(src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr[-4000:]}")
+        return src.name
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for name in ex.map(cc, jobs):
+                if verbose:
+                    print(f"[hiop_amd.build] compiled {name}", file=sys.stderr)
+    objs = [OBJDIR / (s.stem + ".o") for s in srcs]
+    if force or jobs or not LIB.exists():
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-L/opt/rocm/lib", "-lrccl",
+               "-Wl,-rpath,/opt/rocm/lib", "-o", str(LIB)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[hiop_amd.build] linked {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,166 @@
+// Execution context, memory entry points and the RCCL all-reduce hook.
+//
+// reference plug point: src/ExecBackends/ExecSpace.hpp:345-457 (alloc_array / dealloc_array / copy
+// forwarded to AllocImpl / DeAllocImpl / TransferImpl) and the MPI_Allreduce call sites of the
+// column-distributed objects.  Here the collective is RCCL over xGMI: one
+// communicator per context, one rank per GPU, reductions issued on the context's stream so that
+// they are ordered with the kernels that produce / consume the (device-resident) small blocks.
+#include "common.hpp"
+
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+namespace {
+struct RcclState {
+  ncclComm_t comm = nullptr;
+};
+
+int rccl_allreduce(void* user, double* buf, size_t count, int op, void* stream)
+{
+  RcclState* st = static_cast<RcclState*>(user);
+  ncclRedOp_t rop = ncclSum;
+  if(op == HIOPAMD_MIN) rop = ncclMin;
+  if(op == HIOPAMD_MAX) rop = ncclMax;
+  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, rop, st->comm, (hipStream_t)stream);
+  return r == ncclSuccess ? 0 : -1;
+}
+}  // namespace
+
+extern "C" {
+
+const char* hiopamd_version(void) { return "hiop_amd 0.1.0 (gfx950)"; }
+
+int hiopamd_device_info(char* name_host, size_t name_len, int* cu_count_host, size_t* hbm_bytes_host)
+{
+  int dev = 0;
+  HIOPAMD_CHECK(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  HIOPAMD_CHECK(hipGetDeviceProperties(&p, dev));
+  if(name_host && name_len) {
+    std::snprintf(name_host, name_len, "%s (%s)", p.name, p.gcnArchName);
+  }
+  if(cu_count_host) *cu_count_host = p.multiProcessorCount;
+  if(hbm_bytes_host) *hbm_bytes_host = p.totalGlobalMem;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ctx_create(hiopamd_ctx** out, void* hip_stream)
+{
+  if(!out) return HIOPAMD_ERR_ARG;
+  int ndev = 0;
+  if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    std::fprintf(stderr, "[hiop_amd] no HIP device visible: this library has no CPU path\n");
+    return HIOPAMD_ERR_NODEVICE;
+  }
+  hiopamd_ctx* c = new hiopamd_ctx();
+  if(hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+  } else {
+    HIOPAMD_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  HIOPAMD_CHECK(hipMalloc(&c->d_partials, sizeof(double) * 4 * hiopamd::kPartials));
+  HIOPAMD_CHECK(hipMalloc(&c->d_result, sizeof(double) * hiopamd::kHostSlots));
+  HIOPAMD_CHECK(hipMalloc(&c->d_iresult, 256));
+  HIOPAMD_CHECK(hipHostMalloc(&c->h_result, sizeof(double) * hiopamd::kHostSlots, hipHostMallocMapped));
+  HIOPAMD_CHECK(hipHostGetDevicePointer((void**)&c->h_result_dev, c->h_result, 0));
+  std::memset(c->h_result, 0, sizeof(double) * hiopamd::kHostSlots);
+  *out = c;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ctx_destroy(hiopamd_ctx* c)
+{
+  if(!c) return HIOPAMD_OK;
+  hipStreamSynchronize(c->stream);
+  if(c->allreduce == rccl_allreduce && c->allreduce_user) {
+    RcclState* st = static_cast<RcclState*>(c->allreduce_user);
+    if(st->comm) ncclCommDestroy(st->comm);
+    delete st;
+  }
+  hipFree(c->d_partials);
+  hipFree(c->d_result);
+  hipFree(c->d_iresult);
+  hipHostFree(c->h_result);
+  if(c->d_work) hipFree(c->d_work);
+  if(c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ctx_sync(hiopamd_ctx* c)
+{
+  HIOPAMD_CHECK(hipStreamSynchronize(c->stream));
+  return HIOPAMD_OK;
+}
+
+void* hiopamd_ctx_stream(hiopamd_ctx* c) { return (void*)c->stream; }
+
+int hiopamd_ctx_set_allreduce(hiopamd_ctx* c, hiopamd_allreduce_fn fn, void* user, int rank, int size)
+{
+  if(!c || size < 1 || rank < 0 || rank >= size) return HIOPAMD_ERR_ARG;
+  c->allreduce = fn;
+  c->allreduce_user = user;
+  c->comm_rank = rank;
+  c->comm_size = size;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_rccl_unique_id(unsigned char* unique_id_128_host)
+{
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  if(ncclGetUniqueId(&id) != ncclSuccess) return HIOPAMD_ERR_HIP;
+  std::memcpy(unique_id_128_host, &id, sizeof(id));
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ctx_init_rccl(hiopamd_ctx* c, const unsigned char* unique_id_128_host, int rank, int size)
+{
+  if(!c || !unique_id_128_host || size < 1 || rank < 0 || rank >= size) return HIOPAMD_ERR_ARG;
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id_128_host, sizeof(id));
+  RcclState* st = new RcclState();
+  if(ncclCommInitRank(&st->comm, size, id, rank) != ncclSuccess) {
+    delete st;
+    return HIOPAMD_ERR_HIP;
+  }
+  return hiopamd_ctx_set_allreduce(c, rccl_allreduce, st, rank, size);
+}
+
+int hiopamd_alloc(void** dptr, size_t bytes)
+{
+  if(!dptr) return HIOPAMD_ERR_ARG;
+  *dptr = nullptr;
+  if(bytes == 0) return HIOPAMD_OK;
+  HIOPAMD_CHECK(hipMalloc(dptr, bytes));
+  return HIOPAMD_OK;
+}
+int hiopamd_free(void* dptr)
+{
+  if(dptr) HIOPAMD_CHECK(hipFree(dptr));
+  return HIOPAMD_OK;
+}
+int hiopamd_copy_h2d(hiopamd_ctx* c, void* dst, const void* src_host, size_t bytes)
+{
+  if(bytes == 0) return HIOPAMD_OK;
+  HIOPAMD_CHECK(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+  HIOPAMD_CHECK(hipStreamSynchronize(c->stream));
+  return HIOPAMD_OK;
+}
+int hiopamd_copy_d2h(hiopamd_ctx* c, void* dst_host, const void* src, size_t bytes)
+{
+  if(bytes == 0) return HIOPAMD_OK;
+  HIOPAMD_CHECK(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIOPAMD_CHECK(hipStreamSynchronize(c->stream));
+  return HIOPAMD_OK;
+}
+int hiopamd_copy_d2d(hiopamd_ctx* c, void* dst, const void* src, size_t bytes)
+{
+  if(bytes == 0) return HIOPAMD_OK;
+  HIOPAMD_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return HIOPAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,498 @@
+// hiopMatrixDense (row-major) kernels for gfx950.
+//
+// reference: src/LinAlg/hiopMatrixDenseRowMajor.cpp (method line numbers are cited on the entry
+// points in include/hiop_amd.h).  The matrices on the KKT hot path are either tall-skinny
+// (Jacobian k x n_local, k <= ~200, n_local ~ 1e6: GEMV is HBM-bound, one pass over A) or the
+// N x N condensed KKT matrix (assembly = streaming scatter of dense blocks).  Layout is the
+// reference's: row-major, rows contiguous, so every kernel walks a row with consecutive lanes
+// (512 B / wave / instruction) and tiles rows so the x / y vector is re-used from registers/L2.
+#include "device_utils.hpp"
+
+namespace hiopamd {
+
+// ------------------------------------------------------------------------------------------
+// y = beta*y + alpha*A*x      A: m x n row-major.
+// stage 1: block (cx, ry) owns ROWS_PER_BLOCK rows x COLS_PER_BLOCK columns, writes partial sums
+//          part[cx][row];  stage 2 folds the column chunks in index order (deterministic).
+// ------------------------------------------------------------------------------------------
+constexpr int GEMV_ROWS = 8;
+constexpr int GEMV_COLS_PER_THREAD = 8;
+constexpr int GEMV_COLS = kBlock * GEMV_COLS_PER_THREAD;  // 2048 columns per block
+
+__global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const double* __restrict__ A, int64_t lda,
+                                                        const double* __restrict__ x, double* __restrict__ part)
+{
+  const int64_t c0 = (int64_t)blockIdx.x * GEMV_COLS;
+  const int r0 = blockIdx.y * GEMV_ROWS;
+  double xv[GEMV_COLS_PER_THREAD];
+#pragma unroll
+  for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) {
+    int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
+    xv[u] = (j < n) ? x[j] : 0.0;
+  }
+  double acc[GEMV_ROWS];
+#pragma unroll
+  for(int r = 0; r < GEMV_ROWS; ++r) {
+    acc[r] = 0.0;
+    const int row = r0 + r;
+    if(row < m) {
+      const double* Ar = A + (int64_t)row * lda;
+#pragma unroll
+      for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) {
+        int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
+        if(j < n) acc[r] = fma(Ar[j], xv[u], acc[r]);
+      }
+    }
+  }
+  // block reduce the 8 accumulators
+  __shared__ double sm[GEMV_ROWS][kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for(int r = 0; r < GEMV_ROWS; ++r) {
+    double v = acc[r];
+    for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if(lane == 0) sm[r][wave] = v;
+  }
+  __syncthreads();
+  if(threadIdx.x < GEMV_ROWS) {
+    const int row = r0 + threadIdx.x;
+    if(row < m) {
+      double v = ((sm[threadIdx.x][0] + sm[threadIdx.x][1]) + sm[threadIdx.x][2]) + sm[threadIdx.x][3];
+      part[(int64_t)blockIdx.x * m + row] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gemv_n_stage2(int m, int nchunks, const double* __restrict__ part,
+                                                        double beta, double* __restrict__ y, double alpha)
+{
+  // one wave per row: lanes fold chunks lane, lane+64, ... then shuffle tree
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if(wave >= m) return;
+  double v = 0.0;
+  for(int c = lane; c < nchunks; c += 64) v += part[(int64_t)c * m + wave];
+  for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if(lane == 0) {
+    // reference (DGEMV semantics): beta==0 overwrites (no NaN propagation from y)
+    y[wave] = (beta == 0.0 ? 0.0 : beta * y[wave]) + alpha * v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// y = beta*y + alpha*A^T*x    A: m x n row-major ; y has n entries.
+// thread per column (coalesced along rows); rows split over blockIdx.y when m is large.
+// ------------------------------------------------------------------------------------------
+constexpr int GEMVT_ROWCHUNK = 64;
+
+__global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const double* __restrict__ A, int64_t lda,
+                                                        const double* __restrict__ x, int rows_per_split,
+                                                        double* __restrict__ out, int64_t out_stride, double beta,
+                                                        double alpha, int direct)
+{
+  const int r_begin = blockIdx.y * rows_per_split;
+  int r_end = r_begin + rows_per_split;
+  if(r_end > m) r_end = m;
+  __shared__ double xs[GEMVT_ROWCHUNK];
+  const int64_t j0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
+  double a0 = 0.0, a1 = 0.0;
+  const bool two = (j0 + 1 < n) && ((lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0);
+  for(int rb = r_begin; rb < r_end; rb += GEMVT_ROWCHUNK) {
+    int rc = r_end - rb;
+    if(rc > GEMVT_ROWCHUNK) rc = GEMVT_ROWCHUNK;
+    __syncthreads();
+    if(threadIdx.x < rc) xs[threadIdx.x] = x[rb + threadIdx.x];
+    __syncthreads();
+    if(j0 < n) {
+      const double* Ap = A + (int64_t)rb * lda + j0;
+      if(two) {
+#pragma unroll 8
+        for(int r = 0; r < rc; ++r) {
+          const double2 v = *reinterpret_cast<const double2*>(Ap + (int64_t)r * lda);
+          a0 = fma(v.x, xs[r], a0);
+          a1 = fma(v.y, xs[r], a1);
+        }
+      } else {
+        for(int r = 0; r < rc; ++r) {
+          a0 = fma(Ap[(int64_t)r * lda], xs[r], a0);
+          if(j0 + 1 < n) a1 = fma(Ap[(int64_t)r * lda + 1], xs[r], a1);
+        }
+      }
+    }
+  }
+  if(j0 < n) {
+    if(direct) {
+      out[j0] = (beta == 0.0 ? 0.0 : beta * out[j0]) + alpha * a0;
+      if(j0 + 1 < n) out[j0 + 1] = (beta == 0.0 ? 0.0 : beta * out[j0 + 1]) + alpha * a1;
+    } else {
+      double* o = out + (int64_t)blockIdx.y * out_stride;
+      o[j0] = a0;
+      if(j0 + 1 < n) o[j0 + 1] = a1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gemv_t_fold(int64_t n, int nsplit, const double* __restrict__ part,
+                                                      int64_t stride, double beta, double* __restrict__ y, double alpha)
+{
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if(j >= n) return;
+  double v = 0.0;
+  for(int s = 0; s < nsplit; ++s) v += part[(int64_t)s * stride + j];
+  y[j] = (beta == 0.0 ? 0.0 : beta * y[j]) + alpha * v;
+}
+
+// ------------------------------------------------------------------------------------------
+// small generic GEMM: C(M x N) = beta*C + alpha*opA(M x K)*opB(K x N), arbitrary element strides.
+// Used for the l x l / k x 2l / 2l x k products of the low-rank KKT (reference DGEMM call sites
+// hiopMatrixDenseRowMajor.cpp:601,640,673).  LDS-tiled 16x16, one output per thread.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void small_gemm(int M, int N, int K, const double* __restrict__ A, int64_t a_rs,
+                                                  int64_t a_cs, const double* __restrict__ B, int64_t b_rs,
+                                                  int64_t b_cs, double beta, double* __restrict__ C, int64_t ldc,
+                                                  double alpha)
+{
+  __shared__ double As[16][17];
+  __shared__ double Bs[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+  double acc = 0.0;
+  for(int k0 = 0; k0 < K; k0 += 16) {
+    As[ty][tx] = (row < M && k0 + tx < K) ? A[(int64_t)row * a_rs + (int64_t)(k0 + tx) * a_cs] : 0.0;
+    Bs[ty][tx] = (k0 + ty < K && col < N) ? B[(int64_t)(k0 + ty) * b_rs + (int64_t)col * b_cs] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for(int kk = 0; kk < 16; ++kk) acc = fma(As[ty][kk], Bs[kk][tx], acc);
+    __syncthreads();
+  }
+  if(row < M && col < N) {
+    double* c = C + (int64_t)row * ldc + col;
+    *c = (beta == 0.0 ? 0.0 : beta * (*c)) + alpha * acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// assembly kernels
+// ------------------------------------------------------------------------------------------
+// W[row_start + jc][col_start + ir] += alpha*A[ir][jc]   (32x32 LDS transpose, coalesced both sides)
+__global__ __launch_bounds__(256) void trans_add_kernel(int m, int n, const double* __restrict__ A, int64_t lda,
+                                                        int row_start, int col_start, double alpha,
+                                                        double* __restrict__ W, int64_t ldw)
+{
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int ir0 = blockIdx.y * 32, jc0 = blockIdx.x * 32;
+#pragma unroll
+  for(int r = ty; r < 32; r += 8) {
+    int ir = ir0 + r, jc = jc0 + tx;
+    tile[r][tx] = (ir < m && jc < n) ? A[(int64_t)ir * lda + jc] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for(int r = ty; r < 32; r += 8) {
+    int jc = jc0 + r, ir = ir0 + tx;  // W row = jc, W col = ir
+    if(ir < m && jc < n) {
+      double* w = W + (int64_t)(row_start + jc) * ldw + (col_start + ir);
+      *w += alpha * tile[tx][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void add_upper_kernel(int n, const double* __restrict__ A, int64_t lda,
+                                                           int diag_start, double alpha, double* __restrict__ W,
+                                                           int64_t ldw)
+{
+  const int i = blockIdx.y;
+  const double* Ar = A + (int64_t)i * lda;
+  double* Wr = W + (int64_t)(i + diag_start) * ldw + diag_start;
+  for(int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+    if(j >= i) Wr[j] += alpha * Ar[j];
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void mat_ew_kernel(int m, int64_t n, F f)
+{
+  // 2-D element-wise: blockIdx.y strides rows, x strides columns
+  for(int i = blockIdx.y; i < m; i += gridDim.y) {
+    for(int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) f(i, j);
+  }
+}
+template <class F>
+static inline int launch_mat_ew(hiopamd_ctx* ctx, int m, int64_t n, F f)
+{
+  if(m < 0 || n < 0) return HIOPAMD_ERR_ARG;
+  if(m == 0 || n == 0) return HIOPAMD_OK;
+  int gx = (int)((n + kBlock - 1) / kBlock);
+  if(gx > 1024) gx = 1024;
+  int gy = m;
+  while((int64_t)gx * gy > 16384 && gy > 1) gy = (gy + 1) / 2;
+  hipLaunchKernelGGL(mat_ew_kernel<F>, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, m, n, f);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+struct OpMatAbsMax {
+  const double* A;
+  int64_t lda, n;
+  __device__ double identity() const { return 0.0; }
+  __device__ double map(int64_t t) const
+  {
+    int64_t i = t / n, j = t - i * n;
+    return fabs(A[i * lda + j]);
+  }
+  __device__ double combine(double a, double b) const { return (b > a) ? b : a; }
+};
+struct OpMatNotFinite {
+  const double* A;
+  int64_t lda, n;
+  __device__ double identity() const { return 0.0; }
+  __device__ double map(int64_t t) const
+  {
+    int64_t i = t / n, j = t - i * n;
+    return isfinite(A[i * lda + j]) ? 0.0 : 1.0;
+  }
+  __device__ double combine(double a, double b) const { return a + b; }
+};
+
+// one block per row: max |A[i,:]|
+__global__ __launch_bounds__(kBlock) void row_max_abs_kernel(int64_t n, const double* __restrict__ A, int64_t lda,
+                                                             double* __restrict__ out)
+{
+  const double* Ar = A + (int64_t)blockIdx.x * lda;
+  double v = 0.0;
+  for(int64_t j = threadIdx.x; j < n; j += kBlock) {
+    double a = fabs(Ar[j]);
+    if(a > v) v = a;
+  }
+  for(int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_down(v, off, 64);
+    if(o > v) v = o;
+  }
+  __shared__ double sm[kBlock / 64];
+  if((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    for(int w = 1; w < kBlock / 64; ++w)
+      if(sm[w] > v) v = sm[w];
+    out[blockIdx.x] = v;
+  }
+}
+
+}  // namespace hiopamd
+
+using namespace hiopamd;
+
+extern "C" {
+
+int hiopamd_mat_set_to_constant(hiopamd_ctx* ctx, int m, int64_t n, double* A, int64_t lda, double c)
+{
+  if(lda == n) return hiopamd_vec_set_to_constant(ctx, (int64_t)m * n, A, c);
+  return launch_mat_ew(ctx, m, n, [=] __device__(int i, int64_t j) { A[(int64_t)i * lda + j] = c; });
+}
+
+int hiopamd_mat_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, double beta, double* y,
+                          double alpha, const double* x)
+{
+  if(m < 0 || n < 0) return HIOPAMD_ERR_ARG;
+  if(m == 0) return HIOPAMD_OK;
+  if(n == 0) return hiopamd_vec_scale(ctx, m, y, beta);
+  const int nchunks = (int)((n + GEMV_COLS - 1) / GEMV_COLS);
+  const int rtiles = (m + GEMV_ROWS - 1) / GEMV_ROWS;
+  double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nchunks * m);
+  hipLaunchKernelGGL(gemv_n_stage1, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
+  const int waves_per_block = kBlock / 64;
+  hipLaunchKernelGGL(gemv_n_stage2, dim3((m + waves_per_block - 1) / waves_per_block), dim3(kBlock), 0, ctx->stream, m,
+                     nchunks, part, beta, y, alpha);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_mat_trans_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, double beta,
+                                double* y, double alpha, const double* x)
+{
+  if(m < 0 || n < 0) return HIOPAMD_ERR_ARG;
+  if(n == 0) return HIOPAMD_OK;
+  if(m == 0) return hiopamd_vec_scale(ctx, n, y, beta);
+  const int gx = (int)((n + 2 * kBlock - 1) / (2 * kBlock));
+  // split rows so that the launch has >= ~1024 workgroups when the matrix is not tall-skinny
+  int nsplit = 1;
+  if(gx < 1024) {
+    nsplit = (1024 + gx - 1) / gx;
+    int maxsplit = (m + GEMVT_ROWCHUNK - 1) / GEMVT_ROWCHUNK;
+    if(nsplit > maxsplit) nsplit = maxsplit;
+    if(nsplit < 1) nsplit = 1;
+  }
+  int rows_per_split = (m + nsplit - 1) / nsplit;
+  rows_per_split = ((rows_per_split + GEMVT_ROWCHUNK - 1) / GEMVT_ROWCHUNK) * GEMVT_ROWCHUNK;
+  nsplit = (m + rows_per_split - 1) / rows_per_split;
+  if(nsplit == 1) {
+    hipLaunchKernelGGL(gemv_t_kernel, dim3(gx, 1), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split, y,
+                       (int64_t)0, beta, alpha, 1);
+  } else {
+    double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * n);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3(gx, nsplit), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split,
+                       part, n, 0.0, 1.0, 0);
+    hipLaunchKernelGGL(gemv_t_fold, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, nsplit,
+                       part, n, beta, y, alpha);
+  }
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+static int launch_small_gemm(hiopamd_ctx* ctx, int M, int N, int K, const double* A, int64_t a_rs, int64_t a_cs,
+                             const double* B, int64_t b_rs, int64_t b_cs, double beta, double* C, int64_t ldc,
+                             double alpha)
+{
+  if(M < 0 || N < 0 || K < 0) return HIOPAMD_ERR_ARG;
+  if(M == 0 || N == 0) return HIOPAMD_OK;
+  hipLaunchKernelGGL(small_gemm, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, ctx->stream, M, N, K, A, a_rs, a_cs,
+                     B, b_rs, b_cs, beta, C, ldc, alpha);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_mat_times_mat(hiopamd_ctx* ctx, int m, int n, int k, const double* A, int64_t lda, double beta, double* W,
+                          int64_t ldw, double alpha, const double* X, int64_t ldx)
+{
+  return launch_small_gemm(ctx, m, k, n, A, lda, 1, X, ldx, 1, beta, W, ldw, alpha);
+}
+int hiopamd_mat_trans_times_mat(hiopamd_ctx* ctx, int m, int n, int k, const double* A, int64_t lda, double beta,
+                                double* W, int64_t ldw, double alpha, const double* X, int64_t ldx)
+{
+  return launch_small_gemm(ctx, n, k, m, A, 1, lda, X, ldx, 1, beta, W, ldw, alpha);
+}
+int hiopamd_mat_times_mat_trans(hiopamd_ctx* ctx, int m, int64_t n, int k, const double* A, int64_t lda, double beta,
+                                double* W, int64_t ldw, double alpha, const double* X, int64_t ldx)
+{
+  // A(m x n) * X(k x n)^T over a long n is the (unweighted) Gram kernel on MFMA
+  if(n > 4096) return hiopamd_gram_weighted(ctx, m, k, n, A, lda, X, ldx, nullptr, beta, W, ldw, alpha, 0);
+  return launch_small_gemm(ctx, m, k, (int)n, A, lda, 1, X, 1, ldx, beta, W, ldw, alpha);
+}
+
+int hiopamd_mat_add_sub_diagonal(hiopamd_ctx* ctx, double* A, int64_t lda, int start, double alpha, const double* d,
+                                 int src_start, int num)
+{
+  if(num < 0 || start < 0 || src_start < 0) return HIOPAMD_ERR_ARG;
+  return launch_ew(ctx, num, [=] __device__(int64_t i) {
+    A[(int64_t)(start + i) * lda + (start + i)] += alpha * d[src_start + i];
+  });
+}
+int hiopamd_mat_add_sub_diagonal_const(hiopamd_ctx* ctx, double* A, int64_t lda, int start, int num, double c)
+{
+  if(num < 0 || start < 0) return HIOPAMD_ERR_ARG;
+  return launch_ew(ctx, num, [=] __device__(int64_t i) { A[(int64_t)(start + i) * lda + (start + i)] += c; });
+}
+int hiopamd_mat_add_diagonal_vec(hiopamd_ctx* ctx, int n, double* A, int64_t lda, double alpha, const double* d)
+{
+  return hiopamd_mat_add_sub_diagonal(ctx, A, lda, 0, alpha, d, 0, n);
+}
+int hiopamd_mat_add_diagonal_const(hiopamd_ctx* ctx, int n, double* A, int64_t lda, double value)
+{
+  return hiopamd_mat_add_sub_diagonal_const(ctx, A, lda, 0, n, value);
+}
+int hiopamd_mat_add_matrix(hiopamd_ctx* ctx, int m, int64_t n, double* A, int64_t lda, double alpha, const double* X,
+                           int64_t ldx)
+{
+  return launch_mat_ew(ctx, m, n,
+                       [=] __device__(int i, int64_t j) { A[(int64_t)i * lda + j] += alpha * X[(int64_t)i * ldx + j]; });
+}
+
+int hiopamd_mat_trans_add_to_sym_upper(hiopamd_ctx* ctx, int m, int n, const double* A, int64_t lda, int row_start,
+                                       int col_start, double alpha, double* W, int64_t ldw)
+{
+  if(m < 0 || n < 0 || row_start < 0 || col_start < 0) return HIOPAMD_ERR_ARG;
+  if(m == 0 || n == 0) return HIOPAMD_OK;
+  // precondition of the reference (assert iW<=jW): the block maps inside the upper triangle
+  if(row_start + n - 1 > col_start) return HIOPAMD_ERR_ARG;
+  hipLaunchKernelGGL(trans_add_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, ctx->stream, m, n, A, lda,
+                     row_start, col_start, alpha, W, ldw);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_mat_add_upper_to_sym_upper(hiopamd_ctx* ctx, int n, const double* A, int64_t lda, int diag_start,
+                                       double alpha, double* W, int64_t ldw)
+{
+  if(n < 0 || diag_start < 0) return HIOPAMD_ERR_ARG;
+  if(n == 0) return HIOPAMD_OK;
+  int gx = (n + kBlock - 1) / kBlock;
+  if(gx > 8) gx = 8;
+  hipLaunchKernelGGL(add_upper_kernel, dim3(gx, n), dim3(kBlock), 0, ctx->stream, n, A, lda, diag_start, alpha, W, ldw);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_mat_copy_rows_from(hiopamd_ctx* ctx, int num_rows, int64_t n, double* A, int64_t lda, int row_dest,
+                               const double* src, int64_t ldsrc)
+{
+  if(num_rows <= 0 || n <= 0) return (num_rows < 0 || n < 0) ? HIOPAMD_ERR_ARG : HIOPAMD_OK;
+  HIOPAMD_CHECK(hipMemcpy2DAsync(A + (int64_t)row_dest * lda, lda * sizeof(double), src, ldsrc * sizeof(double),
+                                 n * sizeof(double), num_rows, hipMemcpyDeviceToDevice, ctx->stream));
+  return HIOPAMD_OK;
+}
+int hiopamd_mat_copy_rows_from_idx(hiopamd_ctx* ctx, int num_rows, int64_t n, double* A, int64_t lda,
+                                   const double* src, int64_t ldsrc, const int* rows_idxs)
+{
+  return launch_mat_ew(ctx, num_rows, n, [=] __device__(int i, int64_t j) {
+    A[(int64_t)i * lda + j] = src[(int64_t)rows_idxs[i] * ldsrc + j];
+  });
+}
+int hiopamd_mat_copy_block(hiopamd_ctx* ctx, int m, int n, double* dst, int64_t lddst, const double* src,
+                           int64_t ldsrc)
+{
+  return hiopamd_mat_copy_rows_from(ctx, m, n, dst, lddst, 0, src, ldsrc);
+}
+
+int hiopamd_mat_shift_rows(hiopamd_ctx* ctx, int m, int64_t n, double* A, int64_t lda, int shift)
+{
+  // reference :238 — rows move by `shift` (|shift| < m); vacated rows keep their old content.
+  if(shift == 0 || m == 0 || n == 0) return HIOPAMD_OK;
+  if(abs(shift) >= m) return HIOPAMD_ERR_ARG;
+  const int cnt = m - abs(shift);
+  // overlapping row ranges: stage through the workspace (one extra pass over l x n doubles)
+  double* tmp = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)cnt * n);
+  const double* src = shift > 0 ? A : A + (int64_t)(-shift) * lda;
+  double* dst = shift > 0 ? A + (int64_t)shift * lda : A;
+  HIOPAMD_CHECK(hipMemcpy2DAsync(tmp, n * sizeof(double), src, lda * sizeof(double), n * sizeof(double), cnt,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+  HIOPAMD_CHECK(hipMemcpy2DAsync(dst, lda * sizeof(double), tmp, n * sizeof(double), n * sizeof(double), cnt,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+  return HIOPAMD_OK;
+}
+
+int hiopamd_mat_max_abs(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, double* out)
+{
+  return launch_reduce<double>(ctx, (int64_t)m * n, OpMatAbsMax{A, lda, n}, out);
+}
+int hiopamd_mat_is_finite(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, int* out)
+{
+  double c = 0.0;
+  int st = launch_reduce<double>(ctx, (int64_t)m * n, OpMatNotFinite{A, lda, n}, &c);
+  *out = (c == 0.0) ? 1 : 0;
+  return st;
+}
+int hiopamd_mat_row_max_abs(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, double* ret_vec)
+{
+  if(m <= 0) return HIOPAMD_OK;
+  hipLaunchKernelGGL(row_max_abs_kernel, dim3(m), dim3(kBlock), 0, ctx->stream, n, A, lda, ret_vec);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+int hiopamd_mat_scale_rows(hiopamd_ctx* ctx, int m, int64_t n, double* A, int64_t lda, const double* scal, int inv)
+{
+  return launch_mat_ew(ctx, m, n, [=] __device__(int i, int64_t j) {
+    double s = scal[i];
+    if(inv) s = 1.0 / s;
+    A[(int64_t)i * lda + j] *= s;
+  });
+}
+int hiopamd_mat_symmetrize(hiopamd_ctx* ctx, int n, double* A, int64_t lda)
+{
+  // copy the upper triangle onto the lower (reference :912 symmetrize())
+  return launch_mat_ew(ctx, n, n, [=] __device__(int i, int64_t j) {
+    if(j > i) A[j * lda + i] = A[(int64_t)i * lda + j];
+  });
+}
+
+}  // extern "C"

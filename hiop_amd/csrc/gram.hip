@@ -1,0 +1,165 @@
+// Weighted Gram kernels  W = beta*W + alpha * A * diag(d) * B^T  on fp64 MFMA (gfx950).
+//
+// reference: hiopHessianLowRank::symmMatTimesDiagTimesMatTrans_local
+// (src/Optimization/hiopHessianLowRank.cpp:1079, triple scalar loop, no blocking) and
+// matTimesDiagTimesMatTrans_local (:1119); the un-weighted form is hiopMatrixDense::timesMatTrans
+// (src/LinAlg/hiopMatrixDenseRowMajor.cpp:646).  These are the quasi-Newton hot kernels: A is the
+// k x n_local constraint Jacobian (k <= ~256, n_local ~ 1e6), so the contraction runs over the LONG
+// dimension.  Both operands are K-contiguous ("NT" GEMM): tiles are staged through LDS with coalesced
+// 256-byte row pieces, the weight d is folded in while staging, the K range is split across workgroups
+// (>= 2 per CU) and the per-split partial tiles are folded in a fixed order by a second kernel
+// (deterministic, no atomics) which also applies alpha/beta and the upper-triangle mask.
+#include "device_utils.hpp"
+
+namespace hiopamd {
+
+constexpr int GR_T = 128;        // tile edge (rows of A x rows of B per workgroup)
+constexpr int GR_KT = 32;        // k-depth per LDS stage
+constexpr int GR_LDS = GR_KT + 2;  // 34: 16 rows x 2 k land on 32 distinct 8-byte LDS slots
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// stage a 128 x 32 tile of X (rows r0.., cols k0..) into LDS, optionally scaled by d[k]
+__device__ __forceinline__ void gram_stage(const double* __restrict__ X, int64_t ldx, int nrows, int r0, int64_t k0,
+                                           int64_t kend, const double* __restrict__ d, bool vec_ok,
+                                           double (*Xs)[GR_LDS], int tid)
+{
+  const int kk = (tid & 15) * 2;
+  const int64_t k = k0 + kk;
+  double w0 = 1.0, w1 = 1.0;
+  if(d) {
+    w0 = (k < kend) ? d[k] : 0.0;
+    w1 = (k + 1 < kend) ? d[k + 1] : 0.0;
+  }
+#pragma unroll
+  for(int p = 0; p < 8; ++p) {
+    const int r = p * 16 + (tid >> 4);
+    const int gr = r0 + r;
+    double v0 = 0.0, v1 = 0.0;
+    if(gr < nrows) {
+      const double* src = X + (int64_t)gr * ldx + k;
+      if(vec_ok && k + 1 < kend) {
+        const double2 t = *reinterpret_cast<const double2*>(src);
+        v0 = t.x;
+        v1 = t.y;
+      } else {
+        if(k < kend) v0 = src[0];
+        if(k + 1 < kend) v1 = src[1];
+      }
+    }
+    Xs[r][kk] = v0 * w0;
+    Xs[r][kk + 1] = v1 * w1;
+  }
+}
+
+// partial[split][tile][128][128] (dense 128x128 slabs; only the valid part is read back)
+__global__ __launch_bounds__(kBlock, 2) void gram_partial_kernel(int ma, int mb, int64_t n, const double* __restrict__ A,
+                                                                 int64_t lda, const double* __restrict__ B,
+                                                                 int64_t ldb, const double* __restrict__ d,
+                                                                 int64_t kchunk, int tiles_b, int sym,
+                                                                 double* __restrict__ partial)
+{
+  const int tile = blockIdx.y;
+  const int ta = tile / tiles_b, tb = tile % tiles_b;
+  if(sym && tb < ta) return;
+  const int split = blockIdx.x;
+  const int64_t kbeg = (int64_t)split * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if(kend > n) kend = n;
+  __shared__ double As[GR_T][GR_LDS];
+  __shared__ double Bs[GR_T][GR_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lk = lane >> 4, li = lane & 15;
+  const bool a_vec = ((lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0);
+  const bool b_vec = ((ldb & 1) == 0) && ((((uintptr_t)B) & 15) == 0);
+  const bool same = sym && (ta == tb) && (A == B);
+
+  double4_t acc[4][4];
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+  for(int64_t k0 = kbeg; k0 < kend; k0 += GR_KT) {
+    __syncthreads();
+    // the weight goes on the A side only; the un-weighted symmetric diagonal tile re-uses As for B
+    gram_stage(A, lda, ma, ta * GR_T, k0, kend, d, a_vec, As, tid);
+    const bool reuse = same && (d == nullptr);
+    if(!reuse) gram_stage(B, ldb, mb, tb * GR_T, k0, kend, nullptr, b_vec, Bs, tid);
+    __syncthreads();
+    const double(*Bsrc)[GR_LDS] = reuse ? As : Bs;
+#pragma unroll
+    for(int kk = 0; kk < GR_KT / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for(int i = 0; i < 4; ++i) a[i] = As[wr * 64 + i * 16 + li][kk * 4 + lk];
+#pragma unroll
+      for(int j = 0; j < 4; ++j) b[j] = Bsrc[wc * 64 + j * 16 + li][kk * 4 + lk];
+#pragma unroll
+      for(int i = 0; i < 4; ++i)
+#pragma unroll
+        for(int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // write the partial slab (row-major 128x128)
+  double* P = partial + ((int64_t)split * gridDim.y + tile) * (GR_T * GR_T);
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int row = wr * 64 + i * 16 + lk + 4 * reg;
+#pragma unroll
+      for(int j = 0; j < 4; ++j) {
+        const int col = wc * 64 + j * 16 + li;
+        P[row * GR_T + col] = acc[i][j][reg];
+      }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gram_fold_kernel(int ma, int mb, int nsplit, int ntiles, int tiles_b, int sym,
+                                                           const double* __restrict__ partial, double beta,
+                                                           double* __restrict__ W, int64_t ldw, double alpha)
+{
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if(e >= (int64_t)ma * mb) return;
+  const int i = (int)(e / mb), j = (int)(e % mb);
+  if(sym && j < i) return;
+  const int tile = (i / GR_T) * tiles_b + (j / GR_T);
+  const int off = (i % GR_T) * GR_T + (j % GR_T);
+  double s = 0.0;
+  for(int sp = 0; sp < nsplit; ++sp) s += partial[((int64_t)sp * ntiles + tile) * (GR_T * GR_T) + off];
+  double* w = W + (int64_t)i * ldw + j;
+  *w = (beta == 0.0 ? 0.0 : beta * (*w)) + alpha * s;
+}
+
+}  // namespace hiopamd
+
+using namespace hiopamd;
+
+extern "C" int hiopamd_gram_weighted(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const double* A, int64_t lda,
+                                     const double* B, int64_t ldb, const double* d, double beta, double* W,
+                                     int64_t ldw, double alpha, int sym_upper)
+{
+  if(ma < 0 || mb < 0 || n < 0) return HIOPAMD_ERR_ARG;
+  if(ma == 0 || mb == 0) return HIOPAMD_OK;
+  const int sym = (sym_upper && A == B && ma == mb) ? 1 : 0;
+  const int tiles_a = (ma + GR_T - 1) / GR_T, tiles_b = (mb + GR_T - 1) / GR_T;
+  const int ntiles = tiles_a * tiles_b;
+  // K split: aim at ~2 workgroups per CU (512) over all tiles, chunk a multiple of the stage depth
+  int nsplit = 512 / ntiles;
+  if(nsplit < 1) nsplit = 1;
+  int64_t kchunk = (n + nsplit - 1) / nsplit;
+  kchunk = ((kchunk + GR_KT - 1) / GR_KT) * GR_KT;
+  if(kchunk < 8 * GR_KT) kchunk = 8 * GR_KT;
+  nsplit = (int)((n + kchunk - 1) / kchunk);
+  if(nsplit < 1) nsplit = 1;
+  double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * ntiles * GR_T * GR_T);
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, lda, B, ldb,
+                     d, kchunk, tiles_b, sym, partial);
+  const int64_t tot = (int64_t)ma * mb;
+  hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ma,
+                     mb, nsplit, ntiles, tiles_b, sym, partial, beta, W, ldw, alpha);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}

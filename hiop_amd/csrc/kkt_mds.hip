@@ -1,0 +1,211 @@
+// hiopKKTLinSysCompressedMDSXYcYd on MI355X: condensed mixed-dense-sparse KKT
+//   assemble (build_kkt_matrix) -> factor + inertia (factorizeWithCurvCheck) -> solveCompressed.
+//
+// reference: src/Optimization/hiopKKTLinSysMDS.cpp:78-110 (factorizeWithCurvCheck),
+// :172-305 (build_kkt_matrix), :307-403 (solveCompressed); formulas in
+// src/Optimization/hiopKKTLinSysMDS.hpp:59-95.  The condensed matrix (upper triangle, row-major) is
+//   [ Hd+Dxd+dwx*I      Jcd^T                         Jdd^T                               ]
+//   [                  -Jcs Hxs^-1 Jcs^T - dcc*I     -Jcs Hxs^-1 Jds^T                    ]
+//   [                                                -Jds Hxs^-1 Jds^T - (Dd+dwd)^-1 - dcd*I ]
+// with Hxs = diag(Hs) + Dxs + dwx*I.  Everything stays in HBM: the N x N matrix is owned by the
+// linear-solver object (reference: hiopLinSolverSymDense::sysMatrix, hiopLinSolver.hpp:117-130) and
+// is assembled in place, factored in place and never crosses PCIe (the reference's MAGMA path copies
+// it H2D at every factorisation, hiopLinSolverSymDenseMagma.cpp:337-340).
+#include "device_utils.hpp"
+
+#include <vector>
+
+struct hiopamd_kkt_mds {
+  hiopamd_ctx* ctx = nullptr;
+  hiopamd_mds_structure s{};
+  hiopamd_linsolver* ls = nullptr;
+  hiopamd_sp_plan* plan_cc = nullptr;
+  hiopamd_sp_plan* plan_dd = nullptr;
+  hiopamd_sp_plan* plan_cd = nullptr;
+  // current values (borrowed device pointers)
+  const double *Jcs_val = nullptr, *Jds_val = nullptr, *Hss_val = nullptr;
+  const double *Jcd = nullptr, *Jdd = nullptr, *Hdd = nullptr, *Dx = nullptr, *Dd = nullptr;
+  // owned device buffers
+  double* Hxs = nullptr;      // nxs
+  double* Dd_inv = nullptr;   // nineq
+  double* rhs = nullptr;      // N
+  double* buf_xs = nullptr;   // nxs
+  bool built = false;
+};
+
+using namespace hiopamd;
+
+extern "C" {
+
+int hiopamd_kkt_mds_create(hiopamd_kkt_mds** out, hiopamd_ctx* ctx, const hiopamd_mds_structure* st)
+{
+  if(!out || !ctx || !st) return HIOPAMD_ERR_ARG;
+  if(st->nxs < 0 || st->nxd < 0 || st->neq < 0 || st->nineq < 0) return HIOPAMD_ERR_ARG;
+  hiopamd_kkt_mds* k = new hiopamd_kkt_mds();
+  k->ctx = ctx;
+  k->s = *st;
+  const int N = st->nxd + st->neq + st->nineq;
+  int rc = hiopamd_linsolver_create(&k->ls, ctx, N);
+  // symbolic plans of the three Schur blocks (pattern is fixed over the IPM iterations)
+  if(rc == HIOPAMD_OK)
+    rc = hiopamd_sp_plan_create(&k->plan_cc, st->neq, st->neq, st->nxs, st->nnz_Jcs, st->Jcs_i_host, st->Jcs_j_host,
+                                st->nnz_Jcs, st->Jcs_i_host, st->Jcs_j_host, 1);
+  if(rc == HIOPAMD_OK)
+    rc = hiopamd_sp_plan_create(&k->plan_dd, st->nineq, st->nineq, st->nxs, st->nnz_Jds, st->Jds_i_host, st->Jds_j_host,
+                                st->nnz_Jds, st->Jds_i_host, st->Jds_j_host, 1);
+  if(rc == HIOPAMD_OK)
+    rc = hiopamd_sp_plan_create(&k->plan_cd, st->neq, st->nineq, st->nxs, st->nnz_Jcs, st->Jcs_i_host, st->Jcs_j_host,
+                                st->nnz_Jds, st->Jds_i_host, st->Jds_j_host, 0);
+  auto dalloc = [](double** p, size_t n) { return hipMalloc((void**)p, sizeof(double) * (n ? n : 1)); };
+  if(rc == HIOPAMD_OK) {
+    if(dalloc(&k->Hxs, st->nxs) != hipSuccess || dalloc(&k->Dd_inv, st->nineq) != hipSuccess ||
+       dalloc(&k->rhs, N) != hipSuccess || dalloc(&k->buf_xs, st->nxs) != hipSuccess)
+      rc = HIOPAMD_ERR_HIP;
+  }
+  if(rc != HIOPAMD_OK) {
+    hiopamd_kkt_mds_destroy(k);
+    return rc;
+  }
+  *out = k;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_mds_destroy(hiopamd_kkt_mds* k)
+{
+  if(!k) return HIOPAMD_OK;
+  if(k->ls) hiopamd_linsolver_destroy(k->ls);
+  hiopamd_sp_plan_destroy(k->plan_cc);
+  hiopamd_sp_plan_destroy(k->plan_dd);
+  hiopamd_sp_plan_destroy(k->plan_cd);
+  (void)hipFree(k->Hxs);
+  (void)hipFree(k->Dd_inv);
+  (void)hipFree(k->rhs);
+  (void)hipFree(k->buf_xs);
+  delete k;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_mds_set_values(hiopamd_kkt_mds* k, const double* Jcs_val, const double* Jds_val, const double* Hss_val,
+                               const double* Jcd, const double* Jdd, const double* Hdd, const double* Dx,
+                               const double* Dd)
+{
+  if(!k) return HIOPAMD_ERR_ARG;
+  k->Jcs_val = Jcs_val;
+  k->Jds_val = Jds_val;
+  k->Hss_val = Hss_val;
+  k->Jcd = Jcd;
+  k->Jdd = Jdd;
+  k->Hdd = Hdd;
+  k->Dx = Dx;
+  k->Dd = Dd;
+  k->built = false;
+  return HIOPAMD_OK;
+}
+
+#define RC(x)                         \
+  do {                                \
+    int rc_ = (x);                    \
+    if(rc_ != HIOPAMD_OK) return rc_; \
+  } while(0)
+
+int hiopamd_kkt_mds_build(hiopamd_kkt_mds* k, double delta_wx, double delta_wd, double delta_cc, double delta_cd)
+{
+  if(!k || !k->Dx) return HIOPAMD_ERR_STATE;
+  hiopamd_ctx* ctx = k->ctx;
+  const hiopamd_mds_structure& s = k->s;
+  const int nxs = s.nxs, nxd = s.nxd, neq = s.neq, nineq = s.nineq;
+  const int N = nxd + neq + nineq;
+  double* M = hiopamd_linsolver_sys_matrix(k->ls);
+  const int64_t ld = N;
+
+  // Msys.setToZero()                                                        (:196)
+  HIOPAMD_CHECK(hipMemsetAsync(M, 0, sizeof(double) * (size_t)N * (size_t)N, ctx->stream));
+  // (1,1) += upper(Hd); (1,2) += Jcd^T; (1,3) += Jdd^T                       (:204-206)
+  RC(hiopamd_mat_add_upper_to_sym_upper(ctx, nxd, k->Hdd, nxd, 0, 1.0, M, ld));
+  RC(hiopamd_mat_trans_add_to_sym_upper(ctx, neq, nxd, k->Jcd, nxd, 0, nxd, 1.0, M, ld));
+  RC(hiopamd_mat_trans_add_to_sym_upper(ctx, nineq, nxd, k->Jdd, nxd, 0, nxd + neq, 1.0, M, ld));
+  // diag(1,1) += Dxd + delta_wx                                              (:213-215)
+  RC(hiopamd_mat_add_sub_diagonal(ctx, M, ld, 0, 1.0, k->Dx, nxs, nxd));
+  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, ld, 0, nxd, delta_wx));
+  // Hxs = Dxs + delta_wx + diag(Hss)                                         (:223-231)
+  {
+    const double* Dx = k->Dx;
+    double* Hxs = k->Hxs;
+    RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { Hxs[i] = Dx[i] + delta_wx; }));
+    RC(hiopamd_spsym_add_diag_to_vec(ctx, s.nnz_Hss, s.Hss_i, s.Hss_j, k->Hss_val, 1.0, Hxs, 0, nxs, 0, nxs));
+  }
+  // (2,2) += -Jcs Hxs^-1 Jcs^T ; -delta_cc                                   (:239-245)
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cc, k->Jcs_val, k->Jcs_val, k->Hxs, -1.0, M, ld, nxd, nxd));
+  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, ld, nxd, neq, -delta_cc));
+  // (3,3) += -Jds Hxs^-1 Jds^T ; (2,3) += -Jcs Hxs^-1 Jds^T                  (:267-276)
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_dd, k->Jds_val, k->Jds_val, k->Hxs, -1.0, M, ld, nxd + neq, nxd + neq));
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cd, k->Jcs_val, k->Jds_val, k->Hxs, -1.0, M, ld, nxd, nxd + neq));
+  // Dd_inv = 1/(Dd + delta_wd); (3,3) -= Dd_inv + delta_cd                   (:280-290)
+  {
+    const double* Dd = k->Dd;
+    double* Ddi = k->Dd_inv;
+    RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { Ddi[i] = 1.0 / (delta_wd + Dd[i]); }));
+  }
+  RC(hiopamd_mat_add_sub_diagonal(ctx, M, ld, nxd + neq, -1.0, k->Dd_inv, 0, nineq));
+  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, ld, nxd + neq, nineq, -delta_cd));
+  k->built = true;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_mds_factorize(hiopamd_kkt_mds* k, int* n_neg_host)
+{
+  if(!k || !n_neg_host) return HIOPAMD_ERR_ARG;
+  if(!k->built) return HIOPAMD_ERR_STATE;
+  int n_neg = 0;
+  RC(hiopamd_linsolver_matrix_changed(k->ls, &n_neg));
+  if(n_neg >= 0) {
+    // Haynsworth inertia additivity: add the negative entries of the sparse (1,1) block   (:83-108)
+    int64_t nneg_xs = 0, nzero_xs = 0;
+    RC(hiopamd_vec_num_elems_less_than(k->ctx, k->s.nxs, k->Hxs, -1e-14, &nneg_xs));
+    RC(hiopamd_vec_num_elems_abs_less_than(k->ctx, k->s.nxs, k->Hxs, 1e-14, &nzero_xs));
+    if(nzero_xs > 0) n_neg = -1;
+    else n_neg += (int)nneg_xs;
+  }
+  *n_neg_host = n_neg;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const double* ryc, double* ryd, double* dx,
+                                     double* dyc, double* dyd)
+{
+  if(!k) return HIOPAMD_ERR_ARG;
+  hiopamd_ctx* ctx = k->ctx;
+  const hiopamd_mds_structure& s = k->s;
+  const int nxs = s.nxs, nxd = s.nxd, neq = s.neq, nineq = s.nineq;
+  double* rxs = k->buf_xs;
+  const double* Hxs = k->Hxs;
+  // rxs = Hxs^-1 rx_sparse                                                   (:337-338)
+  RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { rxs[i] = rx[i] / Hxs[i]; }));
+  // dyc = ryc - Jcs rxs ; ryd = ryd - Jds rxs                                (:343-347)
+  RC(hiopamd_vec_copy(ctx, neq, dyc, ryc));
+  RC(hiopamd_sp_times_vec(ctx, neq, nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, 1.0, dyc, -1.0, rxs));
+  RC(hiopamd_sp_times_vec(ctx, nineq, nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, 1.0, ryd, -1.0, rxs));
+  // rhs = [rx_dense; dyc; ryd]                                               (:353-357)
+  RC(hiopamd_vec_copy(ctx, nxd, k->rhs, rx + nxs));
+  RC(hiopamd_vec_copy(ctx, neq, k->rhs + nxd, dyc));
+  RC(hiopamd_vec_copy(ctx, nineq, k->rhs + nxd + neq, ryd));
+  // solve                                                                    (:367)
+  RC(hiopamd_linsolver_solve(k->ls, k->rhs, 1));
+  // unpack                                                                   (:383-385)
+  RC(hiopamd_vec_copy(ctx, nxd, dx + nxs, k->rhs));
+  RC(hiopamd_vec_copy(ctx, neq, dyc, k->rhs + nxd));
+  RC(hiopamd_vec_copy(ctx, nineq, dyd, k->rhs + nxd + neq));
+  // dxs = Hxs^-1 (rxs - Jcs^T dyc - Jds^T dyd)                               (:390-395)
+  double* dxs = k->buf_xs;
+  RC(hiopamd_vec_copy(ctx, nxs, dxs, rx));
+  RC(hiopamd_sp_trans_times_vec(ctx, neq, nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, 1.0, dxs, -1.0, dyc));
+  RC(hiopamd_sp_trans_times_vec(ctx, nineq, nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, 1.0, dxs, -1.0, dyd));
+  RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { dx[i] = dxs[i] / Hxs[i]; }));
+  return HIOPAMD_OK;
+}
+
+double* hiopamd_kkt_mds_sys_matrix(hiopamd_kkt_mds* k) { return k ? hiopamd_linsolver_sys_matrix(k->ls) : nullptr; }
+double* hiopamd_kkt_mds_Hxs(hiopamd_kkt_mds* k) { return k ? k->Hxs : nullptr; }
+hiopamd_linsolver* hiopamd_kkt_mds_linsolver(hiopamd_kkt_mds* k) { return k ? k->ls : nullptr; }
+
+}  // extern "C"

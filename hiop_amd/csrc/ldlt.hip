@@ -1,0 +1,570 @@
+// Dense symmetric-indefinite (quasi-definite KKT) factorisation A = U^T D U without pivoting,
+// inertia, and triangular solves, for gfx950 (MI355X) — the hiopLinSolverSymDense operator.
+//
+// reference operator: src/LinAlg/hiopLinSolver.hpp:78-130 (sysMatrix / matrixChanged / solve);
+// reference GPU implementation it replaces: MAGMA magma_dsytrf_nopiv_gpu / magma_dsytrs_nopiv_gpu /
+// magmablas_ddiinertia (src/LinAlg/hiopLinSolverSymDenseMagma.cpp:324-480); CPU implementation used
+// for parity checks: LAPACK DSYTRF/DSYTRS + LINPACK-dsidi style inertia
+// (src/LinAlg/hiopLinSolverSymDenseLapack.hpp:75-195).
+//
+// Layout: the KKT matrix is row-major with only its UPPER triangle populated
+// (src/LinAlg/readme.md:24-26) — i.e. column-major lower in LAPACK's eyes.  Row k of the upper
+// factor U is therefore contiguous, which is what every kernel below streams.
+//
+// Algorithm (two-level right-looking, all on one stream, no host sync inside):
+//   for each super-panel of NB=256 rows:
+//     for each panel of nb=64 rows inside it:
+//       ldlt_panel   : every workgroup factors the 64x64 diagonal block in LDS (redundantly, 8 us of
+//                      latency, removes a launch + a grid sync), then forward-substitutes its 256
+//                      columns of the row panel: V = U11^-T A12 (kept un-scaled in a workspace) and
+//                      U12 = D^-1 V (in place).
+//       ldlt_update  : rows of the super-panel below the panel:  A[r][c] -= sum_k V[k][r] U[k][c]  (K=64)
+//     ldlt_update    : trailing matrix, K=256 rank update on fp64 MFMA (v_mfma_f64_16x16x4_f64)
+// K=256 for the trailing update is what makes it MFMA-bound instead of HBM-bound: the C tile is
+// read+written once per 2*256 flops/element (32 flop/B vs the ~12.5 flop/B ridge of
+// 78.6 TFLOP/s / 6.3 TB/s).
+#include "device_utils.hpp"
+
+#include <vector>
+
+namespace hiopamd {
+
+constexpr int LD_NB = 256;   // super-panel rows (K of the trailing update)
+constexpr int LD_nb = 64;    // panel rows
+constexpr int LD_TM = 128;   // update tile
+constexpr int LD_TN = 128;
+constexpr int LD_KT = 16;    // k-depth staged in LDS per step
+constexpr int LD_LDP = LD_TM + 16;  // padded LDS row stride (doubles): rows k,k+1 land on disjoint bank halves
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// diag kernel: LDL^T of the kb x kb (<=64) diagonal block by ONE workgroup in LDS.
+// Writes U11 (unit upper, strictly-upper part) and D (diagonal) back into A, a compact copy of the
+// block into Dk (64x64 row-major, zero padded) for the substitution kernel, and dinv.
+// info[0] = 1-based index of the first zero / non-finite pivot (0 = none)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int kb,
+                                                           double* __restrict__ dinv, double* __restrict__ Dk,
+                                                           int* __restrict__ info)
+{
+  __shared__ double S[LD_nb][LD_nb + 1];
+  __shared__ double sdinv[LD_nb];
+  const int tid = threadIdx.x;
+  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
+    const int r = e >> 6, c = e & 63;
+    double v = 0.0;
+    if(r < kb && c < kb && c >= r) v = A[(int64_t)(k0 + r) * lda + (k0 + c)];
+    S[r][c] = v;
+  }
+  __syncthreads();
+  const int tr = tid >> 4, tc = tid & 15;
+  for(int k = 0; k < kb; ++k) {
+    const double d = S[k][k];
+    const double di = 1.0 / d;
+    if(tid == 0) {
+      sdinv[k] = di;
+      if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + k + 1);
+    }
+    for(int r = k + 1 + tr; r < kb; r += 16) {
+      const double vr = S[k][r];
+      for(int c = k + 1 + tc; c < kb; c += 16) {
+        if(c >= r) S[r][c] -= vr * (S[k][c] * di);
+      }
+    }
+    __syncthreads();
+  }
+  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
+    const int r = e >> 6, c = e & 63;
+    double v = S[r][c];
+    if(r < kb && c > r && c < kb) v *= sdinv[r];   // U11[r][c] = S[r][c] / d_r
+    Dk[e] = v;
+    if(r < kb && c < kb && c >= r) A[(int64_t)(k0 + r) * lda + (k0 + c)] = v;
+  }
+  if(tid < kb) dinv[k0 + tid] = sdinv[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// substitution kernel for the row panel right of the diagonal block: one column per thread, its 64
+// unknowns in registers:  U11^T x = a ;  V = x (un-scaled, workspace), U12 = D^-1 x (in place).
+// The factor entries U11[s][r] are wave-uniform: they come from the compact read-only copy Dk through
+// the scalar cache (s_load) and feed v_fma_f64 as SGPR operands — no LDS, no per-lane loads.
+// ------------------------------------------------------------------------------------------
+template <int S_>
+__device__ __forceinline__ void trsm_eliminate(double (&x)[LD_nb], const double* __restrict__ Dk)
+{
+  if constexpr(S_ < LD_nb - 1) {
+    const double xs = x[S_];
+#pragma unroll
+    for(int r = S_ + 1; r < LD_nb; ++r) x[r] = fma(-Dk[S_ * LD_nb + r], xs, x[r]);
+    trsm_eliminate<S_ + 1>(x, Dk);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ldlt_trsm_kernel(double* __restrict__ A, int64_t lda, int N, int k0, int kb,
+                                                           double* __restrict__ V, int64_t ldv, int vrow0,
+                                                           const double* __restrict__ dinv,
+                                                           const double* __restrict__ Dk)
+{
+  const int64_t col = (int64_t)k0 + kb + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if(col >= N) return;
+  double x[LD_nb];
+#pragma unroll
+  for(int r = 0; r < LD_nb; ++r) x[r] = (r < kb) ? A[(int64_t)(k0 + r) * lda + col] : 0.0;
+  trsm_eliminate<0>(x, Dk);
+#pragma unroll
+  for(int r = 0; r < LD_nb; ++r) {
+    if(r < kb) {
+      V[(int64_t)(vrow0 + r) * ldv + col] = x[r];
+      A[(int64_t)(k0 + r) * lda + col] = x[r] * dinv[k0 + r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// rank-K update on fp64 MFMA:  A[r][c] -= sum_{k<K} V[vrow0+k][r] * A[urow0+k][c]
+//   for r in [s + ti*128 ...) ∩ [s, row_end),  c in [r, N)   (upper triangle only)
+// One workgroup = 4 wave64 = one 128x128 tile; each wave owns a 64x64 quadrant = 4x4 MFMA tiles
+// of 16x16 (16 x f64x4 accumulators = 128 VGPRs).  Both operands are K-major row panels, so one
+// staging pattern serves A and B: 16 k-rows x 128 columns, coalesced 512 B per wave per row.
+// v_mfma_f64_16x16x4_f64 lane map: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)+4*reg][col=l&15].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restrict__ A, int64_t lda, int N,
+                                                                const double* __restrict__ V, int64_t ldv, int vrow0,
+                                                                int urow0, int K, int s, int row_end)
+{
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if(tj < ti) return;
+  const int r0 = s + ti * LD_TM, c0 = s + tj * LD_TN;
+  if(r0 >= row_end || c0 >= N) return;
+  __shared__ double Vs[LD_KT][LD_LDP];
+  __shared__ double Us[LD_KT][LD_LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lk = lane >> 4, li = lane & 15;
+
+  double4_t acc[4][4];
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+  const int lcol = tid & 127, lrow = tid >> 7;
+  const bool vr_ok = (r0 + lcol) < N;
+  const bool uc_ok = (c0 + lcol) < N;
+  const double* Vp = V + (int64_t)(vrow0 + lrow) * ldv + (r0 + lcol);
+  const double* Up = A + (int64_t)(urow0 + lrow) * lda + (c0 + lcol);
+
+  for(int kt = 0; kt < K; kt += LD_KT) {
+    double vreg[8], ureg[8];
+#pragma unroll
+    for(int q = 0; q < 8; ++q) {
+      vreg[q] = vr_ok ? Vp[(int64_t)(kt + 2 * q) * ldv] : 0.0;
+      ureg[q] = uc_ok ? Up[(int64_t)(kt + 2 * q) * lda] : 0.0;
+    }
+    __syncthreads();  // previous stage fully consumed
+#pragma unroll
+    for(int q = 0; q < 8; ++q) {
+      Vs[2 * q + lrow][lcol] = vreg[q];
+      Us[2 * q + lrow][lcol] = ureg[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for(int kk = 0; kk < LD_KT / 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for(int i = 0; i < 4; ++i) a[i] = Vs[kk * 4 + lk][wr * 64 + i * 16 + li];
+#pragma unroll
+      for(int j = 0; j < 4; ++j) b[j] = Us[kk * 4 + lk][wc * 64 + j * 16 + li];
+#pragma unroll
+      for(int i = 0; i < 4; ++i)
+#pragma unroll
+        for(int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: C -= acc on the upper triangle
+#pragma unroll
+  for(int i = 0; i < 4; ++i) {
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
+      if(row < row_end) {
+        double* Crow = A + (int64_t)row * lda;
+#pragma unroll
+        for(int j = 0; j < 4; ++j) {
+          const int col = c0 + wc * 64 + j * 16 + li;
+          if(col < N && col >= row) Crow[col] -= acc[i][j][reg];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// inertia from D (thresholds of the reference's LAPACK path, hiopLinSolverSymDenseLapack.hpp:154-161:
+// d < -1e-14 negative, |d| < 1e-14 null, else positive)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ldlt_inertia_kernel(int N, const double* __restrict__ A, int64_t lda,
+                                                              int* __restrict__ out3)
+{
+  int pos = 0, neg = 0, nul = 0;
+  for(int i = threadIdx.x; i < N; i += kBlock) {
+    const double d = A[(int64_t)i * lda + i];
+    if(d < -1e-14) ++neg;
+    else if(d < 1e-14) ++nul;   // includes NaN? no: NaN compares false twice -> counted below
+    else if(d >= 1e-14) ++pos;
+    else ++nul;                 // NaN pivot: treat as null (singular)
+  }
+  __shared__ int sm[3][kBlock / 64];
+  for(int off = 32; off > 0; off >>= 1) {
+    pos += __shfl_down(pos, off, 64);
+    neg += __shfl_down(neg, off, 64);
+    nul += __shfl_down(nul, off, 64);
+  }
+  if((threadIdx.x & 63) == 0) {
+    sm[0][threadIdx.x >> 6] = pos;
+    sm[1][threadIdx.x >> 6] = neg;
+    sm[2][threadIdx.x >> 6] = nul;
+  }
+  __syncthreads();
+  if(threadIdx.x < 3) {
+    int v = 0;
+    for(int w = 0; w < kBlock / 64; ++w) v += sm[threadIdx.x][w];
+    out3[threadIdx.x] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// triangular solves, block size 64, one launch per block step; every workgroup (one wave64)
+// solves the 64x64 diagonal system redundantly in registers, workgroup 0 publishes it, and each
+// workgroup then updates its own 64 entries of the running right-hand side.
+// forward:  U^T y = b      (b updated in place for the not-yet-solved entries, y written to yout)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ldlt_fwd_step(const double* __restrict__ A, int64_t lda, int N, int i0, int ib,
+                                                    double* __restrict__ b, double* __restrict__ yout)
+{
+  const int lane = threadIdx.x;
+  // lane r owns unknown r; u[s] = U[i0+s][i0+lane]  (column `lane` of the unit upper block)
+  double u[LD_nb];
+#pragma unroll
+  for(int s2 = 0; s2 < LD_nb; ++s2) u[s2] = (s2 < ib && lane < ib && s2 < lane) ? A[(int64_t)(i0 + s2) * lda + (i0 + lane)] : 0.0;
+  double br = (lane < ib) ? b[i0 + lane] : 0.0;
+#pragma unroll
+  for(int s2 = 0; s2 < LD_nb; ++s2) {
+    const double ys = __shfl(br, s2, 64);
+    br = fma(-u[s2], ys, br);  // u[s2]==0 for s2 >= lane: lane s2 itself and solved lanes are untouched
+  }
+  if(blockIdx.x == 0 && lane < ib) yout[i0 + lane] = br;
+  __shared__ double ysh[LD_nb];
+  ysh[lane] = br;
+  __syncthreads();
+  const int64_t col = (int64_t)i0 + ib + (int64_t)blockIdx.x * 64 + lane;
+  if(col < N) {
+    double acc = b[col];
+    const double* Ac = A + (int64_t)i0 * lda + col;
+#pragma unroll 8
+    for(int s2 = 0; s2 < ib; ++s2) acc = fma(-Ac[(int64_t)s2 * lda], ysh[s2], acc);
+    b[col] = acc;
+  }
+}
+
+// backward:  U x = z, z = D^-1 y.  On entry z holds D^-1 y for rows < i0+ib already corrected by the
+// solved blocks to the right; workgroup 0 writes x_I; each workgroup (4 waves, 32 rows) applies
+//   z[h] -= U[h][I] . x_I   for its rows h < i0  (8 lanes per row, 64-byte pieces, shuffle-reduced)
+__global__ __launch_bounds__(kBlock) void ldlt_bwd_step(const double* __restrict__ A, int64_t lda, int N, int i0,
+                                                        int ib, double* __restrict__ z, double* __restrict__ xout)
+{
+  __shared__ double S[LD_nb][LD_nb + 1];
+  __shared__ double xs[LD_nb];
+  const int tid = threadIdx.x;
+  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
+    const int r = e >> 6, c = e & 63;
+    S[r][c] = (r < ib && c < ib && c > r) ? A[(int64_t)(i0 + r) * lda + (i0 + c)] : 0.0;
+  }
+  __syncthreads();
+  if(tid < 64) {
+    const int lane = tid;
+    double zr = (lane < ib) ? z[i0 + lane] : 0.0;
+    // column-oriented back substitution: for c = ib-1..0: x_c final; z_r -= U[r][c] x_c for r < c
+    for(int c = LD_nb - 1; c >= 0; --c) {
+      const double xc = __shfl(zr, c, 64);
+      zr = fma(-S[lane][c], xc, zr);  // S[lane][c]==0 unless c > lane
+    }
+    xs[lane] = zr;
+    if(blockIdx.x == 0 && lane < ib) xout[i0 + lane] = zr;
+  }
+  __syncthreads();
+  // rows above the block
+  const int sub = tid & 7;                                   // 8 lanes per row
+  const int64_t h = (int64_t)blockIdx.x * (kBlock / 8) + (tid >> 3);
+  double acc = 0.0;
+  if(h < i0) {
+    const double* Ah = A + h * lda + i0 + sub * 8;
+#pragma unroll
+    for(int q = 0; q < 8; ++q) {
+      const int c = sub * 8 + q;
+      if(c < ib) acc = fma(Ah[q], xs[c], acc);
+    }
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  if(h < i0 && sub == 0) z[h] -= acc;
+}
+
+}  // namespace hiopamd
+
+using namespace hiopamd;
+
+// optional per-launch timing of the MFMA update kernel (HIP events on the launch stream)
+struct LdltProfile {
+  bool enabled = false;
+  std::vector<hipEvent_t> pool;   // start/stop pairs
+  size_t used = 0;
+  double flops = 0.0;             // algorithmic flops of the timed update launches (accumulated)
+  double ms = 0.0;                // accumulated update-kernel time
+  long launches = 0;
+  hipEvent_t get()
+  {
+    if(used == pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+  void collect()
+  {
+    for(size_t i = 0; i + 1 < used; i += 2) {
+      float t = 0.f;
+      if(hipEventElapsedTime(&t, pool[i], pool[i + 1]) == hipSuccess) ms += t;
+    }
+    used = 0;
+  }
+  ~LdltProfile()
+  {
+    for(auto e : pool) (void)hipEventDestroy(e);
+  }
+};
+
+// algorithmic flops of one update launch: 2*K per updated element (r in [s,row_end), c in [r,N))
+static double update_flops(int N, int K, int s, int row_end)
+{
+  const double rows = (double)(row_end - s);
+  const double first = (double)(N - s), last = (double)(N - row_end + 1);
+  return 2.0 * K * rows * (first + last) * 0.5;
+}
+
+struct hiopamd_linsolver {
+  hiopamd_ctx* ctx = nullptr;
+  int n = 0;
+  double* M = nullptr;      // n x n row-major
+  double* dinv = nullptr;   // n
+  double* V = nullptr;      // LD_NB x n workspace
+  double* ybuf = nullptr;   // n
+  double* Dblk = nullptr;   // ceil(n/64) staged 64x64 diagonal blocks
+  int* d_info = nullptr;    // [0]=zero-pivot flag, [1..3]=pos,neg,zero
+  bool factored = false;
+  int inertia[3] = {0, 0, 0};
+  LdltProfile prof;
+};
+
+static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, double* dinv, double* V, double* Dblk,
+                            int* d_info, int* inertia3_host, LdltProfile* prof = nullptr)
+{
+  const bool timed = prof && prof->enabled;
+  auto launch_update = [&](dim3 grid, int vrow0, int urow0, int K, int s, int row_end) {
+    if(timed) (void)hipEventRecord(prof->get(), ctx->stream);
+    hipLaunchKernelGGL(ldlt_update_kernel, grid, dim3(kBlock), 0, ctx->stream, A, lda, N, V, (int64_t)N, vrow0, urow0, K, s,
+                       row_end);
+    if(timed) {
+      (void)hipEventRecord(prof->get(), ctx->stream);
+      prof->flops += update_flops(N, K, s, row_end);
+      prof->launches += 1;
+    }
+  };
+  if(N < 0 || lda < N) return HIOPAMD_ERR_ARG;
+  if(N == 0) {
+    if(inertia3_host) inertia3_host[0] = inertia3_host[1] = inertia3_host[2] = 0;
+    return HIOPAMD_OK;
+  }
+  hipStream_t st = ctx->stream;
+  HIOPAMD_CHECK(hipMemsetAsync(d_info, 0, 4 * sizeof(int), st));
+  const int64_t ldv = N;
+  for(int K0 = 0; K0 < N; K0 += LD_NB) {
+    const int Kend = (K0 + LD_NB < N) ? K0 + LD_NB : N;
+    for(int k0 = K0; k0 < Kend; k0 += LD_nb) {
+      const int kb = (k0 + LD_nb <= N) ? LD_nb : (N - k0);
+      const int ncols = N - k0 - kb;
+      double* Dk = Dblk + (int64_t)(k0 / LD_nb) * (LD_nb * LD_nb);
+      hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(kBlock), 0, st, A, lda, k0, kb, dinv, Dk, d_info);
+      if(ncols > 0) {
+        const int g = (ncols + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(ldlt_trsm_kernel, dim3(g), dim3(kBlock), 0, st, A, lda, N, k0, kb, V, ldv, k0 - K0, dinv, Dk);
+      }
+      if(k0 + kb < Kend) {
+        // rows of the super-panel below this panel
+        const int s = k0 + kb;
+        const int tr = (Kend - s + LD_TM - 1) / LD_TM, tc = (N - s + LD_TN - 1) / LD_TN;
+        launch_update(dim3(tc, tr), k0 - K0, k0, kb, s, Kend);
+      }
+    }
+    if(Kend < N) {
+      const int s = Kend;
+      const int t = (N - s + LD_TM - 1) / LD_TM;
+      launch_update(dim3(t, t), 0, K0, Kend - K0, s, N);
+    }
+  }
+  hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
+  HIOPAMD_CHECK(hipGetLastError());
+  int h[4];
+  HIOPAMD_CHECK(hipMemcpyAsync(h, d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIOPAMD_CHECK(hipStreamSynchronize(st));
+  if(timed) prof->collect();
+  if(inertia3_host) {
+    inertia3_host[0] = h[1];
+    inertia3_host[1] = h[2];
+    inertia3_host[2] = h[3];
+  }
+  if(h[0] != 0) return HIOPAMD_ERR_SINGULAR;
+  return HIOPAMD_OK;
+}
+
+static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda, const double* dinv, double* ybuf,
+                           double* rhs, int nrhs)
+{
+  if(N < 0 || nrhs < 0) return HIOPAMD_ERR_ARG;
+  hipStream_t st = ctx->stream;
+  for(int j = 0; j < nrhs; ++j) {
+    double* b = rhs + (int64_t)j * N;
+    // forward: U^T y = b
+    for(int i0 = 0; i0 < N; i0 += LD_nb) {
+      const int ib = (i0 + LD_nb <= N) ? LD_nb : (N - i0);
+      int g = (N - i0 - ib + 63) / 64;
+      if(g < 1) g = 1;
+      hipLaunchKernelGGL(ldlt_fwd_step, dim3(g), dim3(64), 0, st, A, lda, N, i0, ib, b, ybuf);
+    }
+    // z = D^-1 y
+    int rc = hiopamd_vec_component_mult(ctx, N, ybuf, dinv);
+    if(rc != HIOPAMD_OK) return rc;
+    // backward: U x = z   (x written into b)
+    const int nblk = (N + LD_nb - 1) / LD_nb;
+    for(int bI = nblk - 1; bI >= 0; --bI) {
+      const int i0 = bI * LD_nb;
+      const int ib = (i0 + LD_nb <= N) ? LD_nb : (N - i0);
+      int g = (i0 + (kBlock / 8) - 1) / (kBlock / 8);
+      if(g < 1) g = 1;
+      hipLaunchKernelGGL(ldlt_bwd_step, dim3(g), dim3(kBlock), 0, st, A, lda, N, i0, ib, ybuf, b);
+    }
+  }
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+extern "C" {
+
+int hiopamd_ldlt_factor(hiopamd_ctx* ctx, int n, double* A, int64_t lda, double* work_dinv, int* inertia3_host)
+{
+  // workspace: V panel (LD_NB x n) + info flags from the context's grow-only buffer
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  const size_t vbytes = sizeof(double) * (size_t)LD_NB * nn;
+  const size_t dbytes = sizeof(double) * (size_t)LD_nb * LD_nb * ((nn + LD_nb - 1) / LD_nb);
+  char* w = (char*)ctx_workspace(ctx, vbytes + dbytes + 64);
+  return ldlt_factor_impl(ctx, n, A, lda, work_dinv, (double*)w, (double*)(w + vbytes), (int*)(w + vbytes + dbytes),
+                          inertia3_host);
+}
+
+int hiopamd_ldlt_solve(hiopamd_ctx* ctx, int n, const double* A, int64_t lda, const double* work_dinv,
+                       double* rhs_inout, int nrhs)
+{
+  double* y = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)(n > 0 ? n : 1));
+  return ldlt_solve_impl(ctx, n, A, lda, work_dinv, y, rhs_inout, nrhs);
+}
+
+int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
+{
+  if(!out || !ctx || n < 0) return HIOPAMD_ERR_ARG;
+  hiopamd_linsolver* ls = new hiopamd_linsolver();
+  ls->ctx = ctx;
+  ls->n = n;
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->M, sizeof(double) * nn * nn));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->dinv, sizeof(double) * nn));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * LD_nb * LD_nb * ((nn + LD_nb - 1) / LD_nb)));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
+  HIOPAMD_CHECK(hipMemsetAsync(ls->M, 0, sizeof(double) * nn * nn, ctx->stream));
+  *out = ls;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
+{
+  if(!ls) return HIOPAMD_OK;
+  (void)hipStreamSynchronize(ls->ctx->stream);
+  (void)hipFree(ls->M);
+  (void)hipFree(ls->dinv);
+  (void)hipFree(ls->V);
+  (void)hipFree(ls->ybuf);
+  (void)hipFree(ls->Dblk);
+  (void)hipFree(ls->d_info);
+  delete ls;
+  return HIOPAMD_OK;
+}
+
+double* hiopamd_linsolver_sys_matrix(hiopamd_linsolver* ls) { return ls ? ls->M : nullptr; }
+int hiopamd_linsolver_n(const hiopamd_linsolver* ls) { return ls ? ls->n : -1; }
+
+int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
+{
+  if(!ls || !n_neg_host) return HIOPAMD_ERR_ARG;
+  ls->factored = false;
+  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->d_info, ls->inertia, &ls->prof);
+  if(rc == HIOPAMD_ERR_SINGULAR) {
+    // reference: "entry in the factorization's diagonal is exactly zero" -> matrixChanged() returns -1
+    *n_neg_host = -1;
+    return HIOPAMD_OK;
+  }
+  if(rc != HIOPAMD_OK) return rc;
+  ls->factored = true;
+  *n_neg_host = (ls->inertia[2] > 0) ? -1 : ls->inertia[1];
+  return HIOPAMD_OK;
+}
+
+int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs)
+{
+  if(!ls || !rhs_inout) return HIOPAMD_ERR_ARG;
+  if(!ls->factored) return HIOPAMD_ERR_STATE;
+  return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs);
+}
+
+int hiopamd_linsolver_profile(hiopamd_linsolver* ls, int enable)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  ls->prof.enabled = enable != 0;
+  ls->prof.flops = 0.0;
+  ls->prof.ms = 0.0;
+  ls->prof.launches = 0;
+  return HIOPAMD_OK;
+}
+int hiopamd_linsolver_profile_read(const hiopamd_linsolver* ls, double* update_ms_host, double* update_flops_host,
+                                   int64_t* update_launches_host)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  if(update_ms_host) *update_ms_host = ls->prof.ms;
+  if(update_flops_host) *update_flops_host = ls->prof.flops;
+  if(update_launches_host) *update_launches_host = ls->prof.launches;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_linsolver_inertia(const hiopamd_linsolver* ls, int* pos, int* neg, int* zero)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  if(pos) *pos = ls->inertia[0];
+  if(neg) *neg = ls->inertia[1];
+  if(zero) *zero = ls->inertia[2];
+  return HIOPAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,352 @@
+// hiopMatrixSparseTriplet kernels for gfx950: COO SpMV and the MDS Schur row-build
+//   W[r0+i][c0+j] += alpha * sum_c M1[i,c] * M2[j,c] / D[c].
+//
+// reference: src/LinAlg/hiopMatrixSparseTriplet.cpp:73 (timesVec), :110 (transTimesVec),
+// :390 (addMDinvMtransToDiagBlockOfSymDeMatUTri), :447 (addMDinvNtransToSymDeMatUTri).
+// The reference walks ALL m1*m2 row pairs with a sorted merge (O(m^2) merges even when rows are
+// disjoint) and its RAJA GPU port runs one thread per row over all j>i
+// (src/LinAlg/hiopMatrixRajaSparseTripletImpl.hpp:807-847).  Here the sparsity pattern — fixed over
+// the IPM iterations (reference comment :479-489) — is analysed ONCE on the host into a plan:
+// the list of structurally non-zero outputs (i,j) and, for each, its (k1,k2,col) product triples
+// in increasing column order.  The numeric kernel is then one thread (short lists) or one wave
+// (long lists) per output: no atomics, fixed summation order = the reference's merge order.
+#include "device_utils.hpp"
+
+#include <algorithm>
+#include <vector>
+
+struct hiopamd_sp_plan {
+  int m1 = 0, m2 = 0;
+  int64_t n_out = 0, n_prod = 0;
+  int64_t n_short = 0, n_long = 0;  // outputs are stored short-first
+  // device arrays
+  int* out_i = nullptr;
+  int* out_j = nullptr;
+  int64_t* out_ptr = nullptr;  // n_out+1
+  int* k1 = nullptr;
+  int* k2 = nullptr;
+  int* col = nullptr;
+};
+
+namespace hiopamd {
+
+constexpr int kLongList = 32;
+
+__global__ __launch_bounds__(kBlock) void coo_spmv_rows(int nrows, int nnz, const int* __restrict__ iRow,
+                                                        const int* __restrict__ jCol, const double* __restrict__ val,
+                                                        double beta, double* __restrict__ y, double alpha,
+                                                        const double* __restrict__ x)
+{
+  // one wave per row; the row's [lo,hi) range found by binary search in the row-sorted COO
+  const int row = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if(row >= nrows) return;
+  int lo = 0, hi = nnz;
+  while(lo < hi) {  // first k with iRow[k] >= row
+    int mid = (lo + hi) >> 1;
+    if(iRow[mid] < row) lo = mid + 1;
+    else hi = mid;
+  }
+  const int start = lo;
+  hi = nnz;
+  while(lo < hi) {  // first k with iRow[k] > row
+    int mid = (lo + hi) >> 1;
+    if(iRow[mid] <= row) lo = mid + 1;
+    else hi = mid;
+  }
+  const int end = lo;
+  double acc = 0.0;
+  for(int k = start + lane; k < end; k += 64) acc += x[jCol[k]] * val[k];
+  for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if(lane == 0) y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
+}
+
+__global__ __launch_bounds__(kBlock) void coo_spmv_trans_scatter(int nnz, const int* __restrict__ iRow,
+                                                                 const int* __restrict__ jCol,
+                                                                 const double* __restrict__ val, double* __restrict__ y,
+                                                                 double alpha, const double* __restrict__ x)
+{
+  for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
+    // hardware fp64 atomic add (global_atomic_add_f64); column collisions are rare (a few rows/column)
+    unsafeAtomicAdd(&y[jCol[k]], alpha * x[iRow[k]] * val[k]);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void mdinv_short(int64_t n_short, const int* __restrict__ out_i,
+                                                      const int* __restrict__ out_j,
+                                                      const int64_t* __restrict__ out_ptr, const int* __restrict__ k1,
+                                                      const int* __restrict__ k2, const int* __restrict__ col,
+                                                      const double* __restrict__ v1, const double* __restrict__ v2,
+                                                      const double* __restrict__ D, double alpha,
+                                                      double* __restrict__ W, int64_t ldw, int r0, int c0)
+{
+  for(int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_short; p += (int64_t)gridDim.x * kBlock) {
+    double acc = 0.0;
+    const int64_t e = out_ptr[p + 1];
+    for(int64_t q = out_ptr[p]; q < e; ++q) acc += v1[k1[q]] / D[col[q]] * v2[k2[q]];
+    W[(int64_t)(r0 + out_i[p]) * ldw + (c0 + out_j[p])] += alpha * acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void mdinv_long(int64_t first, int64_t n_long, const int* __restrict__ out_i,
+                                                     const int* __restrict__ out_j,
+                                                     const int64_t* __restrict__ out_ptr, const int* __restrict__ k1,
+                                                     const int* __restrict__ k2, const int* __restrict__ col,
+                                                     const double* __restrict__ v1, const double* __restrict__ v2,
+                                                     const double* __restrict__ D, double alpha,
+                                                     double* __restrict__ W, int64_t ldw, int r0, int c0)
+{
+  // one workgroup per long output; fixed-order tree reduction
+  const int64_t p = first + blockIdx.x;
+  if(blockIdx.x >= n_long) return;
+  double acc = 0.0;
+  const int64_t e = out_ptr[p + 1];
+  for(int64_t q = out_ptr[p] + threadIdx.x; q < e; q += kBlock) acc += v1[k1[q]] / D[col[q]] * v2[k2[q]];
+  for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double sm[kBlock / 64];
+  if((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    acc = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    W[(int64_t)(r0 + out_i[p]) * ldw + (c0 + out_j[p])] += alpha * acc;
+  }
+}
+
+// y[vec_start+row] += alpha * Msym[row,row] for row in [diag_src_start, diag_src_start+num_elems)
+// (the destination index is vec_start+row exactly as in the reference loop,
+//  hiopMatrixSparseTriplet.cpp:1034-1042; every caller passes diag_src_start = 0)
+__global__ __launch_bounds__(kBlock) void spsym_diag_to_vec(int nnz, const int* __restrict__ iRow,
+                                                            const int* __restrict__ jCol,
+                                                            const double* __restrict__ val, double alpha,
+                                                            double* __restrict__ y, int vec_start, int diag_src_start,
+                                                            int num_elems)
+{
+  for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
+    const int r = iRow[k];
+    if(r == jCol[k] && r >= diag_src_start && r < diag_src_start + num_elems) {
+      // a sym-sparse matrix holds at most one entry per (i,j); duplicates would need the atomic
+      unsafeAtomicAdd(&y[vec_start + r], alpha * val[k]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void spsym_add_upper(int nnz, const int* __restrict__ iRow,
+                                                          const int* __restrict__ jCol, const double* __restrict__ val,
+                                                          int diag_start, double alpha, double* __restrict__ W,
+                                                          int64_t ldw)
+{
+  for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
+    const int r = iRow[k], c = jCol[k];
+    if(r <= c) unsafeAtomicAdd(&W[(int64_t)(diag_start + r) * ldw + (diag_start + c)], alpha * val[k]);
+  }
+}
+
+template <class T>
+static int upload(T** d, const std::vector<T>& h)
+{
+  *d = nullptr;
+  size_t bytes = sizeof(T) * (h.size() ? h.size() : 1);
+  HIOPAMD_CHECK(hipMalloc((void**)d, bytes));
+  if(h.size()) HIOPAMD_CHECK(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+  return HIOPAMD_OK;
+}
+
+}  // namespace hiopamd
+
+using namespace hiopamd;
+
+extern "C" {
+
+int hiopamd_sp_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
+                         const double* val, double beta, double* y, double alpha, const double* x)
+{
+  (void)ncols;
+  if(nrows < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
+  if(nrows == 0) return HIOPAMD_OK;
+  const int64_t threads = (int64_t)nrows * 64;
+  hipLaunchKernelGGL(coo_spmv_rows, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                     nrows, nnz, iRow, jCol, val, beta, y, alpha, x);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_sp_trans_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
+                               const double* val, double beta, double* y, double alpha, const double* x)
+{
+  (void)nrows;
+  if(ncols < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
+  if(ncols == 0) return HIOPAMD_OK;
+  int st = (beta == 0.0) ? hiopamd_vec_set_to_constant(ctx, ncols, y, 0.0) : hiopamd_vec_scale(ctx, ncols, y, beta);
+  if(st != HIOPAMD_OK || nnz == 0) return st;
+  hipLaunchKernelGGL(coo_spmv_trans_scatter, dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val, y,
+                     alpha, x);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_sp_plan_create(hiopamd_sp_plan** out, int m1, int m2, int ncols, int nnz1, const int* iRow1, const int* jCol1,
+                           int nnz2, const int* iRow2, const int* jCol2, int same_matrix_upper_only)
+{
+  if(!out || m1 < 0 || m2 < 0 || ncols < 0 || nnz1 < 0 || nnz2 < 0) return HIOPAMD_ERR_ARG;
+  for(int k = 0; k < nnz1; ++k)
+    if(iRow1[k] < 0 || iRow1[k] >= m1 || jCol1[k] < 0 || jCol1[k] >= ncols || (k && iRow1[k] < iRow1[k - 1]))
+      return HIOPAMD_ERR_ARG;
+  for(int k = 0; k < nnz2; ++k)
+    if(iRow2[k] < 0 || iRow2[k] >= m2 || jCol2[k] < 0 || jCol2[k] >= ncols || (k && iRow2[k] < iRow2[k - 1]))
+      return HIOPAMD_ERR_ARG;
+
+  // CSC of M2: for each column, its (row j, k2) entries in increasing j (input is row-sorted)
+  std::vector<int64_t> cptr((size_t)ncols + 1, 0);
+  for(int k = 0; k < nnz2; ++k) cptr[jCol2[k] + 1]++;
+  for(int c = 0; c < ncols; ++c) cptr[c + 1] += cptr[c];
+  std::vector<int> crow(nnz2), ck2(nnz2);
+  {
+    std::vector<int64_t> pos(cptr.begin(), cptr.end() - 1);
+    for(int k = 0; k < nnz2; ++k) {
+      int64_t p = pos[jCol2[k]]++;
+      crow[p] = iRow2[k];
+      ck2[p] = k;
+    }
+  }
+  struct Trip {
+    int j, col, k1, k2;
+  };
+  std::vector<int> oi, oj, pk1, pk2, pcol;
+  std::vector<int64_t> optr;
+  std::vector<int64_t> len;
+  optr.push_back(0);
+  std::vector<Trip> cand;
+  int k = 0;
+  for(int i = 0; i < m1; ++i) {
+    cand.clear();
+    for(; k < nnz1 && iRow1[k] == i; ++k) {
+      const int c = jCol1[k];
+      for(int64_t p = cptr[c]; p < cptr[c + 1]; ++p) {
+        if(same_matrix_upper_only && crow[p] < i) continue;
+        cand.push_back(Trip{crow[p], c, k, ck2[p]});
+      }
+    }
+    std::sort(cand.begin(), cand.end(), [](const Trip& a, const Trip& b) {
+      if(a.j != b.j) return a.j < b.j;
+      if(a.col != b.col) return a.col < b.col;
+      if(a.k1 != b.k1) return a.k1 < b.k1;
+      return a.k2 < b.k2;
+    });
+    for(size_t t = 0; t < cand.size();) {
+      size_t e = t;
+      while(e < cand.size() && cand[e].j == cand[t].j) ++e;
+      oi.push_back(i);
+      oj.push_back(cand[t].j);
+      for(size_t q = t; q < e; ++q) {
+        pk1.push_back(cand[q].k1);
+        pk2.push_back(cand[q].k2);
+        pcol.push_back(cand[q].col);
+      }
+      optr.push_back((int64_t)pk1.size());
+      t = e;
+    }
+  }
+  // reorder outputs: short lists first, long lists last (stable)
+  const int64_t n_out = (int64_t)oi.size();
+  std::vector<int64_t> order;
+  order.reserve(n_out);
+  int64_t n_short = 0;
+  for(int64_t p = 0; p < n_out; ++p)
+    if(optr[p + 1] - optr[p] <= kLongList) {
+      order.push_back(p);
+      ++n_short;
+    }
+  for(int64_t p = 0; p < n_out; ++p)
+    if(optr[p + 1] - optr[p] > kLongList) order.push_back(p);
+  std::vector<int> oi2(n_out), oj2(n_out), a1(pk1.size()), a2(pk1.size()), ac(pk1.size());
+  std::vector<int64_t> optr2(n_out + 1, 0);
+  int64_t w = 0;
+  for(int64_t t = 0; t < n_out; ++t) {
+    const int64_t p = order[t];
+    oi2[t] = oi[p];
+    oj2[t] = oj[p];
+    for(int64_t q = optr[p]; q < optr[p + 1]; ++q, ++w) {
+      a1[w] = pk1[q];
+      a2[w] = pk2[q];
+      ac[w] = pcol[q];
+    }
+    optr2[t + 1] = w;
+  }
+  hiopamd_sp_plan* pl = new hiopamd_sp_plan();
+  pl->m1 = m1;
+  pl->m2 = m2;
+  pl->n_out = n_out;
+  pl->n_prod = (int64_t)a1.size();
+  pl->n_short = n_short;
+  pl->n_long = n_out - n_short;
+  int st = upload(&pl->out_i, oi2);
+  if(st == HIOPAMD_OK) st = upload(&pl->out_j, oj2);
+  if(st == HIOPAMD_OK) st = upload(&pl->out_ptr, optr2);
+  if(st == HIOPAMD_OK) st = upload(&pl->k1, a1);
+  if(st == HIOPAMD_OK) st = upload(&pl->k2, a2);
+  if(st == HIOPAMD_OK) st = upload(&pl->col, ac);
+  if(st != HIOPAMD_OK) {
+    hiopamd_sp_plan_destroy(pl);
+    return st;
+  }
+  *out = pl;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_sp_plan_destroy(hiopamd_sp_plan* pl)
+{
+  if(!pl) return HIOPAMD_OK;
+  hipFree(pl->out_i);
+  hipFree(pl->out_j);
+  hipFree(pl->out_ptr);
+  hipFree(pl->k1);
+  hipFree(pl->k2);
+  hipFree(pl->col);
+  delete pl;
+  return HIOPAMD_OK;
+}
+int64_t hiopamd_sp_plan_num_outputs(const hiopamd_sp_plan* pl) { return pl ? pl->n_out : 0; }
+int64_t hiopamd_sp_plan_num_products(const hiopamd_sp_plan* pl) { return pl ? pl->n_prod : 0; }
+
+int hiopamd_sp_add_MDinvNt(hiopamd_ctx* ctx, const hiopamd_sp_plan* pl, const double* val1, const double* val2,
+                           const double* D, double alpha, double* W, int64_t ldw, int r0, int c0)
+{
+  if(!pl) return HIOPAMD_ERR_ARG;
+  if(pl->n_short > 0) {
+    hipLaunchKernelGGL(mdinv_short, dim3(grid_for(pl->n_short)), dim3(kBlock), 0, ctx->stream, pl->n_short, pl->out_i,
+                       pl->out_j, pl->out_ptr, pl->k1, pl->k2, pl->col, val1, val2, D, alpha, W, ldw, r0, c0);
+  }
+  if(pl->n_long > 0) {
+    hipLaunchKernelGGL(mdinv_long, dim3((unsigned)pl->n_long), dim3(kBlock), 0, ctx->stream, pl->n_short, pl->n_long,
+                       pl->out_i, pl->out_j, pl->out_ptr, pl->k1, pl->k2, pl->col, val1, val2, D, alpha, W, ldw, r0,
+                       c0);
+  }
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_spsym_add_diag_to_vec(hiopamd_ctx* ctx, int nnz, const int* iRow, const int* jCol, const double* val,
+                                  double alpha, double* y, int vec_start, int n_vec, int diag_src_start, int num_elems)
+{
+  if(nnz < 0 || vec_start < 0 || diag_src_start < 0) return HIOPAMD_ERR_ARG;
+  if(num_elems < 0) num_elems = n_vec;
+  if(diag_src_start + num_elems + vec_start > n_vec) num_elems = n_vec - vec_start - diag_src_start;
+  if(nnz == 0 || num_elems <= 0) return HIOPAMD_OK;
+  hipLaunchKernelGGL(spsym_diag_to_vec, dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val, alpha, y,
+                     vec_start, diag_src_start, num_elems);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_spsym_add_upper_to_sym_upper(hiopamd_ctx* ctx, int nnz, const int* iRow, const int* jCol, const double* val,
+                                         int diag_start, double alpha, double* W, int64_t ldw)
+{
+  if(nnz < 0 || diag_start < 0) return HIOPAMD_ERR_ARG;
+  if(nnz == 0) return HIOPAMD_OK;
+  hipLaunchKernelGGL(spsym_add_upper, dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val,
+                     diag_start, alpha, W, ldw);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+"""Host-side handles of the stateful KKT objects of the C ABI.
+
+`KKTLinSysCompressedMDSXYcYd` mirrors the reference class of the same name
+(src/Optimization/hiopKKTLinSysMDS.hpp:97; update/build_kkt_matrix/factorizeWithCurvCheck/solveCompressed)
+and `LinSolverSymDense` mirrors hiopLinSolverSymDense (src/LinAlg/hiopLinSolver.hpp:117:
+sysMatrix / matrixChanged / solve).  All heavy lifting happens in libhiopamd.so on the device."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import MdsStructure, check, lib
+from .runtime import Context, dev, dptr
+
+
+class LinSolverSymDense:
+    def __init__(self, ctx: Context, n: int):
+        self.ctx, self.n = ctx, n
+        self._L = lib()
+        h = C.c_void_p()
+        check(self._L.hiopamd_linsolver_create(C.byref(h), ctx.h, n), "hiopamd_linsolver_create")
+        self.h = h
+
+    def sys_matrix_ptr(self) -> int:
+        return self._L.hiopamd_linsolver_sys_matrix(self.h)
+
+    def set_sys_matrix(self, M: torch.Tensor):
+        """Copy an n x n row-major device matrix (upper triangle significant) into sysMatrix()."""
+        assert M.shape == (self.n, self.n) and M.dtype == torch.float64 and M.is_cuda
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, C.c_void_p(self.sys_matrix_ptr()), dptr(M.contiguous()),
+                                       self.n * self.n * 8), "copy_d2d")
+
+    def get_sys_matrix(self) -> torch.Tensor:
+        out = torch.empty((self.n, self.n), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(self.sys_matrix_ptr()), self.n * self.n * 8),
+              "copy_d2d")
+        self.ctx.sync()
+        return out
+
+    def matrix_changed(self) -> int:
+        nneg = C.c_int(0)
+        check(self._L.hiopamd_linsolver_matrix_changed(self.h, C.byref(nneg)), "hiopamd_linsolver_matrix_changed")
+        return nneg.value
+
+    def solve(self, rhs: torch.Tensor, nrhs: int = 1) -> bool:
+        rc = self._L.hiopamd_linsolver_solve(self.h, dptr(rhs), nrhs)
+        check(rc, "hiopamd_linsolver_solve")
+        return True
+
+    def inertia(self):
+        p, n, z = C.c_int(), C.c_int(), C.c_int()
+        check(self._L.hiopamd_linsolver_inertia(self.h, C.byref(p), C.byref(n), C.byref(z)), "inertia")
+        return p.value, n.value, z.value
+
+    def close(self):
+        if self.h is not None:
+            self._L.hiopamd_linsolver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KKTLinSysCompressedMDSXYcYd:
+    """Device-resident condensed MDS KKT.  `prob` carries the (host, numpy) structure + constant blocks;
+    they are uploaded once and stay in HBM."""
+
+    def __init__(self, ctx: Context, nxs, nxd, neq, nineq, Jcs_ij, Jds_ij, Hss_ij):
+        self.ctx = ctx
+        self._L = lib()
+        self.nxs, self.nxd, self.neq, self.nineq = nxs, nxd, neq, nineq
+        self.N = nxd + neq + nineq
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        self._host = [i32(Jcs_ij[0]), i32(Jcs_ij[1]), i32(Jds_ij[0]), i32(Jds_ij[1]), i32(Hss_ij[0]), i32(Hss_ij[1])]
+        self._devi = [dev(a, torch.int32) for a in self._host]
+        torch.cuda.synchronize()
+        s = MdsStructure()
+        s.nxs, s.nxd, s.neq, s.nineq = nxs, nxd, neq, nineq
+        s.nnz_Jcs = self._host[0].size
+        s.Jcs_i, s.Jcs_j = self._devi[0].data_ptr(), self._devi[1].data_ptr()
+        s.Jcs_i_host, s.Jcs_j_host = self._host[0].ctypes.data, self._host[1].ctypes.data
+        s.nnz_Jds = self._host[2].size
+        s.Jds_i, s.Jds_j = self._devi[2].data_ptr(), self._devi[3].data_ptr()
+        s.Jds_i_host, s.Jds_j_host = self._host[2].ctypes.data, self._host[3].ctypes.data
+        s.nnz_Hss = self._host[4].size
+        s.Hss_i, s.Hss_j = self._devi[4].data_ptr(), self._devi[5].data_ptr()
+        h = C.c_void_p()
+        check(self._L.hiopamd_kkt_mds_create(C.byref(h), ctx.h, C.byref(s)), "hiopamd_kkt_mds_create")
+        self.h = h
+        self._vals = None
+
+    def set_values(self, Jcs_val, Jds_val, Hss_val, Jcd, Jdd, Hdd, Dx, Dd):
+        """All arguments are device fp64 tensors; they are borrowed (kept alive here) until the next call."""
+        self._vals = [Jcs_val, Jds_val, Hss_val, Jcd, Jdd, Hdd, Dx, Dd]
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_kkt_mds_set_values(self.h, *[dptr(t) for t in self._vals]), "hiopamd_kkt_mds_set_values")
+
+    def build_kkt_matrix(self, delta_wx=0.0, delta_wd=0.0, delta_cc=0.0, delta_cd=0.0):
+        check(self._L.hiopamd_kkt_mds_build(self.h, delta_wx, delta_wd, delta_cc, delta_cd), "hiopamd_kkt_mds_build")
+
+    def factorize_with_curv_check(self) -> int:
+        nneg = C.c_int(0)
+        check(self._L.hiopamd_kkt_mds_factorize(self.h, C.byref(nneg)), "hiopamd_kkt_mds_factorize")
+        return nneg.value
+
+    def solve_compressed(self, rx, ryc, ryd, dx, dyc, dyd):
+        check(self._L.hiopamd_kkt_mds_solve_compressed(self.h, dptr(rx), dptr(ryc), dptr(ryd), dptr(dx), dptr(dyc),
+                                                       dptr(dyd)), "hiopamd_kkt_mds_solve_compressed")
+
+    def sys_matrix(self) -> torch.Tensor:
+        """Copy of the N x N system matrix (device tensor)."""
+        ptr = self._L.hiopamd_kkt_mds_sys_matrix(self.h)
+        out = torch.empty((self.N, self.N), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), self.N * self.N * 8), "copy_d2d")
+        self.ctx.sync()
+        return out
+
+    def Hxs(self) -> torch.Tensor:
+        ptr = self._L.hiopamd_kkt_mds_Hxs(self.h)
+        out = torch.empty(self.nxs, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), self.nxs * 8), "copy_d2d")
+        self.ctx.sync()
+        return out
+
+    def close(self):
+        if self.h is not None:
+            self._L.hiopamd_kkt_mds_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mds_from_problem(ctx: Context, p) -> tuple["KKTLinSysCompressedMDSXYcYd", dict]:
+    """Upload an MDS problem description (numpy arrays: sizes, COO index/value arrays, dense blocks) to the device; returns the KKT handle and
+    the dict of device tensors holding the constant blocks."""
+    k = KKTLinSysCompressedMDSXYcYd(ctx, p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j),
+                                    (p.Hss_i, p.Hss_j))
+    d = dict(Jcs_v=dev(p.Jcs_v), Jds_v=dev(p.Jds_v), Hss_v=dev(p.Hss_v), Jcd=dev(p.Jcd), Jdd=dev(p.Jdd), Hdd=dev(p.Hdd))
+    return k, d

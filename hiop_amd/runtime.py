@@ -1,0 +1,101 @@
+"""Host-side runtime glue: execution context + device-array helpers (torch owns the HBM allocations).
+
+Mirrors what the reference's LinearAlgebraFactory + ExecSpace do for the `HIP` mem-space
+(src/LinAlg/LinAlgFactory.cpp:100-180, src/ExecBackends/ExecSpace.hpp:345-457): arrays live in device
+memory and only raw pointers cross into the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import lib, check
+
+
+def dptr(t) -> C.c_void_p:
+    """Raw device (or host) address of a torch tensor / numpy array / None."""
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return C.c_void_p(t.ctypes.data)
+    raise TypeError(type(t))
+
+
+def dev(a, dtype=None, device="cuda"):
+    """numpy -> device tensor (fp64 / int32)."""
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device).contiguous()
+
+
+class Context:
+    """Owns a hiopamd_ctx (HIP stream + reduction scratch).  All kernels of one context are stream-ordered."""
+
+    def __init__(self, device_index: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("hiop_amd needs a MI355X (gfx950) device: no HIP device is visible and there is no CPU path")
+        torch.cuda.set_device(device_index)
+        self._L = lib()
+        h = C.c_void_p()
+        check(self._L.hiopamd_ctx_create(C.byref(h), None), "hiopamd_ctx_create")
+        self.h = h
+        self.stream_ptr = self._L.hiopamd_ctx_stream(self.h)
+        self.torch_stream = torch.cuda.ExternalStream(self.stream_ptr)
+
+    def sync(self):
+        check(self._L.hiopamd_ctx_sync(self.h), "hiopamd_ctx_sync")
+
+    def close(self):
+        if self.h is not None:
+            self._L.hiopamd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- small call helpers ----
+    def call(self, name, *args):
+        fn = getattr(self._L, name)
+        conv = []
+        for a in args:
+            if isinstance(a, (torch.Tensor, np.ndarray)) or a is None:
+                conv.append(dptr(a))
+            else:
+                conv.append(a)
+        check(fn(self.h, *conv), name)
+
+    def reduce_double(self, name, *args) -> float:
+        out = C.c_double(0.0)
+        self.call(name, *args, C.byref(out))
+        return out.value
+
+    def reduce_int(self, name, *args) -> int:
+        out = C.c_int(0)
+        self.call(name, *args, C.byref(out))
+        return out.value
+
+    def reduce_int64(self, name, *args) -> int:
+        out = C.c_int64(0)
+        self.call(name, *args, C.byref(out))
+        return out.value
+
+    def init_rccl_from_torch_distributed(self):
+        """One RCCL communicator per context; the 128-byte unique id travels over torch.distributed."""
+        import torch.distributed as dist
+        rank, size = dist.get_rank(), dist.get_world_size()
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            check(self._L.hiopamd_rccl_unique_id(uid), "hiopamd_rccl_unique_id")
+        t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+        dist.broadcast(t, 0)
+        arr = (C.c_ubyte * 128)(*t.cpu().tolist())
+        check(self._L.hiopamd_ctx_init_rccl(self.h, arr, rank, size), "hiopamd_ctx_init_rccl")

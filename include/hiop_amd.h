@@ -1,0 +1,311 @@
+/* hiop_amd.h — C ABI of the MI355X-native KKT hot path for HiOp.
+ *
+ * Every entry point takes plain device pointers (HBM, fp64 / int32) and sizes; nothing in this
+ * header depends on PyTorch, RAJA, Umpire or MAGMA.  Each group cites the reference interface
+ * (file:line under LLNL/hiop @ v1.1.0) that a HiOp-side subclass forwards to it; the subclass
+ * stubs are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *  - all kernels are enqueued on the context's HIP stream; functions that return a scalar
+ *    (`double* out_host` / `int* out_host`) synchronise that stream before returning;
+ *  - dense matrices are ROW-MAJOR with explicit leading dimension `ld` (reference:
+ *    src/LinAlg/hiopMatrixDenseRowMajor.cpp:90-93);
+ *  - symmetric KKT matrices hold only their UPPER triangle (reference: src/LinAlg/readme.md:24-26);
+ *  - "pattern"/"select" vectors are fp64 arrays of exact 0.0 / 1.0
+ *    (reference: src/LinAlg/hiopVectorPar.cpp:144,782,1053);
+ *  - return value: HIOPAMD_OK (0) or a negative error code; functions never fall back to a CPU
+ *    path.
+ */
+#ifndef HIOP_AMD_H
+#define HIOP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  HIOPAMD_OK = 0,
+  HIOPAMD_ERR_HIP = -1,       /* a HIP runtime call failed */
+  HIOPAMD_ERR_ARG = -2,       /* invalid argument */
+  HIOPAMD_ERR_NODEVICE = -3,  /* no gfx950 device visible */
+  HIOPAMD_ERR_SINGULAR = -4,  /* zero / non-finite pivot met */
+  HIOPAMD_ERR_STATE = -5      /* call sequence error (e.g. solve before factorize) */
+} hiopamd_status;
+
+typedef struct hiopamd_ctx hiopamd_ctx;
+
+/* reduction ops for the all-reduce hook (reference: MPI_SUM/MPI_MIN/MPI_MAX call sites listed in
+ * SURVEY.md §2.2, e.g. src/LinAlg/hiopVectorPar.cpp:474-548) */
+typedef enum { HIOPAMD_SUM = 0, HIOPAMD_MIN = 1, HIOPAMD_MAX = 2 } hiopamd_redop;
+
+/* All-reduce hook: reduce `count` fp64 values in DEVICE buffer `buf` in place across the ranks
+ * of the column partition, ordered on `stream` (a hipStream_t).  Return 0 on success. */
+typedef int (*hiopamd_allreduce_fn)(void* user, double* buf, size_t count, int op, void* stream);
+
+/* ---- context (plays ExecSpace<MemBackendHip,ExecPolicyHip>; src/ExecBackends/ExecSpace.hpp:345) */
+int hiopamd_ctx_create(hiopamd_ctx** out, void* hip_stream /* hipStream_t or NULL */);
+int hiopamd_ctx_destroy(hiopamd_ctx* ctx);
+int hiopamd_ctx_sync(hiopamd_ctx* ctx);
+void* hiopamd_ctx_stream(hiopamd_ctx* ctx);
+int hiopamd_ctx_set_allreduce(hiopamd_ctx* ctx, hiopamd_allreduce_fn fn, void* user, int rank, int size);
+/* RCCL-backed all-reduce: `unique_id_128` is the 128-byte ncclUniqueId produced by
+ * hiopamd_rccl_unique_id on rank 0 and broadcast by the host side. */
+int hiopamd_rccl_unique_id(unsigned char* unique_id_128_host);
+int hiopamd_ctx_init_rccl(hiopamd_ctx* ctx, const unsigned char* unique_id_128_host, int rank, int size);
+const char* hiopamd_version(void);
+int hiopamd_device_info(char* name_host, size_t name_len, int* cu_count_host, size_t* hbm_bytes_host);
+
+/* ---- memory (AllocImpl / DeAllocImpl / TransferImpl; src/ExecBackends/MemBackendHipImpl.hpp:73-135) */
+int hiopamd_alloc(void** dptr, size_t bytes);
+int hiopamd_free(void* dptr);
+int hiopamd_copy_h2d(hiopamd_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+int hiopamd_copy_d2h(hiopamd_ctx* ctx, void* dst_host, const void* src, size_t bytes);
+int hiopamd_copy_d2d(hiopamd_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* =====================================================================================
+ * hiopVector element-wise family  (reference: src/LinAlg/hiopVector.hpp:74-1003, CPU semantics
+ * src/LinAlg/hiopVectorPar.cpp:120-1320).  `y` is always `this`.
+ * ===================================================================================== */
+int hiopamd_vec_set_to_constant(hiopamd_ctx*, int64_t n, double* y, double c);                          /* :127 */
+int hiopamd_vec_set_to_constant_w_pattern(hiopamd_ctx*, int64_t n, double* y, double c, const double* select); /* :139 */
+int hiopamd_vec_copy(hiopamd_ctx*, int64_t n, double* y, const double* x);                              /* copyFrom :153 */
+int hiopamd_vec_copy_from_w_pattern(hiopamd_ctx*, int64_t n, double* y, const double* x, const double* select); /* :179 */
+int hiopamd_vec_copy_from_indexes(hiopamd_ctx*, int64_t n, double* y, const double* src, const int* idx); /* :194 */
+int hiopamd_vec_copy_to_starting_at_w_pattern(hiopamd_ctx*, int64_t n, const double* x, double* dest,
+                                              int64_t start_in_dest, const double* select, int64_t* nnz_out_host); /* :322 */
+int hiopamd_vec_starting_at_copy_to_starting_at_w_pattern(hiopamd_ctx*, const double* src, int64_t start_src,
+                                                          double* dest, int64_t n_dest, int64_t start_dest,
+                                                          const double* select_dest, int64_t num_elems); /* :431 */
+int hiopamd_vec_copy_from_two_vec_w_pattern(hiopamd_ctx*, double* y, const double* c, const int* c_map, int64_t nc,
+                                            const double* d, const int* d_map, int64_t nd);             /* :345 */
+int hiopamd_vec_copy_to_two_vec_w_pattern(hiopamd_ctx*, const double* y, double* c, const int* c_map, int64_t nc,
+                                          double* d, const int* d_map, int64_t nd);                     /* :372 */
+int hiopamd_vec_component_mult(hiopamd_ctx*, int64_t n, double* y, const double* x);                    /* :564 */
+int hiopamd_vec_component_div(hiopamd_ctx*, int64_t n, double* y, const double* x);                     /* :573 */
+int hiopamd_vec_component_div_w_pattern(hiopamd_ctx*, int64_t n, double* y, const double* x, const double* select); /* :580 */
+int hiopamd_vec_component_min_c(hiopamd_ctx*, int64_t n, double* y, double c);                          /* :594 */
+int hiopamd_vec_component_min_v(hiopamd_ctx*, int64_t n, double* y, const double* x);                   /* :603 */
+int hiopamd_vec_component_max_c(hiopamd_ctx*, int64_t n, double* y, double c);                          /* :613 */
+int hiopamd_vec_component_max_v(hiopamd_ctx*, int64_t n, double* y, const double* x);                   /* :622 */
+int hiopamd_vec_component_abs(hiopamd_ctx*, int64_t n, double* y);                                      /* :632 */
+int hiopamd_vec_component_sgn(hiopamd_ctx*, int64_t n, double* y);                                      /* :639 */
+int hiopamd_vec_component_sqrt(hiopamd_ctx*, int64_t n, double* y);                                     /* :649 */
+int hiopamd_vec_scale(hiopamd_ctx*, int64_t n, double* y, double c);                                    /* :657 */
+int hiopamd_vec_axpy(hiopamd_ctx*, int64_t n, double* y, double alpha, const double* x);                /* :664 */
+int hiopamd_vec_axpy_w_pattern(hiopamd_ctx*, int64_t n, double* y, double alpha, const double* x, const double* select); /* :692 */
+int hiopamd_vec_axpy_w_map(hiopamd_ctx*, int64_t nidx, double* y, double alpha, const double* x, const int* idx);      /* :676 */
+int hiopamd_vec_axzpy(hiopamd_ctx*, int64_t n, double* y, double alpha, const double* x, const double* z);  /* :710 */
+int hiopamd_vec_axdzpy(hiopamd_ctx*, int64_t n, double* y, double alpha, const double* x, const double* z); /* :736 */
+int hiopamd_vec_axdzpy_w_pattern(hiopamd_ctx*, int64_t n, double* y, double alpha, const double* x, const double* z,
+                                 const double* select);                                                 /* :767 */
+int hiopamd_vec_add_constant(hiopamd_ctx*, int64_t n, double* y, double c);                             /* :793 */
+int hiopamd_vec_add_constant_w_pattern(hiopamd_ctx*, int64_t n, double* y, double c, const double* select); /* :798 */
+int hiopamd_vec_negate(hiopamd_ctx*, int64_t n, double* y);                                             /* :846 */
+int hiopamd_vec_invert(hiopamd_ctx*, int64_t n, double* y);                                             /* :852 */
+int hiopamd_vec_add_log_barrier_grad(hiopamd_ctx*, int64_t n, double* y, double alpha, const double* x,
+                                     const double* select);                                             /* :893 */
+int hiopamd_vec_add_linear_damping_term(hiopamd_ctx*, int64_t n, double* y, const double* ixleft,
+                                        const double* ixright, double alpha, double ct);                /* :927 */
+int hiopamd_vec_select_pattern(hiopamd_ctx*, int64_t n, double* y, const double* select);               /* :1063 */
+int hiopamd_vec_adjust_duals_plh(hiopamd_ctx*, int64_t n, double* z, const double* x, const double* select,
+                                 double mu, double kappa);                                              /* :1117 */
+int hiopamd_vec_project_into_bounds(hiopamd_ctx*, int64_t n, double* x, const double* xl, const double* ixl,
+                                    const double* xu, const double* ixu, double kappa1, double kappa2,
+                                    int* ok_out_host);                                                  /* :964 */
+int hiopamd_vec_set_to_linspace(hiopamd_ctx*, int64_t n, double* y, double x0, double dx);
+
+/* ---- hiopVector reductions (local part; the *_global variants add the all-reduce hook) */
+int hiopamd_vec_dot(hiopamd_ctx*, int64_t n, const double* x, const double* y, double* out_host);        /* :480 */
+int hiopamd_vec_twonorm(hiopamd_ctx*, int64_t n, const double* x, double* out_host);                     /* :463 */
+int hiopamd_vec_infnorm(hiopamd_ctx*, int64_t n, const double* x, double* out_host);                     /* :501 */
+int hiopamd_vec_onenorm(hiopamd_ctx*, int64_t n, const double* x, double* out_host);                     /* :540 */
+int hiopamd_vec_sum(hiopamd_ctx*, int64_t n, const double* x, double* out_host);                         /* :883 */
+int hiopamd_vec_min(hiopamd_ctx*, int64_t n, const double* x, double* out_host);                         /* :806 */
+int hiopamd_vec_min_w_pattern(hiopamd_ctx*, int64_t n, const double* x, const double* select, double* out_host); /* :821 */
+int hiopamd_vec_log_barrier(hiopamd_ctx*, int64_t n, const double* x, const double* select, double* out_host);   /* :863 */
+int hiopamd_vec_linear_damping_term(hiopamd_ctx*, int64_t n, const double* x, const double* ixleft,
+                                    const double* ixright, double mu, double kappa_d, double* out_host); /* :907 */
+int hiopamd_vec_fraction_to_the_bdry(hiopamd_ctx*, int64_t n, const double* x, const double* d, double tau,
+                                     double* out_host);                                                  /* :1017 */
+int hiopamd_vec_fraction_to_the_bdry_w_pattern(hiopamd_ctx*, int64_t n, const double* x, const double* d,
+                                               double tau, const double* select, double* out_host);      /* :1038 */
+int hiopamd_vec_all_positive(hiopamd_ctx*, int64_t n, const double* x, int* out_host);                   /* :946 */
+int hiopamd_vec_all_positive_w_pattern(hiopamd_ctx*, int64_t n, const double* x, const double* select, int* out_host); /* :1095 */
+int hiopamd_vec_matches_pattern(hiopamd_ctx*, int64_t n, const double* x, const double* select, int* out_host); /* :1073 */
+int hiopamd_vec_is_zero(hiopamd_ctx*, int64_t n, const double* x, int* out_host);                        /* :1150 */
+int hiopamd_vec_isnan(hiopamd_ctx*, int64_t n, const double* x, int* out_host);                          /* :1167 */
+int hiopamd_vec_isinf(hiopamd_ctx*, int64_t n, const double* x, int* out_host);                          /* :1173 */
+int hiopamd_vec_isfinite(hiopamd_ctx*, int64_t n, const double* x, int* out_host);                       /* :1179 */
+int hiopamd_vec_num_elems_less_than(hiopamd_ctx*, int64_t n, const double* x, double val, int64_t* out_host);     /* :1222 */
+int hiopamd_vec_num_elems_abs_less_than(hiopamd_ctx*, int64_t n, const double* x, double val, int64_t* out_host); /* :1241 */
+int hiopamd_vec_is_equal(hiopamd_ctx*, int64_t n, const double* x, const double* y, int* out_host);      /* :1283 */
+/* fused step-length kernel used by hiopIterate::fractionToTheBdry (src/Optimization/hiopIterate.cpp:330-365):
+ * `k` (x,d,select) triples reduced in ONE launch; out_host[0] = min over all. */
+int hiopamd_vec_fraction_to_the_bdry_multi(hiopamd_ctx*, int k, const int64_t* n_host, const double* const* x_host,
+                                           const double* const* d_host, const double* const* select_host,
+                                           double tau, double* out_host);
+
+/* =====================================================================================
+ * hiopMatrixDense (row-major)  (reference: src/LinAlg/hiopMatrixDenseRowMajor.cpp)
+ * A is m x n with leading dimension lda (doubles).
+ * ===================================================================================== */
+int hiopamd_mat_set_to_constant(hiopamd_ctx*, int m, int64_t n, double* A, int64_t lda, double c);       /* :374 */
+/* y = beta*y + alpha*A*x  (local part; DGEMV-T at :471) */
+int hiopamd_mat_times_vec(hiopamd_ctx*, int m, int64_t n, const double* A, int64_t lda, double beta, double* y,
+                          double alpha, const double* x);                                               /* :458 */
+/* y = beta*y + alpha*A^T*x */
+int hiopamd_mat_trans_times_vec(hiopamd_ctx*, int m, int64_t n, const double* A, int64_t lda, double beta,
+                                double* y, double alpha, const double* x);                               /* :510 */
+/* W(m x k) = beta*W + alpha*A(m x n)*X(n x k) */
+int hiopamd_mat_times_mat(hiopamd_ctx*, int m, int n, int k, const double* A, int64_t lda, double beta, double* W,
+                          int64_t ldw, double alpha, const double* X, int64_t ldx);                      /* :578 */
+/* W(n x k) = beta*W + alpha*A^T(n x m)*X(m x k) */
+int hiopamd_mat_trans_times_mat(hiopamd_ctx*, int m, int n, int k, const double* A, int64_t lda, double beta,
+                                double* W, int64_t ldw, double alpha, const double* X, int64_t ldx);     /* :616 */
+/* W(m x k) = beta*W + alpha*A(m x n)*X(k x n)^T  (local part; caller all-reduces) */
+int hiopamd_mat_times_mat_trans(hiopamd_ctx*, int m, int64_t n, int k, const double* A, int64_t lda, double beta,
+                                double* W, int64_t ldw, double alpha, const double* X, int64_t ldx);     /* :646 */
+int hiopamd_mat_add_diagonal_vec(hiopamd_ctx*, int n, double* A, int64_t lda, double alpha, const double* d); /* :703 */
+int hiopamd_mat_add_diagonal_const(hiopamd_ctx*, int n, double* A, int64_t lda, double value);           /* :715 */
+/* A[start+i][start+i] += alpha*d[src_start+i], i<num  (the three addSubDiagonal overloads :719,735,755) */
+int hiopamd_mat_add_sub_diagonal(hiopamd_ctx*, double* A, int64_t lda, int start_on_dest_diag, double alpha,
+                                 const double* d, int start_on_src_vec, int num_elems);
+int hiopamd_mat_add_sub_diagonal_const(hiopamd_ctx*, double* A, int64_t lda, int start_on_dest_diag, int num_elems,
+                                       double c);
+int hiopamd_mat_add_matrix(hiopamd_ctx*, int m, int64_t n, double* A, int64_t lda, double alpha, const double* X,
+                           int64_t ldx);                                                                /* :766 */
+/* block of W += alpha*A^T at (row_start, col_start) of W (upper triangle)  :779 */
+int hiopamd_mat_trans_add_to_sym_upper(hiopamd_ctx*, int m, int n, const double* A, int64_t lda, int row_start,
+                                       int col_start, double alpha, double* W, int64_t ldw);
+/* diagonal block of W += alpha*upper(A), A n x n  :810 */
+int hiopamd_mat_add_upper_to_sym_upper(hiopamd_ctx*, int n, const double* A, int64_t lda, int diag_start,
+                                       double alpha, double* W, int64_t ldw);
+int hiopamd_mat_copy_rows_from(hiopamd_ctx*, int num_rows, int64_t n, double* A, int64_t lda, int row_dest,
+                               const double* src, int64_t ldsrc);                                       /* :169 */
+int hiopamd_mat_copy_rows_from_idx(hiopamd_ctx*, int num_rows, int64_t n, double* A, int64_t lda,
+                                   const double* src, int64_t ldsrc, const int* rows_idxs);              /* :182 */
+int hiopamd_mat_copy_block(hiopamd_ctx*, int m, int n, double* dst, int64_t lddst, const double* src,
+                           int64_t ldsrc);                                                              /* :200,222 */
+int hiopamd_mat_shift_rows(hiopamd_ctx*, int m, int64_t n, double* A, int64_t lda, int shift);           /* :238 */
+int hiopamd_mat_max_abs(hiopamd_ctx*, int m, int64_t n, const double* A, int64_t lda, double* out_host);  /* :832 */
+int hiopamd_mat_row_max_abs(hiopamd_ctx*, int m, int64_t n, const double* A, int64_t lda, double* ret_vec); /* :844 */
+int hiopamd_mat_scale_rows(hiopamd_ctx*, int m, int64_t n, double* A, int64_t lda, const double* scal, int inv); /* :865 */
+int hiopamd_mat_symmetrize(hiopamd_ctx*, int n, double* A, int64_t lda);                                  /* :912 (upper -> lower) */
+int hiopamd_mat_is_finite(hiopamd_ctx*, int m, int64_t n, const double* A, int64_t lda, int* out_host);   /* :889 */
+
+/* =====================================================================================
+ * Weighted Gram kernels of the low-rank (quasi-Newton) KKT
+ * (reference: src/Optimization/hiopHessianLowRank.cpp:1079 symmMatTimesDiagTimesMatTrans_local,
+ *  :1119 matTimesDiagTimesMatTrans_local).  fp64 MFMA (v_mfma_f64_16x16x4_f64).
+ * W(ma x mb) = beta*W + alpha * A(ma x n) * diag(d) * B(mb x n)^T ; d may be NULL (= ones).
+ * If A==B && sym_upper!=0 only the upper triangle of W is written (reference :1079 semantics).
+ * ===================================================================================== */
+int hiopamd_gram_weighted(hiopamd_ctx*, int ma, int mb, int64_t n, const double* A, int64_t lda, const double* B,
+                          int64_t ldb, const double* d, double beta, double* W, int64_t ldw, double alpha,
+                          int sym_upper);
+
+/* =====================================================================================
+ * hiopMatrixSparseTriplet (row-sorted COO, int32 indices)
+ * (reference: src/LinAlg/hiopMatrixSparseTriplet.cpp)
+ * ===================================================================================== */
+int hiopamd_sp_times_vec(hiopamd_ctx*, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
+                         const double* val, double beta, double* y, double alpha, const double* x);      /* :73 */
+int hiopamd_sp_trans_times_vec(hiopamd_ctx*, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
+                               const double* val, double beta, double* y, double alpha, const double* x); /* :110 */
+/* symbolic plan for  W[r0+i][c0+j] += alpha * sum_c M1[i,c]*M2[j,c]/D[c]  (pattern fixed across IPM iterations,
+ * reference comment :479-489).  Index arrays are HOST pointers here (the plan is built once on the host). */
+typedef struct hiopamd_sp_plan hiopamd_sp_plan;
+int hiopamd_sp_plan_create(hiopamd_sp_plan** out, int m1, int m2, int ncols, int nnz1, const int* iRow1_host,
+                           const int* jCol1_host, int nnz2, const int* iRow2_host, const int* jCol2_host,
+                           int same_matrix_upper_only);
+int hiopamd_sp_plan_destroy(hiopamd_sp_plan* plan);
+int64_t hiopamd_sp_plan_num_outputs(const hiopamd_sp_plan* plan);
+int64_t hiopamd_sp_plan_num_products(const hiopamd_sp_plan* plan);
+/* addMDinvMtransToDiagBlockOfSymDeMatUTri :390 (same matrix) / addMDinvNtransToSymDeMatUTri :447 */
+int hiopamd_sp_add_MDinvNt(hiopamd_ctx*, const hiopamd_sp_plan* plan, const double* val1, const double* val2,
+                           const double* D, double alpha, double* W, int64_t ldw, int row_dest_start,
+                           int col_dest_start);
+/* y[start_dest+i] += alpha * diag(Msym)[i]  (hiopMatrixSymSparseTriplet::startingAtAddSubDiagonalToStartingAt :1018) */
+int hiopamd_spsym_add_diag_to_vec(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, const double* val,
+                                  double alpha, double* y, int vec_start, int n_vec, int diag_src_start,
+                                  int num_elems);
+/* W upper += alpha * Msym (upper triangle entries) at diag_start (:980) */
+int hiopamd_spsym_add_upper_to_sym_upper(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, const double* val,
+                                         int diag_start, double alpha, double* W, int64_t ldw);
+
+/* =====================================================================================
+ * hiopLinSolverSymDense operator — no-pivot blocked LDL^T on fp64 MFMA + inertia
+ * (reference: src/LinAlg/hiopLinSolver.hpp:78-130; semantics of
+ *  src/LinAlg/hiopLinSolverSymDenseMagma.cpp:324-480 (MagmaNopiv) and the inertia thresholds of
+ *  src/LinAlg/hiopLinSolverSymDenseLapack.hpp:154-161).
+ * ===================================================================================== */
+typedef struct hiopamd_linsolver hiopamd_linsolver;
+int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n);
+int hiopamd_linsolver_destroy(hiopamd_linsolver* ls);
+/* device pointer of the n x n row-major system matrix (ld = n); the KKT class writes its upper triangle */
+double* hiopamd_linsolver_sys_matrix(hiopamd_linsolver* ls);
+int hiopamd_linsolver_n(const hiopamd_linsolver* ls);
+/* matrixChanged(): factorise in place; *n_neg_host = number of negative pivots, or -1 if a pivot is
+ * (numerically) zero / non-finite -- the reference's "singular" return. */
+int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host);
+/* solve(): rhs (device, length n * nrhs, column after column) overwritten by the solution */
+int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs);
+/* last factorisation: pos/neg/zero pivot counts (magmablas_ddiinertia equivalent) */
+int hiopamd_linsolver_inertia(const hiopamd_linsolver* ls, int* pos_host, int* neg_host, int* zero_host);
+/* per-launch HIP-event timing of the MFMA rank-K update kernel (bench / roofline only; off by default).
+ * read: accumulated kernel milliseconds, algorithmic flops (2*K per updated element) and launch count
+ * since the last hiopamd_linsolver_profile(ls, 1). */
+int hiopamd_linsolver_profile(hiopamd_linsolver* ls, int enable);
+int hiopamd_linsolver_profile_read(const hiopamd_linsolver* ls, double* update_ms_host, double* update_flops_host,
+                                   int64_t* update_launches_host);
+/* stand-alone entry points on caller-owned storage */
+int hiopamd_ldlt_factor(hiopamd_ctx*, int n, double* A, int64_t lda, double* work_dinv /* n doubles */,
+                        int* inertia3_host /* pos,neg,zero */);
+int hiopamd_ldlt_solve(hiopamd_ctx*, int n, const double* A, int64_t lda, const double* work_dinv, double* rhs_inout,
+                       int nrhs);
+/* SPD solve with equilibration + refinement for the k x k low-rank KKT reduced system
+ * (reference: hiopKKTLinSysLowRank::solveWithRefin, src/Optimization/hiopKKTLinSys.cpp:1192-1330). */
+int hiopamd_posv_refine(hiopamd_ctx*, int k, const double* N_upper, int64_t ldn, double* rhs_inout,
+                        double* work /* 3*k*k + 8*k doubles */, int* info_host, double* resid_rel_host);
+
+/* =====================================================================================
+ * KKT objects (stateful): condensed MDS KKT and quasi-Newton low-rank KKT
+ * ===================================================================================== */
+/* hiopKKTLinSysCompressedMDSXYcYd (reference: src/Optimization/hiopKKTLinSysMDS.cpp:112-403) */
+typedef struct hiopamd_kkt_mds hiopamd_kkt_mds;
+typedef struct {
+  int nxs, nxd, neq, nineq;
+  /* sparse Jacobian blocks, row-sorted COO; index arrays given BOTH on device (kernels) and host (plan) */
+  int nnz_Jcs; const int* Jcs_i; const int* Jcs_j; const int* Jcs_i_host; const int* Jcs_j_host;
+  int nnz_Jds; const int* Jds_i; const int* Jds_j; const int* Jds_i_host; const int* Jds_j_host;
+  /* sparse Hessian block (diagonal entries used), COO */
+  int nnz_Hss; const int* Hss_i; const int* Hss_j;
+} hiopamd_mds_structure;
+int hiopamd_kkt_mds_create(hiopamd_kkt_mds** out, hiopamd_ctx* ctx, const hiopamd_mds_structure* s);
+int hiopamd_kkt_mds_destroy(hiopamd_kkt_mds* k);
+/* values for the current iterate (device pointers, kept by reference until the next call):
+ * Jcs_val, Jds_val, Hss_val (COO values), Jcd (neq x nxd), Jdd (nineq x nxd), Hdd (nxd x nxd, upper used),
+ * Dx (nxs+nxd: log-barrier diagonal, sparse part first), Dd (nineq: (Sdl)^-1 Vl + (Sdu)^-1 Vu, WITHOUT delta_wd) */
+int hiopamd_kkt_mds_set_values(hiopamd_kkt_mds* k, const double* Jcs_val, const double* Jds_val, const double* Hss_val,
+                               const double* Jcd, const double* Jdd, const double* Hdd, const double* Dx,
+                               const double* Dd);
+/* build_kkt_matrix (:172) with scalar inertia-correction perturbations, then factorizeWithCurvCheck (:78).
+ * *n_neg_host = #negative eigenvalues of the full XYcYd system (dense part + sparse (1,1) block), or -1. */
+int hiopamd_kkt_mds_build(hiopamd_kkt_mds* k, double delta_wx, double delta_wd, double delta_cc, double delta_cd);
+int hiopamd_kkt_mds_factorize(hiopamd_kkt_mds* k, int* n_neg_host);
+/* solveCompressed (:307): all device vectors; rx (nxs+nxd), ryc (neq), ryd (nineq) are inputs (ryd is
+ * overwritten like in the reference), dx, dyc, dyd outputs. */
+int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const double* ryc, double* ryd,
+                                     double* dx, double* dyc, double* dyd);
+double* hiopamd_kkt_mds_sys_matrix(hiopamd_kkt_mds* k);   /* device, N x N row-major, N = nxd+neq+nineq */
+double* hiopamd_kkt_mds_Hxs(hiopamd_kkt_mds* k);          /* device, nxs */
+hiopamd_linsolver* hiopamd_kkt_mds_linsolver(hiopamd_kkt_mds* k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIOP_AMD_H */

@@ -1,0 +1,461 @@
+"""CPU oracle for the HiOp KKT hot path — TEST INFRASTRUCTURE ONLY.
+
+This module restates, in numpy (fp64) + LAPACK, the algorithms of the reference's CPU path for the
+hot path this repository accelerates.  It is the *checker*: only tests/, __graft_entry__.smoke() and
+bench.py's `cpu_baseline` leg may import it.  Nothing under hiop_amd/ imports it, and the product
+path has no CPU fallback.
+
+Every function cites the reference file:line (LLNL/hiop v1.1.0) whose loop it follows.
+
+Third-party dependency of the reference path: LAPACK/BLAS (Fortran ABI; the reference links
+whatever `find_package(LAPACK)` finds, CMakeLists.txt:99-106).  Here the same published routines
+(DSYTRF / DSYTRS / DPOSVX / DPOTRF / DPOTRS, Bunch-Kaufman as in LAPACK 3.9+) come from the
+OpenBLAS build bundled with scipy 1.15.3 (`scipy.linalg.lapack`).
+
+Pinning: the reference cannot be built in this image under the project
+rules (it needs two CMake-generated headers, one of which requires a Fortran compiler), so the
+oracle is pinned against the known answers the reference's own tests hold:
+  * closed-form expected values of tests/LinAlg/{vectorTests,matrixTestsDense,matrixTestsSparse,
+    matrixTestsSymSparse}.hpp  (tests/test_oracle_vs_reference_unit_tests.py),
+  * the `-selfcheck` objective values of the Dense/MDS drivers
+    (src/Drivers/MDS/NlpMdsEx1Driver.cpp:149, src/Drivers/Dense/NlpDenseConsEx1Driver.cpp:139-140,
+    NlpDenseConsEx2Driver.cpp:124-125) reproduced by oracle/ipm.py driving THIS module's KKT path,
+  * `write_kkt` triples (matrix, rhs, solution) of the reference's MdsEx1 run committed under
+    tests/golden/ (provenance in tests/golden/README.md).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.linalg import lapack
+
+# =====================================================================================
+# hiopVector (reference: src/LinAlg/hiopVectorPar.cpp) — element-wise family
+# Functions mutate `y` in place like the reference methods mutate `this`.
+# =====================================================================================
+
+
+def set_to_constant_w_pattern(y, c, select):          # :139
+    y[:] = np.where(select == 1.0, c, 0.0)
+
+
+def copy_from_w_pattern(y, x, select):                 # :179
+    m = select == 1.0
+    y[m] = x[m]
+
+
+def copy_to_starting_at_w_pattern(x, dest, start, select):   # :322
+    sel = x[select == 1.0]
+    dest[start:start + sel.size] = sel
+    return sel.size
+
+
+def starting_at_copy_to_starting_at_w_pattern(src, start_src, dest, start_dest, select_dest, num_elems=-1):  # :431
+    n_src_avail = src.size - start_src
+    if num_elems < 0:
+        num_elems = min(n_src_avail, dest.size - start_dest)
+    else:
+        num_elems = min(num_elems, n_src_avail, dest.size - start_dest)
+    idx = np.nonzero(select_dest[start_dest:] == 1.0)[0][:num_elems] + start_dest
+    dest[idx] = src[start_src:start_src + idx.size]
+
+
+def component_div_w_pattern(y, x, select):             # :580
+    with np.errstate(divide="ignore", invalid="ignore"):
+        y[:] = np.where(select == 0.0, 0.0, y / x)
+
+
+def component_sgn(y):                                  # :639
+    y[:] = (0.0 < y).astype(np.float64) - (y < 0.0).astype(np.float64)
+
+
+def axzpy(y, alpha, x, z):                             # :710
+    if alpha == 1.0:
+        y += x * z
+    elif alpha == -1.0:
+        y -= x * z
+    elif alpha != 0.0:
+        y += alpha * x * z
+
+
+def axdzpy(y, alpha, x, z):                            # :736
+    if alpha == 0.0:
+        return
+    if alpha == 1.0:
+        y += x / z
+    elif alpha == -1.0:
+        y -= x / z
+    else:
+        y += x / z * alpha
+
+
+def axdzpy_w_pattern(y, alpha, x, z, select):          # :767
+    m = select == 1.0
+    if alpha == 1.0:
+        y[m] += x[m] / z[m]
+    elif alpha == -1.0:
+        y[m] -= x[m] / z[m]
+    else:
+        y[m] += alpha * x[m] / z[m]
+
+
+def add_log_barrier_grad(y, alpha, x, select):         # :893
+    m = select == 1.0
+    y[m] += alpha / x[m]
+
+
+def add_linear_damping_term(y, ixl, ixr, alpha, ct):   # :927
+    y[:] = alpha * y + (ixl - ixr) * ct
+
+
+def adjust_duals_plh(z, x, select, mu, kappa):         # :1117
+    m = select == 1.0
+    a = mu / x[m]
+    b = a / kappa
+    a = a * kappa
+    zi = z[m].copy()
+    out = zi.copy()
+    c1 = zi < b
+    out[c1] = b[c1]
+    c2 = (~c1) & (a <= b)
+    out[c2] = b[c2]
+    c3 = (~c1) & (~c2) & (a < zi)
+    out[c3] = a[c3]
+    z[m] = out
+
+
+def project_into_bounds(x0, xl, ixl, xu, ixu, kappa1, kappa2):   # :964
+    small = np.finfo(np.float64).tiny * 100
+    both = (ixl != 0) & (ixu != 0)
+    if np.any(both & (xl > xu)):
+        return False
+    aux = kappa2 * (xu - xl) - small
+    lo = xl + np.minimum(kappa1 * np.maximum(1.0, np.abs(xl)), aux)
+    hi = xu - np.minimum(kappa1 * np.maximum(1.0, np.abs(xu)), aux)
+    v = x0.copy()
+    c_lo = both & (v < lo)
+    c_hi = both & ~c_lo & (v > hi)
+    v[c_lo] = lo[c_lo]
+    v[c_hi] = hi[c_hi]
+    only_l = (~both) & (ixl != 0)
+    v[only_l] = np.maximum(v[only_l], xl[only_l] + kappa1 * np.maximum(1.0, np.abs(xl[only_l])) - small)
+    only_u = (~both) & (ixl == 0) & (ixu != 0)
+    v[only_u] = np.minimum(v[only_u], xu[only_u] - kappa1 * np.maximum(1.0, np.abs(xu[only_u])) - small)
+    x0[:] = v
+    return True
+
+
+# ---- reductions ----
+def infnorm(x):                                        # :501
+    return float(np.max(np.abs(x))) if x.size else 0.0
+
+
+def onenorm(x):                                        # :540
+    return float(np.sum(np.abs(x)))
+
+
+def vmin_w_pattern(x, select):                         # :821
+    m = select == 1.0
+    return float(np.min(x[m])) if np.any(m) else float(np.finfo(np.float64).max)
+
+
+def log_barrier(x, select):                            # :863 (Kahan-compensated in the reference)
+    m = select == 1.0
+    return float(np.sum(np.log(x[m].astype(np.longdouble))))
+
+
+def linear_damping_term(x, ixl, ixr, mu, kappa_d):     # :907
+    m = (ixl == 1.0) & (ixr == 0.0)
+    return float(np.sum(x[m])) * mu * kappa_d
+
+
+def fraction_to_the_bdry(x, d, tau):                   # :1017
+    m = d < 0
+    if not np.any(m):
+        return 1.0
+    return float(min(1.0, np.min(-tau * x[m] / d[m])))
+
+
+def fraction_to_the_bdry_w_pattern(x, d, tau, select):  # :1038
+    m = (d < 0) & (select != 0)
+    if not np.any(m):
+        return 1.0
+    return float(min(1.0, np.min(-tau * x[m] / d[m])))
+
+
+def all_positive_w_pattern(x, select):                 # :1095
+    return int(not np.any((select != 0.0) & (x <= 0.0)))
+
+
+def matches_pattern(x, select):                        # :1073
+    return int(not np.any((select == 0.0) & (x != 0.0)))
+
+
+# =====================================================================================
+# hiopMatrixDenseRowMajor (reference: src/LinAlg/hiopMatrixDenseRowMajor.cpp)
+# =====================================================================================
+def times_vec(A, beta, y, alpha, x):                   # :458
+    y[:] = (0.0 if beta == 0.0 else beta * y) + alpha * (A @ x)
+
+
+def trans_times_vec(A, beta, y, alpha, x):             # :510
+    y[:] = (0.0 if beta == 0.0 else beta * y) + alpha * (A.T @ x)
+
+
+def add_sub_diagonal(A, start, alpha, d, src_start=0, num=-1):      # :719,735
+    if num < 0:
+        num = d.size - src_start
+    num = min(num, A.shape[0] - start)
+    idx = np.arange(num) + start
+    A[idx, idx] += alpha * d[src_start:src_start + num]
+
+
+def trans_add_to_sym_upper(A, row_start, col_start, alpha, W):      # :779
+    m, n = A.shape
+    W[row_start:row_start + n, col_start:col_start + m] += alpha * A.T
+
+
+def add_upper_to_sym_upper(A, diag_start, alpha, W):                # :810
+    n = A.shape[0]
+    W[diag_start:diag_start + n, diag_start:diag_start + n] += alpha * np.triu(A)
+
+
+def shift_rows(A, shift):                              # :238
+    m = A.shape[0]
+    if shift == 0 or abs(shift) == m or m <= 1:
+        return
+    if shift < 0:
+        A[:m + shift, :] = A[-shift:, :].copy()
+    else:
+        A[shift:, :] = A[:m - shift, :].copy()
+
+
+# =====================================================================================
+# hiopMatrixSparseTriplet (reference: src/LinAlg/hiopMatrixSparseTriplet.cpp)
+# COO, row-sorted, int32 indices
+# =====================================================================================
+def sp_times_vec(nrows, iRow, jCol, val, beta, y, alpha, x):        # :73
+    y *= beta
+    np.add.at(y, iRow, alpha * x[jCol] * val)
+
+
+def sp_trans_times_vec(ncols, iRow, jCol, val, beta, y, alpha, x):  # :110
+    y *= beta
+    np.add.at(y, jCol, alpha * x[iRow] * val)
+
+
+def _to_dense(nrows, ncols, iRow, jCol, val):
+    M = np.zeros((nrows, ncols))
+    np.add.at(M, (iRow, jCol), val)
+    return M
+
+
+def sp_add_MDinvMtrans_diag_block(m, ncols, iRow, jCol, val, start, alpha, D, W):   # :390
+    """W[start+i, start+j] += alpha * sum_c M[i,c] M[j,c] / D[c], j >= i (upper triangle only)."""
+    import scipy.sparse as sp
+    M = sp.csr_matrix((val, (iRow, jCol)), shape=(m, ncols))
+    S = (M @ sp.diags(1.0 / D) @ M.T).toarray()
+    W[start:start + m, start:start + m] += alpha * np.triu(S)
+
+
+def sp_add_MDinvNtrans(m1, m2, ncols, i1, j1, v1, i2, j2, v2, row_start, col_start, alpha, D, W):   # :447
+    import scipy.sparse as sp
+    M1 = sp.csr_matrix((v1, (i1, j1)), shape=(m1, ncols))
+    M2 = sp.csr_matrix((v2, (i2, j2)), shape=(m2, ncols))
+    S = (M1 @ sp.diags(1.0 / D) @ M2.T).toarray()
+    W[row_start:row_start + m1, col_start:col_start + m2] += alpha * S
+
+
+def sp_add_MDinvMtrans_rowmerge(m, iRow, jCol, val, start, alpha, D, W):
+    """Literal restatement of the reference's sorted-merge double loop (:406-437); small cases only."""
+    rs = np.searchsorted(iRow, np.arange(m + 1))
+    for i in range(m):
+        acc = 0.0
+        for k in range(rs[i], rs[i + 1]):
+            acc += val[k] / D[jCol[k]] * val[k]
+        W[i + start, i + start] += alpha * acc
+        for j in range(i + 1, m):
+            acc = 0.0
+            ki, kj = rs[i], rs[j]
+            while ki < rs[i + 1] and kj < rs[j + 1]:
+                if jCol[ki] == jCol[kj]:
+                    acc += val[ki] / D[jCol[ki]] * val[kj]
+                    ki += 1
+                    kj += 1
+                elif jCol[ki] < jCol[kj]:
+                    ki += 1
+                else:
+                    kj += 1
+            W[i + start, j + start] += alpha * acc
+
+
+def spsym_add_diag_to_vec(iRow, jCol, val, alpha, y, vec_start, diag_src_start=0, num_elems=-1):    # :1018
+    if num_elems < 0:
+        num_elems = y.size
+    m = (iRow == jCol) & (iRow >= diag_src_start) & (iRow < diag_src_start + num_elems)
+    np.add.at(y, vec_start + iRow[m], alpha * val[m])
+
+
+# =====================================================================================
+# hiopLinSolverSymDenseLapack (reference: src/LinAlg/hiopLinSolverSymDenseLapack.hpp:75-195)
+# =====================================================================================
+class LinSolverSymDenseLapack:
+    """M holds the UPPER triangle, row-major (= LAPACK column-major lower, uplo='L')."""
+
+    def __init__(self, n):
+        self.n = n
+        self.M = np.zeros((n, n))
+        self.ldu = None
+        self.ipiv = None
+
+    def matrix_changed(self):
+        n = self.n
+        if n == 0:
+            return 0
+        # row-major upper == Fortran lower of the transposed view
+        a = np.asfortranarray(self.M.T)
+        ldu, ipiv, info = lapack.dsytrf(a, lower=1)
+        if info != 0:
+            return -1
+        self.ldu, self.ipiv = ldu, ipiv
+        # inertia, LINPACK dsidi style (:127-167); scipy returns 1-based LAPACK ipiv (negative = 2x2 block)
+        neg = null = 0
+        t = 0.0
+        MM = ldu.T  # MM[k, k+1] is the sub-diagonal entry of the 2x2 block in the C view
+        for k in range(n):
+            d = MM[k, k]
+            if ipiv[k] <= 0:
+                if t == 0.0:
+                    if k + 1 < n:
+                        t = abs(MM[k, k + 1])
+                        d = (d / t) * MM[k + 1, k + 1] - t
+                else:
+                    d = t
+                    t = 0.0
+            if d < -1e-14:
+                neg += 1
+            elif d < 1e-14:
+                null += 1
+        if null > 0:
+            return -1
+        return neg
+
+    def solve(self, rhs):
+        if self.n == 0:
+            return True
+        x, info = lapack.dsytrs(self.ldu, self.ipiv, rhs, lower=1)
+        rhs[:] = x
+        return info == 0
+
+
+def ldlt_nopiv(M_upper):
+    """Reference semantics of the no-pivot GPU solver (MAGMA dsytrf_nopiv, hiopLinSolverSymDenseMagma.cpp:349):
+    A = U^T D U; returns (U unit upper, d).  Plain loops; small cases only."""
+    n = M_upper.shape[0]
+    A = np.triu(M_upper).copy()
+    d = np.zeros(n)
+    for k in range(n):
+        d[k] = A[k, k]
+        if k + 1 < n:
+            v = A[k, k + 1:].copy()
+            u = v / d[k]
+            A[k + 1:, k + 1:] -= np.triu(np.outer(v, u))
+            A[k, k + 1:] = u
+    U = np.triu(A, 1) + np.eye(n)
+    return U, d
+
+
+# =====================================================================================
+# hiopKKTLinSysCompressedMDSXYcYd (reference: src/Optimization/hiopKKTLinSysMDS.cpp)
+# =====================================================================================
+class KKTLinSysCompressedMDSXYcYd:
+    def __init__(self, nxs, nxd, neq, nineq, Jcs, Jds, Hss):
+        """Jcs/Jds/Hss: (iRow, jCol) int32 index pairs (row-sorted COO)."""
+        self.nxs, self.nxd, self.neq, self.nineq = nxs, nxd, neq, nineq
+        self.Jcs_ij, self.Jds_ij, self.Hss_ij = Jcs, Jds, Hss
+        self.linsys = LinSolverSymDenseLapack(nxd + neq + nineq)
+
+    def set_values(self, Jcs_val, Jds_val, Hss_val, Jcd, Jdd, Hdd, Dx, Dd):
+        self.Jcs_val, self.Jds_val, self.Hss_val = Jcs_val, Jds_val, Hss_val
+        self.Jcd, self.Jdd, self.Hdd, self.Dx, self.Dd = Jcd, Jdd, Hdd, Dx, Dd
+
+    def build_kkt_matrix(self, delta_wx, delta_wd, delta_cc, delta_cd):       # :172-305
+        nxs, nxd, neq, nineq = self.nxs, self.nxd, self.neq, self.nineq
+        M = self.linsys.M
+        M[:] = 0.0                                                           # :196
+        add_upper_to_sym_upper(self.Hdd, 0, 1.0, M)                          # :204
+        trans_add_to_sym_upper(self.Jcd, 0, nxd, 1.0, M)                     # :205
+        trans_add_to_sym_upper(self.Jdd, 0, nxd + neq, 1.0, M)               # :206
+        add_sub_diagonal(M, 0, 1.0, self.Dx, nxs, nxd)                       # :213
+        idx = np.arange(nxd)
+        M[idx, idx] += delta_wx                                              # :215
+        Hxs = self.Dx[:nxs] + delta_wx                                       # :223-227
+        spsym_add_diag_to_vec(self.Hss_ij[0], self.Hss_ij[1], self.Hss_val, 1.0, Hxs, 0)   # :231
+        self.Hxs = Hxs
+        ci, cj = self.Jcs_ij
+        di, dj = self.Jds_ij
+        sp_add_MDinvMtrans_diag_block(neq, nxs, ci, cj, self.Jcs_val, nxd, -1.0, Hxs, M)   # :239
+        idx = np.arange(neq) + nxd
+        M[idx, idx] += -delta_cc                                             # :245
+        sp_add_MDinvMtrans_diag_block(nineq, nxs, di, dj, self.Jds_val, nxd + neq, -1.0, Hxs, M)   # :267
+        sp_add_MDinvNtrans(neq, nineq, nxs, ci, cj, self.Jcs_val, di, dj, self.Jds_val, nxd, nxd + neq, -1.0, Hxs, M)  # :275
+        self.Dd_inv = 1.0 / (delta_wd + self.Dd)                             # :280-286
+        idx = np.arange(nineq) + nxd + neq
+        M[idx, idx] += -self.Dd_inv                                          # :289
+        M[idx, idx] += -delta_cd                                             # :290
+        return M
+
+    def factorize_with_curv_check(self):                                     # :78-110
+        n_neg = self.linsys.matrix_changed()
+        if n_neg >= 0:
+            n_neg_xs = int(np.sum(self.Hxs < -1e-14))
+            n_zero_xs = int(np.sum(np.abs(self.Hxs) < 1e-14))
+            if n_zero_xs > 0:
+                return -1
+            n_neg += n_neg_xs
+        return n_neg
+
+    def solve_compressed(self, rx, ryc, ryd):                                # :307-403
+        nxs, nxd, neq, nineq = self.nxs, self.nxd, self.neq, self.nineq
+        ci, cj = self.Jcs_ij
+        di, dj = self.Jds_ij
+        rxs = rx[:nxs] / self.Hxs                                            # :337-338
+        dyc = ryc.copy()
+        sp_times_vec(neq, ci, cj, self.Jcs_val, 1.0, dyc, -1.0, rxs)         # :344
+        ryd = ryd.copy()
+        sp_times_vec(nineq, di, dj, self.Jds_val, 1.0, ryd, -1.0, rxs)       # :347
+        rhs = np.concatenate([rx[nxs:], dyc, ryd])                           # :353-357
+        self.last_rhs = rhs.copy()
+        ok = self.linsys.solve(rhs)                                          # :367
+        dx = np.empty(nxs + nxd)
+        dx[nxs:] = rhs[:nxd]                                                 # :383
+        dyc = rhs[nxd:nxd + neq].copy()
+        dyd = rhs[nxd + neq:].copy()
+        dxs = rx[:nxs].copy()                                                # :390
+        sp_trans_times_vec(nxs, ci, cj, self.Jcs_val, 1.0, dxs, -1.0, dyc)   # :391
+        sp_trans_times_vec(nxs, di, dj, self.Jds_val, 1.0, dxs, -1.0, dyd)   # :392
+        dx[:nxs] = dxs / self.Hxs                                            # :393
+        return ok, dx, dyc, dyd
+
+
+def kkt_mds_full_residual(k: KKTLinSysCompressedMDSXYcYd, deltas, rx, ryc, ryd, dx, dyc, dyd):
+    """Residual of the UNcondensed XYcYd system
+        [H+Dx+dwx  Jc^T  Jd^T ] [dx ]   [rx ]
+        [Jc       -dcc   0    ] [dyc] = [ryc]
+        [Jd        0  -(Dd+dwd)^-1-dcd] [dyd]   [ryd]
+    (reference: the HIOP_DEEPCHECKS errorCompressedLinsys, hiopKKTLinSys.cpp:695-740).  Returns the
+    inf-norms of the three block residuals relative to the rhs."""
+    dwx, dwd, dcc, dcd = deltas
+    nxs, nxd, neq, nineq = k.nxs, k.nxd, k.neq, k.nineq
+    import scipy.sparse as sp
+    Jcs = sp.csr_matrix((k.Jcs_val, k.Jcs_ij), shape=(neq, nxs))
+    Jds = sp.csr_matrix((k.Jds_val, k.Jds_ij), shape=(nineq, nxs))
+    Hs_diag = np.zeros(nxs)
+    spsym_add_diag_to_vec(k.Hss_ij[0], k.Hss_ij[1], k.Hss_val, 1.0, Hs_diag, 0)
+    Hd = np.triu(k.Hdd) + np.triu(k.Hdd, 1).T
+    dxs, dxd = dx[:nxs], dx[nxs:]
+    r1s = (Hs_diag + k.Dx[:nxs] + dwx) * dxs + Jcs.T @ dyc + Jds.T @ dyd - rx[:nxs]
+    r1d = Hd @ dxd + (k.Dx[nxs:] + dwx) * dxd + k.Jcd.T @ dyc + k.Jdd.T @ dyd - rx[nxs:]
+    r2 = Jcs @ dxs + k.Jcd @ dxd - dcc * dyc - ryc
+    r3 = Jds @ dxs + k.Jdd @ dxd - (1.0 / (k.Dd + dwd) + dcd) * dyd - ryd
+    scale = max(1.0, infnorm(rx), infnorm(ryc), infnorm(ryd))
+    return max(infnorm(r1s), infnorm(r1d)) / scale, infnorm(r2) / scale, infnorm(r3) / scale

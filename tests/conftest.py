@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from hiop_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()

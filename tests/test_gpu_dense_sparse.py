@@ -1,0 +1,267 @@
+"""GPU parity of the hiopMatrixDense / hiopMatrixSparseTriplet kernels against the numpy oracle.
+Mirrors tests/LinAlg/matrixTestsDense.hpp / matrixTestsSparse.hpp of the reference (one test per method),
+with the reference's driver sizes (tests/testMatrixDense.cpp:168-170: M=50, K=100, N=500) plus ragged
+and tall-skinny shapes of the KKT hot path.  fp64 tolerance: rtol 1e-12 on GEMV/GEMM-like sums."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hiop_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def D(a, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def run(ctx, name, *args):
+    torch.cuda.synchronize()
+    ctx.call(name, *args)
+    ctx.sync()
+
+
+SHAPES = [(1, 1), (4, 1000), (50, 500), (7, 2049), (100, 100003), (129, 257), (300, 300), (1000, 33)]
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+def test_times_vec_and_trans(ctx, m, n):
+    r = rng(m * 1000 + n)
+    A = r.uniform(-1, 1, (m, n))
+    x, y = r.uniform(-1, 1, n), r.uniform(-1, 1, m)
+    Ad = D(A)
+    for beta, alpha in ((0.0, 1.0), (1.0, -1.0), (0.5, 2.0)):
+        yd = D(y)
+        run(ctx, "hiopamd_mat_times_vec", m, n, Ad, n, beta, yd, alpha, D(x))
+        e = y.copy(); ho.times_vec(A, beta, e, alpha, x)
+        np.testing.assert_allclose(yd.cpu().numpy(), e, rtol=1e-12, atol=1e-12)
+        xd = D(x)
+        run(ctx, "hiopamd_mat_trans_times_vec", m, n, Ad, n, beta, xd, alpha, D(y))
+        e = x.copy(); ho.trans_times_vec(A, beta, e, alpha, y)
+        np.testing.assert_allclose(xd.cpu().numpy(), e, rtol=1e-12, atol=1e-12)
+
+
+def test_times_vec_beta_zero_ignores_nan_in_y(ctx):
+    A = rng(1).uniform(-1, 1, (5, 300)); x = rng(2).uniform(-1, 1, 300)
+    yd = D(np.full(5, np.nan))
+    run(ctx, "hiopamd_mat_times_vec", 5, 300, D(A), 300, 0.0, yd, 1.0, D(x))
+    np.testing.assert_allclose(yd.cpu().numpy(), A @ x, rtol=1e-12)
+
+
+def test_leading_dimension(ctx):
+    big = rng(3).uniform(-1, 1, (20, 700))
+    A = big[:, 100:600]  # lda = 700, odd offset -> unaligned double2 path
+    Ad = D(big)
+    x = rng(4).uniform(-1, 1, 500); y = rng(5).uniform(-1, 1, 20)
+    torch.cuda.synchronize()
+    off = C.c_void_p(Ad.data_ptr() + 100 * 8)
+    yd = D(y)
+    ctx.call("hiopamd_mat_times_vec", 20, 500, off, 700, 0.0, yd, 1.0, D(x)); ctx.sync()
+    np.testing.assert_allclose(yd.cpu().numpy(), A @ x, rtol=1e-12)
+    off = C.c_void_p(Ad.data_ptr() + 101 * 8)
+    xd = D(x[:499])
+    ctx.call("hiopamd_mat_trans_times_vec", 20, 499, off, 700, 0.0, xd, 1.0, D(y)); ctx.sync()
+    np.testing.assert_allclose(xd.cpu().numpy(), big[:, 101:600].T @ y, rtol=1e-12)
+
+
+@pytest.mark.parametrize("m,n,k", [(50, 100, 500), (12, 12, 12), (3, 200, 7), (65, 33, 129)])
+def test_small_gemm_family(ctx, m, n, k):
+    r = rng(m + n + k)
+    A = r.uniform(-1, 1, (m, n)); X = r.uniform(-1, 1, (n, k)); W = r.uniform(-1, 1, (m, k))
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_times_mat", m, n, k, D(A), n, 0.5, Wd, k, 2.0, D(X), k)
+    np.testing.assert_allclose(Wd.cpu().numpy(), 0.5 * W + 2.0 * A @ X, rtol=1e-12, atol=1e-12)
+    X2 = r.uniform(-1, 1, (m, k)); W2 = r.uniform(-1, 1, (n, k))
+    Wd = D(W2)
+    run(ctx, "hiopamd_mat_trans_times_mat", m, n, k, D(A), n, 1.0, Wd, k, -1.0, D(X2), k)
+    np.testing.assert_allclose(Wd.cpu().numpy(), W2 - A.T @ X2, rtol=1e-12, atol=1e-12)
+    X3 = r.uniform(-1, 1, (k, n)); W3 = r.uniform(-1, 1, (m, k))
+    Wd = D(W3)
+    run(ctx, "hiopamd_mat_times_mat_trans", m, n, k, D(A), n, 0.0, Wd, k, 1.0, D(X3), n)
+    np.testing.assert_allclose(Wd.cpu().numpy(), A @ X3.T, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("ma,mb,n", [(4, 6, 5000), (100, 100, 70001), (130, 12, 9999), (200, 200, 20000), (6, 6, 33)])
+def test_gram_weighted_mfma(ctx, ma, mb, n):
+    """fp64-MFMA weighted Gram against numpy; asymmetric operands catch a transposed fragment layout."""
+    r = rng(ma * 7 + mb)
+    A = r.uniform(-1, 1, (ma, n)); B = r.uniform(-1, 1, (mb, n)); d = r.uniform(0.1, 2.0, n)
+    W = r.uniform(-1, 1, (ma, mb))
+    Wd = D(W)
+    run(ctx, "hiopamd_gram_weighted", ma, mb, n, D(A), n, D(B), n, D(d), 0.5, Wd, mb, 2.0, 0)
+    e = 0.5 * W + 2.0 * (A * d) @ B.T
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-11, atol=1e-10)
+    Wd = D(W)
+    run(ctx, "hiopamd_gram_weighted", ma, mb, n, D(A), n, D(B), n, None, 0.0, Wd, mb, 1.0, 0)
+    np.testing.assert_allclose(Wd.cpu().numpy(), A @ B.T, rtol=1e-11, atol=1e-10)
+    if ma == mb:
+        Ad = D(A)
+        W0 = r.uniform(-1, 1, (ma, ma))
+        Wd = D(W0)
+        run(ctx, "hiopamd_gram_weighted", ma, ma, n, Ad, n, Ad, n, D(d), 1.0, Wd, ma, -1.0, 1)
+        e = W0 - np.triu((A * d) @ A.T)   # lower triangle untouched (reference :1079 semantics)
+        got = Wd.cpu().numpy()
+        np.testing.assert_allclose(np.triu(got), np.triu(e), rtol=1e-11, atol=1e-10)
+        np.testing.assert_array_equal(np.tril(got, -1), np.tril(W0, -1))
+
+
+def test_assembly_kernels(ctx):
+    r = rng(99)
+    nW = 301
+    W = r.uniform(-1, 1, (nW, nW))
+    A = r.uniform(-1, 1, (37, 70))       # m x n, goes transposed into W rows [10,80) cols [100,137)
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_trans_add_to_sym_upper", 37, 70, D(A), 70, 10, 100, 0.5, Wd, nW)
+    e = W.copy(); ho.trans_add_to_sym_upper(A, 10, 100, 0.5, e)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    H = r.uniform(-1, 1, (90, 90))
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_add_upper_to_sym_upper", 90, D(H), 90, 5, -2.0, Wd, nW)
+    e = W.copy(); ho.add_upper_to_sym_upper(H, 5, -2.0, e)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    d = r.uniform(-1, 1, 200)
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_add_sub_diagonal", Wd, nW, 7, 0.25, D(d), 13, 50)
+    e = W.copy(); ho.add_sub_diagonal(e, 7, 0.25, d, 13, 50)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_add_sub_diagonal_const", Wd, nW, 3, 20, 1.5)
+    e = W.copy(); e[np.arange(3, 23), np.arange(3, 23)] += 1.5
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_add_diagonal_vec", nW, Wd, nW, 2.0, D(r.uniform(-1, 1, nW) * 0 + 1))
+    e = W.copy(); e[np.arange(nW), np.arange(nW)] += 2.0
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    X = r.uniform(-1, 1, (nW, nW))
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_add_matrix", nW, nW, Wd, nW, 0.3, D(X), nW)
+    np.testing.assert_allclose(Wd.cpu().numpy(), W + 0.3 * X, rtol=4e-16)
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_symmetrize", nW, Wd, nW)
+    e = np.triu(W) + np.triu(W, 1).T
+    np.testing.assert_array_equal(Wd.cpu().numpy(), e)
+    Wd = D(W)
+    run(ctx, "hiopamd_mat_set_to_constant", nW, nW, Wd, nW, 0.125)
+    assert torch.all(Wd == 0.125).item()
+
+
+def test_row_ops(ctx):
+    r = rng(5)
+    A = r.uniform(-1, 1, (12, 1000))
+    for shift in (1, -1, 3, -5):
+        Ad = D(A)
+        run(ctx, "hiopamd_mat_shift_rows", 12, 1000, Ad, 1000, shift)
+        e = A.copy(); ho.shift_rows(e, shift)
+        np.testing.assert_array_equal(Ad.cpu().numpy(), e)
+    src = r.uniform(-1, 1, (5, 1000))
+    Ad = D(A)
+    run(ctx, "hiopamd_mat_copy_rows_from", 5, 1000, Ad, 1000, 4, D(src), 1000)
+    e = A.copy(); e[4:9] = src
+    np.testing.assert_array_equal(Ad.cpu().numpy(), e)
+    idx = np.array([3, 0, 4], np.int32)
+    Ad = D(A)
+    run(ctx, "hiopamd_mat_copy_rows_from_idx", 3, 1000, Ad, 1000, D(src), 1000, D(idx, torch.int32))
+    e = A.copy(); e[:3] = src[idx]
+    np.testing.assert_array_equal(Ad.cpu().numpy(), e)
+    torch.cuda.synchronize()
+    assert ctx.reduce_double("hiopamd_mat_max_abs", 12, 1000, D(A), 1000) == np.abs(A).max()
+    assert ctx.reduce_int("hiopamd_mat_is_finite", 12, 1000, D(A), 1000) == 1
+    rm = D(np.zeros(12))
+    run(ctx, "hiopamd_mat_row_max_abs", 12, 1000, D(A), 1000, rm)
+    np.testing.assert_array_equal(rm.cpu().numpy(), np.abs(A).max(axis=1))
+    sc = r.uniform(0.5, 2, 12)
+    Ad = D(A)
+    run(ctx, "hiopamd_mat_scale_rows", 12, 1000, Ad, 1000, D(sc), 1)
+    np.testing.assert_allclose(Ad.cpu().numpy(), A * (1.0 / sc)[:, None], rtol=4e-16)
+
+
+def _rand_sparse(r, m, n, density):
+    M = (r.uniform(0, 1, (m, n)) < density) * r.uniform(0.5, 2.0, (m, n))
+    i, j = np.nonzero(M)   # row-major order == row-sorted, columns ascending
+    return i.astype(np.int32), j.astype(np.int32), M[i, j]
+
+
+@pytest.mark.parametrize("m,n,dens", [(1, 1, 1.0), (40, 80, 0.1), (300, 1000, 0.01), (5, 3000, 0.5), (64, 64, 0.0)])
+def test_sparse_spmv(ctx, m, n, dens):
+    r = rng(m + n)
+    i, j, v = _rand_sparse(r, m, n, dens)
+    x, y = r.uniform(-1, 1, n), r.uniform(-1, 1, m)
+    id_, jd, vd = D(i, torch.int32), D(j, torch.int32), D(v)
+    for beta, alpha in ((1.0, -1.0), (0.0, 1.0), (0.5, 2.0)):
+        yd = D(y)
+        run(ctx, "hiopamd_sp_times_vec", m, n, v.size, id_, jd, vd, beta, yd, alpha, D(x))
+        e = y.copy(); ho.sp_times_vec(m, i, j, v, beta, e, alpha, x)
+        np.testing.assert_allclose(yd.cpu().numpy(), e, rtol=1e-12, atol=1e-13)
+        xd = D(x)
+        run(ctx, "hiopamd_sp_trans_times_vec", m, n, v.size, id_, jd, vd, beta, xd, alpha, D(y))
+        e = x.copy(); ho.sp_trans_times_vec(n, i, j, v, beta, e, alpha, y)
+        np.testing.assert_allclose(xd.cpu().numpy(), e, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("m1,m2,n,dens", [(30, 30, 60, 0.15), (100, 7, 400, 0.05), (3, 3, 5000, 0.6), (50, 50, 50, 0.0)])
+def test_sparse_schur_rowbuild(ctx, m1, m2, n, dens):
+    """addMDinvMtransToDiagBlockOfSymDeMatUTri / addMDinvNtransToSymDeMatUTri vs the literal row-merge loop."""
+    from hiop_amd._lib import lib
+    L = lib()
+    r = rng(m1 * 31 + m2)
+    i1, j1, v1 = _rand_sparse(r, m1, n, dens)
+    i2, j2, v2 = _rand_sparse(r, m2, n, dens)
+    Dv = r.uniform(0.5, 3.0, n)
+    nW = m1 + m2 + 9
+    W = r.uniform(-1, 1, (nW, nW))
+    # same-matrix diagonal block (upper triangle only)
+    plan = C.c_void_p()
+    rc = L.hiopamd_sp_plan_create(C.byref(plan), m1, m1, n, v1.size, i1.ctypes.data, j1.ctypes.data, v1.size,
+                                  i1.ctypes.data, j1.ctypes.data, 1)
+    assert rc == 0
+    Wd = D(W)
+    v1d, Dd = D(v1), D(Dv)
+    run(ctx, "hiopamd_sp_add_MDinvNt", plan, v1d, v1d, Dd, -1.0, Wd, nW, 4, 4)
+    e = W.copy(); ho.sp_add_MDinvMtrans_rowmerge(m1, i1, j1, v1, 4, -1.0, Dv, e)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-13, atol=1e-14)
+    L.hiopamd_sp_plan_destroy(plan)
+    # two-matrix off-diagonal block
+    rc = L.hiopamd_sp_plan_create(C.byref(plan), m1, m2, n, v1.size, i1.ctypes.data, j1.ctypes.data, v2.size,
+                                  i2.ctypes.data, j2.ctypes.data, 0)
+    assert rc == 0
+    Wd = D(W)
+    run(ctx, "hiopamd_sp_add_MDinvNt", plan, v1d, D(v2), Dd, 0.5, Wd, nW, 2, 5 + m1)
+    e = W.copy(); ho.sp_add_MDinvNtrans(m1, m2, n, i1, j1, v1, i2, j2, v2, 2, 5 + m1, 0.5, Dv, e)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-13, atol=1e-14)
+    L.hiopamd_sp_plan_destroy(plan)
+
+
+def test_sparse_plan_rejects_unsorted_rows():
+    from hiop_amd._lib import lib
+    L = lib()
+    i = np.array([1, 0], np.int32); j = np.array([0, 0], np.int32)
+    plan = C.c_void_p()
+    rc = L.hiopamd_sp_plan_create(C.byref(plan), 2, 2, 1, 2, i.ctypes.data, j.ctypes.data, 2, i.ctypes.data,
+                                  j.ctypes.data, 0)
+    assert rc == -2
+
+
+def test_symsparse_diag_ops(ctx):
+    r = rng(8)
+    n = 500
+    i = np.arange(n, dtype=np.int32); j = i.copy()
+    # add a few off-diagonal upper entries
+    i = np.concatenate([i, np.array([0, 3, 10], np.int32)]); j = np.concatenate([j, np.array([5, 9, 499], np.int32)])
+    o = np.lexsort((j, i)); i, j = i[o], j[o]
+    v = r.uniform(-1, 1, i.size)
+    y = r.uniform(-1, 1, n)
+    yd = D(y)
+    run(ctx, "hiopamd_spsym_add_diag_to_vec", v.size, D(i, torch.int32), D(j, torch.int32), D(v), 0.5, yd, 0, n, 0, n)
+    e = y.copy(); ho.spsym_add_diag_to_vec(i, j, v, 0.5, e, 0)
+    np.testing.assert_allclose(yd.cpu().numpy(), e, rtol=1e-15)
+    W = r.uniform(-1, 1, (n + 3, n + 3))
+    Wd = D(W)
+    run(ctx, "hiopamd_spsym_add_upper_to_sym_upper", v.size, D(i, torch.int32), D(j, torch.int32), D(v), 2, -1.0, Wd, n + 3)
+    e = W.copy(); np.add.at(e, (i + 2, j + 2), -v)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)

@@ -1,0 +1,227 @@
+"""GPU parity of the hiopLinSolverSymDense operator (blocked no-pivot LDL^T on fp64 MFMA) and of the
+condensed MDS KKT (assemble -> factor+inertia -> solveCompressed) against the oracle (LAPACK
+Bunch-Kaufman path of the reference) and the reference's own `write_kkt` dumps.
+
+Tolerances (fp64): factors vs the unblocked no-pivot recurrence rtol 1e-9 (conditioning of the
+quasi-definite test matrices ~1e4); solutions: relative KKT residual <= 1e-10 and agreement with the
+LAPACK solution <= 1e-8 relative; inertia exact."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hiop_oracle as ho
+from oracle import problems as pr
+from oracle.iajaaa import read_iajaaa
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def D(a, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def quasi_definite(n1, n2, seed):
+    """[[H, J^T],[J, -C]] with H, C SPD: every symmetric permutation has an LDL^T (Vanderbei)."""
+    r = rng(seed)
+    n = n1 + n2
+    G = r.uniform(-1, 1, (n1, n1)); H = G @ G.T / n1 + np.eye(n1) * 2.0
+    J = r.uniform(-1, 1, (n2, n1))
+    Cm = np.diag(r.uniform(0.5, 2.0, n2))
+    A = np.zeros((n, n))
+    A[:n1, :n1] = H; A[n1:, :n1] = J; A[:n1, n1:] = J.T; A[n1:, n1:] = -Cm
+    return A
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 0), (3, 2), (40, 24), (64, 1), (65, 64), (100, 157), (300, 203), (700, 324)])
+def test_ldlt_factor_matches_unblocked_recurrence(ctx, n1, n2):
+    from hiop_amd.kkt import LinSolverSymDense
+    A = quasi_definite(n1, n2, n1 * 13 + n2)
+    n = n1 + n2
+    ls = LinSolverSymDense(ctx, n)
+    Mu = np.triu(A) + np.tril(rng(1).uniform(5, 6, (n, n)), -1)  # garbage below the diagonal must be ignored
+    ls.set_sys_matrix(D(Mu))
+    nneg = ls.matrix_changed()
+    assert nneg == n2
+    assert ls.inertia() == (n1, n2, 0)
+    F = ls.get_sys_matrix().cpu().numpy()
+    U, d = ho.ldlt_nopiv(A)
+    np.testing.assert_allclose(np.diag(F), d, rtol=1e-9)
+    np.testing.assert_allclose(np.triu(F, 1), np.triu(U, 1), rtol=1e-8, atol=1e-11)
+    # lower triangle untouched
+    np.testing.assert_array_equal(np.tril(F, -1), np.tril(Mu, -1))
+    # solves
+    r = rng(2)
+    for nrhs in (1, 3):
+        B = r.uniform(-1, 1, (nrhs, n))
+        Bd = D(B)
+        torch.cuda.synchronize()
+        ls.solve(Bd, nrhs)
+        ctx.sync()
+        X = Bd.cpu().numpy()
+        for q in range(nrhs):
+            res = np.abs(A @ X[q] - B[q]).max() / (np.abs(A).max() * np.abs(X[q]).max())
+            assert res < 1e-12
+    ls.close()
+
+
+def test_ldlt_full_size_property(ctx):
+    """N=8192 (BASELINE config 3 size): residual + inertia properties, no O(N^3) host work."""
+    from hiop_amd.kkt import LinSolverSymDense
+    n1, n2 = 4096, 4096
+    n = n1 + n2
+    g = torch.Generator(device="cuda"); g.manual_seed(1234)
+    J = torch.rand((n2, n1), generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    Hd = torch.rand(n1, generator=g, device="cuda", dtype=torch.float64) + 50.0
+    Hoff = (torch.rand((n1, n1), generator=g, device="cuda", dtype=torch.float64) - 0.5) * 0.01
+    A = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    A[:n1, :n1] = torch.diag(Hd) + (Hoff + Hoff.T)
+    A[:n1, n1:] = J.T
+    A[n1:, :n1] = J
+    A[n1:, n1:] = -torch.diag(torch.rand(n2, generator=g, device="cuda", dtype=torch.float64) + 0.5)
+    ls = LinSolverSymDense(ctx, n)
+    ls.set_sys_matrix(torch.triu(A))
+    nneg = ls.matrix_changed()
+    assert nneg == n2 and ls.inertia() == (n1, n2, 0)
+    b = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    x = b.clone()
+    torch.cuda.synchronize()
+    ls.solve(x, 1); ctx.sync()
+    res = (A @ x - b).abs().max().item() / (A.abs().max().item() * x.abs().max().item())
+    assert res < 1e-11
+    ls.close()
+
+
+def test_singular_matrix_returns_minus_one(ctx):
+    from hiop_amd.kkt import LinSolverSymDense
+    n = 70
+    A = quasi_definite(50, 20, 5)
+    A[10, :] = 0; A[:, 10] = 0      # exactly zero pivot in no-pivot elimination order -> 'singular' (-1)
+    ls = LinSolverSymDense(ctx, n)
+    ls.set_sys_matrix(D(np.triu(A)))
+    assert ls.matrix_changed() == -1
+    # solve before a successful factorisation is a call-sequence error, not a silent garbage solve
+    from hiop_amd import HiopAmdError
+    with pytest.raises(HiopAmdError):
+        ls.solve(D(np.ones(n)), 1)
+    ls.close()
+
+
+@pytest.mark.parametrize("it", [0, 5, 10])
+def test_golden_reference_kkt_systems(ctx, it):
+    """(matrix, rhs) -> solution triples written by the reference's LAPACK path (`write_kkt yes`)."""
+    from hiop_amd.kkt import LinSolverSymDense
+    g = read_iajaaa(GOLD / f"kkt_linsys_{it}.iajaaa")
+    n = g["n"]
+    ls = LinSolverSymDense(ctx, n)
+    ls.set_sys_matrix(D(g["M_upper"]))
+    assert ls.matrix_changed() == g["neq"] + g["nineq"]
+    for rhs, sol in g["pairs"]:
+        x = D(rhs)
+        torch.cuda.synchronize()
+        ls.solve(x, 1); ctx.sync()
+        np.testing.assert_allclose(x.cpu().numpy(), sol, rtol=1e-9, atol=1e-9 * np.abs(sol).max())
+    ls.close()
+
+
+def _kkt_pair(ctx, p, seed=3):
+    from hiop_amd.kkt import mds_from_problem
+    Dx, Dd = pr.barrier_diagonals(p, seed=seed)
+    ko = ho.KKTLinSysCompressedMDSXYcYd(p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j),
+                                        (p.Hss_i, p.Hss_j))
+    ko.set_values(p.Jcs_v, p.Jds_v, p.Hss_v, p.Jcd, p.Jdd, p.Hdd, Dx, Dd)
+    kg, dv = mds_from_problem(ctx, p)
+    dv["Dx"], dv["Dd"] = D(Dx), D(Dd)
+    kg.set_values(dv["Jcs_v"], dv["Jds_v"], dv["Hss_v"], dv["Jcd"], dv["Jdd"], dv["Hdd"], dv["Dx"], dv["Dd"])
+    return ko, kg, dv
+
+
+PROBLEMS = [
+    lambda: pr.mds_ex1(4, 4),
+    lambda: pr.mds_ex1(40, 12),
+    lambda: pr.mds_ex1(40, 12, empty_sp_row=True),
+    lambda: pr.mds_ex1(400, 100),
+    lambda: pr.mds_ex1_g(600, 130, 257),
+]
+
+
+@pytest.mark.parametrize("mk", PROBLEMS)
+@pytest.mark.parametrize("deltas", [(0.0, 0.0, 0.0, 0.0), (1e-4, 1e-4, 1e-8, 1e-8)])
+def test_kkt_mds_assemble_factor_solve(ctx, mk, deltas):
+    p = mk()
+    ko, kg, dv = _kkt_pair(ctx, p)
+    Mo = ko.build_kkt_matrix(*deltas).copy()
+    kg.build_kkt_matrix(*deltas)
+    Mg = kg.sys_matrix().cpu().numpy()
+    np.testing.assert_allclose(np.triu(Mg), np.triu(Mo), rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(kg.Hxs().cpu().numpy(), ko.Hxs, rtol=1e-15)
+    n_o = ko.factorize_with_curv_check()
+    n_g = kg.factorize_with_curv_check()
+    assert n_o == p.neq + p.nineq
+    assert n_g == n_o
+    rx, ryc, ryd = pr.random_rhs(p)
+    ok, dx_o, dyc_o, dyd_o = ko.solve_compressed(rx, ryc, ryd)
+    assert ok
+    dx, dyc, dyd = D(np.zeros_like(rx)), D(np.zeros_like(ryc)), D(np.zeros_like(ryd))
+    rxd, rycd, rydd = D(rx), D(ryc), D(ryd)
+    torch.cuda.synchronize()
+    kg.solve_compressed(rxd, rycd, rydd, dx, dyc, dyd)
+    ctx.sync()
+    dx, dyc, dyd = dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy()
+    # fp64 tolerance on the KKT residual of the UNcondensed system (north_star's parity statement)
+    res = ho.kkt_mds_full_residual(ko, deltas, rx, ryc, ryd, dx, dyc, dyd)
+    res_o = ho.kkt_mds_full_residual(ko, deltas, rx, ryc, ryd, dx_o, dyc_o, dyd_o)
+    assert max(res) < 1e-10, (res, res_o)
+    scale = max(np.abs(dx_o).max(), np.abs(dyc_o).max(), np.abs(dyd_o).max())
+    assert np.abs(dx - dx_o).max() / scale < 1e-8
+    assert np.abs(dyc - dyc_o).max() / scale < 1e-8
+    assert np.abs(dyd - dyd_o).max() / scale < 1e-8
+    # rx/ryc are inputs only (reference :341-343 keeps them intact)
+    np.testing.assert_array_equal(rxd.cpu().numpy(), rx)
+    np.testing.assert_array_equal(rycd.cpu().numpy(), ryc)
+    kg.close()
+
+
+def test_kkt_mds_inertia_correction_signal(ctx):
+    """A negative entry in Hxs (non-convex sparse block) must show up in the inertia count through
+    Haynsworth additivity (hiopKKTLinSysMDS.cpp:83-108); a zero entry must yield -1."""
+    p = pr.mds_ex1(40, 12)
+    ko, kg, dv = _kkt_pair(ctx, p)
+    Hneg = p.Hss_v.copy(); Hneg[3] = -5.0
+    dv["Hss_v2"] = D(Hneg)
+    kg.set_values(dv["Jcs_v"], dv["Jds_v"], dv["Hss_v2"], dv["Jcd"], dv["Jdd"], dv["Hdd"], dv["Dx"], dv["Dd"])
+    ko.set_values(p.Jcs_v, p.Jds_v, Hneg, p.Jcd, p.Jdd, p.Hdd, ko.Dx, ko.Dd)
+    ko.build_kkt_matrix(0, 0, 0, 0); kg.build_kkt_matrix(0, 0, 0, 0)
+    assert kg.factorize_with_curv_check() == ko.factorize_with_curv_check()
+    Hz = p.Hss_v.copy(); Hz[5] = -ko.Dx[5]
+    dv["Hss_v3"] = D(Hz)
+    kg.set_values(dv["Jcs_v"], dv["Jds_v"], dv["Hss_v3"], dv["Jcd"], dv["Jdd"], dv["Hdd"], dv["Dx"], dv["Dd"])
+    kg.build_kkt_matrix(0, 0, 0, 0)
+    assert kg.factorize_with_curv_check() == -1
+    kg.close()
+
+
+def test_kkt_mds_full_size_roundtrip(ctx):
+    """BASELINE config 3 (n_sparse=1e5, n_dense=4096, m=4096 -> N=8192): assemble -> factor -> solve, checked
+    by the size-independent property 'residual of the uncondensed KKT system' (sparse mat-vecs on host)."""
+    p = pr.mds_ex1_g(50000, 4096, 4093)
+    assert p.N == 8192 and p.nxs == 100000
+    ko, kg, dv = _kkt_pair(ctx, p)
+    deltas = (0.0, 0.0, 0.0, 0.0)
+    kg.build_kkt_matrix(*deltas)
+    assert kg.factorize_with_curv_check() == p.neq + p.nineq
+    rx, ryc, ryd = pr.random_rhs(p)
+    dx, dyc, dyd = D(np.zeros_like(rx)), D(np.zeros_like(ryc)), D(np.zeros_like(ryd))
+    rxd, rycd, rydd = D(rx), D(ryc), D(ryd)
+    torch.cuda.synchronize()
+    kg.solve_compressed(rxd, rycd, rydd, dx, dyc, dyd); ctx.sync()
+    res = ho.kkt_mds_full_residual(ko, deltas, rx, ryc, ryd, dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy())
+    assert max(res) < 1e-9, res
+    kg.close()
