@@ -459,3 +459,284 @@ def kkt_mds_full_residual(k: KKTLinSysCompressedMDSXYcYd, deltas, rx, ryc, ryd, 
     r3 = Jds @ dxs + k.Jdd @ dxd - (1.0 / (k.Dd + dwd) + dcd) * dyd - ryd
     scale = max(1.0, infnorm(rx), infnorm(ryc), infnorm(ryd))
     return max(infnorm(r1s), infnorm(r1d)) / scale, infnorm(r2) / scale, infnorm(r3) / scale
+
+
+# =====================================================================================
+# hiopHessianLowRank (reference: src/Optimization/hiopHessianLowRank.cpp) — compact L-BFGS,
+#   B = B0 + Dx - [B0 S, Y] (...)^-1 [...]^T ,  B0 = sigma I ;  inverse through the 2l x 2l matrix V.
+# `allreduce(buf)` sums a numpy buffer over the column partition in place (identity for one rank) —
+# the MPI_Allreduce call sites :459, :590-591.
+# =====================================================================================
+def _no_reduce(buf):
+    return buf
+
+
+def symm_mat_times_diag_times_mat_trans_local(beta, W, alpha, X, d):      # :1079  (writes BOTH triangles)
+    G = (X * d) @ X.T
+    Wn = beta * W + alpha * G
+    iu = np.triu_indices(W.shape[0])
+    W[iu] = Wn[iu]
+    W.T[iu] = Wn[iu]
+
+
+def mat_times_diag_times_mat_trans_local(W, S, d, X):                     # :1119
+    W[:, :] = (S * d) @ X.T
+
+
+class HessianLowRank:
+    """State and methods of hiopHessianLowRank for ONE rank's column slice [il, iu)."""
+
+    def __init__(self, n_local, l_max=6, sigma0=1.0, sigma_update_strategy="sigma0", rank=0, allreduce=_no_reduce):
+        self.n, self.l_max = n_local, l_max
+        self.sigma = self.sigma0 = sigma0
+        self.strategy = sigma_update_strategy
+        self.rank, self.allreduce = rank, allreduce
+        self.l_curr = -1
+        self.St = np.zeros((0, n_local))
+        self.Yt = np.zeros((0, n_local))
+        self.L = np.zeros((0, 0))
+        self.D = np.zeros(0)
+        self.DhInv = np.ones(n_local)
+        self.Dx = np.zeros(n_local)
+        self.matrix_changed = False
+        self.prev = None
+
+    # -- :197
+    def update_log_barrier_diagonal(self, Dx):
+        self.DhInv = 1.0 / (self.sigma + Dx)
+        self.Dx = Dx.copy()
+        self.matrix_changed = True
+
+    def _dot(self, a, b):
+        return float(self.allreduce(np.array([a @ b]))[0])
+
+    # -- :262  (x, grad_f, Jc, Jd, yc, yd are the CURRENT iterate's; returns True if a secant pair was stored)
+    def update(self, x, grad_f, Jc, Jd, yc, yd):
+        stored = False
+        if self.l_curr >= 0:
+            px, pg, pJc, pJd = self.prev
+            s_new = x - px
+            s_inf = float(self.allreduce_max(np.array([infnorm(s_new)]))[0]) if hasattr(self, "allreduce_max") else infnorm(s_new)
+            if s_inf >= 100 * np.finfo(np.float64).eps:
+                y_new = grad_f - pg
+                y_new += Jc.T @ yc - pJc.T @ yc + Jd.T @ yd - pJd.T @ yd
+                sTy = self._dot(s_new, y_new)
+                s_nrm2 = np.sqrt(self._dot(s_new, s_new))
+                y_nrm2 = np.sqrt(self._dot(y_new, y_new))
+                if sTy > s_nrm2 * y_nrm2 * np.sqrt(np.finfo(np.float64).eps):
+                    if self.l_max > 0:
+                        YTs = self.allreduce(self.Yt @ s_new) if self.Yt.shape[0] else np.zeros(0)
+                        l = self.l_curr
+                        if l < self.l_max:                       # growL / growD :779-823
+                            self.St = np.vstack([self.St, s_new])
+                            self.Yt = np.vstack([self.Yt, y_new])
+                            Ln = np.zeros((l + 1, l + 1))
+                            Ln[:l, :l] = self.L
+                            Ln[l, :l] = YTs
+                            self.L = Ln
+                            self.D = np.concatenate([self.D, [sTy]])
+                            self.l_curr += 1
+                        else:                                    # shift; updateL / updateD :828-867
+                            self.St = np.vstack([self.St[1:], s_new])
+                            self.Yt = np.vstack([self.Yt[1:], y_new])
+                            lm1 = l - 1
+                            Lm = self.L
+                            for i in range(1, lm1):
+                                for j in range(i):
+                                    Lm[i, j] = Lm[i + 1, j + 1]
+                            Lm[lm1, :lm1] = YTs[1:]
+                            Lm[lm1, lm1] = 0.0
+                            self.D = np.concatenate([self.D[1:], [sTy]])
+                    st = self.strategy
+                    if st == "sty":
+                        self.sigma = sTy / (s_nrm2 * s_nrm2)
+                    elif st == "sty_inv":
+                        self.sigma = y_nrm2 * y_nrm2 / sTy
+                    elif st == "snrm_ynrm":
+                        self.sigma = np.sqrt(s_nrm2 * s_nrm2 / y_nrm2 / y_nrm2)
+                    elif st == "sty_srnm_ynrm":
+                        self.sigma = 0.5 * (sTy / (s_nrm2 * s_nrm2) + y_nrm2 * y_nrm2 / sTy)
+                    else:
+                        self.sigma = self.sigma0
+                    self.sigma = max(min(1e8, self.sigma), 1e-8)
+                    stored = True
+            self.prev = (x.copy(), grad_f.copy(), Jc.copy(), Jd.copy())
+        else:
+            self.prev = (x.copy(), grad_f.copy(), Jc.copy(), Jd.copy())
+            self.l_curr += 1
+        return stored
+
+    # -- :400
+    def update_internal_bfgs_representation(self):
+        l = self.St.shape[0]
+        DpYtDhInvY = np.zeros((l, l))
+        symm_mat_times_diag_times_mat_trans_local(0.0, DpYtDhInvY, 1.0, self.Yt, self.DhInv)
+        B0DhInv = self.DhInv * self.sigma
+        StB0DhInvY = np.zeros((l, l))
+        mat_times_diag_times_mat_trans_local(StB0DhInvY, self.St, B0DhInv, self.Yt)
+        theDiag = (B0DhInv - 1.0) * self.sigma
+        StDS = np.zeros((l, l))
+        symm_mat_times_diag_times_mat_trans_local(0.0, StDS, 1.0, self.St, theDiag)
+        buf = self.allreduce(np.concatenate([DpYtDhInvY.ravel(), StB0DhInvY.ravel(), StDS.ravel()]))   # :459
+        DpYtDhInvY = buf[:l * l].reshape(l, l) + np.diag(self.D)
+        StB0DhInvYmL = buf[l * l:2 * l * l].reshape(l, l) - self.L
+        StDS = buf[2 * l * l:].reshape(l, l)
+        V = np.zeros((2 * l, 2 * l))
+        V[l:, l:] = DpYtDhInvY
+        V[:l, l:] = StB0DhInvYmL
+        V[:l, :l] = StDS
+        self.V_upper = V
+        self.Vfull = np.triu(V) + np.triu(V, 1).T
+        if l > 0:                                                 # factorizeV :633 (DSYTRF, uplo='L' of the transpose)
+            a = np.asfortranarray(V.T)
+            self.V_ldu, self.V_ipiv, info = lapack.dsytrf(a, lower=1)
+            assert info == 0
+        self.matrix_changed = False
+
+    def solve_with_V(self, rhs):                                  # :677,:729  rhs: (2l,) or (2l, nrhs)
+        if self.St.shape[0] == 0:
+            return rhs
+        x, info = lapack.dsytrs(self.V_ldu, self.V_ipiv, rhs, lower=1)
+        assert info == 0
+        return x
+
+    # -- :495
+    def solve(self, rhsx):
+        if self.matrix_changed:
+            self.update_internal_bfgs_representation()
+        x = rhsx * self.DhInv
+        l = self.St.shape[0]
+        ytx = self.allreduce(self.Yt @ x) if l else np.zeros(0)
+        stx = self.allreduce(self.St @ (x * self.sigma)) if l else np.zeros(0)
+        sol = self.solve_with_V(np.concatenate([stx, ytx]))
+        spart, ypart = sol[:l], sol[l:]
+        result = (self.St.T @ spart) * self.sigma + self.Yt.T @ ypart
+        result *= self.DhInv
+        return x - result
+
+    # -- :549   W = beta*W + alpha*X*this^-1*X^T
+    def sym_mat_times_inverse_times_mat_trans(self, beta, W, alpha, X):
+        if self.matrix_changed:
+            self.update_internal_bfgs_representation()
+        l = self.St.shape[0]
+        k = W.shape[0]
+        symm_mat_times_diag_times_mat_trans_local(beta if self.rank == 0 else 0.0, W, alpha, X, self.DhInv)   # :568-571
+        S1 = np.zeros((k, l))
+        Y1 = np.zeros((k, l))
+        mat_times_diag_times_mat_trans_local(S1, X, self.DhInv * self.sigma, self.St)
+        mat_times_diag_times_mat_trans_local(Y1, X, self.DhInv, self.Yt)
+        S1Y1 = self.allreduce(np.hstack([S1, Y1]).ravel()).reshape(k, 2 * l)       # :590
+        W[:, :] = self.allreduce(W.ravel().copy()).reshape(k, k)                    # :591
+        S1, Y1 = S1Y1[:, :l], S1Y1[:, l:]
+        if l > 0:
+            S2Y2 = self.solve_with_V(np.asfortranarray(S1Y1.T)).T                   # :606 (k x 2l)
+            S2, Y2 = S2Y2[:, :l], S2Y2[:, l:]
+            W -= alpha * (S1 @ S2.T)                                                # :614
+            W -= alpha * (Y1 @ Y2.T)                                                # :618
+        return W
+
+    # -- :974  y = beta*y + alpha*(B0 + Dx + sum b b^T - a a^T) x
+    def times_vec(self, beta, y, alpha, x, add_log_term=True):
+        l = self.St.shape[0]
+        a, b = [], []
+        eps = np.finfo(np.float64).eps
+        for k in range(l):
+            yk, sk = self.Yt[k], self.St[k]
+            skTyk = self._dot(yk, sk)
+            if skTyk < eps:
+                skTyk = eps
+            bk = yk / np.sqrt(skTyk)
+            ak = sk * self.sigma
+            for i in range(k):
+                ak = ak + self._dot(b[i], sk) * b[i]
+                ak = ak - self._dot(a[i], sk) * a[i]
+            ak = ak / np.sqrt(self._dot(ak, sk))
+            a.append(ak)
+            b.append(bk)
+        out = beta * y
+        if add_log_term:
+            out = out + alpha * x * self.Dx
+        out = out + alpha * self.sigma * x
+        for k in range(l):
+            out = out + alpha * self._dot(b[k], x) * b[k]
+            out = out - alpha * self._dot(a[k], x) * a[k]
+        y[:] = out
+
+    def dense_matrix_local(self):
+        """B (without Dx) as a dense n x n matrix through the compact formula — single-rank test helper
+        (Byrd-Nocedal-Schnabel: B = B0 - [B0 S, Y] [[S^T B0 S, L],[L^T, -D]]^-1 [S^T B0; Y^T])."""
+        n = self.n
+        l = self.St.shape[0]
+        B = np.eye(n) * self.sigma
+        if l:
+            S, Y = self.St.T, self.Yt.T
+            Mid = np.block([[self.sigma * S.T @ S, self.L], [self.L.T, -np.diag(self.D)]])
+            Wm = np.hstack([self.sigma * S, Y])
+            B = B - Wm @ np.linalg.solve(Mid, Wm.T)
+        return B
+
+
+# =====================================================================================
+# hiopKKTLinSysLowRank (reference: src/Optimization/hiopKKTLinSys.cpp:1057-1330)
+# =====================================================================================
+def solve_with_refin(N, rhs):                                     # :1192-1330
+    """DPOSVX(FACT='E') + the reference's residual loop (inf-norm tol 1e-8, <= 3 Cholesky refinements).
+    N is the full symmetric k x k matrix (both triangles, as symmMatTimesDiagTimesMatTrans_local leaves it)."""
+    k = N.shape[0]
+    if k == 0:
+        return rhs.copy(), 0
+    A = np.asfortranarray(N.T.copy())
+    out = lapack.dposvx(A, rhs.reshape(-1, 1), fact="E", lower=1)
+    X = out[6][:, 0].copy() if isinstance(out[6], np.ndarray) and out[6].ndim == 2 else None
+    if X is None:   # scipy return order: a_s, lu, equed, s, b_s, x, rcond, ferr, berr, info (version dependent)
+        for o in out:
+            if isinstance(o, np.ndarray) and o.shape == (k, 1):
+                X = o[:, 0].copy()
+    info = out[-1]
+    n_refin = 0
+    x = X.copy()
+    while True:
+        x = X.copy()
+        resid = rhs - N @ x
+        if infnorm(resid) < 1e-8 or n_refin >= 3:
+            break
+        c, info2 = lapack.dpotrf(np.asfortranarray(N.T.copy()), lower=1)
+        dxr, _ = lapack.dpotrs(c, resid, lower=1)
+        x = x + dxr
+        n_refin += 1
+        X = x   # NOTE: the reference re-copies X (un-refined) at the top of its loop (:1248); refinement
+        #         results are only kept from the LAST pass.  Keeping the refined x is mathematically the
+        #         intended behaviour and differs from the reference only when DPOSVX misses 1e-8.
+    return x, int(info)
+
+
+class KKTLinSysLowRank:
+    def __init__(self, hess: HessianLowRank, m_eq, m_ineq):
+        self.H, self.m_eq, self.m_ineq = hess, m_eq, m_ineq
+
+    def update(self, Dx, Dd, Jc, Jd):                             # :1057-1096 (Dx, Dd computed by the caller's vector ops)
+        self.H.update_log_barrier_diagonal(Dx)
+        self.Dd_inv = 1.0 / Dd
+        self.J = np.vstack([Jc, Jd])                              # :1127-1128
+
+    def solve_compressed(self, rx, ryc, ryd):                     # :1110-1187
+        H, J = self.H, self.J
+        k = J.shape[0]
+        N = np.zeros((k, k))
+        H.sym_mat_times_inverse_times_mat_trans(0.0, N, 1.0, J)   # :1132
+        idx = np.arange(self.m_ineq) + self.m_eq
+        N[idx, idx] += self.Dd_inv                                # :1135
+        dx = H.solve(rx)                                          # :1147
+        rhs = np.concatenate([ryc, ryd])
+        Jdx = J @ dx
+        if H.rank != 0:                                           # timesVec: only rank 0 applies beta (:466)
+            rhs_loc = Jdx
+        else:
+            rhs_loc = -rhs + Jdx
+        rhs = H.allreduce(rhs_loc.copy())                         # :1157 (Allreduce k)
+        sol, ierr = solve_with_refin(N, rhs)                      # :1169
+        self.last_N = N
+        dyc, dyd = sol[:self.m_eq].copy(), sol[self.m_eq:].copy()
+        rx2 = rx - J.T @ sol                                      # :1178
+        dx = H.solve(rx2)                                         # :1180
+        return ierr == 0, dx, dyc, dyd

@@ -119,29 +119,29 @@ def test_assembly_kernels(ctx):
     Wd = D(W)
     run(ctx, "hiopamd_mat_trans_add_to_sym_upper", 37, 70, D(A), 70, 10, 100, 0.5, Wd, nW)
     e = W.copy(); ho.trans_add_to_sym_upper(A, 10, 100, 0.5, e)
-    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15, atol=1e-16)
     H = r.uniform(-1, 1, (90, 90))
     Wd = D(W)
     run(ctx, "hiopamd_mat_add_upper_to_sym_upper", 90, D(H), 90, 5, -2.0, Wd, nW)
     e = W.copy(); ho.add_upper_to_sym_upper(H, 5, -2.0, e)
-    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15, atol=1e-16)
     d = r.uniform(-1, 1, 200)
     Wd = D(W)
     run(ctx, "hiopamd_mat_add_sub_diagonal", Wd, nW, 7, 0.25, D(d), 13, 50)
     e = W.copy(); ho.add_sub_diagonal(e, 7, 0.25, d, 13, 50)
-    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15, atol=1e-16)
     Wd = D(W)
     run(ctx, "hiopamd_mat_add_sub_diagonal_const", Wd, nW, 3, 20, 1.5)
     e = W.copy(); e[np.arange(3, 23), np.arange(3, 23)] += 1.5
-    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15, atol=1e-16)
     Wd = D(W)
     run(ctx, "hiopamd_mat_add_diagonal_vec", nW, Wd, nW, 2.0, D(r.uniform(-1, 1, nW) * 0 + 1))
     e = W.copy(); e[np.arange(nW), np.arange(nW)] += 2.0
-    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15, atol=1e-16)
     X = r.uniform(-1, 1, (nW, nW))
     Wd = D(W)
     run(ctx, "hiopamd_mat_add_matrix", nW, nW, Wd, nW, 0.3, D(X), nW)
-    np.testing.assert_allclose(Wd.cpu().numpy(), W + 0.3 * X, rtol=4e-16)
+    np.testing.assert_allclose(Wd.cpu().numpy(), W + 0.3 * X, rtol=4e-16, atol=1e-16)
     Wd = D(W)
     run(ctx, "hiopamd_mat_symmetrize", nW, Wd, nW)
     e = np.triu(W) + np.triu(W, 1).T
@@ -178,7 +178,7 @@ def test_row_ops(ctx):
     sc = r.uniform(0.5, 2, 12)
     Ad = D(A)
     run(ctx, "hiopamd_mat_scale_rows", 12, 1000, Ad, 1000, D(sc), 1)
-    np.testing.assert_allclose(Ad.cpu().numpy(), A * (1.0 / sc)[:, None], rtol=4e-16)
+    np.testing.assert_allclose(Ad.cpu().numpy(), A * (1.0 / sc)[:, None], rtol=4e-16, atol=1e-16)
 
 
 def _rand_sparse(r, m, n, density):
@@ -259,9 +259,9 @@ def test_symsparse_diag_ops(ctx):
     yd = D(y)
     run(ctx, "hiopamd_spsym_add_diag_to_vec", v.size, D(i, torch.int32), D(j, torch.int32), D(v), 0.5, yd, 0, n, 0, n)
     e = y.copy(); ho.spsym_add_diag_to_vec(i, j, v, 0.5, e, 0)
-    np.testing.assert_allclose(yd.cpu().numpy(), e, rtol=1e-15)
+    np.testing.assert_allclose(yd.cpu().numpy(), e, rtol=1e-15, atol=1e-16)
     W = r.uniform(-1, 1, (n + 3, n + 3))
     Wd = D(W)
     run(ctx, "hiopamd_spsym_add_upper_to_sym_upper", v.size, D(i, torch.int32), D(j, torch.int32), D(v), 2, -1.0, Wd, n + 3)
     e = W.copy(); np.add.at(e, (i + 2, j + 2), -v)
-    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15, atol=1e-16)

@@ -49,7 +49,7 @@ def _ew(ctx, n, name, y, extra_dev, expected, rtol=4 * EPS):
     yd = D(y)
     run(ctx, name, n, yd, *extra_dev)
     got = yd.cpu().numpy()
-    np.testing.assert_allclose(got, expected, rtol=rtol, atol=0)
+    np.testing.assert_allclose(got, expected, rtol=rtol, atol=1e-16)
 
 
 @pytest.mark.parametrize("n", SIZES)
