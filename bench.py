@@ -177,7 +177,7 @@ def main():
                                    f"N={p.N}; step = 1 assemble + 1 LDL^T factor(+inertia) + {a.solves} solveCompressed",
                        "parallelism": "single GPU" if world == 1 else f"replicas only x{world} (MDS path does not shard)"},
             "roofline": roofline,
-            "check": {"kkt_residual_rel_inf": max(res), "inertia_neg": expected_neg},
+            "check": {"kkt_backward_error": max(res), "inertia_neg": expected_neg},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, Dx, Dd, rhs, a.solves, a.cpu_steps)

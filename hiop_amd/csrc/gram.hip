@@ -8,7 +8,8 @@
 // dimension.  Both operands are K-contiguous ("NT" GEMM): tiles are staged through LDS with coalesced
 // 256-byte row pieces, the weight d is folded in while staging, the K range is split across workgroups
 // (>= 2 per CU) and the per-split partial tiles are folded in a fixed order by a second kernel
-// (deterministic, no atomics) which also applies alpha/beta and the upper-triangle mask.
+// (deterministic, no atomics) which also applies alpha/beta and, for the symmetric product, mirrors the
+// upper triangle onto the lower one.
 #include "device_utils.hpp"
 
 namespace hiopamd {
@@ -130,7 +131,11 @@ __global__ __launch_bounds__(kBlock) void gram_fold_kernel(int ma, int mb, int n
   double s = 0.0;
   for(int sp = 0; sp < nsplit; ++sp) s += partial[((int64_t)sp * ntiles + tile) * (GR_T * GR_T) + off];
   double* w = W + (int64_t)i * ldw + j;
-  *w = (beta == 0.0 ? 0.0 : beta * (*w)) + alpha * s;
+  const double v = (beta == 0.0 ? 0.0 : beta * (*w)) + alpha * s;
+  *w = v;
+  // symmetric product: mirror onto the lower triangle, exactly like the reference's
+  // Wdata[i*k+j] = Wdata[j*k+i] = beta*Wdata[i*k+j] + alpha*acc  (hiopHessianLowRank.cpp:1107)
+  if(sym && j > i) W[(int64_t)j * ldw + i] = v;
 }
 
 }  // namespace hiopamd
@@ -139,11 +144,11 @@ using namespace hiopamd;
 
 extern "C" int hiopamd_gram_weighted(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const double* A, int64_t lda,
                                      const double* B, int64_t ldb, const double* d, double beta, double* W,
-                                     int64_t ldw, double alpha, int sym_upper)
+                                     int64_t ldw, double alpha, int sym)
 {
   if(ma < 0 || mb < 0 || n < 0) return HIOPAMD_ERR_ARG;
   if(ma == 0 || mb == 0) return HIOPAMD_OK;
-  const int sym = (sym_upper && A == B && ma == mb) ? 1 : 0;
+  const int symm = (sym && A == B && ma == mb) ? 1 : 0;
   const int tiles_a = (ma + GR_T - 1) / GR_T, tiles_b = (mb + GR_T - 1) / GR_T;
   const int ntiles = tiles_a * tiles_b;
   // K split: aim at ~2 workgroups per CU (512) over all tiles, chunk a multiple of the stage depth
@@ -156,10 +161,10 @@ extern "C" int hiopamd_gram_weighted(hiopamd_ctx* ctx, int ma, int mb, int64_t n
   if(nsplit < 1) nsplit = 1;
   double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * ntiles * GR_T * GR_T);
   hipLaunchKernelGGL(gram_partial_kernel, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, lda, B, ldb,
-                     d, kchunk, tiles_b, sym, partial);
+                     d, kchunk, tiles_b, symm, partial);
   const int64_t tot = (int64_t)ma * mb;
   hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ma,
-                     mb, nsplit, ntiles, tiles_b, sym, partial, beta, W, ldw, alpha);
+                     mb, nsplit, ntiles, tiles_b, symm, partial, beta, W, ldw, alpha);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
 }

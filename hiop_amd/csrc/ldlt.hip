@@ -39,14 +39,22 @@ constexpr int LD_LDP = LD_TM + 16;  // padded LDS row stride (doubles): rows k,k
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
-// diag kernel: LDL^T of the kb x kb (<=64) diagonal block by ONE workgroup in LDS.
-// Writes U11 (unit upper, strictly-upper part) and D (diagonal) back into A, a compact copy of the
-// block into Dk (64x64 row-major, zero padded) for the substitution kernel, and dinv.
-// info[0] = 1-based index of the first zero / non-finite pivot (0 = none)
+// diag kernel: LDL^T of the kb x kb (<=64) diagonal block by ONE workgroup, blocked by 16:
+//   (i)   the 16x16 diagonal sub-block is factored by wave 0 entirely in registers (4 entries per
+//         lane, pivot row / multiplier broadcast with wave shuffles — no LDS round trips, no barriers);
+//   (ii)  the 16 x (rest) row panel is forward-substituted, one column per thread;
+//   (iii) the trailing part of the 64x64 block gets the rank-16 update, 9 entries per thread.
+// During the factorisation S holds UN-scaled rows (v_kc = d_k * u_kc); rows are scaled at the end.
+// Outputs: U11 (strictly upper, unit diagonal implied) and D (diagonal) written back into A; a compact
+// zero-padded 64x64 copy Dk for the substitution kernel; dinv; and Li = the four 16x16 inverses of the
+// unit-lower diagonal sub-blocks of L11 = U11^T (row-major [sb][i][j]), which turn the panel
+// substitution into MFMA GEMMs.  info[0] = 1-based index of the first zero / non-finite pivot.
 // ------------------------------------------------------------------------------------------
+constexpr int LD_SB = 16;
+
 __global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int kb,
                                                            double* __restrict__ dinv, double* __restrict__ Dk,
-                                                           int* __restrict__ info)
+                                                           double* __restrict__ Li, int* __restrict__ info)
 {
   __shared__ double S[LD_nb][LD_nb + 1];
   __shared__ double sdinv[LD_nb];
@@ -57,66 +65,197 @@ __global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ 
     if(r < kb && c < kb && c >= r) v = A[(int64_t)(k0 + r) * lda + (k0 + c)];
     S[r][c] = v;
   }
+  if(tid < LD_nb) sdinv[tid] = 1.0;
   __syncthreads();
-  const int tr = tid >> 4, tc = tid & 15;
-  for(int k = 0; k < kb; ++k) {
-    const double d = S[k][k];
-    const double di = 1.0 / d;
-    if(tid == 0) {
-      sdinv[k] = di;
-      if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + k + 1);
+
+  for(int sb = 0; sb < LD_nb / LD_SB; ++sb) {
+    const int o = sb * LD_SB;
+    if(o >= kb) break;  // uniform
+    // ---- (i) 16x16 diagonal sub-block in registers of wave 0: lane = 4*row + quarter
+    if(tid < 64) {
+      const int r = tid >> 2, cq = tid & 3;
+      double a[4];
+#pragma unroll
+      for(int j = 0; j < 4; ++j) a[j] = S[o + r][o + cq * 4 + j];
+#pragma unroll
+      for(int k = 0; k < LD_SB; ++k) {
+        if(o + k < kb) {  // uniform
+          double pk[4];
+#pragma unroll
+          for(int j = 0; j < 4; ++j) pk[j] = __shfl(a[j], k * 4 + cq, 64);  // pivot row, my 4 columns
+          const double d = __shfl(a[k & 3], k * 4 + (k >> 2), 64);           // pivot
+          const double di = 1.0 / d;
+          // multiplier S[k][r] lives in lane 4k + (r>>2), element r&3
+          const int src = k * 4 + (r >> 2);
+          const double t0 = __shfl(a[0], src, 64), t1 = __shfl(a[1], src, 64);
+          const double t2 = __shfl(a[2], src, 64), t3 = __shfl(a[3], src, 64);
+          const int rq = r & 3;
+          const double vkr = rq == 0 ? t0 : (rq == 1 ? t1 : (rq == 2 ? t2 : t3));
+          if(r > k) {
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+              if(cq * 4 + j >= r) a[j] -= vkr * (pk[j] * di);
+          }
+          if(tid == 0) {
+            sdinv[o + k] = di;
+            if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + o + k + 1);
+          }
+        }
+      }
+#pragma unroll
+      for(int j = 0; j < 4; ++j)
+        if(cq * 4 + j >= r) S[o + r][o + cq * 4 + j] = a[j];
     }
-    for(int r = k + 1 + tr; r < kb; r += 16) {
-      const double vr = S[k][r];
-      for(int c = k + 1 + tc; c < kb; c += 16) {
-        if(c >= r) S[r][c] -= vr * (S[k][c] * di);
+    __syncthreads();
+    // ---- (ii) row panel: columns c >= o+16, one per thread; x_r -= S[o+s][o+r] * (x_s/d_s)
+    {
+      const int c = o + LD_SB + tid;
+      if(c < LD_nb && c < kb) {
+        double x[LD_SB];
+#pragma unroll
+        for(int r = 0; r < LD_SB; ++r) x[r] = S[o + r][c];
+#pragma unroll
+        for(int q = 0; q < LD_SB - 1; ++q) {
+          const double us = x[q] * sdinv[o + q];
+#pragma unroll
+          for(int r = q + 1; r < LD_SB; ++r) x[r] = fma(-S[o + q][o + r], us, x[r]);
+        }
+#pragma unroll
+        for(int r = 0; r < LD_SB; ++r) S[o + r][c] = x[r];
       }
     }
     __syncthreads();
+    // ---- (iii) trailing rank-16 update inside the block: S[r][c] -= sum_k v_kr * v_kc / d_k, c >= r >= o+16
+    {
+      const int tr = tid >> 4, tc = tid & 15;
+      double acc[3][3];
+#pragma unroll
+      for(int i = 0; i < 3; ++i)
+#pragma unroll
+        for(int j = 0; j < 3; ++j) acc[i][j] = 0.0;
+      const int rb = o + LD_SB + tr, cb = o + LD_SB + tc;
+#pragma unroll 4
+      for(int k = 0; k < LD_SB; ++k) {
+        const double di = sdinv[o + k];
+        double vr[3], uc[3];
+#pragma unroll
+        for(int i = 0; i < 3; ++i) vr[i] = (rb + 16 * i < LD_nb) ? S[o + k][rb + 16 * i] : 0.0;
+#pragma unroll
+        for(int j = 0; j < 3; ++j) uc[j] = (cb + 16 * j < LD_nb) ? S[o + k][cb + 16 * j] * di : 0.0;
+#pragma unroll
+        for(int i = 0; i < 3; ++i)
+#pragma unroll
+          for(int j = 0; j < 3; ++j) acc[i][j] = fma(vr[i], uc[j], acc[i][j]);
+      }
+      __syncthreads();  // all reads of the k-panel done before anybody writes (rows >= o+16 only, but keep it simple)
+#pragma unroll
+      for(int i = 0; i < 3; ++i)
+#pragma unroll
+        for(int j = 0; j < 3; ++j) {
+          const int r = rb + 16 * i, c = cb + 16 * j;
+          if(r < LD_nb && c < LD_nb && c >= r) S[r][c] -= acc[i][j];
+        }
+    }
+    __syncthreads();
   }
+  // scale the rows, write the factor back and the compact copy
   for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
     const int r = e >> 6, c = e & 63;
     double v = S[r][c];
-    if(r < kb && c > r && c < kb) v *= sdinv[r];   // U11[r][c] = S[r][c] / d_r
-    Dk[e] = v;
-    if(r < kb && c < kb && c >= r) A[(int64_t)(k0 + r) * lda + (k0 + c)] = v;
+    if(c > r) v *= sdinv[r];
+    const bool in = (r < kb && c < kb && c >= r);
+    Dk[e] = in ? v : 0.0;
+    if(in) A[(int64_t)(k0 + r) * lda + (k0 + c)] = v;
   }
   if(tid < kb) dinv[k0 + tid] = sdinv[tid];
-}
-
-// ------------------------------------------------------------------------------------------
-// substitution kernel for the row panel right of the diagonal block: one column per thread, its 64
-// unknowns in registers:  U11^T x = a ;  V = x (un-scaled, workspace), U12 = D^-1 x (in place).
-// The factor entries U11[s][r] are wave-uniform: they come from the compact read-only copy Dk through
-// the scalar cache (s_load) and feed v_fma_f64 as SGPR operands — no LDS, no per-lane loads.
-// ------------------------------------------------------------------------------------------
-template <int S_>
-__device__ __forceinline__ void trsm_eliminate(double (&x)[LD_nb], const double* __restrict__ Dk)
-{
-  if constexpr(S_ < LD_nb - 1) {
-    const double xs = x[S_];
+  // inverses of the four unit-lower 16x16 diagonal sub-blocks of L11 = U11^T:
+  // thread (sb, j) solves L x = e_j;  L[i][q] = S[o+q][o+i]*sdinv[o+q] for i > q
+  if(tid < LD_nb) {
+    const int sb = tid >> 4, j = tid & 15, o = sb * LD_SB;
+    double x[LD_SB];
 #pragma unroll
-    for(int r = S_ + 1; r < LD_nb; ++r) x[r] = fma(-Dk[S_ * LD_nb + r], xs, x[r]);
-    trsm_eliminate<S_ + 1>(x, Dk);
+    for(int i = 0; i < LD_SB; ++i) x[i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for(int q = 0; q < LD_SB - 1; ++q) {
+      const double xq = x[q] * sdinv[o + q];   // zero for q < j
+#pragma unroll
+      for(int i = q + 1; i < LD_SB; ++i) x[i] = fma(-S[o + q][o + i], xq, x[i]);
+    }
+#pragma unroll
+    for(int i = 0; i < LD_SB; ++i) Li[sb * (LD_SB * LD_SB) + i * LD_SB + j] = x[i];
   }
 }
 
-__global__ __launch_bounds__(kBlock) void ldlt_trsm_kernel(double* __restrict__ A, int64_t lda, int N, int k0, int kb,
-                                                           double* __restrict__ V, int64_t ldv, int vrow0,
-                                                           const double* __restrict__ dinv,
-                                                           const double* __restrict__ Dk)
+// ------------------------------------------------------------------------------------------
+// substitution kernel for the row panel right of the diagonal block, on fp64 MFMA:
+//   V = L11^-1 A12  (un-scaled, to the workspace)   and   U12 = D^-1 V  (in place),
+// as a block forward substitution over the four 16-row blocks I of the panel:
+//   T_I = A_I - sum_{J<I} L_IJ V_J ,   V_I = Linv_II T_I .
+// One wave64 per workgroup = 64 columns = 4 independent groups of 16 columns (independent MFMA
+// chains hide the 64-cycle MFMA latency).  The MFMA D layout (row = (l>>4)+4*reg, col = l&15) of a
+// 16x16 block is exactly the B-operand layout of its four k-steps (k-step kk <-> reg kk), so V_J feeds
+// the next product straight from the accumulator registers.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ldlt_trsm_kernel(double* __restrict__ A, int64_t lda, int N, int k0,
+                                                       double* __restrict__ V, int64_t ldv, int vrow0,
+                                                       const double* __restrict__ dinv,
+                                                       const double* __restrict__ Dk, const double* __restrict__ Li)
 {
-  const int64_t col = (int64_t)k0 + kb + (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if(col >= N) return;
-  double x[LD_nb];
+  const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
+  const int64_t colbase = (int64_t)k0 + LD_nb + (int64_t)blockIdx.x * 64;
+  // A operands (shared by the 4 column groups)
+  double negL[4][4][4];  // [I][J][kk], J < I : -L11[16I+li][16J+4kk+g] = -U11[16J+4kk+g][16I+li]
+  double inv[4][4];      // [I][kk]    : Linv_II[li][4kk+g]
 #pragma unroll
-  for(int r = 0; r < LD_nb; ++r) x[r] = (r < kb) ? A[(int64_t)(k0 + r) * lda + col] : 0.0;
-  trsm_eliminate<0>(x, Dk);
+  for(int I = 0; I < 4; ++I) {
 #pragma unroll
-  for(int r = 0; r < LD_nb; ++r) {
-    if(r < kb) {
-      V[(int64_t)(vrow0 + r) * ldv + col] = x[r];
-      A[(int64_t)(k0 + r) * lda + col] = x[r] * dinv[k0 + r];
+    for(int kk = 0; kk < 4; ++kk) {
+      inv[I][kk] = Li[I * 256 + li * 16 + 4 * kk + g];
+#pragma unroll
+      for(int J = 0; J < 4; ++J)
+        negL[I][J][kk] = (J < I) ? -Dk[(16 * J + 4 * kk + g) * LD_nb + 16 * I + li] : 0.0;
+    }
+  }
+  double dsc[4][4];  // dinv of row 16I + g + 4r
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) dsc[I][r] = dinv[k0 + 16 * I + g + 4 * r];
+
+#pragma unroll
+  for(int grp = 0; grp < 4; ++grp) {
+    const int64_t col = colbase + grp * 16 + li;
+    const bool ok = col < N;
+    double4_t a[4];
+#pragma unroll
+    for(int I = 0; I < 4; ++I)
+#pragma unroll
+      for(int r = 0; r < 4; ++r) a[I][r] = ok ? A[(int64_t)(k0 + 16 * I + g + 4 * r) * lda + col] : 0.0;
+    double4_t Vv[4];
+#pragma unroll
+    for(int I = 0; I < 4; ++I) {
+      double4_t t = a[I];
+#pragma unroll
+      for(int J = 0; J < 4; ++J) {
+        if(J < I) {
+#pragma unroll
+          for(int kk = 0; kk < 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(negL[I][J][kk], Vv[J][kk], t, 0, 0, 0);
+        }
+      }
+      double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[I][kk], t[kk], v, 0, 0, 0);
+      Vv[I] = v;
+    }
+    if(ok) {
+#pragma unroll
+      for(int I = 0; I < 4; ++I)
+#pragma unroll
+        for(int r = 0; r < 4; ++r) {
+          const int row = 16 * I + g + 4 * r;
+          V[(int64_t)(vrow0 + row) * ldv + col] = Vv[I][r];
+          A[(int64_t)(k0 + row) * lda + col] = Vv[I][r] * dsc[I][r];
+        }
     }
   }
 }
@@ -155,13 +294,15 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
   const double* Vp = V + (int64_t)(vrow0 + lrow) * ldv + (r0 + lcol);
   const double* Up = A + (int64_t)(urow0 + lrow) * lda + (c0 + lcol);
 
-  for(int kt = 0; kt < K; kt += LD_KT) {
-    double vreg[8], ureg[8];
+  // register-prefetch pipeline over one LDS buffer: the global loads of stage kt+1 are in flight while the
+  // 64 MFMAs of stage kt issue
+  double vreg[8], ureg[8];
 #pragma unroll
-    for(int q = 0; q < 8; ++q) {
-      vreg[q] = vr_ok ? Vp[(int64_t)(kt + 2 * q) * ldv] : 0.0;
-      ureg[q] = uc_ok ? Up[(int64_t)(kt + 2 * q) * lda] : 0.0;
-    }
+  for(int q = 0; q < 8; ++q) {
+    vreg[q] = vr_ok ? Vp[(int64_t)(2 * q) * ldv] : 0.0;
+    ureg[q] = uc_ok ? Up[(int64_t)(2 * q) * lda] : 0.0;
+  }
+  for(int kt = 0; kt < K; kt += LD_KT) {
     __syncthreads();  // previous stage fully consumed
 #pragma unroll
     for(int q = 0; q < 8; ++q) {
@@ -169,6 +310,13 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
       Us[2 * q + lrow][lcol] = ureg[q];
     }
     __syncthreads();
+    if(kt + LD_KT < K) {
+#pragma unroll
+      for(int q = 0; q < 8; ++q) {
+        vreg[q] = vr_ok ? Vp[(int64_t)(kt + LD_KT + 2 * q) * ldv] : 0.0;
+        ureg[q] = uc_ok ? Up[(int64_t)(kt + LD_KT + 2 * q) * lda] : 0.0;
+      }
+    }
 #pragma unroll
     for(int kk = 0; kk < LD_KT / 4; ++kk) {
       double a[4], b[4];
@@ -235,47 +383,87 @@ __global__ __launch_bounds__(kBlock) void ldlt_inertia_kernel(int N, const doubl
 }
 
 // ------------------------------------------------------------------------------------------
-// triangular solves, block size 64, one launch per block step; every workgroup (one wave64)
-// solves the 64x64 diagonal system redundantly in registers, workgroup 0 publishes it, and each
-// workgroup then updates its own 64 entries of the running right-hand side.
-// forward:  U^T y = b      (b updated in place for the not-yet-solved entries, y written to yout)
+// triangular solves  U^T y = b,  z = D^-1 y,  U x = z   with 64-row blocks, one launch per block step.
+// The sequential part (the 64x64 unit-triangular solve) is taken off every workgroup's critical path by
+// LOOK-AHEAD: the launch that applies block I's solution to the rest of the right-hand side also solves
+// the NEXT diagonal block inside the one workgroup that owns its entries (its 64 factor loads are issued
+// at kernel entry, independent of everything else), so each launch starts with its block solution
+// already in memory.  Per-step latency = one round of loads + a 64-step shuffle/FMA chain.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ldlt_fwd_step(const double* __restrict__ A, int64_t lda, int N, int i0, int ib,
-                                                    double* __restrict__ b, double* __restrict__ yout)
+// lane r of one wave holds rhs entry r; returns y_r of the unit-lower solve with L = U_bb^T, where
+// u[s] = U[j0+s][j0+r] for s < r (zero otherwise)
+__device__ __forceinline__ double wave_fwd_chain(const double (&u)[LD_nb], double v)
 {
-  const int lane = threadIdx.x;
-  // lane r owns unknown r; u[s] = U[i0+s][i0+lane]  (column `lane` of the unit upper block)
-  double u[LD_nb];
-#pragma unroll
-  for(int s2 = 0; s2 < LD_nb; ++s2) u[s2] = (s2 < ib && lane < ib && s2 < lane) ? A[(int64_t)(i0 + s2) * lda + (i0 + lane)] : 0.0;
-  double br = (lane < ib) ? b[i0 + lane] : 0.0;
 #pragma unroll
   for(int s2 = 0; s2 < LD_nb; ++s2) {
-    const double ys = __shfl(br, s2, 64);
-    br = fma(-u[s2], ys, br);  // u[s2]==0 for s2 >= lane: lane s2 itself and solved lanes are untouched
+    const double ys = __shfl(v, s2, 64);
+    v = fma(-u[s2], ys, v);
   }
-  if(blockIdx.x == 0 && lane < ib) yout[i0 + lane] = br;
+  return v;
+}
+
+__global__ __launch_bounds__(64) void ldlt_fwd_first(const double* __restrict__ A, int64_t lda, int ib,
+                                                     const double* __restrict__ b, double* __restrict__ y)
+{
+  const int lane = threadIdx.x;
+  double u[LD_nb];
+#pragma unroll
+  for(int s2 = 0; s2 < LD_nb; ++s2) u[s2] = (s2 < lane && lane < ib) ? A[(int64_t)s2 * lda + lane] : 0.0;
+  double v = (lane < ib) ? b[lane] : 0.0;
+  v = wave_fwd_chain(u, v);
+  if(lane < ib) y[lane] = v;
+}
+
+// y_I (block [i0,i0+64)) is ready in y; apply it to b[col], col >= i0+64; workgroup 0 owns the next
+// diagonal block [j0, j0+jb) and solves it.
+__global__ __launch_bounds__(64) void ldlt_fwd_step(const double* __restrict__ A, int64_t lda, int N, int i0,
+                                                    double* __restrict__ b, double* __restrict__ y)
+{
+  const int lane = threadIdx.x;
+  const int j0 = i0 + LD_nb;
+  const int jb = (N - j0 < LD_nb) ? (N - j0) : LD_nb;
+  const bool spine = (blockIdx.x == 0);
+  double u[LD_nb];
+  if(spine) {
+#pragma unroll
+    for(int s2 = 0; s2 < LD_nb; ++s2) u[s2] = (s2 < lane && lane < jb) ? A[(int64_t)(j0 + s2) * lda + (j0 + lane)] : 0.0;
+  }
   __shared__ double ysh[LD_nb];
-  ysh[lane] = br;
+  ysh[lane] = y[i0 + lane];
   __syncthreads();
-  const int64_t col = (int64_t)i0 + ib + (int64_t)blockIdx.x * 64 + lane;
+  const int64_t col = (int64_t)j0 + (int64_t)blockIdx.x * 64 + lane;
+  double acc = 0.0;
   if(col < N) {
-    double acc = b[col];
+    acc = b[col];
     const double* Ac = A + (int64_t)i0 * lda + col;
-#pragma unroll 8
-    for(int s2 = 0; s2 < ib; ++s2) acc = fma(-Ac[(int64_t)s2 * lda], ysh[s2], acc);
+#pragma unroll 16
+    for(int s2 = 0; s2 < LD_nb; ++s2) acc = fma(-Ac[(int64_t)s2 * lda], ysh[s2], acc);
     b[col] = acc;
+  }
+  if(spine) {
+    const double v = wave_fwd_chain(u, acc);   // acc == 0 for lanes >= jb
+    if(lane < jb) y[j0 + lane] = v;
   }
 }
 
-// backward:  U x = z, z = D^-1 y.  On entry z holds D^-1 y for rows < i0+ib already corrected by the
-// solved blocks to the right; workgroup 0 writes x_I; each workgroup (4 waves, 32 rows) applies
-//   z[h] -= U[h][I] . x_I   for its rows h < i0  (8 lanes per row, 64-byte pieces, shuffle-reduced)
-__global__ __launch_bounds__(kBlock) void ldlt_bwd_step(const double* __restrict__ A, int64_t lda, int N, int i0,
-                                                        int ib, double* __restrict__ z, double* __restrict__ xout)
+// backward: wave 0 solves the unit-upper 64x64 (or ib x ib) block held in LDS (strictly upper, zero padded)
+__device__ __forceinline__ double wave_bwd_chain(const double (*S)[LD_nb + 1], int lane, double v)
+{
+  double srow[LD_nb];
+#pragma unroll
+  for(int c = 0; c < LD_nb; ++c) srow[c] = S[lane][c];
+#pragma unroll
+  for(int c = LD_nb - 1; c >= 0; --c) {
+    const double xc = __shfl(v, c, 64);
+    v = fma(-srow[c], xc, v);   // srow[c] == 0 unless c > lane
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void ldlt_bwd_first(const double* __restrict__ A, int64_t lda, int i0, int ib,
+                                                         const double* __restrict__ z, double* __restrict__ x)
 {
   __shared__ double S[LD_nb][LD_nb + 1];
-  __shared__ double xs[LD_nb];
   const int tid = threadIdx.x;
   for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
     const int r = e >> 6, c = e & 63;
@@ -283,33 +471,57 @@ __global__ __launch_bounds__(kBlock) void ldlt_bwd_step(const double* __restrict
   }
   __syncthreads();
   if(tid < 64) {
-    const int lane = tid;
-    double zr = (lane < ib) ? z[i0 + lane] : 0.0;
-    // column-oriented back substitution: for c = ib-1..0: x_c final; z_r -= U[r][c] x_c for r < c
-    for(int c = LD_nb - 1; c >= 0; --c) {
-      const double xc = __shfl(zr, c, 64);
-      zr = fma(-S[lane][c], xc, zr);  // S[lane][c]==0 unless c > lane
-    }
-    xs[lane] = zr;
-    if(blockIdx.x == 0 && lane < ib) xout[i0 + lane] = zr;
+    double v = (tid < ib) ? z[i0 + tid] : 0.0;
+    v = wave_bwd_chain(S, tid, v);
+    if(tid < ib) x[i0 + tid] = v;
   }
+}
+
+// x_I (block [i0, i0+ib)) is ready in x; rows h < i0:  z[h] -= U[h][I] . x_I  (4 lanes per row, 16 columns
+// = 128 bytes each).  Workgroup 0 owns the 64 rows of block I-1 and solves that diagonal block.
+__global__ __launch_bounds__(kBlock) void ldlt_bwd_step(const double* __restrict__ A, int64_t lda, int i0, int ib,
+                                                        double* __restrict__ z, double* __restrict__ x)
+{
+  __shared__ double S[LD_nb][LD_nb + 1];
+  __shared__ double xs[LD_nb];
+  __shared__ double zs[LD_nb];
+  const int tid = threadIdx.x;
+  const bool spine = (blockIdx.x == 0);
+  const int p0 = i0 - LD_nb;  // previous diagonal block (always a full one)
+  if(spine) {
+    for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
+      const int r = e >> 6, c = e & 63;
+      S[r][c] = (c > r) ? A[(int64_t)(p0 + r) * lda + (p0 + c)] : 0.0;
+    }
+  }
+  if(tid < LD_nb) xs[tid] = (tid < ib) ? x[i0 + tid] : 0.0;
   __syncthreads();
-  // rows above the block
-  const int sub = tid & 7;                                   // 8 lanes per row
-  const int64_t h = (int64_t)blockIdx.x * (kBlock / 8) + (tid >> 3);
+  const int rloc = tid >> 2, sub = tid & 3;
+  const int64_t h = (int64_t)i0 - (int64_t)LD_nb * (blockIdx.x + 1) + rloc;
   double acc = 0.0;
-  if(h < i0) {
-    const double* Ah = A + h * lda + i0 + sub * 8;
+  if(h >= 0) {
+    const double* Ah = A + h * lda + i0 + sub * 16;
 #pragma unroll
-    for(int q = 0; q < 8; ++q) {
-      const int c = sub * 8 + q;
+    for(int q = 0; q < 16; ++q) {
+      const int c = sub * 16 + q;
       if(c < ib) acc = fma(Ah[q], xs[c], acc);
     }
   }
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
-  acc += __shfl_xor(acc, 4, 64);
-  if(h < i0 && sub == 0) z[h] -= acc;
+  double znew = 0.0;
+  if(h >= 0 && sub == 0) {
+    znew = z[h] - acc;
+    z[h] = znew;
+  }
+  if(spine) {
+    if(sub == 0) zs[rloc] = znew;
+    __syncthreads();
+    if(tid < 64) {
+      const double v = wave_bwd_chain(S, tid, zs[tid]);
+      x[p0 + tid] = v;
+    }
+  }
 }
 
 }  // namespace hiopamd
@@ -372,6 +584,9 @@ struct hiopamd_linsolver {
 static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, double* dinv, double* V, double* Dblk,
                             int* d_info, int* inertia3_host, LdltProfile* prof = nullptr)
 {
+  // Dblk: per 64-row panel a compact 64x64 copy of the factored diagonal block, followed (after all
+  // the blocks) by the per-panel 4 x 16x16 inverses
+  double* Li = Dblk + (int64_t)((N + LD_nb - 1) / LD_nb) * (LD_nb * LD_nb);
   const bool timed = prof && prof->enabled;
   auto launch_update = [&](dim3 grid, int vrow0, int urow0, int K, int s, int row_end) {
     if(timed) (void)hipEventRecord(prof->get(), ctx->stream);
@@ -397,10 +612,12 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       const int kb = (k0 + LD_nb <= N) ? LD_nb : (N - k0);
       const int ncols = N - k0 - kb;
       double* Dk = Dblk + (int64_t)(k0 / LD_nb) * (LD_nb * LD_nb);
-      hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(kBlock), 0, st, A, lda, k0, kb, dinv, Dk, d_info);
+      double* Lik = Li + (int64_t)(k0 / LD_nb) * (4 * LD_SB * LD_SB);
+      hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(kBlock), 0, st, A, lda, k0, kb, dinv, Dk, Lik, d_info);
       if(ncols > 0) {
-        const int g = (ncols + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(ldlt_trsm_kernel, dim3(g), dim3(kBlock), 0, st, A, lda, N, k0, kb, V, ldv, k0 - K0, dinv, Dk);
+        // a partial panel (kb < 64) can only be the last one, which has no columns to its right
+        const int g = (ncols + 63) / 64;
+        hipLaunchKernelGGL(ldlt_trsm_kernel, dim3(g), dim3(64), 0, st, A, lda, N, k0, V, ldv, k0 - K0, dinv, Dk, Lik);
       }
       if(k0 + kb < Kend) {
         // rows of the super-panel below this panel
@@ -434,27 +651,33 @@ static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda
                            double* rhs, int nrhs)
 {
   if(N < 0 || nrhs < 0) return HIOPAMD_ERR_ARG;
+  if(N == 0) return HIOPAMD_OK;
   hipStream_t st = ctx->stream;
+  const int nblk = (N + LD_nb - 1) / LD_nb;
   for(int j = 0; j < nrhs; ++j) {
     double* b = rhs + (int64_t)j * N;
     // forward: U^T y = b
-    for(int i0 = 0; i0 < N; i0 += LD_nb) {
-      const int ib = (i0 + LD_nb <= N) ? LD_nb : (N - i0);
-      int g = (N - i0 - ib + 63) / 64;
-      if(g < 1) g = 1;
-      hipLaunchKernelGGL(ldlt_fwd_step, dim3(g), dim3(64), 0, st, A, lda, N, i0, ib, b, ybuf);
+    {
+      const int ib0 = (N < LD_nb) ? N : LD_nb;
+      hipLaunchKernelGGL(ldlt_fwd_first, dim3(1), dim3(64), 0, st, A, lda, ib0, b, ybuf);
+      for(int I = 0; I + 1 < nblk; ++I) {
+        const int i0 = I * LD_nb;
+        const int g = (N - i0 - LD_nb + 63) / 64;
+        hipLaunchKernelGGL(ldlt_fwd_step, dim3(g), dim3(64), 0, st, A, lda, N, i0, b, ybuf);
+      }
     }
     // z = D^-1 y
     int rc = hiopamd_vec_component_mult(ctx, N, ybuf, dinv);
     if(rc != HIOPAMD_OK) return rc;
     // backward: U x = z   (x written into b)
-    const int nblk = (N + LD_nb - 1) / LD_nb;
-    for(int bI = nblk - 1; bI >= 0; --bI) {
-      const int i0 = bI * LD_nb;
-      const int ib = (i0 + LD_nb <= N) ? LD_nb : (N - i0);
-      int g = (i0 + (kBlock / 8) - 1) / (kBlock / 8);
-      if(g < 1) g = 1;
-      hipLaunchKernelGGL(ldlt_bwd_step, dim3(g), dim3(kBlock), 0, st, A, lda, N, i0, ib, ybuf, b);
+    {
+      const int iL = (nblk - 1) * LD_nb;
+      hipLaunchKernelGGL(ldlt_bwd_first, dim3(1), dim3(kBlock), 0, st, A, lda, iL, N - iL, ybuf, b);
+      for(int I = nblk - 1; I >= 1; --I) {
+        const int i0 = I * LD_nb;
+        const int ib = (i0 + LD_nb <= N) ? LD_nb : (N - i0);
+        hipLaunchKernelGGL(ldlt_bwd_step, dim3(I), dim3(kBlock), 0, st, A, lda, i0, ib, ybuf, b);
+      }
     }
   }
   HIOPAMD_CHECK(hipGetLastError());
@@ -468,7 +691,7 @@ int hiopamd_ldlt_factor(hiopamd_ctx* ctx, int n, double* A, int64_t lda, double*
   // workspace: V panel (LD_NB x n) + info flags from the context's grow-only buffer
   const size_t nn = (size_t)(n > 0 ? n : 1);
   const size_t vbytes = sizeof(double) * (size_t)LD_NB * nn;
-  const size_t dbytes = sizeof(double) * (size_t)LD_nb * LD_nb * ((nn + LD_nb - 1) / LD_nb);
+  const size_t dbytes = sizeof(double) * (size_t)(LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb);
   char* w = (char*)ctx_workspace(ctx, vbytes + dbytes + 64);
   return ldlt_factor_impl(ctx, n, A, lda, work_dinv, (double*)w, (double*)(w + vbytes), (int*)(w + vbytes + dbytes),
                           inertia3_host);
@@ -492,7 +715,7 @@ int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
   HIOPAMD_CHECK(hipMalloc((void**)&ls->dinv, sizeof(double) * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * LD_nb * LD_nb * ((nn + LD_nb - 1) / LD_nb)));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb)));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
   HIOPAMD_CHECK(hipMemsetAsync(ls->M, 0, sizeof(double) * nn * nn, ctx->stream));
   *out = ls;

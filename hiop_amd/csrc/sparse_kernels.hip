@@ -61,6 +61,52 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_rows(int nrows, int nnz, cons
   if(lane == 0) y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
 }
 
+// few-row matrices (e.g. the 3 inequality rows of MdsEx1, one of them with n_s/2 entries): every row is cut
+// into SPMV_SPLIT slices, one workgroup per (row, slice); the slice sums are folded in slice order.
+constexpr int SPMV_SPLIT = 16;
+__global__ __launch_bounds__(kBlock) void coo_spmv_rows_split(int nrows, int nnz, const int* __restrict__ iRow,
+                                                              const int* __restrict__ jCol,
+                                                              const double* __restrict__ val,
+                                                              const double* __restrict__ x, double* __restrict__ part)
+{
+  const int row = blockIdx.x / SPMV_SPLIT, sl = blockIdx.x % SPMV_SPLIT;
+  int lo = 0, hi = nnz;
+  while(lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if(iRow[mid] < row) lo = mid + 1;
+    else hi = mid;
+  }
+  const int start = lo;
+  hi = nnz;
+  while(lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if(iRow[mid] <= row) lo = mid + 1;
+    else hi = mid;
+  }
+  const int end = lo;
+  const int len = end - start;
+  const int chunk = (len + SPMV_SPLIT - 1) / SPMV_SPLIT;
+  const int b0 = start + sl * chunk;
+  int b1 = b0 + chunk;
+  if(b1 > end) b1 = end;
+  double acc = 0.0;
+  for(int k = b0 + threadIdx.x; k < b1; k += kBlock) acc += x[jCol[k]] * val[k];
+  for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double sm[kBlock / 64];
+  if((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if(threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+__global__ void coo_spmv_fold(int nrows, const double* __restrict__ part, double beta, double* __restrict__ y,
+                              double alpha)
+{
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if(row >= nrows) return;
+  double s = 0.0;
+  for(int q = 0; q < SPMV_SPLIT; ++q) s += part[row * SPMV_SPLIT + q];
+  y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * s;
+}
+
 __global__ __launch_bounds__(kBlock) void coo_spmv_trans_scatter(int nnz, const int* __restrict__ iRow,
                                                                  const int* __restrict__ jCol,
                                                                  const double* __restrict__ val, double* __restrict__ y,
@@ -163,6 +209,14 @@ int hiopamd_sp_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const 
   (void)ncols;
   if(nrows < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
   if(nrows == 0) return HIOPAMD_OK;
+  if(nrows <= 256 && nnz > 64 * nrows) {
+    double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nrows * SPMV_SPLIT);
+    hipLaunchKernelGGL(coo_spmv_rows_split, dim3(nrows * SPMV_SPLIT), dim3(kBlock), 0, ctx->stream, nrows, nnz, iRow,
+                       jCol, val, x, part);
+    hipLaunchKernelGGL(coo_spmv_fold, dim3((nrows + 63) / 64), dim3(64), 0, ctx->stream, nrows, part, beta, y, alpha);
+    HIOPAMD_CHECK(hipGetLastError());
+    return HIOPAMD_OK;
+  }
   const int64_t threads = (int64_t)nrows * 64;
   hipLaunchKernelGGL(coo_spmv_rows, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
                      nrows, nnz, iRow, jCol, val, beta, y, alpha, x);

@@ -22,6 +22,7 @@ class LinSolverSymDense:
         h = C.c_void_p()
         check(self._L.hiopamd_linsolver_create(C.byref(h), ctx.h, n), "hiopamd_linsolver_create")
         self.h = h
+        ctx._register(self)
 
     def sys_matrix_ptr(self) -> int:
         return self._L.hiopamd_linsolver_sys_matrix(self.h)
@@ -58,7 +59,8 @@ class LinSolverSymDense:
 
     def close(self):
         if self.h is not None:
-            self._L.hiopamd_linsolver_destroy(self.h)
+            if self.ctx.h is not None:
+                self._L.hiopamd_linsolver_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -95,6 +97,7 @@ class KKTLinSysCompressedMDSXYcYd:
         check(self._L.hiopamd_kkt_mds_create(C.byref(h), ctx.h, C.byref(s)), "hiopamd_kkt_mds_create")
         self.h = h
         self._vals = None
+        ctx._register(self)
 
     def set_values(self, Jcs_val, Jds_val, Hss_val, Jcd, Jdd, Hdd, Dx, Dd):
         """All arguments are device fp64 tensors; they are borrowed (kept alive here) until the next call."""
@@ -133,7 +136,8 @@ class KKTLinSysCompressedMDSXYcYd:
 
     def close(self):
         if self.h is not None:
-            self._L.hiopamd_kkt_mds_destroy(self.h)
+            if self.ctx.h is not None:
+                self._L.hiopamd_kkt_mds_destroy(self.h)
             self.h = None
 
     def __del__(self):

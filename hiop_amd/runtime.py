@@ -47,12 +47,23 @@ class Context:
         self.h = h
         self.stream_ptr = self._L.hiopamd_ctx_stream(self.h)
         self.torch_stream = torch.cuda.ExternalStream(self.stream_ptr)
+        self._children = []   # weakrefs of objects holding C handles that reference this context
+
+    def _register(self, obj):
+        import weakref
+        self._children.append(weakref.ref(obj))
 
     def sync(self):
         check(self._L.hiopamd_ctx_sync(self.h), "hiopamd_ctx_sync")
 
     def close(self):
         if self.h is not None:
+            # destroy dependants first: their C structs keep a pointer to this context
+            for w in self._children:
+                o = w()
+                if o is not None:
+                    o.close()
+            self._children = []
             self._L.hiopamd_ctx_destroy(self.h)
             self.h = None
 

@@ -202,11 +202,12 @@ int hiopamd_mat_is_finite(hiopamd_ctx*, int m, int64_t n, const double* A, int64
  * (reference: src/Optimization/hiopHessianLowRank.cpp:1079 symmMatTimesDiagTimesMatTrans_local,
  *  :1119 matTimesDiagTimesMatTrans_local).  fp64 MFMA (v_mfma_f64_16x16x4_f64).
  * W(ma x mb) = beta*W + alpha * A(ma x n) * diag(d) * B(mb x n)^T ; d may be NULL (= ones).
- * If A==B && sym_upper!=0 only the upper triangle of W is written (reference :1079 semantics).
+ * If A==B && sym!=0 only the upper triangle is computed and it is mirrored onto the lower one
+ * (reference :1079-1108: W[i][j] = W[j][i] = beta*W[i][j] + alpha*acc for j >= i).
  * ===================================================================================== */
 int hiopamd_gram_weighted(hiopamd_ctx*, int ma, int mb, int64_t n, const double* A, int64_t lda, const double* B,
                           int64_t ldb, const double* d, double beta, double* W, int64_t ldw, double alpha,
-                          int sym_upper);
+                          int sym);
 
 /* =====================================================================================
  * hiopMatrixSparseTriplet (row-sorted COO, int32 indices)

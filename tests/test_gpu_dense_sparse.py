@@ -105,10 +105,10 @@ def test_gram_weighted_mfma(ctx, ma, mb, n):
         W0 = r.uniform(-1, 1, (ma, ma))
         Wd = D(W0)
         run(ctx, "hiopamd_gram_weighted", ma, ma, n, Ad, n, Ad, n, D(d), 1.0, Wd, ma, -1.0, 1)
-        e = W0 - np.triu((A * d) @ A.T)   # lower triangle untouched (reference :1079 semantics)
+        e = W0.copy(); ho.symm_mat_times_diag_times_mat_trans_local(1.0, e, -1.0, A, d)   # both triangles (:1079)
         got = Wd.cpu().numpy()
-        np.testing.assert_allclose(np.triu(got), np.triu(e), rtol=1e-11, atol=1e-10)
-        np.testing.assert_array_equal(np.tril(got, -1), np.tril(W0, -1))
+        np.testing.assert_allclose(got, e, rtol=1e-11, atol=1e-10)
+        np.testing.assert_array_equal(got, got.T)
 
 
 def test_assembly_kernels(ctx):

@@ -178,7 +178,7 @@ def test_kkt_mds_assemble_factor_solve(ctx, mk, deltas):
     # fp64 tolerance on the KKT residual of the UNcondensed system (north_star's parity statement)
     res = ho.kkt_mds_full_residual(ko, deltas, rx, ryc, ryd, dx, dyc, dyd)
     res_o = ho.kkt_mds_full_residual(ko, deltas, rx, ryc, ryd, dx_o, dyc_o, dyd_o)
-    assert max(res) < 1e-10, (res, res_o)
+    assert max(res) < 1e-12, (res, res_o)   # componentwise backward error
     scale = max(np.abs(dx_o).max(), np.abs(dyc_o).max(), np.abs(dyd_o).max())
     assert np.abs(dx - dx_o).max() / scale < 1e-8
     assert np.abs(dyc - dyc_o).max() / scale < 1e-8
@@ -223,5 +223,5 @@ def test_kkt_mds_full_size_roundtrip(ctx):
     torch.cuda.synchronize()
     kg.solve_compressed(rxd, rycd, rydd, dx, dyc, dyd); ctx.sync()
     res = ho.kkt_mds_full_residual(ko, deltas, rx, ryc, ryd, dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy())
-    assert max(res) < 1e-9, res
+    assert max(res) < 1e-11, res   # componentwise backward error of the uncondensed system
     kg.close()
