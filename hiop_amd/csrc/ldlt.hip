@@ -38,6 +38,28 @@ constexpr int LD_LDP = LD_TM + 16;  // padded LDS row stride (doubles): rows k,k
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// wave-uniform broadcast of lane `src` (a compile-time constant after unrolling): two v_readlane_b32
+// into SGPRs instead of a ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ double bcast_lane(double v, int src)
+{
+  union {
+    double d;
+    int i[2];
+  } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
+// reciprocal: v_rcp_f64 seed + one Newton step (error <= 1 ulp; the factor is checked by residual tests)
+__device__ __forceinline__ double fast_rcp(double d)
+{
+  double x = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, x, 1.0);
+  x = fma(x, e, x);
+  return x;
+}
+
 // ------------------------------------------------------------------------------------------
 // diag kernel: LDL^T of the kb x kb (<=64) diagonal block by ONE workgroup, blocked by 16:
 //   (i)   the 16x16 diagonal sub-block is factored by wave 0 entirely in registers (4 entries per
@@ -59,11 +81,21 @@ __global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ 
   __shared__ double S[LD_nb][LD_nb + 1];
   __shared__ double sdinv[LD_nb];
   const int tid = threadIdx.x;
-  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
-    const int r = e >> 6, c = e & 63;
-    double v = 0.0;
-    if(r < kb && c < kb && c >= r) v = A[(int64_t)(k0 + r) * lda + (k0 + c)];
-    S[r][c] = v;
+  {
+    double sv[LD_nb * LD_nb / kBlock];
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      const int r = e >> 6, c = e & 63;
+      const int rr = (r < kb) ? r : (kb - 1), cc = (c < kb) ? c : (kb - 1);
+      const double t = A[(int64_t)(k0 + rr) * lda + (k0 + cc)];   // unconditional clamped load + select
+      sv[q] = (r < kb && c < kb && c >= r) ? t : 0.0;
+    }
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      S[e >> 6][e & 63] = sv[q];
+    }
   }
   if(tid < LD_nb) sdinv[tid] = 1.0;
   __syncthreads();
@@ -71,30 +103,22 @@ __global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ 
   for(int sb = 0; sb < LD_nb / LD_SB; ++sb) {
     const int o = sb * LD_SB;
     if(o >= kb) break;  // uniform
-    // ---- (i) 16x16 diagonal sub-block in registers of wave 0: lane = 4*row + quarter
+    // ---- (i) 16x16 diagonal sub-block in registers of wave 0: lane c (< 16) holds column c
     if(tid < 64) {
-      const int r = tid >> 2, cq = tid & 3;
-      double a[4];
+      const int c = tid & 15;
+      double a[LD_SB];
 #pragma unroll
-      for(int j = 0; j < 4; ++j) a[j] = S[o + r][o + cq * 4 + j];
+      for(int r = 0; r < LD_SB; ++r) a[r] = S[o + r][o + c];   // zeros below the diagonal
 #pragma unroll
       for(int k = 0; k < LD_SB; ++k) {
         if(o + k < kb) {  // uniform
-          double pk[4];
+          const double d = bcast_lane(a[k], k);          // pivot S[k][k]
+          const double di = fast_rcp(d);
+          const double ukc = a[k] * di;                  // scaled pivot-row entry of my column
 #pragma unroll
-          for(int j = 0; j < 4; ++j) pk[j] = __shfl(a[j], k * 4 + cq, 64);  // pivot row, my 4 columns
-          const double d = __shfl(a[k & 3], k * 4 + (k >> 2), 64);           // pivot
-          const double di = 1.0 / d;
-          // multiplier S[k][r] lives in lane 4k + (r>>2), element r&3
-          const int src = k * 4 + (r >> 2);
-          const double t0 = __shfl(a[0], src, 64), t1 = __shfl(a[1], src, 64);
-          const double t2 = __shfl(a[2], src, 64), t3 = __shfl(a[3], src, 64);
-          const int rq = r & 3;
-          const double vkr = rq == 0 ? t0 : (rq == 1 ? t1 : (rq == 2 ? t2 : t3));
-          if(r > k) {
-#pragma unroll
-            for(int j = 0; j < 4; ++j)
-              if(cq * 4 + j >= r) a[j] -= vkr * (pk[j] * di);
+          for(int r = k + 1; r < LD_SB; ++r) {
+            const double vkr = bcast_lane(a[k], r);      // S[k][r] = pivot-row entry of column r
+            a[r] = fma(-vkr, ukc, a[r]);
           }
           if(tid == 0) {
             sdinv[o + k] = di;
@@ -102,9 +126,11 @@ __global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ 
           }
         }
       }
+      if(tid < LD_SB) {
 #pragma unroll
-      for(int j = 0; j < 4; ++j)
-        if(cq * 4 + j >= r) S[o + r][o + cq * 4 + j] = a[j];
+        for(int r = 0; r < LD_SB; ++r)
+          if(c >= r) S[o + r][o + c] = a[r];
+      }
     }
     __syncthreads();
     // ---- (ii) row panel: columns c >= o+16, one per thread; x_r -= S[o+s][o+r] * (x_s/d_s)
@@ -270,9 +296,34 @@ __global__ __launch_bounds__(64) void ldlt_trsm_kernel(double* __restrict__ A, i
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restrict__ A, int64_t lda, int N,
                                                                 const double* __restrict__ V, int64_t ldv, int vrow0,
-                                                                int urow0, int K, int s, int row_end)
+                                                                int urow0, int K, int s, int row_end, int xcd_map)
 {
-  const int ti = blockIdx.y, tj = blockIdx.x;
+  int ti, tj;
+  if(xcd_map) {
+    // 1-D grid over the upper-triangular tile domain, XCD-aware: workgroup b runs on XCD b%8 (observed
+    // dispatch order; a different placement only costs speed).  The tile domain is cut into 8x8-tile
+    // super-tiles; super-tile k goes to XCD k%8 and the 64 workgroups an XCD holds at a time (32 CUs x 2)
+    // walk ONE super-tile, so its 8+8 panel blocks are fetched once into that XCD's L2 and shared.
+    const int T = xcd_map;                 // tiles per side
+    const int Sside = (T + 7) >> 3;        // super-tiles per side
+    const int nS = Sside * (Sside + 1) / 2;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int k = (q >> 6) * 8 + xcd;
+    if(k >= nS) return;
+    // k -> (Si, Sj), Sj >= Si, rows of the triangle have lengths Sside, Sside-1, ...
+    int Si = (int)((2.0 * Sside + 1.0 - sqrt((2.0 * Sside + 1.0) * (2.0 * Sside + 1.0) - 8.0 * k)) * 0.5);
+    while(Si > 0 && Si * Sside - Si * (Si - 1) / 2 > k) --Si;
+    while((Si + 1) * Sside - (Si + 1) * Si / 2 <= k) ++Si;
+    const int Sj = Si + (k - (Si * Sside - Si * (Si - 1) / 2));
+    const int t = q & 63;
+    ti = Si * 8 + (t >> 3);
+    tj = Sj * 8 + (t & 7);
+    if(ti >= T || tj >= T) return;
+  } else {
+    ti = blockIdx.y;
+    tj = blockIdx.x;
+  }
   if(tj < ti) return;
   const int r0 = s + ti * LD_TM, c0 = s + tj * LD_TN;
   if(r0 >= row_end || c0 >= N) return;
@@ -330,19 +381,32 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
         for(int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-  // epilogue: C -= acc on the upper triangle
+  // epilogue: C -= acc on the upper triangle.  All 16 loads of a row-group are issued before the first
+  // store (the compiler cannot reorder a load above a possibly-aliasing store, which would otherwise turn
+  // the 64 read-modify-writes into 64 serialized memory round trips).
 #pragma unroll
   for(int i = 0; i < 4; ++i) {
+    double cv[4][4];
+    bool ok[4][4];
 #pragma unroll
     for(int reg = 0; reg < 4; ++reg) {
       const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
-      if(row < row_end) {
-        double* Crow = A + (int64_t)row * lda;
+      const double* Crow = A + (int64_t)row * lda;
 #pragma unroll
-        for(int j = 0; j < 4; ++j) {
-          const int col = c0 + wc * 64 + j * 16 + li;
-          if(col < N && col >= row) Crow[col] -= acc[i][j][reg];
-        }
+      for(int j = 0; j < 4; ++j) {
+        const int col = c0 + wc * 64 + j * 16 + li;
+        ok[reg][j] = (row < row_end) && (col < N) && (col >= row);
+        cv[reg][j] = ok[reg][j] ? Crow[col] : 0.0;
+      }
+    }
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
+      double* Crow = A + (int64_t)row * lda;
+#pragma unroll
+      for(int j = 0; j < 4; ++j) {
+        const int col = c0 + wc * 64 + j * 16 + li;
+        if(ok[reg][j]) Crow[col] = cv[reg][j] - acc[i][j][reg];
       }
     }
   }
@@ -396,7 +460,7 @@ __device__ __forceinline__ double wave_fwd_chain(const double (&u)[LD_nb], doubl
 {
 #pragma unroll
   for(int s2 = 0; s2 < LD_nb; ++s2) {
-    const double ys = __shfl(v, s2, 64);
+    const double ys = bcast_lane(v, s2);
     v = fma(-u[s2], ys, v);
   }
   return v;
@@ -408,7 +472,16 @@ __global__ __launch_bounds__(64) void ldlt_fwd_first(const double* __restrict__ 
   const int lane = threadIdx.x;
   double u[LD_nb];
 #pragma unroll
-  for(int s2 = 0; s2 < LD_nb; ++s2) u[s2] = (s2 < lane && lane < ib) ? A[(int64_t)s2 * lda + lane] : 0.0;
+  for(int s2 = 0; s2 < LD_nb; ++s2) {
+    const int rr = (s2 < ib) ? s2 : (ib - 1);
+    const int cc = (lane < ib) ? lane : (ib - 1);
+    u[s2] = A[(int64_t)rr * lda + cc];
+  }
+#pragma unroll
+  for(int s2 = 0; s2 < LD_nb; ++s2) {
+    asm volatile("" : "+v"(u[s2]));
+    u[s2] = (s2 < lane && lane < ib) ? u[s2] : 0.0;
+  }
   double v = (lane < ib) ? b[lane] : 0.0;
   v = wave_fwd_chain(u, v);
   if(lane < ib) y[lane] = v;
@@ -423,24 +496,45 @@ __global__ __launch_bounds__(64) void ldlt_fwd_step(const double* __restrict__ A
   const int j0 = i0 + LD_nb;
   const int jb = (N - j0 < LD_nb) ? (N - j0) : LD_nb;
   const bool spine = (blockIdx.x == 0);
+  const double yI = y[i0 + lane];   // issued first: vmcnt retires in order, so this wait does not cover the loads below
   double u[LD_nb];
   if(spine) {
 #pragma unroll
-    for(int s2 = 0; s2 < LD_nb; ++s2) u[s2] = (s2 < lane && lane < jb) ? A[(int64_t)(j0 + s2) * lda + (j0 + lane)] : 0.0;
+    for(int s2 = 0; s2 < LD_nb; ++s2) {
+      // unconditional (clamped) loads, all 64 in flight; the select happens after the opaque barrier below
+      // (a predicated load per element compiles to 64 branches, each followed by a full vmcnt wait)
+      const int rr = (j0 + s2 < N) ? (j0 + s2) : (N - 1);
+      const int cc = (j0 + lane < N) ? (j0 + lane) : (N - 1);
+      u[s2] = A[(int64_t)rr * lda + cc];
+    }
+
   }
   __shared__ double ysh[LD_nb];
-  ysh[lane] = y[i0 + lane];
+  ysh[lane] = yI;
   __syncthreads();
   const int64_t col = (int64_t)j0 + (int64_t)blockIdx.x * 64 + lane;
   double acc = 0.0;
   if(col < N) {
     acc = b[col];
     const double* Ac = A + (int64_t)i0 * lda + col;
-#pragma unroll 16
-    for(int s2 = 0; s2 < LD_nb; ++s2) acc = fma(-Ac[(int64_t)s2 * lda], ysh[s2], acc);
+    // 64 independent loads in flight (4 batches of 16 staged in registers) before the FMA chain
+#pragma unroll
+    for(int sb = 0; sb < LD_nb; sb += 16) {
+      double av[16];
+#pragma unroll
+      for(int q = 0; q < 16; ++q) av[q] = Ac[(int64_t)(sb + q) * lda];
+#pragma unroll
+      for(int q = 0; q < 16; ++q) acc = fma(-av[q], ysh[sb + q], acc);
+    }
     b[col] = acc;
   }
   if(spine) {
+    // the 64 factor loads issued at kernel entry are consumed only here
+#pragma unroll
+    for(int s2 = 0; s2 < LD_nb; ++s2) {
+      asm volatile("" : "+v"(u[s2]));
+      u[s2] = (s2 < lane && lane < jb) ? u[s2] : 0.0;
+    }
     const double v = wave_fwd_chain(u, acc);   // acc == 0 for lanes >= jb
     if(lane < jb) y[j0 + lane] = v;
   }
@@ -454,7 +548,7 @@ __device__ __forceinline__ double wave_bwd_chain(const double (*S)[LD_nb + 1], i
   for(int c = 0; c < LD_nb; ++c) srow[c] = S[lane][c];
 #pragma unroll
   for(int c = LD_nb - 1; c >= 0; --c) {
-    const double xc = __shfl(v, c, 64);
+    const double xc = bcast_lane(v, c);
     v = fma(-srow[c], xc, v);   // srow[c] == 0 unless c > lane
   }
   return v;
@@ -465,9 +559,21 @@ __global__ __launch_bounds__(kBlock) void ldlt_bwd_first(const double* __restric
 {
   __shared__ double S[LD_nb][LD_nb + 1];
   const int tid = threadIdx.x;
-  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
-    const int r = e >> 6, c = e & 63;
-    S[r][c] = (r < ib && c < ib && c > r) ? A[(int64_t)(i0 + r) * lda + (i0 + c)] : 0.0;
+  {
+    double sv[LD_nb * LD_nb / kBlock];
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      const int r = e >> 6, c = e & 63;
+      const int rr = (r < ib) ? r : (ib - 1), cc = (c < ib) ? c : (ib - 1);
+      const double t = A[(int64_t)(i0 + rr) * lda + (i0 + cc)];
+      sv[q] = (r < ib && c < ib && c > r) ? t : 0.0;
+    }
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      S[e >> 6][e & 63] = sv[q];
+    }
   }
   __syncthreads();
   if(tid < 64) {
@@ -489,9 +595,18 @@ __global__ __launch_bounds__(kBlock) void ldlt_bwd_step(const double* __restrict
   const bool spine = (blockIdx.x == 0);
   const int p0 = i0 - LD_nb;  // previous diagonal block (always a full one)
   if(spine) {
-    for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
+    double sv[LD_nb * LD_nb / kBlock];
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
       const int r = e >> 6, c = e & 63;
-      S[r][c] = (c > r) ? A[(int64_t)(p0 + r) * lda + (p0 + c)] : 0.0;
+      const double t = A[(int64_t)(p0 + r) * lda + (p0 + c)];
+      sv[q] = (c > r) ? t : 0.0;
+    }
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      S[e >> 6][e & 63] = sv[q];
     }
   }
   if(tid < LD_nb) xs[tid] = (tid < ib) ? x[i0 + tid] : 0.0;
@@ -501,11 +616,11 @@ __global__ __launch_bounds__(kBlock) void ldlt_bwd_step(const double* __restrict
   double acc = 0.0;
   if(h >= 0) {
     const double* Ah = A + h * lda + i0 + sub * 16;
+    double av[16];
 #pragma unroll
-    for(int q = 0; q < 16; ++q) {
-      const int c = sub * 16 + q;
-      if(c < ib) acc = fma(Ah[q], xs[c], acc);
-    }
+    for(int q = 0; q < 16; ++q) av[q] = (sub * 16 + q < ib) ? Ah[q] : 0.0;
+#pragma unroll
+    for(int q = 0; q < 16; ++q) acc = fma(av[q], xs[sub * 16 + q], acc);
   }
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
@@ -590,8 +705,17 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   const bool timed = prof && prof->enabled;
   auto launch_update = [&](dim3 grid, int vrow0, int urow0, int K, int s, int row_end) {
     if(timed) (void)hipEventRecord(prof->get(), ctx->stream);
+    int xcd_map = 0;
+    if(row_end == N && grid.x == grid.y && grid.x >= 16) {
+      // square trailing update: XCD-aware 1-D launch over 8x8-tile super-tiles
+      xcd_map = (int)grid.x;
+      const int Sside = (xcd_map + 7) / 8;
+      const int nS = Sside * (Sside + 1) / 2;
+      const int per_xcd = (nS + 7) / 8;           // super-tiles per XCD
+      grid = dim3((unsigned)(per_xcd * 64 * 8), 1, 1);
+    }
     hipLaunchKernelGGL(ldlt_update_kernel, grid, dim3(kBlock), 0, ctx->stream, A, lda, N, V, (int64_t)N, vrow0, urow0, K, s,
-                       row_end);
+                       row_end, xcd_map);
     if(timed) {
       (void)hipEventRecord(prof->get(), ctx->stream);
       prof->flops += update_flops(N, K, s, row_end);
