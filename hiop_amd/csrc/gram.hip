@@ -20,10 +20,18 @@ constexpr int GR_LDS = GR_KT + 2;  // 34: 16 rows x 2 k land on 32 distinct 8-by
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// stage a 128 x 32 tile of X (rows r0.., cols k0..) into LDS, optionally scaled by d[k]
-__device__ __forceinline__ void gram_stage(const double* __restrict__ X, int64_t ldx, int nrows, int r0, int64_t k0,
-                                           int64_t kend, const double* __restrict__ d, bool vec_ok,
-                                           double (*Xs)[GR_LDS], int tid)
+// B operand = up to three stacked row blocks (e.g. [X; S; Y] of the low-rank KKT: one pass over the long
+// dimension yields X D X^T, X D S^T and X D Y^T together)
+struct GramRows {
+  const double* p[3];
+  int64_t ld[3];
+  int rows[3];   // cumulative END row of each segment
+};
+
+// stage a 128 x 32 tile of the stacked matrix (rows r0.., cols k0..) into LDS, optionally scaled by d[k].
+// All 8 row loads are issued (unconditionally, clamped) before the first LDS store.
+__device__ __forceinline__ void gram_stage(const GramRows X, int nrows, int r0, int64_t k0, int64_t kend,
+                                           const double* __restrict__ d, bool vec_ok, double (*Xs)[GR_LDS], int tid)
 {
   const int kk = (tid & 15) * 2;
   const int64_t k = k0 + kk;
@@ -32,33 +40,42 @@ __device__ __forceinline__ void gram_stage(const double* __restrict__ X, int64_t
     w0 = (k < kend) ? d[k] : 0.0;
     w1 = (k + 1 < kend) ? d[k + 1] : 0.0;
   }
+  const bool k0ok = k < kend, k1ok = k + 1 < kend;
+  const int64_t kc0 = k0ok ? k : (kend - 1), kc1 = k1ok ? (k + 1) : (kend - 1);
 #pragma unroll
-  for(int p = 0; p < 8; ++p) {
-    const int r = p * 16 + (tid >> 4);
-    const int gr = r0 + r;
-    double v0 = 0.0, v1 = 0.0;
-    if(gr < nrows) {
-      const double* src = X + (int64_t)gr * ldx + k;
-      if(vec_ok && k + 1 < kend) {
-        const double2 t = *reinterpret_cast<const double2*>(src);
-        v0 = t.x;
-        v1 = t.y;
+  for(int hb = 0; hb < 8; hb += 4) {   // two batches of 4 rows: 4 (x2) independent loads in flight each
+    double v0[4], v1[4];
+#pragma unroll
+    for(int p = 0; p < 4; ++p) {
+      const int gr = r0 + (hb + p) * 16 + (tid >> 4);
+      const int grc = (gr < nrows) ? gr : (nrows - 1);
+      const int seg = (grc < X.rows[0]) ? 0 : ((grc < X.rows[1]) ? 1 : 2);
+      const int base = (seg == 0) ? 0 : X.rows[seg - 1];
+      const double* src = X.p[seg] + (int64_t)(grc - base) * X.ld[seg];
+      if(vec_ok && k1ok) {
+        const double2 t = *reinterpret_cast<const double2*>(src + k);
+        v0[p] = t.x;
+        v1[p] = t.y;
       } else {
-        if(k < kend) v0 = src[0];
-        if(k + 1 < kend) v1 = src[1];
+        v0[p] = src[kc0];
+        v1[p] = src[kc1];
       }
     }
-    Xs[r][kk] = v0 * w0;
-    Xs[r][kk + 1] = v1 * w1;
+#pragma unroll
+    for(int p = 0; p < 4; ++p) {
+      const int r = (hb + p) * 16 + (tid >> 4);
+      const bool rok = (r0 + r) < nrows;
+      Xs[r][kk] = (rok && k0ok) ? v0[p] * w0 : 0.0;
+      Xs[r][kk + 1] = (rok && k1ok) ? v1[p] * w1 : 0.0;
+    }
   }
 }
 
 // partial[split][tile][128][128] (dense 128x128 slabs; only the valid part is read back)
-__global__ __launch_bounds__(kBlock, 2) void gram_partial_kernel(int ma, int mb, int64_t n, const double* __restrict__ A,
-                                                                 int64_t lda, const double* __restrict__ B,
-                                                                 int64_t ldb, const double* __restrict__ d,
-                                                                 int64_t kchunk, int tiles_b, int sym,
-                                                                 double* __restrict__ partial)
+__global__ __launch_bounds__(kBlock, 2) void gram_partial_kernel(int ma, int mb, int64_t n, const GramRows A,
+                                                                 const GramRows B, int same_ab, int vec_all,
+                                                                 const double* __restrict__ d, int64_t kchunk,
+                                                                 int tiles_b, int sym, double* __restrict__ partial)
 {
   const int tile = blockIdx.y;
   const int ta = tile / tiles_b, tb = tile % tiles_b;
@@ -72,9 +89,8 @@ __global__ __launch_bounds__(kBlock, 2) void gram_partial_kernel(int ma, int mb,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int lk = lane >> 4, li = lane & 15;
-  const bool a_vec = ((lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0);
-  const bool b_vec = ((ldb & 1) == 0) && ((((uintptr_t)B) & 15) == 0);
-  const bool same = sym && (ta == tb) && (A == B);
+  const bool a_vec = vec_all != 0, b_vec = vec_all != 0;
+  const bool same = sym && (ta == tb) && same_ab;
 
   double4_t acc[4][4];
 #pragma unroll
@@ -85,9 +101,9 @@ __global__ __launch_bounds__(kBlock, 2) void gram_partial_kernel(int ma, int mb,
   for(int64_t k0 = kbeg; k0 < kend; k0 += GR_KT) {
     __syncthreads();
     // the weight goes on the A side only; the un-weighted symmetric diagonal tile re-uses As for B
-    gram_stage(A, lda, ma, ta * GR_T, k0, kend, d, a_vec, As, tid);
+    gram_stage(A, ma, ta * GR_T, k0, kend, d, a_vec, As, tid);
     const bool reuse = same && (d == nullptr);
-    if(!reuse) gram_stage(B, ldb, mb, tb * GR_T, k0, kend, nullptr, b_vec, Bs, tid);
+    if(!reuse) gram_stage(B, mb, tb * GR_T, k0, kend, nullptr, b_vec, Bs, tid);
     __syncthreads();
     const double(*Bsrc)[GR_LDS] = reuse ? As : Bs;
 #pragma unroll
@@ -142,13 +158,21 @@ __global__ __launch_bounds__(kBlock) void gram_fold_kernel(int ma, int mb, int n
 
 using namespace hiopamd;
 
-extern "C" int hiopamd_gram_weighted(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const double* A, int64_t lda,
-                                     const double* B, int64_t ldb, const double* d, double beta, double* W,
-                                     int64_t ldw, double alpha, int sym)
+static bool seg_vec_ok(const GramRows& R, int nseg)
+{
+  for(int q = 0; q < nseg; ++q)
+    if((R.ld[q] & 1) != 0 || (((uintptr_t)R.p[q]) & 15) != 0) return false;
+  return true;
+}
+
+// W(ma x mb) = beta*W + alpha * A diag(d) [B0;B1;B2]^T
+static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRows& A, int nsegA, const GramRows& B,
+                       int nsegB, bool same_ab, const double* d, double beta, double* W, int64_t ldw, double alpha,
+                       int sym)
 {
   if(ma < 0 || mb < 0 || n < 0) return HIOPAMD_ERR_ARG;
   if(ma == 0 || mb == 0) return HIOPAMD_OK;
-  const int symm = (sym && A == B && ma == mb) ? 1 : 0;
+  const int symm = (sym && same_ab && ma == mb) ? 1 : 0;
   const int tiles_a = (ma + GR_T - 1) / GR_T, tiles_b = (mb + GR_T - 1) / GR_T;
   const int ntiles = tiles_a * tiles_b;
   // K split: aim at ~2 workgroups per CU (512) over all tiles, chunk a multiple of the stage depth
@@ -160,11 +184,36 @@ extern "C" int hiopamd_gram_weighted(hiopamd_ctx* ctx, int ma, int mb, int64_t n
   nsplit = (int)((n + kchunk - 1) / kchunk);
   if(nsplit < 1) nsplit = 1;
   double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * ntiles * GR_T * GR_T);
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, lda, B, ldb,
-                     d, kchunk, tiles_b, symm, partial);
+  const int vec_all = (seg_vec_ok(A, nsegA) && seg_vec_ok(B, nsegB)) ? 1 : 0;
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, B,
+                     same_ab ? 1 : 0, vec_all, d, kchunk, tiles_b, symm, partial);
   const int64_t tot = (int64_t)ma * mb;
   hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ma,
                      mb, nsplit, ntiles, tiles_b, symm, partial, beta, W, ldw, alpha);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
+}
+
+extern "C" int hiopamd_gram_weighted(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const double* A, int64_t lda,
+                                     const double* B, int64_t ldb, const double* d, double beta, double* W,
+                                     int64_t ldw, double alpha, int sym)
+{
+  GramRows Ra{{A, A, A}, {lda, lda, lda}, {ma, ma, ma}};
+  GramRows Rb{{B, B, B}, {ldb, ldb, ldb}, {mb, mb, mb}};
+  return gram_launch(ctx, ma, mb, n, Ra, 1, Rb, 1, A == B && lda == ldb, d, beta, W, ldw, alpha, sym);
+}
+
+// W(ma x (m0+m1+m2)) = beta*W + alpha * A diag(d) [B0;B1;B2]^T in ONE pass over the long dimension
+extern "C" int hiopamd_gram_weighted_stacked(hiopamd_ctx* ctx, int ma, int64_t n, const double* A, int64_t lda, int m0,
+                                             const double* B0, int64_t ldb0, int m1, const double* B1, int64_t ldb1,
+                                             int m2, const double* B2, int64_t ldb2, const double* d, double beta,
+                                             double* W, int64_t ldw, double alpha)
+{
+  if(m0 < 0 || m1 < 0 || m2 < 0) return HIOPAMD_ERR_ARG;
+  GramRows Ra{{A, A, A}, {lda, lda, lda}, {ma, ma, ma}};
+  // empty segments borrow a valid pointer so the clamped loads stay in bounds
+  const double* q1 = m1 > 0 ? B1 : B0;
+  const double* q2 = m2 > 0 ? B2 : q1;
+  GramRows Rb{{B0, q1, q2}, {ldb0, m1 > 0 ? ldb1 : ldb0, m2 > 0 ? ldb2 : (m1 > 0 ? ldb1 : ldb0)}, {m0, m0 + m1, m0 + m1 + m2}};
+  return gram_launch(ctx, ma, m0 + m1 + m2, n, Ra, 1, Rb, 3, false, d, beta, W, ldw, alpha, 0);
 }

@@ -154,3 +154,125 @@ def mds_from_problem(ctx: Context, p) -> tuple["KKTLinSysCompressedMDSXYcYd", di
                                     (p.Hss_i, p.Hss_j))
     d = dict(Jcs_v=dev(p.Jcs_v), Jds_v=dev(p.Jds_v), Hss_v=dev(p.Hss_v), Jcd=dev(p.Jcd), Jdd=dev(p.Jdd), Hdd=dev(p.Hdd))
     return k, d
+
+
+_SIGMA = {"sty": 1, "sty_inv": 2, "snrm_ynrm": 3, "sty_srnm_ynrm": 4, "sigma0": 5}
+
+
+class HessianLowRank:
+    """Device-resident compact L-BFGS Hessian (mirrors hiopHessianLowRank, src/Optimization/hiopHessianLowRank.hpp)."""
+
+    def __init__(self, ctx: Context, n_local: int, m_eq: int, m_ineq: int, l_max: int = 6, sigma0: float = 1.0,
+                 sigma_update_strategy: str = "sigma0"):
+        self.ctx, self.n, self.m_eq, self.m_ineq, self.l_max = ctx, n_local, m_eq, m_ineq, l_max
+        self._L = lib()
+        h = C.c_void_p()
+        check(self._L.hiopamd_hess_lowrank_create(C.byref(h), ctx.h, n_local, m_eq, m_ineq, l_max, sigma0,
+                                                  _SIGMA[sigma_update_strategy]), "hiopamd_hess_lowrank_create")
+        self.h = h
+        ctx._register(self)
+
+    def update(self, x, grad_f, Jc, Jd, yc, yd) -> bool:
+        stored = C.c_int(0)
+        check(self._L.hiopamd_hess_lowrank_update(self.h, dptr(x), dptr(grad_f), dptr(Jc), dptr(Jd), dptr(yc), dptr(yd),
+                                                  C.byref(stored)), "hiopamd_hess_lowrank_update")
+        return bool(stored.value)
+
+    def update_log_barrier_diagonal(self, Dx):
+        check(self._L.hiopamd_hess_lowrank_update_log_barrier_diagonal(self.h, dptr(Dx)), "update_log_barrier_diagonal")
+
+    def solve(self, rhs, x):
+        check(self._L.hiopamd_hess_lowrank_solve(self.h, dptr(rhs), dptr(x)), "hiopamd_hess_lowrank_solve")
+
+    def sym_mat_times_inverse_times_mat_trans(self, beta, W, alpha, X):
+        k = W.shape[0]
+        work = torch.empty(k * (k + 2 * self.l_max) + 2 * k * self.l_max + 8, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(self.h, beta, dptr(W), k, alpha, dptr(X),
+                                                                                 dptr(work)), "symMatTimesInverseTimesMatTrans")
+        self.ctx.sync()
+
+    def times_vec(self, beta, y, alpha, x):
+        check(self._L.hiopamd_hess_lowrank_times_vec(self.h, beta, dptr(y), alpha, dptr(x)), "hiopamd_hess_lowrank_times_vec")
+
+    @property
+    def l_curr(self) -> int:
+        return self._L.hiopamd_hess_lowrank_l_curr(self.h)
+
+    @property
+    def sigma(self) -> float:
+        return self._L.hiopamd_hess_lowrank_sigma(self.h)
+
+    def _rows(self, ptr):
+        l = self.l_curr
+        out = torch.empty((l, self.n), dtype=torch.float64, device="cuda")
+        if l:
+            torch.cuda.synchronize()
+            check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), l * self.n * 8), "copy_d2d")
+            self.ctx.sync()
+        return out
+
+    def St(self):
+        return self._rows(self._L.hiopamd_hess_lowrank_St(self.h))
+
+    def Yt(self):
+        return self._rows(self._L.hiopamd_hess_lowrank_Yt(self.h))
+
+    def close(self):
+        if self.h is not None:
+            if self.ctx.h is not None:
+                self._L.hiopamd_hess_lowrank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KKTLinSysLowRank:
+    """Mirrors hiopKKTLinSysLowRank (src/Optimization/hiopKKTLinSys.hpp:385): update / solveCompressed."""
+
+    def __init__(self, ctx: Context, hess: HessianLowRank):
+        self.ctx, self.hess = ctx, hess
+        self._L = lib()
+        h = C.c_void_p()
+        check(self._L.hiopamd_kkt_lowrank_create(C.byref(h), ctx.h, hess.h), "hiopamd_kkt_lowrank_create")
+        self.h = h
+        self.k = hess.m_eq + hess.m_ineq
+        ctx._register(self)
+
+    def update(self, zl, sxl, ixl, zu, sxu, ixu, vl, sdl, idl, vu, sdu, idu, Jc, Jd):
+        args = [zl, sxl, ixl, zu, sxu, ixu, vl, sdl, idl, vu, sdu, idu, Jc, Jd]
+        check(self._L.hiopamd_kkt_lowrank_update(self.h, *[dptr(a) for a in args]), "hiopamd_kkt_lowrank_update")
+
+    def update_diag(self, Dx, Dd, Jc, Jd):
+        check(self._L.hiopamd_kkt_lowrank_update_diag(self.h, dptr(Dx), dptr(Dd), dptr(Jc), dptr(Jd)),
+              "hiopamd_kkt_lowrank_update_diag")
+
+    def solve_compressed(self, rx, ryc, ryd, dx, dyc, dyd) -> bool:
+        ok = C.c_int(0)
+        check(self._L.hiopamd_kkt_lowrank_solve_compressed(self.h, dptr(rx), dptr(ryc), dptr(ryd), dptr(dx), dptr(dyc),
+                                                           dptr(dyd), C.byref(ok)), "hiopamd_kkt_lowrank_solve_compressed")
+        return bool(ok.value)
+
+    def N(self) -> torch.Tensor:
+        ptr = self._L.hiopamd_kkt_lowrank_N(self.h)
+        out = torch.empty((self.k, self.k), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), self.k * self.k * 8), "copy_d2d")
+        self.ctx.sync()
+        return out
+
+    def close(self):
+        if self.h is not None:
+            if self.ctx.h is not None:
+                self._L.hiopamd_kkt_lowrank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -209,6 +209,14 @@ int hiopamd_gram_weighted(hiopamd_ctx*, int ma, int mb, int64_t n, const double*
                           int64_t ldb, const double* d, double beta, double* W, int64_t ldw, double alpha,
                           int sym);
 
+/* one pass over the long dimension for several right factors:
+ * W(ma x (m0+m1+m2)) = beta*W + alpha * A diag(d) [B0;B1;B2]^T  -- the low-rank KKT needs X D X^T, X D S^T and
+ * X D Y^T of the same X (reference: hiopHessianLowRank.cpp:566-583 makes three separate passes). */
+int hiopamd_gram_weighted_stacked(hiopamd_ctx*, int ma, int64_t n, const double* A, int64_t lda, int m0,
+                                  const double* B0, int64_t ldb0, int m1, const double* B1, int64_t ldb1, int m2,
+                                  const double* B2, int64_t ldb2, const double* d, double beta, double* W, int64_t ldw,
+                                  double alpha);
+
 /* =====================================================================================
  * hiopMatrixSparseTriplet (row-sorted COO, int32 indices)
  * (reference: src/LinAlg/hiopMatrixSparseTriplet.cpp)
@@ -305,6 +313,48 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
 double* hiopamd_kkt_mds_sys_matrix(hiopamd_kkt_mds* k);   /* device, N x N row-major, N = nxd+neq+nineq */
 double* hiopamd_kkt_mds_Hxs(hiopamd_kkt_mds* k);          /* device, nxs */
 hiopamd_linsolver* hiopamd_kkt_mds_linsolver(hiopamd_kkt_mds* k);
+
+/* =====================================================================================
+ * Quasi-Newton low-rank path: hiopHessianLowRank + hiopKKTLinSysLowRank
+ * (reference: src/Optimization/hiopHessianLowRank.cpp, src/Optimization/hiopKKTLinSys.cpp:1030-1330).
+ * All n-sized arguments are the LOCAL column slice of a rank (n_local); k x k / 2l x 2l objects are
+ * replicated; the context's all-reduce hook sums the small blocks across the column partition.
+ * sigma_update_strategy: 1 sty, 2 sty_inv, 3 snrm_ynrm, 4 sty_srnm_ynrm, 5 sigma0 (:69-73, :111-122).
+ * ===================================================================================== */
+typedef struct hiopamd_hess_lowrank hiopamd_hess_lowrank;
+int hiopamd_hess_lowrank_create(hiopamd_hess_lowrank** out, hiopamd_ctx* ctx, int64_t n_local, int m_eq, int m_ineq,
+                                int l_max, double sigma0, int sigma_update_strategy);
+int hiopamd_hess_lowrank_destroy(hiopamd_hess_lowrank* h);
+/* update (:262): secant pair from the current iterate; *stored_host = 1 if (s,y) entered the memory */
+int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const double* grad_f, const double* Jc,
+                                const double* Jd, const double* yc, const double* yd, int* stored_host);
+int hiopamd_hess_lowrank_update_log_barrier_diagonal(hiopamd_hess_lowrank* h, const double* Dx);      /* :197 */
+int hiopamd_hess_lowrank_solve(hiopamd_hess_lowrank* h, const double* rhs, double* x);                /* :495 */
+/* W(k x k) = beta*W + alpha*X*(B+Dx)^-1*X^T (:549); work: k*(k+2l_max) + 2*k*l_max doubles */
+int hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(hiopamd_hess_lowrank* h, double beta, double* W, int k,
+                                                               double alpha, const double* X, double* work);
+int hiopamd_hess_lowrank_times_vec(hiopamd_hess_lowrank* h, double beta, double* y, double alpha, const double* x); /* :974 */
+int hiopamd_hess_lowrank_l_curr(const hiopamd_hess_lowrank* h);
+double hiopamd_hess_lowrank_sigma(const hiopamd_hess_lowrank* h);
+double* hiopamd_hess_lowrank_St(hiopamd_hess_lowrank* h);   /* l_max x n_local, rows 0..l_curr-1 valid */
+double* hiopamd_hess_lowrank_Yt(hiopamd_hess_lowrank* h);
+
+typedef struct hiopamd_kkt_lowrank hiopamd_kkt_lowrank;
+int hiopamd_kkt_lowrank_create(hiopamd_kkt_lowrank** out, hiopamd_ctx* ctx, hiopamd_hess_lowrank* H);
+int hiopamd_kkt_lowrank_destroy(hiopamd_kkt_lowrank* K);
+/* update (:1057-1096) from the iterate's dual/slack vectors and bound patterns */
+int hiopamd_kkt_lowrank_update(hiopamd_kkt_lowrank* K, const double* zl, const double* sxl, const double* ixl,
+                               const double* zu, const double* sxu, const double* ixu, const double* vl,
+                               const double* sdl, const double* idl, const double* vu, const double* sdu,
+                               const double* idu, const double* Jc, const double* Jd);
+/* same with pre-computed diagonals Dx (n_local) and Dd = vl/sdl + vu/sdu (m_ineq) */
+int hiopamd_kkt_lowrank_update_diag(hiopamd_kkt_lowrank* K, const double* Dx, const double* Dd, const double* Jc,
+                                    const double* Jd);
+/* solveCompressed (:1110-1187); rx is modified like in the reference (:1178); *ok_host = 0 if N was not SPD */
+int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, const double* ryc, const double* ryd,
+                                         double* dx, double* dyc, double* dyd, int* ok_host);
+double* hiopamd_kkt_lowrank_N(hiopamd_kkt_lowrank* K);   /* device, k x k, the last reduced matrix */
+double hiopamd_kkt_lowrank_last_residual(const hiopamd_kkt_lowrank* K);
 
 #ifdef __cplusplus
 }

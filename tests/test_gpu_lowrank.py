@@ -1,0 +1,158 @@
+"""GPU parity of the quasi-Newton low-rank path (hiopHessianLowRank + hiopKKTLinSysLowRank) against the
+oracle restatement of src/Optimization/hiopHessianLowRank.cpp and hiopKKTLinSys.cpp:1057-1330.
+
+A sequence of secant updates is driven through both implementations with identical inputs (memory growth,
+then memory shift), then every operator is compared.  fp64 tolerances: multivectors bit-exact (copies),
+sigma 1e-13 rel, operator results 1e-9 relative (they go through 2l x 2l and k x k solves whose condition
+numbers are ~1e3-1e6), KKT residual of the full XYcYd system <= 1e-10."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hiop_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def D(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(torch.float64).cuda()
+
+
+def drive(ctx, n, me, mi, l_max, nupd, strategy, seed=0):
+    from hiop_amd.kkt import HessianLowRank
+    r = rng(seed)
+    Ho = ho.HessianLowRank(n, l_max=l_max, sigma0=1.0, sigma_update_strategy=strategy)
+    Hg = HessianLowRank(ctx, n, me, mi, l_max=l_max, sigma0=1.0, sigma_update_strategy=strategy)
+    q = r.uniform(0.5, 3.0, n)       # objective 0.5 sum q_i x_i^2  -> grad = q*x (strictly convex: s^T y > 0)
+    Jc0 = r.uniform(-1, 1, (me, n)); Jd0 = r.uniform(-1, 1, (mi, n))
+    x = r.uniform(-1, 1, n)
+    stored = []
+    for it in range(nupd):
+        g = q * x
+        # mildly nonlinear constraints: Jacobian drifts a little, duals random
+        Jc = Jc0 + 0.01 * it * np.sin(np.arange(me * n).reshape(me, n))
+        Jd = Jd0 + 0.01 * it * np.cos(np.arange(mi * n).reshape(mi, n))
+        yc, yd = r.uniform(-0.1, 0.1, me), r.uniform(-0.1, 0.1, mi)
+        so = Ho.update(x, g, Jc, Jd, yc, yd)
+        torch.cuda.synchronize()
+        sg = Hg.update(D(x), D(g), D(Jc), D(Jd), D(yc), D(yd))
+        ctx.sync()
+        assert so == sg
+        stored.append(so)
+        x = x + r.uniform(-0.2, 0.2, n) * (1.0 if it != 3 else 0.0)   # it==3: zero step -> update must be skipped
+    return Ho, Hg, (Jc, Jd), r, stored
+
+
+@pytest.mark.parametrize("n,me,mi,l_max,nupd,strategy", [
+    (300, 3, 4, 6, 5, "sigma0"),          # memory still growing
+    (1000, 1, 0, 6, 12, "snrm_ynrm"),     # memory full + shifts, Dense Ex1 shape (m=1)
+    (5001, 2, 2, 6, 10, "sty"),           # odd n (unaligned double2 path), Dense Ex2 shape (m=4)
+    (20000, 60, 40, 4, 7, "sty_inv"),
+    (777, 0, 3, 2, 6, "sty_srnm_ynrm"),
+])
+def test_hessian_lowrank_against_oracle(ctx, n, me, mi, l_max, nupd, strategy):
+    Ho, Hg, (Jc, Jd), r, stored = drive(ctx, n, me, mi, l_max, nupd, strategy, seed=n)
+    assert Hg.l_curr == Ho.St.shape[0] == min(l_max, sum(stored))
+    assert stored[4] is False if nupd > 4 else True      # the zero step was rejected
+    np.testing.assert_array_equal(Hg.St().cpu().numpy(), Ho.St)
+    np.testing.assert_allclose(Hg.Yt().cpu().numpy(), Ho.Yt, rtol=1e-12, atol=1e-13)
+    assert Hg.sigma == pytest.approx(Ho.sigma, rel=1e-12)
+    Dx = r.uniform(0, 2, n) * (r.uniform(0, 1, n) < 0.5)     # free variables have Dx = 0 (singular leading block of V)
+    Ho.update_log_barrier_diagonal(Dx)
+    Hg.update_log_barrier_diagonal(D(Dx))
+    rhs = r.uniform(-1, 1, n)
+    xo = Ho.solve(rhs)
+    xg = D(np.zeros(n))
+    torch.cuda.synchronize()
+    Hg.solve(D(rhs), xg); ctx.sync()
+    np.testing.assert_allclose(xg.cpu().numpy(), xo, rtol=1e-9, atol=1e-9 * np.abs(xo).max())
+    # B x through the compact form vs the reference's a_k/b_k recursion
+    yo = r.uniform(-1, 1, n); yg = D(yo)
+    Ho.times_vec(0.5, yo, -2.0, rhs)
+    torch.cuda.synchronize()
+    Hg.times_vec(0.5, yg, -2.0, D(rhs)); ctx.sync()
+    np.testing.assert_allclose(yg.cpu().numpy(), yo, rtol=1e-9, atol=1e-9 * np.abs(yo).max())
+    # solve and times_vec are inverses of each other
+    back = D(np.zeros(n))
+    torch.cuda.synchronize()
+    Hg.times_vec(0.0, back, 1.0, xg); ctx.sync()
+    np.testing.assert_allclose(back.cpu().numpy(), rhs, rtol=1e-9, atol=1e-9)
+    # W = beta*W + alpha*X (B+Dx)^-1 X^T
+    k = me + mi
+    if k:
+        X = np.vstack([Jc, Jd])
+        W0 = r.uniform(-1, 1, (k, k)); W0 = W0 + W0.T
+        Wo = W0.copy()
+        Ho.sym_mat_times_inverse_times_mat_trans(0.5, Wo, 2.0, X)
+        Wg = D(W0)
+        Hg.sym_mat_times_inverse_times_mat_trans(0.5, Wg, 2.0, D(X))
+        np.testing.assert_allclose(Wg.cpu().numpy(), Wo, rtol=1e-9, atol=1e-9 * np.abs(Wo).max())
+    Hg.close()
+
+
+@pytest.mark.parametrize("n,me,mi", [(1000, 1, 0), (5000, 2, 2), (100003, 30, 70)])
+def test_kkt_lowrank_solve_compressed(ctx, n, me, mi):
+    from hiop_amd.kkt import KKTLinSysLowRank
+    Ho, Hg, (Jc, Jd), r, _ = drive(ctx, n, me, mi, 6, 9, "sigma0", seed=n + 1)
+    ixl = (r.uniform(0, 1, n) < 0.6).astype(np.float64); ixu = (r.uniform(0, 1, n) < 0.3).astype(np.float64)
+    zl, zu = r.uniform(0.1, 1, n) * ixl, r.uniform(0.1, 1, n) * ixu
+    sxl, sxu = r.uniform(0.1, 2, n), r.uniform(0.1, 2, n)
+    idl, idu = np.ones(mi), (r.uniform(0, 1, mi) < 0.5).astype(np.float64)
+    vl, vu = r.uniform(0.1, 1, mi), r.uniform(0.1, 1, mi) * idu
+    sdl, sdu = r.uniform(0.1, 2, mi), r.uniform(0.1, 2, mi)
+    Dx = np.zeros(n); ho.axdzpy_w_pattern(Dx, 1.0, zl, sxl, ixl); ho.axdzpy_w_pattern(Dx, 1.0, zu, sxu, ixu)
+    Dd = np.zeros(mi); ho.axdzpy_w_pattern(Dd, 1.0, vl, sdl, idl); ho.axdzpy_w_pattern(Dd, 1.0, vu, sdu, idu)
+    Ko = ho.KKTLinSysLowRank(Ho, me, mi)
+    Ko.update(Dx, Dd, Jc, Jd)
+    Kg = KKTLinSysLowRank(ctx, Hg)
+    dev = [D(a) for a in (zl, sxl, ixl, zu, sxu, ixu, vl, sdl, idl, vu, sdu, idu, Jc, Jd)]
+    torch.cuda.synchronize()
+    Kg.update(*dev)
+    rx, ryc, ryd = r.uniform(-1, 1, n), r.uniform(-1, 1, me), r.uniform(-1, 1, mi)
+    ok_o, dx_o, dyc_o, dyd_o = Ko.solve_compressed(rx.copy(), ryc, ryd)
+    rxd, dx, dyc, dyd = D(rx), D(np.zeros(n)), D(np.zeros(me)), D(np.zeros(mi))
+    torch.cuda.synchronize()
+    ok_g = Kg.solve_compressed(rxd, D(ryc), D(ryd), dx, dyc, dyd); ctx.sync()
+    assert ok_o and ok_g
+    np.testing.assert_allclose(Kg.N().cpu().numpy(), Ko.last_N, rtol=1e-9, atol=1e-9 * np.abs(Ko.last_N).max())
+    dx, dyc, dyd = dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy()
+    # residual of the full XYcYd system with the explicit dense Hessian (single rank)
+    if n <= 5000:
+        B = Ho.dense_matrix_local() + np.diag(Dx)
+        r1 = B @ dx + Jc.T @ dyc + Jd.T @ dyd - rx
+        r2 = Jc @ dx - ryc
+        r3 = Jd @ dx - dyd / Dd - ryd
+        sc = max(1.0, np.abs(dx).max(), np.abs(dyc).max() if me else 0, np.abs(dyd).max() if mi else 0)
+        assert max(np.abs(r1).max(), np.abs(r2).max() if me else 0, np.abs(r3).max() if mi else 0) / sc < 1e-10
+    sc = max(np.abs(dx_o).max(), 1e-300)
+    assert np.abs(dx - dx_o).max() / sc < 1e-7
+    if me:
+        assert np.abs(dyc - dyc_o).max() / max(np.abs(dyc_o).max(), 1e-300) < 1e-7
+    if mi:
+        assert np.abs(dyd - dyd_o).max() / max(np.abs(dyd_o).max(), 1e-300) < 1e-7
+    Kg.close(); Hg.close()
+
+
+def test_posv_refine(ctx):
+    import ctypes as C
+    r = rng(5)
+    for k in (1, 7, 100, 200):
+        G = r.uniform(-1, 1, (k, 3 * k + 5)); Nm = G @ G.T + np.diag(r.uniform(0.1, 10, k) ** 3)   # badly scaled SPD
+        b = r.uniform(-1, 1, k)
+        bd = D(b); work = torch.zeros(3 * k * k + 8 * k + 8, dtype=torch.float64, device="cuda")
+        info, res = C.c_int(-1), C.c_double(-1)
+        torch.cuda.synchronize()
+        ctx.call("hiopamd_posv_refine", k, D(np.triu(Nm)), k, bd, work, C.byref(info), C.byref(res)); ctx.sync()
+        assert info.value == 0 and res.value < 1e-8
+        xo, _ = ho.solve_with_refin(Nm, b)
+        np.testing.assert_allclose(bd.cpu().numpy(), xo, rtol=1e-8, atol=1e-10)
+    # not positive definite -> info != 0 (DPOSVX INFO > 0)
+    Nm = np.diag([1.0, -2.0, 3.0])
+    info = C.c_int(-1)
+    ctx.call("hiopamd_posv_refine", 3, D(Nm), 3, D(np.ones(3)), torch.zeros(200, dtype=torch.float64, device="cuda"),
+             C.byref(info), None); ctx.sync()
+    assert info.value != 0
