@@ -15,6 +15,9 @@ iteration = 2 preconditioner solves).
 Multi-GPU (`--gpus N`, launched by torch.distributed.run): the MDS path does not shard (the reference's
 MDS interface is explicitly single-rank, src/Interface/hiopInterface.hpp:582-584) -> "replicas only":
 every rank runs the same workload on its own GPU, value = N * steps / max-over-ranks time, scaling weak.
+The path that DOES shard — the memory-distributed dense-constraint quasi-Newton KKT (variables split by
+columns, RCCL all-reduce of the small blocks) — is measured in the same run at every N and reported in the
+`dense_sharded` object of the same JSON line (weak scaling: n_local per GPU fixed).
 
 Prints ONE JSON line on rank 0.
 """
@@ -46,6 +49,9 @@ def parse():
     ap.add_argument("--solves", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--dense-nlocal", type=int, default=1_250_000, help="columns per GPU of the sharded dense case")
+    ap.add_argument("--dense-k", type=int, default=200, help="number of dense constraints m")
+    ap.add_argument("--no-dense", action="store_true")
     return ap.parse_args()
 
 
@@ -73,6 +79,73 @@ def cpu_baseline(p, Dx, Dd, rhs, nsolves, steps):
     return dict(value=steps / dt, unit="KKT iterations/s", cores=int(thr), kind="port",
                 sample=f"{steps} steps of the same workload (N={p.N}; build + DSYTRF + {nsolves}x DSYTRS), "
                        f"{dt:.1f} s on the host via oracle/hiop_oracle.py (numpy + scipy-OpenBLAS LAPACK)")
+
+
+def dense_lowrank_bench(ctx, world, rank, a, dist):
+    """Memory-distributed dense-constraint case (BASELINE configs[1]/[3]): quasi-Newton low-rank KKT with the
+    variables column-sharded over the GPUs of the node, n_local per GPU fixed (weak scaling), k = m constraints,
+    l = 6 secant pairs; small blocks all-reduced with RCCL over xGMI through the context hook.
+    One step = hiopHessianLowRank::update + hiopKKTLinSysLowRank::update + `solves` x solveCompressed."""
+    import torch
+    from hiop_amd.kkt import HessianLowRank, KKTLinSysLowRank
+    n, me, mi, l = a.dense_nlocal, a.dense_k // 2, a.dense_k - a.dense_k // 2, 6
+    if world > 1:
+        ctx.init_rccl_from_torch_distributed()
+    gl = torch.Generator(device="cuda"); gl.manual_seed(1000 + rank)     # local (sharded) data
+    gr = torch.Generator(device="cuda"); gr.manual_seed(7)               # replicated data
+    U = lambda g, *shape, lo=-1.0, hi=1.0: torch.rand(*shape, generator=g, device="cuda", dtype=torch.float64) * (hi - lo) + lo
+    Jc, Jd = U(gl, me, n), U(gl, mi, n)
+    q = U(gl, n, lo=0.5, hi=3.0)
+    x = U(gl, n)
+    H = HessianLowRank(ctx, n, me, mi, l_max=l, sigma0=1.0, sigma_update_strategy="sty")
+    K = KKTLinSysLowRank(ctx, H)
+    Dx = U(gl, n, lo=0.0, hi=2.0); Dd = U(gr, mi, lo=0.5, hi=2.0)
+    rx0 = U(gl, n); ryc, ryd = U(gr, me), U(gr, mi)
+    rx = rx0.clone()
+    dx, dyc, dyd = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros_like(ryc), torch.zeros_like(ryd)
+    yc, yd = U(gr, me, lo=-0.1, hi=0.1), U(gr, mi, lo=-0.1, hi=0.1)
+    steps_x = [U(gl, n, lo=-0.05, hi=0.05) for _ in range(4)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        nonlocal x
+        x = x + steps_x[i % 4]
+        g = q * x
+        torch.cuda.synchronize()          # torch's stream -> context stream hand-off of x, g
+        H.update(x, g, Jc, Jd, yc, yd)
+        K.update_diag(Dx, Dd, Jc, Jd)
+        for _ in range(a.solves):
+            rx.copy_(rx0)
+            torch.cuda.synchronize()
+            if not K.solve_compressed(rx, ryc, ryd, dx, dyc, dyd):
+                raise RuntimeError("reduced system not SPD")
+
+    def barrier():
+        ctx.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(8 + a.warmup):      # fill the secant memory, then warm up
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    k = me + mi
+    gram_flops = 2.0 * k * (k + 2 * l) * n            # per rank per solveCompressed (one stacked pass)
+    out = dict(value=a.steps / dt, unit="KKT iterations/s", ms_per_step=1e3 * dt / a.steps, scaling="weak",
+               workload=f"NlpDenseCons quasi-Newton low-rank KKT, n_local={n} per GPU (n={n * world}), m={k}, l={l}; "
+                        f"step = Hessian secant update + KKT update + {a.solves} solveCompressed",
+               collective="RCCL all-reduce (ncclAllReduce on the context stream), " + ("%d ranks" % world),
+               gram_gflop_per_solve_per_gpu=gram_flops / 1e9, hbm_gb_J_per_gpu=8.0 * k * n / 1e9)
+    K.close(); H.close()
+    return out
 
 
 def main():
@@ -165,6 +238,10 @@ def main():
     res = ho.kkt_mds_full_residual(ko, (0.0, 0.0, 0.0, 0.0), rhs[0], rhs[1], rhs[2], dx.cpu().numpy(), dyc.cpu().numpy(),
                                    dyd.cpu().numpy())
 
+    dense = None
+    if not a.no_dense:
+        dense = dense_lowrank_bench(ctx, world, rank, a, dist)
+
     out = None
     if rank == 0:
         value = world * a.steps / dt
@@ -179,6 +256,8 @@ def main():
             "roofline": roofline,
             "check": {"kkt_backward_error": max(res), "inertia_neg": expected_neg},
         }
+        if dense is not None:
+            out["dense_sharded"] = dense
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, Dx, Dd, rhs, a.solves, a.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -183,7 +183,8 @@ struct hiopamd_hess_lowrank {
 
 static int allreduce_dev(hiopamd_ctx* ctx, double* buf, size_t count, int op)
 {
-  if(ctx->comm_size <= 1 || !ctx->allreduce) return HIOPAMD_OK;
+  // a hook installed on a 1-rank partition is still called (lets the RCCL path run on a single GPU)
+  if(!ctx->allreduce) return HIOPAMD_OK;
   return ctx->allreduce(ctx->allreduce_user, buf, count, op, (void*)ctx->stream) == 0 ? HIOPAMD_OK : HIOPAMD_ERR_HIP;
 }
 static int to_host(hiopamd_ctx* ctx, void* dst, const void* src, size_t bytes)
@@ -305,7 +306,7 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
   }));
   double s_inf = 0.0;
   RC(hiopamd_vec_infnorm(ctx, n, s_new, &s_inf));
-  if(ctx->comm_size > 1) {
+  if(ctx->allreduce) {
     RC(to_dev(ctx, h->dsmall, &s_inf, sizeof(double)));
     RC(allreduce_dev(ctx, h->dsmall, 1, HIOPAMD_MAX));
     RC(to_host(ctx, &s_inf, h->dsmall, sizeof(double)));
@@ -319,7 +320,7 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
     // [s^T y, s^T s, y^T y] in one pass + one all-reduce                      (:301)
     dot3_t d3{0, 0, 0};
     RC(launch_reduce<dot3_t>(ctx, n, OpDot3{s_new, y_new}, &d3));
-    if(ctx->comm_size > 1) {
+    if(ctx->allreduce) {
       RC(to_dev(ctx, h->dsmall, &d3, sizeof(d3)));
       RC(allreduce_dev(ctx, h->dsmall, 3, HIOPAMD_SUM));
       RC(to_host(ctx, &d3, h->dsmall, sizeof(d3)));

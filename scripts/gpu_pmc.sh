@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() {  # name, counters...
   name=$1; shift
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmc/$name -o pmc --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc/$name.json 2> $R/gpurun_out/pmc/$name.err); echo "$name exit $?"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmc/$name -o pmc --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dense > $R/gpurun_out/pmc/$name.json 2> $R/gpurun_out/pmc/$name.err); echo "$name exit $?"
 }
 run fetch FETCH_SIZE
 run write WRITE_SIZE

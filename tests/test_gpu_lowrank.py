@@ -156,3 +156,49 @@ def test_posv_refine(ctx):
     ctx.call("hiopamd_posv_refine", 3, D(Nm), 3, D(np.ones(3)), torch.zeros(200, dtype=torch.float64, device="cuda"),
              C.byref(info), None); ctx.sync()
     assert info.value != 0
+
+
+def test_rccl_allreduce_hook_single_rank(ctx):
+    """RCCL communicator (world_size 1) installed as the context's all-reduce hook: every reduction site of the
+    low-rank path goes through ncclAllReduce on the context's stream; results must be unchanged."""
+    import os
+    import torch.distributed as dist
+    from hiop_amd.runtime import Context
+    from hiop_amd.kkt import HessianLowRank, KKTLinSysLowRank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    c2 = Context(0)
+    try:
+        c2.init_rccl_from_torch_distributed()
+        n, me, mi = 4000, 3, 2
+        r = rng(77)
+        Ho = ho.HessianLowRank(n, l_max=6, sigma0=1.0, sigma_update_strategy="sty")
+        Hg = HessianLowRank(c2, n, me, mi, l_max=6, sigma0=1.0, sigma_update_strategy="sty")
+        q = r.uniform(0.5, 3.0, n); Jc = r.uniform(-1, 1, (me, n)); Jd = r.uniform(-1, 1, (mi, n))
+        x = r.uniform(-1, 1, n)
+        for it in range(8):
+            yc, yd = r.uniform(-0.1, 0.1, me), r.uniform(-0.1, 0.1, mi)
+            Ho.update(x, q * x, Jc, Jd, yc, yd)
+            torch.cuda.synchronize()
+            Hg.update(D(x), D(q * x), D(Jc), D(Jd), D(yc), D(yd)); c2.sync()
+            x = x + r.uniform(-0.2, 0.2, n)
+        Dx = r.uniform(0, 2, n); Dd = r.uniform(0.5, 2, mi)
+        Ko = ho.KKTLinSysLowRank(Ho, me, mi); Ko.update(Dx, Dd, Jc, Jd)
+        Kg = KKTLinSysLowRank(c2, Hg)
+        torch.cuda.synchronize()
+        Kg.update_diag(D(Dx), D(Dd), D(Jc), D(Jd))
+        rx, ryc, ryd = r.uniform(-1, 1, n), r.uniform(-1, 1, me), r.uniform(-1, 1, mi)
+        _, dx_o, dyc_o, dyd_o = Ko.solve_compressed(rx.copy(), ryc, ryd)
+        dx, dyc, dyd = D(np.zeros(n)), D(np.zeros(me)), D(np.zeros(mi))
+        torch.cuda.synchronize()
+        assert Kg.solve_compressed(D(rx), D(ryc), D(ryd), dx, dyc, dyd); c2.sync()
+        np.testing.assert_allclose(dx.cpu().numpy(), dx_o, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(dyc.cpu().numpy(), dyc_o, rtol=1e-7, atol=1e-9)
+        Kg.close(); Hg.close()
+    finally:
+        c2.close()
+        if own:
+            dist.destroy_process_group()
