@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Transcribes the closed-form known answers of the reference's LinAlg unit tests into
+tests/golden/reference_unit_tests.json (DATA: constant inputs + expected values; no reference code).
+
+Sources (LLNL/hiop v1.1.0): tests/LinAlg/vectorTests.hpp, matrixTestsDense.hpp, matrixTestsSparse.hpp,
+matrixTestsSymSparse.hpp; driver sizes tests/testVector.cpp:235 (Nlocal = 1000), tests/testMatrixDense.cpp:168-170
+(M = 50, K = 100, N = 500 -> scaled to M = 10, N = 100 here), tests/testMatrixSparse.cpp:85-103 (M = 5, N = 50,
+5 entries per row at columns 0, 10, 20, 30, 49 — matrixTestsSparseTriplet.cpp:303-330).
+Constants of tests/LinAlg/testBase.hpp: zero, quarter, half, one, two, three.
+
+Array encoding: {"n": N, "fill": c, "set": [[idx, val], ...]} (negative idx counts from the end); matrices
+{"m": M, "n": N, "fill": c, "set": [[i, j, val], ...]}.
+"""
+import json
+import math
+import os
+
+N = 1000
+zero, quarter, half, one, two, three = 0.0, 0.25, 0.5, 1.0, 2.0, 3.0
+
+
+def V(fill, sets=(), n=N):
+    return {"n": n, "fill": fill, "set": [list(s) for s in sets]}
+
+
+def Mx(m, n, fill, sets=()):
+    return {"m": m, "n": n, "fill": fill, "set": [list(s) for s in sets]}
+
+
+cases = []
+
+
+def case(op, ref, args, expect):
+    cases.append({"op": op, "ref": ref, "args": args, "expect": expect})
+
+
+VT = "tests/LinAlg/vectorTests.hpp"
+# ---- element-wise
+case("setToConstant", f"{VT}:119", {"y": V(zero), "c": one}, {"y": V(one)})
+case("setToConstant_w_patternSelect", f"{VT}:164", {"y": V(zero), "c": two, "select": V(one, [(-1, zero)])},
+     {"y": V(two, [(-1, zero)])})
+case("copyFrom", f"{VT}:198", {"y": V(zero), "x": V(one)}, {"y": V(one)})
+case("selectPattern", f"{VT}:750", {"y": V(two), "select": V(one, [(-1, zero)])}, {"y": V(two, [(-1, zero)])})
+case("scale", f"{VT}:781", {"y": V(half), "c": half}, {"y": V(quarter)})
+case("componentMult", f"{VT}:795", {"y": V(half), "x": V(half)}, {"y": V(quarter)})
+case("componentDiv", f"{VT}:814", {"y": V(one), "x": V(two)}, {"y": V(half)})
+case("componentDiv_w_selectPattern", f"{VT}:833",
+     {"y": V(half), "x": V(one, [(-1, zero)]), "select": V(one, [(-1, zero)])}, {"y": V(half, [(-1, zero)])})
+case("component_min_c", f"{VT}:872", {"y": V(one), "c": half}, {"y": V(half)})
+case("component_min_v", f"{VT}:887", {"y": V(one), "x": V(half)}, {"y": V(half)})
+case("component_max_c", f"{VT}:906", {"y": V(one), "c": two}, {"y": V(two)})
+case("component_max_v", f"{VT}:921", {"y": V(one), "x": V(two)}, {"y": V(two)})
+case("component_abs", f"{VT}:940", {"y": V(-quarter, [(-1, half)])}, {"y": V(quarter, [(-1, half)])})
+case("component_sqrt", f"{VT}:968", {"y": V(quarter, [(-1, two * two)])}, {"y": V(half, [(-1, two)])})
+case("component_sgn", f"{VT}:996", {"y": V(-quarter, [(-1, half)])}, {"y": V(-one, [(-1, one)])})
+case("axpy", f"{VT}:1077", {"y": V(two), "alpha": half, "x": V(two)}, {"y": V(two + half * two)})
+case("axzpy", f"{VT}:1103", {"y": V(two), "alpha": half, "x": V(two), "z": V(two)}, {"y": V(two + half * two * two)})
+case("axdzpy", f"{VT}:1135", {"y": V(two), "alpha": three, "x": V(half), "z": V(half)}, {"y": V(two + three * half / half)})
+case("axdzpy_w_pattern", f"{VT}:1167",
+     {"y": V(two), "alpha": three, "x": V(half), "z": V(half, [(-1, zero)]), "select": V(one, [(-1, zero)])},
+     {"y": V(two + three * half / half, [(-1, two)])})
+case("addConstant", f"{VT}:1211", {"y": V(zero), "c": two}, {"y": V(two)})
+case("addConstant_w_patternSelect", f"{VT}:1228", {"y": V(zero), "c": half, "select": V(one, [(-1, zero)])},
+     {"y": V(half, [(-1, zero)])})
+case("negate", f"{VT}:1283", {"y": V(one)}, {"y": V(-one)})
+case("invert", f"{VT}:1296", {"y": V(two)}, {"y": V(half)})
+case("addLogBarrierGrad", f"{VT}:1372", {"y": V(two), "alpha": half, "x": V(two), "select": V(one, [(-1, zero)])},
+     {"y": V(two + half / two, [(-1, two)])})
+case("addLinearDampingTerm", f"{VT}:1461",
+     {"y": V(one), "ixl": V(one, [(0, zero), (1, zero), (2, one), (3, one)]),
+      "ixr": V(zero, [(0, one), (1, zero), (2, one), (3, zero)]), "alpha": quarter, "ct": two},
+     {"y_first4": [quarter - two, quarter, quarter, quarter + two]})
+# adjustDuals_plh: z = 1, x = 2, mu = kappa = 1/2: a = mu/x = 1/4, b = a/kappa = 1/2, a*kappa = 1/8; z=1 >= b, a<=b -> z = b
+case("adjustDuals_plh", f"{VT}:1891", {"z": V(one), "x": V(two), "select": V(one), "mu": half, "kappa": half}, {"z": V(half)})
+# ---- reductions
+case("onenorm", f"{VT}:1024", {"x": V(-one)}, {"value": float(N)})
+case("twonorm", f"{VT}:1040", {"x": V(-one)}, {"value": math.sqrt(N)})
+case("infnorm", f"{VT}:1057", {"x": V(one, [(-1, -two)])}, {"value": two})
+case("dotProductWith", f"{VT}:1259", {"x": V(one), "y": V(two)}, {"value": two * N})
+case("logBarrier_local", f"{VT}:1309", {"x": V(one, [(-1, 1000 * three)]), "select": V(one, [(-1, zero)])},
+     {"value": (N - 1) * math.log(one)})
+case("logBarrier_local", f"{VT}:1331", {"x": V(zero, [(-1, one)]), "select": V(zero, [(-1, one)])}, {"value": math.log(one)})
+case("sum_local", f"{VT}:1350", {"x": V(half, [(-1, two)])}, {"value": (N - 1) * half + two})
+case("linearDampingTerm_local", f"{VT}:1417",
+     {"x": V(one), "ixl": V(one, [(-1, two)]), "ixr": V(zero, [(-1, two)]), "mu": two, "kappa_d": two},
+     {"value": (N - 1) * one * two * two})
+case("allPositive", f"{VT}:1552", {"x": V(one)}, {"value": 1})
+case("allPositive", f"{VT}:1560", {"x": V(one, [(-1, -one)])}, {"value": 0})
+case("allPositive_w_patternSelect", f"{VT}:1574", {"x": V(one), "select": V(one)}, {"value": 1})
+case("allPositive_w_patternSelect", f"{VT}:1584", {"x": V(-one), "select": V(one)}, {"value": 0})
+case("allPositive_w_patternSelect", f"{VT}:1590", {"x": V(one, [(-1, -one)]), "select": V(one)}, {"value": 0})
+case("min", f"{VT}:1606", {"x": V(two, [(-1, -one)])}, {"value": -one})
+case("min", f"{VT}:1616", {"x": V(one, [(-1, two)])}, {"value": one})
+case("min_w_pattern", f"{VT}:1630", {"x": V(one, [(-1, -one)]), "select": V(one)}, {"value": -one})
+case("min_w_pattern", f"{VT}:1644", {"x": V(one, [(-1, -one)]), "select": V(one, [(-1, zero)])}, {"value": one})
+case("fractionToTheBdry_local", f"{VT}:1773", {"x": V(one), "d": V(two), "tau": half}, {"value": one})
+case("fractionToTheBdry_local", f"{VT}:1790", {"x": V(one), "d": V(-one, [(-1, -two)]), "tau": half}, {"value": quarter})
+case("fractionToTheBdry_w_pattern_local", f"{VT}:1809", {"x": V(one), "d": V(one), "tau": half, "select": V(one)}, {"value": one})
+case("fractionToTheBdry_w_pattern_local", f"{VT}:1828",
+     {"x": V(one), "d": V(one, [(-1, -half)]), "tau": half, "select": V(one, [(-1, zero)])}, {"value": one})
+case("fractionToTheBdry_w_pattern_local", f"{VT}:1840",
+     {"x": V(one), "d": V(-one, [(-1, -two)]), "tau": half, "select": V(one)}, {"value": quarter})
+case("matchesPattern", f"{VT}:1860", {"x": V(one), "select": V(one)}, {"value": 1})
+case("matchesPattern", f"{VT}:1870", {"x": V(one), "select": V(one, [(-1, zero)])}, {"value": 0})
+case("matchesPattern", f"{VT}:1876", {"x": V(one, [(-1, zero)]), "select": V(one)}, {"value": 1})
+# projectIntoBounds (kappa1 = kappa2 = 1/2)
+PB = f"{VT}:1656"
+case("projectIntoBounds_local", PB, {"x": V(one), "xl": V(one), "ixl": V(one), "xu": V(-one), "ixu": V(one), "kappa1": half,
+                                      "kappa2": half}, {"ok": 0})
+case("projectIntoBounds_local", PB, {"x": V(one), "xl": V(-one), "ixl": V(one), "xu": V(one), "ixu": V(one), "kappa1": half,
+                                      "kappa2": half}, {"ok": 1, "x": V(half)})
+case("projectIntoBounds_local", PB, {"x": V(-two), "xl": V(zero), "ixl": V(one), "xu": V(two), "ixu": V(one), "kappa1": half,
+                                      "kappa2": half}, {"ok": 1, "x": V(half)})
+case("projectIntoBounds_local", PB, {"x": V(two), "xl": V(-two), "ixl": V(one), "xu": V(zero), "ixu": V(one), "kappa1": half,
+                                      "kappa2": half}, {"ok": 1, "x": V(-half)})
+
+# ---- dense matrices (row-major M x Nn), tests/LinAlg/matrixTestsDense.hpp
+MD = "tests/LinAlg/matrixTestsDense.hpp"
+M_, Nn = 10, 100
+case("mat_timesVec", f"{MD}:173", {"A": Mx(M_, Nn, one), "beta": one, "y": V(three, n=M_), "alpha": one, "x": V(three, n=Nn)},
+     {"y": V(three + three * Nn, n=M_)})
+case("mat_transTimesVec", f"{MD}:208",
+     {"A": Mx(M_, Nn, one, [(i, Nn - 1, zero) for i in range(M_)]), "beta": one, "y": V(three, n=Nn), "alpha": one,
+      "x": V(three, n=M_)}, {"y": V(three + three * M_, [(-1, three)], n=Nn)})
+case("mat_addSubDiagonal", f"{MD}:447", {"A": Mx(Nn, Nn, half), "alpha": half, "start": Nn - M_, "d": V(one, n=M_), "src_start": 0,
+                                          "num": M_},
+     {"A": Mx(Nn, Nn, half, [(i, i, half + half) for i in range(Nn - M_, Nn)])})
+case("mat_addSubDiagonal", f"{MD}:475", {"A": Mx(Nn, Nn, half), "alpha": half, "start": Nn - M_ + 1, "d": V(one, n=M_),
+                                          "src_start": 1, "num": M_ - 1},
+     {"A": Mx(Nn, Nn, half, [(i, i, half + half) for i in range(Nn - M_ + 1, Nn)])})
+case("mat_addSubDiagonal_const", f"{MD}:494", {"A": Mx(Nn, Nn, half), "start": 1, "num": Nn - 2, "c": two},
+     {"A": Mx(Nn, Nn, half, [(i, i, half + two) for i in range(1, Nn - 1)])})
+case("mat_addMatrix", f"{MD}:516", {"A": Mx(M_, Nn, half), "alpha": half, "B": Mx(M_, Nn, one)}, {"A": Mx(M_, Nn, half + half)})
+case("mat_transAddToSymDenseMatrixUpperTriangle", f"{MD}:544",
+     {"A": Mx(M_, 20, half), "row_start": 0, "col_start": Nn - M_, "alpha": half, "W": Mx(Nn, Nn, one)},
+     {"W": Mx(Nn, Nn, one, [(i, j, one + half * half) for i in range(20) for j in range(Nn - M_, Nn)])})
+case("mat_addUpperTriangleToSymDenseMatrixUpperTriangle", f"{MD}:587",
+     {"A": Mx(M_, M_, half), "diag_start": 0, "alpha": half, "W": Mx(Nn, Nn, one)},
+     {"W": Mx(Nn, Nn, one, [(i, j, one + half * half) for i in range(M_) for j in range(i, M_)])})
+
+# ---- sparse triplet (matrixTestsSparse.hpp), M = 5, N = 50, entries at columns 0,10,20,30,49 of every row, values 1
+MS = "tests/LinAlg/matrixTestsSparse.hpp"
+sm, sn = 5, 50
+cols = [0, 10, 20, 30, 49]
+sp = {"m": sm, "n": sn, "iRow": [r for r in range(sm) for _ in cols], "jCol": [c for _ in range(sm) for c in cols],
+      "val": [one] * (sm * len(cols))}
+off = 2
+Wn = sm + 2 * off
+# W += alpha * A D^-1 A^T on the upper triangle of the diagonal block at `off`: alpha=1/2, A=1, d=1/2 -> 1/2*1*1/(1/2)*5 = 5
+case("sp_addMDinvMtransToDiagBlockOfSymDeMatUTri", f"{MS}:415",
+     {"A": sp, "offset": off, "alpha": half, "D": V(half, n=sn), "W": Mx(Wn, Wn, zero)},
+     {"W": Mx(Wn, Wn, zero, [(i, j, half * one * one / half * len(cols)) for i in range(off, off + sm) for j in range(i, off + sm)])})
+case("sp_timesVec", f"{MS}:128", {"A": sp, "beta": one, "y": V(two, n=sm), "alpha": one, "x": V(three, n=sn)},
+     {"y": V(two + three * len(cols), n=sm)})
+case("sp_transTimesVec", f"{MS}:162", {"A": sp, "beta": one, "y": V(two, n=sn), "alpha": one, "x": V(three, n=sm)},
+     {"y": V(two, [(c, two + three * sm) for c in cols], n=sn)})
+# sym sparse: y += alpha*diag(A) (matrixTestsSymSparse.hpp:180): A = 1/2 on its entries, W = 1, alpha = 1/2
+ss = {"m": 6, "n": 6, "iRow": [0, 0, 1, 2, 3, 3, 5], "jCol": [0, 4, 1, 5, 3, 4, 5], "val": [half] * 7}
+case("spsym_startingAtAddSubDiagonalToStartingAt", "tests/LinAlg/matrixTestsSymSparse.hpp:180",
+     {"A": ss, "alpha": half, "y": V(one, n=6)}, {"y": V(one, [(0, one + quarter), (1, one + quarter), (3, one + quarter), (5, one + quarter)], n=6)})
+
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_unit_tests.json")
+with open(out, "w") as f:
+    json.dump({"source": "LLNL/hiop v1.1.0 tests/LinAlg (transcribed constants and expected values)", "cases": cases}, f, indent=0)
+print(f"{out}: {len(cases)} cases")

