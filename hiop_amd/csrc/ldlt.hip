@@ -74,6 +74,128 @@ __device__ __forceinline__ double fast_rcp(double d)
 // ------------------------------------------------------------------------------------------
 constexpr int LD_SB = 16;
 
+// LDL^T of a kb x kb (<= 64) block resident in LDS (upper part, zero padded; sdinv preset to 1), blocked by 16:
+//   (i)   wave 0 factors the 16x16 diagonal sub-block entirely in registers (lane c = column c; pivot row and
+//         multipliers broadcast with v_readlane; v_rcp + one Newton step) and, Gauss-Jordan style, applies the same
+//         row operations to an identity: the unit-lower inverse Linv16 comes out of the same 16 pivots for free;
+//   (ii)  the 16 x (rest) row panel is V = Linv16 * A on fp64 MFMA (one 16-column group per wave);
+//   (iii) the trailing part gets the rank-16 update C -= V^T D^-1 V on fp64 MFMA (6 upper 16x16 tiles over 4 waves).
+// During the factorisation S holds UN-scaled rows (v_kc = d_k u_kc); they are scaled by diag_emit.
+// Li (global, [sb][i][j] row-major) receives the four 16x16 inverses; info[0] the first zero / non-finite pivot.
+__device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* sdinv, int kb, int k0, int* info,
+                                                double* __restrict__ Li, int tid)
+{
+  __shared__ double Lv[LD_SB][LD_SB + 1];
+  const int lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
+  for(int sb = 0; sb < LD_nb / LD_SB; ++sb) {
+    const int o = sb * LD_SB;
+    if(o >= kb) {   // uniform: padded sub-block -> identity inverse
+      if(tid < LD_SB * LD_SB) Li[sb * 256 + tid] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
+      continue;
+    }
+    // ---- (i)
+    if(tid < 64) {
+      const int c = li;
+      double a[LD_SB], m[LD_SB];
+#pragma unroll
+      for(int r = 0; r < LD_SB; ++r) {
+        a[r] = S[o + r][o + c];   // zeros below the diagonal
+        m[r] = (r == c) ? 1.0 : 0.0;
+      }
+#pragma unroll
+      for(int k = 0; k < LD_SB; ++k) {
+        if(o + k < kb) {  // uniform
+          const double d = bcast_lane(a[k], k);          // pivot
+          const double di = fast_rcp(d);
+          const double ukc = a[k] * di;                  // scaled pivot-row entry of my column
+          const double mkc = m[k] * di;
+#pragma unroll
+          for(int r = k + 1; r < LD_SB; ++r) {
+            const double vkr = bcast_lane(a[k], r);      // S[k][r]: multiplier of row r is vkr/d
+            a[r] = fma(-vkr, ukc, a[r]);
+            m[r] = fma(-vkr, mkc, m[r]);
+          }
+          if(tid == 0) {
+            sdinv[o + k] = di;
+            if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + o + k + 1);
+          }
+        }
+      }
+      if(tid < LD_SB) {
+#pragma unroll
+        for(int r = 0; r < LD_SB; ++r) {
+          if(c >= r) S[o + r][o + c] = a[r];
+          Lv[r][c] = m[r];
+          Li[sb * 256 + r * 16 + c] = m[r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (ii) V = Linv16 * A_panel, one 16-column group per wave
+    {
+      const int cbase = o + LD_SB + 16 * w;
+      if(cbase < LD_nb && cbase < kb) {   // wave-uniform
+        double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+        double aop[4], bop[4];
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) {
+          aop[kk] = Lv[li][4 * kk + g];
+          bop[kk] = S[o + 4 * kk + g][cbase + li];
+        }
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], bop[kk], acc, 0, 0, 0);
+#pragma unroll
+        for(int reg = 0; reg < 4; ++reg) S[o + g + 4 * reg][cbase + li] = acc[reg];
+      }
+    }
+    __syncthreads();
+    // ---- (iii) C -= V^T D^-1 V on the upper 16x16 tiles of the trailing part
+    {
+      double aop[4], dk[4];
+#pragma unroll
+      for(int t6 = w; t6 < 6; t6 += 4) {
+        // (ti,tj): 0:(0,0) 1:(0,1) 2:(0,2) 3:(1,1) 4:(1,2) 5:(2,2)
+        const int ti = (t6 < 3) ? 0 : ((t6 < 5) ? 1 : 2);
+        const int tj = (t6 < 3) ? t6 : ((t6 < 5) ? (t6 - 2) : 2);
+        const int ro = o + LD_SB + 16 * ti, co = o + LD_SB + 16 * tj;
+        if(co < LD_nb && ro < kb) {   // wave-uniform
+          double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+          double bop[4];
+#pragma unroll
+          for(int kk = 0; kk < 4; ++kk) {
+            dk[kk] = sdinv[o + 4 * kk + g];
+            aop[kk] = S[o + 4 * kk + g][ro + li];
+            bop[kk] = S[o + 4 * kk + g][co + li] * dk[kk];
+          }
+#pragma unroll
+          for(int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], bop[kk], acc, 0, 0, 0);
+#pragma unroll
+          for(int reg = 0; reg < 4; ++reg) {
+            const int r = ro + g + 4 * reg, c = co + li;
+            if(c >= r) S[r][c] -= acc[reg];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// scale rows, write U11/D into A, the compact copy Dk and dinv
+__device__ __forceinline__ void diag_emit(double (*S)[LD_nb + 1], const double* sdinv, int kb, int k0, double* A, int64_t lda,
+                                          double* dinv, double* Dk, int tid)
+{
+  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
+    const int r = e >> 6, c = e & 63;
+    double v = S[r][c];
+    if(c > r) v *= sdinv[r];
+    const bool in = (r < kb && c < kb && c >= r);
+    Dk[e] = in ? v : 0.0;
+    if(in) A[(int64_t)(k0 + r) * lda + (k0 + c)] = v;
+  }
+  if(tid < kb) dinv[k0 + tid] = sdinv[tid];
+}
+
 __global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int kb,
                                                            double* __restrict__ dinv, double* __restrict__ Dk,
                                                            double* __restrict__ Li, int* __restrict__ info)
@@ -99,117 +221,8 @@ __global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ 
   }
   if(tid < LD_nb) sdinv[tid] = 1.0;
   __syncthreads();
-
-  for(int sb = 0; sb < LD_nb / LD_SB; ++sb) {
-    const int o = sb * LD_SB;
-    if(o >= kb) break;  // uniform
-    // ---- (i) 16x16 diagonal sub-block in registers of wave 0: lane c (< 16) holds column c
-    if(tid < 64) {
-      const int c = tid & 15;
-      double a[LD_SB];
-#pragma unroll
-      for(int r = 0; r < LD_SB; ++r) a[r] = S[o + r][o + c];   // zeros below the diagonal
-#pragma unroll
-      for(int k = 0; k < LD_SB; ++k) {
-        if(o + k < kb) {  // uniform
-          const double d = bcast_lane(a[k], k);          // pivot S[k][k]
-          const double di = fast_rcp(d);
-          const double ukc = a[k] * di;                  // scaled pivot-row entry of my column
-#pragma unroll
-          for(int r = k + 1; r < LD_SB; ++r) {
-            const double vkr = bcast_lane(a[k], r);      // S[k][r] = pivot-row entry of column r
-            a[r] = fma(-vkr, ukc, a[r]);
-          }
-          if(tid == 0) {
-            sdinv[o + k] = di;
-            if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + o + k + 1);
-          }
-        }
-      }
-      if(tid < LD_SB) {
-#pragma unroll
-        for(int r = 0; r < LD_SB; ++r)
-          if(c >= r) S[o + r][o + c] = a[r];
-      }
-    }
-    __syncthreads();
-    // ---- (ii) row panel: columns c >= o+16, one per thread; x_r -= S[o+s][o+r] * (x_s/d_s)
-    {
-      const int c = o + LD_SB + tid;
-      if(c < LD_nb && c < kb) {
-        double x[LD_SB];
-#pragma unroll
-        for(int r = 0; r < LD_SB; ++r) x[r] = S[o + r][c];
-#pragma unroll
-        for(int q = 0; q < LD_SB - 1; ++q) {
-          const double us = x[q] * sdinv[o + q];
-#pragma unroll
-          for(int r = q + 1; r < LD_SB; ++r) x[r] = fma(-S[o + q][o + r], us, x[r]);
-        }
-#pragma unroll
-        for(int r = 0; r < LD_SB; ++r) S[o + r][c] = x[r];
-      }
-    }
-    __syncthreads();
-    // ---- (iii) trailing rank-16 update inside the block: S[r][c] -= sum_k v_kr * v_kc / d_k, c >= r >= o+16
-    {
-      const int tr = tid >> 4, tc = tid & 15;
-      double acc[3][3];
-#pragma unroll
-      for(int i = 0; i < 3; ++i)
-#pragma unroll
-        for(int j = 0; j < 3; ++j) acc[i][j] = 0.0;
-      const int rb = o + LD_SB + tr, cb = o + LD_SB + tc;
-#pragma unroll 4
-      for(int k = 0; k < LD_SB; ++k) {
-        const double di = sdinv[o + k];
-        double vr[3], uc[3];
-#pragma unroll
-        for(int i = 0; i < 3; ++i) vr[i] = (rb + 16 * i < LD_nb) ? S[o + k][rb + 16 * i] : 0.0;
-#pragma unroll
-        for(int j = 0; j < 3; ++j) uc[j] = (cb + 16 * j < LD_nb) ? S[o + k][cb + 16 * j] * di : 0.0;
-#pragma unroll
-        for(int i = 0; i < 3; ++i)
-#pragma unroll
-          for(int j = 0; j < 3; ++j) acc[i][j] = fma(vr[i], uc[j], acc[i][j]);
-      }
-      __syncthreads();  // all reads of the k-panel done before anybody writes (rows >= o+16 only, but keep it simple)
-#pragma unroll
-      for(int i = 0; i < 3; ++i)
-#pragma unroll
-        for(int j = 0; j < 3; ++j) {
-          const int r = rb + 16 * i, c = cb + 16 * j;
-          if(r < LD_nb && c < LD_nb && c >= r) S[r][c] -= acc[i][j];
-        }
-    }
-    __syncthreads();
-  }
-  // scale the rows, write the factor back and the compact copy
-  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
-    const int r = e >> 6, c = e & 63;
-    double v = S[r][c];
-    if(c > r) v *= sdinv[r];
-    const bool in = (r < kb && c < kb && c >= r);
-    Dk[e] = in ? v : 0.0;
-    if(in) A[(int64_t)(k0 + r) * lda + (k0 + c)] = v;
-  }
-  if(tid < kb) dinv[k0 + tid] = sdinv[tid];
-  // inverses of the four unit-lower 16x16 diagonal sub-blocks of L11 = U11^T:
-  // thread (sb, j) solves L x = e_j;  L[i][q] = S[o+q][o+i]*sdinv[o+q] for i > q
-  if(tid < LD_nb) {
-    const int sb = tid >> 4, j = tid & 15, o = sb * LD_SB;
-    double x[LD_SB];
-#pragma unroll
-    for(int i = 0; i < LD_SB; ++i) x[i] = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-    for(int q = 0; q < LD_SB - 1; ++q) {
-      const double xq = x[q] * sdinv[o + q];   // zero for q < j
-#pragma unroll
-      for(int i = q + 1; i < LD_SB; ++i) x[i] = fma(-S[o + q][o + i], xq, x[i]);
-    }
-#pragma unroll
-    for(int i = 0; i < LD_SB; ++i) Li[sb * (LD_SB * LD_SB) + i * LD_SB + j] = x[i];
-  }
+  diag_factor_lds(S, sdinv, kb, k0, info, Li, tid);
+  diag_emit(S, sdinv, kb, k0, A, lda, dinv, Dk, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -283,6 +296,333 @@ __global__ __launch_bounds__(64) void ldlt_trsm_kernel(double* __restrict__ A, i
           A[(int64_t)(k0 + row) * lda + col] = Vv[I][r] * dsc[I][r];
         }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Super-panel kernels (NB = 256 rows = 4 panels of 64): the whole panel chain of a super-panel in TWO launches.
+//
+// block_row_solve<P>: for ONE group of 16 columns held by one wave, the block-row P of the row panel,
+//     T_P = A_P - sum_{q<P} L_Pq V_q            (64x64 by 64x16 products on fp64 MFMA; L_Pq = U_qP^T read from A)
+//     V_P = L_PP^-1 T_P                         (16-row block substitution with the 16x16 inverses, as above)
+// V_q (q < P) never leave the registers: the MFMA D layout of a 16x16 block of V_q is the B-operand layout of the
+// next product (k-step kk <-> accumulator register kk), and the A-operand layout of the symmetric update below.
+// BYPASS = true makes the loads of data produced earlier IN THE SAME LAUNCH by other waves go to L2
+// (relaxed agent-scope atomic load = `sc1`): a CU's vector L1 is not refreshed by stores.
+// ------------------------------------------------------------------------------------------
+template <bool BYPASS>
+__device__ __forceinline__ double ld_maybe_bypass(const double* p)
+{
+  if constexpr(BYPASS) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    return *p;
+  }
+}
+
+template <int P, bool BYPASS>
+__device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, int K0, int kbs, int64_t col, bool col_ok,
+                                                const double* Dk_sp, const double* Li_sp, double4_t (&Vv)[4][4], int g,
+                                                int li)
+{
+  // rows of block-row P that exist (the last super-panel may be ragged)
+  double4_t t[4];
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      const int row = 64 * P + 16 * I + g + 4 * r;
+      const int rowc = (row < kbs) ? row : (kbs - 1);
+      const double v = A[(int64_t)(K0 + rowc) * lda + col];
+      t[I][r] = (col_ok && row < kbs) ? v : 0.0;
+    }
+  // T_P -= L_Pq V_q
+#pragma unroll
+  for(int q = 0; q < P; ++q) {
+#pragma unroll
+    for(int I = 0; I < 4; ++I) {
+      double Lop[4][4];  // [Jq][kk]: -L_Pq[16I+li][16Jq+4kk+g] = -U[K0+64q+16Jq+4kk+g][K0+64P+16I+li]
+#pragma unroll
+      for(int Jq = 0; Jq < 4; ++Jq)
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk)
+          Lop[Jq][kk] = -ld_maybe_bypass<BYPASS>(A + (int64_t)(K0 + 64 * q + 16 * Jq + 4 * kk + g) * lda + (K0 + 64 * P + 16 * I + li));
+#pragma unroll
+      for(int Jq = 0; Jq < 4; ++Jq)
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) t[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lop[Jq][kk], Vv[q][Jq][kk], t[I], 0, 0, 0);
+    }
+  }
+  // V_P = L_PP^-1 T_P by 16-row blocks
+  const double* Dk = Dk_sp + P * (LD_nb * LD_nb);
+  const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
+#pragma unroll
+  for(int I = 0; I < 4; ++I) {
+    double4_t u = t[I];
+#pragma unroll
+    for(int J = 0; J < 4; ++J) {
+      if(J < I) {
+        double nl[4];
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) nl[kk] = -ld_maybe_bypass<BYPASS>(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li);
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[kk], Vv[P][J][kk], u, 0, 0, 0);
+      }
+    }
+    double iv[4];
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) iv[kk] = ld_maybe_bypass<BYPASS>(Li + I * 256 + li * 16 + 4 * kk + g);
+    double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[kk], u[kk], v, 0, 0, 0);
+    Vv[P][I] = v;
+  }
+}
+
+// store block-row P of V (un-scaled, workspace rows 64P..) and U = D^-1 V (in place)
+template <int P>
+__device__ __forceinline__ void block_row_store(double* A, int64_t lda, double* V, int64_t ldv, int K0, int kbs, int64_t col,
+                                                bool col_ok, const double* dinv_sp /*256 entries of this super-panel*/,
+                                                const double4_t (&Vv)[4][4], int g, int li)
+{
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      const int row = 64 * P + 16 * I + g + 4 * r;
+      if(row < kbs) {
+        const double v = Vv[P][I][r];
+        const double u = v * dinv_sp[row];
+        if(col_ok) {
+          V[(int64_t)row * ldv + col] = v;
+          A[(int64_t)(K0 + row) * lda + col] = u;
+        }
+      }
+    }
+}
+
+// cooperative (256 threads) load of a 64x64 block into S, bypassing L1 (data written earlier in this launch)
+__device__ __forceinline__ void stage_block_bypass(double (*S)[LD_nb + 1], const double* src, int64_t ld, int tid)
+{
+  double sv[LD_nb * LD_nb / kBlock];
+#pragma unroll
+  for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+    const int e = tid + q * kBlock;
+    sv[q] = __hip_atomic_load(src + (int64_t)(e >> 6) * ld + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+    const int e = tid + q * kBlock;
+    S[e >> 6][e & 63] = sv[q];
+  }
+}
+
+// block-row P of the current panel's 64 columns inside the super-diagonal kernel.  The 4 waves of the workgroup
+// need the SAME L_Pq / Dk_P operand blocks: they are staged once in LDS (the S buffer, free during phase (a)); the
+// already computed block rows V_q (q < P) of the current panel live in LDS too (Vs, un-scaled), so nothing but the
+// 16x16 accumulators stays in registers across phases.  Must be called by the whole workgroup.
+__device__ __forceinline__ void block_row_solve_lds(const int P, double* A, int64_t lda, double* V, int64_t ldv, int K0, int64_t col,
+                                                    bool col_ok, int cl, const double* Dk_sp, const double* Li_sp,
+                                                    const double* dall, int g, int li, double (*S)[LD_nb + 1],
+                                                    double (*Vs)[80], int tid)
+{
+  double4_t t[4];
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      const int row = 64 * P + 16 * I + g + 4 * r;   // block rows below the current panel are always full
+      const double v = A[(int64_t)(K0 + row) * lda + col];
+      t[I][r] = col_ok ? v : 0.0;
+    }
+#pragma unroll 1
+  for(int q = 0; q < P; ++q) {
+    __syncthreads();
+    stage_block_bypass(S, A + (int64_t)(K0 + 64 * q) * lda + (K0 + 64 * P), lda, tid);   // U_qP = L_Pq^T
+    __syncthreads();
+#pragma unroll
+    for(int I = 0; I < 4; ++I) {
+#pragma unroll
+      for(int Jq = 0; Jq < 4; ++Jq) {
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk)
+          t[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[16 * Jq + 4 * kk + g][16 * I + li],
+                                                      Vs[64 * q + 16 * Jq + 4 * kk + g][cl], t[I], 0, 0, 0);
+        asm volatile("" ::: "memory");   // bound the number of LDS operand reads in flight (register pressure)
+      }
+    }
+  }
+  __syncthreads();
+  stage_block_bypass(S, Dk_sp + P * (LD_nb * LD_nb), LD_nb, tid);
+  __syncthreads();
+  const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
+  double4_t vp[4];
+#pragma unroll
+  for(int I = 0; I < 4; ++I) {
+    double4_t u = t[I];
+#pragma unroll
+    for(int J = 0; J < 4; ++J) {
+      if(J < I) {
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk)
+          u = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[16 * J + 4 * kk + g][16 * I + li], vp[J][kk], u, 0, 0, 0);
+      }
+    }
+    double iv[4];
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk)
+      iv[kk] = __hip_atomic_load(Li + I * 256 + li * 16 + 4 * kk + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[kk], u[kk], v, 0, 0, 0);
+    vp[I] = v;
+  }
+  // V (workspace, un-scaled), U = D^-1 V (in place), and the LDS copy of V for the later block rows / phase (b)
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      const int row = 64 * P + 16 * I + g + 4 * r;
+      const double v = col_ok ? vp[I][r] : 0.0;
+      Vs[row][cl] = v;
+      if(col_ok) {
+        V[(int64_t)row * ldv + col] = v;
+        A[(int64_t)(K0 + row) * lda + col] = v * dall[row];
+      }
+    }
+}
+
+// one workgroup: LDL^T of the kbs x kbs (<= 256) diagonal block of a super-panel, panel after panel (left-looking):
+//   (a) the 64 columns of panel j go through block rows p < j (4 waves x 16 columns, MFMA)
+//   (b) A_jj -= sum_{p<j} V_pj^T D_p^-1 V_pj   (both MFMA operands from the LDS copy of V)
+//   (c) A_jj = U^T D U in LDS (diag_factor_lds), factor / compact copy / 16x16 inverses written out
+__global__ __launch_bounds__(kBlock) void ldlt_superdiag_kernel(double* __restrict__ A, int64_t lda, int K0, int kbs,
+                                                                double* __restrict__ V, int64_t ldv,
+                                                                double* __restrict__ dinv, double* __restrict__ Dk_sp,
+                                                                double* __restrict__ Li_sp, int* __restrict__ info,
+                                                                long long* __restrict__ tstamp)
+{
+  __shared__ double S[LD_nb][LD_nb + 1];
+  __shared__ double sdinv[LD_nb];
+  __shared__ double dall[LD_NB];
+  __shared__ double Vs[192][80];
+#define SD_STAMP(slot)                                                         \
+  do {                                                                         \
+    if(tstamp && threadIdx.x == 0) tstamp[slot] = (long long)wall_clock64(); \
+  } while(0)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int np = (kbs + LD_nb - 1) / LD_nb;
+  for(int j = 0; j < np; ++j) {
+    const int k0 = K0 + 64 * j;
+    const int kbj = (kbs - 64 * j < LD_nb) ? (kbs - 64 * j) : LD_nb;
+    const int cl = 16 * w + li;              // column inside panel j
+    const int64_t col = (int64_t)k0 + cl;
+    const bool col_ok = cl < kbj;
+    const int64_t colc = col_ok ? col : (int64_t)k0;   // clamped (loads stay in bounds)
+    SD_STAMP(j * 4 + 0);
+    // A_jj is not touched by phase (a): issue its loads now so their HBM latency hides behind (a)
+    double sv[LD_nb * LD_nb / kBlock];
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      const int r = e >> 6, c = e & 63;
+      const int rr = (r < kbj) ? r : (kbj - 1), cc = (c < kbj) ? c : (kbj - 1);
+      sv[q] = A[(int64_t)(k0 + rr) * lda + (k0 + cc)];
+    }
+    // ---- (a)
+#pragma unroll 1
+    for(int P = 0; P < j; ++P) {
+      if(P == j - 1) {
+        // only the newest block row needs what panel j-1 emitted (A rows, Dk, Li): drain this wave's stores here,
+        // after the older block rows have been processed, instead of stalling at the end of the previous panel
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      block_row_solve_lds(P, A, lda, V, ldv, K0, colc, col_ok, cl, Dk_sp, Li_sp, dall, g, li, S, Vs, tid);
+    }
+    // ---- (b) S = A_jj (upper, zero padded)
+    __syncthreads();   // every wave is done with the operand blocks staged in S during (a); Vs complete
+    SD_STAMP(j * 4 + 1);
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      const int r = e >> 6, c = e & 63;
+      S[r][c] = (r < kbj && c < kbj && c >= r) ? sv[q] : 0.0;
+    }
+    if(tid < LD_nb) sdinv[tid] = 1.0;
+    __syncthreads();
+    if(j > 0) {
+      double4_t acc[4];
+#pragma unroll
+      for(int wc = 0; wc < 4; ++wc) acc[wc] = double4_t{0.0, 0.0, 0.0, 0.0};
+      const int nk = 64 * j;   // rows of V above the diagonal block
+      for(int kb16 = 0; kb16 < nk; kb16 += 16) {
+        double aop[4], bop[4][4];
+#pragma unroll
+        for(int u = 0; u < 4; ++u) {
+          const int row = kb16 + 4 * u + g;
+          aop[u] = Vs[row][cl];                    // A operand [i = li][k = g]: V[row][my column]
+          const double di = dall[row];
+#pragma unroll
+          for(int wc = 0; wc < 4; ++wc) bop[u][wc] = Vs[row][16 * wc + li] * di;
+        }
+#pragma unroll
+        for(int u = 0; u < 4; ++u)
+#pragma unroll
+          for(int wc = 0; wc < 4; ++wc) acc[wc] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], bop[u][wc], acc[wc], 0, 0, 0);
+      }
+#pragma unroll
+      for(int wc = 0; wc < 4; ++wc)
+#pragma unroll
+        for(int reg = 0; reg < 4; ++reg) {
+          const int r = 16 * w + g + 4 * reg, c = 16 * wc + li;
+          if(c >= r) S[r][c] -= acc[wc][reg];
+        }
+      __syncthreads();
+    }
+    // ---- (c)
+    SD_STAMP(j * 4 + 2);
+    diag_factor_lds(S, sdinv, kbj, k0, info, Li_sp + j * (4 * LD_SB * LD_SB), tid);
+    SD_STAMP(j * 4 + 3);
+    diag_emit(S, sdinv, kbj, k0, A, lda, dinv, Dk_sp + j * (LD_nb * LD_nb), tid);
+    if(tid < LD_nb) dall[64 * j + tid] = sdinv[tid];
+    __syncthreads();   // dall / S hand-over; the global stores are drained lazily (see phase (a))
+  }
+  SD_STAMP(16);
+#undef SD_STAMP
+}
+
+// the row panel right of the super-panel's diagonal block: one wave per 16 columns, all (up to) 4 block rows
+__global__ __launch_bounds__(64) void ldlt_supertrsm_kernel(double* __restrict__ A, int64_t lda, int N, int K0, int kbs,
+                                                            double* __restrict__ V, int64_t ldv,
+                                                            const double* __restrict__ dinv,
+                                                            const double* __restrict__ Dk_sp,
+                                                            const double* __restrict__ Li_sp)
+{
+  const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
+  const int64_t col = (int64_t)K0 + kbs + (int64_t)blockIdx.x * 16 + li;
+  const bool col_ok = col < N;
+  const int64_t colc = col_ok ? col : (int64_t)(N - 1);
+  const int np = (kbs + LD_nb - 1) / LD_nb;
+  const double* dsp = dinv + K0;
+  double4_t Vv[4][4];
+#pragma unroll
+  for(int a = 0; a < 4; ++a)
+#pragma unroll
+    for(int b = 0; b < 4; ++b) Vv[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  block_row_solve<0, false>(A, lda, K0, kbs, colc, col_ok, Dk_sp, Li_sp, Vv, g, li);
+  block_row_store<0>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
+  if(np > 1) {
+    block_row_solve<1, false>(A, lda, K0, kbs, colc, col_ok, Dk_sp, Li_sp, Vv, g, li);
+    block_row_store<1>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
+  }
+  if(np > 2) {
+    block_row_solve<2, false>(A, lda, K0, kbs, colc, col_ok, Dk_sp, Li_sp, Vv, g, li);
+    block_row_store<2>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
+  }
+  if(np > 3) {
+    block_row_solve<3, false>(A, lda, K0, kbs, colc, col_ok, Dk_sp, Li_sp, Vv, g, li);
+    block_row_store<3>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   }
 }
 
@@ -732,28 +1072,39 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   const int64_t ldv = N;
   for(int K0 = 0; K0 < N; K0 += LD_NB) {
     const int Kend = (K0 + LD_NB < N) ? K0 + LD_NB : N;
-    for(int k0 = K0; k0 < Kend; k0 += LD_nb) {
-      const int kb = (k0 + LD_nb <= N) ? LD_nb : (N - k0);
-      const int ncols = N - k0 - kb;
-      double* Dk = Dblk + (int64_t)(k0 / LD_nb) * (LD_nb * LD_nb);
-      double* Lik = Li + (int64_t)(k0 / LD_nb) * (4 * LD_SB * LD_SB);
-      hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(kBlock), 0, st, A, lda, k0, kb, dinv, Dk, Lik, d_info);
-      if(ncols > 0) {
-        // a partial panel (kb < 64) can only be the last one, which has no columns to its right
-        const int g = (ncols + 63) / 64;
-        hipLaunchKernelGGL(ldlt_trsm_kernel, dim3(g), dim3(64), 0, st, A, lda, N, k0, V, ldv, k0 - K0, dinv, Dk, Lik);
-      }
-      if(k0 + kb < Kend) {
-        // rows of the super-panel below this panel
-        const int s = k0 + kb;
-        const int tr = (Kend - s + LD_TM - 1) / LD_TM, tc = (N - s + LD_TN - 1) / LD_TN;
-        launch_update(dim3(tc, tr), k0 - K0, k0, kb, s, Kend);
-      }
+    const int kbs = Kend - K0;
+    // per-super-panel slices of the compact factor copies (4 panels each)
+    double* Dk_sp = Dblk + (int64_t)(K0 / LD_nb) * (LD_nb * LD_nb);
+    double* Li_sp = Li + (int64_t)(K0 / LD_nb) * (4 * LD_SB * LD_SB);
+    // (1) the super-panel's 256 x 256 diagonal block: one workgroup, left-looking over its 4 panels
+    static long long* d_ts = nullptr;   // debug: HIOPAMD_SD_TRACE=1 prints the phase timeline of one super-panel
+    static int trace_state = -1;
+    if(trace_state < 0) trace_state = (std::getenv("HIOPAMD_SD_TRACE") != nullptr) ? 1 : 0;
+    long long* ts_arg = nullptr;
+    if(trace_state == 1 && K0 == 0 && kbs == LD_NB) {
+      if(!d_ts) (void)hipMalloc((void**)&d_ts, 32 * sizeof(long long));
+      ts_arg = d_ts;
+    }
+    hipLaunchKernelGGL(ldlt_superdiag_kernel, dim3(1), dim3(kBlock), 0, st, A, lda, K0, kbs, V, ldv, dinv, Dk_sp, Li_sp,
+                       d_info, ts_arg);
+    if(ts_arg) {
+      long long h[17];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, d_ts, sizeof(h), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "[hiop_amd] superdiag timeline (wall_clock64 ticks, 100 MHz => 10 ns):");
+      for(int q = 1; q <= 16; ++q) std::fprintf(stderr, " %lld", h[q] - h[0]);
+      std::fprintf(stderr, "\n");
+      trace_state = 2;
     }
     if(Kend < N) {
+      // (2) the row panel right of it: V = L^-1 A12, U12 = D^-1 V, one wave per 16 columns
+      const int ncols = N - Kend;
+      hipLaunchKernelGGL(ldlt_supertrsm_kernel, dim3((ncols + 15) / 16), dim3(64), 0, st, A, lda, N, K0, kbs, V, ldv, dinv,
+                         Dk_sp, Li_sp);
+      // (3) trailing update, K = 256
       const int s = Kend;
       const int t = (N - s + LD_TM - 1) / LD_TM;
-      launch_update(dim3(t, t), 0, K0, Kend - K0, s, N);
+      launch_update(dim3(t, t), 0, K0, kbs, s, N);
     }
   }
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
