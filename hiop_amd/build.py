@@ -28,6 +28,7 @@ SOURCES = [
     "small_solvers.hip",
     "kkt_mds.hip",
     "lowrank.hip",
+    "kkt_xycyd.hip",
 ]
 
 ARCH = "gfx950"

@@ -204,6 +204,67 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
   return HIOPAMD_OK;
 }
 
+int hiopamd_kkt_mds_set_diagonals(hiopamd_kkt_mds* k, const double* Dx, const double* Dd)
+{
+  if(!k) return HIOPAMD_ERR_ARG;
+  k->Dx = Dx;
+  k->Dd = Dd;
+  k->built = false;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_mds_dims(const hiopamd_kkt_mds* k, int* dims4_host)
+{
+  if(!k || !dims4_host) return HIOPAMD_ERR_ARG;
+  dims4_host[0] = k->s.nxs;
+  dims4_host[1] = k->s.nxd;
+  dims4_host[2] = k->s.neq;
+  dims4_host[3] = k->s.nineq;
+  return HIOPAMD_OK;
+}
+
+// y = beta*y + alpha*Hess*x, Hess = blockdiag(Hss (sym sparse), Hdd (dense))   (hiopMatrixMDS.hpp:310-318)
+int hiopamd_kkt_mds_hess_times_vec(hiopamd_kkt_mds* k, double beta, double* y, double alpha, const double* x)
+{
+  if(!k || !k->Hdd) return HIOPAMD_ERR_STATE;
+  const hiopamd_mds_structure& s = k->s;
+  RC(hiopamd_spsym_times_vec(k->ctx, s.nxs, s.nnz_Hss, s.Hss_i, s.Hss_j, k->Hss_val, beta, y, alpha, x));
+  RC(hiopamd_mat_times_vec(k->ctx, s.nxd, s.nxd, k->Hdd, s.nxd, beta, y + s.nxs, alpha, x + s.nxs));
+  return HIOPAMD_OK;
+}
+
+// y = beta*y + alpha*[Js Jd]*x                                                 (hiopMatrixMDS.hpp:68-74)
+int hiopamd_kkt_mds_jac_times_vec(hiopamd_kkt_mds* k, int which, double beta, double* y, double alpha, const double* x)
+{
+  if(!k || !k->Jcd) return HIOPAMD_ERR_STATE;
+  const hiopamd_mds_structure& s = k->s;
+  if(which == 0) {
+    RC(hiopamd_sp_times_vec(k->ctx, s.neq, s.nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, beta, y, alpha, x));
+    RC(hiopamd_mat_times_vec(k->ctx, s.neq, s.nxd, k->Jcd, s.nxd, 1.0, y, alpha, x + s.nxs));
+  } else {
+    RC(hiopamd_sp_times_vec(k->ctx, s.nineq, s.nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, beta, y, alpha, x));
+    RC(hiopamd_mat_times_vec(k->ctx, s.nineq, s.nxd, k->Jdd, s.nxd, 1.0, y, alpha, x + s.nxs));
+  }
+  return HIOPAMD_OK;
+}
+
+// y = beta*y + alpha*[Js Jd]^T*x                                               (hiopMatrixMDS.hpp:75-81)
+int hiopamd_kkt_mds_jac_trans_times_vec(hiopamd_kkt_mds* k, int which, double beta, double* y, double alpha,
+                                        const double* x)
+{
+  if(!k || !k->Jcd) return HIOPAMD_ERR_STATE;
+  const hiopamd_mds_structure& s = k->s;
+  if(which == 0) {
+    RC(hiopamd_sp_trans_times_vec(k->ctx, s.neq, s.nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, beta, y, alpha, x));
+    RC(hiopamd_mat_trans_times_vec(k->ctx, s.neq, s.nxd, k->Jcd, s.nxd, beta, y + s.nxs, alpha, x));
+  } else {
+    RC(hiopamd_sp_trans_times_vec(k->ctx, s.nineq, s.nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, beta, y, alpha, x));
+    RC(hiopamd_mat_trans_times_vec(k->ctx, s.nineq, s.nxd, k->Jdd, s.nxd, beta, y + s.nxs, alpha, x));
+  }
+  return HIOPAMD_OK;
+}
+
+double* hiopamd_kkt_mds_Dd_inv(hiopamd_kkt_mds* k) { return k ? k->Dd_inv : nullptr; }
 double* hiopamd_kkt_mds_sys_matrix(hiopamd_kkt_mds* k) { return k ? hiopamd_linsolver_sys_matrix(k->ls) : nullptr; }
 double* hiopamd_kkt_mds_Hxs(hiopamd_kkt_mds* k) { return k ? k->Hxs : nullptr; }
 hiopamd_linsolver* hiopamd_kkt_mds_linsolver(hiopamd_kkt_mds* k) { return k ? k->ls : nullptr; }

@@ -1,0 +1,977 @@
+// Full-space layer of the KKT hot path on MI355X: everything HiOp does per IPM iteration between "iterate +
+// residual" and "search direction", on top of a condensed XYcYd solver (MDS, dense or quasi-Newton low-rank):
+//
+//   update            hiopKKTLinSysCompressedXYcYd::update            src/Optimization/hiopKKTLinSys.cpp:543-583
+//   factorize         hiopKKTLinSysCurvCheck::factorize               :316-376   (inertia-correction loop)
+//                     hiopPDPerturbationPrimalFirstScalar             hiopPDPerturbation.cpp:161-395
+//                     hiopFactAcceptorIC::requireReFactorization      hiopFactAcceptor.cpp:63-104
+//   compute_directions hiopKKTLinSysCompressedXYcYd::computeDirections :585-690
+//                     hiopKKTLinSys::compute_directions_for_full_space :218-314
+//   times_vec         hiopMatVecKKTFullOpr::times_vec                 :1619-1736
+//   compute_directions_w_IR  hiopKKTLinSys::compute_directions_w_IR   :911-961
+//                     hiopBiCGStabSolver::solve                       src/LinAlg/hiopKrylovSolver.cpp:390-700
+//                     hiopPrecondKKTOpr::times_vec                    hiopKKTLinSys.cpp:1900-1909
+//   dense backend     hiopKKTLinSysDenseXYcYd                         hiopKKTLinSysDense.hpp:84-212
+//
+// Data layout: an iterate / direction / residual is ONE contiguous fp64 slab in HBM holding the 12 parts in the
+// order of hiopVectorCompoundPD (hiopVectorCompoundPD.cpp:99-210)
+//     [ x | d | yc | yd | sxl | sxu | sdl | sdu | zl | zu | vl | vu ]        (residual: rx rd ryc ryd rxl ... rsvu)
+// so that every compound-vector operation of the Krylov loop is a single launch, and the rhs reduction /
+// direction recovery / 12-block operator are one fused element-wise kernel each instead of ~40 BLAS-1 calls.
+#include "device_utils.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+using namespace hiopamd;
+
+#define RC(x)                         \
+  do {                                \
+    int rc_ = (x);                    \
+    if(rc_ != HIOPAMD_OK) return rc_; \
+  } while(0)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// hiopPDPerturbationPrimalFirstScalar: scalar state machine, lives on the host like in the reference
+// ------------------------------------------------------------------------------------------------------
+struct PdPerturb {
+  enum Degeneracy { NotEstablished, NotDegenerate, Degenerate };
+  enum TestType { NoTest, Dc0Dw0, DcposDw0, Dc0Dwpos, DcposDwpos };
+  bool null_mode = false;   // hiopPDPerturbationNull (quasi-Newton path): deltas stay 0
+  double wx = 0, wd = 0, cc = 0, cd = 0;
+  double wx_last = 0, wd_last = 0, cc_last = 0, cd_last = 0;
+  // hiopOptions.cpp:1080-1123 defaults
+  double delta_w_min_bar = 1e-20, delta_w_max_bar = 1e20, delta_w_0_bar = 1e-4, kappa_w_minus = 1. / 3,
+         kappa_w_plus_bar = 100., kappa_w_plus = 8., delta_c_bar = 1e-8, kappa_c = 0.25;
+  Degeneracy hess_degenerate = NotEstablished, jac_degenerate = NotEstablished;
+  int num_degen_iters = 0;
+  const int num_degen_max_iters = 3;
+  TestType test_type = NoTest;
+  double mu = 1e-8;
+
+  double compute_delta_c() const { return delta_c_bar * std::pow(mu, kappa_c); }   // :361
+
+  void update_degeneracy_type()   // :108-157
+  {
+    switch(test_type) {
+      case NoTest: return;
+      case Dc0Dw0:
+        if(hess_degenerate == NotEstablished && jac_degenerate == NotEstablished) {
+          hess_degenerate = jac_degenerate = NotDegenerate;
+        } else if(hess_degenerate == NotEstablished) {
+          hess_degenerate = NotDegenerate;
+        } else if(jac_degenerate == NotEstablished) {
+          jac_degenerate = NotDegenerate;
+        }
+        break;
+      case DcposDw0:
+        if(hess_degenerate == NotEstablished) hess_degenerate = NotDegenerate;
+        if(jac_degenerate == NotEstablished) {
+          if(++num_degen_iters >= num_degen_max_iters) jac_degenerate = Degenerate;
+        }
+        break;
+      case Dc0Dwpos:
+        if(jac_degenerate == NotEstablished) jac_degenerate = NotDegenerate;
+        if(hess_degenerate == NotEstablished) {
+          if(++num_degen_iters >= num_degen_max_iters) hess_degenerate = Degenerate;
+        }
+        break;
+      case DcposDwpos:
+        if(++num_degen_iters >= num_degen_max_iters) hess_degenerate = jac_degenerate = Degenerate;
+        break;
+    }
+  }
+
+  bool guts_wrong_inertia()   // :331-358
+  {
+    if(wx == 0.) {
+      wx = (wx_last == 0.) ? delta_w_0_bar : std::fmax(delta_w_min_bar, wx_last * kappa_w_minus);
+    } else {
+      wx = (wx_last == 0. || 1e5 * wx_last < wx) ? kappa_w_plus_bar * wx : kappa_w_plus * wx;
+    }
+    wd = wx;
+    if(wx > delta_w_max_bar) {
+      wx_last = wd_last = 0.;
+      return false;
+    }
+    return true;
+  }
+
+  bool compute_initial_deltas()   // :161-212
+  {
+    if(null_mode) return true;
+    double delta_temp = 0.0, delta_temp2 = 0.0;
+    update_degeneracy_type();
+    if(wx > 0.) wx_last = wx;
+    if(wd > 0.) wd_last = wd;
+    if(cc > 0.) cc_last = cc;
+    if(cd > 0.) cd_last = cd;
+    test_type = (hess_degenerate == NotEstablished || jac_degenerate == NotEstablished) ? Dc0Dw0 : NoTest;
+    delta_temp = (jac_degenerate == Degenerate) ? compute_delta_c() : 0.0;
+    cc = cd = delta_temp;
+    if(hess_degenerate == Degenerate) {
+      wx = wd = 0.;
+      if(!guts_wrong_inertia()) return false;
+      // the reference then assigns its two locals, which the call above never writes (:203-209)
+    } else {
+      delta_temp = delta_temp2 = 0.;
+    }
+    wx = delta_temp;
+    wd = delta_temp2;
+    return true;
+  }
+
+  bool compute_perturb_wrong_inertia()   // :215-243
+  {
+    if(null_mode) return true;
+    update_degeneracy_type();
+    bool ret = guts_wrong_inertia();
+    if(!ret && cc == 0.) {
+      wx = wd = 0.;
+      cc = cd = compute_delta_c();
+      test_type = NoTest;
+      if(hess_degenerate == Degenerate) hess_degenerate = NotEstablished;
+      ret = guts_wrong_inertia();
+    }
+    return ret;
+  }
+
+  bool compute_perturb_singularity()   // :248-325
+  {
+    if(null_mode) return true;
+    bool bret = true;
+    if(hess_degenerate == NotEstablished || jac_degenerate == NotEstablished) {
+      switch(test_type) {
+        case Dc0Dw0:
+          if(jac_degenerate == NotEstablished) {
+            cc = cd = compute_delta_c();
+            test_type = DcposDw0;
+          } else {
+            if(!guts_wrong_inertia()) {
+              bret = false;
+              break;
+            }
+            test_type = Dc0Dwpos;
+          }
+          break;
+        case DcposDw0:
+          cd = cc = 0.;
+          if(!guts_wrong_inertia()) {
+            bret = false;
+            break;
+          }
+          test_type = Dc0Dwpos;
+          break;
+        case Dc0Dwpos:
+          cc = cd = compute_delta_c();
+          if(!guts_wrong_inertia()) {
+            bret = false;
+            break;
+          }
+          test_type = DcposDwpos;
+          break;
+        case DcposDwpos:
+          if(!guts_wrong_inertia()) bret = false;
+          break;
+        case NoTest: bret = false; break;   // the reference asserts here (:302)
+      }
+    } else {
+      if(cc > 0.) {
+        if(!guts_wrong_inertia()) bret = false;
+      } else {
+        cd = cc = compute_delta_c();
+      }
+    }
+    return bret;
+  }
+};
+
+// hiopFactAcceptorIC::requireReFactorization (hiopFactAcceptor.cpp:63-104)
+int require_refactorization(PdPerturb& pd, int n_required_neg_eig, int n_neg_eig)
+{
+  if(n_required_neg_eig > 0) {
+    if(n_neg_eig < 0) return pd.compute_perturb_singularity() ? 1 : -1;
+    if(n_neg_eig != n_required_neg_eig) return pd.compute_perturb_wrong_inertia() ? 1 : -1;
+    return 0;
+  }
+  if(n_neg_eig != 0) return pd.compute_perturb_wrong_inertia() ? 1 : -1;
+  return 0;
+}
+
+enum Kind { KIND_MDS = 1, KIND_DENSE = 2, KIND_LOWRANK = 3 };
+
+// two sums in one pass: the column-partitioned parts of the slab (x-sized, all-reduced) and the replicated ones
+struct dot2_t {
+  double dist, repl;
+};
+struct OpSlabDot2 {
+  const double *a, *b;
+  int64_t o1, o4, o6, o8, o10;   // dist = [0,o1) u [o4,o6) u [o8,o10)
+  __device__ dot2_t identity() const { return dot2_t{0.0, 0.0}; }
+  __device__ dot2_t map(int64_t i) const
+  {
+    const double p = a[i] * b[i];
+    const bool dist = i < o1 || (i >= o4 && i < o6) || (i >= o8 && i < o10);
+    return dist ? dot2_t{p, 0.0} : dot2_t{0.0, p};
+  }
+  __device__ dot2_t combine(dot2_t p, dot2_t q) const { return dot2_t{p.dist + q.dist, p.repl + q.repl}; }
+};
+
+__device__ inline double sel(double pattern, double v) { return pattern == 0.0 ? 0.0 : v; }
+
+}  // namespace
+
+struct hiopamd_kkt_xycyd {
+  hiopamd_ctx* ctx = nullptr;
+  int kind = 0;
+  int64_t nx = 0;
+  int nd = 0, nyc = 0, nyd = 0;
+  int64_t off[13] = {0};
+  int64_t dim = 0;
+  const double *ixl = nullptr, *ixu = nullptr, *idl = nullptr, *idu = nullptr;   // borrowed, device
+  const double* iter = nullptr;                                                   // borrowed, device slab
+  hiopamd_kkt_mds* mds = nullptr;
+  hiopamd_kkt_lowrank* lr = nullptr;
+  // dense backend (hiopKKTLinSysDenseXYcYd) and the Jacobians of the low-rank backend
+  hiopamd_linsolver* ls = nullptr;
+  const double *H = nullptr, *Jc = nullptr, *Jd = nullptr;
+  double *dense_rhs = nullptr, *dense_Dd_inv = nullptr;
+  // owned
+  double *Dx = nullptr, *Dd = nullptr, *rx_tilde = nullptr, *ryd_tilde = nullptr, *ryd2 = nullptr;
+  double* krylov = nullptr;   // 9 slabs, allocated at the first IR call
+  double* dsmall = nullptr;   // 4 doubles of device scratch for the sharded dot
+  PdPerturb pd;
+  int n_required_neg = 0;
+  int num_refact = 0;
+};
+
+namespace {
+
+const double* Dd_inv_of(hiopamd_kkt_xycyd* h)
+{
+  switch(h->kind) {
+    case KIND_MDS: return hiopamd_kkt_mds_Dd_inv(h->mds);
+    case KIND_LOWRANK: return hiopamd_kkt_lowrank_Dd_inv(h->lr);
+    default: return h->dense_Dd_inv;
+  }
+}
+
+// ---- backend: (re)build the condensed matrix for the current deltas -----------------------------------
+int backend_build(hiopamd_kkt_xycyd* h)
+{
+  const PdPerturb& pd = h->pd;
+  hiopamd_ctx* ctx = h->ctx;
+  if(h->kind == KIND_MDS) return hiopamd_kkt_mds_build(h->mds, pd.wx, pd.wd, pd.cc, pd.cd);
+  if(h->kind == KIND_LOWRANK) return HIOPAMD_OK;   // N is formed inside solveCompressed (hiopKKTLinSys.cpp:1132)
+  // hiopKKTLinSysDenseXYcYd::build_kkt_matrix (hiopKKTLinSysDense.hpp:84-170)
+  if(!h->H || (!h->Jc && h->nyc > 0) || (!h->Jd && h->nyd > 0)) return HIOPAMD_ERR_STATE;
+  const int nx = (int)h->nx, neq = h->nyc, nineq = h->nyd, n = nx + neq + nineq;
+  double* M = hiopamd_linsolver_sys_matrix(h->ls);
+  HIOPAMD_CHECK(hipMemsetAsync(M, 0, sizeof(double) * (size_t)n * (size_t)n, ctx->stream));     // :134
+  RC(hiopamd_mat_add_upper_to_sym_upper(ctx, nx, h->H, nx, 0, 1.0, M, n));                       // :137
+  RC(hiopamd_mat_trans_add_to_sym_upper(ctx, neq, nx, h->Jc, nx, 0, nx, 1.0, M, n));             // :139
+  RC(hiopamd_mat_trans_add_to_sym_upper(ctx, nineq, nx, h->Jd, nx, 0, nx + neq, 1.0, M, n));     // :140
+  RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, 0, 1.0, h->Dx, 0, nx));                             // :142
+  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, 0, nx, pd.wx));                               // :143
+  {
+    const double* Dd = h->Dd;
+    double* Ddi = h->dense_Dd_inv;
+    const double dwd = pd.wd;
+    RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { Ddi[i] = 1.0 / (dwd + Dd[i]); }));      // :146-152
+  }
+  RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, nx + neq, -1.0, h->dense_Dd_inv, 0, nineq));        // :155
+  // :160 is literally addSubDiagonal(-1, nx, delta_cd): nineq entries starting at diagonal position nx
+  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx, nineq, -pd.cd));
+  return HIOPAMD_OK;
+}
+
+int backend_factorize(hiopamd_kkt_xycyd* h, int* n_neg)
+{
+  if(h->kind == KIND_MDS) return hiopamd_kkt_mds_factorize(h->mds, n_neg);
+  if(h->kind == KIND_LOWRANK) {
+    *n_neg = h->n_required_neg;
+    return HIOPAMD_OK;
+  }
+  return hiopamd_linsolver_matrix_changed(h->ls, n_neg);   // hiopKKTLinSys.cpp:310-313
+}
+
+// solveCompressed: rx and ryd may be overwritten (the reference's classes do the same)
+int backend_solve(hiopamd_kkt_xycyd* h, double* rx, const double* ryc, double* ryd, double* dx, double* dyc,
+                  double* dyd, int* ok)
+{
+  *ok = 1;
+  hiopamd_ctx* ctx = h->ctx;
+  if(h->kind == KIND_MDS) return hiopamd_kkt_mds_solve_compressed(h->mds, rx, ryc, ryd, dx, dyc, dyd);
+  if(h->kind == KIND_LOWRANK) return hiopamd_kkt_lowrank_solve_compressed(h->lr, rx, ryc, ryd, dx, dyc, dyd, ok);
+  // hiopKKTLinSysDenseXYcYd::solveCompressed (hiopKKTLinSysDense.hpp:172-212)
+  const int nx = (int)h->nx, nyc = h->nyc, nyd = h->nyd;
+  RC(hiopamd_vec_copy(ctx, nx, h->dense_rhs, rx));
+  RC(hiopamd_vec_copy(ctx, nyc, h->dense_rhs + nx, ryc));
+  RC(hiopamd_vec_copy(ctx, nyd, h->dense_rhs + nx + nyc, ryd));
+  RC(hiopamd_linsolver_solve(h->ls, h->dense_rhs, 1));
+  RC(hiopamd_vec_copy(ctx, nx, dx, h->dense_rhs));
+  RC(hiopamd_vec_copy(ctx, nyc, dyc, h->dense_rhs + nx));
+  RC(hiopamd_vec_copy(ctx, nyd, dyd, h->dense_rhs + nx + nyc));
+  return HIOPAMD_OK;
+}
+
+int backend_hess_times_vec(hiopamd_kkt_xycyd* h, double* y, const double* x)   // y = Hess*x
+{
+  if(h->kind == KIND_MDS) return hiopamd_kkt_mds_hess_times_vec(h->mds, 0.0, y, 1.0, x);
+  if(h->kind == KIND_LOWRANK)   // hiopHessianLowRank::timesVec: no log-barrier term (hiopHessianLowRank.cpp:1061)
+    return hiopamd_hess_lowrank_times_vec(hiopamd_kkt_lowrank_hess(h->lr), 0.0, y, 1.0, x, 0);
+  return hiopamd_mat_times_vec(h->ctx, (int)h->nx, h->nx, h->H, h->nx, 0.0, y, 1.0, x);
+}
+
+// yc = Jc*x, yd = Jd*x (yc, yd contiguous: one all-reduce on a column partition)
+int backend_jac_times_vec(hiopamd_kkt_xycyd* h, double* ycd, const double* x)
+{
+  hiopamd_ctx* ctx = h->ctx;
+  if(h->kind == KIND_MDS) {
+    RC(hiopamd_kkt_mds_jac_times_vec(h->mds, 0, 0.0, ycd, 1.0, x));
+    return hiopamd_kkt_mds_jac_times_vec(h->mds, 1, 0.0, ycd + h->nyc, 1.0, x);
+  }
+  if(h->kind == KIND_LOWRANK) {
+    const int k = h->nyc + h->nyd;
+    RC(hiopamd_mat_times_vec(ctx, k, h->nx, hiopamd_kkt_lowrank_J(h->lr), h->nx, 0.0, ycd, 1.0, x));
+    if(ctx->allreduce && ctx->allreduce(ctx->allreduce_user, ycd, (size_t)k, HIOPAMD_SUM, (void*)ctx->stream) != 0)
+      return HIOPAMD_ERR_HIP;
+    return HIOPAMD_OK;
+  }
+  RC(hiopamd_mat_times_vec(ctx, h->nyc, h->nx, h->Jc, h->nx, 0.0, ycd, 1.0, x));
+  return hiopamd_mat_times_vec(ctx, h->nyd, h->nx, h->Jd, h->nx, 0.0, ycd + h->nyc, 1.0, x);
+}
+
+// y += Jc^T*yc + Jd^T*yd
+int backend_jac_trans_times_vec_add(hiopamd_kkt_xycyd* h, double* y, const double* yc, const double* yd)
+{
+  hiopamd_ctx* ctx = h->ctx;
+  if(h->kind == KIND_MDS) {
+    RC(hiopamd_kkt_mds_jac_trans_times_vec(h->mds, 0, 1.0, y, 1.0, yc));
+    return hiopamd_kkt_mds_jac_trans_times_vec(h->mds, 1, 1.0, y, 1.0, yd);
+  }
+  if(h->kind == KIND_LOWRANK) {   // [Jc; Jd]^T [yc; yd] in one pass (yc, yd contiguous in the slab)
+    if(yd != yc + h->nyc) return HIOPAMD_ERR_ARG;
+    return hiopamd_mat_trans_times_vec(ctx, h->nyc + h->nyd, h->nx, hiopamd_kkt_lowrank_J(h->lr), h->nx, 1.0, y, 1.0, yc);
+  }
+  RC(hiopamd_mat_trans_times_vec(ctx, h->nyc, h->nx, h->Jc, h->nx, 1.0, y, 1.0, yc));
+  return hiopamd_mat_trans_times_vec(ctx, h->nyd, h->nx, h->Jd, h->nx, 1.0, y, 1.0, yd);
+}
+
+// ---- compound-vector reductions --------------------------------------------------------------------------
+int slab_dot(hiopamd_kkt_xycyd* h, const double* a, const double* b, double* out)
+{
+  hiopamd_ctx* ctx = h->ctx;
+  if(!(h->kind == KIND_LOWRANK && ctx->allreduce)) return hiopamd_vec_dot(ctx, h->dim, a, b, out);
+  // column partition: x, sxl, sxu, zl, zu are distributed, the rest is replicated
+  // (hiopVectorCompoundPD::dotProductWith sums the parts' own dot products)
+  dot2_t r{0.0, 0.0};
+  RC(launch_reduce<dot2_t>(ctx, h->dim, OpSlabDot2{a, b, h->off[1], h->off[4], h->off[6], h->off[8], h->off[10]}, &r));
+  HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, &r.dist, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+  if(ctx->allreduce(ctx->allreduce_user, h->dsmall, 1, HIOPAMD_SUM, (void*)ctx->stream) != 0) return HIOPAMD_ERR_HIP;
+  HIOPAMD_CHECK(hipMemcpyAsync(&r.dist, h->dsmall, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = r.dist + r.repl;
+  return HIOPAMD_OK;
+}
+
+int slab_norm(hiopamd_kkt_xycyd* h, const double* a, double* out)
+{
+  double d = 0.0;
+  RC(slab_dot(h, a, a, &d));
+  *out = std::sqrt(d);
+  return HIOPAMD_OK;
+}
+
+// ---- the fused element-wise stages ---------------------------------------------------------------------
+// (1) update: Dx = zl/sxl + zu/sxu, Dd = vl/sdl + vu/sdu on the bound patterns                      (:562-572)
+int stage_update_diagonals(hiopamd_kkt_xycyd* h)
+{
+  const double* it = h->iter;
+  const int64_t* o = h->off;
+  const int64_t nx = h->nx, nd = h->nd;
+  const double *sxl = it + o[4], *sxu = it + o[5], *sdl = it + o[6], *sdu = it + o[7], *zl = it + o[8],
+               *zu = it + o[9], *vl = it + o[10], *vu = it + o[11];
+  const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu;
+  double *Dx = h->Dx, *Dd = h->Dd;
+  return launch_ew(h->ctx, std::max<int64_t>(nx, nd), [=] __device__(int64_t i) {
+    if(i < nx) {
+      double v = 0.0;
+      if(ixl[i] == 1.0) v += zl[i] / sxl[i];
+      if(ixu[i] == 1.0) v += zu[i] / sxu[i];
+      Dx[i] = v;
+    }
+    if(i < nd) {
+      double v = 0.0;
+      if(idl[i] == 1.0) v += vl[i] / sdl[i];
+      if(idu[i] == 1.0) v += vu[i] / sdu[i];
+      Dd[i] = v;
+    }
+  });
+}
+
+// (2) reduction of the 12-part residual to the XYcYd right-hand side                                 (:599-640)
+int stage_reduce_rhs(hiopamd_kkt_xycyd* h, const double* r)
+{
+  const double* it = h->iter;
+  const int64_t* o = h->off;
+  const int64_t nx = h->nx, nd = h->nd;
+  const double *sxl = it + o[4], *sxu = it + o[5], *sdl = it + o[6], *sdu = it + o[7], *zl = it + o[8],
+               *zu = it + o[9], *vl = it + o[10], *vu = it + o[11];
+  const double *rx = r + o[0], *rd = r + o[1], *ryd = r + o[3], *rxl = r + o[4], *rxu = r + o[5], *rdl = r + o[6],
+               *rdu = r + o[7], *rszl = r + o[8], *rszu = r + o[9], *rsvl = r + o[10], *rsvu = r + o[11];
+  const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu;
+  const double* Ddi = Dd_inv_of(h);
+  double *rx_tilde = h->rx_tilde, *ryd_tilde = h->ryd_tilde, *ryd2 = h->ryd2;
+  return launch_ew(h->ctx, std::max<int64_t>(nx, nd), [=] __device__(int64_t i) {
+    if(i < nx) {
+      double v = rx[i];
+      if(ixl[i] == 1.0) v += (rszl[i] - zl[i] * rxl[i]) / sxl[i];
+      if(ixu[i] == 1.0) v -= (rszu[i] - zu[i] * rxu[i]) / sxu[i];
+      rx_tilde[i] = v;
+    }
+    if(i < nd) {
+      double v = rd[i];
+      if(idl[i] == 1.0) v += (rsvl[i] - vl[i] * rdl[i]) / sdl[i];
+      if(idu[i] == 1.0) v -= (rsvu[i] - vu[i] * rdu[i]) / sdu[i];
+      ryd2[i] = v;
+      ryd_tilde[i] = ryd[i] + v * Ddi[i];
+    }
+  });
+}
+
+// (3) dd and the eight bound-slack / bound-dual directions                              (:664-666, :218-284)
+int stage_recover_directions(hiopamd_kkt_xycyd* h, const double* r, double* dir)
+{
+  const double* it = h->iter;
+  const int64_t* o = h->off;
+  const int64_t nx = h->nx, nd = h->nd;
+  const double *sxl = it + o[4], *sxu = it + o[5], *sdl = it + o[6], *sdu = it + o[7], *zl = it + o[8],
+               *zu = it + o[9], *vl = it + o[10], *vu = it + o[11];
+  const double *rxl = r + o[4], *rxu = r + o[5], *rdl = r + o[6], *rdu = r + o[7], *rszl = r + o[8],
+               *rszu = r + o[9], *rsvl = r + o[10], *rsvu = r + o[11];
+  const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu;
+  const double* Ddi = Dd_inv_of(h);
+  const double* ryd2 = h->ryd2;
+  const double *dx = dir + o[0], *dyd = dir + o[3];
+  double *dd = dir + o[1], *dsxl = dir + o[4], *dsxu = dir + o[5], *dsdl = dir + o[6], *dsdu = dir + o[7],
+         *dzl = dir + o[8], *dzu = dir + o[9], *dvl = dir + o[10], *dvu = dir + o[11];
+  return launch_ew(h->ctx, std::max<int64_t>(nx, nd), [=] __device__(int64_t i) {
+    if(i < nx) {
+      const double x = dx[i];
+      const double sl = sel(ixl[i], rxl[i] + x);
+      dsxl[i] = sl;
+      dzl[i] = ixl[i] == 0.0 ? 0.0 : (rszl[i] - zl[i] * sl) / sxl[i];
+      const double su = sel(ixu[i], rxu[i] - x);
+      dsxu[i] = su;
+      dzu[i] = ixu[i] == 0.0 ? 0.0 : (rszu[i] - zu[i] * su) / sxu[i];
+    }
+    if(i < nd) {
+      const double d = (ryd2[i] + dyd[i]) * Ddi[i];
+      dd[i] = d;
+      const double sl = sel(idl[i], rdl[i] + d);
+      dsdl[i] = sl;
+      dvl[i] = idl[i] == 0.0 ? 0.0 : (rsvl[i] - vl[i] * sl) / sdl[i];
+      const double su = sel(idu[i], rdu[i] - d);
+      dsdu[i] = su;
+      dvu[i] = idu[i] == 0.0 ? 0.0 : (rsvu[i] - vu[i] * su) / sdu[i];
+    }
+  });
+}
+
+// (4) all element-wise terms of the 12-block operator; the matrix products are already in y's rx/ryc/ryd parts
+int stage_times_vec_ew(hiopamd_kkt_xycyd* h, double* y, const double* x)
+{
+  const double* it = h->iter;
+  const int64_t* o = h->off;
+  const int64_t nx = h->nx, nd = h->nd, nyc = h->nyc;
+  const double *sxl = it + o[4], *sxu = it + o[5], *sdl = it + o[6], *sdu = it + o[7], *zl = it + o[8],
+               *zu = it + o[9], *vl = it + o[10], *vu = it + o[11];
+  const double *dx = x + o[0], *dd = x + o[1], *dyc = x + o[2], *dyd = x + o[3], *dsxl = x + o[4], *dsxu = x + o[5],
+               *dsdl = x + o[6], *dsdu = x + o[7], *dzl = x + o[8], *dzu = x + o[9], *dvl = x + o[10],
+               *dvu = x + o[11];
+  double *yrx = y + o[0], *yrd = y + o[1], *yryc = y + o[2], *yryd = y + o[3], *yrxl = y + o[4], *yrxu = y + o[5],
+         *yrdl = y + o[6], *yrdu = y + o[7], *yrszl = y + o[8], *yrszu = y + o[9], *yrsvl = y + o[10],
+         *yrsvu = y + o[11];
+  const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu;
+  const double dwx = h->pd.wx, dwd = h->pd.wd, dcc = h->pd.cc, dcd = h->pd.cd;
+  const int64_t n = std::max<int64_t>(std::max<int64_t>(nx, nd), nyc);
+  return launch_ew(h->ctx, n, [=] __device__(int64_t i) {
+    if(i < nx) {
+      const double xv = dx[i];
+      yrx[i] += dwx * xv - dzl[i] + dzu[i];                       // :1672-1678
+      yrxl[i] = sel(ixl[i], dsxl[i] - xv);                        // :1697-1699
+      yrxu[i] = sel(ixu[i], dsxu[i] + xv);                        // :1702-1704
+      yrszl[i] = sxl[i] * dzl[i] + zl[i] * dsxl[i];               // :1717-1719
+      yrszu[i] = sxu[i] * dzu[i] + zu[i] * dsxu[i];               // :1722-1724
+    }
+    if(i < nd) {
+      const double dv = dd[i], ydv = dyd[i];
+      yrd[i] = -ydv - dvl[i] + dvu[i] + dwd * dv;                 // :1681-1685
+      yryd[i] += -dv - dcd * ydv;                                 // :1692-1694
+      yrdl[i] = sel(idl[i], dsdl[i] - dv);                        // :1707-1709
+      yrdu[i] = sel(idu[i], dsdu[i] + dv);                        // :1712-1714
+      yrsvl[i] = sdl[i] * dvl[i] + vl[i] * dsdl[i];               // :1727-1729
+      yrsvu[i] = sdu[i] * dvu[i] + vu[i] * dsdu[i];               // :1732-1734
+    }
+    if(i < nyc) yryc[i] -= dcc * dyc[i];                          // :1688-1689
+  });
+}
+
+int do_factorize(hiopamd_kkt_xycyd* h, int* ok)   // hiopKKTLinSysCurvCheck::factorize (:316-376)
+{
+  const int max_refactorization = 10;
+  h->num_refact = 0;
+  *ok = 0;
+  if(!h->pd.compute_initial_deltas()) return HIOPAMD_OK;
+  while(h->num_refact <= max_refactorization) {
+    RC(backend_build(h));
+    int n_neg = 0;
+    RC(backend_factorize(h, &n_neg));
+    const int cont = require_refactorization(h->pd, h->n_required_neg, n_neg);
+    if(cont == -1) return HIOPAMD_OK;
+    if(cont == 0) break;
+    h->num_refact++;
+  }
+  *ok = h->num_refact <= max_refactorization ? 1 : 0;
+  return HIOPAMD_OK;
+}
+
+int do_compute_directions(hiopamd_kkt_xycyd* h, const double* resid, double* dir, int* ok)
+{
+  if(!h->iter) return HIOPAMD_ERR_STATE;
+  if(resid == dir) return HIOPAMD_ERR_ARG;
+  const int64_t* o = h->off;
+  RC(stage_reduce_rhs(h, resid));
+  RC(backend_solve(h, h->rx_tilde, resid + o[2], h->ryd_tilde, dir + o[0], dir + o[2], dir + o[3], ok));
+  // the reference recovers dd before testing sol_ok and skips the rest on failure (:664-681)
+  return stage_recover_directions(h, resid, dir);
+}
+
+int do_times_vec(hiopamd_kkt_xycyd* h, double* y, const double* x)
+{
+  if(!h->iter) return HIOPAMD_ERR_STATE;
+  if(x == y) return HIOPAMD_ERR_ARG;
+  const int64_t* o = h->off;
+  RC(backend_hess_times_vec(h, y + o[0], x + o[0]));
+  RC(backend_jac_trans_times_vec_add(h, y + o[0], x + o[2], x + o[3]));
+  RC(backend_jac_times_vec(h, y + o[2], x + o[0]));
+  return stage_times_vec_ew(h, y, x);
+}
+
+// r = b - A*x
+int residual_into(hiopamd_kkt_xycyd* h, double* r, const double* b, const double* x)
+{
+  RC(do_times_vec(h, r, x));
+  return launch_ew(h->ctx, h->dim, [=] __device__(int64_t i) { r[i] = b[i] - r[i]; });
+}
+
+}  // namespace
+
+extern "C" {
+
+static int create_common(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, int kind, int64_t nx, int nd, int nyc, int nyd,
+                         const double* ixl, const double* ixu, const double* idl, const double* idu)
+{
+  if(!out || !ctx || nx < 0 || nd < 0 || nyc < 0 || nyd < 0) return HIOPAMD_ERR_ARG;
+  if((nx > 0 && (!ixl || !ixu)) || (nd > 0 && (!idl || !idu))) return HIOPAMD_ERR_ARG;
+  hiopamd_kkt_xycyd* h = new hiopamd_kkt_xycyd();
+  h->ctx = ctx;
+  h->kind = kind;
+  h->nx = nx;
+  h->nd = nd;
+  h->nyc = nyc;
+  h->nyd = nyd;
+  const int64_t sz[12] = {nx, nd, nyc, nyd, nx, nx, nd, nd, nx, nx, nd, nd};
+  for(int p = 0; p < 12; ++p) h->off[p + 1] = h->off[p] + sz[p];
+  h->dim = h->off[12];
+  h->ixl = ixl;
+  h->ixu = ixu;
+  h->idl = idl;
+  h->idu = idu;
+  h->n_required_neg = nyc + nyd;   // hiopAlgFilterIPM.cpp:2096
+  auto A = [](double** p, size_t n) { return hipMalloc((void**)p, sizeof(double) * (n ? n : 1)) == hipSuccess; };
+  if(!(A(&h->Dx, nx) && A(&h->Dd, nd) && A(&h->rx_tilde, nx) && A(&h->ryd_tilde, nd) && A(&h->ryd2, nd) &&
+       A(&h->dsmall, 4))) {
+    hiopamd_kkt_xycyd_destroy(h);
+    return HIOPAMD_ERR_HIP;
+  }
+  *out = h;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_create_mds(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_mds* k, const double* ixl,
+                                 const double* ixu, const double* idl, const double* idu)
+{
+  if(!k) return HIOPAMD_ERR_ARG;
+  int d[4];
+  RC(hiopamd_kkt_mds_dims(k, d));
+  RC(create_common(out, ctx, KIND_MDS, (int64_t)d[0] + d[1], d[3], d[2], d[3], ixl, ixu, idl, idu));
+  (*out)->mds = k;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_create_dense(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, int nx, int neq, int nineq,
+                                   const double* ixl, const double* ixu, const double* idl, const double* idu)
+{
+  RC(create_common(out, ctx, KIND_DENSE, nx, nineq, neq, nineq, ixl, ixu, idl, idu));
+  hiopamd_kkt_xycyd* h = *out;
+  int rc = hiopamd_linsolver_create(&h->ls, ctx, nx + neq + nineq);
+  if(rc == HIOPAMD_OK &&
+     (hipMalloc((void**)&h->dense_rhs, sizeof(double) * (size_t)(nx + neq + nineq + 1)) != hipSuccess ||
+      hipMalloc((void**)&h->dense_Dd_inv, sizeof(double) * (size_t)(nineq + 1)) != hipSuccess))
+    rc = HIOPAMD_ERR_HIP;
+  if(rc != HIOPAMD_OK) {
+    hiopamd_kkt_xycyd_destroy(h);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int hiopamd_kkt_xycyd_create_lowrank(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_lowrank* K,
+                                     const double* ixl, const double* ixu, const double* idl, const double* idu)
+{
+  if(!K) return HIOPAMD_ERR_ARG;
+  int64_t n = 0;
+  int me = 0, mi = 0;
+  RC(hiopamd_kkt_lowrank_dims(K, &n, &me, &mi));
+  RC(create_common(out, ctx, KIND_LOWRANK, n, mi, me, mi, ixl, ixu, idl, idu));
+  (*out)->lr = K;
+  (*out)->pd.null_mode = true;   // hiopAlgFilterIPMQuasiNewton uses hiopPDPerturbationNull (hiopAlgFilterIPM.cpp:1054)
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_destroy(hiopamd_kkt_xycyd* h)
+{
+  if(!h) return HIOPAMD_OK;
+  if(h->ls) hiopamd_linsolver_destroy(h->ls);
+  (void)hipFree(h->dense_rhs);
+  (void)hipFree(h->dense_Dd_inv);
+  (void)hipFree(h->Dx);
+  (void)hipFree(h->Dd);
+  (void)hipFree(h->rx_tilde);
+  (void)hipFree(h->ryd_tilde);
+  (void)hipFree(h->ryd2);
+  (void)hipFree(h->krylov);
+  (void)hipFree(h->dsmall);
+  delete h;
+  return HIOPAMD_OK;
+}
+
+int64_t hiopamd_kkt_xycyd_dim(const hiopamd_kkt_xycyd* h) { return h ? h->dim : -1; }
+
+int hiopamd_kkt_xycyd_offsets(const hiopamd_kkt_xycyd* h, int64_t* off13_host)
+{
+  if(!h || !off13_host) return HIOPAMD_ERR_ARG;
+  for(int p = 0; p < 13; ++p) off13_host[p] = h->off[p];
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_set_matrices(hiopamd_kkt_xycyd* h, const double* H, const double* Jc, const double* Jd)
+{
+  if(!h) return HIOPAMD_ERR_ARG;
+  if(h->kind == KIND_MDS) return HIOPAMD_ERR_STATE;   // the MDS object holds its own values (hiopamd_kkt_mds_set_values)
+  if(h->kind == KIND_DENSE && !H) return HIOPAMD_ERR_ARG;
+  h->H = H;
+  h->Jc = Jc;
+  h->Jd = Jd;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_set_mu(hiopamd_kkt_xycyd* h, double mu)   // hiopPDPerturbation::set_mu
+{
+  if(!h) return HIOPAMD_ERR_ARG;
+  h->pd.mu = mu;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_set_perturbation_options(hiopamd_kkt_xycyd* h, const double* o)
+{
+  if(!h || !o) return HIOPAMD_ERR_ARG;
+  PdPerturb& p = h->pd;
+  p.delta_w_min_bar = o[0];
+  p.delta_w_max_bar = o[1];
+  p.delta_w_0_bar = o[2];
+  p.kappa_w_minus = o[3];
+  p.kappa_w_plus_bar = o[4];
+  p.kappa_w_plus = o[5];
+  p.delta_c_bar = o[6];
+  p.kappa_c = o[7];
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_set_required_neg_eig(hiopamd_kkt_xycyd* h, int n_required)
+{
+  if(!h) return HIOPAMD_ERR_ARG;
+  h->n_required_neg = n_required;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_update(hiopamd_kkt_xycyd* h, const double* iter, int* ok_host)
+{
+  if(!h || !iter || !ok_host) return HIOPAMD_ERR_ARG;
+  h->iter = iter;
+  RC(stage_update_diagonals(h));
+  if(h->kind == KIND_MDS) {
+    RC(hiopamd_kkt_mds_set_diagonals(h->mds, h->Dx, h->Dd));
+  } else if(h->kind == KIND_LOWRANK) {
+    // hiopKKTLinSysLowRank::update (hiopKKTLinSys.cpp:1057-1096): refresh the Hessian's log-barrier diagonal, Dd^-1
+    if((!h->Jc && h->nyc > 0) || (!h->Jd && h->nyd > 0)) return HIOPAMD_ERR_STATE;
+    RC(hiopamd_kkt_lowrank_update_diag(h->lr, h->Dx, h->Dd, h->Jc, h->Jd));
+  }
+  return do_factorize(h, ok_host);
+}
+
+int hiopamd_kkt_xycyd_factorize(hiopamd_kkt_xycyd* h, int* ok_host)
+{
+  if(!h || !ok_host) return HIOPAMD_ERR_ARG;
+  if(!h->iter) return HIOPAMD_ERR_STATE;
+  return do_factorize(h, ok_host);
+}
+
+int hiopamd_kkt_xycyd_deltas(const hiopamd_kkt_xycyd* h, double* d4)
+{
+  if(!h || !d4) return HIOPAMD_ERR_ARG;
+  d4[0] = h->pd.wx;
+  d4[1] = h->pd.wd;
+  d4[2] = h->pd.cc;
+  d4[3] = h->pd.cd;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_num_refactorizations(const hiopamd_kkt_xycyd* h) { return h ? h->num_refact : -1; }
+
+int hiopamd_kkt_xycyd_compute_directions(hiopamd_kkt_xycyd* h, const double* resid, double* dir, int* ok_host)
+{
+  if(!h || !resid || !dir || !ok_host) return HIOPAMD_ERR_ARG;
+  return do_compute_directions(h, resid, dir, ok_host);
+}
+
+int hiopamd_kkt_xycyd_times_vec(hiopamd_kkt_xycyd* h, double* y, const double* x)
+{
+  if(!h || !x || !y) return HIOPAMD_ERR_ARG;
+  return do_times_vec(h, y, x);
+}
+
+// compute_directions_w_IR (:911-961) = BiCGStab (hiopKrylovSolver.cpp:390-700) on the 12-block operator with the
+// condensed solve as left preconditioner, x0 = 0, tol = min(mu*tol_factor, tol_min), relative to ||rhs||_2.
+// info4_host = {flag, iter, abs_resid, rel_resid}; *ok_host = 1 always once the solve ran ("accept the step since
+// this is IR", :949-953), *converged_host reports BiCGStab's own verdict.
+int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double* resid, double* dir,
+                                              double ir_outer_tol_factor, double ir_outer_tol_min, int ir_outer_maxit,
+                                              int* ok_host, int* converged_host, double* info4_host)
+{
+  if(!h || !resid || !dir || !ok_host) return HIOPAMD_ERR_ARG;
+  if(!h->iter) return HIOPAMD_ERR_STATE;
+  double info[4] = {0, 0, 0, 0};
+  int conv = 1;
+  auto finish = [&](int rc) {
+    if(converged_host) *converged_host = conv;
+    if(info4_host)
+      for(int q = 0; q < 4; ++q) info4_host[q] = info[q];
+    return rc;
+  };
+  if(ir_outer_maxit <= 0) return finish(do_compute_directions(h, resid, dir, ok_host));   // :916-919
+  *ok_host = 1;
+  hiopamd_ctx* ctx = h->ctx;
+  const int64_t n = h->dim;
+  if(!h->krylov && hipMalloc((void**)&h->krylov, sizeof(double) * (size_t)(9 * n + 1)) != hipSuccess)
+    return HIOPAMD_ERR_HIP;
+  double *xk = h->krylov, *xmin = xk + n, *res = xmin + n, *pk = res + n, *ph = pk + n, *v = ph + n, *sk = v + n,
+         *t = sk + n, *rt = t + n;
+  const double tol = std::min(h->pd.mu * ir_outer_tol_factor, ir_outer_tol_min);
+  const double* b = resid;
+  double n2b = 0.0;
+  RC(slab_norm(h, b, &n2b));
+  if(n2b == 0.0) {   // rhs = 0 -> solution = 0 (:405-413)
+    RC(hiopamd_vec_set_to_constant(ctx, n, dir, 0.0));
+    return finish(HIOPAMD_OK);
+  }
+  int flag = 1;
+  double iter = 0.0, imin = 0.0;
+  const double tolb = tol * n2b;
+  RC(hiopamd_vec_set_to_constant(ctx, n, xk, 0.0));     // set_x0(0.0)
+  RC(hiopamd_vec_set_to_constant(ctx, n, xmin, 0.0));
+  RC(residual_into(h, res, b, xk));                       // :446-449
+  double normr = 0.0;
+  RC(slab_norm(h, res, &normr));
+  double abs_resid = normr;
+  if(normr <= tolb) {                                     // :453-461
+    RC(hiopamd_vec_copy(ctx, n, dir, xk));
+    info[2] = normr;
+    info[3] = normr / n2b;
+    return finish(HIOPAMD_OK);
+  }
+  RC(hiopamd_vec_copy(ctx, n, rt, res));
+  double normrmin = normr, rho = 1.0, omega = 1.0, alpha = 0.0, rho1;
+  int stagsteps = 0, moresteps = 0;
+  const double eps = std::numeric_limits<double>::epsilon();
+  const int maxmsteps = 100, maxstagsteps = 3;
+  int ok_prec = 1;
+  int ii = 0;
+  for(; ii < ir_outer_maxit; ++ii) {
+    rho1 = rho;
+    RC(slab_dot(h, rt, res, &rho));
+    if(rho == 0 || std::abs(rho) > 1e40) {
+      flag = 4;
+      iter = ii + 1 - 0.5;
+      break;
+    }
+    if(ii == 0) {
+      RC(hiopamd_vec_copy(ctx, n, pk, res));
+    } else {
+      const double beta = rho / rho1 * (alpha / omega);
+      if(beta == 0 || std::abs(beta) > 1e40) {
+        flag = 4;
+        iter = ii + 1 - 0.5;
+        break;
+      }
+      const double om = omega;
+      RC(launch_ew(ctx, n, [=] __device__(int64_t i) { pk[i] = (pk[i] - om * v[i]) * beta + res[i]; }));   // :498-500
+    }
+    RC(do_compute_directions(h, pk, ph, &ok_prec));   // ph = M^-1 pk (hiopPrecondKKTOpr::times_vec)
+    RC(do_times_vec(h, v, ph));
+    double rtv = 0.0;
+    RC(slab_dot(h, rt, v, &rtv));
+    if(rtv == 0.0 || std::abs(rtv) > 1e40) {
+      flag = 4;
+      iter = ii + 1 - 0.5;
+      break;
+    }
+    alpha = rho / rtv;
+    if(std::abs(alpha) > 1e20) {
+      flag = 4;
+      iter = ii + 1 - 0.5;
+      break;
+    }
+    double nph = 0.0, nxk = 0.0;
+    RC(slab_norm(h, ph, &nph));
+    RC(slab_norm(h, xk, &nxk));
+    stagsteps = (nph * std::abs(alpha) < eps * nxk) ? stagsteps + 1 : 0;   // :531-535
+    {
+      const double al = alpha;
+      RC(launch_ew(ctx, n, [=] __device__(int64_t i) {
+        xk[i] += al * ph[i];
+        sk[i] = res[i] - al * v[i];
+      }));
+    }
+    RC(slab_norm(h, sk, &normr));
+    abs_resid = normr;
+    if(normr <= tolb || stagsteps >= maxstagsteps || moresteps) {   // :546-570
+      RC(residual_into(h, sk, b, xk));
+      RC(slab_norm(h, sk, &abs_resid));
+      if(abs_resid <= tolb) {
+        flag = 0;
+        iter = ii + 1 - 0.5;
+        break;
+      }
+      if(stagsteps >= maxstagsteps && moresteps == 0) stagsteps = 0;
+      moresteps++;
+      if(moresteps >= maxmsteps) {
+        flag = 3;
+        iter = ii + 1 - 0.5;
+        break;
+      }
+    }
+    if(stagsteps >= maxstagsteps) {
+      iter = ii + 1 - 0.5;
+      flag = 3;
+      break;
+    }
+    if(abs_resid < normrmin) {
+      normrmin = abs_resid;
+      RC(hiopamd_vec_copy(ctx, n, xmin, xk));
+      imin = ii + 1 - 0.5;
+    }
+    RC(do_compute_directions(h, sk, ph, &ok_prec));
+    RC(do_times_vec(h, t, ph));
+    double tt = 0.0, ts = 0.0;
+    RC(slab_dot(h, t, t, &tt));
+    if(tt == 0.0 || std::abs(tt) > 1e20) {
+      iter = ii + 1;
+      flag = 4;
+      break;
+    }
+    RC(slab_dot(h, t, sk, &ts));
+    omega = ts / tt;
+    if(std::abs(omega) > 1e20) {
+      iter = ii + 1;
+      flag = 4;
+      break;
+    }
+    RC(slab_norm(h, ph, &nph));
+    RC(slab_norm(h, xk, &nxk));
+    stagsteps = (nph * std::abs(omega) < eps * nxk) ? stagsteps + 1 : 0;
+    {
+      const double om = omega;
+      RC(launch_ew(ctx, n, [=] __device__(int64_t i) {
+        xk[i] += om * ph[i];
+        res[i] = sk[i] - om * t[i];
+      }));
+    }
+    RC(slab_norm(h, res, &normr));
+    abs_resid = normr;
+    if(normr <= tolb || stagsteps >= maxstagsteps || moresteps) {   // :623-648
+      RC(residual_into(h, res, b, xk));
+      RC(slab_norm(h, res, &abs_resid));
+      if(abs_resid <= tolb) {
+        flag = 0;
+        iter = ii + 1;
+        break;
+      }
+      if(stagsteps >= maxstagsteps && moresteps == 0) stagsteps = 0;
+      moresteps++;
+      if(moresteps >= maxmsteps) {
+        flag = 3;
+        iter = ii + 1;
+        break;
+      }
+    }
+    if(abs_resid < normrmin) {
+      normrmin = abs_resid;
+      RC(hiopamd_vec_copy(ctx, n, xmin, xk));
+      imin = ii + 1;
+    }
+    if(stagsteps >= maxstagsteps) {
+      iter = ii + 1 - 0.5;
+      flag = 3;
+      break;
+    }
+  }
+  double rel_resid;
+  if(flag == 0) {                                          // :665-669
+    rel_resid = abs_resid / n2b;
+    RC(hiopamd_vec_copy(ctx, n, dir, xk));
+    conv = 1;
+  } else {                                                 // :671-688
+    RC(residual_into(h, res, b, xmin));
+    double normr_comp = 0.0;
+    RC(slab_norm(h, res, &normr_comp));
+    if(normr_comp <= abs_resid) {
+      RC(hiopamd_vec_copy(ctx, n, dir, xmin));
+      iter = imin + 1;
+      abs_resid = normr_comp;
+      rel_resid = normr_comp / n2b;
+    } else {
+      RC(hiopamd_vec_copy(ctx, n, dir, xk));
+      iter = ii + 1;
+      rel_resid = abs_resid / n2b;
+    }
+    conv = 0;
+  }
+  info[0] = flag;
+  info[1] = iter;
+  info[2] = abs_resid;
+  info[3] = rel_resid;
+  return finish(HIOPAMD_OK);
+}
+
+hiopamd_linsolver* hiopamd_kkt_xycyd_linsolver(hiopamd_kkt_xycyd* h) { return h ? h->ls : nullptr; }
+double* hiopamd_kkt_xycyd_Dx(hiopamd_kkt_xycyd* h) { return h ? h->Dx : nullptr; }
+double* hiopamd_kkt_xycyd_Dd(hiopamd_kkt_xycyd* h) { return h ? h->Dd : nullptr; }
+
+}  // extern "C"

@@ -486,7 +486,8 @@ int hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(hiopamd_hess_lowr
 // The reference rebuilds the recursive a_k, b_k vectors (O(l^2) passes over n) on every call; here the
 // mathematically identical compact form  B = sigma I - [sigma S, Y] M^-1 [sigma S, Y]^T  is applied with the
 // middle matrix M cached per update: 2 skinny GEMVs, one 2l x 2l solve, 2 transposed GEMVs.
-int hiopamd_hess_lowrank_times_vec(hiopamd_hess_lowrank* h, double beta, double* y, double alpha, const double* x)
+int hiopamd_hess_lowrank_times_vec(hiopamd_hess_lowrank* h, double beta, double* y, double alpha, const double* x,
+                                   int add_log_barrier_term)
 {
   if(!h) return HIOPAMD_ERR_ARG;
   if(h->matrix_changed) RC(update_internal_bfgs_representation(h));
@@ -495,8 +496,9 @@ int hiopamd_hess_lowrank_times_vec(hiopamd_hess_lowrank* h, double beta, double*
   const int l = h->l_curr < 0 ? 0 : h->l_curr;
   const double sigma = h->sigma;
   const double* Dx = h->Dx;
+  const bool add_log = add_log_barrier_term != 0;   // timesVecCmn's addLogTerm (:975, :1045-1047)
   RC(launch_ew(ctx, n, [=] __device__(int64_t i) {
-    y[i] = (beta == 0.0 ? 0.0 : beta * y[i]) + alpha * (sigma + Dx[i]) * x[i];
+    y[i] = (beta == 0.0 ? 0.0 : beta * y[i]) + alpha * (sigma + (add_log ? Dx[i] : 0.0)) * x[i];
   }));
   if(l == 0) return HIOPAMD_OK;
   double* sy = h->dsmall + 4 * h->l_max;
@@ -595,6 +597,18 @@ int hiopamd_kkt_lowrank_update(hiopamd_kkt_lowrank* K, const double* zl, const d
 }
 
 // direct variant for callers that already hold Dx and Dd (= vl/sdl + vu/sdu)
+double* hiopamd_kkt_lowrank_Dd_inv(hiopamd_kkt_lowrank* K) { return K ? K->Dd_inv : nullptr; }
+double* hiopamd_kkt_lowrank_J(hiopamd_kkt_lowrank* K) { return K ? K->J : nullptr; }
+hiopamd_hess_lowrank* hiopamd_kkt_lowrank_hess(hiopamd_kkt_lowrank* K) { return K ? K->H : nullptr; }
+int hiopamd_kkt_lowrank_dims(const hiopamd_kkt_lowrank* K, int64_t* n_local_host, int* m_eq_host, int* m_ineq_host)
+{
+  if(!K) return HIOPAMD_ERR_ARG;
+  if(n_local_host) *n_local_host = K->n;
+  if(m_eq_host) *m_eq_host = K->m_eq;
+  if(m_ineq_host) *m_ineq_host = K->m_ineq;
+  return HIOPAMD_OK;
+}
+
 int hiopamd_kkt_lowrank_update_diag(hiopamd_kkt_lowrank* K, const double* Dx_in, const double* Dd, const double* Jc,
                                     const double* Jd)
 {

@@ -118,6 +118,21 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_trans_scatter(int nnz, const 
   }
 }
 
+// y += alpha * Msym * x for upper-triangle triplets: each off-diagonal entry contributes to two rows
+// (reference: hiopMatrixSymSparseTriplet::timesVec, hiopMatrixSparseTriplet.cpp:941-958)
+__global__ __launch_bounds__(kBlock) void spsym_spmv_scatter(int nnz, const int* __restrict__ iRow,
+                                                             const int* __restrict__ jCol,
+                                                             const double* __restrict__ val, double* __restrict__ y,
+                                                             double alpha, const double* __restrict__ x)
+{
+  for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
+    const int i = iRow[k], j = jCol[k];
+    const double v = val[k];
+    unsafeAtomicAdd(&y[i], alpha * x[j] * v);
+    if(i != j) unsafeAtomicAdd(&y[j], alpha * x[i] * v);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void mdinv_short(int64_t n_short, const int* __restrict__ out_i,
                                                       const int* __restrict__ out_j,
                                                       const int64_t* __restrict__ out_ptr, const int* __restrict__ k1,
@@ -233,6 +248,20 @@ int hiopamd_sp_trans_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, 
   int st = (beta == 0.0) ? hiopamd_vec_set_to_constant(ctx, ncols, y, 0.0) : hiopamd_vec_scale(ctx, ncols, y, beta);
   if(st != HIOPAMD_OK || nnz == 0) return st;
   hipLaunchKernelGGL(coo_spmv_trans_scatter, dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val, y,
+                     alpha, x);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
+int hiopamd_spsym_times_vec(hiopamd_ctx* ctx, int n, int nnz, const int* iRow, const int* jCol, const double* val,
+                            double beta, double* y, double alpha, const double* x)
+{
+  if(n < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
+  if(n == 0) return HIOPAMD_OK;
+  int st = (beta == 0.0) ? hiopamd_vec_set_to_constant(ctx, n, y, 0.0)
+                         : (beta == 1.0 ? HIOPAMD_OK : hiopamd_vec_scale(ctx, n, y, beta));
+  if(st != HIOPAMD_OK || nnz == 0) return st;
+  hipLaunchKernelGGL(spsym_spmv_scatter, dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val, y,
                      alpha, x);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;

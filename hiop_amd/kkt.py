@@ -192,8 +192,9 @@ class HessianLowRank:
                                                                                  dptr(work)), "symMatTimesInverseTimesMatTrans")
         self.ctx.sync()
 
-    def times_vec(self, beta, y, alpha, x):
-        check(self._L.hiopamd_hess_lowrank_times_vec(self.h, beta, dptr(y), alpha, dptr(x)), "hiopamd_hess_lowrank_times_vec")
+    def times_vec(self, beta, y, alpha, x, add_log_term=True):
+        check(self._L.hiopamd_hess_lowrank_times_vec(self.h, beta, dptr(y), alpha, dptr(x), 1 if add_log_term else 0),
+              "hiopamd_hess_lowrank_times_vec")
 
     @property
     def l_curr(self) -> int:
@@ -269,6 +270,120 @@ class KKTLinSysLowRank:
         if self.h is not None:
             if self.ctx.h is not None:
                 self._L.hiopamd_kkt_lowrank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+ITER_PARTS = ("x", "d", "yc", "yd", "sxl", "sxu", "sdl", "sdu", "zl", "zu", "vl", "vu")
+RESID_PARTS = ("rx", "rd", "ryc", "ryd", "rxl", "rxu", "rdl", "rdu", "rszl", "rszu", "rsvl", "rsvu")
+
+
+class KKTLinSysXYcYd:
+    """Full-space layer (mirrors hiopKKTLinSysCompressedXYcYd + hiopKKTLinSysCurvCheck::factorize +
+    compute_directions_w_IR, src/Optimization/hiopKKTLinSys.hpp:226-330): update / computeDirections /
+    compute_directions_w_IR on 12-part device slabs.  Built on an MDS, dense or low-rank condensed solver."""
+
+    def __init__(self, ctx: Context, backend, ixl, ixu, idl, idu, dense_dims=None):
+        self.ctx, self.backend = ctx, backend
+        self._L = lib()
+        self._pat = [ixl, ixu, idl, idu]          # borrowed by the C object: keep alive
+        torch.cuda.synchronize()
+        h = C.c_void_p()
+        p = [dptr(t) for t in self._pat]
+        if isinstance(backend, KKTLinSysCompressedMDSXYcYd):
+            check(self._L.hiopamd_kkt_xycyd_create_mds(C.byref(h), ctx.h, backend.h, *p), "hiopamd_kkt_xycyd_create_mds")
+        elif isinstance(backend, KKTLinSysLowRank):
+            check(self._L.hiopamd_kkt_xycyd_create_lowrank(C.byref(h), ctx.h, backend.h, *p),
+                  "hiopamd_kkt_xycyd_create_lowrank")
+        else:
+            nx, neq, nineq = dense_dims
+            check(self._L.hiopamd_kkt_xycyd_create_dense(C.byref(h), ctx.h, nx, neq, nineq, *p),
+                  "hiopamd_kkt_xycyd_create_dense")
+        self.h = h
+        self.dim = self._L.hiopamd_kkt_xycyd_dim(h)
+        off = (C.c_int64 * 13)()
+        check(self._L.hiopamd_kkt_xycyd_offsets(h, off), "offsets")
+        self.off = list(off)
+        self._keep = []
+        ctx._register(self)
+
+    # -- slab helpers (host numpy dict <-> one device tensor)
+    def pack(self, parts: dict, names) -> torch.Tensor:
+        return dev(np.concatenate([np.asarray(parts[k], dtype=np.float64) for k in names]))
+
+    def unpack(self, slab: torch.Tensor, names) -> dict:
+        a = slab.cpu().numpy()
+        return {k: a[self.off[i]:self.off[i + 1]].copy() for i, k in enumerate(names)}
+
+    def set_matrices(self, H, Jc, Jd):
+        self._keep = [H, Jc, Jd]
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_kkt_xycyd_set_matrices(self.h, dptr(H), dptr(Jc), dptr(Jd)), "set_matrices")
+
+    def set_mu(self, mu: float):
+        check(self._L.hiopamd_kkt_xycyd_set_mu(self.h, mu), "set_mu")
+
+    def set_perturbation_options(self, opts8):
+        arr = (C.c_double * 8)(*opts8)
+        check(self._L.hiopamd_kkt_xycyd_set_perturbation_options(self.h, arr), "set_perturbation_options")
+
+    def update(self, it: torch.Tensor) -> bool:
+        self._iter = it
+        ok = C.c_int(0)
+        check(self._L.hiopamd_kkt_xycyd_update(self.h, dptr(it), C.byref(ok)), "hiopamd_kkt_xycyd_update")
+        return bool(ok.value)
+
+    def factorize(self) -> bool:
+        ok = C.c_int(0)
+        check(self._L.hiopamd_kkt_xycyd_factorize(self.h, C.byref(ok)), "hiopamd_kkt_xycyd_factorize")
+        return bool(ok.value)
+
+    def deltas(self):
+        d = (C.c_double * 4)()
+        check(self._L.hiopamd_kkt_xycyd_deltas(self.h, d), "deltas")
+        return tuple(d)
+
+    @property
+    def num_refact(self) -> int:
+        return self._L.hiopamd_kkt_xycyd_num_refactorizations(self.h)
+
+    def compute_directions(self, resid: torch.Tensor, dir_: torch.Tensor) -> bool:
+        ok = C.c_int(0)
+        check(self._L.hiopamd_kkt_xycyd_compute_directions(self.h, dptr(resid), dptr(dir_), C.byref(ok)),
+              "hiopamd_kkt_xycyd_compute_directions")
+        return bool(ok.value)
+
+    def times_vec(self, y: torch.Tensor, x: torch.Tensor):
+        check(self._L.hiopamd_kkt_xycyd_times_vec(self.h, dptr(y), dptr(x)), "hiopamd_kkt_xycyd_times_vec")
+
+    def compute_directions_w_IR(self, resid, dir_, ir_outer_tol_factor=1e-2, ir_outer_tol_min=1e-6, ir_outer_maxit=8):
+        ok, conv = C.c_int(0), C.c_int(0)
+        info = (C.c_double * 4)()
+        check(self._L.hiopamd_kkt_xycyd_compute_directions_w_IR(self.h, dptr(resid), dptr(dir_), ir_outer_tol_factor,
+                                                                ir_outer_tol_min, ir_outer_maxit, C.byref(ok),
+                                                                C.byref(conv), info),
+              "hiopamd_kkt_xycyd_compute_directions_w_IR")
+        return bool(ok.value), {"converged": bool(conv.value), "flag": int(info[0]), "iter": info[1],
+                                "abs_resid": info[2], "rel_resid": info[3]}
+
+    def linsolver_sys_matrix(self, n) -> torch.Tensor:
+        ls = self._L.hiopamd_kkt_xycyd_linsolver(self.h)
+        ptr = self._L.hiopamd_linsolver_sys_matrix(C.c_void_p(ls))
+        out = torch.empty((n, n), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), n * n * 8), "copy_d2d")
+        self.ctx.sync()
+        return out
+
+    def close(self):
+        if self.h is not None:
+            if self.ctx.h is not None:
+                self._L.hiopamd_kkt_xycyd_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -242,6 +242,9 @@ int hiopamd_sp_add_MDinvNt(hiopamd_ctx*, const hiopamd_sp_plan* plan, const doub
 int hiopamd_spsym_add_diag_to_vec(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, const double* val,
                                   double alpha, double* y, int vec_start, int n_vec, int diag_src_start,
                                   int num_elems);
+/* y = beta*y + alpha*Msym*x for upper-triangle triplets (hiopMatrixSymSparseTriplet::timesVec :924-958) */
+int hiopamd_spsym_times_vec(hiopamd_ctx*, int n, int nnz, const int* iRow, const int* jCol, const double* val,
+                            double beta, double* y, double alpha, const double* x);
 /* W upper += alpha * Msym (upper triangle entries) at diag_start (:980) */
 int hiopamd_spsym_add_upper_to_sym_upper(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, const double* val,
                                          int diag_start, double alpha, double* W, int64_t ldw);
@@ -310,6 +313,17 @@ int hiopamd_kkt_mds_factorize(hiopamd_kkt_mds* k, int* n_neg_host);
  * overwritten like in the reference), dx, dyc, dyd outputs. */
 int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const double* ryc, double* ryd,
                                      double* dx, double* dyc, double* dyd);
+/* only the log-barrier diagonals change (hiopKKTLinSysCompressedXYcYd::update, hiopKKTLinSys.cpp:562-572) */
+int hiopamd_kkt_mds_set_diagonals(hiopamd_kkt_mds* k, const double* Dx, const double* Dd);
+int hiopamd_kkt_mds_dims(const hiopamd_kkt_mds* k, int* dims4_host /* nxs, nxd, neq, nineq */);
+/* the MDS matrices' products, on the values of the last set_values
+ * (hiopMatrixSymBlockDiagMDS::timesVec hiopMatrixMDS.hpp:310, hiopMatrixMDS::timesVec :68 / transTimesVec :75);
+ * which: 0 = Jac_c, 1 = Jac_d */
+int hiopamd_kkt_mds_hess_times_vec(hiopamd_kkt_mds* k, double beta, double* y, double alpha, const double* x);
+int hiopamd_kkt_mds_jac_times_vec(hiopamd_kkt_mds* k, int which, double beta, double* y, double alpha, const double* x);
+int hiopamd_kkt_mds_jac_trans_times_vec(hiopamd_kkt_mds* k, int which, double beta, double* y, double alpha,
+                                        const double* x);
+double* hiopamd_kkt_mds_Dd_inv(hiopamd_kkt_mds* k);       /* device, nineq: 1/(Dd + delta_wd) of the last build */
 double* hiopamd_kkt_mds_sys_matrix(hiopamd_kkt_mds* k);   /* device, N x N row-major, N = nxd+neq+nineq */
 double* hiopamd_kkt_mds_Hxs(hiopamd_kkt_mds* k);          /* device, nxs */
 hiopamd_linsolver* hiopamd_kkt_mds_linsolver(hiopamd_kkt_mds* k);
@@ -333,7 +347,10 @@ int hiopamd_hess_lowrank_solve(hiopamd_hess_lowrank* h, const double* rhs, doubl
 /* W(k x k) = beta*W + alpha*X*(B+Dx)^-1*X^T (:549); work: k*(k+2l_max) + 2*k*l_max doubles */
 int hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(hiopamd_hess_lowrank* h, double beta, double* W, int k,
                                                                double alpha, const double* X, double* work);
-int hiopamd_hess_lowrank_times_vec(hiopamd_hess_lowrank* h, double beta, double* y, double alpha, const double* x); /* :974 */
+/* timesVecCmn (:974-1059): y = beta*y + alpha*(B0 [+ Dx] + low-rank part)*x; hiopHessianLowRank::timesVec (:1061)
+ * is add_log_barrier_term = 0, timesVec_noLogBarrierTerm's counterpart with the term is 1 */
+int hiopamd_hess_lowrank_times_vec(hiopamd_hess_lowrank* h, double beta, double* y, double alpha, const double* x,
+                                   int add_log_barrier_term);
 int hiopamd_hess_lowrank_l_curr(const hiopamd_hess_lowrank* h);
 double hiopamd_hess_lowrank_sigma(const hiopamd_hess_lowrank* h);
 double* hiopamd_hess_lowrank_St(hiopamd_hess_lowrank* h);   /* l_max x n_local, rows 0..l_curr-1 valid */
@@ -353,8 +370,70 @@ int hiopamd_kkt_lowrank_update_diag(hiopamd_kkt_lowrank* K, const double* Dx, co
 /* solveCompressed (:1110-1187); rx is modified like in the reference (:1178); *ok_host = 0 if N was not SPD */
 int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, const double* ryc, const double* ryd,
                                          double* dx, double* dyc, double* dyd, int* ok_host);
+double* hiopamd_kkt_lowrank_Dd_inv(hiopamd_kkt_lowrank* K);   /* device, m_ineq */
+double* hiopamd_kkt_lowrank_J(hiopamd_kkt_lowrank* K);        /* device, (m_eq+m_ineq) x n_local: [Jc; Jd] of the last update */
+hiopamd_hess_lowrank* hiopamd_kkt_lowrank_hess(hiopamd_kkt_lowrank* K);
+int hiopamd_kkt_lowrank_dims(const hiopamd_kkt_lowrank* K, int64_t* n_local_host, int* m_eq_host, int* m_ineq_host);
 double* hiopamd_kkt_lowrank_N(hiopamd_kkt_lowrank* K);   /* device, k x k, the last reduced matrix */
 double hiopamd_kkt_lowrank_last_residual(const hiopamd_kkt_lowrank* K);
+
+/* =====================================================================================
+ * Full-space XYcYd layer: iterate/residual -> search direction
+ * (reference: src/Optimization/hiopKKTLinSys.cpp — hiopKKTLinSysCompressedXYcYd::update :543,
+ *  hiopKKTLinSysCurvCheck::factorize :316, ::computeDirections :585, compute_directions_for_full_space :218,
+ *  compute_directions_w_IR :911, hiopMatVecKKTFullOpr::times_vec :1619, hiopPrecondKKTOpr::times_vec :1900;
+ *  src/LinAlg/hiopKrylovSolver.cpp:390-700 hiopBiCGStabSolver::solve;
+ *  src/Optimization/hiopPDPerturbation.cpp:161-395 hiopPDPerturbationPrimalFirstScalar;
+ *  src/Optimization/hiopFactAcceptor.cpp:63-104 hiopFactAcceptorIC;
+ *  src/Optimization/hiopKKTLinSysDense.hpp:84-212 hiopKKTLinSysDenseXYcYd).
+ * An iterate, a direction and a residual are each ONE contiguous device slab with the 12 parts in the order of
+ * hiopVectorCompoundPD (src/LinAlg/hiopVectorCompoundPD.cpp:99-210):
+ *   iterate/direction: x d yc yd sxl sxu sdl sdu zl zu vl vu     residual: rx rd ryc ryd rxl rxu rdl rdu rszl rszu rsvl rsvu
+ * with sizes nx nd nyc nyd nx nx nd nd nx nx nd nd (nd = nyd = #inequalities); hiopamd_kkt_xycyd_offsets returns
+ * the 13 prefix offsets.  ixl/ixu/idl/idu are the 0/1 bound patterns (device, borrowed for the object's lifetime).
+ * ===================================================================================== */
+typedef struct hiopamd_kkt_xycyd hiopamd_kkt_xycyd;
+/* on top of the condensed MDS system (values given to the MDS object by hiopamd_kkt_mds_set_values; its Dx/Dd
+ * arguments may be NULL there: update() below supplies them) */
+int hiopamd_kkt_xycyd_create_mds(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_mds* k, const double* ixl,
+                                 const double* ixu, const double* idl, const double* idu);
+/* hiopKKTLinSysDenseXYcYd: the whole (nx+neq+nineq)^2 system as one dense matrix; owns its linear solver */
+int hiopamd_kkt_xycyd_create_dense(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, int nx, int neq, int nineq,
+                                   const double* ixl, const double* ixu, const double* idl, const double* idu);
+/* on top of hiopKKTLinSysLowRank (column-sharded: x-sized parts are the rank's slice, the rest is replicated);
+ * perturbations are hiopPDPerturbationNull like in hiopAlgFilterIPMQuasiNewton */
+int hiopamd_kkt_xycyd_create_lowrank(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_lowrank* K,
+                                     const double* ixl, const double* ixu, const double* idl, const double* idu);
+int hiopamd_kkt_xycyd_destroy(hiopamd_kkt_xycyd* h);
+int64_t hiopamd_kkt_xycyd_dim(const hiopamd_kkt_xycyd* h);                       /* 5nx + 5nd + nyc + nyd */
+int hiopamd_kkt_xycyd_offsets(const hiopamd_kkt_xycyd* h, int64_t* off13_host);
+/* dense backend: H (nx x nx, full symmetric), Jc (neq x nx), Jd (nineq x nx); low-rank backend: H = NULL,
+ * Jc, Jd (k x n_local) — the arguments of update(iter, grad_f, Jac_c, Jac_d, Hess) that are matrices (:543) */
+int hiopamd_kkt_xycyd_set_matrices(hiopamd_kkt_xycyd* h, const double* H, const double* Jc, const double* Jd);
+int hiopamd_kkt_xycyd_set_mu(hiopamd_kkt_xycyd* h, double mu);                   /* hiopPDPerturbation::set_mu */
+/* opts8 = delta_w_min_bar, delta_w_max_bar, delta_0_bar, kappa_w_minus, kappa_w_plus_bar, kappa_w_plus,
+ * delta_c_bar, kappa_c (defaults of src/Utils/hiopOptions.cpp:1080-1123 are built in) */
+int hiopamd_kkt_xycyd_set_perturbation_options(hiopamd_kkt_xycyd* h, const double* opts8_host);
+int hiopamd_kkt_xycyd_set_required_neg_eig(hiopamd_kkt_xycyd* h, int n_required); /* default neq+nineq (hiopAlgFilterIPM.cpp:2096) */
+/* update (:543): barrier diagonals from the iterate, then factorize (:316): build + factor + inertia-correction
+ * loop (<= 10 re-factorizations).  *ok_host = the reference's bool return. */
+int hiopamd_kkt_xycyd_update(hiopamd_kkt_xycyd* h, const double* iter, int* ok_host);
+int hiopamd_kkt_xycyd_factorize(hiopamd_kkt_xycyd* h, int* ok_host);
+int hiopamd_kkt_xycyd_deltas(const hiopamd_kkt_xycyd* h, double* deltas4_host);  /* delta_wx, wd, cc, cd in use */
+int hiopamd_kkt_xycyd_num_refactorizations(const hiopamd_kkt_xycyd* h);
+/* computeDirections (:585) + compute_directions_for_full_space (:218): resid -> dir (distinct slabs) */
+int hiopamd_kkt_xycyd_compute_directions(hiopamd_kkt_xycyd* h, const double* resid, double* dir, int* ok_host);
+/* y = KKT_full * x (:1619), including the current perturbations */
+int hiopamd_kkt_xycyd_times_vec(hiopamd_kkt_xycyd* h, double* y, const double* x);
+/* compute_directions_w_IR (:911): BiCGStab, left-preconditioned by compute_directions, x0 = 0,
+ * tol = min(mu*ir_outer_tol_factor, ir_outer_tol_min); info4_host = flag, iter, abs_resid, rel_resid
+ * (hiopKrylovSolver.hpp flag codes: 0 converged, 1 max iter, 3 stagnation, 4 breakdown) */
+int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double* resid, double* dir,
+                                              double ir_outer_tol_factor, double ir_outer_tol_min, int ir_outer_maxit,
+                                              int* ok_host, int* converged_host, double* info4_host);
+hiopamd_linsolver* hiopamd_kkt_xycyd_linsolver(hiopamd_kkt_xycyd* h);            /* dense backend only */
+double* hiopamd_kkt_xycyd_Dx(hiopamd_kkt_xycyd* h);                              /* device, nx */
+double* hiopamd_kkt_xycyd_Dd(hiopamd_kkt_xycyd* h);                              /* device, nd */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,94 @@
+"""CPU checks pinning oracle/kkt_full.py (the restatement of HiOp's full-space KKT layer) through algebraic
+identities of the 12-block system it encodes (hiopKKTLinSys.cpp:1619 block matrix)."""
+import numpy as np
+import pytest
+
+from oracle import kkt_full as kf
+from tests import kkt_full_cases as cases
+
+
+def _flat_err(full, r, d):
+    y = full.times_vec(d)
+    e = kf.pack(y, kf.RESID_PARTS) - kf.pack(r, kf.RESID_PARTS)
+    return np.linalg.norm(e) / np.linalg.norm(kf.pack(r, kf.RESID_PARTS))
+
+
+@pytest.mark.parametrize("ns,nd,neq", [(8, 6, None), (12, 5, 7)])
+def test_mds_compute_directions_solves_full_system(ns, nd, neq):
+    p, k, full, it = cases.mds_case(ns, nd, neq)
+    assert full.update(it)
+    assert full.num_refact == 0 and full.perturb.deltas() == (0.0, 0.0, 0.0, 0.0)
+    r = cases.random_resid(full.sizes, full.ixl, full.ixu, full.idl, full.idu)
+    ok, d = full.compute_directions(r)
+    assert ok
+    assert _flat_err(full, r, d) < 1e-11
+    # directions respect the bound patterns (the reference's DEEPCHECKS asserts, hiopKKTLinSys.cpp:296-303)
+    for s, pat in (("sxl", full.ixl), ("zl", full.ixl), ("sxu", full.ixu), ("zu", full.ixu), ("sdl", full.idl),
+                   ("vl", full.idl), ("sdu", full.idu), ("vu", full.idu)):
+        assert np.all(d[s][pat == 0] == 0.0)
+
+
+def test_dense_compute_directions_and_ir():
+    _, full, it = cases.dense_case()
+    assert full.update(it)
+    r = cases.random_resid(full.sizes, full.ixl, full.ixu, full.idl, full.idu)
+    ok, d = full.compute_directions(r)
+    assert ok and _flat_err(full, r, d) < 1e-11
+    ok, d2, info = full.compute_directions_w_IR(r, mu=1e-3)
+    assert ok and info["converged"] and info["flag"] == 0
+    assert info["iter"] <= 1.0          # the preconditioner is the exact inverse: converges in the first half step
+    assert _flat_err(full, r, d2) <= 1e-5 * 1.0001
+
+
+def test_inertia_correction_loop_nonconvex():
+    p, k, full, it = cases.mds_case(8, 6, nonconvex=True)
+    assert full.update(it)
+    dwx, dwd, dcc, dcd = full.perturb.deltas()
+    # first trial delta_0_bar = 1e-4, then x kappa_w_plus_bar = 100 while no earlier successful delta is known
+    # (delta_last == 0), until the inertia is (n, m, 0)                      (hiopPDPerturbation.cpp:335-346)
+    assert full.num_refact >= 2 and dwx == dwd and dwx > 0 and dcc == dcd == 0.0
+    assert np.isclose(dwx, 1e-4 * 100.0 ** (full.num_refact - 1))
+    assert full.p.factorize() == p.neq + p.nineq
+    # next factorization starts from the last successful delta / 3  (kappa_w_minus)
+    last = dwx
+    assert full.update(it)
+    assert np.isclose(full.perturb.deltas()[0], last / 3) and full.num_refact == 1
+
+
+def test_singular_jacobian_gets_delta_c():
+    p, k, full, it = cases.mds_case(8, 6)
+    # an all-zero equality row -> exactly singular KKT at delta_c = 0 (detected by pivoted and unpivoted LDL^T alike)
+    cases.zero_equality_row(k, 1)
+    full.perturb.set_mu(1e-2)
+    ok = full.update(it)
+    assert ok
+    dwx, dwd, dcc, dcd = full.perturb.deltas()
+    assert dcc == dcd == pytest.approx(1e-8 * (1e-2) ** 0.25)
+
+
+def test_bicgstab_plain_and_preconditioned():
+    rng = np.random.Generator(np.random.PCG64(1))
+    n = 40
+    A = rng.uniform(-1, 1, (n, n)) + n * np.eye(n)
+    b = rng.uniform(-1, 1, n)
+    x, conv, flag, it, absr, relr = kf.bicgstab(lambda v: A @ v, None, b, 1e-10, 200)
+    assert conv and flag == 0 and np.linalg.norm(A @ x - b) <= 1e-10 * np.linalg.norm(b) * 1.01
+    Ainv = np.linalg.inv(A)
+    x, conv, flag, it, absr, relr = kf.bicgstab(lambda v: A @ v, lambda v: Ainv @ v, b, 1e-10, 8)
+    assert conv and it == 0.5
+    # zero rhs -> zero solution, converged with 0 iterations (hiopKrylovSolver.cpp:405-413)
+    x, conv, flag, it, absr, relr = kf.bicgstab(lambda v: A @ v, None, np.zeros(n), 1e-10, 8)
+    assert conv and it == 0 and not x.any()
+    # max-iter exhaustion returns the minimum-residual iterate and reports failure
+    x, conv, flag, it, absr, relr = kf.bicgstab(lambda v: A @ v, None, b, 1e-300, 2)
+    assert not conv and np.isclose(np.linalg.norm(A @ x - b), absr)
+
+
+def test_ir_improves_perturbed_preconditioner():
+    """With delta_w > 0 the compressed solve is still an exact inverse of the *perturbed* full system the operator
+    applies (times_vec includes the deltas, hiopKKTLinSys.cpp:1672-1690), so IR converges at once."""
+    p, k, full, it = cases.mds_case(8, 6, nonconvex=True)
+    assert full.update(it)
+    r = cases.random_resid(full.sizes, full.ixl, full.ixu, full.idl, full.idu)
+    ok, d, info = full.compute_directions_w_IR(r, mu=1e-4)
+    assert ok and info["converged"] and _flat_err(full, r, d) <= 1e-6 * 1.0001
