@@ -201,7 +201,20 @@ int require_refactorization(PdPerturb& pd, int n_required_neg_eig, int n_neg_eig
   return 0;
 }
 
-enum Kind { KIND_MDS = 1, KIND_DENSE = 2, KIND_LOWRANK = 3 };
+// hiopFactAcceptorInertiaFreeDWD::requireReFactorization (hiopFactAcceptor.cpp:106-155)
+int require_refactorization_inertia_free(PdPerturb& pd, int n_required_neg_eig, int n_neg_eig, bool force_reg)
+{
+  if(n_required_neg_eig > 0) {
+    if(n_neg_eig < 0) return pd.compute_perturb_singularity() ? 1 : -1;
+    if(!force_reg) return 0;
+    return pd.compute_perturb_wrong_inertia() ? 1 : -1;
+  }
+  if(n_neg_eig < 0) return pd.compute_perturb_wrong_inertia() ? 1 : -1;
+  if(!force_reg) return 0;
+  return pd.compute_perturb_wrong_inertia() ? 1 : -1;
+}
+
+enum Kind { KIND_MDS = 1, KIND_DENSE = 2, KIND_LOWRANK = 3, KIND_DENSE_XDYCYD = 4 };
 
 // two sums in one pass: the column-partitioned parts of the slab (x-sized, all-reduced) and the replicated ones
 struct dot2_t {
@@ -246,6 +259,8 @@ struct hiopamd_kkt_xycyd {
   PdPerturb pd;
   int n_required_neg = 0;
   int num_refact = 0;
+  int acceptor = 0;   // 0: hiopFactAcceptorIC, 1: hiopFactAcceptorInertiaFreeDWD
+  bool is_xd() const { return kind == KIND_DENSE_XDYCYD; }
 };
 
 namespace {
@@ -266,6 +281,28 @@ int backend_build(hiopamd_kkt_xycyd* h)
   hiopamd_ctx* ctx = h->ctx;
   if(h->kind == KIND_MDS) return hiopamd_kkt_mds_build(h->mds, pd.wx, pd.wd, pd.cc, pd.cd);
   if(h->kind == KIND_LOWRANK) return HIOPAMD_OK;   // N is formed inside solveCompressed (hiopKKTLinSys.cpp:1132)
+  if(h->kind == KIND_DENSE_XDYCYD) {
+    // hiopKKTLinSysDenseXDYcYd::build_kkt_matrix (hiopKKTLinSysDense.hpp:249-328)
+    if(!h->H || (!h->Jc && h->nyc > 0) || (!h->Jd && h->nyd > 0)) return HIOPAMD_ERR_STATE;
+    const int nx = (int)h->nx, neq = h->nyc, nineq = h->nyd, n = nx + neq + 2 * nineq;
+    double* M = hiopamd_linsolver_sys_matrix(h->ls);
+    HIOPAMD_CHECK(hipMemsetAsync(M, 0, sizeof(double) * (size_t)n * (size_t)n, ctx->stream));       // :283
+    RC(hiopamd_mat_add_upper_to_sym_upper(ctx, nx, h->H, nx, 0, 1.0, M, n));                         // :286
+    RC(hiopamd_mat_trans_add_to_sym_upper(ctx, neq, nx, h->Jc, nx, 0, nx + nineq, 1.0, M, n));       // :288
+    RC(hiopamd_mat_trans_add_to_sym_upper(ctx, nineq, nx, h->Jd, nx, 0, nx + nineq + neq, 1.0, M, n));   // :289
+    RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, 0, 1.0, h->Dx, 0, nx));                               // :292
+    RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, 0, nx, pd.wx));                                 // :293
+    RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, nx, 1.0, h->Dd, 0, nineq));                           // :295
+    RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx, nineq, pd.wd));                             // :296
+    {
+      const int64_t ld = n;
+      const int c0 = nx + nineq + neq;
+      RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { M[(nx + i) * ld + c0 + i] -= 1.0; }));      // :299-307
+    }
+    // :312 is literally addSubDiagonal(-1, nx+nineq, delta_cd): nineq entries starting at diagonal nx+nineq
+    RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx + nineq, nineq, -pd.cd));
+    return HIOPAMD_OK;
+  }
   // hiopKKTLinSysDenseXYcYd::build_kkt_matrix (hiopKKTLinSysDense.hpp:84-170)
   if(!h->H || (!h->Jc && h->nyc > 0) || (!h->Jd && h->nyd > 0)) return HIOPAMD_ERR_STATE;
   const int nx = (int)h->nx, neq = h->nyc, nineq = h->nyd, n = nx + neq + nineq;
@@ -315,6 +352,26 @@ int backend_solve(hiopamd_kkt_xycyd* h, double* rx, const double* ryc, double* r
   RC(hiopamd_vec_copy(ctx, nx, dx, h->dense_rhs));
   RC(hiopamd_vec_copy(ctx, nyc, dyc, h->dense_rhs + nx));
   RC(hiopamd_vec_copy(ctx, nyd, dyd, h->dense_rhs + nx + nyc));
+  return HIOPAMD_OK;
+}
+
+// hiopKKTLinSysDenseXDYcYd::solveCompressed (hiopKKTLinSysDense.hpp:330-362): system order [x | d | yc | yd]
+int backend_solve_xd(hiopamd_kkt_xycyd* h, const double* rx, const double* rd, const double* ryc, const double* ryd,
+                     double* dx, double* dd, double* dyc, double* dyd, int* ok)
+{
+  *ok = 1;
+  hiopamd_ctx* ctx = h->ctx;
+  const int nx = (int)h->nx, nyc = h->nyc, nyd = h->nyd;
+  double* rhs = h->dense_rhs;
+  RC(hiopamd_vec_copy(ctx, nx, rhs, rx));
+  RC(hiopamd_vec_copy(ctx, nyd, rhs + nx, rd));
+  RC(hiopamd_vec_copy(ctx, nyc, rhs + nx + nyd, ryc));
+  RC(hiopamd_vec_copy(ctx, nyd, rhs + nx + nyd + nyc, ryd));
+  RC(hiopamd_linsolver_solve(h->ls, rhs, 1));
+  RC(hiopamd_vec_copy(ctx, nx, dx, rhs));
+  RC(hiopamd_vec_copy(ctx, nyd, dd, rhs + nx));
+  RC(hiopamd_vec_copy(ctx, nyc, dyc, rhs + nx + nyd));
+  RC(hiopamd_vec_copy(ctx, nyd, dyd, rhs + nx + nyd + nyc));
   return HIOPAMD_OK;
 }
 
@@ -425,7 +482,7 @@ int stage_reduce_rhs(hiopamd_kkt_xycyd* h, const double* r)
   const double *rx = r + o[0], *rd = r + o[1], *ryd = r + o[3], *rxl = r + o[4], *rxu = r + o[5], *rdl = r + o[6],
                *rdu = r + o[7], *rszl = r + o[8], *rszu = r + o[9], *rsvl = r + o[10], *rsvu = r + o[11];
   const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu;
-  const double* Ddi = Dd_inv_of(h);
+  const double* Ddi = h->is_xd() ? nullptr : Dd_inv_of(h);
   double *rx_tilde = h->rx_tilde, *ryd_tilde = h->ryd_tilde, *ryd2 = h->ryd2;
   return launch_ew(h->ctx, std::max<int64_t>(nx, nd), [=] __device__(int64_t i) {
     if(i < nx) {
@@ -438,8 +495,8 @@ int stage_reduce_rhs(hiopamd_kkt_xycyd* h, const double* r)
       double v = rd[i];
       if(idl[i] == 1.0) v += (rsvl[i] - vl[i] * rdl[i]) / sdl[i];
       if(idu[i] == 1.0) v -= (rsvu[i] - vu[i] * rdu[i]) / sdu[i];
-      ryd2[i] = v;
-      ryd_tilde[i] = ryd[i] + v * Ddi[i];
+      ryd2[i] = v;                                  // = rd_tilde of the XDYcYd form (hiopKKTLinSys.cpp:845-860)
+      if(Ddi) ryd_tilde[i] = ryd[i] + v * Ddi[i];
     }
   });
 }
@@ -455,7 +512,7 @@ int stage_recover_directions(hiopamd_kkt_xycyd* h, const double* r, double* dir)
   const double *rxl = r + o[4], *rxu = r + o[5], *rdl = r + o[6], *rdu = r + o[7], *rszl = r + o[8],
                *rszu = r + o[9], *rsvl = r + o[10], *rsvu = r + o[11];
   const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu;
-  const double* Ddi = Dd_inv_of(h);
+  const double* Ddi = h->is_xd() ? nullptr : Dd_inv_of(h);   // XDYcYd: dd comes out of the linear solve
   const double* ryd2 = h->ryd2;
   const double *dx = dir + o[0], *dyd = dir + o[3];
   double *dd = dir + o[1], *dsxl = dir + o[4], *dsxu = dir + o[5], *dsdl = dir + o[6], *dsdu = dir + o[7],
@@ -471,7 +528,7 @@ int stage_recover_directions(hiopamd_kkt_xycyd* h, const double* r, double* dir)
       dzu[i] = ixu[i] == 0.0 ? 0.0 : (rszu[i] - zu[i] * su) / sxu[i];
     }
     if(i < nd) {
-      const double d = (ryd2[i] + dyd[i]) * Ddi[i];
+      const double d = Ddi ? (ryd2[i] + dyd[i]) * Ddi[i] : dd[i];
       dd[i] = d;
       const double sl = sel(idl[i], rdl[i] + d);
       dsdl[i] = sl;
@@ -532,12 +589,38 @@ int do_factorize(hiopamd_kkt_xycyd* h, int* ok)   // hiopKKTLinSysCurvCheck::fac
     RC(backend_build(h));
     int n_neg = 0;
     RC(backend_factorize(h, &n_neg));
-    const int cont = require_refactorization(h->pd, h->n_required_neg, n_neg);
+    const int cont = h->acceptor == 0 ? require_refactorization(h->pd, h->n_required_neg, n_neg)
+                                      : require_refactorization_inertia_free(h->pd, h->n_required_neg, n_neg, false);
     if(cont == -1) return HIOPAMD_OK;
     if(cont == 0) break;
     h->num_refact++;
   }
   *ok = h->num_refact <= max_refactorization ? 1 : 0;
+  return HIOPAMD_OK;
+}
+
+int do_factorize_inertia_free(hiopamd_kkt_xycyd* h, int* ok)   // hiopKKTLinSysCurvCheck::factorize_inertia_free (:376-448)
+{
+  *ok = 0;
+  const int non_singular_mat = 1;
+  if(h->acceptor == 0)   // :388 (result unused); hiopFactAcceptorIC ignores force_reg
+    (void)require_refactorization(h->pd, h->n_required_neg, non_singular_mat);
+  else
+    (void)require_refactorization_inertia_free(h->pd, h->n_required_neg, non_singular_mat, true);
+  RC(backend_build(h));
+  int solver_flag = 0;
+  RC(backend_factorize(h, &solver_flag));
+  const int max_refactorization = 10;
+  h->num_refact = 0;
+  while(h->num_refact <= max_refactorization && solver_flag < 0) {
+    const int cont = h->acceptor == 0 ? require_refactorization(h->pd, h->n_required_neg, solver_flag)
+                                      : require_refactorization_inertia_free(h->pd, h->n_required_neg, solver_flag, false);
+    if(cont == -1) return HIOPAMD_OK;
+    RC(backend_build(h));
+    RC(backend_factorize(h, &solver_flag));
+    h->num_refact++;
+  }
+  *ok = 1;
   return HIOPAMD_OK;
 }
 
@@ -547,6 +630,11 @@ int do_compute_directions(hiopamd_kkt_xycyd* h, const double* resid, double* dir
   if(resid == dir) return HIOPAMD_ERR_ARG;
   const int64_t* o = h->off;
   RC(stage_reduce_rhs(h, resid));
+  if(h->is_xd()) {   // hiopKKTLinSysCompressedXDYcYd::computeDirections (:810-905)
+    RC(backend_solve_xd(h, h->rx_tilde, h->ryd2, resid + o[2], resid + o[3], dir + o[0], dir + o[1], dir + o[2],
+                        dir + o[3], ok));
+    return stage_recover_directions(h, resid, dir);
+  }
   RC(backend_solve(h, h->rx_tilde, resid + o[2], h->ryd_tilde, dir + o[0], dir + o[2], dir + o[3], ok));
   // the reference recovers dd before testing sol_ok and skips the rest on failure (:664-681)
   return stage_recover_directions(h, resid, dir);
@@ -632,6 +720,22 @@ int hiopamd_kkt_xycyd_create_dense(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, in
   return rc;
 }
 
+int hiopamd_kkt_xycyd_create_dense_xdycyd(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, int nx, int neq, int nineq,
+                                          const double* ixl, const double* ixu, const double* idl, const double* idu)
+{
+  RC(create_common(out, ctx, KIND_DENSE_XDYCYD, nx, nineq, neq, nineq, ixl, ixu, idl, idu));
+  hiopamd_kkt_xycyd* h = *out;
+  const int n = nx + neq + 2 * nineq;
+  int rc = hiopamd_linsolver_create(&h->ls, ctx, n);
+  if(rc == HIOPAMD_OK && hipMalloc((void**)&h->dense_rhs, sizeof(double) * (size_t)(n + 1)) != hipSuccess)
+    rc = HIOPAMD_ERR_HIP;
+  if(rc != HIOPAMD_OK) {
+    hiopamd_kkt_xycyd_destroy(h);
+    *out = nullptr;
+  }
+  return rc;
+}
+
 int hiopamd_kkt_xycyd_create_lowrank(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_lowrank* K,
                                      const double* ixl, const double* ixu, const double* idl, const double* idu)
 {
@@ -675,7 +779,7 @@ int hiopamd_kkt_xycyd_set_matrices(hiopamd_kkt_xycyd* h, const double* H, const 
 {
   if(!h) return HIOPAMD_ERR_ARG;
   if(h->kind == KIND_MDS) return HIOPAMD_ERR_STATE;   // the MDS object holds its own values (hiopamd_kkt_mds_set_values)
-  if(h->kind == KIND_DENSE && !H) return HIOPAMD_ERR_ARG;
+  if((h->kind == KIND_DENSE || h->kind == KIND_DENSE_XDYCYD) && !H) return HIOPAMD_ERR_ARG;
   h->H = H;
   h->Jc = Jc;
   h->Jd = Jd;
@@ -731,6 +835,63 @@ int hiopamd_kkt_xycyd_factorize(hiopamd_kkt_xycyd* h, int* ok_host)
   if(!h || !ok_host) return HIOPAMD_ERR_ARG;
   if(!h->iter) return HIOPAMD_ERR_STATE;
   return do_factorize(h, ok_host);
+}
+
+int hiopamd_kkt_xycyd_set_fact_acceptor(hiopamd_kkt_xycyd* h, int kind)
+{
+  if(!h || (kind != 0 && kind != 1)) return HIOPAMD_ERR_ARG;
+  h->acceptor = kind;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_factorize_inertia_free(hiopamd_kkt_xycyd* h, int* ok_host)
+{
+  if(!h || !ok_host) return HIOPAMD_ERR_ARG;
+  if(!h->iter) return HIOPAMD_ERR_STATE;
+  return do_factorize_inertia_free(h, ok_host);
+}
+
+// hiopKKTLinSysCompressed::test_direction (:455-513): accept iff  dx'(H + Dx + delta_wx)dx + dd'(Dd + delta_wd)dd
+//   >= neg_curv_test_fact * (||dx||^2 + ||dd||^2)
+int hiopamd_kkt_xycyd_test_direction(hiopamd_kkt_xycyd* h, const double* dir, double neg_curv_test_fact,
+                                     int* accept_host, double* dWd_host, double* xs_nrmsq_host)
+{
+  if(!h || !dir || !accept_host) return HIOPAMD_ERR_ARG;
+  if(!h->iter) return HIOPAMD_ERR_STATE;
+  hiopamd_ctx* ctx = h->ctx;
+  const double *dx = dir + h->off[0], *dd = dir + h->off[1];
+  double* hx = h->rx_tilde;   // work
+  RC(backend_hess_times_vec(h, hx, dx));
+  const double *Dx = h->Dx, *Dd = h->Dd;
+  const double dwx = h->pd.wx, dwd = h->pd.wd;
+  const int64_t nx = h->nx;
+  // {curvature term, squared norm} over the x part (distributed on a column partition) and over the d part
+  struct OpCurv {
+    const double *w, *v, *D;
+    double delta;
+    __device__ dot2_t identity() const { return dot2_t{0.0, 0.0}; }
+    __device__ dot2_t map(int64_t i) const
+    {
+      const double vi = v[i];
+      return dot2_t{(w ? w[i] * vi : 0.0) + (D[i] * vi + delta * vi) * vi, vi * vi};
+    }
+    __device__ dot2_t combine(dot2_t p, dot2_t q) const { return dot2_t{p.dist + q.dist, p.repl + q.repl}; }
+  };
+  dot2_t sx{0, 0}, sd{0, 0};
+  RC(launch_reduce<dot2_t>(ctx, nx, OpCurv{hx, dx, Dx, dwx}, &sx));
+  if(h->kind == KIND_LOWRANK && ctx->allreduce) {
+    HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, &sx, sizeof(sx), hipMemcpyHostToDevice, ctx->stream));
+    HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+    if(ctx->allreduce(ctx->allreduce_user, h->dsmall, 2, HIOPAMD_SUM, (void*)ctx->stream) != 0) return HIOPAMD_ERR_HIP;
+    HIOPAMD_CHECK(hipMemcpyAsync(&sx, h->dsmall, sizeof(sx), hipMemcpyDeviceToHost, ctx->stream));
+    HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  RC(launch_reduce<dot2_t>(ctx, h->nd, OpCurv{nullptr, dd, Dd, dwd}, &sd));
+  const double dWd = sx.dist + sd.dist, xs_nrmsq = sx.repl + sd.repl;
+  if(dWd_host) *dWd_host = dWd;
+  if(xs_nrmsq_host) *xs_nrmsq_host = xs_nrmsq;
+  *accept_host = (dWd < xs_nrmsq * neg_curv_test_fact) ? 0 : 1;
+  return HIOPAMD_OK;
 }
 
 int hiopamd_kkt_xycyd_deltas(const hiopamd_kkt_xycyd* h, double* d4)

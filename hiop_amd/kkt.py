@@ -288,7 +288,7 @@ class KKTLinSysXYcYd:
     compute_directions_w_IR, src/Optimization/hiopKKTLinSys.hpp:226-330): update / computeDirections /
     compute_directions_w_IR on 12-part device slabs.  Built on an MDS, dense or low-rank condensed solver."""
 
-    def __init__(self, ctx: Context, backend, ixl, ixu, idl, idu, dense_dims=None):
+    def __init__(self, ctx: Context, backend, ixl, ixu, idl, idu, dense_dims=None, xd_form=False):
         self.ctx, self.backend = ctx, backend
         self._L = lib()
         self._pat = [ixl, ixu, idl, idu]          # borrowed by the C object: keep alive
@@ -302,8 +302,8 @@ class KKTLinSysXYcYd:
                   "hiopamd_kkt_xycyd_create_lowrank")
         else:
             nx, neq, nineq = dense_dims
-            check(self._L.hiopamd_kkt_xycyd_create_dense(C.byref(h), ctx.h, nx, neq, nineq, *p),
-                  "hiopamd_kkt_xycyd_create_dense")
+            create = self._L.hiopamd_kkt_xycyd_create_dense_xdycyd if xd_form else self._L.hiopamd_kkt_xycyd_create_dense
+            check(create(C.byref(h), ctx.h, nx, neq, nineq, *p), "hiopamd_kkt_xycyd_create_dense")
         self.h = h
         self.dim = self._L.hiopamd_kkt_xycyd_dim(h)
         off = (C.c_int64 * 13)()
@@ -342,6 +342,21 @@ class KKTLinSysXYcYd:
         ok = C.c_int(0)
         check(self._L.hiopamd_kkt_xycyd_factorize(self.h, C.byref(ok)), "hiopamd_kkt_xycyd_factorize")
         return bool(ok.value)
+
+    def set_fact_acceptor(self, inertia_free: bool):
+        check(self._L.hiopamd_kkt_xycyd_set_fact_acceptor(self.h, 1 if inertia_free else 0), "set_fact_acceptor")
+
+    def factorize_inertia_free(self) -> bool:
+        ok = C.c_int(0)
+        check(self._L.hiopamd_kkt_xycyd_factorize_inertia_free(self.h, C.byref(ok)), "factorize_inertia_free")
+        return bool(ok.value)
+
+    def test_direction(self, dir_: torch.Tensor, neg_curv_test_fact: float = 1e-11):
+        acc = C.c_int(0)
+        dWd, nrm = C.c_double(0), C.c_double(0)
+        check(self._L.hiopamd_kkt_xycyd_test_direction(self.h, dptr(dir_), neg_curv_test_fact, C.byref(acc),
+                                                       C.byref(dWd), C.byref(nrm)), "hiopamd_kkt_xycyd_test_direction")
+        return bool(acc.value), dWd.value, nrm.value
 
     def deltas(self):
         d = (C.c_double * 4)()

@@ -400,6 +400,10 @@ int hiopamd_kkt_xycyd_create_mds(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiop
 /* hiopKKTLinSysDenseXYcYd: the whole (nx+neq+nineq)^2 system as one dense matrix; owns its linear solver */
 int hiopamd_kkt_xycyd_create_dense(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, int nx, int neq, int nineq,
                                    const double* ixl, const double* ixu, const double* idl, const double* idu);
+/* hiopKKTLinSysDenseXDYcYd (hiopKKTLinSysDense.hpp:229-380): the XDYcYd form, N = nx + neq + 2 nineq, unknowns
+ * ordered [x | d | yc | yd]; computeDirections is hiopKKTLinSysCompressedXDYcYd's (hiopKKTLinSys.cpp:810-905) */
+int hiopamd_kkt_xycyd_create_dense_xdycyd(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, int nx, int neq, int nineq,
+                                          const double* ixl, const double* ixu, const double* idl, const double* idu);
 /* on top of hiopKKTLinSysLowRank (column-sharded: x-sized parts are the rank's slice, the rest is replicated);
  * perturbations are hiopPDPerturbationNull like in hiopAlgFilterIPMQuasiNewton */
 int hiopamd_kkt_xycyd_create_lowrank(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_lowrank* K,
@@ -419,6 +423,15 @@ int hiopamd_kkt_xycyd_set_required_neg_eig(hiopamd_kkt_xycyd* h, int n_required)
  * loop (<= 10 re-factorizations).  *ok_host = the reference's bool return. */
 int hiopamd_kkt_xycyd_update(hiopamd_kkt_xycyd* h, const double* iter, int* ok_host);
 int hiopamd_kkt_xycyd_factorize(hiopamd_kkt_xycyd* h, int* ok_host);
+/* 0 = hiopFactAcceptorIC (inertia correction, default), 1 = hiopFactAcceptorInertiaFreeDWD (hiopFactAcceptor.cpp:106) */
+int hiopamd_kkt_xycyd_set_fact_acceptor(hiopamd_kkt_xycyd* h, int kind);
+/* hiopKKTLinSysCurvCheck::factorize_inertia_free (:376-448): force one more primal regularisation step, rebuild,
+ * re-factor (and keep regularising while the factorisation reports singular) */
+int hiopamd_kkt_xycyd_factorize_inertia_free(hiopamd_kkt_xycyd* h, int* ok_host);
+/* hiopKKTLinSysCompressed::test_direction (:455-513): *accept_host = 0 if the direction has negative curvature,
+ * i.e. dx'(H+Dx+delta_wx)dx + dd'(Dd+delta_wd)dd < neg_curv_test_fact*(|dx|^2+|dd|^2) (option default 1e-11) */
+int hiopamd_kkt_xycyd_test_direction(hiopamd_kkt_xycyd* h, const double* dir, double neg_curv_test_fact,
+                                     int* accept_host, double* dWd_host, double* xs_nrmsq_host);
 int hiopamd_kkt_xycyd_deltas(const hiopamd_kkt_xycyd* h, double* deltas4_host);  /* delta_wx, wd, cc, cd in use */
 int hiopamd_kkt_xycyd_num_refactorizations(const hiopamd_kkt_xycyd* h);
 /* computeDirections (:585) + compute_directions_for_full_space (:218): resid -> dir (distinct slabs) */

@@ -230,6 +230,20 @@ def require_refactorization(perturb, n_required_neg_eig, n_neg_eig):     # hiopF
     return 0
 
 
+def require_refactorization_inertia_free(perturb, n_required_neg_eig, n_neg_eig, force_reg=False):   # :106-155
+    if n_required_neg_eig > 0:
+        if n_neg_eig < 0:
+            return 1 if perturb.compute_perturb_singularity() else -1
+        if not force_reg:
+            return 0
+        return 1 if perturb.compute_perturb_wrong_inertia() else -1
+    if n_neg_eig < 0:
+        return 1 if perturb.compute_perturb_wrong_inertia() else -1
+    if not force_reg:
+        return 0
+    return 1 if perturb.compute_perturb_wrong_inertia() else -1
+
+
 # ---------------------------------------------------------------------------------------------------------
 # providers: the compressed XYcYd systems the full-space layer sits on
 # ---------------------------------------------------------------------------------------------------------
@@ -333,6 +347,40 @@ class DenseXYcYdProvider:
 
     def jac_trans_times_vec(self, which, y):
         return (self.Jc if which == "c" else self.Jd).T @ y
+
+
+class DenseXDYcYdProvider(DenseXYcYdProvider):
+    """hiopKKTLinSysDenseXDYcYd (hiopKKTLinSysDense.hpp:229-380): unknowns [x | d | yc | yd]."""
+    xd_form = True
+
+    def __init__(self, H, Jc, Jd):
+        n = H.shape[0] + Jc.shape[0] + 2 * Jd.shape[0]
+        super().__init__(H, Jc, Jd, linsolver=ho.LinSolverSymDenseLapack(n))
+
+    def build(self, dwx, dwd, dcc, dcd):                          # :249-328
+        nx, neq, nineq = self.nx, self.nyc, self.nyd
+        M = self.linsys.M
+        M[:] = 0.0
+        ho.add_upper_to_sym_upper(self.H, 0, 1.0, M)              # :286
+        ho.trans_add_to_sym_upper(self.Jc, 0, nx + nineq, 1.0, M)          # :288
+        ho.trans_add_to_sym_upper(self.Jd, 0, nx + nineq + neq, 1.0, M)    # :289
+        idx = np.arange(nx)
+        M[idx, idx] += self.Dx                                    # :292
+        M[idx, idx] += dwx                                        # :293
+        idx = np.arange(nineq) + nx
+        M[idx, idx] += self.Dd                                    # :295
+        M[idx, idx] += dwd                                        # :296
+        M[idx, np.arange(nineq) + nx + nineq + neq] -= 1.0        # :299-307
+        idx = np.arange(nineq) + nx + nineq                       # :312 literally addSubDiagonal(-1, nx+nineq, delta_cd)
+        M[idx, idx] -= dcd
+        return M
+
+    def solve_xd(self, rx, rd, ryc, ryd):                         # :330-362
+        rhs = np.concatenate([rx, rd, ryc, ryd])
+        ok = self.linsys.solve(rhs)
+        nx, nyc, nyd = self.nx, self.nyc, self.nyd
+        return (ok, rhs[:nx].copy(), rhs[nx:nx + nyd].copy(), rhs[nx + nyd:nx + nyd + nyc].copy(),
+                rhs[nx + nyd + nyc:].copy())
 
 
 class LowRankProvider:
@@ -509,8 +557,9 @@ class KKTLinSysFull:
     """update / factorize / computeDirections / compute_directions_w_IR of hiopKKTLinSysCompressedXYcYd on top of
     a provider.  Iterates and residuals are dicts keyed by ITER_PARTS / RESID_PARTS."""
 
-    def __init__(self, prov, ixl, ixu, idl, idu, perturb=None, n_required_neg_eig=None):
+    def __init__(self, prov, ixl, ixu, idl, idu, perturb=None, n_required_neg_eig=None, inertia_free=False):
         self.p = prov
+        self.inertia_free = inertia_free       # hiopFactAcceptorInertiaFreeDWD instead of hiopFactAcceptorIC
         self.ixl, self.ixu, self.idl, self.idu = ixl, ixu, idl, idu
         self.perturb = perturb if perturb is not None else PDPerturbationPrimalFirstScalar()
         self.n_req = prov.nyc + prov.nyd if n_required_neg_eig is None else n_required_neg_eig   # hiopAlgFilterIPM.cpp:2096
@@ -538,13 +587,44 @@ class KKTLinSysFull:
         while self.num_refact <= max_refact:
             self.p.build(*self.perturb.deltas())
             n_neg = self.p.factorize()
-            cont = require_refactorization(self.perturb, self.n_req, n_neg)
+            cont = self._accept(n_neg)
             if cont == -1:
                 return False
             if cont == 0:
                 break
             self.num_refact += 1
         return self.num_refact <= max_refact
+
+    def _accept(self, n_neg, force_reg=False):
+        if self.inertia_free:
+            return require_refactorization_inertia_free(self.perturb, self.n_req, n_neg, force_reg)
+        return require_refactorization(self.perturb, self.n_req, n_neg)
+
+    # -- :376-448
+    def factorize_inertia_free(self):
+        self._accept(1, True)                                       # :388 (return value unused)
+        self.p.build(*self.perturb.deltas())
+        solver_flag = self.p.factorize()
+        max_refact, self.num_refact = 10, 0
+        while self.num_refact <= max_refact and solver_flag < 0:
+            if self._accept(solver_flag) == -1:
+                return False
+            self.p.build(*self.perturb.deltas())
+            solver_flag = self.p.factorize()
+            self.num_refact += 1
+        return True
+
+    # -- :455-513
+    def test_direction(self, d, neg_curv_test_fact=1e-11, dot=None):
+        dot = dot or (lambda u, v: float(u @ v))
+        dwx, dwd, _, _ = self.perturb.deltas()
+        x, dd = d["x"], d["d"]
+        dWd = dot(self.p.hess_times_vec(x), x)
+        dWd += dot(x * self.Dx + dwx * x, x)
+        dWd += float((dd * self.Dd + dwd * dd) @ dd)
+        xs_nrmsq = dot(x, x) + float(dd @ dd)
+        self.last_dWd, self.last_xs_nrmsq = dWd, xs_nrmsq
+        return not (dWd < xs_nrmsq * neg_curv_test_fact)
 
     # -- :585-690
     def compute_directions(self, r):
@@ -559,6 +639,13 @@ class KKTLinSysFull:
         ho.axdzpy_w_pattern(ryd2, 1.0, rd2, it["sdl"], self.idl)
         rd2 = r["rsvu"] - it["vu"] * r["rdu"]
         ho.axdzpy_w_pattern(ryd2, -1.0, rd2, it["sdu"], self.idu)
+        if getattr(self.p, "xd_form", False):                       # XDYcYd::computeDirections (:810-905)
+            ok, dx, dd, dyc, dyd = self.p.solve_xd(rx_tilde, ryd2, r["ryc"], r["ryd"])
+            d = {"x": dx, "d": dd, "yc": dyc, "yd": dyd}
+            if not ok:
+                return False, d
+            self.compute_directions_for_full_space(r, d)
+            return True, d
         ryd_tilde = r["ryd"] + ryd2 * self.p.Dd_inv
         ok, dx, dyc, dyd = self.p.solve(rx_tilde, r["ryc"], ryd_tilde)
         d = {"x": dx, "yc": dyc, "yd": dyd}

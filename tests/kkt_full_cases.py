@@ -28,6 +28,13 @@ def random_resid(sizes, ixl, ixu, idl, idu, seed=5):
     return r
 
 
+def negative_curvature_resid(sizes, idx=1):
+    """rx = e_idx, everything else 0: pushes the Newton direction along the coordinate made nonconvex by dense_case."""
+    r = {k: np.zeros(s) for k, s in zip(kf.RESID_PARTS, sizes)}
+    r["rx"][idx] = 1.0
+    return r
+
+
 def patterns(p):
     f = lambda b: b.astype(np.float64)
     return f(p.xl > -1e20), f(p.xu < 1e20), f(p.dl > -1e20), f(p.du < 1e20)
@@ -59,19 +66,22 @@ def mds_case(ns=8, nd=6, neq=None, nonconvex=False, seed=3):
     return p, k, full, it
 
 
-def dense_case(nx=12, neq=3, nineq=4, seed=11, nonconvex=False):
+def dense_case(nx=12, neq=3, nineq=4, seed=11, nonconvex=False, xd_form=False, inertia_free=False, neg_value=-2.0,
+               free_nonconvex=False):
     rng = np.random.Generator(np.random.PCG64(seed))
     A = rng.uniform(-1, 1, (nx, nx))
     H = A @ A.T / nx + np.eye(nx)
     if nonconvex:
-        H[1, 1] = -2.0
+        H[1, 1] = neg_value
     Jc = rng.uniform(-1, 1, (neq, nx))
     Jd = rng.uniform(-1, 1, (nineq, nx))
     ixl = (rng.uniform(0, 1, nx) < 0.6).astype(np.float64)
     ixu = (rng.uniform(0, 1, nx) < 0.4).astype(np.float64)
     idl = np.ones(nineq)
     idu = (rng.uniform(0, 1, nineq) < 0.5).astype(np.float64)
-    prov = kf.DenseXYcYdProvider(H, Jc, Jd)
-    full = kf.KKTLinSysFull(prov, ixl, ixu, idl, idu)
+    if free_nonconvex:            # no bounds on the negative-curvature variable: Dx[1] = 0
+        ixl[1] = ixu[1] = 0.0
+    prov = kf.DenseXDYcYdProvider(H, Jc, Jd) if xd_form else kf.DenseXYcYdProvider(H, Jc, Jd)
+    full = kf.KKTLinSysFull(prov, ixl, ixu, idl, idu, inertia_free=inertia_free)
     it = random_iterate(nx, nineq, neq, nineq, ixl, ixu, idl, idu, seed)
     return (H, Jc, Jd, ixl, ixu, idl, idu), full, it

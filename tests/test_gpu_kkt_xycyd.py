@@ -279,3 +279,64 @@ def test_full_size_config_directions_and_ir(ctx):
     for s, pat in (("sxl", ixl), ("zl", ixl), ("sxu", ixu), ("zu", ixu), ("sdl", idl), ("vl", idl), ("sdu", idu),
                    ("vu", idu)):
         assert not d[s][pat == 0].any()
+
+
+@pytest.mark.parametrize("nx,neq,nineq,nonconvex", [(14, 3, 5, False), (60, 8, 21, True), (20, 0, 4, False)])
+def test_dense_xdycyd_form(ctx, nx, neq, nineq, nonconvex):
+    """hiopKKTLinSysDenseXDYcYd + hiopKKTLinSysCompressedXDYcYd::computeDirections (a12, second form)."""
+    from hiop_amd.kkt import KKTLinSysXYcYd
+    (H, Jc, Jd, ixl, ixu, idl, idu), fo, it = cases.dense_case(nx, neq, nineq, seed=nx + 1, nonconvex=nonconvex,
+                                                               xd_form=True)
+    fg = KKTLinSysXYcYd(ctx, None, D(ixl), D(ixu), D(idl), D(idu), dense_dims=(nx, neq, nineq), xd_form=True)
+    fg.set_matrices(D(H), D(Jc), D(Jd))
+    it_g = fg.pack(it, kf.ITER_PARTS)
+    # assembled matrix (upper triangle) before factorisation: build only, compare, then update
+    assert fo.update(it) and fg.update(it_g)
+    assert fg.num_refact == fo.num_refact and fg.deltas() == fo.perturb.deltas()
+    r = cases.random_resid(fo.sizes, ixl, ixu, idl, idu)
+    ok_o, d_o = fo.compute_directions(r)
+    d_g = torch.zeros(fg.dim, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert fg.compute_directions(fg.pack(r, kf.RESID_PARTS), d_g) and ok_o
+    ctx.sync()
+    compare_dirs(fg, d_g, d_o)
+    y = torch.zeros_like(d_g)
+    fg.times_vec(y, d_g); ctx.sync()
+    close(y.cpu().numpy(), kf.pack(r, kf.RESID_PARTS), 1e-9)
+
+
+def test_inertia_free_acceptor_test_direction_and_refactorize(ctx):
+    """hiopFactAcceptorInertiaFreeDWD + test_direction + factorize_inertia_free, driven the way
+    hiopAlgFilterIPMBase::compute_search_direction_inertia_free does (hiopAlgFilterIPM.cpp:3374-3440)."""
+    from hiop_amd.kkt import KKTLinSysXYcYd
+    nx, neq, nineq = 16, 3, 4
+    (H, Jc, Jd, ixl, ixu, idl, idu), fo, it = cases.dense_case(nx, neq, nineq, seed=21, nonconvex=True, inertia_free=True,
+                                                               neg_value=-50.0, free_nonconvex=True)
+    fg = KKTLinSysXYcYd(ctx, None, D(ixl), D(ixu), D(idl), D(idu), dense_dims=(nx, neq, nineq))
+    fg.set_fact_acceptor(True)
+    fg.set_matrices(D(H), D(Jc), D(Jd))
+    it_g = fg.pack(it, kf.ITER_PARTS)
+    assert fo.update(it) and fg.update(it_g)
+    assert fg.num_refact == fo.num_refact == 0 and fg.deltas() == fo.perturb.deltas() == (0.0, 0.0, 0.0, 0.0)
+    r = cases.negative_curvature_resid(fo.sizes)
+    r_g = fg.pack(r, kf.RESID_PARTS)
+    d_g = torch.zeros(fg.dim, dtype=torch.float64, device="cuda")
+    rounds = 0
+    while True:
+        ok_o, d_o = fo.compute_directions(r)
+        torch.cuda.synchronize()
+        assert fg.compute_directions(r_g, d_g) and ok_o
+        ctx.sync()
+        compare_dirs(fg, d_g, d_o, rtol=1e-8)
+        acc_o = fo.test_direction(d_o)
+        acc_g, dWd, nrm = fg.test_direction(d_g)
+        assert acc_g == acc_o
+        assert dWd == pytest.approx(fo.last_dWd, rel=1e-7, abs=1e-9 * fo.last_xs_nrmsq)
+        assert nrm == pytest.approx(fo.last_xs_nrmsq, rel=1e-7)
+        if acc_g:
+            break
+        assert fo.factorize_inertia_free() and fg.factorize_inertia_free()
+        assert fg.deltas() == fo.perturb.deltas()
+        rounds += 1
+        assert rounds <= 10
+    assert rounds >= 1 and fg.deltas()[0] > 0

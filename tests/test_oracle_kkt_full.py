@@ -92,3 +92,35 @@ def test_ir_improves_perturbed_preconditioner():
     r = cases.random_resid(full.sizes, full.ixl, full.ixu, full.idl, full.idu)
     ok, d, info = full.compute_directions_w_IR(r, mu=1e-4)
     assert ok and info["converged"] and _flat_err(full, r, d) <= 1e-6 * 1.0001
+
+
+def test_xdycyd_form_gives_the_same_directions():
+    _, f1, it = cases.dense_case(14, 3, 5, seed=4)
+    _, f2, _ = cases.dense_case(14, 3, 5, seed=4, xd_form=True)
+    assert f1.update(it) and f2.update(it)
+    r = cases.random_resid(f1.sizes, f1.ixl, f1.ixu, f1.idl, f1.idu)
+    ok1, d1 = f1.compute_directions(r)
+    ok2, d2 = f2.compute_directions(r)
+    assert ok1 and ok2
+    np.testing.assert_allclose(kf.pack(d2, kf.ITER_PARTS), kf.pack(d1, kf.ITER_PARTS), rtol=1e-9, atol=1e-11)
+    assert _flat_err(f2, r, d2) < 1e-11
+
+
+def test_inertia_free_path_regularises_until_curvature_is_positive():
+    """The inertia-free acceptor takes the first factorisation as is; the direction then fails the curvature test and
+    factorize_inertia_free adds delta_w until test_direction accepts (hiopAlgFilterIPM.cpp:3374-3440)."""
+    _, full, it = cases.dense_case(16, 3, 4, seed=21, nonconvex=True, inertia_free=True,
+                                                               neg_value=-50.0, free_nonconvex=True)
+    assert full.update(it) and full.num_refact == 0 and full.perturb.deltas()[0] == 0.0
+    r = cases.negative_curvature_resid(full.sizes)
+    rounds = 0
+    while True:
+        ok, d = full.compute_directions(r)
+        assert ok
+        if full.test_direction(d):
+            break
+        assert full.factorize_inertia_free()
+        rounds += 1
+        assert rounds <= 10
+    assert full.last_dWd >= 1e-11 * full.last_xs_nrmsq
+    assert rounds >= 1 and full.perturb.deltas()[0] > 0
