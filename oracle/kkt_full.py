@@ -706,6 +706,20 @@ class KKTLinSysFull:
         return True, unpack(x, ITER_PARTS, self.sizes), info          # accepted even if not converged (:949-953)
 
 
+def sharded_dot(sizes, allreduce):
+    """Dot product of two local slabs on a column partition: the x-sized parts (x, sxl, sxu, zl, zu) are slices and
+    their partial sums are all-reduced, the other parts are replicated (hiopVectorCompoundPD::dotProductWith sums the
+    parts' own dotProductWith, each with its own communicator semantics)."""
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    dist_parts = (0, 4, 5, 8, 9)
+
+    def dot(u, v):
+        d = sum(float(u[offs[p]:offs[p + 1]] @ v[offs[p]:offs[p + 1]]) for p in dist_parts)
+        rpl = sum(float(u[offs[p]:offs[p + 1]] @ v[offs[p]:offs[p + 1]]) for p in range(12) if p not in dist_parts)
+        return float(allreduce(np.array([d]))[0]) + rpl
+    return dot
+
+
 def _div_w_select(num, den, pattern):                                  # hiopVectorPar.cpp:580
     out = np.zeros_like(num)
     m = pattern != 0.0

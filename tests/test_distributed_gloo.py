@@ -125,6 +125,99 @@ def test_sharded_lowrank_kkt_equals_single_rank(n, me, mi):
     np.testing.assert_allclose(y, ref[4], rtol=1e-9, atol=1e-10)
 
 
+def _full_space_run(H, K, sl, prob, rank_allreduce=None):
+    """Full-space layer (update -> compute_directions_w_IR) on one rank's slice; returns the direction parts."""
+    from oracle import kkt_full as kf
+    from tests import kkt_full_cases as cases
+    q, Jc, Jd, xs, ycs, yds, Dx, Dd, rx, ryc, ryd = prob
+    n, me, mi = Jc.shape[1], Jc.shape[0], Jd.shape[0]
+    for it, x in enumerate(xs):
+        H.update(x[sl], (q * x)[sl], Jc[:, sl], Jd[:, sl], ycs[it], yds[it])
+    r = np.random.Generator(np.random.PCG64(99))
+    ixl = (r.uniform(0, 1, n) < 0.7).astype(np.float64)
+    ixu = (r.uniform(0, 1, n) < 0.3).astype(np.float64)
+    idl = np.ones(mi)
+    idu = (r.uniform(0, 1, mi) < 0.5).astype(np.float64)
+    it_full = cases.random_iterate(n, mi, me, mi, ixl, ixu, idl, idu, seed=3)
+    res_full = cases.random_resid(kf.part_sizes(n, mi, me, mi), ixl, ixu, idl, idu, seed=5)
+    xparts = ("x", "sxl", "sxu", "zl", "zu", "rx", "rxl", "rxu", "rszl", "rszu")
+    loc = lambda d: {k: (v[sl] if k in xparts else v) for k, v in d.items()}
+    prov = kf.LowRankProvider(K, Jc[:, sl], Jd[:, sl])
+    full = kf.KKTLinSysFull(prov, ixl[sl], ixu[sl], idl, idu, perturb=kf.PDPerturbationNull())
+    assert full.update(loc(it_full))
+    dot = kf.sharded_dot(full.sizes, rank_allreduce) if rank_allreduce else None
+    ok, d, info = full.compute_directions_w_IR(loc(res_full), mu=1e-8, dot=dot)
+    y = full.times_vec(d)
+    return ok, d, info, y
+
+
+def _worker_full(rank, world, port, n, me, mi, seed, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import hiop_oracle as ho
+
+    def allreduce(buf):
+        t = torch.from_numpy(np.ascontiguousarray(buf))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def allreduce_max(buf):
+        t = torch.from_numpy(np.ascontiguousarray(buf))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.numpy()
+
+    prob = _problem(n, me, mi, seed)
+    cols = col_partition(n, world)
+    sl = slice(cols[rank], cols[rank + 1])
+    H = ho.HessianLowRank(sl.stop - sl.start, l_max=6, sigma0=1.0, sigma_update_strategy="sty", rank=rank,
+                          allreduce=allreduce)
+    H.allreduce_max = allreduce_max
+    K = ho.KKTLinSysLowRank(H, me, mi)
+    ok, d, info, y = _full_space_run(H, K, sl, prob, allreduce)
+    parts = [None] * world
+    dist.all_gather_object(parts, (d, y))
+    if rank == 0:
+        q.put((ok, parts, info))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,me,mi", [(101, 2, 3)])
+def test_sharded_full_space_ir_equals_single_rank(n, me, mi):
+    """12-part compound vectors on a column partition: x-sized parts sliced, dual-sized parts replicated; the
+    BiCGStab scalars must come out identical on every rank (hiopVectorCompoundPD dot-product semantics)."""
+    from oracle import hiop_oracle as ho
+    from oracle import kkt_full as kf
+    seed = 11
+    prob = _problem(n, me, mi, seed)
+    H1 = ho.HessianLowRank(n, l_max=6, sigma0=1.0, sigma_update_strategy="sty")
+    K1 = ho.KKTLinSysLowRank(H1, me, mi)
+    ok1, d1, info1, y1 = _full_space_run(H1, K1, slice(0, n), prob)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_full, args=(r, 2, port, n, me, mi, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, parts, info = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and ok1 and info["converged"] and info1["converged"] and info["iter"] == info1["iter"]
+    xparts = ("x", "sxl", "sxu", "zl", "zu")
+    for k in kf.ITER_PARTS:
+        got = np.concatenate([p[0][k] for p in parts]) if k in xparts else parts[0][0][k]
+        np.testing.assert_allclose(got, d1[k], rtol=1e-8, atol=1e-10, err_msg=k)
+        if k not in xparts:     # replicated parts are identical on both ranks
+            np.testing.assert_array_equal(parts[0][0][k], parts[1][0][k])
+    rx = ("rx", "rxl", "rxu", "rszl", "rszu")
+    for k in kf.RESID_PARTS:
+        got = np.concatenate([p[1][k] for p in parts]) if k in rx else parts[0][1][k]
+        np.testing.assert_allclose(got, y1[k], rtol=1e-8, atol=1e-10, err_msg=k)
+
+
 def test_col_partition_matches_reference_rule():
     assert col_partition(10, 3) == [0, 4, 7, 10]
     assert col_partition(8, 8) == list(range(9))

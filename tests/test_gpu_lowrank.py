@@ -197,7 +197,31 @@ def test_rccl_allreduce_hook_single_rank(ctx):
         assert Kg.solve_compressed(D(rx), D(ryc), D(ryd), dx, dyc, dyd); c2.sync()
         np.testing.assert_allclose(dx.cpu().numpy(), dx_o, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(dyc.cpu().numpy(), dyc_o, rtol=1e-7, atol=1e-9)
-        Kg.close(); Hg.close()
+        # the full-space layer on the same (1-rank) partition: compound-vector dots split into their distributed and
+        # replicated parts, Jacobian products all-reduced (hiopamd_kkt_xycyd_*, sharded code path)
+        from hiop_amd.kkt import KKTLinSysXYcYd
+        from oracle import kkt_full as kf
+        from tests import kkt_full_cases as cases
+        ixl = (r.uniform(0, 1, n) < 0.7).astype(np.float64); ixu = (r.uniform(0, 1, n) < 0.3).astype(np.float64)
+        idl = np.ones(mi); idu = np.array([1.0, 0.0])
+        fo = kf.KKTLinSysFull(kf.LowRankProvider(Ko, Jc, Jd), ixl, ixu, idl, idu, perturb=kf.PDPerturbationNull())
+        fg = KKTLinSysXYcYd(c2, Kg, D(ixl), D(ixu), D(idl), D(idu))
+        fg.set_matrices(None, D(Jc), D(Jd))
+        it = cases.random_iterate(n, mi, me, mi, ixl, ixu, idl, idu, seed=3)
+        res = cases.random_resid(fo.sizes, ixl, ixu, idl, idu)
+        it_g, r_g = fg.pack(it, kf.ITER_PARTS), fg.pack(res, kf.RESID_PARTS)
+        assert fo.update(it) and fg.update(it_g)
+        d_g = torch.zeros(fg.dim, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ok_g, info_g = fg.compute_directions_w_IR(r_g, d_g); c2.sync()
+        ok_o, d_o, info_o = fo.compute_directions_w_IR(res, mu=1e-8)
+        assert ok_g and info_g["converged"] and info_o["converged"]
+        got = kf.pack(fg.unpack(d_g, kf.ITER_PARTS), kf.ITER_PARTS)
+        want = kf.pack(d_o, kf.ITER_PARTS)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-8 * np.abs(want).max())
+        acc, dWd, nrm = fg.test_direction(d_g)
+        assert acc == fo.test_direction(d_o) and dWd == pytest.approx(fo.last_dWd, rel=1e-7)
+        fg.close(); Kg.close(); Hg.close()
     finally:
         c2.close()
         if own:
