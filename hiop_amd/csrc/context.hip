@@ -84,6 +84,20 @@ int hiopamd_ctx_destroy(hiopamd_ctx* c)
   hipFree(c->d_iresult);
   hipHostFree(c->h_result);
   if(c->d_work) hipFree(c->d_work);
+  for(int q = 0; q < 4; ++q)
+    if(c->aux_cand[q]) {
+      hipStreamSynchronize(c->aux_cand[q]);
+      hipStreamDestroy(c->aux_cand[q]);
+    }
+  if(c->diag_stream) {
+    hipStreamSynchronize(c->diag_stream);
+    hipStreamDestroy(c->diag_stream);
+  }
+  if(c->upd_stream) {
+    hipStreamSynchronize(c->upd_stream);
+    hipStreamDestroy(c->upd_stream);
+  }
+  for(int i = 0; i < c->n_events; ++i) hipEventDestroy(c->ev_pool[i]);
   if(c->own_stream) hipStreamDestroy(c->stream);
   delete c;
   return HIOPAMD_OK;

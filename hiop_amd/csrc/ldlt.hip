@@ -25,6 +25,7 @@
 // 78.6 TFLOP/s / 6.3 TB/s).
 #include "device_utils.hpp"
 
+#include <chrono>
 #include <vector>
 
 namespace hiopamd {
@@ -322,6 +323,7 @@ __device__ __forceinline__ double ld_maybe_bypass(const double* p)
 
 template <int P, bool BYPASS>
 __device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, int K0, int kbs, int64_t col, bool col_ok,
+                                                const double* Cd /* compact diagonal block, ld = LD_NB */,
                                                 const double* Dk_sp, const double* Li_sp, double4_t (&Vv)[4][4], int g,
                                                 int li)
 {
@@ -346,7 +348,7 @@ __device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, in
       for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
         for(int kk = 0; kk < 4; ++kk)
-          Lop[Jq][kk] = -ld_maybe_bypass<BYPASS>(A + (int64_t)(K0 + 64 * q + 16 * Jq + 4 * kk + g) * lda + (K0 + 64 * P + 16 * I + li));
+          Lop[Jq][kk] = -ld_maybe_bypass<BYPASS>(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (64 * P + 16 * I + li));
 #pragma unroll
       for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
@@ -485,11 +487,27 @@ __device__ __forceinline__ void block_row_solve_lds(const int P, double* A, int6
       const int row = 64 * P + 16 * I + g + 4 * r;
       const double v = col_ok ? vp[I][r] : 0.0;
       Vs[row][cl] = v;
-      if(col_ok) {
-        V[(int64_t)row * ldv + col] = v;
-        A[(int64_t)(K0 + row) * lda + col] = v * dall[row];
-      }
+      if(col_ok) A[(int64_t)(K0 + row) * lda + col] = v * dall[row];   // U = D^-1 V (V itself is only needed in LDS)
     }
+}
+
+// Compact (contiguous, ld = 256) copies of the 256x256 diagonal blocks.  The 1-workgroup super-diagonal kernel makes
+// ~30 dependent global round trips; on the row-major N x N matrix consecutive rows are 64 KB apart and every round trip
+// pays TLB misses (~14 us measured), on a 512 KB contiguous block it is an L2 hit.  The trailing update writes the
+// next block's compact copy from its epilogue; only the very first block is gathered by ldlt_pack_diag_kernel.
+__global__ __launch_bounds__(kBlock) void ldlt_pack_diag_kernel(const double* __restrict__ A, int64_t lda, int K0, int kbs,
+                                                                double* __restrict__ C)
+{
+  const int r = blockIdx.x, c = threadIdx.x;
+  C[r * LD_NB + c] = (r < kbs && c < kbs && c >= r) ? A[(int64_t)(K0 + r) * lda + (K0 + c)] : 0.0;
+}
+
+// factored block (U strictly upper, D on the diagonal) back into the matrix
+__global__ __launch_bounds__(kBlock) void ldlt_unpack_diag_kernel(const double* __restrict__ C, double* __restrict__ A,
+                                                                  int64_t lda, int K0, int kbs)
+{
+  const int r = blockIdx.x, c = threadIdx.x;
+  if(r < kbs && c < kbs && c >= r) A[(int64_t)(K0 + r) * lda + (K0 + c)] = C[r * LD_NB + c];
 }
 
 // one workgroup: LDL^T of the kbs x kbs (<= 256) diagonal block of a super-panel, panel after panel (left-looking):
@@ -596,6 +614,7 @@ __global__ __launch_bounds__(kBlock) void ldlt_superdiag_kernel(double* __restri
 __global__ __launch_bounds__(64) void ldlt_supertrsm_kernel(double* __restrict__ A, int64_t lda, int N, int K0, int kbs,
                                                             double* __restrict__ V, int64_t ldv,
                                                             const double* __restrict__ dinv,
+                                                            const double* __restrict__ Cd,
                                                             const double* __restrict__ Dk_sp,
                                                             const double* __restrict__ Li_sp)
 {
@@ -610,18 +629,18 @@ __global__ __launch_bounds__(64) void ldlt_supertrsm_kernel(double* __restrict__
   for(int a = 0; a < 4; ++a)
 #pragma unroll
     for(int b = 0; b < 4; ++b) Vv[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  block_row_solve<0, false>(A, lda, K0, kbs, colc, col_ok, Dk_sp, Li_sp, Vv, g, li);
+  block_row_solve<0, false>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
   block_row_store<0>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   if(np > 1) {
-    block_row_solve<1, false>(A, lda, K0, kbs, colc, col_ok, Dk_sp, Li_sp, Vv, g, li);
+    block_row_solve<1, false>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
     block_row_store<1>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   }
   if(np > 2) {
-    block_row_solve<2, false>(A, lda, K0, kbs, colc, col_ok, Dk_sp, Li_sp, Vv, g, li);
+    block_row_solve<2, false>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
     block_row_store<2>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   }
   if(np > 3) {
-    block_row_solve<3, false>(A, lda, K0, kbs, colc, col_ok, Dk_sp, Li_sp, Vv, g, li);
+    block_row_solve<3, false>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
     block_row_store<3>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   }
 }
@@ -636,7 +655,8 @@ __global__ __launch_bounds__(64) void ldlt_supertrsm_kernel(double* __restrict__
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restrict__ A, int64_t lda, int N,
                                                                 const double* __restrict__ V, int64_t ldv, int vrow0,
-                                                                int urow0, int K, int s, int row_end, int xcd_map)
+                                                                int urow0, int K, int s, int row_end, int xcd_map,
+                                                                double* __restrict__ Cnext)
 {
   int ti, tj;
   if(xcd_map) {
@@ -739,6 +759,8 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
         cv[reg][j] = ok[reg][j] ? Crow[col] : 0.0;
       }
     }
+    // tiles of the next super-panel's diagonal block also feed its compact copy (origin s, ld = 256)
+    const bool to_compact = Cnext && r0 < s + LD_NB && c0 < s + LD_NB;
 #pragma unroll
     for(int reg = 0; reg < 4; ++reg) {
       const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
@@ -746,7 +768,11 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
 #pragma unroll
       for(int j = 0; j < 4; ++j) {
         const int col = c0 + wc * 64 + j * 16 + li;
-        if(ok[reg][j]) Crow[col] = cv[reg][j] - acc[i][j][reg];
+        if(ok[reg][j]) {
+          const double nv = cv[reg][j] - acc[i][j][reg];
+          Crow[col] = nv;
+          if(to_compact && row < s + LD_NB && col < s + LD_NB) Cnext[(row - s) * LD_NB + (col - s)] = nv;
+        }
       }
     }
   }
@@ -1030,6 +1056,7 @@ struct hiopamd_linsolver {
   double* V = nullptr;      // LD_NB x n workspace
   double* ybuf = nullptr;   // n
   double* Dblk = nullptr;   // ceil(n/64) staged 64x64 diagonal blocks
+  double* Cd = nullptr;     // ceil(n/256) compact 256x256 diagonal blocks (ld = 256)
   int* d_info = nullptr;    // [0]=zero-pivot flag, [1..3]=pos,neg,zero
   bool factored = false;
   int inertia[3] = {0, 0, 0};
@@ -1037,14 +1064,16 @@ struct hiopamd_linsolver {
 };
 
 static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, double* dinv, double* V, double* Dblk,
-                            int* d_info, int* inertia3_host, LdltProfile* prof = nullptr)
+                            double* Cd, int* d_info, int* inertia3_host, LdltProfile* prof = nullptr)
 {
   // Dblk: per 64-row panel a compact 64x64 copy of the factored diagonal block, followed (after all
   // the blocks) by the per-panel 4 x 16x16 inverses
   double* Li = Dblk + (int64_t)((N + LD_nb - 1) / LD_nb) * (LD_nb * LD_nb);
   const bool timed = prof && prof->enabled;
-  auto launch_update = [&](dim3 grid, int vrow0, int urow0, int K, int s, int row_end) {
-    if(timed) (void)hipEventRecord(prof->get(), ctx->stream);
+  hipStream_t upd_stream = ctx->stream;
+  auto launch_update = [&](dim3 grid, const double* Vb, int urow0, int K, int s, int row_end, double* Cnext) {
+    const int vrow0 = 0;
+    if(timed) (void)hipEventRecord(prof->get(), upd_stream);
     int xcd_map = 0;
     if(row_end == N && grid.x == grid.y && grid.x >= 16) {
       // square trailing update: XCD-aware 1-D launch over 8x8-tile super-tiles
@@ -1054,10 +1083,10 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       const int per_xcd = (nS + 7) / 8;           // super-tiles per XCD
       grid = dim3((unsigned)(per_xcd * 64 * 8), 1, 1);
     }
-    hipLaunchKernelGGL(ldlt_update_kernel, grid, dim3(kBlock), 0, ctx->stream, A, lda, N, V, (int64_t)N, vrow0, urow0, K, s,
-                       row_end, xcd_map);
+    hipLaunchKernelGGL(ldlt_update_kernel, grid, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, s,
+                       row_end, xcd_map, Cnext);
     if(timed) {
-      (void)hipEventRecord(prof->get(), ctx->stream);
+      (void)hipEventRecord(prof->get(), upd_stream);
       prof->flops += update_flops(N, K, s, row_end);
       prof->launches += 1;
     }
@@ -1070,26 +1099,55 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   hipStream_t st = ctx->stream;
   HIOPAMD_CHECK(hipMemsetAsync(d_info, 0, 4 * sizeof(int), st));
   const int64_t ldv = N;
-  for(int K0 = 0; K0 < N; K0 += LD_NB) {
+  // LOOK-AHEAD.  The serial chain of the NEXT super-panel (super-diagonal factor, then its row panel) only needs the
+  // first 256 rows of the current trailing update (upd_a), so it runs concurrently with the rest of it (upd_b):
+  //   su : ... upd_a(j) | ev_a | upd_b(j) ............................ | wait ev_b | upd_a(j+1) | ...
+  //   sd :               wait ev_a | superdiag(j+1) | ev_d
+  //   sc :                                            wait ev_d | supertrsm(j+1) | ev_b
+  // su/sd are CU-masked streams (248 CUs / one reserved CU per XCD, see ctx_cu_split): the 1-workgroup super-diagonal
+  // kernel needs a whole CU's LDS and would otherwise starve behind the update grid; sc is an unmasked normal-priority
+  // stream whose single-wave workgroups slip into the CUs as update tiles retire (a HIGH-priority sc made the whole
+  // factorisation 1.6x slower: the update's 512-VGPR waves get preempted).  A cross-stream dependency costs ~15 us.  V is double-buffered: the row panel
+  // of super-panel j+1 is written while upd_b(j) still reads the one of super-panel j.
+  const int nsp = (N + LD_NB - 1) / LD_NB;
+  static int la_mode = -1;   // HIOPAMD_LA_MODE=0 switches the look-ahead off (debug / A-B timing)
+  if(la_mode < 0) la_mode = std::getenv("HIOPAMD_LA_MODE") ? std::atoi(std::getenv("HIOPAMD_LA_MODE")) : 1;
+  const bool lookahead = nsp > 2 && la_mode > 0 && ctx_cu_split(ctx);
+  hipStream_t su = st, sd = st, sc = st;
+  const bool calibrate = lookahead && nsp >= 8;   // time this factorisation for the helper-stream choice
+  const int aux_idx = lookahead ? ctx_aux_pick(ctx) : 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  if(lookahead) {
+    su = ctx->upd_stream;
+    sd = ctx->diag_stream;
+    sc = ctx_aux_stream(ctx, aux_idx);
+  }
+  upd_stream = su;
+  static long long* d_ts = nullptr;   // debug: HIOPAMD_SD_TRACE=1 prints the phase timeline of one super-panel
+  static int trace_state = -1;
+  if(trace_state < 0) trace_state = (std::getenv("HIOPAMD_SD_TRACE") != nullptr) ? 1 : 0;
+  int evn = 0;
+  auto next_event = [&]() { return ctx_event(ctx, (evn++) % 160); };
+  auto chain = [&](int jp, hipStream_t s_diag, hipStream_t s_trsm) -> int {   // super-diagonal factor + row panel of super-panel jp
+    const int K0 = jp * LD_NB;
     const int Kend = (K0 + LD_NB < N) ? K0 + LD_NB : N;
     const int kbs = Kend - K0;
-    // per-super-panel slices of the compact factor copies (4 panels each)
+    double* Vb = V + (int64_t)(jp & 1) * LD_NB * ldv;
     double* Dk_sp = Dblk + (int64_t)(K0 / LD_nb) * (LD_nb * LD_nb);
     double* Li_sp = Li + (int64_t)(K0 / LD_nb) * (4 * LD_SB * LD_SB);
-    // (1) the super-panel's 256 x 256 diagonal block: one workgroup, left-looking over its 4 panels
-    static long long* d_ts = nullptr;   // debug: HIOPAMD_SD_TRACE=1 prints the phase timeline of one super-panel
-    static int trace_state = -1;
-    if(trace_state < 0) trace_state = (std::getenv("HIOPAMD_SD_TRACE") != nullptr) ? 1 : 0;
     long long* ts_arg = nullptr;
     if(trace_state == 1 && K0 == 0 && kbs == LD_NB) {
       if(!d_ts) (void)hipMalloc((void**)&d_ts, 32 * sizeof(long long));
       ts_arg = d_ts;
     }
-    hipLaunchKernelGGL(ldlt_superdiag_kernel, dim3(1), dim3(kBlock), 0, st, A, lda, K0, kbs, V, ldv, dinv, Dk_sp, Li_sp,
-                       d_info, ts_arg);
+    // the super-diagonal kernel works on the compact copy of its block: matrix pointer = Cj, ld = 256, origin 0
+    double* Cj = Cd + (int64_t)jp * (LD_NB * LD_NB);
+    if(jp == 0) hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, s_diag, A, lda, K0, kbs, Cj);
+    hipLaunchKernelGGL(ldlt_superdiag_kernel, dim3(1), dim3(kBlock), 0, s_diag, Cj, (int64_t)LD_NB, 0, kbs, Vb, ldv, dinv + K0,
+                       Dk_sp, Li_sp, d_info, ts_arg);
     if(ts_arg) {
       long long h[17];
-      (void)hipStreamSynchronize(st);
+      (void)hipStreamSynchronize(s_diag);
       (void)hipMemcpy(h, d_ts, sizeof(h), hipMemcpyDeviceToHost);
       std::fprintf(stderr, "[hiop_amd] superdiag timeline (wall_clock64 ticks, 100 MHz => 10 ns):");
       for(int q = 1; q <= 16; ++q) std::fprintf(stderr, " %lld", h[q] - h[0]);
@@ -1097,21 +1155,77 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       trace_state = 2;
     }
     if(Kend < N) {
-      // (2) the row panel right of it: V = L^-1 A12, U12 = D^-1 V, one wave per 16 columns
+      if(s_trsm != s_diag) {
+        hipEvent_t ev_d = next_event();
+        HIOPAMD_CHECK(hipEventRecord(ev_d, s_diag));
+        HIOPAMD_CHECK(hipStreamWaitEvent(s_trsm, ev_d, 0));
+      }
       const int ncols = N - Kend;
-      hipLaunchKernelGGL(ldlt_supertrsm_kernel, dim3((ncols + 15) / 16), dim3(64), 0, st, A, lda, N, K0, kbs, V, ldv, dinv,
-                         Dk_sp, Li_sp);
-      // (3) trailing update, K = 256
-      const int s = Kend;
-      const int t = (N - s + LD_TM - 1) / LD_TM;
-      launch_update(dim3(t, t), 0, K0, kbs, s, N);
+      hipLaunchKernelGGL(ldlt_supertrsm_kernel, dim3((ncols + 15) / 16), dim3(64), 0, s_trsm, A, lda, N, K0, kbs, Vb, ldv,
+                         dinv, Cj, Dk_sp, Li_sp);
     }
+    // the factored block goes back into the matrix off the critical path (the solves and the inertia read it there)
+    hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, s_diag, Cj, A, lda, K0, kbs);
+    return HIOPAMD_OK;
+  };
+  {
+    int rc = chain(0, st, st);
+    if(rc != HIOPAMD_OK) return rc;
+  }
+  if(lookahead) {   // fork: the update stream starts after everything queued on the caller's stream so far
+    hipEvent_t ev0 = next_event();
+    HIOPAMD_CHECK(hipEventRecord(ev0, st));
+    HIOPAMD_CHECK(hipStreamWaitEvent(su, ev0, 0));
+  }
+  for(int jp = 0; jp < nsp; ++jp) {
+    const int K0 = jp * LD_NB;
+    const int Kend = (K0 + LD_NB < N) ? K0 + LD_NB : N;
+    const int kbs = Kend - K0;
+    if(Kend >= N) break;
+    const double* Vb = V + (int64_t)(jp & 1) * LD_NB * ldv;
+    const int s = Kend;
+    const int sa_end = (s + LD_NB < N) ? s + LD_NB : N;   // rows of the next super-panel
+    // upd_a: the rows the next super-panel's chain needs
+    {
+      const int tcols = (N - s + LD_TN - 1) / LD_TN;
+      const int trows = (sa_end - s + LD_TM - 1) / LD_TM;
+      launch_update(dim3(tcols, trows), Vb, K0, kbs, s, sa_end, Cd + (int64_t)(jp + 1) * (LD_NB * LD_NB));
+    }
+    if(lookahead) {
+      hipEvent_t ev_a = next_event();
+      HIOPAMD_CHECK(hipEventRecord(ev_a, su));
+      HIOPAMD_CHECK(hipStreamWaitEvent(sd, ev_a, 0));
+    }
+    {
+      int rc = chain(jp + 1, sd, sc);
+      if(rc != HIOPAMD_OK) return rc;
+    }
+    // upd_b: the rest of the trailing matrix, concurrent with the chain above
+    if(sa_end < N) {
+      const int t = (N - sa_end + LD_TM - 1) / LD_TM;
+      launch_update(dim3(t, t), Vb, K0, kbs, sa_end, N, nullptr);
+    }
+    if(lookahead) {
+      hipEvent_t ev_b = next_event();
+      HIOPAMD_CHECK(hipEventRecord(ev_b, (sa_end < N) ? sc : sd));
+      HIOPAMD_CHECK(hipStreamWaitEvent(su, ev_b, 0));
+    }
+  }
+  if(lookahead) {   // join (su: last update; sd: last unpack)
+    hipEvent_t evj = next_event();
+    HIOPAMD_CHECK(hipEventRecord(evj, su));
+    HIOPAMD_CHECK(hipStreamWaitEvent(st, evj, 0));
+    hipEvent_t evd = next_event();
+    HIOPAMD_CHECK(hipEventRecord(evd, sd));
+    HIOPAMD_CHECK(hipStreamWaitEvent(st, evd, 0));
   }
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
   HIOPAMD_CHECK(hipGetLastError());
   int h[4];
   HIOPAMD_CHECK(hipMemcpyAsync(h, d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   HIOPAMD_CHECK(hipStreamSynchronize(st));
+  if(calibrate)
+    ctx_aux_report(ctx, aux_idx, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   if(timed) prof->collect();
   if(inertia3_host) {
     inertia3_host[0] = h[1];
@@ -1165,11 +1279,12 @@ int hiopamd_ldlt_factor(hiopamd_ctx* ctx, int n, double* A, int64_t lda, double*
 {
   // workspace: V panel (LD_NB x n) + info flags from the context's grow-only buffer
   const size_t nn = (size_t)(n > 0 ? n : 1);
-  const size_t vbytes = sizeof(double) * (size_t)LD_NB * nn;
+  const size_t vbytes = sizeof(double) * (size_t)LD_NB * nn * 2;
   const size_t dbytes = sizeof(double) * (size_t)(LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb);
-  char* w = (char*)ctx_workspace(ctx, vbytes + dbytes + 64);
-  return ldlt_factor_impl(ctx, n, A, lda, work_dinv, (double*)w, (double*)(w + vbytes), (int*)(w + vbytes + dbytes),
-                          inertia3_host);
+  const size_t cbytes = sizeof(double) * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB);
+  char* w = (char*)ctx_workspace(ctx, vbytes + dbytes + cbytes + 64);
+  return ldlt_factor_impl(ctx, n, A, lda, work_dinv, (double*)w, (double*)(w + vbytes), (double*)(w + vbytes + dbytes),
+                          (int*)(w + vbytes + dbytes + cbytes), inertia3_host);
 }
 
 int hiopamd_ldlt_solve(hiopamd_ctx* ctx, int n, const double* A, int64_t lda, const double* work_dinv,
@@ -1188,9 +1303,10 @@ int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
   const size_t nn = (size_t)(n > 0 ? n : 1);
   HIOPAMD_CHECK(hipMalloc((void**)&ls->M, sizeof(double) * nn * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->dinv, sizeof(double) * nn));
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB * 2));   // double-buffered row panel
   HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb)));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB)));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
   HIOPAMD_CHECK(hipMemsetAsync(ls->M, 0, sizeof(double) * nn * nn, ctx->stream));
   *out = ls;
@@ -1206,6 +1322,7 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->V);
   (void)hipFree(ls->ybuf);
   (void)hipFree(ls->Dblk);
+  (void)hipFree(ls->Cd);
   (void)hipFree(ls->d_info);
   delete ls;
   return HIOPAMD_OK;
@@ -1218,7 +1335,7 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
 {
   if(!ls || !n_neg_host) return HIOPAMD_ERR_ARG;
   ls->factored = false;
-  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->d_info, ls->inertia, &ls->prof);
+  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof);
   if(rc == HIOPAMD_ERR_SINGULAR) {
     // reference: "entry in the factorization's diagonal is exactly zero" -> matrixChanged() returns -1
     *n_neg_host = -1;
