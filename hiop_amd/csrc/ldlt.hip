@@ -616,10 +616,10 @@ __global__ __launch_bounds__(64) void ldlt_supertrsm_kernel(double* __restrict__
                                                             const double* __restrict__ dinv,
                                                             const double* __restrict__ Cd,
                                                             const double* __restrict__ Dk_sp,
-                                                            const double* __restrict__ Li_sp)
+                                                            const double* __restrict__ Li_sp, int col_ofs)
 {
   const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
-  const int64_t col = (int64_t)K0 + kbs + (int64_t)blockIdx.x * 16 + li;
+  const int64_t col = (int64_t)K0 + kbs + col_ofs + (int64_t)blockIdx.x * 16 + li;
   const bool col_ok = col < N;
   const int64_t colc = col_ok ? col : (int64_t)(N - 1);
   const int np = (kbs + LD_nb - 1) / LD_nb;
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64) void ldlt_supertrsm_kernel(double* __restrict__
 __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restrict__ A, int64_t lda, int N,
                                                                 const double* __restrict__ V, int64_t ldv, int vrow0,
                                                                 int urow0, int K, int s, int row_end, int xcd_map,
-                                                                double* __restrict__ Cnext)
+                                                                double* __restrict__ Cnext, int col_end, int skip_diag)
 {
   int ti, tj;
   if(xcd_map) {
@@ -686,7 +686,8 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
   }
   if(tj < ti) return;
   const int r0 = s + ti * LD_TM, c0 = s + tj * LD_TN;
-  if(r0 >= row_end || c0 >= N) return;
+  if(r0 >= row_end || c0 >= col_end) return;
+  if(skip_diag && r0 < s + LD_NB && c0 < s + LD_NB) return;   // the next diagonal block is updated by the chain stream
   __shared__ double Vs[LD_KT][LD_LDP];
   __shared__ double Us[LD_KT][LD_LDP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
 #pragma unroll
       for(int j = 0; j < 4; ++j) {
         const int col = c0 + wc * 64 + j * 16 + li;
-        ok[reg][j] = (row < row_end) && (col < N) && (col >= row);
+        ok[reg][j] = (row < row_end) && (col < col_end) && (col >= row);
         cv[reg][j] = ok[reg][j] ? Crow[col] : 0.0;
       }
     }
@@ -1071,11 +1072,17 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   double* Li = Dblk + (int64_t)((N + LD_nb - 1) / LD_nb) * (LD_nb * LD_nb);
   const bool timed = prof && prof->enabled;
   hipStream_t upd_stream = ctx->stream;
-  auto launch_update = [&](dim3 grid, const double* Vb, int urow0, int K, int s, int row_end, double* Cnext) {
+  auto launch_update = [&](dim3 grid, const double* Vb, int urow0, int K, int s, int row_end, double* Cnext, int col_end,
+                           int skip_diag) {
     const int vrow0 = 0;
     if(timed) (void)hipEventRecord(prof->get(), upd_stream);
     int xcd_map = 0;
-    if(row_end == N && grid.x == grid.y && grid.x >= 16) {
+    static int xcd_min = -1;   // HIOPAMD_XCD_MIN_TILES: smallest tile count per side that uses the XCD-aware mapping
+    // default: off.  On the CU-masked update stream an XCD has 31 CUs = 62 tile slots, so an 8x8-tile super-tile no longer
+    // fits one round per XCD and the mapping costs ~50 us per launch (measured: 8.5 ms -> 7.6 ms of update time per
+    // factorisation without it); it never showed a measurable gain on the full device either.
+    if(xcd_min < 0) xcd_min = std::getenv("HIOPAMD_XCD_MIN_TILES") ? std::atoi(std::getenv("HIOPAMD_XCD_MIN_TILES")) : 100000;
+    if(row_end == N && grid.x == grid.y && (int)grid.x >= xcd_min) {
       // square trailing update: XCD-aware 1-D launch over 8x8-tile super-tiles
       xcd_map = (int)grid.x;
       const int Sside = (xcd_map + 7) / 8;
@@ -1084,7 +1091,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       grid = dim3((unsigned)(per_xcd * 64 * 8), 1, 1);
     }
     hipLaunchKernelGGL(ldlt_update_kernel, grid, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, s,
-                       row_end, xcd_map, Cnext);
+                       row_end, xcd_map, Cnext, col_end, skip_diag);
     if(timed) {
       (void)hipEventRecord(prof->get(), upd_stream);
       prof->flops += update_flops(N, K, s, row_end);
@@ -1099,133 +1106,145 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   hipStream_t st = ctx->stream;
   HIOPAMD_CHECK(hipMemsetAsync(d_info, 0, 4 * sizeof(int), st));
   const int64_t ldv = N;
-  // LOOK-AHEAD.  The serial chain of the NEXT super-panel (super-diagonal factor, then its row panel) only needs the
-  // first 256 rows of the current trailing update (upd_a), so it runs concurrently with the rest of it (upd_b):
-  //   su : ... upd_a(j) | ev_a | upd_b(j) ............................ | wait ev_b | upd_a(j+1) | ...
-  //   sd :               wait ev_a | superdiag(j+1) | ev_d
-  //   sc :                                            wait ev_d | supertrsm(j+1) | ev_b
-  // su/sd are CU-masked streams (248 CUs / one reserved CU per XCD, see ctx_cu_split): the 1-workgroup super-diagonal
-  // kernel needs a whole CU's LDS and would otherwise starve behind the update grid; sc is an unmasked normal-priority
-  // stream whose single-wave workgroups slip into the CUs as update tiles retire (a HIGH-priority sc made the whole
-  // factorisation 1.6x slower: the update's 512-VGPR waves get preempted).  A cross-stream dependency costs ~15 us.  V is double-buffered: the row panel
-  // of super-panel j+1 is written while upd_b(j) still reads the one of super-panel j.
+  // LOOK-AHEAD on two CU-masked streams (ctx_cu_split): `sd` owns one reserved CU per XCD and runs the serial chain
+  // of the factorisation without ever leaving its stream; `su` owns the other 248 CUs and runs the wide work.
+  //   sd : superdiag(j) | trsm_head(j) | upd_diag(j) | superdiag(j+1) | trsm_head(j+1) | ...
+  //   su :     wait diag(j) | trsm_tail(j) | wait head(j) | upd_rest(j) | wait diag(j+1) | trsm_tail(j+1) | ...
+  // superdiag : 1 workgroup, the 256x256 diagonal block (needs a whole CU's LDS: it would starve behind the update grid
+  //             on a shared CU — the dispatcher back-fills partially free CUs with update tiles);
+  // trsm_head : the first 256 columns of the row panel (16 waves) — all upd_diag needs;
+  // upd_diag  : the 3 tiles of the NEXT diagonal block, written to the matrix and to the block's compact copy;
+  // trsm_tail / upd_rest : the rest of the row panel and of the trailing update (one launch, diagonal tiles skipped).
+  // The chain crosses streams only to wait for upd_rest(j-1) (rows of panel j complete) before trsm_head(j); a
+  // cross-stream dependency costs ~15 us on this machine, so none sits between the chain's own kernels.  V is
+  // double-buffered (row panel j+1 is written while upd_rest(j) reads row panel j).
   const int nsp = (N + LD_NB - 1) / LD_NB;
   static int la_mode = -1;   // HIOPAMD_LA_MODE=0 switches the look-ahead off (debug / A-B timing)
   if(la_mode < 0) la_mode = std::getenv("HIOPAMD_LA_MODE") ? std::atoi(std::getenv("HIOPAMD_LA_MODE")) : 1;
   const bool lookahead = nsp > 2 && la_mode > 0 && ctx_cu_split(ctx);
-  hipStream_t su = st, sd = st, sc = st;
-  const bool calibrate = lookahead && nsp >= 8;   // time this factorisation for the helper-stream choice
-  const int aux_idx = lookahead ? ctx_aux_pick(ctx) : 0;
-  const auto t_begin = std::chrono::steady_clock::now();
+  hipStream_t su = st, sd = st;
   if(lookahead) {
     su = ctx->upd_stream;
     sd = ctx->diag_stream;
-    sc = ctx_aux_stream(ctx, aux_idx);
   }
-  upd_stream = su;
   static long long* d_ts = nullptr;   // debug: HIOPAMD_SD_TRACE=1 prints the phase timeline of one super-panel
   static int trace_state = -1;
   if(trace_state < 0) trace_state = (std::getenv("HIOPAMD_SD_TRACE") != nullptr) ? 1 : 0;
   int evn = 0;
   auto next_event = [&]() { return ctx_event(ctx, (evn++) % 160); };
-  auto chain = [&](int jp, hipStream_t s_diag, hipStream_t s_trsm) -> int {   // super-diagonal factor + row panel of super-panel jp
-    const int K0 = jp * LD_NB;
-    const int Kend = (K0 + LD_NB < N) ? K0 + LD_NB : N;
-    const int kbs = Kend - K0;
-    double* Vb = V + (int64_t)(jp & 1) * LD_NB * ldv;
-    double* Dk_sp = Dblk + (int64_t)(K0 / LD_nb) * (LD_nb * LD_nb);
-    double* Li_sp = Li + (int64_t)(K0 / LD_nb) * (4 * LD_SB * LD_SB);
+  auto dep = [&](hipStream_t from, hipStream_t to) -> int {   // `to` continues after everything queued on `from`
+    if(from == to) return HIOPAMD_OK;
+    hipEvent_t e = next_event();
+    HIOPAMD_CHECK(hipEventRecord(e, from));
+    HIOPAMD_CHECK(hipStreamWaitEvent(to, e, 0));
+    return HIOPAMD_OK;
+  };
+  struct Panel {
+    int K0, Kend, kbs;
+    double *Vb, *Dk_sp, *Li_sp, *Cj;
+  };
+  auto panel = [&](int jp) {
+    Panel p;
+    p.K0 = jp * LD_NB;
+    p.Kend = (p.K0 + LD_NB < N) ? p.K0 + LD_NB : N;
+    p.kbs = p.Kend - p.K0;
+    p.Vb = V + (int64_t)(jp & 1) * LD_NB * ldv;
+    p.Dk_sp = Dblk + (int64_t)(p.K0 / LD_nb) * (LD_nb * LD_nb);
+    p.Li_sp = Li + (int64_t)(p.K0 / LD_nb) * (4 * LD_SB * LD_SB);
+    p.Cj = Cd + (int64_t)jp * (LD_NB * LD_NB);
+    return p;
+  };
+  auto superdiag = [&](int jp, hipStream_t stream) {
+    const Panel p = panel(jp);
     long long* ts_arg = nullptr;
-    if(trace_state == 1 && K0 == 0 && kbs == LD_NB) {
+    if(trace_state == 1 && p.K0 == 0 && p.kbs == LD_NB) {
       if(!d_ts) (void)hipMalloc((void**)&d_ts, 32 * sizeof(long long));
       ts_arg = d_ts;
     }
-    // the super-diagonal kernel works on the compact copy of its block: matrix pointer = Cj, ld = 256, origin 0
-    double* Cj = Cd + (int64_t)jp * (LD_NB * LD_NB);
-    if(jp == 0) hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, s_diag, A, lda, K0, kbs, Cj);
-    hipLaunchKernelGGL(ldlt_superdiag_kernel, dim3(1), dim3(kBlock), 0, s_diag, Cj, (int64_t)LD_NB, 0, kbs, Vb, ldv, dinv + K0,
-                       Dk_sp, Li_sp, d_info, ts_arg);
+    // the kernel works on the compact copy of its block: matrix pointer = Cj, ld = 256, origin 0
+    hipLaunchKernelGGL(ldlt_superdiag_kernel, dim3(1), dim3(kBlock), 0, stream, p.Cj, (int64_t)LD_NB, 0, p.kbs, p.Vb, ldv,
+                       dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, ts_arg);
     if(ts_arg) {
       long long h[17];
-      (void)hipStreamSynchronize(s_diag);
+      (void)hipStreamSynchronize(stream);
       (void)hipMemcpy(h, d_ts, sizeof(h), hipMemcpyDeviceToHost);
       std::fprintf(stderr, "[hiop_amd] superdiag timeline (wall_clock64 ticks, 100 MHz => 10 ns):");
       for(int q = 1; q <= 16; ++q) std::fprintf(stderr, " %lld", h[q] - h[0]);
       std::fprintf(stderr, "\n");
       trace_state = 2;
     }
-    if(Kend < N) {
-      if(s_trsm != s_diag) {
-        hipEvent_t ev_d = next_event();
-        HIOPAMD_CHECK(hipEventRecord(ev_d, s_diag));
-        HIOPAMD_CHECK(hipStreamWaitEvent(s_trsm, ev_d, 0));
-      }
-      const int ncols = N - Kend;
-      hipLaunchKernelGGL(ldlt_supertrsm_kernel, dim3((ncols + 15) / 16), dim3(64), 0, s_trsm, A, lda, N, K0, kbs, Vb, ldv,
-                         dinv, Cj, Dk_sp, Li_sp);
-    }
-    // the factored block goes back into the matrix off the critical path (the solves and the inertia read it there)
-    hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, s_diag, Cj, A, lda, K0, kbs);
-    return HIOPAMD_OK;
   };
+  auto trsm = [&](int jp, hipStream_t stream, int col_ofs, int ncols) {
+    if(ncols <= 0) return;
+    const Panel p = panel(jp);
+    hipLaunchKernelGGL(ldlt_supertrsm_kernel, dim3((ncols + 15) / 16), dim3(64), 0, stream, A, lda, N, p.K0, p.kbs, p.Vb, ldv,
+                       dinv, p.Cj, p.Dk_sp, p.Li_sp, col_ofs);
+  };
+  const bool calibrate = false;
+  (void)calibrate;
+  // panel 0's diagonal block on the caller's stream, then fork
   {
-    int rc = chain(0, st, st);
+    const Panel p0 = panel(0);
+    hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, A, lda, p0.K0, p0.kbs, p0.Cj);
+    superdiag(0, st);
+    hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, p0.Cj, A, lda, p0.K0, p0.kbs);
+  }
+  if(lookahead) {
+    int rc = dep(st, su);
+    if(rc == HIOPAMD_OK) rc = dep(st, sd);
     if(rc != HIOPAMD_OK) return rc;
   }
-  if(lookahead) {   // fork: the update stream starts after everything queued on the caller's stream so far
-    hipEvent_t ev0 = next_event();
-    HIOPAMD_CHECK(hipEventRecord(ev0, st));
-    HIOPAMD_CHECK(hipStreamWaitEvent(su, ev0, 0));
-  }
+  hipEvent_t ev_rest_prev = nullptr;   // upd_rest(j-1) done (recorded on su)
   for(int jp = 0; jp < nsp; ++jp) {
-    const int K0 = jp * LD_NB;
-    const int Kend = (K0 + LD_NB < N) ? K0 + LD_NB : N;
-    const int kbs = Kend - K0;
-    if(Kend >= N) break;
-    const double* Vb = V + (int64_t)(jp & 1) * LD_NB * ldv;
-    const int s = Kend;
-    const int sa_end = (s + LD_NB < N) ? s + LD_NB : N;   // rows of the next super-panel
-    // upd_a: the rows the next super-panel's chain needs
+    const Panel p = panel(jp);
+    if(p.Kend >= N) break;
+    const int s = p.Kend;
+    const int head = (N - s < LD_NB) ? (N - s) : LD_NB;   // columns of the next super-panel
+    const int sa_end = s + head;
+    // ---- chain stream
+    if(lookahead && ev_rest_prev) HIOPAMD_CHECK(hipStreamWaitEvent(sd, ev_rest_prev, 0));   // rows of panel jp complete
+    trsm(jp, sd, 0, head);
+    hipEvent_t ev_head = nullptr;
+    if(lookahead) {
+      ev_head = next_event();
+      HIOPAMD_CHECK(hipEventRecord(ev_head, sd));
+    }
+    upd_stream = sd;
+    launch_update(dim3(2, 2), p.Vb, p.K0, p.kbs, s, sa_end, panel(jp + 1).Cj, sa_end, 0);
+    superdiag(jp + 1, sd);
+    hipEvent_t ev_diag = nullptr;
+    if(lookahead) {
+      ev_diag = next_event();
+      HIOPAMD_CHECK(hipEventRecord(ev_diag, sd));
+    }
     {
-      const int tcols = (N - s + LD_TN - 1) / LD_TN;
-      const int trows = (sa_end - s + LD_TM - 1) / LD_TM;
-      launch_update(dim3(tcols, trows), Vb, K0, kbs, s, sa_end, Cd + (int64_t)(jp + 1) * (LD_NB * LD_NB));
+      const Panel pn = panel(jp + 1);
+      hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, sd, pn.Cj, A, lda, pn.K0, pn.kbs);
+    }
+    // ---- wide stream: (superdiag(jp) is already waited for: fork for jp = 0, ev_diag of the previous iteration below)
+    trsm(jp, su, head, N - sa_end);
+    if(lookahead) HIOPAMD_CHECK(hipStreamWaitEvent(su, ev_head, 0));
+    {
+      const int t = (N - s + LD_TM - 1) / LD_TM;
+      upd_stream = su;
+      launch_update(dim3(t, t), p.Vb, p.K0, p.kbs, s, N, nullptr, N, 1);
     }
     if(lookahead) {
-      hipEvent_t ev_a = next_event();
-      HIOPAMD_CHECK(hipEventRecord(ev_a, su));
-      HIOPAMD_CHECK(hipStreamWaitEvent(sd, ev_a, 0));
-    }
-    {
-      int rc = chain(jp + 1, sd, sc);
-      if(rc != HIOPAMD_OK) return rc;
-    }
-    // upd_b: the rest of the trailing matrix, concurrent with the chain above
-    if(sa_end < N) {
-      const int t = (N - sa_end + LD_TM - 1) / LD_TM;
-      launch_update(dim3(t, t), Vb, K0, kbs, sa_end, N, nullptr);
-    }
-    if(lookahead) {
-      hipEvent_t ev_b = next_event();
-      HIOPAMD_CHECK(hipEventRecord(ev_b, (sa_end < N) ? sc : sd));
-      HIOPAMD_CHECK(hipStreamWaitEvent(su, ev_b, 0));
+      ev_rest_prev = next_event();
+      HIOPAMD_CHECK(hipEventRecord(ev_rest_prev, su));
+      HIOPAMD_CHECK(hipStreamWaitEvent(su, ev_diag, 0));   // trsm_tail(jp+1) needs superdiag(jp+1)
     }
   }
-  if(lookahead) {   // join (su: last update; sd: last unpack)
-    hipEvent_t evj = next_event();
-    HIOPAMD_CHECK(hipEventRecord(evj, su));
-    HIOPAMD_CHECK(hipStreamWaitEvent(st, evj, 0));
-    hipEvent_t evd = next_event();
-    HIOPAMD_CHECK(hipEventRecord(evd, sd));
-    HIOPAMD_CHECK(hipStreamWaitEvent(st, evd, 0));
+  if(lookahead) {   // join
+    int rc = dep(su, st);
+    if(rc == HIOPAMD_OK) rc = dep(sd, st);
+    if(rc != HIOPAMD_OK) return rc;
   }
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
   HIOPAMD_CHECK(hipGetLastError());
   int h[4];
   HIOPAMD_CHECK(hipMemcpyAsync(h, d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   HIOPAMD_CHECK(hipStreamSynchronize(st));
-  if(calibrate)
-    ctx_aux_report(ctx, aux_idx, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   if(timed) prof->collect();
   if(inertia3_host) {
     inertia3_host[0] = h[1];
