@@ -503,11 +503,28 @@ __global__ __launch_bounds__(kBlock) void ldlt_pack_diag_kernel(const double* __
 }
 
 // factored block (U strictly upper, D on the diagonal) back into the matrix
+// (and the transpose of its strictly upper part into CT, zero elsewhere: the backward solve reads columns of U)
 __global__ __launch_bounds__(kBlock) void ldlt_unpack_diag_kernel(const double* __restrict__ C, double* __restrict__ A,
-                                                                  int64_t lda, int K0, int kbs)
+                                                                  int64_t lda, int K0, int kbs, double* __restrict__ CT)
 {
-  const int r = blockIdx.x, c = threadIdx.x;
-  if(r < kbs && c < kbs && c >= r) A[(int64_t)(K0 + r) * lda + (K0 + c)] = C[r * LD_NB + c];
+  __shared__ double tile[32][33];
+  // 8 x 8 tiles of 32 x 32: blockIdx.x = tile id, 256 threads = 32 x 8
+  const int tr = blockIdx.x >> 3, tc = blockIdx.x & 7;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for(int k = 0; k < 4; ++k) {
+    const int r = 32 * tr + ty + 8 * k, c = 32 * tc + tx;
+    const bool in = (r < kbs && c < kbs && c >= r);
+    const double v = in ? C[r * LD_NB + c] : 0.0;
+    if(in) A[(int64_t)(K0 + r) * lda + (K0 + c)] = v;
+    tile[ty + 8 * k][tx] = (c > r) ? v : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for(int k = 0; k < 4; ++k) {
+    const int c = 32 * tc + ty + 8 * k, r = 32 * tr + tx;   // CT[c][r] = U[r][c]
+    CT[c * LD_NB + r] = tile[tx][ty + 8 * k];
+  }
 }
 
 // one workgroup: LDL^T of the kbs x kbs (<= 256) diagonal block of a super-panel, panel after panel (left-looking):
@@ -1006,6 +1023,254 @@ __global__ __launch_bounds__(kBlock) void ldlt_bwd_step(const double* __restrict
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 256-row solve steps.  A dependent kernel launch costs ~6.7 us on this machine whatever the kernel does
+// (scripts/probes/hop_probe.hip), so the 64-row steps above (254 launches per solve) are launch-bound; these do the
+// same work in 64 launches.  One launch = apply the solved block I to the rest of the right-hand side (every
+// workgroup: 256 columns/rows) + LOOK-AHEAD solve of the next 256 x 256 diagonal block in workgroup 0, which reads the
+// block from its compact copy (forward: Cd, row-major U; backward: CdT, its transpose), both contiguous 512 KB.
+// Inside the block: four 64 x 64 unit-triangular chains (LDS-resident, waves 0/1 alternate) and the six 64 x 64
+// off-diagonal products between them (register-resident, one per wave 2..7, loaded at kernel entry).
+// ------------------------------------------------------------------------------------------
+constexpr int SV_B = 256;
+constexpr int SV_T = 512;   // threads per workgroup
+
+// wave -> off-diagonal pair (p, q), p < q, of the 4 x 4 block grid: waves 2..7
+__device__ __forceinline__ void sv_pair_of_wave(int w, int& p, int& q)
+{
+  p = (w <= 4) ? 0 : ((w <= 6) ? 1 : 2);
+  q = (w == 2) ? 1 : (w == 3) ? 2 : (w == 4) ? 3 : (w == 5) ? 2 : 3;
+}
+
+// forward: workgroup g owns columns [j0 + 256 g, +256), j0 = i0 + 256 (block I = [i0, i0 + 256) is solved, always
+// full); i0 < 0: first launch, only the diagonal solve of block 0.
+__global__ __launch_bounds__(SV_T) void ldlt_fwd_step256(const double* __restrict__ A, int64_t lda, int N, int i0,
+                                                         const double* __restrict__ Cd, double* __restrict__ b,
+                                                         double* __restrict__ y)
+{
+  __shared__ double Sd[4][LD_nb][LD_nb + 1];
+  __shared__ double ysh[SV_B];
+  __shared__ double bs[SV_B];
+  __shared__ double part[2][SV_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row pointers below stay in SGPRs
+  const int cgp = w & 3, rh = w >> 2;
+  const bool spine = (blockIdx.x == 0);
+  const int j0 = (i0 < 0) ? 0 : i0 + SV_B;
+  const int jb = (N - j0 < SV_B) ? (N - j0) : SV_B;
+  const int cl = 64 * cgp + lane;   // column inside the workgroup's 256
+  const int64_t col = (int64_t)j0 + (int64_t)SV_B * blockIdx.x + cl;
+  const bool col_ok = col < N;
+  const int64_t colc = col_ok ? col : (int64_t)(N - 1);
+  const double bold = (rh == 0 && col_ok) ? b[col] : 0.0;
+  // Load schedule (everything below is latency-bound: keep as many independent loads in flight as registers allow):
+  //   Cd diagonal blocks (spine, 32/thread) + rows 0..63 of this wave's half (64/lane)  ->  consume, then rows 64..127
+  //   ->  stage the diagonal blocks in LDS, then this wave's off-diagonal block (64/lane, needed after the first chain)
+  const double* Cj = Cd + (int64_t)(j0 / SV_B) * (SV_B * SV_B);
+  double m[LD_nb];
+  int pp = 0, pq = 0;
+  double sv[32];
+  if(spine) {
+#pragma unroll
+    for(int k = 0; k < 32; ++k) {
+      const int e = tid + k * SV_T;
+      const int q = e >> 12, s2 = (e >> 6) & 63, r = e & 63;
+      sv[k] = Cj[(64 * q + s2) * SV_B + 64 * q + r];
+    }
+  }
+  double acc = 0.0;
+  if(i0 >= 0) {
+    const double* Ar = A + (int64_t)(i0 + 128 * rh) * lda;   // uniform
+    const int co = (int)colc;
+    if(tid < SV_B) ysh[tid] = y[i0 + tid];
+#pragma unroll 1
+    for(int sb = 0; sb < 128; sb += 64) {   // 64 independent loads per lane in flight, twice
+      double av[64];
+#pragma unroll
+      for(int q = 0; q < 64; ++q) av[q] = (Ar + (int64_t)(sb + q) * lda)[co];
+      if(sb == 0) __syncthreads();   // ysh
+#pragma unroll
+      for(int q = 0; q < 64; ++q) acc = fma(av[q], ysh[128 * rh + sb + q], acc);
+    }
+    if(spine) {
+#pragma unroll
+      for(int k = 0; k < 32; ++k) {
+        const int e = tid + k * SV_T;
+        const int q = e >> 12, s2 = (e >> 6) & 63, r = e & 63;
+        asm volatile("" : "+v"(sv[k]));
+        Sd[q][s2][r] = (s2 < r && 64 * q + r < jb) ? sv[k] : 0.0;
+      }
+    }
+  } else if(spine) {
+#pragma unroll
+    for(int k = 0; k < 32; ++k) {
+      const int e = tid + k * SV_T;
+      const int q = e >> 12, s2 = (e >> 6) & 63, r = e & 63;
+      asm volatile("" : "+v"(sv[k]));
+      Sd[q][s2][r] = (s2 < r && 64 * q + r < jb) ? sv[k] : 0.0;
+    }
+  }
+  if(spine && w >= 2) {
+    // this wave's off-diagonal block: its 64 loads must not be hoisted above the batches (they would not fit in the
+    // register file next to them) -> make their address depend on the accumulated value
+    int dep = 0;
+    asm volatile("" : "+v"(dep) : "v"(acc));
+    sv_pair_of_wave(w, pp, pq);
+    const double* Cm = Cj + (64 * pp) * SV_B + 64 * pq + lane + dep;
+#pragma unroll
+    for(int s2 = 0; s2 < LD_nb; ++s2) m[s2] = Cm[s2 * SV_B];
+  }
+  part[rh][cl] = acc;
+  __syncthreads();
+  if(rh == 0) {
+    const double nb = bold - part[0][cl] - part[1][cl];
+    if(spine)
+      bs[cl] = (cl < jb) ? nb : 0.0;
+    else if(col_ok)
+      b[col] = nb;
+  }
+  if(!spine) return;
+  __syncthreads();
+  // ---- diagonal block J: y_q = L_qq^-1 (b_q - sum_{p<q} L_qp y_p),  L = U^T
+#pragma unroll
+  for(int q = 0; q < 4; ++q) {
+    if(w == (q & 1)) {
+      double v = bs[64 * q + lane];
+#pragma unroll
+      for(int sb = 0; sb < LD_nb; sb += 16) {   // 16 LDS reads in flight at a time (the whole 64 would not fit next to m[])
+        double u[16];
+#pragma unroll
+        for(int s2 = 0; s2 < 16; ++s2) u[s2] = Sd[q][sb + s2][lane];
+#pragma unroll
+        for(int s2 = 0; s2 < 16; ++s2) {
+          const double ys = bcast_lane(v, sb + s2);
+          v = fma(-u[s2], ys, v);
+        }
+      }
+      ysh[64 * q + lane] = v;
+    }
+    __syncthreads();
+    if(q < 3 && w >= 2 && pp == q) {
+      double c = 0.0;
+#pragma unroll
+      for(int s2 = 0; s2 < LD_nb; ++s2) {   // the last block may be ragged: nothing outside jb x jb is defined
+        asm volatile("" : "+v"(m[s2]));
+        const double mv = (64 * pp + s2 < jb) ? m[s2] : 0.0;
+        c = fma(mv, ysh[64 * q + s2], c);
+      }
+      if(64 * pq + lane < jb) bs[64 * pq + lane] -= c;
+    }
+    __syncthreads();
+  }
+  if(tid < jb) y[j0 + tid] = ysh[tid];
+}
+
+// backward: block I = [i0, i0 + ib) is solved (x); rows above it: z[h] -= U[h][I] . x_I.  Workgroup g owns the 256
+// rows [p0 - 256 g, +256), p0 = i0 - 256; workgroup 0 also solves block P = [p0, i0) from CdT.  first != 0: only the
+// diagonal solve of the LAST (possibly ragged) block [i0, i0 + ib).
+__global__ __launch_bounds__(SV_T) void ldlt_bwd_step256(const double* __restrict__ A, int64_t lda, int i0, int ib,
+                                                         const double* __restrict__ CdT, double* __restrict__ z,
+                                                         double* __restrict__ x, int first)
+{
+  __shared__ double Sd[4][LD_nb][LD_nb + 1];
+  __shared__ double xsh[SV_B];
+  __shared__ double zs[SV_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+  const bool spine = (blockIdx.x == 0);
+  const int p0 = first ? i0 : i0 - SV_B;          // block solved by the spine
+  const int pb = first ? ib : SV_B;
+  const double* Ct = CdT + (int64_t)(p0 / SV_B) * (SV_B * SV_B);
+  double m[LD_nb];
+  int pp = 0, pq = 0;   // pair (pp, pq), pp < pq: contribution of x_pq to z_pp
+  double sv[32];
+  if(spine) {
+#pragma unroll
+    for(int k = 0; k < 32; ++k) {
+      const int e = tid + k * SV_T;
+      const int q = e >> 12, c = (e >> 6) & 63, r = e & 63;
+      sv[k] = Ct[(64 * q + c) * SV_B + 64 * q + r];   // U[64q + r][64q + c]
+    }
+  }
+  if(!first) {
+    if(tid < SV_B) xsh[tid] = (tid < ib) ? x[i0 + tid] : 0.0;
+    __syncthreads();
+    // 16 lanes per row, 4 rows per wave pass, 8 passes: wave w owns rows 32 w .. 32 w + 31 of the workgroup's 256
+    const int rr = lane >> 4, pt = lane & 15;
+    const int64_t hbase = (int64_t)p0 - (int64_t)SV_B * blockIdx.x + 32 * w;
+#pragma unroll 1
+    for(int ps = 0; ps < 8; ++ps) {
+      // (more passes in flight did not help: the round trips are TLB-miss bound — 4 rows per pass, 64 KB apart —
+      //  and the extra registers spilled)
+      const int64_t h = hbase + 4 * ps + rr;
+      const int64_t hc = (h >= 0) ? h : 0;
+      const double* Ah = A + hc * lda + i0 + pt;
+      double av[16];
+#pragma unroll
+      for(int k = 0; k < 16; ++k) av[k] = Ah[(16 * k + pt < ib) ? 16 * k : 0];
+      double acc = 0.0;
+#pragma unroll
+      for(int k = 0; k < 16; ++k) acc = fma(av[k], xsh[16 * k + pt], acc);   // xsh is 0 beyond ib
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      acc += __shfl_xor(acc, 8, 64);
+      if(pt == 0 && h >= 0) {
+        const double zn = z[h] - acc;
+        if(spine)
+          zs[32 * w + 4 * ps + rr] = zn;
+        else
+          z[h] = zn;
+      }
+    }
+  } else {
+    if(tid < SV_B) zs[tid] = (tid < ib) ? z[i0 + tid] : 0.0;
+  }
+  if(!spine) return;
+  {
+#pragma unroll
+    for(int k = 0; k < 32; ++k) {
+      const int e = tid + k * SV_T;
+      const int q = e >> 12, c = (e >> 6) & 63, r = e & 63;
+      asm volatile("" : "+v"(sv[k]));
+      Sd[q][c][r] = (c > r && 64 * q + c < pb) ? sv[k] : 0.0;
+    }
+    if(w >= 2) {
+      int dep = 0;
+      asm volatile("" : "+v"(dep) : "v"(sv[31]));   // after the staging above (register pressure)
+      sv_pair_of_wave(w, pp, pq);
+      const double* Cm = Ct + (64 * pq) * SV_B + 64 * pp + lane + dep;
+#pragma unroll
+      for(int c = 0; c < LD_nb; ++c) m[c] = Cm[c * SV_B];   // U[64pp + lane][64pq + c]
+    }
+  }
+  __syncthreads();
+  // ---- diagonal block P: x_q = U_qq^-1 (z_q - sum_{p>q} U_qp x_p)
+#pragma unroll
+  for(int qi = 0; qi < 4; ++qi) {
+    const int q = 3 - qi;
+    if(w == (q & 1)) {
+      double v = zs[64 * q + lane];
+#pragma unroll
+      for(int c = LD_nb - 1; c >= 0; --c) {
+        const double xc = bcast_lane(v, c);
+        v = fma(-Sd[q][c][lane], xc, v);   // 0 unless c > lane
+      }
+      xsh[64 * q + lane] = v;
+    }
+    __syncthreads();
+    if(q > 0 && w >= 2 && pq == q) {
+      double c2 = 0.0;
+#pragma unroll
+      for(int c = 0; c < LD_nb; ++c) c2 = fma(m[c], xsh[64 * q + c], c2);
+      zs[64 * pp + lane] -= c2;
+    }
+    __syncthreads();
+  }
+  if(tid < pb) x[p0 + tid] = xsh[tid];
+}
+
 }  // namespace hiopamd
 
 using namespace hiopamd;
@@ -1119,6 +1384,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   // cross-stream dependency costs ~15 us on this machine, so none sits between the chain's own kernels.  V is
   // double-buffered (row panel j+1 is written while upd_rest(j) reads row panel j).
   const int nsp = (N + LD_NB - 1) / LD_NB;
+  const int64_t cdt_ofs = (int64_t)nsp * (LD_NB * LD_NB);   // the transposed compact blocks follow the compact blocks
   static int la_mode = -1;   // HIOPAMD_LA_MODE=0 switches the look-ahead off (debug / A-B timing)
   if(la_mode < 0) la_mode = std::getenv("HIOPAMD_LA_MODE") ? std::atoi(std::getenv("HIOPAMD_LA_MODE")) : 1;
   const bool lookahead = nsp > 2 && la_mode > 0 && ctx_cu_split(ctx);
@@ -1187,7 +1453,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     const Panel p0 = panel(0);
     hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, A, lda, p0.K0, p0.kbs, p0.Cj);
     superdiag(0, st);
-    hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, p0.Cj, A, lda, p0.K0, p0.kbs);
+    hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(64), dim3(kBlock), 0, st, p0.Cj, A, lda, p0.K0, p0.kbs, p0.Cj + cdt_ofs);
   }
   if(lookahead) {
     int rc = dep(st, su);
@@ -1219,7 +1485,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     }
     {
       const Panel pn = panel(jp + 1);
-      hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, sd, pn.Cj, A, lda, pn.K0, pn.kbs);
+      hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(64), dim3(kBlock), 0, sd, pn.Cj, A, lda, pn.K0, pn.kbs, pn.Cj + cdt_ofs);
     }
     // ---- wide stream: (superdiag(jp) is already waited for: fork for jp = 0, ev_diag of the previous iteration below)
     trsm(jp, su, head, N - sa_end);
@@ -1256,12 +1522,36 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
 }
 
 static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda, const double* dinv, double* ybuf,
-                           double* rhs, int nrhs)
+                           double* rhs, int nrhs, const double* Cd = nullptr)
 {
   if(N < 0 || nrhs < 0) return HIOPAMD_ERR_ARG;
   if(N == 0) return HIOPAMD_OK;
   hipStream_t st = ctx->stream;
   const int nblk = (N + LD_nb - 1) / LD_nb;
+  if(Cd) {   // 256-row steps on the compact diagonal blocks (the factorisation object keeps them)
+    const int nsp = (N + SV_B - 1) / SV_B;
+    const double* CdT = Cd + (int64_t)nsp * (SV_B * SV_B);
+    for(int j = 0; j < nrhs; ++j) {
+      double* b = rhs + (int64_t)j * N;
+      hipLaunchKernelGGL(ldlt_fwd_step256, dim3(1), dim3(SV_T), 0, st, A, lda, N, -1, Cd, b, ybuf);
+      for(int I = 0; I + 1 < nsp; ++I) {
+        const int i0 = I * SV_B;
+        const int g = (N - i0 - SV_B + SV_B - 1) / SV_B;
+        hipLaunchKernelGGL(ldlt_fwd_step256, dim3(g), dim3(SV_T), 0, st, A, lda, N, i0, Cd, b, ybuf);
+      }
+      int rc = hiopamd_vec_component_mult(ctx, N, ybuf, dinv);
+      if(rc != HIOPAMD_OK) return rc;
+      const int iL = (nsp - 1) * SV_B;
+      hipLaunchKernelGGL(ldlt_bwd_step256, dim3(1), dim3(SV_T), 0, st, A, lda, iL, N - iL, CdT, ybuf, b, 1);
+      for(int I = nsp - 1; I >= 1; --I) {
+        const int i0 = I * SV_B;
+        const int ib = (i0 + SV_B <= N) ? SV_B : (N - i0);
+        hipLaunchKernelGGL(ldlt_bwd_step256, dim3(I), dim3(SV_T), 0, st, A, lda, i0, ib, CdT, ybuf, b, 0);
+      }
+    }
+    HIOPAMD_CHECK(hipGetLastError());
+    return HIOPAMD_OK;
+  }
   for(int j = 0; j < nrhs; ++j) {
     double* b = rhs + (int64_t)j * N;
     // forward: U^T y = b
@@ -1300,7 +1590,7 @@ int hiopamd_ldlt_factor(hiopamd_ctx* ctx, int n, double* A, int64_t lda, double*
   const size_t nn = (size_t)(n > 0 ? n : 1);
   const size_t vbytes = sizeof(double) * (size_t)LD_NB * nn * 2;
   const size_t dbytes = sizeof(double) * (size_t)(LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb);
-  const size_t cbytes = sizeof(double) * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB);
+  const size_t cbytes = sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB);
   char* w = (char*)ctx_workspace(ctx, vbytes + dbytes + cbytes + 64);
   return ldlt_factor_impl(ctx, n, A, lda, work_dinv, (double*)w, (double*)(w + vbytes), (double*)(w + vbytes + dbytes),
                           (int*)(w + vbytes + dbytes + cbytes), inertia3_host);
@@ -1325,7 +1615,7 @@ int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
   HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB * 2));   // double-buffered row panel
   HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb)));
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB)));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB)));   // blocks + transposes
   HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
   HIOPAMD_CHECK(hipMemsetAsync(ls->M, 0, sizeof(double) * nn * nn, ctx->stream));
   *out = ls;
@@ -1370,7 +1660,7 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs)
 {
   if(!ls || !rhs_inout) return HIOPAMD_ERR_ARG;
   if(!ls->factored) return HIOPAMD_ERR_STATE;
-  return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs);
+  return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd);
 }
 
 int hiopamd_linsolver_profile(hiopamd_linsolver* ls, int enable)
