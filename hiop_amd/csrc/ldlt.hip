@@ -796,6 +796,94 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
   }
 }
 
+// 64 x 64-tile variant for the 256 x 256 diagonal block of the NEXT super-panel (the only update on the serial chain):
+// 10 workgroups instead of 3, each with a quarter of the MFMA work, on the reserved CUs.  Same operand layout as above;
+// each wave owns a 32 x 32 quadrant = 2 x 2 MFMA tiles.  Writes the matrix and the block's compact copy.
+__global__ __launch_bounds__(kBlock) void ldlt_update_diag_kernel(double* __restrict__ A, int64_t lda, int N,
+                                                                  const double* __restrict__ V, int64_t ldv, int urow0,
+                                                                  int K, int s, int row_end, double* __restrict__ Cnext)
+{
+  constexpr int TS = 64, LDQ = TS + 16;
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if(tj < ti) return;
+  const int r0 = s + ti * TS, c0 = s + tj * TS;
+  if(r0 >= row_end || c0 >= row_end) return;
+  __shared__ double Vs[LD_KT][LDQ];
+  __shared__ double Us[LD_KT][LDQ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lk = lane >> 4, li = lane & 15;
+  double4_t acc[2][2];
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int lcol = tid & 63, lrow = tid >> 6;   // 4 k-rows per pass, 4 passes per 16-deep stage
+  const int vcol = (r0 + lcol < N) ? (r0 + lcol) : (N - 1);
+  const int ucol = (c0 + lcol < N) ? (c0 + lcol) : (N - 1);
+  const double* Vp = V + (int64_t)lrow * ldv + vcol;
+  const double* Up = A + (int64_t)(urow0 + lrow) * lda + ucol;
+  double vreg[4], ureg[4];
+#pragma unroll
+  for(int q = 0; q < 4; ++q) {
+    vreg[q] = Vp[(int64_t)(4 * q) * ldv];
+    ureg[q] = Up[(int64_t)(4 * q) * lda];
+  }
+  for(int kt = 0; kt < K; kt += LD_KT) {
+    __syncthreads();
+#pragma unroll
+    for(int q = 0; q < 4; ++q) {
+      Vs[4 * q + lrow][lcol] = vreg[q];
+      Us[4 * q + lrow][lcol] = ureg[q];
+    }
+    __syncthreads();
+    if(kt + LD_KT < K) {
+#pragma unroll
+      for(int q = 0; q < 4; ++q) {
+        vreg[q] = Vp[(int64_t)(kt + LD_KT + 4 * q) * ldv];
+        ureg[q] = Up[(int64_t)(kt + LD_KT + 4 * q) * lda];
+      }
+    }
+#pragma unroll
+    for(int kk = 0; kk < LD_KT / 4; ++kk) {
+      double a[2], b[2];
+#pragma unroll
+      for(int i = 0; i < 2; ++i) a[i] = Vs[kk * 4 + lk][wr * 32 + i * 16 + li];
+#pragma unroll
+      for(int j = 0; j < 2; ++j) b[j] = Us[kk * 4 + lk][wc * 32 + j * 16 + li];
+#pragma unroll
+      for(int i = 0; i < 2; ++i)
+#pragma unroll
+        for(int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  double cv[2][2][4];
+  bool ok[2][2][4];
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int j = 0; j < 2; ++j)
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg) {
+        const int row = r0 + wr * 32 + i * 16 + lk + 4 * reg, col = c0 + wc * 32 + j * 16 + li;
+        ok[i][j][reg] = (row < row_end) && (col < row_end) && (col >= row);
+        cv[i][j][reg] = ok[i][j][reg] ? A[(int64_t)row * lda + col] : 0.0;
+      }
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int j = 0; j < 2; ++j)
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg) {
+        const int row = r0 + wr * 32 + i * 16 + lk + 4 * reg, col = c0 + wc * 32 + j * 16 + li;
+        if(ok[i][j][reg]) {
+          const double nv = cv[i][j][reg] - acc[i][j][reg];
+          A[(int64_t)row * lda + col] = nv;
+          Cnext[(row - s) * LD_NB + (col - s)] = nv;
+        }
+      }
+}
+
 // ------------------------------------------------------------------------------------------
 // inertia from D (thresholds of the reference's LAPACK path, hiopLinSolverSymDenseLapack.hpp:154-161:
 // d < -1e-14 negative, |d| < 1e-14 null, else positive)
@@ -1475,8 +1563,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       ev_head = next_event();
       HIOPAMD_CHECK(hipEventRecord(ev_head, sd));
     }
-    upd_stream = sd;
-    launch_update(dim3(2, 2), p.Vb, p.K0, p.kbs, s, sa_end, panel(jp + 1).Cj, sa_end, 0);
+    hipLaunchKernelGGL(ldlt_update_diag_kernel, dim3(4, 4), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, p.K0, p.kbs, s, sa_end,
+                       panel(jp + 1).Cj);
     superdiag(jp + 1, sd);
     hipEvent_t ev_diag = nullptr;
     if(lookahead) {
