@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -224,9 +225,21 @@ def main():
     flops_per_launch = ufl.value / launches
     ms_per_launch = ums.value / launches
     achieved = (flops_per_launch / (ms_per_launch * 1e-3)) / 1e12 if ms_per_launch > 0 else 0.0
+    # HBM traffic of that kernel: from the committed PMC passes (scripts/gpu_pmc.sh -> profiles/<round>_pmc/summary.json);
+    # bench.py cannot collect hardware counters itself, so this field is a measured constant of the same binary/workload
+    traffic, traffic_src = None, None
+    for cand in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc", "summary.json"))):
+        try:
+            with open(cand) as f:
+                u = json.load(f).get("ldlt_update_kernel", {})
+            if "hbm_bytes_per_launch" in u:
+                traffic, traffic_src = u["hbm_bytes_per_launch"], os.path.relpath(cand, os.path.dirname(os.path.abspath(__file__)))
+        except Exception:
+            pass
     roofline = dict(bound="mfma", kernel="ldlt_update_kernel (rank-K trailing update, v_mfma_f64_16x16x4_f64)",
                     achieved=achieved, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
-                    traffic=None, launches_per_step=launches / a.steps, avg_launch_ms=ms_per_launch,
+                    traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
+                    launches_per_step=launches / a.steps, avg_launch_ms=ms_per_launch,
                     algorithmic_flops_per_launch=flops_per_launch,
                     update_ms_per_step=ums.value / a.steps)
 

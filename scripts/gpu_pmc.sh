@@ -14,14 +14,36 @@ run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
 run wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_F64
 find gpurun_out/pmc -name "*.csv" | head -20
 python3 - <<'PY'
-import csv, glob, collections
-for d in ["fetch","write","mfma","wait"]:
+# per-kernel aggregation of each pass + the per-launch HBM traffic of the dominant kernel
+# (MI355X_MICROARCH.md HBM section: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports by 2x on gfx950)
+import csv, glob, collections, json
+summary = {}
+for d in ["fetch", "write", "mfma", "wait"]:
     fs = glob.glob(f"gpurun_out/pmc/{d}/**/*counter_collection.csv", recursive=True)
-    if not fs: print(d, "no csv"); continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    if not fs:
+        print(d, "no csv"); continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
     for row in csv.DictReader(open(fs[0])):
-        k = row.get("Kernel_Name","?")[:50]
-        agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
-    for k in sorted(agg, key=lambda k: -sum(agg[k].values()))[:8]:
-        print(d, k, dict(agg[k]))
+        k = row.get("Kernel_Name", "?")
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        disp[k].add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+    names = sorted({c for k in agg for c in agg[k]})
+    with open(f"gpurun_out/pmc/{d}_by_kernel.csv", "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["Kernel_Name", "Dispatches"] + names)
+        for k in sorted(agg, key=lambda k: -sum(agg[k].values())):
+            w.writerow([k, len(disp[k])] + [agg[k].get(c, 0.0) for c in names])
+    for k in agg:
+        if "ldlt_update_kernel" in k:
+            summary.setdefault("ldlt_update_kernel", {})["dispatches_" + d] = len(disp[k])
+            for c in names:
+                summary["ldlt_update_kernel"][c] = agg[k].get(c, 0.0)
+    for k in sorted(agg, key=lambda k: -sum(agg[k].values()))[:6]:
+        print(d, k[:60], len(disp[k]), dict(agg[k]))
+u = summary.get("ldlt_update_kernel")
+if u and "FETCH_SIZE" in u and "WRITE_SIZE" in u:
+    n = u["dispatches_fetch"]
+    u["hbm_bytes_per_launch"] = (2.0 * u["FETCH_SIZE"] * 1024.0 / n) + (u["WRITE_SIZE"] * 1024.0 / u["dispatches_write"])
+    u["note"] = "FETCH_SIZE[KB]*1024*2 (gfx950 correction) + WRITE_SIZE[KB]*1024, per launch; separate --pmc passes, kernel-trace only"
+json.dump(summary, open("gpurun_out/pmc/summary.json", "w"), indent=1)
+print(json.dumps(summary, indent=1))
 PY
