@@ -246,6 +246,7 @@ struct hiopamd_kkt_xycyd {
   int64_t dim = 0;
   const double *ixl = nullptr, *ixu = nullptr, *idl = nullptr, *idu = nullptr;   // borrowed, device
   const double* iter = nullptr;                                                   // borrowed, device slab
+  const double *xl = nullptr, *xu = nullptr, *dl = nullptr, *du = nullptr, *crhs = nullptr;   // borrowed (set_bounds)
   hiopamd_kkt_mds* mds = nullptr;
   hiopamd_kkt_lowrank* lr = nullptr;
   // dense backend (hiopKKTLinSysDenseXYcYd) and the Jacobians of the low-rank backend
@@ -1134,5 +1135,376 @@ int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double
 hiopamd_linsolver* hiopamd_kkt_xycyd_linsolver(hiopamd_kkt_xycyd* h) { return h ? h->ls : nullptr; }
 double* hiopamd_kkt_xycyd_Dx(hiopamd_kkt_xycyd* h) { return h ? h->Dx : nullptr; }
 double* hiopamd_kkt_xycyd_Dd(hiopamd_kkt_xycyd* h) { return h ? h->Dd : nullptr; }
+
+}  // extern "C"
+
+// =========================================================================================================
+// hiopIterate / hiopResidual on the 12-part slabs: the steps either side of the KKT solve
+//   hiopResidual::update                       src/Optimization/hiopResidual.cpp:154-365
+//   hiopIterate::fractionToTheBdry             src/Optimization/hiopIterate.cpp:330-362
+//   hiopIterate::takeStep_primals / _duals     :367-390
+//   hiopIterate::determineSlacks / compute_safe_slacks / adjust_small_slacks   :274-312, :414-505
+//   hiopIterate::determineDualsBounds_d        :314-327
+//   hiopIterate::adjustDuals_primalLogHessian  :507-521
+//   hiopIterate::evalLogBarrier / linearDampingTerm   :523-566
+// =========================================================================================================
+namespace {
+
+// four running values, max for components [0, nmax), sum for the rest
+struct red4_t {
+  double v[4];
+};
+template <class Map>
+struct OpRed4 {
+  Map m;
+  int nmax;
+  __device__ red4_t identity() const { return red4_t{{0.0, 0.0, 0.0, 0.0}}; }
+  __device__ red4_t map(int64_t i) const { return m(i); }
+  __device__ red4_t combine(red4_t p, red4_t q) const
+  {
+    red4_t r;
+#pragma unroll
+    for(int c = 0; c < 4; ++c) r.v[c] = (c < nmax) ? (p.v[c] > q.v[c] ? p.v[c] : q.v[c]) : (p.v[c] + q.v[c]);
+    return r;
+  }
+};
+template <class Map>
+int reduce4(hiopamd_ctx* ctx, int64_t n, Map m, int nmax, red4_t* out)
+{
+  *out = red4_t{{0.0, 0.0, 0.0, 0.0}};
+  if(n <= 0) return HIOPAMD_OK;
+  return launch_reduce<red4_t>(ctx, n, OpRed4<Map>{m, nmax}, out);
+}
+
+// all-reduce of the x-part contributions on a column partition (low-rank back-end with a hook): max then sum parts
+int xpart_allreduce(hiopamd_kkt_xycyd* h, red4_t* r, int nmax)
+{
+  hiopamd_ctx* ctx = h->ctx;
+  if(!(h->kind == KIND_LOWRANK && ctx->allreduce)) return HIOPAMD_OK;
+  HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, r->v, 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+  if(nmax > 0 && ctx->allreduce(ctx->allreduce_user, h->dsmall, (size_t)nmax, HIOPAMD_MAX, (void*)ctx->stream) != 0)
+    return HIOPAMD_ERR_HIP;
+  if(nmax < 4 && ctx->allreduce(ctx->allreduce_user, h->dsmall + nmax, (size_t)(4 - nmax), HIOPAMD_SUM, (void*)ctx->stream) != 0)
+    return HIOPAMD_ERR_HIP;
+  HIOPAMD_CHECK(hipMemcpyAsync(r->v, h->dsmall, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+  return HIOPAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hiopamd_kkt_xycyd_set_bounds(hiopamd_kkt_xycyd* h, const double* xl, const double* xu, const double* dl,
+                                 const double* du, const double* crhs)
+{
+  if(!h) return HIOPAMD_ERR_ARG;
+  h->xl = xl;
+  h->xu = xu;
+  h->dl = dl;
+  h->du = du;
+  h->crhs = crhs;
+  return HIOPAMD_OK;
+}
+
+// hiopResidual::update.  c, d: constraint bodies at x (device, nyc / nyd); grad_f (nx).  norms11_host =
+//   [nrmInf_nlp_optim, nrmInf_nlp_feasib, nrmInf_nlp_complem, nrmInf_bar_optim, nrmInf_bar_feasib, nrmInf_bar_complem,
+//    nrmOne_nlp_feasib, nrmOne_bar_feasib, nrmOne_nlp_optim, nrmOne_bar_optim, nrmInf_cons_violation]
+int hiopamd_residual_update(hiopamd_kkt_xycyd* h, const double* it, const double* c, const double* d, const double* grad_f,
+                            double mu, double kappa_d, double* resid, double* norms11_host)
+{
+  if(!h || !it || !grad_f || !resid || !norms11_host) return HIOPAMD_ERR_ARG;
+  if((h->nx > 0 && (!h->xl || !h->xu)) || (h->nd > 0 && (!h->dl || !h->du || !d)) || (h->nyc > 0 && (!h->crhs || !c)))
+    return HIOPAMD_ERR_STATE;
+  hiopamd_ctx* ctx = h->ctx;
+  const int64_t* o = h->off;
+  const int64_t nx = h->nx, nd = h->nd, nyc = h->nyc;
+  const double *x = it + o[0], *dit = it + o[1], *yc = it + o[2], *yd = it + o[3], *sxl = it + o[4], *sxu = it + o[5],
+               *sdl = it + o[6], *sdu = it + o[7], *zl = it + o[8], *zu = it + o[9], *vl = it + o[10], *vu = it + o[11];
+  double *rx = resid + o[0], *rd = resid + o[1], *ryc = resid + o[2], *ryd = resid + o[3], *rxl = resid + o[4],
+         *rxu = resid + o[5], *rdl = resid + o[6], *rdu = resid + o[7], *rszl = resid + o[8], *rszu = resid + o[9],
+         *rsvl = resid + o[10], *rsvu = resid + o[11];
+  const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu;
+  const double *xl = h->xl, *xu = h->xu, *dl = h->dl, *du = h->du, *crhs = h->crhs;
+  // rx = grad_f + Jc^T yc + Jd^T yd   (the back-end's matrices: those of the last update / set_values)   :181-184
+  RC(hiopamd_vec_copy(ctx, nx, rx, grad_f));
+  RC(backend_jac_trans_times_vec_add(h, rx, yc, yd));
+  const double ctx_damp = (kappa_d > 0.0) ? kappa_d * mu : 0.0;   // addNonLogBarTermsToGrad_* (hiopLogBarProblem.hpp:135-145)
+  // x-sized parts: one pass; returns {inf(rx_nlp), inf(rx_bar), one(rx_nlp), one(rx_bar)} and later the complementarity maxima
+  red4_t ox, cx;
+  RC(reduce4(ctx, nx,
+             [=] __device__(int64_t i) {
+               const double pre = rx[i] - zl[i] + zu[i];                          // :185-186
+               const double bar = -(pre + (ixl[i] - ixu[i]) * ctx_damp);          // :195-196
+               rx[i] = bar;
+               rxl[i] = ixl[i] == 0.0 ? 0.0 : x[i] - sxl[i] - xl[i];              // :236-243
+               rxu[i] = ixu[i] == 0.0 ? 0.0 : xu[i] - x[i] - sxu[i];              // :248-254
+               const double cl = ixl[i] == 0.0 ? 0.0 : -sxl[i] * zl[i];           // :287-292
+               const double cu = ixu[i] == 0.0 ? 0.0 : -sxu[i] * zu[i];           // :302-307
+               rszl[i] = ixl[i] == 1.0 ? cl + mu : cl;                            // :295
+               rszu[i] = ixu[i] == 1.0 ? cu + mu : cu;                            // :311
+               return red4_t{{fabs(pre), fabs(bar), fabs(pre), fabs(bar)}};
+             },
+             2, &ox));
+  RC(reduce4(ctx, nx,
+             [=] __device__(int64_t i) {
+               const double cl = ixl[i] == 0.0 ? 0.0 : -sxl[i] * zl[i];
+               const double cu = ixu[i] == 0.0 ? 0.0 : -sxu[i] * zu[i];
+               return red4_t{{fmax(fabs(cl), fabs(cu)), fmax(fabs(rszl[i]), fabs(rszu[i])), 0.0, 0.0}};
+             },
+             2, &cx));
+  RC(xpart_allreduce(h, &ox, 2));
+  RC(xpart_allreduce(h, &cx, 2));
+  // d-sized parts (replicated)
+  red4_t od, fd, cd;
+  RC(reduce4(ctx, nd,
+             [=] __device__(int64_t i) {
+               const double pre = yd[i] + vl[i] - vu[i];                          // :203-205
+               const double bar = pre + (idl[i] - idu[i]) * (-ctx_damp);          // :212
+               rd[i] = bar;
+               return red4_t{{fabs(pre), fabs(bar), fabs(pre), fabs(bar)}};
+             },
+             2, &od));
+  RC(reduce4(ctx, nd,
+             [=] __device__(int64_t i) {
+               const double r = dit[i] - d[i];                                    // :229-230
+               ryd[i] = r;
+               rdl[i] = idl[i] == 0.0 ? 0.0 : dit[i] - sdl[i] - dl[i];            // :260-262
+               rdu[i] = idu[i] == 0.0 ? 0.0 : du[i] - sdu[i] - dit[i];            // :268-272
+               // constraint violation of the inequality bodies                    :219-227
+               double viol = 0.0;
+               if(idl[i] == 1.0) viol = fmax(viol, -(d[i] - dl[i]));
+               if(idu[i] == 1.0) viol = fmax(viol, -(du[i] - d[i]));
+               return red4_t{{fabs(r), viol, fabs(r), 0.0}};
+             },
+             2, &fd));
+  RC(reduce4(ctx, nd,
+             [=] __device__(int64_t i) {
+               const double cl = idl[i] == 0.0 ? 0.0 : -sdl[i] * vl[i];           // :317-323
+               const double cu = idu[i] == 0.0 ? 0.0 : -sdu[i] * vu[i];           // :332-338
+               const double bl = idl[i] == 1.0 ? cl + mu : cl;
+               const double bu = idu[i] == 1.0 ? cu + mu : cu;
+               rsvl[i] = bl;
+               rsvu[i] = bu;
+               return red4_t{{fmax(fabs(cl), fabs(cu)), fmax(fabs(bl), fabs(bu)), 0.0, 0.0}};
+             },
+             2, &cd));
+  // equality part
+  red4_t fc;
+  RC(reduce4(ctx, nyc,
+             [=] __device__(int64_t i) {
+               const double r = crhs[i] - c[i];                                   // :214-215
+               ryc[i] = r;
+               return red4_t{{fabs(r), 0.0, fabs(r), 0.0}};
+             },
+             2, &fc));
+  double* n = norms11_host;
+  n[0] = fmax(ox.v[0], od.v[0]);                 // nrmInf_nlp_optim
+  n[8] = ox.v[2] + od.v[2];                      // nrmOne_nlp_optim
+  n[3] = fmax(ox.v[1], od.v[1]);                 // nrmInf_bar_optim
+  n[9] = ox.v[3] + od.v[3];                      // nrmOne_bar_optim
+  n[1] = fmax(fc.v[0], fd.v[0]);                 // nrmInf_nlp_feasib
+  n[6] = fc.v[2] + fd.v[2];                      // nrmOne_nlp_feasib
+  n[4] = n[1];                                   // nrmInf_bar_feasib  (:279)
+  n[7] = n[6];                                   // nrmOne_bar_feasib  (:280)
+  n[10] = fmax(fc.v[0], fd.v[1]);                // nrmInf_cons_violation (:218-227)
+  n[2] = fmax(cx.v[0], cd.v[0]);                 // nrmInf_nlp_complem
+  n[5] = fmax(cx.v[1], cd.v[1]);                 // nrmInf_bar_complem
+  return HIOPAMD_OK;
+}
+
+// hiopIterate::fractionToTheBdry: one reduction over the 8 slack/dual parts (x-sized ones all-reduced with MIN)
+int hiopamd_iterate_fraction_to_the_bdry(hiopamd_kkt_xycyd* h, const double* it, const double* dir, double tau,
+                                         double* alpha_primal_host, double* alpha_dual_host)
+{
+  if(!h || !it || !dir || !alpha_primal_host || !alpha_dual_host) return HIOPAMD_ERR_ARG;
+  hiopamd_ctx* ctx = h->ctx;
+  const int64_t* o = h->off;
+  double ap = 10.0, ad = 10.0;   // :334
+  auto pass = [&](const int (&parts)[4], double* out) -> int {
+    int64_t n4[4];
+    const double *x4[4], *d4[4], *s4[4];
+    const double* pat[12] = {nullptr, nullptr, nullptr, nullptr, h->ixl, h->ixu, h->idl, h->idu, h->ixl, h->ixu, h->idl, h->idu};
+    for(int q = 0; q < 4; ++q) {
+      const int pidx = parts[q];
+      n4[q] = o[pidx + 1] - o[pidx];
+      x4[q] = it + o[pidx];
+      d4[q] = dir + o[pidx];
+      s4[q] = pat[pidx];
+    }
+    double r = 1.0;
+    RC(hiopamd_vec_fraction_to_the_bdry_multi(ctx, 4, n4, x4, d4, s4, tau, &r));
+    *out = r;
+    return HIOPAMD_OK;
+  };
+  double a1 = 1.0, a2 = 1.0;
+  const int prim[4] = {4, 5, 6, 7}, dual[4] = {8, 9, 10, 11};
+  RC(pass(prim, &a1));
+  RC(pass(dual, &a2));
+  ap = std::fmin(ap, a1);
+  ad = std::fmin(ad, a2);
+  if(h->kind == KIND_LOWRANK && ctx->allreduce) {   // MPI_Allreduce(MIN) :355-359  (max of the negatives)
+    double buf[2] = {-ap, -ad};
+    HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, buf, sizeof(buf), hipMemcpyHostToDevice, ctx->stream));
+    HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+    if(ctx->allreduce(ctx->allreduce_user, h->dsmall, 2, HIOPAMD_MAX, (void*)ctx->stream) != 0) return HIOPAMD_ERR_HIP;
+    HIOPAMD_CHECK(hipMemcpyAsync(buf, h->dsmall, sizeof(buf), hipMemcpyDeviceToHost, ctx->stream));
+    HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+    ap = -buf[0];
+    ad = -buf[1];
+  }
+  *alpha_primal_host = ap;
+  *alpha_dual_host = ad;
+  return HIOPAMD_OK;
+}
+
+// takeStep_primals (x, d) and/or takeStep_duals (yc, yd with alpha_primal; zl, zu, vl, vu with alpha_dual)
+int hiopamd_iterate_take_step(hiopamd_kkt_xycyd* h, double* out, const double* it, const double* dir, double alpha_primal,
+                              double alpha_dual, int primals, int duals)
+{
+  if(!h || !out || !it || !dir) return HIOPAMD_ERR_ARG;
+  const int64_t o2 = h->off[2], o4 = h->off[4], o8 = h->off[8], o12 = h->off[12];
+  return launch_ew(h->ctx, o12, [=] __device__(int64_t i) {
+    if(i < o2) {
+      if(primals) out[i] = it[i] + alpha_primal * dir[i];
+    } else if(i < o4) {
+      if(duals) out[i] = it[i] + alpha_primal * dir[i];
+    } else if(i >= o8) {
+      if(duals) out[i] = it[i] + alpha_dual * dir[i];
+    }
+  });
+}
+
+// determineSlacks (:274-291)
+int hiopamd_iterate_determine_slacks(hiopamd_kkt_xycyd* h, double* it)
+{
+  if(!h || !it) return HIOPAMD_ERR_ARG;
+  if((h->nx > 0 && (!h->xl || !h->xu)) || (h->nd > 0 && (!h->dl || !h->du))) return HIOPAMD_ERR_STATE;
+  const int64_t* o = h->off;
+  const int64_t nx = h->nx, nd = h->nd;
+  const double *x = it + o[0], *d = it + o[1];
+  double *sxl = it + o[4], *sxu = it + o[5], *sdl = it + o[6], *sdu = it + o[7];
+  const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu, *xl = h->xl, *xu = h->xu, *dl = h->dl, *du = h->du;
+  return launch_ew(h->ctx, std::max<int64_t>(nx, nd), [=] __device__(int64_t i) {
+    if(i < nx) {
+      sxl[i] = ixl[i] == 0.0 ? 0.0 : x[i] - xl[i];
+      sxu[i] = ixu[i] == 0.0 ? 0.0 : xu[i] - x[i];
+    }
+    if(i < nd) {
+      sdl[i] = idl[i] == 0.0 ? 0.0 : d[i] - dl[i];
+      sdu[i] = idu[i] == 0.0 ? 0.0 : du[i] - d[i];
+    }
+  });
+}
+
+// adjust_small_slacks (:414-505) for the four slack parts of `it`, duals taken from `it_curr`; returns the number adjusted
+int hiopamd_iterate_adjust_small_slacks(hiopamd_kkt_xycyd* h, double* it, const double* it_curr, double mu,
+                                        int* num_adjusted_host)
+{
+  if(!h || !it || !it_curr || !num_adjusted_host) return HIOPAMD_ERR_ARG;
+  hiopamd_ctx* ctx = h->ctx;
+  const int64_t* o = h->off;
+  const double eps = std::numeric_limits<double>::epsilon();
+  const double small_val = eps * std::fmin(1.0, mu);
+  const double scale_fact = std::pow(eps, 0.75);
+  const double* pat[4] = {h->ixl, h->ixu, h->idl, h->idu};
+  const double* bnd[4] = {h->xl, h->xu, h->dl, h->du};
+  int total = 0;
+  for(int q = 0; q < 4; ++q) {
+    const int64_t n = o[4 + q + 1] - o[4 + q];
+    if(n <= 0) continue;
+    double* slack = it + o[4 + q];
+    const double* dual = it_curr + o[8 + q];
+    const double *sel_ = pat[q], *bound = bnd[q];
+    if(!bound) return HIOPAMD_ERR_STATE;
+    double slack_min = 0.0;
+    RC(hiopamd_vec_min_w_pattern(ctx, n, slack, sel_, &slack_min));   // local, like the reference (:432)
+    if(!(slack_min < small_val)) continue;
+    red4_t cnt;
+    RC(reduce4(ctx, n,
+               [=] __device__(int64_t i) {
+                 const double s0 = slack[i];
+                 // arg1 = -sgn(min(slack - small_val [selected], 0))  -> 1 where the slack is too small, else 0
+                 double a1 = s0 + (sel_[i] == 1.0 ? -small_val : 0.0);
+                 a1 = a1 < 0.0 ? a1 : 0.0;
+                 const double flag = a1 < 0.0 ? 1.0 : 0.0;
+                 const double sl = s0 > 0.0 ? s0 : 0.0;                            // slack.component_max(0)
+                 double a2 = sel_[i] == 1.0 ? mu : 0.0;                            // mu / dual on the pattern
+                 a2 = sel_[i] == 0.0 ? 0.0 : a2 / dual[i];
+                 const double a3 = sel_[i] == 1.0 ? small_val : 0.0;
+                 a2 = (a2 > a3 ? a2 : a3) - sl;
+                 double n1 = flag * a2 + sl;                                       // candidate 1
+                 double b2 = sel_[i] == 1.0 ? 1.0 : 0.0;
+                 const double ab = fabs(bound[i]);
+                 b2 = (b2 > ab ? b2 : ab) * scale_fact + sl;                       // cap
+                 n1 = n1 < b2 ? n1 : b2;
+                 slack[i] = n1;
+                 return red4_t{{0.0, 0.0, flag, 0.0}};
+               },
+               2, &cnt));
+    total += (int)(cnt.v[2] + 0.5);
+  }
+  *num_adjusted_host = total;
+  return HIOPAMD_OK;
+}
+
+// determineDualsBounds_d (:314-327): vl = mu / sdl, vu = mu / sdu on the patterns
+int hiopamd_iterate_determine_duals_bounds_d(hiopamd_kkt_xycyd* h, double* it, double mu)
+{
+  if(!h || !it) return HIOPAMD_ERR_ARG;
+  const int64_t* o = h->off;
+  const double *sdl = it + o[6], *sdu = it + o[7], *idl = h->idl, *idu = h->idu;
+  double *vl = it + o[10], *vu = it + o[11];
+  return launch_ew(h->ctx, h->nd, [=] __device__(int64_t i) {
+    vl[i] = idl[i] == 0.0 ? 0.0 : mu / sdl[i];
+    vu[i] = idu[i] == 0.0 ? 0.0 : mu / sdu[i];
+  });
+}
+
+// adjustDuals_primalLogHessian (:507-521)
+int hiopamd_iterate_adjust_duals_plh(hiopamd_kkt_xycyd* h, double* it, double mu, double kappa_Sigma)
+{
+  if(!h || !it) return HIOPAMD_ERR_ARG;
+  const int64_t* o = h->off;
+  RC(hiopamd_vec_adjust_duals_plh(h->ctx, h->nx, it + o[8], it + o[4], h->ixl, mu, kappa_Sigma));
+  RC(hiopamd_vec_adjust_duals_plh(h->ctx, h->nx, it + o[9], it + o[5], h->ixu, mu, kappa_Sigma));
+  RC(hiopamd_vec_adjust_duals_plh(h->ctx, h->nd, it + o[10], it + o[6], h->idl, mu, kappa_Sigma));
+  RC(hiopamd_vec_adjust_duals_plh(h->ctx, h->nd, it + o[11], it + o[7], h->idu, mu, kappa_Sigma));
+  return HIOPAMD_OK;
+}
+
+// evalLogBarrier (:523-540) and linearDampingTerm (:552-566): x-sized parts all-reduced on a column partition
+int hiopamd_iterate_eval_log_barrier(hiopamd_kkt_xycyd* h, const double* it, double* out_host)
+{
+  if(!h || !it || !out_host) return HIOPAMD_ERR_ARG;
+  hiopamd_ctx* ctx = h->ctx;
+  const int64_t* o = h->off;
+  double a = 0, b = 0, c = 0, d = 0;
+  RC(hiopamd_vec_log_barrier(ctx, h->nx, it + o[4], h->ixl, &a));
+  RC(hiopamd_vec_log_barrier(ctx, h->nx, it + o[5], h->ixu, &b));
+  red4_t r{{0.0, 0.0, a + b, 0.0}};
+  RC(xpart_allreduce(h, &r, 2));
+  RC(hiopamd_vec_log_barrier(ctx, h->nd, it + o[6], h->idl, &c));
+  RC(hiopamd_vec_log_barrier(ctx, h->nd, it + o[7], h->idu, &d));
+  *out_host = r.v[2] + c + d;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_iterate_linear_damping_term(hiopamd_kkt_xycyd* h, const double* it, double mu, double kappa_d, double* out_host)
+{
+  if(!h || !it || !out_host) return HIOPAMD_ERR_ARG;
+  hiopamd_ctx* ctx = h->ctx;
+  const int64_t* o = h->off;
+  double a = 0, b = 0, c = 0, d = 0;
+  RC(hiopamd_vec_linear_damping_term(ctx, h->nx, it + o[4], h->ixl, h->ixu, mu, kappa_d, &a));
+  RC(hiopamd_vec_linear_damping_term(ctx, h->nx, it + o[5], h->ixu, h->ixl, mu, kappa_d, &b));
+  red4_t r{{0.0, 0.0, a + b, 0.0}};
+  RC(xpart_allreduce(h, &r, 2));
+  RC(hiopamd_vec_linear_damping_term(ctx, h->nd, it + o[6], h->idl, h->idu, mu, kappa_d, &c));
+  RC(hiopamd_vec_linear_damping_term(ctx, h->nd, it + o[7], h->idu, h->idl, mu, kappa_d, &d));
+  *out_host = r.v[2] + c + d;
+  return HIOPAMD_OK;
+}
 
 }  // extern "C"

@@ -406,3 +406,56 @@ class KKTLinSysXYcYd:
             self.close()
         except Exception:
             pass
+
+
+class IpmSlabOps:
+    """hiopIterate / hiopResidual steps on the 12-part slabs of a KKTLinSysXYcYd (hiopamd_residual_update,
+    hiopamd_iterate_*): mirrors src/Optimization/hiopResidual.cpp:154 and hiopIterate.cpp:274-566."""
+
+    def __init__(self, full: KKTLinSysXYcYd, xl, xu, dl, du, crhs):
+        self.full, self._L = full, lib()
+        self._b = [xl, xu, dl, du, crhs]
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_kkt_xycyd_set_bounds(full.h, *[dptr(t) for t in self._b]), "set_bounds")
+
+    def residual_update(self, it, c, d, grad_f, mu, kappa_d, resid):
+        n = (C.c_double * 11)()
+        check(self._L.hiopamd_residual_update(self.full.h, dptr(it), dptr(c), dptr(d), dptr(grad_f), mu, kappa_d,
+                                              dptr(resid), n), "hiopamd_residual_update")
+        return list(n)
+
+    def fraction_to_the_bdry(self, it, dir_, tau):
+        ap, ad = C.c_double(0), C.c_double(0)
+        check(self._L.hiopamd_iterate_fraction_to_the_bdry(self.full.h, dptr(it), dptr(dir_), tau, C.byref(ap), C.byref(ad)),
+              "fraction_to_the_bdry")
+        return ap.value, ad.value
+
+    def take_step(self, out, it, dir_, alpha_primal, alpha_dual, primals=True, duals=True):
+        check(self._L.hiopamd_iterate_take_step(self.full.h, dptr(out), dptr(it), dptr(dir_), alpha_primal, alpha_dual,
+                                                int(primals), int(duals)), "take_step")
+
+    def determine_slacks(self, it):
+        check(self._L.hiopamd_iterate_determine_slacks(self.full.h, dptr(it)), "determine_slacks")
+
+    def adjust_small_slacks(self, it, it_curr, mu) -> int:
+        n = C.c_int(0)
+        check(self._L.hiopamd_iterate_adjust_small_slacks(self.full.h, dptr(it), dptr(it_curr), mu, C.byref(n)),
+              "adjust_small_slacks")
+        return n.value
+
+    def determine_duals_bounds_d(self, it, mu):
+        check(self._L.hiopamd_iterate_determine_duals_bounds_d(self.full.h, dptr(it), mu), "determine_duals_bounds_d")
+
+    def adjust_duals_plh(self, it, mu, kappa_sigma):
+        check(self._L.hiopamd_iterate_adjust_duals_plh(self.full.h, dptr(it), mu, kappa_sigma), "adjust_duals_plh")
+
+    def eval_log_barrier(self, it) -> float:
+        v = C.c_double(0)
+        check(self._L.hiopamd_iterate_eval_log_barrier(self.full.h, dptr(it), C.byref(v)), "eval_log_barrier")
+        return v.value
+
+    def linear_damping_term(self, it, mu, kappa_d) -> float:
+        v = C.c_double(0)
+        check(self._L.hiopamd_iterate_linear_damping_term(self.full.h, dptr(it), mu, kappa_d, C.byref(v)),
+              "linear_damping_term")
+        return v.value

@@ -448,6 +448,33 @@ hiopamd_linsolver* hiopamd_kkt_xycyd_linsolver(hiopamd_kkt_xycyd* h);           
 double* hiopamd_kkt_xycyd_Dx(hiopamd_kkt_xycyd* h);                              /* device, nx */
 double* hiopamd_kkt_xycyd_Dd(hiopamd_kkt_xycyd* h);                              /* device, nd */
 
+/* ---- the steps either side of the KKT solve, on the same 12-part slabs ------------------------------
+ * bounds / right-hand sides of the problem (device, borrowed): xl, xu (nx), dl, du (nd), crhs (nyc) */
+int hiopamd_kkt_xycyd_set_bounds(hiopamd_kkt_xycyd* h, const double* xl, const double* xu, const double* dl,
+                                 const double* du, const double* crhs);
+/* hiopResidual::update (src/Optimization/hiopResidual.cpp:154-365): all 12 residual parts from the iterate, the
+ * constraint bodies c(x), d(x), grad_f and the back-end's Jacobians; kappa_d > 0 adds the linear damping terms
+ * (hiopLogBarProblem.hpp:135-145).  norms11_host = nrmInf_nlp_optim, nrmInf_nlp_feasib, nrmInf_nlp_complem,
+ * nrmInf_bar_optim, nrmInf_bar_feasib, nrmInf_bar_complem, nrmOne_nlp_feasib, nrmOne_bar_feasib, nrmOne_nlp_optim,
+ * nrmOne_bar_optim, nrmInf_cons_violation */
+int hiopamd_residual_update(hiopamd_kkt_xycyd* h, const double* iter, const double* c, const double* d,
+                            const double* grad_f, double mu, double kappa_d, double* resid, double* norms11_host);
+/* hiopIterate (src/Optimization/hiopIterate.cpp): fractionToTheBdry :330, takeStep_primals/_duals :367-390,
+ * determineSlacks :274, adjust_small_slacks :414-505, determineDualsBounds_d :314, adjustDuals_primalLogHessian :507,
+ * evalLogBarrier :523, linearDampingTerm :552 */
+int hiopamd_iterate_fraction_to_the_bdry(hiopamd_kkt_xycyd* h, const double* iter, const double* dir, double tau,
+                                         double* alpha_primal_host, double* alpha_dual_host);
+int hiopamd_iterate_take_step(hiopamd_kkt_xycyd* h, double* out, const double* iter, const double* dir,
+                              double alpha_primal, double alpha_dual, int primals, int duals);
+int hiopamd_iterate_determine_slacks(hiopamd_kkt_xycyd* h, double* iter);
+int hiopamd_iterate_adjust_small_slacks(hiopamd_kkt_xycyd* h, double* iter, const double* iter_curr, double mu,
+                                        int* num_adjusted_host);
+int hiopamd_iterate_determine_duals_bounds_d(hiopamd_kkt_xycyd* h, double* iter, double mu);
+int hiopamd_iterate_adjust_duals_plh(hiopamd_kkt_xycyd* h, double* iter, double mu, double kappa_Sigma);
+int hiopamd_iterate_eval_log_barrier(hiopamd_kkt_xycyd* h, const double* iter, double* out_host);
+int hiopamd_iterate_linear_damping_term(hiopamd_kkt_xycyd* h, const double* iter, double mu, double kappa_d,
+                                        double* out_host);
+
 #ifdef __cplusplus
 }
 #endif

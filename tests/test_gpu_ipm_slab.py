@@ -1,0 +1,103 @@
+"""GPU parity of the hiopIterate / hiopResidual slab steps (hiopamd_residual_update, hiopamd_iterate_*) against
+oracle/ipm_slab.py (restatement of hiopResidual.cpp:154-365 and hiopIterate.cpp:274-566).  Element-wise results 4 ulp
+(FMA contraction), norms/sums 1e-13 relative, step lengths and counts exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ipm_slab as osl
+from oracle import kkt_full as kf
+from tests import kkt_full_cases as cases
+from tests.test_gpu_kkt_xycyd import D, gpu_mds
+
+pytestmark = pytest.mark.gpu
+
+
+def setup_case(ctx, ns, nd, neq, seed=3):
+    from hiop_amd.kkt import IpmSlabOps
+    p, k, fo, it = cases.mds_case(ns, nd, neq, seed=seed)
+    kg, fg, keep = gpu_mds(ctx, p, k, fo.ixl, fo.ixu, fo.idl, fo.idu)
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    bounds = (np.where(fo.ixl == 1.0, p.xl, -1e20), np.where(fo.ixu == 1.0, p.xu, 1e20), np.where(fo.idl == 1.0, p.dl, -1e20),
+              np.where(fo.idu == 1.0, p.du, 1e20), rng.uniform(-1, 1, p.neq))
+    bg = [D(b) for b in bounds]
+    ops = IpmSlabOps(fg, *bg)
+    return p, fo, fg, ops, it, bounds, rng
+
+
+def assert_parts(fg, slab, want, names, rtol=1e-14):
+    got = fg.unpack(slab, names)
+    for kname in names:
+        np.testing.assert_allclose(got[kname], want[kname], rtol=rtol, atol=rtol * max(1.0, np.abs(want[kname]).max(initial=0.0)),
+                                   err_msg=kname)
+
+
+@pytest.mark.parametrize("ns,nd,neq,kappa_d", [(8, 6, None, 1e-5), (300, 70, 129, 0.0), (64, 33, 17, 1e-5)])
+def test_residual_update(ctx, ns, nd, neq, kappa_d):
+    p, fo, fg, ops, it, bounds, rng = setup_case(ctx, ns, nd, neq)
+    nx = p.nxs + p.nxd
+    c, d, grad = rng.uniform(-1, 1, p.neq), rng.uniform(-3, 3, p.nineq), rng.uniform(-1, 1, nx)
+    mu = 0.37
+    fo.it = it
+    r_o, n_o = osl.residual_update(fo, it, c, d, grad, bounds, mu, kappa_d)
+    it_g = fg.pack(it, kf.ITER_PARTS)
+    res_g = torch.zeros(fg.dim, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    norms = ops.residual_update(it_g, D(c), D(d), D(grad), mu, kappa_d, res_g)
+    ctx.sync()
+    assert_parts(fg, res_g, r_o, kf.RESID_PARTS, rtol=1e-13)
+    for val, name in zip(norms, osl.NORM_ORDER):
+        assert val == pytest.approx(n_o[name], rel=1e-13, abs=1e-300), name
+    # the residual this produces is what compute_directions consumes: K * dir = resid on the full system
+    assert fo.update(it) and fg.update(it_g)
+    d_g = torch.zeros_like(res_g)
+    assert fg.compute_directions(res_g, d_g)
+    y = torch.zeros_like(res_g)
+    fg.times_vec(y, d_g); ctx.sync()
+    assert (torch.linalg.norm(y - res_g) / torch.linalg.norm(res_g)).item() < 1e-10
+
+
+def test_step_routines(ctx):
+    p, fo, fg, ops, it, bounds, rng = setup_case(ctx, 40, 33, 17, seed=9)
+    fo.it = it
+    dr = {k: rng.uniform(-1, 1, v.size) for k, v in it.items()}
+    for s, pat in (("sxl", fo.ixl), ("zl", fo.ixl), ("sxu", fo.ixu), ("zu", fo.ixu), ("sdl", fo.idl), ("vl", fo.idl),
+                   ("sdu", fo.idu), ("vu", fo.idu)):
+        dr[s] *= pat * 5.0
+    it_g, dr_g = fg.pack(it, kf.ITER_PARTS), fg.pack(dr, kf.ITER_PARTS)
+    torch.cuda.synchronize()
+    tau = 0.995
+    ap_o, ad_o = osl.fraction_to_the_bdry(fo, it, dr, tau)
+    ap_g, ad_g = ops.fraction_to_the_bdry(it_g, dr_g, tau)
+    assert (ap_g, ad_g) == (ap_o, ad_o) and ap_g < 1.0 and ad_g < 1.0
+    # takeStep_primals + takeStep_duals into a trial iterate; slack parts are left alone
+    trial_o = osl.take_step(it, dr, ap_o, ad_o)
+    trial_g = it_g.clone()
+    torch.cuda.synchronize()
+    ops.take_step(trial_g, it_g, dr_g, ap_g, ad_g); ctx.sync()
+    assert_parts(fg, trial_g, trial_o, kf.ITER_PARTS)
+    # determineSlacks + adjust_small_slacks: push some primal values onto / beyond their bounds first
+    xl, xu, dl, du, _ = bounds
+    xt = trial_o["x"].copy()
+    low = np.nonzero(fo.ixl == 1.0)[0]
+    xt[low[:5]] = xl[low[:5]] - np.array([0.0, 1e-18, 1e-3, -1e-17, 1e-30])      # on, just below, below, just above the bound
+    trial_o["x"] = xt
+    trial_g2 = fg.pack(trial_o, kf.ITER_PARTS)
+    torch.cuda.synchronize()
+    osl.determine_slacks(fo, trial_o, bounds)
+    ops.determine_slacks(trial_g2); ctx.sync()
+    assert_parts(fg, trial_g2, trial_o, kf.ITER_PARTS)
+    mu = 1e-3
+    n_o = osl.adjust_small_slacks(fo, trial_o, it, bounds, mu)
+    n_g = ops.adjust_small_slacks(trial_g2, it_g, mu); ctx.sync()
+    assert n_g == n_o and n_o >= 4
+    assert_parts(fg, trial_g2, trial_o, kf.ITER_PARTS, rtol=1e-13)
+    assert np.all(fg.unpack(trial_g2, kf.ITER_PARTS)["sxl"][fo.ixl == 1.0] > 0.0)
+    # duals from the slacks, dual safeguard, barrier terms
+    osl.determine_duals_bounds_d(fo, trial_o, mu)
+    ops.determine_duals_bounds_d(trial_g2, mu); ctx.sync()
+    osl.adjust_duals_plh(fo, trial_o, mu, 1e10)
+    ops.adjust_duals_plh(trial_g2, mu, 1e10); ctx.sync()
+    assert_parts(fg, trial_g2, trial_o, kf.ITER_PARTS, rtol=1e-13)
+    assert ops.eval_log_barrier(it_g) == pytest.approx(osl.eval_log_barrier(fo, it), rel=1e-13)
+    assert ops.linear_damping_term(it_g, 0.1, 1e-5) == pytest.approx(osl.linear_damping_term(fo, it, 0.1, 1e-5), rel=1e-13)

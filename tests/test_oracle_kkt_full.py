@@ -124,3 +124,31 @@ def test_inertia_free_path_regularises_until_curvature_is_positive():
         assert rounds <= 10
     assert full.last_dWd >= 1e-11 * full.last_xs_nrmsq
     assert rounds >= 1 and full.perturb.deltas()[0] > 0
+
+
+def test_ipm_slab_restatement_consistency():
+    """oracle/ipm_slab.py: the residual parts feed computeDirections (K dir = resid), the norms are those of the parts,
+    a full step keeps the patterns, adjust_small_slacks restores strictly positive slacks."""
+    from oracle import ipm_slab as osl
+    p, k, full, it = cases.mds_case(12, 5, 7)
+    rng = np.random.Generator(np.random.PCG64(2))
+    nx = p.nxs + p.nxd
+    bounds = (np.where(full.ixl == 1.0, p.xl, -1e20), np.where(full.ixu == 1.0, p.xu, 1e20),
+              np.where(full.idl == 1.0, p.dl, -1e20), np.where(full.idu == 1.0, p.du, 1e20), rng.uniform(-1, 1, p.neq))
+    c, d, g = rng.uniform(-1, 1, p.neq), rng.uniform(-3, 3, p.nineq), rng.uniform(-1, 1, nx)
+    mu = 0.2
+    assert full.update(it)
+    r, n = osl.residual_update(full, it, c, d, g, bounds, mu, 1e-5)
+    assert n["nrmInf_bar_feasib"] == max(np.abs(r["ryc"]).max(), np.abs(r["ryd"]).max())
+    assert n["nrmInf_bar_complem"] == max(np.abs(r[q]).max() for q in ("rszl", "rszu", "rsvl", "rsvu"))
+    ok, dr = full.compute_directions(r)
+    assert ok and _flat_err(full, r, dr) < 1e-11
+    ap, ad = osl.fraction_to_the_bdry(full, it, dr, 0.995)
+    assert 0 < ap <= 1 and 0 < ad <= 1
+    trial = osl.take_step(it, dr, ap, ad)
+    osl.determine_slacks(full, trial, bounds)
+    trial["x"][np.nonzero(full.ixl == 1.0)[0][0]] = bounds[0][np.nonzero(full.ixl == 1.0)[0][0]]   # on its lower bound
+    osl.determine_slacks(full, trial, bounds)
+    assert osl.adjust_small_slacks(full, trial, it, bounds, mu) >= 1
+    for s, pat in (("sxl", full.ixl), ("sxu", full.ixu), ("sdl", full.idl), ("sdu", full.idu)):
+        assert np.all(trial[s][pat == 1.0] > 0) and not trial[s][pat == 0.0].any()
