@@ -90,14 +90,54 @@ __global__ __launch_bounds__(256, 2) void mfma4_tile_loop(int iters, double* out
   out[blockIdx.x * 256 + threadIdx.x] = t;
 }
 template <int DPP>
+__global__ __launch_bounds__(256, 1) void mfma4_tile_loop_agpr(int iters, double* out)
+{
+  double acc[4][4][4];
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+#pragma unroll
+      for(int s = 0; s < 4; ++s) acc[i][j][s] = 0.0;
+  double a[4], b[4];
+#pragma unroll
+  for(int i = 0; i < 4; ++i) { a[i] = 1.0 + (threadIdx.x + i) * 1e-9; b[i] = 1.0 - (threadIdx.x + i) * 1e-9; }
+  for(int it = 0; it < iters; ++it) {
+    double br[4][4];
+#pragma unroll
+    for(int j = 0; j < 4; ++j) {
+      asm volatile("" : "+v"(b[j]));
+      br[j][0] = b[j];
+      if(DPP) { br[j][1] = ror4(br[j][0]); br[j][2] = ror4(br[j][1]); br[j][3] = ror4(br[j][2]); }
+      else { br[j][1] = br[j][0]; br[j][2] = br[j][0]; br[j][3] = br[j][0]; }
+    }
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+#pragma unroll
+      for(int j = 0; j < 4; ++j)
+#pragma unroll
+        for(int s = 0; s < 4; ++s) acc[i][j][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], br[j][s], acc[i][j][s], 0, 0, 0);
+  }
+  double t = 0.0;
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+#pragma unroll
+      for(int s = 0; s < 4; ++s) t += acc[i][j][s];
+  out[blockIdx.x * 256 + threadIdx.x] = t;
+}
+template <int DPP, int AGPR>
 static int run_tile(int wgs, int iters, double* d, const char* tag)
 {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(mfma4_tile_loop<DPP>, dim3(wgs), dim3(256), 0, 0, 10, d);
+  if(AGPR) hipLaunchKernelGGL(mfma4_tile_loop_agpr<DPP>, dim3(wgs), dim3(256), 0, 0, 10, d);
+  else hipLaunchKernelGGL(mfma4_tile_loop<DPP>, dim3(wgs), dim3(256), 0, 0, 10, d);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(mfma4_tile_loop<DPP>, dim3(wgs), dim3(256), 0, 0, iters, d);
+  if(AGPR) hipLaunchKernelGGL(mfma4_tile_loop_agpr<DPP>, dim3(wgs), dim3(256), 0, 0, iters, d);
+  else hipLaunchKernelGGL(mfma4_tile_loop<DPP>, dim3(wgs), dim3(256), 0, 0, iters, d);
   CK(hipEventRecord(e1, 0));
   CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -157,9 +197,12 @@ int main()
     run4<16>(256, 80000, d, dc, "1 WG/CU");
     run4<16>(512, 80000, d, dc, "2 WG/CU");
     run4<4>(512, 320000, d, dc, "2 WG/CU");
-    run_tile<0>(512, 20000, d, "no DPP, 2 WG/CU");
-    run_tile<1>(512, 20000, d, "DPP rotations, 2 WG/CU");
-    run_tile<1>(256, 20000, d, "DPP rotations, 1 WG/CU");
+    run_tile<0, 0>(512, 20000, d, "no DPP, 2 WG/CU");
+    run_tile<1, 0>(512, 20000, d, "DPP rotations, 2 WG/CU");
+    run_tile<1, 0>(256, 20000, d, "DPP rotations, 1 WG/CU");
+    run_tile<0, 1>(256, 20000, d, "AGPR acc, no DPP, 1 WG/CU");
+    run_tile<0, 1>(512, 20000, d, "AGPR acc, no DPP, 512 WGs");
+    run_tile<1, 1>(256, 20000, d, "AGPR acc, DPP, 1 WG/CU");
   }
   return 0;
 }
