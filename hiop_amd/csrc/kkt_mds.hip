@@ -30,6 +30,7 @@ struct hiopamd_kkt_mds {
   double* Dd_inv = nullptr;   // nineq
   double* rhs = nullptr;      // N
   double* buf_xs = nullptr;   // nxs
+  double* ones_xs = nullptr;  // nxs, all ones (D = I for J J^T through the Schur plans)
   bool built = false;
 };
 
@@ -59,8 +60,10 @@ int hiopamd_kkt_mds_create(hiopamd_kkt_mds** out, hiopamd_ctx* ctx, const hiopam
   auto dalloc = [](double** p, size_t n) { return hipMalloc((void**)p, sizeof(double) * (n ? n : 1)); };
   if(rc == HIOPAMD_OK) {
     if(dalloc(&k->Hxs, st->nxs) != hipSuccess || dalloc(&k->Dd_inv, st->nineq) != hipSuccess ||
-       dalloc(&k->rhs, N) != hipSuccess || dalloc(&k->buf_xs, st->nxs) != hipSuccess)
+       dalloc(&k->rhs, N) != hipSuccess || dalloc(&k->buf_xs, st->nxs) != hipSuccess ||
+       dalloc(&k->ones_xs, st->nxs) != hipSuccess)
       rc = HIOPAMD_ERR_HIP;
+    if(rc == HIOPAMD_OK) rc = hiopamd_vec_set_to_constant(ctx, st->nxs, k->ones_xs, 1.0);
   }
   if(rc != HIOPAMD_OK) {
     hiopamd_kkt_mds_destroy(k);
@@ -81,6 +84,7 @@ int hiopamd_kkt_mds_destroy(hiopamd_kkt_mds* k)
   (void)hipFree(k->Dd_inv);
   (void)hipFree(k->rhs);
   (void)hipFree(k->buf_xs);
+  (void)hipFree(k->ones_xs);
   delete k;
   return HIOPAMD_OK;
 }
@@ -260,6 +264,28 @@ int hiopamd_kkt_mds_jac_trans_times_vec(hiopamd_kkt_mds* k, int which, double be
   } else {
     RC(hiopamd_sp_trans_times_vec(k->ctx, s.nineq, s.nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, beta, y, alpha, x));
     RC(hiopamd_mat_trans_times_vec(k->ctx, s.nineq, s.nxd, k->Jdd, s.nxd, beta, y + s.nxs, alpha, x));
+  }
+  return HIOPAMD_OK;
+}
+
+// W (m x m, m = neq + nineq, upper triangle) = [Jc; Jd] [Jc; Jd]^T for the MDS Jacobians: sparse parts through the Schur
+// plans with D = I, dense parts as Grams (hiopMatrixMDS::timesMatTrans, hiopMatrixMDS.hpp:94-100)
+int hiopamd_kkt_mds_jac_jac_trans(hiopamd_kkt_mds* k, double* W, int64_t ldw)
+{
+  if(!k || !W || !k->Jcd) return HIOPAMD_ERR_STATE;
+  hiopamd_ctx* ctx = k->ctx;
+  const hiopamd_mds_structure& s = k->s;
+  const int m = s.neq + s.nineq;
+  if(ldw < m) return HIOPAMD_ERR_ARG;
+  HIOPAMD_CHECK(hipMemset2DAsync(W, sizeof(double) * (size_t)ldw, 0, sizeof(double) * (size_t)m, (size_t)m, ctx->stream));
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cc, k->Jcs_val, k->Jcs_val, k->ones_xs, 1.0, W, ldw, 0, 0));
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_dd, k->Jds_val, k->Jds_val, k->ones_xs, 1.0, W, ldw, s.neq, s.neq));
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cd, k->Jcs_val, k->Jds_val, k->ones_xs, 1.0, W, ldw, 0, s.neq));
+  if(s.nxd > 0) {
+    RC(hiopamd_gram_weighted(ctx, s.neq, s.neq, s.nxd, k->Jcd, s.nxd, k->Jcd, s.nxd, nullptr, 1.0, W, ldw, 1.0, 1));
+    RC(hiopamd_gram_weighted(ctx, s.neq, s.nineq, s.nxd, k->Jcd, s.nxd, k->Jdd, s.nxd, nullptr, 1.0, W + s.neq, ldw, 1.0, 0));
+    RC(hiopamd_gram_weighted(ctx, s.nineq, s.nineq, s.nxd, k->Jdd, s.nxd, k->Jdd, s.nxd, nullptr, 1.0,
+                             W + (int64_t)s.neq * ldw + s.neq, ldw, 1.0, 1));
   }
   return HIOPAMD_OK;
 }

@@ -257,6 +257,7 @@ struct hiopamd_kkt_xycyd {
   double *Dx = nullptr, *Dd = nullptr, *rx_tilde = nullptr, *ryd_tilde = nullptr, *ryd2 = nullptr;
   double* krylov = nullptr;   // 9 slabs, allocated at the first IR call
   double* dsmall = nullptr;   // 4 doubles of device scratch for the sharded dot
+  double* lsq = nullptr;      // LSQ dual update workspace: M (m^2) | rhs (m) | posv work (3 m^2 + 8 m)
   PdPerturb pd;
   int n_required_neg = 0;
   int num_refact = 0;
@@ -763,6 +764,7 @@ int hiopamd_kkt_xycyd_destroy(hiopamd_kkt_xycyd* h)
   (void)hipFree(h->ryd2);
   (void)hipFree(h->krylov);
   (void)hipFree(h->dsmall);
+  (void)hipFree(h->lsq);
   delete h;
   return HIOPAMD_OK;
 }
@@ -1504,6 +1506,66 @@ int hiopamd_iterate_linear_damping_term(hiopamd_kkt_xycyd* h, const double* it, 
   RC(hiopamd_vec_linear_damping_term(ctx, h->nd, it + o[6], h->idl, h->idu, mu, kappa_d, &c));
   RC(hiopamd_vec_linear_damping_term(ctx, h->nd, it + o[7], h->idu, h->idl, mu, kappa_d, &d));
   *out_host = r.v[2] + c + d;
+  return HIOPAMD_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// hiopDualsLsqUpdateLinsysRedDense::do_lsq_update (src/Optimization/hiopDualsUpdater.cpp:239-330):
+//   [ Jc Jc^T   Jc Jd^T     ] [yc]     [ Jc   0 ] [ grad_f - zl + zu ]
+//   [ Jd Jc^T   Jd Jd^T + I ] [yd] = - [ Jd   I ] [     vl - vu      ]
+// The three Grams are assembled on the device (MDS: sparse parts through the Schur plans with D = I + dense Grams;
+// dense / low-rank: MFMA Gram kernel, all-reduced on a column partition), the SPD solve is hiopamd_posv_refine
+// (the reference: DPOTRF/DPOTRS or MAGMA).  yc, yd of `iter` are overwritten.  *ok_host = 0 if M is not SPD.
+int hiopamd_duals_lsq_update(hiopamd_kkt_xycyd* h, double* iter, const double* grad_f, int* ok_host)
+{
+  if(!h || !iter || !grad_f || !ok_host) return HIOPAMD_ERR_ARG;
+  hiopamd_ctx* ctx = h->ctx;
+  const int64_t* o = h->off;
+  const int me = h->nyc, mi = h->nyd, m = me + mi;
+  const int64_t nx = h->nx;
+  *ok_host = 1;
+  if(m == 0) return HIOPAMD_OK;
+  const size_t mm = (size_t)m * m;
+  if(!h->lsq && hipMalloc((void**)&h->lsq, sizeof(double) * (4 * mm + 9 * (size_t)m + 8)) != hipSuccess) return HIOPAMD_ERR_HIP;
+  double *M = h->lsq, *rhs = M + mm, *work = rhs + m;
+  // ---- M
+  if(h->kind == KIND_MDS) {
+    RC(hiopamd_kkt_mds_jac_jac_trans(h->mds, M, m));
+  } else {
+    const double *Jc = h->Jc, *Jd = h->Jd;
+    if(h->kind == KIND_LOWRANK && (!Jc || !Jd)) {   // the [Jc; Jd] copy of the last update
+      Jc = hiopamd_kkt_lowrank_J(h->lr);
+      Jd = Jc + (int64_t)me * nx;
+    }
+    if((me > 0 && !Jc) || (mi > 0 && !Jd)) return HIOPAMD_ERR_STATE;
+    if(me > 0) RC(hiopamd_gram_weighted(ctx, me, me, nx, Jc, nx, Jc, nx, nullptr, 0.0, M, m, 1.0, 1));
+    if(me > 0 && mi > 0) RC(hiopamd_gram_weighted(ctx, me, mi, nx, Jc, nx, Jd, nx, nullptr, 0.0, M + me, m, 1.0, 0));
+    if(mi > 0) RC(hiopamd_gram_weighted(ctx, mi, mi, nx, Jd, nx, Jd, nx, nullptr, 0.0, M + (int64_t)me * m + me, m, 1.0, 1));
+    if(h->kind == KIND_LOWRANK && ctx->allreduce &&
+       ctx->allreduce(ctx->allreduce_user, M, mm, HIOPAMD_SUM, (void*)ctx->stream) != 0)
+      return HIOPAMD_ERR_HIP;
+  }
+  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, m, me, mi, 1.0));   // mixmi->addDiagonal(1.0)  (:256)
+  // ---- rhs = -[Jc; Jd] vecx - [0; vecd],  vecx = grad_f - zl + zu,  vecd = vl - vu          (:285-297)
+  {
+    double* vecx = h->rx_tilde;
+    const double *zl = iter + o[8], *zu = iter + o[9], *vl = iter + o[10], *vu = iter + o[11];
+    RC(launch_ew(ctx, nx, [=] __device__(int64_t i) { vecx[i] = grad_f[i] - zl[i] + zu[i]; }));
+    RC(backend_jac_times_vec(h, rhs, vecx));
+    RC(launch_ew(ctx, m, [=] __device__(int64_t i) { rhs[i] = -rhs[i] - (i >= me ? (vl[i - me] - vu[i - me]) : 0.0); }));
+  }
+  int info = 0;
+  double resid = 0.0;
+  RC(hiopamd_posv_refine(ctx, m, M, m, rhs, work, &info, &resid));
+  if(info != 0) {
+    *ok_host = 0;
+    return HIOPAMD_OK;
+  }
+  RC(hiopamd_vec_copy(ctx, me, iter + o[2], rhs));
+  RC(hiopamd_vec_copy(ctx, mi, iter + o[3], rhs + me));
   return HIOPAMD_OK;
 }
 

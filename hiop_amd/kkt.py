@@ -454,6 +454,11 @@ class IpmSlabOps:
         check(self._L.hiopamd_iterate_eval_log_barrier(self.full.h, dptr(it), C.byref(v)), "eval_log_barrier")
         return v.value
 
+    def duals_lsq_update(self, it, grad_f) -> bool:
+        ok = C.c_int(0)
+        check(self._L.hiopamd_duals_lsq_update(self.full.h, dptr(it), dptr(grad_f), C.byref(ok)), "hiopamd_duals_lsq_update")
+        return bool(ok.value)
+
     def linear_damping_term(self, it, mu, kappa_d) -> float:
         v = C.c_double(0)
         check(self._L.hiopamd_iterate_linear_damping_term(self.full.h, dptr(it), mu, kappa_d, C.byref(v)),

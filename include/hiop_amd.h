@@ -323,6 +323,8 @@ int hiopamd_kkt_mds_hess_times_vec(hiopamd_kkt_mds* k, double beta, double* y, d
 int hiopamd_kkt_mds_jac_times_vec(hiopamd_kkt_mds* k, int which, double beta, double* y, double alpha, const double* x);
 int hiopamd_kkt_mds_jac_trans_times_vec(hiopamd_kkt_mds* k, int which, double beta, double* y, double alpha,
                                         const double* x);
+/* W (m x m, ld ldw, upper triangle) = [Jc; Jd][Jc; Jd]^T (hiopMatrixMDS::timesMatTrans, hiopMatrixMDS.hpp:94-100) */
+int hiopamd_kkt_mds_jac_jac_trans(hiopamd_kkt_mds* k, double* W, int64_t ldw);
 double* hiopamd_kkt_mds_Dd_inv(hiopamd_kkt_mds* k);       /* device, nineq: 1/(Dd + delta_wd) of the last build */
 double* hiopamd_kkt_mds_sys_matrix(hiopamd_kkt_mds* k);   /* device, N x N row-major, N = nxd+neq+nineq */
 double* hiopamd_kkt_mds_Hxs(hiopamd_kkt_mds* k);          /* device, nxs */
@@ -474,6 +476,9 @@ int hiopamd_iterate_adjust_duals_plh(hiopamd_kkt_xycyd* h, double* iter, double 
 int hiopamd_iterate_eval_log_barrier(hiopamd_kkt_xycyd* h, const double* iter, double* out_host);
 int hiopamd_iterate_linear_damping_term(hiopamd_kkt_xycyd* h, const double* iter, double mu, double kappa_d,
                                         double* out_host);
+/* hiopDualsLsqUpdateLinsysRedDense::do_lsq_update (src/Optimization/hiopDualsUpdater.cpp:239-330): least-squares
+ * estimate of the constraint duals; overwrites the yc, yd parts of `iter`; *ok_host = 0 if the m x m system is not SPD */
+int hiopamd_duals_lsq_update(hiopamd_kkt_xycyd* h, double* iter, const double* grad_f, int* ok_host);
 
 #ifdef __cplusplus
 }

@@ -177,3 +177,29 @@ def linear_damping_term(full, it, mu, kappa_d):                                 
             ho.linear_damping_term(it["sxu"], full.ixu, full.ixl, mu, kappa_d) +
             ho.linear_damping_term(it["sdl"], full.idl, full.idu, mu, kappa_d) +
             ho.linear_damping_term(it["sdu"], full.idu, full.idl, mu, kappa_d))
+
+
+def duals_lsq_update(full, it, grad_f):
+    """hiopDualsLsqUpdateLinsysRedDense::do_lsq_update (src/Optimization/hiopDualsUpdater.cpp:239-330): returns
+    (ok, yc, yd).  M = [Jc Jc^T, Jc Jd^T; Jd Jc^T, Jd Jd^T + I] (Cholesky, DPOTRF/DPOTRS in the reference)."""
+    p = full.p
+    me, mi = p.nyc, p.nyd
+    m = me + mi
+    # J as a dense matrix through the provider's products (columns of the identity) — small test sizes only
+    J = np.zeros((m, p.nx))
+    for r in range(m):
+        e = np.zeros(m)
+        e[r] = 1.0
+        J[r] = p.jac_trans_times_vec("c", e[:me]) + p.jac_trans_times_vec("d", e[me:])
+    M = J @ J.T                                                                    # :250-252
+    M[me:, me:] += np.eye(mi)                                                      # :256
+    vecx = grad_f - it["zl"] + it["zu"]                                            # :285-288
+    vecd = it["vl"] - it["vu"]                                                     # :290-291
+    rhs = -(J @ vecx)                                                              # :293-294
+    rhs[me:] -= vecd                                                               # :295
+    try:
+        L = np.linalg.cholesky(M)
+    except np.linalg.LinAlgError:
+        return False, None, None
+    sol = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+    return True, sol[:me].copy(), sol[me:].copy()

@@ -101,3 +101,65 @@ def test_step_routines(ctx):
     assert_parts(fg, trial_g2, trial_o, kf.ITER_PARTS, rtol=1e-13)
     assert ops.eval_log_barrier(it_g) == pytest.approx(osl.eval_log_barrier(fo, it), rel=1e-13)
     assert ops.linear_damping_term(it_g, 0.1, 1e-5) == pytest.approx(osl.linear_damping_term(fo, it, 0.1, 1e-5), rel=1e-13)
+
+
+@pytest.mark.parametrize("ns,nd,neq", [(8, 6, None), (64, 33, 17), (300, 70, 129)])
+def test_duals_lsq_update_mds(ctx, ns, nd, neq):
+    p, fo, fg, ops, it, bounds, rng = setup_case(ctx, ns, nd, neq)
+    nx = p.nxs + p.nxd
+    grad = rng.uniform(-1, 1, nx)
+    fo.it = it
+    ok_o, yc_o, yd_o = osl.duals_lsq_update(fo, it, grad)
+    it_g = fg.pack(it, kf.ITER_PARTS)
+    torch.cuda.synchronize()
+    ok_g = ops.duals_lsq_update(it_g, D(grad)); ctx.sync()
+    assert ok_g and ok_o
+    got = fg.unpack(it_g, kf.ITER_PARTS)
+    sc = max(np.abs(yc_o).max(), np.abs(yd_o).max())
+    np.testing.assert_allclose(got["yc"], yc_o, rtol=0, atol=1e-9 * sc)
+    np.testing.assert_allclose(got["yd"], yd_o, rtol=0, atol=1e-9 * sc)
+    for kname in kf.ITER_PARTS:          # nothing else moves
+        if kname not in ("yc", "yd"):
+            np.testing.assert_array_equal(got[kname], it[kname])
+
+
+def test_duals_lsq_update_dense_and_lowrank(ctx):
+    from hiop_amd.kkt import IpmSlabOps, KKTLinSysLowRank, KKTLinSysXYcYd
+    from oracle import hiop_oracle as ho
+    from tests.test_gpu_kkt_xycyd import lowrank_pair
+    # dense XYcYd back-end
+    nx, neq, nineq = 40, 6, 9
+    (H, Jc, Jd, ixl, ixu, idl, idu), fo, it = cases.dense_case(nx, neq, nineq, seed=5)
+    fg = KKTLinSysXYcYd(ctx, None, D(ixl), D(ixu), D(idl), D(idu), dense_dims=(nx, neq, nineq))
+    fg.set_matrices(D(H), D(Jc), D(Jd))
+    ops = IpmSlabOps(fg, None, None, None, None, None)
+    rng = np.random.Generator(np.random.PCG64(3))
+    grad = rng.uniform(-1, 1, nx)
+    ok_o, yc_o, yd_o = osl.duals_lsq_update(fo, it, grad)
+    it_g = fg.pack(it, kf.ITER_PARTS)
+    torch.cuda.synchronize()
+    assert ops.duals_lsq_update(it_g, D(grad)) and ok_o
+    ctx.sync()
+    got = fg.unpack(it_g, kf.ITER_PARTS)
+    np.testing.assert_allclose(np.concatenate([got["yc"], got["yd"]]), np.concatenate([yc_o, yd_o]), rtol=1e-9, atol=1e-11)
+    # low-rank back-end (Jacobians = the [Jc; Jd] copy of the last update)
+    n, me, mi = 3000, 3, 4
+    Ho, Hg, Jc, Jd, r = lowrank_pair(ctx, n, me, mi, seed=8)
+    ixl = (r.uniform(0, 1, n) < 0.7).astype(np.float64); ixu = (r.uniform(0, 1, n) < 0.3).astype(np.float64)
+    idl = np.ones(mi); idu = (r.uniform(0, 1, mi) < 0.5).astype(np.float64)
+    Ko = ho.KKTLinSysLowRank(Ho, me, mi)
+    fo = kf.KKTLinSysFull(kf.LowRankProvider(Ko, Jc, Jd), ixl, ixu, idl, idu, perturb=kf.PDPerturbationNull())
+    Kg = KKTLinSysLowRank(ctx, Hg)
+    fg = KKTLinSysXYcYd(ctx, Kg, D(ixl), D(ixu), D(idl), D(idu))
+    fg.set_matrices(None, D(Jc), D(Jd))
+    it = cases.random_iterate(n, mi, me, mi, ixl, ixu, idl, idu, seed=3)
+    it_g = fg.pack(it, kf.ITER_PARTS)
+    assert fo.update(it) and fg.update(it_g)
+    ops = IpmSlabOps(fg, None, None, None, None, None)
+    grad = r.uniform(-1, 1, n)
+    ok_o, yc_o, yd_o = osl.duals_lsq_update(fo, it, grad)
+    torch.cuda.synchronize()
+    assert ops.duals_lsq_update(it_g, D(grad)) and ok_o
+    ctx.sync()
+    got = fg.unpack(it_g, kf.ITER_PARTS)
+    np.testing.assert_allclose(np.concatenate([got["yc"], got["yd"]]), np.concatenate([yc_o, yd_o]), rtol=1e-9, atol=1e-11)
