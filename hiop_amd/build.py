@@ -29,6 +29,7 @@ SOURCES = [
     "kkt_mds.hip",
     "lowrank.hip",
     "kkt_xycyd.hip",
+    "io.hip",
 ]
 
 ARCH = "gfx950"

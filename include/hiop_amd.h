@@ -480,6 +480,15 @@ int hiopamd_iterate_linear_damping_term(hiopamd_kkt_xycyd* h, const double* iter
  * estimate of the constraint duals; overwrites the yc, yd parts of `iter`; *ok_host = 0 if the m x m system is not SPD */
 int hiopamd_duals_lsq_update(hiopamd_kkt_xycyd* h, double* iter, const double* grad_f, int* ok_host);
 
+/* =====================================================================================
+ * `.iajaaa` linear-system dumps (reference: src/Utils/hiopCSR_IO.hpp:44-152, src/LinAlg/csr_iajaaa.md) — the
+ * `write_kkt yes` debugging path; byte-compatible with upstream tooling (load_kkt_mat.m).  `path` is a host string;
+ * the matrix is the row-major upper triangle BEFORE factorisation (write it between build and factorize).
+ * ===================================================================================== */
+int hiopamd_io_write_iajaaa_matrix(hiopamd_ctx* ctx, const char* path, int m, const double* M_dev, int64_t ld, int nx,
+                                   int meq, int mineq);
+int hiopamd_io_append_iajaaa_vector(hiopamd_ctx* ctx, const char* path, int m, const double* v_dev);
+
 #ifdef __cplusplus
 }
 #endif

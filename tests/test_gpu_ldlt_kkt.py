@@ -277,3 +277,28 @@ def test_ipm_iterations_on_the_hip_kkt_track_the_cpu_path(ctx, ns, nd):
         gold = json.loads((GOLD / "selfcheck_objectives.json").read_text())["MdsEx1"]
         assert abs(r_gpu["obj"] - gold["objective"]) < 1e-4
     ad.k.close()
+
+
+@pytest.mark.parametrize("fname", ["kkt_linsys_0.iajaaa", "kkt_linsys_10.iajaaa"])
+def test_iajaaa_writer_reproduces_reference_files(ctx, fname, tmp_path):
+    """hiopamd_io_write_iajaaa_matrix / _append_iajaaa_vector (hiopCSR_IO.hpp:44-152): a dump of the reference's own
+    matrix, rhs and solution from device memory must be token-for-token the file the reference wrote."""
+    import ctypes as C
+    import os
+    from hiop_amd._lib import lib, check
+    from oracle.iajaaa import read_iajaaa
+    src = os.path.join(os.path.dirname(__file__), "golden", fname)
+    g = read_iajaaa(src)
+    n = g["n"]
+    Md = torch.as_tensor(np.ascontiguousarray(g["M_upper"])).cuda()
+    out = str(tmp_path / fname).encode()
+    L = lib()
+    torch.cuda.synchronize()
+    check(L.hiopamd_io_write_iajaaa_matrix(ctx.h, C.c_char_p(out), n, C.c_void_p(Md.data_ptr()), n, g["nx"], g["neq"],
+                                           g["nineq"]), "write_iajaaa_matrix")
+    for rhs, sol in g["pairs"]:
+        for v in (rhs, sol):
+            vd = torch.as_tensor(np.ascontiguousarray(v)).cuda()
+            torch.cuda.synchronize()
+            check(L.hiopamd_io_append_iajaaa_vector(ctx.h, C.c_char_p(out), n, C.c_void_p(vd.data_ptr())), "append")
+    assert open(out.decode()).read().split() == open(src).read().split()
