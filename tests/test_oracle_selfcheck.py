@@ -34,3 +34,32 @@ def test_mds_ex1_empty_sparse_row_variant():
     b = ipm.solve_mds(pr.mds_ex1(40, 12, empty_sp_row=True), tol=1e-9)
     assert a["err"] < 1e-9 and b["err"] < 1e-9
     assert np.isfinite(a["obj"]) and np.isfinite(b["obj"])
+
+
+def _full_layer_setup(p):
+    from oracle import hiop_oracle as ho
+    from oracle import ipm_full, kkt_full as kf
+    k = ho.KKTLinSysCompressedMDSXYcYd(p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j), (p.Hss_i, p.Hss_j))
+    k.set_values(p.Jcs_v, p.Jds_v, p.Hss_v, p.Jcd, p.Jdd, p.Hdd, None, None)
+    f = lambda b: b.astype(np.float64)
+    ixl, ixu, idl, idu = f(p.xl > -1e20), f(p.xu < 1e20), f(p.dl > -1e20), f(p.du < 1e20)
+    full = kf.KKTLinSysFull(kf.MdsProvider(k), ixl, ixu, idl, idu)
+    bounds = (p.xl, p.xu, p.dl, p.du, np.zeros(p.neq))
+    model, q = ipm_full.mds_model(p)
+    return full, bounds, model, q
+
+
+def test_mds_ex1_selfcheck_objective_through_the_full_space_layer():
+    """The same stored objective, reached by an IPM written only in terms of the full-space layer's operations
+    (hiopResidual::update, XYcYd::update with inertia correction, compute_directions_w_IR, hiopIterate steps) — the
+    restatements in oracle/kkt_full.py and oracle/ipm_slab.py, composed."""
+    from oracle import ipm_full
+    g = GOLD["MdsEx1"]
+    p = pr.mds_ex1(*g["args"])
+    full, bounds, model, q = _full_layer_setup(p)
+    it0 = ipm_full.initial_iterate(full, bounds, p.x0, lambda x: model(x)[3], g["driver_mu0"])
+    ops = ipm_full.OracleOps(full, bounds, model)
+    r = ipm_full.solve(ops, it0, mu0=g["driver_mu0"], tol=g["driver_tolerance"])
+    assert r["err"] < g["driver_tolerance"]
+    assert abs(r["obj"] - g["objective"]) < 2e-4
+    assert r["iters"] < 40
