@@ -149,3 +149,26 @@ def barrier_diagonals(p: MdsProblem, seed: int = 20240916, mu: float = 0.1):
 def random_rhs(p: MdsProblem, seed: int = 7):
     rng = np.random.Generator(np.random.PCG64(seed))
     return (rng.uniform(-1, 1, p.nxs + p.nxd), rng.uniform(-1, 1, p.neq), rng.uniform(-1, 1, p.nineq))
+
+
+def dense_ex2(n: int):
+    """The reference's DenseConsEx2 (src/Drivers/Dense/NlpDenseConsEx2.hpp:18-30, .cpp:60-330):
+        min sum 1/4 (x_i - 1)^4   s.t.  sum x_i = n+1;  5 <= 2 x_1 + sum_{i>=2} x_i;
+        1 <= 2 x_1 + 0.5 x_2 + sum_{i>=3} x_i <= 2n;   4 x_1 + 2 x_2 + 2 x_3 + sum_{i>=4} x_i <= 4n;
+        x_1 free, x_2 >= 0, 1.5 <= x_3 <= 10, x_i >= 0.5 (i >= 4);  x0 = 0.
+    Returned in HiOp's split form: equality Jacobian Jc (1 x n) with rhs, inequality Jacobian Jd (3 x n) with dl/du."""
+    assert n >= 4
+    Jc = np.ones((1, n))
+    Jd = np.ones((3, n))
+    Jd[0, 0] = 2.0
+    Jd[1, 0], Jd[1, 1] = 2.0, 0.5
+    Jd[2, 0], Jd[2, 1], Jd[2, 2] = 4.0, 2.0, 2.0
+    xl = np.full(n, 0.5)
+    xu = np.full(n, 1e20)
+    xl[0] = -1e20
+    xl[1] = 0.0
+    xl[2], xu[2] = 1.5, 10.0
+    return dict(n=n, Jc=Jc, Jd=Jd, crhs=np.array([n + 1.0]), dl=np.array([5.0, 1.0, -1e20]),
+                du=np.array([1e20, 2.0 * n, 4.0 * n]), xl=xl, xu=xu, x0=np.zeros(n),
+                f=lambda x: 0.25 * float(np.sum((x - 1.0) ** 4)), grad=lambda x: (x - 1.0) ** 3,
+                hess_diag=lambda x: 3.0 * (x - 1.0) ** 2)

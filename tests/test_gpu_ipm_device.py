@@ -105,3 +105,89 @@ def test_device_ipm_follows_the_oracle_and_reaches_the_selfcheck_objective(ctx, 
     np.testing.assert_allclose(r_gpu["x"], r_cpu["x"], rtol=0, atol=1e-7 * max(1.0, np.abs(r_cpu["x"]).max()))
     if (ns, nd) == (400, 100):
         assert abs(r_gpu["obj"] - GOLD["MdsEx1"]["objective"]) < 2e-4
+
+
+class DeviceOpsDenseEx2:
+    """DenseConsEx2 on the quasi-Newton low-rank path, everything in HBM: the problem callbacks are torch expressions on
+    device tensors (the role of the user's eval_f / eval_grad_f / eval_cons with mem_space = device), the secant update,
+    KKT, residuals and steps are the library's."""
+
+    def __init__(self, ctx, q, full_o, bounds):
+        from hiop_amd.kkt import HessianLowRank, IpmSlabOps, KKTLinSysLowRank, KKTLinSysXYcYd
+        self.ctx, self.n = ctx, q["n"]
+        self.Jc, self.Jd = D(q["Jc"]), D(q["Jd"])
+        self.H = HessianLowRank(ctx, self.n, 1, 3, l_max=6, sigma0=1.0, sigma_update_strategy="sigma0")
+        self.K = KKTLinSysLowRank(ctx, self.H)
+        self.fg = KKTLinSysXYcYd(ctx, self.K, D(full_o.ixl), D(full_o.ixu), D(full_o.idl), D(full_o.idu))
+        self.fg.set_matrices(None, self.Jc, self.Jd)
+        self.ops = IpmSlabOps(self.fg, *[D(b) for b in bounds])
+        self.o = self.fg.off
+
+    def from_host(self, it):
+        return self.fg.pack(it, kf.ITER_PARTS)
+
+    def primal(self, it):
+        return it[:self.n].cpu().numpy()
+
+    def evaluate(self, it):
+        self.ctx.sync()
+        x = it[:self.n]
+        t = x - 1.0
+        f = 0.25 * float((t ** 4).sum())
+        self.grad = (t ** 3).contiguous()
+        self.c = (self.Jc @ x).contiguous()
+        self.d = (self.Jd @ x).contiguous()
+        torch.cuda.synchronize()
+        return f, self.grad, self.c, self.d
+
+    def residual(self, it, ev, mu, kappa_d):
+        resid = torch.empty_like(it)
+        torch.cuda.synchronize()
+        return resid, self.ops.residual_update(it, ev[2], ev[3], ev[1], mu, kappa_d, resid)
+
+    def kkt_update(self, it, mu):
+        o = self.o
+        x, yc, yd = it[o[0]:o[1]], it[o[2]:o[3]], it[o[3]:o[4]]
+        self.H.update(x, self.grad, self.Jc, self.Jd, yc, yd)
+        self.fg.set_mu(mu)
+        return self.fg.update(it)
+
+    def directions(self, resid):
+        d = torch.empty_like(resid)
+        torch.cuda.synchronize()
+        ok, info = self.fg.compute_directions_w_IR(resid, d)
+        return ok, d
+
+    def fraction_to_the_bdry(self, it, d, tau):
+        return self.ops.fraction_to_the_bdry(it, d, tau)
+
+    def step(self, it, d, ap, ad, mu):
+        trial = it.clone()
+        torch.cuda.synchronize()
+        self.ops.take_step(trial, it, d, ap, ad)
+        self.ops.determine_slacks(trial)
+        nadj = self.ops.adjust_small_slacks(trial, it, mu)
+        self.ops.adjust_duals_plh(trial, mu, 1e10)
+        self.ctx.sync()
+        return trial, nadj
+
+    def n_refactorizations(self):
+        return 0
+
+
+@pytest.mark.parametrize("n", [500, 5000])
+def test_device_quasi_newton_ipm_dense_ex2(ctx, n):
+    """Quasi-Newton (L-BFGS, l = 6) interior-point solve of the reference's DenseConsEx2 with the low-rank KKT path on the
+    device; convex problem -> the optimum 1/64 whatever the path; the reference stores 1.5625102e-2 for its own
+    early-terminated run (src/Drivers/Dense/NlpDenseConsEx2Driver.cpp:124-125, 6 digits)."""
+    from tests.test_oracle_selfcheck import _dense_ex2_setup
+    q, full, bounds, prov = _dense_ex2_setup(n, lowrank=True)
+    it0 = ipm_full.initial_iterate(full, bounds, q["x0"], lambda x: q["Jd"] @ x, 0.1)
+    dev = DeviceOpsDenseEx2(ctx, q, full, bounds)
+    t = []
+    r = ipm_full.solve(dev, it0, mu0=0.1, tol=1e-7, max_iter=400, trace=t)
+    assert r["err"] < 1e-7
+    assert 0.0 <= r["obj"] - 1.0 / 64 < 2e-7
+    gold = GOLD["DenseConsEx2"]
+    assert r["obj"] == pytest.approx(gold["objective"][gold["n"].index(n)], rel=1e-5)
+    assert r["iters"] < 200

@@ -63,3 +63,65 @@ def test_mds_ex1_selfcheck_objective_through_the_full_space_layer():
     assert r["err"] < g["driver_tolerance"]
     assert abs(r["obj"] - g["objective"]) < 2e-4
     assert r["iters"] < 40
+
+
+def _dense_ex2_setup(n, lowrank):
+    from oracle import hiop_oracle as ho
+    from oracle import ipm_full, kkt_full as kf
+    q = pr.dense_ex2(n)
+    f = lambda b: b.astype(np.float64)
+    ixl, ixu, idl, idu = f(q["xl"] > -1e20), f(q["xu"] < 1e20), f(q["dl"] > -1e20), f(q["du"] < 1e20)
+    bounds = (q["xl"], q["xu"], q["dl"], q["du"], q["crhs"])
+    if lowrank:
+        H = ho.HessianLowRank(n, l_max=6, sigma0=1.0, sigma_update_strategy="sigma0")
+        K = ho.KKTLinSysLowRank(H, 1, 3)
+        prov = kf.LowRankProvider(K, q["Jc"], q["Jd"])
+        full = kf.KKTLinSysFull(prov, ixl, ixu, idl, idu, perturb=kf.PDPerturbationNull())
+    else:
+        prov = kf.DenseXYcYdProvider(np.eye(n), q["Jc"], q["Jd"])
+        full = kf.KKTLinSysFull(prov, ixl, ixu, idl, idu)
+    return q, full, bounds, prov
+
+
+def test_dense_ex2_selfcheck_objective_newton_through_the_dense_xycyd_backend():
+    """DenseConsEx2 is convex, so its optimum does not depend on the Hessian approximation: a Newton barrier method
+    through hiopKKTLinSysDenseXYcYd's restatement must land on the objective the reference's quasi-Newton run stores
+    (src/Drivers/Dense/NlpDenseConsEx2Driver.cpp:124, n = 500, 6 digits)."""
+    from oracle import ipm_full
+    g = GOLD["DenseConsEx2"]
+    n = g["n"][0]
+    q, full, bounds, prov = _dense_ex2_setup(n, lowrank=False)
+
+    def model(x):
+        prov.H = np.diag(q["hess_diag"](x))
+        return q["f"](x), q["grad"](x), q["Jc"] @ x, q["Jd"] @ x
+    it0 = ipm_full.initial_iterate(full, bounds, q["x0"], lambda x: q["Jd"] @ x, 0.1)
+    r = ipm_full.solve(ipm_full.OracleOps(full, bounds, model), it0, mu0=0.1, tol=1e-8)
+    assert r["err"] < 1e-8
+    # the exact optimum is 1/64 (x_3 = 1.5 on its bound, every other x_i = 1); the reference's quasi-Newton run stops
+    # 1.0e-7 above it (6.5e-6 relative), this converged run 1e-9 above it
+    assert 0.0 <= r["obj"] - 1.0 / 64 < 1e-8
+    assert r["obj"] == pytest.approx(g["objective"][0], rel=1e-5)
+
+
+def test_dense_ex2_selfcheck_objective_quasi_newton_through_the_lowrank_backend():
+    """The same optimum with the secant (L-BFGS, l = 6) Hessian of the quasi-Newton path: hiopHessianLowRank::update every
+    iteration, hiopKKTLinSysLowRank behind the full-space layer."""
+    from oracle import ipm_full
+    g = GOLD["DenseConsEx2"]
+    n = g["n"][0]
+    q, full, bounds, prov = _dense_ex2_setup(n, lowrank=True)
+    state = {}
+
+    def model(x):
+        return q["f"](x), q["grad"](x), q["Jc"] @ x, q["Jd"] @ x
+
+    class Ops(ipm_full.OracleOps):
+        def kkt_update(self, it, mu):       # the secant update precedes the KKT update (hiopAlgFilterIPMQuasiNewton::run)
+            prov.K.H.update(it["x"], q["grad"](it["x"]), q["Jc"], q["Jd"], it["yc"], it["yd"])
+            return super().kkt_update(it, mu)
+    it0 = ipm_full.initial_iterate(full, bounds, q["x0"], lambda x: q["Jd"] @ x, 0.1)
+    r = ipm_full.solve(Ops(full, bounds, model), it0, mu0=0.1, tol=1e-7, max_iter=400)
+    assert r["err"] < 1e-7
+    assert 0.0 <= r["obj"] - 1.0 / 64 < 2e-7
+    assert r["obj"] == pytest.approx(g["objective"][0], rel=1e-5)
