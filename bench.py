@@ -95,7 +95,8 @@ def dense_lowrank_bench(ctx, world, rank, a, dist):
     gl = torch.Generator(device="cuda"); gl.manual_seed(1000 + rank)     # local (sharded) data
     gr = torch.Generator(device="cuda"); gr.manual_seed(7)               # replicated data
     U = lambda g, *shape, lo=-1.0, hi=1.0: torch.rand(*shape, generator=g, device="cuda", dtype=torch.float64) * (hi - lo) + lo
-    Jc, Jd = U(gl, me, n), U(gl, mi, n)
+    J = U(gl, me + mi, n)                    # [Jc; Jd] stored as one block: the KKT object borrows it (no 2 GB copy per update)
+    Jc, Jd = J[:me], J[me:]
     q = U(gl, n, lo=0.5, hi=3.0)
     x = U(gl, n)
     H = HessianLowRank(ctx, n, me, mi, l_max=l, sigma0=1.0, sigma_update_strategy="sty")

@@ -521,7 +521,8 @@ struct hiopamd_kkt_lowrank {
   hiopamd_hess_lowrank* H = nullptr;
   int64_t n = 0;
   int m_eq = 0, m_ineq = 0;
-  double *J = nullptr;        // k x n   ([Jc; Jd])
+  double *J = nullptr;        // k x n   ([Jc; Jd]) owned copy, used when the caller's Jc / Jd are not adjacent
+  const double* Jcur = nullptr;   // the [Jc; Jd] in use: K->J or the caller's own contiguous storage (no copy)
   double *N = nullptr;        // k x k
   double *Dd_inv = nullptr;   // m_ineq
   double *Dx = nullptr;       // n
@@ -530,6 +531,8 @@ struct hiopamd_kkt_lowrank {
   size_t work_cnt = 0;
   double last_resid = 0.0;
 };
+
+static int lowrank_set_J(hiopamd_kkt_lowrank* K, const double* Jc, const double* Jd);
 
 extern "C" {
 
@@ -546,7 +549,8 @@ int hiopamd_kkt_lowrank_create(hiopamd_kkt_lowrank** out, hiopamd_ctx* ctx, hiop
   const size_t kw = k + 2 * (size_t)H->l_max;
   K->work_cnt = k * kw + k * 2 * H->l_max + 3 * k * k + 16 * k + 64;
   auto A = [](double** p, size_t cnt) { return hipMalloc((void**)p, sizeof(double) * (cnt ? cnt : 1)) == hipSuccess; };
-  if(!(A(&K->J, k * n) && A(&K->N, k * k) && A(&K->Dd_inv, K->m_ineq) && A(&K->Dx, n) && A(&K->rhs, k) &&
+  (void)n;   // K->J (k x n) is allocated lazily, only if the caller's Jacobians are not one contiguous block
+  if(!(A(&K->N, k * k) && A(&K->Dd_inv, K->m_ineq) && A(&K->Dx, n) && A(&K->rhs, k) &&
        A(&K->work, K->work_cnt))) {
     hiopamd_kkt_lowrank_destroy(K);
     return HIOPAMD_ERR_HIP;
@@ -591,14 +595,32 @@ int hiopamd_kkt_lowrank_update(hiopamd_kkt_lowrank* K, const double* zl, const d
     Ddi[i] = 1.0 / d;   // (:1081-1088)
   }));
   // J = [Jc; Jd]  (copyRowsFrom, :1127-1128 — done once per update instead of once per solveCompressed)
-  RC(hiopamd_vec_copy(ctx, (int64_t)K->m_eq * n, K->J, Jc));
-  RC(hiopamd_vec_copy(ctx, (int64_t)K->m_ineq * n, K->J + (int64_t)K->m_eq * n, Jd));
+  RC(lowrank_set_J(K, Jc, Jd));
   return HIOPAMD_OK;
 }
 
 // direct variant for callers that already hold Dx and Dd (= vl/sdl + vu/sdu)
+// [Jc; Jd] as one k x n block: borrowed if the caller already stores Jd right after Jc (the 2 GB copy per update is
+// 1.6 ms at n_local = 1.25e6, k = 200), copied otherwise
+static int lowrank_set_J(hiopamd_kkt_lowrank* K, const double* Jc, const double* Jd)
+{
+  const int64_t n = K->n;
+  if(K->m_eq == 0 && K->m_ineq > 0) {
+    K->Jcur = Jd;
+  } else if(K->m_ineq == 0 || Jd == Jc + (int64_t)K->m_eq * n) {
+    K->Jcur = Jc;
+  } else {
+    if(!K->J && hipMalloc((void**)&K->J, sizeof(double) * (size_t)(K->m_eq + K->m_ineq) * (size_t)(n > 0 ? n : 1)) != hipSuccess)
+      return HIOPAMD_ERR_HIP;
+    RC(hiopamd_vec_copy(K->ctx, (int64_t)K->m_eq * n, K->J, Jc));
+    RC(hiopamd_vec_copy(K->ctx, (int64_t)K->m_ineq * n, K->J + (int64_t)K->m_eq * n, Jd));
+    K->Jcur = K->J;
+  }
+  return HIOPAMD_OK;
+}
+
 double* hiopamd_kkt_lowrank_Dd_inv(hiopamd_kkt_lowrank* K) { return K ? K->Dd_inv : nullptr; }
-double* hiopamd_kkt_lowrank_J(hiopamd_kkt_lowrank* K) { return K ? K->J : nullptr; }
+double* hiopamd_kkt_lowrank_J(hiopamd_kkt_lowrank* K) { return K ? const_cast<double*>(K->Jcur ? K->Jcur : K->J) : nullptr; }
 hiopamd_hess_lowrank* hiopamd_kkt_lowrank_hess(hiopamd_kkt_lowrank* K) { return K ? K->H : nullptr; }
 int hiopamd_kkt_lowrank_dims(const hiopamd_kkt_lowrank* K, int64_t* n_local_host, int* m_eq_host, int* m_ineq_host)
 {
@@ -619,8 +641,7 @@ int hiopamd_kkt_lowrank_update_diag(hiopamd_kkt_lowrank* K, const double* Dx_in,
   RC(hiopamd_hess_lowrank_update_log_barrier_diagonal(K->H, K->Dx));
   double* Ddi = K->Dd_inv;
   RC(launch_ew(ctx, K->m_ineq, [=] __device__(int64_t i) { Ddi[i] = 1.0 / Dd[i]; }));
-  RC(hiopamd_vec_copy(ctx, (int64_t)K->m_eq * n, K->J, Jc));
-  RC(hiopamd_vec_copy(ctx, (int64_t)K->m_ineq * n, K->J + (int64_t)K->m_eq * n, Jd));
+  RC(lowrank_set_J(K, Jc, Jd));
   return HIOPAMD_OK;
 }
 
@@ -634,7 +655,7 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
   const int me = K->m_eq, mi = K->m_ineq, k = me + mi;
   if(ok_host) *ok_host = 1;
   // N = J (H+Dx)^-1 J^T                                                       (:1132)
-  RC(hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(K->H, 0.0, K->N, k, 1.0, K->J, K->work));
+  RC(hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(K->H, 0.0, K->N, k, 1.0, K->Jcur, K->work));
   // N[me.., me..] += Dd^-1                                                     (:1135)
   RC(hiopamd_mat_add_sub_diagonal(ctx, K->N, k, me, 1.0, K->Dd_inv, 0, mi));
   // dx = (H+Dx)^-1 rx                                                          (:1147)
@@ -644,9 +665,9 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
   if(ctx->comm_rank == 0) {
     RC(hiopamd_vec_copy(ctx, me, rhs, ryc));
     RC(hiopamd_vec_copy(ctx, mi, rhs + me, ryd));
-    RC(hiopamd_mat_times_vec(ctx, k, n, K->J, n, -1.0, rhs, 1.0, dx));
+    RC(hiopamd_mat_times_vec(ctx, k, n, K->Jcur, n, -1.0, rhs, 1.0, dx));
   } else {
-    RC(hiopamd_mat_times_vec(ctx, k, n, K->J, n, 0.0, rhs, 1.0, dx));
+    RC(hiopamd_mat_times_vec(ctx, k, n, K->Jcur, n, 0.0, rhs, 1.0, dx));
   }
   RC(allreduce_dev(ctx, rhs, (size_t)k, HIOPAMD_SUM));
   // solve N [dyc; dyd] = rhs with equilibration + refinement                  (:1169, solveWithRefin :1192)
@@ -659,7 +680,7 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
   RC(hiopamd_vec_copy(ctx, me, dyc, rhs));
   RC(hiopamd_vec_copy(ctx, mi, dyd, rhs + me));
   // rx = rx - J^T [dyc; dyd] ; dx = (H+Dx)^-1 rx                               (:1178-1180)
-  RC(hiopamd_mat_trans_times_vec(ctx, k, n, K->J, n, 1.0, rx, -1.0, rhs));
+  RC(hiopamd_mat_trans_times_vec(ctx, k, n, K->Jcur, n, 1.0, rx, -1.0, rhs));
   RC(hiopamd_hess_lowrank_solve(K->H, rx, dx));
   return HIOPAMD_OK;
 }
