@@ -75,11 +75,15 @@ __device__ __forceinline__ void gram_stage(const GramRows X, int nrows, int r0, 
 __global__ __launch_bounds__(kBlock, 2) void gram_partial_kernel(int ma, int mb, int64_t n, const GramRows A,
                                                                  const GramRows B, int same_ab, int vec_all,
                                                                  const double* __restrict__ d, int64_t kchunk,
-                                                                 int tiles_b, int sym, double* __restrict__ partial)
+                                                                 int tiles_b, int sym, int sym_cols,
+                                                                 double* __restrict__ partial)
 {
   const int tile = blockIdx.y;
   const int ta = tile / tiles_b, tb = tile % tiles_b;
   if(sym && tb < ta) return;
+  // stacked product A D [A; B1; B2]^T: a tile below the diagonal whose columns all belong to the A block is the
+  // transpose of a tile above it -> not computed, the fold kernel mirrors it
+  if(sym_cols > 0 && tb < ta && (tb + 1) * GR_T <= sym_cols) return;
   const int split = blockIdx.x;
   const int64_t kbeg = (int64_t)split * kchunk;
   int64_t kend = kbeg + kchunk;
@@ -135,15 +139,18 @@ __global__ __launch_bounds__(kBlock, 2) void gram_partial_kernel(int ma, int mb,
 }
 
 __global__ __launch_bounds__(kBlock) void gram_fold_kernel(int ma, int mb, int nsplit, int ntiles, int tiles_b, int sym,
-                                                           const double* __restrict__ partial, double beta,
+                                                           int sym_cols, const double* __restrict__ partial, double beta,
                                                            double* __restrict__ W, int64_t ldw, double alpha)
 {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if(e >= (int64_t)ma * mb) return;
   const int i = (int)(e / mb), j = (int)(e % mb);
   if(sym && j < i) return;
-  const int tile = (i / GR_T) * tiles_b + (j / GR_T);
-  const int off = (i % GR_T) * GR_T + (j % GR_T);
+  // element of a skipped (mirrored) tile: read the transposed element's partials
+  const bool mirrored = sym_cols > 0 && (j / GR_T) < (i / GR_T) && ((j / GR_T) + 1) * GR_T <= sym_cols;
+  const int si = mirrored ? j : i, sj = mirrored ? i : j;
+  const int tile = (si / GR_T) * tiles_b + (sj / GR_T);
+  const int off = (si % GR_T) * GR_T + (sj % GR_T);
   double s = 0.0;
   for(int sp = 0; sp < nsplit; ++sp) s += partial[((int64_t)sp * ntiles + tile) * (GR_T * GR_T) + off];
   double* w = W + (int64_t)i * ldw + j;
@@ -151,6 +158,76 @@ __global__ __launch_bounds__(kBlock) void gram_fold_kernel(int ma, int mb, int n
   *w = v;
   // symmetric product: mirror onto the lower triangle, exactly like the reference's
   // Wdata[i*k+j] = Wdata[j*k+i] = beta*Wdata[i*k+j] + alpha*acc  (hiopHessianLowRank.cpp:1107)
+  if(sym && j > i) W[(int64_t)j * ldw + i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small Gram: ma, mb <= 8 (the l x l blocks of the compact L-BFGS representation, l <= 8).  The 128 x 128 MFMA tile
+// above would do (128/l)^2 times the useful work (1.1 ms for a 6 x 6 block at n = 1.25e6); this one is a plain
+// streaming reduction: every thread owns columns k = k0 + t, k0 + t + 256, ..., keeps the ma x mb running sums in
+// registers, the workgroup reduces them through LDS in a fixed order, a second launch folds the workgroups' partials.
+// HBM-bound: (ma + mb + 1) * n * 8 bytes.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GS_M = 8;
+
+__global__ __launch_bounds__(kBlock) void gram_small_partial(int ma, int mb, int64_t n, const double* __restrict__ A,
+                                                             int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                                             const double* __restrict__ d, int64_t kchunk,
+                                                             double* __restrict__ partial)
+{
+  const int64_t kbeg = (int64_t)blockIdx.x * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if(kend > n) kend = n;
+  double acc[GS_M][GS_M];
+#pragma unroll
+  for(int i = 0; i < GS_M; ++i)
+#pragma unroll
+    for(int j = 0; j < GS_M; ++j) acc[i][j] = 0.0;
+  for(int64_t k = kbeg + threadIdx.x; k < kend; k += kBlock) {
+    const double w = d ? d[k] : 1.0;
+    double a[GS_M], b[GS_M];
+#pragma unroll
+    for(int i = 0; i < GS_M; ++i) a[i] = (i < ma) ? A[(int64_t)i * lda + k] * w : 0.0;
+#pragma unroll
+    for(int j = 0; j < GS_M; ++j) b[j] = (j < mb) ? B[(int64_t)j * ldb + k] : 0.0;
+#pragma unroll
+    for(int i = 0; i < GS_M; ++i)
+#pragma unroll
+      for(int j = 0; j < GS_M; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  }
+  // fixed-order reduction: wave shuffle tree, then the 4 waves through LDS
+  __shared__ double red[kBlock / 64][GS_M * GS_M];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for(int i = 0; i < GS_M; ++i)
+#pragma unroll
+    for(int j = 0; j < GS_M; ++j) {
+      double v = acc[i][j];
+      for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if(lane == 0) red[wave][i * GS_M + j] = v;
+    }
+  __syncthreads();
+  if(threadIdx.x < GS_M * GS_M) {
+    const int e = threadIdx.x;
+    partial[(int64_t)blockIdx.x * (GS_M * GS_M) + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+  }
+}
+
+// one wave per output element: lane-strided partial sums, shuffle tree (fixed order)
+__global__ __launch_bounds__(64) void gram_small_fold(int ma, int mb, int nsplit, int sym, const double* __restrict__ partial,
+                                                      double beta, double* __restrict__ W, int64_t ldw, double alpha)
+{
+  const int e = blockIdx.x;
+  const int i = e / GS_M, j = e % GS_M;
+  if(i >= ma || j >= mb) return;
+  if(sym && j < i) return;
+  double s = 0.0;
+  for(int sp = threadIdx.x; sp < nsplit; sp += 64) s += partial[(int64_t)sp * (GS_M * GS_M) + e];
+  for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if(threadIdx.x != 0) return;
+  double* w = W + (int64_t)i * ldw + j;
+  const double v = (beta == 0.0 ? 0.0 : beta * (*w)) + alpha * s;
+  *w = v;
   if(sym && j > i) W[(int64_t)j * ldw + i] = v;
 }
 
@@ -168,15 +245,37 @@ static bool seg_vec_ok(const GramRows& R, int nseg)
 // W(ma x mb) = beta*W + alpha * A diag(d) [B0;B1;B2]^T
 static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRows& A, int nsegA, const GramRows& B,
                        int nsegB, bool same_ab, const double* d, double beta, double* W, int64_t ldw, double alpha,
-                       int sym)
+                       int sym, int sym_cols = 0)
 {
   if(ma < 0 || mb < 0 || n < 0) return HIOPAMD_ERR_ARG;
   if(ma == 0 || mb == 0) return HIOPAMD_OK;
   const int symm = (sym && same_ab && ma == mb) ? 1 : 0;
+  if(ma <= GS_M && mb <= GS_M && nsegA == 1 && nsegB == 1 && n > 0) {   // streaming reduction for the tiny blocks
+    int nsplit = 512;
+    int64_t kchunk = (n + nsplit - 1) / nsplit;
+    if(kchunk < 4 * kBlock) kchunk = 4 * kBlock;
+    nsplit = (int)((n + kchunk - 1) / kchunk);
+    double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * GS_M * GS_M);
+    hipLaunchKernelGGL(gram_small_partial, dim3(nsplit), dim3(kBlock), 0, ctx->stream, ma, mb, n, A.p[0], A.ld[0], B.p[0],
+                       B.ld[0], d, kchunk, partial);
+    hipLaunchKernelGGL(gram_small_fold, dim3(GS_M * GS_M), dim3(64), 0, ctx->stream, ma, mb, nsplit, symm, partial, beta, W,
+                       ldw, alpha);
+    HIOPAMD_CHECK(hipGetLastError());
+    return HIOPAMD_OK;
+  }
   const int tiles_a = (ma + GR_T - 1) / GR_T, tiles_b = (mb + GR_T - 1) / GR_T;
   const int ntiles = tiles_a * tiles_b;
-  // K split: aim at ~2 workgroups per CU (512) over all tiles, chunk a multiple of the stage depth
-  int nsplit = 512 / ntiles;
+  // K split: aim at ~2 workgroups per CU (512) over the tiles that are actually computed (symmetric / mirrored ones
+  // return at once), chunk a multiple of the stage depth
+  int live_tiles = 0;
+  for(int ta = 0; ta < tiles_a; ++ta)
+    for(int tb = 0; tb < tiles_b; ++tb) {
+      if(symm && tb < ta) continue;
+      if(sym_cols > 0 && tb < ta && (tb + 1) * GR_T <= sym_cols) continue;
+      ++live_tiles;
+    }
+  if(live_tiles < 1) live_tiles = 1;
+  int nsplit = 480 / live_tiles;   // <= 2 per CU with some slack: a second partial round would double the time
   if(nsplit < 1) nsplit = 1;
   int64_t kchunk = (n + nsplit - 1) / nsplit;
   kchunk = ((kchunk + GR_KT - 1) / GR_KT) * GR_KT;
@@ -186,10 +285,10 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
   double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * ntiles * GR_T * GR_T);
   const int vec_all = (seg_vec_ok(A, nsegA) && seg_vec_ok(B, nsegB)) ? 1 : 0;
   hipLaunchKernelGGL(gram_partial_kernel, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, B,
-                     same_ab ? 1 : 0, vec_all, d, kchunk, tiles_b, symm, partial);
+                     same_ab ? 1 : 0, vec_all, d, kchunk, tiles_b, symm, sym_cols, partial);
   const int64_t tot = (int64_t)ma * mb;
   hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ma,
-                     mb, nsplit, ntiles, tiles_b, symm, partial, beta, W, ldw, alpha);
+                     mb, nsplit, ntiles, tiles_b, symm, sym_cols, partial, beta, W, ldw, alpha);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
 }
@@ -215,5 +314,8 @@ extern "C" int hiopamd_gram_weighted_stacked(hiopamd_ctx* ctx, int ma, int64_t n
   const double* q1 = m1 > 0 ? B1 : B0;
   const double* q2 = m2 > 0 ? B2 : q1;
   GramRows Rb{{B0, q1, q2}, {ldb0, m1 > 0 ? ldb1 : ldb0, m2 > 0 ? ldb2 : (m1 > 0 ? ldb1 : ldb0)}, {m0, m0 + m1, m0 + m1 + m2}};
-  return gram_launch(ctx, ma, m0 + m1 + m2, n, Ra, 1, Rb, 3, false, d, beta, W, ldw, alpha, 0);
+  // first column block = A itself -> its part of the result is symmetric: the tiles below the diagonal inside it are
+  // mirrored instead of computed (one tile in four at k = 200)
+  const int sym_cols = (B0 == A && ldb0 == lda && m0 == ma) ? m0 : 0;
+  return gram_launch(ctx, ma, m0 + m1 + m2, n, Ra, 1, Rb, 3, false, d, beta, W, ldw, alpha, 0, sym_cols);
 }

@@ -786,6 +786,8 @@ int hiopamd_kkt_xycyd_set_matrices(hiopamd_kkt_xycyd* h, const double* H, const 
   h->H = H;
   h->Jc = Jc;
   h->Jd = Jd;
+  // the low-rank object's [Jc; Jd] view is what the operator products use: make it valid before the first update
+  if(h->kind == KIND_LOWRANK) return hiopamd_kkt_lowrank_set_jacobians(h->lr, Jc, Jd);
   return HIOPAMD_OK;
 }
 

@@ -619,6 +619,12 @@ static int lowrank_set_J(hiopamd_kkt_lowrank* K, const double* Jc, const double*
   return HIOPAMD_OK;
 }
 
+int hiopamd_kkt_lowrank_set_jacobians(hiopamd_kkt_lowrank* K, const double* Jc, const double* Jd)
+{
+  if(!K || (K->m_eq > 0 && !Jc) || (K->m_ineq > 0 && !Jd)) return HIOPAMD_ERR_ARG;
+  return lowrank_set_J(K, Jc, Jd);
+}
+
 double* hiopamd_kkt_lowrank_Dd_inv(hiopamd_kkt_lowrank* K) { return K ? K->Dd_inv : nullptr; }
 double* hiopamd_kkt_lowrank_J(hiopamd_kkt_lowrank* K) { return K ? const_cast<double*>(K->Jcur ? K->Jcur : K->J) : nullptr; }
 hiopamd_hess_lowrank* hiopamd_kkt_lowrank_hess(hiopamd_kkt_lowrank* K) { return K ? K->H : nullptr; }

@@ -372,6 +372,8 @@ int hiopamd_kkt_lowrank_update_diag(hiopamd_kkt_lowrank* K, const double* Dx, co
 /* solveCompressed (:1110-1187); rx is modified like in the reference (:1178); *ok_host = 0 if N was not SPD */
 int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, const double* ryc, const double* ryd,
                                          double* dx, double* dyc, double* dyd, int* ok_host);
+/* Jacobians without touching the barrier diagonals (borrowed if Jd follows Jc in memory, copied into one block otherwise) */
+int hiopamd_kkt_lowrank_set_jacobians(hiopamd_kkt_lowrank* K, const double* Jc, const double* Jd);
 double* hiopamd_kkt_lowrank_Dd_inv(hiopamd_kkt_lowrank* K);   /* device, m_ineq */
 double* hiopamd_kkt_lowrank_J(hiopamd_kkt_lowrank* K);        /* device, (m_eq+m_ineq) x n_local: [Jc; Jd] of the last update */
 hiopamd_hess_lowrank* hiopamd_kkt_lowrank_hess(hiopamd_kkt_lowrank* K);

@@ -111,6 +111,21 @@ def test_gram_weighted_mfma(ctx, ma, mb, n):
         np.testing.assert_array_equal(got, got.T)
 
 
+@pytest.mark.parametrize("k,l,n", [(200, 6, 9000), (130, 3, 4097), (256, 8, 5000), (100, 6, 3000)])
+def test_gram_stacked_symmetric_block_is_mirrored(ctx, k, l, n):
+    """X D [X; S; Y]^T in one pass: the tiles below the diagonal inside the X x X block are not computed but mirrored by the
+    fold kernel (k > 128: two tile rows) — every entry, both triangles, against numpy."""
+    r = rng(k + l)
+    X = r.uniform(-1, 1, (k, n)); S = r.uniform(-1, 1, (l, n)); Y = r.uniform(-1, 1, (l, n)); d = r.uniform(0.1, 2.0, n)
+    kw = k + 2 * l
+    W0 = r.uniform(-1, 1, (k, kw))
+    Wd = D(W0)
+    Xd = D(X)
+    run(ctx, "hiopamd_gram_weighted_stacked", k, n, Xd, n, k, Xd, n, l, D(S), n, l, D(Y), n, D(d), 0.25, Wd, kw, 1.5)
+    e = 0.25 * W0 + 1.5 * (X * d) @ np.vstack([X, S, Y]).T
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-11, atol=1e-10)
+
+
 def test_assembly_kernels(ctx):
     r = rng(99)
     nW = 301

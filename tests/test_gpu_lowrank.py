@@ -94,7 +94,7 @@ def test_hessian_lowrank_against_oracle(ctx, n, me, mi, l_max, nupd, strategy):
     Hg.close()
 
 
-@pytest.mark.parametrize("n,me,mi", [(1000, 1, 0), (5000, 2, 2), (100003, 30, 70)])
+@pytest.mark.parametrize("n,me,mi", [(1000, 1, 0), (5000, 2, 2), (100003, 30, 70), (4000, 90, 110)])   # last: k = 200, 2 x 2 Gram tiles (mirrored tile)
 def test_kkt_lowrank_solve_compressed(ctx, n, me, mi):
     from hiop_amd.kkt import KKTLinSysLowRank
     Ho, Hg, (Jc, Jd), r, _ = drive(ctx, n, me, mi, 6, 9, "sigma0", seed=n + 1)
