@@ -12,6 +12,8 @@
 // upper triangle onto the lower one.
 #include "device_utils.hpp"
 
+#include <cstdlib>
+
 namespace hiopamd {
 
 constexpr int GR_T = 128;        // tile edge (rows of A x rows of B per workgroup)
@@ -136,6 +138,156 @@ __global__ __launch_bounds__(kBlock, 2) void gram_partial_kernel(int ma, int mb,
         P[row * GR_T + col] = acc[i][j][reg];
       }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// v3 of the tile kernel (default).  Same 128 x 128 tile per workgroup, 64 x 64 quadrant per wave, but
+//  * every 16 x 16 x 4 block product is FOUR v_mfma_f64_4x4x4_4b_f64 (block-diagonal 4 x 4 products; the B operand is read
+//    from LDS with its row index rotated by 0/4/8/12 inside the 16-row block): 75 TFLOP/s sustained on MI355X versus
+//    36-46 for v_mfma_f64_16x16x4_f64 (scripts/probes/mfma_f64_peak.hip);
+//  * NO workgroup barrier in the K loop: one s_barrier per 32-deep stage costs 1.6 us against 3.6 us of MFMA work
+//    (scripts/probes/mfma_lds_feed.hip: 74.6 -> 51.5 TFLOP/s), so every wave stages its OWN 64 A-rows and 64 B-rows
+//    in a private LDS region (2x the L2->LDS traffic, 62.6 TFLOP/s in the probe) and only orders its own LDS
+//    stores/loads;
+//  * one workgroup per CU (512 VGPRs per lane): the global loads of stage s+2 are in flight during the MFMAs of stage
+//    s+1 (64 prefetch doubles per lane).
+// acc[i][j][s] of lane l = element (A-row 4*((l>>2)&3) + (l>>4),  B-row ((l&15) + 4 s) & 15) of block (i, j).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock, 1) void gram_partial3_kernel(int ma, int mb, int64_t n, const GramRows A,
+                                                                  const GramRows B, int vec_all,
+                                                                  const double* __restrict__ d, int64_t kchunk,
+                                                                  int tiles_b, int sym, int sym_cols,
+                                                                  double* __restrict__ partial)
+{
+  const int tile = blockIdx.y;
+  const int ta = tile / tiles_b, tb = tile % tiles_b;
+  if(sym && tb < ta) return;
+  if(sym_cols > 0 && tb < ta && (tb + 1) * GR_T <= sym_cols) return;
+  const int split = blockIdx.x;
+  const int64_t kbeg = (int64_t)split * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if(kend > n) kend = n;
+  __shared__ __attribute__((aligned(16))) double Ws[4][GR_T][GR_LDS];   // per wave: rows 0..63 A, 64..127 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lk = lane >> 4, li = lane & 15;
+  const bool vec = vec_all != 0;
+  double(*W)[GR_LDS] = Ws[wave];
+
+  double acc[4][4][4];
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+#pragma unroll
+      for(int sft = 0; sft < 4; ++sft) acc[i][j][sft] = 0.0;
+
+  // this wave's rows: A rows ra0 + [0,64), B rows rb0 + [0,64); lane -> (row lk + 4 p, k pair 2 li)
+  const int ra0 = ta * GR_T + wr * 64, rb0 = tb * GR_T + wc * 64;
+  const double* srcA[16];
+  const double* srcB[16];
+#pragma unroll
+  for(int p = 0; p < 16; ++p) {
+    {
+      const int gr = ra0 + 4 * p + lk;
+      const int grc = (gr < ma) ? gr : (ma - 1);
+      const int seg = (grc < A.rows[0]) ? 0 : ((grc < A.rows[1]) ? 1 : 2);
+      const int base = (seg == 0) ? 0 : A.rows[seg - 1];
+      srcA[p] = A.p[seg] + (int64_t)(grc - base) * A.ld[seg];
+    }
+    {
+      const int gr = rb0 + 4 * p + lk;
+      const int grc = (gr < mb) ? gr : (mb - 1);
+      const int seg = (grc < B.rows[0]) ? 0 : ((grc < B.rows[1]) ? 1 : 2);
+      const int base = (seg == 0) ? 0 : B.rows[seg - 1];
+      srcB[p] = B.p[seg] + (int64_t)(grc - base) * B.ld[seg];
+    }
+  }
+  double pa0[16], pa1[16], pb0[16], pb1[16], w0 = 1.0, w1 = 1.0;
+  auto gload = [&](int64_t k0) {
+    const int64_t k = k0 + 2 * li;
+    const bool k1ok = k + 1 < kend;
+    const int64_t kc0 = (k < kend) ? k : (kend - 1), kc1 = k1ok ? (k + 1) : (kend - 1);
+#pragma unroll
+    for(int p = 0; p < 16; ++p) {
+      if(vec && k1ok) {
+        const double2 t = *reinterpret_cast<const double2*>(srcA[p] + k);
+        pa0[p] = t.x;
+        pa1[p] = t.y;
+        const double2 u = *reinterpret_cast<const double2*>(srcB[p] + k);
+        pb0[p] = u.x;
+        pb1[p] = u.y;
+      } else {
+        pa0[p] = srcA[p][kc0];
+        pa1[p] = srcA[p][kc1];
+        pb0[p] = srcB[p][kc0];
+        pb1[p] = srcB[p][kc1];
+      }
+    }
+    if(d) {
+      w0 = d[kc0];
+      w1 = d[kc1];
+    }
+  };
+  auto lstore = [&](int64_t k0) {
+    const int64_t k = k0 + 2 * li;
+    const bool k0ok = k < kend, k1ok = k + 1 < kend;
+#pragma unroll
+    for(int p = 0; p < 16; ++p) {
+      const int r = 4 * p + lk;
+      const bool aok = (ra0 + r) < ma, bok = (rb0 + r) < mb;
+      *reinterpret_cast<double2*>(&W[r][2 * li]) = double2{(aok && k0ok) ? pa0[p] * w0 : 0.0, (aok && k1ok) ? pa1[p] * w1 : 0.0};
+      *reinterpret_cast<double2*>(&W[64 + r][2 * li]) = double2{(bok && k0ok) ? pb0[p] : 0.0, (bok && k1ok) ? pb1[p] : 0.0};
+    }
+  };
+  auto compute = [&]() {
+    // operand reads right before each k-step: the probe reaches 74.5 TFLOP/s this way, pipelining them one step ahead adds
+    // 40 VGPRs for nothing (mfma_lds_feed.hip); two k-steps per loop trip bound what the scheduler may hoist
+#pragma unroll 2
+    for(int kk = 0; kk < GR_KT / 4; ++kk) {
+      double a[4], b[4][4];
+#pragma unroll
+      for(int i = 0; i < 4; ++i) a[i] = W[i * 16 + li][kk * 4 + lk];
+#pragma unroll
+      for(int j = 0; j < 4; ++j)
+#pragma unroll
+        for(int sft = 0; sft < 4; ++sft) b[j][sft] = W[64 + j * 16 + ((li + 4 * sft) & 15)][kk * 4 + lk];
+#pragma unroll
+      for(int i = 0; i < 4; ++i)
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+#pragma unroll
+          for(int sft = 0; sft < 4; ++sft)
+            acc[i][j][sft] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j][sft], acc[i][j][sft], 0, 0, 0);
+    }
+  };
+  if(kbeg < kend) {
+    gload(kbeg);
+    lstore(kbeg);
+    if(kbeg + GR_KT < kend) gload(kbeg + GR_KT);
+    for(int64_t k0 = kbeg; k0 < kend; k0 += GR_KT) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS stores are visible to its own reads
+      compute();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its reads are done before the region is refilled
+      if(k0 + GR_KT < kend) {
+        lstore(k0 + GR_KT);
+        if(k0 + 2 * GR_KT < kend) gload(k0 + 2 * GR_KT);
+      }
+    }
+  }
+  double* P = partial + ((int64_t)split * gridDim.y + tile) * (GR_T * GR_T);
+  const int arow = 4 * ((lane >> 2) & 3) + (lane >> 4);
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+#pragma unroll
+      for(int sft = 0; sft < 4; ++sft) {
+        const int row = wr * 64 + i * 16 + arow;
+        const int col = wc * 64 + j * 16 + ((li + 4 * sft) & 15);
+        P[row * GR_T + col] = acc[i][j][sft];
+      }
 }
 
 __global__ __launch_bounds__(kBlock) void gram_fold_kernel(int ma, int mb, int nsplit, int ntiles, int tiles_b, int sym,
@@ -275,7 +427,13 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
       ++live_tiles;
     }
   if(live_tiles < 1) live_tiles = 1;
-  int nsplit = 480 / live_tiles;   // <= 2 per CU with some slack: a second partial round would double the time
+  // HIOPAMD_GRAM_V2=1 selects the experimental 4x4x4 / wave-private-LDS kernel (gram_partial3_kernel); it is slower
+  // than the 16x16x4 kernel on the k = 200 stack (5.8 vs 4.4 ms, profiles/r01_probes/README.md) and stays opt-in
+  static int v2 = -1;
+  if(v2 < 0) v2 = std::getenv("HIOPAMD_GRAM_V2") ? std::atoi(std::getenv("HIOPAMD_GRAM_V2")) : 0;
+  // the default kernel runs two workgroups per CU, the experimental one a single one: size the split so that all
+  // live workgroups fit one round with some slack
+  int nsplit = (v2 ? 248 : 480) / live_tiles;
   if(nsplit < 1) nsplit = 1;
   int64_t kchunk = (n + nsplit - 1) / nsplit;
   kchunk = ((kchunk + GR_KT - 1) / GR_KT) * GR_KT;
@@ -284,8 +442,12 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
   if(nsplit < 1) nsplit = 1;
   double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * ntiles * GR_T * GR_T);
   const int vec_all = (seg_vec_ok(A, nsegA) && seg_vec_ok(B, nsegB)) ? 1 : 0;
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, B,
-                     same_ab ? 1 : 0, vec_all, d, kchunk, tiles_b, symm, sym_cols, partial);
+  if(v2)
+    hipLaunchKernelGGL(gram_partial3_kernel, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, B, vec_all, d,
+                       kchunk, tiles_b, symm, sym_cols, partial);
+  else
+    hipLaunchKernelGGL(gram_partial_kernel, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, B,
+                       same_ab ? 1 : 0, vec_all, d, kchunk, tiles_b, symm, sym_cols, partial);
   const int64_t tot = (int64_t)ma * mb;
   hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ma,
                      mb, nsplit, ntiles, tiles_b, symm, sym_cols, partial, beta, W, ldw, alpha);
