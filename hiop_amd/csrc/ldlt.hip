@@ -1359,6 +1359,421 @@ __global__ __launch_bounds__(SV_T) void ldlt_bwd_step256(const double* __restric
   if(tid < pb) x[p0 + tid] = xsh[tid];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Dataflow solve.  The stepwise solves above are bound by the serial chain "solve a 256 x 256 triangle, launch, apply":
+// 64 dependent launches of ~23 us per right-hand side against ~0.1 ms of memory traffic.  Here ONE launch runs the
+// whole solve as a task graph over the 256 x 256 blocks of U:
+//   * the diagonal blocks are inverted once per factorisation (W_J = U_JJ^-1, ldlt_inv_diag_kernel), so a diagonal
+//     solve is a block mat-vec like every other task;
+//   * one workgroup = one task = a 64-wide chunk of one block product.  It takes a ticket (tasks are issued in a
+//     topological order, so a task only ever waits for tasks that are already running), loads its 256 x 64 piece of
+//     the block into registers, and only THEN waits for its input vector: when the flag arrives the operand is
+//     resident and the critical path per block step is two flag hops + 64 fused multiply-adds;
+//   * off-diagonal tasks write their product to a private slot, the diagonal task adds the slots in a fixed order:
+//     no floating-point atomics, results are bitwise reproducible from run to run.
+// Flags are monotone 64-bit counters compared against epoch * (expected count), so nothing is reset between solves.
+// ------------------------------------------------------------------------------------------
+constexpr int FL_R = 4;   // 64-wide chunks per 256-block
+constexpr int FL_LEAD = 3;   // block steps of lead of the operand loads over the chain (see the pacing note in the kernel)
+enum { FL_FWD_OFF = 0, FL_FWD_DIAG = 1, FL_BWD_OFF = 2, FL_BWD_DIAG = 3 };
+
+// Everything one task hands to another (y, x, the product slots) moves with agent-scope relaxed atomic loads and stores:
+// they are coherent across the XCDs' L2s by themselves, so no cache write-back / invalidate sits on the critical path
+// (acquire/release fences cost 1.9 us per hop against 1.1 us this way, scripts/probes/flag_hop_probe.hip — and a
+// release fence per task throttles the whole kernel: every one walks the L2).
+__device__ __forceinline__ double flow_ld(const double* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flow_st(double* p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The one input a task on the critical path waits for (y_I for the sub-diagonal product, that product for the next
+// diagonal task) is not announced by a flag at all: the consumer polls the data words themselves, which hold a poison
+// pattern until the producer's store lands — one memory round trip per hop instead of three (store-ack, flag add, flag
+// poll, data load).  The exchange buffers exist twice; a launch uses the copy of its epoch's parity and every producer
+// re-poisons the words it will write in the NEXT launch.
+constexpr unsigned long long FL_POISON = 0x7FF8A5A5DEADBEEFull;   // a quiet NaN no arithmetic produces
+__device__ __forceinline__ double flow_poll(const double* p)
+{
+  unsigned long long u;
+  while((u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == FL_POISON)
+    __builtin_amdgcn_s_sleep(1);
+  return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ void flow_poison(double* p)
+{
+  __hip_atomic_store((unsigned long long*)p, FL_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// v - sum of `cnt` product slots p[0], p[stride], ... (fixed order; eight loads in flight at a time)
+__device__ __forceinline__ double flow_sub_slots(double v, const double* p, int64_t stride, int cnt)
+{
+  int i = 0;
+  for(; i + 8 <= cnt; i += 8) {
+    double t[8];
+#pragma unroll
+    for(int k = 0; k < 8; ++k) t[k] = flow_ld(p + (int64_t)(i + k) * stride);
+#pragma unroll
+    for(int k = 0; k < 8; ++k) v -= t[k];
+  }
+  for(; i < cnt; ++i) v -= flow_ld(p + (int64_t)i * stride);
+  return v;
+}
+
+__device__ __forceinline__ void flow_wait(const unsigned long long* p, unsigned long long target)
+{
+  if(threadIdx.x == 0) {
+    while(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+
+// Wait for flag idx of a chain of flags that complete in order (step = -1: idx-1 completes before idx; +1: idx+1 does).
+// Hundreds of resident tasks wait at any time; if they all polled their own flag at full rate the few flags about to
+// flip would sit behind a queue of atomic loads.  So a task first watches the flags two and one steps ahead of its own
+// with long sleeps and only then polls its own tightly: the number of tight pollers stays at the handful of tasks next
+// in line.
+__device__ __forceinline__ void flow_wait_chain(const unsigned long long* f, int idx, int step, int nb,
+                                                unsigned long long target, int dist)
+{
+  if(threadIdx.x == 0) {
+    const int i2 = idx + 2 * step, i1 = idx + step;
+    if(i2 >= 0 && i2 < nb)
+      while(__hip_atomic_load(f + i2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(96);
+    if(i1 >= 0 && i1 < nb)
+      while(__hip_atomic_load(f + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(24);
+    if(dist == 0) {
+      // next in line: the caller polls the data itself (flow_poll)
+    } else {
+      // not next in line (the product is consumed `dist` block steps later): poll slowly, and stagger the read of the
+      // 2 KB input vector — every waiting task of this column reads the same lines, i.e. the same memory channel, and
+      // the one task the chain is waiting for must not queue behind a hundred others
+      while(__hip_atomic_load(f + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(16);
+      for(int d = 0; d < dist && d < 24; ++d) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+}
+
+// called by wave 0 after it stored the task's outputs (flow_st): the stores are acknowledged before the flag moves
+__device__ __forceinline__ void flow_signal(unsigned long long* p)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if(threadIdx.x == 0) (void)__hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sync layout (unsigned long long): [0] ticket | fy | fa | fb | bx | ba | bb | fc | bc   (nb entries each)
+// fa[J]: products (I, J) with I <= J - 3 delivered, fc[J]: I = J - 2, fb[J]: I = J - 1 (the diagonal task adds them in
+// that order: the bulk is summed two block steps before the last one arrives); ba / bc / bb likewise for the rows.
+// P: nb x nb slots of 256 doubles; slot (a, b) = (a * nb + b) * 256: forward uses (J, I), backward (I, J), I < J.
+__global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* __restrict__ A, int64_t lda, int N, int nb,
+                                                                 const double* __restrict__ W,
+                                                                 const double* __restrict__ dinv,
+                                                                 const int4* __restrict__ tasks, int ntasks,
+                                                                 unsigned long long* sync, unsigned long long epoch,
+                                                                 double* P, double* y, double* xc, double* Po, double* yo, double* xo,
+                                                                 double* b, long long* ts)
+{
+  __shared__ int s_ticket;
+  __shared__ double vsh[SV_B];
+  __shared__ double red[4][64];
+  const int tid = threadIdx.x;
+  if(tid == 0) {
+    const unsigned long long t = __hip_atomic_fetch_add(sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ticket = (int)(t - (epoch - 1ull) * (unsigned long long)ntasks);
+  }
+  __syncthreads();
+  const int4 tk = tasks[s_ticket];
+  if(ts && tid == 0) ts[4 * s_ticket + 0] = wall_clock64();
+  const int kind = tk.x, I = tk.y, J = tk.z, ch = tk.w;
+  unsigned long long* fy = sync + 1;
+  unsigned long long* fa = fy + nb;
+  unsigned long long* fb = fa + nb;
+  unsigned long long* bx = fb + nb;
+  unsigned long long* ba = bx + nb;
+  unsigned long long* bb = ba + nb;
+  unsigned long long* fc = bb + nb;
+  unsigned long long* bc = fc + nb;
+  const unsigned long long eR = epoch * (unsigned long long)FL_R;
+  // Pacing: tasks are issued in the order their results are needed, and the chain of diagonal solves sets the length of
+  // the solve, so the operand blocks only have to arrive at a uniform rate.  Left alone, every resident task loads at
+  // once and the chain's own small round trips queue behind 100 MB of streaming (block steps of 15 us instead of 4).
+  // A task therefore starts loading when the chain has reached the same fraction of its way as the task's ticket,
+  // minus a lead of FL_LEAD block steps.
+  {
+    const int half = ntasks >> 1;
+    const bool fwd = s_ticket < half;
+    const int rel = fwd ? s_ticket : s_ticket - half;
+    const int pace = (int)(((long long)rel * nb) / half) - FL_LEAD;   // block step of the chain to wait for
+    if(pace >= 0) {
+      const unsigned long long* f = fwd ? (fy + pace) : (bx + (nb - 1 - pace));
+      if(tid == 0)
+        while(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < eR) __builtin_amdgcn_s_sleep(64);
+      __syncthreads();
+    }
+  }
+  double m[64];
+  if(kind <= FL_FWD_DIAG) {
+    // ---- forward, out[c] = sum_r M[r][c] v[r]: lane <-> column, wave rg <-> rows 64 rg .. 64 rg + 63
+    const int cl = tid & 63;
+    const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t gcol = (int64_t)J * SV_B + ch * 64 + cl;
+    const bool colok = gcol < N;
+    bool live = true;
+    if(kind == FL_FWD_OFF) {
+      const int64_t cc = colok ? gcol : (int64_t)(N - 1);
+      const double* src = A + ((int64_t)I * SV_B + rg * 64) * lda + cc;
+#pragma unroll
+      for(int q = 0; q < 64; ++q) m[q] = src[(int64_t)q * lda];
+    } else {
+      live = rg <= ch;   // W is upper triangular
+      const double* src = W + (int64_t)J * (SV_B * SV_B) + (rg * 64) * SV_B + ch * 64 + cl;
+      if(live) {
+#pragma unroll
+        for(int q = 0; q < 64; ++q) m[q] = src[q * SV_B];
+      } else {
+#pragma unroll
+        for(int q = 0; q < 64; ++q) m[q] = 0.0;
+      }
+    }
+    if(kind == FL_FWD_OFF) {
+      flow_wait_chain(fy, I, -1, nb, eR, J - I - 1);
+      vsh[tid] = (J - I == 1) ? flow_poll(y + (int64_t)I * SV_B + tid) : flow_ld(y + (int64_t)I * SV_B + tid);
+    } else {
+      const int64_t gi = (int64_t)J * SV_B + tid;
+      double v = (gi < N) ? b[gi] : 0.0;
+      if(J >= 3) {
+        flow_wait(fa + J, eR * (unsigned long long)(J - 2));
+        v = flow_sub_slots(v, P + (int64_t)J * nb * SV_B + tid, SV_B, J - 2);
+      }
+      if(J >= 2) {
+        flow_wait(fc + J, eR);
+        v -= flow_ld(P + ((int64_t)J * nb + (J - 2)) * SV_B + tid);
+      }
+      if(J >= 1) {
+        const double* pl = P + ((int64_t)J * nb + (J - 1)) * SV_B + tid;
+        v -= flow_poll(pl);
+      }
+      vsh[tid] = v;
+    }
+    if(ts && tid == 0) ts[4 * s_ticket + 1] = wall_clock64();
+    __syncthreads();
+    double acc = 0.0;
+    if(live) {
+#pragma unroll
+      for(int q = 0; q < 64; ++q) acc = fma(m[q], vsh[rg * 64 + q], acc);
+    }
+    red[rg][cl] = acc;
+    __syncthreads();
+    if(tid < 64) {
+      const double out = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+      if(kind == FL_FWD_OFF) {
+        flow_st(P + ((int64_t)J * nb + I) * SV_B + ch * 64 + tid, colok ? out : 0.0);
+        if(I == J - 1) flow_poison(Po + ((int64_t)J * nb + I) * SV_B + ch * 64 + tid);
+        flow_signal((I == J - 1) ? (fb + J) : (I == J - 2) ? (fc + J) : (fa + J));
+        if(ts && tid == 0) ts[4 * s_ticket + 2] = wall_clock64();
+      } else {
+        if(colok) {
+          flow_st(y + gcol, out);
+          flow_poison(yo + gcol);
+        }
+        flow_signal(fy + J);
+        if(ts && tid == 0) ts[4 * s_ticket + 2] = wall_clock64();
+      }
+    }
+    return;
+  }
+  // ---- backward, out[r] = sum_c M[r][c] v[c]: 16 lanes per row, 16 rows per pass, 4 passes
+  const int rr = tid >> 4, pt = tid & 15;
+  if(kind == FL_BWD_OFF) {
+#pragma unroll
+    for(int ps = 0; ps < 4; ++ps) {
+      const double* src = A + ((int64_t)I * SV_B + ch * 64 + ps * 16 + rr) * lda;
+#pragma unroll
+      for(int k = 0; k < 16; ++k) {
+        const int64_t gc = (int64_t)J * SV_B + 16 * k + pt;
+        m[ps * 16 + k] = src[(gc < N) ? gc : (int64_t)(N - 1)];
+      }
+    }
+    flow_wait_chain(bx, J, +1, nb, eR, J - I - 1);
+    const int64_t gj = (int64_t)J * SV_B + tid;
+    vsh[tid] = (gj < N) ? ((J - I == 1) ? flow_poll(xc + gj) : flow_ld(xc + gj)) : 0.0;
+  } else {
+    const double* Wi = W + (int64_t)I * (SV_B * SV_B);
+#pragma unroll
+    for(int ps = 0; ps < 4; ++ps) {
+      const double* src = Wi + (ch * 64 + ps * 16 + rr) * SV_B + pt;
+#pragma unroll
+      for(int k = 0; k < 16; ++k) {
+        // columns 16k..16k+15 lie left of every row of this pass: structurally zero
+        m[ps * 16 + k] = (16 * k + 15 < ch * 64 + ps * 16) ? 0.0 : src[16 * k];
+      }
+    }
+    const int64_t gi = (int64_t)I * SV_B + tid;
+    flow_wait(fy + I, eR);
+    double v = (gi < N) ? flow_ld(y + gi) * dinv[gi] : 0.0;
+    const int above = nb - 1 - I;
+    if(above >= 3) {   // J = nb-1 .. I+3, descending
+      flow_wait(ba + I, eR * (unsigned long long)(above - 2));
+      v = flow_sub_slots(v, P + ((int64_t)I * nb + (nb - 1)) * SV_B + tid, -(int64_t)SV_B, above - 2);
+    }
+    if(above >= 2) {
+      flow_wait(bc + I, eR);
+      v -= flow_ld(P + ((int64_t)I * nb + (I + 2)) * SV_B + tid);
+    }
+    if(above >= 1) {
+      const double* pl = P + ((int64_t)I * nb + (I + 1)) * SV_B + tid;
+      v -= flow_poll(pl);
+    }
+    vsh[tid] = v;
+  }
+  if(ts && tid == 0) ts[4 * s_ticket + 1] = wall_clock64();
+  __syncthreads();
+  double xv[16];
+#pragma unroll
+  for(int k = 0; k < 16; ++k) xv[k] = vsh[16 * k + pt];
+#pragma unroll
+  for(int ps = 0; ps < 4; ++ps) {
+    double acc = 0.0;
+#pragma unroll
+    for(int k = 0; k < 16; ++k) acc = fma(m[ps * 16 + k], xv[k], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if(pt == 0) red[0][ps * 16 + rr] = acc;
+  }
+  __syncthreads();
+  if(tid < 64) {
+    const double out = red[0][tid];
+    if(kind == FL_BWD_OFF) {
+      flow_st(P + ((int64_t)I * nb + J) * SV_B + ch * 64 + tid, out);
+      if(J == I + 1) flow_poison(Po + ((int64_t)I * nb + J) * SV_B + ch * 64 + tid);
+      flow_signal((J == I + 1) ? (bb + I) : (J == I + 2) ? (bc + I) : (ba + I));
+      if(ts && tid == 0) ts[4 * s_ticket + 2] = wall_clock64();
+    } else {
+      const int64_t go = (int64_t)I * SV_B + ch * 64 + tid;
+      if(go < N) {
+        flow_st(xc + go, out);   // for the tasks of this launch
+        flow_poison(xo + go);
+        b[go] = out;             // the caller's copy
+      }
+      flow_signal(bx + I);
+      if(ts && tid == 0) ts[4 * s_ticket + 2] = wall_clock64();
+    }
+  }
+}
+
+// W_J = U_JJ^-1 for every 256 x 256 diagonal block (unit upper triangular; entries outside the jb x jb leading part of a
+// ragged last block are treated as identity).  One workgroup per block:
+//   1. the four 64 x 64 diagonal sub-blocks by back substitution, one wave each, lane = column, the column in registers;
+//   2. the six off-diagonal sub-blocks by block back substitution  W_pq = -T_p (sum_{p<s<=q} U_ps W_sq).
+__global__ __launch_bounds__(kBlock) void ldlt_inv_diag_kernel(const double* __restrict__ Cd, int N, double* __restrict__ W)
+{
+  __shared__ __attribute__((aligned(16))) double Ls[4 * 64 * 64];
+  const int Jb = blockIdx.x;
+  const int jb = (N - Jb * SV_B < SV_B) ? (N - Jb * SV_B) : SV_B;
+  const double* C = Cd + (int64_t)Jb * (SV_B * SV_B);
+  double* Wj = W + (int64_t)Jb * (SV_B * SV_B);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // zero the strictly lower sub-blocks of W and stage the diagonal sub-blocks of U
+  for(int e = tid; e < 6 * 64 * 64; e += kBlock) {
+    const int blk = e >> 12, r = (e >> 6) & 63, c = e & 63;
+    // (p, q), p > q: (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
+    const int p = (blk == 0) ? 1 : (blk <= 2) ? 2 : 3;
+    const int q = (blk == 0) ? 0 : (blk == 1) ? 0 : (blk == 2) ? 1 : blk - 3;
+    Wj[(64 * p + r) * SV_B + 64 * q + c] = 0.0;
+  }
+  for(int e = tid; e < 4 * 64 * 64; e += kBlock) {
+    const int q = e >> 12, r = (e >> 6) & 63, c = e & 63;
+    Ls[e] = (r < c && 64 * q + c < jb) ? C[(64 * q + r) * SV_B + 64 * q + c] : 0.0;
+  }
+  __syncthreads();
+  {
+    const double* Lq = Ls + w * 4096;
+    double wv[64];
+#pragma unroll
+    for(int r = 63; r >= 0; --r) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for(int k = r + 1; k < 64; ++k) {
+        if(k & 1)
+          s1 = fma(Lq[r * 64 + k], wv[k], s1);
+        else
+          s0 = fma(Lq[r * 64 + k], wv[k], s0);
+      }
+      wv[r] = ((r == lane) ? 1.0 : 0.0) - (s0 + s1);
+    }
+#pragma unroll
+    for(int r = 0; r < 64; ++r) Wj[(64 * w + r) * SV_B + 64 * w + lane] = wv[r];
+  }
+  __syncthreads();
+  // off-diagonal sub-blocks.  Thread (ty, tx): rows 4 ty .. 4 ty + 3, columns tx + 16 j.
+  double* Xs = Ls;              // [64][65]
+  double* Ys = Ls + 64 * 65;    // [64][64]
+  const int ty = tid >> 4, tx = tid & 15;
+  auto stage = [&](const double* src, int ld, bool is_u, int col0) {
+    // Xs[r][c] <- src[r * ld + c]; U blocks are masked beyond jb (col0 = first column of the block inside the 256)
+    for(int e = tid; e < 4096; e += kBlock) {
+      const int r = e >> 6, c = e & 63;
+      const double v = src[r * ld + c];
+      Xs[r * 65 + c] = (!is_u || col0 + c < jb) ? v : 0.0;
+    }
+  };
+  auto stage_y = [&](const double* src, int ld) {
+    for(int e = tid; e < 4096; e += kBlock) Ys[e] = src[(e >> 6) * ld + (e & 63)];
+  };
+  auto mult = [&](double (&acc)[16]) {
+#pragma unroll 4
+    for(int k = 0; k < 64; ++k) {
+      double xa[4], yb[4];
+#pragma unroll
+      for(int i = 0; i < 4; ++i) xa[i] = Xs[(4 * ty + i) * 65 + k];
+#pragma unroll
+      for(int j = 0; j < 4; ++j) yb[j] = Ys[k * 64 + tx + 16 * j];
+#pragma unroll
+      for(int i = 0; i < 4; ++i)
+#pragma unroll
+        for(int j = 0; j < 4; ++j) acc[4 * i + j] = fma(xa[i], yb[j], acc[4 * i + j]);
+    }
+  };
+  for(int q = 1; q < 4; ++q) {
+    for(int p = q - 1; p >= 0; --p) {
+      double acc[16];
+#pragma unroll
+      for(int i = 0; i < 16; ++i) acc[i] = 0.0;
+      for(int s2 = p + 1; s2 <= q; ++s2) {
+        stage(C + (64 * p) * SV_B + 64 * s2, SV_B, true, 64 * s2);
+        stage_y(Wj + (64 * s2) * SV_B + 64 * q, SV_B);
+        __syncthreads();
+        mult(acc);
+        __syncthreads();
+      }
+      // S -> Ys, T_p -> Xs
+#pragma unroll
+      for(int i = 0; i < 4; ++i)
+#pragma unroll
+        for(int j = 0; j < 4; ++j) Ys[(4 * ty + i) * 64 + tx + 16 * j] = acc[4 * i + j];
+      stage(Wj + (64 * p) * SV_B + 64 * p, SV_B, false, 0);
+      __syncthreads();
+      double a2[16];
+#pragma unroll
+      for(int i = 0; i < 16; ++i) a2[i] = 0.0;
+      mult(a2);
+#pragma unroll
+      for(int i = 0; i < 4; ++i)
+#pragma unroll
+        for(int j = 0; j < 4; ++j) Wj[(64 * p + 4 * ty + i) * SV_B + 64 * q + tx + 16 * j] = -a2[4 * i + j];
+      __syncthreads();   // W_pq is read back (from global memory) by the next products
+    }
+  }
+}
+
 }  // namespace hiopamd
 
 using namespace hiopamd;
@@ -1412,13 +1827,20 @@ struct hiopamd_linsolver {
   double* Dblk = nullptr;   // ceil(n/64) staged 64x64 diagonal blocks
   double* Cd = nullptr;     // ceil(n/256) compact 256x256 diagonal blocks (ld = 256)
   int* d_info = nullptr;    // [0]=zero-pivot flag, [1..3]=pos,neg,zero
+  // dataflow solve (ldlt_solve_flow_kernel)
+  double* W = nullptr;                  // ceil(n/256) inverted diagonal blocks
+  double* P = nullptr;                  // nb x nb product slots of 256
+  unsigned long long* fl_sync = nullptr;
+  int4* fl_tasks = nullptr;
+  int fl_ntasks = 0;
+  unsigned long long fl_epoch = 0;
   bool factored = false;
   int inertia[3] = {0, 0, 0};
   LdltProfile prof;
 };
 
 static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, double* dinv, double* V, double* Dblk,
-                            double* Cd, int* d_info, int* inertia3_host, LdltProfile* prof = nullptr)
+                            double* Cd, int* d_info, int* inertia3_host, LdltProfile* prof = nullptr, double* Winv = nullptr)
 {
   // Dblk: per 64-row panel a compact 64x64 copy of the factored diagonal block, followed (after all
   // the blocks) by the per-panel 4 x 16x16 inverses
@@ -1595,6 +2017,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     if(rc != HIOPAMD_OK) return rc;
   }
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
+  if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(nsp), dim3(kBlock), 0, st, Cd, N, Winv);
   HIOPAMD_CHECK(hipGetLastError());
   int h[4];
   HIOPAMD_CHECK(hipMemcpyAsync(h, d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1610,12 +2033,54 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
 }
 
 static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda, const double* dinv, double* ybuf,
-                           double* rhs, int nrhs, const double* Cd = nullptr)
+                           double* rhs, int nrhs, const double* Cd = nullptr, hiopamd_linsolver* flow = nullptr)
 {
   if(N < 0 || nrhs < 0) return HIOPAMD_ERR_ARG;
   if(N == 0) return HIOPAMD_OK;
   hipStream_t st = ctx->stream;
   const int nblk = (N + LD_nb - 1) / LD_nb;
+  static int flow_mode = -1;   // HIOPAMD_SOLVE_FLOW=0: stepwise 256-row solves (A/B timing)
+  if(flow_mode < 0) flow_mode = std::getenv("HIOPAMD_SOLVE_FLOW") ? std::atoi(std::getenv("HIOPAMD_SOLVE_FLOW")) : 1;
+  if(flow && flow->W && flow_mode > 0) {
+    const int nb = (N + SV_B - 1) / SV_B;
+    static long long* d_ts = nullptr;   // HIOPAMD_FLOW_TRACE=<file>: per-task timestamps of the 5th solve
+    static int trace_count = 0;
+    const char* trace_path = std::getenv("HIOPAMD_FLOW_TRACE");
+    for(int j = 0; j < nrhs; ++j) {
+      flow->fl_epoch += 1;
+      long long* ts = nullptr;
+      if(trace_path && ++trace_count == 5) {
+        (void)hipMalloc((void**)&d_ts, sizeof(long long) * 4 * (size_t)flow->fl_ntasks);
+        (void)hipMemset(d_ts, 0, sizeof(long long) * 4 * (size_t)flow->fl_ntasks);
+        ts = d_ts;
+      }
+      // exchange buffers of this epoch's parity (c) and of the next launch (n): y | x | product slots, twice
+      const int64_t npad = (int64_t)nb * SV_B, psz = (int64_t)SV_B * nb * nb, half = 2 * npad + psz;
+      double* cur = flow->P + (int64_t)(flow->fl_epoch & 1ull) * half;
+      double* nxt = flow->P + (int64_t)((flow->fl_epoch + 1ull) & 1ull) * half;
+      double *yc = cur, *xcur = cur + npad, *Pc = cur + 2 * npad;
+      double *yn = nxt, *xn = nxt + npad, *Pn = nxt + 2 * npad;
+      hipLaunchKernelGGL(ldlt_solve_flow_kernel, dim3(flow->fl_ntasks), dim3(kBlock), 0, st, A, lda, N, nb, flow->W, dinv,
+                         flow->fl_tasks, flow->fl_ntasks, flow->fl_sync, flow->fl_epoch, Pc, yc, xcur, Pn, yn, xn,
+                         rhs + (int64_t)j * N, ts);
+      if(ts) {
+        (void)hipStreamSynchronize(st);
+        std::vector<long long> h(4 * (size_t)flow->fl_ntasks);
+        std::vector<int4> tk(flow->fl_ntasks);
+        (void)hipMemcpy(h.data(), d_ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(tk.data(), flow->fl_tasks, sizeof(int4) * tk.size(), hipMemcpyDeviceToHost);
+        if(FILE* f = std::fopen(trace_path, "w")) {
+          std::fprintf(f, "# ticket kind I J chunk t_start t_input t_signal (10 ns ticks, relative to the first task)\n");
+          for(int t = 0; t < flow->fl_ntasks; ++t)
+            std::fprintf(f, "%d %d %d %d %d %lld %lld %lld\n", t, tk[t].x, tk[t].y, tk[t].z, tk[t].w, h[4 * t] - h[0],
+                         h[4 * t + 1] - h[0], h[4 * t + 2] - h[0]);
+          std::fclose(f);
+        }
+      }
+    }
+    HIOPAMD_CHECK(hipGetLastError());
+    return HIOPAMD_OK;
+  }
   if(Cd) {   // 256-row steps on the compact diagonal blocks (the factorisation object keeps them)
     const int nsp = (N + SV_B - 1) / SV_B;
     const double* CdT = Cd + (int64_t)nsp * (SV_B * SV_B);
@@ -1705,6 +2170,35 @@ int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb)));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB)));   // blocks + transposes
   HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
+  {
+    // dataflow solve: inverted diagonal blocks, product slots, flags, and the task list in issue order
+    const int nb = (int)((nn + SV_B - 1) / SV_B);
+    HIOPAMD_CHECK(hipMalloc((void**)&ls->W, sizeof(double) * (size_t)SV_B * SV_B * nb));
+    {
+      // two copies of (y | x | product slots), poisoned (flow_poll)
+      const size_t words = 2 * ((size_t)2 * nb * SV_B + (size_t)SV_B * nb * nb);
+      HIOPAMD_CHECK(hipMalloc((void**)&ls->P, sizeof(double) * words));
+      std::vector<unsigned long long> poison(words, FL_POISON);
+      HIOPAMD_CHECK(hipMemcpy(ls->P, poison.data(), sizeof(double) * words, hipMemcpyHostToDevice));
+    }
+    HIOPAMD_CHECK(hipMalloc((void**)&ls->fl_sync, sizeof(unsigned long long) * (size_t)(1 + 8 * nb)));
+    HIOPAMD_CHECK(hipMemsetAsync(ls->fl_sync, 0, sizeof(unsigned long long) * (size_t)(1 + 8 * nb), ctx->stream));
+    std::vector<int4> tk;
+    tk.reserve((size_t)FL_R * nb * (nb + 1));
+    for(int J = 0; J < nb; ++J) {   // forward: column J needs y_I, I < J; its diagonal task closes it
+      for(int I = 0; I < J; ++I)
+        for(int c = 0; c < FL_R; ++c) tk.push_back(make_int4(FL_FWD_OFF, I, J, c));
+      for(int c = 0; c < FL_R; ++c) tk.push_back(make_int4(FL_FWD_DIAG, J, J, c));
+    }
+    for(int I = nb - 1; I >= 0; --I) {   // backward: row I needs x_J, J > I
+      for(int J = nb - 1; J > I; --J)
+        for(int c = 0; c < FL_R; ++c) tk.push_back(make_int4(FL_BWD_OFF, I, J, c));
+      for(int c = 0; c < FL_R; ++c) tk.push_back(make_int4(FL_BWD_DIAG, I, I, c));
+    }
+    ls->fl_ntasks = (int)tk.size();
+    HIOPAMD_CHECK(hipMalloc((void**)&ls->fl_tasks, sizeof(int4) * tk.size()));
+    HIOPAMD_CHECK(hipMemcpy(ls->fl_tasks, tk.data(), sizeof(int4) * tk.size(), hipMemcpyHostToDevice));
+  }
   HIOPAMD_CHECK(hipMemsetAsync(ls->M, 0, sizeof(double) * nn * nn, ctx->stream));
   *out = ls;
   return HIOPAMD_OK;
@@ -1721,6 +2215,10 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->Dblk);
   (void)hipFree(ls->Cd);
   (void)hipFree(ls->d_info);
+  (void)hipFree(ls->W);
+  (void)hipFree(ls->P);
+  (void)hipFree(ls->fl_sync);
+  (void)hipFree(ls->fl_tasks);
   delete ls;
   return HIOPAMD_OK;
 }
@@ -1732,7 +2230,7 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
 {
   if(!ls || !n_neg_host) return HIOPAMD_ERR_ARG;
   ls->factored = false;
-  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof);
+  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W);
   if(rc == HIOPAMD_ERR_SINGULAR) {
     // reference: "entry in the factorization's diagonal is exactly zero" -> matrixChanged() returns -1
     *n_neg_host = -1;
@@ -1748,7 +2246,7 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs)
 {
   if(!ls || !rhs_inout) return HIOPAMD_ERR_ARG;
   if(!ls->factored) return HIOPAMD_ERR_STATE;
-  return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd);
+  return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd, ls);
 }
 
 int hiopamd_linsolver_profile(hiopamd_linsolver* ls, int enable)
