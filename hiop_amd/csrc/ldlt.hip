@@ -311,72 +311,83 @@ __global__ __launch_bounds__(64) void ldlt_trsm_kernel(double* __restrict__ A, i
 // BYPASS = true makes the loads of data produced earlier IN THE SAME LAUNCH by other waves go to L2
 // (relaxed agent-scope atomic load = `sc1`): a CU's vector L1 is not refreshed by stores.
 // ------------------------------------------------------------------------------------------
-template <bool BYPASS>
-__device__ __forceinline__ double ld_maybe_bypass(const double* p)
+// Loads of block_row_solve: wave-scope relaxed atomics = ordinary loads (no cache-policy bits) that the compiler keeps
+// where they are written.  As plain loads they were sunk next to their uses: one load, one s_waitcnt, one MFMA, 600 times
+// over — every one a full memory round trip for the single wave of this workgroup.  Written as batches that are issued
+// together, a block row costs a handful of round trips.
+__device__ __forceinline__ double ld_batch(const double* p)
 {
-  if constexpr(BYPASS) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    return *p;
-  }
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-template <int P, bool BYPASS>
+template <int P, bool IDENT = false>
 __device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, int K0, int kbs, int64_t col, bool col_ok,
                                                 const double* Cd /* compact diagonal block, ld = LD_NB */,
                                                 const double* Dk_sp, const double* Li_sp, double4_t (&Vv)[4][4], int g,
                                                 int li)
 {
-  // rows of block-row P that exist (the last super-panel may be ragged)
+  // ---- batch 0: the 64 x 16 block of the matrix, and the operands of the in-block substitution (independent of V)
   double4_t t[4];
 #pragma unroll
   for(int I = 0; I < 4; ++I)
 #pragma unroll
     for(int r = 0; r < 4; ++r) {
-      const int row = 64 * P + 16 * I + g + 4 * r;
-      const int rowc = (row < kbs) ? row : (kbs - 1);
-      const double v = A[(int64_t)(K0 + rowc) * lda + col];
-      t[I][r] = (col_ok && row < kbs) ? v : 0.0;
+      const int row = 64 * P + 16 * I + g + 4 * r;   // rows of block-row P that exist (the last super-panel may be ragged)
+      if constexpr(IDENT) {   // right-hand side = identity (col = column inside the block): the result is L^-1
+        t[I][r] = (row == (int)col && row < kbs) ? 1.0 : 0.0;
+      } else {
+        const int rowc = (row < kbs) ? row : (kbs - 1);
+        const double v = ld_batch(A + (int64_t)(K0 + rowc) * lda + col);
+        t[I][r] = (col_ok & (row < kbs)) ? v : 0.0;
+      }
     }
-  // T_P -= L_Pq V_q
+  const double* Dk = Dk_sp + P * (LD_nb * LD_nb);
+  const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
+  double nl[6][4];   // pairs (I, J), J < I: (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
+  double iv[4][4];
+#pragma unroll
+  for(int I = 1; I < 4; ++I)
+#pragma unroll
+    for(int J = 0; J < I; ++J)
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) nl[I * (I - 1) / 2 + J][kk] = -ld_batch(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li);
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) iv[I][kk] = ld_batch(Li + I * 256 + li * 16 + 4 * kk + g);
+  // ---- T_P -= L_Pq V_q: one batch of 64 operand loads per q, then its 64 MFMAs
 #pragma unroll
   for(int q = 0; q < P; ++q) {
+    double Lop[4][4][4];  // [I][Jq][kk]: -L_Pq[16I+li][16Jq+4kk+g] = -U[K0+64q+16Jq+4kk+g][K0+64P+16I+li]
 #pragma unroll
-    for(int I = 0; I < 4; ++I) {
-      double Lop[4][4];  // [Jq][kk]: -L_Pq[16I+li][16Jq+4kk+g] = -U[K0+64q+16Jq+4kk+g][K0+64P+16I+li]
+    for(int I = 0; I < 4; ++I)
 #pragma unroll
       for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
         for(int kk = 0; kk < 4; ++kk)
-          Lop[Jq][kk] = -ld_maybe_bypass<BYPASS>(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (64 * P + 16 * I + li));
+          Lop[I][Jq][kk] = -ld_batch(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (64 * P + 16 * I + li));
 #pragma unroll
-      for(int Jq = 0; Jq < 4; ++Jq)
+    for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
-        for(int kk = 0; kk < 4; ++kk) t[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lop[Jq][kk], Vv[q][Jq][kk], t[I], 0, 0, 0);
-    }
+      for(int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for(int I = 0; I < 4; ++I)   // four independent accumulators back to back
+          t[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lop[I][Jq][kk], Vv[q][Jq][kk], t[I], 0, 0, 0);
   }
-  // V_P = L_PP^-1 T_P by 16-row blocks
-  const double* Dk = Dk_sp + P * (LD_nb * LD_nb);
-  const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
+  // ---- V_P = L_PP^-1 T_P by 16-row blocks
 #pragma unroll
   for(int I = 0; I < 4; ++I) {
     double4_t u = t[I];
 #pragma unroll
     for(int J = 0; J < 4; ++J) {
       if(J < I) {
-        double nl[4];
 #pragma unroll
-        for(int kk = 0; kk < 4; ++kk) nl[kk] = -ld_maybe_bypass<BYPASS>(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li);
-#pragma unroll
-        for(int kk = 0; kk < 4; ++kk) u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[kk], Vv[P][J][kk], u, 0, 0, 0);
+        for(int kk = 0; kk < 4; ++kk) u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[I * (I - 1) / 2 + J][kk], Vv[P][J][kk], u, 0, 0, 0);
       }
     }
-    double iv[4];
-#pragma unroll
-    for(int kk = 0; kk < 4; ++kk) iv[kk] = ld_maybe_bypass<BYPASS>(Li + I * 256 + li * 16 + 4 * kk + g);
     double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[kk], u[kk], v, 0, 0, 0);
+    for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[I][kk], u[kk], v, 0, 0, 0);
     Vv[P][I] = v;
   }
 }
@@ -646,20 +657,58 @@ __global__ __launch_bounds__(64) void ldlt_supertrsm_kernel(double* __restrict__
   for(int a = 0; a < 4; ++a)
 #pragma unroll
     for(int b = 0; b < 4; ++b) Vv[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  block_row_solve<0, false>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
+  block_row_solve<0>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
   block_row_store<0>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   if(np > 1) {
-    block_row_solve<1, false>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
+    block_row_solve<1>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
     block_row_store<1>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   }
   if(np > 2) {
-    block_row_solve<2, false>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
+    block_row_solve<2>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
     block_row_store<2>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   }
   if(np > 3) {
-    block_row_solve<3, false>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
+    block_row_solve<3>(A, lda, K0, kbs, colc, col_ok, Cd, Dk_sp, Li_sp, Vv, g, li);
     block_row_store<3>(A, lda, V, ldv, K0, kbs, col, col_ok, dsp, Vv, g, li);
   }
+}
+
+// W_J = U_JJ^-1 = (L_JJ^-1)^T of every 256 x 256 diagonal block, for the dataflow solve: the row-panel substitution
+// above applied to an identity.  grid = (16, number of blocks), one wave per 16 columns of the identity.
+__global__ __launch_bounds__(64) void ldlt_inv_diag_kernel(int N, const double* __restrict__ Cd_all,
+                                                           const double* __restrict__ Dblk, const double* __restrict__ Li_all,
+                                                           double* __restrict__ W)
+{
+  const int Jb = blockIdx.y, K0 = Jb * LD_NB;
+  const int kbs = (N - K0 < LD_NB) ? (N - K0) : LD_NB;
+  const int np = (kbs + LD_nb - 1) / LD_nb;
+  const double* Cd = Cd_all + (int64_t)Jb * (LD_NB * LD_NB);
+  const double* Dk_sp = Dblk + (int64_t)(K0 / LD_nb) * (LD_nb * LD_nb);
+  const double* Li_sp = Li_all + (int64_t)(K0 / LD_nb) * (4 * LD_SB * LD_SB);
+  double* Wj = W + (int64_t)Jb * (LD_NB * LD_NB);
+  const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
+  const int c = blockIdx.x * 16 + li;
+  double4_t Vv[4][4];
+#pragma unroll
+  for(int a = 0; a < 4; ++a)
+#pragma unroll
+    for(int b = 0; b < 4; ++b) Vv[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  block_row_solve<0, true>(nullptr, 0, K0, kbs, c, true, Cd, Dk_sp, Li_sp, Vv, g, li);
+  if(np > 1) block_row_solve<1, true>(nullptr, 0, K0, kbs, c, true, Cd, Dk_sp, Li_sp, Vv, g, li);
+  if(np > 2) block_row_solve<2, true>(nullptr, 0, K0, kbs, c, true, Cd, Dk_sp, Li_sp, Vv, g, li);
+  if(np > 3) block_row_solve<3, true>(nullptr, 0, K0, kbs, c, true, Cd, Dk_sp, Li_sp, Vv, g, li);
+  // W[c][row] = Linv[row][c]; outside the kbs x kbs leading part of a ragged last block: identity
+#pragma unroll
+  for(int P = 0; P < 4; ++P)
+#pragma unroll
+    for(int I = 0; I < 4; ++I)
+#pragma unroll
+      for(int r = 0; r < 4; ++r) {
+        const int row = 64 * P + 16 * I + g + 4 * r;
+        double v = (row < kbs && c < kbs) ? Vv[P][I][r] : ((row == c) ? 1.0 : 0.0);
+        if(row < c) v = 0.0;
+        Wj[c * LD_NB + row] = v;
+      }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1668,112 +1717,6 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
   }
 }
 
-// W_J = U_JJ^-1 for every 256 x 256 diagonal block (unit upper triangular; entries outside the jb x jb leading part of a
-// ragged last block are treated as identity).  One workgroup per block:
-//   1. the four 64 x 64 diagonal sub-blocks by back substitution, one wave each, lane = column, the column in registers;
-//   2. the six off-diagonal sub-blocks by block back substitution  W_pq = -T_p (sum_{p<s<=q} U_ps W_sq).
-__global__ __launch_bounds__(kBlock) void ldlt_inv_diag_kernel(const double* __restrict__ Cd, int N, double* __restrict__ W)
-{
-  __shared__ __attribute__((aligned(16))) double Ls[4 * 64 * 64];
-  const int Jb = blockIdx.x;
-  const int jb = (N - Jb * SV_B < SV_B) ? (N - Jb * SV_B) : SV_B;
-  const double* C = Cd + (int64_t)Jb * (SV_B * SV_B);
-  double* Wj = W + (int64_t)Jb * (SV_B * SV_B);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // zero the strictly lower sub-blocks of W and stage the diagonal sub-blocks of U
-  for(int e = tid; e < 6 * 64 * 64; e += kBlock) {
-    const int blk = e >> 12, r = (e >> 6) & 63, c = e & 63;
-    // (p, q), p > q: (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
-    const int p = (blk == 0) ? 1 : (blk <= 2) ? 2 : 3;
-    const int q = (blk == 0) ? 0 : (blk == 1) ? 0 : (blk == 2) ? 1 : blk - 3;
-    Wj[(64 * p + r) * SV_B + 64 * q + c] = 0.0;
-  }
-  for(int e = tid; e < 4 * 64 * 64; e += kBlock) {
-    const int q = e >> 12, r = (e >> 6) & 63, c = e & 63;
-    Ls[e] = (r < c && 64 * q + c < jb) ? C[(64 * q + r) * SV_B + 64 * q + c] : 0.0;
-  }
-  __syncthreads();
-  {
-    const double* Lq = Ls + w * 4096;
-    double wv[64];
-#pragma unroll
-    for(int r = 63; r >= 0; --r) {
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for(int k = r + 1; k < 64; ++k) {
-        if(k & 1)
-          s1 = fma(Lq[r * 64 + k], wv[k], s1);
-        else
-          s0 = fma(Lq[r * 64 + k], wv[k], s0);
-      }
-      wv[r] = ((r == lane) ? 1.0 : 0.0) - (s0 + s1);
-    }
-#pragma unroll
-    for(int r = 0; r < 64; ++r) Wj[(64 * w + r) * SV_B + 64 * w + lane] = wv[r];
-  }
-  __syncthreads();
-  // off-diagonal sub-blocks.  Thread (ty, tx): rows 4 ty .. 4 ty + 3, columns tx + 16 j.
-  double* Xs = Ls;              // [64][65]
-  double* Ys = Ls + 64 * 65;    // [64][64]
-  const int ty = tid >> 4, tx = tid & 15;
-  auto stage = [&](const double* src, int ld, bool is_u, int col0) {
-    // Xs[r][c] <- src[r * ld + c]; U blocks are masked beyond jb (col0 = first column of the block inside the 256)
-    for(int e = tid; e < 4096; e += kBlock) {
-      const int r = e >> 6, c = e & 63;
-      const double v = src[r * ld + c];
-      Xs[r * 65 + c] = (!is_u || col0 + c < jb) ? v : 0.0;
-    }
-  };
-  auto stage_y = [&](const double* src, int ld) {
-    for(int e = tid; e < 4096; e += kBlock) Ys[e] = src[(e >> 6) * ld + (e & 63)];
-  };
-  auto mult = [&](double (&acc)[16]) {
-#pragma unroll 4
-    for(int k = 0; k < 64; ++k) {
-      double xa[4], yb[4];
-#pragma unroll
-      for(int i = 0; i < 4; ++i) xa[i] = Xs[(4 * ty + i) * 65 + k];
-#pragma unroll
-      for(int j = 0; j < 4; ++j) yb[j] = Ys[k * 64 + tx + 16 * j];
-#pragma unroll
-      for(int i = 0; i < 4; ++i)
-#pragma unroll
-        for(int j = 0; j < 4; ++j) acc[4 * i + j] = fma(xa[i], yb[j], acc[4 * i + j]);
-    }
-  };
-  for(int q = 1; q < 4; ++q) {
-    for(int p = q - 1; p >= 0; --p) {
-      double acc[16];
-#pragma unroll
-      for(int i = 0; i < 16; ++i) acc[i] = 0.0;
-      for(int s2 = p + 1; s2 <= q; ++s2) {
-        stage(C + (64 * p) * SV_B + 64 * s2, SV_B, true, 64 * s2);
-        stage_y(Wj + (64 * s2) * SV_B + 64 * q, SV_B);
-        __syncthreads();
-        mult(acc);
-        __syncthreads();
-      }
-      // S -> Ys, T_p -> Xs
-#pragma unroll
-      for(int i = 0; i < 4; ++i)
-#pragma unroll
-        for(int j = 0; j < 4; ++j) Ys[(4 * ty + i) * 64 + tx + 16 * j] = acc[4 * i + j];
-      stage(Wj + (64 * p) * SV_B + 64 * p, SV_B, false, 0);
-      __syncthreads();
-      double a2[16];
-#pragma unroll
-      for(int i = 0; i < 16; ++i) a2[i] = 0.0;
-      mult(a2);
-#pragma unroll
-      for(int i = 0; i < 4; ++i)
-#pragma unroll
-        for(int j = 0; j < 4; ++j) Wj[(64 * p + 4 * ty + i) * SV_B + 64 * q + tx + 16 * j] = -a2[4 * i + j];
-      __syncthreads();   // W_pq is read back (from global memory) by the next products
-    }
-  }
-}
-
 }  // namespace hiopamd
 
 using namespace hiopamd;
@@ -2017,7 +1960,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     if(rc != HIOPAMD_OK) return rc;
   }
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
-  if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(nsp), dim3(kBlock), 0, st, Cd, N, Winv);
+  if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv);
   HIOPAMD_CHECK(hipGetLastError());
   int h[4];
   HIOPAMD_CHECK(hipMemcpyAsync(h, d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
