@@ -356,6 +356,8 @@ __device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, in
 #pragma unroll
     for(int kk = 0; kk < 4; ++kk) iv[I][kk] = ld_batch(Li + I * 256 + li * 16 + 4 * kk + g);
   // ---- T_P -= L_Pq V_q: one batch of 64 operand loads per q, then its 64 MFMAs
+  // (accumulating the products with a plus sign and subtracting once was 17 us SLOWER per launch: the subtraction
+  //  pulls the accumulators out of the AGPRs and back)
 #pragma unroll
   for(int q = 0; q < P; ++q) {
     double Lop[4][4][4];  // [I][Jq][kk]: -L_Pq[16I+li][16Jq+4kk+g] = -U[K0+64q+16Jq+4kk+g][K0+64P+16I+li]
@@ -515,10 +517,16 @@ __global__ __launch_bounds__(kBlock) void ldlt_pack_diag_kernel(const double* __
 
 // factored block (U strictly upper, D on the diagonal) back into the matrix
 // (and the transpose of its strictly upper part into CT, zero elsewhere: the backward solve reads columns of U)
-__global__ __launch_bounds__(kBlock) void ldlt_unpack_diag_kernel(const double* __restrict__ C, double* __restrict__ A,
-                                                                  int64_t lda, int K0, int kbs, double* __restrict__ CT)
+// grid = (64, number of blocks): all diagonal blocks in one launch after the factorisation (nothing reads the matrix's
+// own copy of a factored diagonal block before that — the panel kernels work on the compact copies).
+__global__ __launch_bounds__(kBlock) void ldlt_unpack_diag_kernel(const double* __restrict__ Call, double* __restrict__ A,
+                                                                  int64_t lda, int N, double* __restrict__ CTall)
 {
   __shared__ double tile[32][33];
+  const int K0 = blockIdx.y * LD_NB;
+  const int kbs = (N - K0 < LD_NB) ? (N - K0) : LD_NB;
+  const double* C = Call + (int64_t)blockIdx.y * (LD_NB * LD_NB);
+  double* CT = CTall + (int64_t)blockIdx.y * (LD_NB * LD_NB);
   // 8 x 8 tiles of 32 x 32: blockIdx.x = tile id, 256 threads = 32 x 8
   const int tr = blockIdx.x >> 3, tc = blockIdx.x & 7;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1906,7 +1914,6 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     const Panel p0 = panel(0);
     hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, A, lda, p0.K0, p0.kbs, p0.Cj);
     superdiag(0, st);
-    hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(64), dim3(kBlock), 0, st, p0.Cj, A, lda, p0.K0, p0.kbs, p0.Cj + cdt_ofs);
   }
   if(lookahead) {
     int rc = dep(st, su);
@@ -1936,10 +1943,6 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       ev_diag = next_event();
       HIOPAMD_CHECK(hipEventRecord(ev_diag, sd));
     }
-    {
-      const Panel pn = panel(jp + 1);
-      hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(64), dim3(kBlock), 0, sd, pn.Cj, A, lda, pn.K0, pn.kbs, pn.Cj + cdt_ofs);
-    }
     // ---- wide stream: (superdiag(jp) is already waited for: fork for jp = 0, ev_diag of the previous iteration below)
     trsm(jp, su, head, N - sa_end);
     if(lookahead) HIOPAMD_CHECK(hipStreamWaitEvent(su, ev_head, 0));
@@ -1959,6 +1962,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     if(rc == HIOPAMD_OK) rc = dep(sd, st);
     if(rc != HIOPAMD_OK) return rc;
   }
+  hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(64, nsp), dim3(kBlock), 0, st, Cd, A, lda, N, Cd + cdt_ofs);
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
   if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv);
   HIOPAMD_CHECK(hipGetLastError());
