@@ -853,6 +853,131 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same rank-K update on v_mfma_f64_4x4x4_4b_f64 — the form of the fp64 MFMA that sustains 75 TFLOP/s on gfx950
+// (the 16x16x4 form above: 36-46, scripts/probes/mfma_f64_peak.hip).  One instruction = four independent 4x4x4 products:
+//   A lane l = A_b[i = l%4][k = l/16], B lane l = B_b[k = l/16][j = l%4], D lane 16i + 4b + j = D_b[i][j],  b = (l%16)/4,
+// so a 16x16x4 block product is four instructions whose B operand is rotated by 0/4/8/12 columns inside the 16 (read
+// from LDS with a rotated column index).  The A operand and the LDS staging are those of the kernel above.
+// In the D layout a lane's 64 results sit in 4-wide pieces of 16 different rows (a read-modify-write instruction would
+// touch 16 rows of C, 64 KB from each other), so the accumulators go through LDS (the staging buffers, free by then),
+// 32 tile rows at a time, and C is read and written in whole 512 B row segments.
+// OPT-IN (HIOPAMD_UPD4=1), NOT faster than the 16x16x4 kernel as it stands: 5.9 vs 5.75 ms of update time per N = 8192
+// factorisation.  With every global access removed it still takes 5.0 ms: the loop is bound by the LDS feed + two barriers
+// per stage (the probe's 51 of 75 TFLOP/s) and by the tail of each of the 31 launches, not by the MFMA rate
+// (profiles/r01_probes/README.md).
+// ------------------------------------------------------------------------------------------
+constexpr int U4_KT = 32;   // k-depth per stage
+__global__ __launch_bounds__(kBlock, 2) void ldlt_update4_kernel(double* __restrict__ A, int64_t lda, int N,
+                                                                 const double* __restrict__ V, int64_t ldv, int vrow0,
+                                                                 int urow0, int K, int s, int row_end, int col_end,
+                                                                 int skip_diag)
+{
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if(tj < ti) return;
+  const int r0 = s + ti * LD_TM, c0 = s + tj * LD_TN;
+  if(r0 >= row_end || c0 >= col_end) return;
+  if(skip_diag && r0 < s + LD_NB && c0 < s + LD_NB) return;
+  __shared__ __attribute__((aligned(16))) double Sh[2 * U4_KT * LD_LDP];
+  double (*Vs)[LD_LDP] = reinterpret_cast<double (*)[LD_LDP]>(Sh);
+  double (*Us)[LD_LDP] = reinterpret_cast<double (*)[LD_LDP]>(Sh + U4_KT * LD_LDP);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lk = lane >> 4, li = lane & 15;
+
+  double acc[4][4][4];   // [ib][jb][rotation]
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+#pragma unroll
+      for(int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  const int lcol = tid & 127, lrow = tid >> 7;
+  const bool vr_ok = (r0 + lcol) < N;
+  const bool uc_ok = (c0 + lcol) < N;
+  const double* Vp = V + (int64_t)(vrow0 + lrow) * ldv + (r0 + lcol);
+  const double* Up = A + (int64_t)(urow0 + lrow) * lda + (c0 + lcol);
+  double vreg[U4_KT / 2], ureg[U4_KT / 2];
+#pragma unroll
+  for(int q = 0; q < U4_KT / 2; ++q) {
+    vreg[q] = vr_ok ? Vp[(int64_t)(2 * q) * ldv] : 0.0;
+    ureg[q] = uc_ok ? Up[(int64_t)(2 * q) * lda] : 0.0;
+  }
+  // rotated column offsets of the B operand inside a 16-column block
+  const int rc0 = li, rc1 = (li + 4) & 15, rc2 = (li + 8) & 15, rc3 = (li + 12) & 15;
+  for(int kt = 0; kt < K; kt += U4_KT) {
+    __syncthreads();
+#pragma unroll
+    for(int q = 0; q < U4_KT / 2; ++q) {
+      Vs[2 * q + lrow][lcol] = vreg[q];
+      Us[2 * q + lrow][lcol] = ureg[q];
+    }
+    __syncthreads();
+    if(kt + U4_KT < K) {
+#pragma unroll
+      for(int q = 0; q < U4_KT / 2; ++q) {
+        vreg[q] = vr_ok ? Vp[(int64_t)(kt + U4_KT + 2 * q) * ldv] : 0.0;
+        ureg[q] = uc_ok ? Up[(int64_t)(kt + U4_KT + 2 * q) * lda] : 0.0;
+      }
+    }
+#pragma unroll 1
+    for(int kk = 0; kk < U4_KT / 4; ++kk) {
+      double a[4];
+#pragma unroll
+      for(int i = 0; i < 4; ++i) a[i] = Vs[kk * 4 + lk][wr * 64 + i * 16 + li];
+#pragma unroll
+      for(int j = 0; j < 4; ++j) {
+        const double* ub = &Us[kk * 4 + lk][wc * 64 + j * 16];
+        const double b0 = ub[rc0], b1 = ub[rc1], b2 = ub[rc2], b3 = ub[rc3];
+#pragma unroll
+        for(int i = 0; i < 4; ++i) {
+          acc[i][j][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b0, acc[i][j][0], 0, 0, 0);
+          acc[i][j][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b1, acc[i][j][1], 0, 0, 0);
+          acc[i][j][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b2, acc[i][j][2], 0, 0, 0);
+          acc[i][j][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b3, acc[i][j][3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- epilogue through LDS: pass q = tile rows {64 wr + 16 q .. + 15}, wr = 0, 1  ->  buffer rows 16 wr + (0..15)
+  constexpr int LDB = LD_TN + 4;
+  double (*Cb)[LDB] = reinterpret_cast<double (*)[LDB]>(Sh);
+  const int di = lane >> 4, db = (lane & 15) >> 2, dj = lane & 3;   // D lane -> (i, b, j)
+#pragma unroll
+  for(int q = 0; q < 4; ++q) {
+    __syncthreads();   // staging buffers / previous pass consumed
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+#pragma unroll
+      for(int r = 0; r < 4; ++r)
+        Cb[16 * wr + 4 * db + di][wc * 64 + 16 * j + 4 * ((db + r) & 3) + dj] = acc[q][j][r];
+    __syncthreads();
+    // wave w: buffer rows 8w .. 8w+7; lane: columns lane and lane + 64.  All 16 loads before the first store (a load
+    // cannot be hoisted above a possibly-aliasing store).
+    double cv[8][2];
+    const int col0 = c0 + lane, col1 = c0 + 64 + lane;
+#pragma unroll
+    for(int rr = 0; rr < 8; ++rr) {
+      const int br = 8 * wave + rr;
+      const int row = r0 + 64 * (br >> 4) + 16 * q + (br & 15);
+      const double* Crow = A + (int64_t)row * lda;
+      const bool okr = row < row_end;
+      cv[rr][0] = (okr && col0 < col_end && col0 >= row) ? Crow[col0] : 0.0;
+      cv[rr][1] = (okr && col1 < col_end && col1 >= row) ? Crow[col1] : 0.0;
+    }
+#pragma unroll
+    for(int rr = 0; rr < 8; ++rr) {
+      const int br = 8 * wave + rr;
+      const int row = r0 + 64 * (br >> 4) + 16 * q + (br & 15);
+      double* Crow = A + (int64_t)row * lda;
+      const bool okr = row < row_end;
+      if(okr && col0 < col_end && col0 >= row) Crow[col0] = cv[rr][0] - Cb[br][lane];
+      if(okr && col1 < col_end && col1 >= row) Crow[col1] = cv[rr][1] - Cb[br][64 + lane];
+    }
+  }
+}
+
 // 64 x 64-tile variant for the 256 x 256 diagonal block of the NEXT super-panel (the only update on the serial chain):
 // 10 workgroups instead of 3, each with a quarter of the MFMA work, on the reserved CUs.  Same operand layout as above;
 // each wave owns a 32 x 32 quadrant = 2 x 2 MFMA tiles.  Writes the matrix and the block's compact copy.
@@ -1816,8 +1941,14 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       const int per_xcd = (nS + 7) / 8;           // super-tiles per XCD
       grid = dim3((unsigned)(per_xcd * 64 * 8), 1, 1);
     }
-    hipLaunchKernelGGL(ldlt_update_kernel, grid, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, s,
-                       row_end, xcd_map, Cnext, col_end, skip_diag);
+    static int upd4 = -1;   // HIOPAMD_UPD4=1: the experimental 4x4x4-MFMA kernel
+    if(upd4 < 0) upd4 = std::getenv("HIOPAMD_UPD4") ? std::atoi(std::getenv("HIOPAMD_UPD4")) : 0;
+    if(upd4 && !xcd_map && !Cnext)
+      hipLaunchKernelGGL(ldlt_update4_kernel, grid, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, s,
+                         row_end, col_end, skip_diag);
+    else
+      hipLaunchKernelGGL(ldlt_update_kernel, grid, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, s,
+                         row_end, xcd_map, Cnext, col_end, skip_diag);
     if(timed) {
       (void)hipEventRecord(prof->get(), upd_stream);
       prof->flops += update_flops(N, K, s, row_end);
