@@ -89,6 +89,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIBPATH} is missing: build it with `python -m hiop_amd.build` (hipcc, gfx950). "
                 "hiop_amd has no CPU fallback.")
+        # PyTorch ships its own libamdhip64.  If libhiopamd.so were loaded first it would pull in /opt/rocm's copy and a
+        # later `import torch` would bring a second HIP runtime into the process (double free at exit): torch goes first,
+        # libhiopamd.so then binds to the runtime that is already there and shares torch's device memory and streams.
+        import torch  # noqa: F401
         L = C.CDLL(str(LIBPATH), mode=C.RTLD_GLOBAL)
         for name, (ret, args) in parse_header().items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -5,6 +5,7 @@
 // the reference's `write_kkt yes` option, not part of the timed hot path).
 #include "common.hpp"
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -62,6 +63,39 @@ int hiopamd_io_append_iajaaa_vector(hiopamd_ctx* ctx, const char* path, int m, c
   std::fprintf(f, "\n");
   std::fclose(f);
   return HIOPAMD_OK;
+}
+
+// hiopAlgFilterIPMNewton::outputIteration (hiopAlgFilterIPM.cpp:2783-2812) / ...QuasiNewton::outputIteration (:1521-1549)
+int hiopamd_io_iteration_header(char* buf, int buflen)
+{
+  if(!buf || buflen <= 0) return HIOPAMD_ERR_ARG;
+  const int n = std::snprintf(buf, (size_t)buflen, "iter    objective     inf_pr     inf_du   lg(mu)  alpha_du   alpha_pr linesrch\n");
+  return (n < 0 || n >= buflen) ? HIOPAMD_ERR_ARG : n;
+}
+
+int hiopamd_io_format_iteration(char* buf, int buflen, int quasi_newton, int iter, double obj, double inf_pr, double inf_du,
+                                double mu, double alpha_du, double alpha_pr, int ls_status, int ls_num, int use_soc,
+                                int use_fr)
+{
+  if(!buf || buflen <= 0) return HIOPAMD_ERR_ARG;
+  int n;
+  if(ls_status == -1) {
+    n = std::snprintf(buf, (size_t)buflen, "%4d %14.7e %7.3e  %7.3e %6.2f  %7.3e  %7.3e  -(-)\n", iter, obj, inf_pr, inf_du,
+                      std::log10(mu), alpha_du, alpha_pr);
+  } else {
+    char step[2] = {'?', 0};
+    if(ls_status == 1) step[0] = 's';
+    else if(ls_status == 2) step[0] = 'h';
+    else if(ls_status == 3) step[0] = 'f';
+    if(use_soc && ls_status >= 1 && ls_status <= 3) step[0] = (char)std::toupper(step[0]);
+    if(use_fr) {
+      if(!quasi_newton) ls_num = 0;   // only the Newton variant resets the count (:2803)
+      step[0] = 'R';
+    }
+    n = std::snprintf(buf, (size_t)buflen, "%4d %14.7e %7.3e  %7.3e %6.2f  %7.3e  %7.3e  %d(%s)\n", iter, obj, inf_pr, inf_du,
+                      std::log10(mu), alpha_du, alpha_pr, ls_num, step);
+  }
+  return (n < 0 || n >= buflen) ? HIOPAMD_ERR_ARG : n;
 }
 
 }  // extern "C"

@@ -491,6 +491,19 @@ int hiopamd_io_write_iajaaa_matrix(hiopamd_ctx* ctx, const char* path, int m, co
                                    int meq, int mineq);
 int hiopamd_io_append_iajaaa_vector(hiopamd_ctx* ctx, const char* path, int m, const double* v_dev);
 
+/* Iteration table of the interior-point loop, character for character what hiopAlgFilterIPMNewton::outputIteration /
+ * hiopAlgFilterIPMQuasiNewton::outputIteration print (src/Optimization/hiopAlgFilterIPM.cpp:2783-2812, :1521-1549), so
+ * that logs can be diffed against upstream runs (the reference's CPU-vs-GPU iteration-table comparison).
+ * Host-only (no device work).  Both write a NUL-terminated line INCLUDING the trailing newline into `buf` and return its
+ * length, or a negative status if `buflen` is too small.
+ *   header: printed by the reference when iter % 10 == 0;
+ *   ls_status: -1 -> "-(-)"; 1/2/3 -> s/h/f (upper case when use_soc != 0); anything else -> "?"; use_fr != 0 -> "R"
+ *   (and, in the Newton variant only, the line-search count is printed as 0);  obj = f / obj_scale, lg(mu) = log10(mu). */
+int hiopamd_io_iteration_header(char* buf, int buflen);
+int hiopamd_io_format_iteration(char* buf, int buflen, int quasi_newton, int iter, double obj, double inf_pr, double inf_du,
+                                double mu, double alpha_du, double alpha_pr, int ls_status, int ls_num, int use_soc,
+                                int use_fr);
+
 #ifdef __cplusplus
 }
 #endif
