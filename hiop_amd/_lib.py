@@ -30,6 +30,7 @@ class MdsStructure(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+LINOP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)   # hiopamd_linop_fn(user, x_dev, y_dev)
 
 
 def _ctype(t: str):
@@ -49,6 +50,8 @@ def _ctype(t: str):
         return None
     if t == "hiopamd_allreduce_fn":
         return ALLREDUCE_FN
+    if t == "hiopamd_linop_fn":
+        return LINOP_FN
     raise ValueError(f"unmapped C type {t!r}")
 
 

@@ -30,6 +30,7 @@ SOURCES = [
     "lowrank.hip",
     "kkt_xycyd.hip",
     "io.hip",
+    "krylov.hip",
 ]
 
 ARCH = "gfx950"

@@ -504,6 +504,31 @@ int hiopamd_io_format_iteration(char* buf, int buflen, int quasi_newton, int ite
                                 double mu, double alpha_du, double alpha_pr, int ls_status, int ls_num, int use_soc,
                                 int use_fr);
 
+/* =====================================================================================
+ * Krylov solvers (reference: src/LinAlg/hiopKrylovSolver.hpp:80-258; hiopPCGSolver::solve hiopKrylovSolver.cpp:152-373,
+ * hiopBiCGStabSolver::solve :397-700).  The reference's hiopLinearOperator::times_vec(y, x) becomes a callback on device
+ * pointers: return 0 on success; `y` never aliases `x`.  kind: 0 = PCG, 1 = BiCGStab.  Defaults tol = 1e-9,
+ * maxit = 8 (:81-82).  `solve` overwrites the right-hand side with the solution (the minimal-residual iterate if the
+ * method did not converge) and reports convergence in *converged_host.  The start vector is the solver's own buffer:
+ * zero at creation, left at the last iterate by every solve, reset by set_x0 — as in the reference (xk_ = x0_).
+ * Flags: 0 converged, 1 maximum number of iterations, 3 stagnation / tolerance too small, 4 breakdown of a scalar.
+ * BiCGStab counts half iterations (get_sol_num_iter returns k - 0.5 when it stops after the first half step).
+ * ===================================================================================== */
+typedef struct hiopamd_krylov hiopamd_krylov;
+typedef int (*hiopamd_linop_fn)(void* user, const double* x_dev, double* y_dev);
+int hiopamd_krylov_create(hiopamd_krylov** out, hiopamd_ctx* ctx, int kind, int64_t n, hiopamd_linop_fn A, void* A_user,
+                          hiopamd_linop_fn Mleft, void* Mleft_user, hiopamd_linop_fn Mright, void* Mright_user);
+int hiopamd_krylov_destroy(hiopamd_krylov* k);
+int hiopamd_krylov_set_tol(hiopamd_krylov* k, double tol);                 /* hiopKrylovSolver.hpp:105 */
+int hiopamd_krylov_set_max_num_iter(hiopamd_krylov* k, int maxit);         /* :98 */
+int hiopamd_krylov_set_x0(hiopamd_krylov* k, double xval);                 /* :95 */
+double* hiopamd_krylov_x0(hiopamd_krylov* k);                              /* device pointer of the start vector */
+int hiopamd_krylov_solve(hiopamd_krylov* k, double* b_inout, int* converged_host);
+int hiopamd_krylov_get_convergence_flag(const hiopamd_krylov* k);          /* :125 */
+double hiopamd_krylov_get_sol_num_iter(const hiopamd_krylov* k);           /* :116 */
+double hiopamd_krylov_get_sol_abs_resid(const hiopamd_krylov* k);          /* :110 */
+double hiopamd_krylov_get_sol_rel_resid(const hiopamd_krylov* k);          /* :113 */
+
 #ifdef __cplusplus
 }
 #endif

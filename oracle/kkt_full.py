@@ -424,15 +424,19 @@ class LowRankProvider:
 # ---------------------------------------------------------------------------------------------------------
 # BiCGStab (hiopKrylovSolver.cpp:390-700) on flat numpy vectors
 # ---------------------------------------------------------------------------------------------------------
-def bicgstab(A, ML, b, tol, maxit, dot=None):
-    """Returns (x, converged, flag, iter, abs_resid, rel_resid).  A, ML: callables v -> matrix*v."""
+def bicgstab(A, ML, b, tol, maxit, dot=None, MR=None, x0=None):
+    """Returns (x, converged, flag, iter, abs_resid, rel_resid).  A, ML, MR: callables v -> matrix*v; the preconditioned
+    direction is MR(ML(v)) (hiopKrylovSolver.cpp:504-511).  x0: start vector (default 0)."""
+    if MR is not None:
+        ML0 = ML
+        ML = (lambda v: MR(ML0(v))) if ML0 is not None else MR
     if dot is None:
         dot = lambda u, v: float(u @ v)
     nrm = lambda u: np.sqrt(dot(u, u))
     n2b = nrm(b)
     if n2b == 0.0:                                                 # :405-413
         return np.zeros_like(b), True, 0, 0.0, 0.0, 0.0
-    xk = np.zeros_like(b)                                          # x0 = 0 (set_x0(0.0), hiopKKTLinSys.cpp:941)
+    xk = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64)   # x0 = 0 (set_x0(0.0), hiopKKTLinSys.cpp:941)
     flag = 1
     imin = 0.0
     tolb = tol * n2b

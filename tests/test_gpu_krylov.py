@@ -1,0 +1,121 @@
+"""hiopamd_krylov_* (hiopPCGSolver / hiopBiCGStabSolver on device vectors) against the oracle restatement on the matrix of
+the reference's tests/test_pcg.cpp and tests/test_bicgstab.cpp, through the C ABI.  The operators are the library's own
+symmetric-triplet SpMV (hiopMatrixSymSparseTriplet::timesVec) and a component-wise product (the Jacobi preconditioner)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import krylov as kr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from hiop_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _device_ops(ctx, n):
+    ii, jj, vv, minv = kr.krylov_test_matrix(n)
+    d = lambda a, dt: torch.tensor(a, dtype=dt, device="cuda")
+    I, J, Vv, Mi = d(ii, torch.int32), d(jj, torch.int32), d(vv, torch.float64), d(minv, torch.float64)
+
+    def A(x, y):
+        ctx.call("hiopamd_spsym_times_vec", n, len(vv), I, J, Vv, 0.0, y, 1.0, x)
+
+    def M(x, y):
+        ctx.call("hiopamd_vec_copy", n, y, x)
+        ctx.call("hiopamd_vec_component_mult", n, y, Mi)
+    host_A = lambda x: kr.sym_times_vec(n, ii, jj, vv, x)
+    host_M = lambda x: minv * x
+    return A, M, host_A, host_M, (I, J, Vv, Mi)
+
+
+@pytest.mark.parametrize("n,tol,maxit", [(50, 1e-9, 8), (50, 1e-12, 200), (5000, 1e-9, 8), (5000, 1e-10, 400)])
+def test_pcg_matches_the_oracle(ctx, n, tol, maxit):
+    from hiop_amd.krylov import KrylovSolver
+    A, M, hA, hM, keep = _device_ops(ctx, n)
+    s = KrylovSolver(ctx, KrylovSolver.PCG, n, A, M, None)
+    s.set_tol(tol); s.set_max_num_iter(maxit)
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+    ok = s.solve(b); ctx.sync()
+    x, ok_o, flag, it, ares, rres, xk = kr.pcg(hA, hM, None, np.ones(n), tol=tol, maxit=maxit)
+    assert ok == ok_o and s.get_convergence_flag() == flag
+    if maxit <= 8:      # short runs: iterate for iterate (different summation order in the reductions only)
+        assert s.get_sol_num_iter() == it
+        np.testing.assert_allclose(b.cpu().numpy(), x, rtol=1e-9, atol=1e-13)
+        assert s.get_sol_abs_resid() == pytest.approx(ares, rel=1e-5, abs=1e-13)
+        assert s.get_sol_rel_resid() == pytest.approx(rres, rel=1e-5, abs=1e-13)
+        np.testing.assert_allclose(s.x0().cpu().numpy(), xk, rtol=1e-9, atol=1e-13)    # the persistent start vector
+    else:               # hundreds of iterations: rounding moves the residual inside the tolerance, not the outcome
+        assert abs(s.get_sol_num_iter() - it) <= 2
+        np.testing.assert_allclose(b.cpu().numpy(), x, rtol=1e-7, atol=1e-12)
+        assert s.get_sol_abs_resid() <= tol * np.sqrt(n) and s.get_sol_rel_resid() <= tol
+    s.close()
+
+
+@pytest.mark.parametrize("n,tol,maxit", [(50, 1e-9, 8), (50, 1e-12, 200), (5000, 1e-9, 8), (5000, 1e-10, 400)])
+def test_bicgstab_matches_the_oracle(ctx, n, tol, maxit):
+    from hiop_amd.krylov import KrylovSolver
+    A, M, hA, hM, keep = _device_ops(ctx, n)
+    s = KrylovSolver(ctx, KrylovSolver.BICGSTAB, n, A, M, None)
+    s.set_tol(tol); s.set_max_num_iter(maxit)
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+    ok = s.solve(b); ctx.sync()
+    x, ok_o, flag, it, ares, rres = kr.bicgstab(hA, hM, np.ones(n), tol, maxit)
+    assert ok == ok_o and s.get_convergence_flag() == flag
+    if maxit <= 8:
+        assert s.get_sol_num_iter() == it
+        np.testing.assert_allclose(b.cpu().numpy(), x, rtol=1e-7, atol=1e-12)
+        assert s.get_sol_abs_resid() == pytest.approx(ares, rel=1e-4, abs=1e-12)
+    else:
+        assert abs(s.get_sol_num_iter() - it) <= 2
+        np.testing.assert_allclose(b.cpu().numpy(), x, rtol=1e-6, atol=1e-11)
+        assert s.get_sol_abs_resid() <= tol * np.sqrt(n)
+    s.close()
+
+
+def test_right_preconditioner_warm_start_and_exit_paths(ctx):
+    from hiop_amd.krylov import KrylovSolver
+    n = 64
+    A, M, hA, hM, keep = _device_ops(ctx, n)
+    # right preconditioner only == left preconditioner only for PCG (z = MR(ML(r)))
+    sl = KrylovSolver(ctx, KrylovSolver.PCG, n, A, M, None); sl.set_max_num_iter(5)
+    sr = KrylovSolver(ctx, KrylovSolver.PCG, n, A, None, M); sr.set_max_num_iter(5)
+    bl = torch.ones(n, dtype=torch.float64, device="cuda"); br = bl.clone()
+    sl.solve(bl); sr.solve(br); ctx.sync()
+    np.testing.assert_allclose(bl.cpu().numpy(), br.cpu().numpy(), rtol=1e-13)
+    # BiCGStab with MR: same as the oracle's MR(ML(v)) composition
+    sb = KrylovSolver(ctx, KrylovSolver.BICGSTAB, n, A, None, M); sb.set_max_num_iter(6)
+    bb = torch.ones(n, dtype=torch.float64, device="cuda")
+    sb.solve(bb); ctx.sync()
+    xo = kr.bicgstab(hA, None, np.ones(n), 1e-9, 6, MR=hM)
+    np.testing.assert_allclose(bb.cpu().numpy(), xo[0], rtol=1e-9)
+    assert sb.get_sol_num_iter() == xo[3] and sb.get_convergence_flag() == xo[2]
+    # warm start: a second solve starts from the previous iterate (x0_ persists); set_x0(0) restores the cold start
+    s = KrylovSolver(ctx, KrylovSolver.PCG, n, A, M, None); s.set_tol(1e-12); s.set_max_num_iter(300)
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+    assert s.solve(b); ctx.sync()
+    it_cold = s.get_sol_num_iter()
+    b2 = torch.ones(n, dtype=torch.float64, device="cuda")
+    assert s.solve(b2); ctx.sync()
+    assert s.get_sol_num_iter() == 0.0                                         # "initial guess is good enough"
+    s.set_x0(0.0)
+    b3 = torch.ones(n, dtype=torch.float64, device="cuda")
+    assert s.solve(b3); ctx.sync()
+    assert s.get_sol_num_iter() == it_cold
+    # zero right-hand side: solution 0, flag 0, no operator call
+    z = torch.zeros(n, dtype=torch.float64, device="cuda")
+    assert s.solve(z) and s.get_convergence_flag() == 0 and s.get_sol_num_iter() == 0.0
+    # indefinite operator: breakdown flag 4
+    def negA(x, y):
+        A(x, y)
+        ctx.call("hiopamd_vec_scale", n, y, -1.0)
+    sn = KrylovSolver(ctx, KrylovSolver.PCG, n, negA, None, None)
+    bn = torch.ones(n, dtype=torch.float64, device="cuda")
+    assert not sn.solve(bn) and sn.get_convergence_flag() == 4
+    for k in (sl, sr, sb, s, sn):
+        k.close()
