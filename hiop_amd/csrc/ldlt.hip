@@ -854,6 +854,105 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// The same update with a templated tile shape — the DEFAULT (64 x 64 workgroup tiles).  Two effects, both measured:
+//  * fewer independent accumulators per wave run faster: 30.4 TFLOP/s with 4 x 4 MFMA tiles per wave (the kernel above),
+//    35.4 with 2 x 4 or 4 x 2, 39.5 with 2 x 2, 1 x 2 or 2 x 1 — the registers-only probe shows the same for the bare
+//    instruction (36 TFLOP/s with 16 accumulators, 46 with 4-8; profiles/r01_probes);
+//  * the tail of each of the 31 launches (the last tiles running on a part of the device) shrinks with the tile.
+// Operand traffic per flop doubles against the 128 x 128 tile but comes out of L2.
+// ------------------------------------------------------------------------------------------
+// Wave tile = (16 WI) x (16 WJ), workgroup tile = (32 WI) x (32 WJ) (2 x 2 waves).
+template <int WI, int WJ>
+__global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __restrict__ A, int64_t lda, int N,
+                                                                  const double* __restrict__ V, int64_t ldv, int vrow0,
+                                                                  int urow0, int K, int s, int row_end, int col_end,
+                                                                  int skip_diag)
+{
+  constexpr int TMx = 32 * WI, TNx = 32 * WJ;
+  const int ti = blockIdx.y, tj = blockIdx.x;   // ti in units of TMx rows, tj in units of TNx columns
+  const int r0 = s + ti * TMx, c0 = s + tj * TNx;
+  if(c0 + TNx - 1 < r0) return;                 // entirely below the diagonal
+  if(r0 >= row_end || c0 >= col_end) return;
+  if(skip_diag && r0 < s + LD_NB && c0 < s + LD_NB) return;
+  __shared__ double Vs[LD_KT][TMx + 16];
+  __shared__ double Us[LD_KT][TNx + 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lk = lane >> 4, li = lane & 15;
+  double4_t acc[WI][WJ];
+#pragma unroll
+  for(int i = 0; i < WI; ++i)
+#pragma unroll
+    for(int j = 0; j < WJ; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // staging: V 16 x TMx, U 16 x TNx; a k-row is read by TMx (TNx) consecutive threads
+  constexpr int VPR = kBlock / TMx, VL = LD_KT / VPR;   // k-rows per pass, loads per thread
+  constexpr int UPR = kBlock / TNx, UL = LD_KT / UPR;
+  const int vcol = tid % TMx, vrow = tid / TMx;
+  const int ucl = tid % TNx, urw = tid / TNx;
+  const bool vr_ok = (r0 + vcol) < N;
+  const bool uc_ok = (c0 + ucl) < N;
+  const double* Vp = V + (int64_t)(vrow0 + vrow) * ldv + (r0 + vcol);
+  const double* Up = A + (int64_t)(urow0 + urw) * lda + (c0 + ucl);
+  double vreg[VL], ureg[UL];
+#pragma unroll
+  for(int q = 0; q < VL; ++q) vreg[q] = vr_ok ? Vp[(int64_t)(VPR * q) * ldv] : 0.0;
+#pragma unroll
+  for(int q = 0; q < UL; ++q) ureg[q] = uc_ok ? Up[(int64_t)(UPR * q) * lda] : 0.0;
+  for(int kt = 0; kt < K; kt += LD_KT) {
+    __syncthreads();
+#pragma unroll
+    for(int q = 0; q < VL; ++q) Vs[VPR * q + vrow][vcol] = vreg[q];
+#pragma unroll
+    for(int q = 0; q < UL; ++q) Us[UPR * q + urw][ucl] = ureg[q];
+    __syncthreads();
+    if(kt + LD_KT < K) {
+#pragma unroll
+      for(int q = 0; q < VL; ++q) vreg[q] = vr_ok ? Vp[(int64_t)(kt + LD_KT + VPR * q) * ldv] : 0.0;
+#pragma unroll
+      for(int q = 0; q < UL; ++q) ureg[q] = uc_ok ? Up[(int64_t)(kt + LD_KT + UPR * q) * lda] : 0.0;
+    }
+#pragma unroll
+    for(int kk = 0; kk < LD_KT / 4; ++kk) {
+      double a[WI], b[WJ];
+#pragma unroll
+      for(int i = 0; i < WI; ++i) a[i] = Vs[kk * 4 + lk][wr * 16 * WI + i * 16 + li];
+#pragma unroll
+      for(int j = 0; j < WJ; ++j) b[j] = Us[kk * 4 + lk][wc * 16 * WJ + j * 16 + li];
+#pragma unroll
+      for(int i = 0; i < WI; ++i)
+#pragma unroll
+        for(int j = 0; j < WJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for(int i = 0; i < WI; ++i) {
+    double cv[4][WJ];
+    bool ok[4][WJ];
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int row = r0 + wr * 16 * WI + i * 16 + lk + 4 * reg;
+      const double* Crow = A + (int64_t)row * lda;
+#pragma unroll
+      for(int j = 0; j < WJ; ++j) {
+        const int col = c0 + wc * 16 * WJ + j * 16 + li;
+        ok[reg][j] = (row < row_end) && (col < col_end) && (col >= row);
+        cv[reg][j] = ok[reg][j] ? Crow[col] : 0.0;
+      }
+    }
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int row = r0 + wr * 16 * WI + i * 16 + lk + 4 * reg;
+      double* Crow = A + (int64_t)row * lda;
+#pragma unroll
+      for(int j = 0; j < WJ; ++j) {
+        const int col = c0 + wc * 16 * WJ + j * 16 + li;
+        if(ok[reg][j]) Crow[col] = cv[reg][j] - acc[i][j][reg];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // The same rank-K update on v_mfma_f64_4x4x4_4b_f64 — the form of the fp64 MFMA that sustains 75 TFLOP/s on gfx950
 // (the 16x16x4 form above: 36-46, scripts/probes/mfma_f64_peak.hip).  One instruction = four independent 4x4x4 products:
 //   A lane l = A_b[i = l%4][k = l/16], B lane l = B_b[k = l/16][j = l%4], D lane 16i + 4b + j = D_b[i][j],  b = (l%16)/4,
@@ -1943,7 +2042,27 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     }
     static int upd4 = -1;   // HIOPAMD_UPD4=1: the experimental 4x4x4-MFMA kernel
     if(upd4 < 0) upd4 = std::getenv("HIOPAMD_UPD4") ? std::atoi(std::getenv("HIOPAMD_UPD4")) : 0;
-    if(upd4 && !xcd_map && !Cnext)
+    // HIOPAMD_UPD64 = 10 WI + WJ selects the wave tile (16 WI) x (16 WJ) of ldlt_update_kernel_t; 0 = the 128 x 128-tile
+    // kernel with 4 x 4 MFMA tiles per wave.  Default 22: 64 x 64 workgroup tiles, 4 accumulators per wave.
+    static int upd64 = -1;
+    if(upd64 < 0) upd64 = std::getenv("HIOPAMD_UPD64") ? std::atoi(std::getenv("HIOPAMD_UPD64")) : 22;
+    if(upd64 && !xcd_map && !Cnext && grid.x == grid.y) {
+      // upd64 = 10 * WI + WJ
+      const int wi = upd64 / 10, wj = upd64 % 10;
+      const int ext = (int)grid.x * LD_TM;   // covered extent (multiple of 128)
+      const dim3 g2((unsigned)((ext + 32 * wj - 1) / (32 * wj)), (unsigned)((ext + 32 * wi - 1) / (32 * wi)));
+#define HIOPAMD_U64(I_, J_)                                                                                                  \
+  hipLaunchKernelGGL((ldlt_update_kernel_t<I_, J_>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, \
+                     s, row_end, col_end, skip_diag)
+      if(wi == 2 && wj == 2) HIOPAMD_U64(2, 2);
+      else if(wi == 1 && wj == 4) HIOPAMD_U64(1, 4);
+      else if(wi == 4 && wj == 2) HIOPAMD_U64(4, 2);
+      else if(wi == 1 && wj == 2) HIOPAMD_U64(1, 2);
+      else if(wi == 2 && wj == 1) HIOPAMD_U64(2, 1);
+      else HIOPAMD_U64(2, 4);
+#undef HIOPAMD_U64
+    }
+    else if(upd4 && !xcd_map && !Cnext)
       hipLaunchKernelGGL(ldlt_update4_kernel, grid, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, s,
                          row_end, col_end, skip_diag);
     else
