@@ -237,7 +237,7 @@ def main():
                 traffic, traffic_src = u["hbm_bytes_per_launch"], os.path.relpath(cand, os.path.dirname(os.path.abspath(__file__)))
         except Exception:
             pass
-    roofline = dict(bound="mfma", kernel="ldlt_update_kernel_t<2,2> (rank-K trailing update, 64x64 tiles, v_mfma_f64_16x16x4_f64)",
+    roofline = dict(bound="mfma", kernel="ldlt_update_kernel_t<2,2,8> (rank-K trailing update, 64x64 tiles, v_mfma_f64_16x16x4_f64)",
                     achieved=achieved, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
                     traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
                     launches_per_step=launches / a.steps, avg_launch_ms=ms_per_launch,

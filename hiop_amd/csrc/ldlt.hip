@@ -862,7 +862,7 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
 // Operand traffic per flop doubles against the 128 x 128 tile but comes out of L2.
 // ------------------------------------------------------------------------------------------
 // Wave tile = (16 WI) x (16 WJ), workgroup tile = (32 WI) x (32 WJ) (2 x 2 waves).
-template <int WI, int WJ>
+template <int WI, int WJ, int KTx = LD_KT>
 __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __restrict__ A, int64_t lda, int N,
                                                                   const double* __restrict__ V, int64_t ldv, int vrow0,
                                                                   int urow0, int K, int s, int row_end, int col_end,
@@ -874,8 +874,8 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
   if(c0 + TNx - 1 < r0) return;                 // entirely below the diagonal
   if(r0 >= row_end || c0 >= col_end) return;
   if(skip_diag && r0 < s + LD_NB && c0 < s + LD_NB) return;
-  __shared__ double Vs[LD_KT][TMx + 16];
-  __shared__ double Us[LD_KT][TNx + 16];
+  __shared__ double Vs[KTx][TMx + 16];
+  __shared__ double Us[KTx][TNx + 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int lk = lane >> 4, li = lane & 15;
@@ -885,8 +885,8 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
 #pragma unroll
     for(int j = 0; j < WJ; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
   // staging: V 16 x TMx, U 16 x TNx; a k-row is read by TMx (TNx) consecutive threads
-  constexpr int VPR = kBlock / TMx, VL = LD_KT / VPR;   // k-rows per pass, loads per thread
-  constexpr int UPR = kBlock / TNx, UL = LD_KT / UPR;
+  constexpr int VPR = kBlock / TMx, VL = KTx / VPR;   // k-rows per pass, loads per thread
+  constexpr int UPR = kBlock / TNx, UL = KTx / UPR;
   const int vcol = tid % TMx, vrow = tid / TMx;
   const int ucl = tid % TNx, urw = tid / TNx;
   const bool vr_ok = (r0 + vcol) < N;
@@ -898,21 +898,21 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
   for(int q = 0; q < VL; ++q) vreg[q] = vr_ok ? Vp[(int64_t)(VPR * q) * ldv] : 0.0;
 #pragma unroll
   for(int q = 0; q < UL; ++q) ureg[q] = uc_ok ? Up[(int64_t)(UPR * q) * lda] : 0.0;
-  for(int kt = 0; kt < K; kt += LD_KT) {
+  for(int kt = 0; kt < K; kt += KTx) {
     __syncthreads();
 #pragma unroll
     for(int q = 0; q < VL; ++q) Vs[VPR * q + vrow][vcol] = vreg[q];
 #pragma unroll
     for(int q = 0; q < UL; ++q) Us[UPR * q + urw][ucl] = ureg[q];
     __syncthreads();
-    if(kt + LD_KT < K) {
+    if(kt + KTx < K) {
 #pragma unroll
-      for(int q = 0; q < VL; ++q) vreg[q] = vr_ok ? Vp[(int64_t)(kt + LD_KT + VPR * q) * ldv] : 0.0;
+      for(int q = 0; q < VL; ++q) vreg[q] = vr_ok ? Vp[(int64_t)(kt + KTx + VPR * q) * ldv] : 0.0;
 #pragma unroll
-      for(int q = 0; q < UL; ++q) ureg[q] = uc_ok ? Up[(int64_t)(kt + LD_KT + UPR * q) * lda] : 0.0;
+      for(int q = 0; q < UL; ++q) ureg[q] = uc_ok ? Up[(int64_t)(kt + KTx + UPR * q) * lda] : 0.0;
     }
 #pragma unroll
-    for(int kk = 0; kk < LD_KT / 4; ++kk) {
+    for(int kk = 0; kk < KTx / 4; ++kk) {
       double a[WI], b[WJ];
 #pragma unroll
       for(int i = 0; i < WI; ++i) a[i] = Vs[kk * 4 + lk][wr * 16 * WI + i * 16 + li];
@@ -2043,18 +2043,29 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     static int upd4 = -1;   // HIOPAMD_UPD4=1: the experimental 4x4x4-MFMA kernel
     if(upd4 < 0) upd4 = std::getenv("HIOPAMD_UPD4") ? std::atoi(std::getenv("HIOPAMD_UPD4")) : 0;
     // HIOPAMD_UPD64 = 10 WI + WJ selects the wave tile (16 WI) x (16 WJ) of ldlt_update_kernel_t; 0 = the 128 x 128-tile
-    // kernel with 4 x 4 MFMA tiles per wave.  Default 22: 64 x 64 workgroup tiles, 4 accumulators per wave.
+    // kernel with 4 x 4 MFMA tiles per wave; 100 KT is added for a k-depth per stage other than 16.  Default 822: 64 x 64
+    // workgroup tiles, 4 accumulators per wave, 8-deep stages (16-deep: 39.5 TFLOP/s, 8 or 4: 40.8, 32: 36.8).
     static int upd64 = -1;
-    if(upd64 < 0) upd64 = std::getenv("HIOPAMD_UPD64") ? std::atoi(std::getenv("HIOPAMD_UPD64")) : 22;
+    if(upd64 < 0) upd64 = std::getenv("HIOPAMD_UPD64") ? std::atoi(std::getenv("HIOPAMD_UPD64")) : 822;
     if(upd64 && !xcd_map && !Cnext && grid.x == grid.y) {
       // upd64 = 10 * WI + WJ
-      const int wi = upd64 / 10, wj = upd64 % 10;
+      const int wi = (upd64 % 100) / 10, wj = upd64 % 10;
       const int ext = (int)grid.x * LD_TM;   // covered extent (multiple of 128)
       const dim3 g2((unsigned)((ext + 32 * wj - 1) / (32 * wj)), (unsigned)((ext + 32 * wi - 1) / (32 * wi)));
 #define HIOPAMD_U64(I_, J_)                                                                                                  \
   hipLaunchKernelGGL((ldlt_update_kernel_t<I_, J_>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, \
                      s, row_end, col_end, skip_diag)
-      if(wi == 2 && wj == 2) HIOPAMD_U64(2, 2);
+      if(upd64 == 322) hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 32>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
+                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
+      else if(upd64 == 422) hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 4>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
+                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
+      else if(upd64 == 812) hipLaunchKernelGGL((ldlt_update_kernel_t<1, 2, 8>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
+                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
+      else if(upd64 == 824) hipLaunchKernelGGL((ldlt_update_kernel_t<2, 4, 8>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
+                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
+      else if(upd64 == 822) hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
+                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
+      else if(wi == 2 && wj == 2) HIOPAMD_U64(2, 2);
       else if(wi == 1 && wj == 4) HIOPAMD_U64(1, 4);
       else if(wi == 4 && wj == 2) HIOPAMD_U64(4, 2);
       else if(wi == 1 && wj == 2) HIOPAMD_U64(1, 2);
