@@ -866,7 +866,7 @@ template <int WI, int WJ, int KTx = LD_KT>
 __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __restrict__ A, int64_t lda, int N,
                                                                   const double* __restrict__ V, int64_t ldv, int vrow0,
                                                                   int urow0, int K, int s, int row_end, int col_end,
-                                                                  int skip_diag)
+                                                                  int skip_diag, double* __restrict__ Cnext)
 {
   constexpr int TMx = 32 * WI, TNx = 32 * WJ;
   const int ti = blockIdx.y, tj = blockIdx.x;   // ti in units of TMx rows, tj in units of TNx columns
@@ -946,7 +946,12 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
 #pragma unroll
       for(int j = 0; j < WJ; ++j) {
         const int col = c0 + wc * 16 * WJ + j * 16 + li;
-        if(ok[reg][j]) Crow[col] = cv[reg][j] - acc[i][j][reg];
+        if(ok[reg][j]) {
+          const double nv = cv[reg][j] - acc[i][j][reg];
+          Crow[col] = nv;
+          // tiles of the next super-panel's diagonal block also feed its compact copy (origin s, ld = 256)
+          if(Cnext && row < s + LD_NB && col < s + LD_NB) Cnext[(row - s) * LD_NB + (col - s)] = nv;
+        }
       }
     }
   }
@@ -2048,29 +2053,19 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     static int upd64 = -1;
     if(upd64 < 0) upd64 = std::getenv("HIOPAMD_UPD64") ? std::atoi(std::getenv("HIOPAMD_UPD64")) : 822;
     if(upd64 && !xcd_map && !Cnext && grid.x == grid.y) {
-      // upd64 = 10 * WI + WJ
-      const int wi = (upd64 % 100) / 10, wj = upd64 % 10;
-      const int ext = (int)grid.x * LD_TM;   // covered extent (multiple of 128)
+      const int wi = (upd64 % 100) / 10, wj = upd64 % 10;   // upd64 = 100 KT + 10 WI + WJ
+      const int ext = (int)grid.x * LD_TM;                  // covered extent (multiple of 128)
       const dim3 g2((unsigned)((ext + 32 * wj - 1) / (32 * wj)), (unsigned)((ext + 32 * wi - 1) / (32 * wi)));
-#define HIOPAMD_U64(I_, J_)                                                                                                  \
-  hipLaunchKernelGGL((ldlt_update_kernel_t<I_, J_>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, \
-                     s, row_end, col_end, skip_diag)
-      if(upd64 == 322) hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 32>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
-                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
-      else if(upd64 == 422) hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 4>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
-                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
-      else if(upd64 == 812) hipLaunchKernelGGL((ldlt_update_kernel_t<1, 2, 8>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
-                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
-      else if(upd64 == 824) hipLaunchKernelGGL((ldlt_update_kernel_t<2, 4, 8>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
-                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
-      else if(upd64 == 822) hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N,
-                                          vrow0, urow0, K, s, row_end, col_end, skip_diag);
-      else if(wi == 2 && wj == 2) HIOPAMD_U64(2, 2);
-      else if(wi == 1 && wj == 4) HIOPAMD_U64(1, 4);
-      else if(wi == 4 && wj == 2) HIOPAMD_U64(4, 2);
-      else if(wi == 1 && wj == 2) HIOPAMD_U64(1, 2);
-      else if(wi == 2 && wj == 1) HIOPAMD_U64(2, 1);
-      else HIOPAMD_U64(2, 4);
+#define HIOPAMD_U64(...)                                                                                                       \
+  hipLaunchKernelGGL((ldlt_update_kernel_t<__VA_ARGS__>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, \
+                     K, s, row_end, col_end, skip_diag, nullptr)
+      if(upd64 == 822) HIOPAMD_U64(2, 2, 8);
+      else if(upd64 == 422) HIOPAMD_U64(2, 2, 4);
+      else if(upd64 == 22) HIOPAMD_U64(2, 2, 16);
+      else if(upd64 == 24) HIOPAMD_U64(2, 4, 16);
+      else if(upd64 == 42) HIOPAMD_U64(4, 2, 16);
+      else if(upd64 == 12) HIOPAMD_U64(1, 2, 16);
+      else HIOPAMD_U64(2, 2, 8);
 #undef HIOPAMD_U64
     }
     else if(upd4 && !xcd_map && !Cnext)
