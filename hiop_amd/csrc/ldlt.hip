@@ -455,16 +455,18 @@ __device__ __forceinline__ void block_row_solve_lds(const int P, double* A, int6
     __syncthreads();
     stage_block_bypass(S, A + (int64_t)(K0 + 64 * q) * lda + (K0 + 64 * P), lda, tid);   // U_qP = L_Pq^T
     __syncthreads();
+    // the four accumulators t[0..3] are independent: interleave them (a chain of 16 MFMAs on ONE accumulator waits for
+    // every result; the B operand is also read once instead of four times)
 #pragma unroll
-    for(int I = 0; I < 4; ++I) {
+    for(int Jq = 0; Jq < 4; ++Jq) {
 #pragma unroll
-      for(int Jq = 0; Jq < 4; ++Jq) {
+      for(int kk = 0; kk < 4; ++kk) {
+        const double vb = Vs[64 * q + 16 * Jq + 4 * kk + g][cl];
 #pragma unroll
-        for(int kk = 0; kk < 4; ++kk)
-          t[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[16 * Jq + 4 * kk + g][16 * I + li],
-                                                      Vs[64 * q + 16 * Jq + 4 * kk + g][cl], t[I], 0, 0, 0);
-        asm volatile("" ::: "memory");   // bound the number of LDS operand reads in flight (register pressure)
+        for(int I = 0; I < 4; ++I)
+          t[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[16 * Jq + 4 * kk + g][16 * I + li], vb, t[I], 0, 0, 0);
       }
+      asm volatile("" ::: "memory");   // bound the number of LDS operand reads in flight (register pressure)
     }
   }
   __syncthreads();
@@ -502,6 +504,125 @@ __device__ __forceinline__ void block_row_solve_lds(const int P, double* A, int6
       Vs[row][cl] = v;
       if(col_ok) A[(int64_t)(K0 + row) * lda + col] = v * dall[row];   // U = D^-1 V (V itself is only needed in LDS)
     }
+}
+
+// Phase (a) of the super-diagonal kernel for panel j, all block rows P < j, software-pipelined: the operand block of the
+// NEXT stage (U_{q+1,P}, or Dk_P + the 16x16 inverses, or the first block of block row P+1) is in flight — 16 + 16 loads
+// per thread, in registers — while the MFMAs of the current stage issue.  Un-pipelined, each of the 1 / 3 / 6 stages of
+// panel 1 / 2 / 3 paid 2-3 us of exposed load latency (in-kernel stamps: 10 / 20 / 33 us for 64 / 192 / 384 MFMAs).
+// Stage (P, q): q < P -> U_qP (from the compact block, rows 64q.., columns 64P..);  q == P -> Dk_P and Li_P.
+__device__ __forceinline__ void panel_block_rows_pipelined(const int j, double* A, int64_t lda, int K0, int64_t col,
+                                                           bool col_ok, int cl, const double* Dk_sp, const double* Li_sp,
+                                                           const double* dall, int g, int li, double (*S)[LD_nb + 1],
+                                                           double (*Vs)[80], int tid)
+{
+  if(j == 0) return;
+  double sv[LD_nb * LD_nb / kBlock];   // the prefetched 64 x 64 block
+  double liv[4][4];                    // the prefetched 16x16 inverses of a diagonal stage: [I][kk]
+  auto issue = [&](int P, int q) {
+    const double* src = (q < P) ? A + (int64_t)(K0 + 64 * q) * lda + (K0 + 64 * P) : Dk_sp + P * (LD_nb * LD_nb);
+    const int64_t ld = (q < P) ? lda : (int64_t)LD_nb;
+#pragma unroll
+    for(int e4 = 0; e4 < LD_nb * LD_nb / kBlock; ++e4) {
+      const int e = tid + e4 * kBlock;
+      sv[e4] = __hip_atomic_load(src + (int64_t)(e >> 6) * ld + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if(q == P) {
+      const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
+#pragma unroll
+      for(int I = 0; I < 4; ++I)
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk)
+          liv[I][kk] = __hip_atomic_load(Li + I * 256 + li * 16 + 4 * kk + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto drain_if_newest = [&](int P) {
+    // only the newest block row needs what panel j-1 emitted (A rows, Dk, Li): drain the stores before its first load
+    if(P == j - 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  };
+  drain_if_newest(0);
+  issue(0, 0);
+#pragma unroll 1
+  for(int P = 0; P < j; ++P) {
+    double4_t t[4];
+#pragma unroll
+    for(int I = 0; I < 4; ++I)
+#pragma unroll
+      for(int r = 0; r < 4; ++r) {
+        const int row = 64 * P + 16 * I + g + 4 * r;   // block rows below the current panel are always full
+        const double v = A[(int64_t)(K0 + row) * lda + col];
+        t[I][r] = col_ok ? v : 0.0;
+      }
+#pragma unroll 1
+    for(int q = 0; q <= P; ++q) {
+      __syncthreads();   // everybody is done with the previous stage's S
+#pragma unroll
+      for(int e4 = 0; e4 < LD_nb * LD_nb / kBlock; ++e4) {
+        const int e = tid + e4 * kBlock;
+        S[e >> 6][e & 63] = sv[e4];
+      }
+      double iv[4][4];
+      if(q == P) {
+#pragma unroll
+        for(int I = 0; I < 4; ++I)
+#pragma unroll
+          for(int kk = 0; kk < 4; ++kk) iv[I][kk] = liv[I][kk];
+      }
+      __syncthreads();
+      // next stage in flight
+      {
+        const int nP = (q < P) ? P : P + 1, nq = (q < P) ? q + 1 : 0;
+        if(nP < j) {
+          if(nq == 0) drain_if_newest(nP);
+          issue(nP, nq);
+        }
+      }
+      if(q < P) {
+#pragma unroll
+        for(int Jq = 0; Jq < 4; ++Jq) {
+#pragma unroll
+          for(int kk = 0; kk < 4; ++kk) {
+            const double vb = Vs[64 * q + 16 * Jq + 4 * kk + g][cl];
+#pragma unroll
+            for(int I = 0; I < 4; ++I)
+              t[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[16 * Jq + 4 * kk + g][16 * I + li], vb, t[I], 0, 0, 0);
+          }
+          asm volatile("" ::: "memory");   // bound the number of LDS operand reads in flight (register pressure)
+        }
+      } else {
+        double4_t vp[4];
+#pragma unroll
+        for(int I = 0; I < 4; ++I) {
+          double4_t u = t[I];
+#pragma unroll
+          for(int J = 0; J < 4; ++J) {
+            if(J < I) {
+#pragma unroll
+              for(int kk = 0; kk < 4; ++kk)
+                u = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[16 * J + 4 * kk + g][16 * I + li], vp[J][kk], u, 0, 0, 0);
+            }
+          }
+          double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[I][kk], u[kk], v, 0, 0, 0);
+          vp[I] = v;
+        }
+        // U = D^-1 V (in place) and the LDS copy of V for the later block rows / phase (b)
+#pragma unroll
+        for(int I = 0; I < 4; ++I)
+#pragma unroll
+          for(int r = 0; r < 4; ++r) {
+            const int row = 64 * P + 16 * I + g + 4 * r;
+            const double v = col_ok ? vp[I][r] : 0.0;
+            Vs[row][cl] = v;
+            if(col_ok) A[(int64_t)(K0 + row) * lda + col] = v * dall[row];
+          }
+      }
+    }
+  }
 }
 
 // Compact (contiguous, ld = 256) copies of the 256x256 diagonal blocks.  The 1-workgroup super-diagonal kernel makes
@@ -584,16 +705,7 @@ __global__ __launch_bounds__(kBlock) void ldlt_superdiag_kernel(double* __restri
       sv[q] = A[(int64_t)(k0 + rr) * lda + (k0 + cc)];
     }
     // ---- (a)
-#pragma unroll 1
-    for(int P = 0; P < j; ++P) {
-      if(P == j - 1) {
-        // only the newest block row needs what panel j-1 emitted (A rows, Dk, Li): drain this wave's stores here,
-        // after the older block rows have been processed, instead of stalling at the end of the previous panel
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
-      block_row_solve_lds(P, A, lda, V, ldv, K0, colc, col_ok, cl, Dk_sp, Li_sp, dall, g, li, S, Vs, tid);
-    }
+    panel_block_rows_pipelined(j, A, lda, K0, colc, col_ok, cl, Dk_sp, Li_sp, dall, g, li, S, Vs, tid);
     // ---- (b) S = A_jj (upper, zero padded)
     __syncthreads();   // every wave is done with the operand blocks staged in S during (a); Vs complete
     SD_STAMP(j * 4 + 1);
