@@ -302,3 +302,34 @@ def test_iajaaa_writer_reproduces_reference_files(ctx, fname, tmp_path):
             torch.cuda.synchronize()
             check(L.hiopamd_io_append_iajaaa_vector(ctx.h, C.c_char_p(out), n, C.c_void_p(vd.data_ptr())), "append")
     assert open(out.decode()).read().split() == open(src).read().split()
+
+
+@pytest.mark.parametrize("n", [1, 17, 255, 256, 257, 511, 513, 1023, 1280, 2049])
+def test_dataflow_solve_block_boundaries_multi_rhs_and_repeats(ctx, n):
+    """hiopamd_linsolver_solve around the 256-block boundaries of the dataflow kernel (ragged last block, one block, N = 1),
+    several right-hand sides in one call, and repeated solves (the exchange buffers alternate by epoch parity and are
+    re-poisoned by the previous launch): every solve must reproduce the dense solution and repeat bit for bit."""
+    from hiop_amd.kkt import LinSolverSymDense
+    g = torch.Generator(device="cuda"); g.manual_seed(100 + n)
+    n1 = (n + 1) // 2
+    M = torch.rand((n, n), generator=g, device="cuda", dtype=torch.float64) - 0.5
+    M = M + M.T
+    sgn = torch.ones(n, device="cuda", dtype=torch.float64); sgn[n1:] = -1.0
+    M = M + torch.diag(sgn * (2.0 + 0.6 * n ** 0.5 * 4))          # quasi-definite: n1 positive, n - n1 negative pivots
+    ls = LinSolverSymDense(ctx, n)
+    ls.set_sys_matrix(torch.triu(M))
+    assert ls.matrix_changed() == n - n1
+    nrhs = 3
+    B = torch.rand((nrhs, n), generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    X = B.clone()
+    ls.solve(X, nrhs); ctx.sync()
+    ref = torch.linalg.solve(M, B.T).T
+    assert (X - ref).abs().max().item() <= 1e-10 * max(1.0, ref.abs().max().item())
+    first = None
+    for rep in range(5):                                        # odd and even epochs
+        x = B[1].clone()
+        ls.solve(x, 1); ctx.sync()
+        if first is None:
+            first = x.clone()
+        assert torch.equal(x, first)
+    assert torch.equal(first, X[1])
