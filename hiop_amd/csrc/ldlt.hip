@@ -793,6 +793,91 @@ __global__ __launch_bounds__(64) void ldlt_supertrsm_kernel(double* __restrict__
   }
 }
 
+// The HEAD of the row panel (the next super-panel's 256 columns — on the serial chain) with FOUR waves per 16 columns:
+// wave I owns the 16-row sub-block I of every block row.  The single-wave kernel above spends 45 us on 640 MFMAs of
+// ~130 cycles each, 384 of them in the products T_P -= L_Pq V_q; split by rows these are 96 per wave, and what stays serial
+// is the 16-row substitution inside a block row: sub-step J = wave J finishes V_P[J] = Linv16_J u, publishes it in LDS,
+// every wave I > J subtracts L_PP[I][J] V_P[J].  V is exchanged through LDS (Vs), one barrier per sub-step.  Only full
+// panels (kbs = 256) are launched with it.  grid = 16-column groups, 256 threads.
+__global__ __launch_bounds__(kBlock) void ldlt_headtrsm_kernel(double* __restrict__ A, int64_t lda, int N, int K0,
+                                                               double* __restrict__ V, int64_t ldv,
+                                                               const double* __restrict__ dinv,
+                                                               const double* __restrict__ Cd,
+                                                               const double* __restrict__ Dk_sp,
+                                                               const double* __restrict__ Li_sp, int col_ofs)
+{
+  __shared__ double Vs[LD_NB][LD_SB + 1];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int I = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's 16-row sub-block
+  const int64_t col = (int64_t)K0 + LD_NB + col_ofs + (int64_t)blockIdx.x * 16 + li;
+  const bool col_ok = col < N;
+  const int64_t colc = col_ok ? col : (int64_t)(N - 1);
+  // the wave's rows of the matrix, all four block rows (independent of everything computed here)
+  double4_t t[4];
+#pragma unroll
+  for(int P = 0; P < 4; ++P)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      const double v = ld_batch(A + (int64_t)(K0 + 64 * P + 16 * I + g + 4 * r) * lda + colc);
+      t[P][r] = col_ok ? v : 0.0;
+    }
+  auto load_L = [&](double (&Lop)[4][4], int P, int q) {   // L_Pq[16 I + li][16 Jq + 4 kk + g], Jq, kk = 0..3
+#pragma unroll
+    for(int Jq = 0; Jq < 4; ++Jq)
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) Lop[Jq][kk] = -ld_batch(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (64 * P + 16 * I + li));
+  };
+#pragma unroll
+  for(int P = 0; P < 4; ++P) {
+    const double* Dk = Dk_sp + P * (LD_nb * LD_nb);
+    const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
+    // operands of the in-block substitution: L_PP[I][J], J < I, and the 16x16 inverse of sub-block I
+    double nl[3][4], iv[4];
+#pragma unroll
+    for(int J = 0; J < 3; ++J)
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) nl[J][kk] = (J < I) ? -ld_batch(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li) : 0.0;
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) iv[kk] = ld_batch(Li + I * 256 + li * 16 + 4 * kk + g);
+    // ---- T_P -= L_Pq V_q, q < P (V_q complete in LDS: the barriers of the previous block row)
+    double4_t u = t[P];
+#pragma unroll
+    for(int q = 0; q < P; ++q) {
+      double Lop[4][4];
+      load_L(Lop, P, q);
+#pragma unroll
+      for(int Jq = 0; Jq < 4; ++Jq)
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk)
+          u = __builtin_amdgcn_mfma_f64_16x16x4f64(Lop[Jq][kk], Vs[64 * q + 16 * Jq + 4 * kk + g][li], u, 0, 0, 0);
+    }
+    // ---- the 16-row substitution across the four waves
+#pragma unroll
+    for(int J = 0; J < 4; ++J) {
+      if(I == J) {   // wave-uniform
+        double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[kk], u[kk], v, 0, 0, 0);
+#pragma unroll
+        for(int r = 0; r < 4; ++r) {
+          const int row = 64 * P + 16 * I + g + 4 * r;
+          Vs[row][li] = v[r];
+          if(col_ok) {
+            V[(int64_t)row * ldv + col] = v[r];
+            A[(int64_t)(K0 + row) * lda + col] = v[r] * dinv[K0 + row];
+          }
+        }
+      }
+      __syncthreads();
+      if(I > J && J < 3) {
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk)
+          u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[J][kk], Vs[64 * P + 16 * J + 4 * kk + g][li], u, 0, 0, 0);
+      }
+    }
+  }
+}
+
 // W_J = U_JJ^-1 = (L_JJ^-1)^T of every 256 x 256 diagonal block, for the dataflow solve: the row-panel substitution
 // above applied to an identity.  grid = (16, number of blocks), one wave per 16 columns of the identity.
 __global__ __launch_bounds__(64) void ldlt_inv_diag_kernel(int N, const double* __restrict__ Cd_all,
@@ -2269,9 +2354,16 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       trace_state = 2;
     }
   };
+  static int head4 = -1;   // HIOPAMD_HEAD4=0: the head of the row panel with the one-wave-per-16-columns kernel
+  if(head4 < 0) head4 = std::getenv("HIOPAMD_HEAD4") ? std::atoi(std::getenv("HIOPAMD_HEAD4")) : 1;
   auto trsm = [&](int jp, hipStream_t stream, int col_ofs, int ncols) {
     if(ncols <= 0) return;
     const Panel p = panel(jp);
+    if(head4 && col_ofs == 0 && ncols <= LD_NB && p.kbs == LD_NB) {   // the head, on the chain stream
+      hipLaunchKernelGGL(ldlt_headtrsm_kernel, dim3((ncols + 15) / 16), dim3(kBlock), 0, stream, A, lda, N, p.K0, p.Vb, ldv, dinv,
+                         p.Cj, p.Dk_sp, p.Li_sp, col_ofs);
+      return;
+    }
     hipLaunchKernelGGL(ldlt_supertrsm_kernel, dim3((ncols + 15) / 16), dim3(64), 0, stream, A, lda, N, p.K0, p.kbs, p.Vb, ldv,
                        dinv, p.Cj, p.Dk_sp, p.Li_sp, col_ofs);
   };
