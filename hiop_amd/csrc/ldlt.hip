@@ -2359,7 +2359,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   auto trsm = [&](int jp, hipStream_t stream, int col_ofs, int ncols) {
     if(ncols <= 0) return;
     const Panel p = panel(jp);
-    if(head4 && col_ofs == 0 && ncols <= LD_NB && p.kbs == LD_NB) {   // the head, on the chain stream
+    if(head4 && p.kbs == LD_NB && (head4 >= 2 || (col_ofs == 0 && ncols <= LD_NB))) {   // the head, on the chain stream (2: the tail too)
       hipLaunchKernelGGL(ldlt_headtrsm_kernel, dim3((ncols + 15) / 16), dim3(kBlock), 0, stream, A, lda, N, p.K0, p.Vb, ldv, dinv,
                          p.Cj, p.Dk_sp, p.Li_sp, col_ofs);
       return;
