@@ -88,50 +88,84 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
 {
   __shared__ double Lv[LD_SB][LD_SB + 1];
   const int lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
-  for(int sb = 0; sb < LD_nb / LD_SB; ++sb) {
+  // (i) for sub-block sb, by wave 0 (call with tid < 64): in-register 16x16 Gauss-Jordan; a padded sub-block (o >= kb)
+  // just gets the identity as its inverse
+  auto factor16 = [&](int sb) {
     const int o = sb * LD_SB;
-    if(o >= kb) {   // uniform: padded sub-block -> identity inverse
-      if(tid < LD_SB * LD_SB) Li[sb * 256 + tid] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
-      continue;
+    if(o >= kb) {
+#pragma unroll
+      for(int q = 0; q < 4; ++q) {
+        const int e = tid + 64 * q;
+        Li[sb * 256 + e] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+      }
+      return;
     }
-    // ---- (i)
-    if(tid < 64) {
-      const int c = li;
-      double a[LD_SB], m[LD_SB];
+    const int c = li;
+    double a[LD_SB], m[LD_SB];
+#pragma unroll
+    for(int r = 0; r < LD_SB; ++r) {
+      a[r] = S[o + r][o + c];   // zeros below the diagonal
+      m[r] = (r == c) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for(int k = 0; k < LD_SB; ++k) {
+      if(o + k < kb) {  // uniform
+        const double d = bcast_lane(a[k], k);          // pivot
+        const double di = fast_rcp(d);
+        const double ukc = a[k] * di;                  // scaled pivot-row entry of my column
+        const double mkc = m[k] * di;
+#pragma unroll
+        for(int r = k + 1; r < LD_SB; ++r) {
+          const double vkr = bcast_lane(a[k], r);      // S[k][r]: multiplier of row r is vkr/d
+          a[r] = fma(-vkr, ukc, a[r]);
+          m[r] = fma(-vkr, mkc, m[r]);
+        }
+        if(tid == 0) {
+          sdinv[o + k] = di;
+          if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + o + k + 1);
+        }
+      }
+    }
+    if(tid < LD_SB) {
 #pragma unroll
       for(int r = 0; r < LD_SB; ++r) {
-        a[r] = S[o + r][o + c];   // zeros below the diagonal
-        m[r] = (r == c) ? 1.0 : 0.0;
-      }
-#pragma unroll
-      for(int k = 0; k < LD_SB; ++k) {
-        if(o + k < kb) {  // uniform
-          const double d = bcast_lane(a[k], k);          // pivot
-          const double di = fast_rcp(d);
-          const double ukc = a[k] * di;                  // scaled pivot-row entry of my column
-          const double mkc = m[k] * di;
-#pragma unroll
-          for(int r = k + 1; r < LD_SB; ++r) {
-            const double vkr = bcast_lane(a[k], r);      // S[k][r]: multiplier of row r is vkr/d
-            a[r] = fma(-vkr, ukc, a[r]);
-            m[r] = fma(-vkr, mkc, m[r]);
-          }
-          if(tid == 0) {
-            sdinv[o + k] = di;
-            if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + o + k + 1);
-          }
-        }
-      }
-      if(tid < LD_SB) {
-#pragma unroll
-        for(int r = 0; r < LD_SB; ++r) {
-          if(c >= r) S[o + r][o + c] = a[r];
-          Lv[r][c] = m[r];
-          Li[sb * 256 + r * 16 + c] = m[r];
-        }
+        if(c >= r) S[o + r][o + c] = a[r];
+        Lv[r][c] = m[r];
+        Li[sb * 256 + r * 16 + c] = m[r];
       }
     }
-    __syncthreads();
+  };
+  // one 16x16 tile of (iii): C -= V^T D^-1 V, (ti, tj) = 0:(0,0) 1:(0,1) 2:(0,2) 3:(1,1) 4:(1,2) 5:(2,2)
+  auto update_tile = [&](int o, int t6) {
+    const int ti = (t6 < 3) ? 0 : ((t6 < 5) ? 1 : 2);
+    const int tj = (t6 < 3) ? t6 : ((t6 < 5) ? (t6 - 2) : 2);
+    const int ro = o + LD_SB + 16 * ti, co = o + LD_SB + 16 * tj;
+    if(co < LD_nb && ro < kb) {   // wave-uniform
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+      double aop[4], bop[4];
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) {
+        const double dk = sdinv[o + 4 * kk + g];
+        aop[kk] = S[o + 4 * kk + g][ro + li];
+        bop[kk] = S[o + 4 * kk + g][co + li] * dk;
+      }
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], bop[kk], acc, 0, 0, 0);
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg) {
+        const int r = ro + g + 4 * reg, c = co + li;
+        if(c >= r) S[r][c] -= acc[reg];
+      }
+    }
+  };
+  if(tid < 64) factor16(0);
+  __syncthreads();
+  for(int sb = 0; sb < LD_nb / LD_SB; ++sb) {
+    const int o = sb * LD_SB;
+    if(o >= kb) {   // uniform: nothing left (its inverse was set by the look-ahead below / above)
+      if(sb + 1 < LD_nb / LD_SB && tid < 64) factor16(sb + 1);
+      continue;
+    }
     // ---- (ii) V = Linv16 * A_panel, one 16-column group per wave
     {
       const int cbase = o + LD_SB + 16 * w;
@@ -150,33 +184,20 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
       }
     }
     __syncthreads();
-    // ---- (iii) C -= V^T D^-1 V on the upper 16x16 tiles of the trailing part
-    {
-      double aop[4], dk[4];
-#pragma unroll
-      for(int t6 = w; t6 < 6; t6 += 4) {
-        // (ti,tj): 0:(0,0) 1:(0,1) 2:(0,2) 3:(1,1) 4:(1,2) 5:(2,2)
-        const int ti = (t6 < 3) ? 0 : ((t6 < 5) ? 1 : 2);
-        const int tj = (t6 < 3) ? t6 : ((t6 < 5) ? (t6 - 2) : 2);
-        const int ro = o + LD_SB + 16 * ti, co = o + LD_SB + 16 * tj;
-        if(co < LD_nb && ro < kb) {   // wave-uniform
-          double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
-          double bop[4];
-#pragma unroll
-          for(int kk = 0; kk < 4; ++kk) {
-            dk[kk] = sdinv[o + 4 * kk + g];
-            aop[kk] = S[o + 4 * kk + g][ro + li];
-            bop[kk] = S[o + 4 * kk + g][co + li] * dk[kk];
-          }
-#pragma unroll
-          for(int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[kk], bop[kk], acc, 0, 0, 0);
-#pragma unroll
-          for(int reg = 0; reg < 4; ++reg) {
-            const int r = ro + g + 4 * reg, c = co + li;
-            if(c >= r) S[r][c] -= acc[reg];
-          }
-        }
-      }
+    // ---- (iii) rank-16 update of the trailing tiles, with LOOK-AHEAD: wave 0 updates the next diagonal tile and goes
+    // straight on to factor it (i) while waves 1-3 update the other five tiles
+    if(w == 0) {
+      update_tile(o, 0);
+      asm volatile("" ::: "memory");
+      if(sb + 1 < LD_nb / LD_SB) factor16(sb + 1);
+    } else if(w == 1) {
+      update_tile(o, 1);
+      update_tile(o, 4);
+    } else if(w == 2) {
+      update_tile(o, 2);
+      update_tile(o, 5);
+    } else {
+      update_tile(o, 3);
     }
     __syncthreads();
   }
