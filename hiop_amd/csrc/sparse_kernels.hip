@@ -146,28 +146,44 @@ __global__ __launch_bounds__(kBlock) void mdinv_short(int64_t n_short, const int
   }
 }
 
-__global__ __launch_bounds__(kBlock) void mdinv_long(int64_t first, int64_t n_long, const int* __restrict__ out_i,
-                                                     const int* __restrict__ out_j,
-                                                     const int64_t* __restrict__ out_ptr, const int* __restrict__ k1,
-                                                     const int* __restrict__ k2, const int* __restrict__ col,
-                                                     const double* __restrict__ v1, const double* __restrict__ v2,
-                                                     const double* __restrict__ D, double alpha,
-                                                     double* __restrict__ W, int64_t ldw, int r0, int c0)
+// long outputs (a pair of rows with thousands of common columns — the inequality rows of MdsEx1): the product list of one
+// output is cut into MDINV_SPLIT slices, one workgroup per (output, slice) — a single workgroup per output walked its
+// 1e5 gather-products in 400 dependent rounds (170 us for 6 outputs on an otherwise idle device); the slice sums are
+// folded in slice order, so the result does not depend on the schedule.
+constexpr int MDINV_SPLIT = 64;
+__global__ __launch_bounds__(kBlock) void mdinv_long(int64_t first, int64_t n_long, const int64_t* __restrict__ out_ptr,
+                                                     const int* __restrict__ k1, const int* __restrict__ k2,
+                                                     const int* __restrict__ col, const double* __restrict__ v1,
+                                                     const double* __restrict__ v2, const double* __restrict__ D,
+                                                     double* __restrict__ part)
 {
-  // one workgroup per long output; fixed-order tree reduction
-  const int64_t p = first + blockIdx.x;
-  if(blockIdx.x >= n_long) return;
+  const int64_t o = blockIdx.x / MDINV_SPLIT;
+  const int sl = blockIdx.x % MDINV_SPLIT;
+  if(o >= n_long) return;
+  const int64_t p = first + o;
+  const int64_t b = out_ptr[p], e = out_ptr[p + 1];
+  const int64_t chunk = (e - b + MDINV_SPLIT - 1) / MDINV_SPLIT;
+  const int64_t q0 = b + sl * chunk;
+  int64_t q1 = q0 + chunk;
+  if(q1 > e) q1 = e;
   double acc = 0.0;
-  const int64_t e = out_ptr[p + 1];
-  for(int64_t q = out_ptr[p] + threadIdx.x; q < e; q += kBlock) acc += v1[k1[q]] / D[col[q]] * v2[k2[q]];
+  for(int64_t q = q0 + threadIdx.x; q < q1; q += kBlock) acc += v1[k1[q]] / D[col[q]] * v2[k2[q]];
   for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   __shared__ double sm[kBlock / 64];
   if((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if(threadIdx.x == 0) {
-    acc = ((sm[0] + sm[1]) + sm[2]) + sm[3];
-    W[(int64_t)(r0 + out_i[p]) * ldw + (c0 + out_j[p])] += alpha * acc;
-  }
+  if(threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+__global__ __launch_bounds__(64) void mdinv_long_fold(int64_t first, int64_t n_long, const int* __restrict__ out_i,
+                                                      const int* __restrict__ out_j, const double* __restrict__ part,
+                                                      double alpha, double* __restrict__ W, int64_t ldw, int r0, int c0)
+{
+  const int64_t o = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if(o >= n_long) return;
+  double s = 0.0;
+  for(int q = 0; q < MDINV_SPLIT; ++q) s += part[o * MDINV_SPLIT + q];
+  const int64_t p = first + o;
+  W[(int64_t)(r0 + out_i[p]) * ldw + (c0 + out_j[p])] += alpha * s;
 }
 
 // y[vec_start+row] += alpha * Msym[row,row] for row in [diag_src_start, diag_src_start+num_elems)
@@ -397,9 +413,11 @@ int hiopamd_sp_add_MDinvNt(hiopamd_ctx* ctx, const hiopamd_sp_plan* pl, const do
                        pl->out_j, pl->out_ptr, pl->k1, pl->k2, pl->col, val1, val2, D, alpha, W, ldw, r0, c0);
   }
   if(pl->n_long > 0) {
-    hipLaunchKernelGGL(mdinv_long, dim3((unsigned)pl->n_long), dim3(kBlock), 0, ctx->stream, pl->n_short, pl->n_long,
-                       pl->out_i, pl->out_j, pl->out_ptr, pl->k1, pl->k2, pl->col, val1, val2, D, alpha, W, ldw, r0,
-                       c0);
+    double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)pl->n_long * MDINV_SPLIT);
+    hipLaunchKernelGGL(mdinv_long, dim3((unsigned)(pl->n_long * MDINV_SPLIT)), dim3(kBlock), 0, ctx->stream, pl->n_short,
+                       pl->n_long, pl->out_ptr, pl->k1, pl->k2, pl->col, val1, val2, D, part);
+    hipLaunchKernelGGL(mdinv_long_fold, dim3((unsigned)((pl->n_long + 63) / 64)), dim3(64), 0, ctx->stream, pl->n_short,
+                       pl->n_long, pl->out_i, pl->out_j, part, alpha, W, ldw, r0, c0);
   }
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
