@@ -183,25 +183,44 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
   const int nxs = s.nxs, nxd = s.nxd, neq = s.neq, nineq = s.nineq;
   double* rxs = k->buf_xs;
   const double* Hxs = k->Hxs;
-  // rxs = Hxs^-1 rx_sparse                                                   (:337-338)
-  RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { rxs[i] = rx[i] / Hxs[i]; }));
-  // dyc = ryc - Jcs rxs ; ryd = ryd - Jds rxs                                (:343-347)
-  RC(hiopamd_vec_copy(ctx, neq, dyc, ryc));
+  double* rhs = k->rhs;
+  // rxs = Hxs^-1 rx_sparse; dyc = ryc  (one pass)                            (:337-338, :343)
+  {
+    const int64_t nmax = (nxs > neq) ? nxs : neq;
+    RC(launch_ew(ctx, nmax, [=] __device__(int64_t i) {
+      if(i < nxs) rxs[i] = rx[i] / Hxs[i];
+      if(i < neq) dyc[i] = ryc[i];
+    }));
+  }
+  // dyc -= Jcs rxs ; ryd -= Jds rxs                                          (:343-347)
   RC(hiopamd_sp_times_vec(ctx, neq, nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, 1.0, dyc, -1.0, rxs));
   RC(hiopamd_sp_times_vec(ctx, nineq, nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, 1.0, ryd, -1.0, rxs));
-  // rhs = [rx_dense; dyc; ryd]                                               (:353-357)
-  RC(hiopamd_vec_copy(ctx, nxd, k->rhs, rx + nxs));
-  RC(hiopamd_vec_copy(ctx, neq, k->rhs + nxd, dyc));
-  RC(hiopamd_vec_copy(ctx, nineq, k->rhs + nxd + neq, ryd));
+  // rhs = [rx_dense; dyc; ryd]  (one pass instead of three copies)            (:353-357)
+  {
+    const double* rxd = rx + nxs;
+    RC(launch_ew(ctx, (int64_t)nxd + neq + nineq, [=] __device__(int64_t i) {
+      rhs[i] = (i < nxd) ? rxd[i] : ((i < nxd + neq) ? dyc[i - nxd] : ryd[i - nxd - neq]);
+    }));
+  }
   // solve                                                                    (:367)
-  RC(hiopamd_linsolver_solve(k->ls, k->rhs, 1));
-  // unpack                                                                   (:383-385)
-  RC(hiopamd_vec_copy(ctx, nxd, dx + nxs, k->rhs));
-  RC(hiopamd_vec_copy(ctx, neq, dyc, k->rhs + nxd));
-  RC(hiopamd_vec_copy(ctx, nineq, dyd, k->rhs + nxd + neq));
-  // dxs = Hxs^-1 (rxs - Jcs^T dyc - Jds^T dyd)                               (:390-395)
+  RC(hiopamd_linsolver_solve(k->ls, rhs, 1));
+  // unpack dx_dense, dyc, dyd and start dxs = rx_sparse  (one pass)           (:383-390)
   double* dxs = k->buf_xs;
-  RC(hiopamd_vec_copy(ctx, nxs, dxs, rx));
+  {
+    double* dxd = dx + nxs;
+    const int64_t m = (int64_t)nxd + neq + nineq;
+    const int64_t nmax = (m > nxs) ? m : nxs;
+    RC(launch_ew(ctx, nmax, [=] __device__(int64_t i) {
+      if(i < m) {
+        const double v = rhs[i];
+        if(i < nxd) dxd[i] = v;
+        else if(i < nxd + neq) dyc[i - nxd] = v;
+        else dyd[i - nxd - neq] = v;
+      }
+      if(i < nxs) dxs[i] = rx[i];
+    }));
+  }
+  // dxs = Hxs^-1 (rxs - Jcs^T dyc - Jds^T dyd)                               (:390-395)
   RC(hiopamd_sp_trans_times_vec(ctx, neq, nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, 1.0, dxs, -1.0, dyc));
   RC(hiopamd_sp_trans_times_vec(ctx, nineq, nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, 1.0, dxs, -1.0, dyd));
   RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { dx[i] = dxs[i] / Hxs[i]; }));
