@@ -253,8 +253,15 @@ def main():
                                    dyd.cpu().numpy())
 
     dense = None
+    dense_c2 = None
     if not a.no_dense:
         dense = dense_lowrank_bench(ctx, world, rank, a, dist)
+        if world == 1:
+            # BASELINE configs[1]: NlpDenseCons_ex2 shape on ONE GPU, n = 1e6, m = 100 (the single-GPU dense low-rank case)
+            import copy
+            a2 = copy.copy(a)
+            a2.dense_nlocal, a2.dense_k = 1_000_000, 100
+            dense_c2 = dense_lowrank_bench(ctx, world, rank, a2, dist)
 
     out = None
     if rank == 0:
@@ -272,6 +279,8 @@ def main():
         }
         if dense is not None:
             out["dense_sharded"] = dense
+        if dense_c2 is not None:
+            out["dense_n1e6_m100"] = dense_c2
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, Dx, Dd, rhs, a.solves, a.cpu_steps)
         print(json.dumps(out), flush=True)
