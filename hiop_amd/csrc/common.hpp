@@ -113,7 +113,7 @@ inline void ctx_aux_report(hiopamd_ctx* ctx, int idx, double seconds)
                    ctx->aux_best);
   }
 }
-// Reserve CU 0 of every XCD for `diag_stream` and give `upd_stream` the other 248 CUs.  Measured on MI355X
+// Reserve CUs 0-1 of every XCD for `diag_stream` and give `upd_stream` the other 240 CUs.  Measured on MI355X
 // (scripts/probes/cu_mask_probe.hip): mask bit i maps to XCD i%8, CU i/8; the workgroups of a masked queue are dealt
 // round-robin over the XCDs, so every XCD must keep at least one enabled CU; a 160 KB-LDS workgroup on the reserved
 // CUs starts within 8 us while the rest of the device is saturated, whereas on an unmasked high-priority stream it
@@ -128,8 +128,14 @@ inline bool ctx_cu_split(hiopamd_ctx* ctx)
   if(hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
   const int ncu = prop.multiProcessorCount;
   if(ncu != 256) return false;   // the mapping above was verified for the 8 x 32 CU layout only
-  uint32_t m[8] = {0xffu, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t mc[8] = {0xffffff00u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  // HIOPAMD_SD_CUS = reserved CUs per XCD for the chain stream (default 2; bits 0..8k-1 of the mask = CUs 0..k-1 of every XCD).
+  // Measured at N = 8192: 1 -> 9.53 ms per step, 2 -> 9.38 (the head substitution's 16 four-wave workgroups and the 10 tiles of
+  // the diagonal-block update get a CU each), 3 -> 9.42; the update's time does not move with 8 or 16 CUs fewer.
+  int per_xcd = std::getenv("HIOPAMD_SD_CUS") ? std::atoi(std::getenv("HIOPAMD_SD_CUS")) : 2;
+  if(per_xcd < 1 || per_xcd > 3) per_xcd = 1;
+  const uint32_t lowbits = (per_xcd == 1) ? 0xffu : (per_xcd == 2) ? 0xffffu : 0xffffffu;
+  uint32_t m[8] = {lowbits, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t mc[8] = {~lowbits, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   if(hipExtStreamCreateWithCUMask(&ctx->diag_stream, 8, m) != hipSuccess) {
     ctx->diag_stream = nullptr;
     (void)hipGetLastError();

@@ -2306,8 +2306,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   hipStream_t st = ctx->stream;
   HIOPAMD_CHECK(hipMemsetAsync(d_info, 0, 4 * sizeof(int), st));
   const int64_t ldv = N;
-  // LOOK-AHEAD on two CU-masked streams (ctx_cu_split): `sd` owns one reserved CU per XCD and runs the serial chain
-  // of the factorisation without ever leaving its stream; `su` owns the other 248 CUs and runs the wide work.
+  // LOOK-AHEAD on two CU-masked streams (ctx_cu_split): `sd` owns the reserved CUs (two per XCD by default) and runs the serial chain
+  // of the factorisation without ever leaving its stream; `su` owns the other CUs (240 with the default of two reserved CUs per XCD) and runs the wide work.
   //   sd : superdiag(j) | trsm_head(j) | upd_diag(j) | superdiag(j+1) | trsm_head(j+1) | ...
   //   su :     wait diag(j) | trsm_tail(j) | wait head(j) | upd_rest(j) | wait diag(j+1) | trsm_tail(j+1) | ...
   // superdiag : 1 workgroup, the 256x256 diagonal block (needs a whole CU's LDS: it would starve behind the update grid
