@@ -2416,8 +2416,25 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       ev_head = next_event();
       HIOPAMD_CHECK(hipEventRecord(ev_head, sd));
     }
-    hipLaunchKernelGGL(ldlt_update_diag_kernel, dim3(4, 4), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, p.K0, p.kbs, s, sa_end,
-                       panel(jp + 1).Cj);
+    {
+      // the next diagonal block (the only update on the chain).  HIOPAMD_UPD_DIAG = 12 / 11 / 22: the tile kernel with
+      // 32x64 (default) / 32x32 / 64x64 tiles (20 / 36 / 10 live workgroups for the 16 reserved CUs); 0: the dedicated 64x64-tile
+      // kernel.  Per step at N = 8192: 9.25 / 9.25 / 9.31 / 9.35 ms.
+      static int ud = -1;
+      if(ud < 0) ud = std::getenv("HIOPAMD_UPD_DIAG") ? std::atoi(std::getenv("HIOPAMD_UPD_DIAG")) : 12;
+      double* Cn = panel(jp + 1).Cj;
+      if(ud == 11)
+        hipLaunchKernelGGL((ldlt_update_kernel_t<1, 1, 8>), dim3(8, 8), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, 0, p.K0, p.kbs, s,
+                           sa_end, sa_end, 0, Cn);
+      else if(ud == 12)
+        hipLaunchKernelGGL((ldlt_update_kernel_t<1, 2, 8>), dim3(4, 8), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, 0, p.K0, p.kbs, s,
+                           sa_end, sa_end, 0, Cn);
+      else if(ud == 22)
+        hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), dim3(4, 4), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, 0, p.K0, p.kbs, s,
+                           sa_end, sa_end, 0, Cn);
+      else
+        hipLaunchKernelGGL(ldlt_update_diag_kernel, dim3(4, 4), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, p.K0, p.kbs, s, sa_end, Cn);
+    }
     superdiag(jp + 1, sd);
     hipEvent_t ev_diag = nullptr;
     if(lookahead) {
