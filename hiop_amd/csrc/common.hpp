@@ -64,13 +64,9 @@ struct hiopamd_ctx {
   void* allreduce_user = nullptr;
   int comm_rank = 0;
   int comm_size = 1;
-  // helper stream + events for intra-operation concurrency (the LDL^T look-ahead chain); created lazily,
-  // always joined back into `stream` before the operation returns
-  hipStream_t aux_stream = nullptr;    // all CUs, normal priority: the candidate in use
-  hipStream_t aux_cand[4] = {nullptr, nullptr, nullptr, nullptr};
-  double aux_time[4] = {0, 0, 0, 0};
-  int aux_trials = 0, aux_best = 0;
-  hipStream_t diag_stream = nullptr;   // CU-masked: one reserved CU per XCD (serial 1-workgroup kernels that need a whole CU's LDS)
+  // CU-masked streams + events for intra-operation concurrency (the LDL^T look-ahead); created lazily, always joined back
+  // into `stream` before the operation returns
+  hipStream_t diag_stream = nullptr;   // CU-masked: the reserved CUs (serial chain; its 1-workgroup kernel needs a whole CU's LDS)
   hipStream_t upd_stream = nullptr;    // CU-masked: every other CU
   int cu_split_state = 0;              // 0 not tried, 1 masked streams available, -1 unavailable
   hipEvent_t ev_pool[160] = {nullptr};
@@ -78,41 +74,6 @@ struct hiopamd_ctx {
 };
 
 namespace hiopamd {
-// Helper streams for work that overlaps a device-filling kernel on another stream.  Which hardware queue / pipe a HIP
-// stream lands on depends on how many streams the process created before, and on MI355X that placement decides whether
-// two streams really overlap: the same look-ahead ran at 16.7 ms or 25 ms per step depending only on the creation
-// index of this stream (a dedicated full-CU-mask queue and a high-priority queue were both in the slow class).  So a
-// few candidates are created and the caller times its real workload on each once, then keeps the fastest
-// (ctx_aux_pick / ctx_aux_report).
-constexpr int kAuxCandidates = 4;
-inline hipStream_t ctx_aux_stream(hiopamd_ctx* ctx, int idx = 0)
-{
-  if(!ctx->aux_cand[0]) {
-    for(int q = 0; q < kAuxCandidates; ++q)
-      HIOPAMD_CHECK_ABORT(hipStreamCreateWithFlags(&ctx->aux_cand[q], hipStreamNonBlocking));
-  }
-  ctx->aux_stream = ctx->aux_cand[idx];
-  return ctx->aux_stream;
-}
-inline int ctx_aux_pick(hiopamd_ctx* ctx)   // candidate to use for the next timed run
-{
-  return ctx->aux_trials < kAuxCandidates ? ctx->aux_trials : ctx->aux_best;
-}
-inline void ctx_aux_report(hiopamd_ctx* ctx, int idx, double seconds)
-{
-  if(ctx->aux_trials >= kAuxCandidates || idx != ctx->aux_trials) return;
-  ctx->aux_time[idx] = seconds;
-  ctx->aux_trials++;
-  if(ctx->aux_trials == kAuxCandidates) {
-    ctx->aux_best = 0;
-    for(int q = 1; q < kAuxCandidates; ++q)
-      if(ctx->aux_time[q] < ctx->aux_time[ctx->aux_best]) ctx->aux_best = q;
-    if(std::getenv("HIOPAMD_VERBOSE"))
-      std::fprintf(stderr, "[hiop_amd] helper-stream calibration: %.2f %.2f %.2f %.2f ms -> candidate %d\n",
-                   ctx->aux_time[0] * 1e3, ctx->aux_time[1] * 1e3, ctx->aux_time[2] * 1e3, ctx->aux_time[3] * 1e3,
-                   ctx->aux_best);
-  }
-}
 // Reserve CUs 0-1 of every XCD for `diag_stream` and give `upd_stream` the other 240 CUs.  Measured on MI355X
 // (scripts/probes/cu_mask_probe.hip): mask bit i maps to XCD i%8, CU i/8; the workgroups of a masked queue are dealt
 // round-robin over the XCDs, so every XCD must keep at least one enabled CU; a 160 KB-LDS workgroup on the reserved

@@ -84,11 +84,6 @@ int hiopamd_ctx_destroy(hiopamd_ctx* c)
   hipFree(c->d_iresult);
   hipHostFree(c->h_result);
   if(c->d_work) hipFree(c->d_work);
-  for(int q = 0; q < 4; ++q)
-    if(c->aux_cand[q]) {
-      hipStreamSynchronize(c->aux_cand[q]);
-      hipStreamDestroy(c->aux_cand[q]);
-    }
   if(c->diag_stream) {
     hipStreamSynchronize(c->diag_stream);
     hipStreamDestroy(c->diag_stream);

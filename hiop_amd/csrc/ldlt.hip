@@ -2388,8 +2388,6 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     hipLaunchKernelGGL(ldlt_supertrsm_kernel, dim3((ncols + 15) / 16), dim3(64), 0, stream, A, lda, N, p.K0, p.kbs, p.Vb, ldv,
                        dinv, p.Cj, p.Dk_sp, p.Li_sp, col_ofs);
   };
-  const bool calibrate = false;
-  (void)calibrate;
   // panel 0's diagonal block on the caller's stream, then fork
   {
     const Panel p0 = panel(0);
