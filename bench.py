@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--neq", type=int, default=4093)
     ap.add_argument("--solves", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--dense-nlocal", type=int, default=1_250_000, help="columns per GPU of the sharded dense case")
     ap.add_argument("--dense-k", type=int, default=200, help="number of dense constraints m")
     ap.add_argument("--no-dense", action="store_true")
@@ -64,33 +64,52 @@ def cpu_baseline(p, Dx, Dd, rhs, nsolves, steps):
                                        (p.Hss_i, p.Hss_j))
     k.set_values(p.Jcs_v, p.Jds_v, p.Hss_v, p.Jcd, p.Jdd, p.Hdd, Dx, Dd)
     rx, ryc, ryd = rhs
-    t0 = time.perf_counter()
-    for _ in range(steps):
+
+    def one_step():
+        t0 = time.perf_counter()
         k.build_kkt_matrix(0.0, 0.0, 0.0, 0.0)
         nneg = k.factorize_with_curv_check()
         assert nneg == p.neq + p.nineq
         for _ in range(nsolves):
             k.solve_compressed(rx, ryc, ryd)
-    dt = time.perf_counter() - t0
+        return time.perf_counter() - t0
+
+    # DSYTRF in OpenBLAS does not scale to every hardware thread of the box (128 threads were SLOWER than the reference's own
+    # 8-core run): one step at each of a few thread counts, then the remaining steps at the best one
+    tried = {}
     try:
-        from threadpoolctl import threadpool_info
-        thr = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_limits
+        ncpu = os.cpu_count() or 1
+        for thr in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 128)}):
+            with threadpool_limits(limits=thr):
+                tried[thr] = one_step()
+        best = min(tried, key=tried.get)
+        ctxm = threadpool_limits(limits=best)
     except Exception:
-        thr = os.cpu_count() or 1
-    return dict(value=steps / dt, unit="KKT iterations/s", cores=int(thr), kind="port",
-                sample=f"{steps} steps of the same workload (N={p.N}; build + DSYTRF + {nsolves}x DSYTRS), "
-                       f"{dt:.1f} s on the host via oracle/hiop_oracle.py (numpy + scipy-OpenBLAS LAPACK)")
+        import contextlib
+        best, ctxm = os.cpu_count() or 1, contextlib.nullcontext()
+    with ctxm:
+        times = [one_step() for _ in range(max(1, steps - 1))]
+    dt = sum(times)
+    return dict(value=len(times) / dt, unit="KKT iterations/s", cores=int(best), kind="port",
+                threads_tried={str(t): round(v, 3) for t, v in tried.items()},
+                sample=f"{len(times)} steps of the same workload (N={p.N}; build + DSYTRF + {nsolves}x DSYTRS) at the best of the "
+                       f"tried OpenBLAS thread counts ({best}), {dt:.1f} s (+ {sum(tried.values()):.1f} s of one-step trials), "
+                       f"on the host via oracle/hiop_oracle.py (numpy + scipy-OpenBLAS LAPACK)")
 
 
-def dense_lowrank_bench(ctx, world, rank, a, dist):
+def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False):
     """Memory-distributed dense-constraint case (BASELINE configs[1]/[3]): quasi-Newton low-rank KKT with the
     variables column-sharded over the GPUs of the node, n_local per GPU fixed (weak scaling), k = m constraints,
     l = 6 secant pairs; small blocks all-reduced with RCCL over xGMI through the context hook.
     One step = hiopHessianLowRank::update + hiopKKTLinSysLowRank::update + `solves` x solveCompressed."""
     import torch
+    import ctypes as C
     from hiop_amd.kkt import HessianLowRank, KKTLinSysLowRank
+    from hiop_amd.runtime import dptr
     n, me, mi, l = a.dense_nlocal, a.dense_k // 2, a.dense_k - a.dense_k // 2, 6
-    if world > 1:
+    hooked = hooked and world > 1
+    if hooked:
         ctx.init_rccl_from_torch_distributed()
     gl = torch.Generator(device="cuda"); gl.manual_seed(1000 + rank)     # local (sharded) data
     gr = torch.Generator(device="cuda"); gr.manual_seed(7)               # replicated data
@@ -140,24 +159,107 @@ def dense_lowrank_bench(ctx, world, rank, a, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     k = me + mi
-    gram_flops = 2.0 * k * (k + 2 * l) * n            # per rank per solveCompressed (one stacked pass)
     out = dict(value=a.steps / dt, unit="KKT iterations/s", ms_per_step=1e3 * dt / a.steps, scaling="weak",
                workload=f"NlpDenseCons quasi-Newton low-rank KKT, n_local={n} per GPU (n={n * world}), m={k}, l={l}; "
-                        f"step = Hessian secant update + KKT update + {a.solves} solveCompressed",
-               collective="RCCL all-reduce (ncclAllReduce on the context stream), " + ("%d ranks" % world),
-               gram_gflop_per_solve_per_gpu=gram_flops / 1e9, hbm_gb_J_per_gpu=8.0 * k * n / 1e9)
+                        f"step = Hessian secant update + KKT update + {a.solves} solveCompressed "
+                        f"(N = J (H+Dx)^-1 J^T formed once per step, cached for the other solves)",
+               collective=("RCCL all-reduce (ncclAllReduce on the context stream), %d ranks" % world) if hooked
+               else "none (single rank, no hook)",
+               hbm_gb_J_per_gpu=8.0 * k * n / 1e9)
+    if rooflines:
+        # the two kernels that carry the step, timed alone with HIP events on the context's stream (20 calls each):
+        #  * weighted stacked Gram  G = J DhInv [J; S; Y]^T  (fp64 MFMA): algorithmic flops = the unique entries only,
+        #    2 n (k(k+1)/2 + 2 l k)   ("symmetric half counted")
+        #  * GEMV  y = J x  (HBM): algorithmic bytes = 8 n (k + 1) + 8 k
+        L = ctx._L
+        kw = k + 2 * l
+        G = torch.zeros(k * kw, dtype=torch.float64, device="cuda")
+        St, Yt = C.c_void_p(L.hiopamd_hess_lowrank_St(H.h)), C.c_void_p(L.hiopamd_hess_lowrank_Yt(H.h))
+        lc = H.l_curr
+        yk = torch.zeros(k, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+
+        def gram():
+            L.hiopamd_gram_weighted_stacked(ctx.h, k, n, dptr(J), n, k, dptr(J), n, lc, St, n, lc, Yt, n, dptr(q), 0.0,
+                                            dptr(G), kw, 1.0)
+
+        def gemv():
+            L.hiopamd_mat_times_vec(ctx.h, k, n, dptr(J), n, 0.0, dptr(yk), 1.0, dptr(x))
+
+        def gemvt():
+            L.hiopamd_mat_trans_times_vec(ctx.h, k, n, dptr(J), n, 0.0, dptr(dx), 1.0, dptr(yk))
+
+        t_gram, t_gemv, t_gemvt = time_on_ctx_stream(ctx, gram), time_on_ctx_stream(ctx, gemv), time_on_ctx_stream(ctx, gemvt)
+        gram_flops = 2.0 * n * (k * (k + 1) / 2 + 2 * lc * k)
+        gemv_bytes = 8.0 * n * (k + 1) + 8.0 * k
+        out["roofline"] = [
+            dict(kernel="gram_weighted_stacked (J DhInv [J;S;Y]^T, v_mfma_f64_16x16x4_f64)", bound="mfma",
+                 achieved=gram_flops / (t_gram * 1e-3) / 1e12, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s",
+                 frac=gram_flops / (t_gram * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS, avg_launch_ms=t_gram,
+                 algorithmic_flops_per_launch=gram_flops, hbm_gbs=8.0 * n * (kw + 1) / (t_gram * 1e-3) / 1e9, traffic=None),
+            dict(kernel="mat_times_vec (y = J x, row-major k x n_local)", bound="hbm",
+                 achieved=gemv_bytes / (t_gemv * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                 frac=gemv_bytes / (t_gemv * 1e-3) / 1e9 / PEAK_HBM_GBS, avg_launch_ms=t_gemv,
+                 algorithmic_bytes_per_launch=gemv_bytes, traffic=None),
+            dict(kernel="mat_trans_times_vec (x = J^T y)", bound="hbm",
+                 achieved=gemv_bytes / (t_gemvt * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                 frac=gemv_bytes / (t_gemvt * 1e-3) / 1e9 / PEAK_HBM_GBS, avg_launch_ms=t_gemvt,
+                 algorithmic_bytes_per_launch=gemv_bytes, traffic=None),
+        ]
     K.close(); H.close()
     return out
 
 
+def time_on_ctx_stream(ctx, fn, reps=20):
+    """average milliseconds of `fn` (a C-ABI call that launches on the context's stream), HIP events on that stream."""
+    import torch
+    s = ctx.torch_stream
+    fn(); fn()
+    ctx.sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(reps):
+        fn()
+    e1.record(s)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, LOCAL_RANK -> device) on
+    127.0.0.1 and relay rank 0's JSON line.  Fails loudly when the node has fewer than N devices."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} HIP device(s) visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a)
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: no HIP device visible (there is no CPU product path)")
     torch.cuda.set_device(local_rank)
@@ -244,6 +346,27 @@ def main():
                     algorithmic_flops_per_launch=flops_per_launch,
                     update_ms_per_step=ums.value / a.steps)
 
+    # ---- run-stats spans (the reference's hiopRunStatsKKT sub-spans): a third pass of the same K steps with the context's
+    # span timers on (HIP events, no host sync inside a span)
+    L.hiopamd_ctx_spans_enable(ctx.h, 1)
+    t0s = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    ctx.sync()
+    dts = time.perf_counter() - t0s
+    sp_ms, sp_cnt = (C.c_double * 8)(), (C.c_int64 * 8)()
+    L.hiopamd_ctx_spans_read(ctx.h, sp_ms, sp_cnt)
+    L.hiopamd_ctx_spans_enable(ctx.h, 0)
+    L.hiopamd_span_name.restype = C.c_char_p
+    spans = {L.hiopamd_span_name(i).decode(): {"ms_per_step": sp_ms[i] / a.steps, "calls_per_step": sp_cnt[i] / a.steps}
+             for i in range(8)}
+    ff, ft = C.c_double(0), C.c_double(0)
+    L.hiopamd_linsolver_flops(ls, C.byref(ff), C.byref(ft))
+    fact_ms = spans["linsolv.tmFactTime"]["ms_per_step"]
+    spans["linsolv.flopsFact_per_step"] = float(p.N) ** 3 / 3.0
+    spans["linsolv.fact_tflops"] = (float(p.N) ** 3 / 3.0) / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else None
+    spans["ms_per_step_with_span_events"] = 1e3 * dts / a.steps
+
     # ---- parity spot check of the last solve against the oracle's residual definition (not timed)
     from oracle import hiop_oracle as ho
     ko = ho.KKTLinSysCompressedMDSXYcYd(p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j),
@@ -255,13 +378,21 @@ def main():
     dense = None
     dense_c2 = None
     if not a.no_dense:
-        dense = dense_lowrank_bench(ctx, world, rank, a, dist)
+        dense = dense_lowrank_bench(ctx, world, rank, a, dist, rooflines=(world == 1))
+        if world > 1:
+            # the same shard on every rank WITHOUT the collective (a second context, no hook): what one rank does alone in the
+            # same time window -> the sharded run's overhead is (ms_per_step / single_rank_ms_per_step - 1)
+            ctx1 = Context(local_rank)
+            alone = dense_lowrank_bench(ctx1, world, rank, a, dist, hooked=False)
+            dense["single_rank_ms_per_step"] = alone["ms_per_step"]
+            dense["n_ranks"] = world
+            ctx1.close()
         if world == 1:
             # BASELINE configs[1]: NlpDenseCons_ex2 shape on ONE GPU, n = 1e6, m = 100 (the single-GPU dense low-rank case)
             import copy
             a2 = copy.copy(a)
             a2.dense_nlocal, a2.dense_k = 1_000_000, 100
-            dense_c2 = dense_lowrank_bench(ctx, world, rank, a2, dist)
+            dense_c2 = dense_lowrank_bench(ctx, world, rank, a2, dist, rooflines=True)
 
     out = None
     if rank == 0:
@@ -275,6 +406,7 @@ def main():
                                    f"N={p.N}; step = 1 assemble + 1 LDL^T factor(+inertia) + {a.solves} solveCompressed",
                        "parallelism": "single GPU" if world == 1 else f"replicas only x{world} (MDS path does not shard)"},
             "roofline": roofline,
+            "kkt_spans": spans,
             "check": {"kkt_backward_error": max(res), "inertia_neg": expected_neg},
         }
         if dense is not None:

@@ -82,7 +82,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
                     print(f"[hiop_amd.build] compiled {name}", file=sys.stderr)
     objs = [OBJDIR / (s.stem + ".o") for s in srcs]
     if force or jobs or not LIB.exists():
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-L/opt/rocm/lib", "-lrccl",
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx",
                "-Wl,-rpath,/opt/rocm/lib", "-o", str(LIB)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -71,6 +71,7 @@ struct hiopamd_ctx {
   int cu_split_state = 0;              // 0 not tried, 1 masked streams available, -1 unavailable
   hipEvent_t ev_pool[160] = {nullptr};
   int n_events = 0;
+  void* spans = nullptr;               // hiopamd::SpanState (context.hip): KKT / linear-solver run-stats spans
 };
 
 namespace hiopamd {
@@ -111,6 +112,21 @@ inline bool ctx_cu_split(hiopamd_ctx* ctx)
   ctx->cu_split_state = 1;
   return true;
 }
+// Run-stats spans = the reference's hiopRunStatsKKT / hiopLinSolStats timers (src/Utils/hiopRunStats.hpp:82-140, :244-300):
+// every span is a roctx range (visible to `rocprofv3 --marker-trace`) and, when enabled with hiopamd_ctx_spans_enable, a
+// pair of HIP events on the context's stream — no host synchronisation on the hot path; the elapsed times are summed
+// when hiopamd_ctx_spans_read is called.  Ids = HIOPAMD_SPAN_* of include/hiop_amd.h.
+void span_begin(hiopamd_ctx* ctx, int id);
+void span_end(hiopamd_ctx* ctx, int id);
+struct SpanScope {
+  hiopamd_ctx* ctx;
+  int id;
+  SpanScope(hiopamd_ctx* c, int i) : ctx(c), id(i) { span_begin(ctx, id); }
+  ~SpanScope() { span_end(ctx, id); }
+  SpanScope(const SpanScope&) = delete;
+  SpanScope& operator=(const SpanScope&) = delete;
+};
+
 inline hipEvent_t ctx_event(hiopamd_ctx* ctx, int i)
 {
   while(ctx->n_events <= i) {

@@ -8,8 +8,10 @@
 #include "common.hpp"
 
 #include <rccl/rccl.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <cstring>
+#include <vector>
 
 namespace {
 struct RcclState {
@@ -27,7 +29,109 @@ int rccl_allreduce(void* user, double* buf, size_t count, int op, void* stream)
 }
 }  // namespace
 
+namespace hiopamd {
+static const char* kSpanNames[HIOPAMD_SPAN_COUNT] = {
+    "kkt.tmUpdateInit",    "kkt.tmUpdateLinsys",  "kkt.tmUpdateInnerFact", "kkt.tmSolveRhsManip",
+    "kkt.tmSolveInner",    "linsolv.tmFactTime",  "linsolv.tmInertiaComp", "linsolv.tmTriuSolves"};
+struct SpanState {
+  bool enabled = false;
+  std::vector<hipEvent_t> pool;            // timing events, reused
+  size_t used = 0;
+  struct Rec {
+    hipEvent_t b, e;
+    int id;
+    bool closed;
+  };
+  std::vector<Rec> recs;
+  std::vector<size_t> open[HIOPAMD_SPAN_COUNT];
+  double ms[HIOPAMD_SPAN_COUNT] = {0};
+  int64_t cnt[HIOPAMD_SPAN_COUNT] = {0};
+  hipEvent_t get()
+  {
+    if(used == pool.size()) {
+      hipEvent_t e = nullptr;
+      if(hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+  // fold the finished records into the sums (the caller has synchronised the stream)
+  void collect()
+  {
+    for(const Rec& r : recs) {
+      if(!r.closed || !r.b || !r.e) continue;
+      float t = 0.f;
+      if(hipEventElapsedTime(&t, r.b, r.e) == hipSuccess) {
+        ms[r.id] += (double)t;
+        cnt[r.id] += 1;
+      }
+    }
+    recs.clear();
+    for(auto& o : open) o.clear();
+    used = 0;
+  }
+};
+void span_begin(hiopamd_ctx* ctx, int id)
+{
+  (void)roctxRangePushA(kSpanNames[id]);
+  SpanState* st = static_cast<SpanState*>(ctx->spans);
+  if(!st || !st->enabled) return;
+  if(st->recs.size() >= 8192) {   // bounded memory between reads: fold what is there (one stream sync every 8192 spans)
+    (void)hipStreamSynchronize(ctx->stream);
+    st->collect();
+  }
+  SpanState::Rec r{st->get(), nullptr, id, false};
+  if(r.b) (void)hipEventRecord(r.b, ctx->stream);
+  st->open[id].push_back(st->recs.size());
+  st->recs.push_back(r);
+}
+void span_end(hiopamd_ctx* ctx, int id)
+{
+  (void)roctxRangePop();
+  SpanState* st = static_cast<SpanState*>(ctx->spans);
+  if(!st || !st->enabled || st->open[id].empty()) return;
+  SpanState::Rec& r = st->recs[st->open[id].back()];
+  st->open[id].pop_back();
+  r.e = st->get();
+  if(r.e) (void)hipEventRecord(r.e, ctx->stream);
+  r.closed = true;
+}
+}  // namespace hiopamd
+
 extern "C" {
+
+const char* hiopamd_span_name(int id) { return (id >= 0 && id < HIOPAMD_SPAN_COUNT) ? hiopamd::kSpanNames[id] : nullptr; }
+
+int hiopamd_ctx_spans_enable(hiopamd_ctx* c, int enable)
+{
+  if(!c) return HIOPAMD_ERR_ARG;
+  hiopamd::SpanState* st = static_cast<hiopamd::SpanState*>(c->spans);
+  if(!st) {
+    st = new hiopamd::SpanState();
+    c->spans = st;
+  }
+  HIOPAMD_CHECK(hipStreamSynchronize(c->stream));
+  st->collect();
+  for(int i = 0; i < HIOPAMD_SPAN_COUNT; ++i) {
+    st->ms[i] = 0.0;
+    st->cnt[i] = 0;
+  }
+  st->enabled = enable != 0;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ctx_spans_read(hiopamd_ctx* c, double* ms_host, int64_t* count_host)
+{
+  if(!c) return HIOPAMD_ERR_ARG;
+  hiopamd::SpanState* st = static_cast<hiopamd::SpanState*>(c->spans);
+  HIOPAMD_CHECK(hipStreamSynchronize(c->stream));
+  if(st) st->collect();
+  for(int i = 0; i < HIOPAMD_SPAN_COUNT; ++i) {
+    if(ms_host) ms_host[i] = st ? st->ms[i] : 0.0;
+    if(count_host) count_host[i] = st ? st->cnt[i] : 0;
+  }
+  return HIOPAMD_OK;
+}
 
 const char* hiopamd_version(void) { return "hiop_amd 0.1.0 (gfx950)"; }
 
@@ -53,18 +157,33 @@ int hiopamd_ctx_create(hiopamd_ctx** out, void* hip_stream)
     std::fprintf(stderr, "[hiop_amd] no HIP device visible: this library has no CPU path\n");
     return HIOPAMD_ERR_NODEVICE;
   }
+  *out = nullptr;
   hiopamd_ctx* c = new hiopamd_ctx();
+  bool ok = true;
   if(hip_stream) {
     c->stream = (hipStream_t)hip_stream;
   } else {
-    HIOPAMD_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
+    ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    c->own_stream = ok;
   }
-  HIOPAMD_CHECK(hipMalloc(&c->d_partials, sizeof(double) * 4 * hiopamd::kPartials));
-  HIOPAMD_CHECK(hipMalloc(&c->d_result, sizeof(double) * hiopamd::kHostSlots));
-  HIOPAMD_CHECK(hipMalloc(&c->d_iresult, 256));
-  HIOPAMD_CHECK(hipHostMalloc(&c->h_result, sizeof(double) * hiopamd::kHostSlots, hipHostMallocMapped));
-  HIOPAMD_CHECK(hipHostGetDevicePointer((void**)&c->h_result_dev, c->h_result, 0));
+  ok = ok && hipMalloc(&c->d_partials, sizeof(double) * 4 * hiopamd::kPartials) == hipSuccess;
+  ok = ok && hipMalloc(&c->d_result, sizeof(double) * hiopamd::kHostSlots) == hipSuccess;
+  ok = ok && hipMalloc(&c->d_iresult, 256) == hipSuccess;
+  ok = ok && hipHostMalloc(&c->h_result, sizeof(double) * hiopamd::kHostSlots, hipHostMallocMapped) == hipSuccess;
+  ok = ok && hipHostGetDevicePointer((void**)&c->h_result_dev, c->h_result, 0) == hipSuccess;
+  if(!ok) {   // nothing leaks: the destroy tolerates the members that were never allocated
+    std::fprintf(stderr, "[hiop_amd] hiopamd_ctx_create: HIP allocation failed (%s)\n", hipGetErrorName(hipGetLastError()));
+    if(c->stream && c->own_stream) hiopamd_ctx_destroy(c);
+    else {
+      c->stream = nullptr;
+      (void)hipFree(c->d_partials);
+      (void)hipFree(c->d_result);
+      (void)hipFree(c->d_iresult);
+      if(c->h_result) (void)hipHostFree(c->h_result);
+      delete c;
+    }
+    return HIOPAMD_ERR_HIP;
+  }
   std::memset(c->h_result, 0, sizeof(double) * hiopamd::kHostSlots);
   *out = c;
   return HIOPAMD_OK;
@@ -93,6 +212,11 @@ int hiopamd_ctx_destroy(hiopamd_ctx* c)
     hipStreamDestroy(c->upd_stream);
   }
   for(int i = 0; i < c->n_events; ++i) hipEventDestroy(c->ev_pool[i]);
+  if(c->spans) {
+    hiopamd::SpanState* st = static_cast<hiopamd::SpanState*>(c->spans);
+    for(hipEvent_t e : st->pool) (void)hipEventDestroy(e);
+    delete st;
+  }
   if(c->own_stream) hipStreamDestroy(c->stream);
   delete c;
   return HIOPAMD_OK;

@@ -121,6 +121,7 @@ int hiopamd_kkt_mds_build(hiopamd_kkt_mds* k, double delta_wx, double delta_wd, 
   const int N = nxd + neq + nineq;
   double* M = hiopamd_linsolver_sys_matrix(k->ls);
   const int64_t ld = N;
+  SpanScope span(ctx, HIOPAMD_SPAN_KKT_UPDATE_LINSYS);   // :193-294
 
   // Msys.setToZero()                                                        (:196)
   HIOPAMD_CHECK(hipMemsetAsync(M, 0, sizeof(double) * (size_t)N * (size_t)N, ctx->stream));
@@ -160,6 +161,7 @@ int hiopamd_kkt_mds_factorize(hiopamd_kkt_mds* k, int* n_neg_host)
 {
   if(!k || !n_neg_host) return HIOPAMD_ERR_ARG;
   if(!k->built) return HIOPAMD_ERR_STATE;
+  SpanScope span(k->ctx, HIOPAMD_SPAN_KKT_UPDATE_INNER_FACT);   // hiopKKTLinSys.cpp:347-352
   int n_neg = 0;
   RC(hiopamd_linsolver_matrix_changed(k->ls, &n_neg));
   if(n_neg >= 0) {
@@ -184,6 +186,12 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
   double* rxs = k->buf_xs;
   const double* Hxs = k->Hxs;
   double* rhs = k->rhs;
+  span_begin(ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);   // :318-363
+  struct SpanGuard {   // closes whatever span is open on an early (error) return
+    hiopamd_ctx* c;
+    int id;
+    ~SpanGuard() { if(id >= 0) span_end(c, id); }
+  } guard{ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP};
   // rxs = Hxs^-1 rx_sparse; dyc = ryc  (one pass)                            (:337-338, :343)
   {
     const int64_t nmax = (nxs > neq) ? nxs : neq;
@@ -202,8 +210,12 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
       rhs[i] = (i < nxd) ? rxd[i] : ((i < nxd + neq) ? dyc[i - nxd] : ryd[i - nxd - neq]);
     }));
   }
-  // solve                                                                    (:367)
+  // solve                                                                    (:364-368)
+  span_end(ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);
+  span_begin(ctx, guard.id = HIOPAMD_SPAN_KKT_SOLVE_INNER);
   RC(hiopamd_linsolver_solve(k->ls, rhs, 1));
+  span_end(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);
+  span_begin(ctx, guard.id = HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);   // :380-401
   // unpack dx_dense, dyc, dyd and start dxs = rx_sparse  (one pass)           (:383-390)
   double* dxs = k->buf_xs;
   {

@@ -283,6 +283,7 @@ int backend_build(hiopamd_kkt_xycyd* h)
   hiopamd_ctx* ctx = h->ctx;
   if(h->kind == KIND_MDS) return hiopamd_kkt_mds_build(h->mds, pd.wx, pd.wd, pd.cc, pd.cd);
   if(h->kind == KIND_LOWRANK) return HIOPAMD_OK;   // N is formed inside solveCompressed (hiopKKTLinSys.cpp:1132)
+  SpanScope span(ctx, HIOPAMD_SPAN_KKT_UPDATE_LINSYS);
   if(h->kind == KIND_DENSE_XDYCYD) {
     // hiopKKTLinSysDenseXDYcYd::build_kkt_matrix (hiopKKTLinSysDense.hpp:249-328)
     if(!h->H || (!h->Jc && h->nyc > 0) || (!h->Jd && h->nyd > 0)) return HIOPAMD_ERR_STATE;
@@ -334,6 +335,7 @@ int backend_factorize(hiopamd_kkt_xycyd* h, int* n_neg)
     *n_neg = h->n_required_neg;
     return HIOPAMD_OK;
   }
+  SpanScope span(h->ctx, HIOPAMD_SPAN_KKT_UPDATE_INNER_FACT);   // hiopKKTLinSys.cpp:347-352
   return hiopamd_linsolver_matrix_changed(h->ls, n_neg);   // hiopKKTLinSys.cpp:310-313
 }
 
@@ -350,7 +352,10 @@ int backend_solve(hiopamd_kkt_xycyd* h, double* rx, const double* ryc, double* r
   RC(hiopamd_vec_copy(ctx, nx, h->dense_rhs, rx));
   RC(hiopamd_vec_copy(ctx, nyc, h->dense_rhs + nx, ryc));
   RC(hiopamd_vec_copy(ctx, nyd, h->dense_rhs + nx + nyc, ryd));
-  RC(hiopamd_linsolver_solve(h->ls, h->dense_rhs, 1));
+  {
+    SpanScope span(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);
+    RC(hiopamd_linsolver_solve(h->ls, h->dense_rhs, 1));
+  }
   RC(hiopamd_vec_copy(ctx, nx, dx, h->dense_rhs));
   RC(hiopamd_vec_copy(ctx, nyc, dyc, h->dense_rhs + nx));
   RC(hiopamd_vec_copy(ctx, nyd, dyd, h->dense_rhs + nx + nyc));
@@ -369,7 +374,10 @@ int backend_solve_xd(hiopamd_kkt_xycyd* h, const double* rx, const double* rd, c
   RC(hiopamd_vec_copy(ctx, nyd, rhs + nx, rd));
   RC(hiopamd_vec_copy(ctx, nyc, rhs + nx + nyd, ryc));
   RC(hiopamd_vec_copy(ctx, nyd, rhs + nx + nyd + nyc, ryd));
-  RC(hiopamd_linsolver_solve(h->ls, rhs, 1));
+  {
+    SpanScope span(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);
+    RC(hiopamd_linsolver_solve(h->ls, rhs, 1));
+  }
   RC(hiopamd_vec_copy(ctx, nx, dx, rhs));
   RC(hiopamd_vec_copy(ctx, nyd, dd, rhs + nx));
   RC(hiopamd_vec_copy(ctx, nyc, dyc, rhs + nx + nyd));
@@ -631,14 +639,19 @@ int do_compute_directions(hiopamd_kkt_xycyd* h, const double* resid, double* dir
   if(!h->iter) return HIOPAMD_ERR_STATE;
   if(resid == dir) return HIOPAMD_ERR_ARG;
   const int64_t* o = h->off;
-  RC(stage_reduce_rhs(h, resid));
+  {
+    SpanScope span(h->ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);   // hiopKKTLinSys.cpp:589-650
+    RC(stage_reduce_rhs(h, resid));
+  }
   if(h->is_xd()) {   // hiopKKTLinSysCompressedXDYcYd::computeDirections (:810-905)
     RC(backend_solve_xd(h, h->rx_tilde, h->ryd2, resid + o[2], resid + o[3], dir + o[0], dir + o[1], dir + o[2],
                         dir + o[3], ok));
+    SpanScope span(h->ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);   // compute_directions_for_full_space (:221-290)
     return stage_recover_directions(h, resid, dir);
   }
   RC(backend_solve(h, h->rx_tilde, resid + o[2], h->ryd_tilde, dir + o[0], dir + o[2], dir + o[3], ok));
   // the reference recovers dd before testing sol_ok and skips the rest on failure (:664-681)
+  SpanScope span(h->ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);   // :666-671 + compute_directions_for_full_space (:221-290)
   return stage_recover_directions(h, resid, dir);
 }
 
@@ -824,13 +837,16 @@ int hiopamd_kkt_xycyd_update(hiopamd_kkt_xycyd* h, const double* iter, int* ok_h
 {
   if(!h || !iter || !ok_host) return HIOPAMD_ERR_ARG;
   h->iter = iter;
-  RC(stage_update_diagonals(h));
-  if(h->kind == KIND_MDS) {
-    RC(hiopamd_kkt_mds_set_diagonals(h->mds, h->Dx, h->Dd));
-  } else if(h->kind == KIND_LOWRANK) {
-    // hiopKKTLinSysLowRank::update (hiopKKTLinSys.cpp:1057-1096): refresh the Hessian's log-barrier diagonal, Dd^-1
-    if((!h->Jc && h->nyc > 0) || (!h->Jd && h->nyd > 0)) return HIOPAMD_ERR_STATE;
-    RC(hiopamd_kkt_lowrank_update_diag(h->lr, h->Dx, h->Dd, h->Jc, h->Jd));
+  {
+    SpanScope span(h->ctx, HIOPAMD_SPAN_KKT_UPDATE_INIT);   // hiopKKTLinSys.cpp:550-576
+    RC(stage_update_diagonals(h));
+    if(h->kind == KIND_MDS) {
+      RC(hiopamd_kkt_mds_set_diagonals(h->mds, h->Dx, h->Dd));
+    } else if(h->kind == KIND_LOWRANK) {
+      // hiopKKTLinSysLowRank::update (hiopKKTLinSys.cpp:1057-1096): refresh the Hessian's log-barrier diagonal, Dd^-1
+      if((!h->Jc && h->nyc > 0) || (!h->Jd && h->nyd > 0)) return HIOPAMD_ERR_STATE;
+      RC(hiopamd_kkt_lowrank_update_diag(h->lr, h->Dx, h->Dd, h->Jc, h->Jd));
+    }
   }
   return do_factorize(h, ok_host);
 }
@@ -1423,7 +1439,14 @@ int hiopamd_iterate_adjust_small_slacks(hiopamd_kkt_xycyd* h, double* it, const 
     const double *sel_ = pat[q], *bound = bnd[q];
     if(!bound) return HIOPAMD_ERR_STATE;
     double slack_min = 0.0;
-    RC(hiopamd_vec_min_w_pattern(ctx, n, slack, sel_, &slack_min));   // local, like the reference (:432)
+    RC(hiopamd_vec_min_w_pattern(ctx, n, slack, sel_, &slack_min));   // :435
+    if(q < 2) {
+      // the x-sized slacks are column-sharded on the low-rank back-end: hiopVectorPar::min_w_pattern all-reduces (MIN,
+      // hiopVectorPar.cpp:833-836), so every rank takes the same branch below
+      red4_t mn{{-slack_min, 0.0, 0.0, 0.0}};
+      RC(xpart_allreduce(h, &mn, 1));
+      slack_min = -mn.v[0];
+    }
     if(!(slack_min < small_val)) continue;
     red4_t cnt;
     RC(reduce4(ctx, n,
@@ -1447,6 +1470,7 @@ int hiopamd_iterate_adjust_small_slacks(hiopamd_kkt_xycyd* h, double* it, const 
                  return red4_t{{0.0, 0.0, flag, 0.0}};
                },
                2, &cnt));
+    if(q < 2) RC(xpart_allreduce(h, &cnt, 2));   // numOfElemsLessThan all-reduces (SUM, hiopVectorPar.cpp:1231-1236)
     total += (int)(cnt.v[2] + 0.5);
   }
   *num_adjusted_host = total;

@@ -2234,6 +2234,7 @@ struct hiopamd_linsolver {
   unsigned long long fl_epoch = 0;
   bool factored = false;
   int inertia[3] = {0, 0, 0};
+  double flops_fact = 0.0, flops_triu = 0.0;   // hiopLinSolStats::flopsFact / flopsTriuSolves (cumulative)
   LdltProfile prof;
 };
 
@@ -2459,7 +2460,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     if(rc != HIOPAMD_OK) return rc;
   }
   hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(64, nsp), dim3(kBlock), 0, st, Cd, A, lda, N, Cd + cdt_ofs);
+  span_begin(ctx, HIOPAMD_SPAN_LINSOLV_INERTIA);   // :127-167 (tmInertiaComp)
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
+  span_end(ctx, HIOPAMD_SPAN_LINSOLV_INERTIA);
   if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv);
   HIOPAMD_CHECK(hipGetLastError());
   int h[4];
@@ -2673,6 +2676,8 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
 {
   if(!ls || !n_neg_host) return HIOPAMD_ERR_ARG;
   ls->factored = false;
+  SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_FACT);   // hiopLinSolverSymDenseLapack.hpp:80-125 (tmFactTime; flopsFact = n^3/3)
+  ls->flops_fact += (double)ls->n * ls->n * ls->n / 3.0;
   int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W);
   if(rc == HIOPAMD_ERR_SINGULAR) {
     // reference: "entry in the factorization's diagonal is exactly zero" -> matrixChanged() returns -1
@@ -2689,6 +2694,8 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs)
 {
   if(!ls || !rhs_inout) return HIOPAMD_ERR_ARG;
   if(!ls->factored) return HIOPAMD_ERR_STATE;
+  SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_TRIU_SOLVES);   // :173-195 (tmTriuSolves; flopsTriuSolves = 2 n^2 per rhs)
+  ls->flops_triu += 2.0 * (double)ls->n * ls->n * nrhs;
   return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd, ls);
 }
 
@@ -2708,6 +2715,14 @@ int hiopamd_linsolver_profile_read(const hiopamd_linsolver* ls, double* update_m
   if(update_ms_host) *update_ms_host = ls->prof.ms;
   if(update_flops_host) *update_flops_host = ls->prof.flops;
   if(update_launches_host) *update_launches_host = ls->prof.launches;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_linsolver_flops(const hiopamd_linsolver* ls, double* flops_fact_host, double* flops_triu_solves_host)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  if(flops_fact_host) *flops_fact_host = ls->flops_fact;
+  if(flops_triu_solves_host) *flops_triu_solves_host = ls->flops_triu;
   return HIOPAMD_OK;
 }
 

@@ -164,6 +164,7 @@ struct hiopamd_hess_lowrank {
   double sigma = 1.0, sigma0 = 1.0;
   int strategy = 3;
   bool matrix_changed = false;
+  unsigned long long version = 0;   // bumped whenever (B + Dx) changes: consumers cache products of its inverse against it
   int m_eq = 0, m_ineq = 0;
   // device
   double *St = nullptr, *Yt = nullptr;       // l_max x n
@@ -272,6 +273,7 @@ int hiopamd_hess_lowrank_update_log_barrier_diagonal(hiopamd_hess_lowrank* h, co
     DhInv[i] = 1.0 / (sigma + d);
   }));
   h->matrix_changed = true;
+  h->version++;
   return HIOPAMD_OK;
 }
 
@@ -368,6 +370,7 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
       }
       h->sigma = std::fmax(std::fmin(1e+8, h->sigma), 1e-8);
       h->matrix_changed = true;
+      h->version++;
       if(stored_host) *stored_host = 1;
     }
   }
@@ -530,9 +533,21 @@ struct hiopamd_kkt_lowrank {
   double *work = nullptr;     // gram / posv workspace
   size_t work_cnt = 0;
   double last_resid = 0.0;
+  // N = J (H+Dx)^-1 J^T + Dd^-1 and its equilibrated factor are cached between the solveCompressed calls of one outer
+  // iteration (the reference rebuilds them on every call, hiopKKTLinSys.cpp:1132-1135 — SURVEY.md §3.1): valid while
+  // neither the Hessian (version), nor the Jacobians / Dd (any update call) changed.  Same kernels, same order, same
+  // inputs => bit-identical to the rebuilt N (tests/test_gpu_lowrank.py::test_cached_N_is_bit_identical).
+  bool cache_enabled = true;
+  bool N_valid = false;
+  unsigned long long N_version = 0;
+  int N_info = 0;
 };
 
 static int lowrank_set_J(hiopamd_kkt_lowrank* K, const double* Jc, const double* Jd);
+namespace hiopamd {
+int posv_refine_impl(hiopamd_ctx* ctx, int k, const double* N_upper, int64_t ldn, double* rhs_inout, double* work,
+                     int* info_host, double* resid_host, int reuse_factor);
+}
 
 extern "C" {
 
@@ -596,6 +611,7 @@ int hiopamd_kkt_lowrank_update(hiopamd_kkt_lowrank* K, const double* zl, const d
   }));
   // J = [Jc; Jd]  (copyRowsFrom, :1127-1128 — done once per update instead of once per solveCompressed)
   RC(lowrank_set_J(K, Jc, Jd));
+  K->N_valid = false;
   return HIOPAMD_OK;
 }
 
@@ -622,6 +638,7 @@ static int lowrank_set_J(hiopamd_kkt_lowrank* K, const double* Jc, const double*
 int hiopamd_kkt_lowrank_set_jacobians(hiopamd_kkt_lowrank* K, const double* Jc, const double* Jd)
 {
   if(!K || (K->m_eq > 0 && !Jc) || (K->m_ineq > 0 && !Jd)) return HIOPAMD_ERR_ARG;
+  K->N_valid = false;
   return lowrank_set_J(K, Jc, Jd);
 }
 
@@ -648,6 +665,7 @@ int hiopamd_kkt_lowrank_update_diag(hiopamd_kkt_lowrank* K, const double* Dx_in,
   double* Ddi = K->Dd_inv;
   RC(launch_ew(ctx, K->m_ineq, [=] __device__(int64_t i) { Ddi[i] = 1.0 / Dd[i]; }));
   RC(lowrank_set_J(K, Jc, Jd));
+  K->N_valid = false;
   return HIOPAMD_OK;
 }
 
@@ -660,10 +678,13 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
   const int64_t n = K->n;
   const int me = K->m_eq, mi = K->m_ineq, k = me + mi;
   if(ok_host) *ok_host = 1;
-  // N = J (H+Dx)^-1 J^T                                                       (:1132)
-  RC(hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(K->H, 0.0, K->N, k, 1.0, K->Jcur, K->work));
-  // N[me.., me..] += Dd^-1                                                     (:1135)
-  RC(hiopamd_mat_add_sub_diagonal(ctx, K->N, k, me, 1.0, K->Dd_inv, 0, mi));
+  const bool reuse = K->cache_enabled && K->N_valid && K->N_version == K->H->version;
+  if(!reuse) {
+    // N = J (H+Dx)^-1 J^T                                                     (:1132)
+    RC(hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(K->H, 0.0, K->N, k, 1.0, K->Jcur, K->work));
+    // N[me.., me..] += Dd^-1                                                   (:1135)
+    RC(hiopamd_mat_add_sub_diagonal(ctx, K->N, k, me, 1.0, K->Dd_inv, 0, mi));
+  }
   // dx = (H+Dx)^-1 rx                                                          (:1147)
   RC(hiopamd_hess_lowrank_solve(K->H, rx, dx));
   // rhs = J dx - [ryc; ryd]   (only rank 0 subtracts, then all-reduce: :466, :1157)
@@ -677,10 +698,13 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
   }
   RC(allreduce_dev(ctx, rhs, (size_t)k, HIOPAMD_SUM));
   // solve N [dyc; dyd] = rhs with equilibration + refinement                  (:1169, solveWithRefin :1192)
-  int info = 0;
+  int info = reuse ? K->N_info : 0;
   double resid = 0.0;
   double* pw = K->work + (size_t)k * (k + 2 * K->H->l_max) + (size_t)k * 2 * K->H->l_max;
-  RC(hiopamd_posv_refine(ctx, k, K->N, k, rhs, pw, &info, &resid));
+  RC(posv_refine_impl(ctx, k, K->N, k, rhs, pw, &info, &resid, reuse ? 1 : 0));
+  K->N_info = info;
+  K->N_version = K->H->version;   // (the Hessian's lazily refreshed internal representation does not bump the version)
+  K->N_valid = true;
   K->last_resid = resid;
   if(info != 0 && ok_host) *ok_host = 0;
   RC(hiopamd_vec_copy(ctx, me, dyc, rhs));
@@ -692,6 +716,13 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
 }
 
 double* hiopamd_kkt_lowrank_N(hiopamd_kkt_lowrank* K) { return K ? K->N : nullptr; }
+int hiopamd_kkt_lowrank_set_cache(hiopamd_kkt_lowrank* K, int enable)
+{
+  if(!K) return HIOPAMD_ERR_ARG;
+  K->cache_enabled = enable != 0;
+  K->N_valid = false;
+  return HIOPAMD_OK;
+}
 double hiopamd_kkt_lowrank_last_residual(const hiopamd_kkt_lowrank* K) { return K ? K->last_resid : -1.0; }
 
 }  // extern "C"

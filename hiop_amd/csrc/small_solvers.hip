@@ -36,11 +36,24 @@ using namespace hiopamd;
     if(rc_ != HIOPAMD_OK) return rc_; \
   } while(0)
 
+// reuse_factor != 0: `work` still holds the equilibration + factor of the SAME matrix from an earlier call (the low-rank
+// KKT caches N between the solves of one outer iteration): only the solve + residual loop run, *info_host keeps the
+// caller's cached value.  Every operation that does run is the one the full call would run, so results are bit-identical.
+namespace hiopamd {
+int posv_refine_impl(hiopamd_ctx* ctx, int k, const double* N_upper, int64_t ldn, double* rhs_inout, double* work,
+                     int* info_host, double* resid_host, int reuse_factor);
+}
 extern "C" int hiopamd_posv_refine(hiopamd_ctx* ctx, int k, const double* N_upper, int64_t ldn, double* rhs_inout,
                                    double* work, int* info_host, double* resid_host)
 {
+  return hiopamd::posv_refine_impl(ctx, k, N_upper, ldn, rhs_inout, work, info_host, resid_host, 0);
+}
+
+int hiopamd::posv_refine_impl(hiopamd_ctx* ctx, int k, const double* N_upper, int64_t ldn, double* rhs_inout, double* work,
+                              int* info_host, double* resid_host, int reuse_factor)
+{
   if(k < 0 || !info_host) return HIOPAMD_ERR_ARG;
-  *info_host = 0;
+  if(!reuse_factor) *info_host = 0;
   if(resid_host) *resid_host = 0.0;
   if(k == 0) return HIOPAMD_OK;
   // work layout: M (k*k) | sc (k) | dinv (k) | b0 (k) | x (k) | r (k) | t (k)
@@ -52,18 +65,25 @@ extern "C" int hiopamd_posv_refine(hiopamd_ctx* ctx, int k, const double* N_uppe
   double* r = x + k;
   double* t = r + k;
   const double* Nm = N_upper;
-  RC(launch_ew(ctx, k, [=] __device__(int64_t i) { sc[i] = 1.0 / sqrt(Nm[i * ldn + i]); }));
-  RC(launch_ew(ctx, (int64_t)k * k, [=] __device__(int64_t e) {
-    const int64_t i = e / k, j = e - i * k;
-    M[e] = (j >= i) ? Nm[i * ldn + j] * sc[i] * sc[j] : 0.0;
-  }));
-  int inertia[3] = {0, 0, 0};
-  int rc = hiopamd_ldlt_factor(ctx, k, M, k, dinv, inertia);
-  if(rc == HIOPAMD_ERR_SINGULAR || inertia[1] > 0 || inertia[2] > 0) {
-    *info_host = 1;  // not (numerically) positive definite -- DPOSVX INFO>0
-    if(rc == HIOPAMD_ERR_SINGULAR) return HIOPAMD_OK;
-  } else if(rc != HIOPAMD_OK) {
-    return rc;
+  if(!reuse_factor) {
+    RC(launch_ew(ctx, k, [=] __device__(int64_t i) { sc[i] = 1.0 / sqrt(Nm[i * ldn + i]); }));
+    RC(launch_ew(ctx, (int64_t)k * k, [=] __device__(int64_t e) {
+      const int64_t i = e / k, j = e - i * k;
+      M[e] = (j >= i) ? Nm[i * ldn + j] * sc[i] * sc[j] : 0.0;
+    }));
+    int inertia[3] = {0, 0, 0};
+    int rc = hiopamd_ldlt_factor(ctx, k, M, k, dinv, inertia);
+    if(rc == HIOPAMD_ERR_SINGULAR || inertia[1] > 0 || inertia[2] > 0) {
+      *info_host = 1;  // not (numerically) positive definite -- DPOSVX INFO>0
+      if(rc == HIOPAMD_ERR_SINGULAR) {
+        *info_host = 2;   // singular: nothing to solve with
+        return HIOPAMD_OK;
+      }
+    } else if(rc != HIOPAMD_OK) {
+      return rc;
+    }
+  } else if(*info_host == 2) {
+    return HIOPAMD_OK;
   }
   RC(hiopamd_vec_copy(ctx, k, b0, rhs_inout));
   // x = S * (M^-1 (S b))

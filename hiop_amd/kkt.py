@@ -258,6 +258,12 @@ class KKTLinSysLowRank:
                                                            dptr(dyd), C.byref(ok)), "hiopamd_kkt_lowrank_solve_compressed")
         return bool(ok.value)
 
+    def set_cache(self, enable: bool):
+        check(self._L.hiopamd_kkt_lowrank_set_cache(self.h, 1 if enable else 0), "hiopamd_kkt_lowrank_set_cache")
+
+    def set_jacobians(self, Jc, Jd):
+        check(self._L.hiopamd_kkt_lowrank_set_jacobians(self.h, dptr(Jc), dptr(Jd)), "hiopamd_kkt_lowrank_set_jacobians")
+
     def N(self) -> torch.Tensor:
         ptr = self._L.hiopamd_kkt_lowrank_N(self.h)
         out = torch.empty((self.k, self.k), dtype=torch.float64, device="cuda")

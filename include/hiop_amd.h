@@ -51,6 +51,28 @@ int hiopamd_ctx_create(hiopamd_ctx** out, void* hip_stream /* hipStream_t or NUL
 int hiopamd_ctx_destroy(hiopamd_ctx* ctx);
 int hiopamd_ctx_sync(hiopamd_ctx* ctx);
 void* hiopamd_ctx_stream(hiopamd_ctx* ctx);
+/* Run-stats spans: the reference's per-iteration KKT timers (src/Utils/hiopRunStats.hpp:82-140: tmUpdateInit,
+ * tmUpdateLinsys, tmUpdateInnerFact, tmSolveRhsManip, tmSolveInner) and linear-solver timers (:244-300: tmFactTime,
+ * tmInertiaComp, tmTriuSolves), placed where the reference starts/stops them (hiopKKTLinSysMDS.cpp:121-401,
+ * hiopKKTLinSys.cpp:221-689, hiopLinSolverSymDenseLapack.hpp:80-195).  Each span is always a roctx range; with
+ * hiopamd_ctx_spans_enable(ctx, 1) it is also timed with HIP events on the context's stream (no host sync inside the
+ * span).  hiopamd_ctx_spans_read synchronises the stream and returns the accumulated milliseconds and call counts
+ * (arrays of HIOPAMD_SPAN_COUNT entries) since the last enable. */
+typedef enum {
+  HIOPAMD_SPAN_KKT_UPDATE_INIT = 0,
+  HIOPAMD_SPAN_KKT_UPDATE_LINSYS = 1,
+  HIOPAMD_SPAN_KKT_UPDATE_INNER_FACT = 2,
+  HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP = 3,
+  HIOPAMD_SPAN_KKT_SOLVE_INNER = 4,
+  HIOPAMD_SPAN_LINSOLV_FACT = 5,
+  HIOPAMD_SPAN_LINSOLV_INERTIA = 6,
+  HIOPAMD_SPAN_LINSOLV_TRIU_SOLVES = 7,
+  HIOPAMD_SPAN_COUNT = 8
+} hiopamd_span;
+int hiopamd_ctx_spans_enable(hiopamd_ctx* ctx, int enable);
+int hiopamd_ctx_spans_read(hiopamd_ctx* ctx, double* ms_host, int64_t* count_host);
+const char* hiopamd_span_name(int span_id);
+
 int hiopamd_ctx_set_allreduce(hiopamd_ctx* ctx, hiopamd_allreduce_fn fn, void* user, int rank, int size);
 /* RCCL-backed all-reduce: `unique_id_128` is the 128-byte ncclUniqueId produced by
  * hiopamd_rccl_unique_id on rank 0 and broadcast by the host side. */
@@ -268,6 +290,9 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host);
 int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs);
 /* last factorisation: pos/neg/zero pivot counts (magmablas_ddiinertia equivalent) */
 int hiopamd_linsolver_inertia(const hiopamd_linsolver* ls, int* pos_host, int* neg_host, int* zero_host);
+/* hiopLinSolStats::flopsFact / flopsTriuSolves (src/Utils/hiopRunStats.hpp:262-270), cumulative over the object's life:
+ * n^3/3 per matrixChanged, 2 n^2 per right-hand side; the times are the HIOPAMD_SPAN_LINSOLV_* spans of the context */
+int hiopamd_linsolver_flops(const hiopamd_linsolver* ls, double* flops_fact_host, double* flops_triu_solves_host);
 /* per-launch HIP-event timing of the MFMA rank-K update kernel (bench / roofline only; off by default).
  * read: accumulated kernel milliseconds, algorithmic flops (2*K per updated element) and launch count
  * since the last hiopamd_linsolver_profile(ls, 1). */
@@ -380,6 +405,11 @@ hiopamd_hess_lowrank* hiopamd_kkt_lowrank_hess(hiopamd_kkt_lowrank* K);
 int hiopamd_kkt_lowrank_dims(const hiopamd_kkt_lowrank* K, int64_t* n_local_host, int* m_eq_host, int* m_ineq_host);
 double* hiopamd_kkt_lowrank_N(hiopamd_kkt_lowrank* K);   /* device, k x k, the last reduced matrix */
 double hiopamd_kkt_lowrank_last_residual(const hiopamd_kkt_lowrank* K);
+/* N = J (H+Dx)^-1 J^T + Dd^-1 and its factor are kept between the solveCompressed calls of one outer iteration (the
+ * reference rebuilds them on every call, hiopKKTLinSys.cpp:1132-1135); any update / update_diag / set_jacobians call or
+ * a change of the Hessian invalidates them.  enable = 0 restores the rebuild-on-every-call behaviour (same results, bit
+ * for bit; for A/B tests). */
+int hiopamd_kkt_lowrank_set_cache(hiopamd_kkt_lowrank* K, int enable);
 
 /* =====================================================================================
  * Full-space XYcYd layer: iterate/residual -> search direction
