@@ -80,7 +80,7 @@ def cpu_baseline(p, Dx, Dd, rhs, nsolves, steps):
     try:
         from threadpoolctl import threadpool_limits
         ncpu = os.cpu_count() or 1
-        for thr in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 128)}):
+        for thr in sorted({t for t in (16, 32, 64) if t <= ncpu} or {ncpu}):
             with threadpool_limits(limits=thr):
                 tried[thr] = one_step()
         best = min(tried, key=tried.get)

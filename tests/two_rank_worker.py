@@ -136,7 +136,7 @@ def install_gloo_hook(ctx, rank, world):
     import torch.distributed as dist
     from hiop_amd._lib import ALLREDUCE_FN, lib, check
     L = lib()
-    calls = {"n": 0, "doubles": 0}
+    calls = {"n": 0, "doubles": 0, "log": []}
 
     def hook(user, buf, count, op, stream):
         try:
@@ -145,7 +145,9 @@ def install_gloo_hook(ctx, rank, world):
                 return -1
             t = torch.from_numpy(host)
             rop = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[int(op)]
+            before = float(np.abs(host).sum())
             dist.all_reduce(t, op=rop)
+            calls["log"].append((int(count), int(op), before, float(np.abs(host).sum())))
             if L.hiopamd_copy_h2d(ctx.h, C.c_void_p(buf), C.c_void_p(host.ctypes.data), int(count) * 8) != 0:
                 return -1
             calls["n"] += 1
