@@ -25,6 +25,7 @@
 // 78.6 TFLOP/s / 6.3 TB/s).
 #include "device_utils.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -83,6 +84,18 @@ constexpr int LD_SB = 16;
 //   (iii) the trailing part gets the rank-16 update C -= V^T D^-1 V on fp64 MFMA (6 upper 16x16 tiles over 4 waves).
 // During the factorisation S holds UN-scaled rows (v_kc = d_k u_kc); they are scaled by diag_emit.
 // Li (global, [sb][i][j] row-major) receives the four 16x16 inverses; info[0] the first zero / non-finite pivot.
+// inter-workgroup data of the dataflow factorisation moves with agent-scope relaxed atomics (`sc1`: write-through stores,
+// L1-bypassing loads) — the form MI355X_MICROARCH.md validates for hand-offs between CUs / XCDs inside a launch
+__device__ __forceinline__ double ldg_sc1(const double* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stg_sc1(double* p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool SC1 = false>
 __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* sdinv, int kb, int k0, int* info,
                                                 double* __restrict__ Li, int tid)
 {
@@ -96,7 +109,9 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
 #pragma unroll
       for(int q = 0; q < 4; ++q) {
         const int e = tid + 64 * q;
-        Li[sb * 256 + e] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        const double idv = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        if constexpr(SC1) stg_sc1(Li + sb * 256 + e, idv);
+        else Li[sb * 256 + e] = idv;
       }
       return;
     }
@@ -131,7 +146,8 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
       for(int r = 0; r < LD_SB; ++r) {
         if(c >= r) S[o + r][o + c] = a[r];
         Lv[r][c] = m[r];
-        Li[sb * 256 + r * 16 + c] = m[r];
+        if constexpr(SC1) stg_sc1(Li + sb * 256 + r * 16 + c, m[r]);
+        else Li[sb * 256 + r * 16 + c] = m[r];
       }
     }
   };
@@ -216,109 +232,6 @@ __device__ __forceinline__ void diag_emit(double (*S)[LD_nb + 1], const double* 
     if(in) A[(int64_t)(k0 + r) * lda + (k0 + c)] = v;
   }
   if(tid < kb) dinv[k0 + tid] = sdinv[tid];
-}
-
-__global__ __launch_bounds__(kBlock) void ldlt_diag_kernel(double* __restrict__ A, int64_t lda, int k0, int kb,
-                                                           double* __restrict__ dinv, double* __restrict__ Dk,
-                                                           double* __restrict__ Li, int* __restrict__ info)
-{
-  __shared__ double S[LD_nb][LD_nb + 1];
-  __shared__ double sdinv[LD_nb];
-  const int tid = threadIdx.x;
-  {
-    double sv[LD_nb * LD_nb / kBlock];
-#pragma unroll
-    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
-      const int e = tid + q * kBlock;
-      const int r = e >> 6, c = e & 63;
-      const int rr = (r < kb) ? r : (kb - 1), cc = (c < kb) ? c : (kb - 1);
-      const double t = A[(int64_t)(k0 + rr) * lda + (k0 + cc)];   // unconditional clamped load + select
-      sv[q] = (r < kb && c < kb && c >= r) ? t : 0.0;
-    }
-#pragma unroll
-    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
-      const int e = tid + q * kBlock;
-      S[e >> 6][e & 63] = sv[q];
-    }
-  }
-  if(tid < LD_nb) sdinv[tid] = 1.0;
-  __syncthreads();
-  diag_factor_lds(S, sdinv, kb, k0, info, Li, tid);
-  diag_emit(S, sdinv, kb, k0, A, lda, dinv, Dk, tid);
-}
-
-// ------------------------------------------------------------------------------------------
-// substitution kernel for the row panel right of the diagonal block, on fp64 MFMA:
-//   V = L11^-1 A12  (un-scaled, to the workspace)   and   U12 = D^-1 V  (in place),
-// as a block forward substitution over the four 16-row blocks I of the panel:
-//   T_I = A_I - sum_{J<I} L_IJ V_J ,   V_I = Linv_II T_I .
-// One wave64 per workgroup = 64 columns = 4 independent groups of 16 columns (independent MFMA
-// chains hide the 64-cycle MFMA latency).  The MFMA D layout (row = (l>>4)+4*reg, col = l&15) of a
-// 16x16 block is exactly the B-operand layout of its four k-steps (k-step kk <-> reg kk), so V_J feeds
-// the next product straight from the accumulator registers.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ldlt_trsm_kernel(double* __restrict__ A, int64_t lda, int N, int k0,
-                                                       double* __restrict__ V, int64_t ldv, int vrow0,
-                                                       const double* __restrict__ dinv,
-                                                       const double* __restrict__ Dk, const double* __restrict__ Li)
-{
-  const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
-  const int64_t colbase = (int64_t)k0 + LD_nb + (int64_t)blockIdx.x * 64;
-  // A operands (shared by the 4 column groups)
-  double negL[4][4][4];  // [I][J][kk], J < I : -L11[16I+li][16J+4kk+g] = -U11[16J+4kk+g][16I+li]
-  double inv[4][4];      // [I][kk]    : Linv_II[li][4kk+g]
-#pragma unroll
-  for(int I = 0; I < 4; ++I) {
-#pragma unroll
-    for(int kk = 0; kk < 4; ++kk) {
-      inv[I][kk] = Li[I * 256 + li * 16 + 4 * kk + g];
-#pragma unroll
-      for(int J = 0; J < 4; ++J)
-        negL[I][J][kk] = (J < I) ? -Dk[(16 * J + 4 * kk + g) * LD_nb + 16 * I + li] : 0.0;
-    }
-  }
-  double dsc[4][4];  // dinv of row 16I + g + 4r
-#pragma unroll
-  for(int I = 0; I < 4; ++I)
-#pragma unroll
-    for(int r = 0; r < 4; ++r) dsc[I][r] = dinv[k0 + 16 * I + g + 4 * r];
-
-#pragma unroll
-  for(int grp = 0; grp < 4; ++grp) {
-    const int64_t col = colbase + grp * 16 + li;
-    const bool ok = col < N;
-    double4_t a[4];
-#pragma unroll
-    for(int I = 0; I < 4; ++I)
-#pragma unroll
-      for(int r = 0; r < 4; ++r) a[I][r] = ok ? A[(int64_t)(k0 + 16 * I + g + 4 * r) * lda + col] : 0.0;
-    double4_t Vv[4];
-#pragma unroll
-    for(int I = 0; I < 4; ++I) {
-      double4_t t = a[I];
-#pragma unroll
-      for(int J = 0; J < 4; ++J) {
-        if(J < I) {
-#pragma unroll
-          for(int kk = 0; kk < 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(negL[I][J][kk], Vv[J][kk], t, 0, 0, 0);
-        }
-      }
-      double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[I][kk], t[kk], v, 0, 0, 0);
-      Vv[I] = v;
-    }
-    if(ok) {
-#pragma unroll
-      for(int I = 0; I < 4; ++I)
-#pragma unroll
-        for(int r = 0; r < 4; ++r) {
-          const int row = 16 * I + g + 4 * r;
-          V[(int64_t)(vrow0 + row) * ldv + col] = Vv[I][r];
-          A[(int64_t)(k0 + row) * lda + col] = Vv[I][r] * dsc[I][r];
-        }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -451,80 +364,6 @@ __device__ __forceinline__ void stage_block_bypass(double (*S)[LD_nb + 1], const
     const int e = tid + q * kBlock;
     S[e >> 6][e & 63] = sv[q];
   }
-}
-
-// block-row P of the current panel's 64 columns inside the super-diagonal kernel.  The 4 waves of the workgroup
-// need the SAME L_Pq / Dk_P operand blocks: they are staged once in LDS (the S buffer, free during phase (a)); the
-// already computed block rows V_q (q < P) of the current panel live in LDS too (Vs, un-scaled), so nothing but the
-// 16x16 accumulators stays in registers across phases.  Must be called by the whole workgroup.
-__device__ __forceinline__ void block_row_solve_lds(const int P, double* A, int64_t lda, double* V, int64_t ldv, int K0, int64_t col,
-                                                    bool col_ok, int cl, const double* Dk_sp, const double* Li_sp,
-                                                    const double* dall, int g, int li, double (*S)[LD_nb + 1],
-                                                    double (*Vs)[80], int tid)
-{
-  double4_t t[4];
-#pragma unroll
-  for(int I = 0; I < 4; ++I)
-#pragma unroll
-    for(int r = 0; r < 4; ++r) {
-      const int row = 64 * P + 16 * I + g + 4 * r;   // block rows below the current panel are always full
-      const double v = A[(int64_t)(K0 + row) * lda + col];
-      t[I][r] = col_ok ? v : 0.0;
-    }
-#pragma unroll 1
-  for(int q = 0; q < P; ++q) {
-    __syncthreads();
-    stage_block_bypass(S, A + (int64_t)(K0 + 64 * q) * lda + (K0 + 64 * P), lda, tid);   // U_qP = L_Pq^T
-    __syncthreads();
-    // the four accumulators t[0..3] are independent: interleave them (a chain of 16 MFMAs on ONE accumulator waits for
-    // every result; the B operand is also read once instead of four times)
-#pragma unroll
-    for(int Jq = 0; Jq < 4; ++Jq) {
-#pragma unroll
-      for(int kk = 0; kk < 4; ++kk) {
-        const double vb = Vs[64 * q + 16 * Jq + 4 * kk + g][cl];
-#pragma unroll
-        for(int I = 0; I < 4; ++I)
-          t[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[16 * Jq + 4 * kk + g][16 * I + li], vb, t[I], 0, 0, 0);
-      }
-      asm volatile("" ::: "memory");   // bound the number of LDS operand reads in flight (register pressure)
-    }
-  }
-  __syncthreads();
-  stage_block_bypass(S, Dk_sp + P * (LD_nb * LD_nb), LD_nb, tid);
-  __syncthreads();
-  const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
-  double4_t vp[4];
-#pragma unroll
-  for(int I = 0; I < 4; ++I) {
-    double4_t u = t[I];
-#pragma unroll
-    for(int J = 0; J < 4; ++J) {
-      if(J < I) {
-#pragma unroll
-        for(int kk = 0; kk < 4; ++kk)
-          u = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[16 * J + 4 * kk + g][16 * I + li], vp[J][kk], u, 0, 0, 0);
-      }
-    }
-    double iv[4];
-#pragma unroll
-    for(int kk = 0; kk < 4; ++kk)
-      iv[kk] = __hip_atomic_load(Li + I * 256 + li * 16 + 4 * kk + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[kk], u[kk], v, 0, 0, 0);
-    vp[I] = v;
-  }
-  // V (workspace, un-scaled), U = D^-1 V (in place), and the LDS copy of V for the later block rows / phase (b)
-#pragma unroll
-  for(int I = 0; I < 4; ++I)
-#pragma unroll
-    for(int r = 0; r < 4; ++r) {
-      const int row = 64 * P + 16 * I + g + 4 * r;
-      const double v = col_ok ? vp[I][r] : 0.0;
-      Vs[row][cl] = v;
-      if(col_ok) A[(int64_t)(K0 + row) * lda + col] = v * dall[row];   // U = D^-1 V (V itself is only needed in LDS)
-    }
 }
 
 // Phase (a) of the super-diagonal kernel for panel j, all block rows P < j, software-pipelined: the operand block of the
@@ -938,50 +777,43 @@ __global__ __launch_bounds__(64) void ldlt_inv_diag_kernel(int N, const double* 
 }
 
 // ------------------------------------------------------------------------------------------
-// rank-K update on fp64 MFMA:  A[r][c] -= sum_{k<K} V[vrow0+k][r] * A[urow0+k][c]
-//   for r in [s + ti*128 ...) ∩ [s, row_end),  c in [r, N)   (upper triangle only)
-// One workgroup = 4 wave64 = one 128x128 tile; each wave owns a 64x64 quadrant = 4x4 MFMA tiles
-// of 16x16 (16 x f64x4 accumulators = 128 VGPRs).  Both operands are K-major row panels, so one
-// staging pattern serves A and B: 16 k-rows x 128 columns, coalesced 512 B per wave per row.
-// v_mfma_f64_16x16x4_f64 lane map: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)+4*reg][col=l&15].
+// rank-K trailing update on fp64 MFMA (the dominant kernel of the factorisation):
+//     A[r][c] -= sum_{k<K} V[vrow0+k][r] * A[urow0+k][c]      r in [s, row_end), c in [max(r, s), col_end), upper triangle
+// One workgroup = one 128 x 128 tile = 4 wave64 of 64 x 64 (4 x 4 tiles of v_mfma_f64_16x16x4_f64, 16 f64x4 accumulators
+// per wave): the shape the vendor DGEMM sustains 76.5 TFLOP/s with on this part (profiles/r02_probes/README.md; round 1's
+// "fewer accumulators are faster" probe result did not hold up).  What this kernel does that round 1's tile kernels did not:
+//   * the K loop runs over stages of 16 k-rows held in a DOUBLE-BUFFERED LDS tile pair: ONE barrier per stage, and the
+//     stores of stage s+1 into the other buffer sit in the middle of stage s's 64 MFMAs per wave (round 1: two barriers
+//     around an exposed LDS refill for every 8 MFMAs);
+//   * the global loads of stage s+2 are issued under stage s (a full stage = 4096 MFMA-pipe cycles of latency cover);
+//   * the LDS operand reads of k-step kk+1 are issued before the 16 MFMAs of k-step kk (software-pipelined registers);
+//   * two workgroups per CU (73.7 KB of LDS, <= 256 VGPR+AGPR each): one's C-tile read-modify-write epilogue runs under the
+//     other's main loop.
+// Both operands are K-major row panels, so one staging pattern serves A and B: 16 k-rows x 128 columns, every k-row read
+// by 128 consecutive threads (1 KB coalesced).  LDS row stride 128 + 16 doubles: the four k-rows (lane>>4) of one
+// ds_read_b64 fall on disjoint bank groups.  MFMA lane map: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D[row = (l>>4) + 4 reg][col = l&15].
+// Algorithmic flops per launch: 2 K per updated element (update_flops()); algorithmic bytes: the C tile read + written
+// once (16 B per element) + the two 256 x 128 operand panels per tile (L2-resident across the tiles of a row/column).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restrict__ A, int64_t lda, int N,
-                                                                const double* __restrict__ V, int64_t ldv, int vrow0,
-                                                                int urow0, int K, int s, int row_end, int xcd_map,
-                                                                double* __restrict__ Cnext, int col_end, int skip_diag)
+constexpr int UD_T = 128;             // tile edge
+constexpr int UD_KT = 16;             // k-rows per stage
+constexpr int UD_LD = UD_T + 16;      // LDS row stride (doubles)
+
+template <int DBG = 0>   // DBG != 0: timing experiments only (scripts/upd_time.py): 1 no C epilogue, 2 no main loop, 3 no global operand loads
+__global__ __launch_bounds__(kBlock, 2) void ldlt_update_db_kernel(double* __restrict__ A, int64_t lda, int N,
+                                                                   const double* __restrict__ V, int64_t ldv, int vrow0,
+                                                                   int urow0, int K, int s, int row_end, int col_end,
+                                                                   int skip_diag, double* __restrict__ Cnext,
+                                                                   unsigned int* __restrict__ rows_done_flag)
 {
-  int ti, tj;
-  if(xcd_map) {
-    // 1-D grid over the upper-triangular tile domain, XCD-aware: workgroup b runs on XCD b%8 (observed
-    // dispatch order; a different placement only costs speed).  The tile domain is cut into 8x8-tile
-    // super-tiles; super-tile k goes to XCD k%8 and the 64 workgroups an XCD holds at a time (32 CUs x 2)
-    // walk ONE super-tile, so its 8+8 panel blocks are fetched once into that XCD's L2 and shared.
-    const int T = xcd_map;                 // tiles per side
-    const int Sside = (T + 7) >> 3;        // super-tiles per side
-    const int nS = Sside * (Sside + 1) / 2;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, q = b >> 3;
-    const int k = (q >> 6) * 8 + xcd;
-    if(k >= nS) return;
-    // k -> (Si, Sj), Sj >= Si, rows of the triangle have lengths Sside, Sside-1, ...
-    int Si = (int)((2.0 * Sside + 1.0 - sqrt((2.0 * Sside + 1.0) * (2.0 * Sside + 1.0) - 8.0 * k)) * 0.5);
-    while(Si > 0 && Si * Sside - Si * (Si - 1) / 2 > k) --Si;
-    while((Si + 1) * Sside - (Si + 1) * Si / 2 <= k) ++Si;
-    const int Sj = Si + (k - (Si * Sside - Si * (Si - 1) / 2));
-    const int t = q & 63;
-    ti = Si * 8 + (t >> 3);
-    tj = Sj * 8 + (t & 7);
-    if(ti >= T || tj >= T) return;
-  } else {
-    ti = blockIdx.y;
-    tj = blockIdx.x;
-  }
-  if(tj < ti) return;
-  const int r0 = s + ti * LD_TM, c0 = s + tj * LD_TN;
-  if(r0 >= row_end || c0 >= col_end) return;
-  if(skip_diag && r0 < s + LD_NB && c0 < s + LD_NB) return;   // the next diagonal block is updated by the chain stream
-  __shared__ double Vs[LD_KT][LD_LDP];
-  __shared__ double Us[LD_KT][LD_LDP];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  const int r0 = s + ti * UD_T, c0 = s + tj * UD_T;
+  const bool live = !(tj < ti) && r0 < row_end && c0 < col_end &&
+                    !(skip_diag && r0 + UD_T <= s + LD_NB && c0 + UD_T <= s + LD_NB);
+  if(!live) return;
+  __shared__ double Vs[2][UD_KT][UD_LD];
+  __shared__ double Us[2][UD_KT][UD_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int lk = lane >> 4, li = lane & 15;
@@ -992,68 +824,101 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
 #pragma unroll
     for(int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
 
+  // staging: thread (lrow = tid >> 7, lcol = tid & 127) owns k-rows lrow + 2 q, q = 0..7, of column lcol of both panels
   const int lcol = tid & 127, lrow = tid >> 7;
   const bool vr_ok = (r0 + lcol) < N;
   const bool uc_ok = (c0 + lcol) < N;
-  const double* Vp = V + (int64_t)(vrow0 + lrow) * ldv + (r0 + lcol);
-  const double* Up = A + (int64_t)(urow0 + lrow) * lda + (c0 + lcol);
-
-  // register-prefetch pipeline over one LDS buffer: the global loads of stage kt+1 are in flight while the
-  // 64 MFMAs of stage kt issue
+  const double* Vp = V + (int64_t)(vrow0 + lrow) * ldv + (vr_ok ? (r0 + lcol) : 0);
+  const double* Up = A + (int64_t)(urow0 + lrow) * lda + (uc_ok ? (c0 + lcol) : 0);
   double vreg[8], ureg[8];
-#pragma unroll
-  for(int q = 0; q < 8; ++q) {
-    vreg[q] = vr_ok ? Vp[(int64_t)(2 * q) * ldv] : 0.0;
-    ureg[q] = uc_ok ? Up[(int64_t)(2 * q) * lda] : 0.0;
-  }
-  for(int kt = 0; kt < K; kt += LD_KT) {
-    __syncthreads();  // previous stage fully consumed
+  const int nst = (K + UD_KT - 1) / UD_KT;
+  auto gload = [&](int st) {   // stage st -> registers (k-rows beyond K: zero)
 #pragma unroll
     for(int q = 0; q < 8; ++q) {
-      Vs[2 * q + lrow][lcol] = vreg[q];
-      Us[2 * q + lrow][lcol] = ureg[q];
+      const int k = st * UD_KT + 2 * q + lrow;
+      const bool kok = k < K;
+      const int kc = kok ? k : 0;
+      const double v = ld_batch(Vp + (int64_t)(kc - lrow) * ldv);   // unconditional (clamped) loads, issued as one batch
+      const double u = ld_batch(Up + (int64_t)(kc - lrow) * lda);
+      vreg[q] = (kok && vr_ok) ? v : 0.0;
+      ureg[q] = (kok && uc_ok) ? u : 0.0;
     }
-    __syncthreads();
-    if(kt + LD_KT < K) {
+  };
+  auto lstore = [&](int buf) {
 #pragma unroll
-      for(int q = 0; q < 8; ++q) {
-        vreg[q] = vr_ok ? Vp[(int64_t)(kt + LD_KT + 2 * q) * ldv] : 0.0;
-        ureg[q] = uc_ok ? Up[(int64_t)(kt + LD_KT + 2 * q) * lda] : 0.0;
+    for(int q = 0; q < 8; ++q) {
+      Vs[buf][2 * q + lrow][lcol] = vreg[q];
+      Us[buf][2 * q + lrow][lcol] = ureg[q];
+    }
+  };
+  gload(0);
+  lstore(0);
+  if(nst > 1) gload(1);
+  __syncthreads();
+  const int arow = wr * 64 + li, bcol = wc * 64 + li;
+  for(int st = 0; st < (DBG == 2 ? 0 : nst); ++st) {
+    const int cur = st & 1;
+    double a[2][4], b[2][4];
+    if(DBG == 6) {
+#pragma unroll
+      for(int i = 0; i < 4; ++i) {
+        a[0][i] = a[1][i] = 1.0 + (tid + i) * 1e-9;
+        b[0][i] = b[1][i] = 1.0 - (tid + 3 * i) * 1e-9;
       }
+    } else {
+#pragma unroll
+      for(int i = 0; i < 4; ++i) a[0][i] = Vs[cur][lk][arow + 16 * i];
+#pragma unroll
+      for(int j = 0; j < 4; ++j) b[0][j] = Us[cur][lk][bcol + 16 * j];
     }
 #pragma unroll
-    for(int kk = 0; kk < LD_KT / 4; ++kk) {
-      double a[4], b[4];
+    for(int kk = 0; kk < UD_KT / 4; ++kk) {
+      const int pb = kk & 1;
+      if(kk + 1 < UD_KT / 4 && DBG != 6) {   // operands of the next k-step
 #pragma unroll
-      for(int i = 0; i < 4; ++i) a[i] = Vs[kk * 4 + lk][wr * 64 + i * 16 + li];
+        for(int i = 0; i < 4; ++i) a[pb ^ 1][i] = Vs[cur][4 * (kk + 1) + lk][arow + 16 * i];
 #pragma unroll
-      for(int j = 0; j < 4; ++j) b[j] = Us[kk * 4 + lk][wc * 64 + j * 16 + li];
+        for(int j = 0; j < 4; ++j) b[pb ^ 1][j] = Us[cur][4 * (kk + 1) + lk][bcol + 16 * j];
+      }
+      if(kk == 1 && st + 1 < nst && DBG < 4) lstore(cur ^ 1);   // stage st+1 -> the other buffer (its loads were issued a stage ago)
+      if(kk == 2 && st + 2 < nst && DBG < 3) gload(st + 2);     // stage st+2 in flight under the rest of this stage and the next
 #pragma unroll
       for(int i = 0; i < 4; ++i)
 #pragma unroll
-        for(int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for(int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[pb][i], b[pb][j], acc[i][j], 0, 0, 0);
     }
+    if(DBG != 4 && DBG != 6) __syncthreads();   // buffer cur^1 complete, everybody done reading buffer cur
   }
-  // epilogue: C -= acc on the upper triangle.  All 16 loads of a row-group are issued before the first
-  // store (the compiler cannot reorder a load above a possibly-aliasing store, which would otherwise turn
-  // the 64 read-modify-writes into 64 serialized memory round trips).
+  // epilogue: C -= acc on the upper triangle, software-pipelined over the four 16-row groups of the wave: the 16 loads of
+  // group i+1 are issued before the stores of group i (a load cannot be hoisted above a possibly-aliasing store).
+  if(DBG == 1 || DBG >= 4) {   // timing experiment: no C traffic (one store per thread keeps the accumulators alive)
+    double t = 0.0;
 #pragma unroll
-  for(int i = 0; i < 4; ++i) {
-    double cv[4][4];
-    bool ok[4][4];
+    for(int i = 0; i < 4; ++i)
+#pragma unroll
+      for(int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if(t == 12345.678) A[(int64_t)r0 * lda + c0 + tid] = t;
+    return;
+  }
+  const bool to_compact = Cnext && r0 < s + LD_NB && c0 < s + LD_NB;
+  double cv[2][4][4];
+  auto cload = [&](int i, int pbuf) {
 #pragma unroll
     for(int reg = 0; reg < 4; ++reg) {
       const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
-      const double* Crow = A + (int64_t)row * lda;
+      const double* Crow = A + (int64_t)(row < row_end ? row : (row_end - 1)) * lda;
 #pragma unroll
       for(int j = 0; j < 4; ++j) {
         const int col = c0 + wc * 64 + j * 16 + li;
-        ok[reg][j] = (row < row_end) && (col < col_end) && (col >= row);
-        cv[reg][j] = ok[reg][j] ? Crow[col] : 0.0;
+        cv[pbuf][reg][j] = Crow[col < col_end ? col : (col_end - 1)];
       }
     }
-    // tiles of the next super-panel's diagonal block also feed its compact copy (origin s, ld = 256)
-    const bool to_compact = Cnext && r0 < s + LD_NB && c0 < s + LD_NB;
+  };
+  cload(0, 0);
+#pragma unroll
+  for(int i = 0; i < 4; ++i) {
+    const int pbuf = i & 1;
+    if(i + 1 < 4) cload(i + 1, pbuf ^ 1);
 #pragma unroll
     for(int reg = 0; reg < 4; ++reg) {
       const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
@@ -1061,12 +926,23 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel(double* __restri
 #pragma unroll
       for(int j = 0; j < 4; ++j) {
         const int col = c0 + wc * 64 + j * 16 + li;
-        if(ok[reg][j]) {
-          const double nv = cv[reg][j] - acc[i][j][reg];
+        if(row < row_end && col < col_end && col >= row) {
+          const double nv = cv[pbuf][reg][j] - acc[i][j][reg];
           Crow[col] = nv;
+          // tiles of the next super-panel's diagonal block also feed its compact copy (origin s, ld = 256)
           if(to_compact && row < s + LD_NB && col < s + LD_NB) Cnext[(row - s) * LD_NB + (col - s)] = nv;
         }
       }
+    }
+  }
+  // hand-over to the chain kernel (look-ahead): the tiles covering the next super-panel's rows announce themselves
+  if(rows_done_flag && r0 < s + LD_NB) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if(tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(rows_done_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1173,219 +1049,6 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
       }
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// The same rank-K update on v_mfma_f64_4x4x4_4b_f64 — the form of the fp64 MFMA that sustains 75 TFLOP/s on gfx950
-// (the 16x16x4 form above: 36-46, scripts/probes/mfma_f64_peak.hip).  One instruction = four independent 4x4x4 products:
-//   A lane l = A_b[i = l%4][k = l/16], B lane l = B_b[k = l/16][j = l%4], D lane 16i + 4b + j = D_b[i][j],  b = (l%16)/4,
-// so a 16x16x4 block product is four instructions whose B operand is rotated by 0/4/8/12 columns inside the 16 (read
-// from LDS with a rotated column index).  The A operand and the LDS staging are those of the kernel above.
-// In the D layout a lane's 64 results sit in 4-wide pieces of 16 different rows (a read-modify-write instruction would
-// touch 16 rows of C, 64 KB from each other), so the accumulators go through LDS (the staging buffers, free by then),
-// 32 tile rows at a time, and C is read and written in whole 512 B row segments.
-// OPT-IN (HIOPAMD_UPD4=1), NOT faster than the 16x16x4 kernel as it stands: 5.9 vs 5.75 ms of update time per N = 8192
-// factorisation.  With every global access removed it still takes 5.0 ms: the loop is bound by the LDS feed + two barriers
-// per stage (the probe's 51 of 75 TFLOP/s) and by the tail of each of the 31 launches, not by the MFMA rate
-// (profiles/r01_probes/README.md).
-// ------------------------------------------------------------------------------------------
-constexpr int U4_KT = 32;   // k-depth per stage
-__global__ __launch_bounds__(kBlock, 2) void ldlt_update4_kernel(double* __restrict__ A, int64_t lda, int N,
-                                                                 const double* __restrict__ V, int64_t ldv, int vrow0,
-                                                                 int urow0, int K, int s, int row_end, int col_end,
-                                                                 int skip_diag)
-{
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if(tj < ti) return;
-  const int r0 = s + ti * LD_TM, c0 = s + tj * LD_TN;
-  if(r0 >= row_end || c0 >= col_end) return;
-  if(skip_diag && r0 < s + LD_NB && c0 < s + LD_NB) return;
-  __shared__ __attribute__((aligned(16))) double Sh[2 * U4_KT * LD_LDP];
-  double (*Vs)[LD_LDP] = reinterpret_cast<double (*)[LD_LDP]>(Sh);
-  double (*Us)[LD_LDP] = reinterpret_cast<double (*)[LD_LDP]>(Sh + U4_KT * LD_LDP);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lk = lane >> 4, li = lane & 15;
-
-  double acc[4][4][4];   // [ib][jb][rotation]
-#pragma unroll
-  for(int i = 0; i < 4; ++i)
-#pragma unroll
-    for(int j = 0; j < 4; ++j)
-#pragma unroll
-      for(int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
-
-  const int lcol = tid & 127, lrow = tid >> 7;
-  const bool vr_ok = (r0 + lcol) < N;
-  const bool uc_ok = (c0 + lcol) < N;
-  const double* Vp = V + (int64_t)(vrow0 + lrow) * ldv + (r0 + lcol);
-  const double* Up = A + (int64_t)(urow0 + lrow) * lda + (c0 + lcol);
-  double vreg[U4_KT / 2], ureg[U4_KT / 2];
-#pragma unroll
-  for(int q = 0; q < U4_KT / 2; ++q) {
-    vreg[q] = vr_ok ? Vp[(int64_t)(2 * q) * ldv] : 0.0;
-    ureg[q] = uc_ok ? Up[(int64_t)(2 * q) * lda] : 0.0;
-  }
-  // rotated column offsets of the B operand inside a 16-column block
-  const int rc0 = li, rc1 = (li + 4) & 15, rc2 = (li + 8) & 15, rc3 = (li + 12) & 15;
-  for(int kt = 0; kt < K; kt += U4_KT) {
-    __syncthreads();
-#pragma unroll
-    for(int q = 0; q < U4_KT / 2; ++q) {
-      Vs[2 * q + lrow][lcol] = vreg[q];
-      Us[2 * q + lrow][lcol] = ureg[q];
-    }
-    __syncthreads();
-    if(kt + U4_KT < K) {
-#pragma unroll
-      for(int q = 0; q < U4_KT / 2; ++q) {
-        vreg[q] = vr_ok ? Vp[(int64_t)(kt + U4_KT + 2 * q) * ldv] : 0.0;
-        ureg[q] = uc_ok ? Up[(int64_t)(kt + U4_KT + 2 * q) * lda] : 0.0;
-      }
-    }
-#pragma unroll 1
-    for(int kk = 0; kk < U4_KT / 4; ++kk) {
-      double a[4];
-#pragma unroll
-      for(int i = 0; i < 4; ++i) a[i] = Vs[kk * 4 + lk][wr * 64 + i * 16 + li];
-#pragma unroll
-      for(int j = 0; j < 4; ++j) {
-        const double* ub = &Us[kk * 4 + lk][wc * 64 + j * 16];
-        const double b0 = ub[rc0], b1 = ub[rc1], b2 = ub[rc2], b3 = ub[rc3];
-#pragma unroll
-        for(int i = 0; i < 4; ++i) {
-          acc[i][j][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b0, acc[i][j][0], 0, 0, 0);
-          acc[i][j][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b1, acc[i][j][1], 0, 0, 0);
-          acc[i][j][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b2, acc[i][j][2], 0, 0, 0);
-          acc[i][j][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b3, acc[i][j][3], 0, 0, 0);
-        }
-      }
-    }
-  }
-  // ---- epilogue through LDS: pass q = tile rows {64 wr + 16 q .. + 15}, wr = 0, 1  ->  buffer rows 16 wr + (0..15)
-  constexpr int LDB = LD_TN + 4;
-  double (*Cb)[LDB] = reinterpret_cast<double (*)[LDB]>(Sh);
-  const int di = lane >> 4, db = (lane & 15) >> 2, dj = lane & 3;   // D lane -> (i, b, j)
-#pragma unroll
-  for(int q = 0; q < 4; ++q) {
-    __syncthreads();   // staging buffers / previous pass consumed
-#pragma unroll
-    for(int j = 0; j < 4; ++j)
-#pragma unroll
-      for(int r = 0; r < 4; ++r)
-        Cb[16 * wr + 4 * db + di][wc * 64 + 16 * j + 4 * ((db + r) & 3) + dj] = acc[q][j][r];
-    __syncthreads();
-    // wave w: buffer rows 8w .. 8w+7; lane: columns lane and lane + 64.  All 16 loads before the first store (a load
-    // cannot be hoisted above a possibly-aliasing store).
-    double cv[8][2];
-    const int col0 = c0 + lane, col1 = c0 + 64 + lane;
-#pragma unroll
-    for(int rr = 0; rr < 8; ++rr) {
-      const int br = 8 * wave + rr;
-      const int row = r0 + 64 * (br >> 4) + 16 * q + (br & 15);
-      const double* Crow = A + (int64_t)row * lda;
-      const bool okr = row < row_end;
-      cv[rr][0] = (okr && col0 < col_end && col0 >= row) ? Crow[col0] : 0.0;
-      cv[rr][1] = (okr && col1 < col_end && col1 >= row) ? Crow[col1] : 0.0;
-    }
-#pragma unroll
-    for(int rr = 0; rr < 8; ++rr) {
-      const int br = 8 * wave + rr;
-      const int row = r0 + 64 * (br >> 4) + 16 * q + (br & 15);
-      double* Crow = A + (int64_t)row * lda;
-      const bool okr = row < row_end;
-      if(okr && col0 < col_end && col0 >= row) Crow[col0] = cv[rr][0] - Cb[br][lane];
-      if(okr && col1 < col_end && col1 >= row) Crow[col1] = cv[rr][1] - Cb[br][64 + lane];
-    }
-  }
-}
-
-// 64 x 64-tile variant for the 256 x 256 diagonal block of the NEXT super-panel (the only update on the serial chain):
-// 10 workgroups instead of 3, each with a quarter of the MFMA work, on the reserved CUs.  Same operand layout as above;
-// each wave owns a 32 x 32 quadrant = 2 x 2 MFMA tiles.  Writes the matrix and the block's compact copy.
-__global__ __launch_bounds__(kBlock) void ldlt_update_diag_kernel(double* __restrict__ A, int64_t lda, int N,
-                                                                  const double* __restrict__ V, int64_t ldv, int urow0,
-                                                                  int K, int s, int row_end, double* __restrict__ Cnext)
-{
-  constexpr int TS = 64, LDQ = TS + 16;
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if(tj < ti) return;
-  const int r0 = s + ti * TS, c0 = s + tj * TS;
-  if(r0 >= row_end || c0 >= row_end) return;
-  __shared__ double Vs[LD_KT][LDQ];
-  __shared__ double Us[LD_KT][LDQ];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lk = lane >> 4, li = lane & 15;
-  double4_t acc[2][2];
-#pragma unroll
-  for(int i = 0; i < 2; ++i)
-#pragma unroll
-    for(int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int lcol = tid & 63, lrow = tid >> 6;   // 4 k-rows per pass, 4 passes per 16-deep stage
-  const int vcol = (r0 + lcol < N) ? (r0 + lcol) : (N - 1);
-  const int ucol = (c0 + lcol < N) ? (c0 + lcol) : (N - 1);
-  const double* Vp = V + (int64_t)lrow * ldv + vcol;
-  const double* Up = A + (int64_t)(urow0 + lrow) * lda + ucol;
-  double vreg[4], ureg[4];
-#pragma unroll
-  for(int q = 0; q < 4; ++q) {
-    vreg[q] = Vp[(int64_t)(4 * q) * ldv];
-    ureg[q] = Up[(int64_t)(4 * q) * lda];
-  }
-  for(int kt = 0; kt < K; kt += LD_KT) {
-    __syncthreads();
-#pragma unroll
-    for(int q = 0; q < 4; ++q) {
-      Vs[4 * q + lrow][lcol] = vreg[q];
-      Us[4 * q + lrow][lcol] = ureg[q];
-    }
-    __syncthreads();
-    if(kt + LD_KT < K) {
-#pragma unroll
-      for(int q = 0; q < 4; ++q) {
-        vreg[q] = Vp[(int64_t)(kt + LD_KT + 4 * q) * ldv];
-        ureg[q] = Up[(int64_t)(kt + LD_KT + 4 * q) * lda];
-      }
-    }
-#pragma unroll
-    for(int kk = 0; kk < LD_KT / 4; ++kk) {
-      double a[2], b[2];
-#pragma unroll
-      for(int i = 0; i < 2; ++i) a[i] = Vs[kk * 4 + lk][wr * 32 + i * 16 + li];
-#pragma unroll
-      for(int j = 0; j < 2; ++j) b[j] = Us[kk * 4 + lk][wc * 32 + j * 16 + li];
-#pragma unroll
-      for(int i = 0; i < 2; ++i)
-#pragma unroll
-        for(int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  double cv[2][2][4];
-  bool ok[2][2][4];
-#pragma unroll
-  for(int i = 0; i < 2; ++i)
-#pragma unroll
-    for(int j = 0; j < 2; ++j)
-#pragma unroll
-      for(int reg = 0; reg < 4; ++reg) {
-        const int row = r0 + wr * 32 + i * 16 + lk + 4 * reg, col = c0 + wc * 32 + j * 16 + li;
-        ok[i][j][reg] = (row < row_end) && (col < row_end) && (col >= row);
-        cv[i][j][reg] = ok[i][j][reg] ? A[(int64_t)row * lda + col] : 0.0;
-      }
-#pragma unroll
-  for(int i = 0; i < 2; ++i)
-#pragma unroll
-    for(int j = 0; j < 2; ++j)
-#pragma unroll
-      for(int reg = 0; reg < 4; ++reg) {
-        const int row = r0 + wr * 32 + i * 16 + lk + 4 * reg, col = c0 + wc * 32 + j * 16 + li;
-        if(ok[i][j][reg]) {
-          const double nv = cv[i][j][reg] - acc[i][j][reg];
-          A[(int64_t)row * lda + col] = nv;
-          Cnext[(row - s) * LD_NB + (col - s)] = nv;
-        }
-      }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2172,6 +1835,8 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
   }
 }
 
+#include "ldlt_dataflow.hpp"
+
 }  // namespace hiopamd
 
 using namespace hiopamd;
@@ -2215,6 +1880,111 @@ static double update_flops(int N, int K, int s, int row_end)
   return 2.0 * K * rows * (first + last) * 0.5;
 }
 
+// ---- host side of the dataflow factorisation: static task tables ------------------------------------------------
+// Chain tasks of ONE super-panel, by owner (role): F(p) / T(p, c) / U(p; a, b) on the 64 x 64 tiles of the window
+// (rows 0..3 = R_j, 4..7 = R_j+1; columns 0..3 = C_j, 4..7 = H_j / next diagonal block).  has_next = false: C_j only.
+static void df_chain_tasks(bool has_next, std::vector<int4>& out)
+{
+  std::vector<std::vector<int4>> by_role(DF_ROLES);
+  const int cmax = has_next ? 7 : 3;
+  auto nn_index = [](int a, int b) {   // upper-triangular tile (a, b) of the 4 x 4 next diagonal block -> 0..9
+    int t = 0;
+    for(int r = 0; r < a; ++r) t += 4 - r;
+    return t + (b - a);
+  };
+  for(int p = 0; p < 4; ++p) {
+    by_role[0].push_back(make_int4(DF_F, p, p, p));
+    for(int c = p + 1; c <= cmax; ++c) {   // tile solves of pivot p
+      int role;
+      if(c == p + 1) role = 0;
+      else if(c == p + 2) role = 1;
+      else if(c <= 3) role = 2;
+      else role = 3 + (c - 4);
+      by_role[role].push_back(make_int4(DF_T, p, p, c));
+    }
+    for(int a = p + 1; a <= cmax; ++a)
+      for(int b = a; b <= cmax; ++b) {   // updates by pivot p
+        int role;
+        if(a == p + 1 && b == p + 1) role = 0;
+        else if((a == p + 1 && b == p + 2) || (a == p + 2 && b == p + 2)) role = 1;
+        else if(b <= 3) role = 2;
+        else if(a <= 3) role = 3 + (b - 4);
+        else role = 7 + nn_index(a - 4, b - 4) % 9;
+        by_role[role].push_back(make_int4(DF_U, p, a, b));
+      }
+  }
+  out.assign((size_t)DF_ROLES * DF_MAXT, make_int4(DF_END, 0, 0, 0));
+  for(int r = 0; r < DF_ROLES; ++r) {
+    if((int)by_role[r].size() >= DF_MAXT) std::abort();
+    for(size_t k = 0; k < by_role[r].size(); ++k) out[(size_t)r * DF_MAXT + k] = by_role[r][k];
+  }
+}
+
+struct DfPlan {
+  int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
+  int64_t off_chain = 0, off_tr = 0, off_ver = 0, nflags = 0;
+  std::vector<int4> ctasks, wtasks;
+  std::vector<unsigned> upcnt;
+  double up_flops = 0.0;   // algorithmic flops of the UP tasks (2 K per updated element)
+};
+static DfPlan df_build_plan(int N)
+{
+  DfPlan P;
+  P.N = N;
+  P.nsp = (N + LD_NB - 1) / LD_NB;
+  P.nt = (N + UD_T - 1) / UD_T;
+  const int nfull = N / LD_NB;
+  if(N % LD_NB == 0) {
+    P.nchain = nfull;
+    P.last_has_next = 0;
+  } else {
+    P.nchain = nfull - 1;   // the last full super-panel has a ragged successor: left to the stepwise kernels
+    P.last_has_next = 1;
+  }
+  if(P.nchain < 0) P.nchain = 0;
+  P.nwide = P.last_has_next ? P.nchain : P.nchain - 1;   // super-panels with a row-panel tail + trailing update
+  if(P.nwide < 0) P.nwide = 0;
+  P.off_chain = DF_HDR;
+  P.off_tr = P.off_chain + (int64_t)(P.nsp + 1) * DF_CH;
+  P.off_ver = P.off_tr + (int64_t)P.nsp * P.nt;
+  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 16 + 512 + 8 * (int64_t)(P.nsp + 1);   // (+ TEMPORARY progress words, stamps)
+  std::vector<int4> t0, t1;
+  df_chain_tasks(true, t0);
+  df_chain_tasks(false, t1);
+  P.ctasks = t0;
+  P.ctasks.insert(P.ctasks.end(), t1.begin(), t1.end());
+  P.upcnt.assign((size_t)P.nsp + 1, 0u);
+  auto emit_tr = [&](int j) {
+    for(int c = LD_NB * (j + 2); c < N; c += 16) P.wtasks.push_back(make_int4(DF_TR, j, c, 0));
+  };
+  auto emit_up = [&](int j, int I) {
+    for(int J = (I < 2 * j + 4) ? 2 * j + 4 : I; J < P.nt; ++J) {
+      P.wtasks.push_back(make_int4(DF_UP, j, I, J));
+      P.upcnt[j] += 1u;
+      // rows r in tile I, columns max(r, 128 J) .. of tile J, inside the matrix
+      const int r0 = UD_T * I, r1 = std::min(N, r0 + UD_T), c0 = UD_T * J, c1 = std::min(N, c0 + UD_T);
+      for(int r = r0; r < r1; ++r) P.up_flops += 2.0 * LD_NB * (double)std::max(0, c1 - std::max(c0, r));
+    }
+  };
+  if(P.nwide > 0) emit_tr(0);
+  for(int j = 0; j < P.nwide; ++j) {
+    emit_up(j, 2 * j + 2);
+    if(2 * j + 3 < P.nt) emit_up(j, 2 * j + 3);
+    if(j + 1 < P.nwide) emit_tr(j + 1);   // the next row panel, as soon as its rows are updated
+    for(int I = 2 * j + 4; I < P.nt; ++I) emit_up(j, I);
+  }
+  return P;
+}
+
+struct DfDevice {
+  DfPlan plan;
+  unsigned* flags = nullptr;
+  int4* ctasks = nullptr;
+  int4* wtasks = nullptr;
+  unsigned* upcnt = nullptr;
+  bool enabled = true;
+};
+
 struct hiopamd_linsolver {
   hiopamd_ctx* ctx = nullptr;
   int n = 0;
@@ -2236,63 +2006,49 @@ struct hiopamd_linsolver {
   int inertia[3] = {0, 0, 0};
   double flops_fact = 0.0, flops_triu = 0.0;   // hiopLinSolStats::flopsFact / flopsTriuSolves (cumulative)
   LdltProfile prof;
+  DfDevice df;   // dataflow factorisation (task tables + flags)
 };
 
 static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, double* dinv, double* V, double* Dblk,
-                            double* Cd, int* d_info, int* inertia3_host, LdltProfile* prof = nullptr, double* Winv = nullptr)
+                            double* Cd, int* d_info, int* inertia3_host, LdltProfile* prof = nullptr, double* Winv = nullptr,
+                            DfDevice* df = nullptr)
 {
   // Dblk: per 64-row panel a compact 64x64 copy of the factored diagonal block, followed (after all
   // the blocks) by the per-panel 4 x 16x16 inverses
   double* Li = Dblk + (int64_t)((N + LD_nb - 1) / LD_nb) * (LD_nb * LD_nb);
   const bool timed = prof && prof->enabled;
   hipStream_t upd_stream = ctx->stream;
-  auto launch_update = [&](dim3 grid, const double* Vb, int urow0, int K, int s, int row_end, double* Cnext, int col_end,
-                           int skip_diag) {
-    const int vrow0 = 0;
+  // trailing update launch: tiles of 128 x 128 covering rows/columns [s, s + 128 t)
+  auto launch_update = [&](int t, const double* Vb, int urow0, int K, int s, int row_end, int col_end, int skip_diag) {
     if(timed) (void)hipEventRecord(prof->get(), upd_stream);
-    int xcd_map = 0;
-    static int xcd_min = -1;   // HIOPAMD_XCD_MIN_TILES: smallest tile count per side that uses the XCD-aware mapping
-    // default: off.  On the CU-masked update stream an XCD has 31 CUs = 62 tile slots, so an 8x8-tile super-tile no longer
-    // fits one round per XCD and the mapping costs ~50 us per launch (measured: 8.5 ms -> 7.6 ms of update time per
-    // factorisation without it); it never showed a measurable gain on the full device either.
-    if(xcd_min < 0) xcd_min = std::getenv("HIOPAMD_XCD_MIN_TILES") ? std::atoi(std::getenv("HIOPAMD_XCD_MIN_TILES")) : 100000;
-    if(row_end == N && grid.x == grid.y && (int)grid.x >= xcd_min) {
-      // square trailing update: XCD-aware 1-D launch over 8x8-tile super-tiles
-      xcd_map = (int)grid.x;
-      const int Sside = (xcd_map + 7) / 8;
-      const int nS = Sside * (Sside + 1) / 2;
-      const int per_xcd = (nS + 7) / 8;           // super-tiles per XCD
-      grid = dim3((unsigned)(per_xcd * 64 * 8), 1, 1);
-    }
-    static int upd4 = -1;   // HIOPAMD_UPD4=1: the experimental 4x4x4-MFMA kernel
-    if(upd4 < 0) upd4 = std::getenv("HIOPAMD_UPD4") ? std::atoi(std::getenv("HIOPAMD_UPD4")) : 0;
-    // HIOPAMD_UPD64 = 10 WI + WJ selects the wave tile (16 WI) x (16 WJ) of ldlt_update_kernel_t; 0 = the 128 x 128-tile
-    // kernel with 4 x 4 MFMA tiles per wave; 100 KT is added for a k-depth per stage other than 16.  Default 822: 64 x 64
-    // workgroup tiles, 4 accumulators per wave, 8-deep stages (16-deep: 39.5 TFLOP/s, 8 or 4: 40.8, 32: 36.8).
-    static int upd64 = -1;
-    if(upd64 < 0) upd64 = std::getenv("HIOPAMD_UPD64") ? std::atoi(std::getenv("HIOPAMD_UPD64")) : 822;
-    if(upd64 && !xcd_map && !Cnext && grid.x == grid.y) {
-      const int wi = (upd64 % 100) / 10, wj = upd64 % 10;   // upd64 = 100 KT + 10 WI + WJ
-      const int ext = (int)grid.x * LD_TM;                  // covered extent (multiple of 128)
-      const dim3 g2((unsigned)((ext + 32 * wj - 1) / (32 * wj)), (unsigned)((ext + 32 * wi - 1) / (32 * wi)));
-#define HIOPAMD_U64(...)                                                                                                       \
-  hipLaunchKernelGGL((ldlt_update_kernel_t<__VA_ARGS__>), g2, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, \
-                     K, s, row_end, col_end, skip_diag, nullptr)
-      if(upd64 == 822) HIOPAMD_U64(2, 2, 8);
-      else if(upd64 == 422) HIOPAMD_U64(2, 2, 4);
-      else if(upd64 == 22) HIOPAMD_U64(2, 2, 16);
-      else if(upd64 == 24) HIOPAMD_U64(2, 4, 16);
-      else if(upd64 == 42) HIOPAMD_U64(4, 2, 16);
-      else if(upd64 == 12) HIOPAMD_U64(1, 2, 16);
-      else HIOPAMD_U64(2, 2, 8);
-#undef HIOPAMD_U64
-    }
-    else if(upd4 && !xcd_map && !Cnext)
-      hipLaunchKernelGGL(ldlt_update4_kernel, grid, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, s,
-                         row_end, col_end, skip_diag);
+    static int upd_old = -1;   // TEMPORARY A/B switch (round 2): HIOPAMD_UPD_OLD=1 = round 1's 64 x 64-tile kernel
+    if(upd_old < 0) upd_old = std::getenv("HIOPAMD_UPD_OLD") ? std::atoi(std::getenv("HIOPAMD_UPD_OLD")) : 0;
+    static int upd_dbg = -1;   // TEMPORARY: timing experiments (results meaningless)
+    if(upd_dbg < 0) upd_dbg = std::getenv("HIOPAMD_UPD_DBG") ? std::atoi(std::getenv("HIOPAMD_UPD_DBG")) : 0;
+    if(upd_old)
+      hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), dim3(2 * t, 2 * t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0,
+                         urow0, K, s, row_end, col_end, skip_diag, nullptr);
+    else if(upd_dbg == 1)
+      hipLaunchKernelGGL(ldlt_update_db_kernel<1>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
+                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
+    else if(upd_dbg == 2)
+      hipLaunchKernelGGL(ldlt_update_db_kernel<2>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
+                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
+    else if(upd_dbg == 4)
+      hipLaunchKernelGGL(ldlt_update_db_kernel<4>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
+                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
+    else if(upd_dbg == 5)
+      hipLaunchKernelGGL(ldlt_update_db_kernel<5>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
+                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
+    else if(upd_dbg == 6)
+      hipLaunchKernelGGL(ldlt_update_db_kernel<6>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
+                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
+    else if(upd_dbg == 3)
+      hipLaunchKernelGGL(ldlt_update_db_kernel<3>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
+                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
     else
-      hipLaunchKernelGGL(ldlt_update_kernel, grid, dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, vrow0, urow0, K, s,
-                         row_end, xcd_map, Cnext, col_end, skip_diag);
+      hipLaunchKernelGGL(ldlt_update_db_kernel<0>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
+                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
     if(timed) {
       (void)hipEventRecord(prof->get(), upd_stream);
       prof->flops += update_flops(N, K, s, row_end);
@@ -2390,18 +2146,102 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
                        dinv, p.Cj, p.Dk_sp, p.Li_sp, col_ofs);
   };
   // panel 0's diagonal block on the caller's stream, then fork
+  int jp0 = 0;
+  bool all_done = false;
+  const bool use_df = df && df->enabled && df->flags && lookahead && lda == N && df->plan.N == N && df->plan.nchain >= 3;
   {
     const Panel p0 = panel(0);
     hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, A, lda, p0.K0, p0.kbs, p0.Cj);
+  }
+  if(use_df) {
+    // ---- dataflow factorisation of the chained super-panels: two persistent kernels, device flags only
+    const DfPlan& P = df->plan;
+    DfArgs a;
+    a.A = A; a.lda = lda; a.N = N; a.V = V; a.ldv = ldv; a.dinv = dinv; a.Dblk = Dblk; a.Li = Li; a.Cd = Cd; a.info = d_info;
+    a.flags = df->flags; a.nsp = P.nsp; a.nt = P.nt; a.nchain = P.nchain; a.last_has_next = P.last_has_next;
+    a.off_chain = P.off_chain; a.off_tr = P.off_tr; a.off_ver = P.off_ver;
+    a.ctasks = df->ctasks; a.wtasks = df->wtasks; a.nwtasks = (int)P.wtasks.size(); a.upcnt = df->upcnt;
+    HIOPAMD_CHECK(hipMemsetAsync(df->flags, 0, sizeof(unsigned) * (size_t)P.nflags, st));
+    hipLaunchKernelGGL(ldlt_df_init_kernel, dim3(1), dim3(kBlock), 0, st, a);
+    int rc = dep(st, su);
+    if(rc == HIOPAMD_OK) rc = dep(st, sd);
+    if(rc != HIOPAMD_OK) return rc;
+    static int df_dbg = -1;   // TEMPORARY bring-up switch: 1 = chain kernel only, 2 = wide kernel only (both must time out cleanly)
+    if(df_dbg < 0) df_dbg = std::getenv("HIOPAMD_DF_DEBUG") ? std::atoi(std::getenv("HIOPAMD_DF_DEBUG")) : 0;
+    a.dbg = df_dbg;
+    a.off_dbg = P.off_ver + (int64_t)P.nt * P.nt;
+    a.off_ts = a.off_dbg + 16 + 512;
+    if(df_dbg != 2) hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
+    if(df_dbg) std::fprintf(stderr, "[hiop_amd] df debug %d: chain launched (%s)\n", df_dbg, hipGetErrorName(hipGetLastError()));
+    if(a.nwtasks > 0 && df_dbg != 1) {
+      if(timed) (void)hipEventRecord(prof->get(), su);
+      const int grid = a.nwtasks < 480 ? a.nwtasks : 480;   // two workgroups on each of the 240 CUs of the wide stream
+      hipLaunchKernelGGL(ldlt_wide_kernel, dim3(grid), dim3(kBlock), 0, su, a);
+      if(timed) {
+        (void)hipEventRecord(prof->get(), su);
+        prof->flops += P.up_flops;
+        prof->launches += 1;
+      }
+    }
+    if(std::getenv("HIOPAMD_DF_DEBUG")) {
+    // TEMPORARY bring-up aid: host watchdog.  If the stream does not drain within 10 s, dump the flag state through a
+    // separate stream and give up (the kernels' own wall-clock bound should have fired long before).
+    const auto t0 = std::chrono::steady_clock::now();
+    while(hipStreamQuery(su) == hipErrorNotReady || hipStreamQuery(sd) == hipErrorNotReady) {
+      if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+        hipStream_t dbg;
+        (void)hipStreamCreateWithFlags(&dbg, hipStreamNonBlocking);
+        std::vector<unsigned> fl((size_t)df->plan.nflags);
+        (void)hipMemcpyAsync(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost, dbg);
+        (void)hipStreamSynchronize(dbg);
+        std::fprintf(stderr, "[hiop_amd] df HOST WATCHDOG: kernels still running after 10 s. header:");
+        for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[q]);
+        std::fprintf(stderr, "\n");
+        for(int j = 0; j < P.nsp; ++j) {
+          std::fprintf(stderr, "  panel %d: cdone %u hdone %u updone %u/%u cv:", j, fl[P.off_chain + j * DF_CH + DF_CDONE],
+                       fl[P.off_chain + j * DF_CH + DF_HDONE], fl[P.off_chain + j * DF_CH + DF_UPDONE], P.upcnt[j]);
+          for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[P.off_chain + j * DF_CH + DF_CV + q]);
+          std::fprintf(stderr, " hv:");
+          for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[P.off_chain + j * DF_CH + DF_HV + q]);
+          std::fprintf(stderr, " tr:");
+          for(int q = 0; q < P.nt; ++q) std::fprintf(stderr, " %u", fl[P.off_tr + (int64_t)j * P.nt + q]);
+          std::fprintf(stderr, "\n");
+        }
+        std::fprintf(stderr, "  streams: su %s, sd %s\n  chain roles:", hipGetErrorName(hipStreamQuery(su)), hipGetErrorName(hipStreamQuery(sd)));
+        {
+          const int64_t od = df->plan.off_ver + (int64_t)df->plan.nt * df->plan.nt;
+          for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[od + q]);
+          std::fprintf(stderr, "\n  wide wgs:");
+          for(int q = 0; q < 80; ++q) std::fprintf(stderr, " %u", fl[od + 16 + q]);
+          std::fprintf(stderr, "\n");
+        }
+        std::fprintf(stderr, "  ver:\n");
+        for(int I = 0; I < P.nt; ++I) {
+          std::fprintf(stderr, "   ");
+          for(int J = 0; J < P.nt; ++J) std::fprintf(stderr, " %u", fl[P.off_ver + (int64_t)I * P.nt + J]);
+          std::fprintf(stderr, "\n");
+        }
+        std::fflush(stderr);
+        std::_Exit(7);
+      }
+    }
+  }
+    rc = dep(su, st);
+    if(rc == HIOPAMD_OK) rc = dep(sd, st);
+    if(rc != HIOPAMD_OK) return rc;
+    jp0 = P.nchain;
+    if(jp0 >= nsp) all_done = true;
+    else superdiag(jp0, st);   // the first super-panel left to the stepwise kernels (its block holds every update)
+  } else {
     superdiag(0, st);
   }
-  if(lookahead) {
+  if(lookahead && !all_done) {
     int rc = dep(st, su);
     if(rc == HIOPAMD_OK) rc = dep(st, sd);
     if(rc != HIOPAMD_OK) return rc;
   }
   hipEvent_t ev_rest_prev = nullptr;   // upd_rest(j-1) done (recorded on su)
-  for(int jp = 0; jp < nsp; ++jp) {
+  for(int jp = jp0; jp < nsp && !all_done; ++jp) {
     const Panel p = panel(jp);
     if(p.Kend >= N) break;
     const int s = p.Kend;
@@ -2416,23 +2256,11 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       HIOPAMD_CHECK(hipEventRecord(ev_head, sd));
     }
     {
-      // the next diagonal block (the only update on the chain).  HIOPAMD_UPD_DIAG = 12 / 11 / 22: the tile kernel with
-      // 32x64 (default) / 32x32 / 64x64 tiles (20 / 36 / 10 live workgroups for the 16 reserved CUs); 0: the dedicated 64x64-tile
-      // kernel.  Per step at N = 8192: 9.25 / 9.25 / 9.31 / 9.35 ms.
-      static int ud = -1;
-      if(ud < 0) ud = std::getenv("HIOPAMD_UPD_DIAG") ? std::atoi(std::getenv("HIOPAMD_UPD_DIAG")) : 12;
+      // the next diagonal block (the only update on the chain): the tile kernel with 32 x 64 tiles = 20 live workgroups for
+      // the 16 reserved CUs, written to the matrix and to the block's compact copy
       double* Cn = panel(jp + 1).Cj;
-      if(ud == 11)
-        hipLaunchKernelGGL((ldlt_update_kernel_t<1, 1, 8>), dim3(8, 8), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, 0, p.K0, p.kbs, s,
-                           sa_end, sa_end, 0, Cn);
-      else if(ud == 12)
-        hipLaunchKernelGGL((ldlt_update_kernel_t<1, 2, 8>), dim3(4, 8), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, 0, p.K0, p.kbs, s,
-                           sa_end, sa_end, 0, Cn);
-      else if(ud == 22)
-        hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), dim3(4, 4), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, 0, p.K0, p.kbs, s,
-                           sa_end, sa_end, 0, Cn);
-      else
-        hipLaunchKernelGGL(ldlt_update_diag_kernel, dim3(4, 4), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, p.K0, p.kbs, s, sa_end, Cn);
+      hipLaunchKernelGGL((ldlt_update_kernel_t<1, 2, 8>), dim3(4, 8), dim3(kBlock), 0, sd, A, lda, N, p.Vb, ldv, 0, p.K0, p.kbs, s,
+                         sa_end, sa_end, 0, Cn);
     }
     superdiag(jp + 1, sd);
     hipEvent_t ev_diag = nullptr;
@@ -2444,9 +2272,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     trsm(jp, su, head, N - sa_end);
     if(lookahead) HIOPAMD_CHECK(hipStreamWaitEvent(su, ev_head, 0));
     {
-      const int t = (N - s + LD_TM - 1) / LD_TM;
+      const int t = (N - s + UD_T - 1) / UD_T;
       upd_stream = su;
-      launch_update(dim3(t, t), p.Vb, p.K0, p.kbs, s, N, nullptr, N, 1);
+      launch_update(t, p.Vb, p.K0, p.kbs, s, N, N, 1);
     }
     if(lookahead) {
       ev_rest_prev = next_event();
@@ -2454,7 +2282,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       HIOPAMD_CHECK(hipStreamWaitEvent(su, ev_diag, 0));   // trsm_tail(jp+1) needs superdiag(jp+1)
     }
   }
-  if(lookahead) {   // join
+  if(lookahead && !all_done) {   // join
     int rc = dep(su, st);
     if(rc == HIOPAMD_OK) rc = dep(sd, st);
     if(rc != HIOPAMD_OK) return rc;
@@ -2466,8 +2294,47 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv);
   HIOPAMD_CHECK(hipGetLastError());
   int h[4];
+  unsigned dfw[16] = {0};
   HIOPAMD_CHECK(hipMemcpyAsync(h, d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  if(use_df) HIOPAMD_CHECK(hipMemcpyAsync(dfw, df->flags, sizeof(dfw), hipMemcpyDeviceToHost, st));
   HIOPAMD_CHECK(hipStreamSynchronize(st));
+  if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
+    const DfPlan& P = df->plan;
+    std::vector<unsigned> ts((size_t)8 * (P.nsp + 1));
+    const int64_t off_ts = P.off_ver + (int64_t)P.nt * P.nt + 16 + 512;
+    (void)hipMemcpy(ts.data(), df->flags + off_ts, sizeof(unsigned) * ts.size(), hipMemcpyDeviceToHost);
+    const unsigned t0 = 0xffffffffu - ts[0];
+    std::fprintf(stderr, "[hiop_amd] df stamps (us since F(0) of panel 0): panel | F0 start, F3 done | last head T | TR first start, last done | UP first start, last done\n");
+    for(int j = 0; j < P.nsp; ++j) {
+      auto us = [&](int k) { const unsigned v = ts[(size_t)8 * j + k]; return v == 0 ? -1.0 : ((k & 1) ? (double)(v - t0) : (double)((0xffffffffu - v) - t0)) * 0.01; };
+      std::fprintf(stderr, "  %2d | %8.1f %8.1f | %8.1f | %8.1f %8.1f | %8.1f %8.1f\n", j, us(0), us(1), us(3), us(4), us(5), us(6), us(7));
+    }
+  }
+  if(dfw[DF_ABORT] && std::getenv("HIOPAMD_DF_DEBUG")) {
+    const DfPlan& P = df->plan;
+    std::vector<unsigned> fl((size_t)P.nflags);
+    (void)hipMemcpy(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost);
+    for(int j = 0; j < P.nsp; ++j) {
+      if(fl[P.off_chain + j * DF_CH + DF_CDONE] == 0 && j > 0 && fl[P.off_chain + (j - 1) * DF_CH + DF_CDONE] == 0) continue;
+      std::fprintf(stderr, "  panel %d: cdone %u hdone %u updone %u/%u cv:", j, fl[P.off_chain + j * DF_CH + DF_CDONE],
+                   fl[P.off_chain + j * DF_CH + DF_HDONE], fl[P.off_chain + j * DF_CH + DF_UPDONE], P.upcnt[j]);
+      for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[P.off_chain + j * DF_CH + DF_CV + q]);
+      std::fprintf(stderr, " hv:");
+      for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[P.off_chain + j * DF_CH + DF_HV + q]);
+      std::fprintf(stderr, "\n");
+    }
+    const int64_t od = P.off_ver + (int64_t)P.nt * P.nt;
+    std::fprintf(stderr, "  chain roles (10000 j + 100 it + 10 type):");
+    for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[od + q]);
+    std::fprintf(stderr, "\n");
+  }
+  if(dfw[DF_ABORT]) {
+    std::fprintf(stderr,
+                 "[hiop_amd] dataflow LDL^T: a bounded wait timed out, factorisation aborted.  waiter %u (1 = TR, 2 = UP, 100+r = "
+                 "chain role r) args %u %u %u %u, condition slot %u: flag word %u is %u, needs >= %u; tickets taken %u\n",
+                 dfw[2], dfw[3], dfw[4], dfw[5], dfw[6], dfw[7], dfw[10], dfw[9], dfw[8], dfw[DF_TICKET]);
+    return HIOPAMD_ERR_HIP;
+  }
   if(timed) prof->collect();
   if(inertia3_host) {
     inertia3_host[0] = h[1];
@@ -2646,6 +2513,23 @@ int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
     HIOPAMD_CHECK(hipMemcpy(ls->fl_tasks, tk.data(), sizeof(int4) * tk.size(), hipMemcpyHostToDevice));
   }
   HIOPAMD_CHECK(hipMemsetAsync(ls->M, 0, sizeof(double) * nn * nn, ctx->stream));
+  {
+    // dataflow factorisation: task tables and flags (HIOPAMD_DF=0 in the environment selects the stepwise kernels)
+    DfDevice& df = ls->df;
+    df.plan = df_build_plan(n);
+    df.enabled = !(std::getenv("HIOPAMD_DF") && std::atoi(std::getenv("HIOPAMD_DF")) == 0);
+    const DfPlan& P = df.plan;
+    if(P.nchain >= 3) {
+      HIOPAMD_CHECK(hipMalloc((void**)&df.flags, sizeof(unsigned) * (size_t)P.nflags));
+      HIOPAMD_CHECK(hipMalloc((void**)&df.ctasks, sizeof(int4) * P.ctasks.size()));
+      HIOPAMD_CHECK(hipMalloc((void**)&df.wtasks, sizeof(int4) * (P.wtasks.size() + 1)));
+      HIOPAMD_CHECK(hipMalloc((void**)&df.upcnt, sizeof(unsigned) * P.upcnt.size()));
+      HIOPAMD_CHECK(hipMemcpy(df.ctasks, P.ctasks.data(), sizeof(int4) * P.ctasks.size(), hipMemcpyHostToDevice));
+      if(!P.wtasks.empty())
+        HIOPAMD_CHECK(hipMemcpy(df.wtasks, P.wtasks.data(), sizeof(int4) * P.wtasks.size(), hipMemcpyHostToDevice));
+      HIOPAMD_CHECK(hipMemcpy(df.upcnt, P.upcnt.data(), sizeof(unsigned) * P.upcnt.size(), hipMemcpyHostToDevice));
+    }
+  }
   *out = ls;
   return HIOPAMD_OK;
 }
@@ -2665,6 +2549,10 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->P);
   (void)hipFree(ls->fl_sync);
   (void)hipFree(ls->fl_tasks);
+  (void)hipFree(ls->df.flags);
+  (void)hipFree(ls->df.ctasks);
+  (void)hipFree(ls->df.wtasks);
+  (void)hipFree(ls->df.upcnt);
   delete ls;
   return HIOPAMD_OK;
 }
@@ -2678,7 +2566,7 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
   ls->factored = false;
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_FACT);   // hiopLinSolverSymDenseLapack.hpp:80-125 (tmFactTime; flopsFact = n^3/3)
   ls->flops_fact += (double)ls->n * ls->n * ls->n / 3.0;
-  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W);
+  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df);
   if(rc == HIOPAMD_ERR_SINGULAR) {
     // reference: "entry in the factorization's diagonal is exactly zero" -> matrixChanged() returns -1
     *n_neg_host = -1;
@@ -2715,6 +2603,37 @@ int hiopamd_linsolver_profile_read(const hiopamd_linsolver* ls, double* update_m
   if(update_ms_host) *update_ms_host = ls->prof.ms;
   if(update_flops_host) *update_flops_host = ls->prof.flops;
   if(update_launches_host) *update_launches_host = ls->prof.launches;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_linsolver_set_dataflow(hiopamd_linsolver* ls, int enable)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  ls->df.enabled = enable != 0;
+  return HIOPAMD_OK;
+}
+
+// the static schedule of the dataflow factorisation for a matrix of order n (host only, no device needed): used by the
+// CPU-side schedule check (tests/test_ldlt_dataflow_plan.py).  dims8 = {nsp, nt, nchain, last_has_next, nwide, roles,
+// max tasks per role, number of wide tasks}; chain_tasks = 2 x roles x max x 4 ints (type, p, a, b), wide_tasks = 4 ints each.
+int hiopamd_ldlt_dataflow_plan(int n, int* dims8_host, int* chain_tasks_host, int* wide_tasks_host, int64_t wide_cap)
+{
+  if(n < 0 || !dims8_host) return HIOPAMD_ERR_ARG;
+  const DfPlan P = df_build_plan(n);
+  const int d[8] = {P.nsp, P.nt, P.nchain, P.last_has_next, P.nwide, DF_ROLES, DF_MAXT, (int)P.wtasks.size()};
+  for(int i = 0; i < 8; ++i) dims8_host[i] = d[i];
+  if(chain_tasks_host)
+    for(size_t i = 0; i < P.ctasks.size(); ++i) {
+      chain_tasks_host[4 * i] = P.ctasks[i].x; chain_tasks_host[4 * i + 1] = P.ctasks[i].y;
+      chain_tasks_host[4 * i + 2] = P.ctasks[i].z; chain_tasks_host[4 * i + 3] = P.ctasks[i].w;
+    }
+  if(wide_tasks_host) {
+    if((int64_t)P.wtasks.size() > wide_cap) return HIOPAMD_ERR_ARG;
+    for(size_t i = 0; i < P.wtasks.size(); ++i) {
+      wide_tasks_host[4 * i] = P.wtasks[i].x; wide_tasks_host[4 * i + 1] = P.wtasks[i].y;
+      wide_tasks_host[4 * i + 2] = P.wtasks[i].z; wide_tasks_host[4 * i + 3] = P.wtasks[i].w;
+    }
+  }
   return HIOPAMD_OK;
 }
 

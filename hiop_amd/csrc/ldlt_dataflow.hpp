@@ -1,0 +1,660 @@
+// Dataflow LDL^T: the whole factorisation as TWO persistent kernels that talk through device flags — no kernel
+// boundaries, no stream events and no host round trips between the 32 super-panels of an N = 8192 KKT matrix.
+// (included by ldlt.hip inside namespace hiopamd, after the tile kernels it re-uses)
+//
+//   chain kernel  (16 workgroups on the reserved CUs, CU-masked stream `diag_stream`):
+//       the serial spine of the factorisation on 64 x 64 tiles of a sliding window: for super-panel j the window is
+//       C_j (the 256 x 256 diagonal block, compact copy), H_j = A[R_j, R_j+1] (the head of the row panel) and
+//       Nn = C_j+1 (the next diagonal block).  Tasks: F(p) factor tile (p,p); T(p,c) tile solve V = L_pp^-1 X, U = D^-1 V;
+//       U(p;a,b) tile(a,b) -= V(p,a)^T U(p,b).  Workgroup 0 (the spine) runs F(p) -> T(p,p+1) -> U(p;p+1,p+1) -> F(p+1) ...,
+//       workgroup 1 the three tasks the spine needs next, the others the rest of the window (static ownership,
+//       chain_task_table()).  Round 1's chain (one workgroup factoring the whole 256 block, then a head substitution launch,
+//       then a diagonal-update launch: 203 us per super-panel) was the critical path of 20 of the 32 super-panels.
+//   wide kernel   (persistent workgroups on the other 240 CUs, CU-masked stream `upd_stream`), a ticket-ordered task list:
+//       TR(j, g)    16 columns of the tail of row panel j: V = L_jj^-1 A[R_j, cols], U = D^-1 V   (4 waves, the head-
+//                   substitution algorithm of ldlt_headtrsm_kernel)
+//       UP(j, I, J) 128 x 128 tile (I, J) of the trailing matrix -= V_j[:, I]^T U_j[:, J]           (the double-buffered
+//                   MFMA tile of ldlt_update_db_kernel)
+//       Tickets are handed out in a topological order (every dependency of a task has a smaller ticket or belongs to the
+//       chain kernel), so a workgroup that waits only ever waits for work that is already running: no deadlock whatever
+//       the residency.  TR(j+1, .) is ticketed right after the first two tile rows of UP(j, ., .): the next row panel is
+//       substituted while the bulk of update j still runs, and the last tiles of update j overlap the first tiles of
+//       update j+1 — the per-launch tails and the 73 us bubble per super-panel of round 1's stream schedule are gone.
+//
+// Flags (unsigned, zeroed by a memset node before every factorisation; all accesses agent-scope relaxed atomics):
+//   ticket, abort | per super-panel j: cv[4][4] / hv[4][4] tile versions of C_j / H_j, cdone, hdone, updone |
+//   tr[j][J] 16-column groups of 128-column block J substituted | ver[I][J] panels applied to trailing tile (I, J).
+// Data hand-over between workgroups: producer = `sc1` (write-through) stores, s_waitcnt vmcnt(0) by every wave, barrier,
+// one lane updates the flag; consumer = one lane polls, barrier, `sc1` (L1-bypassing) loads.  Every spin is bounded: on
+// time-out the abort flag is raised, every wait returns, the host reports HIOPAMD_ERR_HIP.
+
+constexpr int DF_TICKET = 0, DF_ABORT = 1, DF_HDR = 16;
+constexpr int DF_CH = 64;   // flags per super-panel in the chain section
+constexpr int DF_CV = 0, DF_HV = 16, DF_CDONE = 33, DF_HDONE = 34, DF_UPDONE = 35;
+constexpr int DF_MAXT = 40;           // chain tasks per role per super-panel (<= 28 used)
+constexpr int DF_ROLES = 16;
+
+enum { DF_F = 1, DF_T = 2, DF_U = 3, DF_END = 0 };
+enum { DF_TR = 1, DF_UP = 2 };
+
+struct DfArgs {
+  double* A;
+  int64_t lda;
+  int N;
+  double* V;          // 2 x 256 x N (double-buffered row panel, un-scaled)
+  int64_t ldv;
+  double* dinv;
+  double* Dblk;       // per 64-panel compact factored diagonal tile (64 x 64)
+  double* Li;         // per 64-panel four 16 x 16 inverses
+  double* Cd;         // per super-panel compact 256 x 256 diagonal block
+  int* info;
+  unsigned* flags;
+  int nsp;            // super-panels of the matrix
+  int nt;             // 128-tiles per side
+  int nchain;         // super-panels handled by the chain kernel
+  int last_has_next;  // does the last chained super-panel have a (full) next one
+  int64_t off_chain, off_tr, off_ver;
+  int dbg;            // TEMPORARY bring-up switch
+  int64_t off_dbg;    // TEMPORARY: progress words (16 chain roles, then the wide workgroups)
+  int64_t off_ts;     // per super-panel 8 time stamps (100 MHz ticks, low 32 bits): see df_stamp
+  const int4* ctasks;   // [2 variants][DF_ROLES][DF_MAXT]
+  const int4* wtasks;
+  int nwtasks;
+  const unsigned* upcnt;   // UP tasks per super-panel
+};
+
+__device__ __forceinline__ unsigned df_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void df_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void df_add(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// up to four (flag >= value) conditions, in fixed slots (compile-time indices keep them in registers); an unused slot
+// points at a word that always satisfies ">= 0"
+// profiling stamps (a.dbg != 0 only): slot k of super-panel j; even k keep the EARLIEST time (stored inverted), odd k the latest
+__device__ __forceinline__ void df_stamp(const DfArgs& a, int j, int k)
+{
+  if(!a.dbg) return;
+  const unsigned now = (unsigned)wall_clock64();
+  unsigned* p = a.flags + a.off_ts + (int64_t)j * 8 + k;
+  if(k & 1) atomicMax(p, now);
+  else atomicMax(p, 0xffffffffu - now);
+}
+
+struct DfWait {
+  const unsigned* f[4];
+  unsigned v[4];
+  __device__ explicit DfWait(const unsigned* always)
+  {
+#pragma unroll
+    for(int q = 0; q < 4; ++q) {
+      f[q] = always;
+      v[q] = 0u;
+    }
+  }
+  template <int Q>
+  __device__ void set(const unsigned* p, unsigned val)
+  {
+    f[Q] = p;
+    v[Q] = val;
+  }
+};
+// workgroup-wide: lane 0 polls every (flag >= value) pair; returns false when the factorisation was aborted.  Bounded by
+// WALL-CLOCK time (s_memrealtime, 100 MHz): DF_TIMEOUT_TICKS after the workgroup's start every wait gives up, raises the
+// abort word (the first one also leaves a diagnostic record in words 2..11: who waited for what) and every other wait
+// returns within a few polls.  The sleep between polls keeps ~500 pollers from saturating the flags' memory channel.
+constexpr long long DF_TIMEOUT_TICKS = 300000000ll;   // 3 s
+__device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* sh_ok, long long t_start, int who, int a0, int a1,
+                                        int a2, int a3)
+{
+  if(threadIdx.x == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+#pragma unroll
+    for(int q = 0; q < 4; ++q) {   // unrolled: the pairs stay in registers (a runtime index would put them in scratch)
+      if(ok) {
+        while(df_ld(w.f[q]) < w.v[q]) {
+          __builtin_amdgcn_s_sleep(16);
+          if((++spins & 31u) == 0) {
+            const bool late = (long long)wall_clock64() - t_start > DF_TIMEOUT_TICKS;
+            if(late || df_ld(flags + DF_ABORT) != 0) {
+              if(late && atomicCAS(flags + DF_ABORT, 0u, 1u) == 0u) {
+                df_st(flags + 2, (unsigned)who);
+                df_st(flags + 3, (unsigned)a0);
+                df_st(flags + 4, (unsigned)a1);
+                df_st(flags + 5, (unsigned)a2);
+                df_st(flags + 6, (unsigned)a3);
+                df_st(flags + 7, (unsigned)q);
+                df_st(flags + 8, w.v[q]);
+                df_st(flags + 9, df_ld(w.f[q]));
+                df_st(flags + 10, (unsigned)(w.f[q] - flags));
+              }
+              ok = 0;
+              break;
+            }
+          }
+        }
+      }
+    }
+    *sh_ok = ok;
+  }
+  __syncthreads();
+  const bool r = __builtin_amdgcn_readfirstlane(*sh_ok) != 0;   // wave-uniform by construction: keep the branch scalar
+  __syncthreads();
+  return r;
+}
+// every wave drains its stores, then the workgroup meets: after this lane 0 may publish
+__device__ __forceinline__ void df_drain()
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+struct DfTile {
+  double* p;
+  int64_t ld;
+};
+// 64 x 64 tile (r, c) of the window of super-panel j: r in 0..7 (4.. = rows of the next diagonal block), c in 0..7
+__device__ __forceinline__ DfTile df_tile(const DfArgs& a, int j, int r, int c)
+{
+  if(r < 4 && c < 4) return DfTile{a.Cd + (int64_t)j * (LD_NB * LD_NB) + (64 * r) * LD_NB + 64 * c, LD_NB};
+  if(r < 4) return DfTile{a.A + ((int64_t)LD_NB * j + 64 * r) * a.lda + (int64_t)LD_NB * (j + 1) + 64 * (c - 4), a.lda};
+  return DfTile{a.Cd + (int64_t)(j + 1) * (LD_NB * LD_NB) + (64 * (r - 4)) * LD_NB + 64 * (c - 4), LD_NB};
+}
+// the same next-diagonal-block tile inside the matrix itself (its first update reads it from there: the wide kernel's
+// updates of earlier super-panels went to the matrix, the compact copy does not exist yet)
+__device__ __forceinline__ DfTile df_tile_in_matrix(const DfArgs& a, int j, int r, int c)
+{
+  return DfTile{a.A + ((int64_t)LD_NB * (j + 1) + 64 * (r - 4)) * a.lda + (int64_t)LD_NB * (j + 1) + 64 * (c - 4), a.lda};
+}
+__device__ __forceinline__ DfTile df_vtile(const DfArgs& a, int j, int p, int c)
+{
+  return DfTile{a.V + (int64_t)(j & 1) * LD_NB * a.ldv + (int64_t)(64 * p) * a.ldv + (int64_t)LD_NB * j + 64 * c, a.ldv};
+}
+// version counter of window tile (r, c) of super-panel j and the value it has before any task of this super-panel touched it
+__device__ __forceinline__ unsigned* df_ver(const DfArgs& a, int j, int r, int c, unsigned* base)
+{
+  unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
+  if(r < 4 && c < 4) {
+    *base = 4u;   // the four updates of the previous super-panel's pivots (pre-credited for j = 0)
+    return cf + DF_CV + r * 4 + c;
+  }
+  *base = 0u;
+  if(r < 4) return cf + DF_HV + r * 4 + (c - 4);
+  return cf + DF_CH + DF_CV + (r - 4) * 4 + (c - 4);
+}
+// trailing-matrix 128-tile that contains window tile (r, c) (for tiles that the wide kernel updates: H and Nn tiles)
+__device__ __forceinline__ const unsigned* df_wide_ver(const DfArgs& a, int j, int r, int c)
+{
+  const int I = 2 * j + (r >> 1), J = 2 * j + (c >> 1);
+  return a.flags + a.off_ver + (int64_t)I * a.nt + J;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// chain tasks (256 threads)
+// ---------------------------------------------------------------------------------------------------------------
+// F(p): tile (p, p) of C_j = U^T D U; emits U (scaled rows) + D into the tile, the compact copy Dk, dinv, the 16x16 inverses
+__device__ __forceinline__ void df_task_factor(const DfArgs& a, int j, int p, double (*S)[LD_nb + 1], double* sdinv, int tid)
+{
+  const DfTile t = df_tile(a, j, p, p);
+  double sv[LD_nb * LD_nb / kBlock];
+#pragma unroll
+  for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+    const int e = tid + q * kBlock;
+    sv[q] = ldg_sc1(t.p + (int64_t)(e >> 6) * t.ld + (e & 63));
+  }
+#pragma unroll
+  for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+    const int e = tid + q * kBlock;
+    const int r = e >> 6, c = e & 63;
+    S[r][c] = (c >= r) ? sv[q] : 0.0;
+  }
+  if(tid < LD_nb) sdinv[tid] = 1.0;
+  __syncthreads();
+  const int k0 = LD_NB * j + 64 * p;
+  double* Li = a.Li + (int64_t)(k0 / LD_nb) * (4 * LD_SB * LD_SB);
+  double* Dk = a.Dblk + (int64_t)(k0 / LD_nb) * (LD_nb * LD_nb);
+  diag_factor_lds<true>(S, sdinv, LD_nb, k0, a.info, Li, tid);
+  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
+    const int r = e >> 6, c = e & 63;
+    double v = S[r][c];
+    if(c > r) v *= sdinv[r];
+    const bool in = c >= r;
+    stg_sc1(Dk + e, in ? v : 0.0);
+    if(in) stg_sc1(t.p + (int64_t)r * t.ld + c, v);
+  }
+  if(tid < LD_nb) stg_sc1(a.dinv + k0 + tid, sdinv[tid]);
+}
+
+// T(p, c): X = tile (p, c): V = L_pp^-1 X (to the V workspace), U = D_p^-1 V (in place).  One wave per 16 columns; the
+// 16-row block substitution with the 16 x 16 inverses on fp64 MFMA (the in-block part of block_row_solve)
+__device__ __forceinline__ void df_task_solve(const DfArgs& a, int j, int p, int c, int tid)
+{
+  const int lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
+  const DfTile x = df_tile(a, j, p, c), vt = df_vtile(a, j, p, c);
+  const int k0 = LD_NB * j + 64 * p;
+  const double* Li = a.Li + (int64_t)(k0 / LD_nb) * (4 * LD_SB * LD_SB);
+  const double* Dk = a.Dblk + (int64_t)(k0 / LD_nb) * (LD_nb * LD_nb);
+  const int cl = 16 * w + li;
+  double4_t t[4];
+  double nl[6][4], iv[4][4], dsc[4][4];
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      t[I][r] = ldg_sc1(x.p + (int64_t)(16 * I + g + 4 * r) * x.ld + cl);
+      dsc[I][r] = ldg_sc1(a.dinv + k0 + 16 * I + g + 4 * r);
+    }
+#pragma unroll
+  for(int I = 1; I < 4; ++I)
+#pragma unroll
+    for(int J = 0; J < I; ++J)
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) nl[I * (I - 1) / 2 + J][kk] = -ldg_sc1(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li);
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) iv[I][kk] = ldg_sc1(Li + I * 256 + li * 16 + 4 * kk + g);
+  double4_t vp[4];
+#pragma unroll
+  for(int I = 0; I < 4; ++I) {
+    double4_t u = t[I];
+#pragma unroll
+    for(int J = 0; J < 4; ++J) {
+      if(J < I) {
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[I * (I - 1) / 2 + J][kk], vp[J][kk], u, 0, 0, 0);
+      }
+    }
+    double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[I][kk], u[kk], v, 0, 0, 0);
+    vp[I] = v;
+  }
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      const int row = 16 * I + g + 4 * r;
+      stg_sc1(vt.p + (int64_t)row * vt.ld + cl, vp[I][r]);
+      stg_sc1(x.p + (int64_t)row * x.ld + cl, vp[I][r] * dsc[I][r]);
+    }
+}
+
+// U(p; ta, tb): tile (ta, tb) -= V(p, ta)^T U(p, tb)  (64 x 64 x 64): 4 waves as 2 x 2, each a 32 x 32 quadrant = 2 x 2
+// MFMA tiles; operands straight from L2 into the MFMA register layout, the k range in two halves of eight k-steps.
+// src != dst for the first update of a next-diagonal-block tile (read from the matrix, written to the compact copy).
+__device__ __forceinline__ void df_task_update(const DfArgs& a, int j, int p, int ta, int tb, const DfTile src, const DfTile dst,
+                                               int tid)
+{
+  const int lane = tid & 63, w = tid >> 6, lk = lane >> 4, li = lane & 15;
+  const int wr = w >> 1, wc = w & 1;
+  const DfTile va = df_vtile(a, j, p, ta), ub = df_tile(a, j, p, tb);
+  double4_t acc[2][2];
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int q = 0; q < 2; ++q) acc[i][q] = double4_t{0.0, 0.0, 0.0, 0.0};
+  double cv[2][2][4];
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int q = 0; q < 2; ++q)
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg)
+        cv[i][q][reg] = ldg_sc1(src.p + (int64_t)(32 * wr + 16 * i + lk + 4 * reg) * src.ld + 32 * wc + 16 * q + li);
+#pragma unroll
+  for(int half = 0; half < 2; ++half) {
+    double av[8][2], bv[8][2];
+#pragma unroll
+    for(int kk = 0; kk < 8; ++kk) {
+      const int k = 32 * half + 4 * kk + lk;
+#pragma unroll
+      for(int i = 0; i < 2; ++i) av[kk][i] = ldg_sc1(va.p + (int64_t)k * va.ld + 32 * wr + 16 * i + li);
+#pragma unroll
+      for(int q = 0; q < 2; ++q) bv[kk][q] = ldg_sc1(ub.p + (int64_t)k * ub.ld + 32 * wc + 16 * q + li);
+    }
+#pragma unroll
+    for(int kk = 0; kk < 8; ++kk)
+#pragma unroll
+      for(int i = 0; i < 2; ++i)
+#pragma unroll
+        for(int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk][i], bv[kk][q], acc[i][q], 0, 0, 0);
+  }
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int q = 0; q < 2; ++q)
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg)
+        stg_sc1(dst.p + (int64_t)(32 * wr + 16 * i + lk + 4 * reg) * dst.ld + 32 * wc + 16 * q + li, cv[i][q][reg] - acc[i][q][reg]);
+}
+
+__global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
+{
+  __shared__ double S[LD_nb][LD_nb + 1];
+  __shared__ double sdinv[LD_nb];
+  __shared__ int sh_ok;
+  const int tid = threadIdx.x, role = blockIdx.x;
+  const long long t_start = (long long)wall_clock64();
+  for(int j = 0; j < a.nchain; ++j) {
+    const bool has_next = (j + 1 < a.nchain) || a.last_has_next;
+    const int4* tasks = a.ctasks + ((has_next ? 0 : 1) * DF_ROLES + role) * DF_MAXT;
+    unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
+    for(int it = 0; it < DF_MAXT; ++it) {
+      int4 tk = tasks[it];
+      tk.x = __builtin_amdgcn_readfirstlane(tk.x);
+      tk.y = __builtin_amdgcn_readfirstlane(tk.y);
+      tk.z = __builtin_amdgcn_readfirstlane(tk.z);
+      tk.w = __builtin_amdgcn_readfirstlane(tk.w);
+      if(tk.x == DF_END) break;
+      const int p = tk.y, ta = tk.z, tb = tk.w;
+      if(a.dbg && tid == 0) df_st(a.flags + a.off_dbg + role, (unsigned)(10000 * j + 100 * it + 10 * tk.x));
+      DfWait w(a.flags + DF_ABORT);
+      unsigned base;
+      if(tk.x == DF_F) {
+        unsigned* v = df_ver(a, j, p, p, &base);
+        w.set<0>(v, base + p);
+        if(!df_wait(a.flags, w, &sh_ok, t_start, 100 + role, j, tk.x, p, p)) return;
+        if(tid == 0 && p == 0) df_stamp(a, j, 0);
+        df_task_factor(a, j, p, S, sdinv, tid);
+        df_drain();
+        if(tid == 0 && p == 3) df_stamp(a, j, 1);
+        if(tid == 0) {
+          df_add(v, 1u);
+          df_add(cf + DF_CDONE, 1u);
+        }
+      } else if(tk.x == DF_T) {
+        const int c = tb;
+        unsigned bpp;
+        unsigned* v = df_ver(a, j, p, c, &base);
+        unsigned* vpp = df_ver(a, j, p, p, &bpp);
+        w.set<0>(vpp, bpp + p + 1);
+        w.set<1>(v, base + p);
+        if(c >= 4 && p == 0) w.set<2>(df_wide_ver(a, j, p, c), (unsigned)j);   // the wide kernel's updates of panels < j
+        // the V workspace of this parity was read by the update of super-panel j-2
+        if(j >= 2) w.set<3>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
+        if(!df_wait(a.flags, w, &sh_ok, t_start, 100 + role, j, tk.x, p, c)) return;
+        df_task_solve(a, j, p, c, tid);
+        df_drain();
+        if(tid == 0 && c >= 4) df_stamp(a, j, 3);
+        if(tid == 0) {
+          df_add(v, 1u);
+          df_add(cf + (c < 4 ? DF_CDONE : DF_HDONE), 1u);
+        }
+      } else {
+        unsigned ba, bb;
+        unsigned* v = df_ver(a, j, ta, tb, &base);
+        unsigned* va = df_ver(a, j, p, ta, &ba);
+        unsigned* vb = df_ver(a, j, p, tb, &bb);
+        w.set<0>(va, ba + p + 1);
+        w.set<1>(vb, bb + p + 1);
+        w.set<2>(v, base + p);
+        const bool wide_tile = tb >= 4;   // H tiles and next-diagonal-block tiles also receive the wide kernel's updates
+        if(wide_tile && p == 0) w.set<3>(df_wide_ver(a, j, ta, tb), (unsigned)j);
+        if(!df_wait(a.flags, w, &sh_ok, t_start, 100 + role, j, 1000 * p + tk.x, ta, tb)) return;
+        const DfTile dst = df_tile(a, j, ta, tb);
+        const DfTile src = (ta >= 4 && p == 0) ? df_tile_in_matrix(a, j, ta, tb) : dst;
+        df_task_update(a, j, p, ta, tb, src, dst, tid);
+        df_drain();
+        if(tid == 0) df_add(v, 1u);
+      }
+    }
+  }
+  if(a.dbg && tid == 0) df_st(a.flags + a.off_dbg + role, 99999999u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wide tasks (256 threads, LDS buffer shared by the two task kinds)
+// ---------------------------------------------------------------------------------------------------------------
+// TR(j, c16): 16 columns starting at c16 of the tail of row panel j.  FOUR waves: wave I owns the 16-row sub-block I of
+// every 64-row block row (algorithm of ldlt_headtrsm_kernel); every shared operand through sc1 loads.
+__device__ __forceinline__ void df_task_trsm(const DfArgs& a, int j, int c16, double* smem, int tid)
+{
+  double(*Vs)[LD_SB + 1] = reinterpret_cast<double(*)[LD_SB + 1]>(smem);   // 256 x 17
+  const int lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int I = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K0 = LD_NB * j;
+  const int64_t col = (int64_t)c16 + li;
+  const bool col_ok = col < a.N;
+  const int64_t colc = col_ok ? col : (int64_t)(a.N - 1);
+  double* Vb = a.V + (int64_t)(j & 1) * LD_NB * a.ldv;
+  const double* Cd = a.Cd + (int64_t)j * (LD_NB * LD_NB);
+  const double* Dk_sp = a.Dblk + (int64_t)(K0 / LD_nb) * (LD_nb * LD_nb);
+  const double* Li_sp = a.Li + (int64_t)(K0 / LD_nb) * (4 * LD_SB * LD_SB);
+  double4_t t[4];
+#pragma unroll
+  for(int P = 0; P < 4; ++P)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      const double v = ldg_sc1(a.A + (int64_t)(K0 + 64 * P + 16 * I + g + 4 * r) * a.lda + colc);
+      t[P][r] = col_ok ? v : 0.0;
+    }
+  __syncthreads();   // the LDS buffer may still be read by the previous task's waves
+#pragma unroll
+  for(int P = 0; P < 4; ++P) {
+    const double* Dk = Dk_sp + P * (LD_nb * LD_nb);
+    const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
+    double nl[3][4], iv[4];
+#pragma unroll
+    for(int J = 0; J < 3; ++J)
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) nl[J][kk] = (J < I) ? -ldg_sc1(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li) : 0.0;
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) iv[kk] = ldg_sc1(Li + I * 256 + li * 16 + 4 * kk + g);
+    double4_t u = t[P];
+#pragma unroll
+    for(int q = 0; q < P; ++q) {
+      double Lop[4][4];
+#pragma unroll
+      for(int Jq = 0; Jq < 4; ++Jq)
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) Lop[Jq][kk] = -ldg_sc1(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (64 * P + 16 * I + li));
+#pragma unroll
+      for(int Jq = 0; Jq < 4; ++Jq)
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk)
+          u = __builtin_amdgcn_mfma_f64_16x16x4f64(Lop[Jq][kk], Vs[64 * q + 16 * Jq + 4 * kk + g][li], u, 0, 0, 0);
+    }
+#pragma unroll
+    for(int J = 0; J < 4; ++J) {
+      if(I == J) {   // wave-uniform
+        double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[kk], u[kk], v, 0, 0, 0);
+#pragma unroll
+        for(int r = 0; r < 4; ++r) {
+          const int row = 64 * P + 16 * I + g + 4 * r;
+          Vs[row][li] = v[r];
+          if(col_ok) {
+            stg_sc1(Vb + (int64_t)row * a.ldv + col, v[r]);
+            stg_sc1(a.A + (int64_t)(K0 + row) * a.lda + col, v[r] * ldg_sc1(a.dinv + K0 + row));
+          }
+        }
+      }
+      __syncthreads();
+      if(I > J && J < 3) {
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk)
+          u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[J][kk], Vs[64 * P + 16 * J + 4 * kk + g][li], u, 0, 0, 0);
+      }
+    }
+  }
+}
+
+// UP(j, I, J): the 128 x 128 tile (I, J) of the trailing matrix -= V_j[:, rows of I]^T U_j[:, columns of J], K = 256.
+// The main loop of ldlt_update_db_kernel (double-buffered LDS stages of 16 k-rows, one barrier per stage, operand reads
+// of the next k-step under the MFMAs of the current one); operand and C-tile traffic through sc1 loads / stores.
+__device__ __forceinline__ void df_task_tile(const DfArgs& a, int j, int I, int J, double* smem, int tid)
+{
+  double(*Vs)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem);
+  double(*Us)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem + 2 * UD_KT * UD_LD);
+  const int N = a.N;
+  const int r0 = UD_T * I, c0 = UD_T * J;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lk = lane >> 4, li = lane & 15;
+  const double* V = a.V + (int64_t)(j & 1) * LD_NB * a.ldv;
+  const int urow0 = LD_NB * j;
+  double4_t acc[4][4];
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int q = 0; q < 4; ++q) acc[i][q] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int lcol = tid & 127, lrow = tid >> 7;
+  const bool vr_ok = (r0 + lcol) < N;
+  const bool uc_ok = (c0 + lcol) < N;
+  const double* Vp = V + (int64_t)lrow * a.ldv + (vr_ok ? (r0 + lcol) : 0);
+  const double* Up = a.A + (int64_t)(urow0 + lrow) * a.lda + (uc_ok ? (c0 + lcol) : 0);
+  double vreg[8], ureg[8];
+  constexpr int nst = LD_NB / UD_KT;
+  auto gload = [&](int st) {
+#pragma unroll
+    for(int q = 0; q < 8; ++q) {
+      const int k = st * UD_KT + 2 * q;
+      const double v = ldg_sc1(Vp + (int64_t)k * a.ldv);
+      const double u = ldg_sc1(Up + (int64_t)k * a.lda);
+      vreg[q] = vr_ok ? v : 0.0;
+      ureg[q] = uc_ok ? u : 0.0;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for(int q = 0; q < 8; ++q) {
+      Vs[buf][2 * q + lrow][lcol] = vreg[q];
+      Us[buf][2 * q + lrow][lcol] = ureg[q];
+    }
+  };
+  gload(0);
+  __syncthreads();   // the LDS buffer may still be read by the previous task's waves
+  lstore(0);
+  gload(1);
+  __syncthreads();
+  const int arow = wr * 64 + li, bcol = wc * 64 + li;
+  for(int st = 0; st < nst; ++st) {
+    const int cur = st & 1;
+    double av[2][4], bv[2][4];
+#pragma unroll
+    for(int i = 0; i < 4; ++i) av[0][i] = Vs[cur][lk][arow + 16 * i];
+#pragma unroll
+    for(int q = 0; q < 4; ++q) bv[0][q] = Us[cur][lk][bcol + 16 * q];
+#pragma unroll
+    for(int kk = 0; kk < UD_KT / 4; ++kk) {
+      const int pb = kk & 1;
+      if(kk + 1 < UD_KT / 4) {
+#pragma unroll
+        for(int i = 0; i < 4; ++i) av[pb ^ 1][i] = Vs[cur][4 * (kk + 1) + lk][arow + 16 * i];
+#pragma unroll
+        for(int q = 0; q < 4; ++q) bv[pb ^ 1][q] = Us[cur][4 * (kk + 1) + lk][bcol + 16 * q];
+      }
+      if(kk == 1 && st + 1 < nst) lstore(cur ^ 1);
+      if(kk == 2 && st + 2 < nst) gload(st + 2);
+#pragma unroll
+      for(int i = 0; i < 4; ++i)
+#pragma unroll
+        for(int q = 0; q < 4; ++q) acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb][i], bv[pb][q], acc[i][q], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // epilogue: C -= acc on the upper triangle, one 16-row group of the wave at a time (16 loads in flight, then 16 stores;
+  // the other workgroup of the CU computes meanwhile)
+#pragma unroll
+  for(int i = 0; i < 4; ++i) {
+    double cv[4][4];
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
+      const double* Crow = a.A + (int64_t)(row < N ? row : (N - 1)) * a.lda;
+#pragma unroll
+      for(int q = 0; q < 4; ++q) {
+        const int col = c0 + wc * 64 + q * 16 + li;
+        cv[reg][q] = ldg_sc1(Crow + (col < N ? col : (N - 1)));
+      }
+    }
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
+      double* Crow = a.A + (int64_t)row * a.lda;
+#pragma unroll
+      for(int q = 0; q < 4; ++q) {
+        const int col = c0 + wc * 64 + q * 16 + li;
+        if(row < N && col < N && col >= row) stg_sc1(Crow + col, cv[reg][q] - acc[i][q][reg]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock, 2) void ldlt_wide_kernel(const DfArgs a)
+{
+  __shared__ double smem[4 * UD_KT * UD_LD];   // 73,728 B: the update's two double-buffered operand tiles / the substitution's V
+  __shared__ int sh_t, sh_ok;
+  const int tid = threadIdx.x;
+  const long long t_start = (long long)wall_clock64();
+  for(;;) {
+    if(tid == 0) sh_t = (int)__hip_atomic_fetch_add(a.flags + DF_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(sh_t);
+    __syncthreads();
+    unsigned* dbgw = a.flags + a.off_dbg + 16 + blockIdx.x;
+    if(t >= a.nwtasks) {
+      if(a.dbg && tid == 0) df_st(dbgw, 99999999u);
+      return;
+    }
+    if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 1));
+    int4 tk = a.wtasks[t];
+    tk.x = __builtin_amdgcn_readfirstlane(tk.x);
+    tk.y = __builtin_amdgcn_readfirstlane(tk.y);
+    tk.z = __builtin_amdgcn_readfirstlane(tk.z);
+    tk.w = __builtin_amdgcn_readfirstlane(tk.w);
+    const int j = tk.y;
+    unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
+    unsigned* trj = a.flags + a.off_tr + (int64_t)j * a.nt;
+    DfWait w(a.flags + DF_ABORT);   // (the ticket word is busy: the abort word is 0 = "always >= 0")
+    if(tk.x == DF_TR) {
+      const int c16 = tk.z, J = c16 / UD_T;
+      w.set<0>(cf + DF_CDONE, 10u);                                                   // C_j factored (chain kernel)
+      w.set<1>(a.flags + a.off_ver + (int64_t)(2 * j) * a.nt + J, (unsigned)j);       // rows of panel j updated through panel j-1
+      w.set<2>(a.flags + a.off_ver + (int64_t)(2 * j + 1) * a.nt + J, (unsigned)j);
+      if(j >= 2) w.set<3>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);   // V workspace parity
+      if(!df_wait(a.flags, w, &sh_ok, t_start, 1, t, j, c16, J)) {
+        if(a.dbg && tid == 0) df_st(dbgw, 88888888u);
+        return;
+      }
+      if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 2));
+      if(tid == 0) df_stamp(a, j, 4);
+      if(a.dbg != 4) df_task_trsm(a, j, c16, smem, tid);
+      if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 3));
+      df_drain();
+      if(tid == 0) df_add(trj + J, 1u);
+      if(tid == 0) df_stamp(a, j, 5);
+      if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 4));
+    } else {
+      const int I = tk.z, J = tk.w;
+      auto groups = [&](int B) {   // 16-column groups of 128-block B inside the matrix
+        const int rem = a.N - UD_T * B;
+        return (unsigned)((rem >= UD_T) ? 8 : (rem + 15) / 16);
+      };
+      w.set<0>(a.flags + a.off_ver + (int64_t)I * a.nt + J, (unsigned)j);             // this tile updated through panel j-1
+      if(I < 2 * j + 4) w.set<1>(cf + DF_HDONE, 16u);                                 // rows in the head: V from the chain kernel
+      else w.set<1>(trj + I, groups(I));
+      w.set<2>(trj + J, groups(J));
+      if(!df_wait(a.flags, w, &sh_ok, t_start, 2, t, j, I, J)) {
+        if(a.dbg && tid == 0) df_st(dbgw, 88888888u);
+        return;
+      }
+      if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 2));
+      if(tid == 0) df_stamp(a, j, 6);
+      if(a.dbg != 5) df_task_tile(a, j, I, J, smem, tid);
+      df_drain();
+      if(tid == 0) {
+        df_st(a.flags + a.off_ver + (int64_t)I * a.nt + J, (unsigned)(j + 1));
+        df_add(cf + DF_UPDONE, 1u);
+        df_stamp(a, j, 7);
+      }
+    }
+  }
+}
+
+// compact copy of diagonal block 0 + the pre-credits of super-panel 0's tile versions
+__global__ __launch_bounds__(kBlock) void ldlt_df_init_kernel(const DfArgs a)
+{
+  if(blockIdx.x == 0 && threadIdx.x < 16) a.flags[a.off_chain + DF_CV + threadIdx.x] = 4u;
+}

@@ -52,6 +52,10 @@ class LinSolverSymDense:
         check(rc, "hiopamd_linsolver_solve")
         return True
 
+    def set_dataflow(self, enable: bool):
+        """dataflow factorisation (two persistent kernels) on / off (off = the stepwise kernels)."""
+        check(self._L.hiopamd_linsolver_set_dataflow(self.h, 1 if enable else 0), "hiopamd_linsolver_set_dataflow")
+
     def inertia(self):
         p, n, z = C.c_int(), C.c_int(), C.c_int()
         check(self._L.hiopamd_linsolver_inertia(self.h, C.byref(p), C.byref(n), C.byref(z)), "inertia")

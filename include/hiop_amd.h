@@ -292,6 +292,12 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs);
 int hiopamd_linsolver_inertia(const hiopamd_linsolver* ls, int* pos_host, int* neg_host, int* zero_host);
 /* hiopLinSolStats::flopsFact / flopsTriuSolves (src/Utils/hiopRunStats.hpp:262-270), cumulative over the object's life:
  * n^3/3 per matrixChanged, 2 n^2 per right-hand side; the times are the HIOPAMD_SPAN_LINSOLV_* spans of the context */
+/* The factorisation runs as a dataflow of two persistent kernels (csrc/ldlt_dataflow.hpp) when the CU-masked streams are
+ * available and n >= 768; enable = 0 selects the stepwise kernels (one launch per super-panel step) — same results to
+ * rounding, for A/B timing and as a fallback.  HIOPAMD_DF=0 in the environment sets the default off. */
+int hiopamd_linsolver_set_dataflow(hiopamd_linsolver* ls, int enable);
+/* static schedule of the dataflow factorisation for order n (host only): see csrc/ldlt.hip */
+int hiopamd_ldlt_dataflow_plan(int n, int* dims8_host, int* chain_tasks_host, int* wide_tasks_host, int64_t wide_cap);
 int hiopamd_linsolver_flops(const hiopamd_linsolver* ls, double* flops_fact_host, double* flops_triu_solves_host);
 /* per-launch HIP-event timing of the MFMA rank-K update kernel (bench / roofline only; off by default).
  * read: accumulated kernel milliseconds, algorithmic flops (2*K per updated element) and launch count

@@ -72,6 +72,42 @@ def test_ldlt_factor_matches_unblocked_recurrence(ctx, n1, n2):
     ls.close()
 
 
+@pytest.mark.parametrize("n", [768, 1024, 1124, 1280, 2049, 4096])
+def test_dataflow_factorisation_equals_stepwise(ctx, n):
+    """The factorisation as two persistent dataflow kernels (csrc/ldlt_dataflow.hpp) against the stepwise kernels on the
+    same matrix: same inertia, factors equal to rounding (the tile products are summed in a different grouping), the
+    unblocked recurrence to 1e-9, and repeatable (flags are re-initialised by every call)."""
+    from hiop_amd.kkt import LinSolverSymDense
+    n1 = (2 * n) // 3
+    A = quasi_definite(n1, n - n1, n)
+    ls = LinSolverSymDense(ctx, n)
+    Mu = D(np.triu(A))
+    out = {}
+    for mode in (True, False, True):
+        ls.set_dataflow(mode)
+        ls.set_sys_matrix(Mu)
+        assert ls.matrix_changed() == n - n1
+        Fm = ls.get_sys_matrix().cpu().numpy()
+        out.setdefault(mode, []).append(np.triu(Fm))
+    a, b = out[True]
+    assert np.array_equal(a, b)                      # run-to-run reproducible: fixed summation order inside every tile
+    s = out[False][0]
+    assert np.abs(a - s).max() <= 1e-11 * np.abs(s).max()
+    U, d = ho.ldlt_nopiv(A)
+    np.testing.assert_allclose(np.diag(a), d, rtol=1e-9)
+    np.testing.assert_allclose(np.triu(a, 1), np.triu(U, 1), rtol=1e-8, atol=1e-11)
+    # and the dataflow solve on top of it
+    r = rng(4)
+    B = r.uniform(-1, 1, n)
+    Bd = D(B)
+    torch.cuda.synchronize()
+    ls.solve(Bd, 1)
+    ctx.sync()
+    X = Bd.cpu().numpy()
+    assert np.abs(A @ X - B).max() / (np.abs(A).max() * np.abs(X).max()) < 1e-12
+    ls.close()
+
+
 def test_ldlt_full_size_property(ctx):
     """N=8192 (BASELINE config 3 size): residual + inertia properties, no O(N^3) host work."""
     from hiop_amd.kkt import LinSolverSymDense

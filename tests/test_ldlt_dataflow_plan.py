@@ -1,0 +1,330 @@
+"""CPU check of the static schedule of the dataflow LDL^T (csrc/ldlt_dataflow.hpp) — no GPU needed.
+
+`hiopamd_ldlt_dataflow_plan` (host-only entry point of libhiopamd.so) returns the task tables the two persistent kernels
+execute: the chain kernel's per-role lists of F / T / U tile tasks and the wide kernel's ticket-ordered TR / UP list.  This
+test replays them with numpy under the SAME flag protocol the kernels use (tile version counters, cdone / hdone / updone,
+tr[j][J], ver[I][J]; every task may only start when its wait conditions hold) with the 16 chain roles and W wide workers
+advancing in an arbitrary (seeded, adversarial) interleaving, and checks
+  * liveness: every task completes — no role or worker waits forever, for several worker counts (1 .. 64) and orders;
+  * soundness: the factor that comes out equals the unblocked U^T D U recurrence of the same matrix to 1e-10 — i.e. every
+    task saw exactly the operands the algorithm needs (a missing wait shows up as a wrong factor under some interleaving);
+  * the ragged case (N not a multiple of 256) hands over to the stepwise path with a consistent state.
+reference semantics: the no-pivot factorisation of hiopLinSolverSymDenseMagmaNopiv (src/LinAlg/hiopLinSolverSymDenseMagma.cpp:324-480)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+F, T, U, END = 1, 2, 3, 0
+TR, UP = 1, 2
+
+
+def get_plan(n):
+    from hiop_amd._lib import lib
+    L = lib()
+    dims = (C.c_int * 8)()
+    assert L.hiopamd_ldlt_dataflow_plan(n, dims, None, None, 0) == 0
+    nsp, nt, nchain, last_has_next, nwide, roles, maxt, nw = list(dims)
+    ct = (C.c_int * (2 * roles * maxt * 4))()
+    wt = (C.c_int * (4 * max(nw, 1)))()
+    assert L.hiopamd_ldlt_dataflow_plan(n, dims, ct, wt, nw) == 0
+    ct = np.array(ct, dtype=np.int64).reshape(2, roles, maxt, 4)
+    wt = np.array(wt, dtype=np.int64).reshape(-1, 4)[:nw]
+    return dict(nsp=nsp, nt=nt, nchain=nchain, last_has_next=last_has_next, nwide=nwide, roles=roles, ctasks=ct, wtasks=wt)
+
+
+def ldl_nopiv(A):
+    """unblocked A = U^T D U (upper, unit diagonal): the recurrence the tests of the GPU factor compare against."""
+    n = A.shape[0]
+    S = np.triu(A).copy()
+    for k in range(n):
+        d = S[k, k]
+        u = S[k, k + 1:] / d
+        S[k + 1:, k + 1:] -= np.triu(np.outer(S[k, k + 1:], u))
+        S[k, k + 1:] = u
+    return S
+
+
+class Sim:
+    """numpy model of the two kernels.  The matrix is kept as one N x N array (upper part significant); the compact
+    diagonal blocks are modelled by a per-block 'compact' copy exactly where the kernels use one."""
+
+    def __init__(self, A, plan):
+        self.N = A.shape[0]
+        self.P = plan
+        self.A = np.triu(A).copy()                 # trailing matrix + H tiles + U of the tails
+        nsp = plan["nsp"]
+        self.Cd = {0: self.A[:256, :256].copy()}   # compact copies: block 0 packed up front, others created by Nn updates
+        self.V = {}                                # (j, p, c) -> un-scaled 64 x 64 tile ; ("tail", j) -> 256 x N rows
+        self.dinv = np.zeros(self.N)
+        self.cv = np.zeros((nsp + 1, 4, 4), dtype=int)
+        self.cv[0] = 4
+        self.hv = np.zeros((nsp + 1, 4, 4), dtype=int)
+        self.cdone = np.zeros(nsp + 1, dtype=int)
+        self.hdone = np.zeros(nsp + 1, dtype=int)
+        self.updone = np.zeros(nsp + 1, dtype=int)
+        nt = plan["nt"]
+        self.tr = np.zeros((nsp + 1, nt), dtype=int)
+        self.ver = np.zeros((nt, nt), dtype=int)
+        self.upcnt = np.zeros(nsp + 1, dtype=int)
+        for t in plan["wtasks"]:
+            if t[0] == UP:
+                self.upcnt[t[1]] += 1
+        self.Vtail = {}
+
+    # ---- tile access (window of super-panel j)
+    def tile_ref(self, j, r, c):
+        if r < 4 and c < 4:
+            return self.Cd[j], 64 * r, 64 * c
+        if r < 4:
+            return self.A, 256 * j + 64 * r, 256 * (j + 1) + 64 * (c - 4)
+        return self.Cd.setdefault(j + 1, np.zeros((256, 256))), 64 * (r - 4), 64 * (c - 4)
+
+    def get(self, j, r, c):
+        M, a, b = self.tile_ref(j, r, c)
+        return M[a:a + 64, b:b + 64]
+
+    def ver_of(self, j, r, c):
+        if r < 4 and c < 4:
+            return self.cv[j], (r, c), 4
+        if r < 4:
+            return self.hv[j], (r, c - 4), 0
+        return self.cv[j + 1], (r - 4, c - 4), 0
+
+    def wide_ver(self, j, r, c):
+        return self.ver[2 * j + r // 2, 2 * j + c // 2]
+
+    # ---- chain tasks: ready? / run
+    def chain_ready(self, j, tk):
+        ty, p, a, b = tk
+        if ty == F:
+            arr, ix, base = self.ver_of(j, p, p)
+            return arr[ix] >= base + p
+        if ty == T:
+            c = b
+            arr, ix, base = self.ver_of(j, p, c)
+            app, ipp, bpp = self.ver_of(j, p, p)
+            ok = app[ipp] >= bpp + p + 1 and arr[ix] >= base + p
+            if c >= 4 and p == 0:
+                ok = ok and self.wide_ver(j, p, c) >= j
+            if j >= 2:
+                ok = ok and self.updone[j - 2] >= self.upcnt[j - 2]
+            return ok
+        arr, ix, base = self.ver_of(j, a, b)
+        aa, ia, ba = self.ver_of(j, p, a)
+        ab, ib, bb = self.ver_of(j, p, b)
+        ok = aa[ia] >= ba + p + 1 and ab[ib] >= bb + p + 1 and arr[ix] >= base + p
+        if b >= 4 and p == 0:
+            ok = ok and self.wide_ver(j, a, b) >= j
+        return ok
+
+    def chain_run(self, j, tk):
+        ty, p, a, b = tk
+        k0 = 256 * j + 64 * p
+        if ty == F:
+            t = self.get(j, p, p)
+            S = ldl_nopiv(t)
+            t[:] = np.triu(S)
+            self.dinv[k0:k0 + 64] = 1.0 / np.diag(S)
+            arr, ix, _ = self.ver_of(j, p, p)
+            arr[ix] += 1
+            self.cdone[j] += 1
+        elif ty == T:
+            c = b
+            Upp = self.get(j, p, p)
+            Lpp = np.triu(Upp, 1).T + np.eye(64)             # unit lower
+            x = self.get(j, p, c)
+            v = np.linalg.solve(Lpp, x)
+            self.V[(j, p, c)] = v.copy()
+            x[:] = v * self.dinv[k0:k0 + 64][:, None]
+            arr, ix, _ = self.ver_of(j, p, c)
+            arr[ix] += 1
+            if c < 4:
+                self.cdone[j] += 1
+            else:
+                self.hdone[j] += 1
+        else:
+            va = self.V[(j, p, a)]
+            ub = self.get(j, p, b)
+            if a >= 4 and p == 0:      # first update of a next-diagonal-block tile: read from the matrix, write the compact copy
+                r0 = 256 * (j + 1) + 64 * (a - 4)
+                c0 = 256 * (j + 1) + 64 * (b - 4)
+                src = self.A[r0:r0 + 64, c0:c0 + 64]
+            else:
+                src = self.get(j, a, b)
+            res = src - va.T @ ub
+            self.get(j, a, b)[:] = res
+            arr, ix, _ = self.ver_of(j, a, b)
+            arr[ix] += 1
+
+    # ---- wide tasks
+    def groups(self, B):
+        rem = self.N - 128 * B
+        return 8 if rem >= 128 else (rem + 15) // 16
+
+    def wide_ready(self, tk):
+        ty, j, x, y = tk
+        if ty == TR:
+            J = x // 128
+            ok = self.cdone[j] >= 10 and self.ver[2 * j, J] >= j and self.ver[2 * j + 1, J] >= j
+            if j >= 2:
+                ok = ok and self.updone[j - 2] >= self.upcnt[j - 2]
+            return ok
+        I, J = x, y
+        ok = self.ver[I, J] >= j
+        ok = ok and (self.hdone[j] >= 16 if I < 2 * j + 4 else self.tr[j, I] >= self.groups(I))
+        return ok and self.tr[j, J] >= self.groups(J)
+
+    def wide_run(self, tk):
+        ty, j, x, y = tk
+        N = self.N
+        K0 = 256 * j
+        if ty == TR:
+            c0, c1 = x, min(N, x + 16)
+            Ujj = self.Cd[j]
+            L = np.triu(Ujj, 1).T + np.eye(256)
+            blk = self.A[K0:K0 + 256, c0:c1]
+            v = np.linalg.solve(L, blk)
+            self.Vtail.setdefault(j, np.zeros((256, N)))[:, c0:c1] = v
+            blk[:] = v * self.dinv[K0:K0 + 256][:, None]
+            self.tr[j, x // 128] += 1
+            return
+        I, J = x, y
+        r0, r1 = 128 * I, min(N, 128 * I + 128)
+        c0, c1 = 128 * J, min(N, 128 * J + 128)
+        s = 256 * (j + 1)
+        if I < 2 * j + 4:      # rows in the head: V from the chain's T tasks on H tiles
+            Vr = np.zeros((256, r1 - r0))
+            for p in range(4):
+                for q in range(4):
+                    cc0 = s + 64 * q
+                    lo, hi = max(cc0, r0), min(cc0 + 64, r1)
+                    if lo < hi:
+                        Vr[64 * p:64 * p + 64, lo - r0:hi - r0] = self.V[(j, p, 4 + q)][:, lo - cc0:hi - cc0]
+        else:
+            Vr = self.Vtail[j][:, r0:r1]
+        Uc = self.A[K0:K0 + 256, c0:c1]
+        upd = Vr.T @ Uc
+        blk = self.A[r0:r1, c0:c1]
+        if I == J:
+            blk -= np.triu(upd)
+        else:
+            blk -= upd
+        self.ver[I, J] = j + 1
+        self.updone[j] += 1
+
+
+def replay(A, plan, n_workers, seed):
+    rnd = random.Random(seed)
+    sim = Sim(A, plan)
+    roles = plan["roles"]
+    nchain = plan["nchain"]
+    # chain role cursors: (j, index in list)
+    cur = [[0, 0] for _ in range(roles)]
+
+    def role_task(r):
+        while cur[r][0] < nchain:
+            j, it = cur[r]
+            has_next = (j + 1 < nchain) or bool(plan["last_has_next"])
+            lst = plan["ctasks"][0 if has_next else 1][r]
+            if it < len(lst) and lst[it][0] != END:
+                return j, tuple(int(v) for v in lst[it])
+            cur[r] = [j + 1, 0]
+        return None
+
+    wt = [tuple(int(v) for v in t) for t in plan["wtasks"]]
+    next_ticket = 0
+    held = [None] * n_workers   # ticket held by each wide worker
+    done_w = 0
+    while True:
+        agents = []
+        for r in range(roles):
+            t = role_task(r)
+            if t is not None:
+                agents.append(("c", r, t))
+        for w in range(n_workers):
+            if held[w] is None and next_ticket < len(wt):
+                held[w] = next_ticket
+                next_ticket += 1
+            if held[w] is not None:
+                agents.append(("w", w, held[w]))
+        if not agents:
+            break
+        rnd.shuffle(agents)
+        progressed = False
+        for kind, who, t in agents:
+            if kind == "c":
+                j, tk = t
+                if sim.chain_ready(j, tk):
+                    sim.chain_run(j, tk)
+                    cur[who][1] += 1
+                    progressed = True
+                    break            # one step, then re-shuffle: many different interleavings
+            else:
+                if sim.wide_ready(wt[t]):
+                    sim.wide_run(wt[t])
+                    held[who] = None
+                    done_w += 1
+                    progressed = True
+                    break
+        assert progressed, f"deadlock: chain cursors {cur}, tickets held {held}, next {next_ticket}/{len(wt)}"
+    assert done_w == len(wt)
+    return sim
+
+
+def quasi_definite(n, seed):
+    r = np.random.Generator(np.random.PCG64(seed))
+    m = n // 2
+    G = r.uniform(-1, 1, (n, n)) * 0.02
+    A = G + G.T
+    d = np.concatenate([r.uniform(2, 4, m), -r.uniform(2, 4, n - m)])   # [H  J^T; J  -D] flavour: quasi-definite
+    return A + np.diag(d)
+
+
+@pytest.mark.parametrize("n,workers,seed", [(1024, 1, 0), (1024, 7, 1), (1280, 64, 2), (768, 3, 3)])
+def test_schedule_is_live_and_sound(n, workers, seed):
+    plan = get_plan(n)
+    assert plan["nchain"] == n // 256 and plan["last_has_next"] == 0
+    A = quasi_definite(n, seed)
+    sim = replay(A, plan, workers, seed)
+    want = ldl_nopiv(A)
+    got = np.triu(sim.A)
+    for j in range(plan["nsp"]):      # the factored diagonal blocks live in the compact copies
+        got[256 * j:256 * j + 256, 256 * j:256 * j + 256] = np.triu(sim.Cd[j])
+    assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+
+
+def test_ragged_order_hands_over_a_consistent_state():
+    n = 1024 + 100
+    plan = get_plan(n)
+    assert plan["nchain"] == 3 and plan["last_has_next"] == 1 and plan["nwide"] == 3
+    A = quasi_definite(n, 5)
+    sim = replay(A, plan, 5, 5)
+    want = ldl_nopiv(A)
+    s = 256 * plan["nchain"]
+    got = np.triu(sim.A)
+    for j in range(plan["nchain"]):
+        got[256 * j:256 * j + 256, 256 * j:256 * j + 256] = np.triu(sim.Cd[j])
+    # rows of the chained super-panels are final
+    assert np.abs(got[:s] - want[:s]).max() < 1e-10 * np.abs(want).max()
+    # what is left for the stepwise kernels: the trailing matrix with every update of the chained panels applied
+    # (its leading 256 x 256 block is the compact copy of super-panel nchain); finishing it reproduces the factor
+    rest = got[s:, s:].copy()
+    rest[:256, :256] = np.triu(sim.Cd[plan["nchain"]])
+    fin = ldl_nopiv(rest)
+    assert np.abs(fin - want[s:, s:]).max() < 1e-10 * np.abs(want).max()
+
+
+def test_plan_shapes():
+    p = get_plan(8192)
+    assert p["nsp"] == 32 and p["nt"] == 64 and p["nchain"] == 32 and p["nwide"] == 31
+    ups = [t for t in p["wtasks"] if t[0] == UP]
+    assert len(ups) == sum(t * (t + 1) // 2 - 3 for t in range(62, 0, -2))   # tiles of 31 trailing updates minus the skipped diagonal blocks
+    # ticket order is topological for the TR -> UP dependency: every UP(j, I, J) comes after all TR(j, .) of its column blocks
+    seen_tr = set()
+    for ty, j, x, y in p["wtasks"]:
+        if ty == TR:
+            seen_tr.add((j, x // 128))
+        else:
+            assert (j, y) in seen_tr and (x < 2 * j + 4 or (j, x) in seen_tr)
