@@ -254,7 +254,7 @@ __device__ __forceinline__ double ld_batch(const double* p)
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-template <int P, bool IDENT = false>
+template <int P, bool IDENT = false, bool SC1 = false>
 __device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, int K0, int kbs, int64_t col, bool col_ok,
                                                 const double* Cd /* compact diagonal block, ld = LD_NB */,
                                                 const double* Dk_sp, const double* Li_sp, double4_t (&Vv)[4][4], int g,
@@ -271,7 +271,8 @@ __device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, in
         t[I][r] = (row == (int)col && row < kbs) ? 1.0 : 0.0;
       } else {
         const int rowc = (row < kbs) ? row : (kbs - 1);
-        const double v = ld_batch(A + (int64_t)(K0 + rowc) * lda + col);
+        // SC1: the rows were written by other workgroups of the same launch (dataflow factorisation) -> bypass L1
+        const double v = SC1 ? ldg_sc1(A + (int64_t)(K0 + rowc) * lda + col) : ld_batch(A + (int64_t)(K0 + rowc) * lda + col);
         t[I][r] = (col_ok & (row < kbs)) ? v : 0.0;
       }
     }
@@ -329,7 +330,7 @@ __device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, in
 }
 
 // store block-row P of V (un-scaled, workspace rows 64P..) and U = D^-1 V (in place)
-template <int P>
+template <int P, bool SC1 = false>
 __device__ __forceinline__ void block_row_store(double* A, int64_t lda, double* V, int64_t ldv, int K0, int kbs, int64_t col,
                                                 bool col_ok, const double* dinv_sp /*256 entries of this super-panel*/,
                                                 const double4_t (&Vv)[4][4], int g, int li)
@@ -343,8 +344,13 @@ __device__ __forceinline__ void block_row_store(double* A, int64_t lda, double* 
         const double v = Vv[P][I][r];
         const double u = v * dinv_sp[row];
         if(col_ok) {
-          V[(int64_t)row * ldv + col] = v;
-          A[(int64_t)(K0 + row) * lda + col] = u;
+          if constexpr(SC1) {
+            stg_sc1(V + (int64_t)row * ldv + col, v);
+            stg_sc1(A + (int64_t)(K0 + row) * lda + col, u);
+          } else {
+            V[(int64_t)row * ldv + col] = v;
+            A[(int64_t)(K0 + row) * lda + col] = u;
+          }
         }
       }
     }
@@ -777,183 +783,21 @@ __global__ __launch_bounds__(64) void ldlt_inv_diag_kernel(int N, const double* 
 }
 
 // ------------------------------------------------------------------------------------------
-// rank-K trailing update on fp64 MFMA (the dominant kernel of the factorisation):
-//     A[r][c] -= sum_{k<K} V[vrow0+k][r] * A[urow0+k][c]      r in [s, row_end), c in [max(r, s), col_end), upper triangle
-// One workgroup = one 128 x 128 tile = 4 wave64 of 64 x 64 (4 x 4 tiles of v_mfma_f64_16x16x4_f64, 16 f64x4 accumulators
-// per wave): the shape the vendor DGEMM sustains 76.5 TFLOP/s with on this part (profiles/r02_probes/README.md; round 1's
-// "fewer accumulators are faster" probe result did not hold up).  What this kernel does that round 1's tile kernels did not:
-//   * the K loop runs over stages of 16 k-rows held in a DOUBLE-BUFFERED LDS tile pair: ONE barrier per stage, and the
-//     stores of stage s+1 into the other buffer sit in the middle of stage s's 64 MFMAs per wave (round 1: two barriers
-//     around an exposed LDS refill for every 8 MFMAs);
-//   * the global loads of stage s+2 are issued under stage s (a full stage = 4096 MFMA-pipe cycles of latency cover);
-//   * the LDS operand reads of k-step kk+1 are issued before the 16 MFMAs of k-step kk (software-pipelined registers);
-//   * two workgroups per CU (73.7 KB of LDS, <= 256 VGPR+AGPR each): one's C-tile read-modify-write epilogue runs under the
-//     other's main loop.
-// Both operands are K-major row panels, so one staging pattern serves A and B: 16 k-rows x 128 columns, every k-row read
-// by 128 consecutive threads (1 KB coalesced).  LDS row stride 128 + 16 doubles: the four k-rows (lane>>4) of one
-// ds_read_b64 fall on disjoint bank groups.  MFMA lane map: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
-// D[row = (l>>4) + 4 reg][col = l&15].
-// Algorithmic flops per launch: 2 K per updated element (update_flops()); algorithmic bytes: the C tile read + written
-// once (16 B per element) + the two 256 x 128 operand panels per tile (L2-resident across the tiles of a row/column).
+// Geometry of the 128 x 128 trailing-update tile of the dataflow factorisation (df_task_tile, ldlt_dataflow.hpp):
+// 4 wave64 of 64 x 64 (4 x 4 tiles of v_mfma_f64_16x16x4_f64), K in double-buffered LDS stages of 16 k-rows, LDS row
+// stride 128 + 16 doubles (the four k-rows of one ds_read_b64 fall on disjoint bank groups).
 // ------------------------------------------------------------------------------------------
 constexpr int UD_T = 128;             // tile edge
 constexpr int UD_KT = 16;             // k-rows per stage
 constexpr int UD_LD = UD_T + 16;      // LDS row stride (doubles)
 
-template <int DBG = 0>   // DBG != 0: timing experiments only (scripts/upd_time.py): 1 no C epilogue, 2 no main loop, 3 no global operand loads
-__global__ __launch_bounds__(kBlock, 2) void ldlt_update_db_kernel(double* __restrict__ A, int64_t lda, int N,
-                                                                   const double* __restrict__ V, int64_t ldv, int vrow0,
-                                                                   int urow0, int K, int s, int row_end, int col_end,
-                                                                   int skip_diag, double* __restrict__ Cnext,
-                                                                   unsigned int* __restrict__ rows_done_flag)
-{
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  const int r0 = s + ti * UD_T, c0 = s + tj * UD_T;
-  const bool live = !(tj < ti) && r0 < row_end && c0 < col_end &&
-                    !(skip_diag && r0 + UD_T <= s + LD_NB && c0 + UD_T <= s + LD_NB);
-  if(!live) return;
-  __shared__ double Vs[2][UD_KT][UD_LD];
-  __shared__ double Us[2][UD_KT][UD_LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lk = lane >> 4, li = lane & 15;
-
-  double4_t acc[4][4];
-#pragma unroll
-  for(int i = 0; i < 4; ++i)
-#pragma unroll
-    for(int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-
-  // staging: thread (lrow = tid >> 7, lcol = tid & 127) owns k-rows lrow + 2 q, q = 0..7, of column lcol of both panels
-  const int lcol = tid & 127, lrow = tid >> 7;
-  const bool vr_ok = (r0 + lcol) < N;
-  const bool uc_ok = (c0 + lcol) < N;
-  const double* Vp = V + (int64_t)(vrow0 + lrow) * ldv + (vr_ok ? (r0 + lcol) : 0);
-  const double* Up = A + (int64_t)(urow0 + lrow) * lda + (uc_ok ? (c0 + lcol) : 0);
-  double vreg[8], ureg[8];
-  const int nst = (K + UD_KT - 1) / UD_KT;
-  auto gload = [&](int st) {   // stage st -> registers (k-rows beyond K: zero)
-#pragma unroll
-    for(int q = 0; q < 8; ++q) {
-      const int k = st * UD_KT + 2 * q + lrow;
-      const bool kok = k < K;
-      const int kc = kok ? k : 0;
-      const double v = ld_batch(Vp + (int64_t)(kc - lrow) * ldv);   // unconditional (clamped) loads, issued as one batch
-      const double u = ld_batch(Up + (int64_t)(kc - lrow) * lda);
-      vreg[q] = (kok && vr_ok) ? v : 0.0;
-      ureg[q] = (kok && uc_ok) ? u : 0.0;
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for(int q = 0; q < 8; ++q) {
-      Vs[buf][2 * q + lrow][lcol] = vreg[q];
-      Us[buf][2 * q + lrow][lcol] = ureg[q];
-    }
-  };
-  gload(0);
-  lstore(0);
-  if(nst > 1) gload(1);
-  __syncthreads();
-  const int arow = wr * 64 + li, bcol = wc * 64 + li;
-  for(int st = 0; st < (DBG == 2 ? 0 : nst); ++st) {
-    const int cur = st & 1;
-    double a[2][4], b[2][4];
-    if(DBG == 6) {
-#pragma unroll
-      for(int i = 0; i < 4; ++i) {
-        a[0][i] = a[1][i] = 1.0 + (tid + i) * 1e-9;
-        b[0][i] = b[1][i] = 1.0 - (tid + 3 * i) * 1e-9;
-      }
-    } else {
-#pragma unroll
-      for(int i = 0; i < 4; ++i) a[0][i] = Vs[cur][lk][arow + 16 * i];
-#pragma unroll
-      for(int j = 0; j < 4; ++j) b[0][j] = Us[cur][lk][bcol + 16 * j];
-    }
-#pragma unroll
-    for(int kk = 0; kk < UD_KT / 4; ++kk) {
-      const int pb = kk & 1;
-      if(kk + 1 < UD_KT / 4 && DBG != 6) {   // operands of the next k-step
-#pragma unroll
-        for(int i = 0; i < 4; ++i) a[pb ^ 1][i] = Vs[cur][4 * (kk + 1) + lk][arow + 16 * i];
-#pragma unroll
-        for(int j = 0; j < 4; ++j) b[pb ^ 1][j] = Us[cur][4 * (kk + 1) + lk][bcol + 16 * j];
-      }
-      if(kk == 1 && st + 1 < nst && DBG < 4) lstore(cur ^ 1);   // stage st+1 -> the other buffer (its loads were issued a stage ago)
-      if(kk == 2 && st + 2 < nst && DBG < 3) gload(st + 2);     // stage st+2 in flight under the rest of this stage and the next
-#pragma unroll
-      for(int i = 0; i < 4; ++i)
-#pragma unroll
-        for(int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[pb][i], b[pb][j], acc[i][j], 0, 0, 0);
-    }
-    if(DBG != 4 && DBG != 6) __syncthreads();   // buffer cur^1 complete, everybody done reading buffer cur
-  }
-  // epilogue: C -= acc on the upper triangle, software-pipelined over the four 16-row groups of the wave: the 16 loads of
-  // group i+1 are issued before the stores of group i (a load cannot be hoisted above a possibly-aliasing store).
-  if(DBG == 1 || DBG >= 4) {   // timing experiment: no C traffic (one store per thread keeps the accumulators alive)
-    double t = 0.0;
-#pragma unroll
-    for(int i = 0; i < 4; ++i)
-#pragma unroll
-      for(int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if(t == 12345.678) A[(int64_t)r0 * lda + c0 + tid] = t;
-    return;
-  }
-  const bool to_compact = Cnext && r0 < s + LD_NB && c0 < s + LD_NB;
-  double cv[2][4][4];
-  auto cload = [&](int i, int pbuf) {
-#pragma unroll
-    for(int reg = 0; reg < 4; ++reg) {
-      const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
-      const double* Crow = A + (int64_t)(row < row_end ? row : (row_end - 1)) * lda;
-#pragma unroll
-      for(int j = 0; j < 4; ++j) {
-        const int col = c0 + wc * 64 + j * 16 + li;
-        cv[pbuf][reg][j] = Crow[col < col_end ? col : (col_end - 1)];
-      }
-    }
-  };
-  cload(0, 0);
-#pragma unroll
-  for(int i = 0; i < 4; ++i) {
-    const int pbuf = i & 1;
-    if(i + 1 < 4) cload(i + 1, pbuf ^ 1);
-#pragma unroll
-    for(int reg = 0; reg < 4; ++reg) {
-      const int row = r0 + wr * 64 + i * 16 + lk + 4 * reg;
-      double* Crow = A + (int64_t)row * lda;
-#pragma unroll
-      for(int j = 0; j < 4; ++j) {
-        const int col = c0 + wc * 64 + j * 16 + li;
-        if(row < row_end && col < col_end && col >= row) {
-          const double nv = cv[pbuf][reg][j] - acc[i][j][reg];
-          Crow[col] = nv;
-          // tiles of the next super-panel's diagonal block also feed its compact copy (origin s, ld = 256)
-          if(to_compact && row < s + LD_NB && col < s + LD_NB) Cnext[(row - s) * LD_NB + (col - s)] = nv;
-        }
-      }
-    }
-  }
-  // hand-over to the chain kernel (look-ahead): the tiles covering the next super-panel's rows announce themselves
-  if(rows_done_flag && r0 < s + LD_NB) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if(tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(rows_done_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// The same update with a templated tile shape — the DEFAULT (64 x 64 workgroup tiles).  Two effects, both measured:
-//  * fewer independent accumulators per wave run faster: 30.4 TFLOP/s with 4 x 4 MFMA tiles per wave (the kernel above),
-//    35.4 with 2 x 4 or 4 x 2, 39.5 with 2 x 2, 1 x 2 or 2 x 1 — the registers-only probe shows the same for the bare
-//    instruction (36 TFLOP/s with 16 accumulators, 46 with 4-8; profiles/r01_probes);
-//  * the tail of each of the 31 launches (the last tiles running on a part of the device) shrinks with the tile.
-// Operand traffic per flop doubles against the 128 x 128 tile but comes out of L2.
+// rank-K update on fp64 MFMA with a templated tile shape (the STEPWISE path's trailing update, 64 x 64 workgroup tiles,
+// and the chain's diagonal-block update of that path, 32 x 64):
+//     A[r][c] -= sum_{k<K} V[vrow0+k][r] * A[urow0+k][c]      r in [s, row_end), c in [max(r, s), col_end), upper triangle
+// Small tiles = 68 VGPRs and 10 KB of LDS per workgroup: 5-7 waves per SIMD hide the un-pipelined LDS refill of its 8-deep
+// stages (38.9 TFLOP/s over the 31 launches of an N = 8192 factorisation).  v_mfma_f64_16x16x4_f64 lane map:
+// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4 reg][col = l&15].
 // ------------------------------------------------------------------------------------------
 // Wave tile = (16 WI) x (16 WJ), workgroup tile = (32 WI) x (32 WJ) (2 x 2 waves).
 template <int WI, int WJ, int KTx = LD_KT>
@@ -1564,11 +1408,30 @@ __device__ __forceinline__ void flow_st(double* p, double v)
 // poll, data load).  The exchange buffers exist twice; a launch uses the copy of its epoch's parity and every producer
 // re-poisons the words it will write in the NEXT launch.
 constexpr unsigned long long FL_POISON = 0x7FF8A5A5DEADBEEFull;   // a quiet NaN no arithmetic produces
-__device__ __forceinline__ double flow_poll(const double* p)
+// Every spin of the dataflow solve is bounded by wall-clock time (s_memrealtime, 100 MHz): FL_TIMEOUT_TICKS after the
+// workgroup started, a wait gives up and raises the error word (the last word of the sync array).  The results of that
+// launch are then meaningless; the host sees the word at its next synchronising call, re-initialises the exchange state
+// and falls back to the stepwise solve (hiopamd_linsolver_solve_status / matrixChanged).
+constexpr long long FL_TIMEOUT_TICKS = 200000000ll;   // 2 s
+struct FlowGuard {
+  unsigned long long* err;
+  long long deadline;
+  __device__ __forceinline__ bool expired(unsigned& n) const
+  {
+    if((++n & 1023u) != 0) return false;
+    if((long long)wall_clock64() < deadline && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return false;
+    __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+};
+__device__ __forceinline__ double flow_poll(const double* p, const FlowGuard& g)
 {
   unsigned long long u;
-  while((u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == FL_POISON)
+  unsigned n = 0;
+  while((u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == FL_POISON) {
     __builtin_amdgcn_s_sleep(1);
+    if(g.expired(n)) return 0.0;
+  }
   return __longlong_as_double((long long)u);
 }
 __device__ __forceinline__ void flow_poison(double* p)
@@ -1591,10 +1454,14 @@ __device__ __forceinline__ double flow_sub_slots(double v, const double* p, int6
   return v;
 }
 
-__device__ __forceinline__ void flow_wait(const unsigned long long* p, unsigned long long target)
+__device__ __forceinline__ void flow_wait(const unsigned long long* p, unsigned long long target, const FlowGuard& g)
 {
   if(threadIdx.x == 0) {
-    while(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    unsigned n = 0;
+    while(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if(g.expired(n)) break;
+    }
   }
   __syncthreads();
 }
@@ -1605,21 +1472,31 @@ __device__ __forceinline__ void flow_wait(const unsigned long long* p, unsigned 
 // with long sleeps and only then polls its own tightly: the number of tight pollers stays at the handful of tasks next
 // in line.
 __device__ __forceinline__ void flow_wait_chain(const unsigned long long* f, int idx, int step, int nb,
-                                                unsigned long long target, int dist)
+                                                unsigned long long target, int dist, const FlowGuard& g)
 {
   if(threadIdx.x == 0) {
     const int i2 = idx + 2 * step, i1 = idx + step;
+    unsigned n = 0;
     if(i2 >= 0 && i2 < nb)
-      while(__hip_atomic_load(f + i2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(96);
+      while(__hip_atomic_load(f + i2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(96);
+        if(g.expired(n)) break;
+      }
     if(i1 >= 0 && i1 < nb)
-      while(__hip_atomic_load(f + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(24);
+      while(__hip_atomic_load(f + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(24);
+        if(g.expired(n)) break;
+      }
     if(dist == 0) {
       // next in line: the caller polls the data itself (flow_poll)
     } else {
       // not next in line (the product is consumed `dist` block steps later): poll slowly, and stagger the read of the
       // 2 KB input vector — every waiting task of this column reads the same lines, i.e. the same memory channel, and
       // the one task the chain is waiting for must not queue behind a hundred others
-      while(__hip_atomic_load(f + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(16);
+      while(__hip_atomic_load(f + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(16);
+        if(g.expired(n)) break;
+      }
       for(int d = 0; d < dist && d < 24; ++d) __builtin_amdgcn_s_sleep(8);
     }
   }
@@ -1666,6 +1543,7 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
   unsigned long long* fc = bb + nb;
   unsigned long long* bc = fc + nb;
   const unsigned long long eR = epoch * (unsigned long long)FL_R;
+  const FlowGuard guard{bc + nb, (long long)wall_clock64() + FL_TIMEOUT_TICKS};   // error word = the word after the last flag
   // Pacing: tasks are issued in the order their results are needed, and the chain of diagonal solves sets the length of
   // the solve, so the operand blocks only have to arrive at a uniform rate.  Left alone, every resident task loads at
   // once and the chain's own small round trips queue behind 100 MB of streaming (block steps of 15 us instead of 4).
@@ -1678,8 +1556,13 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
     const int pace = (int)(((long long)rel * nb) / half) - FL_LEAD;   // block step of the chain to wait for
     if(pace >= 0) {
       const unsigned long long* f = fwd ? (fy + pace) : (bx + (nb - 1 - pace));
-      if(tid == 0)
-        while(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < eR) __builtin_amdgcn_s_sleep(64);
+      if(tid == 0) {
+        unsigned n = 0;
+        while(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < eR) {
+          __builtin_amdgcn_s_sleep(64);
+          if(guard.expired(n)) break;
+        }
+      }
       __syncthreads();
     }
   }
@@ -1708,22 +1591,22 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
       }
     }
     if(kind == FL_FWD_OFF) {
-      flow_wait_chain(fy, I, -1, nb, eR, J - I - 1);
-      vsh[tid] = (J - I == 1) ? flow_poll(y + (int64_t)I * SV_B + tid) : flow_ld(y + (int64_t)I * SV_B + tid);
+      flow_wait_chain(fy, I, -1, nb, eR, J - I - 1, guard);
+      vsh[tid] = (J - I == 1) ? flow_poll(y + (int64_t)I * SV_B + tid, guard) : flow_ld(y + (int64_t)I * SV_B + tid);
     } else {
       const int64_t gi = (int64_t)J * SV_B + tid;
       double v = (gi < N) ? b[gi] : 0.0;
       if(J >= 3) {
-        flow_wait(fa + J, eR * (unsigned long long)(J - 2));
+        flow_wait(fa + J, eR * (unsigned long long)(J - 2), guard);
         v = flow_sub_slots(v, P + (int64_t)J * nb * SV_B + tid, SV_B, J - 2);
       }
       if(J >= 2) {
-        flow_wait(fc + J, eR);
+        flow_wait(fc + J, eR, guard);
         v -= flow_ld(P + ((int64_t)J * nb + (J - 2)) * SV_B + tid);
       }
       if(J >= 1) {
         const double* pl = P + ((int64_t)J * nb + (J - 1)) * SV_B + tid;
-        v -= flow_poll(pl);
+        v -= flow_poll(pl, guard);
       }
       vsh[tid] = v;
     }
@@ -1766,9 +1649,9 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
         m[ps * 16 + k] = src[(gc < N) ? gc : (int64_t)(N - 1)];
       }
     }
-    flow_wait_chain(bx, J, +1, nb, eR, J - I - 1);
+    flow_wait_chain(bx, J, +1, nb, eR, J - I - 1, guard);
     const int64_t gj = (int64_t)J * SV_B + tid;
-    vsh[tid] = (gj < N) ? ((J - I == 1) ? flow_poll(xc + gj) : flow_ld(xc + gj)) : 0.0;
+    vsh[tid] = (gj < N) ? ((J - I == 1) ? flow_poll(xc + gj, guard) : flow_ld(xc + gj)) : 0.0;
   } else {
     const double* Wi = W + (int64_t)I * (SV_B * SV_B);
 #pragma unroll
@@ -1781,20 +1664,20 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
       }
     }
     const int64_t gi = (int64_t)I * SV_B + tid;
-    flow_wait(fy + I, eR);
+    flow_wait(fy + I, eR, guard);
     double v = (gi < N) ? flow_ld(y + gi) * dinv[gi] : 0.0;
     const int above = nb - 1 - I;
     if(above >= 3) {   // J = nb-1 .. I+3, descending
-      flow_wait(ba + I, eR * (unsigned long long)(above - 2));
+      flow_wait(ba + I, eR * (unsigned long long)(above - 2), guard);
       v = flow_sub_slots(v, P + ((int64_t)I * nb + (nb - 1)) * SV_B + tid, -(int64_t)SV_B, above - 2);
     }
     if(above >= 2) {
-      flow_wait(bc + I, eR);
+      flow_wait(bc + I, eR, guard);
       v -= flow_ld(P + ((int64_t)I * nb + (I + 2)) * SV_B + tid);
     }
     if(above >= 1) {
       const double* pl = P + ((int64_t)I * nb + (I + 1)) * SV_B + tid;
-      v -= flow_poll(pl);
+      v -= flow_poll(pl, guard);
     }
     vsh[tid] = v;
   }
@@ -1947,7 +1830,7 @@ static DfPlan df_build_plan(int N)
   P.off_chain = DF_HDR;
   P.off_tr = P.off_chain + (int64_t)(P.nsp + 1) * DF_CH;
   P.off_ver = P.off_tr + (int64_t)P.nsp * P.nt;
-  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 16 + 512 + 8 * (int64_t)(P.nsp + 1);   // (+ TEMPORARY progress words, stamps)
+  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1);   // (+ the profiling stamps)
   std::vector<int4> t0, t1;
   df_chain_tasks(true, t0);
   df_chain_tasks(false, t1);
@@ -2002,6 +1885,8 @@ struct hiopamd_linsolver {
   int4* fl_tasks = nullptr;
   int fl_ntasks = 0;
   unsigned long long fl_epoch = 0;
+  bool flow_enabled = true;    // dataflow solve in use (false: stepwise 256-row solves)
+  bool flow_dirty = false;     // dataflow solves were launched since the error word was last looked at
   bool factored = false;
   int inertia[3] = {0, 0, 0};
   double flops_fact = 0.0, flops_triu = 0.0;   // hiopLinSolStats::flopsFact / flopsTriuSolves (cumulative)
@@ -2018,37 +1903,12 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   double* Li = Dblk + (int64_t)((N + LD_nb - 1) / LD_nb) * (LD_nb * LD_nb);
   const bool timed = prof && prof->enabled;
   hipStream_t upd_stream = ctx->stream;
-  // trailing update launch: tiles of 128 x 128 covering rows/columns [s, s + 128 t)
+  // trailing update launch of the STEPWISE path (fallback / leftover super-panels): the 64 x 64-tile kernel, t = number of
+  // 128-wide tile columns covering [s, N)
   auto launch_update = [&](int t, const double* Vb, int urow0, int K, int s, int row_end, int col_end, int skip_diag) {
     if(timed) (void)hipEventRecord(prof->get(), upd_stream);
-    static int upd_old = -1;   // TEMPORARY A/B switch (round 2): HIOPAMD_UPD_OLD=1 = round 1's 64 x 64-tile kernel
-    if(upd_old < 0) upd_old = std::getenv("HIOPAMD_UPD_OLD") ? std::atoi(std::getenv("HIOPAMD_UPD_OLD")) : 0;
-    static int upd_dbg = -1;   // TEMPORARY: timing experiments (results meaningless)
-    if(upd_dbg < 0) upd_dbg = std::getenv("HIOPAMD_UPD_DBG") ? std::atoi(std::getenv("HIOPAMD_UPD_DBG")) : 0;
-    if(upd_old)
-      hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), dim3(2 * t, 2 * t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0,
-                         urow0, K, s, row_end, col_end, skip_diag, nullptr);
-    else if(upd_dbg == 1)
-      hipLaunchKernelGGL(ldlt_update_db_kernel<1>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
-                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
-    else if(upd_dbg == 2)
-      hipLaunchKernelGGL(ldlt_update_db_kernel<2>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
-                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
-    else if(upd_dbg == 4)
-      hipLaunchKernelGGL(ldlt_update_db_kernel<4>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
-                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
-    else if(upd_dbg == 5)
-      hipLaunchKernelGGL(ldlt_update_db_kernel<5>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
-                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
-    else if(upd_dbg == 6)
-      hipLaunchKernelGGL(ldlt_update_db_kernel<6>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
-                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
-    else if(upd_dbg == 3)
-      hipLaunchKernelGGL(ldlt_update_db_kernel<3>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
-                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
-    else
-      hipLaunchKernelGGL(ldlt_update_db_kernel<0>, dim3(t, t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0, urow0, K, s,
-                         row_end, col_end, skip_diag, (double*)nullptr, (unsigned int*)nullptr);
+    hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), dim3(2 * t, 2 * t), dim3(kBlock), 0, upd_stream, A, lda, N, Vb, (int64_t)N, 0,
+                       urow0, K, s, row_end, col_end, skip_diag, nullptr);
     if(timed) {
       (void)hipEventRecord(prof->get(), upd_stream);
       prof->flops += update_flops(N, K, s, row_end);
@@ -2077,17 +1937,12 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   // double-buffered (row panel j+1 is written while upd_rest(j) reads row panel j).
   const int nsp = (N + LD_NB - 1) / LD_NB;
   const int64_t cdt_ofs = (int64_t)nsp * (LD_NB * LD_NB);   // the transposed compact blocks follow the compact blocks
-  static int la_mode = -1;   // HIOPAMD_LA_MODE=0 switches the look-ahead off (debug / A-B timing)
-  if(la_mode < 0) la_mode = std::getenv("HIOPAMD_LA_MODE") ? std::atoi(std::getenv("HIOPAMD_LA_MODE")) : 1;
-  const bool lookahead = nsp > 2 && la_mode > 0 && ctx_cu_split(ctx);
+  const bool lookahead = nsp > 2 && ctx_cu_split(ctx);
   hipStream_t su = st, sd = st;
   if(lookahead) {
     su = ctx->upd_stream;
     sd = ctx->diag_stream;
   }
-  static long long* d_ts = nullptr;   // debug: HIOPAMD_SD_TRACE=1 prints the phase timeline of one super-panel
-  static int trace_state = -1;
-  if(trace_state < 0) trace_state = (std::getenv("HIOPAMD_SD_TRACE") != nullptr) ? 1 : 0;
   int evn = 0;
   auto next_event = [&]() { return ctx_event(ctx, (evn++) % 160); };
   auto dep = [&](hipStream_t from, hipStream_t to) -> int {   // `to` continues after everything queued on `from`
@@ -2114,30 +1969,14 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   };
   auto superdiag = [&](int jp, hipStream_t stream) {
     const Panel p = panel(jp);
-    long long* ts_arg = nullptr;
-    if(trace_state == 1 && p.K0 == 0 && p.kbs == LD_NB) {
-      if(!d_ts) (void)hipMalloc((void**)&d_ts, 32 * sizeof(long long));
-      ts_arg = d_ts;
-    }
     // the kernel works on the compact copy of its block: matrix pointer = Cj, ld = 256, origin 0
     hipLaunchKernelGGL(ldlt_superdiag_kernel, dim3(1), dim3(kBlock), 0, stream, p.Cj, (int64_t)LD_NB, 0, p.kbs, p.Vb, ldv,
-                       dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, ts_arg);
-    if(ts_arg) {
-      long long h[17];
-      (void)hipStreamSynchronize(stream);
-      (void)hipMemcpy(h, d_ts, sizeof(h), hipMemcpyDeviceToHost);
-      std::fprintf(stderr, "[hiop_amd] superdiag timeline (wall_clock64 ticks, 100 MHz => 10 ns):");
-      for(int q = 1; q <= 16; ++q) std::fprintf(stderr, " %lld", h[q] - h[0]);
-      std::fprintf(stderr, "\n");
-      trace_state = 2;
-    }
+                       dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, (long long*)nullptr);
   };
-  static int head4 = -1;   // HIOPAMD_HEAD4=0: the head of the row panel with the one-wave-per-16-columns kernel
-  if(head4 < 0) head4 = std::getenv("HIOPAMD_HEAD4") ? std::atoi(std::getenv("HIOPAMD_HEAD4")) : 1;
   auto trsm = [&](int jp, hipStream_t stream, int col_ofs, int ncols) {
     if(ncols <= 0) return;
     const Panel p = panel(jp);
-    if(head4 && p.kbs == LD_NB && (head4 >= 2 || (col_ofs == 0 && ncols <= LD_NB))) {   // the head, on the chain stream (2: the tail too)
+    if(p.kbs == LD_NB && col_ofs == 0 && ncols <= LD_NB) {   // the head, on the chain stream: four waves per 16 columns
       hipLaunchKernelGGL(ldlt_headtrsm_kernel, dim3((ncols + 15) / 16), dim3(kBlock), 0, stream, A, lda, N, p.K0, p.Vb, ldv, dinv,
                          p.Cj, p.Dk_sp, p.Li_sp, col_ofs);
       return;
@@ -2166,16 +2005,13 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     int rc = dep(st, su);
     if(rc == HIOPAMD_OK) rc = dep(st, sd);
     if(rc != HIOPAMD_OK) return rc;
-    static int df_dbg = -1;   // TEMPORARY bring-up switch: 1 = chain kernel only, 2 = wide kernel only (both must time out cleanly)
-    if(df_dbg < 0) df_dbg = std::getenv("HIOPAMD_DF_DEBUG") ? std::atoi(std::getenv("HIOPAMD_DF_DEBUG")) : 0;
-    a.dbg = df_dbg;
-    a.off_dbg = P.off_ver + (int64_t)P.nt * P.nt;
-    a.off_ts = a.off_dbg + 16 + 512;
-    if(df_dbg != 2) hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
-    if(df_dbg) std::fprintf(stderr, "[hiop_amd] df debug %d: chain launched (%s)\n", df_dbg, hipGetErrorName(hipGetLastError()));
-    if(a.nwtasks > 0 && df_dbg != 1) {
+    a.dbg = std::getenv("HIOPAMD_DF_STAMPS") ? 1 : 0;   // profiling aid: per-super-panel time stamps, printed after the call
+    a.off_ts = P.off_ver + (int64_t)P.nt * P.nt;
+    hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
+    if(a.nwtasks > 0) {
       if(timed) (void)hipEventRecord(prof->get(), su);
-      const int grid = a.nwtasks < 480 ? a.nwtasks : 480;   // two workgroups on each of the 240 CUs of the wide stream
+      const int wmax = 240 * DF_WIDE_WG_PER_CU;   // the resident workgroups of the 240 CUs of the wide stream
+      const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
       hipLaunchKernelGGL(ldlt_wide_kernel, dim3(grid), dim3(kBlock), 0, su, a);
       if(timed) {
         (void)hipEventRecord(prof->get(), su);
@@ -2183,49 +2019,6 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
         prof->launches += 1;
       }
     }
-    if(std::getenv("HIOPAMD_DF_DEBUG")) {
-    // TEMPORARY bring-up aid: host watchdog.  If the stream does not drain within 10 s, dump the flag state through a
-    // separate stream and give up (the kernels' own wall-clock bound should have fired long before).
-    const auto t0 = std::chrono::steady_clock::now();
-    while(hipStreamQuery(su) == hipErrorNotReady || hipStreamQuery(sd) == hipErrorNotReady) {
-      if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
-        hipStream_t dbg;
-        (void)hipStreamCreateWithFlags(&dbg, hipStreamNonBlocking);
-        std::vector<unsigned> fl((size_t)df->plan.nflags);
-        (void)hipMemcpyAsync(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost, dbg);
-        (void)hipStreamSynchronize(dbg);
-        std::fprintf(stderr, "[hiop_amd] df HOST WATCHDOG: kernels still running after 10 s. header:");
-        for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[q]);
-        std::fprintf(stderr, "\n");
-        for(int j = 0; j < P.nsp; ++j) {
-          std::fprintf(stderr, "  panel %d: cdone %u hdone %u updone %u/%u cv:", j, fl[P.off_chain + j * DF_CH + DF_CDONE],
-                       fl[P.off_chain + j * DF_CH + DF_HDONE], fl[P.off_chain + j * DF_CH + DF_UPDONE], P.upcnt[j]);
-          for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[P.off_chain + j * DF_CH + DF_CV + q]);
-          std::fprintf(stderr, " hv:");
-          for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[P.off_chain + j * DF_CH + DF_HV + q]);
-          std::fprintf(stderr, " tr:");
-          for(int q = 0; q < P.nt; ++q) std::fprintf(stderr, " %u", fl[P.off_tr + (int64_t)j * P.nt + q]);
-          std::fprintf(stderr, "\n");
-        }
-        std::fprintf(stderr, "  streams: su %s, sd %s\n  chain roles:", hipGetErrorName(hipStreamQuery(su)), hipGetErrorName(hipStreamQuery(sd)));
-        {
-          const int64_t od = df->plan.off_ver + (int64_t)df->plan.nt * df->plan.nt;
-          for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[od + q]);
-          std::fprintf(stderr, "\n  wide wgs:");
-          for(int q = 0; q < 80; ++q) std::fprintf(stderr, " %u", fl[od + 16 + q]);
-          std::fprintf(stderr, "\n");
-        }
-        std::fprintf(stderr, "  ver:\n");
-        for(int I = 0; I < P.nt; ++I) {
-          std::fprintf(stderr, "   ");
-          for(int J = 0; J < P.nt; ++J) std::fprintf(stderr, " %u", fl[P.off_ver + (int64_t)I * P.nt + J]);
-          std::fprintf(stderr, "\n");
-        }
-        std::fflush(stderr);
-        std::_Exit(7);
-      }
-    }
-  }
     rc = dep(su, st);
     if(rc == HIOPAMD_OK) rc = dep(sd, st);
     if(rc != HIOPAMD_OK) return rc;
@@ -2301,7 +2094,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
     const DfPlan& P = df->plan;
     std::vector<unsigned> ts((size_t)8 * (P.nsp + 1));
-    const int64_t off_ts = P.off_ver + (int64_t)P.nt * P.nt + 16 + 512;
+    const int64_t off_ts = P.off_ver + (int64_t)P.nt * P.nt;
     (void)hipMemcpy(ts.data(), df->flags + off_ts, sizeof(unsigned) * ts.size(), hipMemcpyDeviceToHost);
     const unsigned t0 = 0xffffffffu - ts[0];
     std::fprintf(stderr, "[hiop_amd] df stamps (us since F(0) of panel 0): panel | F0 start, F3 done | last head T | TR first start, last done | UP first start, last done\n");
@@ -2309,24 +2102,6 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       auto us = [&](int k) { const unsigned v = ts[(size_t)8 * j + k]; return v == 0 ? -1.0 : ((k & 1) ? (double)(v - t0) : (double)((0xffffffffu - v) - t0)) * 0.01; };
       std::fprintf(stderr, "  %2d | %8.1f %8.1f | %8.1f | %8.1f %8.1f | %8.1f %8.1f\n", j, us(0), us(1), us(3), us(4), us(5), us(6), us(7));
     }
-  }
-  if(dfw[DF_ABORT] && std::getenv("HIOPAMD_DF_DEBUG")) {
-    const DfPlan& P = df->plan;
-    std::vector<unsigned> fl((size_t)P.nflags);
-    (void)hipMemcpy(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost);
-    for(int j = 0; j < P.nsp; ++j) {
-      if(fl[P.off_chain + j * DF_CH + DF_CDONE] == 0 && j > 0 && fl[P.off_chain + (j - 1) * DF_CH + DF_CDONE] == 0) continue;
-      std::fprintf(stderr, "  panel %d: cdone %u hdone %u updone %u/%u cv:", j, fl[P.off_chain + j * DF_CH + DF_CDONE],
-                   fl[P.off_chain + j * DF_CH + DF_HDONE], fl[P.off_chain + j * DF_CH + DF_UPDONE], P.upcnt[j]);
-      for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[P.off_chain + j * DF_CH + DF_CV + q]);
-      std::fprintf(stderr, " hv:");
-      for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[P.off_chain + j * DF_CH + DF_HV + q]);
-      std::fprintf(stderr, "\n");
-    }
-    const int64_t od = P.off_ver + (int64_t)P.nt * P.nt;
-    std::fprintf(stderr, "  chain roles (10000 j + 100 it + 10 type):");
-    for(int q = 0; q < 16; ++q) std::fprintf(stderr, " %u", fl[od + q]);
-    std::fprintf(stderr, "\n");
   }
   if(dfw[DF_ABORT]) {
     std::fprintf(stderr,
@@ -2352,21 +2127,10 @@ static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda
   if(N == 0) return HIOPAMD_OK;
   hipStream_t st = ctx->stream;
   const int nblk = (N + LD_nb - 1) / LD_nb;
-  static int flow_mode = -1;   // HIOPAMD_SOLVE_FLOW=0: stepwise 256-row solves (A/B timing)
-  if(flow_mode < 0) flow_mode = std::getenv("HIOPAMD_SOLVE_FLOW") ? std::atoi(std::getenv("HIOPAMD_SOLVE_FLOW")) : 1;
-  if(flow && flow->W && flow_mode > 0) {
+  if(flow && flow->W && flow->flow_enabled) {
     const int nb = (N + SV_B - 1) / SV_B;
-    static long long* d_ts = nullptr;   // HIOPAMD_FLOW_TRACE=<file>: per-task timestamps of the 5th solve
-    static int trace_count = 0;
-    const char* trace_path = std::getenv("HIOPAMD_FLOW_TRACE");
     for(int j = 0; j < nrhs; ++j) {
       flow->fl_epoch += 1;
-      long long* ts = nullptr;
-      if(trace_path && ++trace_count == 5) {
-        (void)hipMalloc((void**)&d_ts, sizeof(long long) * 4 * (size_t)flow->fl_ntasks);
-        (void)hipMemset(d_ts, 0, sizeof(long long) * 4 * (size_t)flow->fl_ntasks);
-        ts = d_ts;
-      }
       // exchange buffers of this epoch's parity (c) and of the next launch (n): y | x | product slots, twice
       const int64_t npad = (int64_t)nb * SV_B, psz = (int64_t)SV_B * nb * nb, half = 2 * npad + psz;
       double* cur = flow->P + (int64_t)(flow->fl_epoch & 1ull) * half;
@@ -2375,23 +2139,16 @@ static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda
       double *yn = nxt, *xn = nxt + npad, *Pn = nxt + 2 * npad;
       hipLaunchKernelGGL(ldlt_solve_flow_kernel, dim3(flow->fl_ntasks), dim3(kBlock), 0, st, A, lda, N, nb, flow->W, dinv,
                          flow->fl_tasks, flow->fl_ntasks, flow->fl_sync, flow->fl_epoch, Pc, yc, xcur, Pn, yn, xn,
-                         rhs + (int64_t)j * N, ts);
-      if(ts) {
-        (void)hipStreamSynchronize(st);
-        std::vector<long long> h(4 * (size_t)flow->fl_ntasks);
-        std::vector<int4> tk(flow->fl_ntasks);
-        (void)hipMemcpy(h.data(), d_ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(tk.data(), flow->fl_tasks, sizeof(int4) * tk.size(), hipMemcpyDeviceToHost);
-        if(FILE* f = std::fopen(trace_path, "w")) {
-          std::fprintf(f, "# ticket kind I J chunk t_start t_input t_signal (10 ns ticks, relative to the first task)\n");
-          for(int t = 0; t < flow->fl_ntasks; ++t)
-            std::fprintf(f, "%d %d %d %d %d %lld %lld %lld\n", t, tk[t].x, tk[t].y, tk[t].z, tk[t].w, h[4 * t] - h[0],
-                         h[4 * t + 1] - h[0], h[4 * t + 2] - h[0]);
-          std::fclose(f);
-        }
+                         rhs + (int64_t)j * N, (long long*)nullptr);
+      if(hipGetLastError() != hipSuccess) {
+        // the launch did not happen: the device-side flags / poison parity did not advance, neither may the host's epoch
+        flow->fl_epoch -= 1;
+        std::fprintf(stderr, "[hiop_amd] dataflow solve: launch failed, falling back to the stepwise solve\n");
+        flow->flow_enabled = false;
+        return ldlt_solve_impl(ctx, N, A, lda, dinv, ybuf, rhs + (int64_t)j * N, nrhs - j, Cd, flow);
       }
     }
-    HIOPAMD_CHECK(hipGetLastError());
+    flow->flow_dirty = true;   // the error word is looked at by the next synchronising call (flow_check)
     return HIOPAMD_OK;
   }
   if(Cd) {   // 256-row steps on the compact diagonal blocks (the factorisation object keeps them)
@@ -2469,10 +2226,24 @@ int hiopamd_ldlt_solve(hiopamd_ctx* ctx, int n, const double* A, int64_t lda, co
   return ldlt_solve_impl(ctx, n, A, lda, work_dinv, y, rhs_inout, nrhs);
 }
 
+static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n);
+
 int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
 {
   if(!out || !ctx || n < 0) return HIOPAMD_ERR_ARG;
+  *out = nullptr;
   hiopamd_linsolver* ls = new hiopamd_linsolver();
+  const int rc = linsolver_create_impl(ls, ctx, n);
+  if(rc != HIOPAMD_OK) {   // nothing leaks: destroy tolerates the members that were never allocated
+    (void)hiopamd_linsolver_destroy(ls);
+    return rc;
+  }
+  *out = ls;
+  return HIOPAMD_OK;
+}
+
+static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
+{
   ls->ctx = ctx;
   ls->n = n;
   const size_t nn = (size_t)(n > 0 ? n : 1);
@@ -2494,8 +2265,8 @@ int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
       std::vector<unsigned long long> poison(words, FL_POISON);
       HIOPAMD_CHECK(hipMemcpy(ls->P, poison.data(), sizeof(double) * words, hipMemcpyHostToDevice));
     }
-    HIOPAMD_CHECK(hipMalloc((void**)&ls->fl_sync, sizeof(unsigned long long) * (size_t)(1 + 8 * nb)));
-    HIOPAMD_CHECK(hipMemsetAsync(ls->fl_sync, 0, sizeof(unsigned long long) * (size_t)(1 + 8 * nb), ctx->stream));
+    HIOPAMD_CHECK(hipMalloc((void**)&ls->fl_sync, sizeof(unsigned long long) * (size_t)(2 + 8 * nb)));   // + the error word
+    HIOPAMD_CHECK(hipMemsetAsync(ls->fl_sync, 0, sizeof(unsigned long long) * (size_t)(2 + 8 * nb), ctx->stream));
     std::vector<int4> tk;
     tk.reserve((size_t)FL_R * nb * (nb + 1));
     for(int J = 0; J < nb; ++J) {   // forward: column J needs y_I, I < J; its diagonal task closes it
@@ -2530,7 +2301,7 @@ int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
       HIOPAMD_CHECK(hipMemcpy(df.upcnt, P.upcnt.data(), sizeof(unsigned) * P.upcnt.size(), hipMemcpyHostToDevice));
     }
   }
-  *out = ls;
+  ls->flow_enabled = !(std::getenv("HIOPAMD_SOLVE_FLOW") && std::atoi(std::getenv("HIOPAMD_SOLVE_FLOW")) == 0);
   return HIOPAMD_OK;
 }
 
@@ -2560,10 +2331,55 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
 double* hiopamd_linsolver_sys_matrix(hiopamd_linsolver* ls) { return ls ? ls->M : nullptr; }
 int hiopamd_linsolver_n(const hiopamd_linsolver* ls) { return ls ? ls->n : -1; }
 
+// Synchronises the context's stream and looks at the dataflow solve's error word (a bounded wait timed out).  On error the
+// exchange state is re-initialised (flags zeroed, buffers re-poisoned, epoch restarted) and the stepwise solve takes over.
+static int flow_check(hiopamd_linsolver* ls, int* ok_host)
+{
+  if(ok_host) *ok_host = 1;
+  if(!ls->flow_dirty || !ls->fl_sync) return HIOPAMD_OK;
+  const int nb = (int)(((size_t)(ls->n > 0 ? ls->n : 1) + SV_B - 1) / SV_B);
+  unsigned long long err = 0;
+  HIOPAMD_CHECK(hipMemcpyAsync(&err, ls->fl_sync + 1 + 8 * nb, sizeof(err), hipMemcpyDeviceToHost, ls->ctx->stream));
+  HIOPAMD_CHECK(hipStreamSynchronize(ls->ctx->stream));
+  ls->flow_dirty = false;
+  if(err == 0) return HIOPAMD_OK;
+  if(ok_host) *ok_host = 0;
+  std::fprintf(stderr, "[hiop_amd] dataflow solve: a bounded wait timed out; the results of the solves since the last check are "
+                       "invalid.  Exchange state re-initialised, stepwise solve from now on.\n");
+  HIOPAMD_CHECK(hipMemsetAsync(ls->fl_sync, 0, sizeof(unsigned long long) * (size_t)(2 + 8 * nb), ls->ctx->stream));
+  const size_t words = 2 * ((size_t)2 * nb * SV_B + (size_t)SV_B * nb * nb);
+  std::vector<unsigned long long> poison(words, FL_POISON);
+  HIOPAMD_CHECK(hipMemcpy(ls->P, poison.data(), sizeof(double) * words, hipMemcpyHostToDevice));
+  ls->fl_epoch = 0;
+  ls->flow_enabled = false;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_linsolver_solve_status(hiopamd_linsolver* ls, int* ok_host)
+{
+  if(!ls || !ok_host) return HIOPAMD_ERR_ARG;
+  return flow_check(ls, ok_host);
+}
+
+int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  int ok = 1;
+  int rc = flow_check(ls, &ok);
+  if(rc != HIOPAMD_OK) return rc;
+  ls->flow_enabled = enable != 0;
+  return HIOPAMD_OK;
+}
+
 int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
 {
   if(!ls || !n_neg_host) return HIOPAMD_ERR_ARG;
   ls->factored = false;
+  {
+    int ok = 1;
+    int rcf = flow_check(ls, &ok);   // (no extra synchronisation when no dataflow solve ran since the last factorisation)
+    if(rcf != HIOPAMD_OK) return rcf;
+  }
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_FACT);   // hiopLinSolverSymDenseLapack.hpp:80-125 (tmFactTime; flopsFact = n^3/3)
   ls->flops_fact += (double)ls->n * ls->n * ls->n / 3.0;
   int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df);

@@ -54,8 +54,7 @@ struct DfArgs {
   int nchain;         // super-panels handled by the chain kernel
   int last_has_next;  // does the last chained super-panel have a (full) next one
   int64_t off_chain, off_tr, off_ver;
-  int dbg;            // TEMPORARY bring-up switch
-  int64_t off_dbg;    // TEMPORARY: progress words (16 chain roles, then the wide workgroups)
+  int dbg;            // != 0: record the per-super-panel time stamps (HIOPAMD_DF_STAMPS)
   int64_t off_ts;     // per super-panel 8 time stamps (100 MHz ticks, low 32 bits): see df_stamp
   const int4* ctasks;   // [2 variants][DF_ROLES][DF_MAXT]
   const int4* wtasks;
@@ -347,7 +346,6 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
       tk.w = __builtin_amdgcn_readfirstlane(tk.w);
       if(tk.x == DF_END) break;
       const int p = tk.y, ta = tk.z, tb = tk.w;
-      if(a.dbg && tid == 0) df_st(a.flags + a.off_dbg + role, (unsigned)(10000 * j + 100 * it + 10 * tk.x));
       DfWait w(a.flags + DF_ABORT);
       unsigned base;
       if(tk.x == DF_F) {
@@ -397,9 +395,9 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
         df_drain();
         if(tid == 0) df_add(v, 1u);
       }
+      __syncthreads();   // REQUIRED, see ldlt_wide_kernel: separates this task's lane-0 signalling from the next task's lane-0 polling
     }
   }
-  if(a.dbg && tid == 0) df_st(a.flags + a.off_dbg + role, 99999999u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -433,13 +431,17 @@ __device__ __forceinline__ void df_task_trsm(const DfArgs& a, int j, int c16, do
   for(int P = 0; P < 4; ++P) {
     const double* Dk = Dk_sp + P * (LD_nb * LD_nb);
     const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
-    double nl[3][4], iv[4];
+    // the factored diagonal block, its compact tiles and the 16 x 16 inverses are write-once data read after their flag:
+    // ordinary loads, issued unconditionally as one batch (a load per (J < I) test was a full round trip each)
+    double nl[3][4], iv[4], dsc[4];
+#pragma unroll
+    for(int r = 0; r < 4; ++r) dsc[r] = ld_batch(a.dinv + K0 + 64 * P + 16 * I + g + 4 * r);
 #pragma unroll
     for(int J = 0; J < 3; ++J)
 #pragma unroll
-      for(int kk = 0; kk < 4; ++kk) nl[J][kk] = (J < I) ? -ldg_sc1(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li) : 0.0;
+      for(int kk = 0; kk < 4; ++kk) nl[J][kk] = -ld_batch(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li);
 #pragma unroll
-    for(int kk = 0; kk < 4; ++kk) iv[kk] = ldg_sc1(Li + I * 256 + li * 16 + 4 * kk + g);
+    for(int kk = 0; kk < 4; ++kk) iv[kk] = ld_batch(Li + I * 256 + li * 16 + 4 * kk + g);
     double4_t u = t[P];
 #pragma unroll
     for(int q = 0; q < P; ++q) {
@@ -447,7 +449,7 @@ __device__ __forceinline__ void df_task_trsm(const DfArgs& a, int j, int c16, do
 #pragma unroll
       for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
-        for(int kk = 0; kk < 4; ++kk) Lop[Jq][kk] = -ldg_sc1(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (64 * P + 16 * I + li));
+        for(int kk = 0; kk < 4; ++kk) Lop[Jq][kk] = -ld_batch(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (64 * P + 16 * I + li));
 #pragma unroll
       for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
@@ -466,7 +468,7 @@ __device__ __forceinline__ void df_task_trsm(const DfArgs& a, int j, int c16, do
           Vs[row][li] = v[r];
           if(col_ok) {
             stg_sc1(Vb + (int64_t)row * a.ldv + col, v[r]);
-            stg_sc1(a.A + (int64_t)(K0 + row) * a.lda + col, v[r] * ldg_sc1(a.dinv + K0 + row));
+            stg_sc1(a.A + (int64_t)(K0 + row) * a.lda + col, v[r] * dsc[r]);
           }
         }
       }
@@ -582,9 +584,10 @@ __device__ __forceinline__ void df_task_tile(const DfArgs& a, int j, int I, int 
   }
 }
 
-__global__ __launch_bounds__(kBlock, 2) void ldlt_wide_kernel(const DfArgs a)
+constexpr int DF_WIDE_WG_PER_CU = 2;
+__global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(const DfArgs a)
 {
-  __shared__ double smem[4 * UD_KT * UD_LD];   // 73,728 B: the update's two double-buffered operand tiles / the substitution's V
+  __shared__ double smem[4 * UD_KT * UD_LD];   // 73,728 B: the update's two double-buffered operand tile pairs / the substitution's V
   __shared__ int sh_t, sh_ok;
   const int tid = threadIdx.x;
   const long long t_start = (long long)wall_clock64();
@@ -593,12 +596,7 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_wide_kernel(const DfArgs a)
     __syncthreads();
     const int t = __builtin_amdgcn_readfirstlane(sh_t);
     __syncthreads();
-    unsigned* dbgw = a.flags + a.off_dbg + 16 + blockIdx.x;
-    if(t >= a.nwtasks) {
-      if(a.dbg && tid == 0) df_st(dbgw, 99999999u);
-      return;
-    }
-    if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 1));
+    if(t >= a.nwtasks) return;
     int4 tk = a.wtasks[t];
     tk.x = __builtin_amdgcn_readfirstlane(tk.x);
     tk.y = __builtin_amdgcn_readfirstlane(tk.y);
@@ -615,20 +613,16 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_wide_kernel(const DfArgs a)
       w.set<2>(a.flags + a.off_ver + (int64_t)(2 * j + 1) * a.nt + J, (unsigned)j);
       if(j >= 2) w.set<3>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);   // V workspace parity
       if(!df_wait(a.flags, w, &sh_ok, t_start, 1, t, j, c16, J)) {
-        if(a.dbg && tid == 0) df_st(dbgw, 88888888u);
-        return;
+          return;
       }
-      if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 2));
       if(tid == 0) df_stamp(a, j, 4);
-      if(a.dbg != 4) df_task_trsm(a, j, c16, smem, tid);
-      if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 3));
+      df_task_trsm(a, j, c16, smem, tid);
       df_drain();
       if(tid == 0) df_add(trj + J, 1u);
       if(tid == 0) df_stamp(a, j, 5);
-      if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 4));
     } else {
       const int I = tk.z, J = tk.w;
-      auto groups = [&](int B) {   // 16-column groups of 128-block B inside the matrix
+      auto groups = [&](int B) {   // 16-column substitution tasks of 128-block B inside the matrix
         const int rem = a.N - UD_T * B;
         return (unsigned)((rem >= UD_T) ? 8 : (rem + 15) / 16);
       };
@@ -637,12 +631,10 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_wide_kernel(const DfArgs a)
       else w.set<1>(trj + I, groups(I));
       w.set<2>(trj + J, groups(J));
       if(!df_wait(a.flags, w, &sh_ok, t_start, 2, t, j, I, J)) {
-        if(a.dbg && tid == 0) df_st(dbgw, 88888888u);
-        return;
+          return;
       }
-      if(a.dbg && tid == 0) df_st(dbgw, (unsigned)(10 * t + 2));
       if(tid == 0) df_stamp(a, j, 6);
-      if(a.dbg != 5) df_task_tile(a, j, I, J, smem, tid);
+      df_task_tile(a, j, I, J, smem, tid);
       df_drain();
       if(tid == 0) {
         df_st(a.flags + a.off_ver + (int64_t)I * a.nt + J, (unsigned)(j + 1));
@@ -650,6 +642,11 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_wide_kernel(const DfArgs a)
         df_stamp(a, j, 7);
       }
     }
+    // REQUIRED: keeps the lane-0-only signalling block above and the lane-0-only ticket fetch at the loop top in separate
+    // regions.  Without a convergent operation between them the compiler threads the two `tid == 0` tests into one path,
+    // the loop gets two back-edges, LoopSimplify nests it, and lanes 1..63 of wave 0 run the ticket barriers once more
+    // than lane 0 does: the workgroup hangs at s_barrier (seen on ROCm 7.2 / gfx950, no bounded wait can catch it).
+    __syncthreads();
   }
 }
 

@@ -292,6 +292,14 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs);
 int hiopamd_linsolver_inertia(const hiopamd_linsolver* ls, int* pos_host, int* neg_host, int* zero_host);
 /* hiopLinSolStats::flopsFact / flopsTriuSolves (src/Utils/hiopRunStats.hpp:262-270), cumulative over the object's life:
  * n^3/3 per matrixChanged, 2 n^2 per right-hand side; the times are the HIOPAMD_SPAN_LINSOLV_* spans of the context */
+/* The triangular solves run as ONE dataflow launch (a task graph over the 256 x 256 blocks of U with inter-workgroup
+ * waits).  Every wait is bounded (2 s of wall-clock time); a time-out raises a device-side error word that the next
+ * synchronising call sees: hiopamd_linsolver_solve_status synchronises the context's stream and returns *ok_host = 0 if a
+ * solve since the last check was invalid (the object then re-initialises its exchange buffers and uses the stepwise
+ * 256-row solve from there on); matrixChanged performs the same check.  hiopamd_linsolver_set_solve_dataflow(ls, 0)
+ * selects the stepwise solve explicitly (HIOPAMD_SOLVE_FLOW=0 in the environment sets that default). */
+int hiopamd_linsolver_solve_status(hiopamd_linsolver* ls, int* ok_host);
+int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable);
 /* The factorisation runs as a dataflow of two persistent kernels (csrc/ldlt_dataflow.hpp) when the CU-masked streams are
  * available and n >= 768; enable = 0 selects the stepwise kernels (one launch per super-panel step) — same results to
  * rounding, for A/B timing and as a fallback.  HIOPAMD_DF=0 in the environment sets the default off. */

@@ -63,5 +63,9 @@ int main()
     run<4, 0>(512, 80000, d, "builtin");
     run<4, 1>(512, 80000, d, "asm +v");
   }
+  // sustained: ~0.5 s and ~2 s of back-to-back MFMAs on every CU (does the part hold its clock under fp64 matrix load?)
+  run<16, 0>(512, 600000, d, "builtin 0.5s");
+  run<16, 0>(512, 2400000, d, "builtin 2s");
+  run<16, 0>(480, 600000, d, "builtin 480wg");
   return 0;
 }
