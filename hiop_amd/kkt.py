@@ -250,9 +250,11 @@ class KKTLinSysLowRank:
 
     def update(self, zl, sxl, ixl, zu, sxu, ixu, vl, sdl, idl, vu, sdu, idu, Jc, Jd):
         args = [zl, sxl, ixl, zu, sxu, ixu, vl, sdl, idl, vu, sdu, idu, Jc, Jd]
+        self._jac = (Jc, Jd)      # the C object keeps these two pointers until the next update / set_jacobians
         check(self._L.hiopamd_kkt_lowrank_update(self.h, *[dptr(a) for a in args]), "hiopamd_kkt_lowrank_update")
 
     def update_diag(self, Dx, Dd, Jc, Jd):
+        self._jac = (Jc, Jd)
         check(self._L.hiopamd_kkt_lowrank_update_diag(self.h, dptr(Dx), dptr(Dd), dptr(Jc), dptr(Jd)),
               "hiopamd_kkt_lowrank_update_diag")
 
@@ -266,6 +268,7 @@ class KKTLinSysLowRank:
         check(self._L.hiopamd_kkt_lowrank_set_cache(self.h, 1 if enable else 0), "hiopamd_kkt_lowrank_set_cache")
 
     def set_jacobians(self, Jc, Jd):
+        self._jac = (Jc, Jd)
         check(self._L.hiopamd_kkt_lowrank_set_jacobians(self.h, dptr(Jc), dptr(Jd)), "hiopamd_kkt_lowrank_set_jacobians")
 
     def N(self) -> torch.Tensor:

@@ -13,12 +13,23 @@ import torch
 from ._lib import lib, check
 
 
+_LIVE_STREAMS = {}    # id(Context) -> torch.cuda.ExternalStream of every live context
+
+
 def dptr(t) -> C.c_void_p:
-    """Raw device (or host) address of a torch tensor / numpy array / None."""
+    """Raw device (or host) address of a torch tensor / numpy array / None.
+
+    The C ABI is asynchronous on the context's own stream, which torch's caching allocator knows nothing about: a device
+    temporary released right after the call would be recycled for the next allocation while the call's kernels are still
+    queued.  `record_stream` tells the allocator about the foreign use, so the block is only reused once the work queued
+    on the context stream at release time has finished."""
     if t is None:
         return C.c_void_p(0)
     if isinstance(t, torch.Tensor):
         assert t.is_contiguous()
+        if t.is_cuda:
+            for st in _LIVE_STREAMS.values():
+                t.record_stream(st)
         return C.c_void_p(t.data_ptr())
     if isinstance(t, np.ndarray):
         assert t.flags["C_CONTIGUOUS"]
@@ -48,6 +59,7 @@ class Context:
         self.stream_ptr = self._L.hiopamd_ctx_stream(self.h)
         self.torch_stream = torch.cuda.ExternalStream(self.stream_ptr)
         self._children = []   # weakrefs of objects holding C handles that reference this context
+        _LIVE_STREAMS[id(self)] = self.torch_stream
 
     def _register(self, obj):
         import weakref
@@ -64,6 +76,7 @@ class Context:
                 if o is not None:
                     o.close()
             self._children = []
+            _LIVE_STREAMS.pop(id(self), None)
             self._L.hiopamd_ctx_destroy(self.h)
             self.h = None
 

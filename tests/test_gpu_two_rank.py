@@ -129,14 +129,19 @@ def test_cached_N_is_bit_identical(ctx):
         outs = []
         for it in range(5):
             x = prob["xs"][it]
+            # device temporaries must outlive the asynchronous calls that read them (see tests/two_rank_worker.py)
+            args = [D(x), D(prob["q"] * x), Jc, Jd, D(prob["ycs"][it]), D(prob["yds"][it])]
+            diag = [D(prob["Dx"] * (1.0 + 0.1 * it)), D(prob["Dd"])]
             torch.cuda.synchronize()
-            H.update(D(x), D(prob["q"] * x), Jc, Jd, D(prob["ycs"][it]), D(prob["yds"][it]))
-            K.update_diag(D(prob["Dx"] * (1.0 + 0.1 * it)), D(prob["Dd"]), Jc, Jd)
+            H.update(*args)
+            K.update_diag(diag[0], diag[1], Jc, Jd)
+            ctx.sync()
             for s in range(3):
                 rx = D(prob["rx"] * (s + 1.0))
                 dx, dyc, dyd = D(np.zeros(n)), D(np.zeros(me)), D(np.zeros(mi))
+                rr = [D(prob["ryc"]), D(prob["ryd"] + s)]
                 torch.cuda.synchronize()
-                assert K.solve_compressed(rx, D(prob["ryc"]), D(prob["ryd"] + s), dx, dyc, dyd)
+                assert K.solve_compressed(rx, rr[0], rr[1], dx, dyc, dyd)
                 ctx.sync()
                 outs.append((dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy(), K.N().cpu().numpy()))
             if it == 2:   # Jacobian values changed in place + set_jacobians: the cache must not survive
@@ -144,8 +149,9 @@ def test_cached_N_is_bit_identical(ctx):
                 torch.cuda.synchronize()
                 K.set_jacobians(Jc, Jd)
                 dx, dyc, dyd = D(np.zeros(n)), D(np.zeros(me)), D(np.zeros(mi))
+                rr = [D(prob["rx"]), D(prob["ryc"]), D(prob["ryd"])]
                 torch.cuda.synchronize()
-                assert K.solve_compressed(D(prob["rx"]), D(prob["ryc"]), D(prob["ryd"]), dx, dyc, dyd)
+                assert K.solve_compressed(rr[0], rr[1], rr[2], dx, dyc, dyd)
                 ctx.sync()
                 outs.append((dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy(), K.N().cpu().numpy()))
         K.close(); H.close()

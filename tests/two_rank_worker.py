@@ -76,16 +76,25 @@ def run_partition(ctx, prob, sl, tiny_slack_at=None):
     H = HessianLowRank(ctx, nl, me, mi, l_max=6, sigma0=1.0, sigma_update_strategy="sty")
     stored = []
     for it, x in enumerate(prob["xs"]):
+        args = [D(x[sl]), D((prob["q"] * x)[sl]), Jc, Jd, D(prob["ycs"][it]), D(prob["yds"][it])]
         torch.cuda.synchronize()
-        stored.append(H.update(D(x[sl]), D((prob["q"] * x)[sl]), Jc, Jd, D(prob["ycs"][it]), D(prob["yds"][it])))
+        stored.append(H.update(*args))
         ctx.sync()
+        del args
     K = KKTLinSysLowRank(ctx, H)
+    # NOTE: the C ABI is asynchronous on the context's stream.  Device temporaries handed to a call must outlive the kernels
+    # that read them: keep them in variables and synchronise before they are released (torch's caching allocator would
+    # recycle the block for the next upload while the kernels of the call are still queued — with two processes sharing
+    # the GPU that window is wide, and 1 / Dd was once computed from the bytes of the next test vector).
+    Dx_d, Dd_d = D(prob["Dx"][sl]), D(prob["Dd"])
     torch.cuda.synchronize()
-    K.update_diag(D(prob["Dx"][sl]), D(prob["Dd"]), Jc, Jd)
+    K.update_diag(Dx_d, Dd_d, Jc, Jd)
+    ctx.sync()
     rx = D(prob["rx"][sl])
     dx, dyc, dyd = D(np.zeros(nl)), D(np.zeros(me)), D(np.zeros(mi))
+    ryc_d, ryd_d = D(prob["ryc"]), D(prob["ryd"])
     torch.cuda.synchronize()
-    ok = K.solve_compressed(rx, D(prob["ryc"]), D(prob["ryd"]), dx, dyc, dyd)
+    ok = K.solve_compressed(rx, ryc_d, ryd_d, dx, dyc, dyd)
     ctx.sync()
     out = dict(stored=stored, sigma=H.sigma, ok=ok, dx=dx.cpu().numpy(), dyc=dyc.cpu().numpy(), dyd=dyd.cpu().numpy(),
                N=K.N().cpu().numpy())
