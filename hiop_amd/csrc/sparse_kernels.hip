@@ -229,6 +229,27 @@ static int upload(T** d, const std::vector<T>& h)
 
 using namespace hiopamd;
 
+namespace {
+struct PredUnordered {   // hiopMatrixSparseTriplet::checkIndexesAreOrdered :377-388
+  const int *i, *j;
+  __device__ bool operator()(int64_t k) const
+  {
+    return k > 0 && (i[k] < i[k - 1] || (i[k] == i[k - 1] && j[k] < j[k - 1]));
+  }
+};
+struct PredOffDiag {     // is_diagonal :1338-1353 / hiopMatrixSymSparseTriplet::numberOfOffDiagNonzeros :1171-1183
+  const int *i, *j;
+  __device__ bool operator()(int64_t k) const { return i[k] != j[k]; }
+};
+template <class Pred>
+struct OpCountSp {
+  Pred p;
+  __device__ double identity() const { return 0.0; }
+  __device__ double map(int64_t i) const { return p(i) ? 1.0 : 0.0; }
+  __device__ double combine(double a, double b) const { return a + b; }
+};
+}  // namespace
+
 extern "C" {
 
 int hiopamd_sp_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
@@ -445,6 +466,76 @@ int hiopamd_spsym_add_upper_to_sym_upper(hiopamd_ctx* ctx, int nnz, const int* i
                      diag_start, alpha, W, ldw);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
+}
+
+/* ---- the rest of the hiopMatrixSparseTriplet surface used outside the Schur build (one thread per triplet) ---- */
+// block of W += alpha*this^T, destination inside the upper triangle (hiopMatrixSparseTriplet.cpp:255-275)
+int hiopamd_sp_trans_add_to_sym_upper(hiopamd_ctx* ctx, int nnz, const int* iRow, const int* jCol, const double* val,
+                                      int row_start, int col_start, double alpha, double* W, int64_t ldw)
+{
+  if(nnz < 0 || row_start < 0 || col_start < 0) return HIOPAMD_ERR_ARG;
+  // entries of one triplet matrix are distinct (i,j) pairs: no two threads touch the same W element
+  return hiopamd::launch_ew(ctx, nnz, [=] __device__(int64_t k) {
+    W[(int64_t)(jCol[k] + row_start) * ldw + (iRow[k] + col_start)] += alpha * val[k];
+  });
+}
+// ret[i] = max_k |val[k]| over the triplets of row i, 0 for an empty row (:285-300).  |v| >= 0, so the IEEE bit pattern
+// orders like an unsigned integer and a 64-bit atomic max is exact and order-independent.
+int hiopamd_sp_row_max_abs(hiopamd_ctx* ctx, int nrows, int nnz, const int* iRow, const double* val, double* ret)
+{
+  if(nrows < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
+  int st = hiopamd::launch_ew(ctx, nrows, [=] __device__(int64_t i) { ret[i] = 0.0; });
+  if(st != HIOPAMD_OK) return st;
+  unsigned long long* r = reinterpret_cast<unsigned long long*>(ret);
+  return hiopamd::launch_ew(ctx, nnz, [=] __device__(int64_t k) {
+    const double a = fabs(val[k]);
+    if(a == a) atomicMax(&r[iRow[k]], (unsigned long long)__double_as_longlong(a));
+  });
+}
+// val[k] *= scal[iRow[k]]  or  *= 1/scal[iRow[k]]  (:303-319)
+int hiopamd_sp_scale_rows(hiopamd_ctx* ctx, int nnz, const int* iRow, double* val, const double* scal, int inv)
+{
+  if(nnz < 0) return HIOPAMD_ERR_ARG;
+  if(inv) return hiopamd::launch_ew(ctx, nnz, [=] __device__(int64_t k) { val[k] *= 1.0 / scal[iRow[k]]; });
+  return hiopamd::launch_ew(ctx, nnz, [=] __device__(int64_t k) { val[k] *= scal[iRow[k]]; });
+}
+// W = dense(this)  (:363-374; duplicates, if any, accumulate like the reference's +=)
+int hiopamd_sp_copy_to_dense(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
+                             const double* val, double* W, int64_t ldw)
+{
+  if(nrows < 0 || ncols < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
+  int st = hiopamd_mat_set_to_constant(ctx, nrows, ncols, W, ldw, 0.0);
+  if(st != HIOPAMD_OK) return st;
+  return hiopamd::launch_ew(ctx, nnz, [=] __device__(int64_t k) {
+    atomicAdd(&W[(int64_t)iRow[k] * ldw + jCol[k]], val[k]);
+  });
+}
+int hiopamd_sp_indexes_ordered(hiopamd_ctx* ctx, int nnz, const int* iRow, const int* jCol, int* out_host)
+{
+  if(nnz < 0 || !out_host) return HIOPAMD_ERR_ARG;
+  double c = 0.0;
+  int st = hiopamd::launch_reduce<double>(ctx, nnz, OpCountSp<PredUnordered>{{iRow, jCol}}, &c);
+  *out_host = (c == 0.0);
+  return st;
+}
+int hiopamd_sp_num_offdiag(hiopamd_ctx* ctx, int nnz, const int* iRow, const int* jCol, int64_t* out_host)
+{
+  if(nnz < 0 || !out_host) return HIOPAMD_ERR_ARG;
+  double c = 0.0;
+  int st = hiopamd::launch_reduce<double>(ctx, nnz, OpCountSp<PredOffDiag>{{iRow, jCol}}, &c);
+  *out_host = (int64_t)c;
+  return st;
+}
+// diag[i] = this[i][i] (0 when absent)  (:1355-1372)
+int hiopamd_sp_extract_diagonal(hiopamd_ctx* ctx, int n, int nnz, const int* iRow, const int* jCol, const double* val,
+                                double* diag)
+{
+  if(n < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
+  int st = hiopamd::launch_ew(ctx, n, [=] __device__(int64_t i) { diag[i] = 0.0; });
+  if(st != HIOPAMD_OK) return st;
+  return hiopamd::launch_ew(ctx, nnz, [=] __device__(int64_t k) {
+    if(iRow[k] == jCol[k]) diag[iRow[k]] = val[k];
+  });
 }
 
 }  // extern "C"

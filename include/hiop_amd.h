@@ -271,6 +271,18 @@ int hiopamd_spsym_times_vec(hiopamd_ctx*, int n, int nnz, const int* iRow, const
 int hiopamd_spsym_add_upper_to_sym_upper(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, const double* val,
                                          int diag_start, double alpha, double* W, int64_t ldw);
 
+/* the rest of the hiopMatrixSparseTriplet surface (one thread per triplet; used by the HiOp-side adapter) */
+int hiopamd_sp_trans_add_to_sym_upper(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, const double* val,
+                                      int row_start, int col_start, double alpha, double* W, int64_t ldw);   /* :255 */
+int hiopamd_sp_row_max_abs(hiopamd_ctx*, int nrows, int nnz, const int* iRow, const double* val, double* ret_vec); /* :285 */
+int hiopamd_sp_scale_rows(hiopamd_ctx*, int nnz, const int* iRow, double* val, const double* scal, int inv);  /* :303 */
+int hiopamd_sp_copy_to_dense(hiopamd_ctx*, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
+                             const double* val, double* W, int64_t ldw);                                      /* :363 */
+int hiopamd_sp_indexes_ordered(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, int* out_host);        /* :377 */
+int hiopamd_sp_num_offdiag(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, int64_t* out_host);        /* :1171,:1338 */
+int hiopamd_sp_extract_diagonal(hiopamd_ctx*, int n, int nnz, const int* iRow, const int* jCol, const double* val,
+                                double* diag);                                                                /* :1355 */
+
 /* =====================================================================================
  * hiopLinSolverSymDense operator — no-pivot blocked LDL^T on fp64 MFMA + inertia
  * (reference: src/LinAlg/hiopLinSolver.hpp:78-130; semantics of

@@ -295,6 +295,42 @@ def spsym_add_diag_to_vec(iRow, jCol, val, alpha, y, vec_start, diag_src_start=0
     np.add.at(y, vec_start + iRow[m], alpha * val[m])
 
 
+def sp_trans_add_to_sym_upper(iRow, jCol, val, row_start, col_start, alpha, W):                    # :255
+    """W[row_start + j, col_start + i] += alpha * M[i, j] (the destination must be inside the upper triangle)."""
+    assert np.all(jCol + row_start <= iRow + col_start)
+    np.add.at(W, (jCol + row_start, iRow + col_start), alpha * val)
+
+
+def sp_row_max_abs(nrows, iRow, val):                                                               # :285
+    ret = np.zeros(nrows)
+    np.maximum.at(ret, iRow, np.abs(val))
+    return ret
+
+
+def sp_scale_rows(iRow, val, scal, inv):                                                            # :303
+    val *= (1.0 / scal[iRow]) if inv else scal[iRow]
+
+
+def sp_copy_to_dense(nrows, ncols, iRow, jCol, val):                                                # :363
+    return _to_dense(nrows, ncols, iRow, jCol, val)
+
+
+def sp_indexes_ordered(iRow, jCol):                                                                 # :377
+    for k in range(1, iRow.size):
+        if iRow[k] < iRow[k - 1] or (iRow[k] == iRow[k - 1] and jCol[k] < jCol[k - 1]):
+            return False
+    return True
+
+
+def sp_times_mat_trans(m1, m2, ncols, i1, j1, v1, i2, j2, v2, beta, W, alpha):                      # :144
+    """W = beta*W + alpha * M1 * M2^T (both sparse, W dense m1 x m2)."""
+    import scipy.sparse as sp
+    M1 = sp.csr_matrix((v1, (i1, j1)), shape=(m1, ncols))
+    M2 = sp.csr_matrix((v2, (i2, j2)), shape=(m2, ncols))
+    W *= beta
+    W += alpha * (M1 @ M2.T).toarray()
+
+
 # =====================================================================================
 # hiopLinSolverSymDenseLapack (reference: src/LinAlg/hiopLinSolverSymDenseLapack.hpp:75-195)
 # =====================================================================================

@@ -280,3 +280,69 @@ def test_symsparse_diag_ops(ctx):
     run(ctx, "hiopamd_spsym_add_upper_to_sym_upper", v.size, D(i, torch.int32), D(j, torch.int32), D(v), 2, -1.0, Wd, n + 3)
     e = W.copy(); np.add.at(e, (i + 2, j + 2), -v)
     np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-15, atol=1e-16)
+
+
+@pytest.mark.parametrize("m,n,dens", [(1, 1, 1.0), (40, 80, 0.1), (300, 1000, 0.01), (64, 64, 0.0), (500, 20, 0.3)])
+def test_triplet_surface_outside_the_schur_build(ctx, m, n, dens):
+    """transAddToSymDenseMatrixUpperTriangle :255, row_max_abs_value :285, scale_row :303, copy_to(dense) :363,
+    checkIndexesAreOrdered :377, is_diagonal :1338, extract_diagonal :1355 of hiopMatrixSparseTriplet.cpp.
+    Bit-exact: each output element receives at most one product / is a max."""
+    r = rng(7 * m + n)
+    i, j, v = _rand_sparse(r, m, n, dens)
+    v = v * r.choice([-1.0, 1.0], v.size)
+    id_, jd, vd = D(i, torch.int32), D(j, torch.int32), D(v)
+    nnz = v.size
+    # W (n+m+3)^2, destination block rows [1, 1+n) x cols [n+2, n+2+m): strictly above the diagonal
+    nW = n + m + 3
+    W = r.uniform(-1, 1, (nW, nW))
+    Wd = D(W)
+    run(ctx, "hiopamd_sp_trans_add_to_sym_upper", nnz, id_, jd, vd, 1, n + 2, -0.75, Wd, nW)
+    e = W.copy(); ho.sp_trans_add_to_sym_upper(i, j, v, 1, n + 2, -0.75, e)
+    assert np.array_equal(Wd.cpu().numpy(), e)
+    # row max
+    ret = D(r.uniform(5, 6, m))     # must be overwritten, also for empty rows
+    run(ctx, "hiopamd_sp_row_max_abs", m, nnz, id_, vd, ret)
+    assert np.array_equal(ret.cpu().numpy(), ho.sp_row_max_abs(m, i, v))
+    # scale rows, both directions
+    sc = r.uniform(0.5, 2.0, m)
+    for inv in (0, 1):
+        v2 = D(v)
+        run(ctx, "hiopamd_sp_scale_rows", nnz, id_, v2, D(sc), inv)
+        e = v.copy(); ho.sp_scale_rows(i, e, sc, inv)
+        assert np.array_equal(v2.cpu().numpy(), e)
+    # densify
+    Md = D(r.uniform(-1, 1, (m, n + 2)))
+    run(ctx, "hiopamd_sp_copy_to_dense", m, n, nnz, id_, jd, vd, Md, n + 2)
+    assert np.array_equal(Md.cpu().numpy()[:, :n], ho.sp_copy_to_dense(m, n, i, j, v))
+    # ordering / diagonal queries
+    assert ctx.reduce_int("hiopamd_sp_indexes_ordered", nnz, id_, jd) == 1
+    if nnz >= 2:
+        assert ctx.reduce_int("hiopamd_sp_indexes_ordered", nnz, D(i[::-1].copy(), torch.int32), D(j[::-1].copy(), torch.int32)) == \
+            int(ho.sp_indexes_ordered(i[::-1], j[::-1]))
+    assert ctx.reduce_int64("hiopamd_sp_num_offdiag", nnz, id_, jd) == int(np.sum(i != j))
+    k = min(m, n)
+    dg = D(r.uniform(5, 6, k))
+    inside = (i < k) & (j < k)
+    run(ctx, "hiopamd_sp_extract_diagonal", k, int(inside.sum()), D(i[inside], torch.int32), D(j[inside], torch.int32),
+        D(v[inside]), dg)
+    assert np.array_equal(dg.cpu().numpy(), np.diag(ho.sp_copy_to_dense(m, n, i, j, v))[:k])
+
+
+def test_triplet_times_mat_trans_through_the_plan(ctx):
+    """hiopMatrixSparseTriplet::timesMatTrans :144-201 = scale W, then the Schur row-build with D = ones (what the HiOp-side
+    adapter does)."""
+    r = rng(3)
+    m1, m2, n = 37, 11, 300
+    i1, j1, v1 = _rand_sparse(r, m1, n, 0.08)
+    i2, j2, v2 = _rand_sparse(r, m2, n, 0.2)
+    L = ctx._L
+    plan = C.c_void_p()
+    assert L.hiopamd_sp_plan_create(C.byref(plan), m1, m2, n, v1.size, i1.ctypes.data, j1.ctypes.data, v2.size,
+                                    i2.ctypes.data, j2.ctypes.data, 0) == 0
+    W = r.uniform(-1, 1, (m1, m2))
+    Wd = D(W)
+    run(ctx, "hiopamd_vec_scale", m1 * m2, Wd, 0.5)
+    run(ctx, "hiopamd_sp_add_MDinvNt", plan, D(v1), D(v2), D(np.ones(n)), -2.0, Wd, m2, 0, 0)
+    e = W.copy(); ho.sp_times_mat_trans(m1, m2, n, i1, j1, v1, i2, j2, v2, 0.5, e, -2.0)
+    np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-13, atol=1e-14)
+    L.hiopamd_sp_plan_destroy(plan)
