@@ -1807,7 +1807,8 @@ struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
   int64_t off_chain = 0, off_tr = 0, off_ver = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
-  std::vector<unsigned> upcnt;
+  std::vector<unsigned> upcnt, wfirst;
+  std::vector<int4> wq;
   double up_flops = 0.0;   // algorithmic flops of the UP tasks (2 K per updated element)
 };
 static DfPlan df_build_plan(int N)
@@ -1830,32 +1831,42 @@ static DfPlan df_build_plan(int N)
   P.off_chain = DF_HDR;
   P.off_tr = P.off_chain + (int64_t)(P.nsp + 1) * DF_CH;
   P.off_ver = P.off_tr + (int64_t)P.nsp * P.nt;
-  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1);   // (+ the profiling stamps)
+  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 16;   // (+ the profiling stamps and phase sums)
   std::vector<int4> t0, t1;
   df_chain_tasks(true, t0);
   df_chain_tasks(false, t1);
   P.ctasks = t0;
   P.ctasks.insert(P.ctasks.end(), t1.begin(), t1.end());
   P.upcnt.assign((size_t)P.nsp + 1, 0u);
-  auto emit_tr = [&](int j) {
-    for(int c = LD_NB * (j + 2); c < N; c += 16) P.wtasks.push_back(make_int4(DF_TR, j, c, 0));
-  };
+  // wide-kernel queues: TR tasks grouped by super-panel, then UP tasks grouped by super-panel with the two tile rows of the
+  // next row panel first (csrc/ldlt_dataflow.hpp: ldlt_wide_kernel)
+  std::vector<int4> trq, upq;
+  std::vector<int4> wq((size_t)P.nwide + 1, make_int4(0, 0, 0, 0));
+  P.wfirst.assign((size_t)P.nwide + 1, 0u);
   auto emit_up = [&](int j, int I) {
     for(int J = (I < 2 * j + 4) ? 2 * j + 4 : I; J < P.nt; ++J) {
-      P.wtasks.push_back(make_int4(DF_UP, j, I, J));
+      upq.push_back(make_int4(DF_UP, j, I, J));
       P.upcnt[j] += 1u;
       // rows r in tile I, columns max(r, 128 J) .. of tile J, inside the matrix
       const int r0 = UD_T * I, r1 = std::min(N, r0 + UD_T), c0 = UD_T * J, c1 = std::min(N, c0 + UD_T);
       for(int r = r0; r < r1; ++r) P.up_flops += 2.0 * LD_NB * (double)std::max(0, c1 - std::max(c0, r));
     }
   };
-  if(P.nwide > 0) emit_tr(0);
   for(int j = 0; j < P.nwide; ++j) {
+    wq[j].x = (int)trq.size();
+    for(int c = LD_NB * (j + 2); c < N; c += 16) trq.push_back(make_int4(DF_TR, j, c, 0));
+    wq[j].y = (int)trq.size() - wq[j].x;
+    wq[j].z = (int)upq.size();
     emit_up(j, 2 * j + 2);
     if(2 * j + 3 < P.nt) emit_up(j, 2 * j + 3);
-    if(j + 1 < P.nwide) emit_tr(j + 1);   // the next row panel, as soon as its rows are updated
+    P.wfirst[j] = (unsigned)((int)upq.size() - wq[j].z);
     for(int I = 2 * j + 4; I < P.nt; ++I) emit_up(j, I);
+    wq[j].w = (int)upq.size() - wq[j].z;
   }
+  for(int j = 0; j < P.nwide; ++j) wq[j].z += (int)trq.size();
+  P.wtasks = trq;
+  P.wtasks.insert(P.wtasks.end(), upq.begin(), upq.end());
+  P.wq = wq;
   return P;
 }
 
@@ -1865,6 +1876,8 @@ struct DfDevice {
   int4* ctasks = nullptr;
   int4* wtasks = nullptr;
   unsigned* upcnt = nullptr;
+  int4* wq = nullptr;
+  unsigned* wfirst = nullptr;
   bool enabled = true;
 };
 
@@ -2000,19 +2013,25 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.flags = df->flags; a.nsp = P.nsp; a.nt = P.nt; a.nchain = P.nchain; a.last_has_next = P.last_has_next;
     a.off_chain = P.off_chain; a.off_tr = P.off_tr; a.off_ver = P.off_ver;
     a.ctasks = df->ctasks; a.wtasks = df->wtasks; a.nwtasks = (int)P.wtasks.size(); a.upcnt = df->upcnt;
+    a.wq = df->wq; a.wfirst = df->wfirst; a.nwide = P.nwide;
     HIOPAMD_CHECK(hipMemsetAsync(df->flags, 0, sizeof(unsigned) * (size_t)P.nflags, st));
     hipLaunchKernelGGL(ldlt_df_init_kernel, dim3(1), dim3(kBlock), 0, st, a);
     int rc = dep(st, su);
     if(rc == HIOPAMD_OK) rc = dep(st, sd);
     if(rc != HIOPAMD_OK) return rc;
-    a.dbg = std::getenv("HIOPAMD_DF_STAMPS") ? 1 : 0;   // profiling aid: per-super-panel time stamps, printed after the call
+    a.dbg = std::getenv("HIOPAMD_DF_STAMPS") ? std::max(1, std::atoi(std::getenv("HIOPAMD_DF_STAMPS"))) : 0;   // profiling aid (1: all panels; 2 + j: phase sums of super-panel j only): per-super-panel time stamps, printed after the call
     a.off_ts = P.off_ver + (int64_t)P.nt * P.nt;
+    a.off_ph = a.off_ts + 8 * (int64_t)(P.nsp + 1);
     hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
     if(a.nwtasks > 0) {
       if(timed) (void)hipEventRecord(prof->get(), su);
       const int wmax = 240 * DF_WIDE_WG_PER_CU;   // the resident workgroups of the 240 CUs of the wide stream
       const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
-      hipLaunchKernelGGL(ldlt_wide_kernel, dim3(grid), dim3(kBlock), 0, su, a);
+      // 16-byte accesses need even N, lda, ldv (ldv = N); HIOPAMD_DF_TILE=1 forces the 8-byte form (A/B timing)
+      static const int tile_env = std::getenv("HIOPAMD_DF_TILE") ? std::atoi(std::getenv("HIOPAMD_DF_TILE")) : 2;
+      const bool form2 = tile_env != 1 && (N % 2 == 0) && (lda % 2 == 0) && (ldv % 2 == 0) && N >= 2 * UD_T;
+      if(form2) hipLaunchKernelGGL(ldlt_wide_kernel<2>, dim3(grid), dim3(kBlock), 0, su, a);
+      else hipLaunchKernelGGL(ldlt_wide_kernel<1>, dim3(grid), dim3(kBlock), 0, su, a);
       if(timed) {
         (void)hipEventRecord(prof->get(), su);
         prof->flops += P.up_flops;
@@ -2102,6 +2121,17 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       auto us = [&](int k) { const unsigned v = ts[(size_t)8 * j + k]; return v == 0 ? -1.0 : ((k & 1) ? (double)(v - t0) : (double)((0xffffffffu - v) - t0)) * 0.01; };
       std::fprintf(stderr, "  %2d | %8.1f %8.1f | %8.1f | %8.1f %8.1f | %8.1f %8.1f\n", j, us(0), us(1), us(3), us(4), us(5), us(6), us(7));
     }
+  }
+  if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
+    const DfPlan& P = df->plan;
+    unsigned ph[16];
+    (void)hipMemcpy(ph, df->flags + P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1), sizeof(ph), hipMemcpyDeviceToHost);
+    const double nup = ph[7] ? ph[7] : 1, ntr = ph[8] ? ph[8] : 1, ntask = nup + ntr;
+    std::fprintf(stderr,
+                 "[hiop_amd] wide kernel phases, mean us per task: ticket+decode %.2f | TR(%u): wait %.2f body %.2f publish %.2f | "
+                 "UP(%u): wait %.2f body %.2f [prologue %.2f stages %.2f epilogue %.2f] publish %.2f\n",
+                 ph[0] * 0.01 / ntask, ph[8], ph[1] * 0.01 / ntr, ph[2] * 0.01 / ntr, ph[3] * 0.01 / ntr, ph[7], ph[4] * 0.01 / nup,
+                 ph[5] * 0.01 / nup, ph[9] * 0.01 / nup, ph[10] * 0.01 / nup, (ph[5] - ph[9] - ph[10]) * 0.01 / nup, ph[6] * 0.01 / nup);
   }
   if(dfw[DF_ABORT]) {
     std::fprintf(stderr,
@@ -2299,6 +2329,10 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
       if(!P.wtasks.empty())
         HIOPAMD_CHECK(hipMemcpy(df.wtasks, P.wtasks.data(), sizeof(int4) * P.wtasks.size(), hipMemcpyHostToDevice));
       HIOPAMD_CHECK(hipMemcpy(df.upcnt, P.upcnt.data(), sizeof(unsigned) * P.upcnt.size(), hipMemcpyHostToDevice));
+      HIOPAMD_CHECK(hipMalloc((void**)&df.wq, sizeof(int4) * P.wq.size()));
+      HIOPAMD_CHECK(hipMalloc((void**)&df.wfirst, sizeof(unsigned) * P.wfirst.size()));
+      HIOPAMD_CHECK(hipMemcpy(df.wq, P.wq.data(), sizeof(int4) * P.wq.size(), hipMemcpyHostToDevice));
+      HIOPAMD_CHECK(hipMemcpy(df.wfirst, P.wfirst.data(), sizeof(unsigned) * P.wfirst.size(), hipMemcpyHostToDevice));
     }
   }
   ls->flow_enabled = !(std::getenv("HIOPAMD_SOLVE_FLOW") && std::atoi(std::getenv("HIOPAMD_SOLVE_FLOW")) == 0);
@@ -2324,6 +2358,8 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->df.ctasks);
   (void)hipFree(ls->df.wtasks);
   (void)hipFree(ls->df.upcnt);
+  (void)hipFree(ls->df.wq);
+  (void)hipFree(ls->df.wfirst);
   delete ls;
   return HIOPAMD_OK;
 }
@@ -2449,6 +2485,18 @@ int hiopamd_ldlt_dataflow_plan(int n, int* dims8_host, int* chain_tasks_host, in
       wide_tasks_host[4 * i] = P.wtasks[i].x; wide_tasks_host[4 * i + 1] = P.wtasks[i].y;
       wide_tasks_host[4 * i + 2] = P.wtasks[i].z; wide_tasks_host[4 * i + 3] = P.wtasks[i].w;
     }
+  }
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ldlt_dataflow_queues(int n, int* queues_host, int cap_panels)
+{
+  if(n < 0 || !queues_host) return HIOPAMD_ERR_ARG;
+  const DfPlan P = df_build_plan(n);
+  if(P.nwide > cap_panels) return HIOPAMD_ERR_ARG;
+  for(int j = 0; j < P.nwide; ++j) {
+    queues_host[5 * j] = P.wq[j].x; queues_host[5 * j + 1] = P.wq[j].y; queues_host[5 * j + 2] = P.wq[j].z;
+    queues_host[5 * j + 3] = P.wq[j].w; queues_host[5 * j + 4] = (int)P.wfirst[j];
   }
   return HIOPAMD_OK;
 }

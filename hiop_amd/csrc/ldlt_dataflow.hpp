@@ -56,10 +56,14 @@ struct DfArgs {
   int64_t off_chain, off_tr, off_ver;
   int dbg;            // != 0: record the per-super-panel time stamps (HIOPAMD_DF_STAMPS)
   int64_t off_ts;     // per super-panel 8 time stamps (100 MHz ticks, low 32 bits): see df_stamp
+  int64_t off_ph;     // 16 words: phase accounting of the wide kernel (summed 100 MHz ticks / task counts), a.dbg != 0 only
   const int4* ctasks;   // [2 variants][DF_ROLES][DF_MAXT]
-  const int4* wtasks;
+  const int4* wtasks;      // TR tasks grouped by super-panel, then UP tasks grouped by super-panel (first two tile rows first)
   int nwtasks;
   const unsigned* upcnt;   // UP tasks per super-panel
+  const int4* wq;          // per super-panel {first TR task, TR tasks, first UP task, UP tasks} in wtasks
+  const unsigned* wfirst;  // per super-panel: UP tasks of its first two tile rows (the rows of the next row panel)
+  int nwide;               // super-panels with wide-kernel work
 };
 
 __device__ __forceinline__ unsigned df_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -107,9 +111,12 @@ __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* s
   if(threadIdx.x == 0) {
     int ok = 1;
     unsigned spins = 0;
+    // all four polls in flight at once: the common case (everything already satisfied) costs one round trip, not four
+    const unsigned g0 = df_ld(w.f[0]), g1 = df_ld(w.f[1]), g2 = df_ld(w.f[2]), g3 = df_ld(w.f[3]);
+    const bool all_there = g0 >= w.v[0] && g1 >= w.v[1] && g2 >= w.v[2] && g3 >= w.v[3];
 #pragma unroll
     for(int q = 0; q < 4; ++q) {   // unrolled: the pairs stay in registers (a runtime index would put them in scratch)
-      if(ok) {
+      if(ok && !all_there) {
         while(df_ld(w.f[q]) < w.v[q]) {
           __builtin_amdgcn_s_sleep(16);
           if((++spins & 31u) == 0) {
@@ -584,44 +591,324 @@ __device__ __forceinline__ void df_task_tile(const DfArgs& a, int j, int I, int 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Trailing-update tile, second form (even N, lda, ldv): the same 128 x 128 x 256 product, with everything around the MFMAs
+// cut down —
+//   * the C tile is loaded INTO the accumulators before the first stage and U is negated on its way into LDS:
+//     acc = C + V^T (-U), so the epilogue is 32 stores per lane instead of four exposed load -> subtract -> store rounds;
+//   * every global access is a 16-byte `sc1` buffer operation (8-byte sc1 accesses run at 0.54-0.70x (loads) and 1/2.7
+//     (stores) of the 16-byte rate per byte, MI355X_MICROARCH.md): the rows / columns of the wave's 64 x 64 block are dealt
+//     to the MFMA tiles so that tile pairs (2h, 2h+1) own ADJACENT rows (A operand, one ds_read_b128 per pair) and adjacent
+//     columns (B operand and C: one 16-byte access per pair);
+//   * addresses = descriptor (SGPR) + per-lane offset fixed for the whole tile + scalar offset: no 64-bit VALU in the loop.
+// element (i, q, reg) of the accumulators  <->  row  wr*64 + 32*(i>>1) + 2*(lk + 4*reg) + (i&1),
+//                                               col  wc*64 + 32*(q>>1) + 2*li + (q&1)   of the tile.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned int df_u32x4 __attribute__((ext_vector_type(4)));
+typedef double df_double2 __attribute__((ext_vector_type(2)));
+typedef unsigned int df_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int DF_SC1 = 16;   // aux bit of the raw buffer builtins = `sc1` on gfx942 / gfx950
+
+__device__ __forceinline__ df_double2 df_bload2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
+{
+  return __builtin_bit_cast(df_double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, DF_SC1));
+}
+__device__ __forceinline__ void df_bstore2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, df_double2 v)
+{
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(df_u32x4, v), rs, (int)voff, (int)soff, DF_SC1);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t df_rsrc(const double* base)
+{
+  // wave-uniform by construction; make that provable (two readfirstlanes per descriptor, not per access)
+  const unsigned long long b = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0xffffffff, 0x00020000);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void df_task_tile2(const DfArgs& a, int j, int I, int J, double* smem, int tid, unsigned (&ph)[12])
+{
+  const unsigned tp0 = a.dbg ? (unsigned)wall_clock64() : 0u;
+  double(*Vs)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem);
+  double(*Us)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem + 2 * UD_KT * UD_LD);
+  const int N = a.N;
+  const int r0 = UD_T * I, c0 = UD_T * J;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lk = lane >> 4, li = lane & 15;
+  const unsigned lda8 = (unsigned)a.lda * 8u, ldv8 = (unsigned)a.ldv * 8u;
+  const __amdgpu_buffer_rsrc_t rsV = df_rsrc(a.V + (int64_t)(j & 1) * LD_NB * a.ldv + r0);
+  const __amdgpu_buffer_rsrc_t rsU = df_rsrc(a.A + (int64_t)(LD_NB * j) * a.lda + c0);
+  const __amdgpu_buffer_rsrc_t rsC = df_rsrc(a.A + (int64_t)r0 * a.lda + c0);
+  const int rlim = N - r0, clim = N - c0;   // rows / columns of the tile inside the matrix (FULL: both >= 128)
+
+  // ---- staging: pass p of a stage moves rows 4p + wave, two adjacent columns per lane
+  const int col2 = 2 * lane;
+  const unsigned vvoff = 8u * (unsigned)(FULL ? col2 : (col2 < rlim - 2 ? col2 : rlim - 2));
+  const unsigned uvoff = 8u * (unsigned)(FULL ? col2 : (col2 < clim - 2 ? col2 : clim - 2));
+  df_double2 vreg[4], ureg[4];
+  auto gload = [&](int st) {
+#pragma unroll
+    for(int p = 0; p < 4; ++p) {
+      const unsigned k = (unsigned)(st * UD_KT + 4 * p + wave);
+      vreg[p] = df_bload2(rsV, vvoff, k * ldv8);
+      ureg[p] = df_bload2(rsU, uvoff, k * lda8);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for(int p = 0; p < 4; ++p) {
+      *reinterpret_cast<df_double2*>(&Vs[buf][4 * p + wave][col2]) = vreg[p];
+      *reinterpret_cast<df_double2*>(&Us[buf][4 * p + wave][col2]) = -ureg[p];
+    }
+  };
+  // ---- C addressing
+  const unsigned cvoff_full = 8u * (unsigned)(2 * li) + (unsigned)(2 * lk) * lda8;
+  auto crow = [&](int i, int reg) { return wr * 64 + 32 * (i >> 1) + 2 * (lk + 4 * reg) + (i & 1); };
+  auto ccol = [&](int h) { return wc * 64 + 32 * h + 2 * li; };
+  auto c_off = [&](int i, int reg, int h, unsigned& voff, unsigned& soff) {
+    if constexpr(FULL) {
+      voff = cvoff_full;
+      soff = (unsigned)(wr * 64 + 32 * (i >> 1) + 8 * reg + (i & 1)) * lda8 + 8u * (unsigned)(wc * 64 + 32 * h);
+    } else {
+      const int R = crow(i, reg), Cc = ccol(h);
+      voff = (unsigned)(R < rlim ? R : rlim - 1) * lda8 + 8u * (unsigned)(Cc < clim - 2 ? Cc : clim - 2);
+      soff = 0u;
+    }
+  };
+
+  gload(0);
+  double4_t acc[4][4];
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for(int h = 0; h < 2; ++h) {
+        unsigned vo, so;
+        c_off(i, reg, h, vo, so);
+        const df_double2 c = df_bload2(rsC, vo, so);
+        acc[i][2 * h][reg] = c.x;
+        acc[i][2 * h + 1][reg] = c.y;
+      }
+  __syncthreads();   // the LDS buffers may still be read by the previous task's waves
+  lstore(0);
+  gload(1);
+  __syncthreads();
+  constexpr int nst = LD_NB / UD_KT;
+  const int arow = wr * 64 + 2 * li, bcol = wc * 64 + 2 * li;
+  const unsigned tp1 = a.dbg ? (unsigned)wall_clock64() : 0u;
+  for(int st = 0; st < nst; ++st) {
+    const int cur = st & 1;
+    df_double2 av[2][2], bv[2][2];
+#pragma unroll
+    for(int h = 0; h < 2; ++h) {
+      av[0][h] = *reinterpret_cast<const df_double2*>(&Vs[cur][lk][arow + 32 * h]);
+      bv[0][h] = *reinterpret_cast<const df_double2*>(&Us[cur][lk][bcol + 32 * h]);
+    }
+#pragma unroll
+    for(int kk = 0; kk < UD_KT / 4; ++kk) {
+      const int pb = kk & 1;
+      if(kk + 1 < UD_KT / 4) {
+#pragma unroll
+        for(int h = 0; h < 2; ++h) {
+          av[pb ^ 1][h] = *reinterpret_cast<const df_double2*>(&Vs[cur][4 * (kk + 1) + lk][arow + 32 * h]);
+          bv[pb ^ 1][h] = *reinterpret_cast<const df_double2*>(&Us[cur][4 * (kk + 1) + lk][bcol + 32 * h]);
+        }
+      }
+      if(kk == 1 && st + 1 < nst) {
+        lstore(cur ^ 1);
+        if(st + 2 < nst) gload(st + 2);   // the staging registers are free again: three k-steps + a barrier of lead
+      }
+#pragma unroll
+      for(int i = 0; i < 4; ++i)
+#pragma unroll
+        for(int q = 0; q < 4; ++q)
+          acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb][i >> 1][i & 1], bv[pb][q >> 1][q & 1], acc[i][q], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: stores only
+  if(a.dbg && (a.dbg == 1 || j == a.dbg - 2)) {
+    const unsigned tp2 = (unsigned)wall_clock64();
+    ph[9] += tp1 - tp0;    // prologue (first operand stage + C tile in flight, two barriers)
+    ph[10] += tp2 - tp1;   // the 16 stages
+  }
+  const bool diag = (I == J);
+#pragma unroll
+  for(int i = 0; i < 4; ++i)
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for(int h = 0; h < 2; ++h) {
+        unsigned vo, so;
+        c_off(i, reg, h, vo, so);
+        const df_double2 v = df_double2{acc[i][2 * h][reg], acc[i][2 * h + 1][reg]};
+        const int R = crow(i, reg), Cc = ccol(h);
+        const bool inside = FULL || (R < rlim && Cc < clim);
+        if(!diag) {
+          if(inside) df_bstore2(rsC, vo, so, v);
+        } else if(inside) {
+          if(Cc >= R) df_bstore2(rsC, vo, so, v);
+          else if(Cc + 1 == R)   // the pair straddles the diagonal: only its second element is in the upper triangle
+          {
+            const double second = acc[i][2 * h + 1][reg];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(df_u32x2, second), rsC, (int)(vo + 8u), (int)so, DF_SC1);
+          }
+        }
+      }
+}
+
 constexpr int DF_WIDE_WG_PER_CU = 2;
+constexpr int DF_TRQ = 40, DF_UPQ = 41;   // per super-panel: TR / UP tasks of its queues handed out so far
+
+// Two task queues per super-panel instead of one ticket list.  A ticket list must put TR(j+1, .) somewhere inside UP(j, .),
+// and wherever it sits the ~500 substitution tasks are handed out in one burst: they all wait for the chain kernel to
+// finish C_j+1 while occupying every resident workgroup, and the remaining tiles of UP(j) — ready, but with later tickets
+// — do not run (measured at N = 8192: 156 us mean wait per TR task, 41 % of all workgroup time).  Here a workgroup TAKES
+// a task only when the conditions that depend on UNTAKEN work or on the chain kernel's panel factorisation already hold:
+//   TR(j, .)  : C_j factored (cdone), the first two tile rows of UP(j-1) all taken, UP(j-2) complete (V workspace parity)
+//   UP(j, .)  : every TR(j, .) taken (and, by the order the queues are walked, every UP(j-1, .) taken)
+// TR first (it feeds the next update), UP otherwise, sleep-poll when neither queue has an eligible head.  Inside a task
+// every remaining wait is for a task that is already taken or for the chain kernel, so nothing can deadlock whatever the
+// number of resident workgroups (tests/test_ldlt_dataflow_plan.py replays this policy).
+template <int TILE_FORM>   // 1: 8-byte accesses, any N;  2: df_task_tile2 (even N, lda, ldv)
 __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(const DfArgs a)
 {
-  __shared__ double smem[4 * UD_KT * UD_LD];   // 73,728 B: the update's two double-buffered operand tile pairs / the substitution's V
-  __shared__ int sh_t, sh_ok;
+  __shared__ __attribute__((aligned(16))) double smem[4 * UD_KT * UD_LD];   // 73,728 B: the update's two double-buffered operand tile pairs / the substitution's V
+  __shared__ int sh_kind, sh_idx, sh_ok;
   const int tid = threadIdx.x;
   const long long t_start = (long long)wall_clock64();
+  unsigned ph[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // phase accounting (a.dbg != 0): see the host print-out
+  unsigned tph = (unsigned)t_start;
+  bool acct = false;   // a.dbg == 1: every task; a.dbg >= 2: only the tasks of super-panel a.dbg - 2
+  auto lap = [&](int k) {
+    if(a.dbg) {
+      const unsigned now = (unsigned)wall_clock64();
+      if(acct) ph[k] += now - tph;
+      tph = now;
+    }
+  };
+  int jtr = 0, jup = 0;   // first super-panel whose TR / UP queue this workgroup has not seen exhausted (lane 0 only)
   for(;;) {
-    if(tid == 0) sh_t = (int)__hip_atomic_fetch_add(a.flags + DF_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(tid == 0) {
+      int kind = -1, idx = 0;   // 0: every queue exhausted, 1: TR, 2: UP, -2: aborted / timed out
+      unsigned spins = 0;
+      for(;;) {
+        unsigned* qtr = a.flags + a.off_chain + (int64_t)jtr * DF_CH;
+        unsigned* qup = a.flags + a.off_chain + (int64_t)jup * DF_CH;
+        if(jtr < a.nwide) {
+          const int4 q = a.wq[jtr];   // {first TR task, TR tasks, first UP task, UP tasks}
+          const unsigned taken = df_ld(qtr + DF_TRQ), cd = df_ld(qtr + DF_CDONE);
+          const unsigned upprev = jtr >= 1 ? df_ld(qtr - DF_CH + DF_UPQ) : 0u;
+          const unsigned updone2 = jtr >= 2 ? df_ld(qtr - 2 * DF_CH + DF_UPDONE) : 0u;
+          if(taken >= (unsigned)q.y) {
+            ++jtr;
+            continue;
+          }
+          if(cd >= 10u && (jtr < 1 || upprev >= a.wfirst[jtr - 1]) && (jtr < 2 || updone2 >= a.upcnt[jtr - 2])) {
+            const unsigned i = __hip_atomic_fetch_add(qtr + DF_TRQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(i < (unsigned)q.y) {
+              kind = 1;
+              idx = q.x + (int)i;
+              break;
+            }
+            ++jtr;
+            continue;
+          }
+        }
+        if(jup < a.nwide) {
+          const int4 q = a.wq[jup];
+          const unsigned taken = df_ld(qup + DF_UPQ), trtaken = df_ld(qup + DF_TRQ);
+          if(taken >= (unsigned)q.w) {
+            ++jup;
+            continue;
+          }
+          if(trtaken >= (unsigned)q.y) {
+            const unsigned i = __hip_atomic_fetch_add(qup + DF_UPQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(i < (unsigned)q.w) {
+              kind = 2;
+              idx = q.z + (int)i;
+              break;
+            }
+            ++jup;
+            continue;
+          }
+        }
+        if(jtr >= a.nwide && jup >= a.nwide) {
+          kind = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+        if((++spins & 15u) == 0) {
+          const bool late = (long long)wall_clock64() - t_start > DF_TIMEOUT_TICKS;
+          if(late || df_ld(a.flags + DF_ABORT) != 0) {
+            if(late && atomicCAS(a.flags + DF_ABORT, 0u, 1u) == 0u) {
+              df_st(a.flags + 2, 3u);   // waiter 3 = a workgroup of the wide kernel looking for an eligible task
+              df_st(a.flags + 3, (unsigned)jtr);
+              df_st(a.flags + 4, (unsigned)jup);
+              df_st(a.flags + 5, df_ld(qtr + DF_TRQ));
+              df_st(a.flags + 6, df_ld(qup + DF_UPQ));
+              df_st(a.flags + 7, 0u);
+              df_st(a.flags + 8, 10u);
+              df_st(a.flags + 9, df_ld(qtr + DF_CDONE));
+              df_st(a.flags + 10, (unsigned)(qtr + DF_CDONE - a.flags));
+            }
+            kind = -2;
+            break;
+          }
+        }
+      }
+      sh_kind = kind;
+      sh_idx = idx;
+    }
     __syncthreads();
-    const int t = __builtin_amdgcn_readfirstlane(sh_t);
+    const int kind = __builtin_amdgcn_readfirstlane(sh_kind);
+    const int t = __builtin_amdgcn_readfirstlane(sh_idx);
     __syncthreads();
-    if(t >= a.nwtasks) return;
+    if(kind <= 0) {
+      if(a.dbg && tid == 0) {
+#pragma unroll
+        for(int q = 0; q < 12; ++q) atomicAdd(a.flags + a.off_ph + q, ph[q]);
+      }
+      return;
+    }
+    // the task bodies derive dozens of per-lane offsets from the thread index; hoisted out of this persistent loop they
+    // would stay live across every body (scratch spills at 256 VGPRs): make the index opaque per iteration instead
+    int tidv = tid;
+    asm volatile("" : "+v"(tidv));
     int4 tk = a.wtasks[t];
     tk.x = __builtin_amdgcn_readfirstlane(tk.x);
     tk.y = __builtin_amdgcn_readfirstlane(tk.y);
     tk.z = __builtin_amdgcn_readfirstlane(tk.z);
     tk.w = __builtin_amdgcn_readfirstlane(tk.w);
     const int j = tk.y;
+    acct = a.dbg == 1 || j == a.dbg - 2;
     unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
     unsigned* trj = a.flags + a.off_tr + (int64_t)j * a.nt;
-    DfWait w(a.flags + DF_ABORT);   // (the ticket word is busy: the abort word is 0 = "always >= 0")
+    DfWait w(a.flags + DF_ABORT);   // (the abort word is 0 = "always >= 0")
     if(tk.x == DF_TR) {
       const int c16 = tk.z, J = c16 / UD_T;
-      w.set<0>(cf + DF_CDONE, 10u);                                                   // C_j factored (chain kernel)
+      lap(0);
+      // (C_j factored and the V workspace parity were conditions for taking the task)
       w.set<1>(a.flags + a.off_ver + (int64_t)(2 * j) * a.nt + J, (unsigned)j);       // rows of panel j updated through panel j-1
       w.set<2>(a.flags + a.off_ver + (int64_t)(2 * j + 1) * a.nt + J, (unsigned)j);
-      if(j >= 2) w.set<3>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);   // V workspace parity
       if(!df_wait(a.flags, w, &sh_ok, t_start, 1, t, j, c16, J)) {
           return;
       }
       if(tid == 0) df_stamp(a, j, 4);
-      df_task_trsm(a, j, c16, smem, tid);
+      lap(1);
+      df_task_trsm(a, j, c16, smem, tidv);
+      lap(2);
       df_drain();
       if(tid == 0) df_add(trj + J, 1u);
       if(tid == 0) df_stamp(a, j, 5);
+      lap(3);
+      if(acct) ph[8] += 1u;
     } else {
       const int I = tk.z, J = tk.w;
+      lap(0);
       auto groups = [&](int B) {   // 16-column substitution tasks of 128-block B inside the matrix
         const int rem = a.N - UD_T * B;
         return (unsigned)((rem >= UD_T) ? 8 : (rem + 15) / 16);
@@ -634,17 +921,26 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
           return;
       }
       if(tid == 0) df_stamp(a, j, 6);
-      df_task_tile(a, j, I, J, smem, tid);
+      lap(4);
+      if constexpr(TILE_FORM == 2) {
+        if(UD_T * (I + 1) <= a.N && UD_T * (J + 1) <= a.N) df_task_tile2<true>(a, j, I, J, smem, tidv, ph);
+        else df_task_tile2<false>(a, j, I, J, smem, tidv, ph);
+      } else {
+        df_task_tile(a, j, I, J, smem, tidv);
+      }
+      lap(5);
       df_drain();
       if(tid == 0) {
         df_st(a.flags + a.off_ver + (int64_t)I * a.nt + J, (unsigned)(j + 1));
         df_add(cf + DF_UPDONE, 1u);
         df_stamp(a, j, 7);
       }
+      lap(6);
+      if(acct) ph[7] += 1u;
     }
-    // REQUIRED: keeps the lane-0-only signalling block above and the lane-0-only ticket fetch at the loop top in separate
+    // REQUIRED: keeps the lane-0-only signalling block above and the lane-0-only task selection at the loop top in separate
     // regions.  Without a convergent operation between them the compiler threads the two `tid == 0` tests into one path,
-    // the loop gets two back-edges, LoopSimplify nests it, and lanes 1..63 of wave 0 run the ticket barriers once more
+    // the loop gets two back-edges, LoopSimplify nests it, and lanes 1..63 of wave 0 run the selection barriers once more
     // than lane 0 does: the workgroup hangs at s_barrier (seen on ROCm 7.2 / gfx950, no bounded wait can catch it).
     __syncthreads();
   }

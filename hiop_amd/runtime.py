@@ -13,7 +13,8 @@ import torch
 from ._lib import lib, check
 
 
-_LIVE_STREAMS = {}    # id(Context) -> torch.cuda.ExternalStream of every live context
+_LIVE_CONTEXTS = {}    # id(Context) -> Context, every live context (weak: removed by Context.close)
+_KEEP_MAX = 8192
 
 
 def dptr(t) -> C.c_void_p:
@@ -21,15 +22,17 @@ def dptr(t) -> C.c_void_p:
 
     The C ABI is asynchronous on the context's own stream, which torch's caching allocator knows nothing about: a device
     temporary released right after the call would be recycled for the next allocation while the call's kernels are still
-    queued.  `record_stream` tells the allocator about the foreign use, so the block is only reused once the work queued
-    on the context stream at release time has finished."""
+    queued.  Every device tensor whose address crosses the ABI is therefore kept alive by the live contexts until their
+    next synchronisation (`Context.sync`); the list is bounded (a synchronisation is forced when it overflows)."""
     if t is None:
         return C.c_void_p(0)
     if isinstance(t, torch.Tensor):
         assert t.is_contiguous()
         if t.is_cuda:
-            for st in _LIVE_STREAMS.values():
-                t.record_stream(st)
+            for c in _LIVE_CONTEXTS.values():
+                c._keep.append(t)
+                if len(c._keep) > _KEEP_MAX:
+                    c.sync()
         return C.c_void_p(t.data_ptr())
     if isinstance(t, np.ndarray):
         assert t.flags["C_CONTIGUOUS"]
@@ -59,7 +62,8 @@ class Context:
         self.stream_ptr = self._L.hiopamd_ctx_stream(self.h)
         self.torch_stream = torch.cuda.ExternalStream(self.stream_ptr)
         self._children = []   # weakrefs of objects holding C handles that reference this context
-        _LIVE_STREAMS[id(self)] = self.torch_stream
+        self._keep = []       # device tensors handed to asynchronous calls since the last synchronisation
+        _LIVE_CONTEXTS[id(self)] = self
 
     def _register(self, obj):
         import weakref
@@ -67,6 +71,7 @@ class Context:
 
     def sync(self):
         check(self._L.hiopamd_ctx_sync(self.h), "hiopamd_ctx_sync")
+        self._keep.clear()
 
     def close(self):
         if self.h is not None:
@@ -76,7 +81,9 @@ class Context:
                 if o is not None:
                     o.close()
             self._children = []
-            _LIVE_STREAMS.pop(id(self), None)
+            _LIVE_CONTEXTS.pop(id(self), None)
+            self._L.hiopamd_ctx_sync(self.h)
+            self._keep.clear()
             self._L.hiopamd_ctx_destroy(self.h)
             self.h = None
 

@@ -1,9 +1,11 @@
 """CPU check of the static schedule of the dataflow LDL^T (csrc/ldlt_dataflow.hpp) — no GPU needed.
 
 `hiopamd_ldlt_dataflow_plan` (host-only entry point of libhiopamd.so) returns the task tables the two persistent kernels
-execute: the chain kernel's per-role lists of F / T / U tile tasks and the wide kernel's ticket-ordered TR / UP list.  This
-test replays them with numpy under the SAME flag protocol the kernels use (tile version counters, cdone / hdone / updone,
-tr[j][J], ver[I][J]; every task may only start when its wait conditions hold) with the 16 chain roles and W wide workers
+execute: the chain kernel's per-role lists of F / T / U tile tasks and the wide kernel's per-super-panel TR / UP queues
+(`hiopamd_ldlt_dataflow_queues`).  This test replays them with numpy under the SAME protocol the kernels use (tile version
+counters, cdone / hdone / updone, tr[j][J], ver[I][J]; a wide worker TAKES a task only when the take-conditions of
+ldlt_wide_kernel hold — TR(j): C_j factored, first two tile rows of UP(j-1) taken, UP(j-2) complete; UP(j): every TR(j)
+taken — and every task may only start when its wait conditions hold) with the 16 chain roles and W wide workers
 advancing in an arbitrary (seeded, adversarial) interleaving, and checks
   * liveness: every task completes — no role or worker waits forever, for several worker counts (1 .. 64) and orders;
   * soundness: the factor that comes out equals the unblocked U^T D U recurrence of the same matrix to 1e-10 — i.e. every
@@ -31,7 +33,11 @@ def get_plan(n):
     assert L.hiopamd_ldlt_dataflow_plan(n, dims, ct, wt, nw) == 0
     ct = np.array(ct, dtype=np.int64).reshape(2, roles, maxt, 4)
     wt = np.array(wt, dtype=np.int64).reshape(-1, 4)[:nw]
-    return dict(nsp=nsp, nt=nt, nchain=nchain, last_has_next=last_has_next, nwide=nwide, roles=roles, ctasks=ct, wtasks=wt)
+    q = (C.c_int * (5 * max(nwide, 1)))()
+    assert L.hiopamd_ldlt_dataflow_queues(n, q, nwide) == 0
+    q = np.array(q, dtype=np.int64).reshape(-1, 5)[:nwide]
+    return dict(nsp=nsp, nt=nt, nchain=nchain, last_has_next=last_has_next, nwide=nwide, roles=roles, ctasks=ct, wtasks=wt,
+                queues=q)
 
 
 def ldl_nopiv(A):
@@ -234,9 +240,39 @@ def replay(A, plan, n_workers, seed):
         return None
 
     wt = [tuple(int(v) for v in t) for t in plan["wtasks"]]
-    next_ticket = 0
-    held = [None] * n_workers   # ticket held by each wide worker
+    Q = plan["queues"]          # per super-panel: first TR, #TR, first UP, #UP, #UP of the first two tile rows
+    nw = plan["nwide"]
+    trq = [0] * (nw + 1)        # tasks handed out per queue (the DF_TRQ / DF_UPQ words)
+    upq = [0] * (nw + 1)
+    held = [None] * n_workers   # task index held by each wide worker
+    ptr = [[0, 0] for _ in range(n_workers)]   # (jtr, jup) of each worker
     done_w = 0
+
+    def take(w):
+        """the selection loop of ldlt_wide_kernel (one pass): returns a task index, None (nothing eligible), or 'done'"""
+        while True:
+            jtr, jup = ptr[w]
+            if jtr < nw:
+                if trq[jtr] >= Q[jtr][1]:
+                    ptr[w][0] += 1
+                    continue
+                ok = sim.cdone[jtr] >= 10 and (jtr < 1 or upq[jtr - 1] >= Q[jtr - 1][4]) and \
+                    (jtr < 2 or sim.updone[jtr - 2] >= sim.upcnt[jtr - 2])
+                if ok:
+                    i = trq[jtr]; trq[jtr] += 1
+                    return int(Q[jtr][0] + i)
+            if jup < nw:
+                if upq[jup] >= Q[jup][3]:
+                    ptr[w][1] += 1
+                    continue
+                if trq[jup] >= Q[jup][1]:
+                    i = upq[jup]; upq[jup] += 1
+                    return int(Q[jup][2] + i)
+            if jtr >= nw and jup >= nw:
+                return "done"
+            return None
+
+    finished = [False] * n_workers
     while True:
         agents = []
         for r in range(roles):
@@ -244,11 +280,8 @@ def replay(A, plan, n_workers, seed):
             if t is not None:
                 agents.append(("c", r, t))
         for w in range(n_workers):
-            if held[w] is None and next_ticket < len(wt):
-                held[w] = next_ticket
-                next_ticket += 1
-            if held[w] is not None:
-                agents.append(("w", w, held[w]))
+            if not finished[w]:
+                agents.append(("w", w, None))
         if not agents:
             break
         rnd.shuffle(agents)
@@ -262,13 +295,24 @@ def replay(A, plan, n_workers, seed):
                     progressed = True
                     break            # one step, then re-shuffle: many different interleavings
             else:
-                if sim.wide_ready(wt[t]):
-                    sim.wide_run(wt[t])
+                if held[who] is None:
+                    got = take(who)
+                    if got == "done":
+                        finished[who] = True
+                        progressed = True
+                        break
+                    if got is None:
+                        continue
+                    held[who] = got
+                    progressed = True   # taking a task is a step of its own: the run may have to wait
+                    break
+                if sim.wide_ready(wt[held[who]]):
+                    sim.wide_run(wt[held[who]])
                     held[who] = None
                     done_w += 1
                     progressed = True
                     break
-        assert progressed, f"deadlock: chain cursors {cur}, tickets held {held}, next {next_ticket}/{len(wt)}"
+        assert progressed, f"deadlock: chain cursors {cur}, held {held}, queues TR {trq} UP {upq}"
     assert done_w == len(wt)
     return sim
 
@@ -321,10 +365,16 @@ def test_plan_shapes():
     assert p["nsp"] == 32 and p["nt"] == 64 and p["nchain"] == 32 and p["nwide"] == 31
     ups = [t for t in p["wtasks"] if t[0] == UP]
     assert len(ups) == sum(t * (t + 1) // 2 - 3 for t in range(62, 0, -2))   # tiles of 31 trailing updates minus the skipped diagonal blocks
-    # ticket order is topological for the TR -> UP dependency: every UP(j, I, J) comes after all TR(j, .) of its column blocks
-    seen_tr = set()
-    for ty, j, x, y in p["wtasks"]:
-        if ty == TR:
-            seen_tr.add((j, x // 128))
-        else:
-            assert (j, y) in seen_tr and (x < 2 * j + 4 or (j, x) in seen_tr)
+    # the queues: TR tasks grouped by super-panel, then the UP tasks grouped by super-panel, first two tile rows first
+    Q = p["queues"]
+    assert len(Q) == 31
+    pos = 0
+    for j in range(31):
+        assert Q[j][0] == pos and all(t[0] == TR and t[1] == j for t in p["wtasks"][pos:pos + Q[j][1]])
+        pos += Q[j][1]
+    for j in range(31):
+        seg = p["wtasks"][Q[j][2]:Q[j][2] + Q[j][3]]
+        assert Q[j][2] == pos and all(t[0] == UP and t[1] == j for t in seg)
+        assert all(t[2] in (2 * j + 2, 2 * j + 3) for t in seg[:Q[j][4]]) and all(t[2] >= 2 * j + 4 for t in seg[Q[j][4]:])
+        pos += Q[j][3]
+    assert pos == len(p["wtasks"])
