@@ -97,7 +97,7 @@ __device__ __forceinline__ void stg_sc1(double* p, double v)
 
 template <bool SC1 = false>
 __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* sdinv, int kb, int k0, int* info,
-                                                double* __restrict__ Li, int tid)
+                                                double* __restrict__ Li, int tid, double* Li_lds = nullptr)
 {
   __shared__ double Lv[LD_SB][LD_SB + 1];
   const int lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -112,28 +112,27 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
         const double idv = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
         if constexpr(SC1) stg_sc1(Li + sb * 256 + e, idv);
         else Li[sb * 256 + e] = idv;
+        if(Li_lds) Li_lds[sb * 256 + e] = idv;
       }
       return;
     }
+    // lanes 0-15 carry column c of the block (`a`), lanes 16-31 column c of the inverse being built (`m`): the row operation
+    // x[r] -= (S[k][r] / d) * x[k] is the same for both, so one fma per row serves the two halves at once
     const int c = li;
-    double a[LD_SB], m[LD_SB];
+    const bool is_a = (g == 0);
+    double x[LD_SB];
 #pragma unroll
-    for(int r = 0; r < LD_SB; ++r) {
-      a[r] = S[o + r][o + c];   // zeros below the diagonal
-      m[r] = (r == c) ? 1.0 : 0.0;
-    }
+    for(int r = 0; r < LD_SB; ++r) x[r] = is_a ? S[o + r][o + c] /* zeros below the diagonal */ : ((r == c) ? 1.0 : 0.0);
 #pragma unroll
     for(int k = 0; k < LD_SB; ++k) {
       if(o + k < kb) {  // uniform
-        const double d = bcast_lane(a[k], k);          // pivot
+        const double d = bcast_lane(x[k], k);          // pivot (lane k of the `a` half)
         const double di = fast_rcp(d);
-        const double ukc = a[k] * di;                  // scaled pivot-row entry of my column
-        const double mkc = m[k] * di;
+        const double xkc = x[k] * di;                  // scaled pivot-row entry of my column
 #pragma unroll
         for(int r = k + 1; r < LD_SB; ++r) {
-          const double vkr = bcast_lane(a[k], r);      // S[k][r]: multiplier of row r is vkr/d
-          a[r] = fma(-vkr, ukc, a[r]);
-          m[r] = fma(-vkr, mkc, m[r]);
+          const double vkr = bcast_lane(x[k], r);      // S[k][r] (lane r of the `a` half): multiplier of row r is vkr/d
+          x[r] = fma(-vkr, xkc, x[r]);
         }
         if(tid == 0) {
           sdinv[o + k] = di;
@@ -141,13 +140,17 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
         }
       }
     }
-    if(tid < LD_SB) {
+    if(tid < 2 * LD_SB) {
 #pragma unroll
       for(int r = 0; r < LD_SB; ++r) {
-        if(c >= r) S[o + r][o + c] = a[r];
-        Lv[r][c] = m[r];
-        if constexpr(SC1) stg_sc1(Li + sb * 256 + r * 16 + c, m[r]);
-        else Li[sb * 256 + r * 16 + c] = m[r];
+        if(is_a) {
+          if(c >= r) S[o + r][o + c] = x[r];
+        } else {
+          Lv[r][c] = x[r];
+          if constexpr(SC1) stg_sc1(Li + sb * 256 + r * 16 + c, x[r]);
+          else Li[sb * 256 + r * 16 + c] = x[r];
+          if(Li_lds) Li_lds[sb * 256 + r * 16 + c] = x[r];
+        }
       }
     }
   };
@@ -1776,11 +1779,13 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
     return t + (b - a);
   };
   for(int p = 0; p < 4; ++p) {
-    by_role[0].push_back(make_int4(DF_F, p, p, p));
+    // the spine: S(p) = F(p) -> T(p, p+1) -> U(p; p+1, p+1) fused in one task, data carried in LDS (z = 1: with the T / U part);
+    // its companion: R(p) = T(p, p+2) -> U(p; p+1, p+2) -> U(p; p+2, p+2)
+    by_role[0].push_back(make_int4(DF_S, p, (p + 1 <= cmax) ? 1 : 0, 0));
+    if(p + 2 <= cmax) by_role[1].push_back(make_int4(DF_R, p, 0, 0));
     for(int c = p + 1; c <= cmax; ++c) {   // tile solves of pivot p
       int role;
-      if(c == p + 1) role = 0;
-      else if(c == p + 2) role = 1;
+      if(c == p + 1 || c == p + 2) continue;   // inside S(p) / R(p)
       else if(c <= 3) role = 2;
       else role = 3 + (c - 4);
       by_role[role].push_back(make_int4(DF_T, p, p, c));
@@ -1788,8 +1793,8 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
     for(int a = p + 1; a <= cmax; ++a)
       for(int b = a; b <= cmax; ++b) {   // updates by pivot p
         int role;
-        if(a == p + 1 && b == p + 1) role = 0;
-        else if((a == p + 1 && b == p + 2) || (a == p + 2 && b == p + 2)) role = 1;
+        if(a == p + 1 && b == p + 1) continue;                                               // inside S(p)
+        else if((a == p + 1 && b == p + 2) || (a == p + 2 && b == p + 2)) continue;          // inside R(p)
         else if(b <= 3) role = 2;
         else if(a <= 3) role = 3 + (b - 4);
         else role = 7 + nn_index(a - 4, b - 4) % 9;
@@ -2030,8 +2035,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       // 16-byte accesses need even N, lda, ldv (ldv = N); HIOPAMD_DF_TILE=1 forces the 8-byte form (A/B timing)
       static const int tile_env = std::getenv("HIOPAMD_DF_TILE") ? std::atoi(std::getenv("HIOPAMD_DF_TILE")) : 2;
       const bool form2 = tile_env != 1 && (N % 2 == 0) && (lda % 2 == 0) && (ldv % 2 == 0) && N >= 2 * UD_T;
-      if(form2) hipLaunchKernelGGL(ldlt_wide_kernel<2>, dim3(grid), dim3(kBlock), 0, su, a);
-      else hipLaunchKernelGGL(ldlt_wide_kernel<1>, dim3(grid), dim3(kBlock), 0, su, a);
+      if(form2 && a.dbg) hipLaunchKernelGGL((ldlt_wide_kernel<2, true>), dim3(grid), dim3(kBlock), 0, su, a);
+      else if(form2) hipLaunchKernelGGL((ldlt_wide_kernel<2, false>), dim3(grid), dim3(kBlock), 0, su, a);
+      else hipLaunchKernelGGL((ldlt_wide_kernel<1, false>), dim3(grid), dim3(kBlock), 0, su, a);
       if(timed) {
         (void)hipEventRecord(prof->get(), su);
         prof->flops += P.up_flops;
@@ -2132,6 +2138,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
                  "UP(%u): wait %.2f body %.2f [prologue %.2f stages %.2f epilogue %.2f] publish %.2f\n",
                  ph[0] * 0.01 / ntask, ph[8], ph[1] * 0.01 / ntr, ph[2] * 0.01 / ntr, ph[3] * 0.01 / ntr, ph[7], ph[4] * 0.01 / nup,
                  ph[5] * 0.01 / nup, ph[9] * 0.01 / nup, ph[10] * 0.01 / nup, (ph[5] - ph[9] - ph[10]) * 0.01 / nup, ph[6] * 0.01 / nup);
+    if(ph[15])
+      std::fprintf(stderr, "[hiop_amd] spine steps (%u), mean us: F + publish %.2f | wait for the older updates of (p,p+1), (p+1,p+1) %.2f | T + U %.2f\n",
+                   ph[15], ph[12] * 0.01 / ph[15], ph[13] * 0.01 / ph[15], ph[14] * 0.01 / ph[15]);
   }
   if(dfw[DF_ABORT]) {
     std::fprintf(stderr,

@@ -34,7 +34,7 @@ constexpr int DF_CV = 0, DF_HV = 16, DF_CDONE = 33, DF_HDONE = 34, DF_UPDONE = 3
 constexpr int DF_MAXT = 40;           // chain tasks per role per super-panel (<= 28 used)
 constexpr int DF_ROLES = 16;
 
-enum { DF_F = 1, DF_T = 2, DF_U = 3, DF_END = 0 };
+enum { DF_F = 1, DF_T = 2, DF_U = 3, DF_S = 4, DF_R = 5, DF_END = 0 };
 enum { DF_TR = 1, DF_UP = 2 };
 
 struct DfArgs {
@@ -144,6 +144,18 @@ __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* s
   }
   __syncthreads();
   const bool r = __builtin_amdgcn_readfirstlane(*sh_ok) != 0;   // wave-uniform by construction: keep the branch scalar
+  __syncthreads();
+  return r;
+}
+// one non-blocking look at the four conditions (one round trip): true when all of them hold already
+__device__ __forceinline__ bool df_peek(const DfWait& w, int* sh_ok)
+{
+  if(threadIdx.x == 0) {
+    const unsigned g0 = df_ld(w.f[0]), g1 = df_ld(w.f[1]), g2 = df_ld(w.f[2]), g3 = df_ld(w.f[3]);
+    *sh_ok = (g0 >= w.v[0] && g1 >= w.v[1] && g2 >= w.v[2] && g3 >= w.v[3]) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool r = __builtin_amdgcn_readfirstlane(*sh_ok) != 0;
   __syncthreads();
   return r;
 }
@@ -334,16 +346,269 @@ __device__ __forceinline__ void df_task_update(const DfArgs& a, int j, int p, in
         stg_sc1(dst.p + (int64_t)(32 * wr + 16 * i + lk + 4 * reg) * dst.ld + 32 * wc + 16 * q + li, cv[i][q][reg] - acc[i][q][reg]);
 }
 
+// LDS of a chain workgroup (one workgroup per CU: 160 KB available)
+struct DfChainLds {
+  double S[LD_nb][LD_nb + 1];    // the diagonal tile being factored / carried from the previous spine step
+  double sdinv[LD_nb];
+  double Li[4 * LD_SB * LD_SB];  // the four 16 x 16 inverses of the last factored tile
+  double Vl[LD_nb][LD_nb + 1];   // V(p, p+1) (un-scaled) and U(p, p+1) of the spine step, for its own update
+  double Ul[LD_nb][LD_nb + 1];
+};
+
+// S(p): the spine step F(p) -> T(p, p+1) -> U(p; p+1, p+1) in ONE task.  As three tasks every hand-over costs a drain, a
+// flag round trip, a poll and a reload from L2 (12 serial round trips of ~1.5 us per pivot, 131 us per super-panel, the
+// critical path of the whole factorisation); here the factored tile, its 16 x 16 inverses, V / U of the solved tile and the
+// updated next diagonal tile stay in LDS: F's results are published as soon as they are drained (the other roles' tile
+// solves need them), T's and U's together at the end.  `carried`: the tile to factor is already in L.S (left there by the
+// previous step's update).  Returns false when the factorisation was aborted.
+__device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, bool with_tu, bool carried, DfChainLds& L, int* sh_ok,
+                                              long long t_start, int tid)
+{
+  const int lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int k0 = LD_NB * j + 64 * p;
+  unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
+  double* Li = a.Li + (int64_t)(k0 / LD_nb) * (4 * LD_SB * LD_SB);
+  double* Dk = a.Dblk + (int64_t)(k0 / LD_nb) * (LD_nb * LD_nb);
+  const DfTile tpp = df_tile(a, j, p, p);
+  unsigned bpp;
+  unsigned* vpp = df_ver(a, j, p, p, &bpp);
+  const unsigned ts0 = a.dbg ? (unsigned)wall_clock64() : 0u;
+  // ---- F(p)
+  if(!carried) {
+    DfWait w0(a.flags + DF_ABORT);
+    w0.set<0>(vpp, bpp + p);
+    if(!df_wait(a.flags, w0, sh_ok, t_start, 100, j, DF_S, p, 0)) return false;
+    double sv[LD_nb * LD_nb / kBlock];
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      sv[q] = ldg_sc1(tpp.p + (int64_t)(e >> 6) * tpp.ld + (e & 63));
+    }
+#pragma unroll
+    for(int q = 0; q < LD_nb * LD_nb / kBlock; ++q) {
+      const int e = tid + q * kBlock;
+      const int r = e >> 6, c = e & 63;
+      L.S[r][c] = (c >= r) ? sv[q] : 0.0;
+    }
+  }
+  if(tid < LD_nb) L.sdinv[tid] = 1.0;
+  __syncthreads();
+  if(tid == 0 && p == 0) df_stamp(a, j, 0);
+  diag_factor_lds<true>(L.S, L.sdinv, LD_nb, k0, a.info, Li, tid, L.Li);
+  for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
+    const int r = e >> 6, c = e & 63;
+    double v = L.S[r][c];
+    if(c > r) v *= L.sdinv[r];
+    const bool in = c >= r;
+    stg_sc1(Dk + e, in ? v : 0.0);
+    if(in) stg_sc1(tpp.p + (int64_t)r * tpp.ld + c, v);
+  }
+  if(tid < LD_nb) stg_sc1(a.dinv + k0 + tid, L.sdinv[tid]);
+  auto publish_f = [&]() {
+    df_drain();
+    if(tid == 0 && p == 3) df_stamp(a, j, 1);
+    if(tid == 0) {
+      df_add(vpp, 1u);
+      df_add(cf + DF_CDONE, 1u);
+    }
+  };
+  if(!with_tu) {
+    publish_f();
+    return true;
+  }
+  const unsigned ts1 = a.dbg ? (unsigned)wall_clock64() : 0u;
+  // ---- T(p, c), c = p + 1: the tile has the updates of the pivots < p (role 1), the V workspace of this parity is free
+  const int c = p + 1;
+  unsigned bpc, bcc;
+  unsigned* vpc = df_ver(a, j, p, c, &bpc);
+  unsigned* vcc = df_ver(a, j, c, c, &bcc);
+  {
+    DfWait w1(a.flags + DF_ABORT);
+    w1.set<0>(vpc, bpc + p);
+    w1.set<1>(vcc, bcc + p);
+    if(j >= 2) w1.set<2>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
+    // one look at the conditions while F's stores drain, then publish F (the other roles' tile solves wait for it) before
+    // any blocking wait: in the phases where the wide kernel is behind, that wait is long
+    const bool ready = df_peek(w1, sh_ok);
+    publish_f();
+    if(!ready && !df_wait(a.flags, w1, sh_ok, t_start, 100, j, DF_S, p, 1)) return false;
+  }
+  const unsigned ts2 = a.dbg ? (unsigned)wall_clock64() : 0u;
+  const DfTile x = df_tile(a, j, p, c), vt = df_vtile(a, j, p, c), tcc = df_tile(a, j, c, c);
+  const int cl = 16 * w + li;
+  const int wr = w >> 1, wc = w & 1, lk = g;
+  double4_t t[4];
+  double cv[2][2][4];
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) t[I][r] = ldg_sc1(x.p + (int64_t)(16 * I + g + 4 * r) * x.ld + cl);
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int q = 0; q < 2; ++q)
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg)
+        cv[i][q][reg] = ldg_sc1(tcc.p + (int64_t)(32 * wr + 16 * i + lk + 4 * reg) * tcc.ld + 32 * wc + 16 * q + li);
+  double nl[6][4], iv[4][4], dsc[4][4];
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) dsc[I][r] = L.sdinv[16 * I + g + 4 * r];
+#pragma unroll
+  for(int I = 1; I < 4; ++I)
+#pragma unroll
+    for(int J = 0; J < I; ++J)
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) {
+        const int rr = 16 * J + 4 * kk + g;
+        nl[I * (I - 1) / 2 + J][kk] = -(L.S[rr][16 * I + li] * L.sdinv[rr]);   // scaled row of U, as F emitted it
+      }
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) iv[I][kk] = L.Li[I * 256 + li * 16 + 4 * kk + g];
+  double4_t vp[4];
+#pragma unroll
+  for(int I = 0; I < 4; ++I) {
+    double4_t u = t[I];
+#pragma unroll
+    for(int J = 0; J < 4; ++J) {
+      if(J < I) {
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[I * (I - 1) / 2 + J][kk], vp[J][kk], u, 0, 0, 0);
+      }
+    }
+    double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[I][kk], u[kk], v, 0, 0, 0);
+    vp[I] = v;
+  }
+#pragma unroll
+  for(int I = 0; I < 4; ++I)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) {
+      const int row = 16 * I + g + 4 * r;
+      const double vv = vp[I][r], uu = vp[I][r] * dsc[I][r];
+      stg_sc1(vt.p + (int64_t)row * vt.ld + cl, vv);
+      stg_sc1(x.p + (int64_t)row * x.ld + cl, uu);
+      L.Vl[row][cl] = vv;
+      L.Ul[row][cl] = uu;
+    }
+  __syncthreads();   // V / U of the tile complete in LDS; every wave is done with L.S (nl) and L.sdinv
+  // ---- U(p; c, c): tile (c, c) -= V^T U, operands from LDS; the result stays in L.S for the next step's F
+  double4_t acc[2][2];
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int q = 0; q < 2; ++q) acc[i][q] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for(int kk = 0; kk < 16; ++kk) {
+    const int k = 4 * kk + lk;
+    double av[2], bv[2];
+#pragma unroll
+    for(int i = 0; i < 2; ++i) av[i] = L.Vl[k][32 * wr + 16 * i + li];
+#pragma unroll
+    for(int q = 0; q < 2; ++q) bv[q] = L.Ul[k][32 * wc + 16 * q + li];
+#pragma unroll
+    for(int i = 0; i < 2; ++i)
+#pragma unroll
+      for(int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[q], acc[i][q], 0, 0, 0);
+  }
+  // V / U of tile (p, c) were stored before the products above: by now they have landed, publish them (the companion's
+  // U(p; p+1, p+2) waits for exactly this) before the C tile goes out
+  df_drain();
+  if(tid == 0 && c >= 4) df_stamp(a, j, 3);
+  if(tid == 0) {
+    df_add(vpc, 1u);
+    df_add(cf + (c < 4 ? DF_CDONE : DF_HDONE), 1u);
+  }
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int q = 0; q < 2; ++q)
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg) {
+        const int row = 32 * wr + 16 * i + lk + 4 * reg, col = 32 * wc + 16 * q + li;
+        const double r = cv[i][q][reg] - acc[i][q][reg];
+        stg_sc1(tcc.p + (int64_t)row * tcc.ld + col, r);   // (the stepwise hand-over of a ragged order reads it; cheap)
+        L.S[row][col] = (col >= row) ? r : 0.0;
+      }
+  df_drain();
+  if(tid == 0) df_add(vcc, 1u);
+  if(a.dbg && tid == 0) {   // spine accounting: F part | wait for the tile's older updates | T + U part | steps
+    const unsigned ts3 = (unsigned)wall_clock64();
+    atomicAdd(a.flags + a.off_ph + 12, ts1 - ts0);
+    atomicAdd(a.flags + a.off_ph + 13, ts2 - ts1);
+    atomicAdd(a.flags + a.off_ph + 14, ts3 - ts2);
+    atomicAdd(a.flags + a.off_ph + 15, 1u);
+  }
+  return true;
+}
+
+// R(p): the spine's companion T(p, p+2) -> U(p; p+2, p+2) -> U(p; p+1, p+2) in one task (what S(p+1) and R(p+1) need next);
+// only the last part waits for the spine's T(p, p+1)
+__device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p, int* sh_ok, long long t_start, int tid)
+{
+  unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
+  const int c = p + 2, m = p + 1;
+  unsigned bpp, bpc, bpm, bmc, bcc;
+  unsigned* vpp = df_ver(a, j, p, p, &bpp);
+  unsigned* vpc = df_ver(a, j, p, c, &bpc);
+  unsigned* vpm = df_ver(a, j, p, m, &bpm);
+  unsigned* vmc = df_ver(a, j, m, c, &bmc);
+  unsigned* vcc = df_ver(a, j, c, c, &bcc);
+  {
+    DfWait w0(a.flags + DF_ABORT);
+    w0.set<0>(vpp, bpp + p + 1);   // F(p) published
+    w0.set<1>(vpc, bpc + p);
+    if(j >= 2) w0.set<2>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
+    if(!df_wait(a.flags, w0, sh_ok, t_start, 101, j, DF_R, p, 0)) return false;
+  }
+  df_task_solve(a, j, p, c, tid);
+  df_drain();
+  if(tid == 0 && c >= 4) df_stamp(a, j, 3);
+  if(tid == 0) {
+    df_add(vpc, 1u);
+    df_add(cf + (c < 4 ? DF_CDONE : DF_HDONE), 1u);
+  }
+  const DfTile tmc = df_tile(a, j, m, c), tcc = df_tile(a, j, c, c);
+  {   // U(p; p+2, p+2) needs only this task's own V / U (drained above): before the wait for the spine
+    DfWait w1(a.flags + DF_ABORT);
+    w1.set<0>(vcc, bcc + p);
+    if(!df_wait(a.flags, w1, sh_ok, t_start, 101, j, DF_R, p, 1)) return false;
+  }
+  df_task_update(a, j, p, c, c, tcc, tcc, tid);
+  {
+    DfWait w2(a.flags + DF_ABORT);
+    w2.set<0>(vpm, bpm + p + 1);   // the spine's T(p, p+1) published
+    w2.set<1>(vmc, bmc + p);
+    if(!df_wait(a.flags, w2, sh_ok, t_start, 101, j, DF_R, p, 2)) return false;
+  }
+  df_task_update(a, j, p, m, c, tmc, tmc, tid);
+  df_drain();
+  if(tid == 0) {
+    df_add(vcc, 1u);
+    df_add(vmc, 1u);
+  }
+  return true;
+}
+
 __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
 {
-  __shared__ double S[LD_nb][LD_nb + 1];
-  __shared__ double sdinv[LD_nb];
+  __shared__ DfChainLds L;
+  __shared__ int4 sh_tasks[2][DF_MAXT];   // this role's task lists (with / without a next super-panel): no L2 round trip per task
   __shared__ int sh_ok;
+  double(*S)[LD_nb + 1] = L.S;
+  double* sdinv = L.sdinv;
   const int tid = threadIdx.x, role = blockIdx.x;
   const long long t_start = (long long)wall_clock64();
+  if(tid < 2 * DF_MAXT) sh_tasks[tid / DF_MAXT][tid % DF_MAXT] = a.ctasks[((tid / DF_MAXT) * DF_ROLES + role) * DF_MAXT + tid % DF_MAXT];
+  __syncthreads();
+  bool carried = false;   // role 0: the tile to factor next is in L.S
   for(int j = 0; j < a.nchain; ++j) {
     const bool has_next = (j + 1 < a.nchain) || a.last_has_next;
-    const int4* tasks = a.ctasks + ((has_next ? 0 : 1) * DF_ROLES + role) * DF_MAXT;
+    const int4* tasks = sh_tasks[has_next ? 0 : 1];
     unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
     for(int it = 0; it < DF_MAXT; ++it) {
       int4 tk = tasks[it];
@@ -355,7 +620,12 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
       const int p = tk.y, ta = tk.z, tb = tk.w;
       DfWait w(a.flags + DF_ABORT);
       unsigned base;
-      if(tk.x == DF_F) {
+      if(tk.x == DF_S) {
+        if(!df_spine_step(a, j, p, ta != 0, carried, L, &sh_ok, t_start, tid)) return;
+        carried = ta != 0;   // with the T / U part the updated tile (p+1, p+1) — (0, 0) of the next super-panel for p = 3 — is in L.S
+      } else if(tk.x == DF_R) {
+        if(!df_companion_step(a, j, p, &sh_ok, t_start, tid)) return;
+      } else if(tk.x == DF_F) {
         unsigned* v = df_ver(a, j, p, p, &base);
         w.set<0>(v, base + p);
         if(!df_wait(a.flags, w, &sh_ok, t_start, 100 + role, j, tk.x, p, p)) return;
@@ -626,10 +896,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t df_rsrc(const double* base)
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0xffffffff, 0x00020000);
 }
 
-template <bool FULL>
+template <bool FULL, bool PROF>
 __device__ __forceinline__ void df_task_tile2(const DfArgs& a, int j, int I, int J, double* smem, int tid, unsigned (&ph)[12])
 {
-  const unsigned tp0 = a.dbg ? (unsigned)wall_clock64() : 0u;
+  const int dbg = PROF ? a.dbg : 0;
+  const unsigned tp0 = dbg ? (unsigned)wall_clock64() : 0u;
   double(*Vs)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem);
   double(*Us)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem + 2 * UD_KT * UD_LD);
   const int N = a.N;
@@ -698,7 +969,7 @@ __device__ __forceinline__ void df_task_tile2(const DfArgs& a, int j, int I, int
   __syncthreads();
   constexpr int nst = LD_NB / UD_KT;
   const int arow = wr * 64 + 2 * li, bcol = wc * 64 + 2 * li;
-  const unsigned tp1 = a.dbg ? (unsigned)wall_clock64() : 0u;
+  const unsigned tp1 = dbg ? (unsigned)wall_clock64() : 0u;
   for(int st = 0; st < nst; ++st) {
     const int cur = st & 1;
     df_double2 av[2][2], bv[2][2];
@@ -730,7 +1001,7 @@ __device__ __forceinline__ void df_task_tile2(const DfArgs& a, int j, int I, int
     __syncthreads();
   }
   // ---- epilogue: stores only
-  if(a.dbg && (a.dbg == 1 || j == a.dbg - 2)) {
+  if(dbg && (dbg == 1 || j == dbg - 2)) {
     const unsigned tp2 = (unsigned)wall_clock64();
     ph[9] += tp1 - tp0;    // prologue (first operand stage + C tile in flight, two barriers)
     ph[10] += tp2 - tp1;   // the 16 stages
@@ -773,45 +1044,70 @@ constexpr int DF_TRQ = 40, DF_UPQ = 41;   // per super-panel: TR / UP tasks of i
 // TR first (it feeds the next update), UP otherwise, sleep-poll when neither queue has an eligible head.  Inside a task
 // every remaining wait is for a task that is already taken or for the chain kernel, so nothing can deadlock whatever the
 // number of resident workgroups (tests/test_ldlt_dataflow_plan.py replays this policy).
-template <int TILE_FORM>   // 1: 8-byte accesses, any N;  2: df_task_tile2 (even N, lda, ldv)
+// TILE_FORM 1: 8-byte accesses, any N;  2: df_task_tile2 (even N, lda, ldv).  PROF: with the phase accounting of
+// HIOPAMD_DF_STAMPS (its counters cost registers: a separate instantiation, launched only when asked for)
+template <int TILE_FORM, bool PROF>
 __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(const DfArgs a)
 {
+  const int dbg = PROF ? a.dbg : 0;
   __shared__ __attribute__((aligned(16))) double smem[4 * UD_KT * UD_LD];   // 73,728 B: the update's two double-buffered operand tile pairs / the substitution's V
-  __shared__ int sh_kind, sh_idx, sh_ok;
+  __shared__ int sh_kind, sh_ok;
   const int tid = threadIdx.x;
   const long long t_start = (long long)wall_clock64();
   unsigned ph[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // phase accounting (a.dbg != 0): see the host print-out
   unsigned tph = (unsigned)t_start;
   bool acct = false;   // a.dbg == 1: every task; a.dbg >= 2: only the tasks of super-panel a.dbg - 2
   auto lap = [&](int k) {
-    if(a.dbg) {
+    if(dbg) {
       const unsigned now = (unsigned)wall_clock64();
       if(acct) ph[k] += now - tph;
       tph = now;
     }
   };
-  int jtr = 0, jup = 0;   // first super-panel whose TR / UP queue this workgroup has not seen exhausted (lane 0 only)
+  // task selection state (lane 0 only): first super-panel whose TR / UP queue this workgroup has not seen exhausted, and the
+  // cached descriptors of those two super-panels ({first TR task, TR tasks, first UP task, UP tasks}, thresholds)
+  int jtr = 0, jup = 0, jtr_c = -1, jup_c = -1;
+  int4 qt = make_int4(0, 0, 0, 0), qu = make_int4(0, 0, 0, 0);
+  unsigned first_prev = 0u, upcnt_prev2 = 0u;
+  __shared__ int4 sh_task;
   for(;;) {
     if(tid == 0) {
-      int kind = -1, idx = 0;   // 0: every queue exhausted, 1: TR, 2: UP, -2: aborted / timed out
+      int kind = -1;   // 0: every queue exhausted, 1: TR, 2: UP, -2: aborted / timed out
+      int4 task = make_int4(0, 0, 0, 0);
       unsigned spins = 0;
       for(;;) {
-        unsigned* qtr = a.flags + a.off_chain + (int64_t)jtr * DF_CH;
-        unsigned* qup = a.flags + a.off_chain + (int64_t)jup * DF_CH;
+        if(jtr >= a.nwide && jup >= a.nwide) {
+          kind = 0;
+          break;
+        }
+        if(jtr != jtr_c && jtr < a.nwide) {
+          qt = a.wq[jtr];
+          first_prev = jtr >= 1 ? a.wfirst[jtr - 1] : 0u;
+          upcnt_prev2 = jtr >= 2 ? a.upcnt[jtr - 2] : 0u;
+          jtr_c = jtr;
+        }
+        if(jup != jup_c && jup < a.nwide) {
+          qu = a.wq[jup];
+          jup_c = jup;
+        }
+        // every flag of both queue heads in flight at once: one round trip, then the decision
+        const int jt = jtr < a.nwide ? jtr : a.nwide - 1, ju = jup < a.nwide ? jup : a.nwide - 1;
+        unsigned* qtr = a.flags + a.off_chain + (int64_t)jt * DF_CH;
+        unsigned* qup = a.flags + a.off_chain + (int64_t)ju * DF_CH;
+        const unsigned tr_taken = df_ld(qtr + DF_TRQ), cd = df_ld(qtr + DF_CDONE);
+        const unsigned upprev = df_ld(qtr - (jt >= 1 ? DF_CH : 0) + DF_UPQ);
+        const unsigned updone2 = df_ld(qtr - (jt >= 2 ? 2 * DF_CH : 0) + DF_UPDONE);
+        const unsigned up_taken = df_ld(qup + DF_UPQ), up_trtaken = df_ld(qup + DF_TRQ);
         if(jtr < a.nwide) {
-          const int4 q = a.wq[jtr];   // {first TR task, TR tasks, first UP task, UP tasks}
-          const unsigned taken = df_ld(qtr + DF_TRQ), cd = df_ld(qtr + DF_CDONE);
-          const unsigned upprev = jtr >= 1 ? df_ld(qtr - DF_CH + DF_UPQ) : 0u;
-          const unsigned updone2 = jtr >= 2 ? df_ld(qtr - 2 * DF_CH + DF_UPDONE) : 0u;
-          if(taken >= (unsigned)q.y) {
+          if(tr_taken >= (unsigned)qt.y) {
             ++jtr;
             continue;
           }
-          if(cd >= 10u && (jtr < 1 || upprev >= a.wfirst[jtr - 1]) && (jtr < 2 || updone2 >= a.upcnt[jtr - 2])) {
+          if(cd >= 10u && (jtr < 1 || upprev >= first_prev) && (jtr < 2 || updone2 >= upcnt_prev2)) {
             const unsigned i = __hip_atomic_fetch_add(qtr + DF_TRQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if(i < (unsigned)q.y) {
+            if(i < (unsigned)qt.y) {
               kind = 1;
-              idx = q.x + (int)i;
+              task = make_int4(DF_TR, jtr, LD_NB * (jtr + 2) + 16 * (int)i, qt.x + (int)i);   // (no table look-up needed)
               break;
             }
             ++jtr;
@@ -819,26 +1115,20 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
           }
         }
         if(jup < a.nwide) {
-          const int4 q = a.wq[jup];
-          const unsigned taken = df_ld(qup + DF_UPQ), trtaken = df_ld(qup + DF_TRQ);
-          if(taken >= (unsigned)q.w) {
+          if(up_taken >= (unsigned)qu.w) {
             ++jup;
             continue;
           }
-          if(trtaken >= (unsigned)q.y) {
+          if(up_trtaken >= (unsigned)qu.y) {
             const unsigned i = __hip_atomic_fetch_add(qup + DF_UPQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if(i < (unsigned)q.w) {
+            if(i < (unsigned)qu.w) {
               kind = 2;
-              idx = q.z + (int)i;
+              task = a.wtasks[qu.z + (int)i];
               break;
             }
             ++jup;
             continue;
           }
-        }
-        if(jtr >= a.nwide && jup >= a.nwide) {
-          kind = 0;
-          break;
         }
         __builtin_amdgcn_s_sleep(32);
         if((++spins & 15u) == 0) {
@@ -848,11 +1138,11 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
               df_st(a.flags + 2, 3u);   // waiter 3 = a workgroup of the wide kernel looking for an eligible task
               df_st(a.flags + 3, (unsigned)jtr);
               df_st(a.flags + 4, (unsigned)jup);
-              df_st(a.flags + 5, df_ld(qtr + DF_TRQ));
-              df_st(a.flags + 6, df_ld(qup + DF_UPQ));
+              df_st(a.flags + 5, tr_taken);
+              df_st(a.flags + 6, up_taken);
               df_st(a.flags + 7, 0u);
               df_st(a.flags + 8, 10u);
-              df_st(a.flags + 9, df_ld(qtr + DF_CDONE));
+              df_st(a.flags + 9, cd);
               df_st(a.flags + 10, (unsigned)(qtr + DF_CDONE - a.flags));
             }
             kind = -2;
@@ -861,14 +1151,14 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
         }
       }
       sh_kind = kind;
-      sh_idx = idx;
+      sh_task = task;
     }
     __syncthreads();
     const int kind = __builtin_amdgcn_readfirstlane(sh_kind);
-    const int t = __builtin_amdgcn_readfirstlane(sh_idx);
+    int4 tk = sh_task;
     __syncthreads();
     if(kind <= 0) {
-      if(a.dbg && tid == 0) {
+      if(dbg && tid == 0) {
 #pragma unroll
         for(int q = 0; q < 12; ++q) atomicAdd(a.flags + a.off_ph + q, ph[q]);
       }
@@ -878,13 +1168,12 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
     // would stay live across every body (scratch spills at 256 VGPRs): make the index opaque per iteration instead
     int tidv = tid;
     asm volatile("" : "+v"(tidv));
-    int4 tk = a.wtasks[t];
     tk.x = __builtin_amdgcn_readfirstlane(tk.x);
     tk.y = __builtin_amdgcn_readfirstlane(tk.y);
     tk.z = __builtin_amdgcn_readfirstlane(tk.z);
     tk.w = __builtin_amdgcn_readfirstlane(tk.w);
     const int j = tk.y;
-    acct = a.dbg == 1 || j == a.dbg - 2;
+    acct = dbg == 1 || j == dbg - 2;
     unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
     unsigned* trj = a.flags + a.off_tr + (int64_t)j * a.nt;
     DfWait w(a.flags + DF_ABORT);   // (the abort word is 0 = "always >= 0")
@@ -894,7 +1183,7 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
       // (C_j factored and the V workspace parity were conditions for taking the task)
       w.set<1>(a.flags + a.off_ver + (int64_t)(2 * j) * a.nt + J, (unsigned)j);       // rows of panel j updated through panel j-1
       w.set<2>(a.flags + a.off_ver + (int64_t)(2 * j + 1) * a.nt + J, (unsigned)j);
-      if(!df_wait(a.flags, w, &sh_ok, t_start, 1, t, j, c16, J)) {
+      if(!df_wait(a.flags, w, &sh_ok, t_start, 1, tk.w, j, c16, J)) {
           return;
       }
       if(tid == 0) df_stamp(a, j, 4);
@@ -905,7 +1194,7 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
       if(tid == 0) df_add(trj + J, 1u);
       if(tid == 0) df_stamp(a, j, 5);
       lap(3);
-      if(acct) ph[8] += 1u;
+      if(PROF && acct) ph[8] += 1u;
     } else {
       const int I = tk.z, J = tk.w;
       lap(0);
@@ -917,14 +1206,14 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
       if(I < 2 * j + 4) w.set<1>(cf + DF_HDONE, 16u);                                 // rows in the head: V from the chain kernel
       else w.set<1>(trj + I, groups(I));
       w.set<2>(trj + J, groups(J));
-      if(!df_wait(a.flags, w, &sh_ok, t_start, 2, t, j, I, J)) {
+      if(!df_wait(a.flags, w, &sh_ok, t_start, 2, 0, j, I, J)) {
           return;
       }
       if(tid == 0) df_stamp(a, j, 6);
       lap(4);
       if constexpr(TILE_FORM == 2) {
-        if(UD_T * (I + 1) <= a.N && UD_T * (J + 1) <= a.N) df_task_tile2<true>(a, j, I, J, smem, tidv, ph);
-        else df_task_tile2<false>(a, j, I, J, smem, tidv, ph);
+        if(UD_T * (I + 1) <= a.N && UD_T * (J + 1) <= a.N) df_task_tile2<true, PROF>(a, j, I, J, smem, tidv, ph);
+        else df_task_tile2<false, PROF>(a, j, I, J, smem, tidv, ph);
       } else {
         df_task_tile(a, j, I, J, smem, tidv);
       }
@@ -936,7 +1225,7 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
         df_stamp(a, j, 7);
       }
       lap(6);
-      if(acct) ph[7] += 1u;
+      if(PROF && acct) ph[7] += 1u;
     }
     // REQUIRED: keeps the lane-0-only signalling block above and the lane-0-only task selection at the loop top in separate
     // regions.  Without a convergent operation between them the compiler threads the two `tid == 0` tests into one path,

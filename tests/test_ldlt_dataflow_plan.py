@@ -18,7 +18,7 @@ import random
 import numpy as np
 import pytest
 
-F, T, U, END = 1, 2, 3, 0
+F, T, U, SP, RC, END = 1, 2, 3, 4, 5, 0   # SP / RC: the fused spine step S(p) and its companion R(p)
 TR, UP = 1, 2
 
 
@@ -102,8 +102,32 @@ class Sim:
         return self.ver[2 * j + r // 2, 2 * j + c // 2]
 
     # ---- chain tasks: ready? / run
+    def fused_parts(self, tk):
+        ty, p, a, b = tk
+        if ty == SP:    # F(p) -> T(p, p+1) -> U(p; p+1, p+1)
+            return [(F, p, p, p)] + ([(T, p, p, p + 1), (U, p, p + 1, p + 1)] if a else [])
+        return [(T, p, p, p + 2), (U, p, p + 1, p + 2), (U, p, p + 2, p + 2)]   # RC
+
     def chain_ready(self, j, tk):
         ty, p, a, b = tk
+        if ty in (SP, RC):
+            # every wait of the fused task on OTHER roles' work, required up front (stricter than the kernel, which waits for
+            # the later parts' conditions only when it reaches them): conditions on the task's own earlier parts are dropped
+            parts = self.fused_parts(tk)
+            own = set()
+            for q in parts:
+                if not self.part_ready(j, q, own):
+                    return False
+                own.add((q[0], q[1], q[2], q[3]))
+            return True
+        return self.part_ready(j, tk, set())
+
+    def part_ready(self, j, tk, own):
+        ty, p, a, b = tk
+        done_f = (F, p, p, p) in own
+
+        def solved(c):      # T(p, c) part of the same fused task already counted?
+            return (T, p, p, c) in own
         if ty == F:
             arr, ix, base = self.ver_of(j, p, p)
             return arr[ix] >= base + p
@@ -111,7 +135,7 @@ class Sim:
             c = b
             arr, ix, base = self.ver_of(j, p, c)
             app, ipp, bpp = self.ver_of(j, p, p)
-            ok = app[ipp] >= bpp + p + 1 and arr[ix] >= base + p
+            ok = (done_f or app[ipp] >= bpp + p + 1) and arr[ix] >= base + p
             if c >= 4 and p == 0:
                 ok = ok and self.wide_ver(j, p, c) >= j
             if j >= 2:
@@ -120,13 +144,17 @@ class Sim:
         arr, ix, base = self.ver_of(j, a, b)
         aa, ia, ba = self.ver_of(j, p, a)
         ab, ib, bb = self.ver_of(j, p, b)
-        ok = aa[ia] >= ba + p + 1 and ab[ib] >= bb + p + 1 and arr[ix] >= base + p
+        ok = (solved(a) or aa[ia] >= ba + p + 1) and (solved(b) or ab[ib] >= bb + p + 1) and arr[ix] >= base + p
         if b >= 4 and p == 0:
             ok = ok and self.wide_ver(j, a, b) >= j
         return ok
 
     def chain_run(self, j, tk):
         ty, p, a, b = tk
+        if ty in (SP, RC):
+            for q in self.fused_parts(tk):
+                self.chain_run(j, q)
+            return
         k0 = 256 * j + 64 * p
         if ty == F:
             t = self.get(j, p, p)
