@@ -328,18 +328,15 @@ def main():
     flops_per_launch = ufl.value / launches
     ms_per_launch = ums.value / launches
     achieved = (flops_per_launch / (ms_per_launch * 1e-3)) / 1e12 if ms_per_launch > 0 else 0.0
-    # HBM traffic of that kernel: from the committed PMC passes (scripts/gpu_pmc.sh -> profiles/<round>_pmc/summary.json);
-    # bench.py cannot collect hardware counters itself, so this field is a measured constant of the same binary/workload
-    traffic, traffic_src = None, None
-    for cand in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc", "summary.json"))):
-        try:
-            with open(cand) as f:
-                u = json.load(f).get("ldlt_update_kernel", {})
-            if "hbm_bytes_per_launch" in u:
-                traffic, traffic_src = u["hbm_bytes_per_launch"], os.path.relpath(cand, os.path.dirname(os.path.abspath(__file__)))
-        except Exception:
-            pass
-    roofline = dict(bound="mfma", kernel="ldlt_update_kernel_t<2,2,8> (rank-K trailing update, 64x64 tiles, v_mfma_f64_16x16x4_f64)",
+    # HBM traffic of that kernel: rocprofv3 --pmc serialises the dispatches of the process, and the dataflow factorisation is a
+    # PAIR of persistent kernels that wait for each other's flags — it cannot run under counter collection.  `traffic` is
+    # therefore null here; the PMC passes of the stepwise path (same tile algorithm, one launch per super-panel step) are under
+    # profiles/r02_pmc (scripts/gpu_pmc.sh, HIOPAMD_DF=0).
+    traffic, traffic_src = None, "n/a: counter collection serialises the two concurrent dataflow kernels (see profiles/r02_pmc for the stepwise kernels)"
+    # the dominant kernel is the persistent wide kernel of the dataflow factorisation: `achieved` = the algorithmic flops of its
+    # trailing-update tiles (2 K per updated element of the upper triangle) / its WHOLE duration, which also contains the
+    # row-panel substitution tasks and every wait for the chain kernel — a lower bound on the tile rate, by construction
+    roofline = dict(bound="mfma", kernel="ldlt_wide_kernel<2,false> (dataflow LDL^T: row-panel substitution tasks + 128x128x256 trailing-update tiles, v_mfma_f64_16x16x4_f64)",
                     achieved=achieved, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
                     traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
                     launches_per_step=launches / a.steps, avg_launch_ms=ms_per_launch,

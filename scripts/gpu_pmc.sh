@@ -1,5 +1,10 @@
 #!/bin/bash
 # PMC passes over the bench (separate rocprofv3 runs, kernel-trace only, as the GPU pool requires).
+# Counter collection serialises the dispatches of a process, and the dataflow LDL^T is a PAIR of persistent kernels that
+# must run concurrently (each waits for the other's flags): under --pmc the pair cannot make progress.  The passes are
+# therefore taken with HIOPAMD_DF=0 — the stepwise kernels, same tile algorithm launched once per super-panel step — and
+# labelled so; bench.py reports `traffic: null` for the dataflow kernel.
+export HIOPAMD_DF=0
 set -u
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
@@ -32,18 +37,17 @@ for d in ["fetch", "write", "mfma", "wait"]:
         w = csv.writer(f); w.writerow(["Kernel_Name", "Dispatches"] + names)
         for k in sorted(agg, key=lambda k: -sum(agg[k].values())):
             w.writerow([k, len(disp[k])] + [agg[k].get(c, 0.0) for c in names])
-    # the trailing update = the instantiation of the tile kernel with the largest counter totals (the chain's small
-    # diagonal-block update is another instantiation of the same template)
+    # the trailing update of the STEPWISE path = the instantiation of the tile kernel with the largest counter totals
     cand = [k for k in agg if "ldlt_update_kernel" in k]
     if cand:
         k = max(cand, key=lambda k: sum(agg[k].values()))
-        summary.setdefault("ldlt_update_kernel", {})["dispatches_" + d] = len(disp[k])
-        summary["ldlt_update_kernel"]["kernel_" + d] = k.split("(")[0]
+        summary.setdefault("ldlt_update_kernel_stepwise", {})["dispatches_" + d] = len(disp[k])
+        summary["ldlt_update_kernel_stepwise"]["kernel_" + d] = k.split("(")[0]
         for c in names:
-            summary["ldlt_update_kernel"][c] = agg[k].get(c, 0.0)
+            summary["ldlt_update_kernel_stepwise"][c] = agg[k].get(c, 0.0)
     for k in sorted(agg, key=lambda k: -sum(agg[k].values()))[:6]:
         print(d, k[:60], len(disp[k]), dict(agg[k]))
-u = summary.get("ldlt_update_kernel")
+u = summary.get("ldlt_update_kernel_stepwise")
 if u and "FETCH_SIZE" in u and "WRITE_SIZE" in u:
     n = u["dispatches_fetch"]
     u["hbm_bytes_per_launch"] = (2.0 * u["FETCH_SIZE"] * 1024.0 / n) + (u["WRITE_SIZE"] * 1024.0 / u["dispatches_write"])
