@@ -13,6 +13,9 @@
 #include "device_utils.hpp"
 
 #include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
 
 namespace hiopamd {
 
@@ -148,6 +151,160 @@ __global__ __launch_bounds__(128 * WC, (T == 128) ? 2 : 4) void gram_partial_ker
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// Strip Gram: the low-rank KKT's shape — A = the first ma rows of the stacked right factor [A; S; Y] (ma ~ 200, 2l ~ 12) —
+// is a bad fit for 128 x 128 workgroup tiles: 212 columns pad to 256, the symmetric part is skipped only per 128-tile, and
+// every live tile re-stages the long operands (3 live tiles = 98,304 n flops issued for 45,000 n useful).  Here ONE
+// workgroup of 8 waves owns a K-chunk and the WHOLE output for it: the stacked rows are staged once per chunk (each byte of
+// the operands is read from HBM exactly once), the output is cut in 16 x 16 MFMA tiles, tiles below the diagonal of the
+// symmetric block are neither computed nor stored (104 tiles instead of 192 at ma = 200, mb = 212), and the tiles are dealt
+// to the 8 waves in row-major runs (<= 16 accumulators per wave).  The weight d[k] goes onto the A operand in registers.
+// LDS: one stage = 256 rows x 32 k (k permuted so that k and k + 4 are adjacent: one ds_read_b128 feeds two k-steps),
+// double-buffered; 1 workgroup per CU, 256 workgroups.  Partials go to the [split][tile][16][16] slabs gram_fold_kernel<16>
+// folds.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GS_KT = 32;            // k per stage
+constexpr int GS_LD = GS_KT + 2;     // 34 doubles per row: 16 rows x 16 bytes land in 16 distinct 16-byte bank groups
+constexpr int GS_ROWS = 256;         // stacked rows (padded to 16)
+constexpr int GS_WAVES = 8;
+constexpr int GS_TPW = 16;           // tiles (accumulators) per wave
+struct GramStripTiles {
+  unsigned char ti[GS_WAVES][GS_TPW];   // tile row / column (units of 16) of each accumulator of each wave
+  unsigned char tj[GS_WAVES][GS_TPW];
+  unsigned char cnt[GS_WAVES];
+};
+typedef double gs_double2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(64 * GS_WAVES, 1) void gram_strip_kernel(int ma, int mb, int64_t n, const GramRows X, int vec_ok,
+                                                                      const double* __restrict__ d, int64_t kchunk, int tiles_b,
+                                                                      int ntiles, const GramStripTiles tl,
+                                                                      double* __restrict__ partial)
+{
+  __shared__ __attribute__((aligned(16))) double Xs[2][GS_ROWS][GS_LD];
+  __shared__ double ds[2][GS_KT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4, li = lane & 15;
+  const int split = blockIdx.x;
+  const int64_t kbeg = (int64_t)split * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if(kend > n) kend = n;
+  const int rows_pad = ((mb + 15) / 16) * 16;
+  const int ntw = tl.cnt[wave];
+  // staging: 16 threads x 16 bytes per 32-k row piece, 32 rows per pass, rows_pad / 32 (<= 8) passes
+  const int srow = tid >> 4, skk = (tid & 15) * 2;
+  // position of k inside its group of 8: (k % 4) * 2 + (k / 4) % 2  ->  k and k + 4 adjacent
+  const int p0 = (skk & ~7) + ((skk & 3) << 1) + ((skk >> 2) & 1);
+  const int p1 = (skk & ~7) + (((skk + 1) & 3) << 1) + (((skk + 1) >> 2) & 1);
+  constexpr int NP = GS_ROWS / 32;
+  double v0[NP], v1[NP];
+  double dreg = 0.0;
+  // row pointers of this thread's NP rows, resolved ONCE (segment look-ups are dependent loads: inside the K loop they would
+  // serialise every stage's operand loads behind them)
+  const double* rp[NP];
+  bool rok[NP];
+#pragma unroll
+  for(int ps = 0; ps < NP; ++ps) {
+    const int r = ps * 32 + srow;
+    const int rc = (r < mb) ? r : (mb - 1);
+    const int seg = (rc < X.rows[0]) ? 0 : ((rc < X.rows[1]) ? 1 : 2);
+    const int base = (seg == 0) ? 0 : ((seg == 1) ? X.rows[0] : X.rows[1]);
+    const double* p = (seg == 0) ? X.p[0] : ((seg == 1) ? X.p[1] : X.p[2]);
+    const int64_t ld = (seg == 0) ? X.ld[0] : ((seg == 1) ? X.ld[1] : X.ld[2]);
+    rp[ps] = p + (int64_t)(rc - base) * ld;
+    rok[ps] = r < mb;
+  }
+  auto gload = [&](int64_t k0) {
+    const int64_t k = k0 + skk;
+    const bool k0ok = k < kend, k1ok = k + 1 < kend;
+    const int64_t kc0 = k0ok ? k : (kend - 1), kc1 = k1ok ? (k + 1) : (kend - 1);
+#pragma unroll
+    for(int ps = 0; ps < NP; ++ps) {
+      if(ps * 32 < rows_pad) {   // uniform
+        double a0, a1;
+        if(vec_ok && k1ok) {
+          const double2 t = *reinterpret_cast<const double2*>(rp[ps] + k);
+          a0 = t.x;
+          a1 = t.y;
+        } else {
+          a0 = rp[ps][kc0];
+          a1 = rp[ps][kc1];
+        }
+        v0[ps] = (rok[ps] && k0ok) ? a0 : 0.0;
+        v1[ps] = (rok[ps] && k1ok) ? a1 : 0.0;
+      }
+    }
+    if(tid < GS_KT) {
+      const int64_t kd = k0 + tid;
+      dreg = (kd < kend) ? (d ? d[kd] : 1.0) : 0.0;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for(int ps = 0; ps < NP; ++ps) {
+      if(ps * 32 < rows_pad) {
+        Xs[buf][ps * 32 + srow][p0] = v0[ps];
+        Xs[buf][ps * 32 + srow][p1] = v1[ps];
+      }
+    }
+    if(tid < GS_KT) ds[buf][tid] = dreg;
+  };
+  double4_t acc[GS_TPW];
+#pragma unroll
+  for(int t = 0; t < GS_TPW; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // LDS address of this lane's operand element = tile offset (wave-uniform, kept scalar) + lane offset
+  int aoff[GS_TPW], boff[GS_TPW];
+#pragma unroll
+  for(int t = 0; t < GS_TPW; ++t) {
+    aoff[t] = __builtin_amdgcn_readfirstlane(16 * GS_LD * (int)tl.ti[wave][t]);
+    boff[t] = __builtin_amdgcn_readfirstlane(16 * GS_LD * (int)tl.tj[wave][t]);
+  }
+  const int lane_off = li * GS_LD + 2 * lk;
+  if(kbeg < kend) {
+    gload(kbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for(int64_t k0 = kbeg; k0 < kend; k0 += GS_KT) {
+    const bool more = k0 + GS_KT < kend;
+    if(more) gload(k0 + GS_KT);
+#pragma unroll
+    for(int g8 = 0; g8 < GS_KT / 8; ++g8) {
+      // two k-steps per LDS read: k = 8 g8 + lk and k + 4
+      const double w0 = ds[buf][8 * g8 + lk], w1 = ds[buf][8 * g8 + 4 + lk];
+      const double* xb = &Xs[buf][0][0] + lane_off + 8 * g8;
+      gs_double2 a = gs_double2{0.0, 0.0};
+#pragma unroll
+      for(int t = 0; t < GS_TPW; ++t) {
+        if(t < ntw) {   // wave-uniform
+          // the tiles of a wave are a row-major run: the (weighted) A operand changes only when the tile row does
+          if(t == 0 || aoff[t] != aoff[t - 1]) {   // scalar compare
+            a = *reinterpret_cast<const gs_double2*>(xb + aoff[t]);
+            a.x *= w0;
+            a.y *= w1;
+          }
+          const gs_double2 b = *reinterpret_cast<const gs_double2*>(xb + boff[t]);
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if(more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial slabs [split][tile][16][16]
+#pragma unroll
+  for(int t = 0; t < GS_TPW; ++t) {
+    if(t < ntw) {
+      const int tile = tl.ti[wave][t] * tiles_b + tl.tj[wave][t];
+      double* P = partial + ((int64_t)split * ntiles + tile) * 256;
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg) P[(lk + 4 * reg) * 16 + li] = acc[t][reg];
+    }
+  }
+}
+
 template <int T>
 __global__ __launch_bounds__(kBlock) void gram_fold_kernel(int ma, int mb, int nsplit, int ntiles, int tiles_b, int sym,
                                                            int sym_cols, const double* __restrict__ partial, double beta,
@@ -273,6 +430,46 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
                        ldw, alpha);
     HIOPAMD_CHECK(hipGetLastError());
     return HIOPAMD_OK;
+  }
+  // strip form: A = the leading rows of the (stacked) right factor, everything fits one workgroup's tile budget
+  static int strip_env = -1;
+  if(strip_env < 0) strip_env = std::getenv("HIOPAMD_GRAM_STRIP") ? std::atoi(std::getenv("HIOPAMD_GRAM_STRIP")) : 1;
+  const bool a_leads_b = (sym_cols == ma && sym_cols > 0) || (symm != 0);
+  if(strip_env && a_leads_b && ma <= mb && mb <= GS_ROWS && n >= 64 * GS_KT) {
+    const int ta_n = (ma + 15) / 16, tb_n = (mb + 15) / 16;
+    const int scols = symm ? ma : sym_cols;
+    std::vector<std::pair<int, int>> need;
+    for(int i = 0; i < ta_n; ++i)
+      for(int j = 0; j < tb_n; ++j) {
+        if(j < i && (j + 1) * 16 <= scols) continue;   // mirrored by the fold kernel (same rule, T = 16)
+        need.emplace_back(i, j);
+      }
+    if((int)need.size() <= GS_WAVES * GS_TPW) {
+      GramStripTiles tl;
+      std::memset(&tl, 0, sizeof(tl));
+      const int per = ((int)need.size() + GS_WAVES - 1) / GS_WAVES;
+      for(size_t q = 0; q < need.size(); ++q) {
+        const int w = (int)q / per, t = (int)q % per;
+        tl.ti[w][t] = (unsigned char)need[q].first;
+        tl.tj[w][t] = (unsigned char)need[q].second;
+        tl.cnt[w] = (unsigned char)(t + 1);
+      }
+      const int ntiles16 = ta_n * tb_n;
+      int nsplit = 256;
+      int64_t kchunk = (n + nsplit - 1) / nsplit;
+      kchunk = ((kchunk + GS_KT - 1) / GS_KT) * GS_KT;
+      if(kchunk < 8 * GS_KT) kchunk = 8 * GS_KT;
+      nsplit = (int)((n + kchunk - 1) / kchunk);
+      double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * ntiles16 * 256);
+      const int vec = seg_vec_ok(B, nsegB) ? 1 : 0;
+      hipLaunchKernelGGL(gram_strip_kernel, dim3(nsplit), dim3(64 * GS_WAVES), 0, ctx->stream, ma, mb, n, B, vec, d, kchunk, tb_n,
+                         ntiles16, tl, partial);
+      const int64_t tot = (int64_t)ma * mb;
+      hipLaunchKernelGGL(gram_fold_kernel<16>, dim3((unsigned)((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ma, mb,
+                         nsplit, ntiles16, tb_n, symm, symm ? 0 : sym_cols, partial, beta, W, ldw, alpha);
+      HIOPAMD_CHECK(hipGetLastError());
+      return HIOPAMD_OK;
+    }
   }
   // HIOPAMD_GRAM_T = 128: 128 x 128 tiles, 4 x 4 MFMA tiles per wave, two workgroups per CU; 64 (default): 64 x 64 tiles,
   // 2 x 2 MFMA tiles per wave, four workgroups per CU
