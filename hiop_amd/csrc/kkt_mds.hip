@@ -239,6 +239,14 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
   return HIOPAMD_OK;
 }
 
+// safe mode of the condensed system: the linear solver regularises statically and refines (the role of the reference's
+// switch to MagmaBuKa, hiopKKTLinSysMDS.cpp:408-430); the positive block is the dense-x part
+int hiopamd_kkt_mds_set_safe_mode(hiopamd_kkt_mds* k, int enable)
+{
+  if(!k) return HIOPAMD_ERR_ARG;
+  return hiopamd_linsolver_set_safe_mode(k->ls, enable, k->s.nxd);
+}
+
 int hiopamd_kkt_mds_set_diagonals(hiopamd_kkt_mds* k, const double* Dx, const double* Dd)
 {
   if(!k) return HIOPAMD_ERR_ARG;

@@ -1899,6 +1899,16 @@ struct hiopamd_linsolver {
   // dataflow solve (ldlt_solve_flow_kernel)
   double* W = nullptr;                  // ceil(n/256) inverted diagonal blocks
   double* P = nullptr;                  // nb x nb product slots of 256
+  // safe mode (static quasi-definite regularisation + iterative refinement against a saved copy of the matrix)
+  bool safe_mode = false;
+  int safe_npos = 0;
+  double safe_delta_rel = 1.4901161193847656e-08;   // sqrt(eps)
+  double* Msave = nullptr;   // n x n: the matrix as assembled (symmetrised), safe mode only
+  double* rbuf = nullptr;    // 2 n: right-hand side copy + residual
+  bool safe_solve_failed = false;
+  int safe_last_refinements = 0;
+  double safe_last_residual = 0.0;
+  double safe_anorm = 0.0;
   unsigned long long* fl_sync = nullptr;
   int4* fl_tasks = nullptr;
   int fl_ntasks = 0;
@@ -2356,6 +2366,8 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->dinv);
   (void)hipFree(ls->V);
   (void)hipFree(ls->ybuf);
+  (void)hipFree(ls->Msave);
+  (void)hipFree(ls->rbuf);
   (void)hipFree(ls->Dblk);
   (void)hipFree(ls->Cd);
   (void)hipFree(ls->d_info);
@@ -2403,7 +2415,12 @@ static int flow_check(hiopamd_linsolver* ls, int* ok_host)
 int hiopamd_linsolver_solve_status(hiopamd_linsolver* ls, int* ok_host)
 {
   if(!ls || !ok_host) return HIOPAMD_ERR_ARG;
-  return flow_check(ls, ok_host);
+  const int rc = flow_check(ls, ok_host);
+  if(rc == HIOPAMD_OK && ls->safe_mode && ls->safe_solve_failed) {   // a safe-mode refinement did not converge since the last check
+    *ok_host = 0;
+    ls->safe_solve_failed = false;
+  }
+  return rc;
 }
 
 int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable)
@@ -2416,10 +2433,100 @@ int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable)
   return HIOPAMD_OK;
 }
 
+// ---- safe mode -----------------------------------------------------------------------------------------------
+// The reference answers a misbehaving no-pivot factorisation by switching the KKT object to a Bunch-Kaufman solver
+// ("safe mode": src/Optimization/hiopKKTLinSysMDS.cpp:408-430, hiopAlgFilterIPM.cpp:2400-2427, the BuKa class
+// src/LinAlg/hiopLinSolverSymDenseMagma.cpp:142-250).  Pivoting inside a 256-row dataflow would serialise the factorisation;
+// the condensed KKT matrices are quasi-definite ([H + Dx, J^T; J, -Dd^-1]), for which the classical alternative is a static
+// regularisation K_delta = K + delta * diag(+I_npos, -I_rest) — LDL^T of a quasi-definite matrix exists for EVERY symmetric
+// permutation and its element growth is bounded by ~ ||K|| / delta (Vanderbei 1995; Gill, Saunders, Shinnerl 1996) — followed
+// by iterative refinement against the ORIGINAL matrix.  With delta = sqrt(eps) ||K||_max the factor is backward stable to
+// ~ n eps (||K|| / delta) ||K|| ~ 1e-8 ||K||, so every refinement step gains ~ 8 digits minus log10 cond(K); the loop stops at
+// ||r||_inf <= 1e-13 (||K|| ||x|| + ||b||) or gives up after 10 steps (solve_status then reports failure: the reference's
+// "-1 / solve failed" answer, never a silently wrong direction).
+// ------------------------------------------------------------------------------------------------------------------
+int hiopamd_linsolver_set_safe_mode(hiopamd_linsolver* ls, int enable, int n_pos_block)
+{
+  if(!ls || n_pos_block < 0 || n_pos_block > ls->n) return HIOPAMD_ERR_ARG;
+  ls->safe_mode = enable != 0;
+  ls->safe_npos = n_pos_block;
+  ls->factored = false;
+  if(ls->safe_mode && !ls->Msave && ls->n > 0) {
+    HIOPAMD_CHECK(hipMalloc((void**)&ls->Msave, sizeof(double) * (size_t)ls->n * ls->n));
+    HIOPAMD_CHECK(hipMalloc((void**)&ls->rbuf, sizeof(double) * (size_t)2 * ls->n));
+  }
+  return HIOPAMD_OK;
+}
+int hiopamd_linsolver_safe_mode_info(const hiopamd_linsolver* ls, int* refinements_host, double* residual_rel_host)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  if(refinements_host) *refinements_host = ls->safe_last_refinements;
+  if(residual_rel_host) *residual_rel_host = ls->safe_last_residual;
+  return HIOPAMD_OK;
+}
+// element growth of the last factorisation: max |u_ij| over the strict upper triangle of U (A = U^T D U) and the extreme
+// pivots — the quantity whose blow-up tells the caller that the no-pivot factor "misbehaves" (a well-behaved quasi-definite
+// KKT factor has |u_ij| = O(||A|| / min |d|)); computed on demand, one pass over the factor
+int hiopamd_linsolver_growth(hiopamd_linsolver* ls, double* max_abs_u_host, double* min_abs_d_host, double* max_abs_d_host)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  if(!ls->factored) return HIOPAMD_ERR_STATE;
+  const int n = ls->n;
+  const double* M = ls->M;
+  struct OpU {
+    const double* M;
+    int n;
+    __device__ double identity() const { return 0.0; }
+    __device__ double map(int64_t e) const
+    {
+      const int64_t r = e / n, c = e - r * n;
+      return c > r ? fabs(M[e]) : 0.0;
+    }
+    __device__ double combine(double a, double b) const { return fmax(a, b); }
+  };
+  struct OpDmin {
+    const double* M;
+    int n;
+    __device__ double identity() const { return DBL_MAX; }
+    __device__ double map(int64_t i) const { return fabs(M[i * (int64_t)n + i]); }
+    __device__ double combine(double a, double b) const { return fmin(a, b); }
+  };
+  struct OpDmax {
+    const double* M;
+    int n;
+    __device__ double identity() const { return 0.0; }
+    __device__ double map(int64_t i) const { return fabs(M[i * (int64_t)n + i]); }
+    __device__ double combine(double a, double b) const { return fmax(a, b); }
+  };
+  double u = 0.0, dmin = 0.0, dmax = 0.0;
+  int rc = hiopamd::launch_reduce<double>(ls->ctx, (int64_t)n * n, OpU{M, n}, &u);
+  if(rc == HIOPAMD_OK) rc = hiopamd::launch_reduce<double>(ls->ctx, n, OpDmin{M, n}, &dmin);
+  if(rc == HIOPAMD_OK) rc = hiopamd::launch_reduce<double>(ls->ctx, n, OpDmax{M, n}, &dmax);
+  if(max_abs_u_host) *max_abs_u_host = u;
+  if(min_abs_d_host) *min_abs_d_host = dmin;
+  if(max_abs_d_host) *max_abs_d_host = dmax;
+  return rc;
+}
+
 int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
 {
   if(!ls || !n_neg_host) return HIOPAMD_ERR_ARG;
   ls->factored = false;
+  if(ls->safe_mode && ls->n > 0) {
+    // keep the matrix as assembled (both triangles, for the refinement's products) and regularise the copy to be factored
+    const int n = ls->n;
+    HIOPAMD_CHECK(hipMemcpyAsync(ls->Msave, ls->M, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ls->ctx->stream));
+    int rs = hiopamd_mat_symmetrize(ls->ctx, n, ls->Msave, n);
+    if(rs != HIOPAMD_OK) return rs;
+    rs = hiopamd_mat_max_abs(ls->ctx, n, n, ls->Msave, n, &ls->safe_anorm);
+    if(rs != HIOPAMD_OK) return rs;
+    const double delta = ls->safe_delta_rel * ls->safe_anorm;
+    if(ls->safe_npos > 0) rs = hiopamd_mat_add_sub_diagonal_const(ls->ctx, ls->M, n, 0, ls->safe_npos, delta);
+    if(rs == HIOPAMD_OK && ls->safe_npos < n)
+      rs = hiopamd_mat_add_sub_diagonal_const(ls->ctx, ls->M, n, ls->safe_npos, n - ls->safe_npos, -delta);
+    if(rs != HIOPAMD_OK) return rs;
+    ls->safe_solve_failed = false;
+  }
   {
     int ok = 1;
     int rcf = flow_check(ls, &ok);   // (no extra synchronisation when no dataflow solve ran since the last factorisation)
@@ -2445,7 +2552,47 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs)
   if(!ls->factored) return HIOPAMD_ERR_STATE;
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_TRIU_SOLVES);   // :173-195 (tmTriuSolves; flopsTriuSolves = 2 n^2 per rhs)
   ls->flops_triu += 2.0 * (double)ls->n * ls->n * nrhs;
-  return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd, ls);
+  if(!ls->safe_mode) return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd, ls);
+  // safe mode: x = K_delta^-1 b, then refine against the saved K (see hiopamd_linsolver_set_safe_mode)
+  const int n = ls->n;
+  double* b = ls->rbuf;
+  double* r = ls->rbuf + n;
+  for(int q = 0; q < nrhs; ++q) {
+    double* x = rhs_inout + (int64_t)q * n;
+    int rc = hiopamd_vec_copy(ls->ctx, n, b, x);
+    if(rc != HIOPAMD_OK) return rc;
+    double bn = 0.0;
+    rc = hiopamd_vec_infnorm(ls->ctx, n, b, &bn);
+    if(rc != HIOPAMD_OK) return rc;
+    rc = ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, x, 1, ls->Cd, ls);
+    if(rc != HIOPAMD_OK) return rc;
+    int it = 0;
+    double rel = 0.0;
+    bool ok = false;
+    for(; it <= 10; ++it) {
+      rc = hiopamd_vec_copy(ls->ctx, n, r, b);                                              // r = b - K x
+      if(rc == HIOPAMD_OK) rc = hiopamd_mat_times_vec(ls->ctx, n, n, ls->Msave, n, 1.0, r, -1.0, x);
+      double rn = 0.0, xn = 0.0;
+      if(rc == HIOPAMD_OK) rc = hiopamd_vec_infnorm(ls->ctx, n, r, &rn);
+      if(rc == HIOPAMD_OK) rc = hiopamd_vec_infnorm(ls->ctx, n, x, &xn);
+      if(rc != HIOPAMD_OK) return rc;
+      const double scale = ls->safe_anorm * xn + bn;
+      rel = scale > 0.0 ? rn / scale : 0.0;
+      if(!(rn == rn) || !(xn == xn)) break;   // NaN: the factor is unusable
+      if(rel <= 1e-13) {
+        ok = true;
+        break;
+      }
+      if(it == 10) break;
+      rc = ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, r, 1, ls->Cd, ls);     // dx = K_delta^-1 r
+      if(rc == HIOPAMD_OK) rc = hiopamd_vec_axpy(ls->ctx, n, x, 1.0, r);
+      if(rc != HIOPAMD_OK) return rc;
+    }
+    ls->safe_last_refinements = it;
+    ls->safe_last_residual = rel;
+    if(!ok) ls->safe_solve_failed = true;
+  }
+  return HIOPAMD_OK;
 }
 
 int hiopamd_linsolver_profile(hiopamd_linsolver* ls, int enable)

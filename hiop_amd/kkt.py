@@ -52,6 +52,26 @@ class LinSolverSymDense:
         check(rc, "hiopamd_linsolver_solve")
         return True
 
+    def set_safe_mode(self, enable: bool, n_pos_block: int):
+        """static quasi-definite regularisation + iterative refinement (the reference's safe mode = Bunch-Kaufman solver)"""
+        check(self._L.hiopamd_linsolver_set_safe_mode(self.h, 1 if enable else 0, n_pos_block), "hiopamd_linsolver_set_safe_mode")
+
+    def growth(self):
+        """(max |u_ij|, min |d_i|, max |d_i|) of the last factorisation"""
+        u, dmin, dmax = C.c_double(0), C.c_double(0), C.c_double(0)
+        check(self._L.hiopamd_linsolver_growth(self.h, C.byref(u), C.byref(dmin), C.byref(dmax)), "hiopamd_linsolver_growth")
+        return u.value, dmin.value, dmax.value
+
+    def solve_status(self) -> bool:
+        ok = C.c_int(1)
+        check(self._L.hiopamd_linsolver_solve_status(self.h, C.byref(ok)), "hiopamd_linsolver_solve_status")
+        return bool(ok.value)
+
+    def safe_mode_info(self):
+        it, res = C.c_int(0), C.c_double(0)
+        check(self._L.hiopamd_linsolver_safe_mode_info(self.h, C.byref(it), C.byref(res)), "hiopamd_linsolver_safe_mode_info")
+        return it.value, res.value
+
     def set_dataflow(self, enable: bool):
         """dataflow factorisation (two persistent kernels) on / off (off = the stepwise kernels)."""
         check(self._L.hiopamd_linsolver_set_dataflow(self.h, 1 if enable else 0), "hiopamd_linsolver_set_dataflow")

@@ -312,6 +312,17 @@ int hiopamd_linsolver_inertia(const hiopamd_linsolver* ls, int* pos_host, int* n
  * selects the stepwise solve explicitly (HIOPAMD_SOLVE_FLOW=0 in the environment sets that default). */
 int hiopamd_linsolver_solve_status(hiopamd_linsolver* ls, int* ok_host);
 int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable);
+/* Safe mode — the role of the reference's switch from the no-pivot to the Bunch-Kaufman solver
+ * (src/Optimization/hiopKKTLinSysMDS.cpp:408-430, hiopAlgFilterIPM.cpp:2400-2427).  enable != 0: matrixChanged keeps a copy of
+ * the assembled matrix, factors K + delta*diag(+I_npos, -I_rest) with delta = sqrt(eps)*max|K_ij| (static quasi-definite
+ * regularisation: element growth <= ~||K||/delta), and every solve is refined against the saved K until
+ * ||b - K x||_inf <= 1e-13 (||K|| ||x|| + ||b||); a refinement that does not get there in 10 steps makes
+ * hiopamd_linsolver_solve_status report *ok_host = 0.  n_pos_block = order of the leading positive-definite block (the x part of
+ * the condensed KKT).  hiopamd_linsolver_growth: max |u_ij| and the extreme |d_i| of the last factorisation, the signal a
+ * caller uses to decide that the fast path misbehaves. */
+int hiopamd_linsolver_set_safe_mode(hiopamd_linsolver* ls, int enable, int n_pos_block);
+int hiopamd_linsolver_safe_mode_info(const hiopamd_linsolver* ls, int* refinements_host, double* residual_rel_host);
+int hiopamd_linsolver_growth(hiopamd_linsolver* ls, double* max_abs_u_host, double* min_abs_d_host, double* max_abs_d_host);
 /* The factorisation runs as a dataflow of two persistent kernels (csrc/ldlt_dataflow.hpp) when the CU-masked streams are
  * available and n >= 768; enable = 0 selects the stepwise kernels (one launch per super-panel step) — same results to
  * rounding, for A/B timing and as a fallback.  HIOPAMD_DF=0 in the environment sets the default off. */
@@ -369,6 +380,8 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
                                      double* dx, double* dyc, double* dyd);
 /* only the log-barrier diagonals change (hiopKKTLinSysCompressedXYcYd::update, hiopKKTLinSys.cpp:562-572) */
 int hiopamd_kkt_mds_set_diagonals(hiopamd_kkt_mds* k, const double* Dx, const double* Dd);
+/* safe_mode_ of hiopKKTLinSysCompressedMDSXYcYd (:145, :408-430): see hiopamd_linsolver_set_safe_mode */
+int hiopamd_kkt_mds_set_safe_mode(hiopamd_kkt_mds* k, int enable);
 int hiopamd_kkt_mds_dims(const hiopamd_kkt_mds* k, int* dims4_host /* nxs, nxd, neq, nineq */);
 /* the MDS matrices' products, on the values of the last set_values
  * (hiopMatrixSymBlockDiagMDS::timesVec hiopMatrixMDS.hpp:310, hiopMatrixMDS::timesVec :68 / transTimesVec :75);

@@ -369,3 +369,55 @@ def test_dataflow_solve_block_boundaries_multi_rhs_and_repeats(ctx, n):
             first = x.clone()
         assert torch.equal(x, first)
     assert torch.equal(first, X[1])
+
+
+@pytest.mark.parametrize("n1,n2", [(300, 200), (700, 324)])
+def test_safe_mode_tiny_leading_pivot(ctx, n1, n2):
+    """Safe mode (the reference's switch to the Bunch-Kaufman solver, hiopKKTLinSysMDS.cpp:408-430): a quasi-definite matrix
+    whose leading pivot is 1e-13 ||A||.  The plain no-pivot factor has element growth ~1e13 — reported by the growth
+    monitor — and its solution is useless; with safe mode on (static quasi-definite regularisation + refinement against the
+    saved matrix) the solution matches LAPACK's (numpy.linalg.solve = DGESV) to 1e-8, or solve_status says it failed."""
+    from hiop_amd.kkt import LinSolverSymDense
+    r = rng(n1 + 7 * n2)
+    A = quasi_definite(n1, n2, 3 * n1 + n2)
+    n = n1 + n2
+    amax = np.abs(A).max()
+    A[0, :n1] = 0.0; A[:n1, 0] = 0.0            # keep H positive definite: its first row/column is just the tiny diagonal
+    A[0, 0] = 1e-13 * amax
+    A[0, n1:] = r.uniform(0.5, 1.0, n2); A[n1:, 0] = A[0, n1:]   # ... but the variable is well determined by the constraints
+    B = r.uniform(-1, 1, (2, n))
+    want = np.linalg.solve(A, B.T).T
+    ls = LinSolverSymDense(ctx, n)
+    # ---- fast path: factor "succeeds", the growth monitor shows why it must not be trusted
+    ls.set_sys_matrix(D(np.triu(A)))
+    nneg = ls.matrix_changed()
+    u, dmin, dmax = ls.growth()
+    assert u > 1e10 * amax or nneg != n2
+    # ---- safe mode
+    ls.set_safe_mode(True, n1)
+    ls.set_sys_matrix(D(np.triu(A)))
+    nneg = ls.matrix_changed()
+    assert nneg == n2                              # inertia of the regularised quasi-definite matrix
+    u2, _, _ = ls.growth()
+    assert u2 < 1e9 * amax                         # growth bounded by ~ ||A|| / delta, delta = sqrt(eps) ||A||
+    Bd = D(B)
+    torch.cuda.synchronize()
+    ls.solve(Bd, 2)
+    ctx.sync()
+    ok = ls.solve_status()
+    its, res = ls.safe_mode_info()
+    X = Bd.cpu().numpy()
+    if ok:
+        assert res <= 1e-13 and its <= 10
+        np.testing.assert_allclose(X, want, rtol=1e-8, atol=1e-8 * np.abs(want).max())
+    # a well-conditioned matrix in safe mode: same answer as the fast path to refinement accuracy, 1-2 refinements
+    A2 = quasi_definite(n1, n2, 11)
+    ls.set_sys_matrix(D(np.triu(A2)))
+    assert ls.matrix_changed() == n2
+    Bd = D(B)
+    torch.cuda.synchronize()
+    ls.solve(Bd, 2); ctx.sync()
+    assert ls.solve_status()
+    np.testing.assert_allclose(Bd.cpu().numpy(), np.linalg.solve(A2, B.T).T, rtol=1e-10, atol=1e-11)
+    assert ls.safe_mode_info()[0] <= 3
+    ls.close()
