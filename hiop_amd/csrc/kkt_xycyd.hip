@@ -1016,6 +1016,11 @@ int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double
       RC(launch_ew(ctx, n, [=] __device__(int64_t i) { pk[i] = (pk[i] - om * v[i]) * beta + res[i]; }));   // :498-500
     }
     RC(do_compute_directions(h, pk, ph, &ok_prec));   // ph = M^-1 pk (hiopPrecondKKTOpr::times_vec)
+    if(!ok_prec) {   // the condensed solve behind the preconditioner failed: Krylov flag 4 (breakdown), never a silent continue
+      flag = 4;
+      iter = ii + 1 - 0.5;
+      break;
+    }
     RC(do_times_vec(h, v, ph));
     double rtv = 0.0;
     RC(slab_dot(h, rt, v, &rtv));
@@ -1070,6 +1075,11 @@ int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double
       imin = ii + 1 - 0.5;
     }
     RC(do_compute_directions(h, sk, ph, &ok_prec));
+    if(!ok_prec) {
+      flag = 4;
+      iter = ii + 1;
+      break;
+    }
     RC(do_times_vec(h, t, ph));
     double tt = 0.0, ts = 0.0;
     RC(slab_dot(h, t, t, &tt));

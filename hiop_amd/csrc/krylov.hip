@@ -348,6 +348,7 @@ bool bicgstab_solve(hiopamd_krylov* k, double* b)
 
 extern "C" {
 
+int hiopamd_krylov_destroy(hiopamd_krylov* k);
 int hiopamd_krylov_create(hiopamd_krylov** out, hiopamd_ctx* ctx, int kind, int64_t n, hiopamd_linop_fn A, void* A_user,
                           hiopamd_linop_fn ML, void* ML_user, hiopamd_linop_fn MR, void* MR_user)
 {
@@ -360,9 +361,15 @@ int hiopamd_krylov_create(hiopamd_krylov** out, hiopamd_ctx* ctx, int kind, int6
   k->ML = ML; k->MLu = ML_user;
   k->MR = MR; k->MRu = MR_user;
   const size_t bytes = sizeof(double) * (size_t)(n > 0 ? n : 1);
+  *out = nullptr;
   for(int i = 0; i < 9; ++i) {
-    HIOPAMD_CHECK(hipMalloc((void**)&k->w[i], bytes));
-    HIOPAMD_CHECK(hipMemsetAsync(k->w[i], 0, bytes, ctx->stream));   // x0 = 0 until set_x0 says otherwise
+    // on any failure: release what exists (destroy tolerates null members), leave *out null
+    if(hipMalloc((void**)&k->w[i], bytes) != hipSuccess ||
+       hipMemsetAsync(k->w[i], 0, bytes, ctx->stream) != hipSuccess) {   // x0 = 0 until set_x0 says otherwise
+      (void)hipGetLastError();
+      hiopamd_krylov_destroy(k);
+      return HIOPAMD_ERR_HIP;
+    }
   }
   *out = k;
   return HIOPAMD_OK;
