@@ -16,7 +16,8 @@ Pinning: the reference cannot be built in this image un
 rules (it needs two CMake-generated headers, one of which requires a Fortran compiler), so the
 oracle is pinned against the known answers the reference's own tests hold:
   * closed-form expected values of tests/LinAlg/{vectorTests,matrixTestsDense,matrixTestsSparse,
-    matrixTestsSymSparse}.hpp  (tests/test_oracle_vs_reference_unit_tests.py),
+    matrixTestsSymSparse}.hpp  (96 cases in tests/golden/reference_unit_tests.json, generator beside it;
+    tests/test_reference_known_answers.py runs them through this module AND through the HIP library),
   * the `-selfcheck` objective values of the Dense/MDS drivers
     (src/Drivers/MDS/NlpMdsEx1Driver.cpp:149, src/Drivers/Dense/NlpDenseConsEx1Driver.cpp:139-140,
     NlpDenseConsEx2Driver.cpp:124-125) reproduced by oracle/ipm.py driving THIS module's KKT path,
@@ -219,6 +220,56 @@ def add_upper_to_sym_upper(A, diag_start, alpha, W):                # :810
     W[diag_start:diag_start + n, diag_start:diag_start + n] += alpha * np.triu(A)
 
 
+def times_mat(A, beta, W, alpha, X):                   # :578 (timesMat_local)
+    W[:] = beta * W + alpha * (A @ X)
+
+
+def trans_times_mat(A, beta, W, alpha, X):             # :616
+    W[:] = beta * W + alpha * (A.T @ X)
+
+
+def times_mat_trans(A, beta, W, alpha, X):             # :646 (local part; the caller all-reduces)
+    W[:] = beta * W + alpha * (A @ X.T)
+
+
+def add_diagonal(A, alpha, d=None):                    # :703 (vector), :715 (constant)
+    i = np.arange(A.shape[0])
+    A[i, i] += alpha * d if d is not None else alpha
+
+
+def max_abs_value(A):                                  # :832
+    return float(np.max(np.abs(A))) if A.size else 0.0
+
+
+def row_max_abs_value(A):                              # :844
+    return np.max(np.abs(A), axis=1)
+
+
+def scale_row(A, x, inv):                              # :865
+    A *= ((1.0 / x) if inv else x)[:, None]
+
+
+def copy_rows_from(dst, src, num_rows, row_dest):      # :169
+    dst[row_dest:row_dest + num_rows, :] = src[:num_rows, :]
+
+
+def copy_rows_from_select(dst, src, rows):             # :182
+    dst[:len(rows), :] = src[np.asarray(rows), :]
+
+
+def copy_block_from_matrix(dst, i0, j0, src):          # :200
+    dst[i0:i0 + src.shape[0], j0:j0 + src.shape[1]] = src
+
+
+def copy_from_matrix_block(dst, src, i0, j0):          # :222
+    dst[:, :] = src[i0:i0 + dst.shape[0], j0:j0 + dst.shape[1]]
+
+
+def symmetrize(A):                                     # :912 (upper -> lower)
+    iu = np.triu_indices(A.shape[0], 1)
+    A[iu[1], iu[0]] = A[iu]
+
+
 def shift_rows(A, shift):                              # :238
     m = A.shape[0]
     if shift == 0 or abs(shift) == m or m <= 1:
@@ -286,6 +337,17 @@ def sp_add_MDinvMtrans_rowmerge(m, iRow, jCol, val, start, alpha, D, W):
                 else:
                     kj += 1
             W[i + start, j + start] += alpha * acc
+
+
+def spsym_times_vec(n, iRow, jCol, val, beta, y, alpha, x):           # hiopMatrixSymSparseTriplet::timesVec :924-958
+    y *= beta
+    np.add.at(y, iRow, alpha * val * x[jCol])
+    off = iRow != jCol
+    np.add.at(y, jCol[off], alpha * val[off] * x[iRow[off]])
+
+
+def spsym_add_upper_to_sym_upper(iRow, jCol, val, diag_start, alpha, W):   # :980
+    np.add.at(W, (iRow + diag_start, jCol + diag_start), alpha * val)
 
 
 def spsym_add_diag_to_vec(iRow, jCol, val, alpha, y, vec_start, diag_src_start=0, num_elems=-1):    # :1018

@@ -85,16 +85,22 @@ def initial_iterate(full, bounds, x0, d_of_x, mu):
     return it
 
 
-def solve(ops, it0, mu0=0.1, tol=1e-8, max_iter=200, kappa_d=1e-5, trace=None):
+def solve(ops, it0, mu0=0.1, tol=1e-8, max_iter=200, kappa_d=1e-5, trace=None, table=None):
+    """`table` (a list) receives one record per iteration with the columns of the reference's iteration table
+    (hiopAlgFilterIPM.cpp:2783-2812): iter, objective, inf_pr, inf_du, mu, alpha_du, alpha_pr of the step that led here."""
     it = ops.from_host(it0)
     mu = mu0
     nfact = 0
+    ap = ad = 0.0
     for k in range(max_iter):
         ev = ops.evaluate(it)
         resid, n = ops.residual(it, ev, mu, kappa_d)
         err0 = max(n[0], n[1], n[2])                       # nrmInf_nlp_{optim, feasib, complem}
         if trace is not None:
             trace.append((ev[0], err0, mu))
+        if table is not None:
+            table.append(dict(iter=k, objective=float(ev[0]), inf_pr=float(n[1]), inf_du=float(n[0]), mu=float(mu),
+                              alpha_du=float(ad), alpha_pr=float(ap)))
         if err0 < tol:
             break
         changed = False

@@ -172,3 +172,32 @@ def dense_ex2(n: int):
                 du=np.array([1e20, 2.0 * n, 4.0 * n]), xl=xl, xu=xu, x0=np.zeros(n),
                 f=lambda x: 0.25 * float(np.sum((x - 1.0) ** 4)), grad=lambda x: (x - 1.0) ** 3,
                 hess_diag=lambda x: 3.0 * (x - 1.0) ** 2)
+
+
+def dense_ex1(n: int, r: float = 1.0):
+    """The reference's DenseConsEx1 (src/Drivers/Dense/NlpDenseConsEx1.hpp:21-40,136-222, .cpp:17-54,90-104,246-259): the
+    discretised QP  min <c, x> + 1/2 <x, x>  s.t.  integral(x) = 0.5,  0.1 <= x <= 1  on a (distorted) mesh of [0, 1] with
+    element lengths m_k = m1 + k h, h = 2(1-r)/((1+r) n (n-1)), m1 = 2r/((1+r) n); inner products are mass-weighted
+    (<a, b> = sum m_k a_k b_k), c(t) = -1 + 10 t for t <= 0.1 and 0 after, t_k = the middle of element k; x0 = 0.5.
+    No inequality constraints (Jd is 0 x n).  `exact` = the optimum of the discrete problem (x = clip(lambda - c, 0.1, 1))."""
+    k = np.arange(n, dtype=np.float64)
+    m1 = 2.0 * r / ((1.0 + r) * n)
+    h = 2.0 * (1.0 - r) / (1.0 + r) / (n - 1) / n
+    mass = m1 + k * h
+    t = 0.5 * ((2 * k + 1) * m1 + k * k * h)
+    c = np.where(t <= 0.1, -1.0 + 10.0 * t, 0.0)
+
+    def exact():
+        lo, hi = -5.0, 5.0
+        for _ in range(200):
+            lam = 0.5 * (lo + hi)
+            if float(np.sum(mass * np.clip(lam - c, 0.1, 1.0))) > 0.5:
+                hi = lam
+            else:
+                lo = lam
+        x = np.clip(0.5 * (lo + hi) - c, 0.1, 1.0)
+        return float(np.sum(mass * (c * x + 0.5 * x * x))), x
+    return dict(n=n, Jc=mass.reshape(1, n).copy(), Jd=np.zeros((0, n)), crhs=np.array([0.5]), dl=np.zeros(0), du=np.zeros(0),
+                xl=np.full(n, 0.1), xu=np.full(n, 1.0), x0=np.full(n, 0.5), mass=mass, c=c,
+                f=lambda x: float(np.sum(mass * (c * x + 0.5 * x * x))), grad=lambda x: mass * (x + c),
+                hess_diag=lambda x: mass.copy(), exact=exact)

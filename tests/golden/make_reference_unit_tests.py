@@ -159,6 +159,90 @@ ss = {"m": 6, "n": 6, "iRow": [0, 0, 1, 2, 3, 3, 5], "jCol": [0, 4, 1, 5, 3, 4, 
 case("spsym_startingAtAddSubDiagonalToStartingAt", "tests/LinAlg/matrixTestsSymSparse.hpp:180",
      {"A": ss, "alpha": half, "y": V(one, n=6)}, {"y": V(one, [(0, one + quarter), (1, one + quarter), (3, one + quarter), (5, one + quarter)], n=6)})
 
+# ---- round 2: the rest of the a3 / a14 surface --------------------------------------------------------------
+Kk = 12    # inner dimension of the GEMM tests (driver: K = 100, scaled)
+# W = beta W + alpha A X, all local (matrixTestsDense.hpp:270): A = 2, X = 3, W = 2, alpha = beta = 2
+case("mat_timesMat", f"{MD}:270", {"A": Mx(M_, Kk, two), "X": Mx(Kk, Nn, three), "W": Mx(M_, Nn, two), "alpha": two, "beta": two},
+     {"W": Mx(M_, Nn, two * two + two * two * three * Kk)})
+# W = beta W + alpha A^T X (:308): last row of X zero -> K - 1 terms
+case("mat_transTimesMat", f"{MD}:308",
+     {"A": Mx(Kk, M_, two), "X": Mx(Kk, Nn, three, [(Kk - 1, j, zero) for j in range(Nn)]), "W": Mx(M_, Nn, two), "alpha": two,
+      "beta": two}, {"W": Mx(M_, Nn, two * two + two * two * three * (Kk - 1))})
+# W = beta W + alpha A X^T (:360): last row of X zero -> last column of W only beta W
+case("mat_timesMatTrans", f"{MD}:360",
+     {"A": Mx(M_, Nn, two), "X": Mx(Kk, Nn, three, [(Kk - 1, j, zero) for j in range(Nn)]), "W": Mx(M_, Kk, two), "alpha": two,
+      "beta": two},
+     {"W": Mx(M_, Kk, two * two + two * two * three * Nn, [(i, Kk - 1, two * two) for i in range(M_)])})
+case("mat_addDiagonal", f"{MD}:401", {"A": Mx(Nn, Nn, quarter), "alpha": two, "d": V(half, n=Nn)},
+     {"A": Mx(Nn, Nn, quarter, [(i, i, quarter + half * two) for i in range(Nn)])})
+case("mat_addDiagonal_const", f"{MD}:433", {"A": Mx(Nn, Nn, quarter), "alpha": two},
+     {"A": Mx(Nn, Nn, quarter, [(i, i, quarter + two) for i in range(Nn)])})
+case("mat_maxAbsValue", f"{MD}:625", {"A": Mx(M_, Nn, zero, [(M_ - 1, Nn - 1, one)])}, {"value": one})
+case("mat_maxAbsValue", f"{MD}:639", {"A": Mx(M_, Nn, zero, [(M_ - 1, Nn - 1, -one)])}, {"value": one})
+case("mat_row_max_abs_value", f"{MD}:651", {"A": Mx(M_, Nn, one, [(M_ - 1, Nn - 1, -two)])}, {"y": V(one, [(-1, two)], n=M_)})
+case("mat_scale_row", f"{MD}:682", {"A": Mx(M_, Nn, two), "x": V(three, n=M_), "inv": 0}, {"A": Mx(M_, Nn, two * three)})
+case("mat_isFinite", f"{MD}:707", {"A": Mx(M_, Nn, zero)}, {"ok": 1})
+case("mat_isFinite", f"{MD}:719", {"A": Mx(M_, Nn, zero, [(M_ - 1, Nn - 1, "inf")])}, {"ok": 0})
+Ms = 4     # a smaller source / destination for the copy tests
+case("mat_copyRowsFrom", f"{MD}:778", {"dst": Mx(M_, Nn, one), "src": Mx(Ms, Nn, two), "num_rows": Ms, "row_dest": M_ - Ms},
+     {"dst": Mx(M_, Nn, one, [(i, j, two) for i in range(M_ - Ms, M_) for j in range(Nn)])})
+case("mat_copyRowsFromSelect", f"{MD}:818",
+     {"dst": Mx(Ms, Nn, one), "src": Mx(M_, Nn, two, [(Ms - 1, j, zero) for j in range(Nn)]),
+      "rows": [Ms - 1] + list(range(1, Ms - 1)) + [0]},
+     {"dst": Mx(Ms, Nn, two, [(0, j, zero) for j in range(Nn)])})
+case("mat_copyBlockFromMatrix", f"{MD}:859", {"src": Mx(Ms, 20, one), "dst": Mx(M_, Nn, two), "i0": M_ - Ms, "j0": Nn - 20},
+     {"dst": Mx(M_, Nn, two, [(i, j, one) for i in range(M_ - Ms, M_) for j in range(Nn - 20, Nn)])})
+# dst = src[i0 : i0 + m, j0 : j0 + n] with i0 = src_m - dst_m - 1 (:897): the zero at the last element of src is NOT inside
+case("mat_copyFromMatrixBlock", f"{MD}:897",
+     {"src": Mx(M_, Nn, one, [(M_ - 1, Nn - 1, zero)]), "dst": Mx(Ms, 20, two), "i0": M_ - Ms - 1, "j0": Nn - 20 - 1},
+     {"dst": Mx(Ms, 20, one)})
+case("mat_shiftRows", f"{MD}:979", {"A": Mx(M_, Nn, one, [(0, j, two) for j in range(Nn)]), "shift": M_ - 1},
+     {"A": Mx(M_, Nn, one, [(i, j, two) for i in (0, M_ - 1) for j in range(Nn)])})
+case("mat_shiftRows", f"{MD}:1003", {"A": Mx(M_, Nn, one, [(M_ - 1, j, two) for j in range(Nn)]), "shift": -(M_ - 1)},
+     {"A": Mx(M_, Nn, one, [(i, j, two) for i in (0, M_ - 1) for j in range(Nn)])})
+case("mat_symmetrize", f"{MD}:1102", {"A": Mx(M_, M_, zero, [(i, j, one) for i in range(M_) for j in range(i + 1, M_)])},
+     {"A": Mx(M_, M_, one, [(i, i, zero) for i in range(M_)])})
+# ---- sparse (driver tests/testMatrixSparse.cpp:85-170: second matrix M2 = 2 M rows, same columns; offsets i = 1, j = M2 + 1)
+sm2 = 2 * sm
+sp2 = {"m": sm2, "n": sn, "iRow": [r for r in range(sm2) for _ in cols], "jCol": [c for _ in range(sm2) for c in cols],
+       "val": [one] * (sm2 * len(cols))}
+case("sp_maxAbsValue", f"{MS}:195", {"A": dict(sp, val=[zero] * (sm * len(cols) - 1) + [one])}, {"value": one})
+case("sp_maxAbsValue", f"{MS}:209", {"A": dict(sp, val=[one] * (sm * len(cols) - 1) + [-two])}, {"value": two})
+case("sp_row_max_abs_value", f"{MS}:223", {"A": dict(sp, val=[one] * (sm * len(cols) - 1) + [-two])}, {"y": V(one, [(-1, two)], n=sm)})
+case("sp_scale_row", f"{MS}:255", {"A": dict(sp, val=[two] * (sm * len(cols))), "x": V(three, n=sm), "inv": 0},
+     {"val": V(two * three, n=sm * len(cols))})
+case("sp_isFinite", f"{MS}:277", {"A": dict(sp, val=[two] * (sm * len(cols)))}, {"ok": 1})
+case("sp_isFinite", f"{MS}:286", {"A": dict(sp, val=[two] * (sm * len(cols) - 1) + ["inf"])}, {"ok": 0})
+# W = beta W + alpha A B^T (:504): alpha = 1/2, beta = 2, A = B = 1, W = 0: every (i, j) shares all 5 columns
+case("sp_timesMatTrans", f"{MS}:504", {"A": sp, "B": sp2, "W": Mx(sm, sm2, zero), "alpha": half, "beta": two},
+     {"W": Mx(sm, sm2, two * zero + half * one * one * len(cols))})
+# W += alpha A D^-1 B^T above the diagonal (:587): alpha = 1/2, d = 1/2, offsets (1, M2 + 1); W is (N + 10 M)^2 in the driver,
+# here just large enough; only i <= j entries of the block are touched
+Wb = 1 + sm2 + 1 + sm2 + 2
+case("sp_addMDinvNtransToSymDeMatUTri", f"{MS}:587",
+     {"A": sp, "B": sp2, "D": V(half, n=sn), "W": Mx(Wb, Wb, zero), "alpha": half, "i_offset": 1, "j_offset": sm2 + 1},
+     {"W": Mx(Wb, Wb, zero, [(i, j, half * one * one / half * len(cols)) for i in range(1, 1 + sm)
+                             for j in range(sm2 + 1, sm2 + 1 + sm2) if i <= j])})
+# dense copy of the sparse matrix (:1218)
+case("sp_copy_to", f"{MS}:1218", {"A": dict(sp, val=[two] * (sm * len(cols))), "W": Mx(sm, sn, one)},
+     {"W": Mx(sm, sn, zero, [(r, c, two) for r in range(sm) for c in cols])})
+# ---- symmetric sparse (matrixTestsSymSparse.hpp): upper-triangle triplets ss, A = 1/2
+SS = "tests/LinAlg/matrixTestsSymSparse.hpp"
+ssn = 6
+full = {}
+for r_, c_ in zip(ss["iRow"], ss["jCol"]):
+    full[(r_, c_)] = 1
+    full[(c_, r_)] = 1
+per_row = [sum(1 for (r_, c_) in full if r_ == i) for i in range(ssn)]
+# y = beta y + alpha A x (:87): alpha = 2, beta = 1/2, A = 1/2, y = 2, x = 3; a row counts its entries of the FULL symmetric matrix
+case("spsym_timesVec", f"{SS}:87", {"A": ss, "beta": half, "y": V(two, n=ssn), "alpha": two, "x": V(three, n=ssn)},
+     {"y": {"n": ssn, "fill": 0.0, "set": [[i, half * two + two * half * three * per_row[i]] for i in range(ssn)]}})
+# W upper += alpha A at the diagonal offset (:128): alpha = 1/2, A = 1/2, W = 1
+Wd0 = 3
+case("spsym_addUpperTriangleToSymDenseMatrixUpperTriangle", f"{SS}:128",
+     {"A": ss, "diag_start": Wd0, "alpha": half, "W": Mx(ssn + Wd0, ssn + Wd0, one)},
+     {"W": Mx(ssn + Wd0, ssn + Wd0, one, [(Wd0 + r_, Wd0 + c_, one + half * half) for r_, c_ in zip(ss["iRow"], ss["jCol"])])})
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_unit_tests.json")
 with open(out, "w") as f:
     json.dump({"source": "LLNL/hiop v1.1.0 tests/LinAlg (transcribed constants and expected values)", "cases": cases}, f, indent=0)

@@ -22,15 +22,20 @@ def vec(d):
     return a
 
 
+def _num(v):
+    return float("inf") if v == "inf" else v
+
+
 def mat(d):
     a = np.full((d["m"], d["n"]), d["fill"], dtype=np.float64)
     for i, j, v in d["set"]:
-        a[i, j] = v
+        a[i, j] = _num(v)
     return a
 
 
 def coo(d):
-    return (np.array(d["iRow"], np.int32), np.array(d["jCol"], np.int32), np.array(d["val"], np.float64), d["m"], d["n"])
+    return (np.array(d["iRow"], np.int32), np.array(d["jCol"], np.int32), np.array([_num(v) for v in d["val"]], np.float64),
+            d["m"], d["n"])
 
 
 def close(a, b):
@@ -156,6 +161,56 @@ def run_oracle(case):
         W = mat(a["W"]); ho.trans_add_to_sym_upper(mat(a["A"]), a["row_start"], a["col_start"], a["alpha"], W); return {"W": W}
     if op == "mat_addUpperTriangleToSymDenseMatrixUpperTriangle":
         W = mat(a["W"]); ho.add_upper_to_sym_upper(mat(a["A"]), a["diag_start"], a["alpha"], W); return {"W": W}
+    if op == "mat_timesMat":
+        W = mat(a["W"]); ho.times_mat(mat(a["A"]), a["beta"], W, a["alpha"], mat(a["X"])); return {"W": W}
+    if op == "mat_transTimesMat":
+        W = mat(a["W"]); ho.trans_times_mat(mat(a["A"]), a["beta"], W, a["alpha"], mat(a["X"])); return {"W": W}
+    if op == "mat_timesMatTrans":
+        W = mat(a["W"]); ho.times_mat_trans(mat(a["A"]), a["beta"], W, a["alpha"], mat(a["X"])); return {"W": W}
+    if op == "mat_addDiagonal":
+        A = mat(a["A"]); ho.add_diagonal(A, a["alpha"], g("d")); return {"A": A}
+    if op == "mat_addDiagonal_const":
+        A = mat(a["A"]); ho.add_diagonal(A, a["alpha"]); return {"A": A}
+    if op == "mat_maxAbsValue":
+        return {"value": ho.max_abs_value(mat(a["A"]))}
+    if op == "mat_row_max_abs_value":
+        return {"y": ho.row_max_abs_value(mat(a["A"]))}
+    if op == "mat_scale_row":
+        A = mat(a["A"]); ho.scale_row(A, g("x"), a["inv"]); return {"A": A}
+    if op == "mat_isFinite":
+        return {"ok": int(np.all(np.isfinite(mat(a["A"]))))}
+    if op == "mat_copyRowsFrom":
+        dst = mat(a["dst"]); ho.copy_rows_from(dst, mat(a["src"]), a["num_rows"], a["row_dest"]); return {"dst": dst}
+    if op == "mat_copyRowsFromSelect":
+        dst = mat(a["dst"]); ho.copy_rows_from_select(dst, mat(a["src"]), a["rows"]); return {"dst": dst}
+    if op == "mat_copyBlockFromMatrix":
+        dst = mat(a["dst"]); ho.copy_block_from_matrix(dst, a["i0"], a["j0"], mat(a["src"])); return {"dst": dst}
+    if op == "mat_copyFromMatrixBlock":
+        dst = mat(a["dst"]); ho.copy_from_matrix_block(dst, mat(a["src"]), a["i0"], a["j0"]); return {"dst": dst}
+    if op == "mat_shiftRows":
+        A = mat(a["A"]); ho.shift_rows(A, a["shift"]); return {"A": A}
+    if op == "mat_symmetrize":
+        A = mat(a["A"]); ho.symmetrize(A); return {"A": A}
+    if op == "sp_maxAbsValue":
+        return {"value": float(np.max(np.abs(coo(a["A"])[2])))}
+    if op == "sp_row_max_abs_value":
+        i, j, v, m, n = coo(a["A"]); return {"y": ho.sp_row_max_abs(m, i, v)}
+    if op == "sp_scale_row":
+        i, j, v, m, n = coo(a["A"]); ho.sp_scale_rows(i, v, g("x"), a["inv"]); return {"val": v}
+    if op == "sp_isFinite":
+        return {"ok": int(np.all(np.isfinite(coo(a["A"])[2])))}
+    if op == "sp_timesMatTrans":
+        i, j, v, m, n = coo(a["A"]); i2, j2, v2, m2, _ = coo(a["B"]); W = mat(a["W"])
+        ho.sp_times_mat_trans(m, m2, n, i, j, v, i2, j2, v2, a["beta"], W, a["alpha"]); return {"W": W}
+    if op == "sp_addMDinvNtransToSymDeMatUTri":
+        i, j, v, m, n = coo(a["A"]); i2, j2, v2, m2, _ = coo(a["B"]); W = mat(a["W"])
+        ho.sp_add_MDinvNtrans(m, m2, n, i, j, v, i2, j2, v2, a["i_offset"], a["j_offset"], a["alpha"], g("D"), W); return {"W": W}
+    if op == "sp_copy_to":
+        i, j, v, m, n = coo(a["A"]); return {"W": ho.sp_copy_to_dense(m, n, i, j, v)}
+    if op == "spsym_timesVec":
+        i, j, v, m, n = coo(a["A"]); y = g("y"); ho.spsym_times_vec(n, i, j, v, a["beta"], y, a["alpha"], g("x")); return {"y": y}
+    if op == "spsym_addUpperTriangleToSymDenseMatrixUpperTriangle":
+        i, j, v, m, n = coo(a["A"]); W = mat(a["W"]); ho.spsym_add_upper_to_sym_upper(i, j, v, a["diag_start"], a["alpha"], W); return {"W": W}
     if op == "sp_addMDinvMtransToDiagBlockOfSymDeMatUTri":
         i, j, v, m, n = coo(a["A"]); W = mat(a["W"])
         ho.sp_add_MDinvMtrans_rowmerge(m, i, j, v, a["offset"], a["alpha"], g("D"), W); return {"W": W}
@@ -266,9 +321,83 @@ def run_gpu(ctx, case):
         A = mat(a["A"]); W = D(mat(a["W"]))
         run("hiopamd_mat_add_upper_to_sym_upper", A.shape[0], D(A), A.shape[1], a["diag_start"], a["alpha"], W, W.shape[1])
         return {"W": W.cpu().numpy()}
+    if op in ("mat_timesMat", "mat_transTimesMat", "mat_timesMatTrans"):
+        A, X, W = mat(a["A"]), mat(a["X"]), D(mat(a["W"]))
+        if op == "mat_timesMat":
+            run("hiopamd_mat_times_mat", A.shape[0], A.shape[1], X.shape[1], D(A), A.shape[1], a["beta"], W, W.shape[1], a["alpha"], D(X), X.shape[1])
+        elif op == "mat_transTimesMat":
+            run("hiopamd_mat_trans_times_mat", A.shape[0], A.shape[1], X.shape[1], D(A), A.shape[1], a["beta"], W, W.shape[1], a["alpha"], D(X), X.shape[1])
+        else:
+            run("hiopamd_mat_times_mat_trans", A.shape[0], A.shape[1], X.shape[0], D(A), A.shape[1], a["beta"], W, W.shape[1], a["alpha"], D(X), X.shape[1])
+        return {"W": W.cpu().numpy()}
+    if op == "mat_addDiagonal":
+        A = D(mat(a["A"])); run("hiopamd_mat_add_diagonal_vec", A.shape[0], A, A.shape[1], a["alpha"], D(g("d"))); return {"A": A.cpu().numpy()}
+    if op == "mat_addDiagonal_const":
+        A = D(mat(a["A"])); run("hiopamd_mat_add_diagonal_const", A.shape[0], A, A.shape[1], a["alpha"]); return {"A": A.cpu().numpy()}
+    if op == "mat_maxAbsValue":
+        A = D(mat(a["A"])); torch.cuda.synchronize()
+        return {"value": ctx.reduce_double("hiopamd_mat_max_abs", A.shape[0], A.shape[1], A, A.shape[1])}
+    if op == "mat_row_max_abs_value":
+        A = D(mat(a["A"])); y = D(np.zeros(A.shape[0])); run("hiopamd_mat_row_max_abs", A.shape[0], A.shape[1], A, A.shape[1], y)
+        return {"y": y.cpu().numpy()}
+    if op == "mat_scale_row":
+        A = D(mat(a["A"])); run("hiopamd_mat_scale_rows", A.shape[0], A.shape[1], A, A.shape[1], D(g("x")), a["inv"]); return {"A": A.cpu().numpy()}
+    if op == "mat_isFinite":
+        A = D(mat(a["A"])); torch.cuda.synchronize()
+        return {"ok": ctx.reduce_int("hiopamd_mat_is_finite", A.shape[0], A.shape[1], A, A.shape[1])}
+    if op == "mat_copyRowsFrom":
+        dst, src = D(mat(a["dst"])), D(mat(a["src"]))
+        run("hiopamd_mat_copy_rows_from", a["num_rows"], dst.shape[1], dst, dst.shape[1], a["row_dest"], src, src.shape[1]); return {"dst": dst.cpu().numpy()}
+    if op == "mat_copyRowsFromSelect":
+        dst, src = D(mat(a["dst"])), D(mat(a["src"]))
+        run("hiopamd_mat_copy_rows_from_idx", len(a["rows"]), dst.shape[1], dst, dst.shape[1], src, src.shape[1], D(np.array(a["rows"], np.int32), torch.int32))
+        return {"dst": dst.cpu().numpy()}
+    if op == "mat_copyBlockFromMatrix":
+        dst, src = D(mat(a["dst"])), D(mat(a["src"]))
+        sub = dst[a["i0"]:, a["j0"]:]      # (a view: its data pointer is the block's first element, ld = dst's)
+        torch.cuda.synchronize()
+        ctx.call("hiopamd_mat_copy_block", src.shape[0], src.shape[1], C.c_void_p(sub.data_ptr()), dst.shape[1], src, src.shape[1]); ctx.sync()
+        return {"dst": dst.cpu().numpy()}
+    if op == "mat_copyFromMatrixBlock":
+        dst, src = D(mat(a["dst"])), D(mat(a["src"]))
+        sub = src[a["i0"]:, a["j0"]:]
+        torch.cuda.synchronize()
+        ctx.call("hiopamd_mat_copy_block", dst.shape[0], dst.shape[1], dst, dst.shape[1], C.c_void_p(sub.data_ptr()), src.shape[1]); ctx.sync()
+        return {"dst": dst.cpu().numpy()}
+    if op == "mat_shiftRows":
+        A = D(mat(a["A"])); run("hiopamd_mat_shift_rows", A.shape[0], A.shape[1], A, A.shape[1], a["shift"]); return {"A": A.cpu().numpy()}
+    if op == "mat_symmetrize":
+        A = D(mat(a["A"])); run("hiopamd_mat_symmetrize", A.shape[0], A, A.shape[1]); return {"A": A.cpu().numpy()}
     if op.startswith("sp"):
         i, j, v, m, n = coo(a["A"])
         id_, jd, vd = D(i, torch.int32), D(j, torch.int32), D(v)
+        if op == "sp_maxAbsValue":
+            torch.cuda.synchronize(); return {"value": ctx.reduce_double("hiopamd_vec_infnorm", v.size, vd)}
+        if op == "sp_row_max_abs_value":
+            y = D(np.full(m, 9.0)); run("hiopamd_sp_row_max_abs", m, v.size, id_, vd, y); return {"y": y.cpu().numpy()}
+        if op == "sp_scale_row":
+            run("hiopamd_sp_scale_rows", v.size, id_, vd, D(g("x")), a["inv"]); return {"val": vd.cpu().numpy()}
+        if op == "sp_isFinite":
+            torch.cuda.synchronize(); return {"ok": ctx.reduce_int("hiopamd_vec_isfinite", v.size, vd)}
+        if op in ("sp_timesMatTrans", "sp_addMDinvNtransToSymDeMatUTri"):
+            from hiop_amd._lib import lib
+            i2, j2, v2, m2, _ = coo(a["B"])
+            L = lib(); plan = C.c_void_p()
+            assert L.hiopamd_sp_plan_create(C.byref(plan), m, m2, n, v.size, i.ctypes.data, j.ctypes.data, v2.size, i2.ctypes.data, j2.ctypes.data, 0) == 0
+            W = D(mat(a["W"]))
+            if op == "sp_timesMatTrans":      # = scale W, then the row-build with D = ones (what the HiOp-side adapter does)
+                run("hiopamd_vec_scale", W.numel(), W, a["beta"])
+                run("hiopamd_sp_add_MDinvNt", plan, vd, D(v2), D(np.ones(n)), a["alpha"], W, W.shape[1], 0, 0)
+            else:
+                run("hiopamd_sp_add_MDinvNt", plan, vd, D(v2), D(g("D")), a["alpha"], W, W.shape[1], a["i_offset"], a["j_offset"])
+            L.hiopamd_sp_plan_destroy(plan)
+            return {"W": W.cpu().numpy()}
+        if op == "sp_copy_to":
+            W = D(mat(a["W"])); run("hiopamd_sp_copy_to_dense", m, n, v.size, id_, jd, vd, W, W.shape[1]); return {"W": W.cpu().numpy()}
+        if op == "spsym_timesVec":
+            y = D(g("y")); run("hiopamd_spsym_times_vec", n, v.size, id_, jd, vd, a["beta"], y, a["alpha"], D(g("x"))); return {"y": y.cpu().numpy()}
+        if op == "spsym_addUpperTriangleToSymDenseMatrixUpperTriangle":
+            W = D(mat(a["W"])); run("hiopamd_spsym_add_upper_to_sym_upper", v.size, id_, jd, vd, a["diag_start"], a["alpha"], W, W.shape[1]); return {"W": W.cpu().numpy()}
         if op == "sp_timesVec":
             y = D(g("y")); run("hiopamd_sp_times_vec", m, n, v.size, id_, jd, vd, a["beta"], y, a["alpha"], D(g("x"))); return {"y": y.cpu().numpy()}
         if op == "sp_transTimesVec":

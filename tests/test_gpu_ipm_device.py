@@ -96,8 +96,26 @@ def test_device_ipm_follows_the_oracle_and_reaches_the_selfcheck_objective(ctx, 
     t_cpu, t_gpu = [], []
     r_cpu = ipm_full.solve(ipm_full.OracleOps(full, bounds, model), it0, mu0=mu0, tol=tol, trace=t_cpu)
     dev = DeviceOps(ctx, p, full, bounds, q)
-    r_gpu = ipm_full.solve(dev, it0, mu0=mu0, tol=tol, trace=t_gpu)
+    table = []
+    r_gpu = ipm_full.solve(dev, it0, mu0=mu0, tol=tol, trace=t_gpu, table=table)
     assert r_gpu["iters"] == r_cpu["iters"] and r_gpu["n_fact"] == r_cpu["n_fact"]
+    # the iteration table the HIP run prints (hiopamd_io_format_iteration) against the committed table of the oracle run, under
+    # the reference's own CPU-vs-GPU rule (tests/testMDS1CompareIterations.awk:13-40): numeric columns within 1e-5, same tag
+    import sys
+    from pathlib import Path
+    gold_dir = Path(__file__).parent / "golden"
+    sys.path.insert(0, str(gold_dir))
+    from make_iteration_tables import table_lines
+    got = table_lines(table)
+    want = (gold_dir / f"iteration_table_mds_ex1_{ns}_{nd}.txt").read_text().splitlines(keepends=True)
+    assert len(got) == len(want) and got[0] == want[0]
+    for g, w in zip(got[1:], want[1:]):
+        gf, wf = g.split(), w.split()
+        assert len(gf) == 8 and gf[0] == wf[0] and gf[7] == wf[7], (g, w)
+        for c in range(1, 7):
+            assert abs(float(gf[c]) - float(wf[c])) <= 1e-5, (g, w)
+    if (ns, nd) == (400, 100):
+        assert r_gpu["iters"] == 14      # the reference's iteration count on this problem (14 iterations)
     a, b = np.array(t_cpu), np.array(t_gpu)
     np.testing.assert_allclose(b[:, 2], a[:, 2], rtol=0, atol=0)            # identical barrier schedule
     np.testing.assert_allclose(b[:, 0], a[:, 0], rtol=1e-7, atol=1e-9)     # objective per iteration
@@ -116,7 +134,7 @@ class DeviceOpsDenseEx2:
         from hiop_amd.kkt import HessianLowRank, IpmSlabOps, KKTLinSysLowRank, KKTLinSysXYcYd
         self.ctx, self.n = ctx, q["n"]
         self.Jc, self.Jd = D(q["Jc"]), D(q["Jd"])
-        self.H = HessianLowRank(ctx, self.n, 1, 3, l_max=6, sigma0=1.0, sigma_update_strategy="sigma0")
+        self.H = HessianLowRank(ctx, self.n, q["Jc"].shape[0], q["Jd"].shape[0], l_max=6, sigma0=1.0, sigma_update_strategy="sigma0")
         self.K = KKTLinSysLowRank(ctx, self.H)
         self.fg = KKTLinSysXYcYd(ctx, self.K, D(full_o.ixl), D(full_o.ixu), D(full_o.idl), D(full_o.idu))
         self.fg.set_matrices(None, self.Jc, self.Jd)
@@ -191,3 +209,53 @@ def test_device_quasi_newton_ipm_dense_ex2(ctx, n):
     gold = GOLD["DenseConsEx2"]
     assert r["obj"] == pytest.approx(gold["objective"][gold["n"].index(n)], rel=1e-5)
     assert r["iters"] < 200
+
+
+class DeviceOpsDenseEx1(DeviceOpsDenseEx2):
+    """DenseConsEx1 (mass-weighted QP, one equality constraint, no inequalities) with the same device-resident loop."""
+
+    def __init__(self, ctx, q, full_o, bounds):
+        super().__init__(ctx, q, full_o, bounds)
+        self.mass, self.c = D(q["mass"]), D(q["c"])
+
+    def evaluate(self, it):
+        self.ctx.sync()
+        x = it[:self.n]
+        f = float((self.mass * (self.c * x + 0.5 * x * x)).sum())
+        self.grad = (self.mass * (x + self.c)).contiguous()
+        self.c_val = (self.Jc @ x).contiguous()
+        self.d_val = torch.zeros(0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        return f, self.grad, self.c_val, self.d_val
+
+
+def test_device_quasi_newton_ipm_dense_ex1(ctx):
+    """DenseConsEx1 n = 500 on the HIP low-rank path: the reference's stored -selfcheck objective 8.6156700e-2
+    (src/Drivers/Dense/NlpDenseConsEx1Driver.cpp:139) is reproduced to the reference's own criterion (1e-6 relative), and the
+    run follows the oracle's (same iteration count, objective per iteration to 1e-7)."""
+    from tests.test_oracle_selfcheck import _dense_ex1_setup
+    n = 500
+    q, full, bounds, prov = _dense_ex1_setup(n)
+    it0 = ipm_full.initial_iterate(full, bounds, q["x0"], lambda x: q["Jd"] @ x, 0.1)
+
+    def model(x):
+        return q["f"](x), q["grad"](x), q["Jc"] @ x, q["Jd"] @ x
+
+    class Ops(ipm_full.OracleOps):
+        def kkt_update(self, it, mu):
+            prov.K.H.update(it["x"], q["grad"](it["x"]), q["Jc"], q["Jd"], it["yc"], it["yd"])
+            return super().kkt_update(it, mu)
+    t_cpu, t_gpu = [], []
+    r_cpu = ipm_full.solve(Ops(full, bounds, model), it0, mu0=0.1, tol=1e-8, max_iter=900, trace=t_cpu)
+    q2, full2, bounds2, _ = _dense_ex1_setup(n)
+    dev = DeviceOpsDenseEx1(ctx, q2, full2, bounds2)
+    r = ipm_full.solve(dev, it0, mu0=0.1, tol=1e-8, max_iter=900, trace=t_gpu)
+    assert r["err"] < 1e-8
+    stored = GOLD["DenseConsEx1"]["objective"][0]
+    assert abs(r["obj"] - stored) / abs(r["obj"]) < 1e-6
+    exact, _ = q["exact"]()
+    assert 0.0 <= r["obj"] - exact < 1e-6 * exact
+    # secant updates amplify rounding differences over hundreds of iterations: same path for the first 20, same end
+    a, b = np.array(t_cpu[:20]), np.array(t_gpu[:20])
+    np.testing.assert_allclose(b[:, 0], a[:, 0], rtol=1e-7, atol=1e-10)
+    assert abs(r["iters"] - r_cpu["iters"]) <= max(5, r_cpu["iters"] // 10)

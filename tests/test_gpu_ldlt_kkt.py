@@ -421,3 +421,42 @@ def test_safe_mode_tiny_leading_pivot(ctx, n1, n2):
     np.testing.assert_allclose(Bd.cpu().numpy(), np.linalg.solve(A2, B.T).T, rtol=1e-10, atol=1e-11)
     assert ls.safe_mode_info()[0] <= 3
     ls.close()
+
+
+def test_dataflow_kernels_under_reduced_residency(ctx):
+    """Co-residency: the dataflow solve (one launch, tasks waiting for each other's flags) and the dataflow factorisation
+    (two persistent kernels) must complete whatever share of the device they get — tickets / queues are handed out in a
+    topological order, so a resident workgroup only ever waits for work that is already running.  Here another stream keeps
+    the device busy with large fp64 GEMMs (torch) while factorisations and solves run; results must be bitwise those of the
+    quiet device, and no bounded wait may fire."""
+    from hiop_amd.kkt import LinSolverSymDense
+    n = 2048
+    A = quasi_definite(2 * n // 3, n - 2 * n // 3, 77)
+    B = rng(5).uniform(-1, 1, (3, n))
+    ls = LinSolverSymDense(ctx, n)
+    Mu = D(np.triu(A))
+
+    def run_once():
+        ls.set_sys_matrix(Mu)
+        nneg = ls.matrix_changed()
+        Bd = D(B)
+        torch.cuda.synchronize()
+        ls.solve(Bd, 3)
+        ctx.sync()
+        assert ls.solve_status()
+        return nneg, ls.get_sys_matrix().cpu().numpy(), Bd.cpu().numpy()
+
+    quiet = run_once()
+    side = torch.cuda.Stream()
+    G = torch.rand(4096, 4096, dtype=torch.float64, device="cuda")
+    out = torch.empty_like(G)
+    with torch.cuda.stream(side):
+        for _ in range(60):            # ~ 60 x 1.8 ms of device-filling work queued behind each other
+            torch.mm(G, G, out=out)
+    busy = [run_once() for _ in range(3)]
+    side.synchronize()
+    for nneg, F, X in busy:
+        assert nneg == quiet[0]
+        assert np.array_equal(F, quiet[1])
+        assert np.array_equal(X, quiet[2])
+    ls.close()
