@@ -23,6 +23,7 @@ SOURCES = [
     "vector_kernels.hip",
     "dense_kernels.hip",
     "sparse_kernels.hip",
+    "csr_condensed.hip",
     "gram.hip",
     "ldlt.hip",
     "small_solvers.hip",

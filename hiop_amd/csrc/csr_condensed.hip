@@ -1,0 +1,275 @@
+// Sparse condensed KKT matrix  M = Jd^T diag(Hd) Jd + H + Dx + delta_wx I  in CSR on the device, and the CSR kernels around it
+// (first pinnable piece).
+//
+// reference: hiopKKTLinSysCondensedSparse::build_kkt_matrix (src/Optimization/hiopKKTLinSysSparseCondensed.cpp:205-335) builds
+// M through a chain of general CSR operations — triplet -> CSR, transpose, scale_rows, SpGEMM (times_mat_symbolic/numeric,
+// cuSPARSE SpGEMM-reuse on the GPU: src/LinAlg/hiopMatrixSparseCsrCuda.cpp:695-871), three add_matrix passes — each with a
+// symbolic and a numeric phase.  The sparsity patterns are fixed over the IPM iterations, so here the WHOLE chain is analysed
+// once on the host into one plan: the CSR pattern of M (full symmetric, columns sorted), for every nonzero of Jd^T D Jd the
+// list of its (k1, k2, constraint) product triples (the Schur-row-build plan of csrc/sparse_kernels.hip applied to Jd^T), and
+// the destination of every Hessian triplet (and of its mirror image) and of every diagonal entry.  The numeric phase is four
+// launches: zero, products (one thread / one wave per output nonzero, fixed summation order), Hessian scatter, diagonal.
+// The six CSR "diagonal" methods of hiopMatrixSparseCSR (src/LinAlg/hiopMatrixSparseCSR.hpp:97-255: extract_diagonal,
+// set_diagonal, scale_rows, scale_cols, form_diag_from_symbolic, form_diag_from_numeric) and the CSR mat-vec are plain entry
+// points on (rowptr, colidx, values).
+#include "device_utils.hpp"
+
+#include <algorithm>
+#include <map>
+#include <vector>
+
+struct hiopamd_csr_condensed {
+  hiopamd_ctx* ctx = nullptr;
+  int n = 0, m = 0, nnzJ = 0, nnzH = 0;
+  int64_t nnzM = 0, n_out = 0;
+  hiopamd_sp_plan* plan = nullptr;
+  // device
+  int* rowptr = nullptr;
+  int* colidx = nullptr;
+  double* vals = nullptr;
+  int* permJt = nullptr;        // Jt_val[k] = J_val[permJt[k]]  (Jd^T in row-sorted triplets)
+  double* Jt_val = nullptr;
+  double* Dinv = nullptr;       // m: 1 / Hd
+  int64_t* pos_plan = nullptr;  // plan output -> CSR position
+  int64_t* hpos_u = nullptr;    // Hessian triplet -> CSR position of (i, j)
+  int64_t* hpos_l = nullptr;    // ... of (j, i), -1 for a diagonal triplet
+  int64_t* dpos = nullptr;      // row i -> CSR position of (i, i)
+  std::vector<int> h_rowptr, h_colidx;
+};
+
+namespace {
+template <class T>
+int up(T** d, const std::vector<T>& h)
+{
+  *d = nullptr;
+  if(hipMalloc((void**)d, sizeof(T) * (h.size() ? h.size() : 1)) != hipSuccess) return HIOPAMD_ERR_HIP;
+  if(!h.empty() && hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return HIOPAMD_ERR_HIP;
+  return HIOPAMD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hiopamd_csr_condensed_destroy(hiopamd_csr_condensed* c)
+{
+  if(!c) return HIOPAMD_OK;
+  if(c->ctx) (void)hipStreamSynchronize(c->ctx->stream);
+  if(c->plan) hiopamd_sp_plan_destroy(c->plan);
+  (void)hipFree(c->rowptr); (void)hipFree(c->colidx); (void)hipFree(c->vals); (void)hipFree(c->permJt);
+  (void)hipFree(c->Jt_val); (void)hipFree(c->Dinv); (void)hipFree(c->pos_plan); (void)hipFree(c->hpos_u);
+  (void)hipFree(c->hpos_l); (void)hipFree(c->dpos);
+  delete c;
+  return HIOPAMD_OK;
+}
+
+// symbolic phase.  Jd: m x n triplets (row-sorted, as hiopMatrixSparseTriplet keeps them); H: upper-triangle triplets of the
+// n x n Hessian of the Lagrangian.  Index arrays are HOST pointers.
+int hiopamd_csr_condensed_create(hiopamd_csr_condensed** out, hiopamd_ctx* ctx, int n, int m, int nnzJ, const int* iJ_host,
+                                 const int* jJ_host, int nnzH, const int* iH_host, const int* jH_host)
+{
+  if(!out || !ctx || n < 0 || m < 0 || nnzJ < 0 || nnzH < 0) return HIOPAMD_ERR_ARG;
+  *out = nullptr;
+  for(int k = 0; k < nnzJ; ++k)
+    if(iJ_host[k] < 0 || iJ_host[k] >= m || jJ_host[k] < 0 || jJ_host[k] >= n) return HIOPAMD_ERR_ARG;
+  for(int k = 0; k < nnzH; ++k)
+    if(iH_host[k] < 0 || iH_host[k] >= n || jH_host[k] < iH_host[k] || jH_host[k] >= n) return HIOPAMD_ERR_ARG;   // upper triangle
+  auto* c = new hiopamd_csr_condensed();
+  c->ctx = ctx; c->n = n; c->m = m; c->nnzJ = nnzJ; c->nnzH = nnzH;
+  // Jd^T as row-sorted triplets (n x m): stable sort of the entries by column of Jd
+  std::vector<int> perm(nnzJ);
+  for(int k = 0; k < nnzJ; ++k) perm[k] = k;
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+    return jJ_host[a] != jJ_host[b] ? jJ_host[a] < jJ_host[b] : iJ_host[a] < iJ_host[b];
+  });
+  std::vector<int> ti(nnzJ), tj(nnzJ);
+  for(int k = 0; k < nnzJ; ++k) {
+    ti[k] = jJ_host[perm[k]];
+    tj[k] = iJ_host[perm[k]];
+  }
+  int rc = hiopamd_sp_plan_create(&c->plan, n, n, m, nnzJ, ti.data(), tj.data(), nnzJ, ti.data(), tj.data(), 0);
+  if(rc != HIOPAMD_OK) { hiopamd_csr_condensed_destroy(c); return rc; }
+  c->n_out = hiopamd_sp_plan_num_outputs(c->plan);
+  std::vector<int> oi((size_t)c->n_out + 1), oj((size_t)c->n_out + 1);
+  rc = hiopamd_sp_plan_outputs(c->plan, oi.data(), oj.data());
+  if(rc != HIOPAMD_OK) { hiopamd_csr_condensed_destroy(c); return rc; }
+  // pattern of M = union{ outputs of J^T D J, H and its mirror image, the diagonal }
+  std::vector<std::vector<int>> rows((size_t)n);
+  for(int64_t p = 0; p < c->n_out; ++p) rows[oi[p]].push_back(oj[p]);
+  for(int k = 0; k < nnzH; ++k) {
+    rows[iH_host[k]].push_back(jH_host[k]);
+    if(iH_host[k] != jH_host[k]) rows[jH_host[k]].push_back(iH_host[k]);
+  }
+  for(int i = 0; i < n; ++i) rows[i].push_back(i);
+  c->h_rowptr.assign((size_t)n + 1, 0);
+  for(int i = 0; i < n; ++i) {
+    auto& r = rows[i];
+    std::sort(r.begin(), r.end());
+    r.erase(std::unique(r.begin(), r.end()), r.end());
+    c->h_rowptr[i + 1] = c->h_rowptr[i] + (int)r.size();
+  }
+  c->nnzM = c->h_rowptr[n];
+  c->h_colidx.resize((size_t)c->nnzM);
+  for(int i = 0; i < n; ++i) std::copy(rows[i].begin(), rows[i].end(), c->h_colidx.begin() + c->h_rowptr[i]);
+  auto find = [&](int i, int j) -> int64_t {
+    const int* b = c->h_colidx.data() + c->h_rowptr[i];
+    const int* e = c->h_colidx.data() + c->h_rowptr[i + 1];
+    return (int64_t)(std::lower_bound(b, e, j) - c->h_colidx.data());
+  };
+  std::vector<int64_t> pos((size_t)c->n_out), hu((size_t)nnzH), hl((size_t)nnzH), dp((size_t)n);
+  for(int64_t p = 0; p < c->n_out; ++p) pos[p] = find(oi[p], oj[p]);
+  for(int k = 0; k < nnzH; ++k) {
+    hu[k] = find(iH_host[k], jH_host[k]);
+    hl[k] = iH_host[k] != jH_host[k] ? find(jH_host[k], iH_host[k]) : -1;
+  }
+  for(int i = 0; i < n; ++i) dp[i] = find(i, i);
+  rc = up(&c->rowptr, c->h_rowptr);
+  if(rc == HIOPAMD_OK) rc = up(&c->colidx, c->h_colidx);
+  if(rc == HIOPAMD_OK) rc = up(&c->permJt, perm);
+  if(rc == HIOPAMD_OK) rc = up(&c->pos_plan, pos);
+  if(rc == HIOPAMD_OK) rc = up(&c->hpos_u, hu);
+  if(rc == HIOPAMD_OK) rc = up(&c->hpos_l, hl);
+  if(rc == HIOPAMD_OK) rc = up(&c->dpos, dp);
+  if(rc == HIOPAMD_OK && hipMalloc((void**)&c->vals, sizeof(double) * (size_t)(c->nnzM ? c->nnzM : 1)) != hipSuccess) rc = HIOPAMD_ERR_HIP;
+  if(rc == HIOPAMD_OK && hipMalloc((void**)&c->Jt_val, sizeof(double) * (size_t)(nnzJ ? nnzJ : 1)) != hipSuccess) rc = HIOPAMD_ERR_HIP;
+  if(rc == HIOPAMD_OK && hipMalloc((void**)&c->Dinv, sizeof(double) * (size_t)(m ? m : 1)) != hipSuccess) rc = HIOPAMD_ERR_HIP;
+  if(rc != HIOPAMD_OK) { hiopamd_csr_condensed_destroy(c); return rc; }
+  *out = c;
+  return HIOPAMD_OK;
+}
+
+int64_t hiopamd_csr_condensed_nnz(const hiopamd_csr_condensed* c) { return c ? c->nnzM : 0; }
+int64_t hiopamd_csr_condensed_num_products(const hiopamd_csr_condensed* c) { return c ? hiopamd_sp_plan_num_products(c->plan) : 0; }
+const int* hiopamd_csr_condensed_rowptr(const hiopamd_csr_condensed* c) { return c ? c->rowptr : nullptr; }
+const int* hiopamd_csr_condensed_colidx(const hiopamd_csr_condensed* c) { return c ? c->colidx : nullptr; }
+double* hiopamd_csr_condensed_values(hiopamd_csr_condensed* c) { return c ? c->vals : nullptr; }
+int hiopamd_csr_condensed_pattern(const hiopamd_csr_condensed* c, int* rowptr_host, int* colidx_host)
+{
+  if(!c || !rowptr_host || !colidx_host) return HIOPAMD_ERR_ARG;
+  std::copy(c->h_rowptr.begin(), c->h_rowptr.end(), rowptr_host);
+  std::copy(c->h_colidx.begin(), c->h_colidx.end(), colidx_host);
+  return HIOPAMD_OK;
+}
+
+// numeric phase: values of M for the current iterate.  J_val (nnzJ, in the order of the triplets given at creation), H_val (nnzH),
+// Hd (m: the diagonal weights of the condensation, hiopKKTLinSysSparseCondensed.cpp:240-250), Dx (n), all device pointers.
+int hiopamd_csr_condensed_numeric(hiopamd_csr_condensed* c, const double* J_val, const double* H_val, const double* Hd,
+                                  const double* Dx, double delta_wx)
+{
+  if(!c || (c->nnzJ && !J_val) || (c->nnzH && !H_val) || (c->m && !Hd) || (c->n && !Dx)) return HIOPAMD_ERR_ARG;
+  hiopamd_ctx* ctx = c->ctx;
+  double* vals = c->vals;
+  int rc = hiopamd_vec_set_to_constant(ctx, c->nnzM, vals, 0.0);
+  if(rc != HIOPAMD_OK) return rc;
+  {
+    const int* perm = c->permJt;
+    double* jt = c->Jt_val;
+    rc = hiopamd::launch_ew(ctx, c->nnzJ, [=] __device__(int64_t k) { jt[k] = J_val[perm[k]]; });
+    if(rc != HIOPAMD_OK) return rc;
+    double* di = c->Dinv;
+    rc = hiopamd::launch_ew(ctx, c->m, [=] __device__(int64_t r) { di[r] = 1.0 / Hd[r]; });
+    if(rc != HIOPAMD_OK) return rc;
+  }
+  // J^T D J: sum_r Jt[i, r] Jt[j, r] / (1 / Hd[r]), fixed order (increasing r) per output nonzero
+  rc = hiopamd_sp_MDinvNt_scatter(ctx, c->plan, c->Jt_val, c->Jt_val, c->Dinv, 1.0, vals, c->pos_plan);
+  if(rc != HIOPAMD_OK) return rc;
+  {
+    const int64_t *hu = c->hpos_u, *hl = c->hpos_l;
+    rc = hiopamd::launch_ew(ctx, c->nnzH, [=] __device__(int64_t k) {   // duplicates in the triplet list accumulate, like add_matrix
+      atomicAdd(&vals[hu[k]], H_val[k]);
+      if(hl[k] >= 0) atomicAdd(&vals[hl[k]], H_val[k]);
+    });
+    if(rc != HIOPAMD_OK) return rc;
+    const int64_t* dp = c->dpos;
+    rc = hiopamd::launch_ew(ctx, c->n, [=] __device__(int64_t i) { vals[dp[i]] += Dx[i] + delta_wx; });
+  }
+  return rc;
+}
+
+/* ---- generic CSR kernels (row pointers / column indices int32, device) ---- */
+// y = beta y + alpha A x : one wave per row (rows of the condensed KKT hold 5-50 entries)
+namespace {
+__global__ __launch_bounds__(hiopamd::kBlock) void csr_spmv_kernel(int nrows, const int* __restrict__ rowptr,
+                                                                   const int* __restrict__ colidx, const double* __restrict__ val,
+                                                                   double beta, double* __restrict__ y, double alpha,
+                                                                   const double* __restrict__ x)
+{
+  const int lane = threadIdx.x & 63;
+  const int wpb = hiopamd::kBlock / 64;
+  for(int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < nrows; row += gridDim.x * wpb) {
+    double acc = 0.0;
+    for(int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 64) acc += val[k] * x[colidx[k]];
+    for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if(lane == 0) y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
+  }
+}
+}  // namespace
+int hiopamd_csr_times_vec(hiopamd_ctx* ctx, int nrows, const int* rowptr, const int* colidx, const double* val, double beta,
+                          double* y, double alpha, const double* x)
+{
+  if(nrows < 0) return HIOPAMD_ERR_ARG;
+  if(nrows == 0) return HIOPAMD_OK;
+  const int wpb = hiopamd::kBlock / 64;
+  int grid = (nrows + wpb - 1) / wpb;
+  if(grid > 65536) grid = 65536;
+  hipLaunchKernelGGL(csr_spmv_kernel, dim3(grid), dim3(hiopamd::kBlock), 0, ctx->stream, nrows, rowptr, colidx, val, beta, y, alpha, x);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+// hiopMatrixSparseCSR::extract_diagonal (:97) — 0 where the diagonal entry is not stored
+int hiopamd_csr_extract_diagonal(hiopamd_ctx* ctx, int n, const int* rowptr, const int* colidx, const double* val, double* diag)
+{
+  return hiopamd::launch_ew(ctx, n, [=] __device__(int64_t i) {
+    double d = 0.0;
+    for(int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if(colidx[k] == (int)i) d = val[k];
+    diag[i] = d;
+  });
+}
+// set_diagonal (:105): every STORED diagonal entry = value
+int hiopamd_csr_set_diagonal(hiopamd_ctx* ctx, int n, const int* rowptr, const int* colidx, double* val, double value)
+{
+  return hiopamd::launch_ew(ctx, n, [=] __device__(int64_t i) {
+    for(int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if(colidx[k] == (int)i) val[k] = value;
+  });
+}
+// scale_rows (:178): A <- diag(D) A ; scale_cols (:175): A <- A diag(D)
+int hiopamd_csr_scale_rows(hiopamd_ctx* ctx, int n, const int* rowptr, double* val, const double* D)
+{
+  return hiopamd::launch_ew(ctx, n, [=] __device__(int64_t i) {
+    const double d = D[i];
+    for(int k = rowptr[i]; k < rowptr[i + 1]; ++k) val[k] *= d;
+  });
+}
+int hiopamd_csr_scale_cols(hiopamd_ctx* ctx, int64_t nnz, const int* colidx, double* val, const double* D)
+{
+  return hiopamd::launch_ew(ctx, nnz, [=] __device__(int64_t k) { val[k] *= D[colidx[k]]; });
+}
+// form_diag_from_symbolic (:244) / _numeric (:255): the n x n diagonal matrix diag(D) as CSR
+int hiopamd_csr_form_diag_symbolic(hiopamd_ctx* ctx, int n, int* rowptr, int* colidx)
+{
+  return hiopamd::launch_ew(ctx, (int64_t)n + 1, [=] __device__(int64_t i) {
+    rowptr[i] = (int)i;
+    if(i < n) colidx[i] = (int)i;
+  });
+}
+int hiopamd_csr_form_diag_numeric(hiopamd_ctx* ctx, int n, double* val, const double* D)
+{
+  return hiopamd_vec_copy(ctx, n, val, D);
+}
+
+/* operator callbacks for hiopamd_krylov_create (hiopamd_linop_fn): y = M x and the Jacobi preconditioner y = x ./ diag(M) */
+int hiopamd_csr_condensed_apply(void* user, const double* x_dev, double* y_dev)
+{
+  auto* c = static_cast<hiopamd_csr_condensed*>(user);
+  return hiopamd_csr_times_vec(c->ctx, c->n, c->rowptr, c->colidx, c->vals, 0.0, y_dev, 1.0, x_dev);
+}
+int hiopamd_csr_condensed_jacobi(void* user, const double* x_dev, double* y_dev)
+{
+  auto* c = static_cast<hiopamd_csr_condensed*>(user);
+  const double* vals = c->vals;
+  const int64_t* dp = c->dpos;
+  return hiopamd::launch_ew(c->ctx, c->n, [=] __device__(int64_t i) { y_dev[i] = x_dev[i] / vals[dp[i]]; });
+}
+
+}  // extern "C"

@@ -136,13 +136,15 @@ __global__ __launch_bounds__(kBlock) void mdinv_short(int64_t n_short, const int
                                                       const int* __restrict__ k2, const int* __restrict__ col,
                                                       const double* __restrict__ v1, const double* __restrict__ v2,
                                                       const double* __restrict__ D, double alpha,
-                                                      double* __restrict__ W, int64_t ldw, int r0, int c0)
+                                                      double* __restrict__ W, int64_t ldw, int r0, int c0,
+                                                      const int64_t* __restrict__ pos /* != null: W[pos[p]] (sparse sink) */)
 {
   for(int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_short; p += (int64_t)gridDim.x * kBlock) {
     double acc = 0.0;
     const int64_t e = out_ptr[p + 1];
     for(int64_t q = out_ptr[p]; q < e; ++q) acc += v1[k1[q]] / D[col[q]] * v2[k2[q]];
-    W[(int64_t)(r0 + out_i[p]) * ldw + (c0 + out_j[p])] += alpha * acc;
+    if(pos) W[pos[p]] += alpha * acc;
+    else W[(int64_t)(r0 + out_i[p]) * ldw + (c0 + out_j[p])] += alpha * acc;
   }
 }
 
@@ -176,14 +178,16 @@ __global__ __launch_bounds__(kBlock) void mdinv_long(int64_t first, int64_t n_lo
 }
 __global__ __launch_bounds__(64) void mdinv_long_fold(int64_t first, int64_t n_long, const int* __restrict__ out_i,
                                                       const int* __restrict__ out_j, const double* __restrict__ part,
-                                                      double alpha, double* __restrict__ W, int64_t ldw, int r0, int c0)
+                                                      double alpha, double* __restrict__ W, int64_t ldw, int r0, int c0,
+                                                      const int64_t* __restrict__ pos)
 {
   const int64_t o = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if(o >= n_long) return;
   double s = 0.0;
   for(int q = 0; q < MDINV_SPLIT; ++q) s += part[o * MDINV_SPLIT + q];
   const int64_t p = first + o;
-  W[(int64_t)(r0 + out_i[p]) * ldw + (c0 + out_j[p])] += alpha * s;
+  if(pos) W[pos[p]] += alpha * s;
+  else W[(int64_t)(r0 + out_i[p]) * ldw + (c0 + out_j[p])] += alpha * s;
 }
 
 // y[vec_start+row] += alpha * Msym[row,row] for row in [diag_src_start, diag_src_start+num_elems)
@@ -425,22 +429,44 @@ int hiopamd_sp_plan_destroy(hiopamd_sp_plan* pl)
 int64_t hiopamd_sp_plan_num_outputs(const hiopamd_sp_plan* pl) { return pl ? pl->n_out : 0; }
 int64_t hiopamd_sp_plan_num_products(const hiopamd_sp_plan* pl) { return pl ? pl->n_prod : 0; }
 
-int hiopamd_sp_add_MDinvNt(hiopamd_ctx* ctx, const hiopamd_sp_plan* pl, const double* val1, const double* val2,
-                           const double* D, double alpha, double* W, int64_t ldw, int r0, int c0)
+static int sp_add_MDinvNt_impl(hiopamd_ctx* ctx, const hiopamd_sp_plan* pl, const double* val1, const double* val2,
+                               const double* D, double alpha, double* W, int64_t ldw, int r0, int c0, const int64_t* pos)
 {
   if(!pl) return HIOPAMD_ERR_ARG;
   if(pl->n_short > 0) {
     hipLaunchKernelGGL(mdinv_short, dim3(grid_for(pl->n_short)), dim3(kBlock), 0, ctx->stream, pl->n_short, pl->out_i,
-                       pl->out_j, pl->out_ptr, pl->k1, pl->k2, pl->col, val1, val2, D, alpha, W, ldw, r0, c0);
+                       pl->out_j, pl->out_ptr, pl->k1, pl->k2, pl->col, val1, val2, D, alpha, W, ldw, r0, c0, pos);
   }
   if(pl->n_long > 0) {
     double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)pl->n_long * MDINV_SPLIT);
     hipLaunchKernelGGL(mdinv_long, dim3((unsigned)(pl->n_long * MDINV_SPLIT)), dim3(kBlock), 0, ctx->stream, pl->n_short,
                        pl->n_long, pl->out_ptr, pl->k1, pl->k2, pl->col, val1, val2, D, part);
     hipLaunchKernelGGL(mdinv_long_fold, dim3((unsigned)((pl->n_long + 63) / 64)), dim3(64), 0, ctx->stream, pl->n_short,
-                       pl->n_long, pl->out_i, pl->out_j, part, alpha, W, ldw, r0, c0);
+                       pl->n_long, pl->out_i, pl->out_j, part, alpha, W, ldw, r0, c0, pos);
   }
   HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+int hiopamd_sp_add_MDinvNt(hiopamd_ctx* ctx, const hiopamd_sp_plan* pl, const double* val1, const double* val2,
+                           const double* D, double alpha, double* W, int64_t ldw, int r0, int c0)
+{
+  return sp_add_MDinvNt_impl(ctx, pl, val1, val2, D, alpha, W, ldw, r0, c0, nullptr);
+}
+/* the same products scattered into a SPARSE destination: out_vals[pos[p]] += alpha * (output p), pos a device array of
+ * hiopamd_sp_plan_num_outputs entries (used by the condensed sparse KKT assembly, csrc/csr_condensed.hip) */
+int hiopamd_sp_MDinvNt_scatter(hiopamd_ctx* ctx, const hiopamd_sp_plan* pl, const double* val1, const double* val2,
+                               const double* D, double alpha, double* out_vals, const int64_t* pos_dev)
+{
+  if(!pos_dev) return HIOPAMD_ERR_ARG;
+  return sp_add_MDinvNt_impl(ctx, pl, val1, val2, D, alpha, out_vals, 0, 0, 0, pos_dev);
+}
+/* (row, column) of every output of the plan, in the plan's own order (host arrays of hiopamd_sp_plan_num_outputs ints) */
+int hiopamd_sp_plan_outputs(const hiopamd_sp_plan* pl, int* out_i_host, int* out_j_host)
+{
+  if(!pl || !out_i_host || !out_j_host) return HIOPAMD_ERR_ARG;
+  if(pl->n_out == 0) return HIOPAMD_OK;
+  HIOPAMD_CHECK(hipMemcpy(out_i_host, pl->out_i, sizeof(int) * (size_t)pl->n_out, hipMemcpyDeviceToHost));
+  HIOPAMD_CHECK(hipMemcpy(out_j_host, pl->out_j, sizeof(int) * (size_t)pl->n_out, hipMemcpyDeviceToHost));
   return HIOPAMD_OK;
 }
 

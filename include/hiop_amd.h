@@ -271,6 +271,10 @@ int hiopamd_spsym_times_vec(hiopamd_ctx*, int n, int nnz, const int* iRow, const
 int hiopamd_spsym_add_upper_to_sym_upper(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, const double* val,
                                          int diag_start, double alpha, double* W, int64_t ldw);
 
+/* the Schur products scattered into a SPARSE destination: out_vals[pos[p]] += alpha * (output p of the plan) */
+int hiopamd_sp_MDinvNt_scatter(hiopamd_ctx*, const hiopamd_sp_plan* plan, const double* val1, const double* val2,
+                               const double* D, double alpha, double* out_vals, const int64_t* pos_dev);
+int hiopamd_sp_plan_outputs(const hiopamd_sp_plan* plan, int* out_i_host, int* out_j_host);
 /* the rest of the hiopMatrixSparseTriplet surface (one thread per triplet; used by the HiOp-side adapter) */
 int hiopamd_sp_trans_add_to_sym_upper(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, const double* val,
                                       int row_start, int col_start, double alpha, double* W, int64_t ldw);   /* :255 */
@@ -282,6 +286,38 @@ int hiopamd_sp_indexes_ordered(hiopamd_ctx*, int nnz, const int* iRow, const int
 int hiopamd_sp_num_offdiag(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, int64_t* out_host);        /* :1171,:1338 */
 int hiopamd_sp_extract_diagonal(hiopamd_ctx*, int n, int nnz, const int* iRow, const int* jCol, const double* val,
                                 double* diag);                                                                /* :1355 */
+
+/* =====================================================================================
+ * Sparse condensed KKT matrix in CSR (first piece):
+ *   M = Jd^T diag(Hd) Jd + H + Dx + delta_wx I    (hiopKKTLinSysCondensedSparse::build_kkt_matrix,
+ *   src/Optimization/hiopKKTLinSysSparseCondensed.cpp:205-335; CSR operations of src/LinAlg/hiopMatrixSparseCSR.hpp:97-290)
+ * Symbolic analysis once per sparsity pattern (host index arrays), numeric phase on device values.  The direct solver of the
+ * reference (sparse Cholesky) is NOT part of this library; PCG / BiCGStab (hiopamd_krylov_*) run on the operator callbacks.
+ * ===================================================================================== */
+typedef struct hiopamd_csr_condensed hiopamd_csr_condensed;
+int hiopamd_csr_condensed_create(hiopamd_csr_condensed** out, hiopamd_ctx* ctx, int n, int m, int nnzJ, const int* iJ_host,
+                                 const int* jJ_host, int nnzH_upper, const int* iH_host, const int* jH_host);
+int hiopamd_csr_condensed_destroy(hiopamd_csr_condensed* c);
+int64_t hiopamd_csr_condensed_nnz(const hiopamd_csr_condensed* c);
+int64_t hiopamd_csr_condensed_num_products(const hiopamd_csr_condensed* c);
+int hiopamd_csr_condensed_pattern(const hiopamd_csr_condensed* c, int* rowptr_host, int* colidx_host);
+const int* hiopamd_csr_condensed_rowptr(const hiopamd_csr_condensed* c);   /* device */
+const int* hiopamd_csr_condensed_colidx(const hiopamd_csr_condensed* c);   /* device */
+double* hiopamd_csr_condensed_values(hiopamd_csr_condensed* c);            /* device */
+int hiopamd_csr_condensed_numeric(hiopamd_csr_condensed* c, const double* J_val, const double* H_val, const double* Hd,
+                                  const double* Dx, double delta_wx);
+/* hiopamd_linop_fn callbacks (user = the hiopamd_csr_condensed*): y = M x ; y = x ./ diag(M) (Jacobi preconditioner) */
+int hiopamd_csr_condensed_apply(void* user, const double* x_dev, double* y_dev);
+int hiopamd_csr_condensed_jacobi(void* user, const double* x_dev, double* y_dev);
+/* generic CSR kernels (int32 row pointers / column indices on the device) */
+int hiopamd_csr_times_vec(hiopamd_ctx*, int nrows, const int* rowptr, const int* colidx, const double* val, double beta,
+                          double* y, double alpha, const double* x);
+int hiopamd_csr_extract_diagonal(hiopamd_ctx*, int n, const int* rowptr, const int* colidx, const double* val, double* diag); /* :97 */
+int hiopamd_csr_set_diagonal(hiopamd_ctx*, int n, const int* rowptr, const int* colidx, double* val, double value);          /* :105 */
+int hiopamd_csr_scale_rows(hiopamd_ctx*, int n, const int* rowptr, double* val, const double* D);                            /* :178 */
+int hiopamd_csr_scale_cols(hiopamd_ctx*, int64_t nnz, const int* colidx, double* val, const double* D);                      /* :175 */
+int hiopamd_csr_form_diag_symbolic(hiopamd_ctx*, int n, int* rowptr, int* colidx);                                           /* :244 */
+int hiopamd_csr_form_diag_numeric(hiopamd_ctx*, int n, double* val, const double* D);                                        /* :255 */
 
 /* =====================================================================================
  * hiopLinSolverSymDense operator — no-pivot blocked LDL^T on fp64 MFMA + inertia
