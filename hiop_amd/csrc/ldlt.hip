@@ -138,6 +138,11 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
           sdinv[o + k] = di;
           if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + o + k + 1);
         }
+        // force the row operations of THIS pivot to be carried out here: left to itself the compiler sinks every fma to just
+        // before its result is used (pivot r), keeping the broadcast multipliers (SGPR pairs from v_readlane) of all earlier
+        // pivots alive — ~480 SGPRs, spilled lane by lane through v_writelane / v_readlane: the 16 x 16 factor took 3.5 us
+#pragma unroll
+        for(int r = k + 1; r < LD_SB; ++r) asm volatile("" : "+v"(x[r]));
       }
     }
     if(tid < 2 * LD_SB) {
@@ -1836,7 +1841,7 @@ static DfPlan df_build_plan(int N)
   P.off_chain = DF_HDR;
   P.off_tr = P.off_chain + (int64_t)(P.nsp + 1) * DF_CH;
   P.off_ver = P.off_tr + (int64_t)P.nsp * P.nt;
-  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 16;   // (+ the profiling stamps and phase sums)
+  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 24;   // (+ the profiling stamps and phase sums)
   std::vector<int4> t0, t1;
   df_chain_tasks(true, t0);
   df_chain_tasks(false, t1);
@@ -2140,7 +2145,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   }
   if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
     const DfPlan& P = df->plan;
-    unsigned ph[16];
+    unsigned ph[24];
     (void)hipMemcpy(ph, df->flags + P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1), sizeof(ph), hipMemcpyDeviceToHost);
     const double nup = ph[7] ? ph[7] : 1, ntr = ph[8] ? ph[8] : 1, ntask = nup + ntr;
     std::fprintf(stderr,
@@ -2151,6 +2156,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     if(ph[15])
       std::fprintf(stderr, "[hiop_amd] spine steps (%u), mean us: F + publish %.2f | wait for the older updates of (p,p+1), (p+1,p+1) %.2f | T + U %.2f\n",
                    ph[15], ph[12] * 0.01 / ph[15], ph[13] * 0.01 / ph[15], ph[14] * 0.01 / ph[15]);
+    if(ph[15])
+      std::fprintf(stderr, "[hiop_amd]   inside F: set-up %.2f | 64x64 factor in LDS %.2f | emit + rest %.2f\n", ph[16] * 0.01 / 127.0,
+                   ph[17] * 0.01 / 127.0, (ph[12] - ph[16] - ph[17]) * 0.01 / ph[15]);
   }
   if(dfw[DF_ABORT]) {
     std::fprintf(stderr,

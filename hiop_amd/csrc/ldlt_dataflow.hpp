@@ -394,7 +394,12 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
   if(tid < LD_nb) L.sdinv[tid] = 1.0;
   __syncthreads();
   if(tid == 0 && p == 0) df_stamp(a, j, 0);
+  const unsigned tsa = a.dbg ? (unsigned)wall_clock64() : 0u;
   diag_factor_lds<true>(L.S, L.sdinv, LD_nb, k0, a.info, Li, tid, L.Li);
+  if(a.dbg && tid == 0) {
+    atomicAdd(a.flags + a.off_ph + 16, tsa - ts0);                        // load / LDS set-up
+    atomicAdd(a.flags + a.off_ph + 17, (unsigned)wall_clock64() - tsa);   // diag_factor_lds
+  }
   for(int e = tid; e < LD_nb * LD_nb; e += kBlock) {
     const int r = e >> 6, c = e & 63;
     double v = L.S[r][c];
