@@ -1793,13 +1793,23 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
       if(c == p + 1 || c == p + 2) continue;   // inside S(p) / R(p)
       else if(c <= 3) role = 2;
       else role = 3 + (c - 4);
-      by_role[role].push_back(make_int4(DF_T, p, p, c));
+      // C(p, c) = T(p, c) + the updates U(p; a, c), a = p+1 .. min(3, c), of the same window column, one task.
+      // The FIRST H column (c = 4) is on the critical path (T(2,4) of the companion and T(3,4) of the spine need it pivot
+      // after pivot): its role keeps only the tile solve and the update of the next tile (p+1, 4); the other updates of
+      // that column go to role 2, which has little else to do.
+      if(c == 4) {
+        by_role[role].push_back(make_int4(DF_C, p, c, p + 1));
+        for(int a2 = p + 2; a2 <= 3; ++a2) by_role[2].push_back(make_int4(DF_U, p, a2, c));
+      } else {
+        by_role[role].push_back(make_int4(DF_C, p, c, 0));
+      }
     }
     for(int a = p + 1; a <= cmax; ++a)
       for(int b = a; b <= cmax; ++b) {   // updates by pivot p
         int role;
         if(a == p + 1 && b == p + 1) continue;                                               // inside S(p)
         else if((a == p + 1 && b == p + 2) || (a == p + 2 && b == p + 2)) continue;          // inside R(p)
+        else if(a <= 3 && b != p + 1 && b != p + 2) continue;                                // inside C(p, b)
         else if(b <= 3) role = 2;
         else if(a <= 3) role = 3 + (b - 4);
         else role = 7 + nn_index(a - 4, b - 4) % 9;
@@ -1841,7 +1851,7 @@ static DfPlan df_build_plan(int N)
   P.off_chain = DF_HDR;
   P.off_tr = P.off_chain + (int64_t)(P.nsp + 1) * DF_CH;
   P.off_ver = P.off_tr + (int64_t)P.nsp * P.nt;
-  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 24;   // (+ the profiling stamps and phase sums)
+  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 48;   // (+ the profiling stamps and phase sums)
   std::vector<int4> t0, t1;
   df_chain_tasks(true, t0);
   df_chain_tasks(false, t1);
@@ -2145,7 +2155,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   }
   if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
     const DfPlan& P = df->plan;
-    unsigned ph[24];
+    unsigned ph[48];
     (void)hipMemcpy(ph, df->flags + P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1), sizeof(ph), hipMemcpyDeviceToHost);
     const double nup = ph[7] ? ph[7] : 1, ntr = ph[8] ? ph[8] : 1, ntask = nup + ntr;
     std::fprintf(stderr,
@@ -2156,6 +2166,21 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     if(ph[15])
       std::fprintf(stderr, "[hiop_amd] spine steps (%u), mean us: F + publish %.2f | wait for the older updates of (p,p+1), (p+1,p+1) %.2f | T + U %.2f\n",
                    ph[15], ph[12] * 0.01 / ph[15], ph[13] * 0.01 / ph[15], ph[14] * 0.01 / ph[15]);
+    if(ph[15])
+      std::fprintf(stderr, "[hiop_amd]   spine wait in the second half of the super-panels, mean us by pivot p = 0..3: %.1f %.1f %.1f %.1f\n",
+                   ph[18] * 0.01 / (P.nchain - P.nchain / 2), ph[19] * 0.01 / (P.nchain - P.nchain / 2),
+                   ph[20] * 0.01 / (P.nchain - P.nchain / 2), ph[21] * 0.01 / (P.nchain - P.nchain / 2));
+    if(ph[15])
+      std::fprintf(stderr, "[hiop_amd]   at p = 3 (second half): after F's publish, H tile (3,4) ready after %.1f us, then next-diagonal tile (4,4) after another %.1f us\n",
+                   ph[22] * 0.01 / (P.nchain - P.nchain / 2), ph[23] * 0.01 / (P.nchain - P.nchain / 2));
+    if(ph[15]) {
+      const double nl = P.nchain - P.nchain / 2;
+      std::fprintf(stderr, "[hiop_amd]   first H column, mean us since F(0) start (second half): F(p) published at %.0f %.0f %.0f %.0f\n", ph[40] * 0.01 / nl,
+                   ph[41] * 0.01 / nl, ph[42] * 0.01 / nl, ph[43] * 0.01 / nl);
+      for(int r = 0; r < 4; ++r)
+        std::fprintf(stderr, "[hiop_amd]     tile (%d,4): updates by pivots 0,1,2 published at %.0f %.0f %.0f | T(%d,4) published at %.0f\n", r,
+                     ph[24 + 4 * r] * 0.01 / nl, ph[25 + 4 * r] * 0.01 / nl, ph[26 + 4 * r] * 0.01 / nl, r, ph[27 + 4 * r] * 0.01 / nl);
+    }
     if(ph[15])
       std::fprintf(stderr, "[hiop_amd]   inside F: set-up %.2f | 64x64 factor in LDS %.2f | emit + rest %.2f\n", ph[16] * 0.01 / 127.0,
                    ph[17] * 0.01 / 127.0, (ph[12] - ph[16] - ph[17]) * 0.01 / ph[15]);

@@ -34,7 +34,7 @@ constexpr int DF_CV = 0, DF_HV = 16, DF_CDONE = 33, DF_HDONE = 34, DF_UPDONE = 3
 constexpr int DF_MAXT = 40;           // chain tasks per role per super-panel (<= 28 used)
 constexpr int DF_ROLES = 16;
 
-enum { DF_F = 1, DF_T = 2, DF_U = 3, DF_S = 4, DF_R = 5, DF_END = 0 };
+enum { DF_F = 1, DF_T = 2, DF_U = 3, DF_S = 4, DF_R = 5, DF_C = 6, DF_END = 0 };
 enum { DF_TR = 1, DF_UP = 2 };
 
 struct DfArgs {
@@ -80,6 +80,15 @@ __device__ __forceinline__ void df_stamp(const DfArgs& a, int j, int k)
   unsigned* p = a.flags + a.off_ts + (int64_t)j * 8 + k;
   if(k & 1) atomicMax(p, now);
   else atomicMax(p, 0xffffffffu - now);
+}
+
+// profiling aid (a.dbg != 0): mean time, since F(0) of the super-panel started, at which the k-th event of row r of the first
+// H column happened (second half of the super-panels only); slot = 24 + 4 r + k
+__device__ __forceinline__ void df_col4_stamp(const DfArgs& a, int j, int r, int k)
+{
+  if(!a.dbg || j < a.nchain / 2) return;
+  const unsigned start = 0xffffffffu - df_ld(a.flags + a.off_ts + (int64_t)j * 8 + 0);
+  atomicAdd(a.flags + a.off_ph + 24 + 4 * r + k, (unsigned)wall_clock64() - start);
 }
 
 struct DfWait {
@@ -415,6 +424,10 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
     if(tid == 0) {
       df_add(vpp, 1u);
       df_add(cf + DF_CDONE, 1u);
+      if(a.dbg && j >= a.nchain / 2) {
+        const unsigned start = 0xffffffffu - df_ld(a.flags + a.off_ts + (int64_t)j * 8 + 0);
+        atomicAdd(a.flags + a.off_ph + 40 + p, (unsigned)wall_clock64() - start);   // F(p) published
+      }
     }
   };
   if(!with_tu) {
@@ -436,6 +449,17 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
     // any blocking wait: in the phases where the wide kernel is behind, that wait is long
     const bool ready = df_peek(w1, sh_ok);
     publish_f();
+    if(a.dbg && p == 3 && j >= a.nchain / 2 && tid == 0) {   // profiling aid: which of the conditions is the late one?
+      const unsigned t0 = (unsigned)wall_clock64();
+      unsigned tw[3] = {0u, 0u, 0u};
+      for(int q = 0; q < 3; ++q) {
+        unsigned spins = 0;
+        while(df_ld(w1.f[q]) < w1.v[q] && ++spins < 100000u) __builtin_amdgcn_s_sleep(4);
+        tw[q] = (unsigned)wall_clock64() - t0;
+      }
+      atomicAdd(a.flags + a.off_ph + 22, tw[0]);
+      atomicAdd(a.flags + a.off_ph + 23, tw[1] - tw[0]);
+    }
     if(!ready && !df_wait(a.flags, w1, sh_ok, t_start, 100, j, DF_S, p, 1)) return false;
   }
   const unsigned ts2 = a.dbg ? (unsigned)wall_clock64() : 0u;
@@ -545,6 +569,7 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
     const unsigned ts3 = (unsigned)wall_clock64();
     atomicAdd(a.flags + a.off_ph + 12, ts1 - ts0);
     atomicAdd(a.flags + a.off_ph + 13, ts2 - ts1);
+    if(j >= a.nchain / 2) atomicAdd(a.flags + a.off_ph + 18 + p, ts2 - ts1);   // second half of the factorisation, by pivot
     atomicAdd(a.flags + a.off_ph + 14, ts3 - ts2);
     atomicAdd(a.flags + a.off_ph + 15, 1u);
   }
@@ -576,6 +601,7 @@ __device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p,
   if(tid == 0) {
     df_add(vpc, 1u);
     df_add(cf + (c < 4 ? DF_CDONE : DF_HDONE), 1u);
+    if(c == 4) df_col4_stamp(a, j, p, 3);
   }
   const DfTile tmc = df_tile(a, j, m, c), tcc = df_tile(a, j, c, c);
   {   // U(p; p+2, p+2) needs only this task's own V / U (drained above): before the wait for the spine
@@ -595,6 +621,56 @@ __device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p,
   if(tid == 0) {
     df_add(vcc, 1u);
     df_add(vmc, 1u);
+    if(c == 4) df_col4_stamp(a, j, m, p);
+  }
+  return true;
+}
+
+// C(p, c): a column step — T(p, c) followed by the updates U(p; a, c), a = p+1 .. min(3, c), of the tiles below it in the
+// same window column, in ONE task.  As separate tasks the ten tasks of an H column (T(0,c), U(0;1..3,c), T(1,c), ...) were a
+// serial chain of ~13 us links, as long as the spine's own period: the spine waited 29 us per super-panel at p = 3 for the
+// last of them.  Inside one task only the first link pays the task overheads; the updates read this task's own U(p, c) back
+// from L2 (already drained for the publish of T) and are drained together at the end.
+__device__ __forceinline__ bool df_column_step(const DfArgs& a, int j, int p, int c, int amax_in, int role, int* sh_ok,
+                                               long long t_start, int tid)
+{
+  unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
+  unsigned bpp, bpc;
+  unsigned* vpp = df_ver(a, j, p, p, &bpp);
+  unsigned* vpc = df_ver(a, j, p, c, &bpc);
+  {
+    DfWait w(a.flags + DF_ABORT);
+    w.set<0>(vpp, bpp + p + 1);
+    w.set<1>(vpc, bpc + p);
+    if(c >= 4 && p == 0) w.set<2>(df_wide_ver(a, j, p, c), (unsigned)j);
+    if(j >= 2) w.set<3>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
+    if(!df_wait(a.flags, w, sh_ok, t_start, 100 + role, j, DF_C, p, c)) return false;
+  }
+  df_task_solve(a, j, p, c, tid);
+  df_drain();
+  if(tid == 0 && c >= 4) df_stamp(a, j, 3);
+  if(tid == 0) {
+    df_add(vpc, 1u);
+    df_add(cf + (c < 4 ? DF_CDONE : DF_HDONE), 1u);
+    if(c == 4) df_col4_stamp(a, j, p, 3);      // T(p, 4) published
+  }
+  const int amax = amax_in > 0 ? amax_in : (c < 3 ? c : 3);   // (the first H column keeps only its next tile: see df_chain_tasks)
+  for(int ta = p + 1; ta <= amax; ++ta) {
+    unsigned ba, bt;
+    unsigned* va = df_ver(a, j, p, ta, &ba);
+    unsigned* vt = df_ver(a, j, ta, c, &bt);
+    DfWait w(a.flags + DF_ABORT);
+    w.set<0>(va, ba + p + 1);     // V(p, ta) published (this task's own when ta == c)
+    w.set<1>(vt, bt + p);
+    if(c >= 4 && p == 0) w.set<2>(df_wide_ver(a, j, ta, c), (unsigned)j);
+    if(!df_wait(a.flags, w, sh_ok, t_start, 100 + role, j, 1000 * p + DF_C, ta, c)) return false;
+    const DfTile dst = df_tile(a, j, ta, c);
+    df_task_update(a, j, p, ta, c, dst, dst, tid);
+    df_drain();                       // published tile by tile: the next pivot's tile solve of this column waits for the first one
+    if(tid == 0) {
+      df_add(vt, 1u);
+      if(c == 4) df_col4_stamp(a, j, ta, p);   // update of pivot p on tile (ta, 4) published
+    }
   }
   return true;
 }
@@ -630,6 +706,8 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
         carried = ta != 0;   // with the T / U part the updated tile (p+1, p+1) — (0, 0) of the next super-panel for p = 3 — is in L.S
       } else if(tk.x == DF_R) {
         if(!df_companion_step(a, j, p, &sh_ok, t_start, tid)) return;
+      } else if(tk.x == DF_C) {
+        if(!df_column_step(a, j, p, ta, tb, role, &sh_ok, t_start, tid)) return;
       } else if(tk.x == DF_F) {
         unsigned* v = df_ver(a, j, p, p, &base);
         w.set<0>(v, base + p);
@@ -675,7 +753,10 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
         const DfTile src = (ta >= 4 && p == 0) ? df_tile_in_matrix(a, j, ta, tb) : dst;
         df_task_update(a, j, p, ta, tb, src, dst, tid);
         df_drain();
-        if(tid == 0) df_add(v, 1u);
+        if(tid == 0) {
+          df_add(v, 1u);
+          if(tb == 4 && ta < 4) df_col4_stamp(a, j, ta, p);
+        }
       }
       __syncthreads();   // REQUIRED, see ldlt_wide_kernel: separates this task's lane-0 signalling from the next task's lane-0 polling
     }
@@ -687,7 +768,10 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // TR(j, c16): 16 columns starting at c16 of the tail of row panel j.  FOUR waves: wave I owns the 16-row sub-block I of
 // every 64-row block row (algorithm of ldlt_headtrsm_kernel); every shared operand through sc1 loads.
-__device__ __forceinline__ void df_task_trsm(const DfArgs& a, int j, int c16, double* smem, int tid)
+// `early`: the task was taken before C_j was completely factored (see the selection loop): block row P then waits for the
+// tiles of column P of C_j — F(P) and T(q, P), q < P — and the substitution advances in step with the chain kernel.
+__device__ __forceinline__ bool df_task_trsm(const DfArgs& a, int j, int c16, double* smem, int tid, bool early, int* sh_ok,
+                                             long long t_start)
 {
   double(*Vs)[LD_SB + 1] = reinterpret_cast<double(*)[LD_SB + 1]>(smem);   // 256 x 17
   const int lane = tid & 63, g = lane >> 4, li = lane & 15;
@@ -711,6 +795,15 @@ __device__ __forceinline__ void df_task_trsm(const DfArgs& a, int j, int c16, do
   __syncthreads();   // the LDS buffer may still be read by the previous task's waves
 #pragma unroll
   for(int P = 0; P < 4; ++P) {
+    if(early) {
+      unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
+      DfWait w(a.flags + DF_ABORT);
+      w.set<0>(cf + DF_CV + P * 4 + P, 4u + P + 1u);                        // F(P)
+      if(P >= 1) w.set<1>(cf + DF_CV + 0 * 4 + P, 4u + 0 + 1u);             // T(0, P)
+      if(P >= 2) w.set<2>(cf + DF_CV + 1 * 4 + P, 4u + 1 + 1u);             // T(1, P)
+      if(P >= 3) w.set<3>(cf + DF_CV + 2 * 4 + P, 4u + 2 + 1u);             // T(2, P)
+      if(!df_wait(a.flags, w, sh_ok, t_start, 4, j, c16, P, 0)) return false;
+    }
     const double* Dk = Dk_sp + P * (LD_nb * LD_nb);
     const double* Li = Li_sp + P * (4 * LD_SB * LD_SB);
     // the factored diagonal block, its compact tiles and the 16 x 16 inverses are write-once data read after their flag:
@@ -762,6 +855,7 @@ __device__ __forceinline__ void df_task_trsm(const DfArgs& a, int j, int c16, do
       }
     }
   }
+  return true;
 }
 
 // UP(j, I, J): the 128 x 128 tile (I, J) of the trailing matrix -= V_j[:, rows of I]^T U_j[:, columns of J], K = 256.
@@ -1073,7 +1167,7 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
   // cached descriptors of those two super-panels ({first TR task, TR tasks, first UP task, UP tasks}, thresholds)
   int jtr = 0, jup = 0, jtr_c = -1, jup_c = -1;
   int4 qt = make_int4(0, 0, 0, 0), qu = make_int4(0, 0, 0, 0);
-  unsigned first_prev = 0u, upcnt_prev2 = 0u;
+  unsigned first_prev = 0u, upcnt_prev2 = 0u, prev_all = 0u;
   __shared__ int4 sh_task;
   for(;;) {
     if(tid == 0) {
@@ -1088,6 +1182,7 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
         if(jtr != jtr_c && jtr < a.nwide) {
           qt = a.wq[jtr];
           first_prev = jtr >= 1 ? a.wfirst[jtr - 1] : 0u;
+          prev_all = jtr >= 1 ? (unsigned)a.wq[jtr - 1].w : 0u;
           upcnt_prev2 = jtr >= 2 ? a.upcnt[jtr - 2] : 0u;
           jtr_c = jtr;
         }
@@ -1134,6 +1229,23 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
             ++jup;
             continue;
           }
+        }
+        // Nothing to do right now.  Rather than idle, take a substitution task of the row panel whose diagonal block the
+        // chain kernel is STILL factoring (its first tile is done): the task follows the chain block row by block row and
+        // finishes one block row after it, instead of starting ~45 us of latency-bound work when C_j is complete — in the
+        // super-panels where the chain is the bottleneck that latency was on the critical path (chain -> TR -> first update
+        // tiles -> chain).  Only when every update task of the previous super-panel is taken, so that whatever the chain
+        // still waits for is already running.
+        if(jtr < a.nwide && tr_taken < (unsigned)qt.y && cd >= 1u && cd < 10u && (jtr < 1 || upprev >= prev_all) &&
+           (jtr < 2 || updone2 >= upcnt_prev2)) {
+          const unsigned i = __hip_atomic_fetch_add(qtr + DF_TRQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if(i < (unsigned)qt.y) {
+            kind = 1;
+            task = make_int4(DF_TR, jtr, LD_NB * (jtr + 2) + 16 * (int)i, -1);   // w = -1: early
+            break;
+          }
+          ++jtr;
+          continue;
         }
         __builtin_amdgcn_s_sleep(32);
         if((++spins & 15u) == 0) {
@@ -1193,7 +1305,7 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
       }
       if(tid == 0) df_stamp(a, j, 4);
       lap(1);
-      df_task_trsm(a, j, c16, smem, tidv);
+      if(!df_task_trsm(a, j, c16, smem, tidv, tk.w < 0, &sh_ok, t_start)) return;
       lap(2);
       df_drain();
       if(tid == 0) df_add(trj + J, 1u);

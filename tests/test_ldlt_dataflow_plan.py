@@ -18,7 +18,7 @@ import random
 import numpy as np
 import pytest
 
-F, T, U, SP, RC, END = 1, 2, 3, 4, 5, 0   # SP / RC: the fused spine step S(p) and its companion R(p)
+F, T, U, SP, RC, CS, END = 1, 2, 3, 4, 5, 6, 0   # SP / RC / CS: fused spine step S(p), its companion R(p), column step C(p, c)
 TR, UP = 1, 2
 
 
@@ -106,11 +106,15 @@ class Sim:
         ty, p, a, b = tk
         if ty == SP:    # F(p) -> T(p, p+1) -> U(p; p+1, p+1)
             return [(F, p, p, p)] + ([(T, p, p, p + 1), (U, p, p + 1, p + 1)] if a else [])
-        return [(T, p, p, p + 2), (U, p, p + 1, p + 2), (U, p, p + 2, p + 2)]   # RC
+        if ty == RC:
+            return [(T, p, p, p + 2), (U, p, p + 1, p + 2), (U, p, p + 2, p + 2)]
+        c = a                                                                    # CS: T(p, c) + U(p; a', c), a' = p+1 .. amax
+        amax = b if b > 0 else min(3, c)
+        return [(T, p, p, c)] + [(U, p, a2, c) for a2 in range(p + 1, amax + 1)]
 
     def chain_ready(self, j, tk):
         ty, p, a, b = tk
-        if ty in (SP, RC):
+        if ty in (SP, RC, CS):
             # every wait of the fused task on OTHER roles' work, required up front (stricter than the kernel, which waits for
             # the later parts' conditions only when it reaches them): conditions on the task's own earlier parts are dropped
             parts = self.fused_parts(tk)
@@ -151,7 +155,7 @@ class Sim:
 
     def chain_run(self, j, tk):
         ty, p, a, b = tk
-        if ty in (SP, RC):
+        if ty in (SP, RC, CS):
             for q in self.fused_parts(tk):
                 self.chain_run(j, q)
             return
@@ -298,6 +302,12 @@ def replay(A, plan, n_workers, seed):
                     return int(Q[jup][2] + i)
             if jtr >= nw and jup >= nw:
                 return "done"
+            # nothing eligible: an EARLY substitution task (the chain has only started C_jtr); it is held until C_jtr is
+            # complete (the kernel advances it block row by block row — here it simply blocks its worker, which is stricter)
+            if jtr < nw and trq[jtr] < Q[jtr][1] and 1 <= sim.cdone[jtr] < 10 and \
+                    (jtr < 1 or upq[jtr - 1] >= Q[jtr - 1][3]) and (jtr < 2 or sim.updone[jtr - 2] >= sim.upcnt[jtr - 2]):
+                i = trq[jtr]; trq[jtr] += 1
+                return int(Q[jtr][0] + i)
             return None
 
     finished = [False] * n_workers
