@@ -123,8 +123,13 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
     double x[LD_SB];
 #pragma unroll
     for(int r = 0; r < LD_SB; ++r) x[r] = is_a ? S[o + r][o + c] /* zeros below the diagonal */ : ((r == c) ? 1.0 : 0.0);
+    // reciprocal pivots and the first bad pivot are collected in registers and written once after the loop: a `tid == 0`
+    // block per pivot cut the unrolled loop into 16 basic blocks (no scheduling across pivots)
+    double dis[LD_SB];
+    int bad = 0;
 #pragma unroll
     for(int k = 0; k < LD_SB; ++k) {
+      dis[k] = 1.0;
       if(o + k < kb) {  // uniform
         const double d = bcast_lane(x[k], k);          // pivot (lane k of the `a` half)
         const double di = fast_rcp(d);
@@ -134,16 +139,20 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
           const double vkr = bcast_lane(x[k], r);      // S[k][r] (lane r of the `a` half): multiplier of row r is vkr/d
           x[r] = fma(-vkr, xkc, x[r]);
         }
-        if(tid == 0) {
-          sdinv[o + k] = di;
-          if(d == 0.0 || !isfinite(d)) atomicCAS(info, 0, k0 + o + k + 1);
-        }
+        dis[k] = di;
+        bad = (bad == 0 && (d == 0.0 || !isfinite(d))) ? (k + 1) : bad;
         // force the row operations of THIS pivot to be carried out here: left to itself the compiler sinks every fma to just
         // before its result is used (pivot r), keeping the broadcast multipliers (SGPR pairs from v_readlane) of all earlier
         // pivots alive — ~480 SGPRs, spilled lane by lane through v_writelane / v_readlane: the 16 x 16 factor took 3.5 us
 #pragma unroll
         for(int r = k + 1; r < LD_SB; ++r) asm volatile("" : "+v"(x[r]));
       }
+    }
+    if(tid == 0) {
+#pragma unroll
+      for(int k = 0; k < LD_SB; ++k)
+        if(o + k < kb) sdinv[o + k] = dis[k];
+      if(bad) atomicCAS(info, 0, k0 + o + bad);
     }
     if(tid < 2 * LD_SB) {
 #pragma unroll
