@@ -371,7 +371,7 @@ struct DfChainLds {
 // solves need them), T's and U's together at the end.  `carried`: the tile to factor is already in L.S (left there by the
 // previous step's update).  Returns false when the factorisation was aborted.
 __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, bool with_tu, bool carried, DfChainLds& L, int* sh_ok,
-                                              long long t_start, int tid)
+                                              long long t_start, int tid, unsigned*& pending)
 {
   const int lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
   const int k0 = LD_NB * j + 64 * p;
@@ -422,6 +422,7 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
     df_drain();
     if(tid == 0 && p == 3) df_stamp(a, j, 1);
     if(tid == 0) {
+      if(pending) df_add(pending, 1u);   // the previous step's update of this tile: its stores were drained just now as well
       df_add(vpp, 1u);
       df_add(cf + DF_CDONE, 1u);
       if(a.dbg && j >= a.nchain / 2) {
@@ -432,6 +433,7 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
   };
   if(!with_tu) {
     publish_f();
+    pending = nullptr;
     return true;
   }
   const unsigned ts1 = a.dbg ? (unsigned)wall_clock64() : 0u;
@@ -449,6 +451,7 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
     // any blocking wait: in the phases where the wide kernel is behind, that wait is long
     const bool ready = df_peek(w1, sh_ok);
     publish_f();
+    pending = nullptr;
     if(a.dbg && p == 3 && j >= a.nchain / 2 && tid == 0) {   // profiling aid: which of the conditions is the late one?
       const unsigned t0 = (unsigned)wall_clock64();
       unsigned tw[3] = {0u, 0u, 0u};
@@ -563,8 +566,10 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
         stg_sc1(tcc.p + (int64_t)row * tcc.ld + col, r);   // (the stepwise hand-over of a ragged order reads it; cheap)
         L.S[row][col] = (col >= row) ? r : 0.0;
       }
-  df_drain();
-  if(tid == 0) df_add(vcc, 1u);
+  // the count of this update is published with the NEXT step's F (one drain less on the critical path): only tasks that
+  // also wait for that F look at it — the tile itself travels in LDS
+  __syncthreads();
+  pending = vcc;
   if(a.dbg && tid == 0) {   // spine accounting: F part | wait for the tile's older updates | T + U part | steps
     const unsigned ts3 = (unsigned)wall_clock64();
     atomicAdd(a.flags + a.off_ph + 12, ts1 - ts0);
@@ -687,6 +692,7 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
   if(tid < 2 * DF_MAXT) sh_tasks[tid / DF_MAXT][tid % DF_MAXT] = a.ctasks[((tid / DF_MAXT) * DF_ROLES + role) * DF_MAXT + tid % DF_MAXT];
   __syncthreads();
   bool carried = false;   // role 0: the tile to factor next is in L.S
+  unsigned* pending = nullptr;   // role 0: version counter of the tile updated by the last spine step, not yet published
   for(int j = 0; j < a.nchain; ++j) {
     const bool has_next = (j + 1 < a.nchain) || a.last_has_next;
     const int4* tasks = sh_tasks[has_next ? 0 : 1];
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
       DfWait w(a.flags + DF_ABORT);
       unsigned base;
       if(tk.x == DF_S) {
-        if(!df_spine_step(a, j, p, ta != 0, carried, L, &sh_ok, t_start, tid)) return;
+        if(!df_spine_step(a, j, p, ta != 0, carried, L, &sh_ok, t_start, tid, pending)) return;
         carried = ta != 0;   // with the T / U part the updated tile (p+1, p+1) — (0, 0) of the next super-panel for p = 3 — is in L.S
       } else if(tk.x == DF_R) {
         if(!df_companion_step(a, j, p, &sh_ok, t_start, tid)) return;
