@@ -98,6 +98,40 @@ def cpu_baseline(p, Dx, Dd, rhs, nsolves, steps):
                        f"on the host via oracle/hiop_oracle.py (numpy + scipy-OpenBLAS LAPACK)")
 
 
+def _fake_multi():
+    """HIOPAMD_BENCH_FAKE_MULTI=1 (test aid, never set by the driver): run the N > 1 code path on ONE GPU — every rank on device
+    0, torch.distributed over gloo, the library's all-reduce hook staged through the host instead of RCCL.  Timings are
+    meaningless; it exists so that the multi-rank control flow can be exercised where only one GPU is available."""
+    return os.environ.get("HIOPAMD_BENCH_FAKE_MULTI", "0") == "1"
+
+
+def _install_host_allreduce(ctx, dist):
+    """generic all-reduce hook of the library (hiopamd_ctx_set_allreduce) through host staging + gloo"""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from hiop_amd._lib import ALLREDUCE_FN
+    L = ctx._L
+
+    def hook(user, buf, count, op, stream):
+        try:
+            host = np.empty(int(count), dtype=np.float64)
+            if L.hiopamd_copy_d2h(ctx.h, C.c_void_p(host.ctypes.data), C.c_void_p(buf), int(count) * 8) != 0:
+                return -1
+            rop = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[int(op)]
+            dist.all_reduce(torch.from_numpy(host), op=rop)
+            if L.hiopamd_copy_h2d(ctx.h, C.c_void_p(buf), C.c_void_p(host.ctypes.data), int(count) * 8) != 0:
+                return -1
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            print("allreduce hook failed:", e, file=sys.stderr)
+            return -1
+    ctx._allreduce_cb = ALLREDUCE_FN(hook)     # keep the trampoline alive
+    rc = L.hiopamd_ctx_set_allreduce(ctx.h, ctx._allreduce_cb, None, dist.get_rank(), dist.get_world_size())
+    if rc != 0:
+        raise RuntimeError(f"hiopamd_ctx_set_allreduce failed: {rc}")
+
+
 def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False):
     """Memory-distributed dense-constraint case (BASELINE configs[1]/[3]): quasi-Newton low-rank KKT with the
     variables column-sharded over the GPUs of the node, n_local per GPU fixed (weak scaling), k = m constraints,
@@ -110,7 +144,10 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
     n, me, mi, l = a.dense_nlocal, a.dense_k // 2, a.dense_k - a.dense_k // 2, 6
     hooked = hooked and world > 1
     if hooked:
-        ctx.init_rccl_from_torch_distributed()
+        if _fake_multi():
+            _install_host_allreduce(ctx, dist)
+        else:
+            ctx.init_rccl_from_torch_distributed()
     gl = torch.Generator(device="cuda"); gl.manual_seed(1000 + rank)     # local (sharded) data
     gr = torch.Generator(device="cuda"); gr.manual_seed(7)               # replicated data
     U = lambda g, *shape, lo=-1.0, hi=1.0: torch.rand(*shape, generator=g, device="cuda", dtype=torch.float64) * (hi - lo) + lo
@@ -155,7 +192,7 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if _fake_multi() else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     k = me + mi
@@ -232,6 +269,8 @@ def spawn_ranks(a):
     import subprocess
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if _fake_multi() and have >= 1:
+        have = a.gpus
     if have < a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} HIP device(s) visible on this node")
     s = socket.socket()
@@ -262,10 +301,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: no HIP device visible (there is no CPU product path)")
+    if _fake_multi():
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if _fake_multi() else "nccl", rank=rank, world_size=world)
 
     from hiop_amd.runtime import Context, dev
     from hiop_amd.kkt import mds_from_problem
@@ -311,7 +352,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if _fake_multi() else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
