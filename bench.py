@@ -200,7 +200,8 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
                workload=f"NlpDenseCons quasi-Newton low-rank KKT, n_local={n} per GPU (n={n * world}), m={k}, l={l}; "
                         f"step = Hessian secant update + KKT update + {a.solves} solveCompressed "
                         f"(N = J (H+Dx)^-1 J^T formed once per step, cached for the other solves)",
-               collective=("RCCL all-reduce (ncclAllReduce on the context stream), %d ranks" % world) if hooked
+               collective=(("host-staged gloo all-reduce (HIOPAMD_BENCH_FAKE_MULTI rehearsal), %d ranks" if _fake_multi()
+                            else "RCCL all-reduce (ncclAllReduce on the context stream), %d ranks") % world) if hooked
                else "none (single rank, no hook)",
                hbm_gb_J_per_gpu=8.0 * k * n / 1e9)
     if rooflines:

@@ -95,15 +95,107 @@ __device__ __forceinline__ void stg_sc1(double* p, double v)
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool SC1 = false>
+struct DiagNoIdle {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// MF = true: the 16 x 16 sub-block factor as 15 rank-1 MFMA updates (factor16m below); false: the v_readlane / v_fma form.
+// `idle(w)` is called by the waves 1-3 while wave 0 factors the LAST 16 x 16 sub-block alone (they have nothing to do then):
+// the spine of the dataflow factorisation prefetches its next tiles there.
+template <bool SC1 = false, bool MF = true, class Idle = DiagNoIdle>
 __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* sdinv, int kb, int k0, int* info,
-                                                double* __restrict__ Li, int tid, double* Li_lds = nullptr)
+                                                double* __restrict__ Li, int tid, double* Li_lds = nullptr, Idle idle = Idle(),
+                                                unsigned* prof = nullptr)
 {
   __shared__ double Lv[LD_SB][LD_SB + 1];
   const int lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
+  // (i') the same factor on the matrix pipe.  The block and the inverse being built live in the accumulator layout of
+  // v_mfma_f64_16x16x4_f64 (lane (li, g), register reg <-> row g + 4 reg, column li): pivot row k = 4 ks + kg is register ks of
+  // lane group kg, which is exactly where the B operand of k-slot kg is read from, and lane (r, kg) holds a[k][r], the A operand
+  // of row r.  One MFMA with the other three k-slots zero is the rank-1 update  x[r][:] -= a[k][r] * (x[k][:] / d_k)  of all
+  // rows r > k: 2 v_readlane + the reciprocal + 5 VALU operations + 2 MFMAs per pivot instead of ~60 VALU instructions (the
+  // v_readlane form below spends 3 instructions per row and pivot: ~1000 per sub-block, 2-3 us of the spine each).
+  auto factor16m = [&](int sb) {
+    const int o = sb * LD_SB;
+    if(o >= kb) {
+#pragma unroll
+      for(int q = 0; q < 4; ++q) {
+        const int e = tid + 64 * q;
+        const double idv = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        if constexpr(SC1) stg_sc1(Li + sb * 256 + e, idv);
+        else Li[sb * 256 + e] = idv;
+        if(Li_lds) Li_lds[sb * 256 + e] = idv;
+      }
+      return;
+    }
+    double4_t xa, xm;
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      xa[reg] = S[o + g + 4 * reg][o + li];   // zeros below the diagonal
+      xm[reg] = (g + 4 * reg == li) ? 1.0 : 0.0;
+    }
+    // Timing of one pivot on the lone wave (measured, profiles/r02_probes): a v_mfma_f64_16x16x4_f64 holds the matrix pipe for
+    // 64 cycles and delivers after ~76; a dependent VALU instruction issues every ~8 cycles.  Written pivot by pivot (pivot,
+    // reciprocal, operands, the two MFMAs) the wave stalls 64 cycles at the second MFMA and then runs the whole reciprocal
+    // chain of the next pivot behind it: ~225 cycles per pivot.  Here the loop is software-pipelined around the pipe:
+    //     a(k)      update of the block by pivot k                         (issues as soon as its two operands exist)
+    //     d(k+1)    the NEXT pivot, by the same fused multiply-add a(k) applies to that entry, from the values before the
+    //               update; its reciprocal (v_rcp + Newton step)           (VALU work under a(k)'s 64 cycles in the pipe)
+    //     m(k)      the same row operations on the inverse being built     (the pipe is free again by now)
+    // so that after a(k) delivers only the two selects and one multiply of a(k+1)'s operands remain: the pivot loop runs at the
+    // pipe's pace, two MFMAs = 128 cycles per pivot.  Zero / non-finite pivots are found afterwards from the reciprocals
+    // (1/0 = inf, 1/inf -> NaN through the Newton step, NaN propagates), not tested pivot by pivot.
+    int key[4];   // key[kg] = li in lane group kg, -1 elsewhere: lane holds a[k][r], r > k  <=>  key[k & 3] > k
+#pragma unroll
+    for(int q = 0; q < 4; ++q) key[q] = (g == q) ? li : -1;
+    double dis[LD_SB];
+#pragma unroll
+    for(int k = 0; k < LD_SB; ++k) dis[k] = 1.0;
+    double di = fast_rcp(bcast_lane(xa[0], 0));   // (kb > o: pivot 0 exists)
+#pragma unroll
+    for(int k = 0; k < LD_SB; ++k) {
+      if(o + k < kb) {  // uniform
+        const int ks = k >> 2, kg = k & 3;
+        dis[k] = di;
+        if(k + 1 < LD_SB) {
+          const int k1 = k + 1;
+          const double ndi = -di;
+          const double aop = (key[kg] > k) ? xa[ks] : 0.0;   // zero outside lane group kg and for rows <= k: such a slot
+          const double ba = xa[ks] * ndi;                     // cancels whatever B holds there, so B is not masked
+          const double akk1 = bcast_lane(xa[ks], 16 * kg + k1);                 // a[k][k+1]
+          const double ak1k1 = bcast_lane(xa[k1 >> 2], 16 * (k1 & 3) + k1);     // a[k+1][k+1] before the update
+          xa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, ba, xa, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          di = fast_rcp(fma(akk1, akk1 * ndi, ak1k1));
+          const double bm = xm[ks] * ndi;
+          __builtin_amdgcn_sched_barrier(0);
+          xm = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bm, xm, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    int bad = 0;
+#pragma unroll
+    for(int k = LD_SB - 1; k >= 0; --k)
+      if(o + k < kb && !isfinite(dis[k])) bad = k + 1;   // the FIRST one (everything after it is NaN as well)
+    if(tid == 0) {
+#pragma unroll
+      for(int k = 0; k < LD_SB; ++k)
+        if(o + k < kb) sdinv[o + k] = dis[k];
+      if(bad) atomicCAS(info, 0, k0 + o + bad);
+    }
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int r = g + 4 * reg;
+      if(li >= r) S[o + r][o + li] = xa[reg];
+      Lv[r][li] = xm[reg];
+      if constexpr(SC1) stg_sc1(Li + sb * 256 + r * 16 + li, xm[reg]);
+      else Li[sb * 256 + r * 16 + li] = xm[reg];
+      if(Li_lds) Li_lds[sb * 256 + r * 16 + li] = xm[reg];
+    }
+  };
   // (i) for sub-block sb, by wave 0 (call with tid < 64): in-register 16x16 Gauss-Jordan; a padded sub-block (o >= kb)
   // just gets the identity as its inverse
-  auto factor16 = [&](int sb) {
+  auto factor16v = [&](int sb) {
     const int o = sb * LD_SB;
     if(o >= kb) {
 #pragma unroll
@@ -168,6 +260,12 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
       }
     }
   };
+  auto factor16 = [&](int sb) {
+    const unsigned t0 = prof ? (unsigned)wall_clock64() : 0u;   // (profiling runs only: time spent in the sub-block factors)
+    if constexpr(MF) factor16m(sb);
+    else factor16v(sb);
+    if(prof && tid == 0) atomicAdd(prof, (unsigned)wall_clock64() - t0);
+  };
   // one 16x16 tile of (iii): C -= V^T D^-1 V, (ti, tj) = 0:(0,0) 1:(0,1) 2:(0,2) 3:(1,1) 4:(1,2) 5:(2,2)
   auto update_tile = [&](int o, int t6) {
     const int ti = (t6 < 3) ? 0 : ((t6 < 5) ? 1 : 2);
@@ -193,10 +291,11 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
   };
   if(tid < 64) factor16(0);
   __syncthreads();
-  for(int sb = 0; sb < LD_nb / LD_SB; ++sb) {
+  for(int sb = 0; sb + 1 < LD_nb / LD_SB; ++sb) {   // (the last sub-block has no row panel and no trailing part)
     const int o = sb * LD_SB;
     if(o >= kb) {   // uniform: nothing left (its inverse was set by the look-ahead below / above)
-      if(sb + 1 < LD_nb / LD_SB && tid < 64) factor16(sb + 1);
+      if(tid < 64) factor16(sb + 1);
+      else if(sb + 2 == LD_nb / LD_SB) idle(w);
       continue;
     }
     // ---- (ii) V = Linv16 * A_panel, one 16-column group per wave
@@ -232,6 +331,7 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
     } else {
       update_tile(o, 3);
     }
+    if(sb + 2 == LD_nb / LD_SB && w != 0) idle(w);
     __syncthreads();
   }
 }
@@ -554,6 +654,7 @@ __global__ __launch_bounds__(kBlock) void ldlt_unpack_diag_kernel(const double* 
 //   (a) the 64 columns of panel j go through block rows p < j (4 waves x 16 columns, MFMA)
 //   (b) A_jj -= sum_{p<j} V_pj^T D_p^-1 V_pj   (both MFMA operands from the LDS copy of V)
 //   (c) A_jj = U^T D U in LDS (diag_factor_lds), factor / compact copy / 16x16 inverses written out
+template <bool MF>
 __global__ __launch_bounds__(kBlock) void ldlt_superdiag_kernel(double* __restrict__ A, int64_t lda, int K0, int kbs,
                                                                 double* __restrict__ V, int64_t ldv,
                                                                 double* __restrict__ dinv, double* __restrict__ Dk_sp,
@@ -631,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void ldlt_superdiag_kernel(double* __restri
     }
     // ---- (c)
     SD_STAMP(j * 4 + 2);
-    diag_factor_lds(S, sdinv, kbj, k0, info, Li_sp + j * (4 * LD_SB * LD_SB), tid);
+    diag_factor_lds<false, MF>(S, sdinv, kbj, k0, info, Li_sp + j * (4 * LD_SB * LD_SB), tid);
     SD_STAMP(j * 4 + 3);
     diag_emit(S, sdinv, kbj, k0, A, lda, dinv, Dk_sp + j * (LD_nb * LD_nb), tid);
     if(tid < LD_nb) dall[64 * j + tid] = sdinv[tid];
@@ -1741,6 +1842,19 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
 
 using namespace hiopamd;
 
+// HIOPAMD_F16=0: the 16 x 16 sub-block factor in its v_readlane form (A/B timing aid; default: rank-1 MFMA updates)
+static bool f16_mfma()
+{
+  static const bool on = !(std::getenv("HIOPAMD_F16") && std::atoi(std::getenv("HIOPAMD_F16")) == 0);
+  return on;
+}
+// HIOPAMD_DF_SPINE: bit 0 = tile-solve publish deferred to the next spine step, bit 1 = next tiles prefetched into LDS while
+// the last sub-block is factored, bit 2 = F published under the tile solve (default 7; 0 = round-2 schedule; timing aid)
+static int df_spine_opt()
+{
+  static const int v = std::getenv("HIOPAMD_DF_SPINE") ? std::atoi(std::getenv("HIOPAMD_DF_SPINE")) : 7;
+  return v;
+}
 // optional per-launch timing of the MFMA update kernel (HIP events on the launch stream)
 struct LdltProfile {
   bool enabled = false;
@@ -1787,6 +1901,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 {
   std::vector<std::vector<int4>> by_role(DF_ROLES);
   const int cmax = has_next ? 7 : 3;
+  static const bool rsplit = !(std::getenv("HIOPAMD_DF_RSPLIT") && std::atoi(std::getenv("HIOPAMD_DF_RSPLIT")) == 0);
   auto nn_index = [](int a, int b) {   // upper-triangular tile (a, b) of the 4 x 4 next diagonal block -> 0..9
     int t = 0;
     for(int r = 0; r < a; ++r) t += 4 - r;
@@ -1795,8 +1910,13 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
   for(int p = 0; p < 4; ++p) {
     // the spine: S(p) = F(p) -> T(p, p+1) -> U(p; p+1, p+1) fused in one task, data carried in LDS (z = 1: with the T / U part);
     // its companion: R(p) = T(p, p+2) -> U(p; p+1, p+2) -> U(p; p+2, p+2)
+    // (HIOPAMD_DF_RSPLIT != 0, the default: U(p; p+2, p+2) is a task of role 2 instead — R(p) z = 1 — so that the two updates
+    //  the next spine step waits for run side by side; as one task they were 20 us in a row against the spine's 20 us period)
     by_role[0].push_back(make_int4(DF_S, p, (p + 1 <= cmax) ? 1 : 0, 0));
-    if(p + 2 <= cmax) by_role[1].push_back(make_int4(DF_R, p, 0, 0));
+    if(p + 2 <= cmax) {
+      by_role[1].push_back(make_int4(DF_R, p, rsplit ? 1 : 0, 0));
+      if(rsplit) by_role[2].push_back(make_int4(DF_U, p, p + 2, p + 2));
+    }
     for(int c = p + 1; c <= cmax; ++c) {   // tile solves of pivot p
       int role;
       if(c == p + 1 || c == p + 2) continue;   // inside S(p) / R(p)
@@ -1808,7 +1928,12 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
       // that column go to role 2, which has little else to do.
       if(c == 4) {
         by_role[role].push_back(make_int4(DF_C, p, c, p + 1));
-        for(int a2 = p + 2; a2 <= 3; ++a2) by_role[2].push_back(make_int4(DF_U, p, a2, c));
+        // with the companion split role 2 carries the spine-critical diagonal updates: the three left-over updates of the
+        // first H column go to roles 13-15 (one non-critical next-diagonal tile each), ahead of their own tasks of this pivot
+        for(int a2 = p + 2; a2 <= 3; ++a2) {
+          const int lr = rsplit ? 13 + ((p == 0) ? (a2 - 2) : 2) : 2;   // U(0;2,4) -> 13, U(0;3,4) -> 14, U(1;3,4) -> 15
+          by_role[lr].push_back(make_int4(DF_U, p, a2, c));
+        }
       } else {
         by_role[role].push_back(make_int4(DF_C, p, c, 0));
       }
@@ -1834,7 +1959,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 
 struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
-  int64_t off_chain = 0, off_tr = 0, off_ver = 0, nflags = 0;
+  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
   std::vector<unsigned> upcnt, wfirst;
   std::vector<int4> wq;
@@ -1860,7 +1985,10 @@ static DfPlan df_build_plan(int N)
   P.off_chain = DF_HDR;
   P.off_tr = P.off_chain + (int64_t)(P.nsp + 1) * DF_CH;
   P.off_ver = P.off_tr + (int64_t)P.nsp * P.nt;
-  P.nflags = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 48;   // (+ the profiling stamps and phase sums)
+  // (+ the profiling stamps and phase sums, + per super-panel 2 x 4 block-row counters of the substitution tasks that feed the
+  //  first four update tiles, see DF_UPH)
+  P.off_trb = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 48;
+  P.nflags = P.off_trb + 8 * (int64_t)(P.nsp + 1);
   std::vector<int4> t0, t1;
   df_chain_tasks(true, t0);
   df_chain_tasks(false, t1);
@@ -1872,20 +2000,30 @@ static DfPlan df_build_plan(int N)
   std::vector<int4> trq, upq;
   std::vector<int4> wq((size_t)P.nwide + 1, make_int4(0, 0, 0, 0));
   P.wfirst.assign((size_t)P.nwide + 1, 0u);
+  // HIOPAMD_DF_UPH=0: the head tiles as ordinary update tasks (A/B timing aid)
+  static const bool uph = !(std::getenv("HIOPAMD_DF_UPH") && std::atoi(std::getenv("HIOPAMD_DF_UPH")) == 0);
+  auto emit_tile = [&](int kind, int j, int I, int J) {
+    upq.push_back(make_int4(kind, j, I, J));
+    P.upcnt[j] += 1u;
+    // rows r in tile I, columns max(r, 128 J) .. of tile J, inside the matrix
+    const int r0 = UD_T * I, r1 = std::min(N, r0 + UD_T), c0 = UD_T * J, c1 = std::min(N, c0 + UD_T);
+    for(int r = r0; r < r1; ++r) P.up_flops += 2.0 * LD_NB * (double)std::max(0, c1 - std::max(c0, r));
+  };
+  auto is_head = [&](int j, int I, int J) { return uph && I < 2 * j + 4 && J < 2 * j + 6; };
   auto emit_up = [&](int j, int I) {
-    for(int J = (I < 2 * j + 4) ? 2 * j + 4 : I; J < P.nt; ++J) {
-      upq.push_back(make_int4(DF_UP, j, I, J));
-      P.upcnt[j] += 1u;
-      // rows r in tile I, columns max(r, 128 J) .. of tile J, inside the matrix
-      const int r0 = UD_T * I, r1 = std::min(N, r0 + UD_T), c0 = UD_T * J, c1 = std::min(N, c0 + UD_T);
-      for(int r = r0; r < r1; ++r) P.up_flops += 2.0 * LD_NB * (double)std::max(0, c1 - std::max(c0, r));
-    }
+    for(int J = (I < 2 * j + 4) ? 2 * j + 4 : I; J < P.nt; ++J)
+      if(!is_head(j, I, J)) emit_tile(DF_UP, j, I, J);
   };
   for(int j = 0; j < P.nwide; ++j) {
     wq[j].x = (int)trq.size();
     for(int c = LD_NB * (j + 2); c < N; c += 16) trq.push_back(make_int4(DF_TR, j, c, 0));
     wq[j].y = (int)trq.size() - wq[j].x;
     wq[j].z = (int)upq.size();
+    // the four tiles of H_j+1 = A[R_j+1, first 256 columns behind it] first: the NEXT super-panel's chain waits for them
+    // (its first tile solves of the H column), so they follow this super-panel block row by block row (DF_UPH)
+    for(int I = 2 * j + 2; I < 2 * j + 4 && I < P.nt; ++I)
+      for(int J = 2 * j + 4; J < 2 * j + 6 && J < P.nt; ++J)
+        if(is_head(j, I, J)) emit_tile(DF_UPH, j, I, J);
     emit_up(j, 2 * j + 2);
     if(2 * j + 3 < P.nt) emit_up(j, 2 * j + 3);
     P.wfirst[j] = (unsigned)((int)upq.size() - wq[j].z);
@@ -2022,8 +2160,12 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   auto superdiag = [&](int jp, hipStream_t stream) {
     const Panel p = panel(jp);
     // the kernel works on the compact copy of its block: matrix pointer = Cj, ld = 256, origin 0
-    hipLaunchKernelGGL(ldlt_superdiag_kernel, dim3(1), dim3(kBlock), 0, stream, p.Cj, (int64_t)LD_NB, 0, p.kbs, p.Vb, ldv,
-                       dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, (long long*)nullptr);
+    if(f16_mfma())
+      hipLaunchKernelGGL(ldlt_superdiag_kernel<true>, dim3(1), dim3(kBlock), 0, stream, p.Cj, (int64_t)LD_NB, 0, p.kbs, p.Vb, ldv,
+                         dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, (long long*)nullptr);
+    else
+      hipLaunchKernelGGL(ldlt_superdiag_kernel<false>, dim3(1), dim3(kBlock), 0, stream, p.Cj, (int64_t)LD_NB, 0, p.kbs, p.Vb, ldv,
+                         dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, (long long*)nullptr);
   };
   auto trsm = [&](int jp, hipStream_t stream, int col_ofs, int ncols) {
     if(ncols <= 0) return;
@@ -2058,9 +2200,11 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     int rc = dep(st, su);
     if(rc == HIOPAMD_OK) rc = dep(st, sd);
     if(rc != HIOPAMD_OK) return rc;
+    a.spine_opt = df_spine_opt();
     a.dbg = std::getenv("HIOPAMD_DF_STAMPS") ? std::max(1, std::atoi(std::getenv("HIOPAMD_DF_STAMPS"))) : 0;   // profiling aid (1: all panels; 2 + j: phase sums of super-panel j only): per-super-panel time stamps, printed after the call
     a.off_ts = P.off_ver + (int64_t)P.nt * P.nt;
     a.off_ph = a.off_ts + 8 * (int64_t)(P.nsp + 1);
+    a.off_trb = P.off_trb;
     hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
     if(a.nwtasks > 0) {
       if(timed) (void)hipEventRecord(prof->get(), su);
@@ -2191,8 +2335,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
                      ph[24 + 4 * r] * 0.01 / nl, ph[25 + 4 * r] * 0.01 / nl, ph[26 + 4 * r] * 0.01 / nl, r, ph[27 + 4 * r] * 0.01 / nl);
     }
     if(ph[15])
-      std::fprintf(stderr, "[hiop_amd]   inside F: set-up %.2f | 64x64 factor in LDS %.2f | emit + rest %.2f\n", ph[16] * 0.01 / 127.0,
-                   ph[17] * 0.01 / 127.0, (ph[12] - ph[16] - ph[17]) * 0.01 / ph[15]);
+      std::fprintf(stderr, "[hiop_amd]   inside F: set-up %.2f | 64x64 factor in LDS %.2f (of which the four 16x16 sub-block factors %.2f) | emit + rest %.2f\n",
+                   ph[16] * 0.01 / 127.0, ph[17] * 0.01 / 127.0, ph[44] * 0.01 / 127.0, (ph[12] - ph[16] - ph[17]) * 0.01 / ph[15]);
   }
   if(dfw[DF_ABORT]) {
     std::fprintf(stderr,

@@ -35,7 +35,7 @@ constexpr int DF_MAXT = 40;           // chain tasks per role per super-panel (<
 constexpr int DF_ROLES = 16;
 
 enum { DF_F = 1, DF_T = 2, DF_U = 3, DF_S = 4, DF_R = 5, DF_C = 6, DF_END = 0 };
-enum { DF_TR = 1, DF_UP = 2 };
+enum { DF_TR = 1, DF_UP = 2, DF_UPH = 3 };
 
 struct DfArgs {
   double* A;
@@ -64,6 +64,8 @@ struct DfArgs {
   const int4* wq;          // per super-panel {first TR task, TR tasks, first UP task, UP tasks} in wtasks
   const unsigned* wfirst;  // per super-panel: UP tasks of its first two tile rows (the rows of the next row panel)
   int nwide;               // super-panels with wide-kernel work
+  int64_t off_trb;         // per super-panel [2][4]: substitution tasks of 128-column block 2j+4+b that have stored block row P
+  int spine_opt;           // HIOPAMD_DF_SPINE bits (see df_spine_step)
 };
 
 __device__ __forceinline__ unsigned df_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -307,7 +309,7 @@ __device__ __forceinline__ void df_task_solve(const DfArgs& a, int j, int p, int
 }
 
 // U(p; ta, tb): tile (ta, tb) -= V(p, ta)^T U(p, tb)  (64 x 64 x 64): 4 waves as 2 x 2, each a 32 x 32 quadrant = 2 x 2
-// MFMA tiles; operands straight from L2 into the MFMA register layout, the k range in two halves of eight k-steps.
+// MFMA tiles; operands straight from L2 into the MFMA register layout.
 // src != dst for the first update of a next-diagonal-block tile (read from the matrix, written to the compact copy).
 __device__ __forceinline__ void df_task_update(const DfArgs& a, int j, int p, int ta, int tb, const DfTile src, const DfTile dst,
                                                int tid)
@@ -328,19 +330,20 @@ __device__ __forceinline__ void df_task_update(const DfArgs& a, int j, int p, in
 #pragma unroll
       for(int reg = 0; reg < 4; ++reg)
         cv[i][q][reg] = ldg_sc1(src.p + (int64_t)(32 * wr + 16 * i + lk + 4 * reg) * src.ld + 32 * wc + 16 * q + li);
+  // every operand of the task in flight at once (80 loads per lane: the chain kernel has the registers): ONE memory round
+  // trip per update instead of three — these 64 x 64 x 64 updates are links of the serial chains between the spine steps
+  {
+    double av[16][2], bv[16][2];
 #pragma unroll
-  for(int half = 0; half < 2; ++half) {
-    double av[8][2], bv[8][2];
-#pragma unroll
-    for(int kk = 0; kk < 8; ++kk) {
-      const int k = 32 * half + 4 * kk + lk;
+    for(int kk = 0; kk < 16; ++kk) {
+      const int k = 4 * kk + lk;
 #pragma unroll
       for(int i = 0; i < 2; ++i) av[kk][i] = ldg_sc1(va.p + (int64_t)k * va.ld + 32 * wr + 16 * i + li);
 #pragma unroll
       for(int q = 0; q < 2; ++q) bv[kk][q] = ldg_sc1(ub.p + (int64_t)k * ub.ld + 32 * wc + 16 * q + li);
     }
 #pragma unroll
-    for(int kk = 0; kk < 8; ++kk)
+    for(int kk = 0; kk < 16; ++kk)
 #pragma unroll
       for(int i = 0; i < 2; ++i)
 #pragma unroll
@@ -361,8 +364,30 @@ struct DfChainLds {
   double sdinv[LD_nb];
   double Li[4 * LD_SB * LD_SB];  // the four 16 x 16 inverses of the last factored tile
   double Vl[LD_nb][LD_nb + 1];   // V(p, p+1) (un-scaled) and U(p, p+1) of the spine step, for its own update
-  double Ul[LD_nb][LD_nb + 1];
+  double Ul[LD_nb][LD_nb + 1];   // (Vl also receives the prefetched tile (p, p+1) while F(p) runs)
+  double Cl[LD_nb][LD_nb + 1];   // prefetched tile (p+1, p+1), read when its update is written out
+  int pref[4];                   // per wave 1..3: bit 0 = its rows of tile (p, p+1) are in Vl, bit 1 = of (p+1, p+1) in Cl
 };
+// a tile solve of the spine whose results are stored but not yet published (HIOPAMD_DF_SPINE bit 0)
+struct DfPendT {
+  unsigned* v = nullptr;   // version counter of the solved tile
+  unsigned* f = nullptr;   // CDONE / HDONE word of its super-panel
+  int j = 0;
+  bool stamp = false;
+};
+__device__ __forceinline__ void df_drain();
+__device__ __forceinline__ void df_flush_pend(const DfArgs& a, DfPendT& pt, int tid)
+{
+  if(!pt.v) return;   // uniform
+  df_drain();
+  if(tid == 0) {
+    if(pt.stamp) df_stamp(a, pt.j, 3);
+    df_add(pt.v, 1u);
+    df_add(pt.f, 1u);
+  }
+  pt.v = nullptr;
+  __syncthreads();
+}
 
 // S(p): the spine step F(p) -> T(p, p+1) -> U(p; p+1, p+1) in ONE task.  As three tasks every hand-over costs a drain, a
 // flag round trip, a poll and a reload from L2 (12 serial round trips of ~1.5 us per pivot, 131 us per super-panel, the
@@ -370,18 +395,71 @@ struct DfChainLds {
 // updated next diagonal tile stay in LDS: F's results are published as soon as they are drained (the other roles' tile
 // solves need them), T's and U's together at the end.  `carried`: the tile to factor is already in L.S (left there by the
 // previous step's update).  Returns false when the factorisation was aborted.
+// Latency cuts of the step (a.spine_opt, HIOPAMD_DF_SPINE; every one removes a memory round trip from the spine):
+//   bit 0  the publication of T(p, p+1) (a drain of its stores) waits for the START of the next spine step, where those stores
+//          have long landed; the updated tile (p+1, p+1) is not written to memory at all (it travels in LDS; only the hand-over
+//          to the stepwise kernels of a ragged order reads it);
+//   bit 1  while wave 0 factors the last 16 x 16 sub-block of F(p), the idle waves 1-3 look at the version counters of tiles
+//          (p, p+1) and (p+1, p+1) and, when they are complete, fetch them into LDS: the tile solve starts from LDS;
+//   bit 2  with the tile in LDS the tile solve's MFMA chain runs BEFORE F is published: the drain of F's stores and the flag
+//          round trip of the peek are covered by it.
 __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, bool with_tu, bool carried, DfChainLds& L, int* sh_ok,
-                                              long long t_start, int tid, unsigned*& pending)
+                                              long long t_start, int tid, unsigned*& pending, DfPendT& pt)
 {
   const int lane = tid & 63, w = tid >> 6, g = lane >> 4, li = lane & 15;
   const int k0 = LD_NB * j + 64 * p;
+  const int opt = a.spine_opt;
   unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
   double* Li = a.Li + (int64_t)(k0 / LD_nb) * (4 * LD_SB * LD_SB);
   double* Dk = a.Dblk + (int64_t)(k0 / LD_nb) * (LD_nb * LD_nb);
   const DfTile tpp = df_tile(a, j, p, p);
   unsigned bpp;
   unsigned* vpp = df_ver(a, j, p, p, &bpp);
+  df_flush_pend(a, pt, tid);   // the previous step's tile solve: before anything here can wait
   const unsigned ts0 = a.dbg ? (unsigned)wall_clock64() : 0u;
+  // the tiles of the T / U part (c = p + 1), known before F so that the idle waves can prefetch them
+  const int c = p + 1;
+  unsigned bpc = 0u, bcc = 0u;
+  unsigned* vpc = with_tu ? df_ver(a, j, p, c, &bpc) : nullptr;
+  unsigned* vcc = with_tu ? df_ver(a, j, c, c, &bcc) : nullptr;
+  const DfTile x = with_tu ? df_tile(a, j, p, c) : tpp, tcc = with_tu ? df_tile(a, j, c, c) : tpp;
+  auto prefetch = [&](int wv) {
+    if(!(with_tu && (opt & 2))) return;   // uniform
+    const unsigned gx = (unsigned)__builtin_amdgcn_readfirstlane((int)df_ld(vpc));
+    const unsigned gc = (unsigned)__builtin_amdgcn_readfirstlane((int)df_ld(vcc));
+    const bool okx = gx >= bpc + (unsigned)p, okc = gc >= bcc + (unsigned)p;
+    constexpr int NR = 22;   // rows wv-1, wv+2, ... of each tile
+    double vx[NR], vc[NR];
+    if(okx) {
+#pragma unroll
+      for(int i = 0; i < NR; ++i) {
+        const int r = wv - 1 + 3 * i;
+        if(r < LD_nb) vx[i] = ldg_sc1(x.p + (int64_t)r * x.ld + lane);
+      }
+    }
+    if(okc) {
+#pragma unroll
+      for(int i = 0; i < NR; ++i) {
+        const int r = wv - 1 + 3 * i;
+        if(r < LD_nb) vc[i] = ldg_sc1(tcc.p + (int64_t)r * tcc.ld + lane);
+      }
+    }
+    if(okx) {
+#pragma unroll
+      for(int i = 0; i < NR; ++i) {
+        const int r = wv - 1 + 3 * i;
+        if(r < LD_nb) L.Vl[r][lane] = vx[i];
+      }
+    }
+    if(okc) {
+#pragma unroll
+      for(int i = 0; i < NR; ++i) {
+        const int r = wv - 1 + 3 * i;
+        if(r < LD_nb) L.Cl[r][lane] = vc[i];
+      }
+    }
+    if(lane == 0) L.pref[wv] = (okx ? 1 : 0) | (okc ? 2 : 0);
+  };
   // ---- F(p)
   if(!carried) {
     DfWait w0(a.flags + DF_ABORT);
@@ -401,10 +479,13 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
     }
   }
   if(tid < LD_nb) L.sdinv[tid] = 1.0;
+  if(tid < 4) L.pref[tid] = 0;
   __syncthreads();
   if(tid == 0 && p == 0) df_stamp(a, j, 0);
   const unsigned tsa = a.dbg ? (unsigned)wall_clock64() : 0u;
-  diag_factor_lds<true>(L.S, L.sdinv, LD_nb, k0, a.info, Li, tid, L.Li);
+  diag_factor_lds<true, true>(L.S, L.sdinv, LD_nb, k0, a.info, Li, tid, L.Li, prefetch, a.dbg ? a.flags + a.off_ph + 44 : nullptr);
+  const int pf = __builtin_amdgcn_readfirstlane(L.pref[1] & L.pref[2] & L.pref[3]);
+  const bool prefx = (pf & 1) != 0, prefc = (pf & 2) != 0;
   if(a.dbg && tid == 0) {
     atomicAdd(a.flags + a.off_ph + 16, tsa - ts0);                        // load / LDS set-up
     atomicAdd(a.flags + a.off_ph + 17, (unsigned)wall_clock64() - tsa);   // diag_factor_lds
@@ -438,83 +519,113 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
   }
   const unsigned ts1 = a.dbg ? (unsigned)wall_clock64() : 0u;
   // ---- T(p, c), c = p + 1: the tile has the updates of the pivots < p (role 1), the V workspace of this parity is free
-  const int c = p + 1;
-  unsigned bpc, bcc;
-  unsigned* vpc = df_ver(a, j, p, c, &bpc);
-  unsigned* vcc = df_ver(a, j, c, c, &bcc);
+  const DfTile vt = df_vtile(a, j, p, c);
+  const int cl = 16 * w + li;
+  const int wr = w >> 1, wc = w & 1, lk = g;
+  double4_t vp[4];
+  double dsc[4][4];
+  // the tile solve up to its results in registers: X from LDS (prefetched) or from memory, operands of F from LDS
+  auto solve_tile = [&](bool from_lds) {
+    double4_t t[4];
+    if(from_lds) {   // uniform
+#pragma unroll
+      for(int I = 0; I < 4; ++I)
+#pragma unroll
+        for(int r = 0; r < 4; ++r) t[I][r] = L.Vl[16 * I + g + 4 * r][cl];
+    } else {
+#pragma unroll
+      for(int I = 0; I < 4; ++I)
+#pragma unroll
+        for(int r = 0; r < 4; ++r) t[I][r] = ldg_sc1(x.p + (int64_t)(16 * I + g + 4 * r) * x.ld + cl);
+    }
+    double nl[6][4], iv[4][4];
+#pragma unroll
+    for(int I = 0; I < 4; ++I)
+#pragma unroll
+      for(int r = 0; r < 4; ++r) dsc[I][r] = L.sdinv[16 * I + g + 4 * r];
+#pragma unroll
+    for(int I = 1; I < 4; ++I)
+#pragma unroll
+      for(int J = 0; J < I; ++J)
+#pragma unroll
+        for(int kk = 0; kk < 4; ++kk) {
+          const int rr = 16 * J + 4 * kk + g;
+          nl[I * (I - 1) / 2 + J][kk] = -(L.S[rr][16 * I + li] * L.sdinv[rr]);   // scaled row of U, as F emitted it
+        }
+#pragma unroll
+    for(int I = 0; I < 4; ++I)
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) iv[I][kk] = L.Li[I * 256 + li * 16 + 4 * kk + g];
+#pragma unroll
+    for(int I = 0; I < 4; ++I) {
+      double4_t u = t[I];
+#pragma unroll
+      for(int J = 0; J < 4; ++J) {
+        if(J < I) {
+#pragma unroll
+          for(int kk = 0; kk < 4; ++kk) u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[I * (I - 1) / 2 + J][kk], vp[J][kk], u, 0, 0, 0);
+        }
+      }
+      double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[I][kk], u[kk], v, 0, 0, 0);
+      vp[I] = v;
+    }
+  };
+  unsigned ts2 = 0u;
   {
     DfWait w1(a.flags + DF_ABORT);
     w1.set<0>(vpc, bpc + p);
     w1.set<1>(vcc, bcc + p);
     if(j >= 2) w1.set<2>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
-    // one look at the conditions while F's stores drain, then publish F (the other roles' tile solves wait for it) before
-    // any blocking wait: in the phases where the wide kernel is behind, that wait is long
-    const bool ready = df_peek(w1, sh_ok);
-    publish_f();
-    pending = nullptr;
-    if(a.dbg && p == 3 && j >= a.nchain / 2 && tid == 0) {   // profiling aid: which of the conditions is the late one?
-      const unsigned t0 = (unsigned)wall_clock64();
-      unsigned tw[3] = {0u, 0u, 0u};
-      for(int q = 0; q < 3; ++q) {
-        unsigned spins = 0;
-        while(df_ld(w1.f[q]) < w1.v[q] && ++spins < 100000u) __builtin_amdgcn_s_sleep(4);
-        tw[q] = (unsigned)wall_clock64() - t0;
+    if((opt & 4) && prefx) {
+      // the flag round trip and the drain of F's stores run under the solve; nothing of the solve is stored before the
+      // conditions are known to hold (the V workspace of this parity may still be read by update j-2)
+      unsigned g0 = 0u, g1 = 0u, g2 = 0u;
+      if(tid == 0) {
+        g0 = df_ld(w1.f[0]);
+        g1 = df_ld(w1.f[1]);
+        g2 = df_ld(w1.f[2]);
       }
-      atomicAdd(a.flags + a.off_ph + 22, tw[0]);
-      atomicAdd(a.flags + a.off_ph + 23, tw[1] - tw[0]);
+      solve_tile(true);
+      if(tid == 0) *sh_ok = (g0 >= w1.v[0] && g1 >= w1.v[1] && g2 >= w1.v[2]) ? 1 : 0;
+      publish_f();   // (its drain is also the barrier that makes sh_ok visible)
+      pending = nullptr;
+      const bool ready = __builtin_amdgcn_readfirstlane(*sh_ok) != 0;
+      __syncthreads();
+      if(!ready && !df_wait(a.flags, w1, sh_ok, t_start, 100, j, DF_S, p, 1)) return false;
+      ts2 = a.dbg ? (unsigned)wall_clock64() : 0u;
+    } else {
+      // one look at the conditions while F's stores drain, then publish F (the other roles' tile solves wait for it) before
+      // any blocking wait: in the phases where the wide kernel is behind, that wait is long
+      const bool ready = df_peek(w1, sh_ok);
+      publish_f();
+      pending = nullptr;
+      if(a.dbg && p == 3 && j >= a.nchain / 2 && tid == 0) {   // profiling aid: which of the conditions is the late one?
+        const unsigned t0 = (unsigned)wall_clock64();
+        unsigned tw[3] = {0u, 0u, 0u};
+        for(int q = 0; q < 3; ++q) {
+          unsigned spins = 0;
+          while(df_ld(w1.f[q]) < w1.v[q] && ++spins < 100000u) __builtin_amdgcn_s_sleep(4);
+          tw[q] = (unsigned)wall_clock64() - t0;
+        }
+        atomicAdd(a.flags + a.off_ph + 22, tw[0]);
+        atomicAdd(a.flags + a.off_ph + 23, tw[1] - tw[0]);
+      }
+      if(!ready && !df_wait(a.flags, w1, sh_ok, t_start, 100, j, DF_S, p, 1)) return false;
+      ts2 = a.dbg ? (unsigned)wall_clock64() : 0u;
+      solve_tile(prefx);
     }
-    if(!ready && !df_wait(a.flags, w1, sh_ok, t_start, 100, j, DF_S, p, 1)) return false;
   }
-  const unsigned ts2 = a.dbg ? (unsigned)wall_clock64() : 0u;
-  const DfTile x = df_tile(a, j, p, c), vt = df_vtile(a, j, p, c), tcc = df_tile(a, j, c, c);
-  const int cl = 16 * w + li;
-  const int wr = w >> 1, wc = w & 1, lk = g;
-  double4_t t[4];
   double cv[2][2][4];
+  if(!prefc) {
 #pragma unroll
-  for(int I = 0; I < 4; ++I)
+    for(int i = 0; i < 2; ++i)
 #pragma unroll
-    for(int r = 0; r < 4; ++r) t[I][r] = ldg_sc1(x.p + (int64_t)(16 * I + g + 4 * r) * x.ld + cl);
+      for(int q = 0; q < 2; ++q)
 #pragma unroll
-  for(int i = 0; i < 2; ++i)
-#pragma unroll
-    for(int q = 0; q < 2; ++q)
-#pragma unroll
-      for(int reg = 0; reg < 4; ++reg)
-        cv[i][q][reg] = ldg_sc1(tcc.p + (int64_t)(32 * wr + 16 * i + lk + 4 * reg) * tcc.ld + 32 * wc + 16 * q + li);
-  double nl[6][4], iv[4][4], dsc[4][4];
-#pragma unroll
-  for(int I = 0; I < 4; ++I)
-#pragma unroll
-    for(int r = 0; r < 4; ++r) dsc[I][r] = L.sdinv[16 * I + g + 4 * r];
-#pragma unroll
-  for(int I = 1; I < 4; ++I)
-#pragma unroll
-    for(int J = 0; J < I; ++J)
-#pragma unroll
-      for(int kk = 0; kk < 4; ++kk) {
-        const int rr = 16 * J + 4 * kk + g;
-        nl[I * (I - 1) / 2 + J][kk] = -(L.S[rr][16 * I + li] * L.sdinv[rr]);   // scaled row of U, as F emitted it
-      }
-#pragma unroll
-  for(int I = 0; I < 4; ++I)
-#pragma unroll
-    for(int kk = 0; kk < 4; ++kk) iv[I][kk] = L.Li[I * 256 + li * 16 + 4 * kk + g];
-  double4_t vp[4];
-#pragma unroll
-  for(int I = 0; I < 4; ++I) {
-    double4_t u = t[I];
-#pragma unroll
-    for(int J = 0; J < 4; ++J) {
-      if(J < I) {
-#pragma unroll
-        for(int kk = 0; kk < 4; ++kk) u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[I * (I - 1) / 2 + J][kk], vp[J][kk], u, 0, 0, 0);
-      }
-    }
-    double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[I][kk], u[kk], v, 0, 0, 0);
-    vp[I] = v;
+        for(int reg = 0; reg < 4; ++reg)
+          cv[i][q][reg] = ldg_sc1(tcc.p + (int64_t)(32 * wr + 16 * i + lk + 4 * reg) * tcc.ld + 32 * wc + 16 * q + li);
   }
 #pragma unroll
   for(int I = 0; I < 4; ++I)
@@ -549,12 +660,21 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
   }
   // V / U of tile (p, c) were stored before the products above: by now they have landed, publish them (the companion's
   // U(p; p+1, p+2) waits for exactly this) before the C tile goes out
-  df_drain();
-  if(tid == 0 && c >= 4) df_stamp(a, j, 3);
-  if(tid == 0) {
-    df_add(vpc, 1u);
-    df_add(cf + (c < 4 ? DF_CDONE : DF_HDONE), 1u);
+  if(opt & 1) {
+    pt.v = vpc;
+    pt.f = cf + (c < 4 ? DF_CDONE : DF_HDONE);
+    pt.j = j;
+    pt.stamp = c >= 4;
+  } else {
+    df_drain();
+    if(tid == 0 && c >= 4) df_stamp(a, j, 3);
+    if(tid == 0) {
+      df_add(vpc, 1u);
+      df_add(cf + (c < 4 ? DF_CDONE : DF_HDONE), 1u);
+    }
   }
+  // the updated tile travels in LDS; memory needs it only for the hand-over to the stepwise kernels of a ragged order
+  const bool to_memory = !(opt & 1) || (c == 4 && j + 1 >= a.nchain);
 #pragma unroll
   for(int i = 0; i < 2; ++i)
 #pragma unroll
@@ -562,8 +682,9 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
 #pragma unroll
       for(int reg = 0; reg < 4; ++reg) {
         const int row = 32 * wr + 16 * i + lk + 4 * reg, col = 32 * wc + 16 * q + li;
-        const double r = cv[i][q][reg] - acc[i][q][reg];
-        stg_sc1(tcc.p + (int64_t)row * tcc.ld + col, r);   // (the stepwise hand-over of a ragged order reads it; cheap)
+        const double c0 = prefc ? L.Cl[row][col] : cv[i][q][reg];
+        const double r = c0 - acc[i][q][reg];
+        if(to_memory) stg_sc1(tcc.p + (int64_t)row * tcc.ld + col, r);
         L.S[row][col] = (col >= row) ? r : 0.0;
       }
   // the count of this update is published with the NEXT step's F (one drain less on the critical path): only tasks that
@@ -583,7 +704,8 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
 
 // R(p): the spine's companion T(p, p+2) -> U(p; p+2, p+2) -> U(p; p+1, p+2) in one task (what S(p+1) and R(p+1) need next);
 // only the last part waits for the spine's T(p, p+1)
-__device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p, int* sh_ok, long long t_start, int tid)
+__device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p, bool with_diag, int* sh_ok, long long t_start,
+                                                  int tid)
 {
   unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
   const int c = p + 2, m = p + 1;
@@ -609,12 +731,12 @@ __device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p,
     if(c == 4) df_col4_stamp(a, j, p, 3);
   }
   const DfTile tmc = df_tile(a, j, m, c), tcc = df_tile(a, j, c, c);
-  {   // U(p; p+2, p+2) needs only this task's own V / U (drained above): before the wait for the spine
+  if(with_diag) {   // U(p; p+2, p+2) needs only this task's own V / U (drained above): before the wait for the spine
     DfWait w1(a.flags + DF_ABORT);
     w1.set<0>(vcc, bcc + p);
     if(!df_wait(a.flags, w1, sh_ok, t_start, 101, j, DF_R, p, 1)) return false;
+    df_task_update(a, j, p, c, c, tcc, tcc, tid);
   }
-  df_task_update(a, j, p, c, c, tcc, tcc, tid);
   {
     DfWait w2(a.flags + DF_ABORT);
     w2.set<0>(vpm, bpm + p + 1);   // the spine's T(p, p+1) published
@@ -624,7 +746,7 @@ __device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p,
   df_task_update(a, j, p, m, c, tmc, tmc, tid);
   df_drain();
   if(tid == 0) {
-    df_add(vcc, 1u);
+    if(with_diag) df_add(vcc, 1u);
     df_add(vmc, 1u);
     if(c == 4) df_col4_stamp(a, j, m, p);
   }
@@ -693,6 +815,7 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
   __syncthreads();
   bool carried = false;   // role 0: the tile to factor next is in L.S
   unsigned* pending = nullptr;   // role 0: version counter of the tile updated by the last spine step, not yet published
+  DfPendT pt;                    // role 0: the last spine step's tile solve, stored but not yet published
   for(int j = 0; j < a.nchain; ++j) {
     const bool has_next = (j + 1 < a.nchain) || a.last_has_next;
     const int4* tasks = sh_tasks[has_next ? 0 : 1];
@@ -708,10 +831,10 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
       DfWait w(a.flags + DF_ABORT);
       unsigned base;
       if(tk.x == DF_S) {
-        if(!df_spine_step(a, j, p, ta != 0, carried, L, &sh_ok, t_start, tid, pending)) return;
+        if(!df_spine_step(a, j, p, ta != 0, carried, L, &sh_ok, t_start, tid, pending, pt)) return;
         carried = ta != 0;   // with the T / U part the updated tile (p+1, p+1) — (0, 0) of the next super-panel for p = 3 — is in L.S
       } else if(tk.x == DF_R) {
-        if(!df_companion_step(a, j, p, &sh_ok, t_start, tid)) return;
+        if(!df_companion_step(a, j, p, ta == 0, &sh_ok, t_start, tid)) return;
       } else if(tk.x == DF_C) {
         if(!df_column_step(a, j, p, ta, tb, role, &sh_ok, t_start, tid)) return;
       } else if(tk.x == DF_F) {
@@ -767,6 +890,7 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
       __syncthreads();   // REQUIRED, see ldlt_wide_kernel: separates this task's lane-0 signalling from the next task's lane-0 polling
     }
   }
+  df_flush_pend(a, pt, tid);   // (a last spine step with a tile solve: the ragged hand-over)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -776,8 +900,10 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
 // every 64-row block row (algorithm of ldlt_headtrsm_kernel); every shared operand through sc1 loads.
 // `early`: the task was taken before C_j was completely factored (see the selection loop): block row P then waits for the
 // tiles of column P of C_j — F(P) and T(q, P), q < P — and the substitution advances in step with the chain kernel.
+// `rowflags` != nullptr: after block row P is stored, word P is incremented (the head tiles of the update follow the
+// substitution block row by block row, see DF_UPH).
 __device__ __forceinline__ bool df_task_trsm(const DfArgs& a, int j, int c16, double* smem, int tid, bool early, int* sh_ok,
-                                             long long t_start)
+                                             long long t_start, unsigned* rowflags)
 {
   double(*Vs)[LD_SB + 1] = reinterpret_cast<double(*)[LD_SB + 1]>(smem);   // 256 x 17
   const int lane = tid & 63, g = lane >> 4, li = lane & 15;
@@ -859,6 +985,10 @@ __device__ __forceinline__ bool df_task_trsm(const DfArgs& a, int j, int c16, do
         for(int kk = 0; kk < 4; ++kk)
           u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[J][kk], Vs[64 * P + 16 * J + 4 * kk + g][li], u, 0, 0, 0);
       }
+    }
+    if(rowflags) {   // uniform
+      df_drain();
+      if(tid == 0) df_add(rowflags + P, 1u);
     }
   }
   return true;
@@ -1001,9 +1131,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t df_rsrc(const double* base)
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0xffffffff, 0x00020000);
 }
 
-template <bool FULL, bool PROF>
-__device__ __forceinline__ void df_task_tile2(const DfArgs& a, int j, int I, int J, double* smem, int tid, unsigned (&ph)[12])
+// Gate: DfNoGate for an ordinary tile.  A head tile (DF_UPH) passes DfRowGate: gate(P) blocks until block row P of both
+// operand panels is stored (rows 64 P .. 64 P + 63 of V and U = stages 4 P .. 4 P + 3); it is called just before the first
+// loads of such a stage are issued, two stages ahead of their use, with the C tile resident in the accumulators throughout.
+struct DfNoGate {
+  static constexpr bool active = false;
+  __device__ __forceinline__ bool operator()(int) const { return true; }
+};
+template <class G>
+struct DfRowGate {
+  static constexpr bool active = true;
+  G& g;
+  __device__ __forceinline__ bool operator()(int P) const { return g(P); }
+};
+template <bool FULL, bool PROF, class Gate = DfNoGate>
+__device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int J, double* smem, int tid, unsigned (&ph)[12],
+                                              Gate gate = Gate())
 {
+  bool gate_ok = true;
   const int dbg = PROF ? a.dbg : 0;
   const unsigned tp0 = dbg ? (unsigned)wall_clock64() : 0u;
   double(*Vs)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem);
@@ -1095,7 +1240,12 @@ __device__ __forceinline__ void df_task_tile2(const DfArgs& a, int j, int I, int
       }
       if(kk == 1 && st + 1 < nst) {
         lstore(cur ^ 1);
-        if(st + 2 < nst) gload(st + 2);   // the staging registers are free again: three k-steps + a barrier of lead
+        if(st + 2 < nst) {
+          if constexpr(Gate::active) {
+            if(((st + 2) & 3) == 0) gate_ok = gate((st + 2) >> 2) && gate_ok;   // (aborted: the result is discarded anyway)
+          }
+          gload(st + 2);   // the staging registers are free again: three k-steps + a barrier of lead
+        }
       }
 #pragma unroll
       for(int i = 0; i < 4; ++i)
@@ -1134,6 +1284,7 @@ __device__ __forceinline__ void df_task_tile2(const DfArgs& a, int j, int I, int
           }
         }
       }
+  return gate_ok;
 }
 
 constexpr int DF_WIDE_WG_PER_CU = 2;
@@ -1311,7 +1462,10 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
       }
       if(tid == 0) df_stamp(a, j, 4);
       lap(1);
-      if(!df_task_trsm(a, j, c16, smem, tidv, tk.w < 0, &sh_ok, t_start)) return;
+      // the 256 columns behind the next diagonal block feed the head tiles of the update: progress per block row
+      const int hb = (c16 - LD_NB * (j + 2)) / UD_T;
+      unsigned* rowflags = (hb < 2) ? a.flags + a.off_trb + (int64_t)j * 8 + 4 * hb : nullptr;
+      if(!df_task_trsm(a, j, c16, smem, tidv, tk.w < 0, &sh_ok, t_start, rowflags)) return;
       lap(2);
       df_drain();
       if(tid == 0) df_add(trj + J, 1u);
@@ -1325,17 +1479,36 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
         const int rem = a.N - UD_T * B;
         return (unsigned)((rem >= UD_T) ? 8 : (rem + 15) / 16);
       };
+      // a head tile (DF_UPH) in the 16-byte tile form: block row P of its operands = the chain's tile solves T(P, cI),
+      // T(P, cI + 1) of the H columns under tile row I and block row P of the 8 substitution tasks of column block J
+      const bool full_tile = UD_T * (I + 1) <= a.N && UD_T * (J + 1) <= a.N;
+      const bool staged = TILE_FORM == 2 && tk.x == DF_UPH && full_tile;
+      const int cI = 2 * (I - 2 * j - 2);   // (H column - 4) of the first of the two tile solves
+      const unsigned* rowf = a.flags + a.off_trb + (int64_t)j * 8 + 4 * (J - 2 * j - 4);
+      auto row_gate = [&](int P) {
+        DfWait wg(a.flags + DF_ABORT);
+        wg.set<0>(cf + DF_HV + P * 4 + cI, (unsigned)P + 1u);
+        wg.set<1>(cf + DF_HV + P * 4 + cI + 1, (unsigned)P + 1u);
+        wg.set<2>(rowf + P, 8u);
+        return df_wait(a.flags, wg, &sh_ok, t_start, 5, j, I, J, P);
+      };
       w.set<0>(a.flags + a.off_ver + (int64_t)I * a.nt + J, (unsigned)j);             // this tile updated through panel j-1
-      if(I < 2 * j + 4) w.set<1>(cf + DF_HDONE, 16u);                                 // rows in the head: V from the chain kernel
-      else w.set<1>(trj + I, groups(I));
-      w.set<2>(trj + J, groups(J));
+      if(!staged) {
+        if(I < 2 * j + 4) w.set<1>(cf + DF_HDONE, 16u);                               // rows in the head: V from the chain kernel
+        else w.set<1>(trj + I, groups(I));
+        w.set<2>(trj + J, groups(J));
+      }
       if(!df_wait(a.flags, w, &sh_ok, t_start, 2, 0, j, I, J)) {
           return;
       }
+      if(staged && !row_gate(0)) return;
       if(tid == 0) df_stamp(a, j, 6);
       lap(4);
       if constexpr(TILE_FORM == 2) {
-        if(UD_T * (I + 1) <= a.N && UD_T * (J + 1) <= a.N) df_task_tile2<true, PROF>(a, j, I, J, smem, tidv, ph);
+        if(staged) {
+          using RowGate = DfRowGate<decltype(row_gate)>;
+          if(!df_task_tile2<true, PROF, RowGate>(a, j, I, J, smem, tidv, ph, RowGate{row_gate})) return;
+        } else if(full_tile) df_task_tile2<true, PROF>(a, j, I, J, smem, tidv, ph);
         else df_task_tile2<false, PROF>(a, j, I, J, smem, tidv, ph);
       } else {
         df_task_tile(a, j, I, J, smem, tidv);

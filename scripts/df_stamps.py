@@ -16,7 +16,10 @@ for rep in range(10):
     ls.set_sys_matrix(M); ctx.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter(); ls.matrix_changed(); dt = time.perf_counter() - t0
     if rep >= 2: best = min(best, dt)
-print("matrixChanged best of 8: %.3f ms  (%.1f TFLOP/s on n^3/3)" % (best * 1e3, N ** 3 / 3 / best / 1e12))
+b = torch.rand(N, generator=g, device="cuda", dtype=torch.float64)
+x = b.clone(); ls.solve(x); ctx.sync()
+res = float((M @ x - b).abs().max() / b.abs().max())
+print("matrixChanged best of 8: %.3f ms  (%.1f TFLOP/s on n^3/3)  residual %.2e" % (best * 1e3, N ** 3 / 3 / best / 1e12, res))
 if os.environ.get("DF_TIMELINE", "1") == "1":
     for mode in os.environ.get("DF_MODES", "1").split(","):
         os.environ["HIOPAMD_DF_STAMPS"] = mode

@@ -162,3 +162,27 @@ def test_cached_N_is_bit_identical(ctx):
     for i, (u, v) in enumerate(zip(a, b)):
         for x, y in zip(u, v):
             assert np.array_equal(x, y), i
+
+
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """`bench.py --gpus 2` end to end where only one GPU exists: HIOPAMD_BENCH_FAKE_MULTI=1 puts both ranks on device 0,
+    runs torch.distributed over gloo and routes the library's collectives through the generic all-reduce hook.  Checks the
+    contract's shape at N > 1 (one JSON line from rank 0, whole-job value, replicas + the sharded dense case); the timings
+    themselves mean nothing on a shared device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIOPAMD_BENCH_FAKE_MULTI="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--dense-nlocal", "100000"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]    # gloo prints its own banner lines to stdout
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    ds = d["dense_sharded"]
+    assert ds["n_ranks"] == 2 and ds["ms_per_step"] > 0 and "2 ranks" in ds["collective"]
+    assert "cpu_baseline" not in d          # rank 0 at N = 1 only

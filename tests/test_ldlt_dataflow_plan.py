@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 F, T, U, SP, RC, CS, END = 1, 2, 3, 4, 5, 6, 0   # SP / RC / CS: fused spine step S(p), its companion R(p), column step C(p, c)
-TR, UP = 1, 2
+TR, UP, UPH = 1, 2, 3   # UPH: head tile of the update, follows the super-panel block row by block row
 
 
 def get_plan(n):
@@ -75,7 +75,7 @@ class Sim:
         self.ver = np.zeros((nt, nt), dtype=int)
         self.upcnt = np.zeros(nsp + 1, dtype=int)
         for t in plan["wtasks"]:
-            if t[0] == UP:
+            if t[0] in (UP, UPH):
                 self.upcnt[t[1]] += 1
         self.Vtail = {}
 
@@ -106,8 +106,8 @@ class Sim:
         ty, p, a, b = tk
         if ty == SP:    # F(p) -> T(p, p+1) -> U(p; p+1, p+1)
             return [(F, p, p, p)] + ([(T, p, p, p + 1), (U, p, p + 1, p + 1)] if a else [])
-        if ty == RC:
-            return [(T, p, p, p + 2), (U, p, p + 1, p + 2), (U, p, p + 2, p + 2)]
+        if ty == RC:    # (a = 1: the update of the diagonal tile (p+2, p+2) is a separate task of role 2)
+            return [(T, p, p, p + 2), (U, p, p + 1, p + 2)] + ([(U, p, p + 2, p + 2)] if a == 0 else [])
         c = a                                                                    # CS: T(p, c) + U(p; a', c), a' = p+1 .. amax
         amax = b if b > 0 else min(3, c)
         return [(T, p, p, c)] + [(U, p, a2, c) for a2 in range(p + 1, amax + 1)]
@@ -211,6 +211,14 @@ class Sim:
             return ok
         I, J = x, y
         ok = self.ver[I, J] >= j
+        if ty == UPH and 128 * (I + 1) <= self.N and 128 * (J + 1) <= self.N:
+            # the kernel's gates, all four block rows at once (the model runs the tile atomically): the chain's tile solves
+            # T(P, c) of the two H columns under tile row I — NOT all sixteen — and the substitution tasks of column block J
+            assert 2 * j + 2 <= I < 2 * j + 4 and 2 * j + 4 <= J < 2 * j + 6
+            cI = 2 * (I - 2 * j - 2)
+            for P in range(4):
+                ok = ok and self.hv[j][P, cI] >= P + 1 and self.hv[j][P, cI + 1] >= P + 1
+            return ok and self.tr[j, J] >= self.groups(J)
         ok = ok and (self.hdone[j] >= 16 if I < 2 * j + 4 else self.tr[j, I] >= self.groups(I))
         return ok and self.tr[j, J] >= self.groups(J)
 
@@ -401,8 +409,10 @@ def test_ragged_order_hands_over_a_consistent_state():
 def test_plan_shapes():
     p = get_plan(8192)
     assert p["nsp"] == 32 and p["nt"] == 64 and p["nchain"] == 32 and p["nwide"] == 31
-    ups = [t for t in p["wtasks"] if t[0] == UP]
+    ups = [t for t in p["wtasks"] if t[0] in (UP, UPH)]
     assert len(ups) == sum(t * (t + 1) // 2 - 3 for t in range(62, 0, -2))   # tiles of 31 trailing updates minus the skipped diagonal blocks
+    # the head tiles: the (up to) four tiles of A[R_j+1, next 256 columns], first in their queue
+    assert sum(1 for t in ups if t[0] == UPH) == 4 * 30
     # the queues: TR tasks grouped by super-panel, then the UP tasks grouped by super-panel, first two tile rows first
     Q = p["queues"]
     assert len(Q) == 31
@@ -412,7 +422,10 @@ def test_plan_shapes():
         pos += Q[j][1]
     for j in range(31):
         seg = p["wtasks"][Q[j][2]:Q[j][2] + Q[j][3]]
-        assert Q[j][2] == pos and all(t[0] == UP and t[1] == j for t in seg)
+        assert Q[j][2] == pos and all(t[0] in (UP, UPH) and t[1] == j for t in seg)
+        nh = 4 if j < 30 else 0
+        assert all(t[0] == UPH and t[2] < 2 * j + 4 and 2 * j + 4 <= t[3] < 2 * j + 6 for t in seg[:nh])
+        assert all(t[0] == UP for t in seg[nh:])
         assert all(t[2] in (2 * j + 2, 2 * j + 3) for t in seg[:Q[j][4]]) and all(t[2] >= 2 * j + 4 for t in seg[Q[j][4]:])
         pos += Q[j][3]
     assert pos == len(p["wtasks"])
