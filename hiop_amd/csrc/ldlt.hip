@@ -2016,7 +2016,7 @@ static DfPlan df_build_plan(int N)
   };
   for(int j = 0; j < P.nwide; ++j) {
     wq[j].x = (int)trq.size();
-    for(int c = LD_NB * (j + 2); c < N; c += 16) trq.push_back(make_int4(DF_TR, j, c, 0));
+    for(int c = LD_NB * (j + 2); c < N; c += DF_TRW) trq.push_back(make_int4(DF_TR, j, c, DF_TRW));
     wq[j].y = (int)trq.size() - wq[j].x;
     wq[j].z = (int)upq.size();
     // the four tiles of H_j+1 = A[R_j+1, first 256 columns behind it] first: the NEXT super-panel's chain waits for them
@@ -2484,7 +2484,7 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
   const size_t nn = (size_t)(n > 0 ? n : 1);
   HIOPAMD_CHECK(hipMalloc((void**)&ls->M, sizeof(double) * nn * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->dinv, sizeof(double) * nn));
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB * 2));   // double-buffered row panel
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB * DF_NVB));   // row panels of DF_NVB (>= 2) consecutive super-panels
   HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb)));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB)));   // blocks + transposes

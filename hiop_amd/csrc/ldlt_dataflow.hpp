@@ -32,6 +32,11 @@ constexpr int DF_TICKET = 0, DF_ABORT = 1, DF_HDR = 16;
 constexpr int DF_CH = 64;   // flags per super-panel in the chain section
 constexpr int DF_CV = 0, DF_HV = 16, DF_CDONE = 33, DF_HDONE = 34, DF_UPDONE = 35;
 constexpr int DF_MAXT = 40;           // chain tasks per role per super-panel (<= 28 used)
+// Row-panel workspaces V (256 x N each), used round robin by the super-panels.  Super-panel j may write its V only when the
+// update of super-panel j - DF_NVB has read the buffer completely.  With two buffers that wait closed a loop
+// chain(j) -> TR(j) -> UP(j) complete -> chain(j+2) of ~620 us per two super-panels in the update-bound first third of the
+// factorisation (profiles/r02_probes: the chain of super-panel 4 idled until the LAST tile of update 2 was done).
+constexpr int DF_NVB = 3;
 constexpr int DF_ROLES = 16;
 
 enum { DF_F = 1, DF_T = 2, DF_U = 3, DF_S = 4, DF_R = 5, DF_C = 6, DF_END = 0 };
@@ -41,7 +46,7 @@ struct DfArgs {
   double* A;
   int64_t lda;
   int N;
-  double* V;          // 2 x 256 x N (double-buffered row panel, un-scaled)
+  double* V;          // DF_NVB x 256 x N (row panels of DF_NVB consecutive super-panels, un-scaled)
   int64_t ldv;
   double* dinv;
   double* Dblk;       // per 64-panel compact factored diagonal tile (64 x 64)
@@ -196,7 +201,7 @@ __device__ __forceinline__ DfTile df_tile_in_matrix(const DfArgs& a, int j, int 
 }
 __device__ __forceinline__ DfTile df_vtile(const DfArgs& a, int j, int p, int c)
 {
-  return DfTile{a.V + (int64_t)(j & 1) * LD_NB * a.ldv + (int64_t)(64 * p) * a.ldv + (int64_t)LD_NB * j + 64 * c, a.ldv};
+  return DfTile{a.V + (int64_t)(j % DF_NVB) * LD_NB * a.ldv + (int64_t)(64 * p) * a.ldv + (int64_t)LD_NB * j + 64 * c, a.ldv};
 }
 // version counter of window tile (r, c) of super-panel j and the value it has before any task of this super-panel touched it
 __device__ __forceinline__ unsigned* df_ver(const DfArgs& a, int j, int r, int c, unsigned* base)
@@ -577,7 +582,7 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
     DfWait w1(a.flags + DF_ABORT);
     w1.set<0>(vpc, bpc + p);
     w1.set<1>(vcc, bcc + p);
-    if(j >= 2) w1.set<2>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
+    if(j >= DF_NVB) w1.set<2>(a.flags + a.off_chain + (int64_t)(j - DF_NVB) * DF_CH + DF_UPDONE, a.upcnt[j - DF_NVB]);
     if((opt & 4) && prefx) {
       // the flag round trip and the drain of F's stores run under the solve; nothing of the solve is stored before the
       // conditions are known to hold (the V workspace of this parity may still be read by update j-2)
@@ -719,7 +724,7 @@ __device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p,
     DfWait w0(a.flags + DF_ABORT);
     w0.set<0>(vpp, bpp + p + 1);   // F(p) published
     w0.set<1>(vpc, bpc + p);
-    if(j >= 2) w0.set<2>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
+    if(j >= DF_NVB) w0.set<2>(a.flags + a.off_chain + (int64_t)(j - DF_NVB) * DF_CH + DF_UPDONE, a.upcnt[j - DF_NVB]);
     if(!df_wait(a.flags, w0, sh_ok, t_start, 101, j, DF_R, p, 0)) return false;
   }
   df_task_solve(a, j, p, c, tid);
@@ -770,7 +775,7 @@ __device__ __forceinline__ bool df_column_step(const DfArgs& a, int j, int p, in
     w.set<0>(vpp, bpp + p + 1);
     w.set<1>(vpc, bpc + p);
     if(c >= 4 && p == 0) w.set<2>(df_wide_ver(a, j, p, c), (unsigned)j);
-    if(j >= 2) w.set<3>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
+    if(j >= DF_NVB) w.set<3>(a.flags + a.off_chain + (int64_t)(j - DF_NVB) * DF_CH + DF_UPDONE, a.upcnt[j - DF_NVB]);
     if(!df_wait(a.flags, w, sh_ok, t_start, 100 + role, j, DF_C, p, c)) return false;
   }
   df_task_solve(a, j, p, c, tid);
@@ -858,7 +863,7 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
         w.set<1>(v, base + p);
         if(c >= 4 && p == 0) w.set<2>(df_wide_ver(a, j, p, c), (unsigned)j);   // the wide kernel's updates of panels < j
         // the V workspace of this parity was read by the update of super-panel j-2
-        if(j >= 2) w.set<3>(a.flags + a.off_chain + (int64_t)(j - 2) * DF_CH + DF_UPDONE, a.upcnt[j - 2]);
+        if(j >= DF_NVB) w.set<3>(a.flags + a.off_chain + (int64_t)(j - DF_NVB) * DF_CH + DF_UPDONE, a.upcnt[j - DF_NVB]);
         if(!df_wait(a.flags, w, &sh_ok, t_start, 100 + role, j, tk.x, p, c)) return;
         df_task_solve(a, j, p, c, tid);
         df_drain();
@@ -896,34 +901,46 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // wide tasks (256 threads, LDS buffer shared by the two task kinds)
 // ---------------------------------------------------------------------------------------------------------------
-// TR(j, c16): 16 columns starting at c16 of the tail of row panel j.  FOUR waves: wave I owns the 16-row sub-block I of
+// TR(j, c16): DF_TRW columns starting at c16 of the tail of row panel j.  FOUR waves: wave I owns the 16-row sub-block I of
 // every 64-row block row (algorithm of ldlt_headtrsm_kernel); every shared operand through sc1 loads.
 // `early`: the task was taken before C_j was completely factored (see the selection loop): block row P then waits for the
 // tiles of column P of C_j — F(P) and T(q, P), q < P — and the substitution advances in step with the chain kernel.
 // `rowflags` != nullptr: after block row P is stored, word P is incremented (the head tiles of the update follow the
 // substitution block row by block row, see DF_UPH).
+// DF_TRW columns per task = DF_TRG column groups of 16 per wave: the operands that do not depend on the column (the rows of
+// the factored diagonal block, the 16 x 16 inverses, 1/d) are loaded once for both groups and the two groups' MFMA chains
+// interleave — the task is latency-bound (a 16-column task kept a workgroup slot for ~50 us: 18 % of the wide kernel's slot
+// time at N = 8192), so twice the columns cost about the same time.
+constexpr int DF_TRG = 2, DF_TRW = 16 * DF_TRG;
 __device__ __forceinline__ bool df_task_trsm(const DfArgs& a, int j, int c16, double* smem, int tid, bool early, int* sh_ok,
-                                             long long t_start, unsigned* rowflags)
+                                             long long t_start, unsigned* rowflags, unsigned row_inc)
 {
-  double(*Vs)[LD_SB + 1] = reinterpret_cast<double(*)[LD_SB + 1]>(smem);   // 256 x 17
+  double(*Vs)[DF_TRW + 1] = reinterpret_cast<double(*)[DF_TRW + 1]>(smem);   // 256 x 33
   const int lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int I = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K0 = LD_NB * j;
-  const int64_t col = (int64_t)c16 + li;
-  const bool col_ok = col < a.N;
-  const int64_t colc = col_ok ? col : (int64_t)(a.N - 1);
-  double* Vb = a.V + (int64_t)(j & 1) * LD_NB * a.ldv;
+  int64_t col[DF_TRG], colc[DF_TRG];
+  bool col_ok[DF_TRG];
+#pragma unroll
+  for(int gq = 0; gq < DF_TRG; ++gq) {
+    col[gq] = (int64_t)c16 + 16 * gq + li;
+    col_ok[gq] = col[gq] < a.N;
+    colc[gq] = col_ok[gq] ? col[gq] : (int64_t)(a.N - 1);
+  }
+  double* Vb = a.V + (int64_t)(j % DF_NVB) * LD_NB * a.ldv;
   const double* Cd = a.Cd + (int64_t)j * (LD_NB * LD_NB);
   const double* Dk_sp = a.Dblk + (int64_t)(K0 / LD_nb) * (LD_nb * LD_nb);
   const double* Li_sp = a.Li + (int64_t)(K0 / LD_nb) * (4 * LD_SB * LD_SB);
-  double4_t t[4];
+  double4_t t[DF_TRG][4];
 #pragma unroll
-  for(int P = 0; P < 4; ++P)
+  for(int gq = 0; gq < DF_TRG; ++gq)
 #pragma unroll
-    for(int r = 0; r < 4; ++r) {
-      const double v = ldg_sc1(a.A + (int64_t)(K0 + 64 * P + 16 * I + g + 4 * r) * a.lda + colc);
-      t[P][r] = col_ok ? v : 0.0;
-    }
+    for(int P = 0; P < 4; ++P)
+#pragma unroll
+      for(int r = 0; r < 4; ++r) {
+        const double v = ldg_sc1(a.A + (int64_t)(K0 + 64 * P + 16 * I + g + 4 * r) * a.lda + colc[gq]);
+        t[gq][P][r] = col_ok[gq] ? v : 0.0;
+      }
   __syncthreads();   // the LDS buffer may still be read by the previous task's waves
 #pragma unroll
   for(int P = 0; P < 4; ++P) {
@@ -949,7 +966,9 @@ __device__ __forceinline__ bool df_task_trsm(const DfArgs& a, int j, int c16, do
       for(int kk = 0; kk < 4; ++kk) nl[J][kk] = -ld_batch(Dk + (16 * J + 4 * kk + g) * LD_nb + 16 * I + li);
 #pragma unroll
     for(int kk = 0; kk < 4; ++kk) iv[kk] = ld_batch(Li + I * 256 + li * 16 + 4 * kk + g);
-    double4_t u = t[P];
+    double4_t u[DF_TRG];
+#pragma unroll
+    for(int gq = 0; gq < DF_TRG; ++gq) u[gq] = t[gq][P];
 #pragma unroll
     for(int q = 0; q < P; ++q) {
       double Lop[4][4];
@@ -961,21 +980,26 @@ __device__ __forceinline__ bool df_task_trsm(const DfArgs& a, int j, int c16, do
       for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
         for(int kk = 0; kk < 4; ++kk)
-          u = __builtin_amdgcn_mfma_f64_16x16x4f64(Lop[Jq][kk], Vs[64 * q + 16 * Jq + 4 * kk + g][li], u, 0, 0, 0);
+#pragma unroll
+          for(int gq = 0; gq < DF_TRG; ++gq)
+            u[gq] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lop[Jq][kk], Vs[64 * q + 16 * Jq + 4 * kk + g][16 * gq + li], u[gq], 0, 0, 0);
     }
 #pragma unroll
     for(int J = 0; J < 4; ++J) {
       if(I == J) {   // wave-uniform
-        double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[kk], u[kk], v, 0, 0, 0);
+        for(int gq = 0; gq < DF_TRG; ++gq) {
+          double4_t v = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for(int r = 0; r < 4; ++r) {
-          const int row = 64 * P + 16 * I + g + 4 * r;
-          Vs[row][li] = v[r];
-          if(col_ok) {
-            stg_sc1(Vb + (int64_t)row * a.ldv + col, v[r]);
-            stg_sc1(a.A + (int64_t)(K0 + row) * a.lda + col, v[r] * dsc[r]);
+          for(int kk = 0; kk < 4; ++kk) v = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[kk], u[gq][kk], v, 0, 0, 0);
+#pragma unroll
+          for(int r = 0; r < 4; ++r) {
+            const int row = 64 * P + 16 * I + g + 4 * r;
+            Vs[row][16 * gq + li] = v[r];
+            if(col_ok[gq]) {
+              stg_sc1(Vb + (int64_t)row * a.ldv + col[gq], v[r]);
+              stg_sc1(a.A + (int64_t)(K0 + row) * a.lda + col[gq], v[r] * dsc[r]);
+            }
           }
         }
       }
@@ -983,12 +1007,14 @@ __device__ __forceinline__ bool df_task_trsm(const DfArgs& a, int j, int c16, do
       if(I > J && J < 3) {
 #pragma unroll
         for(int kk = 0; kk < 4; ++kk)
-          u = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[J][kk], Vs[64 * P + 16 * J + 4 * kk + g][li], u, 0, 0, 0);
+#pragma unroll
+          for(int gq = 0; gq < DF_TRG; ++gq)
+            u[gq] = __builtin_amdgcn_mfma_f64_16x16x4f64(nl[J][kk], Vs[64 * P + 16 * J + 4 * kk + g][16 * gq + li], u[gq], 0, 0, 0);
       }
     }
     if(rowflags) {   // uniform
       df_drain();
-      if(tid == 0) df_add(rowflags + P, 1u);
+      if(tid == 0) df_add(rowflags + P, row_inc);
     }
   }
   return true;
@@ -1006,7 +1032,7 @@ __device__ __forceinline__ void df_task_tile(const DfArgs& a, int j, int I, int 
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int lk = lane >> 4, li = lane & 15;
-  const double* V = a.V + (int64_t)(j & 1) * LD_NB * a.ldv;
+  const double* V = a.V + (int64_t)(j % DF_NVB) * LD_NB * a.ldv;
   const int urow0 = LD_NB * j;
   double4_t acc[4][4];
 #pragma unroll
@@ -1159,7 +1185,7 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
   const int wr = wave >> 1, wc = wave & 1;
   const int lk = lane >> 4, li = lane & 15;
   const unsigned lda8 = (unsigned)a.lda * 8u, ldv8 = (unsigned)a.ldv * 8u;
-  const __amdgpu_buffer_rsrc_t rsV = df_rsrc(a.V + (int64_t)(j & 1) * LD_NB * a.ldv + r0);
+  const __amdgpu_buffer_rsrc_t rsV = df_rsrc(a.V + (int64_t)(j % DF_NVB) * LD_NB * a.ldv + r0);
   const __amdgpu_buffer_rsrc_t rsU = df_rsrc(a.A + (int64_t)(LD_NB * j) * a.lda + c0);
   const __amdgpu_buffer_rsrc_t rsC = df_rsrc(a.A + (int64_t)r0 * a.lda + c0);
   const int rlim = N - r0, clim = N - c0;   // rows / columns of the tile inside the matrix (FULL: both >= 128)
@@ -1340,7 +1366,7 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
           qt = a.wq[jtr];
           first_prev = jtr >= 1 ? a.wfirst[jtr - 1] : 0u;
           prev_all = jtr >= 1 ? (unsigned)a.wq[jtr - 1].w : 0u;
-          upcnt_prev2 = jtr >= 2 ? a.upcnt[jtr - 2] : 0u;
+          upcnt_prev2 = jtr >= DF_NVB ? a.upcnt[jtr - DF_NVB] : 0u;
           jtr_c = jtr;
         }
         if(jup != jup_c && jup < a.nwide) {
@@ -1353,18 +1379,18 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
         unsigned* qup = a.flags + a.off_chain + (int64_t)ju * DF_CH;
         const unsigned tr_taken = df_ld(qtr + DF_TRQ), cd = df_ld(qtr + DF_CDONE);
         const unsigned upprev = df_ld(qtr - (jt >= 1 ? DF_CH : 0) + DF_UPQ);
-        const unsigned updone2 = df_ld(qtr - (jt >= 2 ? 2 * DF_CH : 0) + DF_UPDONE);
+        const unsigned updone2 = df_ld(qtr - (jt >= DF_NVB ? DF_NVB * DF_CH : 0) + DF_UPDONE);
         const unsigned up_taken = df_ld(qup + DF_UPQ), up_trtaken = df_ld(qup + DF_TRQ);
         if(jtr < a.nwide) {
           if(tr_taken >= (unsigned)qt.y) {
             ++jtr;
             continue;
           }
-          if(cd >= 10u && (jtr < 1 || upprev >= first_prev) && (jtr < 2 || updone2 >= upcnt_prev2)) {
+          if(cd >= 10u && (jtr < 1 || upprev >= first_prev) && (jtr < DF_NVB || updone2 >= upcnt_prev2)) {
             const unsigned i = __hip_atomic_fetch_add(qtr + DF_TRQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if(i < (unsigned)qt.y) {
               kind = 1;
-              task = make_int4(DF_TR, jtr, LD_NB * (jtr + 2) + 16 * (int)i, qt.x + (int)i);   // (no table look-up needed)
+              task = make_int4(DF_TR, jtr, LD_NB * (jtr + 2) + DF_TRW * (int)i, qt.x + (int)i);   // (no table look-up needed)
               break;
             }
             ++jtr;
@@ -1394,11 +1420,11 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
         // tiles -> chain).  Only when every update task of the previous super-panel is taken, so that whatever the chain
         // still waits for is already running.
         if(jtr < a.nwide && tr_taken < (unsigned)qt.y && cd >= 1u && cd < 10u && (jtr < 1 || upprev >= prev_all) &&
-           (jtr < 2 || updone2 >= upcnt_prev2)) {
+           (jtr < DF_NVB || updone2 >= upcnt_prev2)) {
           const unsigned i = __hip_atomic_fetch_add(qtr + DF_TRQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if(i < (unsigned)qt.y) {
             kind = 1;
-            task = make_int4(DF_TR, jtr, LD_NB * (jtr + 2) + 16 * (int)i, -1);   // w = -1: early
+            task = make_int4(DF_TR, jtr, LD_NB * (jtr + 2) + DF_TRW * (int)i, -1);   // w = -1: early
             break;
           }
           ++jtr;
@@ -1465,10 +1491,13 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
       // the 256 columns behind the next diagonal block feed the head tiles of the update: progress per block row
       const int hb = (c16 - LD_NB * (j + 2)) / UD_T;
       unsigned* rowflags = (hb < 2) ? a.flags + a.off_trb + (int64_t)j * 8 + 4 * hb : nullptr;
-      if(!df_task_trsm(a, j, c16, smem, tidv, tk.w < 0, &sh_ok, t_start, rowflags)) return;
+      // 16-column groups of this task inside the matrix (the counters tr[j][J] and the block-row counters count groups)
+      const int remc = a.N - c16;
+      const unsigned ngrp = (unsigned)(remc >= DF_TRW ? DF_TRG : (remc + 15) / 16);
+      if(!df_task_trsm(a, j, c16, smem, tidv, tk.w < 0, &sh_ok, t_start, rowflags, ngrp)) return;
       lap(2);
       df_drain();
-      if(tid == 0) df_add(trj + J, 1u);
+      if(tid == 0) df_add(trj + J, ngrp);
       if(tid == 0) df_stamp(a, j, 5);
       lap(3);
       if(PROF && acct) ph[8] += 1u;

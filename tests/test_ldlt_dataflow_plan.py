@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 
 F, T, U, SP, RC, CS, END = 1, 2, 3, 4, 5, 6, 0   # SP / RC / CS: fused spine step S(p), its companion R(p), column step C(p, c)
+NVB = 3                  # row-panel workspaces used round robin (DF_NVB of csrc/ldlt_dataflow.hpp)
 TR, UP, UPH = 1, 2, 3   # UPH: head tile of the update, follows the super-panel block row by block row
 
 
@@ -62,7 +63,9 @@ class Sim:
         self.A = np.triu(A).copy()                 # trailing matrix + H tiles + U of the tails
         nsp = plan["nsp"]
         self.Cd = {0: self.A[:256, :256].copy()}   # compact copies: block 0 packed up front, others created by Nn updates
-        self.V = {}                                # (j, p, c) -> un-scaled 64 x 64 tile ; ("tail", j) -> 256 x N rows
+        # the V workspaces are modelled as the kernels use them: keyed by j % NVB, so that a super-panel that writes its V
+        # before update j - NVB has read the buffer completely corrupts that update (and the factor check below sees it)
+        self.V = {}                                # (j % NVB, p, c) -> un-scaled 64 x 64 tile
         self.dinv = np.zeros(self.N)
         self.cv = np.zeros((nsp + 1, 4, 4), dtype=int)
         self.cv[0] = 4
@@ -142,8 +145,8 @@ class Sim:
             ok = (done_f or app[ipp] >= bpp + p + 1) and arr[ix] >= base + p
             if c >= 4 and p == 0:
                 ok = ok and self.wide_ver(j, p, c) >= j
-            if j >= 2:
-                ok = ok and self.updone[j - 2] >= self.upcnt[j - 2]
+            if j >= NVB:
+                ok = ok and self.updone[j - NVB] >= self.upcnt[j - NVB]
             return ok
         arr, ix, base = self.ver_of(j, a, b)
         aa, ia, ba = self.ver_of(j, p, a)
@@ -174,7 +177,7 @@ class Sim:
             Lpp = np.triu(Upp, 1).T + np.eye(64)             # unit lower
             x = self.get(j, p, c)
             v = np.linalg.solve(Lpp, x)
-            self.V[(j, p, c)] = v.copy()
+            self.V[(j % NVB, p, c)] = v.copy()
             x[:] = v * self.dinv[k0:k0 + 64][:, None]
             arr, ix, _ = self.ver_of(j, p, c)
             arr[ix] += 1
@@ -183,7 +186,7 @@ class Sim:
             else:
                 self.hdone[j] += 1
         else:
-            va = self.V[(j, p, a)]
+            va = self.V[(j % NVB, p, a)]
             ub = self.get(j, p, b)
             if a >= 4 and p == 0:      # first update of a next-diagonal-block tile: read from the matrix, write the compact copy
                 r0 = 256 * (j + 1) + 64 * (a - 4)
@@ -206,8 +209,8 @@ class Sim:
         if ty == TR:
             J = x // 128
             ok = self.cdone[j] >= 10 and self.ver[2 * j, J] >= j and self.ver[2 * j + 1, J] >= j
-            if j >= 2:
-                ok = ok and self.updone[j - 2] >= self.upcnt[j - 2]
+            if j >= NVB:
+                ok = ok and self.updone[j - NVB] >= self.upcnt[j - NVB]
             return ok
         I, J = x, y
         ok = self.ver[I, J] >= j
@@ -227,14 +230,14 @@ class Sim:
         N = self.N
         K0 = 256 * j
         if ty == TR:
-            c0, c1 = x, min(N, x + 16)
+            c0, c1 = x, min(N, x + y)     # (y = columns per substitution task)
             Ujj = self.Cd[j]
             L = np.triu(Ujj, 1).T + np.eye(256)
             blk = self.A[K0:K0 + 256, c0:c1]
             v = np.linalg.solve(L, blk)
-            self.Vtail.setdefault(j, np.zeros((256, N)))[:, c0:c1] = v
+            self.Vtail.setdefault(j % NVB, np.zeros((256, N)))[:, c0:c1] = v
             blk[:] = v * self.dinv[K0:K0 + 256][:, None]
-            self.tr[j, x // 128] += 1
+            self.tr[j, x // 128] += (c1 - c0 + 15) // 16      # counted in 16-column groups
             return
         I, J = x, y
         r0, r1 = 128 * I, min(N, 128 * I + 128)
@@ -247,9 +250,9 @@ class Sim:
                     cc0 = s + 64 * q
                     lo, hi = max(cc0, r0), min(cc0 + 64, r1)
                     if lo < hi:
-                        Vr[64 * p:64 * p + 64, lo - r0:hi - r0] = self.V[(j, p, 4 + q)][:, lo - cc0:hi - cc0]
+                        Vr[64 * p:64 * p + 64, lo - r0:hi - r0] = self.V[(j % NVB, p, 4 + q)][:, lo - cc0:hi - cc0]
         else:
-            Vr = self.Vtail[j][:, r0:r1]
+            Vr = self.Vtail[j % NVB][:, r0:r1]
         Uc = self.A[K0:K0 + 256, c0:c1]
         upd = Vr.T @ Uc
         blk = self.A[r0:r1, c0:c1]
@@ -297,7 +300,7 @@ def replay(A, plan, n_workers, seed):
                     ptr[w][0] += 1
                     continue
                 ok = sim.cdone[jtr] >= 10 and (jtr < 1 or upq[jtr - 1] >= Q[jtr - 1][4]) and \
-                    (jtr < 2 or sim.updone[jtr - 2] >= sim.upcnt[jtr - 2])
+                    (jtr < NVB or sim.updone[jtr - NVB] >= sim.upcnt[jtr - NVB])
                 if ok:
                     i = trq[jtr]; trq[jtr] += 1
                     return int(Q[jtr][0] + i)
@@ -313,7 +316,7 @@ def replay(A, plan, n_workers, seed):
             # nothing eligible: an EARLY substitution task (the chain has only started C_jtr); it is held until C_jtr is
             # complete (the kernel advances it block row by block row — here it simply blocks its worker, which is stricter)
             if jtr < nw and trq[jtr] < Q[jtr][1] and 1 <= sim.cdone[jtr] < 10 and \
-                    (jtr < 1 or upq[jtr - 1] >= Q[jtr - 1][3]) and (jtr < 2 or sim.updone[jtr - 2] >= sim.upcnt[jtr - 2]):
+                    (jtr < 1 or upq[jtr - 1] >= Q[jtr - 1][3]) and (jtr < NVB or sim.updone[jtr - NVB] >= sim.upcnt[jtr - NVB]):
                 i = trq[jtr]; trq[jtr] += 1
                 return int(Q[jtr][0] + i)
             return None
