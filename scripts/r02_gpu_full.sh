@@ -20,6 +20,6 @@ print("value %.2f it/s  %.3f ms/step  roofline %.1f TF (%.3f)  fact %.3f ms  den
 PY
 if [ "${DO_PROF:-1}" = "1" ]; then
   echo "=== rocprofv3 kernel-trace ==="
-  (cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "rocprof exit: $?"
+  (cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "rocprof exit: $?"
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-150 "$f" | head -16
 fi
