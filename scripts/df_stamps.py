@@ -17,6 +17,14 @@ for rep in range(10):
     t0 = time.perf_counter(); ls.matrix_changed(); dt = time.perf_counter() - t0
     if rep >= 2: best = min(best, dt)
 b = torch.rand(N, generator=g, device="cuda", dtype=torch.float64)
+bs = 1e9
+for rep in range(10):
+    xs = [b.clone() for _ in range(3)]; ctx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for xq in xs: ls.solve(xq)
+    ctx.sync(); dt = time.perf_counter() - t0
+    if rep >= 2: bs = min(bs, dt)
+print("3 solves best of 8: %.3f ms" % (bs * 1e3))
 x = b.clone(); ls.solve(x); ctx.sync()
 res = float((M @ x - b).abs().max() / b.abs().max())
 print("matrixChanged best of 8: %.3f ms  (%.1f TFLOP/s on n^3/3)  residual %.2e" % (best * 1e3, N ** 3 / 3 / best / 1e12, res))
