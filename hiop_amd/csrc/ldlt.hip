@@ -2372,9 +2372,48 @@ static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda
       double* nxt = flow->P + (int64_t)((flow->fl_epoch + 1ull) & 1ull) * half;
       double *yc = cur, *xcur = cur + npad, *Pc = cur + 2 * npad;
       double *yn = nxt, *xn = nxt + npad, *Pn = nxt + 2 * npad;
+      // HIOPAMD_SOLVE_STAMPS=1 (profiling aid): per-task time stamps of every solve, summarised on stderr after a
+      // synchronisation (start | input vector there | result published, 100 MHz ticks)
+      static const bool stamps = std::getenv("HIOPAMD_SOLVE_STAMPS") && std::atoi(std::getenv("HIOPAMD_SOLVE_STAMPS")) != 0;
+      long long* ts = nullptr;
+      if(stamps) {
+        if(hipMalloc((void**)&ts, sizeof(long long) * 4 * (size_t)flow->fl_ntasks) != hipSuccess) ts = nullptr;
+        else (void)hipMemsetAsync(ts, 0, sizeof(long long) * 4 * (size_t)flow->fl_ntasks, st);
+      }
       hipLaunchKernelGGL(ldlt_solve_flow_kernel, dim3(flow->fl_ntasks), dim3(kBlock), 0, st, A, lda, N, nb, flow->W, dinv,
                          flow->fl_tasks, flow->fl_ntasks, flow->fl_sync, flow->fl_epoch, Pc, yc, xcur, Pn, yn, xn,
-                         rhs + (int64_t)j * N, (long long*)nullptr);
+                         rhs + (int64_t)j * N, ts);
+      if(ts) {
+        std::vector<long long> h(4 * (size_t)flow->fl_ntasks);
+        std::vector<int4> tk((size_t)flow->fl_ntasks);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(tk.data(), flow->fl_tasks, sizeof(int4) * tk.size(), hipMemcpyDeviceToHost);
+        (void)hipFree(ts);
+        long long t0 = h[0];
+        for(size_t i = 0; i < tk.size(); ++i) t0 = std::min(t0, h[4 * i]);
+        double sum[4][3] = {{0}};   // per kind: resident before the input arrives | input -> published | count
+        std::vector<double> ydone(nb, 0.0), xdone(nb, 0.0);
+        for(size_t i = 0; i < tk.size(); ++i) {
+          const int k = tk[i].x;
+          sum[k][0] += (h[4 * i + 1] - h[4 * i]) * 0.01;
+          sum[k][1] += (h[4 * i + 2] - h[4 * i + 1]) * 0.01;
+          sum[k][2] += 1.0;
+          const double done = (h[4 * i + 2] - t0) * 0.01;
+          if(k == FL_FWD_DIAG) ydone[tk[i].z] = std::max(ydone[tk[i].z], done);
+          if(k == FL_BWD_DIAG) xdone[tk[i].y] = std::max(xdone[tk[i].y], done);
+        }
+        const char* nm[4] = {"fwd product", "fwd diagonal", "bwd product", "bwd diagonal"};
+        for(int k = 0; k < 4; ++k)
+          if(sum[k][2] > 0)
+            std::fprintf(stderr, "[hiop_amd] solve %-12s %5.0f tasks: resident before the input arrived %7.2f us, input -> published %5.2f us\n",
+                         nm[k], sum[k][2], sum[k][0] / sum[k][2], sum[k][1] / sum[k][2]);
+        std::fprintf(stderr, "[hiop_amd] solve chain: y_J published at (us):");
+        for(int J = 0; J < nb; J += 4) std::fprintf(stderr, " %d:%.0f", J, ydone[J]);
+        std::fprintf(stderr, " | last %.0f\n[hiop_amd] solve chain: x_I published at (us):", ydone[nb - 1]);
+        for(int I = nb - 1; I >= 0; I -= 4) std::fprintf(stderr, " %d:%.0f", I, xdone[I]);
+        std::fprintf(stderr, " | last %.0f\n", xdone[0]);
+      }
       if(hipGetLastError() != hipSuccess) {
         // the launch did not happen: the device-side flags / poison parity did not advance, neither may the host's epoch
         flow->fl_epoch -= 1;
