@@ -102,7 +102,15 @@ def _fake_multi():
     """HIOPAMD_BENCH_FAKE_MULTI=1 (test aid, never set by the driver): run the N > 1 code path on ONE GPU — every rank on device
     0, torch.distributed over gloo, the library's all-reduce hook staged through the host instead of RCCL.  Timings are
     meaningless; it exists so that the multi-rank control flow can be exercised where only one GPU is available."""
-    return os.environ.get("HIOPAMD_BENCH_FAKE_MULTI", "0") == "1"
+    on = os.environ.get("HIOPAMD_BENCH_FAKE_MULTI", "0") == "1"
+    if on:
+        # Two PROCESSES on one device cannot both run the dataflow factorisation: each needs its 16 chain workgroups resident
+        # at the same time on the same 16 reserved CUs (one workgroup per CU: 147 KB of LDS), and the dispatcher may give each
+        # process half of them — both pairs of persistent kernels then wait for roles that can never start (the bounded waits
+        # turn that into an error after 3 s, which is how the rehearsal found it).  One process per GPU, the real
+        # configuration, does not have the problem; the rehearsal uses the stepwise kernels.
+        os.environ["HIOPAMD_DF"] = "0"
+    return on
 
 
 def _install_host_allreduce(ctx, dist):
