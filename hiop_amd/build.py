@@ -32,6 +32,7 @@ SOURCES = [
     "kkt_xycyd.hip",
     "io.hip",
     "krylov.hip",
+    "example_mds.hip",
 ]
 
 # per-file device-code options.  ldlt.hip / gram.hip: the SI load/store optimizer fuses two ds_read_b64 into one

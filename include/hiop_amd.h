@@ -637,6 +637,36 @@ double hiopamd_krylov_get_sol_num_iter(const hiopamd_krylov* k);           /* :1
 double hiopamd_krylov_get_sol_abs_resid(const hiopamd_krylov* k);          /* :110 */
 double hiopamd_krylov_get_sol_rel_resid(const hiopamd_krylov* k);          /* :113 */
 
+/* =====================================================================================
+ * Device-resident user callbacks of the reference's MDS example.
+ * reference: class MdsEx1, src/Drivers/MDS/NlpMdsEx1.hpp:54-560 (RAJA twin: NlpMdsRajaEx1.cpp) — the callbacks of
+ * hiopInterfaceMDS (src/Interface/hiopInterface.hpp:582-780; C FFI src/Interface/hiopInterface.h:63-98) with every array
+ * argument a DEVICE pointer.  Index arrays are int (hiop_index_type).  Any output pointer of the Jacobian / Hessian calls may
+ * be NULL (the reference is called once for the sparsity pattern and once per iteration for the values).  The equalities
+ * and the inequalities are evaluated by separate Jacobian calls because that is how the solver calls eval_Jac_cons
+ * (num_cons = ns with idx_cons = 0..ns-1, then num_cons = 3): the outputs are exactly the arrays
+ * hiopamd_kkt_mds_set_values() takes.  eval_f synchronises (it returns the objective to the host); nothing else does.
+ * ===================================================================================== */
+typedef struct hiopamd_mdsex1 hiopamd_mdsex1;
+int hiopamd_mdsex1_create(hiopamd_mdsex1** out, hiopamd_ctx* ctx, int ns, int nd, int empty_sp_row);       /* :64-97 */
+int hiopamd_mdsex1_destroy(hiopamd_mdsex1* p);
+int hiopamd_mdsex1_get_prob_sizes(const hiopamd_mdsex1* p, int64_t* n, int64_t* m);                         /* :108-113 */
+int hiopamd_mdsex1_get_vars_info(hiopamd_mdsex1* p, double* xlow_dev, double* xupp_dev);                    /* :115-141 */
+int hiopamd_mdsex1_get_cons_info(hiopamd_mdsex1* p, double* clow_dev, double* cupp_dev);                    /* :143-163 */
+int hiopamd_mdsex1_get_sparse_dense_blocks_info(const hiopamd_mdsex1* p, int* nx_sparse, int* nx_dense, int* nnz_sparse_Jaceq,
+                                                int* nnz_sparse_Jacineq, int* nnz_sparse_Hess_Lagr_SS,
+                                                int* nnz_sparse_Hess_Lagr_SD);                              /* :165-184 */
+int hiopamd_mdsex1_get_starting_point(hiopamd_mdsex1* p, double* x0_dev);                                   /* :442-447 */
+int hiopamd_mdsex1_eval_f(hiopamd_mdsex1* p, const double* x_dev, double* obj_host);                        /* :186-209 */
+int hiopamd_mdsex1_eval_grad_f(hiopamd_mdsex1* p, const double* x_dev, double* gradf_dev);                  /* :269-289 */
+int hiopamd_mdsex1_eval_cons(hiopamd_mdsex1* p, const double* x_dev, double* cons_dev);                     /* :211-266, all ns+3 */
+int hiopamd_mdsex1_eval_Jac_cons_eq(hiopamd_mdsex1* p, const double* x_dev, int* iJacS_dev, int* jJacS_dev, double* MJacS_dev,
+                                    double* JacD_dev);                                                      /* :291-400, rows 0..ns-1 */
+int hiopamd_mdsex1_eval_Jac_cons_ineq(hiopamd_mdsex1* p, const double* x_dev, int* iJacS_dev, int* jJacS_dev,
+                                      double* MJacS_dev, double* JacD_dev);                                 /* :291-400, the 3 inequalities */
+int hiopamd_mdsex1_eval_Hess_Lagr(hiopamd_mdsex1* p, const double* x_dev, double obj_factor, const double* lambda_dev,
+                                  int* iHSS_dev, int* jHSS_dev, double* MHSS_dev, double* HDD_dev);         /* :403-440 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,27 @@ def mds_ex1(ns: int, nd: int, empty_sp_row: bool = False) -> MdsProblem:
         xl=xl, xu=xu, dl=np.array([-2.0, -1e20, -2.0]), du=np.array([2.0, 2.0, 1e20]), x0=np.ones(n))
 
 
+def mds_ex1_callbacks(ns: int, nd: int, x: np.ndarray, empty_sp_row: bool = False):
+    """eval_f / eval_grad_f / eval_cons of MdsEx1 at x = (x, s, y), as the reference's loops compute them
+    (NlpMdsEx1.hpp:186-209, :269-289, :211-266; ns already a multiple of four).  Returns (f, grad, cons[ns + 3])."""
+    Q = _Qd(nd)
+    xs, s, y = x[:ns], x[ns:2 * ns], x[2 * ns:]
+    f = 0.0
+    for i in range(ns):                          # :194-195
+        f += xs[i] * (xs[i] - 1.0)
+    f *= 0.5
+    f += 0.5 * float((Q @ y) @ y)                # :197-201
+    f += 0.5 * float(np.sum(s * s))              # :203-206
+    grad = np.concatenate([xs - 0.5, s, Q @ y])  # :273-286
+    ey = float(np.sum(y))
+    cons = np.empty(ns + 3)
+    cons[:ns] = xs + s - ey                      # :228-231, :262-264 (Md = -1)
+    cons[ns] = xs[0] + float(np.sum(s)) + ey     # :238-241
+    cons[ns + 1] = (0.0 if empty_sp_row else xs[1]) + ey   # :242-248
+    cons[ns + 2] = xs[2] + ey                    # :249-251
+    return f, grad, cons
+
+
 def mds_ex1_g(ns: int, nd: int, neq: int) -> MdsProblem:
     """Generalised MdsEx1: `ns` x-variables and `ns` s-variables (n_sparse = 2 ns), `nd` dense variables,
     `neq` <= ns equalities.  Equality j:  sum_{i = j (mod neq)} (x_i + s_i) + 0.5 x_{(j+1) mod ns} + (Md y)_j = 0,

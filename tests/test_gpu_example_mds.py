@@ -1,0 +1,90 @@
+"""Device-resident user callbacks of the reference's MDS example: `hiopamd_mdsex1_*` =
+the hiopInterfaceMDS callbacks of class MdsEx1 (src/Drivers/MDS/NlpMdsEx1.hpp; RAJA twin NlpMdsRajaEx1.cpp) with device
+pointers.  Checked against the numpy restatement of the same class in oracle/problems.py (the one the KKT parity tests and the
+stored -selfcheck objectives already pin), including the layouts hiopamd_kkt_mds_set_values() consumes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from hiop_amd.runtime import dptr
+from oracle import problems as op
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(n, dtype=torch.float64):
+    return torch.full((max(int(n), 1),), -777, dtype=dtype, device="cuda")
+
+
+@pytest.mark.parametrize("ns_in,nd,empty", [(40, 12, False), (400, 100, False), (38, 7, True), (4, 1, False), (2000, 300, True)])
+def test_callbacks_equal_the_reference_example(ctx, ns_in, nd, empty):
+    L = ctx._L
+    h = C.c_void_p()
+    assert L.hiopamd_mdsex1_create(C.byref(h), ctx.h, ns_in, nd, int(empty)) == 0
+    p = op.mds_ex1(ns_in, nd, empty)          # rounds ns up to a multiple of four like the reference
+    ns = p.neq
+    n, m = C.c_int64(), C.c_int64()
+    assert L.hiopamd_mdsex1_get_prob_sizes(h, C.byref(n), C.byref(m)) == 0
+    assert (n.value, m.value) == (2 * ns + nd, ns + 3)
+    info = [C.c_int() for _ in range(6)]
+    assert L.hiopamd_mdsex1_get_sparse_dense_blocks_info(h, *[C.byref(v) for v in info]) == 0
+    assert [v.value for v in info] == [p.nxs, p.nxd, p.Jcs_i.size, p.Jds_i.size, p.Hss_i.size, 0]
+
+    # bounds, starting point
+    xl, xu, cl, cu, x0 = dev(n.value), dev(n.value), dev(m.value), dev(m.value), dev(n.value)
+    assert L.hiopamd_mdsex1_get_vars_info(h, dptr(xl), dptr(xu)) == 0
+    assert L.hiopamd_mdsex1_get_cons_info(h, dptr(cl), dptr(cu)) == 0
+    assert L.hiopamd_mdsex1_get_starting_point(h, dptr(x0)) == 0
+    ctx.sync()
+    np.testing.assert_array_equal(xl.cpu().numpy(), p.xl)
+    np.testing.assert_array_equal(xu.cpu().numpy(), p.xu)
+    np.testing.assert_array_equal(cl.cpu().numpy(), np.concatenate([np.zeros(ns), p.dl]))
+    np.testing.assert_array_equal(cu.cpu().numpy(), np.concatenate([np.zeros(ns), p.du]))
+    np.testing.assert_array_equal(x0.cpu().numpy(), p.x0)
+
+    # objective, gradient, constraints at a random point
+    r = np.random.Generator(np.random.PCG64(ns + nd))
+    xh = r.uniform(-1.5, 2.5, n.value)
+    x = torch.as_tensor(xh).cuda()
+    f = C.c_double()
+    g, c = dev(n.value), dev(m.value)
+    assert L.hiopamd_mdsex1_eval_f(h, dptr(x), C.byref(f)) == 0
+    assert L.hiopamd_mdsex1_eval_grad_f(h, dptr(x), dptr(g)) == 0
+    assert L.hiopamd_mdsex1_eval_cons(h, dptr(x), dptr(c)) == 0
+    ctx.sync()
+    fw, gw, cw = op.mds_ex1_callbacks(ns, nd, xh, empty)
+    assert abs(f.value - fw) <= 1e-13 * max(1.0, abs(fw))      # fp64, summation order differs
+    np.testing.assert_allclose(g.cpu().numpy(), gw, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(c.cpu().numpy(), cw, rtol=1e-13, atol=1e-12)
+
+    # Jacobian: pattern call (values NULL), then values call (pattern NULL), as the solver does
+    ie, je = dev(p.Jcs_i.size, torch.int32), dev(p.Jcs_i.size, torch.int32)
+    ii, ji = dev(p.Jds_i.size, torch.int32), dev(p.Jds_i.size, torch.int32)
+    assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), dptr(ie), dptr(je), None, None) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), dptr(ii), dptr(ji), None, None) == 0
+    ve, vi = dev(p.Jcs_i.size), dev(p.Jds_i.size)
+    Jcd, Jdd = dev(ns * nd), dev(3 * nd)
+    assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), None, None, dptr(ve), dptr(Jcd)) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), None, None, dptr(vi), dptr(Jdd)) == 0
+    ctx.sync()
+    np.testing.assert_array_equal(ie.cpu().numpy()[:p.Jcs_i.size], p.Jcs_i)
+    np.testing.assert_array_equal(je.cpu().numpy()[:p.Jcs_i.size], p.Jcs_j)
+    np.testing.assert_array_equal(ii.cpu().numpy()[:p.Jds_i.size], p.Jds_i)
+    np.testing.assert_array_equal(ji.cpu().numpy()[:p.Jds_i.size], p.Jds_j)
+    np.testing.assert_array_equal(ve.cpu().numpy()[:p.Jcs_i.size], p.Jcs_v)
+    np.testing.assert_array_equal(vi.cpu().numpy()[:p.Jds_i.size], p.Jds_v)
+    np.testing.assert_array_equal(Jcd.cpu().numpy()[:ns * nd].reshape(ns, nd), p.Jcd)
+    np.testing.assert_array_equal(Jdd.cpu().numpy()[:3 * nd].reshape(3, nd), p.Jdd)
+
+    # Hessian of the Lagrangian with obj_factor = 0.75 (lambda is ignored: linear constraints)
+    ih, jh, vh, Hdd = dev(2 * ns, torch.int32), dev(2 * ns, torch.int32), dev(2 * ns), dev(nd * nd)
+    lam = torch.as_tensor(r.uniform(-1, 1, m.value)).cuda()
+    assert L.hiopamd_mdsex1_eval_Hess_Lagr(h, dptr(x), C.c_double(0.75), dptr(lam), dptr(ih), dptr(jh), dptr(vh), dptr(Hdd)) == 0
+    ctx.sync()
+    np.testing.assert_array_equal(ih.cpu().numpy()[:2 * ns], p.Hss_i)
+    np.testing.assert_array_equal(jh.cpu().numpy()[:2 * ns], p.Hss_j)
+    np.testing.assert_array_equal(vh.cpu().numpy()[:2 * ns], 0.75 * p.Hss_v)
+    np.testing.assert_array_equal(Hdd.cpu().numpy()[:nd * nd].reshape(nd, nd), 0.75 * p.Hdd)
+    assert L.hiopamd_mdsex1_destroy(h) == 0

@@ -185,3 +185,28 @@ def test_dense_ex1_selfcheck_objective_quasi_newton(n):
     assert 0.0 <= r["obj"] - exact < (1e-6 if n == 500 else 5e-5) * exact    # a barrier method ends slightly inside the feasible set
     stored = g["objective"][g["n"].index(n)]
     assert abs(r["obj"] - stored) / abs(r["obj"]) < (1e-6 if n == 500 else 5e-5)   # 1e-6: the reference's own -selfcheck criterion
+
+
+def test_mds_ex1_callbacks_agree_with_the_constant_blocks():
+    """the literal loops of MdsEx1::eval_f / eval_grad_f / eval_cons (oracle/problems.py::mds_ex1_callbacks) against the
+    constant Jacobian / Hessian blocks of the same class: the problem is a QP, so cons = J x, grad = H x - 0.5 e_x and
+    f = 0.5 x'Hx - 0.5 e_x'x exactly up to rounding"""
+    from oracle import problems as op
+    for ns, nd, empty in [(40, 12, False), (8, 3, True)]:
+        p = op.mds_ex1(ns, nd, empty)
+        n, m = 2 * ns + nd, ns + 3
+        x = np.random.Generator(np.random.PCG64(ns)).uniform(-1, 2, n)
+        f, g, c = op.mds_ex1_callbacks(ns, nd, x, empty)
+        J = np.zeros((m, n))
+        J[p.Jcs_i, p.Jcs_j] = p.Jcs_v
+        J[:ns, 2 * ns:] = p.Jcd
+        J[ns + p.Jds_i, p.Jds_j] = p.Jds_v
+        J[ns:, 2 * ns:] = p.Jdd
+        H = np.zeros((n, n))
+        H[p.Hss_i, p.Hss_j] = p.Hss_v
+        H[2 * ns:, 2 * ns:] = p.Hdd
+        gw = H @ x
+        gw[:ns] -= 0.5
+        np.testing.assert_allclose(c, J @ x, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(g, gw, rtol=0, atol=1e-13)
+        assert abs(f - (0.5 * x @ H @ x - 0.5 * x[:ns].sum())) < 1e-12
