@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 namespace hiopamd {
@@ -1842,6 +1843,17 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
 
 using namespace hiopamd;
 
+// completion event of the last dataflow factorisation launched by this process on the current device (created on first use)
+static hipEvent_t df_done_event()
+{
+  static std::mutex mu;
+  static hipEvent_t ev[64] = {};
+  int dev = 0;
+  if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if(!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
+  return ev[dev];
+}
 // HIOPAMD_F16=0: the 16 x 16 sub-block factor in its v_readlane form (A/B timing aid; default: rank-1 MFMA updates)
 static bool f16_mfma()
 {
@@ -2188,6 +2200,13 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   }
   if(use_df) {
     // ---- dataflow factorisation of the chained super-panels: two persistent kernels, device flags only
+    // One at a time per device: the chain kernel's 16 roles must all be resident together on the reserved CUs, so two
+    // factorisations in flight (two solver objects of one process on different streams) could each get part of those CUs
+    // and wait for each other.  Every dataflow factorisation of this process therefore starts behind the previous one's
+    // completion event (a no-op on the same stream).  Other PROCESSES on the same device are not covered.
+    hipEvent_t df_done = df_done_event();
+    if(!df_done) return HIOPAMD_ERR_HIP;
+    HIOPAMD_CHECK(hipStreamWaitEvent(st, df_done, 0));
     const DfPlan& P = df->plan;
     DfArgs a;
     a.A = A; a.lda = lda; a.N = N; a.V = V; a.ldv = ldv; a.dinv = dinv; a.Dblk = Dblk; a.Li = Li; a.Cd = Cd; a.info = d_info;
@@ -2225,6 +2244,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     rc = dep(su, st);
     if(rc == HIOPAMD_OK) rc = dep(sd, st);
     if(rc != HIOPAMD_OK) return rc;
+    HIOPAMD_CHECK(hipEventRecord(df_done, st));
     jp0 = P.nchain;
     if(jp0 >= nsp) all_done = true;
     else superdiag(jp0, st);   // the first super-panel left to the stepwise kernels (its block holds every update)
