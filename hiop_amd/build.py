@@ -33,6 +33,7 @@ SOURCES = [
     "io.hip",
     "krylov.hip",
     "example_mds.hip",
+    "example_dense.hip",
 ]
 
 # per-file device-code options.  ldlt.hip / gram.hip: the SI load/store optimizer fuses two ds_read_b64 into one

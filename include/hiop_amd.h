@@ -667,6 +667,24 @@ int hiopamd_mdsex1_eval_Jac_cons_ineq(hiopamd_mdsex1* p, const double* x_dev, in
 int hiopamd_mdsex1_eval_Hess_Lagr(hiopamd_mdsex1* p, const double* x_dev, double obj_factor, const double* lambda_dev,
                                   int* iHSS_dev, int* jHSS_dev, double* MHSS_dev, double* HDD_dev);         /* :403-440 */
 
+/* DenseConsEx2, the example of the memory-distributed dense-constraints path (reference: src/Drivers/Dense/NlpDenseConsEx2.cpp,
+ * callbacks of hiopInterfaceDenseConstraints, src/Interface/hiopInterface.hpp:420-560).  x, gradf, bounds and the rows of
+ * the Jacobian are the LOCAL columns [cols[rank], cols[rank+1]) of this rank (partition of the context's communicator, the
+ * example's own quotient/remainder rule); the objective and the four constraint bodies are summed over the ranks through the
+ * context's all-reduce hook, as the example does with MPI_Allreduce.  Jac is 4 x n_local row-major. */
+typedef struct hiopamd_denseex2 hiopamd_denseex2;
+int hiopamd_denseex2_create(hiopamd_denseex2** out, hiopamd_ctx* ctx, int64_t n_global, int unconstrained);   /* .cpp:7-39 */
+int hiopamd_denseex2_destroy(hiopamd_denseex2* p);
+int hiopamd_denseex2_get_prob_sizes(const hiopamd_denseex2* p, int64_t* n, int64_t* m);                        /* .cpp:45-50 */
+int hiopamd_denseex2_get_vecdistrib_info(const hiopamd_denseex2* p, int64_t* cols_host);                       /* .cpp:293-304 */
+int hiopamd_denseex2_get_vars_info(hiopamd_denseex2* p, double* xlow_dev, double* xupp_dev);                   /* .cpp:52-80 */
+int hiopamd_denseex2_get_cons_info(const hiopamd_denseex2* p, double* clow_host, double* cupp_host);           /* .cpp:82-102 */
+int hiopamd_denseex2_get_starting_point(hiopamd_denseex2* p, double* x0_dev);                                  /* .cpp:307-315 */
+int hiopamd_denseex2_eval_f(hiopamd_denseex2* p, const double* x_dev, double* obj_host);                       /* .cpp:104-117 */
+int hiopamd_denseex2_eval_grad_f(hiopamd_denseex2* p, const double* x_dev, double* gradf_dev);                 /* .cpp:119-126 */
+int hiopamd_denseex2_eval_cons(hiopamd_denseex2* p, const double* x_dev, double* cons_dev);                    /* .cpp:129-221 */
+int hiopamd_denseex2_eval_Jac_cons(hiopamd_denseex2* p, const double* x_dev, double* Jac_dev);                 /* .cpp:224-290 */
+
 #ifdef __cplusplus
 }
 #endif

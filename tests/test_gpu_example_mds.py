@@ -88,3 +88,78 @@ def test_callbacks_equal_the_reference_example(ctx, ns_in, nd, empty):
     np.testing.assert_array_equal(vh.cpu().numpy()[:2 * ns], 0.75 * p.Hss_v)
     np.testing.assert_array_equal(Hdd.cpu().numpy()[:nd * nd].reshape(nd, nd), 0.75 * p.Hdd)
     assert L.hiopamd_mdsex1_destroy(h) == 0
+
+
+@pytest.mark.parametrize("n", [4, 1000, 100003])
+def test_dense_cons_ex2_callbacks_single_rank(ctx, n):
+    """`hiopamd_denseex2_*` = the hiopInterfaceDenseConstraints callbacks of DenseConsEx2
+    (src/Drivers/Dense/NlpDenseConsEx2.cpp) on device pointers, against oracle/problems.py::dense_ex2."""
+    L = ctx._L
+    h = C.c_void_p()
+    assert L.hiopamd_denseex2_create(C.byref(h), ctx.h, n, 0) == 0
+    p = op.dense_ex2(n)
+    nn, mm = C.c_int64(), C.c_int64()
+    assert L.hiopamd_denseex2_get_prob_sizes(h, C.byref(nn), C.byref(mm)) == 0 and (nn.value, mm.value) == (n, 4)
+    cols = (C.c_int64 * 2)()
+    assert L.hiopamd_denseex2_get_vecdistrib_info(h, cols) == 0 and list(cols) == [0, n]
+    cl, cu = (C.c_double * 4)(), (C.c_double * 4)()
+    assert L.hiopamd_denseex2_get_cons_info(h, cl, cu) == 0
+    np.testing.assert_array_equal(np.array(cl), np.concatenate([p["crhs"], p["dl"]]))
+    np.testing.assert_array_equal(np.array(cu), np.concatenate([p["crhs"], p["du"]]))
+    xl, xu, x0 = dev(n), dev(n), dev(n)
+    assert L.hiopamd_denseex2_get_vars_info(h, dptr(xl), dptr(xu)) == 0
+    assert L.hiopamd_denseex2_get_starting_point(h, dptr(x0)) == 0
+    r = np.random.Generator(np.random.PCG64(n))
+    xh = r.uniform(0.0, 3.0, n)
+    x = torch.as_tensor(xh).cuda()
+    f = C.c_double()
+    g, c, J = dev(n), dev(4), dev(4 * n)
+    assert L.hiopamd_denseex2_eval_f(h, dptr(x), C.byref(f)) == 0
+    assert L.hiopamd_denseex2_eval_grad_f(h, dptr(x), dptr(g)) == 0
+    assert L.hiopamd_denseex2_eval_cons(h, dptr(x), dptr(c)) == 0
+    assert L.hiopamd_denseex2_eval_Jac_cons(h, dptr(x), dptr(J)) == 0
+    ctx.sync()
+    np.testing.assert_array_equal(xl.cpu().numpy(), p["xl"])
+    np.testing.assert_array_equal(xu.cpu().numpy(), p["xu"])
+    np.testing.assert_array_equal(x0.cpu().numpy(), p["x0"])
+    Jw = np.vstack([p["Jc"], p["Jd"]])
+    np.testing.assert_array_equal(J.cpu().numpy().reshape(4, n), Jw)
+    assert abs(f.value - p["f"](xh)) <= 1e-12 * max(1.0, abs(p["f"](xh)))
+    np.testing.assert_allclose(g.cpu().numpy(), p["grad"](xh), rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(c.cpu().numpy(), Jw @ xh, rtol=1e-12)
+    assert L.hiopamd_denseex2_destroy(h) == 0
+
+
+def test_dense_cons_ex2_local_part_of_a_three_rank_partition():
+    """rank 1 of 3 (n = 10: columns [4, 7), none of the three special variables is local): partition, bounds, Jacobian
+    columns and the LOCAL contributions to the objective / constraint bodies (a hook that does not reduce)."""
+    from hiop_amd._lib import ALLREDUCE_FN
+    from hiop_amd.runtime import Context
+    c2 = Context(0)
+    L = c2._L
+    cb = ALLREDUCE_FN(lambda user, buf, count, op, stream: 0)
+    assert L.hiopamd_ctx_set_allreduce(c2.h, cb, None, 1, 3) == 0
+    n = 10
+    h = C.c_void_p()
+    assert L.hiopamd_denseex2_create(C.byref(h), c2.h, n, 0) == 0
+    cols = (C.c_int64 * 4)()
+    assert L.hiopamd_denseex2_get_vecdistrib_info(h, cols) == 0 and list(cols) == [0, 4, 7, 10]   # quotient 3, remainder 1
+    p = op.dense_ex2(n)
+    lo, hi = 4, 7
+    xl, xu, J, cc = dev(3), dev(3), dev(12), dev(4)
+    xh = np.array([0.7, 1.9, 2.4])
+    x = torch.as_tensor(xh).cuda()
+    f = C.c_double()
+    assert L.hiopamd_denseex2_get_vars_info(h, dptr(xl), dptr(xu)) == 0
+    assert L.hiopamd_denseex2_eval_Jac_cons(h, dptr(x), dptr(J)) == 0
+    assert L.hiopamd_denseex2_eval_cons(h, dptr(x), dptr(cc)) == 0
+    assert L.hiopamd_denseex2_eval_f(h, dptr(x), C.byref(f)) == 0
+    c2.sync()
+    np.testing.assert_array_equal(xl.cpu().numpy(), p["xl"][lo:hi])
+    np.testing.assert_array_equal(xu.cpu().numpy(), p["xu"][lo:hi])
+    Jw = np.vstack([p["Jc"], p["Jd"]])[:, lo:hi]
+    np.testing.assert_array_equal(J.cpu().numpy().reshape(4, 3), Jw)
+    np.testing.assert_allclose(cc.cpu().numpy(), Jw @ xh, rtol=1e-14)
+    assert abs(f.value - 0.25 * np.sum((xh - 1.0) ** 4)) < 1e-14
+    assert L.hiopamd_denseex2_destroy(h) == 0
+    c2.close()
