@@ -163,3 +163,55 @@ def test_dense_cons_ex2_local_part_of_a_three_rank_partition():
     assert abs(f.value - 0.25 * np.sum((xh - 1.0) ** 4)) < 1e-14
     assert L.hiopamd_denseex2_destroy(h) == 0
     c2.close()
+
+
+def test_callbacks_feed_the_condensed_kkt_without_host_values(ctx):
+    """The purpose of row f4: the values the example's eval_Jac_cons / eval_Hess_Lagr write on the device go straight into
+    hiopamd_kkt_mds_set_values; only the sparsity pattern (once) crosses to the host, for the symbolic plan.  The assembled
+    condensed KKT matrix, its inertia and a solve must equal the oracle's, which is fed from the numpy restatement."""
+    from hiop_amd.kkt import KKTLinSysCompressedMDSXYcYd
+    from oracle import hiop_oracle as ho
+    L = ctx._L
+    ns, nd = 40, 12
+    p = op.mds_ex1(ns, nd)
+    h = C.c_void_p()
+    assert L.hiopamd_mdsex1_create(C.byref(h), ctx.h, ns, nd, 0) == 0
+    x = torch.ones(2 * ns + nd, dtype=torch.float64, device="cuda")
+    lam = torch.zeros(ns + 3, dtype=torch.float64, device="cuda")
+    ie, je, ii, ji = (dev(k, torch.int32) for k in (2 * ns, 2 * ns, ns + 3, ns + 3))
+    ih, jh = dev(2 * ns, torch.int32), dev(2 * ns, torch.int32)
+    assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), dptr(ie), dptr(je), None, None) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), dptr(ii), dptr(ji), None, None) == 0
+    assert L.hiopamd_mdsex1_eval_Hess_Lagr(h, dptr(x), C.c_double(1.0), dptr(lam), dptr(ih), dptr(jh), None, None) == 0
+    ctx.sync()
+    pat = [t.cpu().numpy() for t in (ie, je, ii, ji, ih, jh)]
+    kg = KKTLinSysCompressedMDSXYcYd(ctx, 2 * ns, nd, ns, 3, (pat[0], pat[1]), (pat[2], pat[3]), (pat[4], pat[5]))
+    # values: device to device
+    ve, vi, vh = dev(2 * ns), dev(ns + 3), dev(2 * ns)
+    Jcd, Jdd, Hdd = dev(ns * nd), dev(3 * nd), dev(nd * nd)
+    assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), None, None, dptr(ve), dptr(Jcd)) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), None, None, dptr(vi), dptr(Jdd)) == 0
+    assert L.hiopamd_mdsex1_eval_Hess_Lagr(h, dptr(x), C.c_double(1.0), dptr(lam), None, None, dptr(vh), dptr(Hdd)) == 0
+    Dx, Dd = op.barrier_diagonals(p, seed=3)
+    Dxd, Ddd = torch.as_tensor(Dx).cuda(), torch.as_tensor(Dd).cuda()
+    kg.set_values(ve, vi, vh, Jcd, Jdd, Hdd, Dxd, Ddd)
+    ko = ho.KKTLinSysCompressedMDSXYcYd(p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j), (p.Hss_i, p.Hss_j))
+    ko.set_values(p.Jcs_v, p.Jds_v, p.Hss_v, p.Jcd, p.Jdd, p.Hdd, Dx, Dd)
+    Mo = ko.build_kkt_matrix(0.0, 0.0, 0.0, 0.0).copy()
+    kg.build_kkt_matrix(0.0, 0.0, 0.0, 0.0)
+    np.testing.assert_allclose(np.triu(kg.sys_matrix().cpu().numpy()), np.triu(Mo), rtol=1e-13, atol=1e-13)
+    assert kg.factorize_with_curv_check() == ko.factorize_with_curv_check() == ns + 3
+    rx, ryc, ryd = op.random_rhs(p)
+    ok, dx_o, dyc_o, dyd_o = ko.solve_compressed(rx, ryc, ryd)
+    assert ok
+    dx, dyc, dyd = dev(rx.size), dev(ryc.size), dev(ryd.size)
+    rxd, rycd, rydd = torch.as_tensor(rx).cuda(), torch.as_tensor(ryc).cuda(), torch.as_tensor(ryd).cuda()
+    torch.cuda.synchronize()
+    kg.solve_compressed(rxd, rycd, rydd, dx, dyc, dyd)
+    ctx.sync()
+    scale = max(np.abs(dx_o).max(), np.abs(dyc_o).max(), np.abs(dyd_o).max())
+    assert np.abs(dx.cpu().numpy()[:rx.size] - dx_o).max() / scale < 1e-8
+    assert np.abs(dyc.cpu().numpy()[:ryc.size] - dyc_o).max() / scale < 1e-8
+    assert np.abs(dyd.cpu().numpy()[:ryd.size] - dyd_o).max() / scale < 1e-8
+    kg.close()
+    assert L.hiopamd_mdsex1_destroy(h) == 0
