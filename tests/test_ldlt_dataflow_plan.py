@@ -432,3 +432,34 @@ def test_plan_shapes():
         assert all(t[2] in (2 * j + 2, 2 * j + 3) for t in seg[:Q[j][4]]) and all(t[2] >= 2 * j + 4 for t in seg[Q[j][4]:])
         pos += Q[j][3]
     assert pos == len(p["wtasks"])
+
+
+def test_chain_role_assignment_keeps_the_spine_fed():
+    """The static role lists are part of the critical path (every role runs its list in order): pin the assignment that the
+    measurements of round 2 arrived at (profiles/r02_probes/README.md) so that a change of df_chain_tasks is a conscious one."""
+    p = get_plan(2048)
+    lists = [[tuple(int(v) for v in t) for t in p["ctasks"][0][r] if t[0] != END] for r in range(p["roles"])]
+    # role 0: the four fused spine steps; role 1: their companions without the diagonal update (z = 1)
+    assert lists[0] == [(SP, q, 1, 0) for q in range(4)]
+    assert lists[1] == [(RC, q, 1, 0) for q in range(4)]
+    # role 2: per pivot the diagonal update U(p; p+2, p+2) FIRST (the next spine step waits for it), then column 3 of C_j
+    assert lists[2][0] == (U, 0, 2, 2) and (CS, 0, 3, 0) in lists[2]
+    assert [t for t in lists[2] if t[0] == U] == [(U, q, q + 2, q + 2) for q in range(4)]
+    assert len(lists[2]) <= 6
+    # the first H column: its role keeps T(p, 4) + the update of the next tile only; the left-overs ride on roles 13-15
+    assert lists[3] == [(CS, 0, 4, 1), (CS, 1, 4, 2)]      # (T(2,4) belongs to the companion R(2), T(3,4) to the spine S(3))
+    assert lists[13][0] == (U, 0, 2, 4) and lists[14][0] == (U, 0, 3, 4)
+    assert (U, 1, 3, 4) in lists[15] and lists[15].index((U, 1, 3, 4)) == min(i for i, t in enumerate(lists[15]) if t[1] == 1)
+    # every tile task of a super-panel appears exactly once (fused parts expanded)
+    sim = Sim(np.eye(2048), p)
+    seen = {}
+    for r, lst in enumerate(lists):
+        for t in lst:
+            parts = sim.fused_parts(t) if t[0] in (SP, RC, CS) else [t]
+            for q in parts:
+                assert q not in seen, (q, r, seen[q])
+                seen[q] = r
+    want = {(F, q, q, q) for q in range(4)}
+    want |= {(T, q, q, c) for q in range(4) for c in range(q + 1, 8)}
+    want |= {(U, q, a, b) for q in range(4) for a in range(q + 1, 8) for b in range(a, 8)}
+    assert set(seen) == want
