@@ -4,7 +4,7 @@
 Workload at N=1 (BASELINE.json `metric`, configs[2] — the configuration the metric is quoted on):
   "NlpMDS_ex4 Newton, n_sparse=1e5 n_dense=4096 m=4096": the condensed mixed-dense-sparse KKT system
   of hiopKKTLinSysCompressedMDSXYcYd (N = n_dense + m = 8192) on the generalised MdsEx1 problem
-  (oracle/problems.py::mds_ex1_g, SURVEY.md §8d "MdsEx1-g").
+  (hiop_amd/problems.py::mds_ex1_g, SURVEY.md §8d "MdsEx1-g").
 One "step" = one IPM iteration's worth of KKT work, inputs already resident in HBM:
   1 x build_kkt_matrix  (zero N^2, scatter dense blocks, 3 sparse Schur row-builds, diagonals)
   1 x factorizeWithCurvCheck (blocked no-pivot LDL^T on fp64 MFMA + inertia, returned to the host)
@@ -321,7 +321,7 @@ def main():
     from hiop_amd.kkt import mds_from_problem
     from hiop_amd._lib import lib
     import ctypes as C
-    from oracle import problems as pr
+    from hiop_amd import problems as pr
 
     p = pr.mds_ex1_g(a.ns, a.nd, a.neq)
     Dx, Dd = pr.barrier_diagonals(p)

@@ -122,7 +122,7 @@ def solve(ops, it0, mu0=0.1, tol=1e-8, max_iter=200, kappa_d=1e-5, trace=None, t
 
 
 def mds_model(p):
-    """f, grad, c(x), d(x) of the MdsEx1 family (quadratic objective, linear constraints; oracle/problems.py)."""
+    """f, grad, c(x), d(x) of the MdsEx1 family (quadratic objective, linear constraints; hiop_amd/problems.py)."""
     import scipy.sparse as sp
     nxs = p.nxs
     n = p.nxs + p.nxd

@@ -1,95 +1,16 @@
-"""Problem generators for the parity tests and the bench — TEST INFRASTRUCTURE (numpy, host side).
+"""Example problems for the parity tests — TEST INFRASTRUCTURE (numpy, host side).
 
-MdsEx1      : the reference's MDS example, src/Drivers/MDS/NlpMdsEx1.hpp (sizes :109-113, bounds
-              :115-160, Jacobian :294-400, Hessian :403-440, Qd/Md :79-88).
-MdsEx1G     : the same problem family with the number of equalities decoupled from the number of
-              sparse variables, needed to reach BASELINE config 3 (n_sparse=1e5, n_dense=4096, m=4096)
-              which the stock driver cannot express (m = ns+3, n_sparse = 2 ns).
-Both return the constant Jacobian / Hessian blocks in the layout hiopInterfaceMDS::eval_Jac_cons /
-eval_Hess_Lagr hand to the solver (src/Interface/hiopInterface.hpp:645-657,744-761): sparse blocks as
-row-sorted COO with int32 indices, dense blocks row-major.
+The input generators (constant Jacobian / Hessian blocks, bounds, barrier diagonals, right-hand sides of MdsEx1, MdsEx1G,
+DenseConsEx1/2) live in hiop_amd/problems.py, where the bench takes its synthetic inputs from; they are re-exported here.
+What IS oracle material is below: the literal restatement of the example's callbacks, the checker of the device-resident
+callbacks (csrc/example_mds.hip).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-
 import numpy as np
 
-
-@dataclass
-class MdsProblem:
-    name: str
-    nxs: int
-    nxd: int
-    neq: int
-    nineq: int
-    Jcs_i: np.ndarray
-    Jcs_j: np.ndarray
-    Jcs_v: np.ndarray
-    Jds_i: np.ndarray
-    Jds_j: np.ndarray
-    Jds_v: np.ndarray
-    Hss_i: np.ndarray
-    Hss_j: np.ndarray
-    Hss_v: np.ndarray
-    Jcd: np.ndarray      # neq x nxd
-    Jdd: np.ndarray      # nineq x nxd
-    Hdd: np.ndarray      # nxd x nxd (symmetric, upper triangle is what the KKT uses)
-    xl: np.ndarray
-    xu: np.ndarray
-    dl: np.ndarray       # inequality lower bounds
-    du: np.ndarray
-    x0: np.ndarray
-
-    @property
-    def N(self):
-        return self.nxd + self.neq + self.nineq
-
-
-def _Qd(nd):
-    Q = np.full((nd, nd), 1e-8)
-    Q[np.arange(nd), np.arange(nd)] += 2.0
-    for i in range(1, nd - 1):          # NlpMdsEx1.hpp:83-88 (note: starts at 1)
-        Q[i, i + 1] = 1.0
-        Q[i + 1, i] = 1.0
-    return Q
-
-
-def _ineq_rows(ns, empty_sp_row=False):
-    # NlpMdsEx1.hpp:317-337: row0 = x_1 + e^T s ; row1 = x_2 (unless empty) ; row2 = x_3
-    ii = [0] + [0] * ns
-    jj = [0] + [ns + i for i in range(ns)]
-    if not empty_sp_row:
-        ii.append(1)
-        jj.append(1)
-    ii.append(2)
-    jj.append(2)
-    return np.array(ii, np.int32), np.array(jj, np.int32)
-
-
-def mds_ex1(ns: int, nd: int, empty_sp_row: bool = False) -> MdsProblem:
-    if ns % 4 != 0:
-        ns = 4 * ((4 + ns) // 4)        # NlpMdsEx1.hpp:67-72
-    assert ns >= 4
-    ci = np.repeat(np.arange(ns, dtype=np.int32), 2)
-    cj = np.empty(2 * ns, np.int32)
-    cj[0::2] = np.arange(ns)
-    cj[1::2] = np.arange(ns) + ns
-    di, dj = _ineq_rows(ns, empty_sp_row)
-    n = 2 * ns + nd
-    xl = np.full(n, -1e20)
-    xu = np.full(n, 1e20)
-    xu[:ns] = 3.0
-    xl[ns:2 * ns] = 0.0
-    xl[2 * ns] = -4.0
-    xu[2 * ns] = 4.0
-    return MdsProblem(
-        name=f"MdsEx1(ns={ns},nd={nd})", nxs=2 * ns, nxd=nd, neq=ns, nineq=3,
-        Jcs_i=ci, Jcs_j=cj, Jcs_v=np.ones(2 * ns),
-        Jds_i=di, Jds_j=dj, Jds_v=np.ones(di.size),
-        Hss_i=np.arange(2 * ns, dtype=np.int32), Hss_j=np.arange(2 * ns, dtype=np.int32), Hss_v=np.ones(2 * ns),
-        Jcd=np.full((ns, nd), -1.0), Jdd=np.ones((3, nd)), Hdd=_Qd(nd),
-        xl=xl, xu=xu, dl=np.array([-2.0, -1e20, -2.0]), du=np.array([2.0, 2.0, 1e20]), x0=np.ones(n))
+from hiop_amd.problems import *          # noqa: F401,F403
+from hiop_amd.problems import _Qd, _ineq_rows   # noqa: F401
 
 
 def mds_ex1_callbacks(ns: int, nd: int, x: np.ndarray, empty_sp_row: bool = False):
@@ -113,112 +34,3 @@ def mds_ex1_callbacks(ns: int, nd: int, x: np.ndarray, empty_sp_row: bool = Fals
     return f, grad, cons
 
 
-def mds_ex1_g(ns: int, nd: int, neq: int) -> MdsProblem:
-    """Generalised MdsEx1: `ns` x-variables and `ns` s-variables (n_sparse = 2 ns), `nd` dense variables,
-    `neq` <= ns equalities.  Equality j:  sum_{i = j (mod neq)} (x_i + s_i) + 0.5 x_{(j+1) mod ns} + (Md y)_j = 0,
-    so consecutive rows overlap in one column and the Schur block Jcs Hxs^-1 Jcs^T is tridiagonal-like
-    instead of diagonal.  Inequalities, bounds, objective as in MdsEx1."""
-    assert 4 <= neq <= ns
-    rows, cols, vals = [], [], []
-    for j in range(neq):
-        xs = np.arange(j, ns, neq)
-        c = {int(i): 1.0 for i in xs}
-        extra = (j + 1) % ns
-        c[extra] = c.get(extra, 0.0) + 0.5
-        for i in xs:
-            c[ns + int(i)] = 1.0
-        keys = sorted(c)
-        rows.extend([j] * len(keys))
-        cols.extend(keys)
-        vals.extend(c[k] for k in keys)
-    di, dj = _ineq_rows(ns)
-    n = 2 * ns + nd
-    xl = np.full(n, -1e20)
-    xu = np.full(n, 1e20)
-    xu[:ns] = 3.0
-    xl[ns:2 * ns] = 0.0
-    xl[2 * ns] = -4.0
-    xu[2 * ns] = 4.0
-    return MdsProblem(
-        name=f"MdsEx1G(ns={ns},nd={nd},neq={neq})", nxs=2 * ns, nxd=nd, neq=neq, nineq=3,
-        Jcs_i=np.array(rows, np.int32), Jcs_j=np.array(cols, np.int32), Jcs_v=np.array(vals, np.float64),
-        Jds_i=di, Jds_j=dj, Jds_v=np.ones(di.size),
-        Hss_i=np.arange(2 * ns, dtype=np.int32), Hss_j=np.arange(2 * ns, dtype=np.int32), Hss_v=np.ones(2 * ns),
-        Jcd=np.full((neq, nd), -1.0), Jdd=np.ones((3, nd)), Hdd=_Qd(nd),
-        xl=xl, xu=xu, dl=np.array([-2.0, -1e20, -2.0]), du=np.array([2.0, 2.0, 1e20]), x0=np.ones(n))
-
-
-def barrier_diagonals(p: MdsProblem, seed: int = 20240916, mu: float = 0.1):
-    """Synthetic log-barrier diagonals of an interior iterate (what hiopKKTLinSysCompressedMDSXYcYd::update
-    computes at hiopKKTLinSysMDS.cpp:155-157 and :280-282):  Dx = zl/sxl + zu/sxu on bounded variables
-    (0 on free ones), Dd = vl/sdl + vu/sdu > 0."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    n = p.nxs + p.nxd
-    has_l = p.xl > -1e20
-    has_u = p.xu < 1e20
-    sl = rng.uniform(0.05, 2.0, n)
-    su = rng.uniform(0.05, 2.0, n)
-    Dx = np.where(has_l, mu / sl / sl, 0.0) + np.where(has_u, mu / su / su, 0.0)
-    hl = p.dl > -1e20
-    hu = p.du < 1e20
-    tl = rng.uniform(0.05, 2.0, p.nineq)
-    tu = rng.uniform(0.05, 2.0, p.nineq)
-    Dd = np.where(hl, mu / tl / tl, 0.0) + np.where(hu, mu / tu / tu, 0.0)
-    return Dx, Dd
-
-
-def random_rhs(p: MdsProblem, seed: int = 7):
-    rng = np.random.Generator(np.random.PCG64(seed))
-    return (rng.uniform(-1, 1, p.nxs + p.nxd), rng.uniform(-1, 1, p.neq), rng.uniform(-1, 1, p.nineq))
-
-
-def dense_ex2(n: int):
-    """The reference's DenseConsEx2 (src/Drivers/Dense/NlpDenseConsEx2.hpp:18-30, .cpp:60-330):
-        min sum 1/4 (x_i - 1)^4   s.t.  sum x_i = n+1;  5 <= 2 x_1 + sum_{i>=2} x_i;
-        1 <= 2 x_1 + 0.5 x_2 + sum_{i>=3} x_i <= 2n;   4 x_1 + 2 x_2 + 2 x_3 + sum_{i>=4} x_i <= 4n;
-        x_1 free, x_2 >= 0, 1.5 <= x_3 <= 10, x_i >= 0.5 (i >= 4);  x0 = 0.
-    Returned in HiOp's split form: equality Jacobian Jc (1 x n) with rhs, inequality Jacobian Jd (3 x n) with dl/du."""
-    assert n >= 4
-    Jc = np.ones((1, n))
-    Jd = np.ones((3, n))
-    Jd[0, 0] = 2.0
-    Jd[1, 0], Jd[1, 1] = 2.0, 0.5
-    Jd[2, 0], Jd[2, 1], Jd[2, 2] = 4.0, 2.0, 2.0
-    xl = np.full(n, 0.5)
-    xu = np.full(n, 1e20)
-    xl[0] = -1e20
-    xl[1] = 0.0
-    xl[2], xu[2] = 1.5, 10.0
-    return dict(n=n, Jc=Jc, Jd=Jd, crhs=np.array([n + 1.0]), dl=np.array([5.0, 1.0, -1e20]),
-                du=np.array([1e20, 2.0 * n, 4.0 * n]), xl=xl, xu=xu, x0=np.zeros(n),
-                f=lambda x: 0.25 * float(np.sum((x - 1.0) ** 4)), grad=lambda x: (x - 1.0) ** 3,
-                hess_diag=lambda x: 3.0 * (x - 1.0) ** 2)
-
-
-def dense_ex1(n: int, r: float = 1.0):
-    """The reference's DenseConsEx1 (src/Drivers/Dense/NlpDenseConsEx1.hpp:21-40,136-222, .cpp:17-54,90-104,246-259): the
-    discretised QP  min <c, x> + 1/2 <x, x>  s.t.  integral(x) = 0.5,  0.1 <= x <= 1  on a (distorted) mesh of [0, 1] with
-    element lengths m_k = m1 + k h, h = 2(1-r)/((1+r) n (n-1)), m1 = 2r/((1+r) n); inner products are mass-weighted
-    (<a, b> = sum m_k a_k b_k), c(t) = -1 + 10 t for t <= 0.1 and 0 after, t_k = the middle of element k; x0 = 0.5.
-    No inequality constraints (Jd is 0 x n).  `exact` = the optimum of the discrete problem (x = clip(lambda - c, 0.1, 1))."""
-    k = np.arange(n, dtype=np.float64)
-    m1 = 2.0 * r / ((1.0 + r) * n)
-    h = 2.0 * (1.0 - r) / (1.0 + r) / (n - 1) / n
-    mass = m1 + k * h
-    t = 0.5 * ((2 * k + 1) * m1 + k * k * h)
-    c = np.where(t <= 0.1, -1.0 + 10.0 * t, 0.0)
-
-    def exact():
-        lo, hi = -5.0, 5.0
-        for _ in range(200):
-            lam = 0.5 * (lo + hi)
-            if float(np.sum(mass * np.clip(lam - c, 0.1, 1.0))) > 0.5:
-                hi = lam
-            else:
-                lo = lam
-        x = np.clip(0.5 * (lo + hi) - c, 0.1, 1.0)
-        return float(np.sum(mass * (c * x + 0.5 * x * x))), x
-    return dict(n=n, Jc=mass.reshape(1, n).copy(), Jd=np.zeros((0, n)), crhs=np.array([0.5]), dl=np.zeros(0), du=np.zeros(0),
-                xl=np.full(n, 0.1), xu=np.full(n, 1.0), x0=np.full(n, 0.5), mass=mass, c=c,
-                f=lambda x: float(np.sum(mass * (c * x + 0.5 * x * x))), grad=lambda x: mass * (x + c),
-                hess_diag=lambda x: mass.copy(), exact=exact)

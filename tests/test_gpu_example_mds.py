@@ -1,6 +1,7 @@
 """Device-resident user callbacks of the reference's MDS example: `hiopamd_mdsex1_*` =
 the hiopInterfaceMDS callbacks of class MdsEx1 (src/Drivers/MDS/NlpMdsEx1.hpp; RAJA twin NlpMdsRajaEx1.cpp) with device
-pointers.  Checked against the numpy restatement of the same class in oracle/problems.py (the one the KKT parity tests and the
+pointers.  Checked against the numpy restatement of the same class (constant blocks: hiop_amd/problems.py; callbacks:
+oracle/problems.py — the blocks are the ones the KKT parity tests and the
 stored -selfcheck objectives already pin), including the layouts hiopamd_kkt_mds_set_values() consumes."""
 import ctypes as C
 
@@ -93,7 +94,7 @@ def test_callbacks_equal_the_reference_example(ctx, ns_in, nd, empty):
 @pytest.mark.parametrize("n", [4, 1000, 100003])
 def test_dense_cons_ex2_callbacks_single_rank(ctx, n):
     """`hiopamd_denseex2_*` = the hiopInterfaceDenseConstraints callbacks of DenseConsEx2
-    (src/Drivers/Dense/NlpDenseConsEx2.cpp) on device pointers, against oracle/problems.py::dense_ex2."""
+    (src/Drivers/Dense/NlpDenseConsEx2.cpp) on device pointers, against dense_ex2 of hiop_amd/problems.py (re-exported by oracle/problems.py)."""
     L = ctx._L
     h = C.c_void_p()
     assert L.hiopamd_denseex2_create(C.byref(h), ctx.h, n, 0) == 0
