@@ -1,7 +1,8 @@
 #!/bin/bash
 # Compile the HiOp-side adapters of the `hip-native` back-end against the REFERENCE's own headers and link them against
 # libhiopamd.so.  Proves (a) every pure virtual of hiopVector / hiopMatrixDense / hiopMatrixSparse / hiopLinSolverSymDense
-# is overridden with the reference's exact signature (`override` everywhere, and one object of each class is instantiated),
+# and of the user interface hiopInterfaceMDS (MdsEx1HipNative) is overridden with the reference's exact signature
+# (`override` everywhere, and one object of each class is instantiated),
 # (b) every C-ABI symbol the adapters use exists in the library.
 #
 # Nothing of the reference is copied into the repo: the two headers cmake would generate (hiop_defs.hpp from
@@ -34,7 +35,8 @@ for d in Interface LinAlg Optimization Utils ExecBackends; do INC+=(-I"$REF/src/
 CXX="${CXX:-g++}"
 FLAGS=(-std=c++14 -fPIC -O1 -Wall -Wextra -Wno-unused-parameter -Woverloaded-virtual -Werror=overloaded-virtual)
 
-SRCS=(hiopVectorHipNative.cpp hiopMatrixDenseHipNative.cpp hiopMatrixSparseTripletHipNative.cpp hiopLinSolverSymDenseHipNative.cpp)
+SRCS=(hiopVectorHipNative.cpp hiopMatrixDenseHipNative.cpp hiopMatrixSparseTripletHipNative.cpp hiopLinSolverSymDenseHipNative.cpp
+      MdsEx1HipNative.cpp)
 OBJS=()
 for s in "${SRCS[@]}"; do
   o="$TMP/${s%.cpp}.o"
@@ -61,6 +63,7 @@ cat > "$TMP/instantiate.cpp" <<'EOF'
 #include "hiopMatrixDenseHipNative.hpp"
 #include "hiopMatrixSparseTripletHipNative.hpp"
 #include "hiopLinSolverSymDenseHipNative.hpp"
+#include "MdsEx1HipNative.hpp"
 using namespace hiop;
 void* instantiate_all(hiopNlpFormulation* nlp)
 {
@@ -69,7 +72,8 @@ void* instantiate_all(hiopNlpFormulation* nlp)
   auto* S = new hiopMatrixSparseTripletHipNative(4, 8, 6);
   auto* Y = new hiopMatrixSymSparseTripletHipNative(8, 6);
   auto* L = new hiopLinSolverSymDenseHipNative(8, nlp);
-  static void* all[] = {v, M, S, Y, L};
+  hiopInterfaceMDS* E = new MdsEx1HipNative(40, 12);   // the user-problem side: hiopInterfaceMDS on device pointers
+  static void* all[] = {v, M, S, Y, L, E};
   return all;
 }
 EOF

@@ -151,9 +151,9 @@ __global__ __launch_bounds__(kBlock) void mdsex1_jac_eq_kernel(int ns, int nd, i
 
 // eval_Jac_cons, inequalities (:305-327, :343-361, :375-383): row 0 = x_1 and every s, row 1 = x_2 (unless the example is
 // run with an empty sparse row), row 2 = x_3; dense part = ones
-__global__ __launch_bounds__(kBlock) void mdsex1_jac_ineq_kernel(int ns, int nd, int empty_sp_row, int* __restrict__ iJ,
-                                                                int* __restrict__ jJ, double* __restrict__ M,
-                                                                double* __restrict__ JacD)
+__global__ __launch_bounds__(kBlock) void mdsex1_jac_ineq_kernel(int ns, int nd, int empty_sp_row, int row_offset,
+                                                                int* __restrict__ iJ, int* __restrict__ jJ,
+                                                                double* __restrict__ M, double* __restrict__ JacD)
 {
   const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   if(ns > 0) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void mdsex1_jac_ineq_kernel(int ns, int nd,
         r = 2;
         c = 2;
       }
-      if(iJ) iJ[e] = r;
+      if(iJ) iJ[e] = r + row_offset;
       if(jJ) jJ[e] = c;
       if(M) M[e] = 1.0;
     }
@@ -354,13 +354,14 @@ int hiopamd_mdsex1_eval_Jac_cons_eq(hiopamd_mdsex1* p, const double* x, int* iJa
   return HIOPAMD_OK;
 }
 
-int hiopamd_mdsex1_eval_Jac_cons_ineq(hiopamd_mdsex1* p, const double* x, int* iJacS, int* jJacS, double* MJacS, double* JacD)
+int hiopamd_mdsex1_eval_Jac_cons_ineq(hiopamd_mdsex1* p, const double* x, int row_offset, int* iJacS, int* jJacS, double* MJacS,
+                                      double* JacD)
 {
   (void)x;
   if(!p) return HIOPAMD_ERR_ARG;
   const int64_t work = (int64_t)p->ns + 3 + 3 * (int64_t)p->nd;
   hipLaunchKernelGGL(mdsex1_jac_ineq_kernel, dim3(grid_for(work)), dim3(kBlock), 0, p->ctx->stream, p->ns, p->nd, p->empty_sp_row,
-                     iJacS, jJacS, MJacS, JacD);
+                     row_offset, iJacS, jJacS, MJacS, JacD);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
 }

@@ -662,7 +662,10 @@ int hiopamd_mdsex1_eval_grad_f(hiopamd_mdsex1* p, const double* x_dev, double* g
 int hiopamd_mdsex1_eval_cons(hiopamd_mdsex1* p, const double* x_dev, double* cons_dev);                     /* :211-266, all ns+3 */
 int hiopamd_mdsex1_eval_Jac_cons_eq(hiopamd_mdsex1* p, const double* x_dev, int* iJacS_dev, int* jJacS_dev, double* MJacS_dev,
                                     double* JacD_dev);                                                      /* :291-400, rows 0..ns-1 */
-int hiopamd_mdsex1_eval_Jac_cons_ineq(hiopamd_mdsex1* p, const double* x_dev, int* iJacS_dev, int* jJacS_dev,
+/* row_offset: 0 for the solver's inequality call (rows 0..2); ns for the one-call form of the interface
+ * (hiopInterface.hpp:691-704, MdsEx1OneCallCons in NlpMdsRajaEx1.cpp:894-1011), where the arrays are the tails of the
+ * arrays the equality call filled */
+int hiopamd_mdsex1_eval_Jac_cons_ineq(hiopamd_mdsex1* p, const double* x_dev, int row_offset, int* iJacS_dev, int* jJacS_dev,
                                       double* MJacS_dev, double* JacD_dev);                                 /* :291-400, the 3 inequalities */
 int hiopamd_mdsex1_eval_Hess_Lagr(hiopamd_mdsex1* p, const double* x_dev, double obj_factor, const double* lambda_dev,
                                   int* iHSS_dev, int* jHSS_dev, double* MHSS_dev, double* HDD_dev);         /* :403-440 */

@@ -64,11 +64,11 @@ def test_callbacks_equal_the_reference_example(ctx, ns_in, nd, empty):
     ie, je = dev(p.Jcs_i.size, torch.int32), dev(p.Jcs_i.size, torch.int32)
     ii, ji = dev(p.Jds_i.size, torch.int32), dev(p.Jds_i.size, torch.int32)
     assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), dptr(ie), dptr(je), None, None) == 0
-    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), dptr(ii), dptr(ji), None, None) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), 0, dptr(ii), dptr(ji), None, None) == 0
     ve, vi = dev(p.Jcs_i.size), dev(p.Jds_i.size)
     Jcd, Jdd = dev(ns * nd), dev(3 * nd)
     assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), None, None, dptr(ve), dptr(Jcd)) == 0
-    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), None, None, dptr(vi), dptr(Jdd)) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), 0, None, None, dptr(vi), dptr(Jdd)) == 0
     ctx.sync()
     np.testing.assert_array_equal(ie.cpu().numpy()[:p.Jcs_i.size], p.Jcs_i)
     np.testing.assert_array_equal(je.cpu().numpy()[:p.Jcs_i.size], p.Jcs_j)
@@ -78,6 +78,20 @@ def test_callbacks_equal_the_reference_example(ctx, ns_in, nd, empty):
     np.testing.assert_array_equal(vi.cpu().numpy()[:p.Jds_i.size], p.Jds_v)
     np.testing.assert_array_equal(Jcd.cpu().numpy()[:ns * nd].reshape(ns, nd), p.Jcd)
     np.testing.assert_array_equal(Jdd.cpu().numpy()[:3 * nd].reshape(3, nd), p.Jdd)
+
+    # the one-call layout of the interface (all m rows in one set of arrays): equalities first, the inequalities behind them
+    # with their rows shifted by ns
+    nnz = p.Jcs_i.size + p.Jds_i.size
+    i1, j1, v1, JD = dev(nnz, torch.int32), dev(nnz, torch.int32), dev(nnz), dev((ns + 3) * nd)
+    off = p.Jcs_i.size
+    assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), dptr(i1), dptr(j1), dptr(v1), dptr(JD)) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), ns, C.c_void_p(i1.data_ptr() + 4 * off), C.c_void_p(j1.data_ptr() + 4 * off),
+                                               C.c_void_p(v1.data_ptr() + 8 * off), C.c_void_p(JD.data_ptr() + 8 * ns * nd)) == 0
+    ctx.sync()
+    np.testing.assert_array_equal(i1.cpu().numpy()[:nnz], np.concatenate([p.Jcs_i, p.Jds_i + ns]))
+    np.testing.assert_array_equal(j1.cpu().numpy()[:nnz], np.concatenate([p.Jcs_j, p.Jds_j]))
+    np.testing.assert_array_equal(v1.cpu().numpy()[:nnz], np.ones(nnz))
+    np.testing.assert_array_equal(JD.cpu().numpy()[:(ns + 3) * nd].reshape(ns + 3, nd), np.vstack([p.Jcd, p.Jdd]))
 
     # Hessian of the Lagrangian with obj_factor = 0.75 (lambda is ignored: linear constraints)
     ih, jh, vh, Hdd = dev(2 * ns, torch.int32), dev(2 * ns, torch.int32), dev(2 * ns), dev(nd * nd)
@@ -182,7 +196,7 @@ def test_callbacks_feed_the_condensed_kkt_without_host_values(ctx):
     ie, je, ii, ji = (dev(k, torch.int32) for k in (2 * ns, 2 * ns, ns + 3, ns + 3))
     ih, jh = dev(2 * ns, torch.int32), dev(2 * ns, torch.int32)
     assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), dptr(ie), dptr(je), None, None) == 0
-    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), dptr(ii), dptr(ji), None, None) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), 0, dptr(ii), dptr(ji), None, None) == 0
     assert L.hiopamd_mdsex1_eval_Hess_Lagr(h, dptr(x), C.c_double(1.0), dptr(lam), dptr(ih), dptr(jh), None, None) == 0
     ctx.sync()
     pat = [t.cpu().numpy() for t in (ie, je, ii, ji, ih, jh)]
@@ -191,7 +205,7 @@ def test_callbacks_feed_the_condensed_kkt_without_host_values(ctx):
     ve, vi, vh = dev(2 * ns), dev(ns + 3), dev(2 * ns)
     Jcd, Jdd, Hdd = dev(ns * nd), dev(3 * nd), dev(nd * nd)
     assert L.hiopamd_mdsex1_eval_Jac_cons_eq(h, dptr(x), None, None, dptr(ve), dptr(Jcd)) == 0
-    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), None, None, dptr(vi), dptr(Jdd)) == 0
+    assert L.hiopamd_mdsex1_eval_Jac_cons_ineq(h, dptr(x), 0, None, None, dptr(vi), dptr(Jdd)) == 0
     assert L.hiopamd_mdsex1_eval_Hess_Lagr(h, dptr(x), C.c_double(1.0), dptr(lam), None, None, dptr(vh), dptr(Hdd)) == 0
     Dx, Dd = op.barrier_diagonals(p, seed=3)
     Dxd, Ddd = torch.as_tensor(Dx).cuda(), torch.as_tensor(Dd).cuda()
