@@ -36,7 +36,7 @@ CXX="${CXX:-g++}"
 FLAGS=(-std=c++14 -fPIC -O1 -Wall -Wextra -Wno-unused-parameter -Woverloaded-virtual -Werror=overloaded-virtual)
 
 SRCS=(hiopVectorHipNative.cpp hiopMatrixDenseHipNative.cpp hiopMatrixSparseTripletHipNative.cpp hiopLinSolverSymDenseHipNative.cpp
-      MdsEx1HipNative.cpp)
+      MdsEx1HipNative.cpp DenseConsEx2HipNative.cpp)
 OBJS=()
 for s in "${SRCS[@]}"; do
   o="$TMP/${s%.cpp}.o"
@@ -64,6 +64,7 @@ cat > "$TMP/instantiate.cpp" <<'EOF'
 #include "hiopMatrixSparseTripletHipNative.hpp"
 #include "hiopLinSolverSymDenseHipNative.hpp"
 #include "MdsEx1HipNative.hpp"
+#include "DenseConsEx2HipNative.hpp"
 using namespace hiop;
 void* instantiate_all(hiopNlpFormulation* nlp)
 {
@@ -73,7 +74,8 @@ void* instantiate_all(hiopNlpFormulation* nlp)
   auto* Y = new hiopMatrixSymSparseTripletHipNative(8, 6);
   auto* L = new hiopLinSolverSymDenseHipNative(8, nlp);
   hiopInterfaceMDS* E = new MdsEx1HipNative(40, 12);   // the user-problem side: hiopInterfaceMDS on device pointers
-  static void* all[] = {v, M, S, Y, L, E};
+  hiopInterfaceDenseConstraints* E2 = new DenseConsEx2HipNative(1000);
+  static void* all[] = {v, M, S, Y, L, E, E2};
   return all;
 }
 EOF

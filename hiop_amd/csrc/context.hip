@@ -230,6 +230,14 @@ int hiopamd_ctx_sync(hiopamd_ctx* c)
 
 void* hiopamd_ctx_stream(hiopamd_ctx* c) { return (void*)c->stream; }
 
+int hiopamd_ctx_comm(const hiopamd_ctx* c, int* rank_host, int* size_host)
+{
+  if(!c || !rank_host || !size_host) return HIOPAMD_ERR_ARG;
+  *rank_host = c->comm_rank;
+  *size_host = c->comm_size > 0 ? c->comm_size : 1;
+  return HIOPAMD_OK;
+}
+
 int hiopamd_ctx_set_allreduce(hiopamd_ctx* c, hiopamd_allreduce_fn fn, void* user, int rank, int size)
 {
   if(!c || size < 1 || rank < 0 || rank >= size) return HIOPAMD_ERR_ARG;

@@ -74,6 +74,8 @@ int hiopamd_ctx_spans_read(hiopamd_ctx* ctx, double* ms_host, int64_t* count_hos
 const char* hiopamd_span_name(int span_id);
 
 int hiopamd_ctx_set_allreduce(hiopamd_ctx* ctx, hiopamd_allreduce_fn fn, void* user, int rank, int size);
+/* rank and size the context was given (0 and 1 without a hook) */
+int hiopamd_ctx_comm(const hiopamd_ctx* ctx, int* rank_host, int* size_host);
 /* RCCL-backed all-reduce: `unique_id_128` is the 128-byte ncclUniqueId produced by
  * hiopamd_rccl_unique_id on rank 0 and broadcast by the host side. */
 int hiopamd_rccl_unique_id(unsigned char* unique_id_128_host);
