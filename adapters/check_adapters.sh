@@ -36,7 +36,7 @@ CXX="${CXX:-g++}"
 FLAGS=(-std=c++14 -fPIC -O1 -Wall -Wextra -Wno-unused-parameter -Woverloaded-virtual -Werror=overloaded-virtual)
 
 SRCS=(hiopVectorHipNative.cpp hiopMatrixDenseHipNative.cpp hiopMatrixSparseTripletHipNative.cpp hiopLinSolverSymDenseHipNative.cpp
-      MdsEx1HipNative.cpp DenseConsEx2HipNative.cpp)
+      MdsEx1HipNative.cpp DenseConsEx2HipNative.cpp LinAlgFactoryHipNative.cpp)
 OBJS=()
 for s in "${SRCS[@]}"; do
   o="$TMP/${s%.cpp}.o"
