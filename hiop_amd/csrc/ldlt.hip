@@ -865,9 +865,11 @@ __global__ __launch_bounds__(kBlock) void ldlt_headtrsm_kernel(double* __restric
 
 // W_J = U_JJ^-1 = (L_JJ^-1)^T of every 256 x 256 diagonal block, for the dataflow solve: the row-panel substitution
 // above applied to an identity.  grid = (16, number of blocks), one wave per 16 columns of the identity.
+// wB = 512: W holds inverted 512 x 512 blocks; block Jb goes to the diagonal quadrant Jb % 2 of block Jb / 2 (row stride 512),
+// the upper-right quadrants are filled by ldlt_w512_mm_kernel, the lower-left ones stay zero.
 __global__ __launch_bounds__(64) void ldlt_inv_diag_kernel(int N, const double* __restrict__ Cd_all,
                                                            const double* __restrict__ Dblk, const double* __restrict__ Li_all,
-                                                           double* __restrict__ W)
+                                                           double* __restrict__ W, int wB)
 {
   const int Jb = blockIdx.y, K0 = Jb * LD_NB;
   const int kbs = (N - K0 < LD_NB) ? (N - K0) : LD_NB;
@@ -875,7 +877,9 @@ __global__ __launch_bounds__(64) void ldlt_inv_diag_kernel(int N, const double* 
   const double* Cd = Cd_all + (int64_t)Jb * (LD_NB * LD_NB);
   const double* Dk_sp = Dblk + (int64_t)(K0 / LD_nb) * (LD_nb * LD_nb);
   const double* Li_sp = Li_all + (int64_t)(K0 / LD_nb) * (4 * LD_SB * LD_SB);
-  double* Wj = W + (int64_t)Jb * (LD_NB * LD_NB);
+  const int ldw = (wB == 512) ? 512 : LD_NB;
+  double* Wj = (wB == 512) ? W + (int64_t)(Jb >> 1) * (512 * 512) + (int64_t)(Jb & 1) * (LD_NB * 512 + LD_NB)
+                           : W + (int64_t)Jb * (LD_NB * LD_NB);
   const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
   const int c = blockIdx.x * 16 + li;
   double4_t Vv[4][4];
@@ -897,8 +901,51 @@ __global__ __launch_bounds__(64) void ldlt_inv_diag_kernel(int N, const double* 
         const int row = 64 * P + 16 * I + g + 4 * r;
         double v = (row < kbs && c < kbs) ? Vv[P][I][r] : ((row == c) ? 1.0 : 0.0);
         if(row < c) v = 0.0;
-        Wj[c * LD_NB + row] = v;
+        Wj[c * ldw + row] = v;
       }
+}
+
+// C = alpha * X Y for 256 x 256 row-major blocks, one (X, Y, C) triple per blockIdx.y, one 64 x 64 tile of C per blockIdx.x:
+// the two products that complete an inverted 512 x 512 diagonal block, inv([Ua Uab; 0 Ub]) = [Wa, -Wa Uab Wb; 0, Wb].
+// 4 waves as 2 x 2, each 32 x 32 = 2 x 2 tiles of v_mfma_f64_16x16x4_f64, operands straight from L2 (16 x 0.5 MB per launch).
+__global__ __launch_bounds__(kBlock) void ldlt_w512_mm_kernel(const double* __restrict__ X, int64_t xpair, int64_t ldx,
+                                                              const double* __restrict__ Y, int64_t ypair, int64_t ldy,
+                                                              double* __restrict__ C, int64_t cpair, int64_t ldc, double alpha)
+{
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lk = lane >> 4, li = lane & 15;
+  const int wr = w >> 1, wc = w & 1;
+  const int ti = blockIdx.x >> 2, tj = blockIdx.x & 3;
+  const double* Xp = X + (int64_t)blockIdx.y * xpair + (int64_t)(64 * ti + 32 * wr) * ldx;
+  const double* Yp = Y + (int64_t)blockIdx.y * ypair + 64 * tj + 32 * wc;
+  double* Cp = C + (int64_t)blockIdx.y * cpair + (int64_t)(64 * ti + 32 * wr) * ldc + 64 * tj + 32 * wc;
+  double4_t acc[2][2];
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int q = 0; q < 2; ++q) acc[i][q] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for(int k0 = 0; k0 < LD_NB; k0 += 16) {
+    double av[4][2], bv[4][2];
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk) {
+      const int k = k0 + 4 * kk + lk;
+#pragma unroll
+      for(int i = 0; i < 2; ++i) av[kk][i] = Xp[(int64_t)(16 * i + li) * ldx + k];
+#pragma unroll
+      for(int q = 0; q < 2; ++q) bv[kk][q] = Yp[(int64_t)k * ldy + 16 * q + li];
+    }
+#pragma unroll
+    for(int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for(int i = 0; i < 2; ++i)
+#pragma unroll
+        for(int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk][i], bv[kk][q], acc[i][q], 0, 0, 0);
+  }
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int q = 0; q < 2; ++q)
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg) Cp[(int64_t)(16 * i + lk + 4 * reg) * ldc + 16 * q + li] = alpha * acc[i][q][reg];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1504,8 +1551,10 @@ __global__ __launch_bounds__(SV_T) void ldlt_bwd_step256(const double* __restric
 //     no floating-point atomics, results are bitwise reproducible from run to run.
 // Flags are monotone 64-bit counters compared against epoch * (expected count), so nothing is reset between solves.
 // ------------------------------------------------------------------------------------------
-constexpr int FL_R = 4;   // 64-wide chunks per 256-block
-constexpr int FL_LEAD = 3;   // block steps of lead of the operand loads over the chain (see the pacing note in the kernel)
+// Block size B of the task graph = threads per workgroup: 256, or 512 when the order is a multiple of 512 — the length of a
+// solve is (number of block steps) x (two hand-overs + two small tasks), so half the steps is close to half the time; a 512
+// block's inverse is assembled from the two 256 inverses and one extra product (ldlt_w512_mm_kernel).  B / 64 chunks per block.
+constexpr int FL_LEAD = 3;   // block steps of lead of the operand loads over the chain (default; see the pacing note in the kernel)
 enum { FL_FWD_OFF = 0, FL_FWD_DIAG = 1, FL_BWD_OFF = 2, FL_BWD_DIAG = 3 };
 
 // Everything one task hands to another (y, x, the product slots) moves with agent-scope relaxed atomic loads and stores:
@@ -1633,17 +1682,22 @@ __device__ __forceinline__ void flow_signal(unsigned long long* p)
 // fa[J]: products (I, J) with I <= J - 3 delivered, fc[J]: I = J - 2, fb[J]: I = J - 1 (the diagonal task adds them in
 // that order: the bulk is summed two block steps before the last one arrives); ba / bc / bb likewise for the rows.
 // P: nb x nb slots of 256 doubles; slot (a, b) = (a * nb + b) * 256: forward uses (J, I), backward (I, J), I < J.
-__global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* __restrict__ A, int64_t lda, int N, int nb,
+template <int B>
+__global__ __launch_bounds__(B) void ldlt_solve_flow_kernel(const double* __restrict__ A, int64_t lda, int N, int nb,
                                                                  const double* __restrict__ W,
                                                                  const double* __restrict__ dinv,
                                                                  const int4* __restrict__ tasks, int ntasks,
                                                                  unsigned long long* sync, unsigned long long epoch,
                                                                  double* P, double* y, double* xc, double* Po, double* yo, double* xo,
-                                                                 double* b, long long* ts)
+                                                                 double* b, long long* ts, int lead)
 {
+  constexpr int FL_R = B / 64;    // 64-wide chunks per block
+  constexpr int RP = B / 16;      // backward: rows per pass (16 lanes per row)
+  constexpr int NPASS = 64 / RP;  // passes over the 64 rows of a chunk
+  constexpr int KC = B / 16;      // 16-column strips per lane
   __shared__ int s_ticket;
-  __shared__ double vsh[SV_B];
-  __shared__ double red[4][64];
+  __shared__ double vsh[B];
+  __shared__ double red[FL_R][64];
   const int tid = threadIdx.x;
   if(tid == 0) {
     const unsigned long long t = __hip_atomic_fetch_add(sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1672,7 +1726,7 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
     const int half = ntasks >> 1;
     const bool fwd = s_ticket < half;
     const int rel = fwd ? s_ticket : s_ticket - half;
-    const int pace = (int)(((long long)rel * nb) / half) - FL_LEAD;   // block step of the chain to wait for
+    const int pace = (int)(((long long)rel * nb) / half) - lead;   // block step of the chain to wait for
     if(pace >= 0) {
       const unsigned long long* f = fwd ? (fy + pace) : (bx + (nb - 1 - pace));
       if(tid == 0) {
@@ -1690,20 +1744,20 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
     // ---- forward, out[c] = sum_r M[r][c] v[r]: lane <-> column, wave rg <-> rows 64 rg .. 64 rg + 63
     const int cl = tid & 63;
     const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t gcol = (int64_t)J * SV_B + ch * 64 + cl;
+    const int64_t gcol = (int64_t)J * B + ch * 64 + cl;
     const bool colok = gcol < N;
     bool live = true;
     if(kind == FL_FWD_OFF) {
       const int64_t cc = colok ? gcol : (int64_t)(N - 1);
-      const double* src = A + ((int64_t)I * SV_B + rg * 64) * lda + cc;
+      const double* src = A + ((int64_t)I * B + rg * 64) * lda + cc;
 #pragma unroll
       for(int q = 0; q < 64; ++q) m[q] = src[(int64_t)q * lda];
     } else {
       live = rg <= ch;   // W is upper triangular
-      const double* src = W + (int64_t)J * (SV_B * SV_B) + (rg * 64) * SV_B + ch * 64 + cl;
+      const double* src = W + (int64_t)J * (B * B) + (rg * 64) * B + ch * 64 + cl;
       if(live) {
 #pragma unroll
-        for(int q = 0; q < 64; ++q) m[q] = src[q * SV_B];
+        for(int q = 0; q < 64; ++q) m[q] = src[q * B];
       } else {
 #pragma unroll
         for(int q = 0; q < 64; ++q) m[q] = 0.0;
@@ -1711,20 +1765,20 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
     }
     if(kind == FL_FWD_OFF) {
       flow_wait_chain(fy, I, -1, nb, eR, J - I - 1, guard);
-      vsh[tid] = (J - I == 1) ? flow_poll(y + (int64_t)I * SV_B + tid, guard) : flow_ld(y + (int64_t)I * SV_B + tid);
+      vsh[tid] = (J - I == 1) ? flow_poll(y + (int64_t)I * B + tid, guard) : flow_ld(y + (int64_t)I * B + tid);
     } else {
-      const int64_t gi = (int64_t)J * SV_B + tid;
+      const int64_t gi = (int64_t)J * B + tid;
       double v = (gi < N) ? b[gi] : 0.0;
       if(J >= 3) {
         flow_wait(fa + J, eR * (unsigned long long)(J - 2), guard);
-        v = flow_sub_slots(v, P + (int64_t)J * nb * SV_B + tid, SV_B, J - 2);
+        v = flow_sub_slots(v, P + (int64_t)J * nb * B + tid, B, J - 2);
       }
       if(J >= 2) {
         flow_wait(fc + J, eR, guard);
-        v -= flow_ld(P + ((int64_t)J * nb + (J - 2)) * SV_B + tid);
+        v -= flow_ld(P + ((int64_t)J * nb + (J - 2)) * B + tid);
       }
       if(J >= 1) {
-        const double* pl = P + ((int64_t)J * nb + (J - 1)) * SV_B + tid;
+        const double* pl = P + ((int64_t)J * nb + (J - 1)) * B + tid;
         v -= flow_poll(pl, guard);
       }
       vsh[tid] = v;
@@ -1739,10 +1793,12 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
     red[rg][cl] = acc;
     __syncthreads();
     if(tid < 64) {
-      const double out = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+      double out = red[0][tid];
+#pragma unroll
+      for(int q = 1; q < FL_R; ++q) out += red[q][tid];
       if(kind == FL_FWD_OFF) {
-        flow_st(P + ((int64_t)J * nb + I) * SV_B + ch * 64 + tid, colok ? out : 0.0);
-        if(I == J - 1) flow_poison(Po + ((int64_t)J * nb + I) * SV_B + ch * 64 + tid);
+        flow_st(P + ((int64_t)J * nb + I) * B + ch * 64 + tid, colok ? out : 0.0);
+        if(I == J - 1) flow_poison(Po + ((int64_t)J * nb + I) * B + ch * 64 + tid);
         flow_signal((I == J - 1) ? (fb + J) : (I == J - 2) ? (fc + J) : (fa + J));
         if(ts && tid == 0) ts[4 * s_ticket + 2] = wall_clock64();
       } else {
@@ -1756,76 +1812,76 @@ __global__ __launch_bounds__(kBlock) void ldlt_solve_flow_kernel(const double* _
     }
     return;
   }
-  // ---- backward, out[r] = sum_c M[r][c] v[c]: 16 lanes per row, 16 rows per pass, 4 passes
+  // ---- backward, out[r] = sum_c M[r][c] v[c]: 16 lanes per row, RP = B / 16 rows per pass, 64 / RP passes
   const int rr = tid >> 4, pt = tid & 15;
   if(kind == FL_BWD_OFF) {
 #pragma unroll
-    for(int ps = 0; ps < 4; ++ps) {
-      const double* src = A + ((int64_t)I * SV_B + ch * 64 + ps * 16 + rr) * lda;
+    for(int ps = 0; ps < NPASS; ++ps) {
+      const double* src = A + ((int64_t)I * B + ch * 64 + ps * RP + rr) * lda;
 #pragma unroll
-      for(int k = 0; k < 16; ++k) {
-        const int64_t gc = (int64_t)J * SV_B + 16 * k + pt;
-        m[ps * 16 + k] = src[(gc < N) ? gc : (int64_t)(N - 1)];
+      for(int k = 0; k < KC; ++k) {
+        const int64_t gc = (int64_t)J * B + 16 * k + pt;
+        m[ps * KC + k] = src[(gc < N) ? gc : (int64_t)(N - 1)];
       }
     }
     flow_wait_chain(bx, J, +1, nb, eR, J - I - 1, guard);
-    const int64_t gj = (int64_t)J * SV_B + tid;
+    const int64_t gj = (int64_t)J * B + tid;
     vsh[tid] = (gj < N) ? ((J - I == 1) ? flow_poll(xc + gj, guard) : flow_ld(xc + gj)) : 0.0;
   } else {
-    const double* Wi = W + (int64_t)I * (SV_B * SV_B);
+    const double* Wi = W + (int64_t)I * (B * B);
 #pragma unroll
-    for(int ps = 0; ps < 4; ++ps) {
-      const double* src = Wi + (ch * 64 + ps * 16 + rr) * SV_B + pt;
+    for(int ps = 0; ps < NPASS; ++ps) {
+      const double* src = Wi + (ch * 64 + ps * RP + rr) * B + pt;
 #pragma unroll
-      for(int k = 0; k < 16; ++k) {
+      for(int k = 0; k < KC; ++k) {
         // columns 16k..16k+15 lie left of every row of this pass: structurally zero
-        m[ps * 16 + k] = (16 * k + 15 < ch * 64 + ps * 16) ? 0.0 : src[16 * k];
+        m[ps * KC + k] = (16 * k + 15 < ch * 64 + ps * RP) ? 0.0 : src[16 * k];
       }
     }
-    const int64_t gi = (int64_t)I * SV_B + tid;
+    const int64_t gi = (int64_t)I * B + tid;
     flow_wait(fy + I, eR, guard);
     double v = (gi < N) ? flow_ld(y + gi) * dinv[gi] : 0.0;
     const int above = nb - 1 - I;
     if(above >= 3) {   // J = nb-1 .. I+3, descending
       flow_wait(ba + I, eR * (unsigned long long)(above - 2), guard);
-      v = flow_sub_slots(v, P + ((int64_t)I * nb + (nb - 1)) * SV_B + tid, -(int64_t)SV_B, above - 2);
+      v = flow_sub_slots(v, P + ((int64_t)I * nb + (nb - 1)) * B + tid, -(int64_t)B, above - 2);
     }
     if(above >= 2) {
       flow_wait(bc + I, eR, guard);
-      v -= flow_ld(P + ((int64_t)I * nb + (I + 2)) * SV_B + tid);
+      v -= flow_ld(P + ((int64_t)I * nb + (I + 2)) * B + tid);
     }
     if(above >= 1) {
-      const double* pl = P + ((int64_t)I * nb + (I + 1)) * SV_B + tid;
+      const double* pl = P + ((int64_t)I * nb + (I + 1)) * B + tid;
       v -= flow_poll(pl, guard);
     }
     vsh[tid] = v;
   }
   if(ts && tid == 0) ts[4 * s_ticket + 1] = wall_clock64();
   __syncthreads();
-  double xv[16];
+  double xv[KC];
 #pragma unroll
-  for(int k = 0; k < 16; ++k) xv[k] = vsh[16 * k + pt];
+  for(int k = 0; k < KC; ++k) xv[k] = vsh[16 * k + pt];
 #pragma unroll
-  for(int ps = 0; ps < 4; ++ps) {
+  for(int ps = 0; ps < NPASS; ++ps) {
     double acc = 0.0;
 #pragma unroll
-    for(int k = 0; k < 16; ++k) acc = fma(m[ps * 16 + k], xv[k], acc);
+    for(int k = 0; k < KC; ++k) acc = fma(m[ps * KC + k], xv[k], acc);
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
     acc += __shfl_xor(acc, 8, 64);
-    if(pt == 0) red[0][ps * 16 + rr] = acc;
+    if(pt == 0) red[0][ps * RP + rr] = acc;
   }
   __syncthreads();
   if(tid < 64) {
     const double out = red[0][tid];
     if(kind == FL_BWD_OFF) {
-      flow_st(P + ((int64_t)I * nb + J) * SV_B + ch * 64 + tid, out);
-      if(J == I + 1) flow_poison(Po + ((int64_t)I * nb + J) * SV_B + ch * 64 + tid);
+      flow_st(P + ((int64_t)I * nb + J) * B + ch * 64 + tid, out);
+      if(J == I + 1) flow_poison(Po + ((int64_t)I * nb + J) * B + ch * 64 + tid);
       flow_signal((J == I + 1) ? (bb + I) : (J == I + 2) ? (bc + I) : (ba + I));
       if(ts && tid == 0) ts[4 * s_ticket + 2] = wall_clock64();
     } else {
-      const int64_t go = (int64_t)I * SV_B + ch * 64 + tid;
+      const int64_t go = (int64_t)I * B + ch * 64 + tid;
       if(go < N) {
         flow_st(xc + go, out);   // for the tasks of this launch
         flow_poison(xo + go);
@@ -2071,7 +2127,11 @@ struct hiopamd_linsolver {
   double* Cd = nullptr;     // ceil(n/256) compact 256x256 diagonal blocks (ld = 256)
   int* d_info = nullptr;    // [0]=zero-pivot flag, [1..3]=pos,neg,zero
   // dataflow solve (ldlt_solve_flow_kernel)
-  double* W = nullptr;                  // ceil(n/256) inverted diagonal blocks
+  double* W = nullptr;                  // ceil(n/256) inverted diagonal blocks (fl_B = 256), or n/512 inverted 512 x 512 blocks (fl_B = 512)
+  double* Wt = nullptr;                 // fl_B = 512: scratch for U_ab W_b, one 256 x 256 block per 512-block
+  int fl_B = 256;                       // block size of the dataflow solve's task graph
+  int fl_nb = 0;                        // its number of blocks
+  int fl_lead = FL_LEAD;                // lead of its operand loads (block steps)
   double* P = nullptr;                  // nb x nb product slots of 256
   // safe mode (static quasi-definite regularisation + iterative refinement against a saved copy of the matrix)
   bool safe_mode = false;
@@ -2098,7 +2158,7 @@ struct hiopamd_linsolver {
 
 static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, double* dinv, double* V, double* Dblk,
                             double* Cd, int* d_info, int* inertia3_host, LdltProfile* prof = nullptr, double* Winv = nullptr,
-                            DfDevice* df = nullptr)
+                            DfDevice* df = nullptr, int wB = 256, double* Wt = nullptr)
 {
   // Dblk: per 64-row panel a compact 64x64 copy of the factored diagonal block, followed (after all
   // the blocks) by the per-panel 4 x 16x16 inverses
@@ -2307,7 +2367,16 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   span_begin(ctx, HIOPAMD_SPAN_LINSOLV_INERTIA);   // :127-167 (tmInertiaComp)
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
   span_end(ctx, HIOPAMD_SPAN_LINSOLV_INERTIA);
-  if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv);
+  if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv, wB);
+  if(Winv && wB == 512 && Wt) {
+    // T = U_ab W_b, then the upper-right quadrant = -W_a T   (N is a multiple of 512 here; U_ab = A[rows of a, columns of b])
+    const int np2 = N / 512;
+    const int64_t w2 = 512 * 512;
+    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(16, np2), dim3(kBlock), 0, st, A + LD_NB, (int64_t)512 * lda + 512, lda,
+                       Winv + (int64_t)LD_NB * 512 + LD_NB, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB, (int64_t)LD_NB, 1.0);
+    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(16, np2), dim3(kBlock), 0, st, Winv, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB,
+                       (int64_t)LD_NB, Winv + LD_NB, w2, (int64_t)512, -1.0);
+  }
   HIOPAMD_CHECK(hipGetLastError());
   int h[4];
   unsigned dfw[16] = {0};
@@ -2383,11 +2452,11 @@ static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda
   hipStream_t st = ctx->stream;
   const int nblk = (N + LD_nb - 1) / LD_nb;
   if(flow && flow->W && flow->flow_enabled) {
-    const int nb = (N + SV_B - 1) / SV_B;
+    const int nb = flow->fl_nb, FB = flow->fl_B;
     for(int j = 0; j < nrhs; ++j) {
       flow->fl_epoch += 1;
       // exchange buffers of this epoch's parity (c) and of the next launch (n): y | x | product slots, twice
-      const int64_t npad = (int64_t)nb * SV_B, psz = (int64_t)SV_B * nb * nb, half = 2 * npad + psz;
+      const int64_t npad = (int64_t)nb * FB, psz = (int64_t)FB * nb * nb, half = 2 * npad + psz;
       double* cur = flow->P + (int64_t)(flow->fl_epoch & 1ull) * half;
       double* nxt = flow->P + (int64_t)((flow->fl_epoch + 1ull) & 1ull) * half;
       double *yc = cur, *xcur = cur + npad, *Pc = cur + 2 * npad;
@@ -2400,9 +2469,14 @@ static int ldlt_solve_impl(hiopamd_ctx* ctx, int N, const double* A, int64_t lda
         if(hipMalloc((void**)&ts, sizeof(long long) * 4 * (size_t)flow->fl_ntasks) != hipSuccess) ts = nullptr;
         else (void)hipMemsetAsync(ts, 0, sizeof(long long) * 4 * (size_t)flow->fl_ntasks, st);
       }
-      hipLaunchKernelGGL(ldlt_solve_flow_kernel, dim3(flow->fl_ntasks), dim3(kBlock), 0, st, A, lda, N, nb, flow->W, dinv,
-                         flow->fl_tasks, flow->fl_ntasks, flow->fl_sync, flow->fl_epoch, Pc, yc, xcur, Pn, yn, xn,
-                         rhs + (int64_t)j * N, ts);
+      if(FB == 512)
+        hipLaunchKernelGGL(ldlt_solve_flow_kernel<512>, dim3(flow->fl_ntasks), dim3(512), 0, st, A, lda, N, nb, flow->W, dinv,
+                           flow->fl_tasks, flow->fl_ntasks, flow->fl_sync, flow->fl_epoch, Pc, yc, xcur, Pn, yn, xn,
+                           rhs + (int64_t)j * N, ts, flow->fl_lead);
+      else
+        hipLaunchKernelGGL(ldlt_solve_flow_kernel<256>, dim3(flow->fl_ntasks), dim3(256), 0, st, A, lda, N, nb, flow->W, dinv,
+                           flow->fl_tasks, flow->fl_ntasks, flow->fl_sync, flow->fl_epoch, Pc, yc, xcur, Pn, yn, xn,
+                           rhs + (int64_t)j * N, ts, flow->fl_lead);
       if(ts) {
         std::vector<long long> h(4 * (size_t)flow->fl_ntasks);
         std::vector<int4> tk((size_t)flow->fl_ntasks);
@@ -2550,11 +2624,22 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
   HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
   {
     // dataflow solve: inverted diagonal blocks, product slots, flags, and the task list in issue order
-    const int nb = (int)((nn + SV_B - 1) / SV_B);
-    HIOPAMD_CHECK(hipMalloc((void**)&ls->W, sizeof(double) * (size_t)SV_B * SV_B * nb));
+    // block size of the task graph: 512 for orders that are multiples of 512 (HIOPAMD_SOLVE_B=256 forces 256: A/B timing)
+    static const int b_env = std::getenv("HIOPAMD_SOLVE_B") ? std::atoi(std::getenv("HIOPAMD_SOLVE_B")) : 512;
+    const int FB = (b_env == 512 && n >= 2048 && n % 512 == 0) ? 512 : SV_B;
+    const int FR = FB / 64;
+    const int nb = (int)((nn + FB - 1) / FB);
+    ls->fl_B = FB;
+    ls->fl_nb = nb;
+    ls->fl_lead = std::getenv("HIOPAMD_SOLVE_LEAD") ? std::atoi(std::getenv("HIOPAMD_SOLVE_LEAD")) : (FB == 512 ? 2 : FL_LEAD);
+    HIOPAMD_CHECK(hipMalloc((void**)&ls->W, sizeof(double) * (size_t)FB * FB * nb));
+    if(FB == 512) {
+      HIOPAMD_CHECK(hipMemsetAsync(ls->W, 0, sizeof(double) * (size_t)FB * FB * nb, ctx->stream));   // the lower-left quadrants stay zero
+      HIOPAMD_CHECK(hipMalloc((void**)&ls->Wt, sizeof(double) * (size_t)SV_B * SV_B * nb));
+    }
     {
       // two copies of (y | x | product slots), poisoned (flow_poll)
-      const size_t words = 2 * ((size_t)2 * nb * SV_B + (size_t)SV_B * nb * nb);
+      const size_t words = 2 * ((size_t)2 * nb * FB + (size_t)FB * nb * nb);
       HIOPAMD_CHECK(hipMalloc((void**)&ls->P, sizeof(double) * words));
       std::vector<unsigned long long> poison(words, FL_POISON);
       HIOPAMD_CHECK(hipMemcpy(ls->P, poison.data(), sizeof(double) * words, hipMemcpyHostToDevice));
@@ -2562,16 +2647,16 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
     HIOPAMD_CHECK(hipMalloc((void**)&ls->fl_sync, sizeof(unsigned long long) * (size_t)(2 + 8 * nb)));   // + the error word
     HIOPAMD_CHECK(hipMemsetAsync(ls->fl_sync, 0, sizeof(unsigned long long) * (size_t)(2 + 8 * nb), ctx->stream));
     std::vector<int4> tk;
-    tk.reserve((size_t)FL_R * nb * (nb + 1));
+    tk.reserve((size_t)FR * nb * (nb + 1));
     for(int J = 0; J < nb; ++J) {   // forward: column J needs y_I, I < J; its diagonal task closes it
       for(int I = 0; I < J; ++I)
-        for(int c = 0; c < FL_R; ++c) tk.push_back(make_int4(FL_FWD_OFF, I, J, c));
-      for(int c = 0; c < FL_R; ++c) tk.push_back(make_int4(FL_FWD_DIAG, J, J, c));
+        for(int c = 0; c < FR; ++c) tk.push_back(make_int4(FL_FWD_OFF, I, J, c));
+      for(int c = 0; c < FR; ++c) tk.push_back(make_int4(FL_FWD_DIAG, J, J, c));
     }
     for(int I = nb - 1; I >= 0; --I) {   // backward: row I needs x_J, J > I
       for(int J = nb - 1; J > I; --J)
-        for(int c = 0; c < FL_R; ++c) tk.push_back(make_int4(FL_BWD_OFF, I, J, c));
-      for(int c = 0; c < FL_R; ++c) tk.push_back(make_int4(FL_BWD_DIAG, I, I, c));
+        for(int c = 0; c < FR; ++c) tk.push_back(make_int4(FL_BWD_OFF, I, J, c));
+      for(int c = 0; c < FR; ++c) tk.push_back(make_int4(FL_BWD_DIAG, I, I, c));
     }
     ls->fl_ntasks = (int)tk.size();
     HIOPAMD_CHECK(hipMalloc((void**)&ls->fl_tasks, sizeof(int4) * tk.size()));
@@ -2617,6 +2702,7 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->Cd);
   (void)hipFree(ls->d_info);
   (void)hipFree(ls->W);
+  (void)hipFree(ls->Wt);
   (void)hipFree(ls->P);
   (void)hipFree(ls->fl_sync);
   (void)hipFree(ls->fl_tasks);
@@ -2639,7 +2725,7 @@ static int flow_check(hiopamd_linsolver* ls, int* ok_host)
 {
   if(ok_host) *ok_host = 1;
   if(!ls->flow_dirty || !ls->fl_sync) return HIOPAMD_OK;
-  const int nb = (int)(((size_t)(ls->n > 0 ? ls->n : 1) + SV_B - 1) / SV_B);
+  const int nb = ls->fl_nb, FB = ls->fl_B;
   unsigned long long err = 0;
   HIOPAMD_CHECK(hipMemcpyAsync(&err, ls->fl_sync + 1 + 8 * nb, sizeof(err), hipMemcpyDeviceToHost, ls->ctx->stream));
   HIOPAMD_CHECK(hipStreamSynchronize(ls->ctx->stream));
@@ -2649,7 +2735,7 @@ static int flow_check(hiopamd_linsolver* ls, int* ok_host)
   std::fprintf(stderr, "[hiop_amd] dataflow solve: a bounded wait timed out; the results of the solves since the last check are "
                        "invalid.  Exchange state re-initialised, stepwise solve from now on.\n");
   HIOPAMD_CHECK(hipMemsetAsync(ls->fl_sync, 0, sizeof(unsigned long long) * (size_t)(2 + 8 * nb), ls->ctx->stream));
-  const size_t words = 2 * ((size_t)2 * nb * SV_B + (size_t)SV_B * nb * nb);
+  const size_t words = 2 * ((size_t)2 * nb * FB + (size_t)FB * nb * nb);
   std::vector<unsigned long long> poison(words, FL_POISON);
   HIOPAMD_CHECK(hipMemcpy(ls->P, poison.data(), sizeof(double) * words, hipMemcpyHostToDevice));
   ls->fl_epoch = 0;
@@ -2779,7 +2865,7 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
   }
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_FACT);   // hiopLinSolverSymDenseLapack.hpp:80-125 (tmFactTime; flopsFact = n^3/3)
   ls->flops_fact += (double)ls->n * ls->n * ls->n / 3.0;
-  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df);
+  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
   if(rc == HIOPAMD_ERR_SINGULAR) {
     // reference: "entry in the factorization's diagonal is exactly zero" -> matrixChanged() returns -1
     *n_neg_host = -1;

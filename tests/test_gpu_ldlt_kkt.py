@@ -340,9 +340,10 @@ def test_iajaaa_writer_reproduces_reference_files(ctx, fname, tmp_path):
     assert open(out.decode()).read().split() == open(src).read().split()
 
 
-@pytest.mark.parametrize("n", [1, 17, 255, 256, 257, 511, 513, 1023, 1280, 2049])
+@pytest.mark.parametrize("n", [1, 17, 255, 256, 257, 511, 513, 1023, 1280, 2049, 2048, 2560, 4096])
 def test_dataflow_solve_block_boundaries_multi_rhs_and_repeats(ctx, n):
-    """hiopamd_linsolver_solve around the 256-block boundaries of the dataflow kernel (ragged last block, one block, N = 1),
+    """hiopamd_linsolver_solve around the 256-block boundaries of the dataflow kernel (ragged last block, one block, N = 1;
+    multiples of 512 from 2048 on run the 512-block task graph with the inverted 512 x 512 diagonal blocks),
     several right-hand sides in one call, and repeated solves (the exchange buffers alternate by epoch parity and are
     re-poisoned by the previous launch): every solve must reproduce the dense solution and repeat bit for bit."""
     from hiop_amd.kkt import LinSolverSymDense
