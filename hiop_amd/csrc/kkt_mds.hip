@@ -112,7 +112,82 @@ int hiopamd_kkt_mds_set_values(hiopamd_kkt_mds* k, const double* Jcs_val, const 
     if(rc_ != HIOPAMD_OK) return rc_; \
   } while(0)
 
-int hiopamd_kkt_mds_build(hiopamd_kkt_mds* k, double delta_wx, double delta_wd, double delta_cc, double delta_cd)
+// a regularisation term: one value for every entry (v == nullptr) or a device vector (the reference's delta_wx / delta_wd /
+// delta_cc / delta_cd are vectors: hiopKKTLinSysMDS.cpp:178-181, the randomised perturbations fill them entry by entry)
+struct MdsDelta {
+  const double* v;
+  double s;
+  __device__ __forceinline__ double at(int64_t i) const { return v ? v[i] : s; }
+};
+
+// Dense part of build_kkt_matrix in ONE pass over the upper triangle (reference: setToZero + three block adds + four diagonal
+// adds = eight passes over parts of an N x N matrix, hiopKKTLinSysMDS.cpp:196-215,245,289-290): every element (r, c), c >= r,
+// is written exactly once —
+//   (1,1)  upper(Hd)[r][c]  (+ Dxd + delta_wx on the diagonal)      (1,2)  Jcd[c - nxd][r]        (1,3)  Jdd[c - nxd - neq][r]
+//   (2,2)  -delta_cc on the diagonal, 0 elsewhere        (2,3)  0        (3,3)  -(Dd_inv + delta_cd) on the diagonal, 0 elsewhere
+// and the sparse Schur terms are added afterwards by their plans (a few entries).  64 x 64 tiles; a tile inside a transposed
+// block goes through LDS (source read along its rows, matrix written along its rows), every other tile element by element.
+// The strictly lower triangle is never touched (it is zero since the solver object was created and nothing reads it).
+constexpr int MA_T = 64;
+__global__ __launch_bounds__(hiopamd::kBlock) void kkt_mds_assemble_kernel(double* __restrict__ M, int64_t ld, int nxs, int nxd, int neq,
+                                                                           int nineq, const double* __restrict__ Hdd,
+                                                                           const double* __restrict__ Jcd,
+                                                                           const double* __restrict__ Jdd,
+                                                                           const double* __restrict__ Dx,
+                                                                           const double* __restrict__ Dd_inv, MdsDelta dwx,
+                                                                           MdsDelta dcc, MdsDelta dcd, int ntile)
+{
+  __shared__ double T[MA_T][MA_T + 1];
+  // linear tile index -> (ti, tj), tj >= ti, row by row of the upper triangle
+  int t = blockIdx.x, ti = 0;
+  {
+    // rows have ntile, ntile - 1, ... tiles: solve the quadratic, then fix up
+    const double nt = (double)ntile;
+    ti = (int)floor((2.0 * nt + 1.0 - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)t)) * 0.5);
+    if(ti < 0) ti = 0;
+    while(ti > 0 && (int64_t)ti * ntile - (int64_t)ti * (ti - 1) / 2 > t) --ti;
+    while((int64_t)(ti + 1) * ntile - (int64_t)(ti + 1) * ti / 2 <= t) ++ti;
+  }
+  const int tj = ti + (t - (int)((int64_t)ti * ntile - (int64_t)ti * (ti - 1) / 2));
+  const int N = nxd + neq + nineq;
+  const int r0 = ti * MA_T, c0 = tj * MA_T;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int r1 = min(r0 + MA_T, N), c1 = min(c0 + MA_T, N);
+  auto diag_term = [&](int r) -> double {
+    if(r < nxd) return Dx[nxs + r] + dwx.at(nxs + r);
+    if(r < nxd + neq) return -dcc.at(r - nxd);
+    return -(Dd_inv[r - nxd - neq] + dcd.at(r - nxd - neq));
+  };
+  // tiles wholly inside (rows of x_dense) x (columns of one Jacobian): the transposed blocks
+  const bool in_c = r1 <= nxd && c0 >= nxd && c1 <= nxd + neq;
+  const bool in_d = r1 <= nxd && c0 >= nxd + neq;
+  if(in_c || in_d) {
+    const double* S = in_c ? Jcd + (int64_t)(c0 - nxd) * nxd : Jdd + (int64_t)(c0 - nxd - neq) * nxd;   // row cc of the source = column c0 + cc
+    const int nr = r1 - r0, nc = c1 - c0;
+#pragma unroll 4
+    for(int cc = ty; cc < nc; cc += 4)
+      if(tx < nr) T[tx][cc] = S[(int64_t)cc * nxd + r0 + tx];
+    __syncthreads();
+#pragma unroll 4
+    for(int rr = ty; rr < nr; rr += 4)
+      if(tx < nc) M[(int64_t)(r0 + rr) * ld + c0 + tx] = T[rr][tx];
+    return;
+  }
+  for(int rr = ty; rr < r1 - r0; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    if(c >= c1 || c < r) continue;
+    double v = 0.0;
+    if(r < nxd) {
+      if(c < nxd) v = Hdd[(int64_t)r * nxd + c];
+      else if(c < nxd + neq) v = Jcd[(int64_t)(c - nxd) * nxd + r];
+      else v = Jdd[(int64_t)(c - nxd - neq) * nxd + r];
+    }
+    if(r == c) v += diag_term(r);
+    M[(int64_t)r * ld + c] = v;
+  }
+}
+
+static int kkt_mds_build_impl(hiopamd_kkt_mds* k, MdsDelta dwx, MdsDelta dwd, MdsDelta dcc, MdsDelta dcd)
 {
   if(!k || !k->Dx) return HIOPAMD_ERR_STATE;
   hiopamd_ctx* ctx = k->ctx;
@@ -123,38 +198,50 @@ int hiopamd_kkt_mds_build(hiopamd_kkt_mds* k, double delta_wx, double delta_wd, 
   const int64_t ld = N;
   SpanScope span(ctx, HIOPAMD_SPAN_KKT_UPDATE_LINSYS);   // :193-294
 
-  // Msys.setToZero()                                                        (:196)
-  HIOPAMD_CHECK(hipMemsetAsync(M, 0, sizeof(double) * (size_t)N * (size_t)N, ctx->stream));
-  // (1,1) += upper(Hd); (1,2) += Jcd^T; (1,3) += Jdd^T                       (:204-206)
-  RC(hiopamd_mat_add_upper_to_sym_upper(ctx, nxd, k->Hdd, nxd, 0, 1.0, M, ld));
-  RC(hiopamd_mat_trans_add_to_sym_upper(ctx, neq, nxd, k->Jcd, nxd, 0, nxd, 1.0, M, ld));
-  RC(hiopamd_mat_trans_add_to_sym_upper(ctx, nineq, nxd, k->Jdd, nxd, 0, nxd + neq, 1.0, M, ld));
-  // diag(1,1) += Dxd + delta_wx                                              (:213-215)
-  RC(hiopamd_mat_add_sub_diagonal(ctx, M, ld, 0, 1.0, k->Dx, nxs, nxd));
-  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, ld, 0, nxd, delta_wx));
   // Hxs = Dxs + delta_wx + diag(Hss)                                         (:223-231)
   {
     const double* Dx = k->Dx;
     double* Hxs = k->Hxs;
-    RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { Hxs[i] = Dx[i] + delta_wx; }));
+    RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { Hxs[i] = Dx[i] + dwx.at(i); }));
     RC(hiopamd_spsym_add_diag_to_vec(ctx, s.nnz_Hss, s.Hss_i, s.Hss_j, k->Hss_val, 1.0, Hxs, 0, nxs, 0, nxs));
   }
-  // (2,2) += -Jcs Hxs^-1 Jcs^T ; -delta_cc                                   (:239-245)
-  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cc, k->Jcs_val, k->Jcs_val, k->Hxs, -1.0, M, ld, nxd, nxd));
-  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, ld, nxd, neq, -delta_cc));
-  // (3,3) += -Jds Hxs^-1 Jds^T ; (2,3) += -Jcs Hxs^-1 Jds^T                  (:267-276)
-  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_dd, k->Jds_val, k->Jds_val, k->Hxs, -1.0, M, ld, nxd + neq, nxd + neq));
-  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cd, k->Jcs_val, k->Jds_val, k->Hxs, -1.0, M, ld, nxd, nxd + neq));
-  // Dd_inv = 1/(Dd + delta_wd); (3,3) -= Dd_inv + delta_cd                   (:280-290)
+  // Dd_inv = 1/(Dd + delta_wd)                                                (:280-287)
   {
     const double* Dd = k->Dd;
     double* Ddi = k->Dd_inv;
-    RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { Ddi[i] = 1.0 / (delta_wd + Dd[i]); }));
+    RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { Ddi[i] = 1.0 / (dwd.at(i) + Dd[i]); }));
   }
-  RC(hiopamd_mat_add_sub_diagonal(ctx, M, ld, nxd + neq, -1.0, k->Dd_inv, 0, nineq));
-  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, ld, nxd + neq, nineq, -delta_cd));
+  // Msys = 0; (1,1) += upper(Hd) + Dxd + delta_wx; (1,2) += Jcd^T; (1,3) += Jdd^T; diag(2,2) -= delta_cc;
+  // diag(3,3) -= Dd_inv + delta_cd — one pass over the upper triangle          (:196-215, :245, :289-290)
+  if(N > 0) {
+    const int ntile = (N + MA_T - 1) / MA_T;
+    const int64_t ntri = (int64_t)ntile * (ntile + 1) / 2;
+    hipLaunchKernelGGL(kkt_mds_assemble_kernel, dim3((unsigned)ntri), dim3(kBlock), 0, ctx->stream, M, ld, nxs, nxd, neq, nineq,
+                       k->Hdd, k->Jcd, k->Jdd, k->Dx, k->Dd_inv, dwx, dcc, dcd, ntile);
+    HIOPAMD_CHECK(hipGetLastError());
+  }
+  // (2,2) += -Jcs Hxs^-1 Jcs^T                                               (:239)
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cc, k->Jcs_val, k->Jcs_val, k->Hxs, -1.0, M, ld, nxd, nxd));
+  // (3,3) += -Jds Hxs^-1 Jds^T ; (2,3) += -Jcs Hxs^-1 Jds^T                  (:267-276)
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_dd, k->Jds_val, k->Jds_val, k->Hxs, -1.0, M, ld, nxd + neq, nxd + neq));
+  RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cd, k->Jcs_val, k->Jds_val, k->Hxs, -1.0, M, ld, nxd, nxd + neq));
   k->built = true;
   return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_mds_build(hiopamd_kkt_mds* k, double delta_wx, double delta_wd, double delta_cc, double delta_cd)
+{
+  return kkt_mds_build_impl(k, MdsDelta{nullptr, delta_wx}, MdsDelta{nullptr, delta_wd}, MdsDelta{nullptr, delta_cc},
+                            MdsDelta{nullptr, delta_cd});
+}
+
+// the same with the regularisation as device VECTORS, the reference's actual form (delta_wx over the nxs + nxd primal variables
+// in the solver's order sparse-then-dense, delta_wd and delta_cd over the inequalities, delta_cc over the equalities); a null
+// pointer stands for a zero vector
+int hiopamd_kkt_mds_build_vec(hiopamd_kkt_mds* k, const double* delta_wx, const double* delta_wd, const double* delta_cc,
+                              const double* delta_cd)
+{
+  return kkt_mds_build_impl(k, MdsDelta{delta_wx, 0.0}, MdsDelta{delta_wd, 0.0}, MdsDelta{delta_cc, 0.0}, MdsDelta{delta_cd, 0.0});
 }
 
 int hiopamd_kkt_mds_factorize(hiopamd_kkt_mds* k, int* n_neg_host)

@@ -130,6 +130,14 @@ class KKTLinSysCompressedMDSXYcYd:
         check(self._L.hiopamd_kkt_mds_set_values(self.h, *[dptr(t) for t in self._vals]), "hiopamd_kkt_mds_set_values")
 
     def build_kkt_matrix(self, delta_wx=0.0, delta_wd=0.0, delta_cc=0.0, delta_cd=0.0):
+        """Scalars -> hiopamd_kkt_mds_build; device tensors (or None = zero vector) -> hiopamd_kkt_mds_build_vec."""
+        ds = (delta_wx, delta_wd, delta_cc, delta_cd)
+        if any(isinstance(d, torch.Tensor) or d is None for d in ds):
+            self._deltas = [d for d in ds]   # borrowed by the launch
+            ptrs = [dptr(d) if isinstance(d, torch.Tensor) else None for d in ds]
+            assert all(isinstance(d, torch.Tensor) or d is None for d in ds), "mix of scalars and vectors"
+            check(self._L.hiopamd_kkt_mds_build_vec(self.h, *ptrs), "hiopamd_kkt_mds_build_vec")
+            return
         check(self._L.hiopamd_kkt_mds_build(self.h, delta_wx, delta_wd, delta_cc, delta_cd), "hiopamd_kkt_mds_build")
 
     def factorize_with_curv_check(self) -> int:

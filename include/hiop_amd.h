@@ -411,6 +411,12 @@ int hiopamd_kkt_mds_set_values(hiopamd_kkt_mds* k, const double* Jcs_val, const 
 /* build_kkt_matrix (:172) with scalar inertia-correction perturbations, then factorizeWithCurvCheck (:78).
  * *n_neg_host = #negative eigenvalues of the full XYcYd system (dense part + sparse (1,1) block), or -1. */
 int hiopamd_kkt_mds_build(hiopamd_kkt_mds* k, double delta_wx, double delta_wd, double delta_cc, double delta_cd);
+/* the same with the perturbations as device VECTORS — the reference's actual form (hiopKKTLinSysMDS.cpp:178-181, added entry by
+ * entry at :213-215, :223-227, :245, :280, :289-290; hiopPDPerturbationPrimalFirstRand / DualFirstRand fill them with different
+ * values per entry, hiopPDPerturbation.hpp:296,358): delta_wx over the nxs + nxd primal variables (sparse first), delta_wd and
+ * delta_cd over the nineq inequalities, delta_cc over the neq equalities.  A null pointer stands for a zero vector. */
+int hiopamd_kkt_mds_build_vec(hiopamd_kkt_mds* k, const double* delta_wx, const double* delta_wd, const double* delta_cc,
+                              const double* delta_cd);
 int hiopamd_kkt_mds_factorize(hiopamd_kkt_mds* k, int* n_neg_host);
 /* solveCompressed (:307): all device vectors; rx (nxs+nxd), ryc (neq), ryd (nineq) are inputs (ryd is
  * overwritten like in the reference), dx, dyc, dyd outputs. */

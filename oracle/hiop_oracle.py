@@ -484,22 +484,25 @@ class KKTLinSysCompressedMDSXYcYd:
         trans_add_to_sym_upper(self.Jcd, 0, nxd, 1.0, M)                     # :205
         trans_add_to_sym_upper(self.Jdd, 0, nxd + neq, 1.0, M)               # :206
         add_sub_diagonal(M, 0, 1.0, self.Dx, nxs, nxd)                       # :213
+        # the perturbations are vectors in the reference (:178-181; delta_wx over [sparse; dense] x, delta_wd / delta_cd over the
+        # inequalities, delta_cc over the equalities); a scalar stands for the constant vector
+        dv = lambda d, lo, hi: d if np.isscalar(d) else np.asarray(d, dtype=float)[lo:hi]
         idx = np.arange(nxd)
-        M[idx, idx] += delta_wx                                              # :215
-        Hxs = self.Dx[:nxs] + delta_wx                                       # :223-227
+        M[idx, idx] += dv(delta_wx, nxs, nxs + nxd)                          # :215
+        Hxs = self.Dx[:nxs] + dv(delta_wx, 0, nxs)                           # :223-227
         spsym_add_diag_to_vec(self.Hss_ij[0], self.Hss_ij[1], self.Hss_val, 1.0, Hxs, 0)   # :231
         self.Hxs = Hxs
         ci, cj = self.Jcs_ij
         di, dj = self.Jds_ij
         sp_add_MDinvMtrans_diag_block(neq, nxs, ci, cj, self.Jcs_val, nxd, -1.0, Hxs, M)   # :239
         idx = np.arange(neq) + nxd
-        M[idx, idx] += -delta_cc                                             # :245
+        M[idx, idx] += -dv(delta_cc, 0, neq)                                 # :245
         sp_add_MDinvMtrans_diag_block(nineq, nxs, di, dj, self.Jds_val, nxd + neq, -1.0, Hxs, M)   # :267
         sp_add_MDinvNtrans(neq, nineq, nxs, ci, cj, self.Jcs_val, di, dj, self.Jds_val, nxd, nxd + neq, -1.0, Hxs, M)  # :275
-        self.Dd_inv = 1.0 / (delta_wd + self.Dd)                             # :280-286
+        self.Dd_inv = 1.0 / (dv(delta_wd, 0, nineq) + self.Dd)               # :280-286
         idx = np.arange(nineq) + nxd + neq
         M[idx, idx] += -self.Dd_inv                                          # :289
-        M[idx, idx] += -delta_cd                                             # :290
+        M[idx, idx] += -dv(delta_cd, 0, nineq)                               # :290
         return M
 
     def factorize_with_curv_check(self):                                     # :78-110
@@ -553,8 +556,13 @@ def kkt_mds_full_residual(k: KKTLinSysCompressedMDSXYcYd, deltas, rx, ryc, ryd, 
     spsym_add_diag_to_vec(k.Hss_ij[0], k.Hss_ij[1], k.Hss_val, 1.0, Hs_diag, 0)
     Hd = np.triu(k.Hdd) + np.triu(k.Hdd, 1).T
     dxs, dxd = dx[:nxs], dx[nxs:]
-    D1s = Hs_diag + k.Dx[:nxs] + dwx
-    D1d = k.Dx[nxs:] + dwx
+    if not np.isscalar(dwx):   # vector-valued perturbations (the reference's form): [sparse; dense] split
+        dwx = np.asarray(dwx, dtype=float)
+        dwx_s, dwx_d = dwx[:nxs], dwx[nxs:]
+    else:
+        dwx_s = dwx_d = dwx
+    D1s = Hs_diag + k.Dx[:nxs] + dwx_s
+    D1d = k.Dx[nxs:] + dwx_d
     D3 = 1.0 / (k.Dd + dwd) + dcd
     r1s = D1s * dxs + Jcs.T @ dyc + Jds.T @ dyd - rx[:nxs]
     r1d = Hd @ dxd + D1d * dxd + k.Jcd.T @ dyc + k.Jdd.T @ dyd - rx[nxs:]
@@ -563,7 +571,7 @@ def kkt_mds_full_residual(k: KKTLinSysCompressedMDSXYcYd, deltas, rx, ryc, ryd, 
     a = np.abs
     s1s = a(D1s) * a(dxs) + a(Jcs).T @ a(dyc) + a(Jds).T @ a(dyd) + a(rx[:nxs])
     s1d = a(Hd) @ a(dxd) + a(D1d) * a(dxd) + a(k.Jcd).T @ a(dyc) + a(k.Jdd).T @ a(dyd) + a(rx[nxs:])
-    s2 = a(Jcs) @ a(dxs) + a(k.Jcd) @ a(dxd) + abs(dcc) * a(dyc) + a(ryc)
+    s2 = a(Jcs) @ a(dxs) + a(k.Jcd) @ a(dxd) + np.abs(dcc) * a(dyc) + a(ryc)
     s3 = a(Jds) @ a(dxs) + a(k.Jdd) @ a(dxd) + a(D3) * a(dyd) + a(ryd)
 
     def be(r, sc):

@@ -225,6 +225,44 @@ def test_kkt_mds_assemble_factor_solve(ctx, mk, deltas):
     kg.close()
 
 
+@pytest.mark.parametrize("mk", PROBLEMS[1:])
+def test_kkt_mds_vector_regularisation(ctx, mk):
+    """hiopamd_kkt_mds_build_vec: the perturbations as VECTORS, entry by entry, like the reference adds them
+    (hiopKKTLinSysMDS.cpp:178-181,213-215,223-227,245,280,289-290 — what hiopPDPerturbationPrimalFirstRand / DualFirstRand
+    produce); a null pointer is a zero vector; constant vectors reproduce the scalar entry point bit for bit."""
+    p = mk()
+    ko, kg, dv = _kkt_pair(ctx, p)
+    r = rng(77)
+    dwx = r.uniform(0.5e-4, 1.5e-4, p.nxs + p.nxd)
+    dwd = r.uniform(0.5e-4, 1.5e-4, p.nineq)
+    dcc = r.uniform(0.5e-8, 1.5e-8, p.neq)
+    dcd = r.uniform(0.5e-8, 1.5e-8, p.nineq)
+    Mo = ko.build_kkt_matrix(dwx, dwd, dcc, dcd).copy()
+    kg.build_kkt_matrix(D(dwx), D(dwd), D(dcc), D(dcd))
+    Mg = kg.sys_matrix().cpu().numpy()
+    np.testing.assert_allclose(np.triu(Mg), np.triu(Mo), rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(kg.Hxs().cpu().numpy(), ko.Hxs, rtol=1e-15)
+    assert kg.factorize_with_curv_check() == ko.factorize_with_curv_check() == p.neq + p.nineq
+    rx, ryc, ryd = pr.random_rhs(p)
+    dx, dyc, dyd = D(np.zeros_like(rx)), D(np.zeros_like(ryc)), D(np.zeros_like(ryd))
+    rxd, rycd, rydd = D(rx), D(ryc), D(ryd)
+    torch.cuda.synchronize()
+    kg.solve_compressed(rxd, rycd, rydd, dx, dyc, dyd)
+    ctx.sync()
+    res = ho.kkt_mds_full_residual(ko, (dwx, dwd, dcc, dcd), rx, ryc, ryd, dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy())
+    assert max(res) < 1e-12, res
+    # constant vectors == scalars, bit for bit; null pointers == zeros
+    kg.build_kkt_matrix(1e-4, 1e-4, 1e-8, 1e-8)
+    Ms = kg.sys_matrix()
+    kg.build_kkt_matrix(D(np.full(p.nxs + p.nxd, 1e-4)), D(np.full(p.nineq, 1e-4)), D(np.full(p.neq, 1e-8)), D(np.full(p.nineq, 1e-8)))
+    assert torch.equal(torch.triu(kg.sys_matrix()), torch.triu(Ms))
+    kg.build_kkt_matrix(0.0, 0.0, 0.0, 0.0)
+    M0 = kg.sys_matrix()
+    kg.build_kkt_matrix(None, None, None, None)
+    assert torch.equal(torch.triu(kg.sys_matrix()), torch.triu(M0))
+    kg.close()
+
+
 def test_kkt_mds_inertia_correction_signal(ctx):
     """A negative entry in Hxs (non-convex sparse block) must show up in the inertia count through
     Haynsworth additivity (hiopKKTLinSysMDS.cpp:83-108); a zero entry must yield -1."""
