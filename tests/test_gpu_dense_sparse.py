@@ -111,10 +111,13 @@ def test_gram_weighted_mfma(ctx, ma, mb, n):
         np.testing.assert_array_equal(got, got.T)
 
 
-@pytest.mark.parametrize("k,l,n", [(200, 6, 9000), (130, 3, 4097), (256, 8, 5000), (100, 6, 3000)])
+@pytest.mark.parametrize("k,l,n", [(200, 6, 9000), (130, 3, 4097), (256, 8, 5000), (100, 6, 3000), (64, 6, 4096), (150, 6, 5001),
+                                   (176, 4, 8192), (16, 1, 2500), (112, 8, 6000), (40, 6, 2049), (208, 0, 4100)])
 def test_gram_stacked_symmetric_block_is_mirrored(ctx, k, l, n):
     """X D [X; S; Y]^T in one pass: the tiles below the diagonal inside the X x X block are not computed but mirrored by the
-    fold kernel (k > 128: two tile rows) — every entry, both triangles, against numpy."""
+    fold kernel (k > 128: two tile rows) — every entry, both triangles, against numpy.  The shapes walk through the variants of
+    the strip kernel (4 waves x 4 / 6 / 7 / 8 tiles with two workgroups per CU, 8 waves x 8 / 11 / 13 tiles, the first form for
+    14-16 tiles per wave, 16-byte and 8-byte staging for even / odd n) and the 128-tile kernel (more than 256 stacked rows)."""
     r = rng(k + l)
     X = r.uniform(-1, 1, (k, n)); S = r.uniform(-1, 1, (l, n)); Y = r.uniform(-1, 1, (l, n)); d = r.uniform(0.1, 2.0, n)
     kw = k + 2 * l
