@@ -173,16 +173,20 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
     steps_x = [U(gl, n, lo=-0.05, hi=0.05) for _ in range(4)]
     torch.cuda.synchronize()
 
+    xs = [x.clone(), x.clone()]           # the iterate alternates between two buffers (no allocation inside the step)
+    g = torch.empty_like(x)
+
     def step(i):
-        nonlocal x
-        x = x + steps_x[i % 4]
-        g = q * x
-        torch.cuda.synchronize()          # torch's stream -> context stream hand-off of x, g
-        H.update(x, g, Jc, Jd, yc, yd)
+        # the stand-in for the NLP side (new iterate, its gradient) runs on the CONTEXT's stream like everything else: no
+        # cross-stream hand-off, no host synchronisation besides the ones the reference's API implies (update() returns
+        # whether the pair was stored, solveCompressed() whether the reduced system was positive definite)
+        xn, xo = xs[(i + 1) & 1], xs[i & 1]
+        torch.add(xo, steps_x[i % 4], out=xn)
+        torch.mul(q, xn, out=g)
+        H.update(xn, g, Jc, Jd, yc, yd)
         K.update_diag(Dx, Dd, Jc, Jd)
         for _ in range(a.solves):
             rx.copy_(rx0)
-            torch.cuda.synchronize()
             if not K.solve_compressed(rx, ryc, ryd, dx, dyc, dyd):
                 raise RuntimeError("reduced system not SPD")
 
@@ -191,14 +195,15 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
         if world > 1:
             dist.barrier()
 
-    for i in range(8 + a.warmup):      # fill the secant memory, then warm up
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(ctx.torch_stream):
+        for i in range(8 + a.warmup):      # fill the secant memory, then warm up
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(8 + a.warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if _fake_multi() else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

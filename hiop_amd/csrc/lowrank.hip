@@ -139,6 +139,55 @@ __global__ void assemble_V_kernel(int l, const double* __restrict__ G, const dou
 }
 
 // three dots in one pass: out = [x.y, x.x, y.y]
+// Secant update, Jacobian part in ONE pass (reference: four GEMVs over Jc, Jc_prev, Jd, Jd_prev followed by two full copies
+// Jac_prev <- Jac, hiopHessianLowRank.cpp:293-299,366-371 — 8 x the Jacobian's bytes; here 3 x):
+//   y_new[j] += sum_r (J[r][j] - Jprev[r][j]) * mult[r]      and      Jprev[r][j] = J[r][j]
+// one thread per two adjacent columns, the multipliers staged in LDS per chunk of rows.
+constexpr int SJ_ROWCHUNK = 256;
+__global__ __launch_bounds__(kBlock) void secant_jac_kernel(int m, int64_t n, const double* __restrict__ J, double* __restrict__ Jp,
+                                                            const double* __restrict__ mult, double* __restrict__ y_new)
+{
+  __shared__ double ms[SJ_ROWCHUNK];
+  const int64_t j0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
+  const bool two = (j0 + 1 < n) && ((n & 1) == 0) && ((((uintptr_t)J) & 15) == 0) && ((((uintptr_t)Jp) & 15) == 0);
+  double a0 = 0.0, a1 = 0.0;
+  for(int rb = 0; rb < m; rb += SJ_ROWCHUNK) {
+    const int rc = (m - rb < SJ_ROWCHUNK) ? (m - rb) : SJ_ROWCHUNK;
+    __syncthreads();
+    if((int)threadIdx.x < rc) ms[threadIdx.x] = mult[rb + threadIdx.x];
+    __syncthreads();
+    if(j0 < n) {
+      const double* Jr = J + (int64_t)rb * n + j0;
+      double* Pr = Jp + (int64_t)rb * n + j0;
+      if(two) {
+#pragma unroll 4
+        for(int r = 0; r < rc; ++r) {
+          const double2 v = *reinterpret_cast<const double2*>(Jr + (int64_t)r * n);
+          const double2 q = *reinterpret_cast<const double2*>(Pr + (int64_t)r * n);
+          a0 = fma(v.x - q.x, ms[r], a0);
+          a1 = fma(v.y - q.y, ms[r], a1);
+          *reinterpret_cast<double2*>(Pr + (int64_t)r * n) = v;
+        }
+      } else {
+        for(int r = 0; r < rc; ++r) {
+          const double v0 = Jr[(int64_t)r * n], q0 = Pr[(int64_t)r * n];
+          a0 = fma(v0 - q0, ms[r], a0);
+          Pr[(int64_t)r * n] = v0;
+          if(j0 + 1 < n) {
+            const double v1 = Jr[(int64_t)r * n + 1], q1 = Pr[(int64_t)r * n + 1];
+            a1 = fma(v1 - q1, ms[r], a1);
+            Pr[(int64_t)r * n + 1] = v1;
+          }
+        }
+      }
+    }
+  }
+  if(j0 < n) {
+    y_new[j0] += a0;
+    if(j0 + 1 < n) y_new[j0 + 1] += a1;
+  }
+}
+
 struct dot3_t {
   double a, b, c;
 };
@@ -286,11 +335,18 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
   const int64_t n = h->n;
   const int me = h->m_eq, mi = h->m_ineq;
   if(stored_host) *stored_host = 0;
+  bool jac_saved = false;   // the fused secant pass below leaves Jc_prev / Jd_prev up to date
   auto save_prev = [&]() -> int {
-    RC(hiopamd_vec_copy(ctx, n, h->x_prev, x));
-    RC(hiopamd_vec_copy(ctx, n, h->g_prev, grad_f));
-    RC(hiopamd_vec_copy(ctx, (int64_t)me * n, h->Jc_prev, Jc));
-    RC(hiopamd_vec_copy(ctx, (int64_t)mi * n, h->Jd_prev, Jd));
+    double* xp_ = h->x_prev;
+    double* gp_ = h->g_prev;
+    RC(launch_ew(ctx, n, [=] __device__(int64_t i) {
+      xp_[i] = x[i];
+      gp_[i] = grad_f[i];
+    }));
+    if(!jac_saved) {
+      RC(hiopamd_vec_copy(ctx, (int64_t)me * n, h->Jc_prev, Jc));
+      RC(hiopamd_vec_copy(ctx, (int64_t)mi * n, h->Jd_prev, Jd));
+    }
     return HIOPAMD_OK;
   };
   if(h->l_curr < 0) {  // first iterate: just remember it (:381-389)
@@ -315,10 +371,14 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
   }
   if(s_inf >= 100 * std::numeric_limits<double>::epsilon()) {
     // y_new += (Jc - Jc_prev)^T yc + (Jd - Jd_prev)^T yd                      (:293-299)
-    RC(hiopamd_mat_trans_times_vec(ctx, me, n, Jc, n, 1.0, y_new, 1.0, yc));
-    RC(hiopamd_mat_trans_times_vec(ctx, me, n, h->Jc_prev, n, 1.0, y_new, -1.0, yc));
-    RC(hiopamd_mat_trans_times_vec(ctx, mi, n, Jd, n, 1.0, y_new, 1.0, yd));
-    RC(hiopamd_mat_trans_times_vec(ctx, mi, n, h->Jd_prev, n, 1.0, y_new, -1.0, yd));
+    // (one pass per Jacobian that also refreshes Jc_prev / Jd_prev: secant_jac_kernel)
+    {
+      const unsigned gx = (unsigned)((n + 2 * (int64_t)kBlock - 1) / (2 * (int64_t)kBlock));
+      if(me > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel, dim3(gx), dim3(kBlock), 0, ctx->stream, me, n, Jc, h->Jc_prev, yc, y_new);
+      if(mi > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel, dim3(gx), dim3(kBlock), 0, ctx->stream, mi, n, Jd, h->Jd_prev, yd, y_new);
+      HIOPAMD_CHECK(hipGetLastError());
+      jac_saved = true;
+    }
     // [s^T y, s^T s, y^T y] in one pass + one all-reduce                      (:301)
     dot3_t d3{0, 0, 0};
     RC(launch_reduce<dot3_t>(ctx, n, OpDot3{s_new, y_new}, &d3));

@@ -31,13 +31,13 @@ class LinSolverSymDense:
         """Copy an n x n row-major device matrix (upper triangle significant) into sysMatrix()."""
         assert M.shape == (self.n, self.n) and M.dtype == torch.float64 and M.is_cuda
         torch.cuda.synchronize()
-        check(self._L.hiopamd_copy_d2d(self.ctx.h, C.c_void_p(self.sys_matrix_ptr()), dptr(M.contiguous()),
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, C.c_void_p(self.sys_matrix_ptr()), dptr(M.contiguous(), self.ctx),
                                        self.n * self.n * 8), "copy_d2d")
 
     def get_sys_matrix(self) -> torch.Tensor:
         out = torch.empty((self.n, self.n), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
-        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(self.sys_matrix_ptr()), self.n * self.n * 8),
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out, self.ctx), C.c_void_p(self.sys_matrix_ptr()), self.n * self.n * 8),
               "copy_d2d")
         self.ctx.sync()
         return out
@@ -48,7 +48,7 @@ class LinSolverSymDense:
         return nneg.value
 
     def solve(self, rhs: torch.Tensor, nrhs: int = 1) -> bool:
-        rc = self._L.hiopamd_linsolver_solve(self.h, dptr(rhs), nrhs)
+        rc = self._L.hiopamd_linsolver_solve(self.h, dptr(rhs, self.ctx), nrhs)
         check(rc, "hiopamd_linsolver_solve")
         return True
 
@@ -127,14 +127,14 @@ class KKTLinSysCompressedMDSXYcYd:
         """All arguments are device fp64 tensors; they are borrowed (kept alive here) until the next call."""
         self._vals = [Jcs_val, Jds_val, Hss_val, Jcd, Jdd, Hdd, Dx, Dd]
         torch.cuda.synchronize()
-        check(self._L.hiopamd_kkt_mds_set_values(self.h, *[dptr(t) for t in self._vals]), "hiopamd_kkt_mds_set_values")
+        check(self._L.hiopamd_kkt_mds_set_values(self.h, *[dptr(t, self.ctx) for t in self._vals]), "hiopamd_kkt_mds_set_values")
 
     def build_kkt_matrix(self, delta_wx=0.0, delta_wd=0.0, delta_cc=0.0, delta_cd=0.0):
         """Scalars -> hiopamd_kkt_mds_build; device tensors (or None = zero vector) -> hiopamd_kkt_mds_build_vec."""
         ds = (delta_wx, delta_wd, delta_cc, delta_cd)
         if any(isinstance(d, torch.Tensor) or d is None for d in ds):
             self._deltas = [d for d in ds]   # borrowed by the launch
-            ptrs = [dptr(d) if isinstance(d, torch.Tensor) else None for d in ds]
+            ptrs = [dptr(d, self.ctx) if isinstance(d, torch.Tensor) else None for d in ds]
             assert all(isinstance(d, torch.Tensor) or d is None for d in ds), "mix of scalars and vectors"
             check(self._L.hiopamd_kkt_mds_build_vec(self.h, *ptrs), "hiopamd_kkt_mds_build_vec")
             return
@@ -146,15 +146,15 @@ class KKTLinSysCompressedMDSXYcYd:
         return nneg.value
 
     def solve_compressed(self, rx, ryc, ryd, dx, dyc, dyd):
-        check(self._L.hiopamd_kkt_mds_solve_compressed(self.h, dptr(rx), dptr(ryc), dptr(ryd), dptr(dx), dptr(dyc),
-                                                       dptr(dyd)), "hiopamd_kkt_mds_solve_compressed")
+        check(self._L.hiopamd_kkt_mds_solve_compressed(self.h, dptr(rx, self.ctx), dptr(ryc, self.ctx), dptr(ryd, self.ctx), dptr(dx, self.ctx), dptr(dyc, self.ctx),
+                                                       dptr(dyd, self.ctx)), "hiopamd_kkt_mds_solve_compressed")
 
     def sys_matrix(self) -> torch.Tensor:
         """Copy of the N x N system matrix (device tensor)."""
         ptr = self._L.hiopamd_kkt_mds_sys_matrix(self.h)
         out = torch.empty((self.N, self.N), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
-        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), self.N * self.N * 8), "copy_d2d")
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out, self.ctx), C.c_void_p(ptr), self.N * self.N * 8), "copy_d2d")
         self.ctx.sync()
         return out
 
@@ -162,7 +162,7 @@ class KKTLinSysCompressedMDSXYcYd:
         ptr = self._L.hiopamd_kkt_mds_Hxs(self.h)
         out = torch.empty(self.nxs, dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
-        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), self.nxs * 8), "copy_d2d")
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out, self.ctx), C.c_void_p(ptr), self.nxs * 8), "copy_d2d")
         self.ctx.sync()
         return out
 
@@ -206,26 +206,26 @@ class HessianLowRank:
 
     def update(self, x, grad_f, Jc, Jd, yc, yd) -> bool:
         stored = C.c_int(0)
-        check(self._L.hiopamd_hess_lowrank_update(self.h, dptr(x), dptr(grad_f), dptr(Jc), dptr(Jd), dptr(yc), dptr(yd),
+        check(self._L.hiopamd_hess_lowrank_update(self.h, dptr(x, self.ctx), dptr(grad_f, self.ctx), dptr(Jc, self.ctx), dptr(Jd, self.ctx), dptr(yc, self.ctx), dptr(yd, self.ctx),
                                                   C.byref(stored)), "hiopamd_hess_lowrank_update")
         return bool(stored.value)
 
     def update_log_barrier_diagonal(self, Dx):
-        check(self._L.hiopamd_hess_lowrank_update_log_barrier_diagonal(self.h, dptr(Dx)), "update_log_barrier_diagonal")
+        check(self._L.hiopamd_hess_lowrank_update_log_barrier_diagonal(self.h, dptr(Dx, self.ctx)), "update_log_barrier_diagonal")
 
     def solve(self, rhs, x):
-        check(self._L.hiopamd_hess_lowrank_solve(self.h, dptr(rhs), dptr(x)), "hiopamd_hess_lowrank_solve")
+        check(self._L.hiopamd_hess_lowrank_solve(self.h, dptr(rhs, self.ctx), dptr(x, self.ctx)), "hiopamd_hess_lowrank_solve")
 
     def sym_mat_times_inverse_times_mat_trans(self, beta, W, alpha, X):
         k = W.shape[0]
         work = torch.empty(k * (k + 2 * self.l_max) + 2 * k * self.l_max + 8, dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
-        check(self._L.hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(self.h, beta, dptr(W), k, alpha, dptr(X),
-                                                                                 dptr(work)), "symMatTimesInverseTimesMatTrans")
+        check(self._L.hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(self.h, beta, dptr(W, self.ctx), k, alpha, dptr(X, self.ctx),
+                                                                                 dptr(work, self.ctx)), "symMatTimesInverseTimesMatTrans")
         self.ctx.sync()
 
     def times_vec(self, beta, y, alpha, x, add_log_term=True):
-        check(self._L.hiopamd_hess_lowrank_times_vec(self.h, beta, dptr(y), alpha, dptr(x), 1 if add_log_term else 0),
+        check(self._L.hiopamd_hess_lowrank_times_vec(self.h, beta, dptr(y, self.ctx), alpha, dptr(x, self.ctx), 1 if add_log_term else 0),
               "hiopamd_hess_lowrank_times_vec")
 
     @property
@@ -241,7 +241,7 @@ class HessianLowRank:
         out = torch.empty((l, self.n), dtype=torch.float64, device="cuda")
         if l:
             torch.cuda.synchronize()
-            check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), l * self.n * 8), "copy_d2d")
+            check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out, self.ctx), C.c_void_p(ptr), l * self.n * 8), "copy_d2d")
             self.ctx.sync()
         return out
 
@@ -279,17 +279,17 @@ class KKTLinSysLowRank:
     def update(self, zl, sxl, ixl, zu, sxu, ixu, vl, sdl, idl, vu, sdu, idu, Jc, Jd):
         args = [zl, sxl, ixl, zu, sxu, ixu, vl, sdl, idl, vu, sdu, idu, Jc, Jd]
         self._jac = (Jc, Jd)      # the C object keeps these two pointers until the next update / set_jacobians
-        check(self._L.hiopamd_kkt_lowrank_update(self.h, *[dptr(a) for a in args]), "hiopamd_kkt_lowrank_update")
+        check(self._L.hiopamd_kkt_lowrank_update(self.h, *[dptr(a, self.ctx) for a in args]), "hiopamd_kkt_lowrank_update")
 
     def update_diag(self, Dx, Dd, Jc, Jd):
         self._jac = (Jc, Jd)
-        check(self._L.hiopamd_kkt_lowrank_update_diag(self.h, dptr(Dx), dptr(Dd), dptr(Jc), dptr(Jd)),
+        check(self._L.hiopamd_kkt_lowrank_update_diag(self.h, dptr(Dx, self.ctx), dptr(Dd, self.ctx), dptr(Jc, self.ctx), dptr(Jd, self.ctx)),
               "hiopamd_kkt_lowrank_update_diag")
 
     def solve_compressed(self, rx, ryc, ryd, dx, dyc, dyd) -> bool:
         ok = C.c_int(0)
-        check(self._L.hiopamd_kkt_lowrank_solve_compressed(self.h, dptr(rx), dptr(ryc), dptr(ryd), dptr(dx), dptr(dyc),
-                                                           dptr(dyd), C.byref(ok)), "hiopamd_kkt_lowrank_solve_compressed")
+        check(self._L.hiopamd_kkt_lowrank_solve_compressed(self.h, dptr(rx, self.ctx), dptr(ryc, self.ctx), dptr(ryd, self.ctx), dptr(dx, self.ctx), dptr(dyc, self.ctx),
+                                                           dptr(dyd, self.ctx), C.byref(ok)), "hiopamd_kkt_lowrank_solve_compressed")
         return bool(ok.value)
 
     def set_cache(self, enable: bool):
@@ -297,13 +297,13 @@ class KKTLinSysLowRank:
 
     def set_jacobians(self, Jc, Jd):
         self._jac = (Jc, Jd)
-        check(self._L.hiopamd_kkt_lowrank_set_jacobians(self.h, dptr(Jc), dptr(Jd)), "hiopamd_kkt_lowrank_set_jacobians")
+        check(self._L.hiopamd_kkt_lowrank_set_jacobians(self.h, dptr(Jc, self.ctx), dptr(Jd, self.ctx)), "hiopamd_kkt_lowrank_set_jacobians")
 
     def N(self) -> torch.Tensor:
         ptr = self._L.hiopamd_kkt_lowrank_N(self.h)
         out = torch.empty((self.k, self.k), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
-        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), self.k * self.k * 8), "copy_d2d")
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out, self.ctx), C.c_void_p(ptr), self.k * self.k * 8), "copy_d2d")
         self.ctx.sync()
         return out
 
@@ -335,7 +335,7 @@ class KKTLinSysXYcYd:
         self._pat = [ixl, ixu, idl, idu]          # borrowed by the C object: keep alive
         torch.cuda.synchronize()
         h = C.c_void_p()
-        p = [dptr(t) for t in self._pat]
+        p = [dptr(t, self.ctx) for t in self._pat]
         if isinstance(backend, KKTLinSysCompressedMDSXYcYd):
             check(self._L.hiopamd_kkt_xycyd_create_mds(C.byref(h), ctx.h, backend.h, *p), "hiopamd_kkt_xycyd_create_mds")
         elif isinstance(backend, KKTLinSysLowRank):
@@ -364,7 +364,7 @@ class KKTLinSysXYcYd:
     def set_matrices(self, H, Jc, Jd):
         self._keep = [H, Jc, Jd]
         torch.cuda.synchronize()
-        check(self._L.hiopamd_kkt_xycyd_set_matrices(self.h, dptr(H), dptr(Jc), dptr(Jd)), "set_matrices")
+        check(self._L.hiopamd_kkt_xycyd_set_matrices(self.h, dptr(H, self.ctx), dptr(Jc, self.ctx), dptr(Jd, self.ctx)), "set_matrices")
 
     def set_mu(self, mu: float):
         check(self._L.hiopamd_kkt_xycyd_set_mu(self.h, mu), "set_mu")
@@ -376,7 +376,7 @@ class KKTLinSysXYcYd:
     def update(self, it: torch.Tensor) -> bool:
         self._iter = it
         ok = C.c_int(0)
-        check(self._L.hiopamd_kkt_xycyd_update(self.h, dptr(it), C.byref(ok)), "hiopamd_kkt_xycyd_update")
+        check(self._L.hiopamd_kkt_xycyd_update(self.h, dptr(it, self.ctx), C.byref(ok)), "hiopamd_kkt_xycyd_update")
         return bool(ok.value)
 
     def factorize(self) -> bool:
@@ -395,7 +395,7 @@ class KKTLinSysXYcYd:
     def test_direction(self, dir_: torch.Tensor, neg_curv_test_fact: float = 1e-11):
         acc = C.c_int(0)
         dWd, nrm = C.c_double(0), C.c_double(0)
-        check(self._L.hiopamd_kkt_xycyd_test_direction(self.h, dptr(dir_), neg_curv_test_fact, C.byref(acc),
+        check(self._L.hiopamd_kkt_xycyd_test_direction(self.h, dptr(dir_, self.ctx), neg_curv_test_fact, C.byref(acc),
                                                        C.byref(dWd), C.byref(nrm)), "hiopamd_kkt_xycyd_test_direction")
         return bool(acc.value), dWd.value, nrm.value
 
@@ -410,17 +410,17 @@ class KKTLinSysXYcYd:
 
     def compute_directions(self, resid: torch.Tensor, dir_: torch.Tensor) -> bool:
         ok = C.c_int(0)
-        check(self._L.hiopamd_kkt_xycyd_compute_directions(self.h, dptr(resid), dptr(dir_), C.byref(ok)),
+        check(self._L.hiopamd_kkt_xycyd_compute_directions(self.h, dptr(resid, self.ctx), dptr(dir_, self.ctx), C.byref(ok)),
               "hiopamd_kkt_xycyd_compute_directions")
         return bool(ok.value)
 
     def times_vec(self, y: torch.Tensor, x: torch.Tensor):
-        check(self._L.hiopamd_kkt_xycyd_times_vec(self.h, dptr(y), dptr(x)), "hiopamd_kkt_xycyd_times_vec")
+        check(self._L.hiopamd_kkt_xycyd_times_vec(self.h, dptr(y, self.ctx), dptr(x, self.ctx)), "hiopamd_kkt_xycyd_times_vec")
 
     def compute_directions_w_IR(self, resid, dir_, ir_outer_tol_factor=1e-2, ir_outer_tol_min=1e-6, ir_outer_maxit=8):
         ok, conv = C.c_int(0), C.c_int(0)
         info = (C.c_double * 4)()
-        check(self._L.hiopamd_kkt_xycyd_compute_directions_w_IR(self.h, dptr(resid), dptr(dir_), ir_outer_tol_factor,
+        check(self._L.hiopamd_kkt_xycyd_compute_directions_w_IR(self.h, dptr(resid, self.ctx), dptr(dir_, self.ctx), ir_outer_tol_factor,
                                                                 ir_outer_tol_min, ir_outer_maxit, C.byref(ok),
                                                                 C.byref(conv), info),
               "hiopamd_kkt_xycyd_compute_directions_w_IR")
@@ -432,7 +432,7 @@ class KKTLinSysXYcYd:
         ptr = self._L.hiopamd_linsolver_sys_matrix(C.c_void_p(ls))
         out = torch.empty((n, n), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
-        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out), C.c_void_p(ptr), n * n * 8), "copy_d2d")
+        check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(out, self.ctx), C.c_void_p(ptr), n * n * 8), "copy_d2d")
         self.ctx.sync()
         return out
 
@@ -454,54 +454,54 @@ class IpmSlabOps:
     hiopamd_iterate_*): mirrors src/Optimization/hiopResidual.cpp:154 and hiopIterate.cpp:274-566."""
 
     def __init__(self, full: KKTLinSysXYcYd, xl, xu, dl, du, crhs):
-        self.full, self._L = full, lib()
+        self.full, self._L, self.ctx = full, lib(), full.ctx
         self._b = [xl, xu, dl, du, crhs]
         torch.cuda.synchronize()
-        check(self._L.hiopamd_kkt_xycyd_set_bounds(full.h, *[dptr(t) for t in self._b]), "set_bounds")
+        check(self._L.hiopamd_kkt_xycyd_set_bounds(full.h, *[dptr(t, self.ctx) for t in self._b]), "set_bounds")
 
     def residual_update(self, it, c, d, grad_f, mu, kappa_d, resid):
         n = (C.c_double * 11)()
-        check(self._L.hiopamd_residual_update(self.full.h, dptr(it), dptr(c), dptr(d), dptr(grad_f), mu, kappa_d,
-                                              dptr(resid), n), "hiopamd_residual_update")
+        check(self._L.hiopamd_residual_update(self.full.h, dptr(it, self.ctx), dptr(c, self.ctx), dptr(d, self.ctx), dptr(grad_f, self.ctx), mu, kappa_d,
+                                              dptr(resid, self.ctx), n), "hiopamd_residual_update")
         return list(n)
 
     def fraction_to_the_bdry(self, it, dir_, tau):
         ap, ad = C.c_double(0), C.c_double(0)
-        check(self._L.hiopamd_iterate_fraction_to_the_bdry(self.full.h, dptr(it), dptr(dir_), tau, C.byref(ap), C.byref(ad)),
+        check(self._L.hiopamd_iterate_fraction_to_the_bdry(self.full.h, dptr(it, self.ctx), dptr(dir_, self.ctx), tau, C.byref(ap), C.byref(ad)),
               "fraction_to_the_bdry")
         return ap.value, ad.value
 
     def take_step(self, out, it, dir_, alpha_primal, alpha_dual, primals=True, duals=True):
-        check(self._L.hiopamd_iterate_take_step(self.full.h, dptr(out), dptr(it), dptr(dir_), alpha_primal, alpha_dual,
+        check(self._L.hiopamd_iterate_take_step(self.full.h, dptr(out, self.ctx), dptr(it, self.ctx), dptr(dir_, self.ctx), alpha_primal, alpha_dual,
                                                 int(primals), int(duals)), "take_step")
 
     def determine_slacks(self, it):
-        check(self._L.hiopamd_iterate_determine_slacks(self.full.h, dptr(it)), "determine_slacks")
+        check(self._L.hiopamd_iterate_determine_slacks(self.full.h, dptr(it, self.ctx)), "determine_slacks")
 
     def adjust_small_slacks(self, it, it_curr, mu) -> int:
         n = C.c_int(0)
-        check(self._L.hiopamd_iterate_adjust_small_slacks(self.full.h, dptr(it), dptr(it_curr), mu, C.byref(n)),
+        check(self._L.hiopamd_iterate_adjust_small_slacks(self.full.h, dptr(it, self.ctx), dptr(it_curr, self.ctx), mu, C.byref(n)),
               "adjust_small_slacks")
         return n.value
 
     def determine_duals_bounds_d(self, it, mu):
-        check(self._L.hiopamd_iterate_determine_duals_bounds_d(self.full.h, dptr(it), mu), "determine_duals_bounds_d")
+        check(self._L.hiopamd_iterate_determine_duals_bounds_d(self.full.h, dptr(it, self.ctx), mu), "determine_duals_bounds_d")
 
     def adjust_duals_plh(self, it, mu, kappa_sigma):
-        check(self._L.hiopamd_iterate_adjust_duals_plh(self.full.h, dptr(it), mu, kappa_sigma), "adjust_duals_plh")
+        check(self._L.hiopamd_iterate_adjust_duals_plh(self.full.h, dptr(it, self.ctx), mu, kappa_sigma), "adjust_duals_plh")
 
     def eval_log_barrier(self, it) -> float:
         v = C.c_double(0)
-        check(self._L.hiopamd_iterate_eval_log_barrier(self.full.h, dptr(it), C.byref(v)), "eval_log_barrier")
+        check(self._L.hiopamd_iterate_eval_log_barrier(self.full.h, dptr(it, self.ctx), C.byref(v)), "eval_log_barrier")
         return v.value
 
     def duals_lsq_update(self, it, grad_f) -> bool:
         ok = C.c_int(0)
-        check(self._L.hiopamd_duals_lsq_update(self.full.h, dptr(it), dptr(grad_f), C.byref(ok)), "hiopamd_duals_lsq_update")
+        check(self._L.hiopamd_duals_lsq_update(self.full.h, dptr(it, self.ctx), dptr(grad_f, self.ctx), C.byref(ok)), "hiopamd_duals_lsq_update")
         return bool(ok.value)
 
     def linear_damping_term(self, it, mu, kappa_d) -> float:
         v = C.c_double(0)
-        check(self._L.hiopamd_iterate_linear_damping_term(self.full.h, dptr(it), mu, kappa_d, C.byref(v)),
+        check(self._L.hiopamd_iterate_linear_damping_term(self.full.h, dptr(it, self.ctx), mu, kappa_d, C.byref(v)),
               "linear_damping_term")
         return v.value

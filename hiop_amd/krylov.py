@@ -61,7 +61,7 @@ class KrylovSolver:
 
     def solve(self, b: torch.Tensor) -> bool:
         ok = C.c_int(0)
-        check(self._L.hiopamd_krylov_solve(self.h, dptr(b), C.byref(ok)), "hiopamd_krylov_solve")
+        check(self._L.hiopamd_krylov_solve(self.h, dptr(b, self.ctx), C.byref(ok)), "hiopamd_krylov_solve")
         return bool(ok.value)
 
     def get_convergence_flag(self) -> int:

@@ -13,26 +13,43 @@ import torch
 from ._lib import lib, check
 
 
-_LIVE_CONTEXTS = {}    # id(Context) -> Context, every live context (weak: removed by Context.close)
+import weakref
+
+_LIVE_CONTEXTS = weakref.WeakValueDictionary()   # id(Context) -> Context: a context nobody refers to any more is collected
+_KEEP = []             # [tensor, {ids of the contexts whose stream may still use it}]
 _KEEP_MAX = 8192
 
 
-def dptr(t) -> C.c_void_p:
+def _release_for(ctx_id):
+    """`ctx_id` has synchronised (or is gone): drop it from every entry; entries nobody waits for are freed."""
+    keep = []
+    for e in _KEEP:
+        e[1].discard(ctx_id)
+        if e[1]:
+            keep.append(e)
+    _KEEP[:] = keep
+
+
+def dptr(t, ctx=None) -> C.c_void_p:
     """Raw device (or host) address of a torch tensor / numpy array / None.
 
     The C ABI is asynchronous on the context's own stream, which torch's caching allocator knows nothing about: a device
     temporary released right after the call would be recycled for the next allocation while the call's kernels are still
-    queued.  Every device tensor whose address crosses the ABI is therefore kept alive by the live contexts until their
-    next synchronisation (`Context.sync`); the list is bounded (a synchronisation is forced when it overflows)."""
+    queued.  Every device tensor whose address crosses the ABI is therefore kept alive until the context that uses it
+    (`ctx`; every live context when the caller does not say) has synchronised (`Context.sync`).  The list is bounded: when it
+    overflows, the contexts that entries still wait for are synchronised — an idle or forgotten context cannot pin memory."""
     if t is None:
         return C.c_void_p(0)
     if isinstance(t, torch.Tensor):
         assert t.is_contiguous()
         if t.is_cuda:
-            for c in _LIVE_CONTEXTS.values():
-                c._keep.append(t)
-                if len(c._keep) > _KEEP_MAX:
+            ids = {id(ctx)} if ctx is not None else set(_LIVE_CONTEXTS.keys())
+            if ids:
+                _KEEP.append([t, ids])
+            if len(_KEEP) > _KEEP_MAX:
+                for c in list(_LIVE_CONTEXTS.values()):
                     c.sync()
+                _KEEP.clear()
         return C.c_void_p(t.data_ptr())
     if isinstance(t, np.ndarray):
         assert t.flags["C_CONTIGUOUS"]
@@ -62,16 +79,14 @@ class Context:
         self.stream_ptr = self._L.hiopamd_ctx_stream(self.h)
         self.torch_stream = torch.cuda.ExternalStream(self.stream_ptr)
         self._children = []   # weakrefs of objects holding C handles that reference this context
-        self._keep = []       # device tensors handed to asynchronous calls since the last synchronisation
         _LIVE_CONTEXTS[id(self)] = self
 
     def _register(self, obj):
-        import weakref
         self._children.append(weakref.ref(obj))
 
     def sync(self):
         check(self._L.hiopamd_ctx_sync(self.h), "hiopamd_ctx_sync")
-        self._keep.clear()
+        _release_for(id(self))
 
     def close(self):
         if self.h is not None:
@@ -83,7 +98,7 @@ class Context:
             self._children = []
             _LIVE_CONTEXTS.pop(id(self), None)
             self._L.hiopamd_ctx_sync(self.h)
-            self._keep.clear()
+            _release_for(id(self))
             self._L.hiopamd_ctx_destroy(self.h)
             self.h = None
 
@@ -99,7 +114,7 @@ class Context:
         conv = []
         for a in args:
             if isinstance(a, (torch.Tensor, np.ndarray)) or a is None:
-                conv.append(dptr(a))
+                conv.append(dptr(a, self))
             else:
                 conv.append(a)
         check(fn(self.h, *conv), name)
