@@ -59,7 +59,7 @@ def _hipcc() -> str:
 
 
 def _deps() -> list[Path]:
-    hdrs = list(CSRC.glob("*.hpp")) + list((ROOT.parent / "include").glob("*.h"))
+    hdrs = list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + list((ROOT.parent / "include").glob("*.h"))
     return hdrs
 
 

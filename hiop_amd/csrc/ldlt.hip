@@ -2284,6 +2284,21 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.off_ts = P.off_ver + (int64_t)P.nt * P.nt;
     a.off_ph = a.off_ts + 8 * (int64_t)(P.nsp + 1);
     a.off_trb = P.off_trb;
+    // HIOPAMD_DF_ONE=1 (measurement aid): chain + wide as ONE dispatch on the wide stream, one workgroup per CU — the form the
+    // rocprofv3 counter passes can profile (see ldlt_df_one_kernel); needs the 16-byte tile form
+    static const bool df_one = std::getenv("HIOPAMD_DF_ONE") && std::atoi(std::getenv("HIOPAMD_DF_ONE")) != 0;
+    const bool one = df_one && (N % 2 == 0) && N >= 2 * UD_T && a.nwtasks > 0;
+    if(one) {
+      a.dbg = 0;
+      // on the context's own stream (no CU mask): DF_ROLES + 240 workgroups of one per CU are all resident on 256 CUs
+      if(timed) (void)hipEventRecord(prof->get(), st);
+      hipLaunchKernelGGL(ldlt_df_one_kernel, dim3(DF_ROLES + 240), dim3(kBlock), 0, st, a);
+      if(timed) {
+        (void)hipEventRecord(prof->get(), st);
+        prof->flops += P.up_flops;
+        prof->launches += 1;
+      }
+    } else {
     hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
     if(a.nwtasks > 0) {
       if(timed) (void)hipEventRecord(prof->get(), su);
@@ -2300,6 +2315,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
         prof->flops += P.up_flops;
         prof->launches += 1;
       }
+    }
     }
     rc = dep(su, st);
     if(rc == HIOPAMD_OK) rc = dep(sd, st);

@@ -807,95 +807,20 @@ __device__ __forceinline__ bool df_column_step(const DfArgs& a, int j, int p, in
   return true;
 }
 
+// LDS of a chain workgroup / of a wide workgroup as structs, so that the two bodies can also run as ONE dispatch
+// (ldlt_df_one_kernel: the counter passes of rocprofv3 serialise dispatches, and the chain / wide pair wait for each other)
+struct DfChainShared {
+  DfChainLds L;
+  int4 tasks[2][DF_MAXT];   // this role's task lists (with / without a next super-panel): no L2 round trip per task
+  int ok;
+};
 __global__ __launch_bounds__(kBlock, 1) void ldlt_chain_kernel(const DfArgs a)
 {
   __shared__ DfChainLds L;
   __shared__ int4 sh_tasks[2][DF_MAXT];   // this role's task lists (with / without a next super-panel): no L2 round trip per task
   __shared__ int sh_ok;
-  double(*S)[LD_nb + 1] = L.S;
-  double* sdinv = L.sdinv;
-  const int tid = threadIdx.x, role = blockIdx.x;
-  const long long t_start = (long long)wall_clock64();
-  if(tid < 2 * DF_MAXT) sh_tasks[tid / DF_MAXT][tid % DF_MAXT] = a.ctasks[((tid / DF_MAXT) * DF_ROLES + role) * DF_MAXT + tid % DF_MAXT];
-  __syncthreads();
-  bool carried = false;   // role 0: the tile to factor next is in L.S
-  unsigned* pending = nullptr;   // role 0: version counter of the tile updated by the last spine step, not yet published
-  DfPendT pt;                    // role 0: the last spine step's tile solve, stored but not yet published
-  for(int j = 0; j < a.nchain; ++j) {
-    const bool has_next = (j + 1 < a.nchain) || a.last_has_next;
-    const int4* tasks = sh_tasks[has_next ? 0 : 1];
-    unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
-    for(int it = 0; it < DF_MAXT; ++it) {
-      int4 tk = tasks[it];
-      tk.x = __builtin_amdgcn_readfirstlane(tk.x);
-      tk.y = __builtin_amdgcn_readfirstlane(tk.y);
-      tk.z = __builtin_amdgcn_readfirstlane(tk.z);
-      tk.w = __builtin_amdgcn_readfirstlane(tk.w);
-      if(tk.x == DF_END) break;
-      const int p = tk.y, ta = tk.z, tb = tk.w;
-      DfWait w(a.flags + DF_ABORT);
-      unsigned base;
-      if(tk.x == DF_S) {
-        if(!df_spine_step(a, j, p, ta != 0, carried, L, &sh_ok, t_start, tid, pending, pt)) return;
-        carried = ta != 0;   // with the T / U part the updated tile (p+1, p+1) — (0, 0) of the next super-panel for p = 3 — is in L.S
-      } else if(tk.x == DF_R) {
-        if(!df_companion_step(a, j, p, ta == 0, &sh_ok, t_start, tid)) return;
-      } else if(tk.x == DF_C) {
-        if(!df_column_step(a, j, p, ta, tb, role, &sh_ok, t_start, tid)) return;
-      } else if(tk.x == DF_F) {
-        unsigned* v = df_ver(a, j, p, p, &base);
-        w.set<0>(v, base + p);
-        if(!df_wait(a.flags, w, &sh_ok, t_start, 100 + role, j, tk.x, p, p)) return;
-        if(tid == 0 && p == 0) df_stamp(a, j, 0);
-        df_task_factor(a, j, p, S, sdinv, tid);
-        df_drain();
-        if(tid == 0 && p == 3) df_stamp(a, j, 1);
-        if(tid == 0) {
-          df_add(v, 1u);
-          df_add(cf + DF_CDONE, 1u);
-        }
-      } else if(tk.x == DF_T) {
-        const int c = tb;
-        unsigned bpp;
-        unsigned* v = df_ver(a, j, p, c, &base);
-        unsigned* vpp = df_ver(a, j, p, p, &bpp);
-        w.set<0>(vpp, bpp + p + 1);
-        w.set<1>(v, base + p);
-        if(c >= 4 && p == 0) w.set<2>(df_wide_ver(a, j, p, c), (unsigned)j);   // the wide kernel's updates of panels < j
-        // the V workspace of this parity was read by the update of super-panel j-2
-        if(j >= DF_NVB) w.set<3>(a.flags + a.off_chain + (int64_t)(j - DF_NVB) * DF_CH + DF_UPDONE, a.upcnt[j - DF_NVB]);
-        if(!df_wait(a.flags, w, &sh_ok, t_start, 100 + role, j, tk.x, p, c)) return;
-        df_task_solve(a, j, p, c, tid);
-        df_drain();
-        if(tid == 0 && c >= 4) df_stamp(a, j, 3);
-        if(tid == 0) {
-          df_add(v, 1u);
-          df_add(cf + (c < 4 ? DF_CDONE : DF_HDONE), 1u);
-        }
-      } else {
-        unsigned ba, bb;
-        unsigned* v = df_ver(a, j, ta, tb, &base);
-        unsigned* va = df_ver(a, j, p, ta, &ba);
-        unsigned* vb = df_ver(a, j, p, tb, &bb);
-        w.set<0>(va, ba + p + 1);
-        w.set<1>(vb, bb + p + 1);
-        w.set<2>(v, base + p);
-        const bool wide_tile = tb >= 4;   // H tiles and next-diagonal-block tiles also receive the wide kernel's updates
-        if(wide_tile && p == 0) w.set<3>(df_wide_ver(a, j, ta, tb), (unsigned)j);
-        if(!df_wait(a.flags, w, &sh_ok, t_start, 100 + role, j, 1000 * p + tk.x, ta, tb)) return;
-        const DfTile dst = df_tile(a, j, ta, tb);
-        const DfTile src = (ta >= 4 && p == 0) ? df_tile_in_matrix(a, j, ta, tb) : dst;
-        df_task_update(a, j, p, ta, tb, src, dst, tid);
-        df_drain();
-        if(tid == 0) {
-          df_add(v, 1u);
-          if(tb == 4 && ta < 4) df_col4_stamp(a, j, ta, p);
-        }
-      }
-      __syncthreads();   // REQUIRED, see ldlt_wide_kernel: separates this task's lane-0 signalling from the next task's lane-0 polling
-    }
-  }
-  df_flush_pend(a, pt, tid);   // (a last spine step with a tile solve: the ragged hand-over)
+  const int role = blockIdx.x;
+#include "ldlt_chain_body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1328,235 +1253,46 @@ constexpr int DF_TRQ = 40, DF_UPQ = 41;   // per super-panel: TR / UP tasks of i
 // number of resident workgroups (tests/test_ldlt_dataflow_plan.py replays this policy).
 // TILE_FORM 1: 8-byte accesses, any N;  2: df_task_tile2 (even N, lda, ldv).  PROF: with the phase accounting of
 // HIOPAMD_DF_STAMPS (its counters cost registers: a separate instantiation, launched only when asked for)
+struct DfWideShared {
+  double smem[4 * UD_KT * UD_LD] __attribute__((aligned(16)));   // 73,728 B: the update's two double-buffered operand tile pairs / the substitution's V
+  int4 task;
+  int kind, ok;
+};
 template <int TILE_FORM, bool PROF>
 __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(const DfArgs a)
 {
-  const int dbg = PROF ? a.dbg : 0;
   __shared__ __attribute__((aligned(16))) double smem[4 * UD_KT * UD_LD];   // 73,728 B: the update's two double-buffered operand tile pairs / the substitution's V
   __shared__ int sh_kind, sh_ok;
-  const int tid = threadIdx.x;
-  const long long t_start = (long long)wall_clock64();
-  unsigned ph[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // phase accounting (a.dbg != 0): see the host print-out
-  unsigned tph = (unsigned)t_start;
-  bool acct = false;   // a.dbg == 1: every task; a.dbg >= 2: only the tasks of super-panel a.dbg - 2
-  auto lap = [&](int k) {
-    if(dbg) {
-      const unsigned now = (unsigned)wall_clock64();
-      if(acct) ph[k] += now - tph;
-      tph = now;
-    }
-  };
-  // task selection state (lane 0 only): first super-panel whose TR / UP queue this workgroup has not seen exhausted, and the
-  // cached descriptors of those two super-panels ({first TR task, TR tasks, first UP task, UP tasks}, thresholds)
-  int jtr = 0, jup = 0, jtr_c = -1, jup_c = -1;
-  int4 qt = make_int4(0, 0, 0, 0), qu = make_int4(0, 0, 0, 0);
-  unsigned first_prev = 0u, upcnt_prev2 = 0u, prev_all = 0u;
   __shared__ int4 sh_task;
-  for(;;) {
-    if(tid == 0) {
-      int kind = -1;   // 0: every queue exhausted, 1: TR, 2: UP, -2: aborted / timed out
-      int4 task = make_int4(0, 0, 0, 0);
-      unsigned spins = 0;
-      for(;;) {
-        if(jtr >= a.nwide && jup >= a.nwide) {
-          kind = 0;
-          break;
-        }
-        if(jtr != jtr_c && jtr < a.nwide) {
-          qt = a.wq[jtr];
-          first_prev = jtr >= 1 ? a.wfirst[jtr - 1] : 0u;
-          prev_all = jtr >= 1 ? (unsigned)a.wq[jtr - 1].w : 0u;
-          upcnt_prev2 = jtr >= DF_NVB ? a.upcnt[jtr - DF_NVB] : 0u;
-          jtr_c = jtr;
-        }
-        if(jup != jup_c && jup < a.nwide) {
-          qu = a.wq[jup];
-          jup_c = jup;
-        }
-        // every flag of both queue heads in flight at once: one round trip, then the decision
-        const int jt = jtr < a.nwide ? jtr : a.nwide - 1, ju = jup < a.nwide ? jup : a.nwide - 1;
-        unsigned* qtr = a.flags + a.off_chain + (int64_t)jt * DF_CH;
-        unsigned* qup = a.flags + a.off_chain + (int64_t)ju * DF_CH;
-        const unsigned tr_taken = df_ld(qtr + DF_TRQ), cd = df_ld(qtr + DF_CDONE);
-        const unsigned upprev = df_ld(qtr - (jt >= 1 ? DF_CH : 0) + DF_UPQ);
-        const unsigned updone2 = df_ld(qtr - (jt >= DF_NVB ? DF_NVB * DF_CH : 0) + DF_UPDONE);
-        const unsigned up_taken = df_ld(qup + DF_UPQ), up_trtaken = df_ld(qup + DF_TRQ);
-        if(jtr < a.nwide) {
-          if(tr_taken >= (unsigned)qt.y) {
-            ++jtr;
-            continue;
-          }
-          if(cd >= 10u && (jtr < 1 || upprev >= first_prev) && (jtr < DF_NVB || updone2 >= upcnt_prev2)) {
-            const unsigned i = __hip_atomic_fetch_add(qtr + DF_TRQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if(i < (unsigned)qt.y) {
-              kind = 1;
-              task = make_int4(DF_TR, jtr, LD_NB * (jtr + 2) + DF_TRW * (int)i, qt.x + (int)i);   // (no table look-up needed)
-              break;
-            }
-            ++jtr;
-            continue;
-          }
-        }
-        if(jup < a.nwide) {
-          if(up_taken >= (unsigned)qu.w) {
-            ++jup;
-            continue;
-          }
-          if(up_trtaken >= (unsigned)qu.y) {
-            const unsigned i = __hip_atomic_fetch_add(qup + DF_UPQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if(i < (unsigned)qu.w) {
-              kind = 2;
-              task = a.wtasks[qu.z + (int)i];
-              break;
-            }
-            ++jup;
-            continue;
-          }
-        }
-        // Nothing to do right now.  Rather than idle, take a substitution task of the row panel whose diagonal block the
-        // chain kernel is STILL factoring (its first tile is done): the task follows the chain block row by block row and
-        // finishes one block row after it, instead of starting ~45 us of latency-bound work when C_j is complete — in the
-        // super-panels where the chain is the bottleneck that latency was on the critical path (chain -> TR -> first update
-        // tiles -> chain).  Only when every update task of the previous super-panel is taken, so that whatever the chain
-        // still waits for is already running.
-        if(jtr < a.nwide && tr_taken < (unsigned)qt.y && cd >= 1u && cd < 10u && (jtr < 1 || upprev >= prev_all) &&
-           (jtr < DF_NVB || updone2 >= upcnt_prev2)) {
-          const unsigned i = __hip_atomic_fetch_add(qtr + DF_TRQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if(i < (unsigned)qt.y) {
-            kind = 1;
-            task = make_int4(DF_TR, jtr, LD_NB * (jtr + 2) + DF_TRW * (int)i, -1);   // w = -1: early
-            break;
-          }
-          ++jtr;
-          continue;
-        }
-        __builtin_amdgcn_s_sleep(32);
-        if((++spins & 15u) == 0) {
-          const bool late = (long long)wall_clock64() - t_start > DF_TIMEOUT_TICKS;
-          if(late || df_ld(a.flags + DF_ABORT) != 0) {
-            if(late && atomicCAS(a.flags + DF_ABORT, 0u, 1u) == 0u) {
-              df_st(a.flags + 2, 3u);   // waiter 3 = a workgroup of the wide kernel looking for an eligible task
-              df_st(a.flags + 3, (unsigned)jtr);
-              df_st(a.flags + 4, (unsigned)jup);
-              df_st(a.flags + 5, tr_taken);
-              df_st(a.flags + 6, up_taken);
-              df_st(a.flags + 7, 0u);
-              df_st(a.flags + 8, 10u);
-              df_st(a.flags + 9, cd);
-              df_st(a.flags + 10, (unsigned)(qtr + DF_CDONE - a.flags));
-            }
-            kind = -2;
-            break;
-          }
-        }
-      }
-      sh_kind = kind;
-      sh_task = task;
-    }
-    __syncthreads();
-    const int kind = __builtin_amdgcn_readfirstlane(sh_kind);
-    int4 tk = sh_task;
-    __syncthreads();
-    if(kind <= 0) {
-      if(dbg && tid == 0) {
-#pragma unroll
-        for(int q = 0; q < 12; ++q) atomicAdd(a.flags + a.off_ph + q, ph[q]);
-      }
-      return;
-    }
-    // the task bodies derive dozens of per-lane offsets from the thread index; hoisted out of this persistent loop they
-    // would stay live across every body (scratch spills at 256 VGPRs): make the index opaque per iteration instead
-    int tidv = tid;
-    asm volatile("" : "+v"(tidv));
-    tk.x = __builtin_amdgcn_readfirstlane(tk.x);
-    tk.y = __builtin_amdgcn_readfirstlane(tk.y);
-    tk.z = __builtin_amdgcn_readfirstlane(tk.z);
-    tk.w = __builtin_amdgcn_readfirstlane(tk.w);
-    const int j = tk.y;
-    acct = dbg == 1 || j == dbg - 2;
-    unsigned* cf = a.flags + a.off_chain + (int64_t)j * DF_CH;
-    unsigned* trj = a.flags + a.off_tr + (int64_t)j * a.nt;
-    DfWait w(a.flags + DF_ABORT);   // (the abort word is 0 = "always >= 0")
-    if(tk.x == DF_TR) {
-      const int c16 = tk.z, J = c16 / UD_T;
-      lap(0);
-      // (C_j factored and the V workspace parity were conditions for taking the task)
-      w.set<1>(a.flags + a.off_ver + (int64_t)(2 * j) * a.nt + J, (unsigned)j);       // rows of panel j updated through panel j-1
-      w.set<2>(a.flags + a.off_ver + (int64_t)(2 * j + 1) * a.nt + J, (unsigned)j);
-      if(!df_wait(a.flags, w, &sh_ok, t_start, 1, tk.w, j, c16, J)) {
-          return;
-      }
-      if(tid == 0) df_stamp(a, j, 4);
-      lap(1);
-      // the 256 columns behind the next diagonal block feed the head tiles of the update: progress per block row
-      const int hb = (c16 - LD_NB * (j + 2)) / UD_T;
-      unsigned* rowflags = (hb < 2) ? a.flags + a.off_trb + (int64_t)j * 8 + 4 * hb : nullptr;
-      // 16-column groups of this task inside the matrix (the counters tr[j][J] and the block-row counters count groups)
-      const int remc = a.N - c16;
-      const unsigned ngrp = (unsigned)(remc >= DF_TRW ? DF_TRG : (remc + 15) / 16);
-      if(!df_task_trsm(a, j, c16, smem, tidv, tk.w < 0, &sh_ok, t_start, rowflags, ngrp)) return;
-      lap(2);
-      df_drain();
-      if(tid == 0) df_add(trj + J, ngrp);
-      if(tid == 0) df_stamp(a, j, 5);
-      lap(3);
-      if(PROF && acct) ph[8] += 1u;
-    } else {
-      const int I = tk.z, J = tk.w;
-      lap(0);
-      auto groups = [&](int B) {   // 16-column substitution tasks of 128-block B inside the matrix
-        const int rem = a.N - UD_T * B;
-        return (unsigned)((rem >= UD_T) ? 8 : (rem + 15) / 16);
-      };
-      // a head tile (DF_UPH) in the 16-byte tile form: block row P of its operands = the chain's tile solves T(P, cI),
-      // T(P, cI + 1) of the H columns under tile row I and block row P of the 8 substitution tasks of column block J
-      const bool full_tile = UD_T * (I + 1) <= a.N && UD_T * (J + 1) <= a.N;
-      const bool staged = TILE_FORM == 2 && tk.x == DF_UPH && full_tile;
-      const int cI = 2 * (I - 2 * j - 2);   // (H column - 4) of the first of the two tile solves
-      const unsigned* rowf = a.flags + a.off_trb + (int64_t)j * 8 + 4 * (J - 2 * j - 4);
-      auto row_gate = [&](int P) {
-        DfWait wg(a.flags + DF_ABORT);
-        wg.set<0>(cf + DF_HV + P * 4 + cI, (unsigned)P + 1u);
-        wg.set<1>(cf + DF_HV + P * 4 + cI + 1, (unsigned)P + 1u);
-        wg.set<2>(rowf + P, 8u);
-        return df_wait(a.flags, wg, &sh_ok, t_start, 5, j, I, J, P);
-      };
-      w.set<0>(a.flags + a.off_ver + (int64_t)I * a.nt + J, (unsigned)j);             // this tile updated through panel j-1
-      if(!staged) {
-        if(I < 2 * j + 4) w.set<1>(cf + DF_HDONE, 16u);                               // rows in the head: V from the chain kernel
-        else w.set<1>(trj + I, groups(I));
-        w.set<2>(trj + J, groups(J));
-      }
-      if(!df_wait(a.flags, w, &sh_ok, t_start, 2, 0, j, I, J)) {
-          return;
-      }
-      if(staged && !row_gate(0)) return;
-      if(tid == 0) df_stamp(a, j, 6);
-      lap(4);
-      if constexpr(TILE_FORM == 2) {
-        if(staged) {
-          using RowGate = DfRowGate<decltype(row_gate)>;
-          if(!df_task_tile2<true, PROF, RowGate>(a, j, I, J, smem, tidv, ph, RowGate{row_gate})) return;
-        } else if(full_tile) df_task_tile2<true, PROF>(a, j, I, J, smem, tidv, ph);
-        else df_task_tile2<false, PROF>(a, j, I, J, smem, tidv, ph);
-      } else {
-        df_task_tile(a, j, I, J, smem, tidv);
-      }
-      lap(5);
-      df_drain();
-      if(tid == 0) {
-        df_st(a.flags + a.off_ver + (int64_t)I * a.nt + J, (unsigned)(j + 1));
-        df_add(cf + DF_UPDONE, 1u);
-        df_stamp(a, j, 7);
-      }
-      lap(6);
-      if(PROF && acct) ph[7] += 1u;
-    }
-    // REQUIRED: keeps the lane-0-only signalling block above and the lane-0-only task selection at the loop top in separate
-    // regions.  Without a convergent operation between them the compiler threads the two `tid == 0` tests into one path,
-    // the loop gets two back-edges, LoopSimplify nests it, and lanes 1..63 of wave 0 run the selection barriers once more
-    // than lane 0 does: the workgroup hangs at s_barrier (seen on ROCm 7.2 / gfx950, no bounded wait can catch it).
-    __syncthreads();
+#include "ldlt_wide_body.inc"
+}
+
+// Both roles in ONE dispatch (HIOPAMD_DF_ONE=1; measurement aid): workgroups 0 .. DF_ROLES-1 run the chain, the others the
+// wide task loop.  Every workgroup carries the chain's LDS (one workgroup per CU), so the wide part runs with ONE workgroup
+// per CU instead of two: the schedule is slower, the work and its memory traffic are the same — this is the form the counter
+// passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) profile, because rocprofv3 --pmc serialises dispatches and the two-kernel form
+// needs both kernels running.  All DF_ROLES + wide workgroups must be resident together: the grid is at most one per CU.
+__global__ __launch_bounds__(kBlock, 1) void ldlt_df_one_kernel(const DfArgs a)
+{
+  __shared__ union U {
+    DfChainShared c;
+    DfWideShared w;
+    __device__ U() {}
+  } u;
+  if(blockIdx.x < (unsigned)DF_ROLES) {
+    DfChainLds& L = u.c.L;
+    int4(*sh_tasks)[DF_MAXT] = u.c.tasks;
+    int& sh_ok = u.c.ok;
+    const int role = blockIdx.x;
+#include "ldlt_chain_body.inc"
+  } else {
+    constexpr int TILE_FORM = 2;
+    constexpr bool PROF = false;
+    double* smem = u.w.smem;
+    int& sh_kind = u.w.kind;
+    int& sh_ok = u.w.ok;
+    int4& sh_task = u.w.task;
+#include "ldlt_wide_body.inc"
   }
 }
 
