@@ -383,11 +383,28 @@ def main():
     flops_per_launch = ufl.value / launches
     ms_per_launch = ums.value / launches
     achieved = (flops_per_launch / (ms_per_launch * 1e-3)) / 1e12 if ms_per_launch > 0 else 0.0
-    # HBM traffic of that kernel: rocprofv3 --pmc serialises the dispatches of the process, and the dataflow factorisation is a
-    # PAIR of persistent kernels that wait for each other's flags — it cannot run under counter collection.  `traffic` is
-    # therefore null here; the PMC passes of the stepwise path (same tile algorithm, one launch per super-panel step) are under
-    # profiles/r02_pmc (scripts/gpu_pmc.sh, HIOPAMD_DF=0).
-    traffic, traffic_src = None, "n/a: counter collection serialises the two concurrent dataflow kernels (see profiles/r02_pmc for the stepwise kernels)"
+    # HBM-side traffic of that kernel per launch: PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc
+    # passes with --kernel-trace only) of the SAME task graph run as one dispatch (HIOPAMD_DF_ONE=1: rocprofv3 serialises
+    # dispatches, and the production form is a pair of kernels that wait for each other) — scripts/r03_gpu_1.sh, committed
+    # summary profiles/r03_pmc/summary.json.  Algorithmic bytes of the same launch: every trailing tile read + written once
+    # per super-panel, the two operand row panels read once, the row-panel substitution (read A, write V and U).
+    traffic, traffic_src, alg_bytes = None, "n/a (no committed PMC summary found)", None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc", "summary.json")))
+        if p.N == 8192:
+            traffic = pmc["ldlt_df_one_kernel"]["hbm_bytes_per_launch"]
+            traffic_src = ("profiles/r03_pmc/summary.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of "
+                           "ldlt_df_one_kernel (the dataflow LDL^T's chain + wide roles as ONE dispatch, N = 8192); L2 memory-side "
+                           "requests, Infinity-Cache hits included")
+    except Exception:
+        pass
+    nsp_ = (p.N + 255) // 256
+    alg_bytes = 0.0
+    for j_ in range(nsp_ - 1):
+        m_ = p.N - 256 * (j_ + 1)
+        alg_bytes += 8.0 * 2.0 * (m_ * m_ / 2.0 + 64.0 * m_)      # C tiles of the upper triangle: read + write
+        alg_bytes += 8.0 * 2.0 * 256.0 * m_                       # V and U row panels, once
+        alg_bytes += 8.0 * 3.0 * 256.0 * max(m_ - 256, 0)         # substitution of the row panel's tail: read A, write V and U
     # the dominant kernel is the persistent wide kernel of the dataflow factorisation: `achieved` = the algorithmic flops of its
     # trailing-update tiles (2 K per updated element of the upper triangle) / its WHOLE duration, which also contains the
     # row-panel substitution tasks and every wait for the chain kernel — a lower bound on the tile rate, by construction
@@ -395,7 +412,8 @@ def main():
                     achieved=achieved, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
                     traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
                     launches_per_step=launches / a.steps, avg_launch_ms=ms_per_launch,
-                    algorithmic_flops_per_launch=flops_per_launch,
+                    algorithmic_flops_per_launch=flops_per_launch, algorithmic_bytes_per_launch=alg_bytes,
+                    traffic_over_algorithmic=(traffic / alg_bytes) if traffic and alg_bytes else None,
                     update_ms_per_step=ums.value / a.steps)
 
     # ---- run-stats spans (the reference's hiopRunStatsKKT sub-spans): a third pass of the same K steps with the context's

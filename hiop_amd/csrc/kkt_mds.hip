@@ -15,6 +15,14 @@
 
 #include <vector>
 
+// a regularisation term: one value for every entry (v == nullptr) or a device vector (the reference's delta_wx / delta_wd /
+// delta_cc / delta_cd are vectors: hiopKKTLinSysMDS.cpp:178-181, the randomised perturbations fill them entry by entry)
+struct MdsDelta {
+  const double* v;
+  double s;
+  __device__ __forceinline__ double at(int64_t i) const { return v ? v[i] : s; }
+};
+
 struct hiopamd_kkt_mds {
   hiopamd_ctx* ctx = nullptr;
   hiopamd_mds_structure s{};
@@ -32,6 +40,8 @@ struct hiopamd_kkt_mds {
   double* buf_xs = nullptr;   // nxs
   double* ones_xs = nullptr;  // nxs, all ones (D = I for J J^T through the Schur plans)
   bool built = false;
+  bool solve_failed = false;   // a solve since the last hiopamd_kkt_mds_solve_status is known to have failed
+  MdsDelta last_delta[4] = {{nullptr, 0.0}, {nullptr, 0.0}, {nullptr, 0.0}, {nullptr, 0.0}};   // of the last build (re-assembly after a time-out)
 };
 
 using namespace hiopamd;
@@ -111,14 +121,6 @@ int hiopamd_kkt_mds_set_values(hiopamd_kkt_mds* k, const double* Jcs_val, const 
     int rc_ = (x);                    \
     if(rc_ != HIOPAMD_OK) return rc_; \
   } while(0)
-
-// a regularisation term: one value for every entry (v == nullptr) or a device vector (the reference's delta_wx / delta_wd /
-// delta_cc / delta_cd are vectors: hiopKKTLinSysMDS.cpp:178-181, the randomised perturbations fill them entry by entry)
-struct MdsDelta {
-  const double* v;
-  double s;
-  __device__ __forceinline__ double at(int64_t i) const { return v ? v[i] : s; }
-};
 
 // Dense part of build_kkt_matrix in ONE pass over the upper triangle (reference: setToZero + three block adds + four diagonal
 // adds = eight passes over parts of an N x N matrix, hiopKKTLinSysMDS.cpp:196-215,245,289-290): every element (r, c), c >= r,
@@ -225,6 +227,10 @@ static int kkt_mds_build_impl(hiopamd_kkt_mds* k, MdsDelta dwx, MdsDelta dwd, Md
   // (3,3) += -Jds Hxs^-1 Jds^T ; (2,3) += -Jcs Hxs^-1 Jds^T                  (:267-276)
   RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_dd, k->Jds_val, k->Jds_val, k->Hxs, -1.0, M, ld, nxd + neq, nxd + neq));
   RC(hiopamd_sp_add_MDinvNt(ctx, k->plan_cd, k->Jcs_val, k->Jds_val, k->Hxs, -1.0, M, ld, nxd, nxd + neq));
+  k->last_delta[0] = dwx;
+  k->last_delta[1] = dwd;
+  k->last_delta[2] = dcc;
+  k->last_delta[3] = dcd;
   k->built = true;
   return HIOPAMD_OK;
 }
@@ -244,13 +250,22 @@ int hiopamd_kkt_mds_build_vec(hiopamd_kkt_mds* k, const double* delta_wx, const 
   return kkt_mds_build_impl(k, MdsDelta{delta_wx, 0.0}, MdsDelta{delta_wd, 0.0}, MdsDelta{delta_cc, 0.0}, MdsDelta{delta_cd, 0.0});
 }
 
+static int kkt_mds_build_impl(hiopamd_kkt_mds* k, MdsDelta dwx, MdsDelta dwd, MdsDelta dcc, MdsDelta dcd);
+
 int hiopamd_kkt_mds_factorize(hiopamd_kkt_mds* k, int* n_neg_host)
 {
   if(!k || !n_neg_host) return HIOPAMD_ERR_ARG;
   if(!k->built) return HIOPAMD_ERR_STATE;
   SpanScope span(k->ctx, HIOPAMD_SPAN_KKT_UPDATE_INNER_FACT);   // hiopKKTLinSys.cpp:347-352
   int n_neg = 0;
-  RC(hiopamd_linsolver_matrix_changed(k->ls, &n_neg));
+  int rcm = hiopamd_linsolver_matrix_changed(k->ls, &n_neg);
+  if(rcm == HIOPAMD_ERR_TIMEOUT) {
+    // the dataflow factorisation gave up and left the matrix overwritten; the solver object has switched to the stepwise
+    // kernels: assemble again and factor once more
+    RC(kkt_mds_build_impl(k, k->last_delta[0], k->last_delta[1], k->last_delta[2], k->last_delta[3]));
+    rcm = hiopamd_linsolver_matrix_changed(k->ls, &n_neg);
+  }
+  RC(rcm);
   if(n_neg >= 0) {
     // Haynsworth inertia additivity: add the negative entries of the sparse (1,1) block   (:83-108)
     int64_t nneg_xs = 0, nzero_xs = 0;
@@ -301,6 +316,11 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
   span_end(ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);
   span_begin(ctx, guard.id = HIOPAMD_SPAN_KKT_SOLVE_INNER);
   RC(hiopamd_linsolver_solve(k->ls, rhs, 1));
+  {
+    int okc = 1;
+    RC(hiopamd_linsolver_last_solve_ok(k->ls, &okc));   // no synchronisation: what the host knows already
+    if(!okc) k->solve_failed = true;
+  }
   span_end(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);
   span_begin(ctx, guard.id = HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);   // :380-401
   // unpack dx_dense, dyc, dyd and start dxs = rx_sparse  (one pass)           (:383-390)
@@ -323,6 +343,21 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
   RC(hiopamd_sp_trans_times_vec(ctx, neq, nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, 1.0, dxs, -1.0, dyc));
   RC(hiopamd_sp_trans_times_vec(ctx, nineq, nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, 1.0, dxs, -1.0, dyd));
   RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { dx[i] = dxs[i] / Hxs[i]; }));
+  return HIOPAMD_OK;
+}
+
+// did every solveCompressed since the last call deliver a valid direction?  *ok_host = 0 after a safe-mode refinement that
+// did not converge or a timed-out dataflow solve.  sync != 0 also synchronises the stream and looks at the dataflow solve's
+// error word (hiopamd_linsolver_solve_status); sync == 0 reports what the host knows without waiting.
+int hiopamd_kkt_mds_solve_status(hiopamd_kkt_mds* k, int sync, int* ok_host)
+{
+  if(!k || !ok_host) return HIOPAMD_ERR_ARG;
+  int ok = 1;
+  if(sync) RC(hiopamd_linsolver_solve_status(k->ls, &ok));
+  else RC(hiopamd_linsolver_last_solve_ok(k->ls, &ok));
+  if(k->solve_failed) ok = 0;
+  k->solve_failed = false;
+  *ok_host = ok;
   return HIOPAMD_OK;
 }
 

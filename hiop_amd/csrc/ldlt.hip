@@ -27,7 +27,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <fcntl.h>
 #include <mutex>
+#include <sys/file.h>
+#include <unistd.h>
 #include <vector>
 
 namespace hiopamd {
@@ -905,47 +908,35 @@ __global__ __launch_bounds__(64) void ldlt_inv_diag_kernel(int N, const double* 
       }
 }
 
-// C = alpha * X Y for 256 x 256 row-major blocks, one (X, Y, C) triple per blockIdx.y, one 64 x 64 tile of C per blockIdx.x:
+// C = alpha * X Y for 256 x 256 row-major blocks, one (X, Y, C) triple per blockIdx.y, one 32 x 32 tile of C per blockIdx.x:
 // the two products that complete an inverted 512 x 512 diagonal block, inv([Ua Uab; 0 Ub]) = [Wa, -Wa Uab Wb; 0, Wb].
-// 4 waves as 2 x 2, each 32 x 32 = 2 x 2 tiles of v_mfma_f64_16x16x4_f64, operands straight from L2 (16 x 0.5 MB per launch).
+// Latency-bound work (16 pairs x 2 x 256^3 flops): 4 waves of one v_mfma_f64_16x16x4_f64 tile each, the operands of 32 k-steps
+// in flight at once (two memory round trips per workgroup), 64 tiles x pairs workgroups so that every CU holds several.
 __global__ __launch_bounds__(kBlock) void ldlt_w512_mm_kernel(const double* __restrict__ X, int64_t xpair, int64_t ldx,
                                                               const double* __restrict__ Y, int64_t ypair, int64_t ldy,
                                                               double* __restrict__ C, int64_t cpair, int64_t ldc, double alpha)
 {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lk = lane >> 4, li = lane & 15;
   const int wr = w >> 1, wc = w & 1;
-  const int ti = blockIdx.x >> 2, tj = blockIdx.x & 3;
-  const double* Xp = X + (int64_t)blockIdx.y * xpair + (int64_t)(64 * ti + 32 * wr) * ldx;
-  const double* Yp = Y + (int64_t)blockIdx.y * ypair + 64 * tj + 32 * wc;
-  double* Cp = C + (int64_t)blockIdx.y * cpair + (int64_t)(64 * ti + 32 * wr) * ldc + 64 * tj + 32 * wc;
-  double4_t acc[2][2];
+  const int ti = blockIdx.x >> 3, tj = blockIdx.x & 7;
+  const double* Xp = X + (int64_t)blockIdx.y * xpair + (int64_t)(32 * ti + 16 * wr + li) * ldx + lk;
+  const double* Yp = Y + (int64_t)blockIdx.y * ypair + (int64_t)lk * ldy + 32 * tj + 16 * wc + li;
+  double* Cp = C + (int64_t)blockIdx.y * cpair + (int64_t)(32 * ti + 16 * wr) * ldc + 32 * tj + 16 * wc;
+  double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for(int i = 0; i < 2; ++i)
+  for(int half = 0; half < 2; ++half) {
+    double av[32], bv[32];
 #pragma unroll
-    for(int q = 0; q < 2; ++q) acc[i][q] = double4_t{0.0, 0.0, 0.0, 0.0};
-  for(int k0 = 0; k0 < LD_NB; k0 += 16) {
-    double av[4][2], bv[4][2];
-#pragma unroll
-    for(int kk = 0; kk < 4; ++kk) {
-      const int k = k0 + 4 * kk + lk;
-#pragma unroll
-      for(int i = 0; i < 2; ++i) av[kk][i] = Xp[(int64_t)(16 * i + li) * ldx + k];
-#pragma unroll
-      for(int q = 0; q < 2; ++q) bv[kk][q] = Yp[(int64_t)k * ldy + 16 * q + li];
+    for(int kk = 0; kk < 32; ++kk) {
+      const int k = 128 * half + 4 * kk;   // (+ lk, folded into the base pointers)
+      av[kk] = Xp[k];
+      bv[kk] = Yp[(int64_t)k * ldy];
     }
 #pragma unroll
-    for(int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for(int i = 0; i < 2; ++i)
-#pragma unroll
-        for(int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk][i], bv[kk][q], acc[i][q], 0, 0, 0);
+    for(int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
   }
 #pragma unroll
-  for(int i = 0; i < 2; ++i)
-#pragma unroll
-    for(int q = 0; q < 2; ++q)
-#pragma unroll
-      for(int reg = 0; reg < 4; ++reg) Cp[(int64_t)(16 * i + lk + 4 * reg) * ldc + 16 * q + li] = alpha * acc[i][q][reg];
+  for(int reg = 0; reg < 4; ++reg) Cp[(int64_t)(lk + 4 * reg) * ldc + li] = alpha * acc[reg];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1910,6 +1901,46 @@ static hipEvent_t df_done_event()
   if(!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
   return ev[dev];
 }
+// One dataflow factorisation per DEVICE at a time, also across processes: the chain kernel's 16 roles wait for each other and
+// need their 16 reserved CUs to themselves; two processes sharing a device could each get some of them and starve (round 2
+// turned that into a 3 s time-out).  An advisory file lock per device (flock on /tmp/hiopamd_df_<pci bus id>.lock, taken
+// without blocking for the duration of one factorisation — the call synchronises before it returns) decides who may use the
+// dataflow kernels; whoever does not get it runs the stepwise kernels for this call.
+struct DfDeviceLock {
+  int fd = -1;
+  bool held = false;
+  bool try_acquire()
+  {
+    static std::mutex mu;
+    static int fds[64];
+    static bool init = false;
+    int dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;   // (cannot tell: behave as before)
+    std::lock_guard<std::mutex> lk(mu);
+    if(!init) {
+      for(int& f : fds) f = -1;
+      init = true;
+    }
+    if(fds[dev] < 0) {
+      char bus[64] = "unknown";
+      (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev);
+      for(char* c = bus; *c; ++c)
+        if(*c == ':' || *c == '.' || *c == '/') *c = '_';
+      char path[160];
+      std::snprintf(path, sizeof(path), "/tmp/hiopamd_df_%s.lock", bus);
+      fds[dev] = ::open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+      if(fds[dev] < 0) return true;   // no lock file possible: behave as before
+    }
+    fd = fds[dev];
+    held = ::flock(fd, LOCK_EX | LOCK_NB) == 0;
+    return held;
+  }
+  ~DfDeviceLock()
+  {
+    if(held && fd >= 0) (void)::flock(fd, LOCK_UN);
+  }
+};
+
 // HIOPAMD_F16=0: the 16 x 16 sub-block factor in its v_readlane form (A/B timing aid; default: rank-1 MFMA updates)
 static bool f16_mfma()
 {
@@ -2138,7 +2169,7 @@ struct hiopamd_linsolver {
   int safe_npos = 0;
   double safe_delta_rel = 1.4901161193847656e-08;   // sqrt(eps)
   double* Msave = nullptr;   // n x n: the matrix as assembled (symmetrised), safe mode only
-  double* rbuf = nullptr;    // 2 n: right-hand side copy + residual
+  double* rbuf = nullptr;    // 3 n: right-hand side copy, residual, probe vector of matrixChanged
   bool safe_solve_failed = false;
   int safe_last_refinements = 0;
   double safe_last_residual = 0.0;
@@ -2149,6 +2180,7 @@ struct hiopamd_linsolver {
   unsigned long long fl_epoch = 0;
   bool flow_enabled = true;    // dataflow solve in use (false: stepwise 256-row solves)
   bool flow_dirty = false;     // dataflow solves were launched since the error word was last looked at
+  bool flow_failed = false;    // sticky: a dataflow solve timed out since the last factorisation (its results were invalid)
   bool factored = false;
   int inertia[3] = {0, 0, 0};
   double flops_fact = 0.0, flops_triu = 0.0;   // hiopLinSolStats::flopsFact / flopsTriuSolves (cumulative)
@@ -2253,7 +2285,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   // panel 0's diagonal block on the caller's stream, then fork
   int jp0 = 0;
   bool all_done = false;
-  const bool use_df = df && df->enabled && df->flags && lookahead && lda == N && df->plan.N == N && df->plan.nchain >= 3;
+  bool use_df = df && df->enabled && df->flags && lookahead && lda == N && df->plan.N == N && df->plan.nchain >= 3;
+  DfDeviceLock df_lock;   // released when this call returns (it synchronises the stream first)
+  if(use_df && !df_lock.try_acquire()) use_df = false;   // another process factorises on this device right now: stepwise kernels
   {
     const Panel p0 = panel(0);
     hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, A, lda, p0.K0, p0.kbs, p0.Cj);
@@ -2388,9 +2422,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     // T = U_ab W_b, then the upper-right quadrant = -W_a T   (N is a multiple of 512 here; U_ab = A[rows of a, columns of b])
     const int np2 = N / 512;
     const int64_t w2 = 512 * 512;
-    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(16, np2), dim3(kBlock), 0, st, A + LD_NB, (int64_t)512 * lda + 512, lda,
+    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(64, np2), dim3(kBlock), 0, st, A + LD_NB, (int64_t)512 * lda + 512, lda,
                        Winv + (int64_t)LD_NB * 512 + LD_NB, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB, (int64_t)LD_NB, 1.0);
-    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(16, np2), dim3(kBlock), 0, st, Winv, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB,
+    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(64, np2), dim3(kBlock), 0, st, Winv, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB,
                        (int64_t)LD_NB, Winv + LD_NB, w2, (int64_t)512, -1.0);
   }
   HIOPAMD_CHECK(hipGetLastError());
@@ -2448,7 +2482,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
                  "[hiop_amd] dataflow LDL^T: a bounded wait timed out, factorisation aborted.  waiter %u (1 = TR, 2 = UP, 100+r = "
                  "chain role r) args %u %u %u %u, condition slot %u: flag word %u is %u, needs >= %u; tickets taken %u\n",
                  dfw[2], dfw[3], dfw[4], dfw[5], dfw[6], dfw[7], dfw[10], dfw[9], dfw[8], dfw[DF_TICKET]);
-    return HIOPAMD_ERR_HIP;
+    return HIOPAMD_ERR_TIMEOUT;
   }
   if(timed) prof->collect();
   if(inertia3_host) {
@@ -2748,6 +2782,7 @@ static int flow_check(hiopamd_linsolver* ls, int* ok_host)
   ls->flow_dirty = false;
   if(err == 0) return HIOPAMD_OK;
   if(ok_host) *ok_host = 0;
+  ls->flow_failed = true;
   std::fprintf(stderr, "[hiop_amd] dataflow solve: a bounded wait timed out; the results of the solves since the last check are "
                        "invalid.  Exchange state re-initialised, stepwise solve from now on.\n");
   HIOPAMD_CHECK(hipMemsetAsync(ls->fl_sync, 0, sizeof(unsigned long long) * (size_t)(2 + 8 * nb), ls->ctx->stream));
@@ -2763,11 +2798,22 @@ int hiopamd_linsolver_solve_status(hiopamd_linsolver* ls, int* ok_host)
 {
   if(!ls || !ok_host) return HIOPAMD_ERR_ARG;
   const int rc = flow_check(ls, ok_host);
+  if(rc == HIOPAMD_OK && ls->flow_failed) {   // (a time-out seen by an earlier synchronising call)
+    *ok_host = 0;
+    ls->flow_failed = false;
+  }
   if(rc == HIOPAMD_OK && ls->safe_mode && ls->safe_solve_failed) {   // a safe-mode refinement did not converge since the last check
     *ok_host = 0;
     ls->safe_solve_failed = false;
   }
   return rc;
+}
+
+int hiopamd_linsolver_last_solve_ok(hiopamd_linsolver* ls, int* ok_host)
+{
+  if(!ls || !ok_host) return HIOPAMD_ERR_ARG;
+  *ok_host = (ls->flow_failed || (ls->safe_mode && ls->safe_solve_failed)) ? 0 : 1;
+  return HIOPAMD_OK;
 }
 
 int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable)
@@ -2800,7 +2846,7 @@ int hiopamd_linsolver_set_safe_mode(hiopamd_linsolver* ls, int enable, int n_pos
   ls->factored = false;
   if(ls->safe_mode && !ls->Msave && ls->n > 0) {
     HIOPAMD_CHECK(hipMalloc((void**)&ls->Msave, sizeof(double) * (size_t)ls->n * ls->n));
-    HIOPAMD_CHECK(hipMalloc((void**)&ls->rbuf, sizeof(double) * (size_t)2 * ls->n));
+    HIOPAMD_CHECK(hipMalloc((void**)&ls->rbuf, sizeof(double) * (size_t)3 * ls->n));   // rhs copy, residual, probe vector
   }
   return HIOPAMD_OK;
 }
@@ -2855,33 +2901,59 @@ int hiopamd_linsolver_growth(hiopamd_linsolver* ls, double* max_abs_u_host, doub
   return rc;
 }
 
+static int safe_refined_solve(hiopamd_linsolver* ls, double* x, bool* ok_out);
+
 int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
 {
   if(!ls || !n_neg_host) return HIOPAMD_ERR_ARG;
   ls->factored = false;
-  if(ls->safe_mode && ls->n > 0) {
+  {
+    // a dataflow solve since the last factorisation that timed out delivered garbage: say so BEFORE this matrix is touched
+    // (the caller may call again: the matrix is intact)
+    int ok = 1;
+    int rcf = flow_check(ls, &ok);   // (no extra synchronisation when no dataflow solve ran since the last factorisation)
+    if(rcf != HIOPAMD_OK) return rcf;
+    if(!ok || ls->flow_failed) {
+      ls->flow_failed = false;
+      return HIOPAMD_ERR_SOLVE;
+    }
+  }
+  const int n = ls->n;
+  auto regularise = [&]() -> int {   // safe mode: M <- K + delta diag(+I, -I) (upper triangle), K kept in Msave
+    const double delta = ls->safe_delta_rel * ls->safe_anorm;
+    int rs = HIOPAMD_OK;
+    if(ls->safe_npos > 0) rs = hiopamd_mat_add_sub_diagonal_const(ls->ctx, ls->M, n, 0, ls->safe_npos, delta);
+    if(rs == HIOPAMD_OK && ls->safe_npos < n)
+      rs = hiopamd_mat_add_sub_diagonal_const(ls->ctx, ls->M, n, ls->safe_npos, n - ls->safe_npos, -delta);
+    return rs;
+  };
+  if(ls->safe_mode && n > 0) {
     // keep the matrix as assembled (both triangles, for the refinement's products) and regularise the copy to be factored
-    const int n = ls->n;
     HIOPAMD_CHECK(hipMemcpyAsync(ls->Msave, ls->M, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ls->ctx->stream));
     int rs = hiopamd_mat_symmetrize(ls->ctx, n, ls->Msave, n);
     if(rs != HIOPAMD_OK) return rs;
     rs = hiopamd_mat_max_abs(ls->ctx, n, n, ls->Msave, n, &ls->safe_anorm);
     if(rs != HIOPAMD_OK) return rs;
-    const double delta = ls->safe_delta_rel * ls->safe_anorm;
-    if(ls->safe_npos > 0) rs = hiopamd_mat_add_sub_diagonal_const(ls->ctx, ls->M, n, 0, ls->safe_npos, delta);
-    if(rs == HIOPAMD_OK && ls->safe_npos < n)
-      rs = hiopamd_mat_add_sub_diagonal_const(ls->ctx, ls->M, n, ls->safe_npos, n - ls->safe_npos, -delta);
+    rs = regularise();
     if(rs != HIOPAMD_OK) return rs;
     ls->safe_solve_failed = false;
   }
-  {
-    int ok = 1;
-    int rcf = flow_check(ls, &ok);   // (no extra synchronisation when no dataflow solve ran since the last factorisation)
-    if(rcf != HIOPAMD_OK) return rcf;
-  }
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_FACT);   // hiopLinSolverSymDenseLapack.hpp:80-125 (tmFactTime; flopsFact = n^3/3)
-  ls->flops_fact += (double)ls->n * ls->n * ls->n / 3.0;
-  int rc = ldlt_factor_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+  ls->flops_fact += (double)n * n * n / 3.0;
+  int rc = ldlt_factor_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+  if(rc == HIOPAMD_ERR_TIMEOUT) {
+    // the dataflow kernels gave up (two processes on one device can starve the chain kernel's roles): the matrix is
+    // overwritten.  From now on this object uses the stepwise kernels; with a saved copy (safe mode) the factorisation is
+    // redone right away, otherwise the caller re-assembles and calls again (the KKT objects do).
+    ls->df.enabled = false;
+    std::fprintf(stderr, "[hiop_amd] dataflow LDL^T timed out: this solver object uses the stepwise kernels from now on\n");
+    if(ls->safe_mode && n > 0) {
+      HIOPAMD_CHECK(hipMemcpyAsync(ls->M, ls->Msave, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ls->ctx->stream));
+      int rs = regularise();
+      if(rs != HIOPAMD_OK) return rs;
+      rc = ldlt_factor_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+    }
+  }
   if(rc == HIOPAMD_ERR_SINGULAR) {
     // reference: "entry in the factorization's diagonal is exactly zero" -> matrixChanged() returns -1
     *n_neg_host = -1;
@@ -2890,6 +2962,65 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
   if(rc != HIOPAMD_OK) return rc;
   ls->factored = true;
   *n_neg_host = (ls->inertia[2] > 0) ? -1 : ls->inertia[1];
+  if(ls->safe_mode && n > 0 && *n_neg_host >= 0) {
+    // What was factored is K_delta, and the inertia above is K_delta's.  It is K's as well unless K has an eigenvalue within
+    // ~delta of zero (Weyl) — exactly the case in which the refinement against K cannot converge (its contraction factor is
+    // ~delta / |lambda_min|).  So the question "is K singular to working precision / is the factor unusable?" — what the
+    // reference's Bunch-Kaufman answers with -1 — is put to a PROBE solve: K x = K e refined like every safe-mode solve; no
+    // convergence => -1, and the inertia-correction loop of the IPM reacts instead of trusting the regularised matrix's count.
+    double* x = ls->rbuf + 2 * (size_t)n;
+    int rs = hiopamd_vec_set_to_constant(ls->ctx, n, ls->rbuf, 1.0);
+    if(rs == HIOPAMD_OK) rs = hiopamd_mat_times_vec(ls->ctx, n, n, ls->Msave, n, 0.0, x, 1.0, ls->rbuf);
+    bool ok = false;
+    if(rs == HIOPAMD_OK) rs = safe_refined_solve(ls, x, &ok);
+    if(rs != HIOPAMD_OK) return rs;
+    if(!ok) {
+      ls->factored = false;
+      *n_neg_host = -1;
+    }
+  }
+  return HIOPAMD_OK;
+}
+
+// safe mode: x <- K_delta^-1 x, then refined against the saved K (see hiopamd_linsolver_set_safe_mode); *ok = 0 when the
+// refinement did not reach 1e-13 (||K|| ||x|| + ||b||) in 10 steps
+static int safe_refined_solve(hiopamd_linsolver* ls, double* x, bool* ok_out)
+{
+  const int n = ls->n;
+  double* b = ls->rbuf;
+  double* r = ls->rbuf + n;
+  int rc = hiopamd_vec_copy(ls->ctx, n, b, x);
+  if(rc != HIOPAMD_OK) return rc;
+  double bn = 0.0;
+  rc = hiopamd_vec_infnorm(ls->ctx, n, b, &bn);
+  if(rc != HIOPAMD_OK) return rc;
+  rc = ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, x, 1, ls->Cd, ls);
+  if(rc != HIOPAMD_OK) return rc;
+  int it = 0;
+  double rel = 0.0;
+  bool ok = false;
+  for(; it <= 10; ++it) {
+    rc = hiopamd_vec_copy(ls->ctx, n, r, b);                                              // r = b - K x
+    if(rc == HIOPAMD_OK) rc = hiopamd_mat_times_vec(ls->ctx, n, n, ls->Msave, n, 1.0, r, -1.0, x);
+    double rn = 0.0, xn = 0.0;
+    if(rc == HIOPAMD_OK) rc = hiopamd_vec_infnorm(ls->ctx, n, r, &rn);
+    if(rc == HIOPAMD_OK) rc = hiopamd_vec_infnorm(ls->ctx, n, x, &xn);
+    if(rc != HIOPAMD_OK) return rc;
+    const double scale = ls->safe_anorm * xn + bn;
+    rel = scale > 0.0 ? rn / scale : 0.0;
+    if(!(rn == rn) || !(xn == xn)) break;   // NaN: the factor is unusable
+    if(rel <= 1e-13) {
+      ok = true;
+      break;
+    }
+    if(it == 10) break;
+    rc = ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, r, 1, ls->Cd, ls);     // dx = K_delta^-1 r
+    if(rc == HIOPAMD_OK) rc = hiopamd_vec_axpy(ls->ctx, n, x, 1.0, r);
+    if(rc != HIOPAMD_OK) return rc;
+  }
+  ls->safe_last_refinements = it;
+  ls->safe_last_residual = rel;
+  *ok_out = ok;
   return HIOPAMD_OK;
 }
 
@@ -2900,43 +3031,10 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs)
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_TRIU_SOLVES);   // :173-195 (tmTriuSolves; flopsTriuSolves = 2 n^2 per rhs)
   ls->flops_triu += 2.0 * (double)ls->n * ls->n * nrhs;
   if(!ls->safe_mode) return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd, ls);
-  // safe mode: x = K_delta^-1 b, then refine against the saved K (see hiopamd_linsolver_set_safe_mode)
-  const int n = ls->n;
-  double* b = ls->rbuf;
-  double* r = ls->rbuf + n;
   for(int q = 0; q < nrhs; ++q) {
-    double* x = rhs_inout + (int64_t)q * n;
-    int rc = hiopamd_vec_copy(ls->ctx, n, b, x);
-    if(rc != HIOPAMD_OK) return rc;
-    double bn = 0.0;
-    rc = hiopamd_vec_infnorm(ls->ctx, n, b, &bn);
-    if(rc != HIOPAMD_OK) return rc;
-    rc = ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, x, 1, ls->Cd, ls);
-    if(rc != HIOPAMD_OK) return rc;
-    int it = 0;
-    double rel = 0.0;
     bool ok = false;
-    for(; it <= 10; ++it) {
-      rc = hiopamd_vec_copy(ls->ctx, n, r, b);                                              // r = b - K x
-      if(rc == HIOPAMD_OK) rc = hiopamd_mat_times_vec(ls->ctx, n, n, ls->Msave, n, 1.0, r, -1.0, x);
-      double rn = 0.0, xn = 0.0;
-      if(rc == HIOPAMD_OK) rc = hiopamd_vec_infnorm(ls->ctx, n, r, &rn);
-      if(rc == HIOPAMD_OK) rc = hiopamd_vec_infnorm(ls->ctx, n, x, &xn);
-      if(rc != HIOPAMD_OK) return rc;
-      const double scale = ls->safe_anorm * xn + bn;
-      rel = scale > 0.0 ? rn / scale : 0.0;
-      if(!(rn == rn) || !(xn == xn)) break;   // NaN: the factor is unusable
-      if(rel <= 1e-13) {
-        ok = true;
-        break;
-      }
-      if(it == 10) break;
-      rc = ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, r, 1, ls->Cd, ls);     // dx = K_delta^-1 r
-      if(rc == HIOPAMD_OK) rc = hiopamd_vec_axpy(ls->ctx, n, x, 1.0, r);
-      if(rc != HIOPAMD_OK) return rc;
-    }
-    ls->safe_last_refinements = it;
-    ls->safe_last_residual = rel;
+    const int rc = safe_refined_solve(ls, rhs_inout + (int64_t)q * ls->n, &ok);
+    if(rc != HIOPAMD_OK) return rc;
     if(!ok) ls->safe_solve_failed = true;
   }
   return HIOPAMD_OK;

@@ -117,16 +117,20 @@ struct DfWait {
   }
 };
 // workgroup-wide: lane 0 polls every (flag >= value) pair; returns false when the factorisation was aborted.  Bounded by
-// WALL-CLOCK time (s_memrealtime, 100 MHz): DF_TIMEOUT_TICKS after the workgroup's start every wait gives up, raises the
+// WALL-CLOCK time (s_memrealtime, 100 MHz) PER WAIT: a wait that has been spinning for DF_TIMEOUT_TICKS gives up, raises the
 // abort word (the first one also leaves a diagnostic record in words 2..11: who waited for what) and every other wait
-// returns within a few polls.  The sleep between polls keeps ~500 pollers from saturating the flags' memory channel.
+// returns within a few polls.  (Round 2 measured the limit from the START of the kernel: a factorisation that legitimately
+// runs longer than the limit — an order beyond ~70 000, a throttled or shared device — aborted at its first slow wait although
+// it was making progress.)  The sleep between polls keeps ~500 pollers from saturating the flags' memory channel.
 constexpr long long DF_TIMEOUT_TICKS = 300000000ll;   // 3 s
 __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* sh_ok, long long t_start, int who, int a0, int a1,
                                         int a2, int a3)
 {
+  (void)t_start;
   if(threadIdx.x == 0) {
     int ok = 1;
     unsigned spins = 0;
+    long long t_wait = 0;   // start of this wait's slow phase (first look at the clock)
     // all four polls in flight at once: the common case (everything already satisfied) costs one round trip, not four
     const unsigned g0 = df_ld(w.f[0]), g1 = df_ld(w.f[1]), g2 = df_ld(w.f[2]), g3 = df_ld(w.f[3]);
     const bool all_there = g0 >= w.v[0] && g1 >= w.v[1] && g2 >= w.v[2] && g3 >= w.v[3];
@@ -136,7 +140,9 @@ __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* s
         while(df_ld(w.f[q]) < w.v[q]) {
           __builtin_amdgcn_s_sleep(16);
           if((++spins & 31u) == 0) {
-            const bool late = (long long)wall_clock64() - t_start > DF_TIMEOUT_TICKS;
+            const long long now = (long long)wall_clock64();
+            if(t_wait == 0) t_wait = now;
+            const bool late = now - t_wait > DF_TIMEOUT_TICKS;
             if(late || df_ld(flags + DF_ABORT) != 0) {
               if(late && atomicCAS(flags + DF_ABORT, 0u, 1u) == 0u) {
                 df_st(flags + 2, (unsigned)who);

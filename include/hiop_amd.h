@@ -33,7 +33,10 @@ typedef enum {
   HIOPAMD_ERR_ARG = -2,       /* invalid argument */
   HIOPAMD_ERR_NODEVICE = -3,  /* no gfx950 device visible */
   HIOPAMD_ERR_SINGULAR = -4,  /* zero / non-finite pivot met */
-  HIOPAMD_ERR_STATE = -5      /* call sequence error (e.g. solve before factorize) */
+  HIOPAMD_ERR_STATE = -5,     /* call sequence error (e.g. solve before factorize) */
+  HIOPAMD_ERR_TIMEOUT = -6,   /* a bounded wait of a dataflow kernel expired: the factorisation did not complete and the matrix is
+                               * overwritten — re-assemble and call again (the object has switched itself to the stepwise kernels) */
+  HIOPAMD_ERR_SOLVE = -7      /* a solve since the last check delivered invalid results (dataflow time-out) */
 } hiopamd_status;
 
 typedef struct hiopamd_ctx hiopamd_ctx;
@@ -349,6 +352,10 @@ int hiopamd_linsolver_inertia(const hiopamd_linsolver* ls, int* pos_host, int* n
  * 256-row solve from there on); matrixChanged performs the same check.  hiopamd_linsolver_set_solve_dataflow(ls, 0)
  * selects the stepwise solve explicitly (HIOPAMD_SOLVE_FLOW=0 in the environment sets that default). */
 int hiopamd_linsolver_solve_status(hiopamd_linsolver* ls, int* ok_host);
+/* the same question WITHOUT a synchronisation: *ok_host = 0 if the host already knows that a solve since the last factorisation
+ * failed (a safe-mode refinement that did not converge — known when hiopamd_linsolver_solve returns —, or a dataflow time-out
+ * seen by an earlier synchronising call).  The KKT objects call it after every solve and report ok = 0 upwards. */
+int hiopamd_linsolver_last_solve_ok(hiopamd_linsolver* ls, int* ok_host);
 int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable);
 /* Safe mode — the role of the reference's switch from the no-pivot to the Bunch-Kaufman solver
  * (src/Optimization/hiopKKTLinSysMDS.cpp:408-430, hiopAlgFilterIPM.cpp:2400-2427).  enable != 0: matrixChanged keeps a copy of
@@ -422,6 +429,11 @@ int hiopamd_kkt_mds_factorize(hiopamd_kkt_mds* k, int* n_neg_host);
  * overwritten like in the reference), dx, dyc, dyd outputs. */
 int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const double* ryc, double* ryd,
                                      double* dx, double* dyc, double* dyd);
+/* solveCompressed returns bool in the reference (:307); here the solves are asynchronous, so the answer is a separate question:
+ * *ok_host = 0 if a solveCompressed since the last call is known to have delivered an invalid direction (safe-mode refinement
+ * not converged, dataflow solve timed out).  sync = 0: what the host knows without waiting (free after a safe-mode solve,
+ * which synchronises anyway); sync != 0: synchronise the stream and look at the dataflow solve's error word as well. */
+int hiopamd_kkt_mds_solve_status(hiopamd_kkt_mds* k, int sync, int* ok_host);
 /* only the log-barrier diagonals change (hiopKKTLinSysCompressedXYcYd::update, hiopKKTLinSys.cpp:562-572) */
 int hiopamd_kkt_mds_set_diagonals(hiopamd_kkt_mds* k, const double* Dx, const double* Dd);
 /* safe_mode_ of hiopKKTLinSysCompressedMDSXYcYd (:145, :408-430): see hiopamd_linsolver_set_safe_mode */
