@@ -38,7 +38,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max(initial=0.0) / max(np.abs(b).max(initial=0.0), 1e-300))
 
 
-@pytest.mark.parametrize("n,me,mi", [(4001, 3, 4), (1000, 1, 2)])
+@pytest.mark.parametrize("n,me,mi", [(4001, 3, 4), (1000, 1, 2), (2003, 100, 100)])   # last: k = 200 (the shape of the sharded bench case)
 def test_two_ranks_through_the_library_equal_one_rank(ctx, n, me, mi):
     seed = 11
     prob = tw.make_problem(n, me, mi, seed)
