@@ -24,6 +24,7 @@ SOURCES = [
     "dense_kernels.hip",
     "sparse_kernels.hip",
     "csr_condensed.hip",
+    "kkt_sparse.hip",
     "gram.hip",
     "ldlt.hip",
     "small_solvers.hip",

@@ -214,7 +214,7 @@ int require_refactorization_inertia_free(PdPerturb& pd, int n_required_neg_eig, 
   return pd.compute_perturb_wrong_inertia() ? 1 : -1;
 }
 
-enum Kind { KIND_MDS = 1, KIND_DENSE = 2, KIND_LOWRANK = 3, KIND_DENSE_XDYCYD = 4 };
+enum Kind { KIND_MDS = 1, KIND_DENSE = 2, KIND_LOWRANK = 3, KIND_DENSE_XDYCYD = 4, KIND_SPARSE_CONDENSED = 5 };
 
 // two sums in one pass: the column-partitioned parts of the slab (x-sized, all-reduced) and the replicated ones
 struct dot2_t {
@@ -249,6 +249,7 @@ struct hiopamd_kkt_xycyd {
   const double *xl = nullptr, *xu = nullptr, *dl = nullptr, *du = nullptr, *crhs = nullptr;   // borrowed (set_bounds)
   hiopamd_kkt_mds* mds = nullptr;
   hiopamd_kkt_lowrank* lr = nullptr;
+  hiopamd_kkt_sparse_condensed* sc = nullptr;   // hiopKKTLinSysCondensedSparse (an XDYcYd class without equalities)
   // dense backend (hiopKKTLinSysDenseXYcYd) and the Jacobians of the low-rank backend
   hiopamd_linsolver* ls = nullptr;
   const double *H = nullptr, *Jc = nullptr, *Jd = nullptr;
@@ -262,7 +263,7 @@ struct hiopamd_kkt_xycyd {
   int n_required_neg = 0;
   int num_refact = 0;
   int acceptor = 0;   // 0: hiopFactAcceptorIC, 1: hiopFactAcceptorInertiaFreeDWD
-  bool is_xd() const { return kind == KIND_DENSE_XDYCYD; }
+  bool is_xd() const { return kind == KIND_DENSE_XDYCYD || kind == KIND_SPARSE_CONDENSED; }
 };
 
 namespace {
@@ -283,6 +284,7 @@ int backend_build(hiopamd_kkt_xycyd* h)
   hiopamd_ctx* ctx = h->ctx;
   if(h->kind == KIND_MDS) return hiopamd_kkt_mds_build(h->mds, pd.wx, pd.wd, pd.cc, pd.cd);
   if(h->kind == KIND_LOWRANK) return HIOPAMD_OK;   // N is formed inside solveCompressed (hiopKKTLinSys.cpp:1132)
+  if(h->kind == KIND_SPARSE_CONDENSED) return hiopamd_kkt_sparse_condensed_build(h->sc, pd.wx, pd.wd);
   SpanScope span(ctx, HIOPAMD_SPAN_KKT_UPDATE_LINSYS);
   if(h->kind == KIND_DENSE_XDYCYD) {
     // hiopKKTLinSysDenseXDYcYd::build_kkt_matrix (hiopKKTLinSysDense.hpp:249-328)
@@ -335,6 +337,14 @@ int backend_factorize(hiopamd_kkt_xycyd* h, int* n_neg)
     *n_neg = h->n_required_neg;
     return HIOPAMD_OK;
   }
+  if(h->kind == KIND_SPARSE_CONDENSED) {
+    // the condensed matrix has to be positive definite (Cholesky in the reference); the count the acceptor compares with is
+    // the full system's number of constraints: "0 negative eigenvalues of M" <=> "n_required of the full KKT" (Sylvester)
+    int n0 = 0;
+    RC(hiopamd_kkt_sparse_condensed_factorize(h->sc, &n0));
+    *n_neg = (n0 < 0) ? -1 : h->n_required_neg;
+    return HIOPAMD_OK;
+  }
   SpanScope span(h->ctx, HIOPAMD_SPAN_KKT_UPDATE_INNER_FACT);   // hiopKKTLinSys.cpp:347-352
   return hiopamd_linsolver_matrix_changed(h->ls, n_neg);   // hiopKKTLinSys.cpp:310-313
 }
@@ -368,6 +378,8 @@ int backend_solve_xd(hiopamd_kkt_xycyd* h, const double* rx, const double* rd, c
 {
   *ok = 1;
   hiopamd_ctx* ctx = h->ctx;
+  if(h->kind == KIND_SPARSE_CONDENSED)   // (no equalities: ryc / dyc are empty)
+    return hiopamd_kkt_sparse_condensed_solve_compressed(h->sc, rx, rd, ryd, dx, dd, dyd, ok);
   const int nx = (int)h->nx, nyc = h->nyc, nyd = h->nyd;
   double* rhs = h->dense_rhs;
   RC(hiopamd_vec_copy(ctx, nx, rhs, rx));
@@ -390,6 +402,7 @@ int backend_hess_times_vec(hiopamd_kkt_xycyd* h, double* y, const double* x)   /
   if(h->kind == KIND_MDS) return hiopamd_kkt_mds_hess_times_vec(h->mds, 0.0, y, 1.0, x);
   if(h->kind == KIND_LOWRANK)   // hiopHessianLowRank::timesVec: no log-barrier term (hiopHessianLowRank.cpp:1061)
     return hiopamd_hess_lowrank_times_vec(hiopamd_kkt_lowrank_hess(h->lr), 0.0, y, 1.0, x, 0);
+  if(h->kind == KIND_SPARSE_CONDENSED) return hiopamd_kkt_sparse_condensed_hess_times_vec(h->sc, 0.0, y, 1.0, x);
   return hiopamd_mat_times_vec(h->ctx, (int)h->nx, h->nx, h->H, h->nx, 0.0, y, 1.0, x);
 }
 
@@ -408,6 +421,7 @@ int backend_jac_times_vec(hiopamd_kkt_xycyd* h, double* ycd, const double* x)
       return HIOPAMD_ERR_HIP;
     return HIOPAMD_OK;
   }
+  if(h->kind == KIND_SPARSE_CONDENSED) return hiopamd_kkt_sparse_condensed_jac_times_vec(h->sc, 0.0, ycd + h->nyc, 1.0, x);
   RC(hiopamd_mat_times_vec(ctx, h->nyc, h->nx, h->Jc, h->nx, 0.0, ycd, 1.0, x));
   return hiopamd_mat_times_vec(ctx, h->nyd, h->nx, h->Jd, h->nx, 0.0, ycd + h->nyc, 1.0, x);
 }
@@ -424,6 +438,7 @@ int backend_jac_trans_times_vec_add(hiopamd_kkt_xycyd* h, double* y, const doubl
     if(yd != yc + h->nyc) return HIOPAMD_ERR_ARG;
     return hiopamd_mat_trans_times_vec(ctx, h->nyc + h->nyd, h->nx, hiopamd_kkt_lowrank_J(h->lr), h->nx, 1.0, y, 1.0, yc);
   }
+  if(h->kind == KIND_SPARSE_CONDENSED) return hiopamd_kkt_sparse_condensed_jac_trans_times_vec(h->sc, 1.0, y, 1.0, yd);
   RC(hiopamd_mat_trans_times_vec(ctx, h->nyc, h->nx, h->Jc, h->nx, 1.0, y, 1.0, yc));
   return hiopamd_mat_trans_times_vec(ctx, h->nyd, h->nx, h->Jd, h->nx, 1.0, y, 1.0, yd);
 }
@@ -751,6 +766,20 @@ int hiopamd_kkt_xycyd_create_dense_xdycyd(hiopamd_kkt_xycyd** out, hiopamd_ctx* 
   return rc;
 }
 
+// hiopKKTLinSysCondensedSparse behind the full-space layer: an XDYcYd class for the inequality-only sparse formulation
+// (hiopKKTLinSysSparseCondensed.hpp:78: public hiopKKTLinSysCompressedSparseXDYcYd; "this KKT does not support equality
+// constraints", .cpp:360)
+int hiopamd_kkt_xycyd_create_sparse_condensed(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_sparse_condensed* k,
+                                              const double* ixl, const double* ixu, const double* idl, const double* idu)
+{
+  if(!k) return HIOPAMD_ERR_ARG;
+  int d[4];
+  RC(hiopamd_kkt_sparse_condensed_dims(k, d));
+  RC(create_common(out, ctx, KIND_SPARSE_CONDENSED, d[0], d[1], 0, d[1], ixl, ixu, idl, idu));
+  (*out)->sc = k;
+  return HIOPAMD_OK;
+}
+
 int hiopamd_kkt_xycyd_create_lowrank(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_lowrank* K,
                                      const double* ixl, const double* ixu, const double* idl, const double* idu)
 {
@@ -794,7 +823,7 @@ int hiopamd_kkt_xycyd_offsets(const hiopamd_kkt_xycyd* h, int64_t* off13_host)
 int hiopamd_kkt_xycyd_set_matrices(hiopamd_kkt_xycyd* h, const double* H, const double* Jc, const double* Jd)
 {
   if(!h) return HIOPAMD_ERR_ARG;
-  if(h->kind == KIND_MDS) return HIOPAMD_ERR_STATE;   // the MDS object holds its own values (hiopamd_kkt_mds_set_values)
+  if(h->kind == KIND_MDS || h->kind == KIND_SPARSE_CONDENSED) return HIOPAMD_ERR_STATE;   // these objects hold their own values (set_values)
   if((h->kind == KIND_DENSE || h->kind == KIND_DENSE_XDYCYD) && !H) return HIOPAMD_ERR_ARG;
   h->H = H;
   h->Jc = Jc;
@@ -842,6 +871,8 @@ int hiopamd_kkt_xycyd_update(hiopamd_kkt_xycyd* h, const double* iter, int* ok_h
     RC(stage_update_diagonals(h));
     if(h->kind == KIND_MDS) {
       RC(hiopamd_kkt_mds_set_diagonals(h->mds, h->Dx, h->Dd));
+    } else if(h->kind == KIND_SPARSE_CONDENSED) {
+      RC(hiopamd_kkt_sparse_condensed_set_diagonals(h->sc, h->Dx, h->Dd));
     } else if(h->kind == KIND_LOWRANK) {
       // hiopKKTLinSysLowRank::update (hiopKKTLinSys.cpp:1057-1096): refresh the Hessian's log-barrier diagonal, Dd^-1
       if((!h->Jc && h->nyc > 0) || (!h->Jd && h->nyd > 0)) return HIOPAMD_ERR_STATE;

@@ -324,6 +324,67 @@ ITER_PARTS = ("x", "d", "yc", "yd", "sxl", "sxu", "sdl", "sdu", "zl", "zu", "vl"
 RESID_PARTS = ("rx", "rd", "ryc", "ryd", "rxl", "rxu", "rdl", "rdu", "rszl", "rszu", "rsvl", "rsvu")
 
 
+class KKTLinSysSparseCondensed:
+    """Mirrors hiopKKTLinSysCondensedSparse (src/Optimization/hiopKKTLinSysSparseCondensed.hpp:78): build_kkt_matrix /
+    solveCompressed of the inequality-only sparse formulation; condensed matrix in CSR on the device, PCG + Jacobi inside."""
+
+    def __init__(self, ctx: Context, nx, nineq, Jd_i, Jd_j, H_i, H_j):
+        self.ctx, self.nx, self.nineq = ctx, nx, nineq
+        self._L = lib()
+        self._idx = [np.ascontiguousarray(a, dtype=np.int32) for a in (Jd_i, Jd_j, H_i, H_j)]
+        h = C.c_void_p()
+        check(self._L.hiopamd_kkt_sparse_condensed_create(C.byref(h), ctx.h, nx, nineq, self._idx[0].size, self._idx[0].ctypes.data,
+                                                          self._idx[1].ctypes.data, self._idx[2].size, self._idx[2].ctypes.data,
+                                                          self._idx[3].ctypes.data), "hiopamd_kkt_sparse_condensed_create")
+        self.h = h
+        self._vals = None
+        ctx._register(self)
+
+    def set_values(self, Jd_val, H_val, Dx, Dd):
+        self._vals = [Jd_val, H_val, Dx, Dd]
+        torch.cuda.synchronize()
+        check(self._L.hiopamd_kkt_sparse_condensed_set_values(self.h, *[dptr(t, self.ctx) for t in self._vals]), "set_values")
+
+    def build_kkt_matrix(self, delta_wx=0.0, delta_wd=0.0):
+        if isinstance(delta_wx, torch.Tensor) or isinstance(delta_wd, torch.Tensor) or delta_wx is None or delta_wd is None:
+            self._deltas = [delta_wx, delta_wd]
+            check(self._L.hiopamd_kkt_sparse_condensed_build_vec(self.h, dptr(delta_wx, self.ctx), dptr(delta_wd, self.ctx)), "build_vec")
+        else:
+            check(self._L.hiopamd_kkt_sparse_condensed_build(self.h, C.c_double(delta_wx), C.c_double(delta_wd)), "build")
+
+    def factorize(self) -> int:
+        n = C.c_int(0)
+        check(self._L.hiopamd_kkt_sparse_condensed_factorize(self.h, C.byref(n)), "factorize")
+        return n.value
+
+    def solve_compressed(self, rx, rd, ryd, dx, dd, dyd) -> bool:
+        ok = C.c_int(0)
+        check(self._L.hiopamd_kkt_sparse_condensed_solve_compressed(self.h, dptr(rx, self.ctx), dptr(rd, self.ctx), dptr(ryd, self.ctx),
+                                                                    dptr(dx, self.ctx), dptr(dd, self.ctx), dptr(dyd, self.ctx),
+                                                                    C.byref(ok)), "solve_compressed")
+        return bool(ok.value)
+
+    def set_inner_solver(self, tol, max_iter):
+        check(self._L.hiopamd_kkt_sparse_condensed_set_inner_solver(self.h, C.c_double(tol), int(max_iter)), "set_inner_solver")
+
+    def last_solve(self):
+        f, it, rel = C.c_int(0), C.c_double(0), C.c_double(0)
+        check(self._L.hiopamd_kkt_sparse_condensed_last_solve(self.h, C.byref(f), C.byref(it), C.byref(rel)), "last_solve")
+        return f.value, it.value, rel.value
+
+    def close(self):
+        if self.h is not None:
+            if self.ctx.h is not None:
+                self._L.hiopamd_kkt_sparse_condensed_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class KKTLinSysXYcYd:
     """Full-space layer (mirrors hiopKKTLinSysCompressedXYcYd + hiopKKTLinSysCurvCheck::factorize +
     compute_directions_w_IR, src/Optimization/hiopKKTLinSys.hpp:226-330): update / computeDirections /
@@ -341,6 +402,9 @@ class KKTLinSysXYcYd:
         elif isinstance(backend, KKTLinSysLowRank):
             check(self._L.hiopamd_kkt_xycyd_create_lowrank(C.byref(h), ctx.h, backend.h, *p),
                   "hiopamd_kkt_xycyd_create_lowrank")
+        elif isinstance(backend, KKTLinSysSparseCondensed):
+            check(self._L.hiopamd_kkt_xycyd_create_sparse_condensed(C.byref(h), ctx.h, backend.h, *p),
+                  "hiopamd_kkt_xycyd_create_sparse_condensed")
         else:
             nx, neq, nineq = dense_dims
             create = self._L.hiopamd_kkt_xycyd_create_dense_xdycyd if xd_form else self._L.hiopamd_kkt_xycyd_create_dense

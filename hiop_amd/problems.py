@@ -203,3 +203,36 @@ def dense_ex1(n: int, r: float = 1.0):
                 xl=np.full(n, 0.1), xu=np.full(n, 1.0), x0=np.full(n, 0.5), mass=mass, c=c,
                 f=lambda x: float(np.sum(mass * (c * x + 0.5 * x * x))), grad=lambda x: mass * (x + c),
                 hess_diag=lambda x: mass.copy(), exact=exact)
+
+
+@dataclass
+class SparseIneqProblem:
+    """Data of an inequality-only sparse NLP at one iterate (the hiopNlpSparseIneq formulation the condensed sparse KKT needs,
+    hiopKKTLinSysSparseCondensed.cpp:130-131)."""
+    nx: int
+    nineq: int
+    Jd_i: np.ndarray
+    Jd_j: np.ndarray
+    Jd_v: np.ndarray
+    H_i: np.ndarray
+    H_j: np.ndarray
+    H_v: np.ndarray
+
+
+def sparse_ex2_ineq(n: int, x: np.ndarray | None = None, scal: float = 1.0) -> SparseIneqProblem:
+    """The reference's SparseEx2 (src/Drivers/Sparse/NlpSparseEx2.hpp:30-52, convex objective) with its equality relaxed to a
+    two-sided inequality — the form NlpSparseEx2Driver.cpp:289-296 runs with KKTLinsys = condensed:
+        min  scal * sum 1/4 (x_i - 1)^4 + 1/2 x^T x
+        s.t. 4 x_1 + 2 x_2 (two-sided),  2 x_1 + x_3 >= 5,  1 <= 2 x_1 + 0.5 x_i <= 2 n  (i = 4..n)
+    Jacobian: n - 1 rows, each [2 or 4 at column 0, one more entry]; Hessian of the Lagrangian: diagonal 3 scal (x_i - 1)^2 + 1
+    (the constraints are linear).  `x`: the iterate the Hessian is evaluated at (default: the driver's start point 0)."""
+    assert n >= 3
+    if x is None:
+        x = np.zeros(n)
+    m = n - 1
+    Ji, Jj, Jv = [0, 0, 1, 1], [0, 1, 0, 2], [4.0, 2.0, 2.0, 1.0]
+    for i in range(3, n):            # 0-based variable i, row i - 1
+        Ji += [i - 1, i - 1]; Jj += [0, i]; Jv += [2.0, 0.5]
+    Hi = np.arange(n, dtype=np.int32)
+    Hv = 3.0 * scal * (x - 1.0) ** 2 + 1.0
+    return SparseIneqProblem(n, m, np.array(Ji, np.int32), np.array(Jj, np.int32), np.array(Jv), Hi, Hi.copy(), Hv)

@@ -325,6 +325,48 @@ int hiopamd_csr_form_diag_symbolic(hiopamd_ctx*, int n, int* rowptr, int* colidx
 int hiopamd_csr_form_diag_numeric(hiopamd_ctx*, int n, double* val, const double* D);                                        /* :255 */
 
 /* =====================================================================================
+ * hiopKKTLinSysCondensedSparse — the condensed sparse KKT of the inequality-only sparse formulation (SURVEY section 8 row f2 /
+ * BASELINE configs[4]); reference: src/Optimization/hiopKKTLinSysSparseCondensed.cpp:105-335 (build_kkt_matrix), :346-401
+ * (solve_compressed_direct), :403-449 (solveCompressed):
+ *   (H + Dx + delta_wx I + Jd^T (Dd + delta_wd I) Jd) dx = rx + Jd^T ((Dd + delta_wd I) ryd + rd)
+ *   dd = Jd dx - ryd ;  dyd = (Dd + delta_wd I) dd - rd
+ * The reference's inner solver is a sparse Cholesky (MA57 / cuSOLVER, :469-496: not in the image, not restated); here the
+ * condensed matrix is assembled in CSR on the device (hiopamd_csr_condensed) and solved by PCG with the Jacobi preconditioner
+ * (hiopamd_krylov_*, kind 0).  Index arrays are HOST pointers (symbolic phase once per pattern); values are device pointers.
+ * ===================================================================================== */
+typedef struct hiopamd_kkt_sparse_condensed hiopamd_kkt_sparse_condensed;
+int hiopamd_kkt_sparse_condensed_create(hiopamd_kkt_sparse_condensed** out, hiopamd_ctx* ctx, int nx, int nineq, int nnzJ,
+                                        const int* iJ_host, const int* jJ_host, int nnzH_upper, const int* iH_host,
+                                        const int* jH_host);
+int hiopamd_kkt_sparse_condensed_destroy(hiopamd_kkt_sparse_condensed* k);
+/* Jd triplet values (row-sorted), Hessian upper-triangle triplet values, Dx (nx), Dd (nineq, WITHOUT delta_wd); borrowed */
+int hiopamd_kkt_sparse_condensed_set_values(hiopamd_kkt_sparse_condensed* k, const double* Jd_val, const double* H_val,
+                                            const double* Dx, const double* Dd);
+int hiopamd_kkt_sparse_condensed_set_diagonals(hiopamd_kkt_sparse_condensed* k, const double* Dx, const double* Dd);
+/* build_kkt_matrix (:105) with scalar / vector perturbations (vectors: delta_wx over nx, delta_wd over nineq; null = zero) */
+int hiopamd_kkt_sparse_condensed_build(hiopamd_kkt_sparse_condensed* k, double delta_wx, double delta_wd);
+int hiopamd_kkt_sparse_condensed_build_vec(hiopamd_kkt_sparse_condensed* k, const double* delta_wx, const double* delta_wd);
+/* the answer matrixChanged() of the reference's Cholesky gives the inertia-correction loop: *n_neg_host = 0 when M can be
+ * positive definite (every diagonal entry positive and finite), -1 otherwise; definiteness along the search directions is
+ * tested by every solve (PCG's curvature test) */
+int hiopamd_kkt_sparse_condensed_factorize(hiopamd_kkt_sparse_condensed* k, int* n_neg_host);
+/* solveCompressed (:403): rx (nx), rd, ryd (nineq) in; dx (nx), dd, dyd (nineq) out; *ok_host = 0 when the inner solve failed
+ * (negative curvature met or no convergence) — the reference's `return false` */
+int hiopamd_kkt_sparse_condensed_solve_compressed(hiopamd_kkt_sparse_condensed* k, const double* rx, const double* rd,
+                                                  const double* ryd, double* dx, double* dd, double* dyd, int* ok_host);
+int hiopamd_kkt_sparse_condensed_set_inner_solver(hiopamd_kkt_sparse_condensed* k, double tol, int max_iter);   /* default 1e-12, 2000 */
+int hiopamd_kkt_sparse_condensed_last_solve(const hiopamd_kkt_sparse_condensed* k, int* flag_host, double* iters_host,
+                                            double* rel_resid_host);
+int hiopamd_kkt_sparse_condensed_dims(const hiopamd_kkt_sparse_condensed* k, int* dims4_host /* nx, nineq, nnzJ, nnzH */);
+hiopamd_csr_condensed* hiopamd_kkt_sparse_condensed_matrix(hiopamd_kkt_sparse_condensed* k);
+double* hiopamd_kkt_sparse_condensed_Hd(hiopamd_kkt_sparse_condensed* k);
+/* y = beta y + alpha Hess x ; y = beta y + alpha Jd x ; y = beta y + alpha Jd^T x  on the values of the last set_values */
+int hiopamd_kkt_sparse_condensed_hess_times_vec(hiopamd_kkt_sparse_condensed* k, double beta, double* y, double alpha, const double* x);
+int hiopamd_kkt_sparse_condensed_jac_times_vec(hiopamd_kkt_sparse_condensed* k, double beta, double* y, double alpha, const double* x);
+int hiopamd_kkt_sparse_condensed_jac_trans_times_vec(hiopamd_kkt_sparse_condensed* k, double beta, double* y, double alpha,
+                                                     const double* x);
+
+/* =====================================================================================
  * hiopLinSolverSymDense operator — no-pivot blocked LDL^T on fp64 MFMA + inertia
  * (reference: src/LinAlg/hiopLinSolver.hpp:78-130; semantics of
  *  src/LinAlg/hiopLinSolverSymDenseMagma.cpp:324-480 (MagmaNopiv) and the inertia thresholds of
@@ -538,6 +580,9 @@ int hiopamd_kkt_xycyd_create_dense_xdycyd(hiopamd_kkt_xycyd** out, hiopamd_ctx* 
                                           const double* ixl, const double* ixu, const double* idl, const double* idu);
 /* on top of hiopKKTLinSysLowRank (column-sharded: x-sized parts are the rank's slice, the rest is replicated);
  * perturbations are hiopPDPerturbationNull like in hiopAlgFilterIPMQuasiNewton */
+/* hiopKKTLinSysCondensedSparse behind the full-space layer (XDYcYd order of the compressed system, no equalities) */
+int hiopamd_kkt_xycyd_create_sparse_condensed(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_sparse_condensed* k,
+                                              const double* ixl, const double* ixu, const double* idl, const double* idu);
 int hiopamd_kkt_xycyd_create_lowrank(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, hiopamd_kkt_lowrank* K,
                                      const double* ixl, const double* ixu, const double* idl, const double* idu);
 int hiopamd_kkt_xycyd_destroy(hiopamd_kkt_xycyd* h);
