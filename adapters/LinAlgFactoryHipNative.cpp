@@ -3,6 +3,7 @@
 #include "hiopMatrixDenseHipNative.hpp"
 #include "hiopMatrixSparseTripletHipNative.hpp"
 #include "hiopVectorHipNative.hpp"
+#include "hiopVectorIntHipNative.hpp"
 #include "hiopamd_runtime.hpp"
 
 #include <algorithm>
@@ -22,6 +23,11 @@ bool HipNativeFactory::handles(const ExecSpaceInfo& hi) { return handles(hi.mem_
 hiopVector* HipNativeFactory::create_vector(const ExecSpaceInfo& hi, const size_type& glob_n, index_type* col_part, MPI_Comm comm)
 {
   return handles(hi) ? new hiopVectorHipNative(glob_n, col_part, comm) : nullptr;
+}
+
+hiopVectorInt* HipNativeFactory::create_vector_int(const ExecSpaceInfo& hi, size_type n)
+{
+  return handles(hi) ? new hiopVectorIntHipNative(n) : nullptr;
 }
 
 hiopMatrixDense* HipNativeFactory::create_matrix_dense(const ExecSpaceInfo& hi, const size_type& m, const size_type& glob_n,

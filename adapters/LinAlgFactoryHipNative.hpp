@@ -1,5 +1,5 @@
 // Factory hook of the `hip-native` back-end: what LinearAlgebraFactory (src/LinAlg/LinAlgFactory.{hpp,cpp}) calls first in
-// create_vector / create_matrix_dense / create_matrix_sparse / create_matrix_sym_sparse / create_raw_array / delete_raw_array.
+// create_vector / create_vector_int / create_matrix_dense / create_matrix_sparse / create_matrix_sym_sparse / create_raw_array / delete_raw_array.
 // Every function returns nullptr (false) when the execution space is not "HIP-NATIVE", so the hook is one line per factory
 // method:   if(auto* p = HipNativeFactory::create_vector(hi, glob_n, col_part, comm)) return p;
 // The signatures are the factory's own (ExecSpaceInfo of src/ExecBackends/ExecSpace.hpp:75-108; its constructor needs one more
@@ -10,6 +10,7 @@
 #include "hiopVector.hpp"
 #include "hiopMatrixDense.hpp"
 #include "hiopMatrixSparse.hpp"
+#include "hiopVectorInt.hpp"
 
 namespace hiop {
 
@@ -18,6 +19,8 @@ struct HipNativeFactory {
   static bool handles(const std::string& mem_space);
   static hiopVector* create_vector(const ExecSpaceInfo& hi, const size_type& glob_n, index_type* col_part = nullptr,
                                    MPI_Comm comm = MPI_COMM_SELF);
+  /// src/LinAlg/LinAlgFactory.cpp:182: device int32 index vector of the same mem-space
+  static hiopVectorInt* create_vector_int(const ExecSpaceInfo& hi, size_type n);
   static hiopMatrixDense* create_matrix_dense(const ExecSpaceInfo& hi, const size_type& m, const size_type& glob_n,
                                               index_type* col_part = nullptr, MPI_Comm comm = MPI_COMM_SELF,
                                               const size_type& m_max_alloc = -1);

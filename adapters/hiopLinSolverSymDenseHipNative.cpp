@@ -29,8 +29,18 @@ int hiopLinSolverSymDenseHipNative::matrixChanged()
     double ff = 0.0, fs = 0.0;
     if(hiopamd_linsolver_flops(ls_, &ff, &fs) == HIOPAMD_OK) nlp_->runStats.linsolv.flopsFact = ff / 1e12;
   }
-  if(rc != HIOPAMD_OK) return -1;
-  return n_neg;   // -1: zero / non-finite pivot, the reference's "singular" answer
+  if(rc == HIOPAMD_ERR_TIMEOUT) {
+    // the dataflow kernels gave up and the matrix is overwritten: this is NOT "singular".  The solver object has switched to
+    // its stepwise kernels; the KKT class has to assemble again, which only the caller of matrixChanged() can do — the
+    // reference has no channel for that, so stop loudly rather than send the IPM into inertia correction on a lie
+    std::fprintf(stderr, "hiop_amd: the LDL^T factorisation timed out (device shared with another process?); re-assemble and call matrixChanged() again\n");
+    std::abort();
+  }
+  if(rc != HIOPAMD_OK) {   // a runtime failure (HIP error, invalid solve results seen since the last factorisation): not "singular" either
+    std::fprintf(stderr, "hiop_amd: hiopamd_linsolver_matrix_changed failed with status %d\n", rc);
+    std::abort();
+  }
+  return n_neg;   // -1: zero / non-finite pivot (or, in safe mode, a probe solve that did not converge): the reference's "singular" answer
 }
 
 bool hiopLinSolverSymDenseHipNative::solve(hiopVector& x)

@@ -6,14 +6,6 @@ namespace hiop
 {
 namespace
 {
-[[noreturn]] void hiopamd_not_in_path(const char* method)
-{
-  std::fprintf(stderr,
-               "hiop_amd: hiopMatrixSparseTripletHipNative::%s belongs to the sparse-NLP KKT assembly (hiopKKTLinSysSparse*), "
-               "which is outside the MDS / dense hot path of libhiopamd.so — no silent fallback, stopping.\n",
-               method);
-  std::abort();
-}
 const hiopMatrixSparseTripletHipNative& as_triplet(const hiopMatrix& M)
 {
   return dynamic_cast<const hiopMatrixSparseTripletHipNative&>(M);
@@ -250,58 +242,94 @@ void hiopMatrixSparseTripletHipNative::addSubDiagonal(int, const double&, const 
 void hiopMatrixSparseTripletHipNative::addSubDiagonal(int, int, const double&) { assert(false && "not needed / implemented"); }
 void hiopMatrixSparseTripletHipNative::addMatrix(double, const hiopMatrix&) { assert(false && "not needed"); }
 
-// ---- (3) ----
-void hiopMatrixSparseTripletHipNative::copyRowsFrom(const hiopMatrix&, const index_type*, size_type) { hiopamd_not_in_path("copyRowsFrom"); }
-void hiopMatrixSparseTripletHipNative::copySubDiagonalFrom(const index_type&, const size_type&, const hiopVector&, const index_type&, double)
+// ---- (3) the assembly surface (hiopMatrixSparseTriplet.cpp:216-250, :562-720, :790-922, :1042-1172): one C-ABI call each;
+// index arrays the caller hands in (rows_idxs, iJacS / jJacS / MJacS) are device arrays like every array of this mem-space ----
+void hiopMatrixSparseTripletHipNative::copyRowsFrom(const hiopMatrix& src_gen, const index_type* rows_idxs, size_type n_rows)
 {
-  hiopamd_not_in_path("copySubDiagonalFrom");
+  const auto& src = as_triplet(src_gen);
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_copy_rows_from(ctx_, iRow_, jCol_, values_, src.numberOfNonzeros(), src.i_row(), src.j_col(), src.M(), rows_idxs, n_rows));
 }
-void hiopMatrixSparseTripletHipNative::setSubDiagonalTo(const index_type&, const size_type&, const double&, const index_type&)
+void hiopMatrixSparseTripletHipNative::copySubDiagonalFrom(const index_type& start_on_dest_diag, const size_type& num_elems,
+                                                           const hiopVector& d_, const index_type& start_on_nnz_idx, double scal)
 {
-  hiopamd_not_in_path("setSubDiagonalTo");
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_copy_sub_diagonal_from(ctx_, iRow_, jCol_, values_, start_on_dest_diag, num_elems, d_.local_data_const(), start_on_nnz_idx, scal));
 }
-void hiopMatrixSparseTripletHipNative::copyRowsBlockFrom(const hiopMatrix&, const index_type&, const size_type&, const index_type&,
-                                                         const size_type&)
+void hiopMatrixSparseTripletHipNative::setSubDiagonalTo(const index_type& start_on_dest_diag, const size_type& num_elems,
+                                                        const double& c, const index_type& start_on_nnz_idx)
 {
-  hiopamd_not_in_path("copyRowsBlockFrom");
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_set_sub_diagonal_to(ctx_, iRow_, jCol_, values_, start_on_dest_diag, num_elems, c, start_on_nnz_idx));
 }
-void hiopMatrixSparseTripletHipNative::copySubmatrixFrom(const hiopMatrix&, const index_type&, const index_type&, const size_type&,
-                                                         const bool)
+void hiopMatrixSparseTripletHipNative::copyRowsBlockFrom(const hiopMatrix& src_gen, const index_type& rows_src_idx_st,
+                                                         const size_type& n_rows, const index_type& rows_dest_idx_st,
+                                                         const size_type& dest_nnz_st)
 {
-  hiopamd_not_in_path("copySubmatrixFrom");
+  const auto& src = as_triplet(src_gen);
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_copy_rows_block_from(ctx_, iRow_, jCol_, values_, src.numberOfNonzeros(), src.i_row(), src.j_col(), src.M(), rows_src_idx_st, n_rows, rows_dest_idx_st, dest_nnz_st));
 }
-void hiopMatrixSparseTripletHipNative::copySubmatrixFromTrans(const hiopMatrix&, const index_type&, const index_type&,
-                                                              const size_type&, const bool)
+void hiopMatrixSparseTripletHipNative::copySubmatrixFrom(const hiopMatrix& src_gen, const index_type& dest_row_st,
+                                                         const index_type& dest_col_st, const size_type& dest_nnz_st,
+                                                         const bool offdiag_only)
 {
-  hiopamd_not_in_path("copySubmatrixFromTrans");
+  const auto& src = as_triplet(src_gen);
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_copy_submatrix_from(ctx_, iRow_, jCol_, values_, src.numberOfNonzeros(), src.i_row(), src.j_col(), src.M(), dest_row_st, dest_col_st, dest_nnz_st, offdiag_only ? 1 : 0, 0));
 }
-void hiopMatrixSparseTripletHipNative::setSubmatrixToConstantDiag_w_colpattern(const double&, const index_type&, const index_type&,
-                                                                               const size_type&, const size_type&, const hiopVector&)
+void hiopMatrixSparseTripletHipNative::copySubmatrixFromTrans(const hiopMatrix& src_gen, const index_type& dest_row_st,
+                                                              const index_type& dest_col_st, const size_type& dest_nnz_st,
+                                                              const bool offdiag_only)
 {
-  hiopamd_not_in_path("setSubmatrixToConstantDiag_w_colpattern");
+  const auto& src = as_triplet(src_gen);
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_copy_submatrix_from(ctx_, iRow_, jCol_, values_, src.numberOfNonzeros(), src.i_row(), src.j_col(), src.M(), dest_row_st, dest_col_st, dest_nnz_st, offdiag_only ? 1 : 0, 1));
 }
-void hiopMatrixSparseTripletHipNative::setSubmatrixToConstantDiag_w_rowpattern(const double&, const index_type&, const index_type&,
-                                                                               const size_type&, const size_type&, const hiopVector&)
+void hiopMatrixSparseTripletHipNative::setSubmatrixToConstantDiag_w_colpattern(const double& scalar, const index_type& dest_row_st,
+                                                                               const index_type& dest_col_st, const size_type& dest_nnz_st,
+                                                                               const size_type& nnz_to_copy, const hiopVector& ix)
 {
-  hiopamd_not_in_path("setSubmatrixToConstantDiag_w_rowpattern");
+  (void)nnz_to_copy;
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_set_submatrix_to_constant_diag_w_pattern(ctx_, iRow_, jCol_, values_, scalar, dest_row_st, dest_col_st, dest_nnz_st, ix.get_local_size(), ix.local_data_const(), 0, nullptr));
 }
-void hiopMatrixSparseTripletHipNative::copyDiagMatrixToSubblock(const double&, const index_type&, const index_type&, const size_type&,
-                                                                const size_type&)
+void hiopMatrixSparseTripletHipNative::setSubmatrixToConstantDiag_w_rowpattern(const double& scalar, const index_type& dest_row_st,
+                                                                               const index_type& dest_col_st, const size_type& dest_nnz_st,
+                                                                               const size_type& nnz_to_copy, const hiopVector& ix)
 {
-  hiopamd_not_in_path("copyDiagMatrixToSubblock");
+  (void)nnz_to_copy;
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_set_submatrix_to_constant_diag_w_pattern(ctx_, iRow_, jCol_, values_, scalar, dest_row_st, dest_col_st, dest_nnz_st, ix.get_local_size(), ix.local_data_const(), 1, nullptr));
 }
-void hiopMatrixSparseTripletHipNative::copyDiagMatrixToSubblock_w_pattern(const hiopVector&, const index_type&, const index_type&,
-                                                                          const size_type&, const size_type&, const hiopVector&)
+void hiopMatrixSparseTripletHipNative::copyDiagMatrixToSubblock(const double& src_val, const index_type& dest_row_st,
+                                                                const index_type& dest_col_st, const size_type& dest_nnz_st,
+                                                                const size_type& nnz_to_copy)
 {
-  hiopamd_not_in_path("copyDiagMatrixToSubblock_w_pattern");
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_copy_diag_matrix_to_subblock(ctx_, iRow_, jCol_, values_, src_val, dest_row_st, dest_col_st, dest_nnz_st, nnz_to_copy));
 }
-void hiopMatrixSparseTripletHipNative::set_Jac_FR(const hiopMatrixSparse&, const hiopMatrixSparse&, int*, int*, double*)
+void hiopMatrixSparseTripletHipNative::copyDiagMatrixToSubblock_w_pattern(const hiopVector& x, const index_type& dest_row_st,
+                                                                          const index_type& dest_col_st, const size_type& dest_nnz_st,
+                                                                          const size_type& nnz_to_copy, const hiopVector& pattern)
 {
-  hiopamd_not_in_path("set_Jac_FR");
+  (void)nnz_to_copy;
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_copy_diag_matrix_to_subblock_w_pattern(ctx_, iRow_, jCol_, values_, x.local_data_const(), dest_row_st, dest_col_st, dest_nnz_st, pattern.get_local_size(), pattern.local_data_const(), nullptr));
 }
-void hiopMatrixSparseTripletHipNative::set_Hess_FR(const hiopMatrixSparse&, int*, int*, double*, const hiopVector&)
+void hiopMatrixSparseTripletHipNative::set_Jac_FR(const hiopMatrixSparse& Jac_c, const hiopMatrixSparse& Jac_d, int* iJacS, int* jJacS,
+                                                  double* MJacS)
 {
-  hiopamd_not_in_path("set_Hess_FR");
+  structure_changed();
+  hiopamd_ok(hiopamd_sp_set_jac_fr(ctx_, iRow_, jCol_, values_, Jac_c.n(), Jac_c.m(), Jac_c.numberOfNonzeros(), Jac_c.i_row(), Jac_c.j_col(), Jac_c.M(), Jac_d.m(), Jac_d.numberOfNonzeros(), Jac_d.i_row(), Jac_d.j_col(), Jac_d.M(), iJacS, jJacS, MJacS));
+}
+void hiopMatrixSparseTripletHipNative::set_Hess_FR(const hiopMatrixSparse& Hess, int* iHSS, int* jHSS, double* MHSS,
+                                                   const hiopVector& add_diag)
+{
+  // (the symmetric class owns the meaning of this method in the reference, hiopMatrixSparseTriplet.cpp:1374; the general
+  // triplet class only declares it, hiopMatrixSparseTriplet.hpp:247-255)
+  structure_changed();
+  hiopamd_ok(hiopamd_spsym_set_hess_fr(ctx_, iRow_, jCol_, values_, Hess.m(), Hess.numberOfNonzeros(), Hess.i_row(), Hess.j_col(), Hess.M(), add_diag.get_local_size(), add_diag.local_data_const(), iHSS, jHSS, MHSS));
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -143,10 +143,7 @@ void hiopVectorHipNative::copy_from_indexes(const double* src, const hiopVectorI
 }
 void hiopVectorHipNative::startingAtCopyFromStartingAt(int start_idx_dest, const hiopVector& v, int start_idx_src)
 {
-  int howmany = v.get_local_size() - start_idx_src;
-  const int howmany_max = n_local_ - start_idx_dest;
-  if(howmany > howmany_max) howmany = howmany_max;   // hiopVectorPar.cpp:241-251
-  if(howmany > 0) hiopamd_ok(hiopamd_vec_copy(C_, howmany, data_ + start_idx_dest, dev(v) + start_idx_src));
+  hiopamd_ok(hiopamd_vec_starting_at_copy_from_starting_at(C_, data_, N_, start_idx_dest, dev(v), v.get_local_size(), start_idx_src));
 }
 void hiopVectorHipNative::copyTo(double* dest) const { hiopamd_ok(hiopamd_vec_copy(C_, N_, dest, data_)); }
 void hiopVectorHipNative::copy_to_vectorpar(hiopVectorPar& vdest) const
@@ -185,13 +182,7 @@ void hiopVectorHipNative::copy_to_two_vec_w_pattern(hiopVector& c, const hiopVec
 void hiopVectorHipNative::startingAtCopyToStartingAt(index_type start_idx_in_src, hiopVector& dest, index_type start_idx_dest,
                                                      size_type num_elems) const
 {
-  if(num_elems < 0) {
-    num_elems = n_local_ - start_idx_in_src;
-  } else {
-    if(num_elems > n_local_ - start_idx_in_src) num_elems = n_local_ - start_idx_in_src;   // hiopVectorPar.cpp:409-420
-  }
-  if(num_elems > dest.get_local_size() - start_idx_dest) num_elems = dest.get_local_size() - start_idx_dest;
-  if(num_elems > 0) hiopamd_ok(hiopamd_vec_copy(C_, num_elems, dev(dest) + start_idx_dest, data_ + start_idx_in_src));
+  hiopamd_ok(hiopamd_vec_starting_at_copy_to_starting_at(C_, data_, N_, start_idx_in_src, dev(dest), dest.get_local_size(), start_idx_dest, num_elems));
 }
 void hiopVectorHipNative::startingAtCopyToStartingAt_w_pattern(index_type start_idx_in_src, hiopVector& dest,
                                                                index_type start_idx_dest, const hiopVector& selec_dest,

@@ -23,6 +23,7 @@ SOURCES = [
     "vector_kernels.hip",
     "dense_kernels.hip",
     "sparse_kernels.hip",
+    "sparse_assembly.hip",
     "csr_condensed.hip",
     "kkt_sparse.hip",
     "gram.hip",

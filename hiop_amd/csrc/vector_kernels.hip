@@ -624,4 +624,43 @@ int hiopamd_vec_starting_at_copy_to_starting_at_w_pattern(hiopamd_ctx* ctx, cons
   return HIOPAMD_OK;
 }
 
+// ---- hiopVectorInt (src/LinAlg/hiopVectorInt.hpp:64-118, hiopVectorIntSeq.cpp): int32 index vectors of the same mem-space ----
+int hiopamd_ivec_set_to_constant(hiopamd_ctx* ctx, int64_t n, int* x, int c)                                    // :103, :106
+{
+  if(n < 0) return HIOPAMD_ERR_ARG;
+  return launch_ew(ctx, n, [=] __device__(int64_t i) { x[i] = c; });
+}
+int hiopamd_ivec_linspace(hiopamd_ctx* ctx, int64_t n, int* x, int i0, int di)                                  // :117
+{
+  if(n < 0) return HIOPAMD_ERR_ARG;
+  return launch_ew(ctx, n, [=] __device__(int64_t i) { x[i] = i0 + (int)i * di; });
+}
+int hiopamd_ivec_copy(hiopamd_ctx* ctx, int64_t n, int* dst, const int* src)                                    // :83 (copy_from)
+{
+  if(n < 0) return HIOPAMD_ERR_ARG;
+  return launch_ew(ctx, n, [=] __device__(int64_t i) { dst[i] = src[i]; });
+}
+
+// ---- the two sub-range copies of hiopVector whose bounds are clamped (hiopVectorPar.cpp:241-251, :409-420): the clamping is
+// part of the method's contract, so it lives here and not in the HiOp-side adapter ----
+int hiopamd_vec_starting_at_copy_from_starting_at(hiopamd_ctx* ctx, double* dest, int64_t n_dest, int64_t start_idx_dest,
+                                                  const double* src, int64_t n_src, int64_t start_idx_src)
+{
+  if(start_idx_dest < 0 || start_idx_src < 0 || start_idx_dest > n_dest || start_idx_src > n_src) return HIOPAMD_ERR_ARG;
+  int64_t howmany = n_src - start_idx_src;
+  const int64_t howmany_max = n_dest - start_idx_dest;
+  if(howmany > howmany_max) howmany = howmany_max;
+  if(howmany <= 0) return HIOPAMD_OK;
+  return hiopamd_vec_copy(ctx, howmany, dest + start_idx_dest, src + start_idx_src);
+}
+int hiopamd_vec_starting_at_copy_to_starting_at(hiopamd_ctx* ctx, const double* src, int64_t n_src, int64_t start_idx_in_src,
+                                                double* dest, int64_t n_dest, int64_t start_idx_dest, int64_t num_elems)
+{
+  if(start_idx_in_src < 0 || start_idx_dest < 0 || start_idx_in_src > n_src || start_idx_dest > n_dest) return HIOPAMD_ERR_ARG;
+  if(num_elems < 0 || num_elems > n_src - start_idx_in_src) num_elems = n_src - start_idx_in_src;
+  if(num_elems > n_dest - start_idx_dest) num_elems = n_dest - start_idx_dest;
+  if(num_elems <= 0) return HIOPAMD_OK;
+  return hiopamd_vec_copy(ctx, num_elems, dest + start_idx_dest, src + start_idx_in_src);
+}
+
 }  // extern "C"

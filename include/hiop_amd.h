@@ -170,6 +170,16 @@ int hiopamd_vec_isfinite(hiopamd_ctx*, int64_t n, const double* x, int* out_host
 int hiopamd_vec_num_elems_less_than(hiopamd_ctx*, int64_t n, const double* x, double val, int64_t* out_host);     /* :1222 */
 int hiopamd_vec_num_elems_abs_less_than(hiopamd_ctx*, int64_t n, const double* x, double val, int64_t* out_host); /* :1241 */
 int hiopamd_vec_is_equal(hiopamd_ctx*, int64_t n, const double* x, const double* y, int* out_host);      /* :1283 */
+/* startingAtCopyFromStartingAt (:241-251) / startingAtCopyToStartingAt (:409-420) with the reference's clamping of the count
+ * (num_elems < 0: everything from start_idx_in_src on) */
+int hiopamd_vec_starting_at_copy_from_starting_at(hiopamd_ctx*, double* dest, int64_t n_dest, int64_t start_idx_dest,
+                                                  const double* src, int64_t n_src, int64_t start_idx_src);
+int hiopamd_vec_starting_at_copy_to_starting_at(hiopamd_ctx*, const double* src, int64_t n_src, int64_t start_idx_in_src,
+                                                double* dest, int64_t n_dest, int64_t start_idx_dest, int64_t num_elems);
+/* hiopVectorInt of the same mem-space (src/LinAlg/hiopVectorInt.hpp:64-118): int32 device arrays (hiopamd_alloc) */
+int hiopamd_ivec_set_to_constant(hiopamd_ctx*, int64_t n, int* x, int c);          /* set_to_zero :103, set_to_constant :106 */
+int hiopamd_ivec_linspace(hiopamd_ctx*, int64_t n, int* x, int i0, int di);        /* :117 */
+int hiopamd_ivec_copy(hiopamd_ctx*, int64_t n, int* dst, const int* src);          /* copy_from :83 (device source) */
 /* fused step-length kernel used by hiopIterate::fractionToTheBdry (src/Optimization/hiopIterate.cpp:330-365):
  * `k` (x,d,select) triples reduced in ONE launch; out_host[0] = min over all. */
 int hiopamd_vec_fraction_to_the_bdry_multi(hiopamd_ctx*, int k, const int64_t* n_host, const double* const* x_host,
@@ -291,6 +301,40 @@ int hiopamd_sp_indexes_ordered(hiopamd_ctx*, int nnz, const int* iRow, const int
 int hiopamd_sp_num_offdiag(hiopamd_ctx*, int nnz, const int* iRow, const int* jCol, int64_t* out_host);        /* :1171,:1338 */
 int hiopamd_sp_extract_diagonal(hiopamd_ctx*, int n, int nnz, const int* iRow, const int* jCol, const double* val,
                                 double* diag);                                                                /* :1355 */
+
+/* ---- the triplet ASSEMBLY surface (big triplet matrices out of small ones: sparse KKT classes, feasibility restoration);
+ * reference src/LinAlg/hiopMatrixSparseTriplet.cpp, line of each method on the right.  `iRow, jCol, val` = the destination's
+ * triplet arrays (device); sources must be sorted by (row, column) like hiopMatrixSparseTriplet keeps them. ---- */
+int hiopamd_sp_copy_sub_diagonal_from(hiopamd_ctx*, int* iRow, int* jCol, double* val, int start_on_dest_diag, int num_elems,
+                                      const double* d, int start_on_nnz_idx, double scal);                         /* :216 */
+int hiopamd_sp_set_sub_diagonal_to(hiopamd_ctx*, int* iRow, int* jCol, double* val, int start_on_dest_diag, int num_elems,
+                                   double c, int start_on_nnz_idx);                                                /* :235 */
+int hiopamd_sp_copy_rows_from(hiopamd_ctx*, int* iRow, int* jCol, double* val, int nnz_src, const int* iRow_src,
+                              const int* jCol_src, const double* val_src, const int* rows_idxs_dev, int n_rows);   /* :562 */
+int hiopamd_sp_copy_rows_block_from(hiopamd_ctx*, int* iRow, int* jCol, double* val, int nnz_src, const int* iRow_src,
+                                    const int* jCol_src, const double* val_src, int rows_src_idx_st, int n_rows,
+                                    int rows_dest_idx_st, int dest_nnz_st);                                        /* :619 */
+int hiopamd_sp_copy_diag_matrix_to_subblock(hiopamd_ctx*, int* iRow, int* jCol, double* val, double src_val, int dest_row_st,
+                                            int dest_col_st, int dest_nnz_st, int nnz_to_copy);                    /* :671 */
+int hiopamd_sp_copy_diag_matrix_to_subblock_w_pattern(hiopamd_ctx*, int* iRow, int* jCol, double* val, const double* dx,
+                                                      int dest_row_st, int dest_col_st, int dest_nnz_st, int n,
+                                                      const double* ix, int* nnz_found_host /* may be null */);   /* :689 */
+/* trans = 0: copySubmatrixFrom (:1042); trans = 1: copySubmatrixFromTrans (:1076) */
+int hiopamd_sp_copy_submatrix_from(hiopamd_ctx*, int* iRow, int* jCol, double* val, int nnz_src, const int* iRow_src,
+                                   const int* jCol_src, const double* val_src, int dest_row_st, int dest_col_st,
+                                   int dest_nnz_st, int offdiag_only, int trans);
+/* rowpattern = 0: setSubmatrixToConstantDiag_w_colpattern (:1110); 1: ..._w_rowpattern (:1140) */
+int hiopamd_sp_set_submatrix_to_constant_diag_w_pattern(hiopamd_ctx*, int* iRow, int* jCol, double* val, double scalar,
+                                                        int dest_row_st, int dest_col_st, int dest_nnz_st, int n,
+                                                        const double* ix, int rowpattern, int* nnz_found_host);
+/* this = [Jc -I I 0 0; Jd 0 0 -I I]; iJacS / jJacS (both or none) and MJacS (device, may be null) are filled alongside */
+int hiopamd_sp_set_jac_fr(hiopamd_ctx*, int* iRow, int* jCol, double* val, int n, int m_c, int nnz_c, const int* ic,
+                          const int* jc, const double* vc, int m_d, int nnz_d, const int* id, const int* jd, const double* vd,
+                          int* iJacS, int* jJacS, double* MJacS);                                                  /* :790 */
+/* hiopMatrixSymSparseTriplet::set_Hess_FR: diagonal add_diag merged into / inserted in front of every row's entries */
+int hiopamd_spsym_set_hess_fr(hiopamd_ctx*, int* iRow, int* jCol, double* val, int m_h, int nnz_h, const int* ih,
+                              const int* jh, const double* vh, int n_diag, const double* add_diag, int* iHSS, int* jHSS,
+                              double* MHSS);                                                                       /* :1374 */
 
 /* =====================================================================================
  * Sparse condensed KKT matrix in CSR (first piece):

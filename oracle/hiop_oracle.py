@@ -860,3 +860,132 @@ class KKTLinSysLowRank:
         rx2 = rx - J.T @ sol                                      # :1178
         dx = H.solve(rx2)                                         # :1180
         return ierr == 0, dx, dyc, dyd
+
+
+# =====================================================================================
+# hiopMatrixSparseTriplet — the ASSEMBLY surface (reference: src/LinAlg/hiopMatrixSparseTriplet.cpp).
+# A triplet matrix here is a tuple of three numpy arrays (iRow, jCol, val) modified in place; sources are sorted by
+# (row, column).  The loops follow the reference statement by statement (small sizes only).
+# =====================================================================================
+def sp_copy_sub_diagonal_from(T, start_on_dest_diag, num_elems, d, start_on_nnz_idx, scal=1.0):      # :216-233
+    i, j, v = T
+    for r in range(num_elems):
+        i[r + start_on_nnz_idx] = j[r + start_on_nnz_idx] = r + start_on_dest_diag
+        v[r + start_on_nnz_idx] = scal * d[r]
+
+
+def sp_set_sub_diagonal_to(T, start_on_dest_diag, num_elems, c, start_on_nnz_idx):                    # :235-249
+    i, j, v = T
+    for r in range(num_elems):
+        i[r + start_on_nnz_idx] = j[r + start_on_nnz_idx] = r + start_on_dest_diag
+        v[r + start_on_nnz_idx] = c
+
+
+def sp_copy_rows_from(T, S, rows_idxs):                                                               # :562-611
+    i, j, v = T
+    si, sj, sv = S
+    its, itd = 0, 0
+    for row_dest, row_src in enumerate(rows_idxs):
+        while its < si.size and si[its] < row_src:
+            its += 1
+        while its < si.size and si[its] == row_src:
+            i[itd], j[itd], v[itd] = row_dest, sj[its], sv[its]
+            itd += 1
+            its += 1
+    return itd
+
+
+def sp_copy_rows_block_from(T, S, rows_src_idx_st, n_rows, rows_dest_idx_st, dest_nnz_st):            # :619-669
+    i, j, v = T
+    si, sj, sv = S
+    its, itd = 0, dest_nnz_st
+    for row_add in range(n_rows):
+        row_src, row_dest = rows_src_idx_st + row_add, rows_dest_idx_st + row_add
+        while its < si.size and si[its] < row_src:
+            its += 1
+        while its < si.size and si[its] == row_src:
+            i[itd], j[itd], v[itd] = row_dest, sj[its], sv[its]
+            itd += 1
+            its += 1
+    return itd
+
+
+def sp_copy_diag_matrix_to_subblock(T, src_val, dest_row_st, col_dest_st, dest_nnz_st, nnz_to_copy):  # :671-687
+    i, j, v = T
+    for e in range(nnz_to_copy):
+        i[dest_nnz_st + e], j[dest_nnz_st + e], v[dest_nnz_st + e] = dest_row_st + e, col_dest_st + e, src_val
+
+
+def sp_copy_diag_matrix_to_subblock_w_pattern(T, dx, dest_row_st, dest_col_st, dest_nnz_st, ix):      # :689-719
+    i, j, v = T
+    k, found = dest_nnz_st, 0
+    for q in range(ix.size):
+        if ix[q] != 0.0:
+            i[k], j[k], v[k] = dest_row_st + found, dest_col_st + found, dx[q]
+            k += 1
+            found += 1
+    return found
+
+
+def sp_copy_submatrix_from(T, S, dest_row_st, dest_col_st, dest_nnz_st, offdiag_only=False, trans=False):   # :1042-1108
+    i, j, v = T
+    si, sj, sv = (S[1], S[0], S[2]) if trans else S
+    k = dest_nnz_st
+    for q in range(si.size):
+        if offdiag_only and si[q] == sj[q]:
+            continue
+        i[k], j[k], v[k] = dest_row_st + si[q], dest_col_st + sj[q], sv[q]
+        k += 1
+    return k
+
+
+def sp_set_submatrix_to_constant_diag_w_pattern(T, scalar, dest_row_st, dest_col_st, dest_nnz_st, ix, rowpattern):   # :1110-1168
+    i, j, v = T
+    k, found = dest_nnz_st, 0
+    for q in range(ix.size):
+        if ix[q] != 0.0:
+            i[k] = dest_row_st + (found if rowpattern else q)
+            j[k] = dest_col_st + (q if rowpattern else found)
+            v[k] = scalar
+            k += 1
+            found += 1
+    return found
+
+
+def sp_set_jac_fr(T, n, Jc, m_c, Jd, m_d):                                                            # :790-922
+    """this = [Jc -I I 0 0; Jd 0 0 -I I]; returns the number of entries written."""
+    i, j, v = T
+    k = 0
+    for (si, sj, sv), m, row0, colp in ((Jc, m_c, 0, n), (Jd, m_d, m_c, n + 2 * m_c)):
+        for r in range(m):
+            for q in np.nonzero(si == r)[0]:
+                i[k], j[k], v[k] = r + row0, sj[q], sv[q]
+                k += 1
+            i[k], j[k], v[k] = r + row0, colp + r, -1.0
+            k += 1
+            i[k], j[k], v[k] = r + row0, colp + m + r, 1.0
+            k += 1
+    return k
+
+
+def spsym_set_hess_fr(T, H, m_h, add_diag):                                                           # :1374-1497
+    i, j, v = T
+    hi, hj, hv = H
+    k = 0
+    if m_h > 0:
+        for r in range(m_h):
+            rows = np.nonzero(hi == r)[0]
+            i[k], j[k], v[k] = r, r, add_diag[r]
+            q0 = 0
+            if rows.size and hi[rows[0]] == hj[rows[0]]:
+                v[k] += hv[rows[0]]
+                q0 = 1
+            k += 1
+            for q in rows[q0:]:
+                i[k], j[k], v[k] = r, hj[q], hv[q]
+                k += 1
+    else:
+        for r in range(add_diag.size):
+            i[k], j[k], v[k] = r, r, add_diag[r]
+            k += 1
+    return k
