@@ -6,7 +6,7 @@ mkdir -p gpurun_out/r03_2
 export TMPDIR=/tmp
 O=gpurun_out/r03_2
 echo "=== pytest -m gpu (all) ==="
-timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 > $O/pytest.log 2>&1; echo "pytest exit $?"; tail -30 $O/pytest.log
+timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest exit $?"; tail -30 $O/pytest.log
 echo "=== factor + 3 solves ==="
 DF_TIMELINE=0 timeout -s KILL 180 python scripts/df_stamps.py 2>&1 | tail -2
 HIOPAMD_SOLVE_LEAD=3 DF_TIMELINE=0 timeout -s KILL 180 python scripts/df_stamps.py 2>&1 | tail -2 | head -1

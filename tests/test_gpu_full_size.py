@@ -119,10 +119,10 @@ def test_dense_lowrank_full_size_properties(ctx, case):
     # ---- (4) the secant update with an unchanged Jacobian: the Jacobian term of y_new vanishes exactly (fused difference
     # pass), so the stored pair is (x_new - x_old, g_new - g_old)
     x2 = x + U(n, lo=-0.05, hi=0.05)
-    torch.cuda.synchronize()
-    gx_prev = q * x
-    H.update(x, gx_prev, Jc, Jd, yc, yd); ctx.sync()      # (x may repeat the last iterate: then nothing is stored)
-    assert H.update(x2, q * x2, Jc, Jd, yc, yd); ctx.sync()
+    gx_prev, gx2 = q * x, q * x2
+    torch.cuda.synchronize()                               # torch's stream -> the context's stream
+    H.update(x, gx_prev, Jc, Jd, yc, yd); ctx.sync()
+    assert H.update(x2, gx2, Jc, Jd, yc, yd); ctx.sync()
     S2, Y2 = H.St(), H.Yt()
-    assert torch.equal(S2[-1], x2 - x) and torch.equal(Y2[-1], q * x2 - gx_prev)
+    assert torch.equal(S2[-1], x2 - x) and torch.equal(Y2[-1], gx2 - gx_prev)
     K.close(); H.close()
