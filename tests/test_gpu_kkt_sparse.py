@@ -109,7 +109,7 @@ def test_full_space_layer_on_the_sparse_condensed_backend(ctx, n):
     it_g, r_g = fg.pack(it, kf.ITER_PARTS), fg.pack(res, kf.RESID_PARTS)
     fo.perturb.set_mu(1e-2); fg.set_mu(1e-2)
     assert fo.update(it) and fg.update(it_g)
-    assert fg.num_refact() == fo.num_refact
+    assert fg.num_refact == fo.num_refact
     d_g = torch.zeros(fg.dim, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     assert fg.compute_directions(r_g, d_g); ctx.sync()
