@@ -1,0 +1,285 @@
+"""TEST INFRASTRUCTURE ONLY — restatement of the reference's Newton filter line-search interior-point loop,
+hiopAlgFilterIPMNewton::run (src/Optimization/hiopAlgFilterIPM.cpp:2101-2770), on top of the full-space layer
+(oracle/kkt_full.py) and the iterate/residual steps (oracle/ipm_slab.py).  Written so that the KKT systems the loop
+produces can be compared with the systems the reference itself wrote (`write_kkt yes`): the purpose is to pin the
+oracle's KKT rows (SURVEY.md §8 a/f1) on the reference's OWN trajectory, iteration by iteration, not only at x0.
+
+What is restated (reference line per block below): the bounds relaxation of hiopBoundsRelaxer::relax, startingProcedure
+with `duals_init zero`, evalNlpAndLogErrors (the sd / sc scaling), checkTermination, update_log_barrier_params, the
+filter (hiopFilter) and accept_line_search_conditions, the backtracking loop with compute_safe_slacks, the post
+line-search filter augmentation, hiopDualsNewtonLinearUpdate::go.
+What is NOT restated (and raises if reached): second-order correction, feasibility restoration, the safe-mode switch of
+the linear solver, elastic mode, NLP scaling (the example problems' gradients at x0 are below scaling_max_grad = 100).
+
+The loop is written against an `ops` object so the same driver runs the numpy restatements (FilterOracleOps) and the
+device operations of the GPU tests.
+
+Parity pin: tests/test_oracle_reference_trajectory.py — with the MdsEx1 driver's options (NlpMdsEx1Driver.cpp:130-139) the
+KKT matrices of iterations 0, 5 and 10 equal the matrices in tests/golden/kkt_linsys_{0,5,10}.iajaaa, the first
+right-hand side of each equals the file's, the run takes the reference's 14 factorizations, and the final objective of
+MdsEx1(400, 100) equals the driver's stored -selfcheck value to 1e-6 relative."""
+import numpy as np
+
+from . import hiop_oracle as ho
+from . import ipm_slab as osl
+
+# option defaults, src/Utils/hiopOptions.cpp:560-720
+DEFAULTS = dict(mu0=1.0, tolerance=1e-8, kappa_mu=0.2, theta_mu=1.5, kappa_eps=10.0, tau_min=0.99, kappa1=1e-2, kappa2=1e-2,
+                smax=100.0, kappa_d=1e-5, eta_phi=1e-8, gamma_theta=1e-5, gamma_phi=1e-8, s_theta=1.1, s_phi=2.3, delta=1.0,
+                theta_max_fact=1e4, theta_min_fact=1e-4, dual_tol=1.0, cons_tol=1e-4, comp_tol=1e-4, rel_tolerance=0.0,
+                acceptable_tolerance=1e-6, acceptable_iterations=10, max_iter=3000, min_step_size=1e-16, kappa_Sigma=1e10,
+                bound_relax_perturb=1e-8)
+
+
+def relax_bounds(xl, xu, dl, du, rel):
+    """hiopBoundsRelaxer::relax (src/Optimization/hiopNlpTransforms.cpp:366-389): every entry, 'infinite' ones included
+    (they stay beyond +-1e20)."""
+    r = lambda b, s: b + s * rel * np.maximum(np.abs(b), 1.0)
+    return r(xl, -1.0), r(xu, 1.0), r(dl, -1.0), r(du, 1.0)
+
+
+class Filter:                                                       # src/Optimization/hiopFilter.hpp:60-75, .cpp:55-68
+    def __init__(self):
+        self.entries = []
+
+    def initialize(self, theta_max):
+        self.entries = [(theta_max, -1e20)]
+
+    def add(self, theta, phi):
+        self.entries.insert(0, (theta, phi))
+
+    def contains(self, theta, phi):
+        return any(theta >= t and phi >= p for t, p in self.entries)
+
+
+class FilterOracleOps:
+    """numpy operations of one iteration; `model(x)` -> f, grad, c, d (constant Jacobians / Hessian in the provider)."""
+
+    def __init__(self, full, bounds, model, kappa_d=1e-5, kappa_sigma=1e10):
+        self.full, self.bounds, self.model = full, bounds, model
+        self.kappa_d, self.kappa_sigma = kappa_d, kappa_sigma
+        p = full.p
+        self.n_complem = int(full.ixl.sum() + full.ixu.sum() + full.idl.sum() + full.idu.sum())   # hiopNlpFormulation.hpp:244
+        self.m = p.nyc + p.nyd
+
+    # ---- startingProcedure (hiopAlgFilterIPM.cpp:290-425), duals_init = zero, no warm start
+    def start(self, x0, mu0, kappa1, kappa2):
+        full = self.full
+        xl, xu, dl, du, _ = self.bounds
+        x = x0.copy()
+        ho.project_into_bounds(x, xl, full.ixl, xu, full.ixu, kappa1, kappa2)          # :355
+        d = self.model(x)[3].copy()                                                    # :362, :374
+        ho.project_into_bounds(d, dl, full.idl, du, full.idu, kappa1, kappa2)          # :378
+        p = full.p
+        it = {"x": x, "d": d, "yc": np.zeros(p.nyc), "yd": np.zeros(p.nyd)}
+        for k in ("sxl", "sxu", "zl", "zu"):
+            it[k] = np.zeros(p.nx)
+        for k in ("sdl", "sdu", "vl", "vu"):
+            it[k] = np.zeros(p.nd)
+        osl.determine_slacks(full, it, self.bounds)                                    # :380 compute_safe_slacks
+        if osl.adjust_small_slacks(full, it, it, self.bounds, mu0) > 0:
+            raise NotImplementedError("adjust_bounds at the starting point")
+        it["zl"], it["zu"], it["vl"], it["vu"] = full.ixl.copy(), full.ixu.copy(), full.idl.copy(), full.idu.copy()   # :390
+        return it
+
+    def copy(self, it):
+        return {k: v.copy() for k, v in it.items()}
+
+    def primal(self, it):
+        return it["x"].copy()
+
+    def evaluate(self, it):
+        return self.model(it["x"])
+
+    def residual(self, it, ev, mu):
+        self.full.it = it
+        r, n = osl.residual_update(self.full, it, ev[2], ev[3], ev[1], self.bounds, mu, self.kappa_d)
+        return r, n
+
+    def dual_norms(self, it):                                                          # hiopIterate.cpp:239-257
+        bnd = ho.onenorm(it["zl"]) + ho.onenorm(it["zu"]) + ho.onenorm(it["vl"]) + ho.onenorm(it["vu"])
+        return ho.onenorm(it["yc"]) + ho.onenorm(it["yd"]), bnd
+
+    def logbar(self, it, f, mu):                                                       # hiopLogBarProblem.hpp:94-113, :128-129
+        v = f - mu * osl.eval_log_barrier(self.full, it)
+        if self.kappa_d > 0:
+            v += osl.linear_damping_term(self.full, it, mu, self.kappa_d)
+        return float(v)
+
+    def grad_phi_dx(self, it, dr, grad_f, mu):                                         # hiopLogBarProblem.hpp:91-117, :149-156
+        full = self.full
+        gx = grad_f.copy()
+        gd = np.zeros_like(it["d"])
+        ho.add_log_barrier_grad(gx, -mu, it["sxl"], full.ixl)                          # hiopIterate.cpp:539-550
+        ho.add_log_barrier_grad(gx, mu, it["sxu"], full.ixu)
+        ho.add_log_barrier_grad(gd, -mu, it["sdl"], full.idl)
+        ho.add_log_barrier_grad(gd, mu, it["sdu"], full.idu)
+        if self.kappa_d > 0:
+            ho.add_linear_damping_term(gx, full.ixl, full.ixu, 1.0, self.kappa_d * mu)  # hiopIterate.cpp:568-588
+            ho.add_linear_damping_term(gd, full.idl, full.idu, 1.0, self.kappa_d * mu)
+        return float(dr["x"] @ gx + dr["d"] @ gd)
+
+    def kkt_update(self, it, mu):
+        self.full.perturb.set_mu(mu)
+        self.mu = mu
+        return self.full.update(it)
+
+    def directions(self, resid):
+        ok, d, info = self.full.compute_directions_w_IR(resid, self.mu)
+        return ok, d
+
+    def fraction_to_the_bdry(self, it, d, tau):
+        return osl.fraction_to_the_bdry(self.full, it, d, tau)
+
+    def trial_primals(self, it, d, ap, ad, mu):                                        # :2527-2528
+        trial = osl.take_step(it, d, ap, ad, primals=True, duals=False)
+        osl.determine_slacks(self.full, trial, self.bounds)                            # compute_safe_slacks, hiopIterate.cpp:293-304
+        nadj = osl.adjust_small_slacks(self.full, trial, it, self.bounds, mu)
+        return trial, nadj
+
+    def theta(self, it, c, d):                                                         # hiopResidual.cpp:101-115
+        return ho.onenorm(self.bounds[4] - c) + ho.onenorm(it["d"] - d)
+
+    def duals_update(self, it, trial, d, ap, ad, mu):                                  # hiopDualsUpdater.hpp:412-431
+        out = osl.take_step(it, d, ap, ad, primals=False, duals=True, out=trial)
+        osl.adjust_duals_plh(self.full, out, mu, self.kappa_sigma)
+        return out
+
+    def n_refactorizations(self):
+        return self.full.num_refact
+
+
+def _errors(ops, it, norms, o):
+    """evalNlpAndLogErrors, hiopAlgFilterIPM.cpp:636-712."""
+    eq, bou = ops.dual_norms(it)
+    n, m = ops.n_complem, ops.m
+    smax = o["smax"]
+    sd = min(max(smax, (bou + eq) / (n + m)) / smax, 1e8)
+    sc = 0.0 if n == 0 else min(max(smax, bou / n) / smax, 1e8)
+    e = dict(optim=norms["nrmInf_nlp_optim"], feas=norms["nrmInf_nlp_feasib"], complem=norms["nrmInf_nlp_complem"],
+             cons_violation=norms["nrmInf_cons_violation"])
+    e["nlp"] = max(e["optim"] / sd, e["cons_violation"], e["complem"] / sc)
+    e["log"] = max(norms["nrmInf_bar_optim"] / sd, e["cons_violation"], norms["nrmInf_bar_complem"] / sc)
+    return e
+
+
+def solve(ops, x0, on_kkt=None, table=None, **options):
+    """Returns dict(x, obj, iters, status, n_fact).  `on_kkt(iter_num, it, mu, resid)` is called after every successful
+    kkt update (the point at which the reference writes kkt_linsys_<iter>.iajaaa, hiopKKTLinSysCompressedMDSXYcYd via
+    hiopKKTLinSys.cpp `write_linsys_counter_`)."""
+    o = dict(DEFAULTS)
+    o.update(options)
+    eps_tol = o["tolerance"]
+    mu = o["mu0"]
+    tau = max(o["tau_min"], 1.0 - mu)                                   # hiopAlgFilterIPM.cpp:255 reload_options
+    it = ops.start(x0, mu, o["kappa1"], o["kappa2"])
+    ev = ops.evaluate(it)
+    f_logbar = ops.logbar(it, ev[0], mu)                                # :2145
+    resid, norms = ops.residual(it, ev, mu)                             # :2148
+    theta_max = o["theta_max_fact"] * max(1.0, norms["nrmOne_nlp_feasib"])   # :2157-2158
+    theta_min = o["theta_min_fact"] * max(1.0, norms["nrmOne_nlp_feasib"])
+    filt = Filter()                                                     # cleared, :287; (re)initialized only at mu updates
+    iter_num = 0
+    ap = ad = 0.0
+    e0 = None
+    n_accep = 0
+    n_fact = 0
+    ls_status, ls_num = -1, 0
+    status = "pending"
+    while True:
+        e = _errors(ops, it, norms, o)                                  # :2219
+        if table is not None:
+            table.append(dict(iter=iter_num, objective=float(ev[0]), inf_pr=float(e["feas"]), inf_du=float(e["optim"]), mu=float(mu),
+                              alpha_du=float(ad), alpha_pr=float(ap), ls=ls_status, ls_num=ls_num))
+        if e0 is None:
+            e0 = e
+        # ---- checkTermination, :814-845
+        if e["nlp"] <= eps_tol and e["optim"] <= o["dual_tol"] and e["cons_violation"] <= o["cons_tol"] and e["complem"] <= o["comp_tol"]:
+            status = "Solve_Success"
+            break
+        if iter_num >= o["max_iter"]:
+            status = "Max_Iter_Exceeded"
+            break
+        rt = o["rel_tolerance"]
+        if rt > 0 and e["optim"] <= rt * e0["optim"] and e["feas"] <= rt * e0["feas"] and \
+                e["complem"] <= max(rt, 1e-6) * min(1.0, e0["complem"]):
+            status = "Solve_Success_RelTol"
+            break
+        n_accep = n_accep + 1 if e["nlp"] <= o["acceptable_tolerance"] else 0
+        if n_accep >= o["acceptable_iterations"]:
+            status = "Solve_Acceptable_Level"
+            break
+        # ---- barrier update, :2291-2328 with update_log_barrier_params :556-567
+        while e["log"] <= o["kappa_eps"] * mu:
+            new_mu = max(0.0, min(o["kappa_mu"] * mu, mu ** o["theta_mu"]))
+            new_mu = max(new_mu, min(eps_tol, o["comp_tol"]) / (10.0 + 1.0))
+            if abs(new_mu - mu) < 1e-16:
+                break
+            mu = new_mu
+            tau = max(o["tau_min"], 1.0 - mu)
+            f_logbar = ops.logbar(it, ev[0], mu)
+            resid, norms = ops.residual(it, ev, mu)
+            e = _errors(ops, it, norms, o)
+            filt.initialize(theta_max)                                  # :2321
+        # ---- search direction, :2333-2462 (linsol_mode = stable semantics of the layer: no mode switch restated)
+        if not ops.kkt_update(it, mu):
+            raise RuntimeError("KKT update failed (inertia correction exhausted)")
+        n_fact += 1 + ops.n_refactorizations()
+        if on_kkt is not None:
+            on_kkt(iter_num, it, mu, resid)
+        ok, dr = ops.directions(resid)
+        if not ok:
+            raise RuntimeError("compute_directions_w_IR failed")
+        # ---- backtracking line search, :2477-2588
+        ap, ad = ops.fraction_to_the_bdry(it, dr, tau)
+        theta = norms["nrmOne_nlp_feasib"]                              # resid->get_theta()
+        ls_status, ls_num = 0, 0
+        gpd = None
+        ini_step = True
+        while True:
+            if not ini_step and ap < o["min_step_size"]:
+                raise NotImplementedError("minimum step size reached (feasibility restoration is not restated)")
+            trial, nadj = ops.trial_primals(it, dr, ap, ad, mu)
+            ev_t = ops.evaluate(trial)                                  # functions only in the reference
+            f_logbar_trial = ops.logbar(trial, ev_t[0], mu)
+            theta_trial = ops.theta(trial, ev_t[2], ev_t[3])
+            ls_num += 1
+            # accept_line_search_conditions, :2852-2944
+            suff = theta_trial <= (1 - o["gamma_theta"]) * theta or f_logbar_trial <= f_logbar - o["gamma_phi"] * theta
+            if theta >= theta_min:
+                ls_status = 1 if suff else 0
+            else:
+                if gpd is None:
+                    gpd = ops.grad_phi_dx(it, dr, ev[1], mu)
+                if gpd < 0.0 and ap * (-gpd) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]:
+                    ls_status = 3 if f_logbar_trial <= f_logbar + o["eta_phi"] * ap * gpd else 0
+                else:
+                    ls_status = 2 if suff else 0
+            if ls_status > 0 and filt.contains(theta_trial, f_logbar_trial):
+                ls_status = 0
+            if ls_status > 0:
+                break
+            if ini_step and theta <= theta_trial:
+                raise NotImplementedError("second-order correction is not restated")       # :2561-2579
+            ap *= 0.5
+            ini_step = False
+        if nadj > 0:
+            raise NotImplementedError("adjust_bounds after small slacks")                   # :2592-2603
+        # ---- filter augmentation, :2616-2653
+        if ls_status == 1:
+            if gpd is None:
+                gpd = ops.grad_phi_dx(it, dr, ev[1], mu)
+            if gpd < 0 and ap * (-gpd) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]:
+                if not (f_logbar_trial <= f_logbar + o["eta_phi"] * ap * gpd):
+                    filt.add(theta_trial, f_logbar_trial)
+            else:
+                filt.add(theta_trial, f_logbar_trial)
+        elif ls_status == 2:
+            filt.add(theta_trial, f_logbar_trial)
+        iter_num += 1
+        # ---- duals, then the accepted trial becomes the iterate, :2714-2754
+        it = ops.duals_update(it, trial, dr, ap, ad, mu)
+        ev = ops.evaluate(it)
+        f_logbar = ops.logbar(it, ev[0], mu)
+        resid, norms = ops.residual(it, ev, mu)
+    return dict(x=ops.primal(it), obj=float(ev[0]), iters=iter_num, status=status, n_fact=n_fact, mu=mu, err=e["nlp"], it=it)

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Writes tests/golden/iteration_table_mds_ex1_{40_12,400_100}.txt: the iteration table (format of the reference's
 `outputIteration`, src/Optimization/hiopAlgFilterIPM.cpp:2783-2812, emitted through hiopamd_io_format_iteration) of the
-ORACLE's full-space IPM (oracle/ipm_full.py on the numpy restatements) on MdsEx1 at the driver's settings (mu0 = 0.1,
-tolerance 1e-5).  The HIP run of the same loop must reproduce these lines under the reference's own CPU-vs-GPU rule
-(tests/testMDS1CompareIterations.awk:13-40: every numeric column within 1e-5 absolute, same line-search tag)."""
+ORACLE's restatement of the reference's Newton filter IPM (oracle/ipm_filter.py on the numpy restatements) on MdsEx1 with
+the driver's options (NlpMdsEx1Driver.cpp:130-139: mu0 = 0.1, tolerance 1e-5, duals_init zero, linear duals update).  That
+run follows the reference's own trajectory (tests/test_oracle_reference_trajectory.py: KKT systems of iterations 0, 5, 10
+equal to the reference's dumps to 1e-12, 14 iterations and the stored -selfcheck objective on (400, 100)), so these tables
+are the reference's iteration tables up to rounding of the printed digits.  The HIP run of the same loop must reproduce
+these lines under the reference's own CPU-vs-GPU rule (tests/testMDS1CompareIterations.awk:13-40: every numeric column
+within 1e-5 absolute, same line-search tag)."""
 import ctypes as C
 import os
 import sys
@@ -23,20 +27,18 @@ def table_lines(table):
         first = r["iter"] == 0
         L.hiopamd_io_format_iteration(buf, 256, 0, r["iter"], C.c_double(r["objective"]), C.c_double(r["inf_pr"]),
                                       C.c_double(r["inf_du"]), C.c_double(r["mu"]), C.c_double(r["alpha_du"]),
-                                      C.c_double(r["alpha_pr"]), -1 if first else 1, 0 if first else 1, 0, 0)
+                                      C.c_double(r["alpha_pr"]), r.get("ls", -1 if first else 1),
+                                      r.get("ls_num", 0 if first else 1), 0, 0)
         out.append(buf.value.decode())
     return out
 
 
 def oracle_table(ns, nd):
-    from oracle import ipm_full
-    from oracle import problems as pr
-    from test_oracle_selfcheck import _full_layer_setup
-    p = pr.mds_ex1(ns, nd)
-    full, bounds, model, q = _full_layer_setup(p)
-    it0 = ipm_full.initial_iterate(full, bounds, p.x0, lambda x: model(x)[3], 0.1)
+    from oracle import ipm_filter
+    from test_oracle_reference_trajectory import DRIVER_OPTIONS, reference_setup
+    p, k, full, bounds, model, q = reference_setup(ns, nd)
     table = []
-    ipm_full.solve(ipm_full.OracleOps(full, bounds, model), it0, mu0=0.1, tol=1e-5, table=table)
+    ipm_filter.solve(ipm_filter.FilterOracleOps(full, bounds, model), p.x0, table=table, **DRIVER_OPTIONS)
     return table
 
 

@@ -1,0 +1,89 @@
+"""Pins the oracle on the REFERENCE'S OWN TRAJECTORY.
+
+tests/golden/kkt_linsys_{0,5,10}.iajaaa are the condensed MDS KKT systems the reference wrote (`write_kkt yes`) at outer
+iterations 0, 5 and 10 of `NlpMdsEx1.exe 40 12 0`: matrix, the right-hand side it solved, the solution LAPACK returned.
+oracle/ipm_filter.py restates hiopAlgFilterIPMNewton::run; run with the driver's options (NlpMdsEx1Driver.cpp:130-139) on
+the oracle's MdsEx1 data and the oracle's KKT rows, it must arrive at THE SAME linear systems: same matrix (relative 1e-12),
+same right-hand side (1e-11), same solution (1e-10) — at iteration 10 that is ten Newton steps, ten line searches and two
+barrier updates of accumulated agreement.  On MdsEx1(400, 100) the run takes the reference's 14 iterations (SURVEY.md
+§8c) and ends at the -selfcheck objective the driver stores (NlpMdsEx1Driver.cpp:149) to 1e-8 absolute (the driver's own
+check is 1e-6)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import hiop_oracle as ho
+from oracle import ipm_filter, ipm_full
+from oracle import kkt_full as kf
+from oracle import problems as pr
+from oracle.iajaaa import read_iajaaa
+
+GOLD_DIR = Path(__file__).parent / "golden"
+GOLD = json.loads((GOLD_DIR / "selfcheck_objectives.json").read_text())
+DRIVER_OPTIONS = dict(mu0=0.1, tolerance=1e-5)            # NlpMdsEx1Driver.cpp:138-139; duals_init zero, linear duals: the restatement's
+
+
+def reference_setup(ns, nd):
+    """MdsEx1 as hiopNlpMDS presents it to the algorithm: bounds relaxed by bound_relax_perturb = 1e-8
+    (hiopNlpFormulation.cpp:398-402)."""
+    p = pr.mds_ex1(ns, nd)
+    k = ho.KKTLinSysCompressedMDSXYcYd(p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j), (p.Hss_i, p.Hss_j))
+    k.set_values(p.Jcs_v, p.Jds_v, p.Hss_v, p.Jcd, p.Jdd, p.Hdd, None, None)
+    f = lambda b: b.astype(np.float64)
+    ixl, ixu, idl, idu = f(p.xl > -1e20), f(p.xu < 1e20), f(p.dl > -1e20), f(p.du < 1e20)
+    full = kf.KKTLinSysFull(kf.MdsProvider(k), ixl, ixu, idl, idu)
+    xl, xu, dl, du = ipm_filter.relax_bounds(p.xl, p.xu, p.dl, p.du, ipm_filter.DEFAULTS["bound_relax_perturb"])
+    bounds = (xl, xu, dl, du, np.zeros(p.neq))
+    model, q = ipm_full.mds_model(p)
+    return p, k, full, bounds, model, q
+
+
+def run_and_capture(ns, nd):
+    p, k, full, bounds, model, q = reference_setup(ns, nd)
+    ops = ipm_filter.FilterOracleOps(full, bounds, model)
+    mats, solves, state = {}, {}, {"i": -1}
+    lapack_solve = k.linsys.solve
+
+    def spy(rhs):
+        r0 = rhs.copy()
+        ok = lapack_solve(rhs)
+        solves.setdefault(state["i"], []).append((r0, rhs.copy()))
+        return ok
+    k.linsys.solve = spy
+
+    def on_kkt(i, it, mu, resid):
+        state["i"] = i
+        mats[i] = np.triu(k.build_kkt_matrix(*full.perturb.deltas()))
+    table = []
+    r = ipm_filter.solve(ops, p.x0, on_kkt=on_kkt, table=table, **DRIVER_OPTIONS)
+    return r, mats, solves, table
+
+
+@pytest.fixture(scope="module")
+def run_40_12():
+    return run_and_capture(40, 12)
+
+
+@pytest.mark.parametrize("it", [0, 5, 10])
+def test_kkt_system_of_iteration_equals_the_reference_dump(run_40_12, it):
+    r, mats, solves, table = run_40_12
+    g = read_iajaaa(GOLD_DIR / f"kkt_linsys_{it}.iajaaa")
+    M, (rhs, sol) = g["M_upper"], g["pairs"][0]
+    assert len(g["pairs"]) == len(solves[it])                       # the same number of triangular solves in that iteration
+    assert np.abs(mats[it] - M).max() <= 1e-12 * np.abs(M).max()
+    ro, so = solves[it][0]
+    assert np.abs(ro - rhs).max() <= 1e-11 * np.abs(rhs).max()
+    assert np.abs(so - sol).max() <= 1e-10 * np.abs(sol).max()
+    if it == 0:
+        assert np.array_equal(ro, rhs)                              # bit-identical right-hand side at the starting point
+
+
+def test_mds_ex1_400_100_takes_the_reference_iterations_to_the_selfcheck_objective():
+    g = GOLD["MdsEx1"]
+    r, mats, solves, table = run_and_capture(*g["args"])
+    assert r["status"] == "Solve_Success"
+    assert r["iters"] == 14 and sorted(mats) == list(range(14))     # kkt_linsys_{0..13} in the reference's run
+    assert abs(r["obj"] - g["objective"]) <= 1e-8
+    assert all(len(v) == 1 for v in solves.values())                # BiCGStab IR converged on the first solve throughout

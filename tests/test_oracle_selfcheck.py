@@ -128,10 +128,9 @@ def test_dense_ex2_selfcheck_objective_quasi_newton_through_the_lowrank_backend(
 
 
 def test_iteration_table_fixtures_are_reproducible_and_match_the_reference_iteration_count():
-    """tests/golden/iteration_table_mds_ex1_*.txt are what the committed generator writes from the oracle's full-space IPM; on
-    MdsEx1(400, 100) at the driver's settings the run takes the reference's 14 iterations and ends within 2e-5
-    of the stored -selfcheck objective (the oracle IPM is not hiopAlgFilterIPM: no filter line search, so the last barrier
-    subproblem is left at a slightly different point; 1.8e-5 = 18 mu)."""
+    """tests/golden/iteration_table_mds_ex1_*.txt are what the committed generator writes from the oracle's restatement of
+    the reference's filter IPM (oracle/ipm_filter.py); on MdsEx1(400, 100) at the driver's options the run takes the
+    reference's 14 iterations and ends at the stored -selfcheck objective to 1e-8 (the reference's own check: 1e-6)."""
     import sys
     gold_dir = Path(__file__).parent / "golden"
     sys.path.insert(0, str(gold_dir))
@@ -140,7 +139,7 @@ def test_iteration_table_fixtures_are_reproducible_and_match_the_reference_itera
         table = oracle_table(ns, nd)
         assert table_lines(table) == (gold_dir / f"iteration_table_mds_ex1_{ns}_{nd}.txt").read_text().splitlines(keepends=True)
     assert table[-1]["iter"] == 14
-    assert abs(table[-1]["objective"] - GOLD["MdsEx1"]["objective"]) < 2e-5
+    assert abs(table[-1]["objective"] - GOLD["MdsEx1"]["objective"]) < 1e-8
 
 
 def _dense_ex1_setup(n):
