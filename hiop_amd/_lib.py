@@ -42,6 +42,8 @@ def _ctype(t: str):
         return C.c_int
     if t == "int64_t":
         return C.c_int64
+    if t == "uint64_t":
+        return C.c_uint64
     if t == "size_t":
         return C.c_size_t
     if t == "double":

@@ -19,6 +19,7 @@
 // so that every compound-vector operation of the Krylov loop is a single launch, and the rhs reduction /
 // direction recovery / 12-block operator are one fused element-wise kernel each instead of ~40 BLAS-1 calls.
 #include "device_utils.hpp"
+#include "pd_perturb.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -33,161 +34,6 @@ using namespace hiopamd;
   } while(0)
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------------
-// hiopPDPerturbationPrimalFirstScalar: scalar state machine, lives on the host like in the reference
-// ------------------------------------------------------------------------------------------------------
-struct PdPerturb {
-  enum Degeneracy { NotEstablished, NotDegenerate, Degenerate };
-  enum TestType { NoTest, Dc0Dw0, DcposDw0, Dc0Dwpos, DcposDwpos };
-  bool null_mode = false;   // hiopPDPerturbationNull (quasi-Newton path): deltas stay 0
-  double wx = 0, wd = 0, cc = 0, cd = 0;
-  double wx_last = 0, wd_last = 0, cc_last = 0, cd_last = 0;
-  // hiopOptions.cpp:1080-1123 defaults
-  double delta_w_min_bar = 1e-20, delta_w_max_bar = 1e20, delta_w_0_bar = 1e-4, kappa_w_minus = 1. / 3,
-         kappa_w_plus_bar = 100., kappa_w_plus = 8., delta_c_bar = 1e-8, kappa_c = 0.25;
-  Degeneracy hess_degenerate = NotEstablished, jac_degenerate = NotEstablished;
-  int num_degen_iters = 0;
-  const int num_degen_max_iters = 3;
-  TestType test_type = NoTest;
-  double mu = 1e-8;
-
-  double compute_delta_c() const { return delta_c_bar * std::pow(mu, kappa_c); }   // :361
-
-  void update_degeneracy_type()   // :108-157
-  {
-    switch(test_type) {
-      case NoTest: return;
-      case Dc0Dw0:
-        if(hess_degenerate == NotEstablished && jac_degenerate == NotEstablished) {
-          hess_degenerate = jac_degenerate = NotDegenerate;
-        } else if(hess_degenerate == NotEstablished) {
-          hess_degenerate = NotDegenerate;
-        } else if(jac_degenerate == NotEstablished) {
-          jac_degenerate = NotDegenerate;
-        }
-        break;
-      case DcposDw0:
-        if(hess_degenerate == NotEstablished) hess_degenerate = NotDegenerate;
-        if(jac_degenerate == NotEstablished) {
-          if(++num_degen_iters >= num_degen_max_iters) jac_degenerate = Degenerate;
-        }
-        break;
-      case Dc0Dwpos:
-        if(jac_degenerate == NotEstablished) jac_degenerate = NotDegenerate;
-        if(hess_degenerate == NotEstablished) {
-          if(++num_degen_iters >= num_degen_max_iters) hess_degenerate = Degenerate;
-        }
-        break;
-      case DcposDwpos:
-        if(++num_degen_iters >= num_degen_max_iters) hess_degenerate = jac_degenerate = Degenerate;
-        break;
-    }
-  }
-
-  bool guts_wrong_inertia()   // :331-358
-  {
-    if(wx == 0.) {
-      wx = (wx_last == 0.) ? delta_w_0_bar : std::fmax(delta_w_min_bar, wx_last * kappa_w_minus);
-    } else {
-      wx = (wx_last == 0. || 1e5 * wx_last < wx) ? kappa_w_plus_bar * wx : kappa_w_plus * wx;
-    }
-    wd = wx;
-    if(wx > delta_w_max_bar) {
-      wx_last = wd_last = 0.;
-      return false;
-    }
-    return true;
-  }
-
-  bool compute_initial_deltas()   // :161-212
-  {
-    if(null_mode) return true;
-    double delta_temp = 0.0, delta_temp2 = 0.0;
-    update_degeneracy_type();
-    if(wx > 0.) wx_last = wx;
-    if(wd > 0.) wd_last = wd;
-    if(cc > 0.) cc_last = cc;
-    if(cd > 0.) cd_last = cd;
-    test_type = (hess_degenerate == NotEstablished || jac_degenerate == NotEstablished) ? Dc0Dw0 : NoTest;
-    delta_temp = (jac_degenerate == Degenerate) ? compute_delta_c() : 0.0;
-    cc = cd = delta_temp;
-    if(hess_degenerate == Degenerate) {
-      wx = wd = 0.;
-      if(!guts_wrong_inertia()) return false;
-      // the reference then assigns its two locals, which the call above never writes (:203-209)
-    } else {
-      delta_temp = delta_temp2 = 0.;
-    }
-    wx = delta_temp;
-    wd = delta_temp2;
-    return true;
-  }
-
-  bool compute_perturb_wrong_inertia()   // :215-243
-  {
-    if(null_mode) return true;
-    update_degeneracy_type();
-    bool ret = guts_wrong_inertia();
-    if(!ret && cc == 0.) {
-      wx = wd = 0.;
-      cc = cd = compute_delta_c();
-      test_type = NoTest;
-      if(hess_degenerate == Degenerate) hess_degenerate = NotEstablished;
-      ret = guts_wrong_inertia();
-    }
-    return ret;
-  }
-
-  bool compute_perturb_singularity()   // :248-325
-  {
-    if(null_mode) return true;
-    bool bret = true;
-    if(hess_degenerate == NotEstablished || jac_degenerate == NotEstablished) {
-      switch(test_type) {
-        case Dc0Dw0:
-          if(jac_degenerate == NotEstablished) {
-            cc = cd = compute_delta_c();
-            test_type = DcposDw0;
-          } else {
-            if(!guts_wrong_inertia()) {
-              bret = false;
-              break;
-            }
-            test_type = Dc0Dwpos;
-          }
-          break;
-        case DcposDw0:
-          cd = cc = 0.;
-          if(!guts_wrong_inertia()) {
-            bret = false;
-            break;
-          }
-          test_type = Dc0Dwpos;
-          break;
-        case Dc0Dwpos:
-          cc = cd = compute_delta_c();
-          if(!guts_wrong_inertia()) {
-            bret = false;
-            break;
-          }
-          test_type = DcposDwpos;
-          break;
-        case DcposDwpos:
-          if(!guts_wrong_inertia()) bret = false;
-          break;
-        case NoTest: bret = false; break;   // the reference asserts here (:302)
-      }
-    } else {
-      if(cc > 0.) {
-        if(!guts_wrong_inertia()) bret = false;
-      } else {
-        cd = cc = compute_delta_c();
-      }
-    }
-    return bret;
-  }
-};
 
 // hiopFactAcceptorIC::requireReFactorization (hiopFactAcceptor.cpp:63-104)
 int require_refactorization(PdPerturb& pd, int n_required_neg_eig, int n_neg_eig)
@@ -260,6 +106,9 @@ struct hiopamd_kkt_xycyd {
   double* dsmall = nullptr;   // 4 doubles of device scratch for the sharded dot
   double* lsq = nullptr;      // LSQ dual update workspace: M (m^2) | rhs (m) | posv work (3 m^2 + 8 m)
   PdPerturb pd;
+  // randomized regularisation (hiopPDPerturbation*Rand): the four vectors the builders / the 12-block operator consume
+  double* dvec[4] = {nullptr, nullptr, nullptr, nullptr};   // delta_wx [nx], delta_wd [nd], delta_cc [nyc], delta_cd [nyd]
+  uint64_t reg_seed = 0x9E3779B97F4A7C15ull, reg_draw = 0;
   int n_required_neg = 0;
   int num_refact = 0;
   int acceptor = 0;   // 0: hiopFactAcceptorIC, 1: hiopFactAcceptorInertiaFreeDWD
@@ -277,14 +126,50 @@ const double* Dd_inv_of(hiopamd_kkt_xycyd* h)
   }
 }
 
+// uniform in [lo, hi): counter-based (splitmix64 of seed, draw number, index) so that a draw is reproducible from
+// (seed, draw) alone; hiopVector::set_to_random_uniform's role (hiopVectorPar.cpp:134, host std generator there)
+int fill_uniform(hiopamd_ctx* ctx, int64_t n, double* out, double lo, double hi, uint64_t seed, uint64_t draw)
+{
+  return launch_ew(ctx, n, [=] __device__(int64_t i) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (draw * 0x100000001B3ull + (uint64_t)i + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);   // [0, 1)
+    out[i] = lo + (hi - lo) * u;
+  });
+}
+
+// set_delta_curr_vec of the *Rand classes (hiopPDPerturbation.cpp:433-455, :689-711): redraw the groups the scalar machine marked
+int refresh_delta_vectors(hiopamd_kkt_xycyd* h)
+{
+  PdPerturb& pd = h->pd;
+  if(!pd.randomized || pd.null_mode) return HIOPAMD_OK;
+  const double lo = pd.min_uniform_ratio, hi = pd.max_uniform_ratio;
+  const int64_t len[4] = {h->nx, h->nd, h->nyc, h->nyd};
+  const double sc[4] = {pd.wx, pd.wd, pd.cc, pd.cd};
+  for(int v = 0; v < 4; ++v) {
+    const int group = v < 2 ? PdPerturb::PrimalUpdate : PdPerturb::DualUpdate;
+    if(!(pd.dirty & group)) continue;
+    RC(fill_uniform(h->ctx, len[v], h->dvec[v], lo * sc[v], hi * sc[v], h->reg_seed, h->reg_draw++));
+  }
+  pd.dirty = 0;
+  return HIOPAMD_OK;
+}
+
 // ---- backend: (re)build the condensed matrix for the current deltas -----------------------------------
 int backend_build(hiopamd_kkt_xycyd* h)
 {
   const PdPerturb& pd = h->pd;
   hiopamd_ctx* ctx = h->ctx;
-  if(h->kind == KIND_MDS) return hiopamd_kkt_mds_build(h->mds, pd.wx, pd.wd, pd.cc, pd.cd);
+  const bool rnd = pd.randomized && !pd.null_mode;
+  if(rnd) RC(refresh_delta_vectors(h));
+  double* const* dv = h->dvec;
+  if(h->kind == KIND_MDS)
+    return rnd ? hiopamd_kkt_mds_build_vec(h->mds, dv[0], dv[1], dv[2], dv[3]) : hiopamd_kkt_mds_build(h->mds, pd.wx, pd.wd, pd.cc, pd.cd);
   if(h->kind == KIND_LOWRANK) return HIOPAMD_OK;   // N is formed inside solveCompressed (hiopKKTLinSys.cpp:1132)
-  if(h->kind == KIND_SPARSE_CONDENSED) return hiopamd_kkt_sparse_condensed_build(h->sc, pd.wx, pd.wd);
+  if(h->kind == KIND_SPARSE_CONDENSED)
+    return rnd ? hiopamd_kkt_sparse_condensed_build_vec(h->sc, dv[0], dv[1]) : hiopamd_kkt_sparse_condensed_build(h->sc, pd.wx, pd.wd);
   SpanScope span(ctx, HIOPAMD_SPAN_KKT_UPDATE_LINSYS);
   if(h->kind == KIND_DENSE_XDYCYD) {
     // hiopKKTLinSysDenseXDYcYd::build_kkt_matrix (hiopKKTLinSysDense.hpp:249-328)
@@ -296,16 +181,19 @@ int backend_build(hiopamd_kkt_xycyd* h)
     RC(hiopamd_mat_trans_add_to_sym_upper(ctx, neq, nx, h->Jc, nx, 0, nx + nineq, 1.0, M, n));       // :288
     RC(hiopamd_mat_trans_add_to_sym_upper(ctx, nineq, nx, h->Jd, nx, 0, nx + nineq + neq, 1.0, M, n));   // :289
     RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, 0, 1.0, h->Dx, 0, nx));                               // :292
-    RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, 0, nx, pd.wx));                                 // :293
+    if(rnd) RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, 0, 1.0, dv[0], 0, nx));                       // :293 (delta_wx_ is a vector)
+    else RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, 0, nx, pd.wx));
     RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, nx, 1.0, h->Dd, 0, nineq));                           // :295
-    RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx, nineq, pd.wd));                             // :296
+    if(rnd) RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, nx, 1.0, dv[1], 0, nineq));                   // :296
+    else RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx, nineq, pd.wd));
     {
       const int64_t ld = n;
       const int c0 = nx + nineq + neq;
       RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { M[(nx + i) * ld + c0 + i] -= 1.0; }));      // :299-307
     }
     // :312 is literally addSubDiagonal(-1, nx+nineq, delta_cd): nineq entries starting at diagonal nx+nineq
-    RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx + nineq, nineq, -pd.cd));
+    if(rnd) RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, nx + nineq, -1.0, dv[3], 0, nineq));
+    else RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx + nineq, nineq, -pd.cd));
     return HIOPAMD_OK;
   }
   // hiopKKTLinSysDenseXYcYd::build_kkt_matrix (hiopKKTLinSysDense.hpp:84-170)
@@ -317,16 +205,19 @@ int backend_build(hiopamd_kkt_xycyd* h)
   RC(hiopamd_mat_trans_add_to_sym_upper(ctx, neq, nx, h->Jc, nx, 0, nx, 1.0, M, n));             // :139
   RC(hiopamd_mat_trans_add_to_sym_upper(ctx, nineq, nx, h->Jd, nx, 0, nx + neq, 1.0, M, n));     // :140
   RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, 0, 1.0, h->Dx, 0, nx));                             // :142
-  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, 0, nx, pd.wx));                               // :143
+  if(rnd) RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, 0, 1.0, dv[0], 0, nx));                     // :143 (delta_wx_ is a vector)
+  else RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, 0, nx, pd.wx));
   {
     const double* Dd = h->Dd;
     double* Ddi = h->dense_Dd_inv;
     const double dwd = pd.wd;
-    RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { Ddi[i] = 1.0 / (dwd + Dd[i]); }));      // :146-152
+    const double* dwdv = rnd ? dv[1] : nullptr;
+    RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { Ddi[i] = 1.0 / ((dwdv ? dwdv[i] : dwd) + Dd[i]); }));   // :146-152
   }
   RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, nx + neq, -1.0, h->dense_Dd_inv, 0, nineq));        // :155
   // :160 is literally addSubDiagonal(-1, nx, delta_cd): nineq entries starting at diagonal position nx
-  RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx, nineq, -pd.cd));
+  if(rnd) RC(hiopamd_mat_add_sub_diagonal(ctx, M, n, nx, -1.0, dv[3], 0, nineq));
+  else RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, n, nx, nineq, -pd.cd));
   return HIOPAMD_OK;
 }
 
@@ -581,11 +472,14 @@ int stage_times_vec_ew(hiopamd_kkt_xycyd* h, double* y, const double* x)
          *yrsvu = y + o[11];
   const double *ixl = h->ixl, *ixu = h->ixu, *idl = h->idl, *idu = h->idu;
   const double dwx = h->pd.wx, dwd = h->pd.wd, dcc = h->pd.cc, dcd = h->pd.cd;
+  const bool rnd = h->pd.randomized && !h->pd.null_mode;
+  const double *vwx = rnd ? h->dvec[0] : nullptr, *vwd = rnd ? h->dvec[1] : nullptr, *vcc = rnd ? h->dvec[2] : nullptr,
+               *vcd = rnd ? h->dvec[3] : nullptr;
   const int64_t n = std::max<int64_t>(std::max<int64_t>(nx, nd), nyc);
   return launch_ew(h->ctx, n, [=] __device__(int64_t i) {
     if(i < nx) {
       const double xv = dx[i];
-      yrx[i] += dwx * xv - dzl[i] + dzu[i];                       // :1672-1678
+      yrx[i] += (vwx ? vwx[i] : dwx) * xv - dzl[i] + dzu[i];      // :1672-1678
       yrxl[i] = sel(ixl[i], dsxl[i] - xv);                        // :1697-1699
       yrxu[i] = sel(ixu[i], dsxu[i] + xv);                        // :1702-1704
       yrszl[i] = sxl[i] * dzl[i] + zl[i] * dsxl[i];               // :1717-1719
@@ -593,14 +487,14 @@ int stage_times_vec_ew(hiopamd_kkt_xycyd* h, double* y, const double* x)
     }
     if(i < nd) {
       const double dv = dd[i], ydv = dyd[i];
-      yrd[i] = -ydv - dvl[i] + dvu[i] + dwd * dv;                 // :1681-1685
-      yryd[i] += -dv - dcd * ydv;                                 // :1692-1694
+      yrd[i] = -ydv - dvl[i] + dvu[i] + (vwd ? vwd[i] : dwd) * dv;   // :1681-1685
+      yryd[i] += -dv - (vcd ? vcd[i] : dcd) * ydv;                // :1692-1694
       yrdl[i] = sel(idl[i], dsdl[i] - dv);                        // :1707-1709
       yrdu[i] = sel(idu[i], dsdu[i] + dv);                        // :1712-1714
       yrsvl[i] = sdl[i] * dvl[i] + vl[i] * dsdl[i];               // :1727-1729
       yrsvu[i] = sdu[i] * dvu[i] + vu[i] * dsdu[i];               // :1732-1734
     }
-    if(i < nyc) yryc[i] -= dcc * dyc[i];                          // :1688-1689
+    if(i < nyc) yryc[i] -= (vcc ? vcc[i] : dcc) * dyc[i];         // :1688-1689
   });
 }
 
@@ -807,6 +701,7 @@ int hiopamd_kkt_xycyd_destroy(hiopamd_kkt_xycyd* h)
   (void)hipFree(h->krylov);
   (void)hipFree(h->dsmall);
   (void)hipFree(h->lsq);
+  for(double* v : h->dvec) (void)hipFree(v);
   delete h;
   return HIOPAMD_OK;
 }
@@ -852,6 +747,37 @@ int hiopamd_kkt_xycyd_set_perturbation_options(hiopamd_kkt_xycyd* h, const doubl
   p.kappa_w_plus = o[5];
   p.delta_c_bar = o[6];
   p.kappa_c = o[7];
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_set_regularization(hiopamd_kkt_xycyd* h, int dual_first, int randomized, uint64_t seed)
+{
+  if(!h) return HIOPAMD_ERR_ARG;
+  if(h->pd.null_mode) return HIOPAMD_ERR_STATE;   // the quasi-Newton path runs with hiopPDPerturbationNull
+  h->pd.kind = dual_first ? PdPerturb::DualFirst : PdPerturb::PrimalFirst;
+  h->pd.randomized = randomized != 0;
+  h->pd.dirty = PdPerturb::PDUpdate;
+  h->reg_seed = seed;
+  h->reg_draw = 0;
+  if(randomized && !h->dvec[0]) {
+    const int64_t len[4] = {h->nx, h->nd, h->nyc, h->nyd};
+    for(int v = 0; v < 4; ++v) {
+      HIOPAMD_CHECK(hipMalloc(&h->dvec[v], sizeof(double) * (size_t)std::max<int64_t>(len[v], 1)));
+      HIOPAMD_CHECK(hipMemsetAsync(h->dvec[v], 0, sizeof(double) * (size_t)std::max<int64_t>(len[v], 1), h->ctx->stream));
+    }
+  }
+  return HIOPAMD_OK;
+}
+
+int hiopamd_kkt_xycyd_delta_vectors(hiopamd_kkt_xycyd* h, const double** wx, const double** wd, const double** cc,
+                                    const double** cd)
+{
+  if(!h) return HIOPAMD_ERR_ARG;
+  if(!h->pd.randomized || !h->dvec[0]) return HIOPAMD_ERR_STATE;
+  if(wx) *wx = h->dvec[0];
+  if(wd) *wd = h->dvec[1];
+  if(cc) *cc = h->dvec[2];
+  if(cd) *cd = h->dvec[3];
   return HIOPAMD_OK;
 }
 
@@ -918,19 +844,21 @@ int hiopamd_kkt_xycyd_test_direction(hiopamd_kkt_xycyd* h, const double* dir, do
   const double dwx = h->pd.wx, dwd = h->pd.wd;
   const int64_t nx = h->nx;
   // {curvature term, squared norm} over the x part (distributed on a column partition) and over the d part
+  const bool rnd = h->pd.randomized && !h->pd.null_mode;
   struct OpCurv {
     const double *w, *v, *D;
     double delta;
+    const double* dvec;
     __device__ dot2_t identity() const { return dot2_t{0.0, 0.0}; }
     __device__ dot2_t map(int64_t i) const
     {
       const double vi = v[i];
-      return dot2_t{(w ? w[i] * vi : 0.0) + (D[i] * vi + delta * vi) * vi, vi * vi};
+      return dot2_t{(w ? w[i] * vi : 0.0) + (D[i] * vi + (dvec ? dvec[i] : delta) * vi) * vi, vi * vi};
     }
     __device__ dot2_t combine(dot2_t p, dot2_t q) const { return dot2_t{p.dist + q.dist, p.repl + q.repl}; }
   };
   dot2_t sx{0, 0}, sd{0, 0};
-  RC(launch_reduce<dot2_t>(ctx, nx, OpCurv{hx, dx, Dx, dwx}, &sx));
+  RC(launch_reduce<dot2_t>(ctx, nx, OpCurv{hx, dx, Dx, dwx, rnd ? h->dvec[0] : nullptr}, &sx));
   if(h->kind == KIND_LOWRANK && ctx->allreduce) {
     HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, &sx, sizeof(sx), hipMemcpyHostToDevice, ctx->stream));
     HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
@@ -938,7 +866,7 @@ int hiopamd_kkt_xycyd_test_direction(hiopamd_kkt_xycyd* h, const double* dir, do
     HIOPAMD_CHECK(hipMemcpyAsync(&sx, h->dsmall, sizeof(sx), hipMemcpyDeviceToHost, ctx->stream));
     HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
   }
-  RC(launch_reduce<dot2_t>(ctx, h->nd, OpCurv{nullptr, dd, Dd, dwd}, &sd));
+  RC(launch_reduce<dot2_t>(ctx, h->nd, OpCurv{nullptr, dd, Dd, dwd, rnd ? h->dvec[1] : nullptr}, &sd));
   const double dWd = sx.dist + sd.dist, xs_nrmsq = sx.repl + sd.repl;
   if(dWd_host) *dWd_host = dWd;
   if(xs_nrmsq_host) *xs_nrmsq_host = xs_nrmsq;
@@ -1637,3 +1565,81 @@ int hiopamd_duals_lsq_update(hiopamd_kkt_xycyd* h, double* iter, const double* g
 }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The regularisation state machines on their own (host only, no device work): hiopPDPerturbation's public interface
+// (hiopPDPerturbation.hpp:60-130) for callers that run the inertia-correction loop themselves, and for the CPU tests.
+// ------------------------------------------------------------------------------------------------------------------------
+struct hiopamd_pd_perturbation {
+  PdPerturb pd;
+};
+
+int hiopamd_pd_perturbation_create(hiopamd_pd_perturbation** out, int kind)
+{
+  if(!out || kind < 0 || kind > 2) return HIOPAMD_ERR_ARG;
+  *out = new(std::nothrow) hiopamd_pd_perturbation();
+  if(!*out) return HIOPAMD_ERR_HIP;
+  if(kind == 2) (*out)->pd.null_mode = true;
+  else (*out)->pd.kind = kind;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_pd_perturbation_destroy(hiopamd_pd_perturbation* p)
+{
+  delete p;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_pd_perturbation_set_options(hiopamd_pd_perturbation* p, const double* o)
+{
+  if(!p || !o) return HIOPAMD_ERR_ARG;
+  PdPerturb& q = p->pd;
+  q.delta_w_min_bar = o[0];
+  q.delta_w_max_bar = o[1];
+  q.delta_w_0_bar = o[2];
+  q.kappa_w_minus = o[3];
+  q.kappa_w_plus_bar = o[4];
+  q.kappa_w_plus = o[5];
+  q.delta_c_bar = o[6];
+  q.kappa_c = o[7];
+  return HIOPAMD_OK;
+}
+
+int hiopamd_pd_perturbation_set_mu(hiopamd_pd_perturbation* p, double mu)
+{
+  if(!p) return HIOPAMD_ERR_ARG;
+  p->pd.mu = mu;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_pd_perturbation_compute_initial_deltas(hiopamd_pd_perturbation* p, int* ok)
+{
+  if(!p || !ok) return HIOPAMD_ERR_ARG;
+  *ok = p->pd.compute_initial_deltas() ? 1 : 0;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_pd_perturbation_compute_perturb_wrong_inertia(hiopamd_pd_perturbation* p, int* ok)
+{
+  if(!p || !ok) return HIOPAMD_ERR_ARG;
+  *ok = p->pd.compute_perturb_wrong_inertia() ? 1 : 0;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_pd_perturbation_compute_perturb_singularity(hiopamd_pd_perturbation* p, int* ok)
+{
+  if(!p || !ok) return HIOPAMD_ERR_ARG;
+  *ok = p->pd.compute_perturb_singularity() ? 1 : 0;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_pd_perturbation_get(const hiopamd_pd_perturbation* p, double* curr4, double* last4, int* state4)
+{
+  if(!p) return HIOPAMD_ERR_ARG;
+  const PdPerturb& q = p->pd;
+  if(curr4) { curr4[0] = q.wx; curr4[1] = q.wd; curr4[2] = q.cc; curr4[3] = q.cd; }
+  if(last4) { last4[0] = q.wx_last; last4[1] = q.wd_last; last4[2] = q.cc_last; last4[3] = q.cd_last; }
+  if(state4) { state4[0] = (int)q.hess_degenerate; state4[1] = (int)q.jac_degenerate; state4[2] = (int)q.test_type; state4[3] = q.dirty; }
+  return HIOPAMD_OK;
+}

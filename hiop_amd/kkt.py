@@ -433,6 +433,25 @@ class KKTLinSysXYcYd:
     def set_mu(self, mu: float):
         check(self._L.hiopamd_kkt_xycyd_set_mu(self.h, mu), "set_mu")
 
+    def set_regularization(self, dual_first=False, randomized=False, seed=0x9E3779B97F4A7C15):
+        """hiopPDPerturbation{PrimalFirst,DualFirst}{Scalar,Rand} (hiopAlgFilterIPM.cpp:2165-2177)."""
+        check(self._L.hiopamd_kkt_xycyd_set_regularization(self.h, int(dual_first), int(randomized), C.c_uint64(seed)), "set_regularization")
+
+    def delta_vectors(self):
+        """Copies of the current regularisation vectors (randomized mode): delta_wx, delta_wd, delta_cc, delta_cd."""
+        ptrs = [C.c_void_p() for _ in range(4)]
+        check(self._L.hiopamd_kkt_xycyd_delta_vectors(self.h, *[C.byref(p) for p in ptrs]), "delta_vectors")
+        sizes = [self.off[1] - self.off[0], self.off[2] - self.off[1], self.off[3] - self.off[2], self.off[4] - self.off[3]]
+        out = []
+        for p, n in zip(ptrs, sizes):
+            t = torch.empty(n, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            if n:
+                check(self._L.hiopamd_copy_d2d(self.ctx.h, dptr(t, self.ctx), p, n * 8), "copy_d2d")
+            out.append(t)
+        self.ctx.sync()
+        return out
+
     def set_perturbation_options(self, opts8):
         arr = (C.c_double * 8)(*opts8)
         check(self._L.hiopamd_kkt_xycyd_set_perturbation_options(self.h, arr), "set_perturbation_options")
@@ -569,3 +588,53 @@ class IpmSlabOps:
         check(self._L.hiopamd_iterate_linear_damping_term(self.full.h, dptr(it, self.ctx), mu, kappa_d, C.byref(v)),
               "linear_damping_term")
         return v.value
+
+
+class PDPerturbation:
+    """hiopPDPerturbation's scalar state machines on their own (host only; include/hiop_amd.h hiopamd_pd_perturbation_*):
+    kind "primal_first" (hiopPDPerturbationPrimalFirstScalar), "dual_first" (…DualFirstScalar) or "null"."""
+    KINDS = {"primal_first": 0, "dual_first": 1, "null": 2}
+
+    def __init__(self, kind="primal_first", options8=None):
+        self._L = lib()
+        h = C.c_void_p()
+        check(self._L.hiopamd_pd_perturbation_create(C.byref(h), self.KINDS[kind]), "pd_perturbation_create")
+        self.h = h
+        if options8 is not None:
+            check(self._L.hiopamd_pd_perturbation_set_options(self.h, (C.c_double * 8)(*options8)), "pd_perturbation_set_options")
+
+    def set_mu(self, mu):
+        check(self._L.hiopamd_pd_perturbation_set_mu(self.h, float(mu)), "set_mu")
+
+    def _call(self, name):
+        ok = C.c_int(0)
+        check(getattr(self._L, name)(self.h, C.byref(ok)), name)
+        return bool(ok.value)
+
+    def compute_initial_deltas(self):
+        return self._call("hiopamd_pd_perturbation_compute_initial_deltas")
+
+    def compute_perturb_wrong_inertia(self):
+        return self._call("hiopamd_pd_perturbation_compute_perturb_wrong_inertia")
+
+    def compute_perturb_singularity(self):
+        return self._call("hiopamd_pd_perturbation_compute_perturb_singularity")
+
+    def state(self):
+        c, l, s = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int * 4)()
+        check(self._L.hiopamd_pd_perturbation_get(self.h, c, l, s), "pd_perturbation_get")
+        return tuple(c), tuple(l), tuple(s)
+
+    def deltas(self):
+        return self.state()[0]
+
+    def close(self):
+        if self.h is not None:
+            self._L.hiopamd_pd_perturbation_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

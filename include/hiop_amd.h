@@ -639,6 +639,16 @@ int hiopamd_kkt_xycyd_set_mu(hiopamd_kkt_xycyd* h, double mu);                  
 /* opts8 = delta_w_min_bar, delta_w_max_bar, delta_0_bar, kappa_w_minus, kappa_w_plus_bar, kappa_w_plus,
  * delta_c_bar, kappa_c (defaults of src/Utils/hiopOptions.cpp:1080-1123 are built in) */
 int hiopamd_kkt_xycyd_set_perturbation_options(hiopamd_kkt_xycyd* h, const double* opts8_host);
+/* Which hiopPDPerturbation the inertia-correction loop runs (hiopAlgFilterIPM.cpp:2165-2177: options
+ * `normaleqn_regularization_priority` and `regularization_method`):  dual_first = 0 -> ...PrimalFirst*, 1 -> ...DualFirst*;
+ * randomized = 0 -> ...Scalar (delta * I), 1 -> ...Rand: the regularisation VECTORS are uniform in [0.9, 1.0] x delta
+ * (hiopPDPerturbation.hpp:53-54, .cpp:414-455, :670-711), drawn on the device from (seed, draw counter, index) and consumed by
+ * every backend's build (hiopamd_kkt_mds_build_vec, ..._sparse_condensed_build_vec, the dense builds), by the 12-block operator
+ * of the iterative refinement and by test_direction.  HIOPAMD_ERR_STATE on the quasi-Newton backend (hiopPDPerturbationNull). */
+int hiopamd_kkt_xycyd_set_regularization(hiopamd_kkt_xycyd* h, int dual_first, int randomized, uint64_t seed);
+/* device pointers of the current delta_wx [nx], delta_wd [nineq], delta_cc [neq], delta_cd [nineq] (randomized mode only) */
+int hiopamd_kkt_xycyd_delta_vectors(hiopamd_kkt_xycyd* h, const double** delta_wx, const double** delta_wd,
+                                    const double** delta_cc, const double** delta_cd);
 int hiopamd_kkt_xycyd_set_required_neg_eig(hiopamd_kkt_xycyd* h, int n_required); /* default neq+nineq (hiopAlgFilterIPM.cpp:2096) */
 /* update (:543): barrier diagonals from the iterate, then factorize (:316): build + factor + inertia-correction
  * loop (<= 10 re-factorizations).  *ok_host = the reference's bool return. */
@@ -796,6 +806,25 @@ int hiopamd_denseex2_eval_f(hiopamd_denseex2* p, const double* x_dev, double* ob
 int hiopamd_denseex2_eval_grad_f(hiopamd_denseex2* p, const double* x_dev, double* gradf_dev);                 /* .cpp:119-126 */
 int hiopamd_denseex2_eval_cons(hiopamd_denseex2* p, const double* x_dev, double* cons_dev);                    /* .cpp:129-221 */
 int hiopamd_denseex2_eval_Jac_cons(hiopamd_denseex2* p, const double* x_dev, double* Jac_dev);                 /* .cpp:224-290 */
+
+/* =====================================================================================
+ * hiopPDPerturbation on its own (src/Optimization/hiopPDPerturbation.hpp:10-212): the scalar state machines of the
+ * inertia-correction loop, host only (no device work, no context).  kind: 0 = hiopPDPerturbationPrimalFirstScalar
+ * (.cpp:108-395), 1 = hiopPDPerturbationDualFirstScalar (:457-626), 2 = hiopPDPerturbationNull.  *ok = the bool the
+ * reference method returns.  get: curr4 / last4 = delta_wx, delta_wd, delta_cc, delta_cd (current / last);
+ * state4 = hess_degenerate, jac_degenerate (0 not established, 1 not degenerate, 2 degenerate), deltas_test_type (0..4 in the
+ * order of hiopPDPerturbation.hpp:168-175), and the bit mask of vector groups the last calls marked for update
+ * (1 primal, 2 dual — set_delta_curr_vec's task id).
+ * ===================================================================================== */
+typedef struct hiopamd_pd_perturbation hiopamd_pd_perturbation;
+int hiopamd_pd_perturbation_create(hiopamd_pd_perturbation** out, int kind);
+int hiopamd_pd_perturbation_destroy(hiopamd_pd_perturbation* p);
+int hiopamd_pd_perturbation_set_options(hiopamd_pd_perturbation* p, const double* opts8_host);   /* as hiopamd_kkt_xycyd_set_perturbation_options */
+int hiopamd_pd_perturbation_set_mu(hiopamd_pd_perturbation* p, double mu);
+int hiopamd_pd_perturbation_compute_initial_deltas(hiopamd_pd_perturbation* p, int* ok);
+int hiopamd_pd_perturbation_compute_perturb_wrong_inertia(hiopamd_pd_perturbation* p, int* ok);
+int hiopamd_pd_perturbation_compute_perturb_singularity(hiopamd_pd_perturbation* p, int* ok);
+int hiopamd_pd_perturbation_get(const hiopamd_pd_perturbation* p, double* curr4, double* last4, int* state4);
 
 #ifdef __cplusplus
 }

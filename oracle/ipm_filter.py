@@ -8,7 +8,8 @@ What is restated (reference line per block below): the bounds relaxation of hiop
 with `duals_init zero`, evalNlpAndLogErrors (the sd / sc scaling), checkTermination, update_log_barrier_params, the
 filter (hiopFilter) and accept_line_search_conditions, the backtracking loop with compute_safe_slacks, the post
 line-search filter augmentation, hiopDualsNewtonLinearUpdate::go.
-What is NOT restated (and raises if reached): second-order correction, feasibility restoration, the safe-mode switch of
+the second-order correction (apply_second_order_correction).
+What is NOT restated (and raises if reached): feasibility restoration, the safe-mode switch of
 the linear solver, elastic mode, NLP scaling (the example problems' gradients at x0 are below scaling_max_grad = 100).
 
 The loop is written against an `ops` object so the same driver runs the numpy restatements (FilterOracleOps) and the
@@ -28,7 +29,8 @@ DEFAULTS = dict(mu0=1.0, tolerance=1e-8, kappa_mu=0.2, theta_mu=1.5, kappa_eps=1
                 smax=100.0, kappa_d=1e-5, eta_phi=1e-8, gamma_theta=1e-5, gamma_phi=1e-8, s_theta=1.1, s_phi=2.3, delta=1.0,
                 theta_max_fact=1e4, theta_min_fact=1e-4, dual_tol=1.0, cons_tol=1e-4, comp_tol=1e-4, rel_tolerance=0.0,
                 acceptable_tolerance=1e-6, acceptable_iterations=10, max_iter=3000, min_step_size=1e-16, kappa_Sigma=1e10,
-                bound_relax_perturb=1e-8)
+                bound_relax_perturb=1e-8, duals_lsq_ini_max=1e3, recalc_lsq_duals_tol=1e-6, max_soc_iter=4,
+                kappa_soc=0.99)
 
 
 def relax_bounds(xl, xu, dl, du, rel):
@@ -148,6 +150,40 @@ class FilterOracleOps:
     def n_refactorizations(self):
         return self.full.num_refact
 
+    # ---- second-order correction
+    def c_resid(self, c):
+        return self.bounds[4] - c
+
+    def d_resid(self, it, d):
+        return it["d"] - d
+
+    def soc_resid(self, resid, c_soc, d_soc):
+        r = dict(resid)
+        r["ryc"], r["ryd"] = c_soc, d_soc
+        return r
+
+    def directions_no_ir(self, resid):
+        return self.full.compute_directions(resid)
+
+    # ---- quasi-Newton variant
+    def duals_lsq(self, it, grad_f):                                                   # hiopDualsUpdater.cpp:239-330
+        self.full.it = it
+        ok, yc, yd = osl.duals_lsq_update(self.full, it, grad_f)
+        if ok:
+            it["yc"], it["yd"] = yc, yd
+        return ok
+
+    def dual_norms_inf(self, it):
+        return max(ho.infnorm(it["yc"]), ho.infnorm(it["yd"])), None
+
+    def zero_eq_duals(self, it):
+        it["yc"][:] = 0.0
+        it["yd"][:] = 0.0
+
+    def hess_update(self, it, ev):
+        """hiopHessianLowRank::update(it_curr, grad_f, Jac_c, Jac_d); set by the test for the low-rank provider."""
+        raise NotImplementedError
+
 
 def _errors(ops, it, norms, o):
     """evalNlpAndLogErrors, hiopAlgFilterIPM.cpp:636-712."""
@@ -163,8 +199,28 @@ def _errors(ops, it, norms, o):
     return e
 
 
-def solve(ops, x0, on_kkt=None, table=None, **options):
-    """Returns dict(x, obj, iters, status, n_fact).  `on_kkt(iter_num, it, mu, resid)` is called after every successful
+def _accept(ops, o, filt, theta, theta_trial, ap, f_logbar, f_logbar_trial, theta_min, gpd, it, dr, ev, mu):
+    """accept_line_search_conditions, hiopAlgFilterIPM.cpp:2852-2944; returns (lsStatus, grad_phi_dx or None if not computed)."""
+    suff = theta_trial <= (1 - o["gamma_theta"]) * theta or f_logbar_trial <= f_logbar - o["gamma_phi"] * theta
+    if theta >= theta_min:
+        st = 1 if suff else 0
+    else:
+        if gpd is None:
+            gpd = ops.grad_phi_dx(it, dr, ev[1], mu)
+        if gpd < 0.0 and ap * (-gpd) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]:
+            st = 3 if f_logbar_trial <= f_logbar + o["eta_phi"] * ap * gpd else 0
+        else:
+            st = 2 if suff else 0
+    if st > 0 and filt.contains(theta_trial, f_logbar_trial):
+        st = 0
+    return st, gpd
+
+
+def solve(ops, x0, on_kkt=None, table=None, quasi_newton=False, **options):
+    """quasi_newton=True: hiopAlgFilterIPMQuasiNewton::run (hiopAlgFilterIPM.cpp:960-1480) — the same loop with the secant
+    update of the Hessian before every KKT update (:1212), `duals_init lsq` at the start and the LSQ duals update after the
+    line search (hiopDualsLsqUpdate::go) — ops must provide hess_update(it, ev) and duals_lsq(it, grad_f).
+    Returns dict(x, obj, iters, status, n_fact).  `on_kkt(iter_num, it, mu, resid)` is called after every successful
     kkt update (the point at which the reference writes kkt_linsys_<iter>.iajaaa, hiopKKTLinSysCompressedMDSXYcYd via
     hiopKKTLinSys.cpp `write_linsys_counter_`)."""
     o = dict(DEFAULTS)
@@ -174,6 +230,11 @@ def solve(ops, x0, on_kkt=None, table=None, **options):
     tau = max(o["tau_min"], 1.0 - mu)                                   # hiopAlgFilterIPM.cpp:255 reload_options
     it = ops.start(x0, mu, o["kappa1"], o["kappa2"])
     ev = ops.evaluate(it)
+    if quasi_newton:                                                    # compute_initial_duals_eq, hiopDualsUpdater.hpp:154-186
+        ok = ops.duals_lsq(it, ev[1])
+        eq, _ = ops.dual_norms_inf(it)
+        if not ok or eq > o["duals_lsq_ini_max"]:
+            ops.zero_eq_duals(it)
     f_logbar = ops.logbar(it, ev[0], mu)                                # :2145
     resid, norms = ops.residual(it, ev, mu)                             # :2148
     theta_max = o["theta_max_fact"] * max(1.0, norms["nrmOne_nlp_feasib"])   # :2157-2158
@@ -184,13 +245,13 @@ def solve(ops, x0, on_kkt=None, table=None, **options):
     e0 = None
     n_accep = 0
     n_fact = 0
-    ls_status, ls_num = -1, 0
+    ls_status, ls_num, use_soc = -1, 0, 0
     status = "pending"
     while True:
         e = _errors(ops, it, norms, o)                                  # :2219
         if table is not None:
             table.append(dict(iter=iter_num, objective=float(ev[0]), inf_pr=float(e["feas"]), inf_du=float(e["optim"]), mu=float(mu),
-                              alpha_du=float(ad), alpha_pr=float(ap), ls=ls_status, ls_num=ls_num))
+                              alpha_du=float(ad), alpha_pr=float(ap), ls=ls_status, ls_num=ls_num, use_soc=use_soc))
         if e0 is None:
             e0 = e
         # ---- checkTermination, :814-845
@@ -222,6 +283,8 @@ def solve(ops, x0, on_kkt=None, table=None, **options):
             e = _errors(ops, it, norms, o)
             filt.initialize(theta_max)                                  # :2321
         # ---- search direction, :2333-2462 (linsol_mode = stable semantics of the layer: no mode switch restated)
+        if quasi_newton:
+            ops.hess_update(it, ev)                                     # :1212
         if not ops.kkt_update(it, mu):
             raise RuntimeError("KKT update failed (inertia correction exhausted)")
         n_fact += 1 + ops.n_refactorizations()
@@ -233,7 +296,7 @@ def solve(ops, x0, on_kkt=None, table=None, **options):
         # ---- backtracking line search, :2477-2588
         ap, ad = ops.fraction_to_the_bdry(it, dr, tau)
         theta = norms["nrmOne_nlp_feasib"]                              # resid->get_theta()
-        ls_status, ls_num = 0, 0
+        ls_status, ls_num, use_soc = 0, 0, 0
         gpd = None
         ini_step = True
         while True:
@@ -244,23 +307,34 @@ def solve(ops, x0, on_kkt=None, table=None, **options):
             f_logbar_trial = ops.logbar(trial, ev_t[0], mu)
             theta_trial = ops.theta(trial, ev_t[2], ev_t[3])
             ls_num += 1
-            # accept_line_search_conditions, :2852-2944
-            suff = theta_trial <= (1 - o["gamma_theta"]) * theta or f_logbar_trial <= f_logbar - o["gamma_phi"] * theta
-            if theta >= theta_min:
-                ls_status = 1 if suff else 0
-            else:
-                if gpd is None:
-                    gpd = ops.grad_phi_dx(it, dr, ev[1], mu)
-                if gpd < 0.0 and ap * (-gpd) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]:
-                    ls_status = 3 if f_logbar_trial <= f_logbar + o["eta_phi"] * ap * gpd else 0
-                else:
-                    ls_status = 2 if suff else 0
-            if ls_status > 0 and filt.contains(theta_trial, f_logbar_trial):
-                ls_status = 0
+            ls_status, gpd = _accept(ops, o, filt, theta, theta_trial, ap, f_logbar, f_logbar_trial, theta_min, gpd, it, dr, ev, mu)
             if ls_status > 0:
                 break
-            if ini_step and theta <= theta_trial:
-                raise NotImplementedError("second-order correction is not restated")       # :2561-2579
+            if ini_step and theta <= theta_trial and o["max_soc_iter"] > 0:
+                # ---- apply_second_order_correction, :2949-3038
+                theta_last, th, ap_soc, num_soc, st = 0.0, theta_trial, ap, 0, 0
+                gpd_soc = None
+                c_soc, d_soc = ops.c_resid(ev[2]), ops.d_resid(it, ev[3])
+                while num_soc < o["max_soc_iter"] and (num_soc == 0 or th <= o["kappa_soc"] * theta_last):
+                    theta_last = th
+                    c_soc = ap_soc * c_soc + ops.c_resid(ev_t[2])
+                    d_soc = ap_soc * d_soc + ops.d_resid(trial, ev_t[3])
+                    r_soc = ops.soc_resid(resid, c_soc, d_soc)                   # hiopResidual::update_soc, hiopResidual.cpp:425-600
+                    ok, dr_soc = ops.directions_no_ir(r_soc)                     # kkt->computeDirections
+                    if not ok:
+                        raise RuntimeError("computeDirections failed in the second-order correction")
+                    ap_soc, _ = ops.fraction_to_the_bdry(it, dr_soc, tau)
+                    trial, nadj = ops.trial_primals(it, dr_soc, ap_soc, ap_soc, mu)
+                    ev_t = ops.evaluate(trial)
+                    f_logbar_trial = ops.logbar(trial, ev_t[0], mu)
+                    th = ops.theta(trial, ev_t[2], ev_t[3])
+                    st, gpd_soc = _accept(ops, o, filt, theta, th, ap, f_logbar, f_logbar_trial, theta_min, gpd_soc, it, dr, ev, mu)
+                    if st > 0:
+                        break
+                    num_soc += 1
+                if st > 0:
+                    ls_status, ap, dr, resid, gpd, theta_trial, use_soc = st, ap_soc, dr_soc, r_soc, gpd_soc, th, 1
+                    break
             ap *= 0.5
             ini_step = False
         if nadj > 0:
@@ -279,6 +353,9 @@ def solve(ops, x0, on_kkt=None, table=None, **options):
         iter_num += 1
         # ---- duals, then the accepted trial becomes the iterate, :2714-2754
         it = ops.duals_update(it, trial, dr, ap, ad, mu)
+        if quasi_newton and theta_trial <= o["recalc_lsq_duals_tol"]:   # hiopDualsUpdater.cpp:118-149: with the gradient and the
+            if not ops.duals_lsq(it, ev[1]):                            # Jacobians of the PREVIOUS iterate (they are re-evaluated
+                raise RuntimeError("dual lsq update failed")            # only after `go`, hiopAlgFilterIPM.cpp:1448-1456)
         ev = ops.evaluate(it)
         f_logbar = ops.logbar(it, ev[0], mu)
         resid, norms = ops.residual(it, ev, mu)

@@ -198,6 +198,108 @@ class PDPerturbationPrimalFirstScalar:
         return bret
 
 
+class PDPerturbationDualFirstScalar(PDPerturbationPrimalFirstScalar):
+    """hiopPDPerturbationDualFirstScalar (hiopPDPerturbation.cpp:457-626): for the normal-equation KKT, where a wrong inertia
+    means the condensed matrix is not positive definite — the dual regularisation is tried first, the primal one after."""
+
+    def __init__(self, *a, delta_c_min_bar=1e-20, kappa_c_plus=10., **kw):         # :459-462
+        super().__init__(*a, **kw)
+        self.delta_c_min_bar, self.kappa_c_plus = delta_c_min_bar, kappa_c_plus
+
+    def _dual_perturb_impl(self):                                                   # :558-589
+        if self.cc == 0.:
+            if self.cc_last == 0.:
+                self.cc = max(self.delta_c_min_bar, self.delta_c_bar * self.mu ** self.kappa_c)
+            else:
+                self.cc = max(self.delta_c_min_bar, self.cc_last * self.kappa_w_minus)
+        else:
+            if self.cc_last == 0. or 1e5 * self.cc_last < self.cc:
+                self.cc = self.kappa_w_plus_bar * self.cc
+            else:
+                self.cc = self.kappa_c_plus * self.cc
+        self.cd = self.cc
+        if self.cc > self.delta_w_max_bar:
+            self.cc_last = self.cd_last = 0.
+            return False
+        return True
+
+    def _primal_perturb_impl(self):                                                 # :591-620
+        return self._guts_wrong_inertia()                                           # the same arithmetic as :331-358
+
+    def compute_initial_deltas(self):                                               # :470-512
+        self.update_degeneracy_type()
+        if self.wx > 0.:
+            self.wx_last = self.wx
+        if self.wd > 0.:
+            self.wd_last = self.wd
+        if self.cc > 0.:
+            self.cc_last = self.cc
+        if self.cd > 0.:
+            self.cd_last = self.cd
+        if self.hess_degenerate == self.NOT_EST or self.jac_degenerate == self.NOT_EST:
+            self.test_type = self.C0W0
+        else:
+            self.test_type = self.NO_TEST
+        self.cc = self.cd = 0.
+        if self.jac_degenerate == self.DEG:
+            if not self._dual_perturb_impl():
+                return False
+        self.wx = self.wd = 0.
+        if self.hess_degenerate == self.DEG:
+            if not self._primal_perturb_impl():
+                return False
+        return True
+
+    def compute_perturb_wrong_inertia(self):                                        # :514-547
+        self.update_degeneracy_type()
+        ret = self._dual_perturb_impl()
+        if not ret and self.wx == 0.:
+            self.cc = self.cd = 0.
+            ret = self._primal_perturb_impl()
+            if not ret:
+                return ret
+            self.test_type = self.NO_TEST
+            if self.jac_degenerate == self.DEG:
+                self.jac_degenerate = self.NOT_EST
+            ret = self._dual_perturb_impl()
+        return ret
+
+    def compute_perturb_singularity(self):                                          # :549-556
+        return self.compute_perturb_wrong_inertia()
+
+
+def randomized(base):
+    """hiopPDPerturbationPrimalFirstRand / DualFirstRand (hiopPDPerturbation.cpp:414-455, :670-711): the scalar machine of
+    `base`; deltas() hands out VECTORS, uniform in [min_uniform_ratio, max_uniform_ratio] x scalar (0.9, 1.0;
+    hiopPDPerturbation.hpp:53-54).  The draw itself comes from `source(name, n, lo, hi)` so that a test can feed the very
+    vectors another implementation drew (the reference uses the host's std generator: there is no stream to reproduce)."""
+
+    class Rand(base):
+        min_uniform_ratio, max_uniform_ratio = 0.9, 1.0
+
+        def __init__(self, sizes, source=None, **kw):
+            super().__init__(**kw)
+            self.sizes = sizes                                   # nx, nd, nyc, nyd
+            rng = np.random.default_rng(0)
+            self.source = source or (lambda name, n, lo, hi: rng.uniform(lo, hi, n) if hi > lo else np.full(n, lo))
+
+        def deltas(self):
+            """One draw per value of the scalars (set_delta_curr_vec runs when the machine changes them); callers between two
+            changes (build, the 12-block operator, test_direction) see the same vectors."""
+            key = (self.wx, self.wd, self.cc, self.cd)
+            if getattr(self, "_key", None) != key:
+                self._key = key
+                self._vecs = tuple(self.source(name, n, self.min_uniform_ratio * sc, self.max_uniform_ratio * sc)
+                                   for name, n, sc in zip(("wx", "wd", "cc", "cd"), self.sizes, key))
+            return self._vecs
+    Rand.__name__ = base.__name__.replace("Scalar", "Rand")
+    return Rand
+
+
+PDPerturbationPrimalFirstRand = randomized(PDPerturbationPrimalFirstScalar)
+PDPerturbationDualFirstRand = randomized(PDPerturbationDualFirstScalar)
+
+
 class PDPerturbationNull:
     """hiopPDPerturbationNull (hiopPDPerturbation.hpp:343-370): all deltas stay zero (quasi-Newton path)."""
     wx = wd = cc = cd = 0.0

@@ -87,26 +87,21 @@ class DeviceOps:
         return self.fg.num_refact
 
 
-class DeviceFilterOps(DeviceOps):
-    """The operations oracle/ipm_filter.py needs (restatement of hiopAlgFilterIPMNewton::run), every one on the device."""
+class _FilterOpsOnDevice:
+    """The operations oracle/ipm_filter.py needs (restatement of hiopAlgFilterIPMNewton / QuasiNewton ::run), every one on the
+    device.  Expects: ctx, fg (KKTLinSysXYcYd), ops (IpmSlabOps), nx, neq, nineq and the base class' evaluate / residual /
+    kkt_update / directions / fraction_to_the_bdry / from_host / primal."""
 
-    def __init__(self, ctx, p, full_o, bounds, q, kappa_d=1e-5, kappa_sigma=1e10):
-        super().__init__(ctx, p, full_o, bounds, q)
+    def _init_filter(self, full_o, bounds, kappa_d=1e-5, kappa_sigma=1e10):
         self.kappa_d, self.kappa_sigma = kappa_d, kappa_sigma
         self.n_complem = int(full_o.ixl.sum() + full_o.ixu.sum() + full_o.idl.sum() + full_o.idu.sum())
-        self.m = p.neq + p.nineq
+        self.m = self.neq + self.nineq
         self.pat = [D(v) for v in (full_o.ixl, full_o.ixu, full_o.idl, full_o.idu)]
         self.crhs = D(bounds[4])
         self.o = self.fg.off                      # x d yc yd sxl sxu sdl sdu zl zu vl vu
         self.host_start = ipm_filter.FilterOracleOps(full_o, bounds, None, kappa_d, kappa_sigma)
         self.host_start.model = lambda x: (None, None, None, self._d_of_x(x))
         torch.cuda.synchronize()
-
-    def _d_of_x(self, x):
-        xd = D(x); out = torch.zeros(self.nineq, dtype=torch.float64, device="cuda"); torch.cuda.synchronize()
-        assert self.fg._L.hiopamd_kkt_mds_jac_times_vec(self.kg.h, 1, 0.0, C.c_void_p(out.data_ptr()), 1.0, C.c_void_p(xd.data_ptr())) == 0
-        self.ctx.sync()
-        return out.cpu().numpy()
 
     def part(self, slab, i):
         return slab[self.o[i]:self.o[i + 1]]
@@ -125,8 +120,12 @@ class DeviceFilterOps(DeviceOps):
         resid, n = super().residual(it, ev, mu, self.kappa_d)
         return resid, dict(zip(osl.NORM_ORDER, n))
 
+    def _norm(self, name, it, i):
+        n = self.o[i + 1] - self.o[i]
+        return self.ctx.reduce_double(name, n, self.part(it, i)) if n else 0.0
+
     def dual_norms(self, it):
-        one = lambda i: self.ctx.reduce_double("hiopamd_vec_onenorm", self.o[i + 1] - self.o[i], self.part(it, i))
+        one = lambda i: self._norm("hiopamd_vec_onenorm", it, i)
         return one(2) + one(3), one(8) + one(9) + one(10) + one(11)
 
     def logbar(self, it, f, mu):
@@ -141,12 +140,16 @@ class DeviceFilterOps(DeviceOps):
         torch.cuda.synchronize()
         ctx.call("hiopamd_vec_add_log_barrier_grad", nx, gx, -mu, self.part(it, 4), self.pat[0])
         ctx.call("hiopamd_vec_add_log_barrier_grad", nx, gx, mu, self.part(it, 5), self.pat[1])
-        ctx.call("hiopamd_vec_add_log_barrier_grad", nd, gd, -mu, self.part(it, 6), self.pat[2])
-        ctx.call("hiopamd_vec_add_log_barrier_grad", nd, gd, mu, self.part(it, 7), self.pat[3])
+        v = ctx.reduce_double("hiopamd_vec_dot", nx, self.part(dr, 0), gx) if self.kappa_d <= 0 else None
+        if nd:
+            ctx.call("hiopamd_vec_add_log_barrier_grad", nd, gd, -mu, self.part(it, 6), self.pat[2])
+            ctx.call("hiopamd_vec_add_log_barrier_grad", nd, gd, mu, self.part(it, 7), self.pat[3])
         if self.kappa_d > 0:
             ctx.call("hiopamd_vec_add_linear_damping_term", nx, gx, self.pat[0], self.pat[1], 1.0, self.kappa_d * mu)
-            ctx.call("hiopamd_vec_add_linear_damping_term", nd, gd, self.pat[2], self.pat[3], 1.0, self.kappa_d * mu)
-        return ctx.reduce_double("hiopamd_vec_dot", nx, self.part(dr, 0), gx) + ctx.reduce_double("hiopamd_vec_dot", nd, self.part(dr, 1), gd)
+            if nd:
+                ctx.call("hiopamd_vec_add_linear_damping_term", nd, gd, self.pat[2], self.pat[3], 1.0, self.kappa_d * mu)
+            v = ctx.reduce_double("hiopamd_vec_dot", nx, self.part(dr, 0), gx)
+        return v + (ctx.reduce_double("hiopamd_vec_dot", nd, self.part(dr, 1), gd) if nd else 0.0)
 
     def trial_primals(self, it, d, ap, ad, mu):
         trial = it.clone()
@@ -157,12 +160,33 @@ class DeviceFilterOps(DeviceOps):
         self.ctx.sync()
         return trial, nadj
 
+    def c_resid(self, c):
+        self.ctx.sync()
+        return self.crhs - c
+
+    def d_resid(self, it, d):
+        self.ctx.sync()
+        return self.part(it, 1) - d
+
     def theta(self, it, c, d):
-        ctx = self.ctx
-        rc = self.crhs - c
-        rd = self.part(it, 1) - d
+        rc, rd = self.c_resid(c), self.d_resid(it, d)
         torch.cuda.synchronize()
-        return ctx.reduce_double("hiopamd_vec_onenorm", self.neq, rc) + ctx.reduce_double("hiopamd_vec_onenorm", self.nineq, rd)
+        one = lambda n, v: self.ctx.reduce_double("hiopamd_vec_onenorm", n, v) if n else 0.0
+        return one(self.neq, rc) + one(self.nineq, rd)
+
+    def soc_resid(self, resid, c_soc, d_soc):
+        r = resid.clone()
+        r[self.o[2]:self.o[3]] = c_soc              # RESID_PARTS: rx rd ryc ryd ...
+        r[self.o[3]:self.o[4]] = d_soc
+        torch.cuda.synchronize()
+        return r
+
+    def directions_no_ir(self, resid):
+        d = torch.empty_like(resid)
+        torch.cuda.synchronize()
+        ok = self.fg.compute_directions(resid, d)
+        self.ctx.sync()
+        return ok, d
 
     def duals_update(self, it, trial, d, ap, ad, mu):
         out = trial.clone()
@@ -171,6 +195,32 @@ class DeviceFilterOps(DeviceOps):
         self.ops.adjust_duals_plh(out, mu, self.kappa_sigma)
         self.ctx.sync()
         return out
+
+    # quasi-Newton variant
+    def duals_lsq(self, it, grad_f):
+        ok = self.ops.duals_lsq_update(it, grad_f)
+        self.ctx.sync()
+        return ok
+
+    def dual_norms_inf(self, it):
+        return max(self._norm("hiopamd_vec_infnorm", it, 2), self._norm("hiopamd_vec_infnorm", it, 3)), None
+
+    def zero_eq_duals(self, it):
+        self.ctx.sync()
+        it[self.o[2]:self.o[4]] = 0.0
+        torch.cuda.synchronize()
+
+
+class DeviceFilterOps(_FilterOpsOnDevice, DeviceOps):
+    def __init__(self, ctx, p, full_o, bounds, q):
+        DeviceOps.__init__(self, ctx, p, full_o, bounds, q)
+        self._init_filter(full_o, bounds)
+
+    def _d_of_x(self, x):
+        xd = D(x); out = torch.zeros(self.nineq, dtype=torch.float64, device="cuda"); torch.cuda.synchronize()
+        assert self.fg._L.hiopamd_kkt_mds_jac_times_vec(self.kg.h, 1, 0.0, C.c_void_p(out.data_ptr()), 1.0, C.c_void_p(xd.data_ptr())) == 0
+        self.ctx.sync()
+        return out.cpu().numpy()
 
 
 @pytest.mark.parametrize("ns,nd", [(40, 12), (400, 100)])
@@ -236,11 +286,11 @@ class DeviceOpsDenseEx2:
     device tensors (the role of the user's eval_f / eval_grad_f / eval_cons with mem_space = device), the secant update,
     KKT, residuals and steps are the library's."""
 
-    def __init__(self, ctx, q, full_o, bounds):
+    def __init__(self, ctx, q, full_o, bounds, strategy="sigma0"):
         from hiop_amd.kkt import HessianLowRank, IpmSlabOps, KKTLinSysLowRank, KKTLinSysXYcYd
         self.ctx, self.n = ctx, q["n"]
         self.Jc, self.Jd = D(q["Jc"]), D(q["Jd"])
-        self.H = HessianLowRank(ctx, self.n, q["Jc"].shape[0], q["Jd"].shape[0], l_max=6, sigma0=1.0, sigma_update_strategy="sigma0")
+        self.H = HessianLowRank(ctx, self.n, q["Jc"].shape[0], q["Jd"].shape[0], l_max=6, sigma0=1.0, sigma_update_strategy=strategy)
         self.K = KKTLinSysLowRank(ctx, self.H)
         self.fg = KKTLinSysXYcYd(ctx, self.K, D(full_o.ixl), D(full_o.ixu), D(full_o.idl), D(full_o.idu))
         self.fg.set_matrices(None, self.Jc, self.Jd)
@@ -320,8 +370,8 @@ def test_device_quasi_newton_ipm_dense_ex2(ctx, n):
 class DeviceOpsDenseEx1(DeviceOpsDenseEx2):
     """DenseConsEx1 (mass-weighted QP, one equality constraint, no inequalities) with the same device-resident loop."""
 
-    def __init__(self, ctx, q, full_o, bounds):
-        super().__init__(ctx, q, full_o, bounds)
+    def __init__(self, ctx, q, full_o, bounds, strategy="sigma0"):
+        super().__init__(ctx, q, full_o, bounds, strategy)
         self.mass, self.c = D(q["mass"]), D(q["c"])
 
     def evaluate(self, it):
@@ -365,3 +415,58 @@ def test_device_quasi_newton_ipm_dense_ex1(ctx):
     a, b = np.array(t_cpu[:20]), np.array(t_gpu[:20])
     np.testing.assert_allclose(b[:, 0], a[:, 0], rtol=1e-7, atol=1e-10)
     assert abs(r["iters"] - r_cpu["iters"]) <= r_cpu["iters"] // 4     # (132 vs 153 measured: same problem, rounding-different secant history)
+
+
+def _dense_filter_ops(base):
+    class Ops(_FilterOpsOnDevice, base):
+        """hiopAlgFilterIPMQuasiNewton::run's operations for the dense examples: secant update (hiopHessianLowRank::update) as its
+        own step before the KKT update, LSQ duals."""
+
+        def __init__(self, ctx, q, full_o, bounds):
+            base.__init__(self, ctx, q, full_o, bounds, strategy="sty")        # the reference's default sigma_update_strategy
+            self.nx, self.neq, self.nineq = q["n"], q["Jc"].shape[0], q["Jd"].shape[0]
+            self._init_filter(full_o, bounds)
+
+        def _d_of_x(self, x):
+            return (self.Jd @ D(x)).cpu().numpy()
+
+        def hess_update(self, it, ev):
+            o = self.o
+            x, yc, yd = it[o[0]:o[1]], it[o[2]:o[3]], it[o[3]:o[4]]
+            torch.cuda.synchronize()
+            self.H.update(x, ev[1], self.Jc, self.Jd, yc, yd)
+            self.ctx.sync()
+
+        def kkt_update(self, it, mu):
+            self.fg.set_mu(mu)
+            return self.fg.update(it)
+    return Ops
+
+
+@pytest.mark.parametrize("example,n", [("DenseConsEx2", 500), ("DenseConsEx2", 5000), ("DenseConsEx1", 500), ("DenseConsEx1", 5000),
+                                       ("DenseConsEx1", 50000)])
+def test_device_quasi_newton_filter_ipm_passes_the_reference_selfcheck(ctx, example, n):
+    """The north-star path (secant Hessian + low-rank KKT, hiopKKTLinSysLowRank) under the reference's own quasi-Newton filter
+    IPM loop (oracle/ipm_filter.py, quasi_newton=True) at the dense drivers' default options, every per-iteration operation on
+    the device: the run must (1) end at the objective the driver stores for -selfcheck under the driver's own formula
+    (|saved - obj| / (1 + saved) <= 1e-6; DenseConsEx1: to the stored digits), and (2) follow the numpy run of the same loop —
+    same barrier schedule and line-search decisions, objective per iteration to 1e-6 relative — up to the point where the
+    quasi-Newton iteration has amplified rounding differences (checked on the first 8 iterations and the final objective)."""
+    from tests.test_oracle_reference_trajectory import quasi_newton_setup, reference_selfcheck
+    q = pr.dense_ex2(n) if example == "DenseConsEx2" else pr.dense_ex1(n)
+    ops_cpu, full, bounds = quasi_newton_setup(q)
+    t_cpu, t_gpu = [], []
+    r_cpu = ipm_filter.solve(ops_cpu, q["x0"], table=t_cpu, quasi_newton=True)
+    dev = _dense_filter_ops(DeviceOpsDenseEx2 if example == "DenseConsEx2" else DeviceOpsDenseEx1)(ctx, q, full, bounds)
+    r_gpu = ipm_filter.solve(dev, q["x0"], table=t_gpu, quasi_newton=True)
+    assert r_gpu["status"] == "Solve_Success"
+    g = GOLD[example]
+    saved = g["objective"][g["n"].index(n)]
+    assert reference_selfcheck(saved, r_gpu["obj"])
+    if example == "DenseConsEx1":
+        assert abs(r_gpu["obj"] - saved) <= {500: 5e-9, 5000: 5e-8, 50000: 5e-7}[n]
+    assert abs(r_gpu["obj"] - r_cpu["obj"]) <= 1e-9
+    assert abs(r_gpu["iters"] - r_cpu["iters"]) <= 2
+    for a, b in list(zip(t_cpu, t_gpu))[:8]:
+        assert a["mu"] == b["mu"] and a["ls"] == b["ls"] and a["ls_num"] == b["ls_num"], (a, b)
+        assert abs(a["objective"] - b["objective"]) <= 1e-6 * max(1.0, abs(a["objective"])), (a, b)

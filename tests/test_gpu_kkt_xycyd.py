@@ -340,3 +340,132 @@ def test_inertia_free_acceptor_test_direction_and_refactorize(ctx):
         rounds += 1
         assert rounds <= 10
     assert rounds >= 1 and fg.deltas()[0] > 0
+
+
+class _FrozenDeltas:
+    """The oracle-side stand-in for a *Rand perturbation whose draw was made elsewhere: hands out the given vectors and never
+    changes them (any request for a correction means the oracle disagrees with the inertia the device accepted)."""
+
+    def __init__(self, vecs):
+        self.vecs = tuple(vecs)
+        self.asked = 0
+
+    def set_mu(self, mu):
+        pass
+
+    def deltas(self):
+        return self.vecs
+
+    def compute_initial_deltas(self):
+        return True
+
+    def compute_perturb_wrong_inertia(self):
+        self.asked += 1
+        return True
+
+    compute_perturb_singularity = compute_perturb_wrong_inertia
+
+
+@pytest.mark.parametrize("backend", ["mds", "dense_xycyd", "dense_xdycyd"])
+@pytest.mark.parametrize("dual_first", [False, True])
+def test_randomized_regularisation_vectors(ctx, backend, dual_first):
+    """hiopPDPerturbationPrimalFirstRand / DualFirstRand (regularization_method = randomized): on a non-convex system the
+    inertia-correction loop ends with VECTOR regularisations, uniform in [0.9, 1.0] x the scalar of the state machine
+    (hiopPDPerturbation.hpp:53-54).  Checked: the range and the spread of the drawn vectors, reproducibility from the seed,
+    and that build, solve, 12-block operator and test_direction all consume the same vectors — through the oracle's
+    restatements evaluated WITH THE DEVICE'S VECTORS (the reference draws from the host's std generator: there is no stream
+    to be bit-identical with)."""
+    from hiop_amd.kkt import KKTLinSysXYcYd
+    if backend == "mds":
+        p, k, fo, it = cases.mds_case(16, 9, nonconvex=True)
+        kg, fg, keep = gpu_mds(ctx, p, k, fo.ixl, fo.ixu, fo.idl, fo.idu)
+        kg2, fg2, keep2 = gpu_mds(ctx, p, k, fo.ixl, fo.ixu, fo.idl, fo.idu)
+    else:
+        xd = backend == "dense_xdycyd"
+        nx, neq, nineq = 60, 8, 21
+        (H, Jc, Jd, ixl, ixu, idl, idu), fo, it = cases.dense_case(nx, neq, nineq, seed=nx + int(xd), nonconvex=True, xd_form=xd)
+        mk = lambda: KKTLinSysXYcYd(ctx, None, D(ixl), D(ixu), D(idl), D(idu), dense_dims=(nx, neq, nineq), xd_form=xd)
+        fg, fg2 = mk(), mk()
+        mats = (D(H), D(Jc), D(Jd))
+        fg.set_matrices(*mats); fg2.set_matrices(*mats)
+    fg.set_regularization(dual_first=dual_first, randomized=True, seed=1234)
+    fg2.set_regularization(dual_first=dual_first, randomized=True, seed=1234)
+    it_g = fg.pack(it, kf.ITER_PARTS)
+    ok = fg.update(it_g)
+    sc = fg.deltas()
+    if dual_first and not ok:
+        # dual regularisation alone cannot repair a negative Hessian block: the machine raises delta_c to its cap, then switches
+        # to the primal one (hiopPDPerturbation.cpp:529-540); within 10 re-factorisations that may not finish — same on the oracle
+        fo.perturb = kf.PDPerturbationDualFirstScalar()
+        assert fo.update(it) is False
+        return
+    assert ok and fg.num_refact > 0
+    vecs = [v.cpu().numpy() for v in fg.delta_vectors()]
+    lo, hi = 0.9, 1.0
+    for v, s in zip(vecs, sc):
+        if v.size == 0:
+            continue
+        assert (v >= lo * s).all() and (v <= hi * s).all()
+        if s > 0 and v.size >= 8:
+            assert v.std() > 0.01 * s and abs(v.mean() - 0.95 * s) < 0.04 * s
+    assert sc[0] > 0 or sc[2] > 0
+    # same seed, same sequence of draws -> identical vectors; another seed -> different
+    assert fg2.update(it_g) and fg2.deltas() == sc
+    for a, b in zip(fg2.delta_vectors(), vecs):
+        assert np.array_equal(a.cpu().numpy(), b)
+    fg2.set_regularization(dual_first=dual_first, randomized=True, seed=99)
+    assert fg2.update(it_g)
+    assert any(v.size and not np.array_equal(a.cpu().numpy(), v) for a, v in zip(fg2.delta_vectors(), vecs))
+    # the oracle with the device's vectors: its factorisation of that matrix has the inertia the device accepted ...
+    fo.perturb = _FrozenDeltas(vecs)
+    assert fo.update(it) and fo.perturb.asked == 0
+    # ... and directions, 12-block operator and test_direction agree
+    r = cases.random_resid(fo.sizes, fo.ixl, fo.ixu, fo.idl, fo.idu)
+    r_g = fg.pack(r, kf.RESID_PARTS)
+    ok_o, d_o = fo.compute_directions(r)
+    d_g = torch.zeros(fg.dim, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert fg.compute_directions(r_g, d_g) and ok_o
+    ctx.sync()
+    compare_dirs(fg, d_g, d_o, rtol=1e-8)
+    xr = np.random.Generator(np.random.PCG64(5)).uniform(-1, 1, fg.dim)
+    y = torch.zeros_like(d_g)
+    xr_g = D(xr)
+    torch.cuda.synchronize()
+    fg.times_vec(y, xr_g); ctx.sync()
+    close(y.cpu().numpy(), fo.times_vec_flat(xr), 1e-13)
+    acc_g, dWd, nrm = fg.test_direction(d_g)
+    acc_o = fo.test_direction(d_o)
+    assert acc_g == acc_o and dWd == pytest.approx(fo.last_dWd, rel=1e-6, abs=1e-9 * fo.last_xs_nrmsq)
+    ok_g, info_g = fg.compute_directions_w_IR(r_g, d_g)
+    ctx.sync()
+    ok_o, d_o2, info_o = fo.compute_directions_w_IR(r, mu=1e-8)
+    assert ok_g and info_g["converged"] and info_o["converged"]
+    compare_dirs(fg, d_g, d_o2, rtol=1e-8)
+
+
+@pytest.mark.parametrize("randomized", [False, True])
+def test_dual_first_regularisation_on_a_singular_jacobian(ctx, randomized):
+    """hiopPDPerturbationDualFirstScalar / DualFirstRand on a rank-deficient equality Jacobian: the first correction is the dual
+    one (delta_c = max(1e-20, 1e-8 mu^0.25)), the primal deltas stay zero; scalar mode: deltas and re-factorisation count equal
+    to the oracle's machine; randomized: delta_cc / delta_cd vectors in [0.9, 1.0] x delta_c and the oracle agrees on the
+    inertia of the matrix built with them."""
+    p, k, fo, it = cases.mds_case(8, 6)
+    cases.zero_equality_row(k, 1)
+    kg, fg, keep = gpu_mds(ctx, p, k, fo.ixl, fo.ixu, fo.idl, fo.idu)
+    fo.perturb = kf.PDPerturbationDualFirstScalar()
+    fo.perturb.set_mu(1e-2)
+    fg.set_regularization(dual_first=True, randomized=randomized, seed=7)
+    fg.set_mu(1e-2)
+    it_g = fg.pack(it, kf.ITER_PARTS)
+    assert fo.update(it) and fg.update(it_g)
+    assert fg.num_refact == fo.num_refact == 1
+    assert fg.deltas() == fo.perturb.deltas() == (0.0, 0.0, 1e-8 * 1e-2 ** 0.25, 1e-8 * 1e-2 ** 0.25)
+    if randomized:
+        vecs = [v.cpu().numpy() for v in fg.delta_vectors()]
+        dc = fg.deltas()[2]
+        assert not vecs[0].any() and not vecs[1].any()
+        for v in vecs[2:]:
+            assert (v >= 0.9 * dc).all() and (v <= dc).all() and v.std() > 0
+        fo.perturb = _FrozenDeltas(vecs)
+        assert fo.update(it) and fo.perturb.asked == 0
