@@ -36,6 +36,7 @@ SOURCES = [
     "krylov.hip",
     "example_mds.hip",
     "example_dense.hip",
+    "ipm_mds.hip",
 ]
 
 # per-file device-code options.  ldlt.hip / gram.hip: the SI load/store optimizer fuses two ds_read_b64 into one

@@ -43,6 +43,12 @@ def dptr(t, ctx=None) -> C.c_void_p:
     if isinstance(t, torch.Tensor):
         assert t.is_contiguous()
         if t.is_cuda:
+            # producer side of the same problem: the tensor may have been written by kernels still queued on torch's current
+            # stream — the context's stream waits for them (an event, no host synchronisation)
+            cur = torch.cuda.current_stream()
+            for c in ([ctx] if ctx is not None else list(_LIVE_CONTEXTS.values())):
+                if getattr(c, "torch_stream", None) is not None and cur.cuda_stream != c.torch_stream.cuda_stream:
+                    c.torch_stream.wait_stream(cur)
             ids = {id(ctx)} if ctx is not None else set(_LIVE_CONTEXTS.keys())
             if ids:
                 _KEEP.append([t, ids])

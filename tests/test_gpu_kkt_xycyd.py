@@ -383,7 +383,8 @@ def test_randomized_regularisation_vectors(ctx, backend, dual_first):
     else:
         xd = backend == "dense_xdycyd"
         nx, neq, nineq = 60, 8, 21
-        (H, Jc, Jd, ixl, ixu, idl, idu), fo, it = cases.dense_case(nx, neq, nineq, seed=nx + int(xd), nonconvex=True, xd_form=xd)
+        (H, Jc, Jd, ixl, ixu, idl, idu), fo, it = cases.dense_case(nx, neq, nineq, seed=nx + int(xd), nonconvex=True, xd_form=xd,
+                                                                   neg_value=-50.0, free_nonconvex=True)
         mk = lambda: KKTLinSysXYcYd(ctx, None, D(ixl), D(ixu), D(idl), D(idu), dense_dims=(nx, neq, nineq), xd_form=xd)
         fg, fg2 = mk(), mk()
         mats = (D(H), D(Jc), D(Jd))

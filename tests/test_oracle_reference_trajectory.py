@@ -25,10 +25,10 @@ GOLD = json.loads((GOLD_DIR / "selfcheck_objectives.json").read_text())
 DRIVER_OPTIONS = dict(mu0=0.1, tolerance=1e-5)            # NlpMdsEx1Driver.cpp:138-139; duals_init zero, linear duals: the restatement's
 
 
-def reference_setup(ns, nd):
+def reference_setup(ns, nd, p=None):
     """MdsEx1 as hiopNlpMDS presents it to the algorithm: bounds relaxed by bound_relax_perturb = 1e-8
     (hiopNlpFormulation.cpp:398-402)."""
-    p = pr.mds_ex1(ns, nd)
+    p = pr.mds_ex1(ns, nd) if p is None else p
     k = ho.KKTLinSysCompressedMDSXYcYd(p.nxs, p.nxd, p.neq, p.nineq, (p.Jcs_i, p.Jcs_j), (p.Jds_i, p.Jds_j), (p.Hss_i, p.Hss_j))
     k.set_values(p.Jcs_v, p.Jds_v, p.Hss_v, p.Jcd, p.Jdd, p.Hdd, None, None)
     f = lambda b: b.astype(np.float64)
