@@ -591,8 +591,10 @@ double* hiopamd_kkt_lowrank_N(hiopamd_kkt_lowrank* K);   /* device, k x k, the l
 double hiopamd_kkt_lowrank_last_residual(const hiopamd_kkt_lowrank* K);
 /* N = J (H+Dx)^-1 J^T + Dd^-1 and its factor are kept between the solveCompressed calls of one outer iteration (the
  * reference rebuilds them on every call, hiopKKTLinSys.cpp:1132-1135); any update / update_diag / set_jacobians call or
- * a change of the Hessian invalidates them.  enable = 0 restores the rebuild-on-every-call behaviour (same results, bit
- * for bit; for A/B tests). */
+ * a change of the Hessian invalidates them.  The Jacobians are borrowed: a caller that overwrites their VALUES in place
+ * (same pointers) between two solves must announce it with one of those calls — update() does, which is the reference's
+ * calling sequence (hiopAlgFilterIPM.cpp:1212-1213: update before every solve of a new iterate).  enable = 0 restores the
+ * rebuild-on-every-call behaviour (same results, bit for bit; for A/B tests). */
 int hiopamd_kkt_lowrank_set_cache(hiopamd_kkt_lowrank* K, int enable);
 
 /* =====================================================================================
