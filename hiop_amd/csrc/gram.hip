@@ -321,8 +321,19 @@ struct GramStripTiles2 {
 template <int WAVES, int TPW, int ROWS, bool VEC>
 __device__ __forceinline__ void gram_strip2_body(int ma, int mb, int64_t n, const GramRows& X, const double* __restrict__ d,
                                                  int64_t kchunk, int tiles_b, int ntiles, const GramStripTiles2<WAVES, TPW>& tl,
-                                                 double* __restrict__ partial, double (*Xs)[ROWS][GS_LD], double (*ds)[GS_KT])
+                                                 double* __restrict__ partial, double* __restrict__ Xs, double (*ds)[GS_KT])
 {
+  // LDS layout of a stage buffer (round 3, after PMC showed SQ_LDS_BANK_CONFLICT = 48 % of the LDS cycles with the padded row-major
+  // layout: ds_read_b128 is served in four fixed 16-lane groups, each mixing TWO k-slots lk with complementary row sets, and
+  // conflict-free means 16 distinct 16-byte slots of a 256-byte bank row per group — MI355X_MICROARCH.md §LDS):
+  //   four PLANES, one per k-slot lk = k % 4; inside a plane row r holds its 8 k-values of that slot as four 16-byte pairs
+  //   (k = 8 g + lk, k + 4), pair g stored at position g ^ ((r >> 2) & 3)  (64 bytes per row, no padding).
+  // Slot of lane (li, lk) for pair g: 4 (li & 3) + (g ^ (li >> 2)) + plane shift — within a lane group the two k-slots own rows with
+  // li >> 2 in {0, 3} and {1, 2}: disjoint, whatever g.  Planes 2, 3 start 64 bytes later (mod 128) than planes 0, 1 so that the
+  // 8-byte staging stores of a 16-lane group (k-slots {0, 2} or {1, 3}) fall on 16 distinct bank pairs as well.
+  constexpr int GS_PLANE = ROWS * 8;                  // doubles per plane
+  constexpr int GS_BUF = 4 * GS_PLANE + 16;           // doubles per stage buffer
+  auto plane = [](int lk) { return lk * GS_PLANE + (lk >> 1) * 8; };
   constexpr int NT = 64 * WAVES;
   constexpr int RPP = NT / 16;          // rows per staging pass
   constexpr int NP = ROWS / RPP;        // staging passes
@@ -336,9 +347,11 @@ __device__ __forceinline__ void gram_strip2_body(int ma, int mb, int64_t n, cons
   const int npa = __builtin_amdgcn_readfirstlane((((mb + 15) / 16) * 16 + RPP - 1) / RPP);   // staging passes with live rows
   const int ntw = tl.cnt[wave];
   const int srow = tid >> 4, skk = (tid & 15) * 2;
-  // position of k inside its group of 8: (k % 4) * 2 + (k / 4) % 2  ->  k and k + 4 adjacent (one ds_read_b128 = two k-steps)
-  const int p0 = (skk & ~7) + ((skk & 3) << 1) + ((skk >> 2) & 1);
-  const int p1 = (skk & ~7) + (((skk + 1) & 3) << 1) + (((skk + 1) >> 2) & 1);
+  // staging store offsets of k = skk and k + 1 (same group of 8: skk is even) for row srow (+ 8 ps RPP doubles per pass: RPP is a
+  // multiple of 16, so (row >> 2) & 3 does not depend on the pass)
+  const int sg = skk >> 3, sq = (srow >> 2) & 3;
+  const int p0 = plane(skk & 3) + srow * 8 + ((sg ^ sq) << 1) + ((skk >> 2) & 1);
+  const int p1 = plane((skk + 1) & 3) + srow * 8 + ((sg ^ sq) << 1) + (((skk + 1) >> 2) & 1);
   // Staging without a branch or a wait inside: the row pointers are resolved once (segment look-ups are dependent loads), a
   // row outside the matrix is clamped to the last row and masked when it is written to LDS, a k outside the chunk likewise;
   // all loads of a stage are issued back to back one stage ahead, the masks are applied at the LDS store.
@@ -391,8 +404,8 @@ __device__ __forceinline__ void gram_strip2_body(int ma, int mb, int64_t n, cons
 #pragma unroll
     for(int ps = 0; ps < NP; ++ps) {
       if(ps < npa) {   // scalar; nothing waits inside
-        Xs[buf][ps * RPP + srow][p0] = (rok[ps] && m0) ? v0[ps] : 0.0;
-        Xs[buf][ps * RPP + srow][p1] = (rok[ps] && m1) ? v1[ps] : 0.0;
+        Xs[buf * GS_BUF + ps * RPP * 8 + p0] = (rok[ps] && m0) ? v0[ps] : 0.0;
+        Xs[buf * GS_BUF + ps * RPP * 8 + p1] = (rok[ps] && m1) ? v1[ps] : 0.0;
       }
     }
     if(tid < GS_KT) ds[buf][tid] = md ? (d ? dreg : 1.0) : 0.0;
@@ -405,10 +418,10 @@ __device__ __forceinline__ void gram_strip2_body(int ma, int mb, int64_t n, cons
 #pragma unroll
   for(int t = 0; t < TPW; ++t) {
     const int tt = (t < ntw) ? t : 0;
-    aoff[t] = __builtin_amdgcn_readfirstlane(16 * GS_LD * (int)tl.ti[wave][tt]);
-    boff[t] = __builtin_amdgcn_readfirstlane(16 * GS_LD * (int)tl.tj[wave][tt]);
+    aoff[t] = __builtin_amdgcn_readfirstlane(16 * 8 * (int)tl.ti[wave][tt]);
+    boff[t] = __builtin_amdgcn_readfirstlane(16 * 8 * (int)tl.tj[wave][tt]);
   }
-  const int lane_off = li * GS_LD + 2 * lk;
+  const int lane_off = plane(lk) + li * 8, lq = li >> 2;
   if(kbeg < kend) {
     gload(kbeg);
     lstore(0);
@@ -421,7 +434,7 @@ __device__ __forceinline__ void gram_strip2_body(int ma, int mb, int64_t n, cons
 #pragma unroll
     for(int g8 = 0; g8 < GS_KT / 8; ++g8) {
       const double w0 = ds[buf][8 * g8 + lk], w1 = ds[buf][8 * g8 + 4 + lk];
-      const double* xb = &Xs[buf][0][0] + lane_off + 8 * g8;
+      const double* xb = Xs + buf * GS_BUF + lane_off + ((g8 ^ lq) << 1);
 #pragma unroll
       for(int tb0 = 0; tb0 < TPW; tb0 += TB) {
         gs_double2 av[TB], bv[TB];
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(64 * WAVES, (ROWS <= 128) ? 2 : 1) void gram_strip2
                                                                                        const GramStripTiles2<WAVES, TPW> tl,
                                                                                        double* __restrict__ partial)
 {
-  __shared__ __attribute__((aligned(16))) double Xs[2][ROWS][GS_LD];
+  __shared__ __attribute__((aligned(256))) double Xs[2 * (4 * ROWS * 8 + 16)];
   __shared__ double ds[2][GS_KT];
   if(vec_ok) gram_strip2_body<WAVES, TPW, ROWS, true>(ma, mb, n, X, d, kchunk, tiles_b, ntiles, tl, partial, Xs, ds);
   else gram_strip2_body<WAVES, TPW, ROWS, false>(ma, mb, n, X, d, kchunk, tiles_b, ntiles, tl, partial, Xs, ds);
