@@ -17,42 +17,102 @@ namespace hiopamd {
 // ------------------------------------------------------------------------------------------
 constexpr int GEMV_ROWS = 8;
 constexpr int GEMV_COLS_PER_THREAD = 8;
-constexpr int GEMV_COLS = kBlock * GEMV_COLS_PER_THREAD;  // 2048 columns per block
+constexpr int GEMV_CHUNKS = 4;                                        // column chunks one block walks before it reduces
+constexpr int GEMV_COLS = kBlock * GEMV_COLS_PER_THREAD * GEMV_CHUNKS;  // 8192 columns per block
 
+// Round 3: the counters of the round-2 kernel (profiles/r03_pmc_dense: SQ_WAIT_INST_LDS = 72 % of its busy cycles) showed the
+// cross-lane reduction, not the stream over A, as its largest cost: 8 rows x 6 shuffle steps x 2 ds_bpermute per thread after only
+// 64 loads.  Now a block walks GEMV_CHUNKS column chunks before it reduces, rows are read with 16-byte loads when the layout
+// allows, and the wave reduction halves the number of live sums at every step (lanes l and l ^ 32 split the 8 rows 4 / 4, then 2 / 2,
+// then 1 / 1: 4 + 2 + 1 + 3 exchanges instead of 48).
+template <bool VEC>
 __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const double* __restrict__ A, int64_t lda,
                                                         const double* __restrict__ x, double* __restrict__ part)
 {
-  const int64_t c0 = (int64_t)blockIdx.x * GEMV_COLS;
   const int r0 = blockIdx.y * GEMV_ROWS;
-  double xv[GEMV_COLS_PER_THREAD];
-#pragma unroll
-  for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) {
-    int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
-    xv[u] = (j < n) ? x[j] : 0.0;
-  }
   double acc[GEMV_ROWS];
 #pragma unroll
-  for(int r = 0; r < GEMV_ROWS; ++r) {
-    acc[r] = 0.0;
-    const int row = r0 + r;
-    if(row < m) {
-      const double* Ar = A + (int64_t)row * lda;
+  for(int r = 0; r < GEMV_ROWS; ++r) acc[r] = 0.0;
+  for(int ch = 0; ch < GEMV_CHUNKS; ++ch) {
+    const int64_t c0 = ((int64_t)blockIdx.x * GEMV_CHUNKS + ch) * (kBlock * GEMV_COLS_PER_THREAD);
+    if(c0 >= n) break;
+    if constexpr(VEC) {
+      // columns c0 + 2 t + 512 u (+0, +1): 16 bytes per lane, 1 KB per wave per instruction (n even or the pair test below)
+      double2 xv[GEMV_COLS_PER_THREAD / 2];
+#pragma unroll
+      for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u) {
+        const int64_t j = c0 + 2 * threadIdx.x + (int64_t)u * 2 * kBlock;
+        xv[u] = (j + 1 < n) ? *reinterpret_cast<const double2*>(x + j) : double2{(j < n) ? x[j] : 0.0, 0.0};
+      }
+#pragma unroll
+      for(int r = 0; r < GEMV_ROWS; ++r) {
+        const int row = r0 + r;
+        if(row < m) {
+          const double* Ar = A + (int64_t)row * lda;
+#pragma unroll
+          for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u) {
+            const int64_t j = c0 + 2 * threadIdx.x + (int64_t)u * 2 * kBlock;
+            if(j + 1 < n) {
+              const double2 a = *reinterpret_cast<const double2*>(Ar + j);
+              acc[r] = fma(a.x, xv[u].x, acc[r]);
+              acc[r] = fma(a.y, xv[u].y, acc[r]);
+            } else if(j < n) {
+              acc[r] = fma(Ar[j], xv[u].x, acc[r]);
+            }
+          }
+        }
+      }
+    } else {
+      double xv[GEMV_COLS_PER_THREAD];
 #pragma unroll
       for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) {
-        int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
-        if(j < n) acc[r] = fma(Ar[j], xv[u], acc[r]);
+        const int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
+        xv[u] = (j < n) ? x[j] : 0.0;
+      }
+#pragma unroll
+      for(int r = 0; r < GEMV_ROWS; ++r) {
+        const int row = r0 + r;
+        if(row < m) {
+          const double* Ar = A + (int64_t)row * lda;
+#pragma unroll
+          for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) {
+            const int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
+            if(j < n) acc[r] = fma(Ar[j], xv[u], acc[r]);
+          }
+        }
       }
     }
   }
-  // block reduce the 8 accumulators
-  __shared__ double sm[GEMV_ROWS][kBlock / 64];
+  // wave reduction with halving: after the step with distance D a lane keeps the rows whose bit (log2 of the group) matches its side
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s4[4], s2[2], s1;
+  {
+    const bool hi = (lane & 32) != 0;
 #pragma unroll
-  for(int r = 0; r < GEMV_ROWS; ++r) {
-    double v = acc[r];
-    for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if(lane == 0) sm[r][wave] = v;
+    for(int q = 0; q < 4; ++q) {
+      const double keep = hi ? acc[4 + q] : acc[q], give = hi ? acc[q] : acc[4 + q];
+      s4[q] = keep + __shfl_xor(give, 32, 64);
+    }
   }
+  {
+    const bool hi = (lane & 16) != 0;
+#pragma unroll
+    for(int q = 0; q < 2; ++q) {
+      const double keep = hi ? s4[2 + q] : s4[q], give = hi ? s4[q] : s4[2 + q];
+      s2[q] = keep + __shfl_xor(give, 16, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 8) != 0;
+    const double keep = hi ? s2[1] : s2[0], give = hi ? s2[0] : s2[1];
+    s1 = keep + __shfl_xor(give, 8, 64);
+  }
+  s1 += __shfl_xor(s1, 4, 64);
+  s1 += __shfl_xor(s1, 2, 64);
+  s1 += __shfl_xor(s1, 1, 64);
+  // lane l now holds the wave's sum of row 4 * bit5 + 2 * bit4 + bit3 of l (the same value in its 8 lanes l & ~7 ... | 7)
+  __shared__ double sm[GEMV_ROWS][kBlock / 64];
+  if((lane & 7) == 0) sm[((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)][wave] = s1;
   __syncthreads();
   if(threadIdx.x < GEMV_ROWS) {
     const int row = r0 + threadIdx.x;
@@ -300,7 +360,9 @@ int hiopamd_mat_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, i
   const int nchunks = (int)((n + GEMV_COLS - 1) / GEMV_COLS);
   const int rtiles = (m + GEMV_ROWS - 1) / GEMV_ROWS;
   double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nchunks * m);
-  hipLaunchKernelGGL(gemv_n_stage1, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
+  const bool vec = (lda % 2 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)x % 16 == 0);
+  if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
+  else hipLaunchKernelGGL(gemv_n_stage1<false>, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
   const int waves_per_block = kBlock / 64;
   hipLaunchKernelGGL(gemv_n_stage2, dim3((m + waves_per_block - 1) / waves_per_block), dim3(kBlock), 0, ctx->stream, m,
                      nchunks, part, beta, y, alpha);

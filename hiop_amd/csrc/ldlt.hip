@@ -2061,7 +2061,7 @@ struct DfPlan {
   int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
   std::vector<unsigned> upcnt, wfirst;
-  std::vector<int4> wq;
+  std::vector<int4> wq, wf;
   double up_flops = 0.0;   // algorithmic flops of the UP tasks (2 K per updated element)
 };
 static DfPlan df_build_plan(int N)
@@ -2094,46 +2094,104 @@ static DfPlan df_build_plan(int N)
   P.ctasks = t0;
   P.ctasks.insert(P.ctasks.end(), t1.begin(), t1.end());
   P.upcnt.assign((size_t)P.nsp + 1, 0u);
-  // wide-kernel queues: TR tasks grouped by super-panel, then UP tasks grouped by super-panel with the two tile rows of the
-  // next row panel first (csrc/ldlt_dataflow.hpp: ldlt_wide_kernel)
-  std::vector<int4> trq, upq;
-  std::vector<int4> wq((size_t)P.nwide + 1, make_int4(0, 0, 0, 0));
+  // wide-kernel queues (csrc/ldlt_wide_body.inc): TR tasks grouped by super-panel; NEAR update tasks grouped by super-panel
+  // (head tiles, the two tile rows of the next row panel — counted in wfirst —, for an unpaired or paired-first super-panel also
+  // the two tile rows of the row panel after it); FAR update tasks grouped by super-panel (everything else, row-major).
+  std::vector<int4> trq, nearq, farq;
+  std::vector<int4> wq((size_t)P.nwide + 1, make_int4(0, 0, 0, 0)), wf((size_t)P.nwide + 1, make_int4(0, 0, -1, 0));
   P.wfirst.assign((size_t)P.nwide + 1, 0u);
   // HIOPAMD_DF_UPH=0: the head tiles as ordinary update tasks (A/B timing aid)
   static const bool uph = !(std::getenv("HIOPAMD_DF_UPH") && std::atoi(std::getenv("HIOPAMD_DF_UPH")) == 0);
-  auto emit_tile = [&](int kind, int j, int I, int J) {
-    upq.push_back(make_int4(kind, j, I, J));
+  // HIOPAMD_DF_SPLIT=1: separate NEAR / FAR update lists, NEAR served first (built and measured in round 3: 5.27-5.47 ms against
+  // 5.17-5.30 with the single list per super-panel — the near tiles do jump the queue, but the far tiles they depend on through
+  // `ver` then run later and the chain waits for those instead).  Default: one list per super-panel, everything NEAR, round 2's order.
+  static const bool split = std::getenv("HIOPAMD_DF_SPLIT") && std::atoi(std::getenv("HIOPAMD_DF_SPLIT")) != 0;
+  auto emit_tile = [&](std::vector<int4>& q, int kind, int j, int I, int J) {
+    q.push_back(make_int4(kind, j, I, J));
     P.upcnt[j] += 1u;
+    const int np = kind == DF_UP2 ? 2 : 1;
+    if(kind == DF_UP2) P.upcnt[j - 1] += 1u;   // it reads the row panel of super-panel j - 1 as well
     // rows r in tile I, columns max(r, 128 J) .. of tile J, inside the matrix
     const int r0 = UD_T * I, r1 = std::min(N, r0 + UD_T), c0 = UD_T * J, c1 = std::min(N, c0 + UD_T);
-    for(int r = r0; r < r1; ++r) P.up_flops += 2.0 * LD_NB * (double)std::max(0, c1 - std::max(c0, r));
+    for(int r = r0; r < r1; ++r) P.up_flops += np * 2.0 * LD_NB * (double)std::max(0, c1 - std::max(c0, r));
   };
   auto is_head = [&](int j, int I, int J) { return uph && I < 2 * j + 4 && J < 2 * j + 6; };
-  auto emit_up = [&](int j, int I) {
+  auto emit_up = [&](std::vector<int4>& q, int j, int I) {
     for(int J = (I < 2 * j + 4) ? 2 * j + 4 : I; J < P.nt; ++J)
-      if(!is_head(j, I, J)) emit_tile(DF_UP, j, I, J);
+      if(!is_head(j, I, J)) emit_tile(q, DF_UP, j, I, J);
   };
+  // K = 512 (DF_UP2): super-panels e (even) and e + 1 are applied together to the tile rows behind super-panel e + 2
+  // (I >= 2 e + 6) by FAR tasks of queue e + 1; queue e keeps the rows of super-panels e + 1 and e + 2 (what the next two chains
+  // and substitution rounds wait for).  HIOPAMD_DF_K512 = number of leading super-panels that may be paired (0: off); default: the
+  // update-bound first half (measured at N = 8192: 5.32-5.36 ms unpaired, 5.19-5.27 with 16 of 31, 5.38 with 24 — in the
+  // chain-bound second half a fused task only adds latency).
+  const int k512 = std::getenv("HIOPAMD_DF_K512") ? std::atoi(std::getenv("HIOPAMD_DF_K512")) : (P.nwide + 1) / 2;
+  auto paired_first = [&](int j) { return (j % 2 == 0) && j + 1 < P.nwide && j + 1 < k512; };
+  std::vector<int> near_first((size_t)P.nwide + 1, 0), near_cnt((size_t)P.nwide + 1, 0), far_first((size_t)P.nwide + 1, 0),
+      far_cnt((size_t)P.nwide + 1, 0), near_maxrow((size_t)P.nwide + 1, -1);
   for(int j = 0; j < P.nwide; ++j) {
     wq[j].x = (int)trq.size();
     for(int c = LD_NB * (j + 2); c < N; c += DF_TRW) trq.push_back(make_int4(DF_TR, j, c, DF_TRW));
     wq[j].y = (int)trq.size() - wq[j].x;
-    wq[j].z = (int)upq.size();
+    near_first[j] = (int)nearq.size();
+    far_first[j] = (int)farq.size();
     // the four tiles of H_j+1 = A[R_j+1, first 256 columns behind it] first: the NEXT super-panel's chain waits for them
     // (its first tile solves of the H column), so they follow this super-panel block row by block row (DF_UPH)
     for(int I = 2 * j + 2; I < 2 * j + 4 && I < P.nt; ++I)
       for(int J = 2 * j + 4; J < 2 * j + 6 && J < P.nt; ++J)
-        if(is_head(j, I, J)) emit_tile(DF_UPH, j, I, J);
-    emit_up(j, 2 * j + 2);
-    if(2 * j + 3 < P.nt) emit_up(j, 2 * j + 3);
-    P.wfirst[j] = (unsigned)((int)upq.size() - wq[j].z);
-    for(int I = 2 * j + 4; I < P.nt; ++I) emit_up(j, I);
-    wq[j].w = (int)upq.size() - wq[j].z;
+        if(is_head(j, I, J)) emit_tile(nearq, DF_UPH, j, I, J);
+    emit_up(nearq, j, 2 * j + 2);
+    if(2 * j + 3 < P.nt) emit_up(nearq, j, 2 * j + 3);
+    P.wfirst[j] = (unsigned)((int)nearq.size() - near_first[j]);
+    const bool first = paired_first(j), second = j >= 1 && paired_first(j - 1);
+    std::vector<int4>& rest = split ? farq : nearq;
+    if(second) {
+      for(int I = 2 * j + 4; I < P.nt; ++I)
+        for(int J = I; J < P.nt; ++J) emit_tile(rest, DF_UP2, j, I, J);
+    } else {
+      for(int I = 2 * j + 4; I < 2 * j + 6 && I < P.nt; ++I) emit_up(nearq, j, I);
+      if(!first)
+        for(int I = 2 * j + 6; I < P.nt; ++I) emit_up(rest, j, I);   // (first: the far rows follow in queue j + 1, fused)
+    }
+    near_cnt[j] = (int)nearq.size() - near_first[j];
+    far_cnt[j] = (int)farq.size() - far_first[j];
+    for(int t = near_first[j]; t < (int)nearq.size(); ++t) near_maxrow[j] = std::max(near_maxrow[j], nearq[t].z);
   }
-  for(int j = 0; j < P.nwide; ++j) wq[j].z += (int)trq.size();
+  for(int j = 0; j < P.nwide; ++j) {
+    wq[j].z = (int)trq.size() + near_first[j];
+    wq[j].w = near_cnt[j];
+    wf[j].x = (int)trq.size() + (int)nearq.size() + far_first[j];
+    wf[j].y = far_cnt[j];
+    // the FAR list that feeds this NEAR list's tiles: the latest non-empty one of an earlier super-panel (FAR lists are walked in
+    // order, so its tasks being taken implies every earlier one is); needed: its tasks on tile rows up to this list's last row
+    int dq = -1;
+    for(int q = j - 1; q >= 0; --q)
+      if(far_cnt[q] > 0) {
+        dq = q;
+        break;
+      }
+    wf[j].z = dq;
+    wf[j].w = 0;
+    if(dq >= 0)
+      for(int t = far_first[dq]; t < far_first[dq] + far_cnt[dq]; ++t)
+        if(farq[t].z <= near_maxrow[j]) wf[j].w = t - far_first[dq] + 1;
+  }
   P.wtasks = trq;
-  P.wtasks.insert(P.wtasks.end(), upq.begin(), upq.end());
+  P.wtasks.insert(P.wtasks.end(), nearq.begin(), nearq.end());
+  P.wtasks.insert(P.wtasks.end(), farq.begin(), farq.end());
+  P.wf = wf;
   P.wq = wq;
   return P;
+}
+
+// row-panel workspaces for order n: DF_NVB_MIN = 4 (three + one for the fused update tasks, which hold a buffer one super-panel
+// longer).  HIOPAMD_DF_NVB raises it up to one per super-panel (measured in round 3: 32 buffers instead of 4 at N = 8192 change
+// nothing, 5.30 vs 5.35 ms: the buffers are not what the chain waits for once there are four).
+static int df_nvb_for(int n)
+{
+  const int nsp = (n + LD_NB - 1) / LD_NB;
+  if(const char* e = std::getenv("HIOPAMD_DF_NVB")) return std::max(DF_NVB_MIN, std::min(std::atoi(e), std::max(nsp, DF_NVB_MIN)));
+  return DF_NVB_MIN;
 }
 
 struct DfDevice {
@@ -2143,7 +2201,9 @@ struct DfDevice {
   int4* wtasks = nullptr;
   unsigned* upcnt = nullptr;
   int4* wq = nullptr;
+  int4* wf = nullptr;
   unsigned* wfirst = nullptr;
+  int nvb = DF_NVB_MIN;
   bool enabled = true;
 };
 
@@ -2152,7 +2212,8 @@ struct hiopamd_linsolver {
   int n = 0;
   double* M = nullptr;      // n x n row-major
   double* dinv = nullptr;   // n
-  double* V = nullptr;      // LD_NB x n workspace
+  double* V = nullptr;      // nvb x LD_NB x n workspace
+  int nvb = DF_NVB_MIN;
   double* ybuf = nullptr;   // n
   double* Dblk = nullptr;   // ceil(n/64) staged 64x64 diagonal blocks
   double* Cd = nullptr;     // ceil(n/256) compact 256x256 diagonal blocks (ld = 256)
@@ -2303,11 +2364,11 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     HIOPAMD_CHECK(hipStreamWaitEvent(st, df_done, 0));
     const DfPlan& P = df->plan;
     DfArgs a;
-    a.A = A; a.lda = lda; a.N = N; a.V = V; a.ldv = ldv; a.dinv = dinv; a.Dblk = Dblk; a.Li = Li; a.Cd = Cd; a.info = d_info;
+    a.A = A; a.lda = lda; a.N = N; a.V = V; a.nvb = df->nvb; a.ldv = ldv; a.dinv = dinv; a.Dblk = Dblk; a.Li = Li; a.Cd = Cd; a.info = d_info;
     a.flags = df->flags; a.nsp = P.nsp; a.nt = P.nt; a.nchain = P.nchain; a.last_has_next = P.last_has_next;
     a.off_chain = P.off_chain; a.off_tr = P.off_tr; a.off_ver = P.off_ver;
     a.ctasks = df->ctasks; a.wtasks = df->wtasks; a.nwtasks = (int)P.wtasks.size(); a.upcnt = df->upcnt;
-    a.wq = df->wq; a.wfirst = df->wfirst; a.nwide = P.nwide;
+    a.wq = df->wq; a.wf = df->wf; a.wfirst = df->wfirst; a.nwide = P.nwide;
     HIOPAMD_CHECK(hipMemsetAsync(df->flags, 0, sizeof(unsigned) * (size_t)P.nflags, st));
     hipLaunchKernelGGL(ldlt_df_init_kernel, dim3(1), dim3(kBlock), 0, st, a);
     int rc = dep(st, su);
@@ -2667,7 +2728,9 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
   const size_t nn = (size_t)(n > 0 ? n : 1);
   HIOPAMD_CHECK(hipMalloc((void**)&ls->M, sizeof(double) * nn * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->dinv, sizeof(double) * nn));
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB * DF_NVB));   // row panels of DF_NVB (>= 2) consecutive super-panels
+  ls->nvb = df_nvb_for(n);
+  ls->df.nvb = ls->nvb;
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB * (size_t)ls->nvb));   // row panels of nvb consecutive super-panels
   HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb)));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB)));   // blocks + transposes
@@ -2731,6 +2794,8 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
       HIOPAMD_CHECK(hipMalloc((void**)&df.wq, sizeof(int4) * P.wq.size()));
       HIOPAMD_CHECK(hipMalloc((void**)&df.wfirst, sizeof(unsigned) * P.wfirst.size()));
       HIOPAMD_CHECK(hipMemcpy(df.wq, P.wq.data(), sizeof(int4) * P.wq.size(), hipMemcpyHostToDevice));
+      HIOPAMD_CHECK(hipMalloc((void**)&df.wf, sizeof(int4) * P.wf.size()));
+      HIOPAMD_CHECK(hipMemcpy(df.wf, P.wf.data(), sizeof(int4) * P.wf.size(), hipMemcpyHostToDevice));
       HIOPAMD_CHECK(hipMemcpy(df.wfirst, P.wfirst.data(), sizeof(unsigned) * P.wfirst.size(), hipMemcpyHostToDevice));
     }
   }
@@ -2762,6 +2827,7 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->df.upcnt);
   (void)hipFree(ls->df.wq);
   (void)hipFree(ls->df.wfirst);
+  (void)hipFree(ls->df.wf);
   delete ls;
   return HIOPAMD_OK;
 }
@@ -3098,6 +3164,19 @@ int hiopamd_ldlt_dataflow_queues(int n, int* queues_host, int cap_panels)
   for(int j = 0; j < P.nwide; ++j) {
     queues_host[5 * j] = P.wq[j].x; queues_host[5 * j + 1] = P.wq[j].y; queues_host[5 * j + 2] = P.wq[j].z;
     queues_host[5 * j + 3] = P.wq[j].w; queues_host[5 * j + 4] = (int)P.wfirst[j];
+  }
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ldlt_dataflow_nvb(int n) { return df_nvb_for(n); }
+
+int hiopamd_ldlt_dataflow_far_queues(int n, int* far_host, int cap_panels)
+{
+  if(n < 0 || !far_host) return HIOPAMD_ERR_ARG;
+  const DfPlan P = df_build_plan(n);
+  if(P.nwide > cap_panels) return HIOPAMD_ERR_ARG;
+  for(int j = 0; j < P.nwide; ++j) {
+    far_host[4 * j] = P.wf[j].x; far_host[4 * j + 1] = P.wf[j].y; far_host[4 * j + 2] = P.wf[j].z; far_host[4 * j + 3] = P.wf[j].w;
   }
   return HIOPAMD_OK;
 }

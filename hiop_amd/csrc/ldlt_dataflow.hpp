@@ -36,17 +36,25 @@ constexpr int DF_MAXT = 40;           // chain tasks per role per super-panel (<
 // update of super-panel j - DF_NVB has read the buffer completely.  With two buffers that wait closed a loop
 // chain(j) -> TR(j) -> UP(j) complete -> chain(j+2) of ~620 us per two super-panels in the update-bound first third of the
 // factorisation (profiles/r02_probes: the chain of super-panel 4 idled until the LAST tile of update 2 was done).
-constexpr int DF_NVB = 3;
+// Round 3: FOUR buffers, because a fused update task (DF_UP2, below) of the pair (j, j + 1) reads V_j while queue j + 1 runs: V_j is
+// released one super-panel later than before, the fourth buffer gives the look-ahead back.
+// The number of buffers is a run-time value, DfArgs::nvb (csrc/ldlt.hip::df_nvb_for: 4 unless HIOPAMD_DF_NVB asks for more).
+constexpr int DF_NVB_MIN = 4;
 constexpr int DF_ROLES = 16;
 
 enum { DF_F = 1, DF_T = 2, DF_U = 3, DF_S = 4, DF_R = 5, DF_C = 6, DF_END = 0 };
-enum { DF_TR = 1, DF_UP = 2, DF_UPH = 3 };
+// DF_UP2(j, I, J): K = 512 — the updates of super-panels j AND j + 1 applied to tile (I, J) in one pass over the C tile (one
+// prologue / epilogue / task selection / flag wait for two tiles' worth of MFMAs, half the C traffic); a task of queue j + 1,
+// for the tile rows behind super-panel j + 2 (I >= 2 j + 6).  The sums are accumulated in the same order as by the two
+// separate tasks: results are bit-identical.
+enum { DF_TR = 1, DF_UP = 2, DF_UPH = 3, DF_UP2 = 4 };
 
 struct DfArgs {
   double* A;
   int64_t lda;
   int N;
-  double* V;          // DF_NVB x 256 x N (row panels of DF_NVB consecutive super-panels, un-scaled)
+  double* V;          // nvb x 256 x N (row panels of nvb consecutive super-panels, un-scaled)
+  int nvb;            // row-panel workspaces (>= DF_NVB_MIN; >= nsp: no buffer is ever reused)
   int64_t ldv;
   double* dinv;
   double* Dblk;       // per 64-panel compact factored diagonal tile (64 x 64)
@@ -68,6 +76,7 @@ struct DfArgs {
   const unsigned* upcnt;   // UP tasks per super-panel
   const int4* wq;          // per super-panel {first TR task, TR tasks, first UP task, UP tasks} in wtasks
   const unsigned* wfirst;  // per super-panel: UP tasks of its first two tile rows (the rows of the next row panel)
+  const int4* wf;          // per super-panel {first FAR task in wtasks, FAR tasks, queue whose FAR list feeds this NEAR list (-1: none), how many of its tasks must be taken first}
   int nwide;               // super-panels with wide-kernel work
   int64_t off_trb;         // per super-panel [2][4]: substitution tasks of 128-column block 2j+4+b that have stored block row P
   int spine_opt;           // HIOPAMD_DF_SPINE bits (see df_spine_step)
@@ -207,7 +216,7 @@ __device__ __forceinline__ DfTile df_tile_in_matrix(const DfArgs& a, int j, int 
 }
 __device__ __forceinline__ DfTile df_vtile(const DfArgs& a, int j, int p, int c)
 {
-  return DfTile{a.V + (int64_t)(j % DF_NVB) * LD_NB * a.ldv + (int64_t)(64 * p) * a.ldv + (int64_t)LD_NB * j + 64 * c, a.ldv};
+  return DfTile{a.V + (int64_t)(j % a.nvb) * LD_NB * a.ldv + (int64_t)(64 * p) * a.ldv + (int64_t)LD_NB * j + 64 * c, a.ldv};
 }
 // version counter of window tile (r, c) of super-panel j and the value it has before any task of this super-panel touched it
 __device__ __forceinline__ unsigned* df_ver(const DfArgs& a, int j, int r, int c, unsigned* base)
@@ -588,7 +597,7 @@ __device__ __forceinline__ bool df_spine_step(const DfArgs& a, int j, int p, boo
     DfWait w1(a.flags + DF_ABORT);
     w1.set<0>(vpc, bpc + p);
     w1.set<1>(vcc, bcc + p);
-    if(j >= DF_NVB) w1.set<2>(a.flags + a.off_chain + (int64_t)(j - DF_NVB) * DF_CH + DF_UPDONE, a.upcnt[j - DF_NVB]);
+    if(j >= a.nvb) w1.set<2>(a.flags + a.off_chain + (int64_t)(j - a.nvb) * DF_CH + DF_UPDONE, a.upcnt[j - a.nvb]);
     if((opt & 4) && prefx) {
       // the flag round trip and the drain of F's stores run under the solve; nothing of the solve is stored before the
       // conditions are known to hold (the V workspace of this parity may still be read by update j-2)
@@ -730,7 +739,7 @@ __device__ __forceinline__ bool df_companion_step(const DfArgs& a, int j, int p,
     DfWait w0(a.flags + DF_ABORT);
     w0.set<0>(vpp, bpp + p + 1);   // F(p) published
     w0.set<1>(vpc, bpc + p);
-    if(j >= DF_NVB) w0.set<2>(a.flags + a.off_chain + (int64_t)(j - DF_NVB) * DF_CH + DF_UPDONE, a.upcnt[j - DF_NVB]);
+    if(j >= a.nvb) w0.set<2>(a.flags + a.off_chain + (int64_t)(j - a.nvb) * DF_CH + DF_UPDONE, a.upcnt[j - a.nvb]);
     if(!df_wait(a.flags, w0, sh_ok, t_start, 101, j, DF_R, p, 0)) return false;
   }
   df_task_solve(a, j, p, c, tid);
@@ -781,7 +790,7 @@ __device__ __forceinline__ bool df_column_step(const DfArgs& a, int j, int p, in
     w.set<0>(vpp, bpp + p + 1);
     w.set<1>(vpc, bpc + p);
     if(c >= 4 && p == 0) w.set<2>(df_wide_ver(a, j, p, c), (unsigned)j);
-    if(j >= DF_NVB) w.set<3>(a.flags + a.off_chain + (int64_t)(j - DF_NVB) * DF_CH + DF_UPDONE, a.upcnt[j - DF_NVB]);
+    if(j >= a.nvb) w.set<3>(a.flags + a.off_chain + (int64_t)(j - a.nvb) * DF_CH + DF_UPDONE, a.upcnt[j - a.nvb]);
     if(!df_wait(a.flags, w, sh_ok, t_start, 100 + role, j, DF_C, p, c)) return false;
   }
   df_task_solve(a, j, p, c, tid);
@@ -858,7 +867,7 @@ __device__ __forceinline__ bool df_task_trsm(const DfArgs& a, int j, int c16, do
     col_ok[gq] = col[gq] < a.N;
     colc[gq] = col_ok[gq] ? col[gq] : (int64_t)(a.N - 1);
   }
-  double* Vb = a.V + (int64_t)(j % DF_NVB) * LD_NB * a.ldv;
+  double* Vb = a.V + (int64_t)(j % a.nvb) * LD_NB * a.ldv;
   const double* Cd = a.Cd + (int64_t)j * (LD_NB * LD_NB);
   const double* Dk_sp = a.Dblk + (int64_t)(K0 / LD_nb) * (LD_nb * LD_nb);
   const double* Li_sp = a.Li + (int64_t)(K0 / LD_nb) * (4 * LD_SB * LD_SB);
@@ -963,7 +972,7 @@ __device__ __forceinline__ void df_task_tile(const DfArgs& a, int j, int I, int 
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int lk = lane >> 4, li = lane & 15;
-  const double* V = a.V + (int64_t)(j % DF_NVB) * LD_NB * a.ldv;
+  const double* V = a.V + (int64_t)(j % a.nvb) * LD_NB * a.ldv;
   const int urow0 = LD_NB * j;
   double4_t acc[4][4];
 #pragma unroll
@@ -1101,10 +1110,11 @@ struct DfRowGate {
   G& g;
   __device__ __forceinline__ bool operator()(int P) const { return g(P); }
 };
-template <bool FULL, bool PROF, class Gate = DfNoGate>
+template <bool FULL, bool PROF, class Gate = DfNoGate, int PANELS = 1>
 __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int J, double* smem, int tid, unsigned (&ph)[12],
                                               Gate gate = Gate())
 {
+  static_assert(PANELS == 1 || !Gate::active, "the gated (head) tile is a single-panel task");
   bool gate_ok = true;
   const int dbg = PROF ? a.dbg : 0;
   const unsigned tp0 = dbg ? (unsigned)wall_clock64() : 0u;
@@ -1116,8 +1126,11 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
   const int wr = wave >> 1, wc = wave & 1;
   const int lk = lane >> 4, li = lane & 15;
   const unsigned lda8 = (unsigned)a.lda * 8u, ldv8 = (unsigned)a.ldv * 8u;
-  const __amdgpu_buffer_rsrc_t rsV = df_rsrc(a.V + (int64_t)(j % DF_NVB) * LD_NB * a.ldv + r0);
+  const __amdgpu_buffer_rsrc_t rsV = df_rsrc(a.V + (int64_t)(j % a.nvb) * LD_NB * a.ldv + r0);
   const __amdgpu_buffer_rsrc_t rsU = df_rsrc(a.A + (int64_t)(LD_NB * j) * a.lda + c0);
+  // PANELS == 2: stages 16 .. 31 read the row panel and the factor rows of super-panel j + 1
+  const __amdgpu_buffer_rsrc_t rsV2 = df_rsrc(a.V + (int64_t)((j + 1) % a.nvb) * LD_NB * a.ldv + r0);
+  const __amdgpu_buffer_rsrc_t rsU2 = df_rsrc(a.A + (int64_t)(LD_NB * (j + 1)) * a.lda + c0);
   const __amdgpu_buffer_rsrc_t rsC = df_rsrc(a.A + (int64_t)r0 * a.lda + c0);
   const int rlim = N - r0, clim = N - c0;   // rows / columns of the tile inside the matrix (FULL: both >= 128)
 
@@ -1127,11 +1140,18 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
   const unsigned uvoff = 8u * (unsigned)(FULL ? col2 : (col2 < clim - 2 ? col2 : clim - 2));
   df_double2 vreg[4], ureg[4];
   auto gload = [&](int st) {
+    const bool second = PANELS == 2 && st >= LD_NB / UD_KT;
+    const int sl = second ? st - LD_NB / UD_KT : st;
 #pragma unroll
     for(int p = 0; p < 4; ++p) {
-      const unsigned k = (unsigned)(st * UD_KT + 4 * p + wave);
-      vreg[p] = df_bload2(rsV, vvoff, k * ldv8);
-      ureg[p] = df_bload2(rsU, uvoff, k * lda8);
+      const unsigned k = (unsigned)(sl * UD_KT + 4 * p + wave);
+      if(PANELS == 2 && second) {
+        vreg[p] = df_bload2(rsV2, vvoff, k * ldv8);
+        ureg[p] = df_bload2(rsU2, uvoff, k * lda8);
+      } else {
+        vreg[p] = df_bload2(rsV, vvoff, k * ldv8);
+        ureg[p] = df_bload2(rsU, uvoff, k * lda8);
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -1174,7 +1194,7 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
   lstore(0);
   gload(1);
   __syncthreads();
-  constexpr int nst = LD_NB / UD_KT;
+  constexpr int nst = PANELS * (LD_NB / UD_KT);
   const int arow = wr * 64 + 2 * li, bcol = wc * 64 + 2 * li;
   const unsigned tp1 = dbg ? (unsigned)wall_clock64() : 0u;
   for(int st = 0; st < nst; ++st) {
@@ -1245,7 +1265,7 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
 }
 
 constexpr int DF_WIDE_WG_PER_CU = 2;
-constexpr int DF_TRQ = 40, DF_UPQ = 41;   // per super-panel: TR / UP tasks of its queues handed out so far
+constexpr int DF_TRQ = 40, DF_UPQ = 41, DF_UPQF = 42;   // per super-panel: TR / NEAR update / FAR update tasks of its queues handed out so far
 
 // Two task queues per super-panel instead of one ticket list.  A ticket list must put TR(j+1, .) somewhere inside UP(j, .),
 // and wherever it sits the ~500 substitution tasks are handed out in one burst: they all wait for the chain kernel to

@@ -460,9 +460,13 @@ int hiopamd_linsolver_growth(hiopamd_linsolver* ls, double* max_abs_u_host, doub
 int hiopamd_linsolver_set_dataflow(hiopamd_linsolver* ls, int enable);
 /* static schedule of the dataflow factorisation for order n (host only): see csrc/ldlt.hip */
 int hiopamd_ldlt_dataflow_plan(int n, int* dims8_host, int* chain_tasks_host, int* wide_tasks_host, int64_t wide_cap);
-/* the wide kernel's task queues for order n (host only): per super-panel {first TR task, TR tasks, first UP task, UP tasks,
- * UP tasks of the first two tile rows} as indices into the wide task list of hiopamd_ldlt_dataflow_plan */
+/* the wide kernel's task queues for order n (host only): per super-panel {first TR task, TR tasks, first NEAR update task,
+ * NEAR update tasks, NEAR tasks of the first two tile rows} as indices into the wide task list of hiopamd_ldlt_dataflow_plan;
+ * _far_queues: per super-panel {first FAR update task, FAR tasks, the super-panel whose FAR list feeds this NEAR list (-1: none),
+ * how many of that list's tasks must be taken before a NEAR task of this super-panel may be} (csrc/ldlt_wide_body.inc) */
 int hiopamd_ldlt_dataflow_queues(int n, int* queues5_host, int cap_panels);
+int hiopamd_ldlt_dataflow_far_queues(int n, int* queues4_host, int cap_panels);
+int hiopamd_ldlt_dataflow_nvb(int n);   /* row-panel workspaces a solver of order n allocates (one per super-panel up to 2 GB) */
 int hiopamd_linsolver_flops(const hiopamd_linsolver* ls, double* flops_fact_host, double* flops_triu_solves_host);
 /* per-launch HIP-event timing of the MFMA rank-K update kernel (bench / roofline only; off by default).
  * read: accumulated kernel milliseconds, algorithmic flops (2*K per updated element) and launch count

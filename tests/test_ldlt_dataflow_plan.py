@@ -19,8 +19,10 @@ import numpy as np
 import pytest
 
 F, T, U, SP, RC, CS, END = 1, 2, 3, 4, 5, 6, 0   # SP / RC / CS: fused spine step S(p), its companion R(p), column step C(p, c)
-NVB = 3                  # row-panel workspaces used round robin (DF_NVB of csrc/ldlt_dataflow.hpp)
-TR, UP, UPH = 1, 2, 3   # UPH: head tile of the update, follows the super-panel block row by block row
+NVB = 4                  # row-panel workspaces used round robin: the MINIMUM the library allocates (DF_NVB_MIN of csrc/ldlt_dataflow.hpp;
+                         # it takes one per super-panel when that fits 2 GB — fewer buffers is the stricter protocol, which is what is replayed)
+TR, UP, UPH, UP2 = 1, 2, 3, 4   # UPH: head tile of the update (follows the super-panel block row by block row); UP2: K = 512,
+                                # super-panels j - 1 and j applied together to a tile behind super-panel j + 1 (a task of queue j)
 
 
 def get_plan(n):
@@ -37,7 +39,10 @@ def get_plan(n):
     q = (C.c_int * (5 * max(nwide, 1)))()
     assert L.hiopamd_ldlt_dataflow_queues(n, q, nwide) == 0
     q = np.array(q, dtype=np.int64).reshape(-1, 5)[:nwide]
-    return dict(nsp=nsp, nt=nt, nchain=nchain, last_has_next=last_has_next, nwide=nwide, roles=roles, ctasks=ct, wtasks=wt,
+    fq = (C.c_int * (4 * max(nwide, 1)))()
+    assert L.hiopamd_ldlt_dataflow_far_queues(n, fq, nwide) == 0
+    fq = np.array(fq, dtype=np.int64).reshape(-1, 4)[:nwide]
+    return dict(far=fq, nsp=nsp, nt=nt, nchain=nchain, last_has_next=last_has_next, nwide=nwide, roles=roles, ctasks=ct, wtasks=wt,
                 queues=q)
 
 
@@ -78,8 +83,10 @@ class Sim:
         self.ver = np.zeros((nt, nt), dtype=int)
         self.upcnt = np.zeros(nsp + 1, dtype=int)
         for t in plan["wtasks"]:
-            if t[0] in (UP, UPH):
+            if t[0] in (UP, UPH, UP2):
                 self.upcnt[t[1]] += 1
+            if t[0] == UP2:                     # it reads the row panel of super-panel j - 1 as well
+                self.upcnt[t[1] - 1] += 1
         self.Vtail = {}
 
     # ---- tile access (window of super-panel j)
@@ -213,6 +220,10 @@ class Sim:
                 ok = ok and self.updone[j - NVB] >= self.upcnt[j - NVB]
             return ok
         I, J = x, y
+        if ty == UP2:
+            assert j >= 1 and I >= 2 * j + 4 and J >= I
+            return (self.ver[I, J] >= j - 1 and self.tr[j - 1, I] >= self.groups(I) and self.tr[j - 1, J] >= self.groups(J)
+                    and self.tr[j, I] >= self.groups(I) and self.tr[j, J] >= self.groups(J))
         ok = self.ver[I, J] >= j
         if ty == UPH and 128 * (I + 1) <= self.N and 128 * (J + 1) <= self.N:
             # the kernel's gates, all four block rows at once (the model runs the tile atomically): the chain's tile solves
@@ -242,6 +253,14 @@ class Sim:
         I, J = x, y
         r0, r1 = 128 * I, min(N, 128 * I + 128)
         c0, c1 = 128 * J, min(N, 128 * J + 128)
+        if ty == UP2:
+            blk = self.A[r0:r1, c0:c1]
+            for jj in (j - 1, j):                   # the same order of accumulation as the two separate tasks
+                upd = self.Vtail[jj % NVB][:, r0:r1].T @ self.A[256 * jj:256 * jj + 256, c0:c1]
+                blk -= np.triu(upd) if I == J else upd
+                self.updone[jj] += 1
+            self.ver[I, J] = j + 1
+            return
         s = 256 * (j + 1)
         if I < 2 * j + 4:      # rows in the head: V from the chain's T tasks on H tiles
             Vr = np.zeros((256, r1 - r0))
@@ -283,18 +302,22 @@ def replay(A, plan, n_workers, seed):
         return None
 
     wt = [tuple(int(v) for v in t) for t in plan["wtasks"]]
-    Q = plan["queues"]          # per super-panel: first TR, #TR, first UP, #UP, #UP of the first two tile rows
+    Q = plan["queues"]          # per super-panel: first TR, #TR, first NEAR, #NEAR, #NEAR of the first two tile rows
+    FQ = plan["far"]            # per super-panel: first FAR, #FAR, feeding FAR queue (-1: none), tasks of it that must be taken
     nw = plan["nwide"]
-    trq = [0] * (nw + 1)        # tasks handed out per queue (the DF_TRQ / DF_UPQ words)
+    trq = [0] * (nw + 1)        # tasks handed out per queue (the DF_TRQ / DF_UPQ / DF_UPQF words)
     upq = [0] * (nw + 1)
+    farq = [0] * (nw + 1)
     held = [None] * n_workers   # task index held by each wide worker
-    ptr = [[0, 0] for _ in range(n_workers)]   # (jtr, jup) of each worker
+    ptr = [[0, 0, 0] for _ in range(n_workers)]   # (jtr, jn, jf) of each worker
     done_w = 0
 
     def take(w):
         """the selection loop of ldlt_wide_kernel (one pass): returns a task index, None (nothing eligible), or 'done'"""
         while True:
-            jtr, jup = ptr[w]
+            jtr, jn, jf = ptr[w]
+            if jtr >= nw and jn >= nw and jf >= nw:
+                return "done"
             if jtr < nw:
                 if trq[jtr] >= Q[jtr][1]:
                     ptr[w][0] += 1
@@ -304,15 +327,21 @@ def replay(A, plan, n_workers, seed):
                 if ok:
                     i = trq[jtr]; trq[jtr] += 1
                     return int(Q[jtr][0] + i)
-            if jup < nw:
-                if upq[jup] >= Q[jup][3]:
+            if jn < nw:
+                if upq[jn] >= Q[jn][3]:
                     ptr[w][1] += 1
                     continue
-                if trq[jup] >= Q[jup][1]:
-                    i = upq[jup]; upq[jup] += 1
-                    return int(Q[jup][2] + i)
-            if jtr >= nw and jup >= nw:
-                return "done"
+                dq, need = int(FQ[jn][2]), int(FQ[jn][3])
+                if trq[jn] >= Q[jn][1] and (dq < 0 or farq[dq] >= need):
+                    i = upq[jn]; upq[jn] += 1
+                    return int(Q[jn][2] + i)
+            if jf < nw:
+                if farq[jf] >= FQ[jf][1]:
+                    ptr[w][2] += 1
+                    continue
+                if trq[jf] >= Q[jf][1]:
+                    i = farq[jf]; farq[jf] += 1
+                    return int(FQ[jf][0] + i)
             # nothing eligible: an EARLY substitution task (the chain has only started C_jtr); it is held until C_jtr is
             # complete (the kernel advances it block row by block row — here it simply blocks its worker, which is stricter)
             if jtr < nw and trq[jtr] < Q[jtr][1] and 1 <= sim.cdone[jtr] < 10 and \
@@ -412,24 +441,39 @@ def test_ragged_order_hands_over_a_consistent_state():
 def test_plan_shapes():
     p = get_plan(8192)
     assert p["nsp"] == 32 and p["nt"] == 64 and p["nchain"] == 32 and p["nwide"] == 31
-    ups = [t for t in p["wtasks"] if t[0] in (UP, UPH)]
-    assert len(ups) == sum(t * (t + 1) // 2 - 3 for t in range(62, 0, -2))   # tiles of 31 trailing updates minus the skipped diagonal blocks
+    ups = [t for t in p["wtasks"] if t[0] in (UP, UPH, UP2)]
+    # tiles of 31 trailing updates minus the skipped diagonal blocks; a fused (K = 512) task stands for two of them
+    assert sum(2 if t[0] == UP2 else 1 for t in ups) == sum(t * (t + 1) // 2 - 3 for t in range(62, 0, -2))
+    # default pairing: the update-bound first half, pairs (0,1) ... (14,15); the fused tasks sit in the odd queue and cover exactly
+    # the tile rows behind super-panel j + 1
+    for j in range(31):
+        fused = [t for t in ups if t[0] == UP2 and t[1] == j]
+        if j % 2 == 1 and j < 16:
+            assert sorted((t[2], t[3]) for t in fused) == [(I, J) for I in range(2 * j + 4, 64) for J in range(I, 64)]
+            assert not [t for t in ups if t[0] == UP and t[1] == j and t[2] >= 2 * j + 4]
+            assert not [t for t in ups if t[0] == UP and t[1] == j - 1 and t[2] >= 2 * j + 4]
+        else:
+            assert not fused
     # the head tiles: the (up to) four tiles of A[R_j+1, next 256 columns], first in their queue
     assert sum(1 for t in ups if t[0] == UPH) == 4 * 30
-    # the queues: TR tasks grouped by super-panel, then the UP tasks grouped by super-panel, first two tile rows first
-    Q = p["queues"]
-    assert len(Q) == 31
+    # the lists: TR tasks grouped by super-panel, then the update tasks grouped by super-panel (head tiles, the two tile rows of
+    # the next row panel — counted in Q[j][4] —, then the rest row-major); the FAR lists are empty by default (HIOPAMD_DF_SPLIT=1
+    # moves the rest of every super-panel there; the replay tests above run under that setting as well)
+    Q, FQ = p["queues"], p["far"]
+    assert len(Q) == 31 and len(FQ) == 31
     pos = 0
     for j in range(31):
         assert Q[j][0] == pos and all(t[0] == TR and t[1] == j for t in p["wtasks"][pos:pos + Q[j][1]])
         pos += Q[j][1]
     for j in range(31):
         seg = p["wtasks"][Q[j][2]:Q[j][2] + Q[j][3]]
-        assert Q[j][2] == pos and all(t[0] in (UP, UPH) and t[1] == j for t in seg)
+        assert Q[j][2] == pos and all(t[0] in (UP, UPH, UP2) and t[1] == j for t in seg)
         nh = 4 if j < 30 else 0
         assert all(t[0] == UPH and t[2] < 2 * j + 4 and 2 * j + 4 <= t[3] < 2 * j + 6 for t in seg[:nh])
-        assert all(t[0] == UP for t in seg[nh:])
         assert all(t[2] in (2 * j + 2, 2 * j + 3) for t in seg[:Q[j][4]]) and all(t[2] >= 2 * j + 4 for t in seg[Q[j][4]:])
+        rows = [int(t[2]) for t in seg[Q[j][4]:]]
+        assert rows == sorted(rows)
+        assert FQ[j][1] == 0 and FQ[j][2] == -1
         pos += Q[j][3]
     assert pos == len(p["wtasks"])
 
