@@ -123,6 +123,53 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
   }
 }
 
+constexpr int GEMV1_COLS_PER_THREAD = 8;
+constexpr int GEMV1_COLS = kBlock * GEMV1_COLS_PER_THREAD;
+// A/B aid (HIOPAMD_GEMV=1): round 2's stage 1 (one column chunk per block, full shuffle tree per row)
+__global__ __launch_bounds__(kBlock) void gemv_n_stage1_v1(int m, int64_t n, const double* __restrict__ A, int64_t lda,
+                                                        const double* __restrict__ x, double* __restrict__ part)
+{
+  const int64_t c0 = (int64_t)blockIdx.x * GEMV1_COLS;
+  const int r0 = blockIdx.y * GEMV_ROWS;
+  double xv[GEMV1_COLS_PER_THREAD];
+#pragma unroll
+  for(int u = 0; u < GEMV1_COLS_PER_THREAD; ++u) {
+    int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
+    xv[u] = (j < n) ? x[j] : 0.0;
+  }
+  double acc[GEMV_ROWS];
+#pragma unroll
+  for(int r = 0; r < GEMV_ROWS; ++r) {
+    acc[r] = 0.0;
+    const int row = r0 + r;
+    if(row < m) {
+      const double* Ar = A + (int64_t)row * lda;
+#pragma unroll
+      for(int u = 0; u < GEMV1_COLS_PER_THREAD; ++u) {
+        int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
+        if(j < n) acc[r] = fma(Ar[j], xv[u], acc[r]);
+      }
+    }
+  }
+  // block reduce the 8 accumulators
+  __shared__ double sm[GEMV_ROWS][kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for(int r = 0; r < GEMV_ROWS; ++r) {
+    double v = acc[r];
+    for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if(lane == 0) sm[r][wave] = v;
+  }
+  __syncthreads();
+  if(threadIdx.x < GEMV_ROWS) {
+    const int row = r0 + threadIdx.x;
+    if(row < m) {
+      double v = ((sm[threadIdx.x][0] + sm[threadIdx.x][1]) + sm[threadIdx.x][2]) + sm[threadIdx.x][3];
+      part[(int64_t)blockIdx.x * m + row] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void gemv_n_stage2(int m, int nchunks, const double* __restrict__ part,
                                                         double beta, double* __restrict__ y, double alpha)
 {
@@ -357,11 +404,13 @@ int hiopamd_mat_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, i
   if(m < 0 || n < 0) return HIOPAMD_ERR_ARG;
   if(m == 0) return HIOPAMD_OK;
   if(n == 0) return hiopamd_vec_scale(ctx, m, y, beta);
-  const int nchunks = (int)((n + GEMV_COLS - 1) / GEMV_COLS);
+  static const bool v1 = std::getenv("HIOPAMD_GEMV") && std::atoi(std::getenv("HIOPAMD_GEMV")) == 1;
+  const int nchunks = (int)((n + (v1 ? GEMV1_COLS : GEMV_COLS) - 1) / (v1 ? GEMV1_COLS : GEMV_COLS));
   const int rtiles = (m + GEMV_ROWS - 1) / GEMV_ROWS;
   double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nchunks * m);
   const bool vec = (lda % 2 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)x % 16 == 0);
-  if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
+  if(v1) hipLaunchKernelGGL(gemv_n_stage1_v1, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
+  else if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
   else hipLaunchKernelGGL(gemv_n_stage1<false>, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
   const int waves_per_block = kBlock / 64;
   hipLaunchKernelGGL(gemv_n_stage2, dim3((m + waves_per_block - 1) / waves_per_block), dim3(kBlock), 0, ctx->stream, m,

@@ -486,6 +486,162 @@ __global__ __launch_bounds__(64 * WAVES, (ROWS <= 128) ? 2 : 1) void gram_strip2
   else gram_strip2_body<WAVES, TPW, ROWS, false>(ma, mb, n, X, d, kchunk, tiles_b, ntiles, tl, partial, Xs, ds);
 }
 
+// The stage buffer with rows padded to 34 doubles (48 % bank-conflict cycles, still the faster one: see gram_strip2_launch)
+template <int WAVES, int TPW, int ROWS, bool VEC>
+__device__ __forceinline__ void gram_strip2_body_rm(int ma, int mb, int64_t n, const GramRows& X, const double* __restrict__ d,
+                                                 int64_t kchunk, int tiles_b, int ntiles, const GramStripTiles2<WAVES, TPW>& tl,
+                                                 double* __restrict__ partial, double (*Xs)[ROWS][GS_LD], double (*ds)[GS_KT])
+{
+  constexpr int NT = 64 * WAVES;
+  constexpr int RPP = NT / 16;          // rows per staging pass
+  constexpr int NP = ROWS / RPP;        // staging passes
+  constexpr int TB = (TPW >= 8) ? 4 : TPW;   // tiles per operand batch (registers: 8 per tile)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4, li = lane & 15;
+  const int split = blockIdx.x;
+  const int64_t kbeg = (int64_t)split * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if(kend > n) kend = n;
+  const int npa = __builtin_amdgcn_readfirstlane((((mb + 15) / 16) * 16 + RPP - 1) / RPP);   // staging passes with live rows
+  const int ntw = tl.cnt[wave];
+  const int srow = tid >> 4, skk = (tid & 15) * 2;
+  // position of k inside its group of 8: (k % 4) * 2 + (k / 4) % 2  ->  k and k + 4 adjacent (one ds_read_b128 = two k-steps)
+  const int p0 = (skk & ~7) + ((skk & 3) << 1) + ((skk >> 2) & 1);
+  const int p1 = (skk & ~7) + (((skk + 1) & 3) << 1) + (((skk + 1) >> 2) & 1);
+  // Staging without a branch or a wait inside: the row pointers are resolved once (segment look-ups are dependent loads), a
+  // row outside the matrix is clamped to the last row and masked when it is written to LDS, a k outside the chunk likewise;
+  // all loads of a stage are issued back to back one stage ahead, the masks are applied at the LDS store.
+  const double* rp[NP];
+  bool rok[NP];
+#pragma unroll
+  for(int ps = 0; ps < NP; ++ps) {
+    const int r = ps * RPP + srow;
+    const int rc = (r < mb) ? r : (mb - 1);
+    const int seg = (rc < X.rows[0]) ? 0 : ((rc < X.rows[1]) ? 1 : 2);
+    const int base = (seg == 0) ? 0 : ((seg == 1) ? X.rows[0] : X.rows[1]);
+    const double* p = (seg == 0) ? X.p[0] : ((seg == 1) ? X.p[1] : X.p[2]);
+    const int64_t ld = (seg == 0) ? X.ld[0] : ((seg == 1) ? X.ld[1] : X.ld[2]);
+    rp[ps] = p + (int64_t)(rc - base) * ld;
+    rok[ps] = r < mb;
+  }
+  double v0[NP], v1[NP];
+  double dreg = 0.0;
+  bool m0 = false, m1 = false, md = false;   // k / k + 1 (/ the weight's k) of the stage in flight inside the chunk
+  const double* dsrc = d ? d : X.p[0];
+  auto gload = [&](int64_t k0) {
+    const int64_t k = k0 + skk;
+    m0 = k < kend;
+    m1 = k + 1 < kend;
+    if constexpr(VEC) {
+      // 16-byte loads (rows and leading dimensions 16-byte aligned): k is even; at the ragged end of the chunk the pair is
+      // clamped to the last even position, which is inside the row (an odd n has at least one padding element: ld is even)
+      const int64_t kc = m0 ? k : ((kend - 1) & ~(int64_t)1);
+#pragma unroll
+      for(int ps = 0; ps < NP; ++ps) {
+        const double2 t = *reinterpret_cast<const double2*>(rp[ps] + kc);
+        v0[ps] = t.x;
+        v1[ps] = t.y;
+      }
+    } else {
+      const int64_t kc0 = m0 ? k : (kend - 1), kc1 = m1 ? (k + 1) : (kend - 1);
+#pragma unroll
+      for(int ps = 0; ps < NP; ++ps) {
+        v0[ps] = rp[ps][kc0];
+        v1[ps] = rp[ps][kc1];
+      }
+    }
+    // the weight: always a load (from the matrix itself when there is no weight vector), value and mask applied at the LDS store —
+    // a select on the loaded value here would put a vmcnt(0) right behind the stage's loads
+    const int64_t kd = k0 + (tid & (GS_KT - 1));
+    md = kd < kend;
+    dreg = dsrc[md ? kd : (kend - 1)];
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for(int ps = 0; ps < NP; ++ps) {
+      if(ps < npa) {   // scalar; nothing waits inside
+        Xs[buf][ps * RPP + srow][p0] = (rok[ps] && m0) ? v0[ps] : 0.0;
+        Xs[buf][ps * RPP + srow][p1] = (rok[ps] && m1) ? v1[ps] : 0.0;
+      }
+    }
+    if(tid < GS_KT) ds[buf][tid] = md ? (d ? dreg : 1.0) : 0.0;
+  };
+  double4_t acc[TPW];
+#pragma unroll
+  for(int t = 0; t < TPW; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // LDS offset of each tile's operands (wave-uniform: scalar registers); a padding slot repeats tile 0
+  int aoff[TPW], boff[TPW];
+#pragma unroll
+  for(int t = 0; t < TPW; ++t) {
+    const int tt = (t < ntw) ? t : 0;
+    aoff[t] = __builtin_amdgcn_readfirstlane(16 * GS_LD * (int)tl.ti[wave][tt]);
+    boff[t] = __builtin_amdgcn_readfirstlane(16 * GS_LD * (int)tl.tj[wave][tt]);
+  }
+  const int lane_off = li * GS_LD + 2 * lk;
+  if(kbeg < kend) {
+    gload(kbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for(int64_t k0 = kbeg; k0 < kend; k0 += GS_KT) {
+    const bool more = k0 + GS_KT < kend;
+    if(more) gload(k0 + GS_KT);
+#pragma unroll
+    for(int g8 = 0; g8 < GS_KT / 8; ++g8) {
+      const double w0 = ds[buf][8 * g8 + lk], w1 = ds[buf][8 * g8 + 4 + lk];
+      const double* xb = &Xs[buf][0][0] + lane_off + 8 * g8;
+#pragma unroll
+      for(int tb0 = 0; tb0 < TPW; tb0 += TB) {
+        gs_double2 av[TB], bv[TB];
+#pragma unroll
+        for(int q = 0; q < TB; ++q)
+          if(tb0 + q < TPW) {
+            av[q] = *reinterpret_cast<const gs_double2*>(xb + aoff[tb0 + q]);
+            bv[q] = *reinterpret_cast<const gs_double2*>(xb + boff[tb0 + q]);
+          }
+#pragma unroll
+        for(int q = 0; q < TB; ++q)
+          if(tb0 + q < TPW) {
+            av[q].x *= w0;
+            av[q].y *= w1;
+          }
+#pragma unroll
+        for(int q = 0; q < TB; ++q)
+          if(tb0 + q < TPW) acc[tb0 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q].x, bv[q].x, acc[tb0 + q], 0, 0, 0);
+#pragma unroll
+        for(int q = 0; q < TB; ++q)
+          if(tb0 + q < TPW) acc[tb0 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q].y, bv[q].y, acc[tb0 + q], 0, 0, 0);
+      }
+    }
+    if(more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for(int t = 0; t < TPW; ++t) {
+    if(t < ntw) {
+      const int tile = tl.ti[wave][t] * tiles_b + tl.tj[wave][t];
+      double* P = partial + ((int64_t)split * ntiles + tile) * 256;
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg) P[(lk + 4 * reg) * 16 + li] = acc[t][reg];
+    }
+  }
+}
+
+template <int WAVES, int TPW, int ROWS>
+__global__ __launch_bounds__(64 * WAVES, (ROWS <= 128) ? 2 : 1) void gram_strip2_kernel_rm(int ma, int mb, int64_t n, const GramRows X,
+                                                                                       int vec_ok, const double* __restrict__ d,
+                                                                                       int64_t kchunk, int tiles_b, int ntiles,
+                                                                                       const GramStripTiles2<WAVES, TPW> tl,
+                                                                                       double* __restrict__ partial)
+{
+  __shared__ __attribute__((aligned(16))) double Xs[2][ROWS][GS_LD];
+  __shared__ double ds[2][GS_KT];
+  if(vec_ok) gram_strip2_body_rm<WAVES, TPW, ROWS, true>(ma, mb, n, X, d, kchunk, tiles_b, ntiles, tl, partial, Xs, ds);
+  else gram_strip2_body_rm<WAVES, TPW, ROWS, false>(ma, mb, n, X, d, kchunk, tiles_b, ntiles, tl, partial, Xs, ds);
+}
+
 template <int WAVES, int TPW, int ROWS>
 static void gram_strip2_launch(hiopamd_ctx* ctx, const std::vector<std::pair<int, int>>& need, int ma, int mb, int64_t n, const GramRows& B,
                                int vec, const double* d, int64_t kchunk, int nsplit, int tb_n, int ntiles16, double* partial)
@@ -499,8 +655,17 @@ static void gram_strip2_launch(hiopamd_ctx* ctx, const std::vector<std::pair<int
     tl.tj[w][t] = (unsigned char)need[q].second;
     tl.cnt[w] = (unsigned char)(t + 1);
   }
-  hipLaunchKernelGGL((gram_strip2_kernel<WAVES, TPW, ROWS>), dim3(nsplit), dim3(64 * WAVES), 0, ctx->stream, ma, mb, n, B, vec, d, kchunk,
-                     tb_n, ntiles16, tl, partial);
+  // HIOPAMD_GRAM_LDS=1: the conflict-free stage buffer (one plane per k-slot, XOR-swizzled pairs: SQ_LDS_BANK_CONFLICT 48 % -> 0).
+  // Measured A/B on one box (scripts/r03_gpu_13.sh): 1.36 vs 1.27 ms at k = 200, 0.50 vs 0.48 at k = 100 — SLOWER although the LDS
+  // cycles halve: the kernel is not LDS-bound (MFMA pipe 74 % busy), and the plane layout splits a lane's two staged values over
+  // two planes and adds an XOR per k-group to every operand address.  Default: rows padded to 34 doubles.
+  static const bool planes = std::getenv("HIOPAMD_GRAM_LDS") && std::atoi(std::getenv("HIOPAMD_GRAM_LDS")) == 1;
+  if(planes)
+    hipLaunchKernelGGL((gram_strip2_kernel<WAVES, TPW, ROWS>), dim3(nsplit), dim3(64 * WAVES), 0, ctx->stream, ma, mb, n, B, vec, d, kchunk,
+                       tb_n, ntiles16, tl, partial);
+  else
+    hipLaunchKernelGGL((gram_strip2_kernel_rm<WAVES, TPW, ROWS>), dim3(nsplit), dim3(64 * WAVES), 0, ctx->stream, ma, mb, n, B, vec, d,
+                       kchunk, tb_n, ntiles16, tl, partial);
 }
 
 template <int T>
