@@ -34,8 +34,30 @@ struct hiopamd_csr_condensed {
   int64_t* hpos_u = nullptr;    // Hessian triplet -> CSR position of (i, j)
   int64_t* hpos_l = nullptr;    // ... of (j, i), -1 for a diagonal triplet
   int64_t* dpos = nullptr;      // row i -> CSR position of (i, i)
+  // rows of M with more than CSR_LONG entries (a dense column of Jd makes a dense row AND column of Jd^T D Jd: the arrowhead of the
+  // SparseEx2 pattern, 1e6 entries in row 0): cut in chunks of CSR_LONG, one workgroup per chunk, partial sums folded in chunk order
+  struct Long {
+    int n_long = 0, n_chunks = 0;
+    int* long_row = nullptr;      // n_long: row index
+    int* long_first = nullptr;    // n_long + 1: first chunk of the row
+    int* chunk_beg = nullptr;     // chunk c covers [chunk_beg[c], chunk_end[c]) of the CSR arrays
+    int* chunk_end = nullptr;
+    double* chunk_part = nullptr;
+    void free_all()
+    {
+      (void)hipFree(long_row); (void)hipFree(long_first); (void)hipFree(chunk_beg); (void)hipFree(chunk_end); (void)hipFree(chunk_part);
+    }
+  };
+  Long lM, lJt;
+  // Jd^T in CSR (n rows): row pointers and column indices (= constraint rows); values are Jt_val (refreshed by the numeric phase).
+  // The transposed product Jd^T y runs as a CSR product — no floating-point atomics (the COO scatter form serialises a million
+  // atomic adds on y[0] for the dense column of the SparseEx2 pattern: 12 ms per call), results bit-reproducible.
+  int* jt_rowptr = nullptr;
+  int* jt_colidx = nullptr;
+  double avg_row_M = 0.0, avg_row_Jt = 0.0;
   std::vector<int> h_rowptr, h_colidx;
 };
+constexpr int CSR_LONG = 4096;
 
 namespace {
 template <class T>
@@ -58,6 +80,9 @@ int hiopamd_csr_condensed_destroy(hiopamd_csr_condensed* c)
   (void)hipFree(c->rowptr); (void)hipFree(c->colidx); (void)hipFree(c->vals); (void)hipFree(c->permJt);
   (void)hipFree(c->Jt_val); (void)hipFree(c->Dinv); (void)hipFree(c->pos_plan); (void)hipFree(c->hpos_u);
   (void)hipFree(c->hpos_l); (void)hipFree(c->dpos);
+  c->lM.free_all();
+  c->lJt.free_all();
+  (void)hipFree(c->jt_rowptr); (void)hipFree(c->jt_colidx);
   delete c;
   return HIOPAMD_OK;
 }
@@ -129,6 +154,40 @@ int hiopamd_csr_condensed_create(hiopamd_csr_condensed** out, hiopamd_ctx* ctx, 
   if(rc == HIOPAMD_OK) rc = up(&c->hpos_u, hu);
   if(rc == HIOPAMD_OK) rc = up(&c->hpos_l, hl);
   if(rc == HIOPAMD_OK) rc = up(&c->dpos, dp);
+  {
+    auto build_long = [&](const std::vector<int>& rp, int nrows, hiopamd_csr_condensed::Long& L) {
+      std::vector<int> lr, lf, cb, ce;
+      for(int i = 0; i < nrows; ++i) {
+        const int b = rp[i], e = rp[i + 1];
+        if(e - b > CSR_LONG) {
+          lr.push_back(i);
+          lf.push_back((int)cb.size());
+          for(int k = b; k < e; k += CSR_LONG) {
+            cb.push_back(k);
+            ce.push_back(std::min(e, k + CSR_LONG));
+          }
+        }
+      }
+      lf.push_back((int)cb.size());
+      L.n_long = (int)lr.size();
+      L.n_chunks = (int)cb.size();
+      int r = up(&L.long_row, lr);
+      if(r == HIOPAMD_OK) r = up(&L.long_first, lf);
+      if(r == HIOPAMD_OK) r = up(&L.chunk_beg, cb);
+      if(r == HIOPAMD_OK) r = up(&L.chunk_end, ce);
+      if(r == HIOPAMD_OK && hipMalloc((void**)&L.chunk_part, sizeof(double) * (size_t)std::max(L.n_chunks, 1)) != hipSuccess) r = HIOPAMD_ERR_HIP;
+      return r;
+    };
+    if(rc == HIOPAMD_OK) rc = build_long(c->h_rowptr, n, c->lM);
+    std::vector<int> trp((size_t)n + 1, 0);
+    for(int k = 0; k < nnzJ; ++k) trp[(size_t)ti[k] + 1] += 1;
+    for(int i = 0; i < n; ++i) trp[(size_t)i + 1] += trp[i];
+    if(rc == HIOPAMD_OK) rc = up(&c->jt_rowptr, trp);
+    if(rc == HIOPAMD_OK) rc = up(&c->jt_colidx, tj);
+    if(rc == HIOPAMD_OK) rc = build_long(trp, n, c->lJt);
+    c->avg_row_M = n ? (double)c->nnzM / n : 0.0;
+    c->avg_row_Jt = n ? (double)nnzJ / n : 0.0;
+  }
   if(rc == HIOPAMD_OK && hipMalloc((void**)&c->vals, sizeof(double) * (size_t)(c->nnzM ? c->nnzM : 1)) != hipSuccess) rc = HIOPAMD_ERR_HIP;
   if(rc == HIOPAMD_OK && hipMalloc((void**)&c->Jt_val, sizeof(double) * (size_t)(nnzJ ? nnzJ : 1)) != hipSuccess) rc = HIOPAMD_ERR_HIP;
   if(rc == HIOPAMD_OK && hipMalloc((void**)&c->Dinv, sizeof(double) * (size_t)(m ? m : 1)) != hipSuccess) rc = HIOPAMD_ERR_HIP;
@@ -202,6 +261,55 @@ __global__ __launch_bounds__(hiopamd::kBlock) void csr_spmv_kernel(int nrows, co
     if(lane == 0) y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
   }
 }
+// the same, rows with more than `long_thresh` entries left to csr_spmv_chunk_kernel
+__global__ __launch_bounds__(hiopamd::kBlock) void csr_spmv_short_kernel(int nrows, const int* __restrict__ rowptr,
+                                                                         const int* __restrict__ colidx, const double* __restrict__ val,
+                                                                         double beta, double* __restrict__ y, double alpha,
+                                                                         const double* __restrict__ x, int long_thresh)
+{
+  const int lane = threadIdx.x & 63;
+  const int wpb = hiopamd::kBlock / 64;
+  for(int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < nrows; row += gridDim.x * wpb) {
+    const int b = rowptr[row], e = rowptr[row + 1];
+    if(e - b > long_thresh) continue;
+    double acc = 0.0;
+    for(int k = b + lane; k < e; k += 64) acc += val[k] * x[colidx[k]];
+    for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if(lane == 0) y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
+  }
+}
+// rows of a handful of entries (the condensed matrix of a sparse NLP with 2-3 entries per constraint): one THREAD per row
+__global__ __launch_bounds__(hiopamd::kBlock) void csr_spmv_thread_kernel(int nrows, const int* __restrict__ rowptr,
+                                                                          const int* __restrict__ colidx, const double* __restrict__ val,
+                                                                          double beta, double* __restrict__ y, double alpha,
+                                                                          const double* __restrict__ x, int long_thresh)
+{
+  for(int64_t row = (int64_t)blockIdx.x * hiopamd::kBlock + threadIdx.x; row < nrows; row += (int64_t)gridDim.x * hiopamd::kBlock) {
+    const int b = rowptr[row], e = rowptr[row + 1];
+    if(e - b > long_thresh) continue;
+    double acc = 0.0;
+    for(int k = b; k < e; ++k) acc += val[k] * x[colidx[k]];
+    y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
+  }
+}
+// one workgroup per chunk of a long row: partial sum, fixed order inside the chunk
+__global__ __launch_bounds__(hiopamd::kBlock) void csr_spmv_chunk_kernel(const int* __restrict__ cb, const int* __restrict__ ce,
+                                                                         const int* __restrict__ colidx, const double* __restrict__ val,
+                                                                         const double* __restrict__ x, double* __restrict__ part)
+{
+  const int b = cb[blockIdx.x], e = ce[blockIdx.x];
+  double acc = 0.0;
+  for(int k = b + (int)threadIdx.x; k < e; k += hiopamd::kBlock) acc += val[k] * x[colidx[k]];
+  for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double sm[hiopamd::kBlock / 64];
+  if((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    double v = sm[0];
+    for(int w = 1; w < hiopamd::kBlock / 64; ++w) v += sm[w];
+    part[blockIdx.x] = v;
+  }
+}
 }  // namespace
 int hiopamd_csr_times_vec(hiopamd_ctx* ctx, int nrows, const int* rowptr, const int* colidx, const double* val, double beta,
                           double* y, double alpha, const double* x)
@@ -259,10 +367,65 @@ int hiopamd_csr_form_diag_numeric(hiopamd_ctx* ctx, int n, double* val, const do
 }
 
 /* operator callbacks for hiopamd_krylov_create (hiopamd_linop_fn): y = M x and the Jacobi preconditioner y = x ./ diag(M) */
+// y = beta y + alpha A x for a CSR matrix whose long rows were listed at creation: short rows one wave (or one thread, when rows
+// hold a handful of entries) each, long rows one workgroup per chunk + a fold in chunk order
+static int csr_apply_long(hiopamd_ctx* ctx, int n, const int* rowptr, const int* colidx, const double* vals,
+                          const hiopamd_csr_condensed::Long& L, double avg_row, double beta, double* y, double alpha, const double* x)
+{
+  if(n == 0) return HIOPAMD_OK;
+  if(avg_row <= 6.0) {
+    hipLaunchKernelGGL(csr_spmv_thread_kernel, dim3(hiopamd::grid_for(n)), dim3(hiopamd::kBlock), 0, ctx->stream, n, rowptr, colidx, vals,
+                       beta, y, alpha, x, CSR_LONG);
+  } else {
+    const int wpb = hiopamd::kBlock / 64;
+    int grid = (n + wpb - 1) / wpb;
+    if(grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(csr_spmv_short_kernel, dim3(grid), dim3(hiopamd::kBlock), 0, ctx->stream, n, rowptr, colidx, vals, beta, y, alpha,
+                       x, CSR_LONG);
+  }
+  if(L.n_long == 0) {
+    HIOPAMD_CHECK(hipGetLastError());
+    return HIOPAMD_OK;
+  }
+  hipLaunchKernelGGL(csr_spmv_chunk_kernel, dim3(L.n_chunks), dim3(hiopamd::kBlock), 0, ctx->stream, L.chunk_beg, L.chunk_end, colidx, vals,
+                     x, L.chunk_part);
+  const int *lr = L.long_row, *lf = L.long_first;
+  const double* part = L.chunk_part;
+  return hiopamd::launch_ew(ctx, L.n_long, [=] __device__(int64_t q) {
+    double acc = 0.0;
+    for(int k = lf[q]; k < lf[q + 1]; ++k) acc += part[k];
+    const int r = lr[q];
+    y[r] = (beta == 0.0 ? 0.0 : beta * y[r]) + alpha * acc;
+  });
+}
+
 int hiopamd_csr_condensed_apply(void* user, const double* x_dev, double* y_dev)
 {
   auto* c = static_cast<hiopamd_csr_condensed*>(user);
-  return hiopamd_csr_times_vec(c->ctx, c->n, c->rowptr, c->colidx, c->vals, 0.0, y_dev, 1.0, x_dev);
+  return csr_apply_long(c->ctx, c->n, c->rowptr, c->colidx, c->vals, c->lM, c->avg_row_M, 0.0, y_dev, 1.0, x_dev);
+}
+// Jd^T's values for new Jacobian values (device, in the order of the triplets given at creation); the numeric phase does the same
+int hiopamd_csr_condensed_refresh_jt(hiopamd_csr_condensed* c, const double* J_val)
+{
+  if(!c || (c->nnzJ && !J_val)) return HIOPAMD_ERR_ARG;
+  const int* perm = c->permJt;
+  double* jt = c->Jt_val;
+  return hiopamd::launch_ew(c->ctx, c->nnzJ, [=] __device__(int64_t k) { jt[k] = J_val[perm[k]]; });
+}
+// y (n) = beta y + alpha Jd^T x (m) with the values of the last numeric phase / refresh
+int hiopamd_csr_condensed_jac_trans_times_vec(hiopamd_csr_condensed* c, double beta, double* y, double alpha, const double* x)
+{
+  if(!c) return HIOPAMD_ERR_ARG;
+  return csr_apply_long(c->ctx, c->n, c->jt_rowptr, c->jt_colidx, c->Jt_val, c->lJt, c->avg_row_Jt, beta, y, alpha, x);
+}
+// diag(M) through the diagonal positions found at creation (hiopamd_csr_extract_diagonal scans a row per thread: a million
+// sequential loads for the dense row of an arrowhead)
+int hiopamd_csr_condensed_diagonal(hiopamd_csr_condensed* c, double* diag_dev)
+{
+  if(!c || !diag_dev) return HIOPAMD_ERR_ARG;
+  const double* vals = c->vals;
+  const int64_t* dp = c->dpos;
+  return hiopamd::launch_ew(c->ctx, c->n, [=] __device__(int64_t i) { diag_dev[i] = vals[dp[i]]; });
 }
 int hiopamd_csr_condensed_jacobi(void* user, const double* x_dev, double* y_dev)
 {

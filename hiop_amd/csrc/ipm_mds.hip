@@ -1,5 +1,6 @@
-// The C interface of the MDS solver (include/hiop_amd_interface.h): the reference's C FFI
-// (src/Interface/hiopInterface.h:63-98, chiopInterface.cpp:64-95) in front of this library's device path.
+// The C interfaces of the solvers (include/hiop_amd_interface.h): the reference's C FFI for MDS problems
+// (src/Interface/hiopInterface.h:63-98, chiopInterface.cpp:64-95) and for dense-constraint problems (hiopInterface.h:150-176,
+// chiopInterface.cpp:129-159: quasi-Newton, hiopAlgFilterIPMQuasiNewton::run :960-1480) in front of this library's device path.
 //
 // What is here is HOST control flow only — the counterpart of
 //   hiopNlpMDS / hiopNlpFormulation::finalizeInitialization   src/Optimization/hiopNlpFormulation.cpp:205-700 (equality / inequality
@@ -85,6 +86,12 @@ struct Filter {   // src/Optimization/hiopFilter.hpp:60-75, .cpp:55-68
 
 struct MdsSolver {
   cHiopMDSProblem* prob = nullptr;
+  cHiopDenseProblem* dprob = nullptr;   // != nullptr: the dense-constraints quasi-Newton variant
+  hiopamd_hess_lowrank* hess = nullptr;
+  hiopamd_kkt_lowrank* klr = nullptr;
+  DevBuf<double> d_Jall, d_J;           // dense variant: the user's m x n Jacobian, and [Jc; Jd] in one block
+  int secant_memory_len = 6;
+  double sigma0 = 1.0;
   Options o;
   bool dev_cb = false;
   hiopamd_ctx* ctx = nullptr;
@@ -115,6 +122,8 @@ struct MdsSolver {
   {
     if(full) hiopamd_kkt_xycyd_destroy(full);
     if(kkt) hiopamd_kkt_mds_destroy(kkt);
+    if(klr) hiopamd_kkt_lowrank_destroy(klr);
+    if(hess) hiopamd_hess_lowrank_destroy(hess);
     if(ctx) hiopamd_ctx_destroy(ctx);
   }
 
@@ -153,12 +162,15 @@ struct MdsSolver {
   {
     double* x = nullptr;
     RC(x_for_cb(x_dev, &x));
-    if(prob->eval_f(n, x, 1, f, prob->user_data) != 0) return user_failed("eval_f");
+    void* ud = dprob ? dprob->user_data : prob->user_data;
+    auto cb_f = dprob ? dprob->eval_f : prob->eval_f;
+    auto cb_c = dprob ? dprob->eval_cons : prob->eval_cons;
+    if(cb_f(n, x, 1, f, ud) != 0) return user_failed("eval_f");
     if(dev_cb) {
-      if(prob->eval_cons(n, m, x, 0, cons_dev, prob->user_data) != 0) return user_failed("eval_cons");
+      if(cb_c(n, m, x, 0, cons_dev, ud) != 0) return user_failed("eval_cons");
     } else {
       h_buf.resize((size_t)std::max(m, 1));
-      if(prob->eval_cons(n, m, x, 0, h_buf.data(), prob->user_data) != 0) return user_failed("eval_cons");
+      if(cb_c(n, m, x, 0, h_buf.data(), ud) != 0) return user_failed("eval_cons");
       RC(h2d(cons_dev, h_buf.data(), sizeof(double) * (size_t)m));
     }
     // c = cons[eq], d = cons[ineq]   (hiopNlpFormulation::eval_c_d, hiopNlpFormulation.cpp:1045-1075)
@@ -172,6 +184,27 @@ struct MdsSolver {
   {
     double* x = nullptr;
     RC(x_for_cb(x_dev, &x));
+    if(dprob) {
+      // gradient and the dense m x n Jacobian; rows split into [Jc; Jd] (hiopNlpDenseConstraints::eval_Jac_c_d,
+      // hiopNlpFormulation.cpp:1480-1530).  The Hessian is the secant approximation: nothing to evaluate.
+      const size_t szJ = (size_t)m * (size_t)n;
+      if(dev_cb) {
+        RC(hiopamd_ctx_sync(ctx));
+        if(dprob->eval_grad_f(n, x, 0, d_grad.p, dprob->user_data) != 0) return user_failed("eval_grad_f");
+        if(dprob->eval_Jac_cons(n, m, x, 0, d_Jall.p, dprob->user_data) != 0) return user_failed("eval_Jac_cons");
+      } else {
+        std::vector<double> g((size_t)n), jj(std::max<size_t>(szJ, 1));
+        if(dprob->eval_grad_f(n, x, 0, g.data(), dprob->user_data) != 0) return user_failed("eval_grad_f");
+        if(dprob->eval_Jac_cons(n, m, x, 0, jj.data(), dprob->user_data) != 0) return user_failed("eval_Jac_cons");
+        RC(h2d(d_grad.p, g.data(), sizeof(double) * (size_t)n));
+        RC(h2d(d_Jall.p, jj.data(), sizeof(double) * szJ));
+        RC(hiopamd_ctx_sync(ctx));
+      }
+      RC(hiopamd_mat_copy_rows_from_idx(ctx, neq, n, d_J.p, n, d_Jall.p, n, d_eq_map.p));
+      RC(hiopamd_mat_copy_rows_from_idx(ctx, nineq, n, d_J.p + (size_t)neq * n, n, d_Jall.p, n, d_ineq_map.p));
+      RC(hiopamd_kkt_xycyd_set_matrices(full, nullptr, d_J.p, d_J.p + (size_t)neq * n));
+      return HIOPAMD_OK;
+    }
     const size_t szJD = (size_t)m * (size_t)nd, szHD = (size_t)nd * (size_t)nd;
     // lambda in the user's constraint order (hiopNlpMDS::eval_Hess_Lagr, hiopNlpFormulation.cpp:1757-1800)
     {
@@ -333,27 +366,30 @@ int MdsSolver::setup()
 {
   RC(hiopamd_ctx_create(&ctx, nullptr));
   hiop_size_type nn = 0, mm = 0;
-  if(prob->get_prob_sizes(&nn, &mm, prob->user_data) != 0) return user_failed("get_prob_sizes");
+  void* ud = dprob ? dprob->user_data : prob->user_data;
+  if((dprob ? dprob->get_prob_sizes : prob->get_prob_sizes)(&nn, &mm, ud) != 0) return user_failed("get_prob_sizes");
   n = nn;
   m = mm;
-  hiop_size_type a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
-  if(prob->get_sparse_dense_blocks_info(&a, &b, &c, &d, &e, &f, prob->user_data) != 0)
-    return user_failed("get_sparse_dense_blocks_info");
-  ns = a;
-  nd = b;
-  nnzJ = c + d;
-  nnzH = e;
-  if(ns + nd != n || f != 0) {   // hiopNlpFormulation.cpp:1873 asserts nnz_sparse_Hess_Lagr_SD == 0 as well
-    std::fprintf(stderr, "hiop_amd: MDS problem needs nx_sparse + nx_dense == n and an empty sparse-dense Hessian block\n");
-    status = Invalid_Problem_Definition;
-    return HIOPAMD_ERR_ARG;
+  if(!dprob) {
+    hiop_size_type a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
+    if(prob->get_sparse_dense_blocks_info(&a, &b, &c, &d, &e, &f, prob->user_data) != 0)
+      return user_failed("get_sparse_dense_blocks_info");
+    ns = a;
+    nd = b;
+    nnzJ = c + d;
+    nnzH = e;
+    if(ns + nd != n || f != 0) {   // hiopNlpFormulation.cpp:1873 asserts nnz_sparse_Hess_Lagr_SD == 0 as well
+      std::fprintf(stderr, "hiop_amd: MDS problem needs nx_sparse + nx_dense == n and an empty sparse-dense Hessian block\n");
+      status = Invalid_Problem_Definition;
+      return HIOPAMD_ERR_ARG;
+    }
   }
   xl.resize(n);
   xu.resize(n);
   cl.resize(std::max(m, 1));
   cu.resize(std::max(m, 1));
-  if(prob->get_vars_info(n, xl.data(), xu.data(), prob->user_data) != 0) return user_failed("get_vars_info");
-  if(prob->get_cons_info(m, cl.data(), cu.data(), prob->user_data) != 0) return user_failed("get_cons_info");
+  if((dprob ? dprob->get_vars_info : prob->get_vars_info)(n, xl.data(), xu.data(), ud) != 0) return user_failed("get_vars_info");
+  if((dprob ? dprob->get_cons_info : prob->get_cons_info)(m, cl.data(), cu.data(), ud) != 0) return user_failed("get_cons_info");
   for(int i = 0; i < n; ++i) {
     if(xl[i] == xu[i]) {
       std::fprintf(stderr, "hiop_amd: fixed variable %d (xlow == xupp) — not supported by this interface\n", i);
@@ -401,13 +437,13 @@ int MdsSolver::setup()
   iH.resize(std::max(nnzH, 1));
   jH.resize(std::max(nnzH, 1));
   h_x.assign((size_t)n, 0.0);
-  if(prob->get_starting_point(n, h_x.data(), prob->user_data) != 0) {
+  if((dprob ? dprob->get_starting_point : prob->get_starting_point)(n, h_x.data(), ud) != 0) {
     std::fprintf(stderr, "hiop_amd: user did not provide a starting point; will be set to all zeros\n");   // :326-331
     std::fill(h_x.begin(), h_x.end(), 0.0);
   }
   std::vector<double> x0 = h_x;
   RC(it.alloc(1));   // (placeholder so that x_for_cb below has a context; real slabs follow)
-  {
+  if(!dprob) {
     // the pattern calls take x as well (the reference passes the starting point); device mode needs it on the device
     DevBuf<double> x0d;
     RC(x0d.alloc((size_t)n));
@@ -491,6 +527,15 @@ int MdsSolver::setup()
   RC(up_d(d_idu, idu, nineq));
   RC(hiopamd_ctx_sync(ctx));
 
+  if(dprob) {
+    // hiopHessianLowRank + hiopKKTLinSysLowRank behind the full-space layer (options at their defaults: secant_memory_len 6,
+    // sigma0 1, sigma_update_strategy sty); the perturbation object is hiopPDPerturbationNull (hiopAlgFilterIPM.cpp:1054)
+    RC(hiopamd_hess_lowrank_create(&hess, ctx, n, neq, nineq, secant_memory_len, sigma0, 1));
+    RC(hiopamd_kkt_lowrank_create(&klr, ctx, hess));
+    RC(hiopamd_kkt_xycyd_create_lowrank(&full, ctx, klr, d_ixl.p, d_ixu.p, d_idl.p, d_idu.p));
+    RC(d_Jall.alloc((size_t)m * (size_t)n));
+    RC(d_J.alloc((size_t)m * (size_t)n));
+  }
   hiopamd_mds_structure s;
   std::memset(&s, 0, sizeof(s));
   s.nxs = ns;
@@ -510,8 +555,10 @@ int MdsSolver::setup()
   s.nnz_Hss = nnzH;
   s.Hss_i = d_Hss_i.p;
   s.Hss_j = d_Hss_j.p;
-  RC(hiopamd_kkt_mds_create(&kkt, ctx, &s));
-  RC(hiopamd_kkt_xycyd_create_mds(&full, ctx, kkt, d_ixl.p, d_ixu.p, d_idl.p, d_idu.p));
+  if(!dprob) {
+    RC(hiopamd_kkt_mds_create(&kkt, ctx, &s));
+    RC(hiopamd_kkt_xycyd_create_mds(&full, ctx, kkt, d_ixl.p, d_ixu.p, d_idl.p, d_idu.p));
+  }
   RC(hiopamd_kkt_xycyd_set_bounds(full, d_xl.p, d_xu.p, d_dl.p, d_du.p, d_crhs.p));
   RC(hiopamd_kkt_xycyd_offsets(full, off));
   dim = hiopamd_kkt_xycyd_dim(full);
@@ -561,10 +608,14 @@ int MdsSolver::run()
     // apply_scaling's decision (hiopNlpFormulation.cpp:671-696): scale only when a gradient entry reaches scaling_max_grad
     double g = 0.0, a = 0.0, b = 0.0, c = 0.0, d = 0.0;
     RC(hiopamd_vec_infnorm(ctx, n, d_grad.p, &g));
-    if(nnzJeq) RC(hiopamd_vec_infnorm(ctx, nnzJeq, d_Jcs_v.p, &a));
-    if(nnzJineq) RC(hiopamd_vec_infnorm(ctx, nnzJineq, d_Jds_v.p, &b));
-    if((size_t)neq * nd) RC(hiopamd_vec_infnorm(ctx, (int64_t)neq * nd, d_Jcd.p, &c));
-    if((size_t)nineq * nd) RC(hiopamd_vec_infnorm(ctx, (int64_t)nineq * nd, d_Jdd.p, &d));
+    if(dprob) {
+      if((size_t)m * n) RC(hiopamd_vec_infnorm(ctx, (int64_t)m * n, d_J.p, &a));
+    } else {
+      if(nnzJeq) RC(hiopamd_vec_infnorm(ctx, nnzJeq, d_Jcs_v.p, &a));
+      if(nnzJineq) RC(hiopamd_vec_infnorm(ctx, nnzJineq, d_Jds_v.p, &b));
+      if((size_t)neq * nd) RC(hiopamd_vec_infnorm(ctx, (int64_t)neq * nd, d_Jcd.p, &c));
+      if((size_t)nineq * nd) RC(hiopamd_vec_infnorm(ctx, (int64_t)nineq * nd, d_Jdd.p, &d));
+    }
     if(!(g < o.scaling_max_grad && std::fmax(a, c) < o.scaling_max_grad && std::fmax(b, d) < o.scaling_max_grad)) {
       std::fprintf(stderr, "hiop_amd: the problem needs gradient-based scaling (max |grad f| = %g, max |J| = %g >= %g), which this "
                            "interface does not implement\n", g, std::fmax(std::fmax(a, b), std::fmax(c, d)), o.scaling_max_grad);
@@ -612,7 +663,7 @@ int MdsSolver::run()
         hiopamd_io_iteration_header(line, sizeof(line));
         std::fputs(line, stdout);
       }
-      hiopamd_io_format_iteration(line, sizeof(line), 0, iter_num, f, e.feas, e.optim, mu, ad, ap, ls_status, ls_num, use_soc, 0);
+      hiopamd_io_format_iteration(line, sizeof(line), dprob ? 1 : 0, iter_num, f, e.feas, e.optim, mu, ad, ap, ls_status, ls_num, use_soc, 0);
       std::fputs(line, stdout);
     }
     if(e0.optim < 0) e0 = e;
@@ -650,6 +701,10 @@ int MdsSolver::run()
     // ---- search direction, :2333-2462
     RC(hiopamd_kkt_xycyd_set_mu(full, mu));
     int ok = 0;
+    if(dprob) {   // Hess->update(*it_curr, *_grad_f, *_Jac_c, *_Jac_d), hiopAlgFilterIPM.cpp:1212
+      int stored = 0;
+      RC(hiopamd_hess_lowrank_update(hess, part(it, 0), d_grad.p, d_J.p, d_J.p + (size_t)neq * n, part(it, 2), part(it, 3), &stored));
+    }
     RC(hiopamd_kkt_xycyd_update(full, it.p, &ok));
     nfact += 1 + hiopamd_kkt_xycyd_num_refactorizations(full);
     if(!ok) {
@@ -780,12 +835,20 @@ int MdsSolver::run()
     RC(hiopamd_residual_update(full, it.p, d_c.p, d_d.p, d_grad.p, mu, o.kappa_d, resid.p, norms));
   }
   iters = iter_num;
-  prob->obj_value = f;
-  if(prob->solution) RC(d2h(prob->solution, part(it, 0), sizeof(double) * (size_t)n));
+  double* sol = dprob ? dprob->solution : prob->solution;
+  if(dprob) {
+    dprob->obj_value = f;
+    dprob->niters = iter_num;
+    dprob->status = status;
+  } else {
+    prob->obj_value = f;
+  }
+  if(sol) RC(d2h(sol, part(it, 0), sizeof(double) * (size_t)n));
   return HIOPAMD_OK;
 }
 
 MdsSolver* solver_of(const cHiopMDSProblem* p) { return p ? static_cast<MdsSolver*>(p->refcppHiop) : nullptr; }
+MdsSolver* solver_of(const cHiopDenseProblem* p) { return p ? static_cast<MdsSolver*>(p->refcppHiop) : nullptr; }
 
 }  // namespace
 
@@ -824,6 +887,80 @@ int hiop_mds_destroy_problem(cHiopMDSProblem* problem)
   delete s;
   if(problem) problem->refcppHiop = problem->hiopinterface = nullptr;
   return 0;
+}
+
+// ---- dense-constraints problems (hiopInterface.h:150-176; chiopInterface.cpp:129-159: quasi-Newton, duals linear / zero) --------
+int hiop_dense_create_problem(cHiopDenseProblem* problem)
+{
+  if(!problem || !problem->get_prob_sizes || !problem->get_vars_info || !problem->get_cons_info || !problem->eval_f ||
+     !problem->eval_grad_f || !problem->eval_cons || !problem->eval_Jac_cons || !problem->get_starting_point)
+    return HIOPAMD_ERR_ARG;
+  MdsSolver* s = new(std::nothrow) MdsSolver();
+  if(!s) return HIOPAMD_ERR_HIP;
+  s->dprob = problem;
+  s->o.mu0 = 1.0;   // hiop_dense_create_problem leaves mu0 at the option default (hiopOptions.cpp: 1.)
+  problem->refcppHiop = s;
+  problem->hiopinterface = nullptr;
+  problem->niters = 0;
+  problem->status = NlpSolve_SolveNotCalled;
+  return 0;
+}
+
+int hiop_dense_solve_problem(cHiopDenseProblem* problem)
+{
+  MdsSolver* s = solver_of(problem);
+  if(!s) return HIOPAMD_ERR_ARG;
+  if(!s->full) {
+    const int rc = s->setup();
+    if(rc != HIOPAMD_OK) return rc;
+  }
+  const int rc = s->run();
+  if(rc != HIOPAMD_OK) return rc;
+  return s->status >= 0 ? 0 : s->status;
+}
+
+int hiop_dense_destroy_problem(cHiopDenseProblem* problem)
+{
+  MdsSolver* s = solver_of(problem);
+  delete s;
+  if(problem) problem->refcppHiop = problem->hiopinterface = nullptr;
+  return 0;
+}
+
+int hiopamd_dense_set_callback_mem_space(cHiopDenseProblem* problem, int device)
+{
+  MdsSolver* s = solver_of(problem);
+  if(!s || s->full) return s ? HIOPAMD_ERR_STATE : HIOPAMD_ERR_ARG;
+  s->dev_cb = device != 0;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_dense_set_numeric_option(cHiopDenseProblem* problem, const char* name, double v)
+{
+  MdsSolver* s = solver_of(problem);
+  if(!s || !name) return HIOPAMD_ERR_ARG;
+  if(std::string(name) == "secant_memory_len") {
+    s->secant_memory_len = (int)v;
+    return HIOPAMD_OK;
+  }
+  if(std::string(name) == "sigma0") {
+    s->sigma0 = v;
+    return HIOPAMD_OK;
+  }
+  cHiopMDSProblem shim;
+  std::memset(&shim, 0, sizeof(shim));
+  shim.refcppHiop = s;
+  return hiopamd_mds_set_numeric_option(&shim, name, v);
+}
+
+int hiopamd_dense_get_solve_info(const cHiopDenseProblem* problem, int* status, int* num_iterations, int* num_factorizations)
+{
+  const MdsSolver* s = solver_of(problem);
+  if(!s) return HIOPAMD_ERR_ARG;
+  if(status) *status = s->status;
+  if(num_iterations) *num_iterations = s->iters;
+  if(num_factorizations) *num_factorizations = s->nfact;
+  return HIOPAMD_OK;
 }
 
 int hiopamd_mds_set_callback_mem_space(cHiopMDSProblem* problem, int device)

@@ -135,7 +135,8 @@ int hiopamd_kkt_sparse_condensed_set_values(hiopamd_kkt_sparse_condensed* k, con
   if(!k) return HIOPAMD_ERR_ARG;
   k->J_val = Jd_val; k->H_val = H_val; k->Dx = Dx; k->Dd = Dd;
   k->built = false;
-  return HIOPAMD_OK;
+  // Jd^T (CSR) gets the new values now: the transposed product is asked for before the next build (hiopResidual::update)
+  return Jd_val ? hiopamd_csr_condensed_refresh_jt(k->csr, Jd_val) : HIOPAMD_OK;
 }
 
 // only the log-barrier diagonals change (hiopKKTLinSysCompressedXDYcYd::update)
@@ -165,8 +166,7 @@ int hiopamd_kkt_sparse_condensed_factorize(hiopamd_kkt_sparse_condensed* k, int*
   if(!k->built) return HIOPAMD_ERR_STATE;
   SpanScope span(k->ctx, HIOPAMD_SPAN_KKT_UPDATE_INNER_FACT);
   double* diag = k->rhs;
-  RC(hiopamd_csr_extract_diagonal(k->ctx, k->nx, hiopamd_csr_condensed_rowptr(k->csr), hiopamd_csr_condensed_colidx(k->csr),
-                                  hiopamd_csr_condensed_values(k->csr), diag));
+  RC(hiopamd_csr_condensed_diagonal(k->csr, diag));
   int64_t nonpos = 0;
   int finite = 1;
   RC(hiopamd_vec_num_elems_less_than(k->ctx, k->nx, diag, std::numeric_limits<double>::min(), &nonpos));
@@ -194,7 +194,7 @@ int hiopamd_kkt_sparse_condensed_solve_compressed(hiopamd_kkt_sparse_condensed* 
       if(i < nx) rhs[i] = rx[i];
       if(i < nd) dyd[i] = Hd[i] * ryd[i] + rd[i];
     });
-    if(rc == HIOPAMD_OK) rc = hiopamd_sp_trans_times_vec(ctx, nd, nx, k->nnzJ, k->iJ, k->jJ, k->J_val, 1.0, k->rhs, 1.0, dyd);   // :379
+    if(rc == HIOPAMD_OK) rc = hiopamd_csr_condensed_jac_trans_times_vec(k->csr, 1.0, k->rhs, 1.0, dyd);   // :379
     span_end(ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);
     if(rc != HIOPAMD_OK) return rc;
   }
@@ -268,7 +268,8 @@ int hiopamd_kkt_sparse_condensed_jac_times_vec(hiopamd_kkt_sparse_condensed* k, 
 int hiopamd_kkt_sparse_condensed_jac_trans_times_vec(hiopamd_kkt_sparse_condensed* k, double beta, double* y, double alpha, const double* x)
 {
   if(!k || !k->J_val) return HIOPAMD_ERR_STATE;
-  return hiopamd_sp_trans_times_vec(k->ctx, k->nineq, k->nx, k->nnzJ, k->iJ, k->jJ, k->J_val, beta, y, alpha, x);
+  if(!k->J_val && k->nnzJ) return HIOPAMD_ERR_STATE;
+  return hiopamd_csr_condensed_jac_trans_times_vec(k->csr, beta, y, alpha, x);   // (Jd^T in CSR, values of the last set_values)
 }
 
 }  // extern "C"

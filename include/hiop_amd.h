@@ -357,6 +357,10 @@ int hiopamd_csr_condensed_numeric(hiopamd_csr_condensed* c, const double* J_val,
                                   const double* Dx, double delta_wx);
 /* hiopamd_linop_fn callbacks (user = the hiopamd_csr_condensed*): y = M x ; y = x ./ diag(M) (Jacobi preconditioner) */
 int hiopamd_csr_condensed_apply(void* user, const double* x_dev, double* y_dev);
+int hiopamd_csr_condensed_refresh_jt(hiopamd_csr_condensed* c, const double* J_val);   /* new Jacobian values for the Jd^T copy */
+/* y (n) = beta y + alpha Jd^T x (m), Jd^T kept in CSR by the object (values of the last numeric phase): no floating-point atomics */
+int hiopamd_csr_condensed_jac_trans_times_vec(hiopamd_csr_condensed* c, double beta, double* y, double alpha, const double* x);
+int hiopamd_csr_condensed_diagonal(hiopamd_csr_condensed* c, double* diag_dev);   /* diag(M), device, n */
 int hiopamd_csr_condensed_jacobi(void* user, const double* x_dev, double* y_dev);
 /* generic CSR kernels (int32 row pointers / column indices on the device) */
 int hiopamd_csr_times_vec(hiopamd_ctx*, int nrows, const int* rowptr, const int* colidx, const double* val, double beta,

@@ -70,6 +70,38 @@ int hiopamd_mds_set_numeric_option(cHiopMDSProblem* problem, const char* name, d
  * 5 Max_Iter_Exceeded, -4 Err_Step_Computation, ...), iterations, KKT factorisations (inertia corrections included) */
 int hiopamd_mds_get_solve_info(const cHiopMDSProblem* problem, int* status, int* num_iterations, int* num_factorizations);
 
+/* ---- dense-constraints problems: src/Interface/hiopInterface.h:150-176, chiopInterface.cpp:129-159 ---------------------------
+ * The quasi-Newton solver (hiopAlgFilterIPMQuasiNewton: secant Hessian hiopHessianLowRank, KKT class hiopKKTLinSysLowRank — the
+ * memory-distributed dense path of this library on one rank) with the options hiop_dense_create_problem sets in the reference:
+ * duals_update_type linear, duals_init zero; mu0 and everything else at the reference's defaults.  `MJac` is the m x n row-major
+ * Jacobian.  hiopamd_dense_set_callback_mem_space(problem, 1): x, gradf, cons and MJac are DEVICE pointers.
+ * Not supported (fails loudly): fixed variables (the reference sets fixed_var = relax), NLP scaling, feasibility restoration. */
+typedef struct cHiopDenseProblem {
+  void* refcppHiop;    /* owned by the library */
+  void* hiopinterface; /* owned by the library */
+  void* user_data;
+  double* solution;    /* host array of n doubles provided by the caller */
+  double obj_value;
+  int niters;
+  int status;          /* the reference's hiopSolveStatus value */
+  int (*get_starting_point)(hiop_size_type n, double* x0, void* user_data);
+  int (*get_prob_sizes)(hiop_size_type* n, hiop_size_type* m, void* user_data);
+  int (*get_vars_info)(hiop_size_type n, double* xlow, double* xupp, void* user_data);
+  int (*get_cons_info)(hiop_size_type m, double* clow, double* cupp, void* user_data);
+  int (*eval_f)(hiop_size_type n, double* x, int new_x, double* obj, void* user_data);
+  int (*eval_grad_f)(hiop_size_type n, double* x, int new_x, double* gradf, void* user_data);
+  int (*eval_cons)(hiop_size_type n, hiop_size_type m, double* x, int new_x, double* cons, void* user_data);
+  int (*eval_Jac_cons)(hiop_size_type n, hiop_size_type m, double* x, int new_x, double* MJac, void* user_data);
+} cHiopDenseProblem;
+
+int hiop_dense_create_problem(cHiopDenseProblem* problem);
+int hiop_dense_solve_problem(cHiopDenseProblem* problem);
+int hiop_dense_destroy_problem(cHiopDenseProblem* problem);
+int hiopamd_dense_set_callback_mem_space(cHiopDenseProblem* problem, int device);
+/* the names of hiopamd_mds_set_numeric_option, plus secant_memory_len and sigma0 */
+int hiopamd_dense_set_numeric_option(cHiopDenseProblem* problem, const char* name, double value);
+int hiopamd_dense_get_solve_info(const cHiopDenseProblem* problem, int* status, int* num_iterations, int* num_factorizations);
+
 #ifdef __cplusplus
 }
 #endif

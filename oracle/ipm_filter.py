@@ -216,10 +216,12 @@ def _accept(ops, o, filt, theta, theta_trial, ap, f_logbar, f_logbar_trial, thet
     return st, gpd
 
 
-def solve(ops, x0, on_kkt=None, table=None, quasi_newton=False, **options):
+def solve(ops, x0, on_kkt=None, table=None, quasi_newton=False, lsq_duals=None, **options):
     """quasi_newton=True: hiopAlgFilterIPMQuasiNewton::run (hiopAlgFilterIPM.cpp:960-1480) — the same loop with the secant
     update of the Hessian before every KKT update (:1212), `duals_init lsq` at the start and the LSQ duals update after the
     line search (hiopDualsLsqUpdate::go) — ops must provide hess_update(it, ev) and duals_lsq(it, grad_f).
+    lsq_duals (default: = quasi_newton): `duals_init lsq` + `duals_update_type lsq`; False with quasi_newton=True is the option set
+    of the reference's dense C interface (chiopInterface.cpp:133-135: quasi-Newton Hessian, linear duals, zero initial duals).
     Returns dict(x, obj, iters, status, n_fact).  `on_kkt(iter_num, it, mu, resid)` is called after every successful
     kkt update (the point at which the reference writes kkt_linsys_<iter>.iajaaa, hiopKKTLinSysCompressedMDSXYcYd via
     hiopKKTLinSys.cpp `write_linsys_counter_`)."""
@@ -230,7 +232,9 @@ def solve(ops, x0, on_kkt=None, table=None, quasi_newton=False, **options):
     tau = max(o["tau_min"], 1.0 - mu)                                   # hiopAlgFilterIPM.cpp:255 reload_options
     it = ops.start(x0, mu, o["kappa1"], o["kappa2"])
     ev = ops.evaluate(it)
-    if quasi_newton:                                                    # compute_initial_duals_eq, hiopDualsUpdater.hpp:154-186
+    if lsq_duals is None:
+        lsq_duals = quasi_newton
+    if lsq_duals:                                                       # compute_initial_duals_eq, hiopDualsUpdater.hpp:154-186
         ok = ops.duals_lsq(it, ev[1])
         eq, _ = ops.dual_norms_inf(it)
         if not ok or eq > o["duals_lsq_ini_max"]:
@@ -353,7 +357,7 @@ def solve(ops, x0, on_kkt=None, table=None, quasi_newton=False, **options):
         iter_num += 1
         # ---- duals, then the accepted trial becomes the iterate, :2714-2754
         it = ops.duals_update(it, trial, dr, ap, ad, mu)
-        if quasi_newton and theta_trial <= o["recalc_lsq_duals_tol"]:   # hiopDualsUpdater.cpp:118-149: with the gradient and the
+        if lsq_duals and theta_trial <= o["recalc_lsq_duals_tol"]:   # hiopDualsUpdater.cpp:118-149: with the gradient and the
             if not ops.duals_lsq(it, ev[1]):                            # Jacobians of the PREVIOUS iterate (they are re-evaluated
                 raise RuntimeError("dual lsq update failed")            # only after `go`, hiopAlgFilterIPM.cpp:1448-1456)
         ev = ops.evaluate(it)

@@ -1,0 +1,122 @@
+/* Test program for the C interface of the dense-constraints (quasi-Newton) solver, include/hiop_amd_interface.h — the counterpart
+ * of what a user of the reference's hiop_dense_create/solve/destroy_problem (src/Interface/hiopInterface.h:150-176) writes.
+ * Problem: the reference's DenseConsEx2 (src/Drivers/Dense/NlpDenseConsEx2.hpp:18-30):
+ *   min sum 1/4 (x_i - 1)^4   s.t.  sum x_i = n + 1;  5 <= 2 x_1 + sum_{i>=2} x_i;  1 <= 2 x_1 + 0.5 x_2 + sum_{i>=3} x_i <= 2n;
+ *   4 x_1 + 2 x_2 + 2 x_3 + sum_{i>=4} x_i <= 4n;   x_1 free, x_2 >= 0, 1.5 <= x_3 <= 10, x_i >= 0.5 (i >= 4);  x0 = 0.
+ * Exact optimum 1/64 (x_3 = 1.5 on its bound, every other x_i = 1).
+ *   dense_c_interface [n]    prints "obj=<%.15e> iters=<k> status=<s>"; exit code 0 iff the solve succeeded. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hiop_amd_interface.h"
+
+typedef struct {
+  int n;
+} prob_t;
+
+static int sizes(hiop_size_type* n, hiop_size_type* m, void* u)
+{
+  *n = ((prob_t*)u)->n;
+  *m = 4;
+  return 0;
+}
+static int start(hiop_size_type n, double* x0, void* u)
+{
+  (void)u;
+  for(int i = 0; i < n; ++i) x0[i] = 0.0;
+  return 0;
+}
+static int vars(hiop_size_type n, double* lo, double* up, void* u)
+{
+  (void)u;
+  for(int i = 0; i < n; ++i) lo[i] = 0.5, up[i] = 1e20;
+  lo[0] = -1e20;
+  lo[1] = 0.0;
+  lo[2] = 1.5, up[2] = 10.0;
+  return 0;
+}
+static int cons_info(hiop_size_type m, double* lo, double* up, void* u)
+{
+  const int n = ((prob_t*)u)->n;
+  (void)m;
+  lo[0] = up[0] = n + 1.0;
+  lo[1] = 5.0, up[1] = 1e20;
+  lo[2] = 1.0, up[2] = 2.0 * n;
+  lo[3] = -1e20, up[3] = 4.0 * n;
+  return 0;
+}
+static double coef(int row, int j)
+{
+  if(row == 1) return j == 0 ? 2.0 : 1.0;
+  if(row == 2) return j == 0 ? 2.0 : (j == 1 ? 0.5 : 1.0);
+  if(row == 3) return j == 0 ? 4.0 : (j <= 2 ? 2.0 : 1.0);
+  return 1.0;
+}
+static int f_cb(hiop_size_type n, double* x, int new_x, double* obj, void* u)
+{
+  (void)new_x, (void)u;
+  double s = 0.0;
+  for(int i = 0; i < n; ++i) {
+    const double t = x[i] - 1.0;
+    s += t * t * t * t;
+  }
+  *obj = 0.25 * s;
+  return 0;
+}
+static int g_cb(hiop_size_type n, double* x, int new_x, double* g, void* u)
+{
+  (void)new_x, (void)u;
+  for(int i = 0; i < n; ++i) {
+    const double t = x[i] - 1.0;
+    g[i] = t * t * t;
+  }
+  return 0;
+}
+static int c_cb(hiop_size_type n, hiop_size_type m, double* x, int new_x, double* c, void* u)
+{
+  (void)new_x, (void)u;
+  for(int r = 0; r < m; ++r) {
+    double s = 0.0;
+    for(int j = 0; j < n; ++j) s += coef(r, j) * x[j];
+    c[r] = s;
+  }
+  return 0;
+}
+static int jac_cb(hiop_size_type n, hiop_size_type m, double* x, int new_x, double* J, void* u)
+{
+  (void)x, (void)new_x, (void)u;
+  for(int r = 0; r < m; ++r)
+    for(int j = 0; j < n; ++j) J[(size_t)r * n + j] = coef(r, j);
+  return 0;
+}
+
+int main(int argc, char** argv)
+{
+  prob_t P;
+  P.n = argc > 1 ? atoi(argv[1]) : 500;
+  cHiopDenseProblem prob;
+  memset(&prob, 0, sizeof(prob));
+  prob.user_data = &P;
+  prob.get_starting_point = start;
+  prob.get_prob_sizes = sizes;
+  prob.get_vars_info = vars;
+  prob.get_cons_info = cons_info;
+  prob.eval_f = f_cb;
+  prob.eval_grad_f = g_cb;
+  prob.eval_cons = c_cb;
+  prob.eval_Jac_cons = jac_cb;
+  prob.solution = (double*)calloc((size_t)P.n, sizeof(double));
+  if(hiop_dense_create_problem(&prob) != 0) return 3;
+  const int rc = hiop_dense_solve_problem(&prob);
+  double dev = 0.0;
+  for(int i = 0; i < P.n; ++i) {
+    const double want = i == 2 ? 1.5 : 1.0;
+    if(fabs(prob.solution[i] - want) > dev) dev = fabs(prob.solution[i] - want);
+  }
+  printf("obj=%.15e iters=%d status=%d maxdev=%.3e rc=%d\n", prob.obj_value, prob.niters, prob.status, dev, rc);
+  hiop_dense_destroy_problem(&prob);
+  free(prob.solution);
+  return rc != 0;
+}

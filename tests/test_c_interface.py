@@ -19,11 +19,12 @@ ROOT = Path(__file__).resolve().parent.parent
 SRC = ROOT / "tests" / "c" / "mds_c_interface.c"
 
 
-def _compile(tmp_path):
+def _compile(tmp_path, src=None):
     from hiop_amd.build import build
     lib = build()
-    exe = tmp_path / "mds_c_interface"
-    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", f"-I{ROOT / 'include'}", str(SRC), "-o", str(exe),
+    src = SRC if src is None else src
+    exe = tmp_path / src.stem
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
            f"-L{lib.parent}", "-lhiopamd", "-lm", f"-Wl,-rpath,{lib.parent}"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -89,3 +90,38 @@ def test_c_program_solves_mds_ex1_like_the_reference_driver(tmp_path, mode):
     # the iteration table it printed is the reference's format (header every 10 iterations, one line per iteration)
     lines = [l for l in r.stdout.splitlines() if re.match(r"^\s*\d+\s+-?\d\.\d{7}e", l)]
     assert len(lines) == iters + 1 and r.stdout.count("iter    objective") == iters // 10 + 1
+
+
+DENSE_SRC = ROOT / "tests" / "c" / "dense_c_interface.c"
+
+
+def test_dense_c_program_compiles_and_links(tmp_path):
+    exe = _compile(tmp_path, DENSE_SRC)
+    syms = subprocess.run(["nm", "-D", "--undefined-only", str(exe)], capture_output=True, text=True).stdout
+    for s in ("hiop_dense_create_problem", "hiop_dense_solve_problem", "hiop_dense_destroy_problem"):
+        assert s in syms
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [500, 5000])
+def test_dense_c_program_solves_dense_cons_ex2_with_the_quasi_newton_path(tmp_path, n):
+    """hiop_dense_create/solve/destroy_problem (hiopInterface.h:150-176) on DenseConsEx2 written as C callbacks: the quasi-Newton
+    filter IPM of the reference's dense C interface (chiopInterface.cpp:129-159: secant Hessian, linear duals, zero initial duals)
+    on the device's low-rank KKT path.  The run must end at the problem's optimum 1/64 (x_3 = 1.5, the rest 1; bounds relaxed by 1e-8)
+    and equal the numpy run of the same loop: same iteration count (+-1: the secant recursion amplifies rounding late in the run),
+    objective to 1e-9."""
+    from oracle import ipm_filter
+    from oracle import problems as pr
+    from tests.test_oracle_reference_trajectory import quasi_newton_setup
+    exe = _compile(tmp_path, DENSE_SRC)
+    r = subprocess.run([str(exe), str(n)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    g = re.match(r"obj=(\S+) iters=(\d+) status=(-?\d+) maxdev=(\S+) rc=(-?\d+)", r.stdout.strip().splitlines()[-1])
+    assert g, r.stdout[-500:]
+    obj, iters, status, maxdev = float(g.group(1)), int(g.group(2)), int(g.group(3)), float(g.group(4))
+    assert status == 0 and abs(obj - 1.0 / 64) <= 2e-8 and maxdev <= 1e-2
+    q = pr.dense_ex2(n)
+    ops, full, bounds = quasi_newton_setup(q)
+    o = ipm_filter.solve(ops, q["x0"], quasi_newton=True, lsq_duals=False)
+    assert o["status"] == "Solve_Success"
+    assert abs(iters - o["iters"]) <= 1 and abs(obj - o["obj"]) <= 1e-9
