@@ -314,6 +314,46 @@ def sparse_condensed_bench(ctx, a, n=1_000_000):
     return out
 
 
+def ipm_end_to_end_bench(ns=4092, nd=4097):
+    """The reference's metric measured the reference's way: a REAL interior-point run — hiop_mds_create/solve/destroy_problem of this
+    library (include/hiop_amd_interface.h) on the stock MdsEx1 problem at the headline order (ns = 4092 sparse pairs, nd = 4097 dense
+    variables, m = ns + 3: N = nd + m = 8192), callbacks on device arrays — and iterations / (time inside the KKT span), the span
+    hiopRunKKTStats::tmTotal covers (hiopAlgFilterIPM.cpp:2339-2461).  The driver is the C program of the tests, compiled here with gcc."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from pathlib import Path
+    from hiop_amd.build import build
+    root = Path(__file__).resolve().parent
+    if shutil.which("gcc") is None:
+        return {"error": "no gcc on this box"}
+    lib = build()
+    with tempfile.TemporaryDirectory() as td:
+        exe = Path(td) / "mds_c_interface"
+        cmd = ["gcc", "-std=c11", "-O1", f"-I{root / 'include'}", str(root / "tests" / "c" / "mds_c_interface.c"), "-o", str(exe),
+               f"-L{lib.parent}", "-lhiopamd", "-lm", f"-Wl,-rpath,{lib.parent}"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"error": "gcc: " + r.stderr[-300:]}
+        out = {}
+        for mode in ("device", "host"):
+            r = subprocess.run([str(exe), mode, str(ns), str(nd)], capture_output=True, text=True, timeout=600)
+            g = re.search(r"obj=(\S+) iters=(\d+) status=(-?\d+) nfact=(\d+)", r.stdout)
+            t = re.search(r"times: total=(\S+) kkt=(\S+)", r.stdout)
+            if r.returncode != 0 or not g or not t:
+                out[mode] = {"error": (r.stdout[-200:] + r.stderr[-200:])}
+                continue
+            iters, total, kkt = int(g.group(2)), float(t.group(1)), float(t.group(2))
+            out[mode] = dict(objective=float(g.group(1)), iterations=iters, status=int(g.group(3)), factorizations=int(g.group(4)),
+                             solve_seconds=total, kkt_span_seconds=kkt, kkt_iterations_per_s=iters / kkt if kkt > 0 else None,
+                             ipm_iterations_per_s=iters / total if total > 0 else None)
+    out["workload"] = (f"hiop_mds_solve_problem on stock MdsEx1(ns={ns}, nd={nd}): n={2 * ns + nd}, m={ns + 3}, N={nd + ns + 3}; Newton filter IPM, "
+                       "tolerance 1e-8, mu0 0.1; 'device' = callbacks on device arrays (hiopamd_mdsex1_*), 'host' = callbacks on host arrays "
+                       "(Jacobian / Hessian blocks cross PCIe every iteration: the PCIe-inclusive rate)")
+    return out
+
+
 def time_on_ctx_stream(ctx, fn, reps=20):
     """average milliseconds of `fn` (a C-ABI call that launches on the context's stream), HIP events on that stream."""
     import torch
@@ -524,6 +564,14 @@ def main():
         except Exception as e:      # an auxiliary entry must not take the headline line down
             sparse_c5 = {"error": repr(e)}
 
+    ipm_e2e = None
+    if world == 1 and not a.no_dense:
+        try:
+            ctx.sync()
+            ipm_e2e = ipm_end_to_end_bench()
+        except Exception as e:
+            ipm_e2e = {"error": repr(e)}
+
     out = None
     if rank == 0:
         value = world * a.steps / dt
@@ -545,6 +593,8 @@ def main():
             out["dense_n1e6_m100"] = dense_c2
         if sparse_c5 is not None:
             out["sparse_condensed_n1e6"] = sparse_c5
+        if ipm_e2e is not None:
+            out["ipm_end_to_end_N8192"] = ipm_e2e
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, Dx, Dd, rhs, a.solves, a.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -18,6 +18,7 @@
 #include "../../include/hiop_amd_interface.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -117,6 +118,7 @@ struct MdsSolver {
   std::vector<double> h_x, h_buf;
   // results
   int status = NlpSolve_SolveNotCalled, iters = 0, nfact = 0;
+  double t_total = 0.0, t_kkt = 0.0;   // seconds inside run(); inside the KKT span (update + directions: the reference's runStats.kkt.tmTotal)
 
   ~MdsSolver()
   {
@@ -589,6 +591,14 @@ int MdsSolver::setup()
 
 int MdsSolver::run()
 {
+  using clk = std::chrono::steady_clock;
+  const auto t_run0 = clk::now();
+  t_kkt = 0.0;
+  struct Stop {
+    MdsSolver* s;
+    clk::time_point t0;
+    ~Stop() { s->t_total = std::chrono::duration<double>(clk::now() - t0).count(); }
+  } stop{this, t_run0};
   const double eps_tol = o.tolerance;
   double mu = o.mu0;
   double tau = std::fmax(o.tau_min, 1.0 - mu);   // :269
@@ -699,6 +709,7 @@ int MdsSolver::run()
       filt.initialize(theta_max);                                                        // :2321
     }
     // ---- search direction, :2333-2462
+    const auto t_k0 = clk::now();   // nlp->runStats.kkt.start_optimiz_iteration(), hiopAlgFilterIPM.cpp:2339 / :1209
     RC(hiopamd_kkt_xycyd_set_mu(full, mu));
     int ok = 0;
     if(dprob) {   // Hess->update(*it_curr, *_grad_f, *_Jac_c, *_Jac_d), hiopAlgFilterIPM.cpp:1212
@@ -720,6 +731,7 @@ int MdsSolver::run()
       status = Err_Step_Computation;
       break;
     }
+    t_kkt += std::chrono::duration<double>(clk::now() - t_k0).count();   // end_optimiz_iteration (:2461); the call above synchronised
     // ---- backtracking line search, :2477-2588
     RC(hiopamd_iterate_fraction_to_the_bdry(full, it.p, dir.p, tau, &ap, &ad));
     const double theta = norms[6];   // resid->get_theta()
@@ -994,6 +1006,24 @@ int hiopamd_mds_set_numeric_option(cHiopMDSProblem* problem, const char* name, d
   OPTI(max_iter) OPTI(acceptable_iterations) OPTI(max_soc_iter) OPTI(verbosity_level)
 #undef OPTI
   return HIOPAMD_ERR_ARG;
+}
+
+int hiopamd_mds_get_solve_times(const cHiopMDSProblem* problem, double* total_seconds, double* kkt_seconds)
+{
+  const MdsSolver* s = solver_of(problem);
+  if(!s) return HIOPAMD_ERR_ARG;
+  if(total_seconds) *total_seconds = s->t_total;
+  if(kkt_seconds) *kkt_seconds = s->t_kkt;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_dense_get_solve_times(const cHiopDenseProblem* problem, double* total_seconds, double* kkt_seconds)
+{
+  const MdsSolver* s = solver_of(problem);
+  if(!s) return HIOPAMD_ERR_ARG;
+  if(total_seconds) *total_seconds = s->t_total;
+  if(kkt_seconds) *kkt_seconds = s->t_kkt;
+  return HIOPAMD_OK;
 }
 
 int hiopamd_mds_get_solve_info(const cHiopMDSProblem* problem, int* status, int* num_iterations, int* num_factorizations)

@@ -69,6 +69,10 @@ int hiopamd_mds_set_numeric_option(cHiopMDSProblem* problem, const char* name, d
 /* after solve: status = the reference's hiopSolveStatus value (hiopInterface.hpp:78-110: 0 Solve_Success, 2 Solve_Acceptable_Level,
  * 5 Max_Iter_Exceeded, -4 Err_Step_Computation, ...), iterations, KKT factorisations (inertia corrections included) */
 int hiopamd_mds_get_solve_info(const cHiopMDSProblem* problem, int* status, int* num_iterations, int* num_factorizations);
+/* wall-clock seconds of the last solve: the whole optimisation loop, and the part inside the KKT span the reference's metric is defined on
+ * (runStats.kkt.tmTotal: start_optimiz_iteration ... end_optimiz_iteration, hiopAlgFilterIPM.cpp:2339,2461 — update + factorisation(s) +
+ * directions with refinement); iterations / kkt_seconds is BASELINE's 'KKT iterations per second' measured in a real run */
+int hiopamd_mds_get_solve_times(const cHiopMDSProblem* problem, double* total_seconds, double* kkt_seconds);
 
 /* ---- dense-constraints problems: src/Interface/hiopInterface.h:150-176, chiopInterface.cpp:129-159 ---------------------------
  * The quasi-Newton solver (hiopAlgFilterIPMQuasiNewton: secant Hessian hiopHessianLowRank, KKT class hiopKKTLinSysLowRank — the
@@ -101,6 +105,7 @@ int hiopamd_dense_set_callback_mem_space(cHiopDenseProblem* problem, int device)
 /* the names of hiopamd_mds_set_numeric_option, plus secant_memory_len and sigma0 */
 int hiopamd_dense_set_numeric_option(cHiopDenseProblem* problem, const char* name, double value);
 int hiopamd_dense_get_solve_info(const cHiopDenseProblem* problem, int* status, int* num_iterations, int* num_factorizations);
+int hiopamd_dense_get_solve_times(const cHiopDenseProblem* problem, double* total_seconds, double* kkt_seconds);
 
 #ifdef __cplusplus
 }

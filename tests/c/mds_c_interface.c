@@ -258,6 +258,9 @@ int main(int argc, char** argv)
   double xsum = 0.0;
   for(int i = 0; i < n; ++i) xsum += prob.solution[i];
   printf("obj=%.15e iters=%d status=%d nfact=%d xsum=%.12e rc=%d\n", prob.obj_value, iters, status, nfact, xsum, rc);
+  double t_total = 0.0, t_kkt = 0.0;
+  hiopamd_mds_get_solve_times(&prob, &t_total, &t_kkt);
+  printf("times: total=%.6f kkt=%.6f\n", t_total, t_kkt);
   int ret = rc != 0;
   if(!ret && P.ns == 400 && P.nd == 100 && tol == 0.0 && fabs(prob.obj_value - (-4.999509728895e+01)) > 1e-6) {
     printf("objective mismatch for MDS Ex1 C interface problem with 400 sparse variables and 100 dense variables\n");

@@ -79,7 +79,7 @@ def test_c_program_solves_mds_ex1_like_the_reference_driver(tmp_path, mode):
     exe = _compile(tmp_path)
     r = subprocess.run([str(exe), mode], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    last = r.stdout.strip().splitlines()[-1]
+    last = [l for l in r.stdout.strip().splitlines() if l.startswith("obj=")][-1]
     g = re.match(r"obj=(\S+) iters=(\d+) status=(-?\d+) nfact=(\d+) xsum=(\S+) rc=(-?\d+)", last)
     assert g, last
     obj, iters, status = float(g.group(1)), int(g.group(2)), int(g.group(3))
