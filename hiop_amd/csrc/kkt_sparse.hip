@@ -14,6 +14,7 @@
 // reference ("Code for iterative refinement ... was removed since the parent KKT class performs this now", :432-435).
 #include "device_utils.hpp"
 
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -22,6 +23,12 @@ struct hiopamd_kkt_sparse_condensed {
   int nx = 0, nineq = 0, nnzJ = 0, nnzH = 0;
   hiopamd_csr_condensed* csr = nullptr;
   hiopamd_krylov* pcg = nullptr;
+  // DIRECT inner solver for moderate orders (nx <= HIOPAMD_SPARSE_DIRECT_MAX, default 4096): the condensed matrix expanded to a dense
+  // upper triangle and factored by this library's LDL^T with inertia — the role of the reference's sparse Cholesky (MA57 /
+  // cuSOLVER, hiopKKTLinSysSparseCondensed.cpp:469-496) with the same answer to "is M positive definite" (exact, not through a
+  // Krylov probe).  Beyond that order: PCG + Jacobi.
+  hiopamd_linsolver* dls = nullptr;
+  bool dls_factored = false;   // the dense copy holds factors of the CURRENT M
   // sparsity (device copies of the triplet index arrays: the SpMVs of the right-hand side / recovery and of the operator)
   int *iJ = nullptr, *jJ = nullptr, *iH = nullptr, *jH = nullptr;
   // current values (borrowed)
@@ -60,6 +67,24 @@ int up_int(int** d, const int* h, int n)
   return HIOPAMD_OK;
 }
 
+// dense upper triangle of M (the direct inner solver's system matrix) from its CSR form
+int build_impl_dense_copy(hiopamd_kkt_sparse_condensed* k)
+{
+  hiopamd_ctx* ctx = k->ctx;
+  double* Md = hiopamd_linsolver_sys_matrix(k->dls);
+  const int64_t n = k->nx;
+  HIOPAMD_CHECK(hipMemsetAsync(Md, 0, sizeof(double) * (size_t)n * (size_t)n, ctx->stream));
+  const int* rp = hiopamd_csr_condensed_rowptr(k->csr);
+  const int* ci = hiopamd_csr_condensed_colidx(k->csr);
+  const double* v = hiopamd_csr_condensed_values(k->csr);
+  RC(launch_ew(ctx, n, [=] __device__(int64_t i) {
+    for(int q = rp[i]; q < rp[i + 1]; ++q)
+      if(ci[q] >= i) Md[i * n + ci[q]] = v[q];
+  }));
+  k->dls_factored = false;
+  return HIOPAMD_OK;
+}
+
 int build_impl(hiopamd_kkt_sparse_condensed* k, SpDelta dwx, SpDelta dwd)
 {
   if(!k || !k->J_val || !k->Dx || (k->nineq > 0 && !k->Dd) || (k->nnzH > 0 && !k->H_val)) return HIOPAMD_ERR_STATE;
@@ -76,6 +101,7 @@ int build_impl(hiopamd_kkt_sparse_condensed* k, SpDelta dwx, SpDelta dwd)
   }
   // M = Jd^T diag(Hd) Jd + H + diag(Dx + delta_wx)   (:205-318; one symbolic analysis at create, four launches here)
   RC(hiopamd_csr_condensed_numeric(k->csr, k->J_val, k->H_val, k->Hd, k->Dxp, 0.0));
+  if(k->dls) RC(build_impl_dense_copy(k));
   k->built = true;
   return HIOPAMD_OK;
 }
@@ -88,6 +114,7 @@ int hiopamd_kkt_sparse_condensed_destroy(hiopamd_kkt_sparse_condensed* k)
   if(!k) return HIOPAMD_OK;
   if(k->ctx) (void)hipStreamSynchronize(k->ctx->stream);
   if(k->pcg) hiopamd_krylov_destroy(k->pcg);
+  if(k->dls) hiopamd_linsolver_destroy(k->dls);
   if(k->csr) hiopamd_csr_condensed_destroy(k->csr);
   (void)hipFree(k->iJ); (void)hipFree(k->jJ); (void)hipFree(k->iH); (void)hipFree(k->jH);
   (void)hipFree(k->Hd); (void)hipFree(k->Dxp); (void)hipFree(k->rhs);
@@ -117,6 +144,11 @@ int hiopamd_kkt_sparse_condensed_create(hiopamd_kkt_sparse_condensed** out, hiop
   if(rc == HIOPAMD_OK)
     rc = hiopamd_krylov_create(&k->pcg, ctx, 0, nx, hiopamd_csr_condensed_apply, k->csr, hiopamd_csr_condensed_jacobi, k->csr, nullptr,
                                nullptr);
+  {
+    const char* e = std::getenv("HIOPAMD_SPARSE_DIRECT_MAX");
+    const int direct_max = e ? std::atoi(e) : 4096;
+    if(rc == HIOPAMD_OK && nx > 0 && nx <= direct_max) rc = hiopamd_linsolver_create(&k->dls, ctx, nx);
+  }
   if(rc == HIOPAMD_OK) rc = hiopamd_krylov_set_tol(k->pcg, k->tol);
   if(rc == HIOPAMD_OK) rc = hiopamd_krylov_set_max_num_iter(k->pcg, k->maxit);
   if(rc != HIOPAMD_OK) {
@@ -165,6 +197,15 @@ int hiopamd_kkt_sparse_condensed_factorize(hiopamd_kkt_sparse_condensed* k, int*
   if(!k || !n_neg_host) return HIOPAMD_ERR_ARG;
   if(!k->built) return HIOPAMD_ERR_STATE;
   SpanScope span(k->ctx, HIOPAMD_SPAN_KKT_UPDATE_INNER_FACT);
+  if(k->dls) {   // a Cholesky exists iff no pivot of the LDL^T is non-positive
+    int nneg = 0;
+    if(k->dls_factored) RC(build_impl_dense_copy(k));   // factorize twice on one build: the copy holds factors, not M
+    const int rc = hiopamd_linsolver_matrix_changed(k->dls, &nneg);
+    k->dls_factored = true;
+    if(rc != HIOPAMD_OK && rc != HIOPAMD_ERR_SINGULAR) return rc;
+    *n_neg_host = (rc == HIOPAMD_ERR_SINGULAR || nneg != 0) ? -1 : 0;
+    return HIOPAMD_OK;
+  }
   double* diag = k->rhs;
   RC(hiopamd_csr_condensed_diagonal(k->csr, diag));
   int64_t nonpos = 0;
@@ -199,14 +240,21 @@ int hiopamd_kkt_sparse_condensed_solve_compressed(hiopamd_kkt_sparse_condensed* 
     if(rc != HIOPAMD_OK) return rc;
   }
   int conv = 0;
-  {
+  if(k->dls) {
     SpanScope span(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);   // linSys_->solve(*rhs_)  (:384)
+    RC(hiopamd_linsolver_solve(k->dls, k->rhs, 1));
+    conv = 1;
+    k->last_flag = 0;
+    k->last_iters = 0.0;
+    k->last_rel = 0.0;
+  } else {
+    SpanScope span(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);
     RC(hiopamd_krylov_set_x0(k->pcg, 0.0));
     RC(hiopamd_krylov_solve(k->pcg, k->rhs, &conv));
+    k->last_flag = hiopamd_krylov_get_convergence_flag(k->pcg);
+    k->last_iters = hiopamd_krylov_get_sol_num_iter(k->pcg);
+    k->last_rel = hiopamd_krylov_get_sol_rel_resid(k->pcg);
   }
-  k->last_flag = hiopamd_krylov_get_convergence_flag(k->pcg);
-  k->last_iters = hiopamd_krylov_get_sol_num_iter(k->pcg);
-  k->last_rel = hiopamd_krylov_get_sol_rel_resid(k->pcg);
   if(!conv) return HIOPAMD_OK;   // (*ok_host = 0: the reference returns false here, :386-388)
   SpanScope span(ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);
   {   // dx = rhs ; dd = ryd  (:389-391)

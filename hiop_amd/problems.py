@@ -236,3 +236,30 @@ def sparse_ex2_ineq(n: int, x: np.ndarray | None = None, scal: float = 1.0) -> S
     Hi = np.arange(n, dtype=np.int32)
     Hv = 3.0 * scal * (x - 1.0) ** 2 + 1.0
     return SparseIneqProblem(n, m, np.array(Ji, np.int32), np.array(Jj, np.int32), np.array(Jv), Hi, Hi.copy(), Hv)
+
+
+def sparse_ex2_nlp(n: int, convex_obj: bool = False, rankdefic_eq: bool = True, rankdefic_ineq: bool = True, scal_neg_obj: float = 0.1):
+    """The reference's SparseEx2 as a whole NLP (src/Drivers/Sparse/NlpSparseEx2.{hpp,cpp}: objective :126-143, constraints :156-186,
+    bounds :52-110, start :319-326), with the driver's settings as defaults (NlpSparseEx2Driver.cpp:219-222):
+        min sum (2 convex - 1) scal 1/4 (x_i - 1)^4 + 1/2 x_i^2
+        s.t. 4 x_1 + 2 x_2 = 10;  2 x_1 + x_3 >= 5;  1 <= 2 x_1 + 0.5 x_i <= 2 n (i >= 4);  [4 x_1 + 2 x_3 <= 19];  [4 x_1 + 2 x_2 = 10]
+        x_1 free, x_2 >= 0, 1 <= x_3 <= 10, x_i >= 0.5;  x0 = 0.
+    The two bracketed rows (a dependent inequality, a DUPLICATED equality) make the Jacobians rank deficient; with convex_obj = False
+    the Hessian diagonal -3 scal (x_i - 1)^2 + 1 goes negative away from 1: the inertia-correction loop has work to do.
+    Returns the constraint rows as triplets (row-sorted) with [clow, cupp] in the user's order, plus callables."""
+    sgn = 2 * int(convex_obj) - 1
+    Ji, Jj, Jv, cl, cu = [0, 0, 1, 1], [0, 1, 0, 2], [4.0, 2.0, 2.0, 1.0], [10.0, 5.0], [10.0, 1e20]
+    r = 2
+    for i in range(3, n):
+        Ji += [r, r]; Jj += [0, i]; Jv += [2.0, 0.5]; cl.append(1.0); cu.append(2.0 * n); r += 1
+    if rankdefic_ineq:
+        Ji += [r, r]; Jj += [0, 2]; Jv += [4.0, 2.0]; cl.append(-1e20); cu.append(19.0); r += 1
+    if rankdefic_eq:
+        Ji += [r, r]; Jj += [0, 1]; Jv += [4.0, 2.0]; cl.append(10.0); cu.append(10.0); r += 1
+    xl = np.full(n, 0.5); xu = np.full(n, 1e20)
+    xl[0] = -1e20; xl[1] = 0.0; xl[2] = 1.0; xu[2] = 10.0
+    return dict(n=n, m=r, J_i=np.array(Ji, np.int32), J_j=np.array(Jj, np.int32), J_v=np.array(Jv), clow=np.array(cl), cupp=np.array(cu),
+                xl=xl, xu=xu, x0=np.zeros(n),
+                f=lambda x: float(np.sum(sgn * scal_neg_obj * 0.25 * (x - 1.0) ** 4 + 0.5 * x ** 2)),
+                grad=lambda x: sgn * scal_neg_obj * (x - 1.0) ** 3 + x,
+                hess_diag=lambda x: sgn * scal_neg_obj * 3.0 * (x - 1.0) ** 2 + 1.0)
