@@ -2058,7 +2058,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 
 struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
-  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, nflags = 0;
+  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_run = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
   std::vector<unsigned> upcnt, wfirst;
   std::vector<int4> wq, wf;
@@ -2087,7 +2087,10 @@ static DfPlan df_build_plan(int N)
   // (+ the profiling stamps and phase sums, + per super-panel 2 x 4 block-row counters of the substitution tasks that feed the
   //  first four update tiles, see DF_UPH)
   P.off_trb = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 48;
-  P.nflags = P.off_trb + 8 * (int64_t)(P.nsp + 1);
+  P.off_cu = P.off_trb + 8 * (int64_t)(P.nsp + 1);
+  P.off_wg = P.off_cu + 512;
+  P.off_run = P.off_wg + 2 * 512;   // (at most 480 + 16 workgroups)
+  P.nflags = P.off_run + 0;         // (+ wtasks.size(), added when the lists exist)
   std::vector<int4> t0, t1;
   df_chain_tasks(true, t0);
   df_chain_tasks(false, t1);
@@ -2181,6 +2184,7 @@ static DfPlan df_build_plan(int N)
   P.wtasks.insert(P.wtasks.end(), farq.begin(), farq.end());
   P.wf = wf;
   P.wq = wq;
+  P.nflags = P.off_run + 2 * (int64_t)P.wtasks.size();   // handed out, completed
   return P;
 }
 
@@ -2205,6 +2209,11 @@ struct DfDevice {
   unsigned* wfirst = nullptr;
   int nvb = DF_NVB_MIN;
   bool enabled = true;
+  // a bounded wait expired (hiopamd_linsolver_matrix_changed): the NEXT factorisation of this object — the caller's retry on the
+  // re-assembled matrix — runs the stepwise kernels, the one after that the dataflow pair again; three time-outs in a row
+  // (no successful dataflow factorisation in between) switch the object to the stepwise kernels for good
+  bool skip_once = false;
+  int strikes = 0;
 };
 
 struct hiopamd_linsolver {
@@ -2379,6 +2388,26 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.off_ts = P.off_ver + (int64_t)P.nt * P.nt;
     a.off_ph = a.off_ts + 8 * (int64_t)(P.nsp + 1);
     a.off_trb = P.off_trb;
+    a.off_cu = P.off_cu;
+    a.off_wg = P.off_wg;
+    {   // limit of every bounded wait: 8x a pessimistic estimate of the whole factorisation (20 TFLOP/s + 1 ms), at least 50 ms, at most 3 s;
+        // HIOPAMD_DF_TIMEOUT_MS overrides.  (A wait that is served never lasts longer than the factorisation itself.)
+      static const double env_ms = std::getenv("HIOPAMD_DF_TIMEOUT_MS") ? std::atof(std::getenv("HIOPAMD_DF_TIMEOUT_MS")) : 0.0;
+      const double est_s = (double)N * N * N / 3.0 / 20e12 + 1e-3;
+      const double lim_s = env_ms > 0.0 ? env_ms * 1e-3 : std::min(3.0, std::max(0.05, 8.0 * est_s));
+      a.timeout_ticks = (long long)(lim_s * 1e8);
+    }
+    static const bool df_check = std::getenv("HIOPAMD_DF_CHECK") && std::atoi(std::getenv("HIOPAMD_DF_CHECK")) != 0;
+    a.off_run = df_check ? P.off_run : 0;
+    // In the chain-bound second half the wide kernel's tasks are latency (substitution, head tiles): a workgroup alone on its CU runs
+    // them 1.6x faster than next to a partner, and idle partners poll the same flag words the chain hands over through — measured at
+    // N = 8192 (scripts/r03_gpu_24.sh): 94 us per super-panel with 240 workgroups against 117 with 480, while the update-bound first
+    // half needs the 480 (3.63 ms against 3.90).  So every workgroup that is not the first on its CU leaves when its queue pointers
+    // reach super-panel jretire (default: where the K = 512 pairing ends; HIOPAMD_DF_RETIRE=<j>, a value >= nsp keeps all).
+    {
+      static const int retire_env = std::getenv("HIOPAMD_DF_RETIRE") ? std::atoi(std::getenv("HIOPAMD_DF_RETIRE")) : -1;
+      a.jretire = retire_env >= 0 ? retire_env : (P.nwide + 1) / 2;
+    }
     // HIOPAMD_DF_ONE=1 (measurement aid): chain + wide as ONE dispatch on the wide stream, one workgroup per CU — the form the
     // rocprofv3 counter passes can profile (see ldlt_df_one_kernel); needs the 16-byte tile form
     static const bool df_one = std::getenv("HIOPAMD_DF_ONE") && std::atoi(std::getenv("HIOPAMD_DF_ONE")) != 0;
@@ -2397,7 +2426,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
     if(a.nwtasks > 0) {
       if(timed) (void)hipEventRecord(prof->get(), su);
-      const int wmax = 240 * DF_WIDE_WG_PER_CU;   // the resident workgroups of the 240 CUs of the wide stream
+      // the resident workgroups of the 240 CUs of the wide stream (HIOPAMD_DF_WGS: timing aid — 240 = one workgroup per CU)
+      static const int wgs_env = std::getenv("HIOPAMD_DF_WGS") ? std::atoi(std::getenv("HIOPAMD_DF_WGS")) : 0;
+      const int wmax = wgs_env > 0 ? std::min(wgs_env, 240 * DF_WIDE_WG_PER_CU) : 240 * DF_WIDE_WG_PER_CU;
       const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
       // 16-byte accesses need even N, lda, ldv (ldv = N); HIOPAMD_DF_TILE=1 forces the 8-byte form (A/B timing)
       static const int tile_env = std::getenv("HIOPAMD_DF_TILE") ? std::atoi(std::getenv("HIOPAMD_DF_TILE")) : 2;
@@ -2538,11 +2569,77 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       std::fprintf(stderr, "[hiop_amd]   inside F: set-up %.2f | 64x64 factor in LDS %.2f (of which the four 16x16 sub-block factors %.2f) | emit + rest %.2f\n",
                    ph[16] * 0.01 / 127.0, ph[17] * 0.01 / 127.0, ph[44] * 0.01 / 127.0, (ph[12] - ph[16] - ph[17]) * 0.01 / ph[15]);
   }
+  if(use_df && std::getenv("HIOPAMD_DF_CHECK") && std::atoi(std::getenv("HIOPAMD_DF_CHECK")) != 0) {
+    const DfPlan& P = df->plan;
+    std::vector<unsigned> run(2 * P.wtasks.size());
+    (void)hipMemcpy(run.data(), df->flags + P.off_run, sizeof(unsigned) * run.size(), hipMemcpyDeviceToHost);
+    int bad = 0, jmax = 0;
+    const size_t nt_ = P.wtasks.size();
+    for(size_t t = 0; t < nt_; ++t)
+      if(run[2 * t] != 0u) jmax = std::max(jmax, P.wtasks[t].y);
+    for(size_t t = 0; t < nt_; ++t) {
+      const unsigned h = run[2 * t], c = run[2 * t + 1];
+      const bool early_q = P.wtasks[t].y < jmax - 1;
+      if((h > 1u || c > 1u || (!dfw[DF_ABORT] && (h != 1u || c != 1u)) || (dfw[DF_ABORT] && early_q && (h != 1u || c != 1u))) && bad++ < 24)
+        std::fprintf(stderr, "[hiop_amd] HIOPAMD_DF_CHECK: task %zu (kind %d, super-panel %d, %d %d): handed out %u times, completed %u times\n", t, P.wtasks[t].x, P.wtasks[t].y,
+                     P.wtasks[t].z, P.wtasks[t].w, h, c);
+    }
+    if(bad) std::fprintf(stderr, "[hiop_amd] HIOPAMD_DF_CHECK: %d of %zu tasks not handed out / completed exactly once%s\n", bad, nt_, dfw[DF_ABORT] ? " (aborted run; later queues not listed)" : "");
+  }
   if(dfw[DF_ABORT]) {
     std::fprintf(stderr,
                  "[hiop_amd] dataflow LDL^T: a bounded wait timed out, factorisation aborted.  waiter %u (1 = TR, 2 = UP, 100+r = "
                  "chain role r) args %u %u %u %u, condition slot %u: flag word %u is %u, needs >= %u; tickets taken %u\n",
                  dfw[2], dfw[3], dfw[4], dfw[5], dfw[6], dfw[7], dfw[10], dfw[9], dfw[8], dfw[DF_TICKET]);
+    std::fprintf(stderr, "[hiop_amd]   that wait had lasted %.3f ms on the waiter's clock\n", dfw[11] * 160e-6);
+    static const bool df_debug = std::getenv("HIOPAMD_DF_DEBUG") && std::atoi(std::getenv("HIOPAMD_DF_DEBUG")) != 0;
+    if(df_debug) {   // what every workgroup of the wide kernel held when the kernels gave up
+      const DfPlan& P = df->plan;
+      std::vector<unsigned> wg(2 * 512);
+      (void)hipMemcpy(wg.data(), df->flags + P.off_wg, sizeof(unsigned) * wg.size(), hipMemcpyDeviceToHost);
+      int shown = 0;
+      for(int r = 0; r < 16; ++r) {
+        const unsigned v = wg[2 * (496 + r)];
+        std::fprintf(stderr, "[hiop_amd]   chain role %d: last task kind %u (1 F, 2 T, 3 U, 4 S, 5 R, 6 C) super-panel %u fields %u %u %u\n", r, v >> 28, (v >> 16) & 255u,
+                     (v >> 8) & 15u, (v >> 4) & 15u, v & 15u);
+      }
+      int looking = 0, left = 0, never = 0, between = 0;
+      for(int w = 0; w < 480; ++w) {
+        if(wg[2 * w] == 0u) ++never;
+        if(wg[2 * w] == 0xF0000000u) ++between;
+      }
+      std::fprintf(stderr, "[hiop_amd]   wide kernel: %d of 480 workgroups never started, %d started and nothing else\n", never, between);
+      for(int w = 0; w < 496; ++w) {
+        if((wg[2 * w] >> 24) == 0xF1u) ++looking;
+        if((wg[2 * w] >> 24) == 0xF2u && ((wg[2 * w] >> 16) & 255u) != 1u && ((wg[2 * w] >> 16) & 255u) != 2u) ++left;
+      }
+      std::fprintf(stderr, "[hiop_amd]   wide kernel: %d workgroups were looking for a task, %d had left (queues exhausted / retired / aborted)\n", looking, left);
+      // substitution tasks one by one (others wait for them), update tasks as a histogram by (kind, super-panel, phase)
+      int hist[5][256][4] = {};
+      for(int w = 0; w < 496; ++w) {
+        const unsigned v = wg[2 * w];
+        if(v == 0u || (v >> 24) == 0xF1u || (v >> 24) == 0xF0u) continue;
+        if((v >> 24) == 0xF3u) {
+          std::fprintf(stderr, "[hiop_amd]   workgroup %d finished a task and did not get to the next selection\n", w);
+          continue;
+        }
+        if((v >> 24) == 0xF2u) {
+          const unsigned k = (v >> 16) & 255u;
+          if(k == 1u || k == 2u)
+            std::fprintf(stderr, "[hiop_amd]   workgroup %d took a task (kind %u, super-panel %u) and did not get past the barriers behind the selection\n", w, k, v & 0xffffu);
+          continue;
+        }
+        const unsigned kind = v >> 28, ph = (v >> 24) & 15u, jj = (v >> 16) & 255u;
+        if(kind == 1u)
+          std::fprintf(stderr, "[hiop_amd]   workgroup %d holds substitution task of super-panel %u, columns from %u, list index %d (-1: early), phase %u (1 waits for its inputs, 2 running)\n", w, jj,
+                       v & 0xffffu, (int)wg[2 * w + 1], ph);
+        else if(kind < 5u && ph < 4u) hist[kind][jj][ph] += 1;
+      }
+      for(int k = 2; k < 5; ++k)
+        for(int jj = 0; jj < 256; ++jj)
+          if(hist[k][jj][1] || hist[k][jj][2])
+            std::fprintf(stderr, "[hiop_amd]   update tasks of kind %d (2 UP, 3 UPH, 4 UP2), queue %d: %d wait for their inputs, %d running\n", k, jj, hist[k][jj][1], hist[k][jj][2]);
+    }
     return HIOPAMD_ERR_TIMEOUT;
   }
   if(timed) prof->collect();
@@ -3006,18 +3103,36 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
   }
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_FACT);   // hiopLinSolverSymDenseLapack.hpp:80-125 (tmFactTime; flopsFact = n^3/3)
   ls->flops_fact += (double)n * n * n / 3.0;
-  int rc = ldlt_factor_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+  auto factor_once = [&]() {
+    // (see DfDevice::skip_once)
+    const bool df_was = ls->df.enabled;
+    const bool df_this = df_was && !ls->df.skip_once;
+    ls->df.enabled = df_this;
+    ls->df.skip_once = false;
+    const int r = ldlt_factor_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+    ls->df.enabled = df_was;
+    if(df_this && r == HIOPAMD_ERR_TIMEOUT) {
+      ls->df.skip_once = true;
+      if(++ls->df.strikes >= 3) {
+        ls->df.enabled = false;
+        std::fprintf(stderr, "[hiop_amd] dataflow LDL^T timed out three times in a row: this solver object uses the stepwise kernels from now on\n");
+      }
+    } else if(df_this && r != HIOPAMD_ERR_HIP) {
+      ls->df.strikes = 0;
+    }
+    return r;
+  };
+  int rc = factor_once();
   if(rc == HIOPAMD_ERR_TIMEOUT) {
-    // the dataflow kernels gave up (two processes on one device can starve the chain kernel's roles): the matrix is
-    // overwritten.  From now on this object uses the stepwise kernels; with a saved copy (safe mode) the factorisation is
-    // redone right away, otherwise the caller re-assembles and calls again (the KKT objects do).
-    ls->df.enabled = false;
-    std::fprintf(stderr, "[hiop_amd] dataflow LDL^T timed out: this solver object uses the stepwise kernels from now on\n");
+    // The dataflow kernels gave up — a flag update another workgroup was waiting for did not arrive within the limit (DESIGN.md 3.1:
+    // seen once in a few thousand factorisations at N = 8192; two processes on one device can also starve the chain kernel's roles).
+    // The matrix is overwritten.  With a saved copy (safe mode) the factorisation is redone right away with the stepwise kernels;
+    // otherwise the caller re-assembles and calls again (the KKT objects do), and that call runs the stepwise kernels.
     if(ls->safe_mode && n > 0) {
       HIOPAMD_CHECK(hipMemcpyAsync(ls->M, ls->Msave, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ls->ctx->stream));
       int rs = regularise();
       if(rs != HIOPAMD_OK) return rs;
-      rc = ldlt_factor_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+      rc = factor_once();
     }
   }
   if(rc == HIOPAMD_ERR_SINGULAR) {

@@ -80,11 +80,33 @@ struct DfArgs {
   int nwide;               // super-panels with wide-kernel work
   int64_t off_trb;         // per super-panel [2][4]: substitution tasks of 128-column block 2j+4+b that have stored block row P
   int spine_opt;           // HIOPAMD_DF_SPINE bits (see df_spine_step)
+  int64_t off_cu;          // 512 words: workgroups of the wide kernel that have reported from CU (xcc, se, cu) — a workgroup's rank on its CU
+  int jretire;             // the second (third, ...) workgroup of a CU leaves the wide kernel when its queue pointers reach this super-panel
+  long long timeout_ticks; // limit of every bounded wait, 100 MHz ticks (a multiple of the expected duration of the whole factorisation)
+  int64_t off_run;         // != 0 (HIOPAMD_DF_CHECK=1, soak tests): one counter per task of the wide kernel — how often its ticket was handed out
+  int64_t off_wg;          // 2 words per workgroup of the wide kernel: what it holds right now (see df_wg_state) — read by the host after a time-out
 };
 
-__device__ __forceinline__ unsigned df_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void df_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void df_add(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef HIOPAMD_DF_FLAG_SCOPE
+#define HIOPAMD_DF_FLAG_SCOPE __HIP_MEMORY_SCOPE_AGENT   /* (system scope: measured, no effect on the rare lost flag update) */
+#endif
+__device__ __forceinline__ unsigned df_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, HIOPAMD_DF_FLAG_SCOPE); }
+__device__ __forceinline__ void df_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, HIOPAMD_DF_FLAG_SCOPE); }
+// Read-modify-write operations on the flag words (counters, tickets).  At agent scope the compiler emits them without sc1; with
+// -DHIOPAMD_DF_RMW_SCOPE=__HIP_MEMORY_SCOPE_SYSTEM they carry sc1 (tried against the rare lost flag update of DESIGN.md 3.1: no effect).
+#ifndef HIOPAMD_DF_RMW_SCOPE
+#define HIOPAMD_DF_RMW_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+__device__ __forceinline__ void df_add(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, HIOPAMD_DF_RMW_SCOPE); }
+__device__ __forceinline__ unsigned df_ticket(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, HIOPAMD_DF_RMW_SCOPE); }
+// state word of a wide-kernel workgroup: kind (4 bits) | phase (4: 1 taken, 2 inputs there, 3 body done) | super-panel (8) | ticket-local index (16);
+// second word: the task's third / fourth field.  0 = between tasks.  Two fire-and-forget stores per phase by lane 0.
+__device__ __forceinline__ void df_wg_state(const DfArgs& a, int phase, const int4& tk)
+{
+  unsigned* p = a.flags + a.off_wg + 2 * (int64_t)blockIdx.x;
+  df_st(p, phase == 0 ? 0xF3000000u : (((unsigned)tk.x & 15u) << 28) | (((unsigned)phase & 15u) << 24) | (((unsigned)tk.y & 255u) << 16) | ((unsigned)tk.z & 0xffffu));
+  if(phase == 1) df_st(p + 1, (unsigned)tk.w);
+}
 
 // up to four (flag >= value) conditions, in fixed slots (compile-time indices keep them in registers); an unused slot
 // points at a word that always satisfies ">= 0"
@@ -131,11 +153,11 @@ struct DfWait {
 // returns within a few polls.  (Round 2 measured the limit from the START of the kernel: a factorisation that legitimately
 // runs longer than the limit — an order beyond ~70 000, a throttled or shared device — aborted at its first slow wait although
 // it was making progress.)  The sleep between polls keeps ~500 pollers from saturating the flags' memory channel.
-constexpr long long DF_TIMEOUT_TICKS = 300000000ll;   // 3 s
+constexpr long long DF_TIMEOUT_TICKS = 300000000ll;   // 3 s: the upper end; the limit in force is DfArgs::timeout_ticks (set per order by the host)
 __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* sh_ok, long long t_start, int who, int a0, int a1,
                                         int a2, int a3)
 {
-  (void)t_start;
+  const long long t_limit = t_start;   // (the callers pass DfArgs::timeout_ticks here)
   if(threadIdx.x == 0) {
     int ok = 1;
     unsigned spins = 0;
@@ -151,7 +173,7 @@ __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* s
           if((++spins & 31u) == 0) {
             const long long now = (long long)wall_clock64();
             if(t_wait == 0) t_wait = now;
-            const bool late = now - t_wait > DF_TIMEOUT_TICKS;
+            const bool late = now - t_wait > t_limit;
             if(late || df_ld(flags + DF_ABORT) != 0) {
               if(late && atomicCAS(flags + DF_ABORT, 0u, 1u) == 0u) {
                 df_st(flags + 2, (unsigned)who);
@@ -163,6 +185,7 @@ __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* s
                 df_st(flags + 8, w.v[q]);
                 df_st(flags + 9, df_ld(w.f[q]));
                 df_st(flags + 10, (unsigned)(w.f[q] - flags));
+                df_st(flags + 11, (unsigned)((now - t_wait) >> 4));    // how long this wait lasted, 160 ns units
               }
               ok = 0;
               break;
@@ -1081,9 +1104,15 @@ typedef double df_double2 __attribute__((ext_vector_type(2)));
 typedef unsigned int df_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int DF_SC1 = 16;   // aux bit of the raw buffer builtins = `sc1` on gfx942 / gfx950
 
+// (HIOPAMD_DF_OPAUX: experiment switch — the cache policy of the OPERAND loads of the update tile.  0 = plain loads, which may
+//  hit stale lines of this XCD's L2: wrong factors, only good for timing what L2 reuse of the row panels would be worth.)
+#ifndef HIOPAMD_DF_OPAUX
+#define HIOPAMD_DF_OPAUX DF_SC1
+#endif
+template <int AUX = DF_SC1>
 __device__ __forceinline__ df_double2 df_bload2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
 {
-  return __builtin_bit_cast(df_double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, DF_SC1));
+  return __builtin_bit_cast(df_double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, AUX));
 }
 __device__ __forceinline__ void df_bstore2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, df_double2 v)
 {
@@ -1146,11 +1175,11 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
     for(int p = 0; p < 4; ++p) {
       const unsigned k = (unsigned)(sl * UD_KT + 4 * p + wave);
       if(PANELS == 2 && second) {
-        vreg[p] = df_bload2(rsV2, vvoff, k * ldv8);
-        ureg[p] = df_bload2(rsU2, uvoff, k * lda8);
+        vreg[p] = df_bload2<HIOPAMD_DF_OPAUX>(rsV2, vvoff, k * ldv8);
+        ureg[p] = df_bload2<HIOPAMD_DF_OPAUX>(rsU2, uvoff, k * lda8);
       } else {
-        vreg[p] = df_bload2(rsV, vvoff, k * ldv8);
-        ureg[p] = df_bload2(rsU, uvoff, k * lda8);
+        vreg[p] = df_bload2<HIOPAMD_DF_OPAUX>(rsV, vvoff, k * ldv8);
+        ureg[p] = df_bload2<HIOPAMD_DF_OPAUX>(rsU, uvoff, k * lda8);
       }
     }
   };
@@ -1233,7 +1262,7 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
     __syncthreads();
   }
   // ---- epilogue: stores only
-  if(dbg && (dbg == 1 || j == dbg - 2)) {
+  if(dbg && (dbg == 1 || j + (PANELS - 1) == dbg - 2)) {   // (a fused task is accounted under the queue it was taken from)
     const unsigned tp2 = (unsigned)wall_clock64();
     ph[9] += tp1 - tp0;    // prologue (first operand stage + C tile in flight, two barriers)
     ph[10] += tp2 - tp1;   // the 16 stages

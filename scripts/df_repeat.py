@@ -1,0 +1,26 @@
+"""Dataflow LDL^T repeated many times on one solver object (and on fresh objects): any bounded-wait time-out shows up as an
+exception with the library's diagnostic record on stderr.  DF_N (8192), DF_REPS (300), DF_OBJECTS (4)."""
+import os, sys, time
+import torch
+sys.path.insert(0, ".")
+from hiop_amd.runtime import Context
+from hiop_amd.kkt import LinSolverSymDense
+N = int(os.environ.get("DF_N", "8192")); reps = int(os.environ.get("DF_REPS", "300")); nobj = int(os.environ.get("DF_OBJECTS", "4"))
+ctx = Context(0)
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+M = torch.rand(N, N, generator=g, device="cuda", dtype=torch.float64) * 1e-3
+M = M + M.T + torch.eye(N, device="cuda", dtype=torch.float64) * 10.0
+t0 = time.perf_counter(); done = 0
+for o in range(nobj):
+    ls = LinSolverSymDense(ctx, N)
+    for rep in range(reps):
+        ls.set_sys_matrix(M); ctx.sync(); tc = time.perf_counter()
+        try:
+            ls.matrix_changed()
+        except Exception:
+            print("factorisation %d failed after %.3f s in the call" % (done, time.perf_counter() - tc), flush=True)
+            raise
+        done += 1
+    ls.close() if hasattr(ls, "close") else None
+ctx.sync()
+print("%d factorisations of order %d without a time-out, %.2f ms each" % (done, N, (time.perf_counter() - t0) * 1e3 / done))

@@ -1,0 +1,62 @@
+"""Recovery from an expired bounded wait of the dataflow LDL^T (DESIGN.md 3.1 "lost flag update").  The limit of every wait is forced
+to 1 us (HIOPAMD_DF_TIMEOUT_MS, read once per process: the scenario runs in a child process), so every dataflow factorisation gives up:
+  * the bare solver object reports HIOPAMD_ERR_TIMEOUT (-6) — the matrix is overwritten, the caller re-assembles —, runs the NEXT
+    factorisation with the stepwise kernels (correct factors), tries the dataflow pair again after that, and after three time-outs in
+    a row stays with the stepwise kernels;
+  * in safe mode (a copy of K exists) and inside the MDS KKT object (it re-assembles itself) the caller never sees the failure.
+Reference behaviour mirrored: hiopLinSolverSymDense::matrixChanged never fails for a non-singular matrix (hiopLinSolverSymDenseLapack.hpp:80-125)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CHILD = textwrap.dedent('''
+    import sys
+    import numpy as np, torch
+    sys.path.insert(0, ".")
+    from hiop_amd.runtime import Context
+    from hiop_amd.kkt import LinSolverSymDense
+    from hiop_amd._lib import HiopAmdError
+    N = 1536
+    ctx = Context(0)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    M = torch.rand(N, N, generator=g, device="cuda", dtype=torch.float64) * 1e-3
+    M = M + M.T + torch.diag(torch.cat([torch.full((N // 2,), 10.0), torch.full((N - N // 2,), -10.0)]).to("cuda").double())
+    b = torch.rand(N, generator=g, device="cuda", dtype=torch.float64)
+    def solve_ok(ls):
+        x = b.clone(); ls.solve(x); ctx.sync()
+        return float((M @ x - b).abs().max() / b.abs().max()) < 1e-12
+    ls = LinSolverSymDense(ctx, N)
+    outcome = []
+    for call in range(8):
+        ls.set_sys_matrix(M); ctx.sync()
+        try:
+            nneg = ls.matrix_changed()
+            assert nneg == N - N // 2 and solve_ok(ls)
+            outcome.append("ok")
+        except HiopAmdError as e:
+            assert "-6" in str(e)
+            outcome.append("timeout")
+    print("BARE", " ".join(outcome))
+    ls2 = LinSolverSymDense(ctx, N); ls2.set_safe_mode(True, N // 2)
+    for call in range(3):
+        ls2.set_sys_matrix(M); ctx.sync()
+        assert ls2.matrix_changed() == N - N // 2 and solve_ok(ls2)
+    print("SAFE ok")
+''')
+
+
+def test_timeout_recovery_sequence(ctx):
+    env = dict(os.environ, HIOPAMD_DF_TIMEOUT_MS="0.001")
+    r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    bare = [l for l in r.stdout.splitlines() if l.startswith("BARE")][0].split()[1:]
+    # dataflow gives up, stepwise retry, dataflow gives up (2), stepwise, dataflow gives up (3: switched off), stepwise ever after
+    assert bare == ["timeout", "ok", "timeout", "ok", "timeout", "ok", "ok", "ok"], bare
+    assert "SAFE ok" in r.stdout
+    assert "three times in a row" in r.stderr
