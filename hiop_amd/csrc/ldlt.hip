@@ -2390,11 +2390,11 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.off_trb = P.off_trb;
     a.off_cu = P.off_cu;
     a.off_wg = P.off_wg;
-    {   // limit of every bounded wait: 8x a pessimistic estimate of the whole factorisation (20 TFLOP/s + 1 ms), at least 50 ms, at most 3 s;
-        // HIOPAMD_DF_TIMEOUT_MS overrides.  (A wait that is served never lasts longer than the factorisation itself.)
+    {   // limit of every bounded wait: 20x a pessimistic estimate of the whole factorisation (20 TFLOP/s + 1 ms), at least 250 ms, at most
+        // 3 s; HIOPAMD_DF_TIMEOUT_MS overrides.  (A wait that is served never lasts longer than the factorisation itself.)
       static const double env_ms = std::getenv("HIOPAMD_DF_TIMEOUT_MS") ? std::atof(std::getenv("HIOPAMD_DF_TIMEOUT_MS")) : 0.0;
       const double est_s = (double)N * N * N / 3.0 / 20e12 + 1e-3;
-      const double lim_s = env_ms > 0.0 ? env_ms * 1e-3 : std::min(3.0, std::max(0.05, 8.0 * est_s));
+      const double lim_s = env_ms > 0.0 ? env_ms * 1e-3 : std::min(3.0, std::max(0.25, 20.0 * est_s));
       a.timeout_ticks = (long long)(lim_s * 1e8);
     }
     static const bool df_check = std::getenv("HIOPAMD_DF_CHECK") && std::atoi(std::getenv("HIOPAMD_DF_CHECK")) != 0;

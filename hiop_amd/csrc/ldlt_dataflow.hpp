@@ -97,7 +97,15 @@ __device__ __forceinline__ void df_st(unsigned* p, unsigned v) { __hip_atomic_st
 #ifndef HIOPAMD_DF_RMW_SCOPE
 #define HIOPAMD_DF_RMW_SCOPE __HIP_MEMORY_SCOPE_AGENT
 #endif
+#ifdef HIOPAMD_DF_ADD_RETURNS   /* experiment: the returning form of the instruction (the wave waits for the old value) */
+__device__ __forceinline__ void df_add(unsigned* p, unsigned v)
+{
+  const unsigned r = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, HIOPAMD_DF_RMW_SCOPE);
+  asm volatile("" ::"v"(r));
+}
+#else
 __device__ __forceinline__ void df_add(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, HIOPAMD_DF_RMW_SCOPE); }
+#endif
 __device__ __forceinline__ unsigned df_ticket(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, HIOPAMD_DF_RMW_SCOPE); }
 // state word of a wide-kernel workgroup: kind (4 bits) | phase (4: 1 taken, 2 inputs there, 3 body done) | super-panel (8) | ticket-local index (16);
 // second word: the task's third / fourth field.  0 = between tasks.  Two fire-and-forget stores per phase by lane 0.

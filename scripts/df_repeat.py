@@ -1,5 +1,6 @@
 """Dataflow LDL^T repeated many times on one solver object (and on fresh objects): any bounded-wait time-out shows up as an
-exception with the library's diagnostic record on stderr.  DF_N (8192), DF_REPS (300), DF_OBJECTS (4)."""
+exception with the library's diagnostic record on stderr.  DF_N (8192), DF_REPS (300), DF_OBJECTS (4); DF_VERIFY=1: solve with every
+factor and check the residual."""
 import os, sys, time
 import torch
 sys.path.insert(0, ".")
@@ -10,6 +11,9 @@ ctx = Context(0)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 M = torch.rand(N, N, generator=g, device="cuda", dtype=torch.float64) * 1e-3
 M = M + M.T + torch.eye(N, device="cuda", dtype=torch.float64) * 10.0
+verify = os.environ.get("DF_VERIFY", "0") == "1"
+b = torch.rand(N, generator=g, device="cuda", dtype=torch.float64)
+worst, nbad = 0.0, 0
 t0 = time.perf_counter(); done = 0
 for o in range(nobj):
     ls = LinSolverSymDense(ctx, N)
@@ -21,6 +25,12 @@ for o in range(nobj):
             print("factorisation %d failed after %.3f s in the call" % (done, time.perf_counter() - tc), flush=True)
             raise
         done += 1
+        if verify:
+            x = b.clone(); ls.solve(x); ctx.sync()
+            res = float((M @ x - b).abs().max() / b.abs().max())
+            worst = max(worst, res)
+            if not res < 1e-11:
+                print("factorisation %d: residual %.3e" % (done, res), flush=True); nbad += 1
     ls.close() if hasattr(ls, "close") else None
 ctx.sync()
-print("%d factorisations of order %d without a time-out, %.2f ms each" % (done, N, (time.perf_counter() - t0) * 1e3 / done))
+print("%d factorisations of order %d without a time-out, %.2f ms each%s" % (done, N, (time.perf_counter() - t0) * 1e3 / done, (", worst solve residual %.2e, %d above 1e-11" % (worst, nbad)) if verify else ""))
