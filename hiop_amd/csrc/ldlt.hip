@@ -31,6 +31,8 @@
 #include <mutex>
 #include <sys/file.h>
 #include <unistd.h>
+#include <map>
+#include <string>
 #include <vector>
 
 namespace hiopamd {
@@ -2058,7 +2060,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 
 struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
-  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_run = 0, nflags = 0;
+  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_shadow = 0, off_run = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
   std::vector<unsigned> upcnt, wfirst;
   std::vector<int4> wq, wf;
@@ -2089,7 +2091,8 @@ static DfPlan df_build_plan(int N)
   P.off_trb = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 48;
   P.off_cu = P.off_trb + 8 * (int64_t)(P.nsp + 1);
   P.off_wg = P.off_cu + 512;
-  P.off_run = P.off_wg + 2 * 512;   // (at most 480 + 16 workgroups)
+  P.off_shadow = P.off_wg + 2 * 512;   // (at most 480 + 16 workgroups)
+  P.off_run = P.off_shadow + (int64_t)P.nsp * P.nt + 2 * (int64_t)P.nt * P.nt + (int64_t)P.nsp * 256 + (int64_t)P.nsp * P.nt * P.nt;   // tr, ver, (pad), executions of TR / update tasks
   P.nflags = P.off_run + 0;         // (+ wtasks.size(), added when the lists exist)
   std::vector<int4> t0, t1;
   df_chain_tasks(true, t0);
@@ -2195,6 +2198,10 @@ static int df_nvb_for(int n)
 {
   const int nsp = (n + LD_NB - 1) / LD_NB;
   if(const char* e = std::getenv("HIOPAMD_DF_NVB")) return std::max(DF_NVB_MIN, std::min(std::atoi(e), std::max(nsp, DF_NVB_MIN)));
+  // One workspace per super-panel while that costs at most 2 GB (N <= 16384): no buffer is ever reused, so nothing — neither the chain
+  // kernel nor the idle workgroups of the wide kernel — polls the "updates of super-panel j - nvb complete" counters, which ~1500 tasks
+  // increment (polling a word that is being incremented from everywhere is what delayed flag updates).
+  if((double)nsp * LD_NB * (double)n * 8.0 <= 2.0e9) return std::max(nsp, DF_NVB_MIN);
   return DF_NVB_MIN;
 }
 
@@ -2399,6 +2406,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     }
     static const bool df_check = std::getenv("HIOPAMD_DF_CHECK") && std::atoi(std::getenv("HIOPAMD_DF_CHECK")) != 0;
     a.off_run = df_check ? P.off_run : 0;
+    static const bool df_debug_sh = std::getenv("HIOPAMD_DF_DEBUG") && std::atoi(std::getenv("HIOPAMD_DF_DEBUG")) != 0;
+    a.off_shadow = df_debug_sh ? P.off_shadow : 0;
     // In the chain-bound second half the wide kernel's tasks are latency (substitution, head tiles): a workgroup alone on its CU runs
     // them 1.6x faster than next to a partner, and idle partners poll the same flag words the chain hands over through — measured at
     // N = 8192 (scripts/r03_gpu_24.sh): 94 us per super-panel with 240 workgroups against 117 with 480, while the update-bound first
@@ -2616,6 +2625,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       std::fprintf(stderr, "[hiop_amd]   wide kernel: %d workgroups were looking for a task, %d had left (queues exhausted / retired / aborted)\n", looking, left);
       // substitution tasks one by one (others wait for them), update tasks as a histogram by (kind, super-panel, phase)
       int hist[5][256][4] = {};
+      std::vector<unsigned> fl;
+      std::map<std::string, int> missing;   // unsatisfied input -> number of waiting tasks
       for(int w = 0; w < 496; ++w) {
         const unsigned v = wg[2 * w];
         if(v == 0u || (v >> 24) == 0xF1u || (v >> 24) == 0xF0u) continue;
@@ -2630,10 +2641,111 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
           continue;
         }
         const unsigned kind = v >> 28, ph = (v >> 24) & 15u, jj = (v >> 16) & 255u;
+        if(ph == 1u) {   // which of its inputs is this waiting task missing?  (the conditions of ldlt_wide_body.inc)
+          if(fl.empty()) {
+            fl.resize((size_t)P.nflags);
+            (void)hipMemcpy(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost);
+          }
+          auto verw = [&](int I, int J) { return fl[(size_t)(P.off_ver + (int64_t)I * P.nt + J)]; };
+          auto trw = [&](int jq, int B) { return fl[(size_t)(P.off_tr + (int64_t)jq * P.nt + B)]; };
+          auto grp = [&](int B) { const int rem = N - 128 * B; return (unsigned)(rem >= 128 ? 8 : (rem + 15) / 16); };
+          auto miss = [&](const char* what, int x, int y, unsigned is, unsigned needs) {
+            if(is < needs) {
+              char key[96];
+              std::snprintf(key, sizeof(key), "%s[%d][%d] is %u, needed >= %u", what, x, y, is, needs);
+              missing[key] += 1;
+            }
+          };
+          const int j = (int)jj;
+          if(kind == 1u) {
+            const int J = (int)(v & 0xffffu) / 128;
+            miss("ver", 2 * j, J, verw(2 * j, J), (unsigned)j);
+            miss("ver", 2 * j + 1, J, verw(2 * j + 1, J), (unsigned)j);
+          } else {
+            const int I = (int)(v & 0xffffu), J = (int)wg[2 * w + 1];
+            const bool fusedt = kind == 4u;
+            const int jb = fusedt ? j - 1 : j;
+            miss("ver", I, J, verw(I, J), (unsigned)jb);
+            if(fusedt) {
+              miss("tr", jb, I, trw(jb, I), grp(I));
+              miss("tr", jb, J, trw(jb, J), grp(J));
+              miss("tr", j, I, trw(j, I), grp(I));
+              miss("tr", j, J, trw(j, J), grp(J));
+            } else {
+              if(I < 2 * j + 4) miss("hdone", j, 0, fl[(size_t)(P.off_chain + (int64_t)j * DF_CH + DF_HDONE)], 16u);
+              else miss("tr", j, I, trw(j, I), grp(I));
+              miss("tr", j, J, trw(j, J), grp(J));
+            }
+          }
+        }
         if(kind == 1u)
           std::fprintf(stderr, "[hiop_amd]   workgroup %d holds substitution task of super-panel %u, columns from %u, list index %d (-1: early), phase %u (1 waits for its inputs, 2 running)\n", w, jj,
                        v & 0xffffu, (int)wg[2 * w + 1], ph);
         else if(kind < 5u && ph < 4u) hist[kind][jj][ph] += 1;
+      }
+      if(fl.empty()) {
+        fl.resize((size_t)P.nflags);
+        (void)hipMemcpy(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost);
+      }
+      {
+        int shown_m = 0;
+        for(const auto& kv : missing)
+          if(shown_m++ < 80) std::fprintf(stderr, "[hiop_amd]   %3d waiting tasks miss %s\n", kv.second, kv.first.c_str());
+      }
+      {   // the shadow copies against the real words
+        int nd = 0;
+        for(int jq = 0; jq < P.nsp; ++jq)
+          for(int B = 0; B < P.nt; ++B) {
+            const unsigned r = fl[(size_t)(P.off_tr + (int64_t)jq * P.nt + B)], sh = fl[(size_t)(P.off_shadow + (int64_t)jq * P.nt + B)];
+            if(r != sh && nd++ < 12) std::fprintf(stderr, "[hiop_amd]   substitution counter tr[%d][%d] = %u, its shadow copy = %u\n", jq, B, r, sh);
+          }
+        for(int I = 0; I < P.nt; ++I)
+          for(int B = 0; B < P.nt; ++B) {
+            const unsigned r = fl[(size_t)(P.off_ver + (int64_t)I * P.nt + B)], sh = fl[(size_t)(P.off_shadow + (int64_t)P.nsp * P.nt + (int64_t)I * P.nt + B)];
+            if(r != sh && nd++ < 24) std::fprintf(stderr, "[hiop_amd]   version word ver[%d][%d] = %u, its shadow copy = %u\n", I, B, r, sh);
+          }
+        std::fprintf(stderr, "[hiop_amd]   %d flag words differ from their shadow copies\n", nd);
+        // every task of the lists against the number of times a task with ITS (super-panel, tile) published
+        const int64_t ex_tr = P.off_shadow + (int64_t)P.nsp * P.nt + 2 * (int64_t)P.nt * P.nt, ex_up = ex_tr + (int64_t)P.nsp * 256;
+        int ndup = 0, nnever = 0;
+        for(size_t t = 0; t < P.wtasks.size(); ++t) {
+          const int4 q = P.wtasks[t];
+          const unsigned ex = q.x == DF_TR ? fl[(size_t)(ex_tr + (int64_t)q.y * 256 + q.z / DF_TRW)] : fl[(size_t)(ex_up + ((int64_t)q.y * P.nt + q.z) * P.nt + q.w)];
+          if(ex > 1u && ndup++ < 16) std::fprintf(stderr, "[hiop_amd]   task %zu (kind %d, super-panel %d, %d %d) published %u times\n", t, q.x, q.y, q.z, q.w, ex);
+          if(ex == 0u) ++nnever;
+        }
+        std::fprintf(stderr, "[hiop_amd]   %d tasks published more than once, %d not (yet) at all\n", ndup, nnever);
+        // for every missing input: which tasks write that word, and how often each of them has published
+        int shown_r = 0;
+        for(const auto& kv : missing) {
+          if(shown_r++ >= 12) break;
+          int x = 0, y = 0;
+          std::string line;
+          if(std::sscanf(kv.first.c_str(), "ver[%d][%d]", &x, &y) == 2) {
+            for(size_t t = 0; t < P.wtasks.size(); ++t) {
+              const int4 q = P.wtasks[t];
+              if(q.x != DF_TR && q.z == x && q.w == y) {
+                char buf[64];
+                std::snprintf(buf, sizeof(buf), " (kind %d, queue %d): %u", q.x, q.y, fl[(size_t)(ex_up + ((int64_t)q.y * P.nt + q.z) * P.nt + q.w)]);
+                line += buf;
+              }
+            }
+          } else if(std::sscanf(kv.first.c_str(), "tr[%d][%d]", &x, &y) == 2) {
+            for(int c = 128 * y; c < 128 * y + 128; c += DF_TRW) {
+              char buf[64];
+              std::snprintf(buf, sizeof(buf), " (columns %d): %u", c, fl[(size_t)(ex_tr + (int64_t)x * 256 + c / DF_TRW)]);
+              line += buf;
+            }
+          }
+          if(!line.empty()) std::fprintf(stderr, "[hiop_amd]   writers of %s and their publications:%s\n", kv.first.substr(0, kv.first.find(" is")).c_str(), line.c_str());
+        }
+      }
+      for(int jq = 0, shown_q = 0; jq < P.nwide && shown_q < 10; ++jq) {   // super-panels whose update is not complete although its tickets are out
+        const unsigned* cq = fl.data() + P.off_chain + (int64_t)jq * DF_CH;
+        if(cq[DF_UPQ] == 0u || cq[DF_UPDONE] >= P.upcnt[jq]) continue;
+        std::fprintf(stderr, "[hiop_amd]   super-panel %d: update tasks done %u of %u | tickets: substitution %u of %d, update %u of %d | chain cdone %u hdone %u\n", jq, cq[DF_UPDONE],
+                     P.upcnt[jq], cq[DF_TRQ], P.wq[jq].y, cq[DF_UPQ], P.wq[jq].w, cq[DF_CDONE], cq[DF_HDONE]);
+        ++shown_q;
       }
       for(int k = 2; k < 5; ++k)
         for(int jj = 0; jj < 256; ++jj)

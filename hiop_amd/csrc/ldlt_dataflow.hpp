@@ -82,6 +82,7 @@ struct DfArgs {
   int spine_opt;           // HIOPAMD_DF_SPINE bits (see df_spine_step)
   int64_t off_cu;          // 512 words: workgroups of the wide kernel that have reported from CU (xcc, se, cu) — a workgroup's rank on its CU
   int jretire;             // the second (third, ...) workgroup of a CU leaves the wide kernel when its queue pointers reach this super-panel
+  int64_t off_shadow;      // != 0 (HIOPAMD_DF_DEBUG): second copies of the substitution counters and version words, written right after the real ones
   long long timeout_ticks; // limit of every bounded wait, 100 MHz ticks (a multiple of the expected duration of the whole factorisation)
   int64_t off_run;         // != 0 (HIOPAMD_DF_CHECK=1, soak tests): one counter per task of the wide kernel — how often its ticket was handed out
   int64_t off_wg;          // 2 words per workgroup of the wide kernel: what it holds right now (see df_wg_state) — read by the host after a time-out
@@ -106,6 +107,19 @@ __device__ __forceinline__ void df_add(unsigned* p, unsigned v)
 #else
 __device__ __forceinline__ void df_add(unsigned* p, unsigned v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, HIOPAMD_DF_RMW_SCOPE); }
 #endif
+// Polling read of a flag word; -DHIOPAMD_DF_POLL_RMW=1 makes it a read-modify-write that adds 0 (queues with the writes to that line at the
+// memory side instead of overtaking them).  Tried against the late flag updates of DESIGN.md 3.1: same rate, so the plain load stays.
+#ifndef HIOPAMD_DF_POLL_RMW
+#define HIOPAMD_DF_POLL_RMW 0
+#endif
+__device__ __forceinline__ unsigned df_poll(const unsigned* p)
+{
+#if HIOPAMD_DF_POLL_RMW
+  return __hip_atomic_fetch_add(const_cast<unsigned*>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ unsigned df_ticket(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, HIOPAMD_DF_RMW_SCOPE); }
 // state word of a wide-kernel workgroup: kind (4 bits) | phase (4: 1 taken, 2 inputs there, 3 body done) | super-panel (8) | ticket-local index (16);
 // second word: the task's third / fourth field.  0 = between tasks.  Two fire-and-forget stores per phase by lane 0.
@@ -161,6 +175,23 @@ struct DfWait {
 // returns within a few polls.  (Round 2 measured the limit from the START of the kernel: a factorisation that legitimately
 // runs longer than the limit — an order beyond ~70 000, a throttled or shared device — aborted at its first slow wait although
 // it was making progress.)  The sleep between polls keeps ~500 pollers from saturating the flags' memory channel.
+// Back-off of the polling loops of the WIDE kernel: dozens of workgroups can wait for the same flag word (every update task of a tile row
+// waits for the row's substitution counter), each re-reading it every ~0.4 us.  Once in a few thousand factorisations a publication became
+// visible only after the waiters had given up; with the waiters backing off that happens several times less often.
+// A waiter polls 8 times at 0.4 us, 8 times at 1.7 us, 3.4, 6.8, then every 13.6 us (level 4).
+__device__ __forceinline__ void df_nap(unsigned level)
+{
+  if(level == 0u) __builtin_amdgcn_s_sleep(16);
+  else if(level == 1u) __builtin_amdgcn_s_sleep(64);
+  else {
+    __builtin_amdgcn_s_sleep(127);
+    if(level >= 3u) __builtin_amdgcn_s_sleep(127);
+    if(level >= 4u) {
+      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(127);
+    }
+  }
+}
 constexpr long long DF_TIMEOUT_TICKS = 300000000ll;   // 3 s: the upper end; the limit in force is DfArgs::timeout_ticks (set per order by the host)
 __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* sh_ok, long long t_start, int who, int a0, int a1,
                                         int a2, int a3)
@@ -176,8 +207,9 @@ __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* s
 #pragma unroll
     for(int q = 0; q < 4; ++q) {   // unrolled: the pairs stay in registers (a runtime index would put them in scratch)
       if(ok && !all_there) {
-        while(df_ld(w.f[q]) < w.v[q]) {
-          __builtin_amdgcn_s_sleep(16);
+        while(df_poll(w.f[q]) < w.v[q]) {
+          if(who >= 100) __builtin_amdgcn_s_sleep(16);   // the chain kernel's 16 roles: few pollers, latency matters
+          else df_nap(spins >> 3 < 4u ? spins >> 3 : 4u);   // 0.4 us x 8, 1.7 x 8, 3.4 x 8, 6.8 x 8, then 13.6 us
           if((++spins & 31u) == 0) {
             const long long now = (long long)wall_clock64();
             if(t_wait == 0) t_wait = now;
