@@ -392,9 +392,13 @@ int MdsSolver::setup()
   cu.resize(std::max(m, 1));
   if((dprob ? dprob->get_vars_info : prob->get_vars_info)(n, xl.data(), xu.data(), ud) != 0) return user_failed("get_vars_info");
   if((dprob ? dprob->get_cons_info : prob->get_cons_info)(m, cl.data(), cu.data(), ud) != 0) return user_failed("get_cons_info");
-  for(int i = 0; i < n; ++i) {
+  // Fixed variables (xlow == xupp).  MDS interface: the reference's fixed_var option is at its default "none" there and the solver
+  // terminates (hiopNlpFormulation.cpp:359-366) — so does this one.  Dense interface: hiop_dense_create_problem sets fixed_var = relax
+  // (chiopInterface.cpp:138), and with bound_relax_perturb > 0 (default 1e-8) it is the bounds relaxer that opens them
+  // (hiopNlpFormulation.cpp:342-347, 398-402) — the relaxation below, applied to every bound, does exactly that.
+  for(int i = 0; i < n && !dprob; ++i) {
     if(xl[i] == xu[i]) {
-      std::fprintf(stderr, "hiop_amd: fixed variable %d (xlow == xupp) — not supported by this interface\n", i);
+      std::fprintf(stderr, "hiop_amd: fixed variable %d (xlow == xupp) and fixed_var = none (the MDS interface's setting): Invalid_Problem_Definition\n", i);
       status = Invalid_Problem_Definition;
       return HIOPAMD_ERR_ARG;
     }

@@ -15,7 +15,8 @@
  * scalars (`obj`) and the one-time set-up calls (sizes, bounds, starting point, sparsity pattern) stay on the host.
  * The Jacobian / Hessian callbacks are called once for the pattern (index arrays non-NULL, value arrays NULL) and once per
  * iteration for the values (index arrays NULL), the convention of hiopInterface.hpp:635-643.
- * Not supported (the call fails with a message instead of computing something else): fixed variables (xlow == xupp), a nonzero
+ * Fixed variables (xlow == xupp): Invalid_Problem_Definition, as in the reference at this interface's fixed_var = none.
+ * Not supported (the call fails with a message instead of computing something else): a nonzero
  * sparse-dense Hessian block, NLP scaling (|grad f(x0)| or a Jacobian entry above scaling_max_grad = 100), feasibility restoration.
  */
 #ifndef HIOP_AMD_INTERFACE_H
@@ -79,7 +80,9 @@ int hiopamd_mds_get_solve_times(const cHiopMDSProblem* problem, double* total_se
  * memory-distributed dense path of this library on one rank) with the options hiop_dense_create_problem sets in the reference:
  * duals_update_type linear, duals_init zero; mu0 and everything else at the reference's defaults.  `MJac` is the m x n row-major
  * Jacobian.  hiopamd_dense_set_callback_mem_space(problem, 1): x, gradf, cons and MJac are DEVICE pointers.
- * Not supported (fails loudly): fixed variables (the reference sets fixed_var = relax), NLP scaling, feasibility restoration. */
+ * Fixed variables (xlow == xupp) are relaxed like every other bound (the reference sets fixed_var = relax here and, with
+ * bound_relax_perturb > 0, leaves them to the bounds relaxer: hiopNlpFormulation.cpp:342-347).
+ * Not supported (fails loudly): NLP scaling, feasibility restoration. */
 typedef struct cHiopDenseProblem {
   void* refcppHiop;    /* owned by the library */
   void* hiopinterface; /* owned by the library */

@@ -35,6 +35,7 @@ static int vars(hiop_size_type n, double* lo, double* up, void* u)
   lo[0] = -1e20;
   lo[1] = 0.0;
   lo[2] = 1.5, up[2] = 10.0;
+  if(getenv("DENSE_FIX_LAST")) lo[n - 1] = up[n - 1] = 1.0;   /* a FIXED variable (at its optimal value): the reference's dense C interface relaxes it */
   return 0;
 }
 static int cons_info(hiop_size_type m, double* lo, double* up, void* u)

@@ -8,6 +8,7 @@ GPU: the program solves MdsEx1(400, 100) with HOST callbacks and passes the refe
 -4.999509728895e+01 to 1e-6, NlpMdsEx1.c:376); the run equals the numpy run of the same loop (oracle/ipm_filter.py — itself pinned
 on the reference's KKT dumps): same iteration count, objective to 1e-9.  With DEVICE callbacks (the library's device-resident
 example problem) the same holds against the C++ example's data."""
+import os
 import re
 import subprocess
 from pathlib import Path
@@ -124,4 +125,29 @@ def test_dense_c_program_solves_dense_cons_ex2_with_the_quasi_newton_path(tmp_pa
     ops, full, bounds = quasi_newton_setup(q)
     o = ipm_filter.solve(ops, q["x0"], quasi_newton=True, lsq_duals=False)
     assert o["status"] == "Solve_Success"
+    assert abs(iters - o["iters"]) <= 1 and abs(obj - o["obj"]) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_dense_c_program_with_a_fixed_variable(tmp_path):
+    """xlow == xupp on one variable: the reference's dense C interface runs with fixed_var = relax (chiopInterface.cpp:138), i.e. the
+    bounds relaxer opens the variable by bound_relax_perturb * max(1, |x|) on both sides (hiopNlpFormulation.cpp:342-347, 398-402).  The
+    device run must equal the numpy run of the same loop with the same bounds."""
+    from oracle import ipm_filter
+    from oracle import problems as pr
+    from tests.test_oracle_reference_trajectory import quasi_newton_setup
+    n = 500
+    exe = _compile(tmp_path, DENSE_SRC)
+    r = subprocess.run([str(exe), str(n)], capture_output=True, text=True, timeout=600, env=dict(os.environ, DENSE_FIX_LAST="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    g = re.match(r"obj=(\S+) iters=(\d+) status=(-?\d+) maxdev=(\S+) rc=(-?\d+)", r.stdout.strip().splitlines()[-1])
+    assert g, r.stdout[-500:]
+    obj, iters, status, maxdev = float(g.group(1)), int(g.group(2)), int(g.group(3)), float(g.group(4))
+    q = pr.dense_ex2(n)
+    q["xl"] = q["xl"].copy(); q["xu"] = q["xu"].copy()
+    q["xl"][n - 1] = q["xu"][n - 1] = 1.0
+    ops, full, bounds = quasi_newton_setup(q)
+    o = ipm_filter.solve(ops, q["x0"], quasi_newton=True, lsq_duals=False)
+    assert o["status"] == "Solve_Success" and status == 0 and maxdev <= 1e-2
+    assert abs(float(o["x"][n - 1]) - 1.0) <= 2e-8
     assert abs(iters - o["iters"]) <= 1 and abs(obj - o["obj"]) <= 1e-9
