@@ -106,6 +106,12 @@ struct MdsSolver {
   std::vector<int> eq_map, ineq_map, iJ, jJ, iH, jH;
   // device: problem data
   DevBuf<double> d_xl, d_xu, d_dl, d_du, d_crhs, d_ixl, d_ixu, d_idl, d_idu;
+  // gradient-based NLP scaling (hiopNLPObjGradScaling, hiopNlpTransforms.cpp:423-499): objective factor, one factor per constraint row
+  // ([equalities; inequalities] in the solver's order), decided at the user's starting point (hiopNlpFormulation.cpp:671-714)
+  bool scaled = false;
+  double s_f = 1.0;
+  DevBuf<double> d_scal;   // neq + nineq
+  double scaling_min_grad = 1e-8;
   DevBuf<int> d_eq_map, d_ineq_map, d_jc_src, d_jd_src, d_Jcs_i, d_Jcs_j, d_Jds_i, d_Jds_j, d_Hss_i, d_Hss_j;
   std::vector<int> h_Jcs_i, h_Jcs_j, h_Jds_i, h_Jds_j;
   // device: values of the current iterate (what hiopamd_kkt_mds_set_values borrows)
@@ -178,6 +184,11 @@ struct MdsSolver {
     // c = cons[eq], d = cons[ineq]   (hiopNlpFormulation::eval_c_d, hiopNlpFormulation.cpp:1045-1075)
     RC(hiopamd_vec_copy_from_indexes(ctx, neq, c_dev, cons_dev, d_eq_map.p));
     RC(hiopamd_vec_copy_from_indexes(ctx, nineq, d_dev, cons_dev, d_ineq_map.p));
+    if(scaled) {   // apply_to_obj / apply_to_cons_eq / apply_to_cons_ineq (hiopNlpTransforms.hpp:389, 413-433)
+      *f *= s_f;
+      if(neq) RC(hiopamd_vec_component_mult(ctx, neq, c_dev, d_scal.p));
+      if(nineq) RC(hiopamd_vec_component_mult(ctx, nineq, d_dev, d_scal.p + neq));
+    }
     return HIOPAMD_OK;
   }
 
@@ -204,6 +215,10 @@ struct MdsSolver {
       }
       RC(hiopamd_mat_copy_rows_from_idx(ctx, neq, n, d_J.p, n, d_Jall.p, n, d_eq_map.p));
       RC(hiopamd_mat_copy_rows_from_idx(ctx, nineq, n, d_J.p + (size_t)neq * n, n, d_Jall.p, n, d_ineq_map.p));
+      if(scaled) {   // apply_to_grad_obj, apply_to_jacob_eq / _ineq (hiopNlpTransforms.hpp:399-403, 436-470)
+        RC(hiopamd_vec_scale(ctx, n, d_grad.p, s_f));
+        if(m) RC(hiopamd_mat_scale_rows(ctx, m, n, d_J.p, n, d_scal.p, 0));
+      }
       RC(hiopamd_kkt_xycyd_set_matrices(full, nullptr, d_J.p, d_J.p + (size_t)neq * n));
       return HIOPAMD_OK;
     }
@@ -213,9 +228,11 @@ struct MdsSolver {
       double* lam = d_lambda.p;
       const int *em = d_eq_map.p, *im = d_ineq_map.p;
       const int ne = neq;
+      const double* sc = scaled ? d_scal.p : nullptr;   // the user's Hessian is evaluated with the multipliers of the UNSCALED constraints
       RC(launch_ew(ctx, (int64_t)m, [=] __device__(int64_t i) {
-        if(i < ne) lam[em[i]] = yc[i];
-        else lam[im[i - ne]] = yd[i - ne];
+        const double w = sc ? sc[i] : 1.0;
+        if(i < ne) lam[em[i]] = w * yc[i];
+        else lam[im[i - ne]] = w * yd[i - ne];
       }));
     }
     if(dev_cb) {
@@ -223,7 +240,7 @@ struct MdsSolver {
       if(prob->eval_grad_f(n, x, 0, d_grad.p, prob->user_data) != 0) return user_failed("eval_grad_f");
       if(prob->eval_Jac_cons(n, m, x, 0, ns, nd, nnzJ, nullptr, nullptr, d_MJ.p, d_JacD.p, prob->user_data) != 0)
         return user_failed("eval_Jac_cons");
-      if(prob->eval_Hess_Lagr(n, m, x, 0, 1.0, d_lambda.p, 1, ns, nd, nnzH, nullptr, nullptr, d_MH.p, d_HDD.p, 0, nullptr, nullptr,
+      if(prob->eval_Hess_Lagr(n, m, x, 0, s_f, d_lambda.p, 1, ns, nd, nnzH, nullptr, nullptr, d_MH.p, d_HDD.p, 0, nullptr, nullptr,
                               nullptr, prob->user_data) != 0)
         return user_failed("eval_Hess_Lagr");
     } else {
@@ -233,7 +250,7 @@ struct MdsSolver {
       if(prob->eval_Jac_cons(n, m, x, 0, ns, nd, nnzJ, nullptr, nullptr, mj.data(), jd.data(), prob->user_data) != 0)
         return user_failed("eval_Jac_cons");
       RC(d2h(lam.data(), d_lambda.p, sizeof(double) * (size_t)m));
-      if(prob->eval_Hess_Lagr(n, m, x, 0, 1.0, lam.data(), 1, ns, nd, nnzH, nullptr, nullptr, mh.data(), hd.data(), 0, nullptr,
+      if(prob->eval_Hess_Lagr(n, m, x, 0, s_f, lam.data(), 1, ns, nd, nnzH, nullptr, nullptr, mh.data(), hd.data(), 0, nullptr,
                               nullptr, nullptr, prob->user_data) != 0)
         return user_failed("eval_Hess_Lagr");
       RC(h2d(d_grad.p, g.data(), sizeof(double) * (size_t)n));
@@ -249,6 +266,13 @@ struct MdsSolver {
     RC(hiopamd_vec_copy_from_indexes(ctx, nnzJineq, d_Jds_v.p, d_MJ.p, d_jd_src.p));
     RC(hiopamd_mat_copy_rows_from_idx(ctx, neq, nd, d_Jcd.p, nd, d_JacD.p, nd, d_eq_map.p));
     RC(hiopamd_mat_copy_rows_from_idx(ctx, nineq, nd, d_Jdd.p, nd, d_JacD.p, nd, d_ineq_map.p));
+    if(scaled) {   // gradient and the four Jacobian blocks, row by row (the Hessian came out scaled through obj_factor and lambda)
+      RC(hiopamd_vec_scale(ctx, n, d_grad.p, s_f));
+      if(nnzJeq) RC(hiopamd_sp_scale_rows(ctx, nnzJeq, d_Jcs_i.p, d_Jcs_v.p, d_scal.p, 0));
+      if(nnzJineq) RC(hiopamd_sp_scale_rows(ctx, nnzJineq, d_Jds_i.p, d_Jds_v.p, d_scal.p + neq, 0));
+      if(neq && nd) RC(hiopamd_mat_scale_rows(ctx, neq, nd, d_Jcd.p, nd, d_scal.p, 0));
+      if(nineq && nd) RC(hiopamd_mat_scale_rows(ctx, nineq, nd, d_Jdd.p, nd, d_scal.p + neq, 0));
+    }
     RC(hiopamd_kkt_mds_set_values(kkt, d_Jcs_v.p, d_Jds_v.p, d_MH.p, d_Jcd.p, d_Jdd.p, d_HDD.p, nullptr, nullptr));
     return HIOPAMD_OK;
   }
@@ -360,6 +384,62 @@ struct MdsSolver {
     return HIOPAMD_OK;
   }
 
+  // hiopNlpFormulation::apply_scaling (hiopNlpFormulation.cpp:671-714) + hiopNLPObjGradScaling's constructor
+  // (hiopNlpTransforms.cpp:423-499) on the derivatives of the first evaluation (unscaled, in d_grad and the Jacobian blocks)
+  int decide_scaling()
+  {
+    const double max_grad = o.scaling_max_grad;
+    double g = 0.0, mc = 0.0, md = 0.0, v = 0.0;
+    RC(hiopamd_vec_infnorm(ctx, n, d_grad.p, &g));
+    RC(d_scal.alloc((size_t)std::max(m, 1)));
+    DevBuf<double> tmp;
+    RC(tmp.alloc((size_t)std::max(m, 1)));
+    // row maxima of [Jc; Jd] into d_scal (hiopMatrix::row_max_abs_value)
+    if(dprob) {
+      if(m) RC(hiopamd_mat_row_max_abs(ctx, m, n, d_J.p, n, d_scal.p));
+    } else {
+      RC(hiopamd_vec_set_to_constant(ctx, m, d_scal.p, 0.0));
+      RC(hiopamd_vec_set_to_constant(ctx, m, tmp.p, 0.0));
+      if(nnzJeq) RC(hiopamd_sp_row_max_abs(ctx, neq, nnzJeq, d_Jcs_i.p, d_Jcs_v.p, d_scal.p));
+      if(nnzJineq) RC(hiopamd_sp_row_max_abs(ctx, nineq, nnzJineq, d_Jds_i.p, d_Jds_v.p, d_scal.p + neq));
+      if(neq && nd) RC(hiopamd_mat_row_max_abs(ctx, neq, nd, d_Jcd.p, nd, tmp.p));
+      if(nineq && nd) RC(hiopamd_mat_row_max_abs(ctx, nineq, nd, d_Jdd.p, nd, tmp.p + neq));
+      if(m) RC(hiopamd_vec_component_max_v(ctx, m, d_scal.p, tmp.p));
+    }
+    if(neq) RC(hiopamd_vec_infnorm(ctx, neq, d_scal.p, &mc));
+    if(nineq) RC(hiopamd_vec_infnorm(ctx, nineq, d_scal.p + neq, &md));
+    if(g < max_grad && mc < max_grad && md < max_grad) {   // :691-696: nothing to scale
+      scaled = false;
+      s_f = 1.0;
+      return HIOPAMD_OK;
+    }
+    s_f = g > max_grad ? max_grad / g : 1.0;
+    if(scaling_min_grad > 0.0 && s_f < scaling_min_grad) s_f = scaling_min_grad;
+    // per block: 1 / max(1, rowmax / max_grad) if ANY row of the block exceeds max_grad, else 1   (:473-490)
+    auto block = [&](double* p, int cnt, double blockmax) -> int {
+      if(cnt == 0) return HIOPAMD_OK;
+      if(blockmax > max_grad) {
+        RC(hiopamd_vec_scale(ctx, cnt, p, 1.0 / max_grad));
+        RC(hiopamd_vec_component_max_c(ctx, cnt, p, 1.0));
+        RC(hiopamd_vec_invert(ctx, cnt, p));
+      } else {
+        RC(hiopamd_vec_set_to_constant(ctx, cnt, p, 1.0));
+      }
+      if(scaling_min_grad > 0.0) RC(hiopamd_vec_component_max_c(ctx, cnt, p, scaling_min_grad));
+      return HIOPAMD_OK;
+    };
+    RC(block(d_scal.p, neq, mc));
+    RC(block(d_scal.p + neq, nineq, md));
+    (void)v;
+    // the constraint right-hand sides and bounds live in the scaled space from here on (:707-709)
+    if(neq) RC(hiopamd_vec_component_mult(ctx, neq, d_crhs.p, d_scal.p));
+    if(nineq) RC(hiopamd_vec_component_mult(ctx, nineq, d_dl.p, d_scal.p + neq));
+    if(nineq) RC(hiopamd_vec_component_mult(ctx, nineq, d_du.p, d_scal.p + neq));
+    scaled = true;
+    if(o.verbosity_level >= 3)
+      std::printf("hiop_amd: gradient-based scaling on (max |grad f| = %.3e, max |Jac_c| = %.3e, max |Jac_d| = %.3e): objective factor %.6e\n", g, mc, md, s_f);
+    return HIOPAMD_OK;
+  }
   int setup();
   int run();
 };
@@ -609,34 +689,17 @@ int MdsSolver::run()
   double f = 0.0, f_trial = 0.0;
   // ---- startingProcedure (:290-425) with duals_init = zero, no warm start
   int okp = 1;
-  RC(eval_func(it.p, &f, d_cons.p, d_c.p, d_d.p));   // :343 (and the scaling decision, :349)
-  RC(hiopamd_vec_project_into_bounds(ctx, n, part(it, 0), d_xl.p, d_ixl.p, d_xu.p, d_ixu.p, o.kappa1, o.kappa2, &okp));   // :355
+  RC(eval_func(it.p, &f, d_cons.p, d_c.p, d_d.p));   // :345 evalNlp_noHess at the user's starting point
+  RC(eval_deriv(it.p, part(it, 2), part(it, 3)));    //      (yc = yd = 0)
+  RC(decide_scaling());                              // :351 apply_scaling
+  RC(hiopamd_vec_project_into_bounds(ctx, n, part(it, 0), d_xl.p, d_ixl.p, d_xu.p, d_ixu.p, o.kappa1, o.kappa2, &okp));   // :357
   if(!okp) {
     std::fprintf(stderr, "hiop_amd: inconsistent variable bounds (projectIntoBounds failed)\n");
     status = Invalid_Problem_Definition;
     return HIOPAMD_ERR_ARG;
   }
-  RC(eval_func(it.p, &f, d_cons.p, d_c.p, d_d.p));                                       // :362
-  RC(eval_deriv(it.p, part(it, 2), part(it, 3)));                                        // (yc = yd = 0)
-  {
-    // apply_scaling's decision (hiopNlpFormulation.cpp:671-696): scale only when a gradient entry reaches scaling_max_grad
-    double g = 0.0, a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-    RC(hiopamd_vec_infnorm(ctx, n, d_grad.p, &g));
-    if(dprob) {
-      if((size_t)m * n) RC(hiopamd_vec_infnorm(ctx, (int64_t)m * n, d_J.p, &a));
-    } else {
-      if(nnzJeq) RC(hiopamd_vec_infnorm(ctx, nnzJeq, d_Jcs_v.p, &a));
-      if(nnzJineq) RC(hiopamd_vec_infnorm(ctx, nnzJineq, d_Jds_v.p, &b));
-      if((size_t)neq * nd) RC(hiopamd_vec_infnorm(ctx, (int64_t)neq * nd, d_Jcd.p, &c));
-      if((size_t)nineq * nd) RC(hiopamd_vec_infnorm(ctx, (int64_t)nineq * nd, d_Jdd.p, &d));
-    }
-    if(!(g < o.scaling_max_grad && std::fmax(a, c) < o.scaling_max_grad && std::fmax(b, d) < o.scaling_max_grad)) {
-      std::fprintf(stderr, "hiop_amd: the problem needs gradient-based scaling (max |grad f| = %g, max |J| = %g >= %g), which this "
-                           "interface does not implement\n", g, std::fmax(std::fmax(a, b), std::fmax(c, d)), o.scaling_max_grad);
-      status = Invalid_Problem_Definition;
-      return HIOPAMD_ERR_ARG;
-    }
-  }
+  RC(eval_func(it.p, &f, d_cons.p, d_c.p, d_d.p));                                       // :364 again, after the projection / with the scaling
+  RC(eval_deriv(it.p, part(it, 2), part(it, 3)));
   RC(hiopamd_vec_copy(ctx, nineq, part(it, 1), d_d.p));                                  // :374
   RC(hiopamd_vec_project_into_bounds(ctx, nineq, part(it, 1), d_dl.p, d_idl.p, d_du.p, d_idu.p, o.kappa1, o.kappa2, &okp));   // :378
   if(!okp) {
@@ -677,7 +740,7 @@ int MdsSolver::run()
         hiopamd_io_iteration_header(line, sizeof(line));
         std::fputs(line, stdout);
       }
-      hiopamd_io_format_iteration(line, sizeof(line), dprob ? 1 : 0, iter_num, f, e.feas, e.optim, mu, ad, ap, ls_status, ls_num, use_soc, 0);
+      hiopamd_io_format_iteration(line, sizeof(line), dprob ? 1 : 0, iter_num, f / s_f, e.feas, e.optim, mu, ad, ap, ls_status, ls_num, use_soc, 0);
       std::fputs(line, stdout);
     }
     if(e0.optim < 0) e0 = e;
@@ -853,11 +916,11 @@ int MdsSolver::run()
   iters = iter_num;
   double* sol = dprob ? dprob->solution : prob->solution;
   if(dprob) {
-    dprob->obj_value = f;
+    dprob->obj_value = f / s_f;   // apply_inv_to_obj (hiopNlpTransforms.hpp:387)
     dprob->niters = iter_num;
     dprob->status = status;
   } else {
-    prob->obj_value = f;
+    prob->obj_value = f / s_f;
   }
   if(sol) RC(d2h(sol, part(it, 0), sizeof(double) * (size_t)n));
   return HIOPAMD_OK;

@@ -16,8 +16,12 @@
  * The Jacobian / Hessian callbacks are called once for the pattern (index arrays non-NULL, value arrays NULL) and once per
  * iteration for the values (index arrays NULL), the convention of hiopInterface.hpp:635-643.
  * Fixed variables (xlow == xupp): Invalid_Problem_Definition, as in the reference at this interface's fixed_var = none.
+ * NLP scaling: the reference's default scaling_type = gradient (hiopNlpFormulation.cpp:671-714, hiopNlpTransforms.cpp:423-499) — when
+ * |grad f(x0)| or a Jacobian entry reaches scaling_max_grad = 100 the objective and the offending constraint rows are scaled (the user's
+ * eval_Hess_Lagr is then called with obj_factor = the objective's factor and the multipliers of the unscaled constraints); obj_value is
+ * handed back unscaled.
  * Not supported (the call fails with a message instead of computing something else): a nonzero
- * sparse-dense Hessian block, NLP scaling (|grad f(x0)| or a Jacobian entry above scaling_max_grad = 100), feasibility restoration.
+ * sparse-dense Hessian block, feasibility restoration.
  */
 #ifndef HIOP_AMD_INTERFACE_H
 #define HIOP_AMD_INTERFACE_H
@@ -82,7 +86,7 @@ int hiopamd_mds_get_solve_times(const cHiopMDSProblem* problem, double* total_se
  * Jacobian.  hiopamd_dense_set_callback_mem_space(problem, 1): x, gradf, cons and MJac are DEVICE pointers.
  * Fixed variables (xlow == xupp) are relaxed like every other bound (the reference sets fixed_var = relax here and, with
  * bound_relax_perturb > 0, leaves them to the bounds relaxer: hiopNlpFormulation.cpp:342-347).
- * Not supported (fails loudly): NLP scaling, feasibility restoration. */
+ * Gradient-based NLP scaling as in the MDS interface.  Not supported (fails loudly): feasibility restoration. */
 typedef struct cHiopDenseProblem {
   void* refcppHiop;    /* owned by the library */
   void* hiopinterface; /* owned by the library */

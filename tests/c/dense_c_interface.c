@@ -28,6 +28,9 @@ static int start(hiop_size_type n, double* x0, void* u)
   for(int i = 0; i < n; ++i) x0[i] = 0.0;
   return 0;
 }
+/* a badly scaled variant of the same problem (DENSE_KOBJ, DENSE_KROW in the environment): objective x KOBJ, constraint row 2 — body and
+ * bounds — x KROW.  Same minimiser; the library has to scale it back (gradient-based scaling, the reference's default). */
+static double KOBJ = 1.0, KROW = 1.0;
 static int vars(hiop_size_type n, double* lo, double* up, void* u)
 {
   (void)u;
@@ -44,7 +47,7 @@ static int cons_info(hiop_size_type m, double* lo, double* up, void* u)
   (void)m;
   lo[0] = up[0] = n + 1.0;
   lo[1] = 5.0, up[1] = 1e20;
-  lo[2] = 1.0, up[2] = 2.0 * n;
+  lo[2] = KROW * 1.0, up[2] = KROW * 2.0 * n;
   lo[3] = -1e20, up[3] = 4.0 * n;
   return 0;
 }
@@ -63,7 +66,7 @@ static int f_cb(hiop_size_type n, double* x, int new_x, double* obj, void* u)
     const double t = x[i] - 1.0;
     s += t * t * t * t;
   }
-  *obj = 0.25 * s;
+  *obj = KOBJ * 0.25 * s;
   return 0;
 }
 static int g_cb(hiop_size_type n, double* x, int new_x, double* g, void* u)
@@ -71,7 +74,7 @@ static int g_cb(hiop_size_type n, double* x, int new_x, double* g, void* u)
   (void)new_x, (void)u;
   for(int i = 0; i < n; ++i) {
     const double t = x[i] - 1.0;
-    g[i] = t * t * t;
+    g[i] = KOBJ * t * t * t;
   }
   return 0;
 }
@@ -81,7 +84,7 @@ static int c_cb(hiop_size_type n, hiop_size_type m, double* x, int new_x, double
   for(int r = 0; r < m; ++r) {
     double s = 0.0;
     for(int j = 0; j < n; ++j) s += coef(r, j) * x[j];
-    c[r] = s;
+    c[r] = (r == 2 ? KROW : 1.0) * s;
   }
   return 0;
 }
@@ -89,7 +92,7 @@ static int jac_cb(hiop_size_type n, hiop_size_type m, double* x, int new_x, doub
 {
   (void)x, (void)new_x, (void)u;
   for(int r = 0; r < m; ++r)
-    for(int j = 0; j < n; ++j) J[(size_t)r * n + j] = coef(r, j);
+    for(int j = 0; j < n; ++j) J[(size_t)r * n + j] = (r == 2 ? KROW : 1.0) * coef(r, j);
   return 0;
 }
 
@@ -97,6 +100,8 @@ int main(int argc, char** argv)
 {
   prob_t P;
   P.n = argc > 1 ? atoi(argv[1]) : 500;
+  if(getenv("DENSE_KOBJ")) KOBJ = atof(getenv("DENSE_KOBJ"));
+  if(getenv("DENSE_KROW")) KROW = atof(getenv("DENSE_KROW"));
   cHiopDenseProblem prob;
   memset(&prob, 0, sizeof(prob));
   prob.user_data = &P;

@@ -74,11 +74,14 @@ static int vars(hiop_size_type n, double* lo, double* up, void* u)
   up[2 * ns] = 4.0;
   return 0;
 }
+/* a badly scaled variant (host callbacks only; MDS_KOBJ / MDS_KROW in the environment): objective x KOBJ, the first inequality
+ * (row ns: x_0 + sum(s) + sum(y) in [-2, 2]) x KROW, body and bounds.  Same minimiser. */
+static double KOBJ = 1.0, KROW = 1.0;
 static int cons_info(hiop_size_type m, double* lo, double* up, void* u)
 {
   (void)u;
   for(int i = 0; i < m; ++i) lo[i] = up[i] = 0.0;
-  lo[m - 3] = -2.0, up[m - 3] = 2.0;
+  lo[m - 3] = -2.0 * KROW, up[m - 3] = 2.0 * KROW;
   lo[m - 2] = -1e20, up[m - 2] = 2.0;
   lo[m - 1] = -2.0, up[m - 1] = 1e20;
   return 0;
@@ -97,7 +100,7 @@ static int f_host(hiop_size_type n, double* x, int new_x, double* obj, void* u)
     b += qy * y[i];
   }
   for(int i = 0; i < ns; ++i) c += s[i] * s[i];
-  *obj = 0.5 * a + 0.5 * b + 0.5 * c;
+  *obj = KOBJ * (0.5 * a + 0.5 * b + 0.5 * c);
   return 0;
 }
 static int g_host(hiop_size_type n, double* x, int new_x, double* g, void* u)
@@ -105,12 +108,12 @@ static int g_host(hiop_size_type n, double* x, int new_x, double* g, void* u)
   prob_t* p = (prob_t*)u;
   (void)n, (void)new_x;
   const int ns = p->ns, nd = p->nd;
-  for(int i = 0; i < ns; ++i) g[i] = x[i] - 0.5;
-  for(int i = 0; i < ns; ++i) g[ns + i] = x[ns + i];
+  for(int i = 0; i < ns; ++i) g[i] = KOBJ * (x[i] - 0.5);
+  for(int i = 0; i < ns; ++i) g[ns + i] = KOBJ * x[ns + i];
   for(int i = 0; i < nd; ++i) {
     double qy = 0.0;
     for(int j = 0; j < nd; ++j) qy += p->Q[i * nd + j] * x[2 * ns + j];
-    g[2 * ns + i] = qy;
+    g[2 * ns + i] = KOBJ * qy;
   }
   return 0;
 }
@@ -123,7 +126,7 @@ static int c_host(hiop_size_type n, hiop_size_type m, double* x, int new_x, doub
   for(int j = 0; j < nd; ++j) ey += x[2 * ns + j];
   for(int i = 0; i < ns; ++i) es += x[ns + i];
   for(int i = 0; i < ns; ++i) c[i] = x[i] + x[ns + i] - ey;
-  c[ns] = x[0] + es + ey;
+  c[ns] = KROW * (x[0] + es + ey);
   c[ns + 1] = x[1] + ey;
   c[ns + 2] = x[2] + ey;
   return 0;
@@ -144,11 +147,11 @@ static int jac_host(hiop_size_type n, hiop_size_type m, double* x, int new_x, hi
     ++t;
   }
   if(iJ) iJ[t] = ns, jJ[t] = 0; /* x_0 + sum(s) */
-  if(MJ) MJ[t] = 1.0;
+  if(MJ) MJ[t] = KROW;
   ++t;
   for(int i = 0; i < ns; ++i, ++t) {
     if(iJ) iJ[t] = ns, jJ[t] = ns + i;
-    if(MJ) MJ[t] = 1.0;
+    if(MJ) MJ[t] = KROW;
   }
   if(iJ) iJ[t] = ns + 1, jJ[t] = 1;
   if(MJ) MJ[t] = 1.0;
@@ -158,7 +161,7 @@ static int jac_host(hiop_size_type n, hiop_size_type m, double* x, int new_x, hi
   ++t;
   if(JD) {
     for(int i = 0; i < m; ++i)
-      for(int j = 0; j < nde; ++j) JD[(size_t)i * nde + j] = i < ns ? -1.0 : 1.0;
+      for(int j = 0; j < nde; ++j) JD[(size_t)i * nde + j] = i < ns ? -1.0 : (i == ns ? KROW : 1.0);
   }
   return 0;
 }
@@ -170,10 +173,10 @@ static int hess_host(hiop_size_type n, hiop_size_type m, double* x, int new_x, d
   (void)n, (void)m, (void)x, (void)new_x, (void)lambda, (void)new_lambda, (void)nsp, (void)nnzHSD, (void)iSD, (void)jSD, (void)MSD;
   for(int t = 0; t < nnzHSS; ++t) {
     if(iH) iH[t] = jH[t] = t;
-    if(MH) MH[t] = obj_factor;
+    if(MH) MH[t] = obj_factor * KOBJ;
   }
   if(HDD)
-    for(int i = 0; i < nde * nde; ++i) HDD[i] = obj_factor * p->Q[i];
+    for(int i = 0; i < nde * nde; ++i) HDD[i] = obj_factor * KOBJ * p->Q[i];
   return 0;
 }
 
@@ -226,6 +229,8 @@ int main(int argc, char** argv)
   P.nd = argc > 3 ? atoi(argv[3]) : 100;
   const double tol = argc > 4 ? atof(argv[4]) : 0.0;
   const int n = 2 * P.ns + P.nd;
+  if(getenv("MDS_KOBJ")) KOBJ = atof(getenv("MDS_KOBJ"));
+  if(getenv("MDS_KROW")) KROW = atof(getenv("MDS_KROW"));
   P.Q = (double*)malloc(sizeof(double) * (size_t)P.nd * P.nd);
   for(int i = 0; i < P.nd; ++i)
     for(int j = 0; j < P.nd; ++j) P.Q[i * P.nd + j] = Qentry(P.nd, i, j);

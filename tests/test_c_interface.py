@@ -151,3 +151,157 @@ def test_dense_c_program_with_a_fixed_variable(tmp_path):
     assert o["status"] == "Solve_Success" and status == 0 and maxdev <= 1e-2
     assert abs(float(o["x"][n - 1]) - 1.0) <= 2e-8
     assert abs(iters - o["iters"]) <= 1 and abs(obj - o["obj"]) <= 1e-9
+
+
+def _dense_user_problem(n, kobj, krow):
+    """DenseConsEx2 as the C driver presents it with DENSE_KOBJ / DENSE_KROW: objective x kobj, constraint row 2 (the second inequality)
+    x krow, body and bounds."""
+    from oracle import problems as pr
+    q = pr.dense_ex2(n)
+    u = dict(q)
+    f0, g0 = q["f"], q["grad"]
+    u["f"] = lambda x: kobj * f0(x)
+    u["grad"] = lambda x: kobj * g0(x)
+    u["Jd"] = q["Jd"].copy(); u["Jd"][1] *= krow
+    u["dl"] = q["dl"].copy(); u["dl"][1] *= krow
+    u["du"] = q["du"].copy(); u["du"][1] *= krow
+    return u
+
+
+def _oracle_run_with_reference_scaling(u):
+    """The reference's order of operations: bounds relaxed in the user's space (hiopNlpFormulation.cpp:398-402), scaling decided at the
+    user's starting point and applied to the functions AND to the (relaxed) constraint bounds (:671-714), the loop on the scaled problem,
+    the objective handed back unscaled."""
+    from oracle import hiop_oracle as ho
+    from oracle import ipm_filter
+    from oracle import kkt_full as kf
+    from oracle.nlp_scaling import gradient_scaling
+    n = u["n"]
+    s = gradient_scaling(u["grad"](u["x0"]), u["Jc"], u["Jd"])
+    assert s is not None
+    s_f, s_c, s_d = s
+    xl, xu, dl, du = ipm_filter.relax_bounds(u["xl"], u["xu"], u["dl"], u["du"], ipm_filter.DEFAULTS["bound_relax_perturb"])
+    Jc, Jd = s_c[:, None] * u["Jc"], s_d[:, None] * u["Jd"]
+    bounds = (xl, xu, s_d * dl, s_d * du, s_c * u["crhs"])
+    f64 = lambda b: b.astype(np.float64)
+    ixl, ixu, idl, idu = f64(u["xl"] > -1e20), f64(u["xu"] < 1e20), f64(u["dl"] > -1e20), f64(u["du"] < 1e20)
+    H = ho.HessianLowRank(n, l_max=6, sigma0=1.0, sigma_update_strategy="sty")
+    K = ho.KKTLinSysLowRank(H, Jc.shape[0], Jd.shape[0])
+    full = kf.KKTLinSysFull(kf.LowRankProvider(K, Jc, Jd), ixl, ixu, idl, idu, perturb=kf.PDPerturbationNull())
+    model = lambda x: (s_f * u["f"](x), s_f * u["grad"](x), Jc @ x, Jd @ x)
+
+    class Ops(ipm_filter.FilterOracleOps):
+        def hess_update(self, it, ev):
+            H.update(it["x"], ev[1], Jc, Jd, it["yc"], it["yd"])
+    table = []
+    o = ipm_filter.solve(Ops(full, bounds, model), u["x0"], quasi_newton=True, lsq_duals=False, table=table)
+    o["obj_user"] = o["obj"] / s_f
+    o["table_obj_user"] = [row["objective"] / s_f for row in table]
+    return o, s
+
+
+def test_oracle_scaling_of_a_badly_scaled_dense_problem():
+    """The restated apply_scaling on the badly scaled variant: objective factor 100 / max|grad f(x0)|, only the offending row scaled, and
+    the scaled run ends at the same minimiser (objective = kobj / 64)."""
+    u = _dense_user_problem(200, 1.0e4, 1.0e3)
+    o, (s_f, s_c, s_d) = _oracle_run_with_reference_scaling(u)
+    g0 = np.abs(u["grad"](u["x0"])).max()
+    assert s_f == pytest.approx(100.0 / g0) and np.all(s_c == 1.0)
+    assert s_d[1] == pytest.approx(100.0 / np.abs(u["Jd"][1]).max()) and s_d[0] == 1.0 and s_d[2] == 1.0
+    assert o["status"] == "Solve_Success" and abs(o["obj_user"] - 1.0e4 / 64) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_dense_c_program_on_a_badly_scaled_problem(tmp_path):
+    """Gradient-based NLP scaling (the reference's default scaling_type = gradient; hiopNlpFormulation.cpp:671-714,
+    hiopNlpTransforms.cpp:423-499) behind hiop_dense_solve_problem: objective x 1e4 and one constraint row x 1e3 in the user's
+    callbacks.  The device run must equal the numpy run of the restated scaling + loop: iterations (+-1), reported (unscaled) objective."""
+    n = 500
+    exe = _compile(tmp_path, DENSE_SRC)
+    r = subprocess.run([str(exe), str(n)], capture_output=True, text=True, timeout=600, env=dict(os.environ, DENSE_KOBJ="1e4", DENSE_KROW="1e3"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "gradient-based scaling on" in r.stdout
+    g = re.match(r"obj=(\S+) iters=(\d+) status=(-?\d+) maxdev=(\S+) rc=(-?\d+)", r.stdout.strip().splitlines()[-1])
+    assert g, r.stdout[-500:]
+    obj, iters, status, maxdev = float(g.group(1)), int(g.group(2)), int(g.group(3)), float(g.group(4))
+    o, _ = _oracle_run_with_reference_scaling(_dense_user_problem(n, 1.0e4, 1.0e3))
+    # The row scaled by 1e3 puts the constraint residuals' rounding floor at ~1e-10, and the secant recursion amplifies rounding: late in
+    # the run the two implementations part (one may stop at the acceptable level, 10 iterations below 1e-6, where the other goes on to
+    # 1e-8).  Required: the same trajectory while it is well above that floor, the same optimum.
+    assert o["status"] in ("Solve_Success", "Solve_Acceptable_Level") and status in (0, 2) and maxdev <= 1e-2
+    assert abs(obj - o["obj_user"]) <= 1e-9 * abs(o["obj_user"])
+    dev_obj = [float(l.split()[1]) for l in r.stdout.splitlines() if re.match(r"^\s*\d+\s+-?\d\.\d{7}e", l)]
+    assert len(dev_obj) == iters + 1
+    for i in range(20):
+        assert abs(dev_obj[i] - o["table_obj_user"][i]) <= 2e-7 * abs(o["table_obj_user"][i]), i   # (the table prints 8 digits)
+
+
+def _mds_oracle_run_with_reference_scaling(ns, nd, kobj, krow):
+    """MdsEx1 as the C driver presents it with MDS_KOBJ / MDS_KROW (objective x kobj; the first inequality x krow), then the
+    reference's scaling (decided at x0 = 1, hiopNlpFormulation.cpp:671-714) applied to the problem data — the constraints are linear and
+    the Hessian comes from the objective alone, so scaling the data IS evaluating the scaled functions —, bounds relaxed BEFORE they are
+    scaled, the Newton loop at the C interface's options, the objective handed back unscaled."""
+    import copy
+    from oracle import hiop_oracle as ho
+    from oracle import ipm_filter, ipm_full
+    from oracle import kkt_full as kf
+    from oracle import problems as pr
+    from oracle.nlp_scaling import gradient_scaling
+    p = pr.mds_ex1(ns, nd)
+    Q = p.Hdd.copy()
+    for i in range(1, nd - 1):          # the C driver's Q (see _oracle_run)
+        Q[i, i + 1] = Q[i + 1, i] = 1.0 + 1e-8
+    p.Hdd = Q
+    n = p.nxs + p.nxd
+    q = np.zeros(n); q[:p.nxs // 2] = -0.5
+    # the user's badly scaled problem
+    u = copy.copy(p)
+    u.Hss_v, u.Hdd, u.q_lin = kobj * p.Hss_v, kobj * p.Hdd, kobj * q
+    u.Jds_v = np.where(p.Jds_i == 0, krow, 1.0) * p.Jds_v
+    u.Jdd = p.Jdd.copy(); u.Jdd[0] *= krow
+    u.dl = p.dl.copy(); u.du = p.du.copy(); u.dl[0] *= krow; u.du[0] *= krow
+    x0 = np.ones(n)
+    model_u, _ = ipm_full.mds_model(u)
+    dense = lambda I, J, V, D, m: np.concatenate([np.asarray(__import__("scipy.sparse").sparse.csr_matrix((V, (I, J)), shape=(m, u.nxs)).todense()), D], axis=1)
+    s = gradient_scaling(model_u(x0)[1], dense(u.Jcs_i, u.Jcs_j, u.Jcs_v, u.Jcd, u.neq), dense(u.Jds_i, u.Jds_j, u.Jds_v, u.Jdd, u.nineq))
+    assert s is not None
+    s_f, s_c, s_d = s
+    w = copy.copy(u)
+    w.Hss_v, w.Hdd, w.q_lin = s_f * u.Hss_v, s_f * u.Hdd, s_f * u.q_lin
+    w.Jcs_v, w.Jcd = s_c[u.Jcs_i] * u.Jcs_v, s_c[:, None] * u.Jcd
+    w.Jds_v, w.Jdd = s_d[u.Jds_i] * u.Jds_v, s_d[:, None] * u.Jdd
+    k = ho.KKTLinSysCompressedMDSXYcYd(w.nxs, w.nxd, w.neq, w.nineq, (w.Jcs_i, w.Jcs_j), (w.Jds_i, w.Jds_j), (w.Hss_i, w.Hss_j))
+    k.set_values(w.Jcs_v, w.Jds_v, w.Hss_v, w.Jcd, w.Jdd, w.Hdd, None, None)
+    f64 = lambda b: b.astype(np.float64)
+    full = kf.KKTLinSysFull(kf.MdsProvider(k), f64(u.xl > -1e20), f64(u.xu < 1e20), f64(u.dl > -1e20), f64(u.du < 1e20))
+    xl, xu, dl, du = ipm_filter.relax_bounds(u.xl, u.xu, u.dl, u.du, ipm_filter.DEFAULTS["bound_relax_perturb"])
+    bounds = (xl, xu, s_d * dl, s_d * du, np.zeros(u.neq))
+    model, _ = ipm_full.mds_model(w)
+    o = ipm_filter.solve(ipm_filter.FilterOracleOps(full, bounds, model), x0, mu0=0.1, tolerance=1e-8)
+    o["obj_user"] = o["obj"] / s_f
+    return o, s
+
+
+def test_oracle_scaling_of_a_badly_scaled_mds_problem():
+    o, (s_f, s_c, s_d) = _mds_oracle_run_with_reference_scaling(40, 12, 1.0e4, 1.0e3)
+    assert s_f < 1.0 and np.all(s_c == 1.0) and s_d[0] == pytest.approx(0.1) and np.all(s_d[1:] == 1.0)
+    r = _oracle_run(40, 12, True)
+    assert o["status"] == "Solve_Success" and abs(o["obj_user"] - 1.0e4 * r["obj"]) <= 1e-5 * abs(1.0e4 * r["obj"])
+
+
+@pytest.mark.gpu
+def test_mds_c_program_on_a_badly_scaled_problem(tmp_path):
+    """Gradient-based NLP scaling behind hiop_mds_solve_problem (host callbacks): objective x 1e4 (the user's Hessian gets obj_factor =
+    the objective's scale factor), the first inequality x 1e3 (sparse and dense Jacobian entries, bounds).  Equal to the numpy run of the
+    restated scaling + Newton loop: iterations, the reported (unscaled) objective to 1e-9 relative."""
+    exe = _compile(tmp_path)
+    r = subprocess.run([str(exe), "host"], capture_output=True, text=True, timeout=600, env=dict(os.environ, MDS_KOBJ="1e4", MDS_KROW="1e3"))
+    last = [l for l in r.stdout.strip().splitlines() if l.startswith("obj=")][-1]
+    g = re.match(r"obj=(\S+) iters=(\d+) status=(-?\d+) nfact=(\d+) xsum=(\S+) rc=(-?\d+)", last)
+    assert g, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "gradient-based scaling on" in r.stdout
+    obj, iters, status = float(g.group(1)), int(g.group(2)), int(g.group(3))
+    o, _ = _mds_oracle_run_with_reference_scaling(400, 100, 1.0e4, 1.0e3)
+    assert status == 0 and o["status"] == "Solve_Success"
+    assert iters == o["iters"] and abs(obj - o["obj_user"]) <= 1e-9 * abs(o["obj_user"])
+    assert abs(float(g.group(5)) - float(o["x"].sum())) <= 1e-6 * max(1.0, abs(o["x"].sum()))
