@@ -709,10 +709,9 @@ int MdsSolver::run()
   int nadj = 0;
   RC(hiopamd_iterate_determine_slacks(full, it.p));                                      // :380 compute_safe_slacks
   RC(hiopamd_iterate_adjust_small_slacks(full, it.p, it.p, mu, &nadj));
-  if(nadj > 0) {
-    std::fprintf(stderr, "hiop_amd: %d slacks are too small at the starting point (adjust_bounds is not implemented)\n", nadj);
-    status = Invalid_Problem_Definition;
-    return HIOPAMD_ERR_ARG;
+  if(nadj > 0) {   // :383-386
+    if(o.verbosity_level >= 2) std::printf("%d slacks are too small. Adjust corresponding variable slacks!\n", nadj);
+    RC(hiopamd_iterate_adjust_bounds(full, it.p, d_xl.p, d_xu.p, d_dl.p, d_du.p));
   }
   RC(hiopamd_vec_copy(ctx, n, part(it, 8), d_ixl.p));                                    // :390 setBoundsDualsToConstant(1.)
   RC(hiopamd_vec_copy(ctx, n, part(it, 9), d_ixu.p));
@@ -881,10 +880,9 @@ int MdsSolver::run()
       status = Steplength_Too_Small;
       break;
     }
-    if(nadj > 0) {
-      std::fprintf(stderr, "hiop_amd: %d slacks are too small (adjust_bounds is not implemented)\n", nadj);
-      status = Err_Step_Computation;
-      break;
+    if(nadj > 0) {   // :2589-2593: the bounds follow the slacks adjust_small_slacks moved in the accepted trial point
+      if(o.verbosity_level >= 2) std::printf("%d slacks are too small. Adjust corresponding variable slacks!\n", nadj);
+      RC(hiopamd_iterate_adjust_bounds(full, trial.p, d_xl.p, d_xu.p, d_dl.p, d_du.p));
     }
     // ---- filter augmentation, :2616-2653
     if(ls_status == 1) {

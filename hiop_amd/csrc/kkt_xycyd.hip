@@ -1387,6 +1387,26 @@ int hiopamd_iterate_determine_slacks(hiopamd_kkt_xycyd* h, double* it)
   });
 }
 
+// hiopNlpFormulation::adjust_bounds (hiopNlpFormulation.cpp:1403-1416)
+int hiopamd_iterate_adjust_bounds(hiopamd_kkt_xycyd* h, const double* it, double* xl, double* xu, double* dl, double* du)
+{
+  if(!h || !it) return HIOPAMD_ERR_ARG;
+  hiopamd_ctx* ctx = h->ctx;
+  const int64_t* o = h->off;
+  const int64_t nx = o[1] - o[0], nd = o[2] - o[1];
+  double* bnd[4] = {xl, xu, dl, du};
+  const double* pat[4] = {h->ixl, h->ixu, h->idl, h->idu};
+  for(int q = 0; q < 4; ++q) {
+    const int64_t n = q < 2 ? nx : nd;
+    if(n <= 0) continue;
+    if(!bnd[q] || !pat[q]) return HIOPAMD_ERR_ARG;
+    const double* prim = it + o[q < 2 ? 0 : 1];
+    RC(hiopamd_vec_copy_from_w_pattern(ctx, n, bnd[q], prim, pat[q]));
+    RC(hiopamd_vec_axpy_w_pattern(ctx, n, bnd[q], (q & 1) ? 1.0 : -1.0, it + o[4 + q], pat[q]));
+  }
+  return HIOPAMD_OK;
+}
+
 // adjust_small_slacks (:414-505) for the four slack parts of `it`, duals taken from `it_curr`; returns the number adjusted
 int hiopamd_iterate_adjust_small_slacks(hiopamd_kkt_xycyd* h, double* it, const double* it_curr, double mu,
                                         int* num_adjusted_host)

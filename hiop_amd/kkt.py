@@ -567,6 +567,11 @@ class IpmSlabOps:
               "adjust_small_slacks")
         return n.value
 
+    def adjust_bounds(self, it, xl, xu, dl, du):
+        """hiopNlpFormulation::adjust_bounds: the (device) bound arrays follow the slacks of `it`"""
+        check(self._L.hiopamd_iterate_adjust_bounds(self.full.h, dptr(it, self.ctx), dptr(xl, self.ctx), dptr(xu, self.ctx), dptr(dl, self.ctx),
+                                                    dptr(du, self.ctx)), "adjust_bounds")
+
     def determine_duals_bounds_d(self, it, mu):
         check(self._L.hiopamd_iterate_determine_duals_bounds_d(self.full.h, dptr(it, self.ctx), mu), "determine_duals_bounds_d")
 

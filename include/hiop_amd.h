@@ -710,6 +710,10 @@ int hiopamd_iterate_take_step(hiopamd_kkt_xycyd* h, double* out, const double* i
 int hiopamd_iterate_determine_slacks(hiopamd_kkt_xycyd* h, double* iter);
 int hiopamd_iterate_adjust_small_slacks(hiopamd_kkt_xycyd* h, double* iter, const double* iter_curr, double mu,
                                         int* num_adjusted_host);
+/* hiopNlpFormulation::adjust_bounds (src/Optimization/hiopNlpFormulation.cpp:1403-1416), what the algorithm calls after
+ * adjust_small_slacks moved a slack: the bounds follow the slacks — xl = x - sxl, xu = x + sxu, dl = d - sdl, du = d + sdu on the
+ * respective patterns (other entries untouched).  The four arrays are the ones given to hiopamd_kkt_xycyd_set_bounds (device). */
+int hiopamd_iterate_adjust_bounds(hiopamd_kkt_xycyd* h, const double* iter, double* xl, double* xu, double* dl, double* du);
 int hiopamd_iterate_determine_duals_bounds_d(hiopamd_kkt_xycyd* h, double* iter, double mu);
 int hiopamd_iterate_adjust_duals_plh(hiopamd_kkt_xycyd* h, double* iter, double mu, double kappa_Sigma);
 int hiopamd_iterate_eval_log_barrier(hiopamd_kkt_xycyd* h, const double* iter, double* out_host);

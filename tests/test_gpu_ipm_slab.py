@@ -93,6 +93,15 @@ def test_step_routines(ctx):
     assert n_g == n_o and n_o >= 4
     assert_parts(fg, trial_g2, trial_o, kf.ITER_PARTS, rtol=1e-13)
     assert np.all(fg.unpack(trial_g2, kf.ITER_PARTS)["sxl"][fo.ixl == 1.0] > 0.0)
+    # adjust_bounds (hiopNlpFormulation.cpp:1403-1416): the bounds follow the adjusted slacks, on the patterns only
+    bd = [D(b.copy()) for b in (xl, xu, dl, du)]
+    torch.cuda.synchronize()
+    ops.adjust_bounds(trial_g2, *bd); ctx.sync()
+    want = [np.where(fo.ixl == 1.0, trial_o["x"] - trial_o["sxl"], xl), np.where(fo.ixu == 1.0, trial_o["x"] + trial_o["sxu"], xu),
+            np.where(fo.idl == 1.0, trial_o["d"] - trial_o["sdl"], dl), np.where(fo.idu == 1.0, trial_o["d"] + trial_o["sdu"], du)]
+    for got, w in zip(bd, want):
+        np.testing.assert_allclose(got.cpu().numpy(), w, rtol=1e-15, atol=0.0)
+    assert np.any(bd[0].cpu().numpy() != xl)                      # (the pushed slacks moved their bounds)
     # duals from the slacks, dual safeguard, barrier terms
     osl.determine_duals_bounds_d(fo, trial_o, mu)
     ops.determine_duals_bounds_d(trial_g2, mu); ctx.sync()
