@@ -2060,7 +2060,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 
 struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
-  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_shadow = 0, off_run = 0, nflags = 0;
+  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_snap = 0, off_shadow = 0, off_run = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
   std::vector<unsigned> upcnt, wfirst;
   std::vector<int4> wq, wf;
@@ -2091,7 +2091,8 @@ static DfPlan df_build_plan(int N)
   P.off_trb = P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1) + 48;
   P.off_cu = P.off_trb + 8 * (int64_t)(P.nsp + 1);
   P.off_wg = P.off_cu + 512;
-  P.off_shadow = P.off_wg + 2 * 512;   // (at most 480 + 16 workgroups)
+  P.off_snap = P.off_wg + 2 * 512;     // (at most 480 + 16 workgroups)
+  P.off_shadow = P.off_snap + 1024;
   P.off_run = P.off_shadow + (int64_t)P.nsp * P.nt + 2 * (int64_t)P.nt * P.nt + (int64_t)P.nsp * 256 + (int64_t)P.nsp * P.nt * P.nt;   // tr, ver, (pad), executions of TR / update tasks
   P.nflags = P.off_run + 0;         // (+ wtasks.size(), added when the lists exist)
   std::vector<int4> t0, t1;
@@ -2385,6 +2386,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.off_chain = P.off_chain; a.off_tr = P.off_tr; a.off_ver = P.off_ver;
     a.ctasks = df->ctasks; a.wtasks = df->wtasks; a.nwtasks = (int)P.wtasks.size(); a.upcnt = df->upcnt;
     a.wq = df->wq; a.wf = df->wf; a.wfirst = df->wfirst; a.nwide = P.nwide;
+    a.off_wg = P.off_wg;       // (the init kernel publishes these two offsets in the flags' header: set before its launch)
+    a.off_snap = P.off_snap;
     HIOPAMD_CHECK(hipMemsetAsync(df->flags, 0, sizeof(unsigned) * (size_t)P.nflags, st));
     hipLaunchKernelGGL(ldlt_df_init_kernel, dim3(1), dim3(kBlock), 0, st, a);
     int rc = dep(st, su);
@@ -2397,6 +2400,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.off_trb = P.off_trb;
     a.off_cu = P.off_cu;
     a.off_wg = P.off_wg;
+    a.off_snap = P.off_snap;
     {   // limit of every bounded wait: 20x a pessimistic estimate of the whole factorisation (20 TFLOP/s + 1 ms), at least 250 ms, at most
         // 3 s; HIOPAMD_DF_TIMEOUT_MS overrides.  (A wait that is served never lasts longer than the factorisation itself.)
       static const double env_ms = std::getenv("HIOPAMD_DF_TIMEOUT_MS") ? std::atof(std::getenv("HIOPAMD_DF_TIMEOUT_MS")) : 0.0;
@@ -2605,7 +2609,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     if(df_debug) {   // what every workgroup of the wide kernel held when the kernels gave up
       const DfPlan& P = df->plan;
       std::vector<unsigned> wg(2 * 512);
-      (void)hipMemcpy(wg.data(), df->flags + P.off_wg, sizeof(unsigned) * wg.size(), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(wg.data(), df->flags + P.off_snap, sizeof(unsigned) * wg.size(), hipMemcpyDeviceToHost);   // the state AT the time-out
       int shown = 0;
       for(int r = 0; r < 16; ++r) {
         const unsigned v = wg[2 * (496 + r)];
@@ -2624,7 +2628,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       }
       std::fprintf(stderr, "[hiop_amd]   wide kernel: %d workgroups were looking for a task, %d had left (queues exhausted / retired / aborted)\n", looking, left);
       // substitution tasks one by one (others wait for them), update tasks as a histogram by (kind, super-panel, phase)
-      int hist[5][256][4] = {};
+      int hist[5][256][6] = {};
       std::vector<unsigned> fl;
       std::map<std::string, int> missing;   // unsatisfied input -> number of waiting tasks
       for(int w = 0; w < 496; ++w) {
@@ -2679,9 +2683,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
           }
         }
         if(kind == 1u)
-          std::fprintf(stderr, "[hiop_amd]   workgroup %d holds substitution task of super-panel %u, columns from %u, list index %d (-1: early), phase %u (1 waits for its inputs, 2 running)\n", w, jj,
+          std::fprintf(stderr, "[hiop_amd]   workgroup %d holds substitution task of super-panel %u, columns from %u, list index %d (-1: early), phase %u (1 waits for its inputs, 2 running, 3 draining its stores, 4 publishing)\n", w, jj,
                        v & 0xffffu, (int)wg[2 * w + 1], ph);
-        else if(kind < 5u && ph < 4u) hist[kind][jj][ph] += 1;
+        else if(kind < 5u && ph < 6u) hist[kind][jj][ph] += 1;
       }
       if(fl.empty()) {
         fl.resize((size_t)P.nflags);
@@ -2749,8 +2753,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       }
       for(int k = 2; k < 5; ++k)
         for(int jj = 0; jj < 256; ++jj)
-          if(hist[k][jj][1] || hist[k][jj][2])
-            std::fprintf(stderr, "[hiop_amd]   update tasks of kind %d (2 UP, 3 UPH, 4 UP2), queue %d: %d wait for their inputs, %d running\n", k, jj, hist[k][jj][1], hist[k][jj][2]);
+          if(hist[k][jj][1] || hist[k][jj][2] || hist[k][jj][3] || hist[k][jj][4])
+            std::fprintf(stderr, "[hiop_amd]   update tasks of kind %d (2 UP, 3 UPH, 4 UP2), queue %d: %d wait for their inputs, %d in the tile loop, %d draining their stores, %d publishing\n", k, jj,
+                         hist[k][jj][1], hist[k][jj][2], hist[k][jj][3], hist[k][jj][4]);
     }
     return HIOPAMD_ERR_TIMEOUT;
   }

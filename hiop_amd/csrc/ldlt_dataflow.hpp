@@ -85,6 +85,7 @@ struct DfArgs {
   int64_t off_shadow;      // != 0 (HIOPAMD_DF_DEBUG): second copies of the substitution counters and version words, written right after the real ones
   long long timeout_ticks; // limit of every bounded wait, 100 MHz ticks (a multiple of the expected duration of the whole factorisation)
   int64_t off_run;         // != 0 (HIOPAMD_DF_CHECK=1, soak tests): one counter per task of the wide kernel — how often its ticket was handed out
+  int64_t off_snap;        // 1024 words: copy of the state words taken by the waiter whose wait expired, at that moment
   int64_t off_wg;          // 2 words per workgroup of the wide kernel: what it holds right now (see df_wg_state) — read by the host after a time-out
 };
 
@@ -226,6 +227,10 @@ __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* s
                 df_st(flags + 9, df_ld(w.f[q]));
                 df_st(flags + 10, (unsigned)(w.f[q] - flags));
                 df_st(flags + 11, (unsigned)((now - t_wait) >> 4));    // how long this wait lasted, 160 ns units
+                // what every workgroup / role holds NOW (before anybody reacts to the abort word): flags[14] = offset of the state words,
+                // flags[15] = offset of the snapshot area (both written by ldlt_df_init_kernel; 0: no snapshot)
+                if(const unsigned ow = df_ld(flags + 14), os = df_ld(flags + 15); ow != 0u && os != 0u)
+                  for(unsigned q2 = 0; q2 < 1024u; ++q2) df_st(flags + os + q2, df_ld(flags + ow + q2));
               }
               ok = 0;
               break;
@@ -1395,4 +1400,8 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_df_one_kernel(const DfArgs a)
 __global__ __launch_bounds__(kBlock) void ldlt_df_init_kernel(const DfArgs a)
 {
   if(blockIdx.x == 0 && threadIdx.x < 16) a.flags[a.off_chain + DF_CV + threadIdx.x] = 4u;
+  if(blockIdx.x == 0 && threadIdx.x == 16) {
+    a.flags[14] = (unsigned)a.off_wg;
+    a.flags[15] = (unsigned)a.off_snap;
+  }
 }

@@ -51,7 +51,7 @@ CHILD = textwrap.dedent('''
 
 
 def test_timeout_recovery_sequence(ctx):
-    env = dict(os.environ, HIOPAMD_DF_TIMEOUT_MS="0.001")
+    env = dict(os.environ, HIOPAMD_DF_TIMEOUT_MS="0.001", HIOPAMD_DF_DEBUG="1")
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -60,3 +60,5 @@ def test_timeout_recovery_sequence(ctx):
     assert bare == ["timeout", "ok", "timeout", "ok", "timeout", "ok", "ok", "ok"], bare
     assert "SAFE ok" in r.stdout
     assert "three times in a row" in r.stderr
+    # the debug dump is taken from the waiter's snapshot of the state words: every workgroup had started by then
+    assert "wide kernel: 0 of 480 workgroups never started" in r.stderr or "of 480 workgroups never started" in r.stderr
