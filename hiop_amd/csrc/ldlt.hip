@@ -2533,10 +2533,17 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
                        (int64_t)LD_NB, Winv + LD_NB, w2, (int64_t)512, -1.0);
   }
   HIOPAMD_CHECK(hipGetLastError());
-  int h[4];
-  unsigned dfw[16] = {0};
+  // The results come back through a PINNED host buffer (one per thread, allocated once): these copies are enqueued while the dataflow
+  // kernels are still running, and a copy into pageable memory can make the runtime map / pin pages at that moment — a change of the
+  // process's GPU mappings, for which the kernel driver may preempt and restore the process's queues.  Persistent kernels whose
+  // workgroups wait for each other do not survive a partial restore ("workgroups that freeze in mid-task"; tried: no effect on the rate, kept as the cheaper form).
+  static thread_local unsigned* pinned = nullptr;
+  if(!pinned) HIOPAMD_CHECK(hipHostMalloc((void**)&pinned, 32 * sizeof(unsigned), hipHostMallocDefault));
+  int* h = reinterpret_cast<int*>(pinned);
+  unsigned* dfw = pinned + 8;
+  for(int q = 0; q < 16; ++q) dfw[q] = 0u;
   HIOPAMD_CHECK(hipMemcpyAsync(h, d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-  if(use_df) HIOPAMD_CHECK(hipMemcpyAsync(dfw, df->flags, sizeof(dfw), hipMemcpyDeviceToHost, st));
+  if(use_df) HIOPAMD_CHECK(hipMemcpyAsync(dfw, df->flags, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
   HIOPAMD_CHECK(hipStreamSynchronize(st));
   if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
     const DfPlan& P = df->plan;
@@ -2685,7 +2692,15 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
         if(kind == 1u)
           std::fprintf(stderr, "[hiop_amd]   workgroup %d holds substitution task of super-panel %u, columns from %u, list index %d (-1: early), phase %u (1 waits for its inputs, 2 running, 3 draining its stores, 4 publishing)\n", w, jj,
                        v & 0xffffu, (int)wg[2 * w + 1], ph);
-        else if(kind < 5u && ph < 6u) hist[kind][jj][ph] += 1;
+        else if(kind < 5u && ph < 6u) {
+          hist[kind][jj][ph] += 1;
+          if(ph == 2u) {   // in the tile loop: where?
+            const unsigned w1 = wg[2 * w + 1];
+            if(w1 & 0x80000000u)
+              std::fprintf(stderr, "[hiop_amd]   workgroup %d: update task kind %u of queue %u, tile (%u, %u), in the tile loop at stage %u (100 prologue, 101 epilogue)\n", w, kind, jj,
+                           v & 0xffffu, w1 & 0xffffu, (w1 >> 16) & 0x7fffu);
+          }
+        }
       }
       if(fl.empty()) {
         fl.resize((size_t)P.nflags);

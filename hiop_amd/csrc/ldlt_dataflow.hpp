@@ -1250,6 +1250,12 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
     }
   };
 
+  // progress marker for the debug dump (second state word of the workgroup: 0x80000000 | stage << 16 | J; stage 100 = prologue,
+  // 0 .. nst-1 = that stage of the loop, 101 = epilogue): one fire-and-forget store per stage by lane 0
+  auto mark = [&](unsigned stg) {
+    if(tid == 0) df_st(a.flags + a.off_wg + 2 * (int64_t)blockIdx.x + 1, 0x80000000u | (stg << 16) | ((unsigned)J & 0xffffu));
+  };
+  mark(100u);
   gload(0);
   double4_t acc[4][4];
 #pragma unroll
@@ -1273,6 +1279,7 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
   const unsigned tp1 = dbg ? (unsigned)wall_clock64() : 0u;
   for(int st = 0; st < nst; ++st) {
     const int cur = st & 1;
+    mark((unsigned)st);
     df_double2 av[2][2], bv[2][2];
 #pragma unroll
     for(int h = 0; h < 2; ++h) {
@@ -1307,6 +1314,7 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
     __syncthreads();
   }
   // ---- epilogue: stores only
+  mark(101u);
   if(dbg && (dbg == 1 || j + (PANELS - 1) == dbg - 2)) {   // (a fused task is accounted under the queue it was taken from)
     const unsigned tp2 = (unsigned)wall_clock64();
     ph[9] += tp1 - tp0;    // prologue (first operand stage + C tile in flight, two barriers)
