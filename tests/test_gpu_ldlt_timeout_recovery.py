@@ -62,3 +62,33 @@ def test_timeout_recovery_sequence(ctx):
     assert "three times in a row" in r.stderr
     # the debug dump is taken from the waiter's snapshot of the state words: every workgroup had started by then
     assert "wide kernel: 0 of 480 workgroups never started" in r.stderr or "of 480 workgroups never started" in r.stderr
+
+
+CHECK_CHILD = textwrap.dedent('''
+    import sys
+    import torch
+    sys.path.insert(0, ".")
+    from hiop_amd.runtime import Context
+    from hiop_amd.kkt import LinSolverSymDense
+    ctx = Context(0)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    for N in (8192, 2049, 1536):
+        M = torch.rand(N, N, generator=g, device="cuda", dtype=torch.float64) * 1e-3
+        M = M + M.T + torch.eye(N, device="cuda", dtype=torch.float64) * 10.0
+        ls = LinSolverSymDense(ctx, N)
+        for rep in range(3):
+            ls.set_sys_matrix(M); ctx.sync()
+            assert ls.matrix_changed() == 0
+    print("CHECKED")
+''')
+
+
+def test_every_task_of_the_wide_kernel_is_handed_out_and_completed_exactly_once(ctx):
+    """HIOPAMD_DF_CHECK=1: the wide kernel counts, per entry of its task lists, how often the ticket was handed out and how often the
+    task published; the library verifies both are 1 after every factorisation and says so on stderr otherwise (orders with fused K = 512
+    tasks, a ragged order, an order just above the dataflow threshold)."""
+    env = dict(os.environ, HIOPAMD_DF_CHECK="1")
+    r = subprocess.run([sys.executable, "-c", CHECK_CHILD], capture_output=True, text=True, env=env, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "CHECKED" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "HIOPAMD_DF_CHECK" not in r.stderr, r.stderr[-4000:]
