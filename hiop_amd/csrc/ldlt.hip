@@ -2222,6 +2222,9 @@ struct DfDevice {
   // (no successful dataflow factorisation in between) switch the object to the stepwise kernels for good
   bool skip_once = false;
   int strikes = 0;
+  // workgroups of the wide kernel (0: two per CU).  After a time-out the object goes on with ONE per CU: in the soaks every freeze happened with
+  // two 73.7 KB workgroups sharing a CU, none in 41 600 factorisations with one (scripts/r03_gpu_53.sh; 4 % slower)
+  int wide_wgs = 0;
 };
 
 struct hiopamd_linsolver {
@@ -2441,7 +2444,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       if(timed) (void)hipEventRecord(prof->get(), su);
       // the resident workgroups of the 240 CUs of the wide stream (HIOPAMD_DF_WGS: timing aid — 240 = one workgroup per CU)
       static const int wgs_env = std::getenv("HIOPAMD_DF_WGS") ? std::atoi(std::getenv("HIOPAMD_DF_WGS")) : 0;
-      const int wmax = wgs_env > 0 ? std::min(wgs_env, 240 * DF_WIDE_WG_PER_CU) : 240 * DF_WIDE_WG_PER_CU;
+      const int wmax = wgs_env > 0 ? std::min(wgs_env, 240 * DF_WIDE_WG_PER_CU) : (df->wide_wgs > 0 ? df->wide_wgs : 240 * DF_WIDE_WG_PER_CU);
       const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
       // 16-byte accesses need even N, lda, ldv (ldv = N); HIOPAMD_DF_TILE=1 forces the 8-byte form (A/B timing)
       static const int tile_env = std::getenv("HIOPAMD_DF_TILE") ? std::atoi(std::getenv("HIOPAMD_DF_TILE")) : 2;
@@ -3245,6 +3248,10 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
     ls->df.enabled = df_was;
     if(df_this && r == HIOPAMD_ERR_TIMEOUT) {
       ls->df.skip_once = true;
+      if(ls->df.wide_wgs == 0) {
+        ls->df.wide_wgs = 240;
+        std::fprintf(stderr, "[hiop_amd] dataflow LDL^T timed out: this solver object goes on with one workgroup of the wide kernel per CU\n");
+      }
       if(++ls->df.strikes >= 3) {
         ls->df.enabled = false;
         std::fprintf(stderr, "[hiop_amd] dataflow LDL^T timed out three times in a row: this solver object uses the stepwise kernels from now on\n");
