@@ -283,7 +283,9 @@ class Sim:
         self.updone[j] += 1
 
 
-def replay(A, plan, n_workers, seed):
+def replay(A, plan, n_workers, seed, retire_at=None):
+    """retire_at: the super-panel at which every second worker (the \"second workgroup of its CU\") leaves the wide kernel
+    (HIOPAMD_DF_RETIRE in csrc/ldlt.hip); None: nobody leaves early"""
     rnd = random.Random(seed)
     sim = Sim(A, plan)
     roles = plan["roles"]
@@ -318,6 +320,8 @@ def replay(A, plan, n_workers, seed):
             jtr, jn, jf = ptr[w]
             if jtr >= nw and jn >= nw and jf >= nw:
                 return "done"
+            if retire_at is not None and (w & 1) and jtr >= retire_at and jn >= retire_at and jf >= retire_at:
+                return "done"      # (a worker only leaves between tasks: whatever it took, it finished)
             if jtr < nw:
                 if trq[jtr] >= Q[jtr][1]:
                     ptr[w][0] += 1
@@ -413,6 +417,21 @@ def test_schedule_is_live_and_sound(n, workers, seed):
     want = ldl_nopiv(A)
     got = np.triu(sim.A)
     for j in range(plan["nsp"]):      # the factored diagonal blocks live in the compact copies
+        got[256 * j:256 * j + 256, 256 * j:256 * j + 256] = np.triu(sim.Cd[j])
+    assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n,workers,seed,retire_at", [(1536, 8, 4, 3), (1536, 2, 5, 0), (2048, 6, 6, 4)])
+def test_schedule_stays_live_and_sound_when_every_second_worker_leaves_early(n, workers, seed, retire_at):
+    """Round 3: the second workgroup of every CU leaves the wide kernel at super-panel jretire (the chain-bound half runs faster with one
+    workgroup per CU).  A worker leaves only between tasks, and the protocol never counts on a particular number of workers — replayed
+    here with odd workers leaving at `retire_at` (0: before they take anything)."""
+    plan = get_plan(n)
+    A = quasi_definite(n, seed)
+    sim = replay(A, plan, workers, seed, retire_at=retire_at)
+    want = ldl_nopiv(A)
+    got = np.triu(sim.A)
+    for j in range(plan["nsp"]):
         got[256 * j:256 * j + 256, 256 * j:256 * j + 256] = np.triu(sim.Cd[j])
     assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
 
