@@ -2060,7 +2060,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 
 struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
-  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_snap = 0, off_shadow = 0, off_run = 0, nflags = 0;
+  int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_snap = 0, off_where = 0, off_shadow = 0, off_run = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
   std::vector<unsigned> upcnt, wfirst;
   std::vector<int4> wq, wf;
@@ -2092,7 +2092,8 @@ static DfPlan df_build_plan(int N)
   P.off_cu = P.off_trb + 8 * (int64_t)(P.nsp + 1);
   P.off_wg = P.off_cu + 512;
   P.off_snap = P.off_wg + 2 * 512;     // (at most 480 + 16 workgroups)
-  P.off_shadow = P.off_snap + 1024;
+  P.off_where = P.off_snap + 1024;
+  P.off_shadow = P.off_where + 2 * 512;
   P.off_run = P.off_shadow + (int64_t)P.nsp * P.nt + 2 * (int64_t)P.nt * P.nt + (int64_t)P.nsp * 256 + (int64_t)P.nsp * P.nt * P.nt;   // tr, ver, (pad), executions of TR / update tasks
   P.nflags = P.off_run + 0;         // (+ wtasks.size(), added when the lists exist)
   std::vector<int4> t0, t1;
@@ -2391,6 +2392,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.wq = df->wq; a.wf = df->wf; a.wfirst = df->wfirst; a.nwide = P.nwide;
     a.off_wg = P.off_wg;       // (the init kernel publishes these two offsets in the flags' header: set before its launch)
     a.off_snap = P.off_snap;
+    a.off_where = P.off_where;
     HIOPAMD_CHECK(hipMemsetAsync(df->flags, 0, sizeof(unsigned) * (size_t)P.nflags, st));
     hipLaunchKernelGGL(ldlt_df_init_kernel, dim3(1), dim3(kBlock), 0, st, a);
     int rc = dep(st, su);
@@ -2625,6 +2627,16 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
         const unsigned v = wg[2 * (496 + r)];
         std::fprintf(stderr, "[hiop_amd]   chain role %d: last task kind %u (1 F, 2 T, 3 U, 4 S, 5 R, 6 C) super-panel %u fields %u %u %u\n", r, v >> 28, (v >> 16) & 255u,
                      (v >> 8) & 15u, (v >> 4) & 15u, v & 15u);
+      }
+      {   // did a workgroup finish a task on another CU than the one it took it on?  (final state: after the kernels ended)
+        std::vector<unsigned> wh(2 * 512);
+        (void)hipMemcpy(wh.data(), df->flags + P.off_where, sizeof(unsigned) * wh.size(), hipMemcpyDeviceToHost);
+        int moved = 0;
+        for(int w = 0; w < 480; ++w)
+          if((wh[2 * w] & 0x80000000u) && (wh[2 * w + 1] & 0x80000000u) && wh[2 * w] != wh[2 * w + 1] && moved++ < 8)
+            std::fprintf(stderr, "[hiop_amd]   workgroup %d took its last task on (xcc %u, se %u, cu %u) and published it on (xcc %u, se %u, cu %u)\n", w, (wh[2 * w] >> 6) & 7u,
+                         (wh[2 * w] >> 4) & 3u, wh[2 * w] & 15u, (wh[2 * w + 1] >> 6) & 7u, (wh[2 * w + 1] >> 4) & 3u, wh[2 * w + 1] & 15u);
+        std::fprintf(stderr, "[hiop_amd]   %d workgroups published their last task on another CU than they took it on\n", moved);
       }
       int looking = 0, left = 0, never = 0, between = 0;
       for(int w = 0; w < 480; ++w) {

@@ -85,6 +85,7 @@ struct DfArgs {
   int64_t off_shadow;      // != 0 (HIOPAMD_DF_DEBUG): second copies of the substitution counters and version words, written right after the real ones
   long long timeout_ticks; // limit of every bounded wait, 100 MHz ticks (a multiple of the expected duration of the whole factorisation)
   int64_t off_run;         // != 0 (HIOPAMD_DF_CHECK=1, soak tests): one counter per task of the wide kernel — how often its ticket was handed out
+  int64_t off_where;       // 2 words per workgroup of the wide kernel: (XCC, SE, CU) it ran on when it took its current task / when it published it
   int64_t off_snap;        // 1024 words: copy of the state words taken by the waiter whose wait expired, at that moment
   int64_t off_wg;          // 2 words per workgroup of the wide kernel: what it holds right now (see df_wg_state) — read by the host after a time-out
 };
@@ -122,6 +123,15 @@ __device__ __forceinline__ unsigned df_poll(const unsigned* p)
 #endif
 }
 __device__ __forceinline__ unsigned df_ticket(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, HIOPAMD_DF_RMW_SCOPE); }
+// where am I: XCC id (3 bits) | SE (2) | CU (4) of the executing wave — a workgroup that the driver context-saved and restored elsewhere shows
+// a different value at the end of a task than at its start (debug dump after a time-out)
+__device__ __forceinline__ unsigned df_where()
+{
+  unsigned xcc, hwid;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+  return 0x80000000u | ((xcc & 7u) << 6) | (((hwid >> 13) & 3u) << 4) | ((hwid >> 8) & 15u);
+}
 // state word of a wide-kernel workgroup: kind (4 bits) | phase (4: 1 taken, 2 inputs there, 3 body done) | super-panel (8) | ticket-local index (16);
 // second word: the task's third / fourth field.  0 = between tasks.  Two fire-and-forget stores per phase by lane 0.
 __device__ __forceinline__ void df_wg_state(const DfArgs& a, int phase, const int4& tk)
@@ -129,6 +139,8 @@ __device__ __forceinline__ void df_wg_state(const DfArgs& a, int phase, const in
   unsigned* p = a.flags + a.off_wg + 2 * (int64_t)blockIdx.x;
   df_st(p, phase == 0 ? 0xF3000000u : (((unsigned)tk.x & 15u) << 28) | (((unsigned)phase & 15u) << 24) | (((unsigned)tk.y & 255u) << 16) | ((unsigned)tk.z & 0xffffu));
   if(phase == 1) df_st(p + 1, (unsigned)tk.w);
+  if(phase == 1) df_st(a.flags + a.off_where + 2 * (int64_t)blockIdx.x, df_where());
+  if(phase == 4) df_st(a.flags + a.off_where + 2 * (int64_t)blockIdx.x + 1, df_where());
 }
 
 // up to four (flag >= value) conditions, in fixed slots (compile-time indices keep them in registers); an unused slot
