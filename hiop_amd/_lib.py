@@ -111,7 +111,7 @@ class HiopAmdError(RuntimeError):
     pass
 
 
-_ERR = {-1: "HIP runtime error", -2: "invalid argument", -3: "no gfx950 device", -4: "singular", -5: "bad call sequence"}
+_ERR = {-1: "HIP runtime error", -2: "invalid argument", -3: "no gfx950 device", -4: "singular", -5: "bad call sequence"}   # (-6 time-out, -7 solve failed: shown as numbers)
 
 
 def check(rc: int, what: str = ""):

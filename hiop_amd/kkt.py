@@ -33,6 +33,7 @@ class LinSolverSymDense:
         torch.cuda.synchronize()
         check(self._L.hiopamd_copy_d2d(self.ctx.h, C.c_void_p(self.sys_matrix_ptr()), dptr(M.contiguous(), self.ctx),
                                        self.n * self.n * 8), "copy_d2d")
+        self._assembled_from = M          # (a reference, not a copy: see matrix_changed)
 
     def get_sys_matrix(self) -> torch.Tensor:
         out = torch.empty((self.n, self.n), dtype=torch.float64, device="cuda")
@@ -42,9 +43,20 @@ class LinSolverSymDense:
         self.ctx.sync()
         return out
 
+    # HIOPAMD_ERR_TIMEOUT (-6): a bounded wait of the dataflow factorisation expired, the matrix is overwritten, "the caller re-assembles
+    # and calls again" (include/hiop_amd.h; the native KKT objects do).  This wrapper is that caller when the matrix came through
+    # set_sys_matrix: it copies the source again and calls once more (the library runs that call with the stepwise kernels).
+    retry_after_timeout = True
+
     def matrix_changed(self) -> int:
         nneg = C.c_int(0)
-        check(self._L.hiopamd_linsolver_matrix_changed(self.h, C.byref(nneg)), "hiopamd_linsolver_matrix_changed")
+        rc = self._L.hiopamd_linsolver_matrix_changed(self.h, C.byref(nneg))
+        src = getattr(self, "_assembled_from", None)
+        if rc == -6 and self.retry_after_timeout and src is not None:
+            self.set_sys_matrix(src)
+            self.ctx.sync()
+            rc = self._L.hiopamd_linsolver_matrix_changed(self.h, C.byref(nneg))
+        check(rc, "hiopamd_linsolver_matrix_changed")
         return nneg.value
 
     def solve(self, rhs: torch.Tensor, nrhs: int = 1) -> bool:

@@ -31,6 +31,7 @@ slowest = 0.0
 t0 = time.perf_counter(); done = 0
 for o in range(nobj):
     ls = LinSolverSymDense(ctx, N)
+    ls.retry_after_timeout = False        # (the soak wants to SEE the time-outs)
     for rep in range(reps):
         ls.set_sys_matrix(M); ctx.sync(); tc = time.perf_counter()
         try:
