@@ -200,7 +200,11 @@ int hiopamd_kkt_sparse_condensed_factorize(hiopamd_kkt_sparse_condensed* k, int*
   if(k->dls) {   // a Cholesky exists iff no pivot of the LDL^T is non-positive
     int nneg = 0;
     if(k->dls_factored) RC(build_impl_dense_copy(k));   // factorize twice on one build: the copy holds factors, not M
-    const int rc = hiopamd_linsolver_matrix_changed(k->dls, &nneg);
+    int rc = hiopamd_linsolver_matrix_changed(k->dls, &nneg);
+    if(rc == HIOPAMD_ERR_TIMEOUT) {   // (the dataflow factorisation gave up, DESIGN.md 3.1: the copy again, then the stepwise kernels)
+      RC(build_impl_dense_copy(k));
+      rc = hiopamd_linsolver_matrix_changed(k->dls, &nneg);
+    }
     k->dls_factored = true;
     if(rc != HIOPAMD_OK && rc != HIOPAMD_ERR_SINGULAR) return rc;
     *n_neg_host = (rc == HIOPAMD_ERR_SINGULAR || nneg != 0) ? -1 : 0;

@@ -237,7 +237,14 @@ int backend_factorize(hiopamd_kkt_xycyd* h, int* n_neg)
     return HIOPAMD_OK;
   }
   SpanScope span(h->ctx, HIOPAMD_SPAN_KKT_UPDATE_INNER_FACT);   // hiopKKTLinSys.cpp:347-352
-  return hiopamd_linsolver_matrix_changed(h->ls, n_neg);   // hiopKKTLinSys.cpp:310-313
+  int rc = hiopamd_linsolver_matrix_changed(h->ls, n_neg);   // hiopKKTLinSys.cpp:310-313
+  if(rc == HIOPAMD_ERR_TIMEOUT) {
+    // the dataflow factorisation gave up and left the matrix overwritten: assemble it again for the same deltas (the
+    // randomised delta vectors are not redrawn: nothing is marked dirty) and factor once more — that call runs the stepwise kernels
+    RC(backend_build(h));
+    rc = hiopamd_linsolver_matrix_changed(h->ls, n_neg);
+  }
+  return rc;
 }
 
 // solveCompressed: rx and ryd may be overwritten (the reference's classes do the same)
