@@ -2672,8 +2672,11 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
             fl.resize((size_t)P.nflags);
             (void)hipMemcpy(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost);
           }
-          auto verw = [&](int I, int J) { return fl[(size_t)(P.off_ver + (int64_t)I * P.nt + J)]; };
-          auto trw = [&](int jq, int B) { return fl[(size_t)(P.off_tr + (int64_t)jq * P.nt + B)]; };
+          // (the state words are a snapshot taken while the workgroups run: the second word of a workgroup that has just taken a task may
+          //  still be the previous task's stage marker — every index is range-checked, an inconsistent pair is skipped)
+          auto in_t = [&](int t) { return t >= 0 && t < P.nt; };
+          auto verw = [&](int I, int J) { return (in_t(I) && in_t(J)) ? fl[(size_t)(P.off_ver + (int64_t)I * P.nt + J)] : 0xffffffffu; };
+          auto trw = [&](int jq, int B) { return (jq >= 0 && jq < P.nsp && in_t(B)) ? fl[(size_t)(P.off_tr + (int64_t)jq * P.nt + B)] : 0xffffffffu; };
           auto grp = [&](int B) { const int rem = N - 128 * B; return (unsigned)(rem >= 128 ? 8 : (rem + 15) / 16); };
           auto miss = [&](const char* what, int x, int y, unsigned is, unsigned needs) {
             if(is < needs) {
@@ -2688,7 +2691,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
             miss("ver", 2 * j, J, verw(2 * j, J), (unsigned)j);
             miss("ver", 2 * j + 1, J, verw(2 * j + 1, J), (unsigned)j);
           } else {
-            const int I = (int)(v & 0xffffu), J = (int)wg[2 * w + 1];
+            const int I = (int)(v & 0xffffu), J = (int)(wg[2 * w + 1] & 0xffffu);   // (low half: tile column, also inside a stage marker)
             const bool fusedt = kind == 4u;
             const int jb = fusedt ? j - 1 : j;
             miss("ver", I, J, verw(I, J), (unsigned)jb);
@@ -2698,7 +2701,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
               miss("tr", j, I, trw(j, I), grp(I));
               miss("tr", j, J, trw(j, J), grp(J));
             } else {
-              if(I < 2 * j + 4) miss("hdone", j, 0, fl[(size_t)(P.off_chain + (int64_t)j * DF_CH + DF_HDONE)], 16u);
+              if(I < 2 * j + 4) miss("hdone", j, 0, (j >= 0 && j <= P.nsp) ? fl[(size_t)(P.off_chain + (int64_t)j * DF_CH + DF_HDONE)] : 0xffffffffu, 16u);
               else miss("tr", j, I, trw(j, I), grp(I));
               miss("tr", j, J, trw(j, J), grp(J));
             }
