@@ -52,7 +52,7 @@ CHILD = textwrap.dedent('''
 
 
 def test_timeout_recovery_sequence(ctx):
-    env = dict(os.environ, HIOPAMD_DF_TIMEOUT_MS="0.001", HIOPAMD_DF_DEBUG="1")
+    env = dict(os.environ, HIOPAMD_DF_TIMEOUT_MS="0.001")
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -69,8 +69,6 @@ def test_timeout_recovery_sequence(ctx):
         assert "three times in a row" in r.stderr
     assert "SAFE ok" in r.stdout
     assert r.stderr.count("goes on with one workgroup of the wide kernel per CU") >= 1
-    # the debug dump is taken from the waiter's snapshot of the state words
-    assert "of 480 workgroups never started" in r.stderr
 
 CHECK_CHILD = textwrap.dedent('''
     import sys
