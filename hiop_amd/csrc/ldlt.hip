@@ -2714,9 +2714,12 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
           hist[kind][jj][ph] += 1;
           if(ph == 2u) {   // in the tile loop: where?
             const unsigned w1 = wg[2 * w + 1];
-            if(w1 & 0x80000000u)
-              std::fprintf(stderr, "[hiop_amd]   workgroup %d: update task kind %u of queue %u, tile (%u, %u), in the tile loop at stage %u (100 prologue, 101 epilogue)\n", w, kind, jj,
-                           v & 0xffffu, w1 & 0xffffu, (w1 >> 16) & 0x7fffu);
+            if(w1 & 0x80000000u) {
+              unsigned wh0 = 0u;   // where it took that task (final state of the word: a workgroup does not take another one while it is in this one)
+              (void)hipMemcpy(&wh0, df->flags + P.off_where + 2 * (int64_t)w, sizeof(unsigned), hipMemcpyDeviceToHost);
+              std::fprintf(stderr, "[hiop_amd]   workgroup %d (xcc %u, se %u, cu %u): update task kind %u of queue %u, tile (%u, %u), in the tile loop at stage %u (100 prologue, 101 epilogue)\n", w,
+                           (wh0 >> 6) & 7u, (wh0 >> 4) & 3u, wh0 & 15u, kind, jj, v & 0xffffu, w1 & 0xffffu, (w1 >> 16) & 0x7fffu);
+            }
           }
         }
       }
