@@ -305,3 +305,21 @@ def test_mds_c_program_on_a_badly_scaled_problem(tmp_path):
     assert status == 0 and o["status"] == "Solve_Success"
     assert iters == o["iters"] and abs(obj - o["obj_user"]) <= 1e-9 * abs(o["obj_user"])
     assert abs(float(g.group(5)) - float(o["x"].sum())) <= 1e-6 * max(1.0, abs(o["x"].sum()))
+
+
+def test_gradient_scaling_factors_follow_the_reference_formulas():
+    """oracle/nlp_scaling.py against hand-evaluated cases of hiopNlpFormulation::apply_scaling (hiopNlpFormulation.cpp:671-714) and
+    hiopNLPObjGradScaling's constructor (hiopNlpTransforms.cpp:423-499) at the default options (scaling_max_grad 100, scaling_min_grad
+    1e-8, scaling_max_obj_grad = scaling_max_con_grad = 0)."""
+    from oracle.nlp_scaling import gradient_scaling
+    g = np.array([3.0, -99.9])
+    Jc = np.array([[1.0, -2.0]])
+    Jd = np.array([[0.5, 99.0], [1.0, 1.0]])
+    assert gradient_scaling(g, Jc, Jd) is None                                  # every entry below 100: apply_scaling returns false
+    s_f, s_c, s_d = gradient_scaling(np.array([3.0, -100.0]), Jc, Jd)           # ">= max_grad" triggers, but 100 is not "> max_grad":
+    assert s_f == 1.0 and np.all(s_c == 1.0) and np.all(s_d == 1.0)             # the transformation exists with unit factors
+    s_f, s_c, s_d = gradient_scaling(np.array([3.0, -400.0]), Jc, np.array([[0.5, 250.0], [1.0, 1.0], [-1000.0, 2.0]]))
+    assert s_f == 0.25 and np.all(s_c == 1.0)                                   # 100 / 400; the equality block has no row above 100
+    np.testing.assert_allclose(s_d, [0.4, 1.0, 0.1], rtol=0, atol=0)            # 1 / max(1, rowmax / 100), row by row
+    s_f, _, s_d = gradient_scaling(np.array([1e12]), np.zeros((0, 1)), np.array([[1e11]]))
+    assert s_f == 1e-8 and s_d[0] == 1e-8                                       # the scaling_min_grad floor
