@@ -23,22 +23,24 @@ int hiopLinSolverSymDenseHipNative::matrixChanged()
   assert(M_->n() == M_->m() && M_->n() == n_);
   if(nlp_) nlp_->runStats.linsolv.tmFactTime.start();
   int n_neg = -1;
-  const int rc = hiopamd_linsolver_matrix_changed(ls_, &n_neg);
+  // The solver object keeps a copy of the assembled upper triangle while its dataflow factorisation runs (its default,
+  // hiopamd_linsolver_set_retry_copy): a bounded wait that expires is answered INSIDE this call by a stepwise factorisation of
+  // the restored matrix, so HIOPAMD_ERR_TIMEOUT never arrives here.  HIOPAMD_ERR_SOLVE = "a solve since the last factorisation
+  // delivered invalid results; the matrix is intact, call again" (the solve() that was affected has already returned false).
+  int rc = hiopamd_linsolver_matrix_changed(ls_, &n_neg);
+  if(rc == HIOPAMD_ERR_SOLVE) rc = hiopamd_linsolver_matrix_changed(ls_, &n_neg);
   if(nlp_) {
     nlp_->runStats.linsolv.tmFactTime.stop();
     double ff = 0.0, fs = 0.0;
     if(hiopamd_linsolver_flops(ls_, &ff, &fs) == HIOPAMD_OK) nlp_->runStats.linsolv.flopsFact = ff / 1e12;
   }
-  if(rc == HIOPAMD_ERR_TIMEOUT) {
-    // the dataflow kernels gave up and the matrix is overwritten: this is NOT "singular".  The solver object has switched to
-    // its stepwise kernels; the KKT class has to assemble again, which only the caller of matrixChanged() can do — the
-    // reference has no channel for that, so stop loudly rather than send the IPM into inertia correction on a lie
-    std::fprintf(stderr, "hiop_amd: the LDL^T factorisation timed out (device shared with another process?); re-assemble and call matrixChanged() again\n");
-    std::abort();
-  }
-  if(rc != HIOPAMD_OK) {   // a runtime failure (HIP error, invalid solve results seen since the last factorisation): not "singular" either
-    std::fprintf(stderr, "hiop_amd: hiopamd_linsolver_matrix_changed failed with status %d\n", rc);
-    std::abort();
+  if(rc != HIOPAMD_OK) {
+    // A runtime failure of the device layer (HIP error, lost device).  The reference's contract has exactly two answers — the number
+    // of negative eigenvalues or -1 (hiopLinSolver.hpp:117-130; the LAPACK class returns -1 for info != 0 as well,
+    // hiopLinSolverSymDenseLapack.hpp:103-117) — so this is reported on stderr and answered with -1: the IPM's inertia-correction
+    // loop re-assembles and calls again (hiopKKTLinSys.cpp:316-372), and gives up in its own way if the failure persists.
+    std::fprintf(stderr, "hiop_amd: hiopamd_linsolver_matrix_changed failed with status %d; reporting -1 to the caller\n", rc);
+    return -1;
   }
   return n_neg;   // -1: zero / non-finite pivot (or, in safe mode, a probe solve that did not converge): the reference's "singular" answer
 }

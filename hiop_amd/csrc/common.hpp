@@ -69,6 +69,7 @@ struct hiopamd_ctx {
   hipStream_t diag_stream = nullptr;   // CU-masked: the reserved CUs (serial chain; its 1-workgroup kernel needs a whole CU's LDS)
   hipStream_t upd_stream = nullptr;    // CU-masked: every other CU
   int cu_split_state = 0;              // 0 not tried, 1 masked streams available, -1 unavailable
+  int chain_cus = 0, wide_cus = 0;     // CUs behind diag_stream / upd_stream (from hipDeviceProp_t::multiProcessorCount and the reservation)
   hipEvent_t ev_pool[160] = {nullptr};
   int n_events = 0;
   void* spans = nullptr;               // hiopamd::SpanState (context.hip): KKT / linear-solver run-stats spans
@@ -109,6 +110,8 @@ inline bool ctx_cu_split(hiopamd_ctx* ctx)
     ctx->diag_stream = ctx->upd_stream = nullptr;
     return false;
   }
+  ctx->chain_cus = 8 * per_xcd;
+  ctx->wide_cus = ncu - ctx->chain_cus;
   ctx->cu_split_state = 1;
   return true;
 }

@@ -57,6 +57,7 @@ int hiopamd_kkt_mds_create(hiopamd_kkt_mds** out, hiopamd_ctx* ctx, const hiopam
   k->s = *st;
   const int N = st->nxd + st->neq + st->nineq;
   int rc = hiopamd_linsolver_create(&k->ls, ctx, N);
+  if(rc == HIOPAMD_OK) rc = hiopamd_linsolver_set_retry_copy(k->ls, 0);   // (this object re-assembles after a time-out: hiopamd_kkt_mds_factorize)
   // symbolic plans of the three Schur blocks (pattern is fixed over the IPM iterations)
   if(rc == HIOPAMD_OK)
     rc = hiopamd_sp_plan_create(&k->plan_cc, st->neq, st->neq, st->nxs, st->nnz_Jcs, st->Jcs_i_host, st->Jcs_j_host,

@@ -148,6 +148,7 @@ int hiopamd_kkt_sparse_condensed_create(hiopamd_kkt_sparse_condensed** out, hiop
     const char* e = std::getenv("HIOPAMD_SPARSE_DIRECT_MAX");
     const int direct_max = e ? std::atoi(e) : 4096;
     if(rc == HIOPAMD_OK && nx > 0 && nx <= direct_max) rc = hiopamd_linsolver_create(&k->dls, ctx, nx);
+    if(rc == HIOPAMD_OK && k->dls) rc = hiopamd_linsolver_set_retry_copy(k->dls, 0);   // (the dense copy is rebuilt after a time-out, see factorize)
   }
   if(rc == HIOPAMD_OK) rc = hiopamd_krylov_set_tol(k->pcg, k->tol);
   if(rc == HIOPAMD_OK) rc = hiopamd_krylov_set_max_num_iter(k->pcg, k->maxit);

@@ -640,6 +640,7 @@ int hiopamd_kkt_xycyd_create_dense(hiopamd_kkt_xycyd** out, hiopamd_ctx* ctx, in
   RC(create_common(out, ctx, KIND_DENSE, nx, nineq, neq, nineq, ixl, ixu, idl, idu));
   hiopamd_kkt_xycyd* h = *out;
   int rc = hiopamd_linsolver_create(&h->ls, ctx, nx + neq + nineq);
+  if(rc == HIOPAMD_OK) rc = hiopamd_linsolver_set_retry_copy(h->ls, 0);   // (backend_factorize re-assembles after a time-out)
   if(rc == HIOPAMD_OK &&
      (hipMalloc((void**)&h->dense_rhs, sizeof(double) * (size_t)(nx + neq + nineq + 1)) != hipSuccess ||
       hipMalloc((void**)&h->dense_Dd_inv, sizeof(double) * (size_t)(nineq + 1)) != hipSuccess))
@@ -658,6 +659,7 @@ int hiopamd_kkt_xycyd_create_dense_xdycyd(hiopamd_kkt_xycyd** out, hiopamd_ctx* 
   hiopamd_kkt_xycyd* h = *out;
   const int n = nx + neq + 2 * nineq;
   int rc = hiopamd_linsolver_create(&h->ls, ctx, n);
+  if(rc == HIOPAMD_OK) rc = hiopamd_linsolver_set_retry_copy(h->ls, 0);   // (backend_factorize re-assembles after a time-out)
   if(rc == HIOPAMD_OK && hipMalloc((void**)&h->dense_rhs, sizeof(double) * (size_t)(n + 1)) != hipSuccess)
     rc = HIOPAMD_ERR_HIP;
   if(rc != HIOPAMD_OK) {

@@ -34,6 +34,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 namespace hiopamd {
 
@@ -1888,6 +1889,32 @@ __global__ __launch_bounds__(B) void ldlt_solve_flow_kernel(const double* __rest
 
 #include "ldlt_dataflow.hpp"
 
+// copy of the upper triangle by 128 x 128 tiles (J >= I), 16 bytes per lane where the order allows: the retry copy of the solver object
+// (half the bytes of a full copy: ~0.13 ms at N = 8192)
+__global__ __launch_bounds__(kBlock) void ldlt_triu_copy_kernel(int N, const double* __restrict__ src, double* __restrict__ dst, int64_t ld)
+{
+  const int I = blockIdx.y, J = blockIdx.x;
+  if(J < I) return;
+  const int r0 = 128 * I, c0 = 128 * J;
+  const int tid = threadIdx.x;
+  if((N & 1) == 0 && (ld & 1) == 0) {
+    const int cp = 2 * (tid & 63), rq = tid >> 6;   // 64 lanes x 2 columns, 4 rows per pass
+    if(c0 + cp < N)
+#pragma unroll 4
+      for(int r = rq; r < 128; r += 4) {
+        if(r0 + r < N) {
+          const int64_t e = (int64_t)(r0 + r) * ld + c0 + cp;
+          *reinterpret_cast<double2*>(dst + e) = *reinterpret_cast<const double2*>(src + e);
+        }
+      }
+  } else {
+    const int c = tid & 127, rq = tid >> 7;
+    if(c0 + c < N)
+      for(int r = rq; r < 128; r += 2)
+        if(r0 + r < N) dst[(int64_t)(r0 + r) * ld + c0 + c] = src[(int64_t)(r0 + r) * ld + c0 + c];
+  }
+}
+
 }  // namespace hiopamd
 
 using namespace hiopamd;
@@ -2060,16 +2087,27 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 
 struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
+  bool form8 = false;      // the wide kernel's form for this order: eight waves, one workgroup per CU (ldlt_wide8.hpp) / four waves
+  bool has_far = false;    // a FAR update list exists (HIOPAMD_DF_SPLIT=1)
   int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_snap = 0, off_where = 0, off_shadow = 0, off_run = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
   std::vector<unsigned> upcnt, wfirst;
   std::vector<int4> wq, wf;
   double up_flops = 0.0;   // algorithmic flops of the UP tasks (2 K per updated element)
 };
+// Which form of the wide kernel factorises order N: the eight-wave form (one workgroup per CU, ldlt_wide8.hpp) needs the 16-byte tile
+// accesses (even N; lda = ldv = N in the solver object); HIOPAMD_DF_FORM=4 selects the four-wave form (A/B timing, counter passes).
+static bool df_form8(int N)
+{
+  static const int form_env = std::getenv("HIOPAMD_DF_FORM") ? std::atoi(std::getenv("HIOPAMD_DF_FORM")) : 8;
+  static const bool one_env = std::getenv("HIOPAMD_DF_ONE") && std::atoi(std::getenv("HIOPAMD_DF_ONE")) != 0;   // (the one-dispatch form of the counter passes is four-wave)
+  return form_env != 4 && !one_env && (N % 2 == 0) && N >= 2 * UD_T;
+}
 static DfPlan df_build_plan(int N)
 {
   DfPlan P;
   P.N = N;
+  P.form8 = df_form8(N);
   P.nsp = (N + LD_NB - 1) / LD_NB;
   P.nt = (N + UD_T - 1) / UD_T;
   const int nfull = N / LD_NB;
@@ -2188,6 +2226,7 @@ static DfPlan df_build_plan(int N)
   P.wtasks.insert(P.wtasks.end(), nearq.begin(), nearq.end());
   P.wtasks.insert(P.wtasks.end(), farq.begin(), farq.end());
   P.wf = wf;
+  for(const int4& f : wf) P.has_far = P.has_far || f.y > 0;
   P.wq = wq;
   P.nflags = P.off_run + 2 * (int64_t)P.wtasks.size();   // handed out, completed
   return P;
@@ -2223,8 +2262,8 @@ struct DfDevice {
   // (no successful dataflow factorisation in between) switch the object to the stepwise kernels for good
   bool skip_once = false;
   int strikes = 0;
-  // workgroups of the wide kernel (0: two per CU).  After a time-out the object goes on with ONE per CU: in the soaks every freeze happened with
-  // two 73.7 KB workgroups sharing a CU, none in 41 600 factorisations with one (scripts/r03_gpu_53.sh; 4 % slower)
+  // workgroups of the four-wave wide kernel (0: one per CU of the wide stream, the default of both forms since round 4: in round 3's soaks
+  // every freeze happened with two 73.7 KB workgroups sharing a CU, none in 41 600 factorisations with one, scripts/r03_gpu_53.sh)
   int wide_wgs = 0;
 };
 
@@ -2263,6 +2302,12 @@ struct hiopamd_linsolver {
   bool flow_enabled = true;    // dataflow solve in use (false: stepwise 256-row solves)
   bool flow_dirty = false;     // dataflow solves were launched since the error word was last looked at
   bool flow_failed = false;    // sticky: a dataflow solve timed out since the last factorisation (its results were invalid)
+  // Retry copy: the upper triangle as the caller assembled it, taken before a DATAFLOW factorisation overwrites the matrix, so that a
+  // bounded wait that expires costs one stepwise factorisation instead of an error (hiopamd_linsolver_set_retry_copy; on by default:
+  // the callers of the reference's matrixChanged() cannot re-assemble; the native KKT objects re-assemble themselves and switch it off)
+  bool retry_copy = true;
+  double* Mretry = nullptr;   // n x n, upper 128 x 128 tiles used; allocated on first use
+  long df_timeouts = 0;       // bounded waits that expired over the object's life (hiopamd_linsolver_timeouts)
   bool factored = false;
   int inertia[3] = {0, 0, 0};
   double flops_fact = 0.0, flops_triu = 0.0;   // hiopLinSolStats::flopsFact / flopsTriuSolves (cumulative)
@@ -2367,7 +2412,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   // panel 0's diagonal block on the caller's stream, then fork
   int jp0 = 0;
   bool all_done = false;
-  bool use_df = df && df->enabled && df->flags && lookahead && lda == N && df->plan.N == N && df->plan.nchain >= 3;
+  // (the chain kernel's DF_ROLES workgroups wait for each other: each needs a reserved CU of its own)
+  bool use_df = df && df->enabled && df->flags && lookahead && lda == N && df->plan.N == N && df->plan.nchain >= 3 && ctx->chain_cus >= DF_ROLES &&
+                ctx->wide_cus >= 8;
   DfDeviceLock df_lock;   // released when this call returns (it synchronises the stream first)
   if(use_df && !df_lock.try_acquire()) use_df = false;   // another process factorises on this device right now: stepwise kernels
   {
@@ -2399,6 +2446,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     if(rc == HIOPAMD_OK) rc = dep(st, sd);
     if(rc != HIOPAMD_OK) return rc;
     a.spine_opt = df_spine_opt();
+    a.pipe = 0;
+    a.jpipe = 0;
+    a.has_far = P.has_far ? 1 : 0;
     a.dbg = std::getenv("HIOPAMD_DF_STAMPS") ? std::max(1, std::atoi(std::getenv("HIOPAMD_DF_STAMPS"))) : 0;   // profiling aid (1: all panels; 2 + j: phase sums of super-panel j only): per-super-panel time stamps, printed after the call
     a.off_ts = P.off_ver + (int64_t)P.nt * P.nt;
     a.off_ph = a.off_ts + 8 * (int64_t)(P.nsp + 1);
@@ -2434,7 +2484,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       a.dbg = 0;
       // on the context's own stream (no CU mask): DF_ROLES + 240 workgroups of one per CU are all resident on 256 CUs
       if(timed) (void)hipEventRecord(prof->get(), st);
-      hipLaunchKernelGGL(ldlt_df_one_kernel, dim3(DF_ROLES + 240), dim3(kBlock), 0, st, a);
+      hipLaunchKernelGGL(ldlt_df_one_kernel, dim3(DF_ROLES + ctx->wide_cus), dim3(kBlock), 0, st, a);
       if(timed) {
         (void)hipEventRecord(prof->get(), st);
         prof->flops += P.up_flops;
@@ -2444,9 +2494,24 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
     if(a.nwtasks > 0) {
       if(timed) (void)hipEventRecord(prof->get(), su);
-      // the resident workgroups of the 240 CUs of the wide stream (HIOPAMD_DF_WGS: timing aid — 240 = one workgroup per CU)
+      // ONE workgroup of the wide kernel per CU of the wide stream (ctx->wide_cus, 240 on MI355X with two reserved CUs per XCD).
+      // HIOPAMD_DF_WGS: timing aid — with the four-wave form a value above the number of CUs puts two workgroups on a CU, the faster
+      // and, once in ~1.6e4 factorisations, freezing shape of rounds 2-3; never the default.
       static const int wgs_env = std::getenv("HIOPAMD_DF_WGS") ? std::atoi(std::getenv("HIOPAMD_DF_WGS")) : 0;
-      const int wmax = wgs_env > 0 ? std::min(wgs_env, 240 * DF_WIDE_WG_PER_CU) : (df->wide_wgs > 0 ? df->wide_wgs : 240 * DF_WIDE_WG_PER_CU);
+      const bool form8 = P.form8;
+      if(form8) {
+        const int wmax = wgs_env > 0 ? std::min(wgs_env, ctx->wide_cus) : ctx->wide_cus;
+        const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
+        a.jretire = P.nwide;   // (nobody retires: there is no second workgroup on a CU)
+        static const int pipe_env = std::getenv("HIOPAMD_DF_PIPE") ? std::atoi(std::getenv("HIOPAMD_DF_PIPE")) : 3;
+        static const int pipej_env = std::getenv("HIOPAMD_DF_PIPEJ") ? std::atoi(std::getenv("HIOPAMD_DF_PIPEJ")) : -1;
+        a.pipe = pipe_env;
+        a.jpipe = pipej_env >= 0 ? pipej_env : (P.nwide + 1) / 2;
+        if(a.dbg) hipLaunchKernelGGL((ldlt_wide8_kernel<true>), dim3(grid), dim3(W8_THREADS), 0, su, a);
+        else hipLaunchKernelGGL((ldlt_wide8_kernel<false>), dim3(grid), dim3(W8_THREADS), 0, su, a);
+      } else {
+      const int wmax = wgs_env > 0 ? std::min(wgs_env, ctx->wide_cus * DF_WIDE_WG_PER_CU) : (df->wide_wgs > 0 ? df->wide_wgs : ctx->wide_cus);
+      if(wmax <= ctx->wide_cus) a.jretire = P.nwide;
       const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
       // 16-byte accesses need even N, lda, ldv (ldv = N); HIOPAMD_DF_TILE=1 forces the 8-byte form (A/B timing)
       static const int tile_env = std::getenv("HIOPAMD_DF_TILE") ? std::atoi(std::getenv("HIOPAMD_DF_TILE")) : 2;
@@ -2454,6 +2519,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       if(form2 && a.dbg) hipLaunchKernelGGL((ldlt_wide_kernel<2, true>), dim3(grid), dim3(kBlock), 0, su, a);
       else if(form2) hipLaunchKernelGGL((ldlt_wide_kernel<2, false>), dim3(grid), dim3(kBlock), 0, su, a);
       else hipLaunchKernelGGL((ldlt_wide_kernel<1, false>), dim3(grid), dim3(kBlock), 0, su, a);
+      }
       if(timed) {
         (void)hipEventRecord(prof->get(), su);
         prof->flops += P.up_flops;
@@ -3062,6 +3128,7 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->V);
   (void)hipFree(ls->ybuf);
   (void)hipFree(ls->Msave);
+  (void)hipFree(ls->Mretry);
   (void)hipFree(ls->rbuf);
   (void)hipFree(ls->Dblk);
   (void)hipFree(ls->Cd);
@@ -3266,10 +3333,6 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
     ls->df.enabled = df_was;
     if(df_this && r == HIOPAMD_ERR_TIMEOUT) {
       ls->df.skip_once = true;
-      if(ls->df.wide_wgs == 0) {
-        ls->df.wide_wgs = 240;
-        std::fprintf(stderr, "[hiop_amd] dataflow LDL^T timed out: this solver object goes on with one workgroup of the wide kernel per CU\n");
-      }
       if(++ls->df.strikes >= 3) {
         ls->df.enabled = false;
         std::fprintf(stderr, "[hiop_amd] dataflow LDL^T timed out three times in a row: this solver object uses the stepwise kernels from now on\n");
@@ -3279,17 +3342,31 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
     }
     return r;
   };
+  // the retry copy: only when this call will run the dataflow kernels (the stepwise kernels have no bounded waits) and no other copy
+  // of the matrix exists (safe mode keeps Msave)
+  const bool df_next = ls->df.enabled && !ls->df.skip_once && ls->df.flags && ls->df.plan.nchain >= 3;
+  const bool use_retry = ls->retry_copy && !ls->safe_mode && df_next && n > 0;
+  const dim3 tgrid((unsigned)((n + 127) / 128), (unsigned)((n + 127) / 128));
+  if(use_retry) {
+    if(!ls->Mretry) HIOPAMD_CHECK(hipMalloc((void**)&ls->Mretry, sizeof(double) * (size_t)n * n));
+    hipLaunchKernelGGL(ldlt_triu_copy_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->M, ls->Mretry, (int64_t)n);
+  }
   int rc = factor_once();
   if(rc == HIOPAMD_ERR_TIMEOUT) {
-    // The dataflow kernels gave up — a flag update another workgroup was waiting for did not arrive within the limit (DESIGN.md 3.1:
-    // seen once in a few thousand factorisations at N = 8192; two processes on one device can also starve the chain kernel's roles).
-    // The matrix is overwritten.  With a saved copy (safe mode) the factorisation is redone right away with the stepwise kernels;
-    // otherwise the caller re-assembles and calls again (the KKT objects do), and that call runs the stepwise kernels.
+    // The dataflow kernels gave up — a flag update another workgroup was waiting for did not arrive within the limit (DESIGN.md 3.1;
+    // two processes on one device can also starve the chain kernel's roles).  The matrix is overwritten.  With a copy (the retry copy,
+    // or safe mode's) the factorisation is redone right away with the stepwise kernels and the caller never sees the incident;
+    // without one (hiopamd_linsolver_set_retry_copy(ls, 0): the native KKT objects) the caller re-assembles and calls again, and
+    // that call runs the stepwise kernels.
+    ls->df_timeouts += 1;
     if(ls->safe_mode && n > 0) {
       HIOPAMD_CHECK(hipMemcpyAsync(ls->M, ls->Msave, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ls->ctx->stream));
       int rs = regularise();
       if(rs != HIOPAMD_OK) return rs;
       rc = factor_once();
+    } else if(use_retry) {
+      hipLaunchKernelGGL(ldlt_triu_copy_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mretry, ls->M, (int64_t)n);
+      rc = factor_once();   // (skip_once is set: the stepwise kernels)
     }
   }
   if(rc == HIOPAMD_ERR_SINGULAR) {
@@ -3394,6 +3471,24 @@ int hiopamd_linsolver_profile_read(const hiopamd_linsolver* ls, double* update_m
   if(update_ms_host) *update_ms_host = ls->prof.ms;
   if(update_flops_host) *update_flops_host = ls->prof.flops;
   if(update_launches_host) *update_launches_host = ls->prof.launches;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_linsolver_set_retry_copy(hiopamd_linsolver* ls, int enable)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  ls->retry_copy = enable != 0;
+  if(!ls->retry_copy && ls->Mretry) {
+    (void)hipStreamSynchronize(ls->ctx->stream);
+    (void)hipFree(ls->Mretry);
+    ls->Mretry = nullptr;
+  }
+  return HIOPAMD_OK;
+}
+int hiopamd_linsolver_timeouts(const hiopamd_linsolver* ls, int64_t* count_host)
+{
+  if(!ls || !count_host) return HIOPAMD_ERR_ARG;
+  *count_host = (int64_t)ls->df_timeouts;
   return HIOPAMD_OK;
 }
 

@@ -43,10 +43,19 @@ class LinSolverSymDense:
         self.ctx.sync()
         return out
 
-    # HIOPAMD_ERR_TIMEOUT (-6): a bounded wait of the dataflow factorisation expired, the matrix is overwritten, "the caller re-assembles
-    # and calls again" (include/hiop_amd.h; the native KKT objects do).  This wrapper is that caller when the matrix came through
+    # HIOPAMD_ERR_TIMEOUT (-6) only reaches a caller that switched the object's retry copy off (set_retry_copy(False): "I re-assemble and
+    # call again", what the native KKT objects do).  With the copy off this wrapper is that caller when the matrix came through
     # set_sys_matrix: it copies the source again and calls once more (the library runs that call with the stepwise kernels).
     retry_after_timeout = True
+
+    def set_retry_copy(self, enable: bool):
+        check(self._L.hiopamd_linsolver_set_retry_copy(self.h, 1 if enable else 0), "hiopamd_linsolver_set_retry_copy")
+
+    def timeouts(self) -> int:
+        """bounded waits of the dataflow factorisation that expired over this object's life"""
+        n = C.c_int64(0)
+        check(self._L.hiopamd_linsolver_timeouts(self.h, C.byref(n)), "hiopamd_linsolver_timeouts")
+        return n.value
 
     def matrix_changed(self) -> int:
         nneg = C.c_int(0)

@@ -35,7 +35,8 @@ typedef enum {
   HIOPAMD_ERR_SINGULAR = -4,  /* zero / non-finite pivot met */
   HIOPAMD_ERR_STATE = -5,     /* call sequence error (e.g. solve before factorize) */
   HIOPAMD_ERR_TIMEOUT = -6,   /* a bounded wait of a dataflow kernel expired: the factorisation did not complete and the matrix is
-                               * overwritten — re-assemble and call again (the object has switched itself to the stepwise kernels) */
+                               * overwritten — re-assemble and call again (that call runs the stepwise kernels).  Only returned by a
+                               * solver object whose retry copy was switched off (hiopamd_linsolver_set_retry_copy) */
   HIOPAMD_ERR_SOLVE = -7      /* a solve since the last check delivered invalid results (dataflow time-out) */
 } hiopamd_status;
 
@@ -462,6 +463,15 @@ int hiopamd_linsolver_growth(hiopamd_linsolver* ls, double* max_abs_u_host, doub
  * available and n >= 768; enable = 0 selects the stepwise kernels (one launch per super-panel step) — same results to
  * rounding, for A/B timing and as a fallback.  HIOPAMD_DF=0 in the environment sets the default off. */
 int hiopamd_linsolver_set_dataflow(hiopamd_linsolver* ls, int enable);
+/* Every wait of the dataflow kernels is bounded; one that expires aborts the factorisation with the matrix overwritten.  So that
+ * matrixChanged() keeps the reference's contract — "number of negative eigenvalues, or -1 for a singular matrix", nothing else
+ * (src/LinAlg/hiopLinSolver.hpp:117-130) — the object takes a copy of the upper triangle before a dataflow factorisation
+ * (~0.13 ms at n = 8192) and, after a time-out, restores it and factorises with the stepwise kernels inside the same call: the
+ * caller never sees HIOPAMD_ERR_TIMEOUT.  enable = 0 drops the copy — for callers that can re-assemble (the native KKT objects
+ * do): they get HIOPAMD_ERR_TIMEOUT and call again.  Default: on.  hiopamd_linsolver_timeouts: how many bounded waits have
+ * expired over the object's life (0 in every soak of the default configuration, profiles/r04_soak). */
+int hiopamd_linsolver_set_retry_copy(hiopamd_linsolver* ls, int enable);
+int hiopamd_linsolver_timeouts(const hiopamd_linsolver* ls, int64_t* count_host);
 /* static schedule of the dataflow factorisation for order n (host only): see csrc/ldlt.hip */
 int hiopamd_ldlt_dataflow_plan(int n, int* dims8_host, int* chain_tasks_host, int* wide_tasks_host, int64_t wide_cap);
 /* the wide kernel's task queues for order n (host only): per super-panel {first TR task, TR tasks, first NEAR update task,

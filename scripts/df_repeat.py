@@ -32,6 +32,8 @@ t0 = time.perf_counter(); done = 0
 for o in range(nobj):
     ls = LinSolverSymDense(ctx, N)
     ls.retry_after_timeout = False        # (the soak wants to SEE the time-outs)
+    if os.environ.get("DF_RETRY_COPY", "0") != "1":
+        ls.set_retry_copy(False)          # ... as errors; DF_RETRY_COPY=1: the shipped configuration, time-outs counted through ls.timeouts()
     for rep in range(reps):
         ls.set_sys_matrix(M); ctx.sync(); tc = time.perf_counter()
         try:
@@ -45,6 +47,9 @@ for o in range(nobj):
             print("factorisation %d took %.3f s" % (done, dtc), flush=True)
         slowest = max(slowest, dtc)
         done += 1
+        if os.environ.get("DF_RETRY_COPY", "0") == "1" and (rep % 50 == 49 or rep == reps - 1) and ls.timeouts() > 0:
+            print("time-outs absorbed by the retry copy after %d factorisations: %d" % (done, ls.timeouts()), flush=True)
+            raise SystemExit(3)
         if verify:
             x = b.clone(); ls.solve(x); ctx.sync()
             res = float((M @ x - b).abs().max() / b.abs().max())

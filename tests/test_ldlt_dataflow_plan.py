@@ -283,9 +283,12 @@ class Sim:
         self.updone[j] += 1
 
 
-def replay(A, plan, n_workers, seed, retire_at=None):
+def replay(A, plan, n_workers, seed, retire_at=None, ahead=False):
     """retire_at: the super-panel at which every second worker (the \"second workgroup of its CU\") leaves the wide kernel
-    (HIOPAMD_DF_RETIRE in csrc/ldlt.hip); None: nobody leaves early"""
+    (HIOPAMD_DF_RETIRE in csrc/ldlt.hip); None: nobody leaves early.
+    ahead: the eight-wave wide kernel (csrc/ldlt_wide8_body.inc) selects its NEXT task during the last stages of an ordinary update
+    tile — a worker whose update task has started (its inputs are there) may take one more task, never an early substitution task,
+    and holds it until the current one is done"""
     rnd = random.Random(seed)
     sim = Sim(A, plan)
     roles = plan["roles"]
@@ -314,7 +317,10 @@ def replay(A, plan, n_workers, seed, retire_at=None):
     ptr = [[0, 0, 0] for _ in range(n_workers)]   # (jtr, jn, jf) of each worker
     done_w = 0
 
-    def take(w):
+    nxt = [None] * n_workers      # task selected ahead by each worker
+    started = [False] * n_workers
+
+    def take(w, allow_early=True):
         """the selection loop of ldlt_wide_kernel (one pass): returns a task index, None (nothing eligible), or 'done'"""
         while True:
             jtr, jn, jf = ptr[w]
@@ -348,7 +354,7 @@ def replay(A, plan, n_workers, seed, retire_at=None):
                     return int(FQ[jf][0] + i)
             # nothing eligible: an EARLY substitution task (the chain has only started C_jtr); it is held until C_jtr is
             # complete (the kernel advances it block row by block row — here it simply blocks its worker, which is stricter)
-            if jtr < nw and trq[jtr] < Q[jtr][1] and 1 <= sim.cdone[jtr] < 10 and \
+            if allow_early and jtr < nw and trq[jtr] < Q[jtr][1] and 1 <= sim.cdone[jtr] < 10 and \
                     (jtr < 1 or upq[jtr - 1] >= Q[jtr - 1][3]) and (jtr < NVB or sim.updone[jtr - NVB] >= sim.upcnt[jtr - NVB]):
                 i = trq[jtr]; trq[jtr] += 1
                 return int(Q[jtr][0] + i)
@@ -377,6 +383,10 @@ def replay(A, plan, n_workers, seed, retire_at=None):
                     progressed = True
                     break            # one step, then re-shuffle: many different interleavings
             else:
+                if held[who] is None and nxt[who] is not None:
+                    held[who], nxt[who] = nxt[who], None
+                    progressed = True
+                    break
                 if held[who] is None:
                     got = take(who)
                     if got == "done":
@@ -389,12 +399,22 @@ def replay(A, plan, n_workers, seed, retire_at=None):
                     progressed = True   # taking a task is a step of its own: the run may have to wait
                     break
                 if sim.wide_ready(wt[held[who]]):
-                    sim.wide_run(wt[held[who]])
+                    tk = wt[held[who]]
+                    if ahead and not started[who] and tk[0] in (UP, UP2) and 128 * (tk[2] + 1) <= sim.N and 128 * (tk[3] + 1) <= sim.N \
+                            and rnd.random() < 0.7:
+                        started[who] = True      # in its tile loop: one non-blocking look at the queues
+                        got = take(who, allow_early=False)
+                        if got not in (None, "done"):
+                            nxt[who] = got
+                        progressed = True
+                        break
+                    sim.wide_run(tk)
+                    started[who] = False
                     held[who] = None
                     done_w += 1
                     progressed = True
                     break
-        assert progressed, f"deadlock: chain cursors {cur}, held {held}, queues TR {trq} UP {upq}"
+        assert progressed, f"deadlock: chain cursors {cur}, held {held}, selected ahead {nxt}, queues TR {trq} UP {upq}"
     assert done_w == len(wt)
     return sim
 
@@ -434,6 +454,20 @@ def test_schedule_stays_live_and_sound_when_every_second_worker_leaves_early(n, 
     for j in range(plan["nsp"]):
         got[256 * j:256 * j + 256, 256 * j:256 * j + 256] = np.triu(sim.Cd[j])
     assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n,workers,seed", [(1536, 1, 7), (1536, 5, 8), (2048, 16, 9), (1024 + 100, 3, 10)])
+def test_schedule_stays_live_and_sound_when_tasks_are_selected_ahead(n, workers, seed):
+    """Round 4: the eight-wave wide kernel takes its next task while the current update tile is still in its loop."""
+    plan = get_plan(n)
+    A = quasi_definite(n, seed)
+    sim = replay(A, plan, workers, seed, ahead=True)
+    want = ldl_nopiv(A)
+    s = 256 * plan["nchain"]
+    got = np.triu(sim.A)
+    for j in range(plan["nchain"]):
+        got[256 * j:256 * j + 256, 256 * j:256 * j + 256] = np.triu(sim.Cd[j])
+    assert np.abs(got[:s] - want[:s]).max() < 1e-10 * np.abs(want).max()
 
 
 def test_ragged_order_hands_over_a_consistent_state():

@@ -24,6 +24,7 @@ CHILD = textwrap.dedent('''
     M = torch.rand(N, N, generator=g, device="cuda", dtype=torch.float64) * 1e-3
     M = M + M.T + torch.eye(N, device="cuda", dtype=torch.float64) * 10.0
     ls = LinSolverSymDense(ctx, N)
+    ls.set_retry_copy(False)             # (the time-outs are to be SEEN here)
     ls.retry_after_timeout = False
     seen = 0
     for rep in range(3):
