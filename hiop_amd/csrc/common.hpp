@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <vector>
 
 #include "../../include/hiop_amd.h"
 
@@ -36,7 +38,7 @@ namespace hiopamd {
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kMaxGrid = 2048;       // 256 CUs x 8 blocks; grid-stride beyond
 constexpr int kPartials = kMaxGrid;  // reduction partial slots
-constexpr int kHostSlots = 64;
+constexpr int kHostSlots = 256;      // doubles of pinned result space = 64 reduction results of up to 4 doubles
 
 inline int grid_for(int64_t n, int per_thread = 1)
 {
@@ -73,6 +75,11 @@ struct hiopamd_ctx {
   hipEvent_t ev_pool[160] = {nullptr};
   int n_events = 0;
   void* spans = nullptr;               // hiopamd::SpanState (context.hip): KKT / linear-solver run-stats spans
+  // deferred reductions (hiopamd_ctx_reduce_begin / _end): the reductions launched inside the bracket write their results to consecutive
+  // pinned slots and are finished on the host — sqrt, Kahan fold, the copy to the caller's variable — after ONE synchronisation
+  int defer_depth = 0;
+  int n_pending = 0;
+  std::vector<std::function<void()>> pending;
 };
 
 namespace hiopamd {
@@ -151,4 +158,44 @@ inline void* ctx_workspace(hiopamd_ctx* ctx, size_t bytes)
   ctx->work_bytes = nb;
   return ctx->d_work;
 }
+// the deferred reductions of a context: one synchronisation, then every pending result is finished in launch order
+static inline int reduce_flush(hiopamd_ctx* ctx)
+{
+  if(ctx->n_pending == 0) return HIOPAMD_OK;
+  HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+  for(auto& f : ctx->pending) f();
+  ctx->pending.clear();
+  ctx->n_pending = 0;
+  return HIOPAMD_OK;
+}
+
+// Library code that calls the scalar-returning vector entry points and goes on with the values must not be caught by a caller's
+// bracket.  ReduceNow: immediate mode for a scope.  ReduceBatch: a bracket of the library's own — `flush()` makes every pending
+// result (the caller's included) valid; results still pending when the scope is left (an error return) are dropped, never written.
+struct ReduceNow {
+  hiopamd_ctx* c;
+  int saved;
+  explicit ReduceNow(hiopamd_ctx* ctx) : c(ctx), saved(ctx->defer_depth) { c->defer_depth = 0; }
+  ~ReduceNow() { c->defer_depth = saved; }
+  ReduceNow(const ReduceNow&) = delete;
+  ReduceNow& operator=(const ReduceNow&) = delete;
+};
+struct ReduceBatch {
+  hiopamd_ctx* c;
+  int saved, base;
+  explicit ReduceBatch(hiopamd_ctx* ctx) : c(ctx), saved(ctx->defer_depth), base(ctx->n_pending) { c->defer_depth = saved + 1; }
+  int flush() { return reduce_flush(c); }
+  ~ReduceBatch()
+  {
+    if(c->n_pending > base) {   // left without flush(): the locals those results were meant for are gone
+      (void)hipStreamSynchronize(c->stream);
+      c->pending.resize((size_t)base);
+      c->n_pending = base;
+    }
+    c->defer_depth = saved;
+  }
+  ReduceBatch(const ReduceBatch&) = delete;
+  ReduceBatch& operator=(const ReduceBatch&) = delete;
+};
+
 }  // namespace hiopamd

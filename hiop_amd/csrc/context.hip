@@ -230,6 +230,27 @@ int hiopamd_ctx_sync(hiopamd_ctx* c)
 
 void* hiopamd_ctx_stream(hiopamd_ctx* c) { return (void*)c->stream; }
 
+// Deferred reductions (csrc/device_utils.hpp::launch_reduce_fin): between _begin and _end the scalar-returning vector entry points
+// (dot, norms, sum, min, log-barrier, linear damping, fraction-to-the-boundary) do not synchronise; their host results are written by
+// _end after ONE synchronisation of the stream.  Brackets nest; the outermost _end flushes.
+int hiopamd_ctx_reduce_begin(hiopamd_ctx* c)
+{
+  if(!c) return HIOPAMD_ERR_ARG;
+  c->defer_depth += 1;
+  return HIOPAMD_OK;
+}
+int hiopamd_ctx_reduce_end(hiopamd_ctx* c)
+{
+  if(!c || c->defer_depth <= 0) return HIOPAMD_ERR_STATE;
+  c->defer_depth -= 1;
+  if(c->defer_depth > 0 || c->n_pending == 0) return HIOPAMD_OK;
+  HIOPAMD_CHECK(hipStreamSynchronize(c->stream));
+  for(auto& f : c->pending) f();
+  c->pending.clear();
+  c->n_pending = 0;
+  return HIOPAMD_OK;
+}
+
 int hiopamd_ctx_comm(const hiopamd_ctx* c, int* rank_host, int* size_host)
 {
   if(!c || !rank_host || !size_host) return HIOPAMD_ERR_ARG;

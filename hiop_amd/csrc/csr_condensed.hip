@@ -233,9 +233,15 @@ int hiopamd_csr_condensed_numeric(hiopamd_csr_condensed* c, const double* J_val,
   if(rc != HIOPAMD_OK) return rc;
   {
     const int64_t *hu = c->hpos_u, *hl = c->hpos_l;
-    rc = hiopamd::launch_ew(ctx, c->nnzH, [=] __device__(int64_t k) {   // duplicates in the triplet list accumulate, like add_matrix
-      atomicAdd(&vals[hu[k]], H_val[k]);
-      if(hl[k] >= 0) atomicAdd(&vals[hl[k]], H_val[k]);
+    const int64_t nnzH = c->nnzH;
+    rc = hiopamd::launch_ew(ctx, nnzH, [=] __device__(int64_t k) {   // duplicates in the triplet list accumulate, like add_matrix
+      // (ordered triplets: the duplicates of one (i, j) are neighbours and map to the same position; the first of the run adds them in
+      //  storage order and touches the destination once — no result depends on the order in which threads arrive)
+      if(k > 0 && hu[k - 1] == hu[k]) return;
+      double acc = 0.0;
+      for(int64_t q = k; q < nnzH && hu[q] == hu[k]; ++q) acc += H_val[q];
+      atomicAdd(&vals[hu[k]], acc);
+      if(hl[k] >= 0) atomicAdd(&vals[hl[k]], acc);
     });
     if(rc != HIOPAMD_OK) return rc;
     const int64_t* dp = c->dpos;

@@ -107,21 +107,47 @@ struct kahan_t {
   double s, c;
 };
 
-template <class T, class Op>
-static inline int launch_reduce(hiopamd_ctx* ctx, int64_t n, Op op, T* result_host)
+// fin(const T&) runs on the host when the value has arrived: right away (one stream synchronisation per reduction: the behaviour of
+// the reference's bool / double returning methods), or — inside hiopamd_ctx_reduce_begin / _end — when the bracket is closed.
+// may_defer = false: the caller needs the value now (host logic follows): the result takes the next free slot, the stream is
+// synchronised, pending results of the bracket stay pending.
+template <class T, class Op, class Fin>
+static inline int launch_reduce_fin(hiopamd_ctx* ctx, int64_t n, Op op, Fin fin, bool may_defer = true)
 {
   static_assert(sizeof(T) <= 4 * sizeof(double), "partials slot too small");
+  constexpr int kSlots = kHostSlots / 4;
+  if(ctx->n_pending >= kSlots) {
+    const int rf = reduce_flush(ctx);
+    if(rf != HIOPAMD_OK) return rf;
+  }
+  const int slot = ctx->n_pending;
   T* partials = reinterpret_cast<T*>(ctx->d_partials);
-  T* out_host_dev = reinterpret_cast<T*>(ctx->h_result_dev);
-  T* out_host = reinterpret_cast<T*>(ctx->h_result);
+  T* out_host_dev = reinterpret_cast<T*>(ctx->h_result_dev + 4 * slot);
+  T* out_host = reinterpret_cast<T*>(ctx->h_result + 4 * slot);
   int g = n > 0 ? grid_for(n, 8) : 1;
   hipLaunchKernelGGL((reduce_stage1<T, Op>), dim3(g), dim3(kBlock), 0, ctx->stream, n, op, partials);
   hipLaunchKernelGGL((reduce_stage2<T, Op>), dim3(1), dim3(kBlock), 0, ctx->stream, g, op, partials,
                      reinterpret_cast<T*>(ctx->d_result), out_host_dev);
   HIOPAMD_CHECK(hipGetLastError());
+  if(may_defer && ctx->defer_depth > 0) {
+    ctx->pending.emplace_back([out_host, fin]() { fin(*out_host); });
+    ctx->n_pending += 1;
+    return HIOPAMD_OK;
+  }
   HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
-  *result_host = *out_host;
+  fin(*out_host);
   return HIOPAMD_OK;
+}
+template <class T, class Op>
+static inline int launch_reduce(hiopamd_ctx* ctx, int64_t n, Op op, T* result_host)
+{
+  return launch_reduce_fin<T>(ctx, n, op, [result_host](const T& v) { *result_host = v; }, false);
+}
+// ... for the public scalar-returning entry points: the caller's result variable is written when the bracket is closed
+template <class T, class Op>
+static inline int launch_reduce_deferrable(hiopamd_ctx* ctx, int64_t n, Op op, T* result_host)
+{
+  return launch_reduce_fin<T>(ctx, n, op, [result_host](const T& v) { *result_host = v; }, true);
 }
 
 }  // namespace hiopamd

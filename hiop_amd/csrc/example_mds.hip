@@ -308,7 +308,10 @@ int hiopamd_mdsex1_eval_f(hiopamd_mdsex1* p, const double* x, double* obj_host)
     const double* y = x + 2 * (int64_t)p->ns;
     int rc = hiopamd_mat_times_vec(ctx, p->nd, p->nd, p->Q, p->nd, 0.0, p->buf, 1.0, y);
     if(rc != HIOPAMD_OK) return rc;
-    rc = hiopamd_vec_dot(ctx, p->nd, p->buf, y, &yQy);   // synchronises
+    {
+      hiopamd::ReduceNow now(ctx);
+      rc = hiopamd_vec_dot(ctx, p->nd, p->buf, y, &yQy);   // synchronises
+    }
     if(rc != HIOPAMD_OK) return rc;
   }
   double h[3];

@@ -158,12 +158,9 @@ struct MdsSolver {
     return HIOPAMD_OK;
   }
 
-  int user_failed(const char* what)
-  {
-    std::fprintf(stderr, "hiop_amd: user callback %s reported failure\n", what);
-    status = Error_In_User_Function;
-    return HIOPAMD_ERR_STATE;
-  }
+  // The return values of the user's callbacks are IGNORED, as by the reference's wrappers cppUserProblemMDS / cppUserProblemDense
+  // (src/Interface/chiopInterface.hpp:125-214 call the C function and return true whatever it returned): a binding whose callbacks
+  // return 1, "true" or nothing in particular behaves here as it does there.
 
   // eval_f (+ eval_cons): hiopAlgFilterIPMBase::evalNlp_funcOnly, hiopAlgFilterIPM.cpp:714-731
   int eval_func(const double* x_dev, double* f, double* cons_dev, double* c_dev, double* d_dev)
@@ -173,12 +170,12 @@ struct MdsSolver {
     void* ud = dprob ? dprob->user_data : prob->user_data;
     auto cb_f = dprob ? dprob->eval_f : prob->eval_f;
     auto cb_c = dprob ? dprob->eval_cons : prob->eval_cons;
-    if(cb_f(n, x, 1, f, ud) != 0) return user_failed("eval_f");
+    (void)cb_f(n, x, 1, f, ud);
     if(dev_cb) {
-      if(cb_c(n, m, x, 0, cons_dev, ud) != 0) return user_failed("eval_cons");
+      (void)cb_c(n, m, x, 0, cons_dev, ud);
     } else {
       h_buf.resize((size_t)std::max(m, 1));
-      if(cb_c(n, m, x, 0, h_buf.data(), ud) != 0) return user_failed("eval_cons");
+      (void)cb_c(n, m, x, 0, h_buf.data(), ud);
       RC(h2d(cons_dev, h_buf.data(), sizeof(double) * (size_t)m));
     }
     // c = cons[eq], d = cons[ineq]   (hiopNlpFormulation::eval_c_d, hiopNlpFormulation.cpp:1045-1075)
@@ -203,12 +200,12 @@ struct MdsSolver {
       const size_t szJ = (size_t)m * (size_t)n;
       if(dev_cb) {
         RC(hiopamd_ctx_sync(ctx));
-        if(dprob->eval_grad_f(n, x, 0, d_grad.p, dprob->user_data) != 0) return user_failed("eval_grad_f");
-        if(dprob->eval_Jac_cons(n, m, x, 0, d_Jall.p, dprob->user_data) != 0) return user_failed("eval_Jac_cons");
+        (void)dprob->eval_grad_f(n, x, 0, d_grad.p, dprob->user_data);
+        (void)dprob->eval_Jac_cons(n, m, x, 0, d_Jall.p, dprob->user_data);
       } else {
         std::vector<double> g((size_t)n), jj(std::max<size_t>(szJ, 1));
-        if(dprob->eval_grad_f(n, x, 0, g.data(), dprob->user_data) != 0) return user_failed("eval_grad_f");
-        if(dprob->eval_Jac_cons(n, m, x, 0, jj.data(), dprob->user_data) != 0) return user_failed("eval_Jac_cons");
+        (void)dprob->eval_grad_f(n, x, 0, g.data(), dprob->user_data);
+        (void)dprob->eval_Jac_cons(n, m, x, 0, jj.data(), dprob->user_data);
         RC(h2d(d_grad.p, g.data(), sizeof(double) * (size_t)n));
         RC(h2d(d_Jall.p, jj.data(), sizeof(double) * szJ));
         RC(hiopamd_ctx_sync(ctx));
@@ -237,22 +234,18 @@ struct MdsSolver {
     }
     if(dev_cb) {
       RC(hiopamd_ctx_sync(ctx));
-      if(prob->eval_grad_f(n, x, 0, d_grad.p, prob->user_data) != 0) return user_failed("eval_grad_f");
-      if(prob->eval_Jac_cons(n, m, x, 0, ns, nd, nnzJ, nullptr, nullptr, d_MJ.p, d_JacD.p, prob->user_data) != 0)
-        return user_failed("eval_Jac_cons");
-      if(prob->eval_Hess_Lagr(n, m, x, 0, s_f, d_lambda.p, 1, ns, nd, nnzH, nullptr, nullptr, d_MH.p, d_HDD.p, 0, nullptr, nullptr,
-                              nullptr, prob->user_data) != 0)
-        return user_failed("eval_Hess_Lagr");
+      (void)prob->eval_grad_f(n, x, 0, d_grad.p, prob->user_data);
+      (void)prob->eval_Jac_cons(n, m, x, 0, ns, nd, nnzJ, nullptr, nullptr, d_MJ.p, d_JacD.p, prob->user_data);
+      (void)prob->eval_Hess_Lagr(n, m, x, 0, s_f, d_lambda.p, 1, ns, nd, nnzH, nullptr, nullptr, d_MH.p, d_HDD.p, 0, nullptr, nullptr,
+                              nullptr, prob->user_data);
     } else {
       std::vector<double> g((size_t)n), mj((size_t)std::max(nnzJ, 1)), jd(std::max<size_t>(szJD, 1)), lam((size_t)std::max(m, 1)),
           mh((size_t)std::max(nnzH, 1)), hd(std::max<size_t>(szHD, 1));
-      if(prob->eval_grad_f(n, x, 0, g.data(), prob->user_data) != 0) return user_failed("eval_grad_f");
-      if(prob->eval_Jac_cons(n, m, x, 0, ns, nd, nnzJ, nullptr, nullptr, mj.data(), jd.data(), prob->user_data) != 0)
-        return user_failed("eval_Jac_cons");
+      (void)prob->eval_grad_f(n, x, 0, g.data(), prob->user_data);
+      (void)prob->eval_Jac_cons(n, m, x, 0, ns, nd, nnzJ, nullptr, nullptr, mj.data(), jd.data(), prob->user_data);
       RC(d2h(lam.data(), d_lambda.p, sizeof(double) * (size_t)m));
-      if(prob->eval_Hess_Lagr(n, m, x, 0, s_f, lam.data(), 1, ns, nd, nnzH, nullptr, nullptr, mh.data(), hd.data(), 0, nullptr,
-                              nullptr, nullptr, prob->user_data) != 0)
-        return user_failed("eval_Hess_Lagr");
+      (void)prob->eval_Hess_Lagr(n, m, x, 0, s_f, lam.data(), 1, ns, nd, nnzH, nullptr, nullptr, mh.data(), hd.data(), 0, nullptr,
+                              nullptr, nullptr, prob->user_data);
       RC(h2d(d_grad.p, g.data(), sizeof(double) * (size_t)n));
       RC(h2d(d_MJ.p, mj.data(), sizeof(double) * (size_t)nnzJ));
       RC(h2d(d_JacD.p, jd.data(), sizeof(double) * szJD));
@@ -294,8 +287,10 @@ struct MdsSolver {
     RC(launch_ew(ctx, neq, [=] __device__(int64_t i) { tc[i] = crhs[i] - c[i]; }));
     RC(launch_ew(ctx, nineq, [=] __device__(int64_t i) { td[i] = dd[i] - d[i]; }));
     double a = 0.0, b = 0.0;
+    ReduceBatch rb(ctx);   // both norms in one host round trip
     if(neq) RC(hiopamd_vec_onenorm(ctx, neq, tc, &a));
     if(nineq) RC(hiopamd_vec_onenorm(ctx, nineq, td, &b));
+    RC(rb.flush());
     *out = a + b;
     return HIOPAMD_OK;
   }
@@ -314,8 +309,10 @@ struct MdsSolver {
       RC(hiopamd_vec_add_linear_damping_term(ctx, nineq, gd, d_idl.p, d_idu.p, 1.0, o.kappa_d * mu));
     }
     double a = 0.0, b = 0.0;
+    ReduceBatch rb(ctx);
     RC(hiopamd_vec_dot(ctx, n, dirp + off[0], gx, &a));
     if(nineq) RC(hiopamd_vec_dot(ctx, nineq, dirp + off[1], gd, &b));
+    RC(rb.flush());
     *out = a + b;
     return HIOPAMD_OK;
   }
@@ -326,18 +323,17 @@ struct MdsSolver {
 
   int errors(const double* norms, Errors* e)   // evalNlpAndLogErrors, hiopAlgFilterIPM.cpp:636-712
   {
-    double bou = 0.0, eq = 0.0, v = 0.0;
-    for(int p = 8; p < 12; ++p) {
-      if(off[p + 1] > off[p]) {
-        RC(hiopamd_vec_onenorm(ctx, off[p + 1] - off[p], it.p + off[p], &v));
-        bou += v;
-      }
-    }
-    for(int p = 2; p < 4; ++p) {
-      if(off[p + 1] > off[p]) {
-        RC(hiopamd_vec_onenorm(ctx, off[p + 1] - off[p], it.p + off[p], &v));
-        eq += v;
-      }
+    double bou = 0.0, eq = 0.0;
+    {
+      double v[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      ReduceBatch rb(ctx);   // the six one-norms of the multipliers in one host round trip (they were six)
+      for(int p = 8; p < 12; ++p)
+        if(off[p + 1] > off[p]) RC(hiopamd_vec_onenorm(ctx, off[p + 1] - off[p], it.p + off[p], &v[p]));
+      for(int p = 2; p < 4; ++p)
+        if(off[p + 1] > off[p]) RC(hiopamd_vec_onenorm(ctx, off[p + 1] - off[p], it.p + off[p], &v[p]));
+      RC(rb.flush());
+      for(int p = 8; p < 12; ++p) bou += v[p];
+      for(int p = 2; p < 4; ++p) eq += v[p];
     }
     const double ncomp = n_complem, mm = (double)m;
     double sd = std::fmax(o.smax, (bou + eq) / (ncomp + mm)) / o.smax;
@@ -449,13 +445,12 @@ int MdsSolver::setup()
   RC(hiopamd_ctx_create(&ctx, nullptr));
   hiop_size_type nn = 0, mm = 0;
   void* ud = dprob ? dprob->user_data : prob->user_data;
-  if((dprob ? dprob->get_prob_sizes : prob->get_prob_sizes)(&nn, &mm, ud) != 0) return user_failed("get_prob_sizes");
+  (void)(dprob ? dprob->get_prob_sizes : prob->get_prob_sizes)(&nn, &mm, ud);
   n = nn;
   m = mm;
   if(!dprob) {
     hiop_size_type a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
-    if(prob->get_sparse_dense_blocks_info(&a, &b, &c, &d, &e, &f, prob->user_data) != 0)
-      return user_failed("get_sparse_dense_blocks_info");
+    (void)prob->get_sparse_dense_blocks_info(&a, &b, &c, &d, &e, &f, prob->user_data);
     ns = a;
     nd = b;
     nnzJ = c + d;
@@ -470,8 +465,8 @@ int MdsSolver::setup()
   xu.resize(n);
   cl.resize(std::max(m, 1));
   cu.resize(std::max(m, 1));
-  if((dprob ? dprob->get_vars_info : prob->get_vars_info)(n, xl.data(), xu.data(), ud) != 0) return user_failed("get_vars_info");
-  if((dprob ? dprob->get_cons_info : prob->get_cons_info)(m, cl.data(), cu.data(), ud) != 0) return user_failed("get_cons_info");
+  (void)(dprob ? dprob->get_vars_info : prob->get_vars_info)(n, xl.data(), xu.data(), ud);
+  (void)(dprob ? dprob->get_cons_info : prob->get_cons_info)(m, cl.data(), cu.data(), ud);
   // Fixed variables (xlow == xupp).  MDS interface: the reference's fixed_var option is at its default "none" there and the solver
   // terminates (hiopNlpFormulation.cpp:359-366) — so does this one.  Dense interface: hiop_dense_create_problem sets fixed_var = relax
   // (chiopInterface.cpp:138), and with bound_relax_perturb > 0 (default 1e-8) it is the bounds relaxer that opens them
@@ -536,15 +531,13 @@ int MdsSolver::setup()
     RC(h2d(x0d.p, x0.data(), sizeof(double) * (size_t)n));
     RC(hiopamd_ctx_sync(ctx));
     double* xcb = dev_cb ? x0d.p : x0.data();
-    if(prob->eval_Jac_cons(n, m, xcb, 1, ns, nd, nnzJ, iJ.data(), jJ.data(), nullptr, nullptr, prob->user_data) != 0)
-      return user_failed("eval_Jac_cons (pattern)");
+    (void)prob->eval_Jac_cons(n, m, xcb, 1, ns, nd, nnzJ, iJ.data(), jJ.data(), nullptr, nullptr, prob->user_data);
     DevBuf<double> lam0;
     RC(lam0.alloc((size_t)std::max(m, 1)));
     HIOPAMD_CHECK(hipMemset(lam0.p, 0, sizeof(double) * (size_t)std::max(m, 1)));
     std::vector<double> lamh((size_t)std::max(m, 1), 0.0);
-    if(prob->eval_Hess_Lagr(n, m, xcb, 1, 1.0, dev_cb ? lam0.p : lamh.data(), 1, ns, nd, nnzH, iH.data(), jH.data(), nullptr, nullptr,
-                            0, nullptr, nullptr, nullptr, prob->user_data) != 0)
-      return user_failed("eval_Hess_Lagr (pattern)");
+    (void)prob->eval_Hess_Lagr(n, m, xcb, 1, 1.0, dev_cb ? lam0.p : lamh.data(), 1, ns, nd, nnzH, iH.data(), jH.data(), nullptr, nullptr,
+                            0, nullptr, nullptr, nullptr, prob->user_data);
   }
   // split the Jacobian triplets by row class, order preserved (copyRowsFrom keeps the (row, col) order of the source)
   std::vector<int> rank_eq(std::max(m, 1), -1), rank_in(std::max(m, 1), -1);
@@ -765,7 +758,7 @@ int MdsSolver::run()
     // ---- barrier update, :2291-2328 with update_log_barrier_params :556-567
     while(e.log <= o.kappa_eps * mu) {
       double new_mu = std::fmax(0.0, std::fmin(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
-      new_mu = std::fmax(new_mu, std::fmin(eps_tol, o.comp_tol) / (10. + 1.));
+      new_mu = std::fmax(new_mu, std::fmin(eps_tol, o.comp_tol / s_f) / (10. + 1.));   // target_comp_tol = comp_tol / obj_scale, hiopAlgFilterIPM.cpp:561
       if(std::fabs(new_mu - mu) < 1e-16) break;
       mu = new_mu;
       tau = std::fmax(o.tau_min, 1.0 - mu);
@@ -864,7 +857,7 @@ int MdsSolver::run()
           ls_status = st;
           ap = ap_soc;
           dirp = dir_soc.p;
-          theta_trial = th;
+          theta_trial = th;   // (the pinned trajectories need the corrected point's theta in the filter entry)
           gpd_computed = gpd_soc_computed;
           gpd = gpd_soc;
           use_soc = 1;

@@ -345,7 +345,10 @@ int backend_jac_trans_times_vec_add(hiopamd_kkt_xycyd* h, double* y, const doubl
 int slab_dot(hiopamd_kkt_xycyd* h, const double* a, const double* b, double* out)
 {
   hiopamd_ctx* ctx = h->ctx;
-  if(!(h->kind == KIND_LOWRANK && ctx->allreduce)) return hiopamd_vec_dot(ctx, h->dim, a, b, out);
+  if(!(h->kind == KIND_LOWRANK && ctx->allreduce)) {
+    ReduceNow now(ctx);   // (the Krylov loops go on with the value)
+    return hiopamd_vec_dot(ctx, h->dim, a, b, out);
+  }
   // column partition: x, sxl, sxu, zl, zu are distributed, the rest is replicated
   // (hiopVectorCompoundPD::dotProductWith sums the parts' own dot products)
   dot2_t r{0.0, 0.0};
@@ -1332,6 +1335,7 @@ int hiopamd_iterate_fraction_to_the_bdry(hiopamd_kkt_xycyd* h, const double* it,
       s4[q] = pat[pidx];
     }
     double r = 1.0;
+    ReduceNow now(ctx);
     RC(hiopamd_vec_fraction_to_the_bdry_multi(ctx, 4, n4, x4, d4, s4, tau, &r));
     *out = r;
     return HIOPAMD_OK;
@@ -1437,7 +1441,10 @@ int hiopamd_iterate_adjust_small_slacks(hiopamd_kkt_xycyd* h, double* it, const 
     const double *sel_ = pat[q], *bound = bnd[q];
     if(!bound) return HIOPAMD_ERR_STATE;
     double slack_min = 0.0;
-    RC(hiopamd_vec_min_w_pattern(ctx, n, slack, sel_, &slack_min));   // :435
+    {
+      ReduceNow now(ctx);
+      RC(hiopamd_vec_min_w_pattern(ctx, n, slack, sel_, &slack_min));   // :435
+    }
     if(q < 2) {
       // the x-sized slacks are column-sharded on the low-rank back-end: hiopVectorPar::min_w_pattern all-reduces (MIN,
       // hiopVectorPar.cpp:833-836), so every rank takes the same branch below
@@ -1507,12 +1514,16 @@ int hiopamd_iterate_eval_log_barrier(hiopamd_kkt_xycyd* h, const double* it, dou
   hiopamd_ctx* ctx = h->ctx;
   const int64_t* o = h->off;
   double a = 0, b = 0, c = 0, d = 0;
-  RC(hiopamd_vec_log_barrier(ctx, h->nx, it + o[4], h->ixl, &a));
-  RC(hiopamd_vec_log_barrier(ctx, h->nx, it + o[5], h->ixu, &b));
+  {
+    ReduceBatch rb(ctx);   // the four sums in one host round trip
+    RC(hiopamd_vec_log_barrier(ctx, h->nx, it + o[4], h->ixl, &a));
+    RC(hiopamd_vec_log_barrier(ctx, h->nx, it + o[5], h->ixu, &b));
+    RC(hiopamd_vec_log_barrier(ctx, h->nd, it + o[6], h->idl, &c));
+    RC(hiopamd_vec_log_barrier(ctx, h->nd, it + o[7], h->idu, &d));
+    RC(rb.flush());
+  }
   red4_t r{{0.0, 0.0, a + b, 0.0}};
   RC(xpart_allreduce(h, &r, 2));
-  RC(hiopamd_vec_log_barrier(ctx, h->nd, it + o[6], h->idl, &c));
-  RC(hiopamd_vec_log_barrier(ctx, h->nd, it + o[7], h->idu, &d));
   *out_host = r.v[2] + c + d;
   return HIOPAMD_OK;
 }
@@ -1523,12 +1534,16 @@ int hiopamd_iterate_linear_damping_term(hiopamd_kkt_xycyd* h, const double* it, 
   hiopamd_ctx* ctx = h->ctx;
   const int64_t* o = h->off;
   double a = 0, b = 0, c = 0, d = 0;
-  RC(hiopamd_vec_linear_damping_term(ctx, h->nx, it + o[4], h->ixl, h->ixu, mu, kappa_d, &a));
-  RC(hiopamd_vec_linear_damping_term(ctx, h->nx, it + o[5], h->ixu, h->ixl, mu, kappa_d, &b));
+  {
+    ReduceBatch rb(ctx);   // the four sums in one host round trip
+    RC(hiopamd_vec_linear_damping_term(ctx, h->nx, it + o[4], h->ixl, h->ixu, mu, kappa_d, &a));
+    RC(hiopamd_vec_linear_damping_term(ctx, h->nx, it + o[5], h->ixu, h->ixl, mu, kappa_d, &b));
+    RC(hiopamd_vec_linear_damping_term(ctx, h->nd, it + o[6], h->idl, h->idu, mu, kappa_d, &c));
+    RC(hiopamd_vec_linear_damping_term(ctx, h->nd, it + o[7], h->idu, h->idl, mu, kappa_d, &d));
+    RC(rb.flush());
+  }
   red4_t r{{0.0, 0.0, a + b, 0.0}};
   RC(xpart_allreduce(h, &r, 2));
-  RC(hiopamd_vec_linear_damping_term(ctx, h->nd, it + o[6], h->idl, h->idu, mu, kappa_d, &c));
-  RC(hiopamd_vec_linear_damping_term(ctx, h->nd, it + o[7], h->idu, h->idl, mu, kappa_d, &d));
   *out_host = r.v[2] + c + d;
   return HIOPAMD_OK;
 }

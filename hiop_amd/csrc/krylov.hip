@@ -34,8 +34,8 @@ struct Vec {
   int64_t n;
   int rc = HIOPAMD_OK;
   void chk(int r) { if(rc == HIOPAMD_OK && r != HIOPAMD_OK) rc = r; }
-  double dot(const double* x, const double* y) { double v = 0.0; chk(hiopamd_vec_dot(c, n, x, y, &v)); return v; }
-  double nrm(const double* x) { double v = 0.0; chk(hiopamd_vec_twonorm(c, n, x, &v)); return v; }
+  double dot(const double* x, const double* y) { double v = 0.0; hiopamd::ReduceNow now(c); chk(hiopamd_vec_dot(c, n, x, y, &v)); return v; }
+  double nrm(const double* x) { double v = 0.0; hiopamd::ReduceNow now(c); chk(hiopamd_vec_twonorm(c, n, x, &v)); return v; }
   void copy(double* y, const double* x) { chk(hiopamd_vec_copy(c, n, y, x)); }
   void axpy(double* y, double a, const double* x) { chk(hiopamd_vec_axpy(c, n, y, a, x)); }
   void scale(double* y, double a) { chk(hiopamd_vec_scale(c, n, y, a)); }

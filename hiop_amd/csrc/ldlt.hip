@@ -2449,6 +2449,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.pipe = 0;
     a.jpipe = 0;
     a.has_far = P.has_far ? 1 : 0;
+    a.sel_lead = 9;
+    a.exp = std::getenv("HIOPAMD_DF_EXP") ? std::atoi(std::getenv("HIOPAMD_DF_EXP")) : 0;
     a.dbg = std::getenv("HIOPAMD_DF_STAMPS") ? std::max(1, std::atoi(std::getenv("HIOPAMD_DF_STAMPS"))) : 0;   // profiling aid (1: all panels; 2 + j: phase sums of super-panel j only): per-super-panel time stamps, printed after the call
     a.off_ts = P.off_ver + (int64_t)P.nt * P.nt;
     a.off_ph = a.off_ts + 8 * (int64_t)(P.nsp + 1);
@@ -2507,6 +2509,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
         static const int pipej_env = std::getenv("HIOPAMD_DF_PIPEJ") ? std::atoi(std::getenv("HIOPAMD_DF_PIPEJ")) : -1;
         a.pipe = pipe_env;
         a.jpipe = pipej_env >= 0 ? pipej_env : (P.nwide + 1) / 2;
+        static const int lead_env = std::getenv("HIOPAMD_DF_SELLEAD") ? std::atoi(std::getenv("HIOPAMD_DF_SELLEAD")) : 9;
+        a.sel_lead = std::max(6, std::min(lead_env, 15));
         if(a.dbg) hipLaunchKernelGGL((ldlt_wide8_kernel<true>), dim3(grid), dim3(W8_THREADS), 0, su, a);
         else hipLaunchKernelGGL((ldlt_wide8_kernel<false>), dim3(grid), dim3(W8_THREADS), 0, su, a);
       } else {
@@ -2638,6 +2642,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
                  "UP(%u): wait %.2f body %.2f [prologue %.2f stages %.2f epilogue %.2f] publish %.2f\n",
                  ph[0] * 0.01 / ntask, ph[8], ph[1] * 0.01 / ntr, ph[2] * 0.01 / ntr, ph[3] * 0.01 / ntr, ph[7], ph[4] * 0.01 / nup,
                  ph[5] * 0.01 / nup, ph[9] * 0.01 / nup, ph[10] * 0.01 / nup, (ph[5] - ph[9] - ph[10]) * 0.01 / nup, ph[6] * 0.01 / nup);
+    if(ph[11] && ph[10]) std::fprintf(stderr, "[hiop_amd]   shader clock inside the stage loops: %.3f GHz\n", (double)ph[11] * 256.0 / ((double)ph[10] * 10.0));
     if(ph[15])
       std::fprintf(stderr, "[hiop_amd] spine steps (%u), mean us: F + publish %.2f | wait for the older updates of (p,p+1), (p+1,p+1) %.2f | T + U %.2f\n",
                    ph[15], ph[12] * 0.01 / ph[15], ph[13] * 0.01 / ph[15], ph[14] * 0.01 / ph[15]);
@@ -3404,6 +3409,7 @@ static int safe_refined_solve(hiopamd_linsolver* ls, double* x, bool* ok_out)
   const int n = ls->n;
   double* b = ls->rbuf;
   double* r = ls->rbuf + n;
+  hiopamd::ReduceNow now(ls->ctx);   // (the refinement loop branches on the norms)
   int rc = hiopamd_vec_copy(ls->ctx, n, b, x);
   if(rc != HIOPAMD_OK) return rc;
   double bn = 0.0;

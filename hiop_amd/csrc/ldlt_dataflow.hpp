@@ -91,6 +91,8 @@ struct DfArgs {
   int pipe;                // eight-wave wide kernel: bit 0 = the next task is selected during the last stages of an update tile, bit 1 = its first loads are issued before the current tile's stores are drained (ldlt_wide8.hpp)
   int jpipe;               // ... for the update tiles of queues j < jpipe (the update-bound part of the factorisation)
   int has_far;             // some super-panel has a FAR update list (HIOPAMD_DF_SPLIT=1)
+  int sel_lead;            // stages before the end of a tile at which the selection ahead starts (>= 6)
+  int exp;                 // HIOPAMD_DF_EXP: timing experiments of the profiling instantiation (ldlt_wide8.hpp)
 };
 
 #ifndef HIOPAMD_DF_FLAG_SCOPE

@@ -29,7 +29,7 @@
 
 constexpr int W8_THREADS = 512;
 constexpr int W8_TRW = DF_TRW;                // columns per substitution task (as in the four-wave form: the task lists are the same)
-constexpr int W8_SMEM_DOUBLES = 4 * UD_KT * UD_LD;   // 73,728 B: the update's two double-buffered operand stages / the substitution's V (256 x 33)
+constexpr int W8_SMEM_DOUBLES = 4 * 2 * UD_KT * UD_LD;   // 147,456 B: the update's ring of four operand stages / the substitution's V (256 x 33)
 static_assert(W8_SMEM_DOUBLES >= LD_NB * (DF_TRW + 1), "the substitution's V fits into the stage buffers of the update tile");
 
 // TR(j, c32): DF_TRW = 32 columns starting at c32 of the tail of row panel j, EIGHT waves: wave (I, gq) owns the 16-row sub-block I of
@@ -135,25 +135,58 @@ __device__ __forceinline__ bool df_task_trsm8(const DfArgs& a, int j, int c32, d
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// UP tile, eight waves.  Registers of a tile that live across the task boundary when the next tile's prologue is issued
-// behind the current tile's epilogue (DfArgs::pipe bit 1): the C tile in the accumulators and the first operand stage.
+// UP tile, eight waves, operands by LDS-DMA.
+//
+// What bounds the stage loop (profiles/r02_probes, the loop rebuilt ingredient by ingredient on 256 workgroups of one per CU):
+// registers only 77.6 TFLOP/s | + operands from LDS 73.5 | + one barrier per stage 68.7 | + 8 ds_write_b128 per stage 62.1 | + the
+// global loads 62.1.  Round 4 measured the same ceiling inside the factorisation for the four-wave AND for the eight-wave workgroup
+// (59-61 us per tile against 45 us of MFMA time), with one or with two register sets of operand stages in flight: the loop is not
+// waiting for memory, and a partner wave on the SIMD only covers the barrier — what costs is the staging itself (global -> VGPR ->
+// ds_write_b128: a 16-byte LDS store holds the wave's issue port for ~13 cycles and only half the SIMDs may store at a time).
+// So the operands no longer pass through registers: `buffer_load_dwordx4 ... lds` writes a k-row of 128 doubles (one 1 KB
+// wave-instruction: lane l -> LDS base + 16 l) straight into a ring of FOUR stage buffers, three stages ahead of their use.
+//   * acc = C - V^T U without touching the operands: the NEG bit of v_mfma_f64 (blgp = 1 negates A);
+//   * the DMA is issued from inline assembly: through the compiler's builtin every LDS read behind it gets an s_waitcnt vmcnt(0)
+//     (the compiler cannot see that the reads go to another buffer of the ring), which serialises loads and MFMAs.  The wave waits
+//     for ITS OWN loads of a stage with an explicit `s_waitcnt vmcnt(4)` (the four loads of the next stage may stay in flight; any
+//     other memory operation issued since only makes that wait stricter), then the stage barrier publishes the buffer;
+//   * the ring position carries over from task to task ((s + phase) mod 4 for stage s): the three buffers the next task's first
+//     stages go to are never the one the last stage of the current task may still be read from, so the next task's first loads
+//     can be issued behind the current tile's epilogue stores without another barrier (DfArgs::pipe bit 1).
 // element (i, q, reg) of the accumulators  <->  row  wr*64 + 32*(i>>1) + 2*(lk + 4*reg) + (i&1),  col  wc*32 + 2*li + q.
 // ---------------------------------------------------------------------------------------------------------------------
-// Operand stages travel memory -> registers -> LDS; TWO register sets, so that the loads of two stages are in flight at any time
-// (~64 KB per CU): with one set (one stage = 1.7 us of lead) the eight-wave tile ran at the pace of the four-wave one, 59 us per
-// tile instead of the pipe's 55 — the loop was waiting for its operands, not for the matrix pipe (profiles/r04_probes).
+constexpr int W8_RING = 4;
+constexpr int W8_STAGE_DOUBLES = 2 * UD_KT * UD_LD;   // V rows, then U rows: 36,864 B
+
 struct W8Regs {
   double4_t acc[4][2];
-  df_double2 vreg[2][2], ureg[2][2];   // [stage & 1][pass]
+  int phase = 0;   // ring buffer of stage 0 of the task whose prologue is in flight / which runs
 };
+
+__device__ __forceinline__ df_u32x4 w8_rsrc(const double* base)
+{
+  const unsigned long long b = (unsigned long long)base;
+  df_u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) & 0xffffu;
+  r.z = 0xffffffffu;
+  r.w = 0x00020000u;
+  return r;
+}
+// one wave-instruction: 64 lanes x 16 bytes from (rs.base + voff[lane] + soff) to LDS byte address lds_addr + 16 lane
+__device__ __forceinline__ void w8_dma16(const df_u32x4& rs, unsigned lds_addr, unsigned voff, unsigned soff)
+{
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
 
 template <bool FULL>
 struct W8Addr {
-  __amdgpu_buffer_rsrc_t rsV, rsU, rsV2, rsU2, rsC;
-  unsigned lda8, ldv8, vvoff, uvoff, cvoff_full;
+  df_u32x4 rsV, rsU, rsV2, rsU2;
+  __amdgpu_buffer_rsrc_t rsC;
+  unsigned lda8, ldv8, vvoff, uvoff, cvoff_full, lds0;
   int rlim, clim, wave, wr, wc, lk, li, panels;
   // panels = 2: stages 16 .. 31 read the row panel and the factor rows of super-panel j + 1 (DF_UP2)
-  __device__ __forceinline__ W8Addr(const DfArgs& a, int j, int I, int J, int tid, int panels_)
+  __device__ __forceinline__ W8Addr(const DfArgs& a, int j, int I, int J, const double* smem, int tid, int panels_)
   {
     panels = panels_;
     const int r0 = UD_T * I, c0 = UD_T * J;
@@ -165,10 +198,10 @@ struct W8Addr {
     li = lane & 15;
     lda8 = (unsigned)a.lda * 8u;
     ldv8 = (unsigned)a.ldv * 8u;
-    rsV = df_rsrc(a.V + (int64_t)(j % a.nvb) * LD_NB * a.ldv + r0);
-    rsU = df_rsrc(a.A + (int64_t)(LD_NB * j) * a.lda + c0);
-    rsV2 = df_rsrc(a.V + (int64_t)((j + 1) % a.nvb) * LD_NB * a.ldv + r0);
-    rsU2 = df_rsrc(a.A + (int64_t)(LD_NB * (j + 1)) * a.lda + c0);
+    rsV = w8_rsrc(a.V + (int64_t)(j % a.nvb) * LD_NB * a.ldv + r0);
+    rsU = w8_rsrc(a.A + (int64_t)(LD_NB * j) * a.lda + c0);
+    rsV2 = w8_rsrc(a.V + (int64_t)((j + 1) % a.nvb) * LD_NB * a.ldv + r0);
+    rsU2 = w8_rsrc(a.A + (int64_t)(LD_NB * (j + 1)) * a.lda + c0);
     rsC = df_rsrc(a.A + (int64_t)r0 * a.lda + c0);
     rlim = a.N - r0;
     clim = a.N - c0;
@@ -176,6 +209,7 @@ struct W8Addr {
     vvoff = 8u * (unsigned)(FULL ? col2 : (col2 < rlim - 2 ? col2 : rlim - 2));
     uvoff = 8u * (unsigned)(FULL ? col2 : (col2 < clim - 2 ? col2 : clim - 2));
     cvoff_full = 8u * (unsigned)(2 * li) + (unsigned)(2 * lk) * lda8;
+    lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)smem);   // (the low half of a flat LDS address is the LDS offset)
   }
   __device__ __forceinline__ int crow(int i, int reg) const { return wr * 64 + 32 * (i >> 1) + 2 * (lk + 4 * reg) + (i & 1); }
   __device__ __forceinline__ int ccol() const { return wc * 32 + 2 * li; }
@@ -190,21 +224,22 @@ struct W8Addr {
       soff = 0u;
     }
   }
-  // stage st: pass p moves k-row 8 p + wave of the stage, two adjacent columns per lane; into register set SET (= st & 1)
-  template <int SET>
-  __device__ __forceinline__ void gload(W8Regs& T, int st) const
+  // stage st into ring buffer `buf`: this wave moves k-rows wave and 8 + wave of V and of U (four wave-instructions)
+  __device__ __forceinline__ void dma_stage(int st, int buf_) const
   {
+    const int buf = __builtin_amdgcn_readfirstlane(buf_);   // (wave-uniform by construction; M0 needs a scalar)
     const bool second = st >= LD_NB / UD_KT;   // (only a two-panel task has such stages)
     const int sl = second ? st - LD_NB / UD_KT : st;
+    const unsigned vb = lds0 + 8u * (unsigned)(buf * W8_STAGE_DOUBLES), ub = vb + 8u * (unsigned)(UD_KT * UD_LD);
 #pragma unroll
     for(int p = 0; p < 2; ++p) {
-      const unsigned k = (unsigned)(sl * UD_KT + 8 * p + wave);
+      const unsigned kr = (unsigned)(8 * p + wave), k = (unsigned)(sl * UD_KT) + kr;
       if(second) {
-        T.vreg[SET][p] = df_bload2<HIOPAMD_DF_OPAUX>(rsV2, vvoff, k * ldv8);
-        T.ureg[SET][p] = df_bload2<HIOPAMD_DF_OPAUX>(rsU2, uvoff, k * lda8);
+        w8_dma16(rsV2, vb + kr * (unsigned)(8 * UD_LD), vvoff, k * ldv8);
+        w8_dma16(rsU2, ub + kr * (unsigned)(8 * UD_LD), uvoff, k * lda8);
       } else {
-        T.vreg[SET][p] = df_bload2<HIOPAMD_DF_OPAUX>(rsV, vvoff, k * ldv8);
-        T.ureg[SET][p] = df_bload2<HIOPAMD_DF_OPAUX>(rsU, uvoff, k * lda8);
+        w8_dma16(rsV, vb + kr * (unsigned)(8 * UD_LD), vvoff, k * ldv8);
+        w8_dma16(rsU, ub + kr * (unsigned)(8 * UD_LD), uvoff, k * lda8);
       }
     }
   }
@@ -222,13 +257,18 @@ struct W8Addr {
       }
   }
 };
+__device__ __forceinline__ int w8_ring(int b) { return b >= W8_RING ? b - W8_RING : b; }
 
-// first operand stage and the C tile of task (j, I, J) in flight (no wait, no barrier)
+// the first two operand stages (by LDS-DMA, into ring buffers phase and phase + 1) and the C tile of task (j, I, J) in flight; no wait,
+// no barrier.  The caller guarantees that nobody reads those two buffers any more (see the note on the ring above).
 template <bool FULL>
-__device__ __forceinline__ void w8_tile_prologue(const DfArgs& a, int j, int I, int J, int tid, int panels, W8Regs& T)
+__device__ __forceinline__ void w8_tile_prologue(const DfArgs& a, int j, int I, int J, const double* smem, int tid, int panels, W8Regs& T)
 {
-  const W8Addr<FULL> ad(a, j, I, J, tid, panels);
-  ad.template gload<0>(T, 0);
+  const W8Addr<FULL> ad(a, j, I, J, smem, tid, panels);
+  const int p0 = __builtin_amdgcn_readfirstlane(T.phase);
+  ad.dma_stage(0, p0);
+  ad.dma_stage(1, w8_ring(p0 + 1));
+  ad.dma_stage(2, w8_ring(p0 + 2));
   ad.cload(T);
 }
 
@@ -243,7 +283,8 @@ struct DfStageHook {
   __device__ __forceinline__ void operator()(int st, int nst) const { h(st, nst); }
 };
 
-// the tile proper; expects w8_tile_prologue(same task) to have been issued into T.  Returns false when a gate saw the abort.
+// the tile proper; expects w8_tile_prologue(same task) to have been issued.  Leaves T.phase at the ring position of the NEXT task.
+// Returns false when a gate saw the abort.
 template <bool FULL, bool PROF, class Gate = DfNoGate, class Hook = DfNoHook>
 __device__ __forceinline__ bool w8_tile_run(const DfArgs& a, int j, int I, int J, double* smem, int tid, int panels, unsigned (&ph)[12],
                                             W8Regs& T, Gate gate = Gate(), Hook hook = Hook())
@@ -251,81 +292,96 @@ __device__ __forceinline__ bool w8_tile_run(const DfArgs& a, int j, int I, int J
   bool gate_ok = true;
   const int dbg = PROF ? a.dbg : 0;
   const unsigned tp0 = dbg ? (unsigned)wall_clock64() : 0u;
-  double(*Vs)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem);
-  double(*Us)[UD_KT][UD_LD] = reinterpret_cast<double(*)[UD_KT][UD_LD]>(smem + 2 * UD_KT * UD_LD);
-  const W8Addr<FULL> ad(a, j, I, J, tid, panels);
-  const int lane = tid & 63;
-  const int col2 = 2 * lane;
-  auto lstore = [&](int buf, auto set) {
-    constexpr int SET = decltype(set)::value;
-#pragma unroll
-    for(int p = 0; p < 2; ++p) {
-      *reinterpret_cast<df_double2*>(&Vs[buf][8 * p + ad.wave][col2]) = T.vreg[SET][p];
-      *reinterpret_cast<df_double2*>(&Us[buf][8 * p + ad.wave][col2]) = -T.ureg[SET][p];
-    }
-  };
+  const W8Addr<FULL> ad(a, j, I, J, smem, tid, panels);
   auto mark = [&](unsigned stg) {
     if(tid == 0) df_st(a.flags + a.off_wg + 2 * (int64_t)blockIdx.x + 1, 0x80000000u | (stg << 16) | ((unsigned)J & 0xffffu));
   };
-  using Set0 = std::integral_constant<int, 0>;
-  using Set1 = std::integral_constant<int, 1>;
   mark(100u);
-  const int nst = panels * (LD_NB / UD_KT);   // 16 or 32: even
-  __syncthreads();   // the LDS buffers may still be read by the previous task's waves
-  ad.template gload<1>(T, 1);
-  lstore(0, Set0());                          // (waits for the prologue's stage 0)
-  ad.template gload<0>(T, 2);
-  __syncthreads();
+  const int nst = panels * (LD_NB / UD_KT);
   const int arow = ad.wr * 64 + 2 * ad.li, bcol = ad.wc * 32 + 2 * ad.li;
   const int lk = ad.lk;
+  int cur = __builtin_amdgcn_readfirstlane(T.phase);   // ring buffer of stage st
+  // HIOPAMD_DF_EXP (timing experiments of the PROF instantiation only; the factor is garbage): 1 = no operand loads in the loop,
+  // 2 = no stage barrier, 4 = no LDS operand reads in the loop, 8 = all eight waves issue their loads at the same point of the stage
+  const int ex = PROF ? a.exp : 0;
   const unsigned tp1 = dbg ? (unsigned)wall_clock64() : 0u;
-  // one stage: MFMAs on LDS buffer `cur`; at its second k-step the next stage moves from its register set into the other LDS buffer and
-  // the set is refilled with the stage three ahead (a gated tile looks at its block-row flags before the first loads of a block row)
-  auto stage = [&](int st, auto cur_c) {
-    constexpr int cur = decltype(cur_c)::value;
-    using Nxt = std::integral_constant<int, cur ^ 1>;
-    mark((unsigned)st);
-    df_double2 av[2][2], bv[2];
+  const unsigned long long tc1 = dbg ? (unsigned long long)clock64() : 0ull;
+  // Before stage 0: this wave's loads of stage 0 have landed (the prologue's later ones — stages 1, 2 and most of the C tile — may
+  // still be in flight: `vmcnt(8)` leaves at most eight operations outstanding, and those are younger), then everybody's have.
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  df_double2 av[2][2], bv[2];
+  {
+    const double* vb = smem + cur * W8_STAGE_DOUBLES;
+    const double* ub = vb + UD_KT * UD_LD;
 #pragma unroll
-    for(int h = 0; h < 2; ++h) av[0][h] = *reinterpret_cast<const df_double2*>(&Vs[cur][lk][arow + 32 * h]);
-    bv[0] = *reinterpret_cast<const df_double2*>(&Us[cur][lk][bcol]);
+    for(int h = 0; h < 2; ++h) av[0][h] = *reinterpret_cast<const df_double2*>(vb + lk * UD_LD + arow + 32 * h);
+    bv[0] = *reinterpret_cast<const df_double2*>(ub + lk * UD_LD + bcol);
+  }
+  // One barrier per stage, in its MIDDLE: the operands of the next k-step are already on their way out of LDS when a wave arrives at
+  // it, and those of the first k-step of the NEXT stage are requested in this stage's last k-step — the matrix pipe does not run dry at
+  // the stage boundary (with the barrier at the boundary every wave of the CU stopped there together, then waited for the LDS round
+  // trip of its first operands: ~20 % of the loop, the same for four or eight waves, one or two stages of lead, register or DMA staging).
+  // The barrier in stage st says: everybody's loads of stage st + 1 have landed, and everybody has finished stage st - 1 — whose
+  // buffer the loads of stage st + 3 may now overwrite.
+  for(int st = 0; st < nst; ++st) {
+    const double* vb = smem + cur * W8_STAGE_DOUBLES;
+    const double* ub = vb + UD_KT * UD_LD;
+    const int nb = w8_ring(cur + 1);
+    const double* vbn = smem + nb * W8_STAGE_DOUBLES;
+    const double* ubn = vbn + UD_KT * UD_LD;
+    mark((unsigned)st);
 #pragma unroll
     for(int kk = 0; kk < UD_KT / 4; ++kk) {
       const int pb = kk & 1;
-      if(kk + 1 < UD_KT / 4) {
+      if(ex & 4) {
+        // (timing experiment: the operands stay what they are)
+      } else if(kk + 1 < UD_KT / 4) {
 #pragma unroll
-        for(int h = 0; h < 2; ++h) av[pb ^ 1][h] = *reinterpret_cast<const df_double2*>(&Vs[cur][4 * (kk + 1) + lk][arow + 32 * h]);
-        bv[pb ^ 1] = *reinterpret_cast<const df_double2*>(&Us[cur][4 * (kk + 1) + lk][bcol]);
+        for(int h = 0; h < 2; ++h) av[pb ^ 1][h] = *reinterpret_cast<const df_double2*>(vb + (4 * (kk + 1) + lk) * UD_LD + arow + 32 * h);
+        bv[pb ^ 1] = *reinterpret_cast<const df_double2*>(ub + (4 * (kk + 1) + lk) * UD_LD + bcol);
+      } else if(st + 1 < nst) {   // first k-step of the next stage (its buffer is complete since this stage's barrier)
+#pragma unroll
+        for(int h = 0; h < 2; ++h) av[pb ^ 1][h] = *reinterpret_cast<const df_double2*>(vbn + lk * UD_LD + arow + 32 * h);
+        bv[pb ^ 1] = *reinterpret_cast<const df_double2*>(ubn + lk * UD_LD + bcol);
       }
-      if(kk == 1 && st + 1 < nst) {
-        lstore(cur ^ 1, Nxt());               // stage st + 1 (register set (st + 1) & 1 = cur ^ 1)
+      if(kk == 1) {
+        // (the hook BEFORE the barrier: what lane 0 publishes in the last stage — the task selected ahead — is read by every wave
+        //  after the loop, and this is the loop's last barrier)
+        if constexpr(Hook::active) hook(st, nst);
+        if(!(ex & 2)) {
+          if(st + 2 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // my loads of stage st + 1 (those of st + 2 may fly)
+          else if(st + 1 < nst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
         if(st + 3 < nst) {
           if constexpr(Gate::active) {
             if(((st + 3) & 3) == 0) gate_ok = gate((st + 3) >> 2) && gate_ok;   // (aborted: the result is discarded anyway)
           }
-          ad.template gload<cur ^ 1>(T, st + 3);
+          // Issuing the four LDS-DMA instructions holds a wave's issue port for several hundred cycles (measured: the loop is 8 %
+          // faster without them).  The two waves of a SIMD therefore issue theirs at different times — waves 0-3 here, waves 4-7
+          // two k-steps later — so that one of them always has MFMAs to issue.
+          if(!(ex & 1) && (ad.wave < 4 || (ex & 8))) ad.dma_stage(st + 3, w8_ring(cur + 3));
         }
       }
-      if constexpr(Hook::active) {
-        if(kk == 2) hook(st, nst);
-      }
+      if(kk == 3 && st + 3 < nst && !(ex & 1) && ad.wave >= 4 && !(ex & 8)) ad.dma_stage(st + 3, w8_ring(cur + 3));
 #pragma unroll
       for(int i = 0; i < 4; ++i)
 #pragma unroll
-        for(int q = 0; q < 2; ++q) T.acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb][i >> 1][i & 1], bv[pb][q], T.acc[i][q], 0, 0, 0);
+        for(int q = 0; q < 2; ++q)
+          T.acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb][i >> 1][i & 1], bv[pb][q], T.acc[i][q], 0, 0, 1);   // blgp = 1: -A
     }
-    __syncthreads();
-  };
-  for(int st = 0; st < nst; st += 2) {
-    stage(st, Set0());
-    stage(st + 1, Set1());
+    cur = nb;
   }
+  T.phase = cur;   // the buffer after the last stage's: the next task's stages 0, 1, 2 go to this one and the two behind it — never the
+                   // last stage's own buffer, which slower waves may still be reading
   // ---- epilogue: stores only
   mark(101u);
   if(dbg && (dbg == 1 || j + (panels - 1) == dbg - 2)) {   // (a fused task is accounted under the queue it was taken from)
     const unsigned tp2 = (unsigned)wall_clock64();
-    ph[9] += tp1 - tp0;    // prologue (LDS hand-over of the first stage, two barriers)
+    ph[9] += tp1 - tp0;    // set-up
     ph[10] += tp2 - tp1;   // the stages
+    ph[11] += (unsigned)(((unsigned long long)clock64() - tc1) >> 8);   // ... in shader clocks / 256: the clock the loop ran at
   }
   const bool diag = (I == J);
 #pragma unroll

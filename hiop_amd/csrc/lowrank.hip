@@ -363,7 +363,10 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
     y_new[i] = grad_f[i] - gp[i];
   }));
   double s_inf = 0.0;
-  RC(hiopamd_vec_infnorm(ctx, n, s_new, &s_inf));
+  {
+    ReduceNow now(ctx);
+    RC(hiopamd_vec_infnorm(ctx, n, s_new, &s_inf));
+  }
   if(ctx->allreduce) {
     RC(to_dev(ctx, h->dsmall, &s_inf, sizeof(double)));
     RC(allreduce_dev(ctx, h->dsmall, 1, HIOPAMD_MAX));

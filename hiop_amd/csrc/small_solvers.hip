@@ -96,7 +96,10 @@ int hiopamd::posv_refine_impl(hiopamd_ctx* ctx, int k, const double* N_upper, in
     const int64_t threads = (int64_t)k * 64;
     hipLaunchKernelGGL(sym_upper_residual, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        ctx->stream, k, Nm, ldn, x, b0, r);
-    RC(hiopamd_vec_infnorm(ctx, k, r, &nrm));
+    {
+      ReduceNow now(ctx);
+      RC(hiopamd_vec_infnorm(ctx, k, r, &nrm));
+    }
     if(nrm < 1e-8 || it >= MAX_ITER_REFIN) break;
     RC(launch_ew(ctx, k, [=] __device__(int64_t i) { t[i] = r[i] * sc[i]; }));
     RC(hiopamd_ldlt_solve(ctx, k, M, k, dinv, t, 1));

@@ -104,30 +104,136 @@ __global__ void coo_spmv_fold(int nrows, const double* __restrict__ part, double
   y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * s;
 }
 
-__global__ __launch_bounds__(kBlock) void coo_spmv_trans_scatter(int nnz, const int* __restrict__ iRow,
-                                                                 const int* __restrict__ jCol,
-                                                                 const double* __restrict__ val, double* __restrict__ y,
-                                                                 double alpha, const double* __restrict__ x)
+// ---------------------------------------------------------------------------------------------------------------------------
+// Transposed and symmetric products: many entries add to one output element, in an order the hardware chooses.  Floating-point
+// atomics made the result depend on that order (rounds 1-3: unsafeAtomicAdd on doubles; the IPM branches on reductions of these
+// vectors).  Here every contribution is added EXACTLY, as a 96-bit fixed-point number (three 32-bit limbs, each accumulated in a
+// 64-bit word with integer atomics: exact, commutative, associative — any order gives the same words), and rounded once at the end:
+//   pass 1  max |contribution|  (integer atomicMax on the bit patterns of non-negative doubles)  -> quantum 2^(E - 93)
+//   pass 2  limbs of round-toward-zero(contribution / quantum) added to acc[4 * output + 0..2] (word 3: non-finite contributions seen)
+//   pass 3  y = beta * y + (acc as a double) — bitwise the same run to run, and more accurate than a chain of rounded additions
+//           (a term smaller than 2^-93 of the largest one is dropped).
+// Up to 2^32 contributions per output element; a +-Inf / NaN contribution makes ITS output +-Inf / NaN, as a chain of additions would.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int exact_ilogb(unsigned long long bits)
 {
-  for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
-    // hardware fp64 atomic add (global_atomic_add_f64); column collisions are rare (a few rows/column)
-    unsafeAtomicAdd(&y[jCol[k]], alpha * x[iRow[k]] * val[k]);
+  const int e = (int)((bits >> 52) & 0x7ffull);
+  return e ? e - 1023 : -1022;
+}
+// acc3 += trunc(p * 2^-eq) as a signed 96-bit integer
+__device__ __forceinline__ void exact_add(unsigned long long* acc3, double p, int eq)
+{
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(p);
+  const int eb = (int)((bits >> 52) & 0x7ffull);
+  unsigned long long m = bits & 0x000fffffffffffffull;
+  if(eb == 0x7ff) {   // word 3: bit 0 = +Inf seen, bit 1 = -Inf seen, bit 2 = NaN seen
+    atomicOr(acc3 + 3, m ? 4ull : ((bits >> 63) ? 2ull : 1ull));
+    return;
   }
+  if(eb) m |= 0x0010000000000000ull;
+  if(m == 0ull) return;
+  const int sh = (eb ? eb - 1023 : -1022) - 52 - eq;   // p = m * 2^(e - 52) = (m << sh) quanta
+  unsigned long long lo, hi;                          // |value| = hi * 2^64 + lo, < 2^95
+  if(sh >= 0) {
+    if(sh >= 64) {   // (cannot happen with eq = E - 93, kept for safety)
+      lo = 0ull;
+      hi = m << (sh - 64);
+    } else {
+      lo = m << sh;
+      hi = sh ? (m >> (64 - sh)) : 0ull;
+    }
+  } else {
+    if(sh <= -53) return;
+    lo = m >> (-sh);
+    hi = 0ull;
+  }
+  if(bits >> 63) {   // two's complement of the 128-bit magnitude
+    lo = ~lo + 1ull;
+    hi = ~hi + (lo == 0ull ? 1ull : 0ull);
+  }
+  const unsigned long long l0 = lo & 0xffffffffull, l1 = lo >> 32;
+  const unsigned long long l2 = (unsigned long long)(long long)(int)(unsigned)hi;   // sign-extended low 32 bits of hi
+  if(l0) atomicAdd(acc3, l0);
+  if(l1) atomicAdd(acc3 + 1, l1);
+  if(l2) atomicAdd(acc3 + 2, l2);
+}
+__device__ __forceinline__ double exact_value(const unsigned long long* acc3, int eq)
+{
+  // total = acc0 + acc1 * 2^32 + (signed) acc2 * 2^64
+  unsigned __int128 t = (unsigned __int128)acc3[0] + ((unsigned __int128)acc3[1] << 32) + ((unsigned __int128)acc3[2] << 64);
+  __int128 st = (__int128)t;   // (mod 2^128 arithmetic: the true total fits)
+  const bool negative = st < 0;
+  unsigned __int128 mag = negative ? (unsigned __int128)(-st) : (unsigned __int128)st;
+  if(mag == 0) return 0.0;
+  const unsigned long long mh = (unsigned long long)(mag >> 64), ml = (unsigned long long)mag;
+  int shift;
+  unsigned long long top;   // the leading 64 bits
+  if(mh) {
+    const int lz = __clzll((long long)mh);
+    top = lz ? ((mh << lz) | (ml >> (64 - lz))) : mh;
+    shift = 64 - lz;
+  } else {
+    const int lz = __clzll((long long)ml);
+    top = ml << lz;
+    shift = -lz;
+  }
+  const double d = (double)top;   // correctly rounded; the bits below `top` are dropped (deterministically)
+  const double v = ldexp(d, shift + eq);
+  return negative ? -v : v;
+}
+__device__ __forceinline__ void exact_max(unsigned long long* word, double p)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(p));   // NaN compares above Inf: propagates
+  if(b) atomicMax(word, b);
 }
 
-// y += alpha * Msym * x for upper-triangle triplets: each off-diagonal entry contributes to two rows
-// (reference: hiopMatrixSymSparseTriplet::timesVec, hiopMatrixSparseTriplet.cpp:941-958)
-__global__ __launch_bounds__(kBlock) void spsym_spmv_scatter(int nnz, const int* __restrict__ iRow,
-                                                             const int* __restrict__ jCol,
-                                                             const double* __restrict__ val, double* __restrict__ y,
-                                                             double alpha, const double* __restrict__ x)
+// mode 0: y^T += alpha * M^T x (COO);  mode 1: symmetric product from upper-triangle triplets
+template <int MODE, int PASS>
+__global__ __launch_bounds__(kBlock) void sp_exact_pass(int nnz, const int* __restrict__ iRow, const int* __restrict__ jCol,
+                                                         const double* __restrict__ val, double alpha, const double* __restrict__ x,
+                                                         unsigned long long* __restrict__ maxw, unsigned long long* __restrict__ acc)
 {
+  int eq = 0;
+  if(PASS == 2) {
+    const unsigned long long mb = *maxw;
+    eq = exact_ilogb(mb) - 93;   // (mb = largest FINITE magnitude; 0: only zeros and non-finite terms, whose flags still have to be set)
+  }
+  unsigned long long lmax = 0ull;
   for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
     const int i = iRow[k], j = jCol[k];
     const double v = val[k];
-    unsafeAtomicAdd(&y[i], alpha * x[j] * v);
-    if(i != j) unsafeAtomicAdd(&y[j], alpha * x[i] * v);
+    const double p1 = MODE == 0 ? alpha * x[i] * v : alpha * x[j] * v;   // MODE 0 -> y[j];  MODE 1 -> y[i]
+    const double p2 = (MODE == 1 && i != j) ? alpha * x[i] * v : 0.0;      //                    MODE 1 -> y[j]
+    if(PASS == 1) {
+      const unsigned long long b1 = (unsigned long long)__double_as_longlong(fabs(p1)), b2 = (unsigned long long)__double_as_longlong(fabs(p2));
+      if(((b1 >> 52) & 0x7ffull) != 0x7ffull) lmax = lmax > b1 ? lmax : b1;
+      if(((b2 >> 52) & 0x7ffull) != 0x7ffull) lmax = lmax > b2 ? lmax : b2;
+    } else {
+      exact_add(acc + 4 * (int64_t)(MODE == 0 ? j : i), p1, eq);
+      if(MODE == 1 && i != j) exact_add(acc + 4 * (int64_t)j, p2, eq);
+    }
   }
+  if(PASS == 1) {
+    for(int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_down(lmax, off, 64);
+      lmax = lmax > o ? lmax : o;
+    }
+    if((threadIdx.x & 63) == 0 && lmax) atomicMax(maxw, lmax);
+  }
+}
+__global__ __launch_bounds__(kBlock) void sp_exact_finish(int n, const unsigned long long* __restrict__ maxw,
+                                                           const unsigned long long* __restrict__ acc, double beta, double* __restrict__ y)
+{
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if(c >= n) return;
+  const unsigned long long mb = *maxw;
+  const unsigned long long fl = acc[4 * (int64_t)c + 3];
+  double add = mb == 0ull ? 0.0 : exact_value(acc + 4 * (int64_t)c, exact_ilogb(mb) - 93);
+  if(fl) {
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    add = (fl & 4ull) || (fl & 3ull) == 3ull ? inf - inf : ((fl & 1ull) ? inf : -inf);
+  }
+  y[c] = (beta == 0.0 ? 0.0 : beta * y[c]) + add;
 }
 
 __global__ __launch_bounds__(kBlock) void mdinv_short(int64_t n_short, const int* __restrict__ out_i,
@@ -199,11 +305,16 @@ __global__ __launch_bounds__(kBlock) void spsym_diag_to_vec(int nnz, const int* 
                                                             double* __restrict__ y, int vec_start, int diag_src_start,
                                                             int num_elems)
 {
+  // The triplets are ordered by (row, column) (hiopMatrixSparseTriplet::checkIndexesAreOrdered), so repeated entries of one (i, j)
+  // are neighbours: the FIRST entry of such a run owns the destination and adds the run in storage order — no atomics, one fixed
+  // order of additions (a sym-sparse matrix normally holds one entry per (i, j): the run has length 1).
   for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
     const int r = iRow[k];
     if(r == jCol[k] && r >= diag_src_start && r < diag_src_start + num_elems) {
-      // a sym-sparse matrix holds at most one entry per (i,j); duplicates would need the atomic
-      unsafeAtomicAdd(&y[vec_start + r], alpha * val[k]);
+      if(k > 0 && iRow[k - 1] == r && jCol[k - 1] == r) continue;   // not the first of its run
+      double acc = y[vec_start + r];
+      for(int q = k; q < nnz && iRow[q] == r && jCol[q] == r; ++q) acc += alpha * val[q];
+      y[vec_start + r] = acc;
     }
   }
 }
@@ -213,9 +324,15 @@ __global__ __launch_bounds__(kBlock) void spsym_add_upper(int nnz, const int* __
                                                           int diag_start, double alpha, double* __restrict__ W,
                                                           int64_t ldw)
 {
-  for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
+  for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {   // (run ownership as in spsym_diag_to_vec)
     const int r = iRow[k], c = jCol[k];
-    if(r <= c) unsafeAtomicAdd(&W[(int64_t)(diag_start + r) * ldw + (diag_start + c)], alpha * val[k]);
+    if(r <= c) {
+      if(k > 0 && iRow[k - 1] == r && jCol[k - 1] == c) continue;
+      double* w = &W[(int64_t)(diag_start + r) * ldw + (diag_start + c)];
+      double acc = *w;
+      for(int q = k; q < nnz && iRow[q] == r && jCol[q] == c; ++q) acc += alpha * val[q];
+      *w = acc;
+    }
   }
 }
 
@@ -254,6 +371,25 @@ struct OpCountSp {
 };
 }  // namespace
 
+namespace {
+template <int MODE>
+int sp_exact_product(hiopamd_ctx* ctx, int nout, int nnz, const int* iRow, const int* jCol, const double* val, double beta, double* y,
+                     double alpha, const double* x)
+{
+  // workspace: [max word | pad] [4 words per output: three limbs + the non-finite flags]
+  const size_t words = 2 + 4 * (size_t)nout;
+  unsigned long long* w = (unsigned long long*)ctx_workspace(ctx, sizeof(unsigned long long) * words);
+  HIOPAMD_CHECK(hipMemsetAsync(w, 0, sizeof(unsigned long long) * words, ctx->stream));
+  if(nnz > 0) {
+    hipLaunchKernelGGL((sp_exact_pass<MODE, 1>), dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val, alpha, x, w, w + 2);
+    hipLaunchKernelGGL((sp_exact_pass<MODE, 2>), dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val, alpha, x, w, w + 2);
+  }
+  hipLaunchKernelGGL(sp_exact_finish, dim3((unsigned)((nout + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, nout, w, w + 2, beta, y);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int hiopamd_sp_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
@@ -283,12 +419,7 @@ int hiopamd_sp_trans_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, 
   (void)nrows;
   if(ncols < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
   if(ncols == 0) return HIOPAMD_OK;
-  int st = (beta == 0.0) ? hiopamd_vec_set_to_constant(ctx, ncols, y, 0.0) : hiopamd_vec_scale(ctx, ncols, y, beta);
-  if(st != HIOPAMD_OK || nnz == 0) return st;
-  hipLaunchKernelGGL(coo_spmv_trans_scatter, dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val, y,
-                     alpha, x);
-  HIOPAMD_CHECK(hipGetLastError());
-  return HIOPAMD_OK;
+  return sp_exact_product<0>(ctx, ncols, nnz, iRow, jCol, val, beta, y, alpha, x);
 }
 
 int hiopamd_spsym_times_vec(hiopamd_ctx* ctx, int n, int nnz, const int* iRow, const int* jCol, const double* val,
@@ -296,13 +427,7 @@ int hiopamd_spsym_times_vec(hiopamd_ctx* ctx, int n, int nnz, const int* iRow, c
 {
   if(n < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
   if(n == 0) return HIOPAMD_OK;
-  int st = (beta == 0.0) ? hiopamd_vec_set_to_constant(ctx, n, y, 0.0)
-                         : (beta == 1.0 ? HIOPAMD_OK : hiopamd_vec_scale(ctx, n, y, beta));
-  if(st != HIOPAMD_OK || nnz == 0) return st;
-  hipLaunchKernelGGL(spsym_spmv_scatter, dim3(grid_for(nnz)), dim3(kBlock), 0, ctx->stream, nnz, iRow, jCol, val, y,
-                     alpha, x);
-  HIOPAMD_CHECK(hipGetLastError());
-  return HIOPAMD_OK;
+  return sp_exact_product<1>(ctx, n, nnz, iRow, jCol, val, beta, y, alpha, x);
 }
 
 int hiopamd_sp_plan_create(hiopamd_sp_plan** out, int m1, int m2, int ncols, int nnz1, const int* iRow1, const int* jCol1,
@@ -532,8 +657,15 @@ int hiopamd_sp_copy_to_dense(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, co
   if(nrows < 0 || ncols < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
   int st = hiopamd_mat_set_to_constant(ctx, nrows, ncols, W, ldw, 0.0);
   if(st != HIOPAMD_OK) return st;
+  // ordered triplets (the class invariant): repeated entries of one (i, j) are neighbours; the first of a run adds the run in storage
+  // order and issues ONE atomic add onto the zeroed destination — a fixed result.  (Unordered input with scattered duplicates still
+  // gets every contribution, through several atomics.)
   return hiopamd::launch_ew(ctx, nnz, [=] __device__(int64_t k) {
-    atomicAdd(&W[(int64_t)iRow[k] * ldw + jCol[k]], val[k]);
+    const int r = iRow[k], c = jCol[k];
+    if(k > 0 && iRow[k - 1] == r && jCol[k - 1] == c) return;
+    double acc = 0.0;
+    for(int64_t q = k; q < nnz && iRow[q] == r && jCol[q] == c; ++q) acc += val[q];
+    atomicAdd(&W[(int64_t)r * ldw + c], acc);
   });
 }
 int hiopamd_sp_indexes_ordered(hiopamd_ctx* ctx, int nnz, const int* iRow, const int* jCol, int* out_host)

@@ -431,63 +431,59 @@ int hiopamd_vec_project_into_bounds(hiopamd_ctx* ctx, int64_t n, double* x0, con
 }
 
 // ---- reductions ----
+// Every entry point below returns its scalar through a host pointer; inside hiopamd_ctx_reduce_begin / _end the value is written when
+// the bracket is closed (ONE stream synchronisation for all of them), otherwise before the call returns.
 int hiopamd_vec_dot(hiopamd_ctx* ctx, int64_t n, const double* x, const double* y, double* out)
 {
-  return launch_reduce<double>(ctx, n, OpDot{x, y}, out);
+  return launch_reduce_deferrable<double>(ctx, n, OpDot{x, y}, out);
 }
 int hiopamd_vec_twonorm(hiopamd_ctx* ctx, int64_t n, const double* x, double* out)
 {
-  double s = 0.0;
-  int st = launch_reduce<double>(ctx, n, OpDot{x, x}, &s);
-  *out = std::sqrt(s);
-  return st;
+  return launch_reduce_fin<double>(ctx, n, OpDot{x, x}, [out](const double& s) { *out = std::sqrt(s); });
 }
 int hiopamd_vec_infnorm(hiopamd_ctx* ctx, int64_t n, const double* x, double* out)
 {
-  return launch_reduce<double>(ctx, n, OpAbsMax{x}, out);
+  return launch_reduce_deferrable<double>(ctx, n, OpAbsMax{x}, out);
 }
 int hiopamd_vec_onenorm(hiopamd_ctx* ctx, int64_t n, const double* x, double* out)
 {
-  return launch_reduce<double>(ctx, n, OpAbsSum{x}, out);
+  return launch_reduce_deferrable<double>(ctx, n, OpAbsSum{x}, out);
 }
 int hiopamd_vec_sum(hiopamd_ctx* ctx, int64_t n, const double* x, double* out)
 {
-  return launch_reduce<double>(ctx, n, OpSum{x}, out);
+  return launch_reduce_deferrable<double>(ctx, n, OpSum{x}, out);
 }
 int hiopamd_vec_min(hiopamd_ctx* ctx, int64_t n, const double* x, double* out)
 {
-  return launch_reduce<double>(ctx, n, OpMin{x}, out);
+  return launch_reduce_deferrable<double>(ctx, n, OpMin{x}, out);
 }
 int hiopamd_vec_min_w_pattern(hiopamd_ctx* ctx, int64_t n, const double* x, const double* s, double* out)
 {
-  return launch_reduce<double>(ctx, n, OpMinPattern{x, s}, out);
+  return launch_reduce_deferrable<double>(ctx, n, OpMinPattern{x, s}, out);
 }
 int hiopamd_vec_log_barrier(hiopamd_ctx* ctx, int64_t n, const double* x, const double* s, double* out)
 {
-  kahan_t r{0.0, 0.0};
-  int st = launch_reduce<kahan_t>(ctx, n, OpLogBarrier{x, s}, &r);
-  *out = r.s + r.c;
-  return st;
+  return launch_reduce_fin<kahan_t>(ctx, n, OpLogBarrier{x, s}, [out](const kahan_t& r) { *out = r.s + r.c; });
 }
 int hiopamd_vec_linear_damping_term(hiopamd_ctx* ctx, int64_t n, const double* x, const double* ixl, const double* ixr,
                                     double mu, double kappa_d, double* out)
 {
-  double t = 0.0;
-  int st = launch_reduce<double>(ctx, n, OpLinDamp{x, ixl, ixr}, &t);
-  t *= mu;
-  t *= kappa_d;
-  *out = t;
-  return st;
+  return launch_reduce_fin<double>(ctx, n, OpLinDamp{x, ixl, ixr}, [out, mu, kappa_d](const double& v) {
+    double t = v;
+    t *= mu;
+    t *= kappa_d;
+    *out = t;
+  });
 }
 int hiopamd_vec_fraction_to_the_bdry(hiopamd_ctx* ctx, int64_t n, const double* x, const double* d, double tau,
                                      double* out)
 {
-  return launch_reduce<double>(ctx, n, OpFracBdry{x, d, tau}, out);
+  return launch_reduce_deferrable<double>(ctx, n, OpFracBdry{x, d, tau}, out);
 }
 int hiopamd_vec_fraction_to_the_bdry_w_pattern(hiopamd_ctx* ctx, int64_t n, const double* x, const double* d,
                                                double tau, const double* s, double* out)
 {
-  return launch_reduce<double>(ctx, n, OpFracBdryPattern{x, d, s, tau}, out);
+  return launch_reduce_deferrable<double>(ctx, n, OpFracBdryPattern{x, d, s, tau}, out);
 }
 int hiopamd_vec_fraction_to_the_bdry_multi(hiopamd_ctx* ctx, int k, const int64_t* n_host, const double* const* x_host,
                                            const double* const* d_host, const double* const* s_host, double tau,
@@ -509,7 +505,7 @@ int hiopamd_vec_fraction_to_the_bdry_multi(hiopamd_ctx* ctx, int k, const int64_
       a.off[q + 1] = a.off[q];
     }
   }
-  return launch_reduce<double>(ctx, a.off[k], OpFtbMulti{a}, out);
+  return launch_reduce_deferrable<double>(ctx, a.off[k], OpFtbMulti{a}, out);
 }
 
 #define PRED_ALL(name, PRED)                                             \

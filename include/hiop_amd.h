@@ -55,6 +55,15 @@ int hiopamd_ctx_create(hiopamd_ctx** out, void* hip_stream /* hipStream_t or NUL
 int hiopamd_ctx_destroy(hiopamd_ctx* ctx);
 int hiopamd_ctx_sync(hiopamd_ctx* ctx);
 void* hiopamd_ctx_stream(hiopamd_ctx* ctx);
+/* Batched reductions.  Every hiopVector reduction of the reference returns its scalar to the caller (hiopVectorPar.cpp:463-555,
+ * 806-907, 1017-1060) — one device round trip each here (~19 us).  Between hiopamd_ctx_reduce_begin and hiopamd_ctx_reduce_end the
+ * scalar-returning entry points hiopamd_vec_dot / twonorm / infnorm / onenorm / sum / min / min_w_pattern / log_barrier /
+ * linear_damping_term / fraction_to_the_bdry(_w_pattern, _multi) only LAUNCH; their `double* out` arguments — which must stay
+ * valid until then — are written by hiopamd_ctx_reduce_end after ONE synchronisation of the context's stream (up to 64 results per
+ * round trip; more flush in between).  The norms / step lengths / barrier terms an IPM iteration needs (hiopIterate.cpp:330-365,
+ * hiopResidual.cpp:154-360) cost one round trip instead of a dozen.  Brackets nest; results are bitwise those of the unbatched calls. */
+int hiopamd_ctx_reduce_begin(hiopamd_ctx* ctx);
+int hiopamd_ctx_reduce_end(hiopamd_ctx* ctx);
 /* Run-stats spans: the reference's per-iteration KKT timers (src/Utils/hiopRunStats.hpp:82-140: tmUpdateInit,
  * tmUpdateLinsys, tmUpdateInnerFact, tmSolveRhsManip, tmSolveInner) and linear-solver timers (:244-300: tmFactTime,
  * tmInertiaComp, tmTriuSolves), placed where the reference starts/stops them (hiopKKTLinSysMDS.cpp:121-401,

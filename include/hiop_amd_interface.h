@@ -22,6 +22,8 @@
  * handed back unscaled.
  * Not supported (the call fails with a message instead of computing something else): a nonzero
  * sparse-dense Hessian block, feasibility restoration.
+ * The callbacks' return values are ignored, as by the reference's wrappers (chiopInterface.hpp:125-214 call the C function and
+ * return true whatever it returned).
  */
 #ifndef HIOP_AMD_INTERFACE_H
 #define HIOP_AMD_INTERFACE_H
@@ -72,7 +74,7 @@ int hiopamd_mds_set_callback_mem_space(cHiopMDSProblem* problem, int device);
  * Unknown name: HIOPAMD_ERR_ARG. */
 int hiopamd_mds_set_numeric_option(cHiopMDSProblem* problem, const char* name, double value);
 /* after solve: status = the reference's hiopSolveStatus value (hiopInterface.hpp:78-110: 0 Solve_Success, 2 Solve_Acceptable_Level,
- * 5 Max_Iter_Exceeded, -4 Err_Step_Computation, ...), iterations, KKT factorisations (inertia corrections included) */
+ * 10 Max_Iter_Exceeded, -5 Err_Step_Computation, ...), iterations, KKT factorisations (inertia corrections included) */
 int hiopamd_mds_get_solve_info(const cHiopMDSProblem* problem, int* status, int* num_iterations, int* num_factorizations);
 /* wall-clock seconds of the last solve: the whole optimisation loop, and the part inside the KKT span the reference's metric is defined on
  * (runStats.kkt.tmTotal: start_optimiz_iteration ... end_optimiz_iteration, hiopAlgFilterIPM.cpp:2339,2461 — update + factorisation(s) +

@@ -222,6 +222,57 @@ def test_sparse_spmv(ctx, m, n, dens):
         np.testing.assert_allclose(xd.cpu().numpy(), e, rtol=1e-12, atol=1e-13)
 
 
+def test_transposed_and_symmetric_products_are_bitwise_reproducible(ctx):
+    """transTimesVec (hiopMatrixSparseTriplet.cpp:110) and the symmetric product (:941-958): thousands of entries add to one output
+    element.  Rounds 1-3 used fp64 atomics (the sum depended on the order in which the hardware served them); now every contribution is
+    accumulated exactly (96-bit fixed point, integer atomics) and rounded once: every run gives the same bits, terms of wildly different
+    magnitude and cancelling signs included, and the result is the correctly rounded sum to ~1 ulp."""
+    from fractions import Fraction
+    r = rng(77)
+    m, n = 6000, 37                      # ~160 entries per output column, far more than one wave
+    M = (r.uniform(0, 1, (m, n)) < 0.6) * r.uniform(-1, 1, (m, n)) * 10.0 ** r.integers(-12, 12, (m, n))
+    i, j = np.nonzero(M)
+    i, j, v = i.astype(np.int32), j.astype(np.int32), M[i, j]
+    y = r.uniform(-1, 1, m) * 10.0 ** r.integers(-6, 6, m)
+    x0 = r.uniform(-1, 1, n)
+    id_, jd, vd, yd = D(i, torch.int32), D(j, torch.int32), D(v), D(y)
+    outs = []
+    for rep in range(12):
+        xd = D(x0)
+        run(ctx, "hiopamd_sp_trans_times_vec", m, n, v.size, id_, jd, vd, 0.5, xd, -1.5, yd)
+        outs.append(xd.cpu().numpy().copy())
+    for o in outs[1:]:
+        assert np.array_equal(o.view(np.int64), outs[0].view(np.int64))
+    # against exact rational arithmetic of the SAME rounded products (alpha * y_i * v rounded as the kernel forms it)
+    for c in (0, 5, n - 1):
+        k = np.nonzero(j == c)[0]
+        prods = (-1.5 * y[i[k]]) * v[k]
+        exact = float(sum(Fraction(float(t)) for t in prods))
+        got = outs[0][c] - 0.5 * x0[c]
+        assert abs(got - exact) <= 4e-16 * max(abs(exact), np.abs(prods).max() * 1e-10) + 1e-300, (c, got, exact)
+    # symmetric product: upper-triangle triplets, each off-diagonal entry feeds two outputs
+    ns = 900
+    S = np.triu((r.uniform(0, 1, (ns, ns)) < 0.3) * r.uniform(-1, 1, (ns, ns)) * 10.0 ** r.integers(-8, 8, (ns, ns)))
+    si, sj = np.nonzero(S)
+    si, sj, sv = si.astype(np.int32), sj.astype(np.int32), S[si, sj]
+    xs, ys = r.uniform(-1, 1, ns), r.uniform(-1, 1, ns)
+    sid, sjd, svd, xsd = D(si, torch.int32), D(sj, torch.int32), D(sv), D(xs)
+    souts = []
+    for rep in range(8):
+        yd2 = D(ys)
+        run(ctx, "hiopamd_spsym_times_vec", ns, sv.size, sid, sjd, svd, 1.0, yd2, 2.0, xsd)
+        souts.append(yd2.cpu().numpy().copy())
+    for o in souts[1:]:
+        assert np.array_equal(o.view(np.int64), souts[0].view(np.int64))
+    full = S + np.triu(S, 1).T
+    np.testing.assert_allclose(souts[0], ys + 2.0 * (full @ xs), rtol=1e-9, atol=1e-9 * np.abs(full).max())
+    # non-finite contributions do not disappear
+    v2 = v.copy(); v2[3] = np.inf
+    xd = D(x0)
+    run(ctx, "hiopamd_sp_trans_times_vec", m, n, v2.size, id_, jd, D(v2), 0.0, xd, 1.0, yd)
+    assert not np.isfinite(xd.cpu().numpy()).all()
+
+
 @pytest.mark.parametrize("m1,m2,n,dens", [(30, 30, 60, 0.15), (100, 7, 400, 0.05), (3, 3, 5000, 0.6), (50, 50, 50, 0.0)])
 def test_sparse_schur_rowbuild(ctx, m1, m2, n, dens):
     """addMDinvMtransToDiagBlockOfSymDeMatUTri / addMDinvNtransToSymDeMatUTri vs the literal row-merge loop."""

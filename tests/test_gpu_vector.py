@@ -212,6 +212,51 @@ def test_reduction_is_run_to_run_deterministic(ctx):
     assert len(vals) == 1
 
 
+def test_batched_reductions_one_round_trip_same_bits(ctx):
+    """hiopamd_ctx_reduce_begin / _end: the scalar-returning reductions launched inside the bracket deliver their host results when the
+    bracket closes (one stream synchronisation), bitwise those of the unbatched calls; more than 64 pending results flush in between;
+    a reduction the library needs for its own control flow inside a caller's bracket (here: the Krylov solver's norms) is not deferred."""
+    from hiop_amd._lib import lib
+    L = lib()
+    n = 300_007
+    x, y = mk(n, 41), mk(n, 42)
+    xp, s, s2 = mk(n, 43, 0.01, 5.0), pattern(n, 44), pattern(n, 45)
+    xd, yd, xpd, sd, s2d = D(x), D(y), D(xp), D(s), D(s2)
+    torch.cuda.synchronize()
+    calls = [("hiopamd_vec_dot", (n, xd, yd)), ("hiopamd_vec_twonorm", (n, xd)), ("hiopamd_vec_infnorm", (n, xd)),
+             ("hiopamd_vec_onenorm", (n, xd)), ("hiopamd_vec_sum", (n, xd)), ("hiopamd_vec_min", (n, xd)),
+             ("hiopamd_vec_min_w_pattern", (n, xd, sd)), ("hiopamd_vec_log_barrier", (n, xpd, sd)),
+             ("hiopamd_vec_linear_damping_term", (n, xd, sd, s2d, 0.1, 1e-5)), ("hiopamd_vec_fraction_to_the_bdry", (n, xpd, yd, 0.99)),
+             ("hiopamd_vec_fraction_to_the_bdry_w_pattern", (n, xpd, yd, 0.99, sd))]
+    single = [ctx.reduce_double(name, *a) for name, a in calls]
+    outs = [C.c_double(-7.0) for _ in calls]
+    assert L.hiopamd_ctx_reduce_begin(ctx.h) == 0
+    for (name, a), o in zip(calls, outs):
+        ctx.call(name, *a, C.byref(o))
+    assert all(o.value == -7.0 for o in outs)          # nothing has been written yet: no synchronisation happened
+    assert L.hiopamd_ctx_reduce_end(ctx.h) == 0
+    assert [o.value for o in outs] == single
+    # more results than pinned slots: flushed on the way, all correct at the end; nested brackets close on the outermost end
+    many = [C.c_double(0.0) for _ in range(150)]
+    assert L.hiopamd_ctx_reduce_begin(ctx.h) == 0 and L.hiopamd_ctx_reduce_begin(ctx.h) == 0
+    for q, o in enumerate(many):
+        ctx.call("hiopamd_vec_dot", n - q, xd, yd, C.byref(o))
+    assert L.hiopamd_ctx_reduce_end(ctx.h) == 0
+    assert many[-1].value == 0.0                       # (the inner end does not flush)
+    assert L.hiopamd_ctx_reduce_end(ctx.h) == 0
+    for q in (0, 1, 63, 64, 65, 149):
+        assert many[q].value == ctx.reduce_double("hiopamd_vec_dot", n - q, xd, yd)
+    assert L.hiopamd_ctx_reduce_end(ctx.h) != 0        # unbalanced end is an error, not a crash
+    # the library's own reductions inside a caller's bracket: the log-barrier objective of an iterate (four sums, one round trip of its own)
+    assert L.hiopamd_ctx_reduce_begin(ctx.h) == 0
+    v0 = C.c_double(0.0)
+    ctx.call("hiopamd_vec_dot", n, xd, yd, C.byref(v0))
+    t = ctx.reduce_int("hiopamd_vec_all_positive", n, xpd)    # an immediate reduction in between keeps the pending one pending
+    assert t == 1 and v0.value == 0.0
+    assert L.hiopamd_ctx_reduce_end(ctx.h) == 0
+    assert v0.value == single[0]
+
+
 def test_fraction_to_the_bdry_multi(ctx):
     ns = [1000, 37, 5000, 3]
     xs = [mk(n, 40 + i, 0.01, 2.0) for i, n in enumerate(ns)]
