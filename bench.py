@@ -482,15 +482,17 @@ def main():
     # summary profiles/r03_pmc/summary.json.  Algorithmic bytes of the same launch: every trailing tile read + written once
     # per super-panel, the two operand row panels read once, the row-panel substitution (read A, write V and U).
     traffic, traffic_src, alg_bytes = None, "n/a (no committed PMC summary found)", None
-    try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc", "summary.json")))
-        if p.N == 8192:
-            traffic = pmc["ldlt_df_one_kernel"]["hbm_bytes_per_launch"]
-            traffic_src = ("profiles/r03_pmc/summary.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of "
-                           "ldlt_df_one_kernel (the dataflow LDL^T's chain + wide roles as ONE dispatch, N = 8192); L2 memory-side "
-                           "requests, Infinity-Cache hits included")
-    except Exception:
-        pass
+    for pmc_dir in ("r04_pmc", "r03_pmc"):
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_dir, "summary.json")))
+            if p.N == 8192:
+                traffic = pmc["ldlt_df_one_kernel"]["hbm_bytes_per_launch"]
+                traffic_src = (f"profiles/{pmc_dir}/summary.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of "
+                               "ldlt_df_one_kernel (the dataflow LDL^T's chain + wide roles as ONE dispatch, N = 8192); L2 memory-side "
+                               "requests, Infinity-Cache hits included")
+            break
+        except Exception:
+            continue
     nsp_ = (p.N + 255) // 256
     alg_bytes = 0.0
     for j_ in range(nsp_ - 1):
@@ -501,7 +503,11 @@ def main():
     # the dominant kernel is the persistent wide kernel of the dataflow factorisation: `achieved` = the algorithmic flops of its
     # trailing-update tiles (2 K per updated element of the upper triangle) / its WHOLE duration, which also contains the
     # row-panel substitution tasks and every wait for the chain kernel — a lower bound on the tile rate, by construction
-    roofline = dict(bound="mfma", kernel="ldlt_wide_kernel<2,false> (dataflow LDL^T: row-panel substitution tasks + 128x128x256 trailing-update tiles, v_mfma_f64_16x16x4_f64)",
+    L.hiopamd_ldlt_dataflow_form.restype = C.c_int
+    form = int(L.hiopamd_ldlt_dataflow_form(int(p.N)))
+    kname = ("ldlt_wide8_kernel<false> (eight waves, one workgroup per CU, LDS-DMA operand staging)" if form == 8 else
+             "ldlt_wide_kernel<2,false> (four waves, ONE workgroup per CU)")
+    roofline = dict(bound="mfma", kernel=kname + " — dataflow LDL^T: row-panel substitution tasks + 128x128x256 / x512 trailing-update tiles, v_mfma_f64_16x16x4_f64",
                     achieved=achieved, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
                     traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
                     launches_per_step=launches / a.steps, avg_launch_ms=ms_per_launch,

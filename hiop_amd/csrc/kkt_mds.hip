@@ -12,6 +12,7 @@
 // is assembled in place, factored in place and never crosses PCIe (the reference's MAGMA path copies
 // it H2D at every factorisation, hiopLinSolverSymDenseMagma.cpp:337-340).
 #include "device_utils.hpp"
+#include "sparse_plans.hpp"
 
 #include <vector>
 
@@ -30,6 +31,8 @@ struct hiopamd_kkt_mds {
   hiopamd_sp_plan* plan_cc = nullptr;
   hiopamd_sp_plan* plan_dd = nullptr;
   hiopamd_sp_plan* plan_cd = nullptr;
+  hiopamd_sp_tplan* tplan_c = nullptr;   // column-side plans of Jcs / Jds for the transposed products of every solve
+  hiopamd_sp_tplan* tplan_d = nullptr;
   // current values (borrowed device pointers)
   const double *Jcs_val = nullptr, *Jds_val = nullptr, *Hss_val = nullptr;
   const double *Jcd = nullptr, *Jdd = nullptr, *Hdd = nullptr, *Dx = nullptr, *Dd = nullptr;
@@ -43,6 +46,72 @@ struct hiopamd_kkt_mds {
   bool solve_failed = false;   // a solve since the last hiopamd_kkt_mds_solve_status is known to have failed
   MdsDelta last_delta[4] = {{nullptr, 0.0}, {nullptr, 0.0}, {nullptr, 0.0}, {nullptr, 0.0}};   // of the last build (re-assembly after a time-out)
 };
+
+namespace hiopamd {
+// ---- solveCompressed around the dense solve, fused (hiopKKTLinSysMDS.cpp:318-401 as TWO launches + the products of the long rows)
+// Before: rxs = rx_s / Hxs | dyc = ryc - Jcs rxs (also packed into rhs) | rhs[0 .. nxd) = rx_d            — one launch;
+//         ryd -= Jds rxs, packed into rhs                                                                 — hiopamd_sp_times_vec_copy.
+// After:  dx_d, dyc, dyd out of rhs | dx_s = (rx_s - Jcs^T dyc - Jds^T dyd) / Hxs through the column plans — one launch.
+// Same operations on the same operands in the same order as the unfused sequence (which stays as the fall-back when a column of
+// Jcs / Jds is long): results are bitwise identical.
+__global__ __launch_bounds__(kBlock) void mds_pre_solve_kernel(int nxs, int nxd, int neq, int nnz_c, const int* __restrict__ ci,
+                                                               const int* __restrict__ cj, const double* __restrict__ cv,
+                                                               const double* __restrict__ rx, const double* __restrict__ Hxs,
+                                                               const double* __restrict__ ryc, double* __restrict__ rxs,
+                                                               double* __restrict__ dyc, double* __restrict__ rhs, int blocks_ew)
+{
+  if((int)blockIdx.x < blocks_ew) {   // element-wise part: rxs and the dense part of the right-hand side
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if(i < nxs) rxs[i] = rx[i] / Hxs[i];
+    if(i < nxd) rhs[i] = rx[nxs + i];
+    return;
+  }
+  // one wave per row of Jcs (the kernel of hiopamd_sp_times_vec with x = rx / Hxs formed on the fly)
+  const int row = (int)((((int64_t)blockIdx.x - blocks_ew) * kBlock + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if(row >= neq) return;   // wave-uniform
+  const int start = wave_lower_bound(ci, 0, nnz_c, row, lane);
+  const int end = wave_lower_bound(ci, start, nnz_c, row + 1, lane);
+  double acc = 0.0;
+  for(int k = start + lane; k < end; k += 64) {
+    const int c = cj[k];
+    acc += (rx[c] / Hxs[c]) * cv[k];
+  }
+  for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if(lane == 0) {
+    const double r = 1.0 * ryc[row] + (-1.0) * acc;
+    dyc[row] = r;
+    rhs[nxd + row] = r;
+  }
+}
+__global__ __launch_bounds__(kBlock) void mds_post_solve_kernel(int nxs, int nxd, int neq, int nineq, const double* __restrict__ rhs,
+                                                                const double* __restrict__ rx, const double* __restrict__ Hxs,
+                                                                const int64_t* __restrict__ cptr_c, const int* __restrict__ perm_c,
+                                                                const int* __restrict__ prow_c, const double* __restrict__ cv,
+                                                                const int64_t* __restrict__ cptr_d, const int* __restrict__ perm_d,
+                                                                const int* __restrict__ prow_d, const double* __restrict__ dv,
+                                                                double* __restrict__ dx, double* __restrict__ dyc, double* __restrict__ dyd)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t m = (int64_t)nxd + neq + nineq;
+  if(i < m) {
+    const double v = rhs[i];
+    if(i < nxd) dx[nxs + i] = v;
+    else if(i < nxd + neq) dyc[i - nxd] = v;
+    else dyd[i - nxd - neq] = v;
+  }
+  if(i < nxs) {
+    const double* yc = rhs + nxd;          // (= dyc, dyd: read from the solution vector, not from what this launch writes)
+    const double* yd = rhs + nxd + neq;
+    double ac = 0.0, ad = 0.0;
+    for(int64_t p = cptr_c[i]; p < cptr_c[i + 1]; ++p) ac += yc[prow_c[p]] * cv[perm_c[p]];
+    for(int64_t p = cptr_d[i]; p < cptr_d[i + 1]; ++p) ad += yd[prow_d[p]] * dv[perm_d[p]];
+    double t = 1.0 * rx[i] + (-1.0) * ac;
+    t = 1.0 * t + (-1.0) * ad;
+    dx[i] = t / Hxs[i];
+  }
+}
+}  // namespace hiopamd
 
 using namespace hiopamd;
 
@@ -58,6 +127,8 @@ int hiopamd_kkt_mds_create(hiopamd_kkt_mds** out, hiopamd_ctx* ctx, const hiopam
   const int N = st->nxd + st->neq + st->nineq;
   int rc = hiopamd_linsolver_create(&k->ls, ctx, N);
   if(rc == HIOPAMD_OK) rc = hiopamd_linsolver_set_retry_copy(k->ls, 0);   // (this object re-assembles after a time-out: hiopamd_kkt_mds_factorize)
+  if(rc == HIOPAMD_OK) rc = hiopamd_sp_tplan_create(&k->tplan_c, st->neq, st->nxs, st->nnz_Jcs, st->Jcs_i_host, st->Jcs_j_host);
+  if(rc == HIOPAMD_OK) rc = hiopamd_sp_tplan_create(&k->tplan_d, st->nineq, st->nxs, st->nnz_Jds, st->Jds_i_host, st->Jds_j_host);
   // symbolic plans of the three Schur blocks (pattern is fixed over the IPM iterations)
   if(rc == HIOPAMD_OK)
     rc = hiopamd_sp_plan_create(&k->plan_cc, st->neq, st->neq, st->nxs, st->nnz_Jcs, st->Jcs_i_host, st->Jcs_j_host,
@@ -91,6 +162,8 @@ int hiopamd_kkt_mds_destroy(hiopamd_kkt_mds* k)
   hiopamd_sp_plan_destroy(k->plan_cc);
   hiopamd_sp_plan_destroy(k->plan_dd);
   hiopamd_sp_plan_destroy(k->plan_cd);
+  hiopamd_sp_tplan_destroy(k->tplan_c);
+  hiopamd_sp_tplan_destroy(k->tplan_d);
   (void)hipFree(k->Hxs);
   (void)hipFree(k->Dd_inv);
   (void)hipFree(k->rhs);
@@ -295,6 +368,19 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
     int id;
     ~SpanGuard() { if(id >= 0) span_end(c, id); }
   } guard{ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP};
+  // HIOPAMD_MDS_FUSED=0: the unfused sequence (A/B timing, and the fall-back when a column of Jcs / Jds holds more than 64 entries)
+  static const bool fused_env = !(std::getenv("HIOPAMD_MDS_FUSED") && std::atoi(std::getenv("HIOPAMD_MDS_FUSED")) == 0);
+  const bool fused = fused_env && k->tplan_c->max_len <= 64 && k->tplan_d->max_len <= 64;
+  if(fused) {
+    const int64_t new_ = (nxs > nxd) ? nxs : nxd;
+    const int blocks_ew = (int)((new_ + kBlock - 1) / kBlock);
+    const int blocks_rows = (int)(((int64_t)neq * 64 + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(mds_pre_solve_kernel, dim3((unsigned)(blocks_ew + blocks_rows)), dim3(kBlock), 0, ctx->stream, nxs, nxd, neq,
+                       s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, rx, Hxs, ryc, rxs, dyc, rhs, blocks_ew);
+    HIOPAMD_CHECK(hipGetLastError());
+    // ryd -= Jds rxs, stored into the right-hand side as well                 (:345-347, :355-357)
+    RC(hiopamd_sp_times_vec_copy(ctx, nineq, nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, 1.0, ryd, -1.0, rxs, rhs + nxd + neq));
+  } else {
   // rxs = Hxs^-1 rx_sparse; dyc = ryc  (one pass)                            (:337-338, :343)
   {
     const int64_t nmax = (nxs > neq) ? nxs : neq;
@@ -313,6 +399,7 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
       rhs[i] = (i < nxd) ? rxd[i] : ((i < nxd + neq) ? dyc[i - nxd] : ryd[i - nxd - neq]);
     }));
   }
+  }
   // solve                                                                    (:364-368)
   span_end(ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);
   span_begin(ctx, guard.id = HIOPAMD_SPAN_KKT_SOLVE_INNER);
@@ -324,6 +411,15 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
   }
   span_end(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);
   span_begin(ctx, guard.id = HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP);   // :380-401
+  if(fused) {
+    const int64_t m = (int64_t)nxd + neq + nineq;
+    const int64_t nmax = (m > nxs) ? m : nxs;
+    hipLaunchKernelGGL(mds_post_solve_kernel, dim3((unsigned)((nmax + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, nxs, nxd, neq,
+                       nineq, rhs, rx, Hxs, k->tplan_c->cptr, k->tplan_c->perm, k->tplan_c->prow, k->Jcs_val, k->tplan_d->cptr,
+                       k->tplan_d->perm, k->tplan_d->prow, k->Jds_val, dx, dyc, dyd);
+    HIOPAMD_CHECK(hipGetLastError());
+    return HIOPAMD_OK;
+  }
   // unpack dx_dense, dyc, dyd and start dxs = rx_sparse  (one pass)           (:383-390)
   double* dxs = k->buf_xs;
   {
@@ -341,8 +437,8 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
     }));
   }
   // dxs = Hxs^-1 (rxs - Jcs^T dyc - Jds^T dyd)                               (:390-395)
-  RC(hiopamd_sp_trans_times_vec(ctx, neq, nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, 1.0, dxs, -1.0, dyc));
-  RC(hiopamd_sp_trans_times_vec(ctx, nineq, nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, 1.0, dxs, -1.0, dyd));
+  RC(hiopamd_sp_tplan_trans_times_vec(ctx, k->tplan_c, k->Jcs_val, 1.0, dxs, -1.0, dyc));
+  RC(hiopamd_sp_tplan_trans_times_vec(ctx, k->tplan_d, k->Jds_val, 1.0, dxs, -1.0, dyd));
   RC(launch_ew(ctx, nxs, [=] __device__(int64_t i) { dx[i] = dxs[i] / Hxs[i]; }));
   return HIOPAMD_OK;
 }
@@ -421,10 +517,10 @@ int hiopamd_kkt_mds_jac_trans_times_vec(hiopamd_kkt_mds* k, int which, double be
   if(!k || !k->Jcd) return HIOPAMD_ERR_STATE;
   const hiopamd_mds_structure& s = k->s;
   if(which == 0) {
-    RC(hiopamd_sp_trans_times_vec(k->ctx, s.neq, s.nxs, s.nnz_Jcs, s.Jcs_i, s.Jcs_j, k->Jcs_val, beta, y, alpha, x));
+    RC(hiopamd_sp_tplan_trans_times_vec(k->ctx, k->tplan_c, k->Jcs_val, beta, y, alpha, x));
     RC(hiopamd_mat_trans_times_vec(k->ctx, s.neq, s.nxd, k->Jcd, s.nxd, beta, y + s.nxs, alpha, x));
   } else {
-    RC(hiopamd_sp_trans_times_vec(k->ctx, s.nineq, s.nxs, s.nnz_Jds, s.Jds_i, s.Jds_j, k->Jds_val, beta, y, alpha, x));
+    RC(hiopamd_sp_tplan_trans_times_vec(k->ctx, k->tplan_d, k->Jds_val, beta, y, alpha, x));
     RC(hiopamd_mat_trans_times_vec(k->ctx, s.nineq, s.nxd, k->Jdd, s.nxd, beta, y + s.nxs, alpha, x));
   }
   return HIOPAMD_OK;

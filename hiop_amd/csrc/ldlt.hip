@@ -2087,7 +2087,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 
 struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
-  bool form8 = false;      // the wide kernel's form for this order: eight waves, one workgroup per CU (ldlt_wide8.hpp) / four waves
+  int form = 4;            // the wide kernel's form for this order (df_form)
   bool has_far = false;    // a FAR update list exists (HIOPAMD_DF_SPLIT=1)
   int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_snap = 0, off_where = 0, off_shadow = 0, off_run = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
@@ -2095,19 +2095,26 @@ struct DfPlan {
   std::vector<int4> wq, wf;
   double up_flops = 0.0;   // algorithmic flops of the UP tasks (2 K per updated element)
 };
-// Which form of the wide kernel factorises order N: the eight-wave form (one workgroup per CU, ldlt_wide8.hpp) needs the 16-byte tile
-// accesses (even N; lda = ldv = N in the solver object); HIOPAMD_DF_FORM=4 selects the four-wave form (A/B timing, counter passes).
-static bool df_form8(int N)
+// Which form of the wide kernel factorises order N (HIOPAMD_DF_FORM; the task lists are the same for both):
+//   4  (default) the four-wave kernel (ldlt_wide_kernel), ONE workgroup per CU of the wide stream: 73.7 KB of LDS and 256 registers
+//      per lane, so a CU could hold two of them — the only configuration that never froze in a soak (every
+//      configuration that fills its CUs exactly — two four-wave workgroups per CU, one eight-wave workgroup with 147 KB of LDS —
+//      froze once per 5 000 - 16 000 factorisations).  HIOPAMD_DF_WGS=480 puts two on a CU (timing aid; never the default);
+//   8  eight waves, one workgroup per CU, operands by LDS-DMA, selection ahead (ldlt_wide8_kernel): measured at the same tile-loop
+//      pace, slower overall and not free of the freeze; kept for A/B.  Needs the 16-byte tile accesses (even N).
+// The one-dispatch form of the counter passes (HIOPAMD_DF_ONE=1) is form 4.
+static int df_form(int N)
 {
-  static const int form_env = std::getenv("HIOPAMD_DF_FORM") ? std::atoi(std::getenv("HIOPAMD_DF_FORM")) : 8;
-  static const bool one_env = std::getenv("HIOPAMD_DF_ONE") && std::atoi(std::getenv("HIOPAMD_DF_ONE")) != 0;   // (the one-dispatch form of the counter passes is four-wave)
-  return form_env != 4 && !one_env && (N % 2 == 0) && N >= 2 * UD_T;
+  static const int form_env = std::getenv("HIOPAMD_DF_FORM") ? std::atoi(std::getenv("HIOPAMD_DF_FORM")) : 4;
+  static const bool one_env = std::getenv("HIOPAMD_DF_ONE") && std::atoi(std::getenv("HIOPAMD_DF_ONE")) != 0;
+  if(one_env || (N % 2) != 0 || N < 2 * UD_T) return 4;
+  return form_env == 8 ? 8 : 4;
 }
 static DfPlan df_build_plan(int N)
 {
   DfPlan P;
   P.N = N;
-  P.form8 = df_form8(N);
+  P.form = df_form(N);
   P.nsp = (N + LD_NB - 1) / LD_NB;
   P.nt = (N + UD_T - 1) / UD_T;
   const int nfull = N / LD_NB;
@@ -2500,8 +2507,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       // HIOPAMD_DF_WGS: timing aid — with the four-wave form a value above the number of CUs puts two workgroups on a CU, the faster
       // and, once in ~1.6e4 factorisations, freezing shape of rounds 2-3; never the default.
       static const int wgs_env = std::getenv("HIOPAMD_DF_WGS") ? std::atoi(std::getenv("HIOPAMD_DF_WGS")) : 0;
-      const bool form8 = P.form8;
-      if(form8) {
+      if(P.form != 4) {
         const int wmax = wgs_env > 0 ? std::min(wgs_env, ctx->wide_cus) : ctx->wide_cus;
         const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
         a.jretire = P.nwide;   // (nobody retires: there is no second workgroup on a CU)
@@ -3542,6 +3548,7 @@ int hiopamd_ldlt_dataflow_queues(int n, int* queues_host, int cap_panels)
 }
 
 int hiopamd_ldlt_dataflow_nvb(int n) { return df_nvb_for(n); }
+int hiopamd_ldlt_dataflow_form(int n) { return df_form(n); }
 
 int hiopamd_ldlt_dataflow_far_queues(int n, int* far_host, int cap_panels)
 {

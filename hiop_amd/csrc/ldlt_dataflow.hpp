@@ -1201,9 +1201,20 @@ struct DfRowGate {
   G& g;
   __device__ __forceinline__ bool operator()(int P) const { return g(P); }
 };
-template <bool FULL, bool PROF, class Gate = DfNoGate, int PANELS = 1>
+// Hook: called once per stage, before the stage's operand loads are issued (the selection ahead of ldlt_wide8_body.inc)
+struct DfNoHook {
+  static constexpr bool active = false;
+  __device__ __forceinline__ void operator()(int, int) const {}
+};
+template <class H>
+struct DfStageHook {
+  static constexpr bool active = true;
+  H& h;
+  __device__ __forceinline__ void operator()(int st, int nst) const { h(st, nst); }
+};
+template <bool FULL, bool PROF, class Gate = DfNoGate, int PANELS = 1, class Hook = DfNoHook>
 __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int J, double* smem, int tid, unsigned (&ph)[12],
-                                              Gate gate = Gate())
+                                              Gate gate = Gate(), Hook hook = Hook())
 {
   static_assert(PANELS == 1 || !Gate::active, "the gated (head) tile is a single-panel task");
   bool gate_ok = true;
@@ -1312,6 +1323,9 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
           av[pb ^ 1][h] = *reinterpret_cast<const df_double2*>(&Vs[cur][4 * (kk + 1) + lk][arow + 32 * h]);
           bv[pb ^ 1][h] = *reinterpret_cast<const df_double2*>(&Us[cur][4 * (kk + 1) + lk][bcol + 32 * h]);
         }
+      }
+      if constexpr(Hook::active) {
+        if(kk == 0) hook(st, nst);   // (what it publishes in the last stage is behind that stage's closing barrier)
       }
       if(kk == 1 && st + 1 < nst) {
         lstore(cur ^ 1);

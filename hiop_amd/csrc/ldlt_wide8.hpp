@@ -272,17 +272,6 @@ __device__ __forceinline__ void w8_tile_prologue(const DfArgs& a, int j, int I, 
   ad.cload(T);
 }
 
-struct DfNoHook {
-  static constexpr bool active = false;
-  __device__ __forceinline__ void operator()(int, int) const {}
-};
-template <class H>
-struct DfStageHook {
-  static constexpr bool active = true;
-  H& h;
-  __device__ __forceinline__ void operator()(int st, int nst) const { h(st, nst); }
-};
-
 // the tile proper; expects w8_tile_prologue(same task) to have been issued.  Leaves T.phase at the ring position of the NEXT task.
 // Returns false when a gate saw the abort.
 template <bool FULL, bool PROF, class Gate = DfNoGate, class Hook = DfNoHook>
@@ -419,5 +408,6 @@ __global__ __launch_bounds__(W8_THREADS, 2) void ldlt_wide8_kernel(const DfArgs 
   __shared__ __attribute__((aligned(16))) double smem[W8_SMEM_DOUBLES];
   __shared__ int sh_kind, sh_ok, sh_nkind, sh_nready, sh_nidx;
   __shared__ int4 sh_task, sh_ntask;
+  constexpr int WB_WAVES = 8;
 #include "ldlt_wide8_body.inc"
 }

@@ -11,6 +11,7 @@
 // in increasing column order.  The numeric kernel is then one thread (short lists) or one wave
 // (long lists) per output: no atomics, fixed summation order = the reference's merge order.
 #include "device_utils.hpp"
+#include "sparse_plans.hpp"
 
 #include <algorithm>
 #include <vector>
@@ -32,31 +33,10 @@ namespace hiopamd {
 
 constexpr int kLongList = 32;
 
-// first k in [lo, hi) with iRow[k] >= row (hi if none), searched by a whole wave: 64 probes per step instead of one, so
-// a row boundary among nnz entries costs log64(nnz) dependent loads (3 for 2^18) instead of log2(nnz) (18)
-__device__ __forceinline__ int wave_lower_bound(const int* __restrict__ iRow, int lo, int hi, int row, int lane)
-{
-  while(hi - lo > 64) {
-    const int step = (hi - lo + 63) >> 6;
-    const int pos = lo + lane * step;
-    const int v = (pos < hi) ? iRow[pos] : 0x7fffffff;
-    const unsigned long long m = __ballot(v >= row);
-    const int f = m ? (__ffsll((long long)m) - 1) : 64;   // first probe that is >= row
-    const int nlo = (f > 0) ? lo + (f - 1) * step + 1 : lo;
-    const int nhi = (f < 64 && lo + f * step < hi) ? lo + f * step : hi;
-    lo = nlo;
-    hi = nhi;
-  }
-  const int pos = lo + lane;
-  const int v = (pos < hi) ? iRow[pos] : 0x7fffffff;
-  const unsigned long long m = __ballot(v >= row);
-  return m ? lo + (__ffsll((long long)m) - 1) : hi;
-}
-
 __global__ __launch_bounds__(kBlock) void coo_spmv_rows(int nrows, int nnz, const int* __restrict__ iRow,
                                                         const int* __restrict__ jCol, const double* __restrict__ val,
                                                         double beta, double* __restrict__ y, double alpha,
-                                                        const double* __restrict__ x)
+                                                        const double* __restrict__ x, double* __restrict__ y2)
 {
   // one wave per row; the row's [lo,hi) range found by binary search in the row-sorted COO
   const int row = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -67,7 +47,11 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_rows(int nrows, int nnz, cons
   double acc = 0.0;
   for(int k = start + lane; k < end; k += 64) acc += x[jCol[k]] * val[k];
   for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if(lane == 0) y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
+  if(lane == 0) {
+    const double r = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * acc;
+    y[row] = r;
+    if(y2) y2[row] = r;
+  }
 }
 
 // few-row matrices (e.g. the 3 inequality rows of MdsEx1, one of them with n_s/2 entries): every row is cut
@@ -95,13 +79,15 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_rows_split(int nrows, int nnz
   if(threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 __global__ void coo_spmv_fold(int nrows, const double* __restrict__ part, double beta, double* __restrict__ y,
-                              double alpha)
+                              double alpha, double* __restrict__ y2)
 {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if(row >= nrows) return;
   double s = 0.0;
   for(int q = 0; q < SPMV_SPLIT; ++q) s += part[row * SPMV_SPLIT + q];
-  y[row] = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * s;
+  const double r = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * s;
+  y[row] = r;
+  if(y2) y2[row] = r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -336,6 +322,31 @@ __global__ __launch_bounds__(kBlock) void spsym_add_upper(int nnz, const int* __
   }
 }
 
+// y[c] = beta y[c] + alpha sum_{entries of column c, in list order} x[row] * val: one thread per column (columns of the KKT Jacobians
+// hold a handful of entries), or one wave per column with a fixed-order tree when some column is long — no atomics either way
+__global__ __launch_bounds__(kBlock) void sp_tplan_cols(int ncols, const int64_t* __restrict__ cptr, const int* __restrict__ perm,
+                                                         const int* __restrict__ prow, const double* __restrict__ val, double beta,
+                                                         double* __restrict__ y, double alpha, const double* __restrict__ x)
+{
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if(c >= ncols) return;
+  double acc = 0.0;
+  for(int64_t p = cptr[c]; p < cptr[c + 1]; ++p) acc += x[prow[p]] * val[perm[p]];
+  y[c] = (beta == 0.0 ? 0.0 : beta * y[c]) + alpha * acc;
+}
+__global__ __launch_bounds__(kBlock) void sp_tplan_cols_wave(int ncols, const int64_t* __restrict__ cptr, const int* __restrict__ perm,
+                                                              const int* __restrict__ prow, const double* __restrict__ val, double beta,
+                                                              double* __restrict__ y, double alpha, const double* __restrict__ x)
+{
+  const int c = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if(c >= ncols) return;   // wave-uniform
+  double acc = 0.0;
+  for(int64_t p = cptr[c] + lane; p < cptr[c + 1]; p += 64) acc += x[prow[p]] * val[perm[p]];
+  for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if(lane == 0) y[c] = (beta == 0.0 ? 0.0 : beta * y[c]) + alpha * acc;
+}
+
 template <class T>
 static int upload(T** d, const std::vector<T>& h)
 {
@@ -392,8 +403,9 @@ int sp_exact_product(hiopamd_ctx* ctx, int nout, int nnz, const int* iRow, const
 
 extern "C" {
 
-int hiopamd_sp_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
-                         const double* val, double beta, double* y, double alpha, const double* x)
+// y = beta y + alpha M x; y2 != nullptr: the result is stored there as well (the MDS solve packs it into its right-hand side)
+int hiopamd_sp_times_vec_copy(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol, const double* val,
+                              double beta, double* y, double alpha, const double* x, double* y2)
 {
   (void)ncols;
   if(nrows < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
@@ -402,15 +414,20 @@ int hiopamd_sp_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const 
     double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nrows * SPMV_SPLIT);
     hipLaunchKernelGGL(coo_spmv_rows_split, dim3(nrows * SPMV_SPLIT), dim3(kBlock), 0, ctx->stream, nrows, nnz, iRow,
                        jCol, val, x, part);
-    hipLaunchKernelGGL(coo_spmv_fold, dim3((nrows + 63) / 64), dim3(64), 0, ctx->stream, nrows, part, beta, y, alpha);
+    hipLaunchKernelGGL(coo_spmv_fold, dim3((nrows + 63) / 64), dim3(64), 0, ctx->stream, nrows, part, beta, y, alpha, y2);
     HIOPAMD_CHECK(hipGetLastError());
     return HIOPAMD_OK;
   }
   const int64_t threads = (int64_t)nrows * 64;
   hipLaunchKernelGGL(coo_spmv_rows, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
-                     nrows, nnz, iRow, jCol, val, beta, y, alpha, x);
+                     nrows, nnz, iRow, jCol, val, beta, y, alpha, x, y2);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
+}
+int hiopamd_sp_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
+                         const double* val, double beta, double* y, double alpha, const double* x)
+{
+  return hiopamd_sp_times_vec_copy(ctx, nrows, ncols, nnz, iRow, jCol, val, beta, y, alpha, x, nullptr);
 }
 
 int hiopamd_sp_trans_times_vec(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
@@ -428,6 +445,66 @@ int hiopamd_spsym_times_vec(hiopamd_ctx* ctx, int n, int nnz, const int* iRow, c
   if(n < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
   if(n == 0) return HIOPAMD_OK;
   return sp_exact_product<1>(ctx, n, nnz, iRow, jCol, val, beta, y, alpha, x);
+}
+
+int hiopamd_sp_tplan_create(hiopamd_sp_tplan** out, int nrows, int ncols, int nnz, const int* iRow_host, const int* jCol_host)
+{
+  if(!out || nrows < 0 || ncols < 0 || nnz < 0 || (nnz > 0 && (!iRow_host || !jCol_host))) return HIOPAMD_ERR_ARG;
+  for(int k = 0; k < nnz; ++k)
+    if(iRow_host[k] < 0 || iRow_host[k] >= nrows || jCol_host[k] < 0 || jCol_host[k] >= ncols) return HIOPAMD_ERR_ARG;
+  std::vector<int64_t> cptr((size_t)ncols + 1, 0);
+  for(int k = 0; k < nnz; ++k) cptr[(size_t)jCol_host[k] + 1]++;
+  int max_len = 0;
+  for(int c = 0; c < ncols; ++c) {
+    max_len = std::max<int64_t>(max_len, cptr[(size_t)c + 1]);
+    cptr[(size_t)c + 1] += cptr[c];
+  }
+  std::vector<int> perm((size_t)nnz), prow((size_t)nnz);
+  {
+    std::vector<int64_t> pos(cptr.begin(), cptr.end() - 1);
+    for(int k = 0; k < nnz; ++k) {   // stable: list order inside a column
+      const int64_t p = pos[jCol_host[k]]++;
+      perm[(size_t)p] = k;
+      prow[(size_t)p] = iRow_host[k];
+    }
+  }
+  hiopamd_sp_tplan* pl = new hiopamd_sp_tplan();
+  pl->nrows = nrows;
+  pl->ncols = ncols;
+  pl->nnz = nnz;
+  pl->max_len = max_len;
+  int st = upload(&pl->cptr, cptr);
+  if(st == HIOPAMD_OK) st = upload(&pl->perm, perm);
+  if(st == HIOPAMD_OK) st = upload(&pl->prow, prow);
+  if(st != HIOPAMD_OK) {
+    hiopamd_sp_tplan_destroy(pl);
+    return st;
+  }
+  *out = pl;
+  return HIOPAMD_OK;
+}
+int hiopamd_sp_tplan_destroy(hiopamd_sp_tplan* pl)
+{
+  if(!pl) return HIOPAMD_OK;
+  (void)hipFree(pl->cptr);
+  (void)hipFree(pl->perm);
+  (void)hipFree(pl->prow);
+  delete pl;
+  return HIOPAMD_OK;
+}
+int hiopamd_sp_tplan_trans_times_vec(hiopamd_ctx* ctx, const hiopamd_sp_tplan* pl, const double* val, double beta, double* y,
+                                     double alpha, const double* x)
+{
+  if(!ctx || !pl) return HIOPAMD_ERR_ARG;
+  if(pl->ncols == 0) return HIOPAMD_OK;
+  if(pl->max_len <= 64)
+    hipLaunchKernelGGL(sp_tplan_cols, dim3((unsigned)((pl->ncols + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, pl->ncols,
+                       pl->cptr, pl->perm, pl->prow, val, beta, y, alpha, x);
+  else
+    hipLaunchKernelGGL(sp_tplan_cols_wave, dim3((unsigned)(((int64_t)pl->ncols * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                       pl->ncols, pl->cptr, pl->perm, pl->prow, val, beta, y, alpha, x);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
 }
 
 int hiopamd_sp_plan_create(hiopamd_sp_plan** out, int m1, int m2, int ncols, int nnz1, const int* iRow1, const int* jCol1,

@@ -269,11 +269,23 @@ int hiopamd_gram_weighted_stacked(hiopamd_ctx*, int ma, int64_t n, const double*
  * (reference: src/LinAlg/hiopMatrixSparseTriplet.cpp)
  * ===================================================================================== */
 int hiopamd_sp_times_vec(hiopamd_ctx*, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
-                         const double* val, double beta, double* y, double alpha, const double* x);      /* :73 */
+                         const double* val, double beta, double* y, double alpha, const double* x);
+/* the same product with the result stored a second time at y_copy (may be NULL) */
+int hiopamd_sp_times_vec_copy(hiopamd_ctx*, int nrows, int ncols, int nnz, const int* iRow, const int* jCol, const double* val,
+                              double beta, double* y, double alpha, const double* x, double* y_copy);      /* :73 */
 int hiopamd_sp_trans_times_vec(hiopamd_ctx*, int nrows, int ncols, int nnz, const int* iRow, const int* jCol,
                                const double* val, double beta, double* y, double alpha, const double* x); /* :110 */
 /* symbolic plan for  W[r0+i][c0+j] += alpha * sum_c M1[i,c]*M2[j,c]/D[c]  (pattern fixed across IPM iterations,
  * reference comment :479-489).  Index arrays are HOST pointers here (the plan is built once on the host). */
+/* transTimesVec through a column-side plan (hiopMatrixSparseTriplet.cpp:110): the pattern (host index arrays, any order) is turned
+ * ONCE into a per-column list of entries; the product is then one gather per column in list order — no atomics, bitwise
+ * reproducible, one launch.  The plan-less hiopamd_sp_trans_times_vec gives the same guarantee for ANY index arrays by exact
+ * (fixed-point) accumulation, at three launches. */
+typedef struct hiopamd_sp_tplan hiopamd_sp_tplan;
+int hiopamd_sp_tplan_create(hiopamd_sp_tplan** out, int nrows, int ncols, int nnz, const int* iRow_host, const int* jCol_host);
+int hiopamd_sp_tplan_destroy(hiopamd_sp_tplan* plan);
+int hiopamd_sp_tplan_trans_times_vec(hiopamd_ctx* ctx, const hiopamd_sp_tplan* plan, const double* val, double beta, double* y,
+                                     double alpha, const double* x);
 typedef struct hiopamd_sp_plan hiopamd_sp_plan;
 int hiopamd_sp_plan_create(hiopamd_sp_plan** out, int m1, int m2, int ncols, int nnz1, const int* iRow1_host,
                            const int* jCol1_host, int nnz2, const int* iRow2_host, const int* jCol2_host,
@@ -483,6 +495,9 @@ int hiopamd_linsolver_set_retry_copy(hiopamd_linsolver* ls, int enable);
 int hiopamd_linsolver_timeouts(const hiopamd_linsolver* ls, int64_t* count_host);
 /* static schedule of the dataflow factorisation for order n (host only): see csrc/ldlt.hip */
 int hiopamd_ldlt_dataflow_plan(int n, int* dims8_host, int* chain_tasks_host, int* wide_tasks_host, int64_t wide_cap);
+/* which form of the wide kernel factorises order n: 4 = four waves, one workgroup per CU (the default), 8 = eight waves with LDS-DMA
+ * operand staging and selection ahead (HIOPAMD_DF_FORM=8; csrc/ldlt_wide8.hpp) */
+int hiopamd_ldlt_dataflow_form(int n);
 /* the wide kernel's task queues for order n (host only): per super-panel {first TR task, TR tasks, first NEAR update task,
  * NEAR update tasks, NEAR tasks of the first two tile rows} as indices into the wide task list of hiopamd_ldlt_dataflow_plan;
  * _far_queues: per super-panel {first FAR update task, FAR tasks, the super-panel whose FAR list feeds this NEAR list (-1: none),
