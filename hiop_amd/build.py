@@ -25,6 +25,7 @@ SOURCES = [
     "sparse_kernels.hip",
     "sparse_assembly.hip",
     "csr_condensed.hip",
+    "arrow_ldl.hip",
     "kkt_sparse.hip",
     "gram.hip",
     "ldlt.hip",

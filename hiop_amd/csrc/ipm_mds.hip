@@ -110,6 +110,7 @@ struct MdsSolver {
   // ([equalities; inequalities] in the solver's order), decided at the user's starting point (hiopNlpFormulation.cpp:671-714)
   bool scaled = false;
   double s_f = 1.0;
+  bool solved_once = false;   // hiop_*_solve_problem ran (a second call is refused)
   DevBuf<double> d_scal;   // neq + nineq
   double scaling_min_grad = 1e-8;
   DevBuf<int> d_eq_map, d_ineq_map, d_jc_src, d_jd_src, d_Jcs_i, d_Jcs_j, d_Jds_i, d_Jds_j, d_Hss_i, d_Hss_j;
@@ -942,6 +943,14 @@ int hiop_mds_solve_problem(cHiopMDSProblem* problem)
 {
   MdsSolver* s = solver_of(problem);
   if(!s) return HIOPAMD_ERR_ARG;
+  // One solve per problem object.  The reference re-runs finalizeInitialization on every run() and so starts a second solve from the
+  // user's data; this object has by then scaled its bounds and right-hand sides in place and moved them with the slacks: a second
+  // solve is refused instead of being computed from that state — destroy the problem and create it again.
+  if(s->solved_once) {
+    std::fprintf(stderr, "hiop_amd: this problem object was already solved; destroy it and create a new one to solve again\n");
+    return HIOPAMD_ERR_STATE;
+  }
+  s->solved_once = true;
   if(!s->full) {
     const int rc = s->setup();
     if(rc != HIOPAMD_OK) return rc;
@@ -980,6 +989,14 @@ int hiop_dense_solve_problem(cHiopDenseProblem* problem)
 {
   MdsSolver* s = solver_of(problem);
   if(!s) return HIOPAMD_ERR_ARG;
+  // One solve per problem object.  The reference re-runs finalizeInitialization on every run() and so starts a second solve from the
+  // user's data; this object has by then scaled its bounds and right-hand sides in place and moved them with the slacks: a second
+  // solve is refused instead of being computed from that state — destroy the problem and create it again.
+  if(s->solved_once) {
+    std::fprintf(stderr, "hiop_amd: this problem object was already solved; destroy it and create a new one to solve again\n");
+    return HIOPAMD_ERR_STATE;
+  }
+  s->solved_once = true;
   if(!s->full) {
     const int rc = s->setup();
     if(rc != HIOPAMD_OK) return rc;

@@ -29,6 +29,9 @@ struct hiopamd_kkt_sparse_condensed {
   // Krylov probe).  Beyond that order: PCG + Jacobi.
   hiopamd_linsolver* dls = nullptr;
   bool dls_factored = false;   // the dense copy holds factors of the CURRENT M
+  // SPARSE direct inner solver for bordered-diagonal patterns of any order (csrc/arrow_ldl.hip: the arrowhead of the reference's
+  // sparse examples): exact LDL^T with exact inertia.  HIOPAMD_SPARSE_ARROW=0 switches it off (the Krylov path stays testable).
+  hiopamd_arrow_ldl* arrow = nullptr;
   // sparsity (device copies of the triplet index arrays: the SpMVs of the right-hand side / recovery and of the operator)
   int *iJ = nullptr, *jJ = nullptr, *iH = nullptr, *jH = nullptr;
   // current values (borrowed)
@@ -115,6 +118,7 @@ int hiopamd_kkt_sparse_condensed_destroy(hiopamd_kkt_sparse_condensed* k)
   if(k->ctx) (void)hipStreamSynchronize(k->ctx->stream);
   if(k->pcg) hiopamd_krylov_destroy(k->pcg);
   if(k->dls) hiopamd_linsolver_destroy(k->dls);
+  if(k->arrow) hiopamd_arrow_ldl_destroy(k->arrow);
   if(k->csr) hiopamd_csr_condensed_destroy(k->csr);
   (void)hipFree(k->iJ); (void)hipFree(k->jJ); (void)hipFree(k->iH); (void)hipFree(k->jH);
   (void)hipFree(k->Hd); (void)hipFree(k->Dxp); (void)hipFree(k->rhs);
@@ -149,6 +153,15 @@ int hiopamd_kkt_sparse_condensed_create(hiopamd_kkt_sparse_condensed** out, hiop
     const int direct_max = e ? std::atoi(e) : 4096;
     if(rc == HIOPAMD_OK && nx > 0 && nx <= direct_max) rc = hiopamd_linsolver_create(&k->dls, ctx, nx);
     if(rc == HIOPAMD_OK && k->dls) rc = hiopamd_linsolver_set_retry_copy(k->dls, 0);   // (the dense copy is rebuilt after a time-out, see factorize)
+  }
+  if(rc == HIOPAMD_OK && !k->dls && nx > 0 && !(std::getenv("HIOPAMD_SPARSE_ARROW") && std::atoi(std::getenv("HIOPAMD_SPARSE_ARROW")) == 0)) {
+    // the pattern of M decides: bordered diagonal (<= 32 border variables) -> sparse direct solver, else the Krylov inner solver
+    std::vector<int> rp((size_t)nx + 1), ci((size_t)hiopamd_csr_condensed_nnz(k->csr));
+    rc = hiopamd_csr_condensed_pattern(k->csr, rp.data(), ci.data());
+    if(rc == HIOPAMD_OK) {
+      const int ra = hiopamd_arrow_ldl_create(&k->arrow, ctx, nx, rp.data(), ci.data());
+      if(ra != HIOPAMD_OK && ra != HIOPAMD_ERR_STATE) rc = ra;
+    }
   }
   if(rc == HIOPAMD_OK) rc = hiopamd_krylov_set_tol(k->pcg, k->tol);
   if(rc == HIOPAMD_OK) rc = hiopamd_krylov_set_max_num_iter(k->pcg, k->maxit);
@@ -211,6 +224,12 @@ int hiopamd_kkt_sparse_condensed_factorize(hiopamd_kkt_sparse_condensed* k, int*
     *n_neg_host = (rc == HIOPAMD_ERR_SINGULAR || nneg != 0) ? -1 : 0;
     return HIOPAMD_OK;
   }
+  if(k->arrow) {   // exact: M = L diag(D, S) L^T exists with positive pivots iff M is positive definite
+    int nneg = 0, nzero = 0;
+    RC(hiopamd_arrow_ldl_factorize(k->arrow, hiopamd_csr_condensed_values(k->csr), &nneg, &nzero));
+    *n_neg_host = (nneg != 0 || nzero != 0) ? -1 : 0;
+    return HIOPAMD_OK;
+  }
   double* diag = k->rhs;
   RC(hiopamd_csr_condensed_diagonal(k->csr, diag));
   int64_t nonpos = 0;
@@ -250,6 +269,14 @@ int hiopamd_kkt_sparse_condensed_solve_compressed(hiopamd_kkt_sparse_condensed* 
     RC(hiopamd_linsolver_solve(k->dls, k->rhs, 1));
     conv = 1;
     k->last_flag = 0;
+    k->last_iters = 0.0;
+    k->last_rel = 0.0;
+  } else if(k->arrow) {
+    SpanScope span(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);
+    const int ra = hiopamd_arrow_ldl_solve(k->arrow, k->rhs);
+    if(ra != HIOPAMD_OK && ra != HIOPAMD_ERR_STATE) return ra;
+    conv = ra == HIOPAMD_OK ? 1 : 0;   // (ERR_STATE: the last factorisation found M singular / was never run: the reference returns false)
+    k->last_flag = conv ? 0 : 4;
     k->last_iters = 0.0;
     k->last_rel = 0.0;
   } else {

@@ -371,6 +371,17 @@ int hiopamd_csr_condensed_create(hiopamd_csr_condensed** out, hiopamd_ctx* ctx, 
 int hiopamd_csr_condensed_destroy(hiopamd_csr_condensed* c);
 int64_t hiopamd_csr_condensed_nnz(const hiopamd_csr_condensed* c);
 int64_t hiopamd_csr_condensed_num_products(const hiopamd_csr_condensed* c);
+/* ---- bordered-diagonal sparse direct solver (csrc/arrow_ldl.hip): the inner solver of the condensed sparse KKT when a small set
+ * of "border" variables covers every off-diagonal entry of M (the arrowhead of the reference's sparse examples) — the role of the
+ * reference's sparse Cholesky (MA57 / cuSOLVER, hiopKKTLinSysSparseCondensed.cpp:469-496): exact factorisation
+ * M = L diag(D, S) L^T, exact inertia (Haynsworth), solves without host round trips.  create: the pattern of the full symmetric
+ * matrix in CSR (host arrays); HIOPAMD_ERR_STATE when the pattern needs more than 32 border variables (nothing created). */
+typedef struct hiopamd_arrow_ldl hiopamd_arrow_ldl;
+int hiopamd_arrow_ldl_create(hiopamd_arrow_ldl** out, hiopamd_ctx* ctx, int n, const int* rowptr_host, const int* colidx_host);
+int hiopamd_arrow_ldl_destroy(hiopamd_arrow_ldl* s);
+int hiopamd_arrow_ldl_border(const hiopamd_arrow_ldl* s, int* p_host, int* border_host);
+int hiopamd_arrow_ldl_factorize(hiopamd_arrow_ldl* s, const double* csr_values, int* n_neg_host, int* n_zero_host);
+int hiopamd_arrow_ldl_solve(hiopamd_arrow_ldl* s, double* x_inout);
 int hiopamd_csr_condensed_pattern(const hiopamd_csr_condensed* c, int* rowptr_host, int* colidx_host);
 const int* hiopamd_csr_condensed_rowptr(const hiopamd_csr_condensed* c);   /* device */
 const int* hiopamd_csr_condensed_colidx(const hiopamd_csr_condensed* c);   /* device */

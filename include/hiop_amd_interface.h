@@ -60,7 +60,9 @@ typedef struct cHiopMDSProblem {
                         hiop_index_type* iHSD, hiop_index_type* jHSD, double* MHSD, void* user_data);
 } cHiopMDSProblem;
 
-/* chiopInterface.cpp:64-95.  Return 0 on success; a negative hiopamd status otherwise (the reference asserts). */
+/* chiopInterface.cpp:64-95.  Return 0 on success; a negative hiopamd status otherwise (the reference asserts).
+ * ONE solve per problem object: a second hiop_mds_solve_problem on the same object returns HIOPAMD_ERR_STATE (-5) — destroy and create
+ * again (the reference re-initialises from the user's data on every run; this object scales and moves its bounds in place). */
 int hiop_mds_create_problem(cHiopMDSProblem* problem);
 int hiop_mds_solve_problem(cHiopMDSProblem* problem);
 int hiop_mds_destroy_problem(cHiopMDSProblem* problem);
