@@ -27,16 +27,41 @@ constexpr int GEMV_COLS = kBlock * GEMV_COLS_PER_THREAD * GEMV_CHUNKS;  // 8192 
 // then 1 / 1: 4 + 2 + 1 + 3 exchanges instead of 48).
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const double* __restrict__ A, int64_t lda,
-                                                        const double* __restrict__ x, double* __restrict__ part)
+                                                        const double* __restrict__ x, double* __restrict__ part, int chunks)
 {
   const int r0 = blockIdx.y * GEMV_ROWS;
   double acc[GEMV_ROWS];
 #pragma unroll
   for(int r = 0; r < GEMV_ROWS; ++r) acc[r] = 0.0;
-  for(int ch = 0; ch < GEMV_CHUNKS; ++ch) {
-    const int64_t c0 = ((int64_t)blockIdx.x * GEMV_CHUNKS + ch) * (kBlock * GEMV_COLS_PER_THREAD);
+  for(int ch = 0; ch < chunks; ++ch) {
+    const int64_t c0 = ((int64_t)blockIdx.x * chunks + ch) * (kBlock * GEMV_COLS_PER_THREAD);
     if(c0 >= n) break;
     if constexpr(VEC) {
+      // Interior blocks (all GEMV_ROWS rows, a full chunk of columns): no guards, so the 4 + 32 sixteen-byte loads of a chunk are
+      // issued back to back and are all in flight together.  (Round 4: with the guarded form below the compiler put every load in
+      // its own exec-masked branch with an `s_waitcnt vmcnt(0)` behind it -- ONE load in flight per lane; 5.0 TB/s at k = 200,
+      // n = 1.25e6 came from occupancy alone.)
+      if(r0 + GEMV_ROWS <= m && c0 + (int64_t)kBlock * GEMV_COLS_PER_THREAD <= n) {
+        const double* xb = x + c0 + 2 * threadIdx.x;
+        const double* Ab = A + (int64_t)r0 * lda + c0 + 2 * threadIdx.x;
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v xv[GEMV_COLS_PER_THREAD / 2], av[GEMV_ROWS][GEMV_COLS_PER_THREAD / 2];
+#pragma unroll
+        for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u) xv[u] = *reinterpret_cast<const d2v*>(xb + u * 2 * kBlock);
+#pragma unroll
+        for(int r = 0; r < GEMV_ROWS; ++r)
+#pragma unroll
+          for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u)   // A is read once: non-temporal, out of the way of x in L2 (0.353 -> 0.334 ms)
+            av[r][u] = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(Ab + (int64_t)r * lda + u * 2 * kBlock));
+#pragma unroll
+        for(int r = 0; r < GEMV_ROWS; ++r)
+#pragma unroll
+          for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u) {   // same order of the fused multiply-adds as the guarded form
+            acc[r] = fma(av[r][u].x, xv[u].x, acc[r]);
+            acc[r] = fma(av[r][u].y, xv[u].y, acc[r]);
+          }
+        continue;
+      }
       // columns c0 + 2 t + 512 u (+0, +1): 16 bytes per lane, 1 KB per wave per instruction (n even or the pair test below)
       double2 xv[GEMV_COLS_PER_THREAD / 2];
 #pragma unroll
@@ -192,6 +217,8 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage2(int m, int nchunks, cons
 // ------------------------------------------------------------------------------------------
 constexpr int GEMVT_ROWCHUNK = 64;
 
+// CP: column pairs per thread (pair p of thread t = columns base + 512 p + 2 t, +1)
+template <int CP>
 __global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const double* __restrict__ A, int64_t lda,
                                                         const double* __restrict__ x, int rows_per_split,
                                                         double* __restrict__ out, int64_t out_stride, double beta,
@@ -201,40 +228,52 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const 
   int r_end = r_begin + rows_per_split;
   if(r_end > m) r_end = m;
   __shared__ double xs[GEMVT_ROWCHUNK];
-  const int64_t j0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
-  double a0 = 0.0, a1 = 0.0;
-  const bool two = (j0 + 1 < n) && ((lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0);
+  const int64_t jb = (int64_t)blockIdx.x * (2 * kBlock * CP) + 2 * threadIdx.x;
+  double a0[CP], a1[CP];
+#pragma unroll
+  for(int p = 0; p < CP; ++p) a0[p] = a1[p] = 0.0;
+  const bool full = (jb + (int64_t)(CP - 1) * 2 * kBlock + 1 < n) && ((lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0);
   for(int rb = r_begin; rb < r_end; rb += GEMVT_ROWCHUNK) {
     int rc = r_end - rb;
     if(rc > GEMVT_ROWCHUNK) rc = GEMVT_ROWCHUNK;
     __syncthreads();
     if(threadIdx.x < rc) xs[threadIdx.x] = x[rb + threadIdx.x];
     __syncthreads();
-    if(j0 < n) {
-      const double* Ap = A + (int64_t)rb * lda + j0;
-      if(two) {
-#pragma unroll 8
-        for(int r = 0; r < rc; ++r) {
-          const double2 v = *reinterpret_cast<const double2*>(Ap + (int64_t)r * lda);
-          a0 = fma(v.x, xs[r], a0);
-          a1 = fma(v.y, xs[r], a1);
+    if(full) {
+      const double* Ap = A + (int64_t)rb * lda + jb;
+#pragma unroll(8 / CP)
+      for(int r = 0; r < rc; ++r) {
+#pragma unroll
+        for(int p = 0; p < CP; ++p) {
+          const double2 v = *reinterpret_cast<const double2*>(Ap + (int64_t)r * lda + p * 2 * kBlock);
+          a0[p] = fma(v.x, xs[r], a0[p]);
+          a1[p] = fma(v.y, xs[r], a1[p]);
         }
-      } else {
+      }
+    } else {
+#pragma unroll
+      for(int p = 0; p < CP; ++p) {
+        const int64_t j0 = jb + (int64_t)p * 2 * kBlock;
+        if(j0 >= n) continue;
+        const double* Ap = A + (int64_t)rb * lda + j0;
         for(int r = 0; r < rc; ++r) {
-          a0 = fma(Ap[(int64_t)r * lda], xs[r], a0);
-          if(j0 + 1 < n) a1 = fma(Ap[(int64_t)r * lda + 1], xs[r], a1);
+          a0[p] = fma(Ap[(int64_t)r * lda], xs[r], a0[p]);
+          if(j0 + 1 < n) a1[p] = fma(Ap[(int64_t)r * lda + 1], xs[r], a1[p]);
         }
       }
     }
   }
-  if(j0 < n) {
+#pragma unroll
+  for(int p = 0; p < CP; ++p) {
+    const int64_t j0 = jb + (int64_t)p * 2 * kBlock;
+    if(j0 >= n) continue;
     if(direct) {
-      out[j0] = (beta == 0.0 ? 0.0 : beta * out[j0]) + alpha * a0;
-      if(j0 + 1 < n) out[j0 + 1] = (beta == 0.0 ? 0.0 : beta * out[j0 + 1]) + alpha * a1;
+      out[j0] = (beta == 0.0 ? 0.0 : beta * out[j0]) + alpha * a0[p];
+      if(j0 + 1 < n) out[j0 + 1] = (beta == 0.0 ? 0.0 : beta * out[j0 + 1]) + alpha * a1[p];
     } else {
       double* o = out + (int64_t)blockIdx.y * out_stride;
-      o[j0] = a0;
-      if(j0 + 1 < n) o[j0 + 1] = a1;
+      o[j0] = a0[p];
+      if(j0 + 1 < n) o[j0 + 1] = a1[p];
     }
   }
 }
@@ -405,13 +444,20 @@ int hiopamd_mat_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, i
   if(m == 0) return HIOPAMD_OK;
   if(n == 0) return hiopamd_vec_scale(ctx, m, y, beta);
   static const bool v1 = std::getenv("HIOPAMD_GEMV") && std::atoi(std::getenv("HIOPAMD_GEMV")) == 1;
-  const int nchunks = (int)((n + (v1 ? GEMV1_COLS : GEMV_COLS) - 1) / (v1 ? GEMV1_COLS : GEMV_COLS));
+  // column chunks one block walks before it reduces: 4 for the tall-skinny Jacobians (k >= 100 rows: thousands of blocks anyway), fewer
+  // when there are few row tiles (the l x n secant blocks, l <= 8: ONE row tile -- 153 blocks at n = 1.25e6 with 4 chunks, 611 with 1)
   const int rtiles = (m + GEMV_ROWS - 1) / GEMV_ROWS;
+  int chunks = GEMV_CHUNKS;
+  while(chunks > 1 && (int64_t)rtiles * ((n + (int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks - 1) / ((int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks)) < 2048)
+    chunks >>= 1;
+  const int64_t cols = v1 ? GEMV1_COLS : (int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks;
+  const int nchunks = (int)((n + cols - 1) / cols);
   double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nchunks * m);
   const bool vec = (lda % 2 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)x % 16 == 0);
-  if(v1) hipLaunchKernelGGL(gemv_n_stage1_v1, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
-  else if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
-  else hipLaunchKernelGGL(gemv_n_stage1<false>, dim3(nchunks, rtiles), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, part);
+  const dim3 g1(nchunks, rtiles), b1(kBlock);
+  if(v1) hipLaunchKernelGGL(gemv_n_stage1_v1, g1, b1, 0, ctx->stream, m, n, A, lda, x, part);
+  else if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks);
+  else hipLaunchKernelGGL(gemv_n_stage1<false>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks);
   const int waves_per_block = kBlock / 64;
   hipLaunchKernelGGL(gemv_n_stage2, dim3((m + waves_per_block - 1) / waves_per_block), dim3(kBlock), 0, ctx->stream, m,
                      nchunks, part, beta, y, alpha);
@@ -425,7 +471,8 @@ int hiopamd_mat_trans_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double
   if(m < 0 || n < 0) return HIOPAMD_ERR_ARG;
   if(n == 0) return HIOPAMD_OK;
   if(m == 0) return hiopamd_vec_scale(ctx, n, y, beta);
-  const int gx = (int)((n + 2 * kBlock - 1) / (2 * kBlock));
+  constexpr int cp = 1;   // column pairs per thread (two: 0.41 vs 0.36 ms at k = 200, n = 1.25e6 -- scripts/r04_gpu_13.sh)
+  const int gx = (int)((n + 2 * kBlock * cp - 1) / (2 * kBlock * cp));
   // split rows so that the launch has >= ~1024 workgroups when the matrix is not tall-skinny
   int nsplit = 1;
   if(gx < 1024) {
@@ -437,12 +484,13 @@ int hiopamd_mat_trans_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double
   int rows_per_split = (m + nsplit - 1) / nsplit;
   rows_per_split = ((rows_per_split + GEMVT_ROWCHUNK - 1) / GEMVT_ROWCHUNK) * GEMVT_ROWCHUNK;
   nsplit = (m + rows_per_split - 1) / rows_per_split;
+  auto kern = gemv_t_kernel<cp>;
   if(nsplit == 1) {
-    hipLaunchKernelGGL(gemv_t_kernel, dim3(gx, 1), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split, y,
+    hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split, y,
                        (int64_t)0, beta, alpha, 1);
   } else {
     double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * n);
-    hipLaunchKernelGGL(gemv_t_kernel, dim3(gx, nsplit), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split,
+    hipLaunchKernelGGL(kern, dim3(gx, nsplit), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split,
                        part, n, 0.0, 1.0, 0);
     hipLaunchKernelGGL(gemv_t_fold, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, nsplit,
                        part, n, beta, y, alpha);

@@ -683,7 +683,19 @@ __global__ __launch_bounds__(kBlock) void gram_fold_kernel(int ma, int mb, int n
   const int tile = (si / T) * tiles_b + (sj / T);
   const int off = (si % T) * T + (sj % T);
   double s = 0.0;
-  for(int sp = 0; sp < nsplit; ++sp) s += partial[((int64_t)sp * ntiles + tile) * (T * T) + off];
+  // sixteen partials in flight per lane, summed in split order (round 4: the plain loop was one dependent load per addition --
+  // 256 splits x one memory latency = 125 us for 166 workgroups' worth of outputs)
+  const double* pp = partial + (int64_t)tile * (T * T) + off;
+  const int64_t ps = (int64_t)ntiles * (T * T);
+  int sp = 0;
+  for(; sp + 16 <= nsplit; sp += 16) {
+    double t[16];
+#pragma unroll
+    for(int u = 0; u < 16; ++u) t[u] = pp[(int64_t)(sp + u) * ps];
+#pragma unroll
+    for(int u = 0; u < 16; ++u) s += t[u];
+  }
+  for(; sp < nsplit; ++sp) s += pp[(int64_t)sp * ps];
   double* w = W + (int64_t)i * ldw + j;
   const double v = (beta == 0.0 ? 0.0 : beta * (*w)) + alpha * s;
   *w = v;
@@ -760,6 +772,76 @@ __global__ __launch_bounds__(64) void gram_small_fold(int ma, int mb, int nsplit
   const double v = (beta == 0.0 ? 0.0 : beta * (*w)) + alpha * s;
   *w = v;
   if(sym && j > i) W[(int64_t)j * ldw + i] = v;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// The four l x l blocks of hiopHessianLowRank::updateInternalBFGSRepresentation (hiopHessianLowRank.cpp:400-460) and of the compact
+// direct form in ONE pass over S, Y and DhInv (round 4; before: four gram_small passes, each re-reading its rows and a weight vector
+// written by an element-wise launch in between):
+//   G0 = Y DhInv Y^T      G1 = S (sigma DhInv) Y^T      G2 = S (sigma (sigma DhInv - 1)) S^T      G3 = sigma S S^T
+// Wave q of a workgroup accumulates block q over the workgroup's column chunk (the four waves read the same lines: HBM once, the
+// repeats are L2 / L1 hits); the weights are formed per element exactly as the element-wise launches formed them.  Partials go
+// to [split][4][64]; gram_quad_fold sums the splits lane-strided + shuffle tree (fixed order), mirrors the symmetric blocks.
+// ---------------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(kBlock) void gram_quad_partial(int64_t n, const double* __restrict__ S, const double* __restrict__ Y,
+                                                            int64_t ld, const double* __restrict__ dh, double sigma, int64_t kchunk,
+                                                            double* __restrict__ partial)
+{
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t kbeg = (int64_t)blockIdx.x * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if(kend > n) kend = n;
+  const double* __restrict__ A = (q == 0) ? Y : S;
+  const double* __restrict__ B = (q <= 1) ? Y : S;
+  double acc[L][L];
+#pragma unroll
+  for(int i = 0; i < L; ++i)
+#pragma unroll
+    for(int j = 0; j < L; ++j) acc[i][j] = 0.0;
+  for(int64_t k = kbeg + lane; k < kend; k += 64) {
+    double a[L], b[L];
+    const double d = (q == 3) ? 1.0 : dh[k];
+#pragma unroll
+    for(int i = 0; i < L; ++i) a[i] = A[(int64_t)i * ld + k];
+#pragma unroll
+    for(int j = 0; j < L; ++j) b[j] = B[(int64_t)j * ld + k];
+    const double w = (q == 0) ? d : (q == 1) ? d * sigma : (q == 2) ? (d * sigma - 1.0) * sigma : 1.0;
+#pragma unroll
+    for(int i = 0; i < L; ++i) a[i] *= w;
+#pragma unroll
+    for(int i = 0; i < L; ++i)
+#pragma unroll
+      for(int j = 0; j < L; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  }
+  double* out = partial + ((int64_t)blockIdx.x * 4 + q) * (GS_M * GS_M);
+#pragma unroll
+  for(int i = 0; i < L; ++i)
+#pragma unroll
+    for(int j = 0; j < L; ++j) {
+      double v = acc[i][j];
+      for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if(lane == 0) out[i * GS_M + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void gram_quad_fold(int l, int nsplit, const double* __restrict__ partial, double sigma,
+                                                     double* __restrict__ G)
+{
+  const int q = blockIdx.x / (GS_M * GS_M), e = blockIdx.x % (GS_M * GS_M);
+  const int i = e / GS_M, j = e % GS_M;
+  if(i >= l || j >= l) return;
+  const bool sym = q != 1;
+  if(sym && j < i) return;
+  double s = 0.0;
+  for(int sp = threadIdx.x; sp < nsplit; sp += 64) s += partial[((int64_t)sp * 4 + q) * (GS_M * GS_M) + e];
+  for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if(threadIdx.x != 0) return;
+  const double v = (q == 3) ? sigma * s : s;
+  double* W = G + (int64_t)q * l * l;
+  W[i * l + j] = v;
+  if(sym && j > i) W[j * l + i] = v;
 }
 
 }  // namespace hiopamd
@@ -925,4 +1007,32 @@ extern "C" int hiopamd_gram_weighted_stacked(hiopamd_ctx* ctx, int ma, int64_t n
   // mirrored instead of computed (one tile in four at k = 200)
   const int sym_cols = (B0 == A && ldb0 == lda && m0 == ma) ? m0 : 0;
   return gram_launch(ctx, ma, m0 + m1 + m2, n, Ra, 1, Rb, 3, false, d, beta, W, ldw, alpha, 0, sym_cols);
+}
+
+// G (4 l^2 doubles) = [ Y DhInv Y^T | S (sigma DhInv) Y^T | S (sigma (sigma DhInv - 1)) S^T | sigma S S^T ], l x l row-major each
+extern "C" int hiopamd_gram_lowrank_blocks(hiopamd_ctx* ctx, int l, int64_t n, const double* St, const double* Yt, int64_t ld,
+                                           const double* DhInv, double sigma, double* G)
+{
+  if(!ctx || l < 0 || l > GS_M || n < 0 || (l > 0 && (!St || !Yt || !DhInv || !G))) return HIOPAMD_ERR_ARG;
+  if(l == 0) return HIOPAMD_OK;
+  if(n == 0) return hiopamd_vec_set_to_constant(ctx, 4 * (int64_t)l * l, G, 0.0);
+  int nsplit = 512;
+  int64_t kchunk = (n + nsplit - 1) / nsplit;
+  if(kchunk < 16 * 64) kchunk = 16 * 64;
+  nsplit = (int)((n + kchunk - 1) / kchunk);
+  double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * 4 * GS_M * GS_M);
+  const dim3 g(nsplit), b(kBlock);
+  switch(l) {
+    case 1: hipLaunchKernelGGL(gram_quad_partial<1>, g, b, 0, ctx->stream, n, St, Yt, ld, DhInv, sigma, kchunk, partial); break;
+    case 2: hipLaunchKernelGGL(gram_quad_partial<2>, g, b, 0, ctx->stream, n, St, Yt, ld, DhInv, sigma, kchunk, partial); break;
+    case 3: hipLaunchKernelGGL(gram_quad_partial<3>, g, b, 0, ctx->stream, n, St, Yt, ld, DhInv, sigma, kchunk, partial); break;
+    case 4: hipLaunchKernelGGL(gram_quad_partial<4>, g, b, 0, ctx->stream, n, St, Yt, ld, DhInv, sigma, kchunk, partial); break;
+    case 5: hipLaunchKernelGGL(gram_quad_partial<5>, g, b, 0, ctx->stream, n, St, Yt, ld, DhInv, sigma, kchunk, partial); break;
+    case 6: hipLaunchKernelGGL(gram_quad_partial<6>, g, b, 0, ctx->stream, n, St, Yt, ld, DhInv, sigma, kchunk, partial); break;
+    case 7: hipLaunchKernelGGL(gram_quad_partial<7>, g, b, 0, ctx->stream, n, St, Yt, ld, DhInv, sigma, kchunk, partial); break;
+    default: hipLaunchKernelGGL(gram_quad_partial<8>, g, b, 0, ctx->stream, n, St, Yt, ld, DhInv, sigma, kchunk, partial); break;
+  }
+  hipLaunchKernelGGL(gram_quad_fold, dim3(4 * GS_M * GS_M), dim3(64), 0, ctx->stream, l, nsplit, partial, sigma, G);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
 }

@@ -36,18 +36,20 @@ namespace hiopamd {
 
 constexpr int kMaxV = 64;  // 2*l_max <= 64
 
-// Solve V X = B for `nrhs` right-hand sides by LU with partial pivoting; V (nv x nv, full symmetric,
-// row-major, ld = nv) is NOT modified; B is nrhs x nv row-major (each ROW is one right-hand side — the
-// "RHS_fortran" view of the reference, hiopHessianLowRank.cpp:601-606) and is overwritten by the solutions.
-// Every workgroup factors V redundantly in LDS (nv <= 64) and solves 256 right-hand sides.
-__global__ __launch_bounds__(kBlock) void small_lu_solve_kernel(int nv, const double* __restrict__ V, int nrhs,
-                                                                double* __restrict__ B, int64_t ldb, int* __restrict__ info)
+// V X = B for the 2l x 2l middle matrices (V of solveWithV, hiopHessianLowRank.cpp:677; M of the compact direct form): LU with
+// partial pivoting.  Round 4: the factorisation runs ONCE per secant update (small_lu_factor_kernel: one workgroup, factors and
+// pivots to device memory); a solve loads them into LDS and substitutes (small_lu_apply_kernel: one thread per right-hand side,
+// its vector in LDS).  Before, every solve re-factored V and kept its vector in a dynamically indexed private array (scratch
+// memory): 25 us per call, seven calls per KKT step.  B is nrhs x nv row-major (each ROW is one right-hand side -- the
+// "RHS_fortran" view of the reference, :601-606); X may be B (in place).
+__global__ __launch_bounds__(kBlock) void small_lu_factor_kernel(int nv, const double* __restrict__ V, double* __restrict__ LUg,
+                                                                 int* __restrict__ pivg, int* __restrict__ info)
 {
   __shared__ double LU[kMaxV][kMaxV + 1];
-  __shared__ int piv[kMaxV];
   __shared__ int pr;
   const int tid = threadIdx.x;
   for(int e = tid; e < nv * nv; e += kBlock) LU[e / nv][e % nv] = V[e];
+  if(tid == 0) *info = 0;
   __syncthreads();
   for(int k = 0; k < nv; ++k) {
     if(tid == 0) {
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(kBlock) void small_lu_solve_kernel(int nv, const do
         }
       }
       pr = p;
-      piv[k] = p;
-      if((best == 0.0 || !isfinite(best)) && blockIdx.x == 0) atomicCAS(info, 0, k + 1);
+      pivg[k] = p;
+      if((best == 0.0 || !isfinite(best)) && *info == 0) *info = k + 1;
     }
     __syncthreads();
     const int p = pr;
@@ -84,32 +86,45 @@ __global__ __launch_bounds__(kBlock) void small_lu_solve_kernel(int nv, const do
     }
     __syncthreads();
   }
-  // one right-hand side per thread, kept in LDS-free local storage of fixed size
-  const int j = blockIdx.x * kBlock + tid;
+  for(int e = tid; e < nv * nv; e += kBlock) LUg[e] = LU[e / nv][e % nv];
+}
+
+constexpr int kLuApplyBlock = 64;
+__global__ __launch_bounds__(kLuApplyBlock) void small_lu_apply_kernel(int nv, const double* __restrict__ LUg,
+                                                                       const int* __restrict__ pivg, int nrhs,
+                                                                       const double* B, int64_t ldb, double* X, int64_t ldx)
+{
+  extern __shared__ double lu_sm[];   // LU (nv x nv) | x (nv x 64: element i of thread t at [i * 64 + t])
+  double* LU = lu_sm;
+  double* xs = lu_sm + nv * nv;
+  const int tid = threadIdx.x;
+  for(int e = tid; e < nv * nv; e += kLuApplyBlock) LU[e] = LUg[e];
+  __syncthreads();
+  const int j = blockIdx.x * kLuApplyBlock + tid;
   if(j >= nrhs) return;
-  double x[kMaxV];
-  double* b = B + (int64_t)j * ldb;
-#pragma unroll 1
-  for(int i = 0; i < nv; ++i) x[i] = b[i];
+  double* x = xs + tid;
+  const double* b = B + (int64_t)j * ldb;
+  for(int i = 0; i < nv; ++i) x[i * kLuApplyBlock] = b[i];
   for(int k = 0; k < nv; ++k) {
-    const int p = piv[k];
+    const int p = pivg[k];
     if(p != k) {
-      const double t = x[k];
-      x[k] = x[p];
-      x[p] = t;
+      const double t = x[k * kLuApplyBlock];
+      x[k * kLuApplyBlock] = x[p * kLuApplyBlock];
+      x[p * kLuApplyBlock] = t;
     }
   }
   for(int i = 1; i < nv; ++i) {
-    double acc = x[i];
-    for(int c = 0; c < i; ++c) acc -= LU[i][c] * x[c];
-    x[i] = acc;
+    double acc = x[i * kLuApplyBlock];
+    for(int c = 0; c < i; ++c) acc -= LU[i * nv + c] * x[c * kLuApplyBlock];
+    x[i * kLuApplyBlock] = acc;
   }
   for(int i = nv - 1; i >= 0; --i) {
-    double acc = x[i];
-    for(int c = i + 1; c < nv; ++c) acc -= LU[i][c] * x[c];
-    x[i] = acc / LU[i][i];
+    double acc = x[i * kLuApplyBlock];
+    for(int c = i + 1; c < nv; ++c) acc -= LU[i * nv + c] * x[c * kLuApplyBlock];
+    x[i * kLuApplyBlock] = acc / LU[i * nv + i];
   }
-  for(int i = 0; i < nv; ++i) b[i] = x[i];
+  double* xo = X + (int64_t)j * ldx;
+  for(int i = 0; i < nv; ++i) xo[i] = x[i * kLuApplyBlock];
 }
 
 // V (2l x 2l, full symmetric) from the three reduced Gram blocks G = [YtDhInvY | StB0DhInvY | StDS] (each l x l)
@@ -138,56 +153,94 @@ __global__ void assemble_V_kernel(int l, const double* __restrict__ G, const dou
   }
 }
 
-// three dots in one pass: out = [x.y, x.x, y.y]
 // Secant update, Jacobian part in ONE pass (reference: four GEMVs over Jc, Jc_prev, Jd, Jd_prev followed by two full copies
 // Jac_prev <- Jac, hiopHessianLowRank.cpp:293-299,366-371 — 8 x the Jacobian's bytes; here 3 x):
 //   y_new[j] += sum_r (J[r][j] - Jprev[r][j]) * mult[r]      and      Jprev[r][j] = J[r][j]
 // one thread per two adjacent columns, the multipliers staged in LDS per chunk of rows.
 constexpr int SJ_ROWCHUNK = 256;
+// CP: column pairs per thread (pair p of thread t = columns base + 512 p + 2 t, +1): a workgroup streams CP x 4 KB of every row
+template <int CP>
 __global__ __launch_bounds__(kBlock) void secant_jac_kernel(int m, int64_t n, const double* __restrict__ J, double* __restrict__ Jp,
                                                             const double* __restrict__ mult, double* __restrict__ y_new)
 {
   __shared__ double ms[SJ_ROWCHUNK];
-  const int64_t j0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
-  const bool two = (j0 + 1 < n) && ((n & 1) == 0) && ((((uintptr_t)J) & 15) == 0) && ((((uintptr_t)Jp) & 15) == 0);
-  double a0 = 0.0, a1 = 0.0;
+  const int64_t jb = (int64_t)blockIdx.x * (2 * kBlock * CP) + 2 * threadIdx.x;
+  const bool vec_ok = ((n & 1) == 0) && ((((uintptr_t)J) & 15) == 0) && ((((uintptr_t)Jp) & 15) == 0);
+  double a0[CP], a1[CP];
+#pragma unroll
+  for(int p = 0; p < CP; ++p) a0[p] = a1[p] = 0.0;
+  const bool full = vec_ok && (jb + (int64_t)(CP - 1) * 2 * kBlock + 1 < n);   // every pair of this thread inside the row
   for(int rb = 0; rb < m; rb += SJ_ROWCHUNK) {
     const int rc = (m - rb < SJ_ROWCHUNK) ? (m - rb) : SJ_ROWCHUNK;
     __syncthreads();
     if((int)threadIdx.x < rc) ms[threadIdx.x] = mult[rb + threadIdx.x];
     __syncthreads();
-    if(j0 < n) {
-      const double* Jr = J + (int64_t)rb * n + j0;
-      double* Pr = Jp + (int64_t)rb * n + j0;
-      if(two) {
-#pragma unroll 4
-        for(int r = 0; r < rc; ++r) {
-          const double2 v = *reinterpret_cast<const double2*>(Jr + (int64_t)r * n);
-          const double2 q = *reinterpret_cast<const double2*>(Pr + (int64_t)r * n);
-          a0 = fma(v.x - q.x, ms[r], a0);
-          a1 = fma(v.y - q.y, ms[r], a1);
-          *reinterpret_cast<double2*>(Pr + (int64_t)r * n) = v;
+    if(full) {
+      // batches of RBATCH rows: all loads of a batch are issued before its first store (the compiler cannot move a load of J_prev
+      // across a store to J_prev on its own: with the plain loop 2 loads were in flight per lane); same order of the multiply-adds
+      constexpr int RBATCH = 8 / CP;
+      const double* Jr = J + (int64_t)rb * n + jb;
+      double* Pr = Jp + (int64_t)rb * n + jb;
+      int r = 0;
+      for(; r + RBATCH <= rc; r += RBATCH) {
+        double2 v[RBATCH][CP], q[RBATCH][CP];
+#pragma unroll
+        for(int u = 0; u < RBATCH; ++u)
+#pragma unroll
+          for(int p = 0; p < CP; ++p) v[u][p] = *reinterpret_cast<const double2*>(Jr + (int64_t)(r + u) * n + p * 2 * kBlock);
+#pragma unroll
+        for(int u = 0; u < RBATCH; ++u)
+#pragma unroll
+          for(int p = 0; p < CP; ++p) q[u][p] = *reinterpret_cast<const double2*>(Pr + (int64_t)(r + u) * n + p * 2 * kBlock);
+#pragma unroll
+        for(int u = 0; u < RBATCH; ++u)
+#pragma unroll
+          for(int p = 0; p < CP; ++p) {
+            a0[p] = fma(v[u][p].x - q[u][p].x, ms[r + u], a0[p]);
+            a1[p] = fma(v[u][p].y - q[u][p].y, ms[r + u], a1[p]);
+            *reinterpret_cast<double2*>(Pr + (int64_t)(r + u) * n + p * 2 * kBlock) = v[u][p];
+          }
+      }
+      for(; r < rc; ++r)
+#pragma unroll
+        for(int p = 0; p < CP; ++p) {
+          const double2 v = *reinterpret_cast<const double2*>(Jr + (int64_t)r * n + p * 2 * kBlock);
+          const double2 q = *reinterpret_cast<const double2*>(Pr + (int64_t)r * n + p * 2 * kBlock);
+          a0[p] = fma(v.x - q.x, ms[r], a0[p]);
+          a1[p] = fma(v.y - q.y, ms[r], a1[p]);
+          *reinterpret_cast<double2*>(Pr + (int64_t)r * n + p * 2 * kBlock) = v;
         }
-      } else {
+    } else {
+#pragma unroll
+      for(int p = 0; p < CP; ++p) {
+        const int64_t j0 = jb + (int64_t)p * 2 * kBlock;
+        if(j0 >= n) continue;
+        const double* Jr = J + (int64_t)rb * n + j0;
+        double* Pr = Jp + (int64_t)rb * n + j0;
         for(int r = 0; r < rc; ++r) {
           const double v0 = Jr[(int64_t)r * n], q0 = Pr[(int64_t)r * n];
-          a0 = fma(v0 - q0, ms[r], a0);
+          a0[p] = fma(v0 - q0, ms[r], a0[p]);
           Pr[(int64_t)r * n] = v0;
           if(j0 + 1 < n) {
             const double v1 = Jr[(int64_t)r * n + 1], q1 = Pr[(int64_t)r * n + 1];
-            a1 = fma(v1 - q1, ms[r], a1);
+            a1[p] = fma(v1 - q1, ms[r], a1[p]);
             Pr[(int64_t)r * n + 1] = v1;
           }
         }
       }
     }
   }
-  if(j0 < n) {
-    y_new[j0] += a0;
-    if(j0 + 1 < n) y_new[j0 + 1] += a1;
+#pragma unroll
+  for(int p = 0; p < CP; ++p) {
+    const int64_t j0 = jb + (int64_t)p * 2 * kBlock;
+    if(j0 < n) {
+      y_new[j0] += a0[p];
+      if(j0 + 1 < n) y_new[j0 + 1] += a1[p];
+    }
   }
 }
 
+// three dots in one pass: out = [x.y, x.x, y.y]
 struct dot3_t {
   double a, b, c;
 };
@@ -200,6 +253,24 @@ struct OpDot3 {
     return dot3_t{xv * yv, xv * xv, yv * yv};
   }
   __device__ dot3_t combine(dot3_t p, dot3_t q) const { return dot3_t{p.a + q.a, p.b + q.b, p.c + q.c}; }
+};
+// the secant update's four scalars in one pass: max |s_i| (comparison semantics of vec_infnorm: a NaN never replaces the running
+// maximum) and the three dot products of OpDot3, summed in the same order as there
+struct sec4_t {
+  double a, b, c, smax;
+};
+struct OpSecant4 {
+  const double *x, *y;
+  __device__ sec4_t identity() const { return sec4_t{0.0, 0.0, 0.0, 0.0}; }
+  __device__ sec4_t map(int64_t i) const
+  {
+    const double xv = x[i], yv = y[i];
+    return sec4_t{xv * yv, xv * xv, yv * yv, fabs(xv)};
+  }
+  __device__ sec4_t combine(sec4_t p, sec4_t q) const
+  {
+    return sec4_t{p.a + q.a, p.b + q.b, p.c + q.c, (q.smax > p.smax) ? q.smax : p.smax};
+  }
 };
 
 }  // namespace hiopamd
@@ -226,6 +297,8 @@ struct hiopamd_hess_lowrank {
   double *dSS = nullptr;                     // [sigma S^T S | L ; L^T | -D] for the compact mat-vec
   double *dsmall = nullptr;                  // small vectors (8 * 2 l_max)
   int* dinfo = nullptr;
+  double *dVlu = nullptr, *dSSlu = nullptr;  // LU factors of dV / dSS (once per secant update)
+  int *dVpiv = nullptr, *dSSpiv = nullptr;   // their pivots (inside the dinfo allocation)
   // host mirrors of the tiny BFGS bookkeeping (reference keeps L_, D_ on the host as well)
   std::vector<double> L, D;
   bool have_prev = false;
@@ -250,13 +323,23 @@ static int to_dev(hiopamd_ctx* ctx, void* dst, const void* src, size_t bytes)
   return HIOPAMD_OK;
 }
 
-static int small_lu_solve(hiopamd_ctx* ctx, int nv, const double* V, int nrhs, double* B, int64_t ldb, int* dinfo)
+static int small_lu_factor(hiopamd_ctx* ctx, int nv, const double* V, double* LU, int* piv, int* dinfo)
+{
+  if(nv == 0) return HIOPAMD_OK;
+  if(nv > kMaxV) return HIOPAMD_ERR_ARG;
+  hipLaunchKernelGGL(small_lu_factor_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, nv, V, LU, piv, dinfo);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+// X (nrhs rows of nv, leading dimension ldx) = solutions of the factored system for the rows of B; X == B allowed
+static int small_lu_apply(hiopamd_ctx* ctx, int nv, const double* LU, const int* piv, int nrhs, const double* B, int64_t ldb,
+                          double* X, int64_t ldx)
 {
   if(nv == 0 || nrhs == 0) return HIOPAMD_OK;
   if(nv > kMaxV) return HIOPAMD_ERR_ARG;
-  HIOPAMD_CHECK(hipMemsetAsync(dinfo, 0, sizeof(int), ctx->stream));
-  hipLaunchKernelGGL(small_lu_solve_kernel, dim3((nrhs + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nv, V, nrhs,
-                     B, ldb, dinfo);
+  const size_t lds = sizeof(double) * ((size_t)nv * nv + (size_t)nv * kLuApplyBlock);
+  hipLaunchKernelGGL(small_lu_apply_kernel, dim3((nrhs + kLuApplyBlock - 1) / kLuApplyBlock), dim3(kLuApplyBlock), lds, ctx->stream,
+                     nv, LU, piv, nrhs, B, ldb, X, ldx);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
 }
@@ -279,9 +362,13 @@ int hiopamd_hess_lowrank_create(hiopamd_hess_lowrank** out, hiopamd_ctx* ctx, in
   auto A = [](double** p, size_t cnt) { return hipMalloc((void**)p, sizeof(double) * (cnt ? cnt : 1)) == hipSuccess; };
   bool ok = A(&h->St, lm * n) && A(&h->Yt, lm * n) && A(&h->DhInv, n) && A(&h->Dx, n) && A(&h->x_prev, n) &&
             A(&h->g_prev, n) && A(&h->Jc_prev, (size_t)m_eq * n) && A(&h->Jd_prev, (size_t)m_ineq * n) && A(&h->nv1, n) &&
-            A(&h->nv2, n) && A(&h->dL, lm * lm) && A(&h->dD, lm) && A(&h->dG, 3 * lm * lm) && A(&h->dV, 4 * lm * lm) &&
-            A(&h->dSS, 4 * lm * lm) && A(&h->dsmall, 16 * 2 * lm + 64);
-  ok = ok && hipMalloc((void**)&h->dinfo, 64) == hipSuccess;
+            A(&h->nv2, n) && A(&h->dL, lm * lm) && A(&h->dD, lm) && A(&h->dG, 4 * lm * lm) && A(&h->dV, 4 * lm * lm) &&
+            A(&h->dSS, 4 * lm * lm) && A(&h->dVlu, 4 * lm * lm) && A(&h->dSSlu, 4 * lm * lm) && A(&h->dsmall, 16 * 2 * lm + 64);
+  ok = ok && hipMalloc((void**)&h->dinfo, 64 + sizeof(int) * 4 * (size_t)lm) == hipSuccess;
+  if(ok) {
+    h->dVpiv = h->dinfo + 16;
+    h->dSSpiv = h->dVpiv + 2 * lm;
+  }
   if(!ok) {
     hiopamd_hess_lowrank_destroy(h);
     return HIOPAMD_ERR_HIP;
@@ -297,7 +384,7 @@ int hiopamd_hess_lowrank_destroy(hiopamd_hess_lowrank* h)
   if(!h) return HIOPAMD_OK;
   (void)hipStreamSynchronize(h->ctx->stream);
   double* ps[] = {h->St, h->Yt, h->DhInv, h->Dx, h->x_prev, h->g_prev, h->Jc_prev, h->Jd_prev, h->nv1, h->nv2,
-                  h->dL, h->dD, h->dG,    h->dV, h->dSS,    h->dsmall};
+                  h->dL, h->dD, h->dG,    h->dV, h->dSS,    h->dsmall, h->dVlu, h->dSSlu};
   for(double* p : ps) (void)hipFree(p);
   (void)hipFree(h->dinfo);
   delete h;
@@ -362,44 +449,44 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
     s_new[i] = x[i] - xp[i];
     y_new[i] = grad_f[i] - gp[i];
   }));
-  double s_inf = 0.0;
+  // One pass for the secant pair and ONE host round trip for everything the decisions below need (round 4; before: infnorm,
+  // the three dot products and Yt*s were three round trips, three collectives).  The Jacobian pass runs before the step-length test
+  // instead of behind it: for a zero step it adds (J - J_prev)^T y to a y_new nobody reads and refreshes J_prev, which
+  // save_prev() would do anyway.
+  //   y_new += (Jc - Jc_prev)^T yc + (Jd - Jd_prev)^T yd                      (:293-299)
   {
-    ReduceNow now(ctx);
-    RC(hiopamd_vec_infnorm(ctx, n, s_new, &s_inf));
+    // (two column pairs per thread -- 8 KB of a row per workgroup -- measured slower: 5.84 vs 5.56 ms per step, scripts/r04_gpu_13.sh)
+    const unsigned gx = (unsigned)((n + 2 * (int64_t)kBlock - 1) / (2 * (int64_t)kBlock));
+    if(me > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel<1>, dim3(gx), dim3(kBlock), 0, ctx->stream, me, n, Jc, h->Jc_prev, yc, y_new);
+    if(mi > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel<1>, dim3(gx), dim3(kBlock), 0, ctx->stream, mi, n, Jd, h->Jd_prev, yd, y_new);
+    HIOPAMD_CHECK(hipGetLastError());
+    jac_saved = true;
   }
-  if(ctx->allreduce) {
-    RC(to_dev(ctx, h->dsmall, &s_inf, sizeof(double)));
-    RC(allreduce_dev(ctx, h->dsmall, 1, HIOPAMD_MAX));
-    RC(to_host(ctx, &s_inf, h->dsmall, sizeof(double)));
+  const int l0 = (h->l_max > 0 && h->l_curr > 0) ? h->l_curr : 0;
+  std::vector<double> YTs(l0 > 0 ? l0 : 1, 0.0);
+  if(l0 > 0) {  // YTs = Yt * s_new (:311), fetched together with the scalars
+    RC(hiopamd_mat_times_vec(ctx, l0, n, h->Yt, n, 0.0, h->dsmall, 1.0, s_new));
+    if(!ctx->allreduce) HIOPAMD_CHECK(hipMemcpyAsync(YTs.data(), h->dsmall, sizeof(double) * l0, hipMemcpyDeviceToHost, ctx->stream));
   }
+  sec4_t d4{0, 0, 0, 0};   // [max |s|, s^T y, s^T s, y^T y]                     (:283, :301)
+  RC(launch_reduce<sec4_t>(ctx, n, OpSecant4{s_new, y_new}, &d4));
+  if(ctx->allreduce) {     // two collectives: SUM over [Yt s (l), s^T y, s^T s, y^T y], MAX over |s|
+    RC(to_dev(ctx, h->dsmall + l0, &d4.a, sizeof(double) * 3));
+    RC(allreduce_dev(ctx, h->dsmall, (size_t)l0 + 3, HIOPAMD_SUM));
+    RC(to_dev(ctx, h->dsmall + l0 + 3, &d4.smax, sizeof(double)));
+    RC(allreduce_dev(ctx, h->dsmall + l0 + 3, 1, HIOPAMD_MAX));
+    std::vector<double> back((size_t)l0 + 4);
+    RC(to_host(ctx, back.data(), h->dsmall, sizeof(double) * back.size()));
+    for(int j = 0; j < l0; ++j) YTs[j] = back[j];
+    d4.a = back[l0], d4.b = back[l0 + 1], d4.c = back[l0 + 2], d4.smax = back[l0 + 3];
+  }
+  const double s_inf = d4.smax;
   if(s_inf >= 100 * std::numeric_limits<double>::epsilon()) {
-    // y_new += (Jc - Jc_prev)^T yc + (Jd - Jd_prev)^T yd                      (:293-299)
-    // (one pass per Jacobian that also refreshes Jc_prev / Jd_prev: secant_jac_kernel)
-    {
-      const unsigned gx = (unsigned)((n + 2 * (int64_t)kBlock - 1) / (2 * (int64_t)kBlock));
-      if(me > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel, dim3(gx), dim3(kBlock), 0, ctx->stream, me, n, Jc, h->Jc_prev, yc, y_new);
-      if(mi > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel, dim3(gx), dim3(kBlock), 0, ctx->stream, mi, n, Jd, h->Jd_prev, yd, y_new);
-      HIOPAMD_CHECK(hipGetLastError());
-      jac_saved = true;
-    }
-    // [s^T y, s^T s, y^T y] in one pass + one all-reduce                      (:301)
-    dot3_t d3{0, 0, 0};
-    RC(launch_reduce<dot3_t>(ctx, n, OpDot3{s_new, y_new}, &d3));
-    if(ctx->allreduce) {
-      RC(to_dev(ctx, h->dsmall, &d3, sizeof(d3)));
-      RC(allreduce_dev(ctx, h->dsmall, 3, HIOPAMD_SUM));
-      RC(to_host(ctx, &d3, h->dsmall, sizeof(d3)));
-    }
+    const dot3_t d3{d4.a, d4.b, d4.c};
     const double sTy = d3.a, s_nrm2 = std::sqrt(d3.b), y_nrm2 = std::sqrt(d3.c);
     if(sTy > s_nrm2 * y_nrm2 * std::sqrt(std::numeric_limits<double>::epsilon())) {
       if(h->l_max > 0) {
         const int l = h->l_curr;
-        std::vector<double> YTs(l > 0 ? l : 1, 0.0);
-        if(l > 0) {  // YTs = Yt * s_new (:311)
-          RC(hiopamd_mat_times_vec(ctx, l, n, h->Yt, n, 0.0, h->dsmall, 1.0, s_new));
-          RC(allreduce_dev(ctx, h->dsmall, l, HIOPAMD_SUM));
-          RC(to_host(ctx, YTs.data(), h->dsmall, sizeof(double) * l));
-        }
         if(l < h->l_max) {  // grow (:313-320, growL :779, growD :808)
           RC(hiopamd_vec_copy(ctx, n, h->St + (int64_t)l * n, s_new));
           RC(hiopamd_vec_copy(ctx, n, h->Yt + (int64_t)l * n, y_new));
@@ -450,25 +537,19 @@ static int update_internal_bfgs_representation(hiopamd_hess_lowrank* h)
   h->matrix_changed = false;
   if(l == 0) return HIOPAMD_OK;
   double* G = h->dG;
-  double* w = h->nv1;
-  const double* DhInv = h->DhInv;
   const double sigma = h->sigma;
-  // G0 = Yt DhInv Yt^T ; G1 = St (sigma DhInv) Yt^T ; G2 = St (sigma (sigma DhInv - 1)) St^T
-  RC(hiopamd_gram_weighted(ctx, l, l, n, h->Yt, n, h->Yt, n, DhInv, 0.0, G, l, 1.0, 1));
-  RC(launch_ew(ctx, n, [=] __device__(int64_t i) { w[i] = DhInv[i] * sigma; }));
-  RC(hiopamd_gram_weighted(ctx, l, l, n, h->St, n, h->Yt, n, w, 0.0, G + l * l, l, 1.0, 0));
-  RC(launch_ew(ctx, n, [=] __device__(int64_t i) { w[i] = (DhInv[i] * sigma - 1.0) * sigma; }));
-  RC(hiopamd_gram_weighted(ctx, l, l, n, h->St, n, h->St, n, w, 0.0, G + 2 * l * l, l, 1.0, 1));
-  RC(allreduce_dev(ctx, G, (size_t)3 * l * l, HIOPAMD_SUM));                  // (:459)
+  // G0 = Yt DhInv Yt^T ; G1 = St (sigma DhInv) Yt^T ; G2 = St (sigma (sigma DhInv - 1)) St^T (:440-458) and G3 = sigma St St^T, the
+  // leading block of the middle matrix of the compact DIRECT form for timesVec, M = [sigma S^T S, L; L^T, -D]: one pass over S, Y and
+  // DhInv, one all-reduce (round 3: four passes, two collectives)
+  RC(hiopamd_gram_lowrank_blocks(ctx, l, n, h->St, h->Yt, n, h->DhInv, sigma, G));
+  RC(allreduce_dev(ctx, G, (size_t)4 * l * l, HIOPAMD_SUM));                  // (:459)
   HIOPAMD_CHECK(hipMemcpyAsync(h->dL, h->L.data(), sizeof(double) * l * l, hipMemcpyHostToDevice, ctx->stream));
   HIOPAMD_CHECK(hipMemcpyAsync(h->dD, h->D.data(), sizeof(double) * l, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(assemble_V_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, l, G, h->dL, h->dD, h->dV);
-  // middle matrix of the compact DIRECT form for timesVec: M = [sigma S^T S, L; L^T, -D]
-  RC(hiopamd_gram_weighted(ctx, l, l, n, h->St, n, h->St, n, nullptr, 0.0, G, l, sigma, 1));
-  RC(allreduce_dev(ctx, G, (size_t)l * l, HIOPAMD_SUM));
+  RC(small_lu_factor(ctx, 2 * l, h->dV, h->dVlu, h->dVpiv, h->dinfo));
   {
     double* M = h->dSS;
-    const double* SS = G;
+    const double* SS = G + 3 * l * l;
     const double* Lm = h->dL;
     const double* Dv = h->dD;
     const int nv = 2 * l;
@@ -482,6 +563,7 @@ static int update_internal_bfgs_representation(hiopamd_hess_lowrank* h)
       M[e] = v;
     }));
   }
+  RC(small_lu_factor(ctx, 2 * l, h->dSS, h->dSSlu, h->dSSpiv, h->dinfo + 1));
   HIOPAMD_CHECK(hipGetLastError());
   HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));  // h->L / h->D host buffers must outlive the async copies
   return HIOPAMD_OK;
@@ -503,7 +585,7 @@ int hiopamd_hess_lowrank_solve(hiopamd_hess_lowrank* h, const double* rhs, doubl
   RC(hiopamd_mat_times_vec(ctx, l, n, h->St, n, 0.0, sy, sigma, x));       // S^T B0 DhInv r
   RC(hiopamd_mat_times_vec(ctx, l, n, h->Yt, n, 0.0, sy + l, 1.0, x));
   RC(allreduce_dev(ctx, sy, (size_t)2 * l, HIOPAMD_SUM));
-  RC(small_lu_solve(ctx, 2 * l, h->dV, 1, sy, 2 * l, h->dinfo));            // solveWithV (:677)
+  RC(small_lu_apply(ctx, 2 * l, h->dVlu, h->dVpiv, 1, sy, 2 * l, sy, 2 * l));   // solveWithV (:677)
   double* res = h->nv1;
   RC(hiopamd_mat_trans_times_vec(ctx, l, n, h->St, n, 0.0, res, sigma, sy));
   RC(hiopamd_mat_trans_times_vec(ctx, l, n, h->Yt, n, 1.0, res, 1.0, sy + l));
@@ -541,7 +623,7 @@ int hiopamd_hess_lowrank_sym_mat_times_inverse_times_mat_trans(hiopamd_hess_lowr
     }
   }));
   if(l > 0) {
-    RC(small_lu_solve(ctx, 2 * l, h->dV, k, S2Y2, 2 * l, h->dinfo));        // (:606)
+    RC(small_lu_apply(ctx, 2 * l, h->dVlu, h->dVpiv, k, S2Y2, 2 * l, S2Y2, 2 * l));   // (:606)
     // W -= alpha * [S1 Y1] [S2 Y2]^T                                         (:614-618)
     RC(hiopamd_mat_times_mat_trans(ctx, k, 2 * l, k, G + k, kw, 1.0, W, k, -alpha, S2Y2, 2 * l));
   }
@@ -571,7 +653,7 @@ int hiopamd_hess_lowrank_times_vec(hiopamd_hess_lowrank* h, double beta, double*
   RC(hiopamd_mat_times_vec(ctx, l, n, h->St, n, 0.0, sy, sigma, x));
   RC(hiopamd_mat_times_vec(ctx, l, n, h->Yt, n, 0.0, sy + l, 1.0, x));
   RC(allreduce_dev(ctx, sy, (size_t)2 * l, HIOPAMD_SUM));
-  RC(small_lu_solve(ctx, 2 * l, h->dSS, 1, sy, 2 * l, h->dinfo));
+  RC(small_lu_apply(ctx, 2 * l, h->dSSlu, h->dSSpiv, 1, sy, 2 * l, sy, 2 * l));
   RC(hiopamd_mat_trans_times_vec(ctx, l, n, h->St, n, 1.0, y, -alpha * sigma, sy));
   RC(hiopamd_mat_trans_times_vec(ctx, l, n, h->Yt, n, 1.0, y, -alpha, sy + l));
   return HIOPAMD_OK;
@@ -593,6 +675,7 @@ struct hiopamd_kkt_lowrank {
   double *Dd_inv = nullptr;   // m_ineq
   double *Dx = nullptr;       // n
   double *rhs = nullptr;      // k
+  double *tsy = nullptr;      // k + 4 l_max: [t ; sy ; z] of solveCompressed
   double *work = nullptr;     // gram / posv workspace
   size_t work_cnt = 0;
   double last_resid = 0.0;
@@ -628,7 +711,7 @@ int hiopamd_kkt_lowrank_create(hiopamd_kkt_lowrank** out, hiopamd_ctx* ctx, hiop
   K->work_cnt = k * kw + k * 2 * H->l_max + 3 * k * k + 16 * k + 64;
   auto A = [](double** p, size_t cnt) { return hipMalloc((void**)p, sizeof(double) * (cnt ? cnt : 1)) == hipSuccess; };
   (void)n;   // K->J (k x n) is allocated lazily, only if the caller's Jacobians are not one contiguous block
-  if(!(A(&K->N, k * k) && A(&K->Dd_inv, K->m_ineq) && A(&K->Dx, n) && A(&K->rhs, k) &&
+  if(!(A(&K->N, k * k) && A(&K->Dd_inv, K->m_ineq) && A(&K->Dx, n) && A(&K->rhs, k) && A(&K->tsy, k + 4 * (size_t)H->l_max + 8) &&
        A(&K->work, K->work_cnt))) {
     hiopamd_kkt_lowrank_destroy(K);
     return HIOPAMD_ERR_HIP;
@@ -641,7 +724,7 @@ int hiopamd_kkt_lowrank_destroy(hiopamd_kkt_lowrank* K)
 {
   if(!K) return HIOPAMD_OK;
   (void)hipStreamSynchronize(K->ctx->stream);
-  double* ps[] = {K->J, K->N, K->Dd_inv, K->Dx, K->rhs, K->work};
+  double* ps[] = {K->J, K->N, K->Dd_inv, K->Dx, K->rhs, K->tsy, K->work};
   for(double* p : ps) (void)hipFree(p);
   delete K;
   return HIOPAMD_OK;
@@ -748,33 +831,68 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
     // N[me.., me..] += Dd^-1                                                   (:1135)
     RC(hiopamd_mat_add_sub_diagonal(ctx, K->N, k, me, 1.0, K->Dd_inv, 0, mi));
   }
-  // dx = (H+Dx)^-1 rx                                                          (:1147)
-  RC(hiopamd_hess_lowrank_solve(K->H, rx, dx));
-  // rhs = J dx - [ryc; ryd]   (only rank 0 subtracts, then all-reduce: :466, :1157)
-  double* rhs = K->rhs;
-  if(ctx->comm_rank == 0) {
-    RC(hiopamd_vec_copy(ctx, me, rhs, ryc));
-    RC(hiopamd_vec_copy(ctx, mi, rhs + me, ryd));
-    RC(hiopamd_mat_times_vec(ctx, k, n, K->Jcur, n, -1.0, rhs, 1.0, dx));
+  // The reference's sequence is  dx = (H+Dx)^-1 rx (:1147);  rhs = J dx - [ryc; ryd] (:466, :1157);  N dy = rhs (:1169);
+  // rx -= J^T dy;  dx = (H+Dx)^-1 rx (:1178-1180)  -- two applications of the low-rank inverse, each with its own all-reduce of
+  // [sigma S; Y] DhInv r, and the all-reduce of rhs: three collectives behind the one of N.  Round 4 writes the same algebra with
+  // (H+Dx)^-1 = DhInv - DhInv [sigma S, Y]^T V^-1 [sigma S; Y] DhInv  multiplied out against J, using the block
+  // S1Y1 = J DhInv [sigma S, Y]^T (k x 2l) that the build of N left in the work area (replicated, already reduced):
+  //    w   = DhInv rx                       t  = J w - [ryc; ryd]        sy = [sigma S; Y] w     -> ONE all-reduce of [t; sy]
+  //    rhs = t - S1Y1 V^-1 sy               ( = J dx - ry )
+  //    sy' = sy - S1Y1^T dy                 ( = [sigma S; Y] DhInv (rx - J^T dy): no second reduction )
+  //    dx  = DhInv (rx - J^T dy) - DhInv [sigma S, Y]^T V^-1 sy'
+  // Per call: 2 passes over J, 4 over the 2l secant rows (8 before), ONE collective (+ the one of N when it is rebuilt).
+  hiopamd_hess_lowrank* H = K->H;
+  if(H->matrix_changed) RC(update_internal_bfgs_representation(H));
+  const int l = H->l_curr < 0 ? 0 : H->l_curr;
+  const int kw = k + 2 * l;
+  const double* DhInv = H->DhInv;
+  const double sigma = H->sigma;
+  const double* S1Y1 = K->work + k;           // columns k .. k+2l of G (leading dimension kw), scaled by sigma where it applies
+  double* t = K->tsy;                         // [t (k) ; sy (2l)] contiguous: one buffer for the collective
+  double* sy = t + k;
+  double* z = sy + 2 * (size_t)H->l_max;
+  RC(launch_ew(ctx, n, [=] __device__(int64_t i) { dx[i] = rx[i] * DhInv[i]; }));   // w lives in dx until the end
+  if(ctx->comm_rank == 0) {   // only rank 0 subtracts ry, then all-reduce (:466, :1157)
+    RC(launch_ew(ctx, k, [=] __device__(int64_t i) { t[i] = (i < me) ? ryc[i] : ryd[i - me]; }));
+    RC(hiopamd_mat_times_vec(ctx, k, n, K->Jcur, n, -1.0, t, 1.0, dx));
   } else {
-    RC(hiopamd_mat_times_vec(ctx, k, n, K->Jcur, n, 0.0, rhs, 1.0, dx));
+    RC(hiopamd_mat_times_vec(ctx, k, n, K->Jcur, n, 0.0, t, 1.0, dx));
   }
-  RC(allreduce_dev(ctx, rhs, (size_t)k, HIOPAMD_SUM));
+  if(l > 0) {
+    RC(hiopamd_mat_times_vec(ctx, l, n, H->St, n, 0.0, sy, sigma, dx));
+    RC(hiopamd_mat_times_vec(ctx, l, n, H->Yt, n, 0.0, sy + l, 1.0, dx));
+  }
+  RC(allreduce_dev(ctx, t, (size_t)k + 2 * (size_t)l, HIOPAMD_SUM));
+  if(l > 0) {
+    RC(small_lu_apply(ctx, 2 * l, H->dVlu, H->dVpiv, 1, sy, 2 * l, z, 2 * l));   // solveWithV (:677)
+    RC(hiopamd_mat_times_vec(ctx, k, 2 * l, S1Y1, kw, 1.0, t, -1.0, z));
+  }
   // solve N [dyc; dyd] = rhs with equilibration + refinement                  (:1169, solveWithRefin :1192)
   int info = reuse ? K->N_info : 0;
   double resid = 0.0;
   double* pw = K->work + (size_t)k * (k + 2 * K->H->l_max) + (size_t)k * 2 * K->H->l_max;
-  RC(posv_refine_impl(ctx, k, K->N, k, rhs, pw, &info, &resid, reuse ? 1 : 0));
+  RC(posv_refine_impl(ctx, k, K->N, k, t, pw, &info, &resid, reuse ? 1 : 0));
   K->N_info = info;
   K->N_version = K->H->version;   // (the Hessian's lazily refreshed internal representation does not bump the version)
   K->N_valid = true;
   K->last_resid = resid;
   if(info != 0 && ok_host) *ok_host = 0;
-  RC(hiopamd_vec_copy(ctx, me, dyc, rhs));
-  RC(hiopamd_vec_copy(ctx, mi, dyd, rhs + me));
-  // rx = rx - J^T [dyc; dyd] ; dx = (H+Dx)^-1 rx                               (:1178-1180)
-  RC(hiopamd_mat_trans_times_vec(ctx, k, n, K->Jcur, n, 1.0, rx, -1.0, rhs));
-  RC(hiopamd_hess_lowrank_solve(K->H, rx, dx));
+  RC(launch_ew(ctx, k, [=] __device__(int64_t i) {
+    if(i < me) dyc[i] = t[i];
+    else dyd[i - me] = t[i];
+  }));
+  // rx = rx - J^T [dyc; dyd]  (rx is modified, as in the reference :1178)
+  RC(hiopamd_mat_trans_times_vec(ctx, k, n, K->Jcur, n, 1.0, rx, -1.0, t));
+  if(l > 0) {
+    RC(hiopamd_mat_trans_times_vec(ctx, k, 2 * l, S1Y1, kw, 1.0, sy, -1.0, t));
+    RC(small_lu_apply(ctx, 2 * l, H->dVlu, H->dVpiv, 1, sy, 2 * l, sy, 2 * l));
+    double* res = H->nv1;
+    RC(hiopamd_mat_trans_times_vec(ctx, l, n, H->St, n, 0.0, res, sigma, sy));
+    RC(hiopamd_mat_trans_times_vec(ctx, l, n, H->Yt, n, 1.0, res, 1.0, sy + l));
+    RC(launch_ew(ctx, n, [=] __device__(int64_t i) { dx[i] = rx[i] * DhInv[i] - res[i] * DhInv[i]; }));
+  } else {
+    RC(launch_ew(ctx, n, [=] __device__(int64_t i) { dx[i] = rx[i] * DhInv[i]; }));
+  }
   return HIOPAMD_OK;
 }
 

@@ -85,9 +85,12 @@ int hiopamd::posv_refine_impl(hiopamd_ctx* ctx, int k, const double* N_upper, in
   } else if(*info_host == 2) {
     return HIOPAMD_OK;
   }
-  RC(hiopamd_vec_copy(ctx, k, b0, rhs_inout));
-  // x = S * (M^-1 (S b))
-  RC(launch_ew(ctx, k, [=] __device__(int64_t i) { x[i] = b0[i] * sc[i]; }));
+  // b0 = b ; x = S * (M^-1 (S b))
+  RC(launch_ew(ctx, k, [=] __device__(int64_t i) {
+    const double b = rhs_inout[i];
+    b0[i] = b;
+    x[i] = b * sc[i];
+  }));
   RC(hiopamd_ldlt_solve(ctx, k, M, k, dinv, x, 1));
   RC(hiopamd_vec_component_mult(ctx, k, x, sc));
   const int MAX_ITER_REFIN = 3;

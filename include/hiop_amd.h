@@ -264,6 +264,13 @@ int hiopamd_gram_weighted_stacked(hiopamd_ctx*, int ma, int64_t n, const double*
                                   const double* B2, int64_t ldb2, const double* d, double beta, double* W, int64_t ldw,
                                   double alpha);
 
+/* the four l x l blocks of hiopHessianLowRank::updateInternalBFGSRepresentation (hiopHessianLowRank.cpp:400-460: the three
+ * weighted products :440-458) and of the middle matrix of the compact direct form in ONE pass over S, Y (l x n, leading dimension ld,
+ * l <= 8) and DhInv:  G (4 l^2 doubles, l x l row-major each) =
+ *   [ Y DhInv Y^T | S (sigma DhInv) Y^T | S (sigma (sigma DhInv - 1)) S^T | sigma S S^T ];  local sums (the caller all-reduces G). */
+int hiopamd_gram_lowrank_blocks(hiopamd_ctx*, int l, int64_t n, const double* St, const double* Yt, int64_t ld,
+                                const double* DhInv, double sigma, double* G);
+
 /* =====================================================================================
  * hiopMatrixSparseTriplet (row-sorted COO, int32 indices)
  * (reference: src/LinAlg/hiopMatrixSparseTriplet.cpp)

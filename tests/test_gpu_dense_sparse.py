@@ -129,6 +129,29 @@ def test_gram_stacked_symmetric_block_is_mirrored(ctx, k, l, n):
     np.testing.assert_allclose(Wd.cpu().numpy(), e, rtol=1e-11, atol=1e-10)
 
 
+@pytest.mark.parametrize("l,n,ld", [(6, 50000, 50000), (1, 777, 777), (8, 4099, 4100), (3, 63, 64), (5, 1, 8)])
+def test_gram_lowrank_blocks_one_pass(ctx, l, n, ld):
+    """The four l x l blocks of updateInternalBFGSRepresentation (hiopHessianLowRank.cpp:400-460) in one pass, against numpy with the
+    weights formed as the reference forms them (DhInv * sigma; (DhInv * sigma - 1) * sigma); symmetric blocks exactly symmetric;
+    the columns between n and ld are never read (NaN-filled)."""
+    r = rng(l * 1000 + n)
+    S = np.full((l, ld), np.nan); Y = np.full((l, ld), np.nan)
+    S[:, :n] = r.uniform(-1, 1, (l, n)); Y[:, :n] = r.uniform(-1, 1, (l, n))
+    d = r.uniform(0.1, 2.0, n); sigma = 0.73
+    G = D(np.full(4 * l * l, np.nan))
+    run(ctx, "hiopamd_gram_lowrank_blocks", l, n, D(S), D(Y), ld, D(d), sigma, G)
+    got = G.cpu().numpy().reshape(4, l, l)
+    s_, y_ = S[:, :n], Y[:, :n]
+    e = [(y_ * d) @ y_.T, (s_ * (d * sigma)) @ y_.T, (s_ * ((d * sigma - 1.0) * sigma)) @ s_.T, sigma * (s_ @ s_.T)]
+    for q in range(4):
+        np.testing.assert_allclose(got[q], e[q], rtol=1e-12, atol=1e-12 * max(1.0, n))
+        if q != 1:
+            np.testing.assert_array_equal(got[q], got[q].T)
+    G2 = D(np.full(4 * l * l, np.nan))          # run to run: bitwise (fixed order of the partial sums)
+    run(ctx, "hiopamd_gram_lowrank_blocks", l, n, D(S), D(Y), ld, D(d), sigma, G2)
+    np.testing.assert_array_equal(G2.cpu().numpy(), G.cpu().numpy())
+
+
 def test_assembly_kernels(ctx):
     r = rng(99)
     nW = 301
