@@ -330,6 +330,12 @@ int hiopamd_kkt_sparse_condensed_dims(const hiopamd_kkt_sparse_condensed* k, int
   dims4_host[0] = k->nx; dims4_host[1] = k->nineq; dims4_host[2] = k->nnzJ; dims4_host[3] = k->nnzH;
   return HIOPAMD_OK;
 }
+// which inner solver the object runs: 0 dense LDL^T of the expanded matrix, 1 bordered-diagonal direct solver, 2 PCG + Jacobi
+int hiopamd_kkt_sparse_condensed_inner_kind(const hiopamd_kkt_sparse_condensed* k)
+{
+  if(!k) return HIOPAMD_ERR_ARG;
+  return k->dls ? 0 : (k->arrow ? 1 : 2);
+}
 hiopamd_csr_condensed* hiopamd_kkt_sparse_condensed_matrix(hiopamd_kkt_sparse_condensed* k) { return k ? k->csr : nullptr; }
 double* hiopamd_kkt_sparse_condensed_Hd(hiopamd_kkt_sparse_condensed* k) { return k ? k->Hd : nullptr; }
 

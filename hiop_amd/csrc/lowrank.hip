@@ -240,6 +240,44 @@ __global__ __launch_bounds__(kBlock) void secant_jac_kernel(int m, int64_t n, co
   }
 }
 
+// Secant memory full: rows move up by one and the new pair goes into the last row -- St, Yt in ONE launch, in place (a thread owns
+// two adjacent columns and walks the rows: read row r + 1, write row r).  Round 3 staged each shift through the workspace with two
+// hipMemcpy2DAsync and copied the new rows with two more (reference: shiftRows + copyRowsFrom, hiopHessianLowRank.cpp:322-329).
+__global__ __launch_bounds__(kBlock) void secant_shift_append_kernel(int l, int64_t n, double* __restrict__ St, double* __restrict__ Yt,
+                                                                     const double* __restrict__ s_new,
+                                                                     const double* __restrict__ y_new)
+{
+  const int64_t j0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
+  if(j0 >= n) return;
+  const bool two = (j0 + 1 < n) && ((n & 1) == 0) && ((((uintptr_t)St) & 15) == 0) && ((((uintptr_t)Yt) & 15) == 0) &&
+                   ((((uintptr_t)s_new) & 15) == 0) && ((((uintptr_t)y_new) & 15) == 0);
+  for(int which = 0; which < 2; ++which) {
+    double* M = which ? Yt : St;
+    const double* nw = which ? y_new : s_new;
+    if(two) {
+      int r = 0;
+      for(; r + 4 <= l - 1; r += 4) {
+        double2 v[4];
+#pragma unroll
+        for(int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const double2*>(M + (int64_t)(r + 1 + u) * n + j0);
+#pragma unroll
+        for(int u = 0; u < 4; ++u) *reinterpret_cast<double2*>(M + (int64_t)(r + u) * n + j0) = v[u];
+      }
+      for(; r < l - 1; ++r) {
+        const double2 v = *reinterpret_cast<const double2*>(M + (int64_t)(r + 1) * n + j0);
+        *reinterpret_cast<double2*>(M + (int64_t)r * n + j0) = v;
+      }
+      *reinterpret_cast<double2*>(M + (int64_t)(l - 1) * n + j0) = *reinterpret_cast<const double2*>(nw + j0);
+    } else {
+      for(int c = 0; c < 2 && j0 + c < n; ++c) {
+        for(int r = 0; r < l - 1; ++r) M[(int64_t)r * n + j0 + c] = M[(int64_t)(r + 1) * n + j0 + c];
+        M[(int64_t)(l - 1) * n + j0 + c] = nw[j0 + c];
+      }
+    }
+  }
+}
+
+
 // three dots in one pass: out = [x.y, x.x, y.y]
 struct dot3_t {
   double a, b, c;
@@ -455,7 +493,8 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
   // save_prev() would do anyway.
   //   y_new += (Jc - Jc_prev)^T yc + (Jd - Jd_prev)^T yd                      (:293-299)
   {
-    // (two column pairs per thread -- 8 KB of a row per workgroup -- measured slower: 5.84 vs 5.56 ms per step, scripts/r04_gpu_13.sh)
+    // (two column pairs per thread -- 8 KB of a row per workgroup -- measured slower: 5.84 vs 5.56 ms per step, scripts/r04_gpu_13.sh;
+    //  software-pipelining the batches changed nothing: 1.17 vs 1.09-1.17 ms for the two launches, scripts/r04_gpu_14.sh)
     const unsigned gx = (unsigned)((n + 2 * (int64_t)kBlock - 1) / (2 * (int64_t)kBlock));
     if(me > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel<1>, dim3(gx), dim3(kBlock), 0, ctx->stream, me, n, Jc, h->Jc_prev, yc, y_new);
     if(mi > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel<1>, dim3(gx), dim3(kBlock), 0, ctx->stream, mi, n, Jd, h->Jd_prev, yd, y_new);
@@ -498,10 +537,11 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
           h->D.push_back(sTy);
           h->l_curr = l + 1;
         } else {  // shift (:322-329, updateL :828, updateD :861)
-          RC(hiopamd_mat_shift_rows(ctx, l, n, h->St, n, -1));
-          RC(hiopamd_mat_shift_rows(ctx, l, n, h->Yt, n, -1));
-          RC(hiopamd_vec_copy(ctx, n, h->St + (int64_t)(l - 1) * n, s_new));
-          RC(hiopamd_vec_copy(ctx, n, h->Yt + (int64_t)(l - 1) * n, y_new));
+          if(n > 0) {
+            hipLaunchKernelGGL(secant_shift_append_kernel, dim3((unsigned)((n + 2 * (int64_t)kBlock - 1) / (2 * (int64_t)kBlock))),
+                               dim3(kBlock), 0, ctx->stream, l, n, h->St, h->Yt, s_new, y_new);
+            HIOPAMD_CHECK(hipGetLastError());
+          }
           const int lm1 = l - 1;
           for(int i = 1; i < lm1; ++i)
             for(int j = 0; j < i; ++j) h->L[(size_t)i * l + j] = h->L[(size_t)(i + 1) * l + j + 1];

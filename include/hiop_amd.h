@@ -446,6 +446,8 @@ int hiopamd_kkt_sparse_condensed_set_inner_solver(hiopamd_kkt_sparse_condensed* 
 int hiopamd_kkt_sparse_condensed_last_solve(const hiopamd_kkt_sparse_condensed* k, int* flag_host, double* iters_host,
                                             double* rel_resid_host);
 int hiopamd_kkt_sparse_condensed_dims(const hiopamd_kkt_sparse_condensed* k, int* dims4_host /* nx, nineq, nnzJ, nnzH */);
+/* the inner solver in use: 0 dense LDL^T of the expanded matrix (nx <= 4096), 1 bordered-diagonal direct solver, 2 PCG + Jacobi */
+int hiopamd_kkt_sparse_condensed_inner_kind(const hiopamd_kkt_sparse_condensed* k);
 hiopamd_csr_condensed* hiopamd_kkt_sparse_condensed_matrix(hiopamd_kkt_sparse_condensed* k);
 double* hiopamd_kkt_sparse_condensed_Hd(hiopamd_kkt_sparse_condensed* k);
 /* y = beta y + alpha Hess x ; y = beta y + alpha Jd x ; y = beta y + alpha Jd^T x  on the values of the last set_values */
