@@ -29,6 +29,7 @@ SOURCES = [
     "kkt_sparse.hip",
     "gram.hip",
     "ldlt.hip",
+    "ldlt_bk.hip",
     "small_solvers.hip",
     "kkt_mds.hip",
     "lowrank.hip",

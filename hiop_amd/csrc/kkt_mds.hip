@@ -463,7 +463,12 @@ int hiopamd_kkt_mds_solve_status(hiopamd_kkt_mds* k, int sync, int* ok_host)
 int hiopamd_kkt_mds_set_safe_mode(hiopamd_kkt_mds* k, int enable)
 {
   if(!k) return HIOPAMD_ERR_ARG;
-  return hiopamd_linsolver_set_safe_mode(k->ls, enable, k->s.nxd);
+  if(enable == 2) {
+    const int rc = hiopamd_linsolver_set_safe_mode(k->ls, 0, k->s.nxd);
+    return rc != HIOPAMD_OK ? rc : hiopamd_linsolver_set_pivoting(k->ls, 1);
+  }
+  const int rc = hiopamd_linsolver_set_pivoting(k->ls, 0);
+  return rc != HIOPAMD_OK ? rc : hiopamd_linsolver_set_safe_mode(k->ls, enable, k->s.nxd);
 }
 
 int hiopamd_kkt_mds_set_diagonals(hiopamd_kkt_mds* k, const double* Dx, const double* Dd)

@@ -1055,6 +1055,19 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
   }
 }
 
+// The same kernel for the pivoted factorisation (ldlt_bk.hip): A[r][c] -= sum_{k<K} V[k][r] * A[urow0+k][c] for c >= r >= s, K a
+// multiple of 8 (V = the panel W = L D, the A rows = the panel's columns of L in the column-major-lower reading of the storage)
+int ldlt_rankk_update(hiopamd_ctx* ctx, double* A, int64_t lda, int N, const double* V, int64_t ldv, int urow0, int K, int s)
+{
+  if(K <= 0 || s >= N) return HIOPAMD_OK;
+  if(K % 8 != 0) return HIOPAMD_ERR_ARG;
+  const int t = (N - s + 127) / 128;
+  hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), dim3(2 * t, 2 * t), dim3(kBlock), 0, ctx->stream, A, lda, N, V, ldv, 0, urow0, K, s, N,
+                     N, 0, (double*)nullptr);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // inertia from D (thresholds of the reference's LAPACK path, hiopLinSolverSymDenseLapack.hpp:154-161:
 // d < -1e-14 negative, |d| < 1e-14 null, else positive)
@@ -2315,6 +2328,9 @@ struct hiopamd_linsolver {
   bool retry_copy = true;
   double* Mretry = nullptr;   // n x n, upper 128 x 128 tiles used; allocated on first use
   long df_timeouts = 0;       // bounded waits that expired over the object's life (hiopamd_linsolver_timeouts)
+  // pivoted mode (Bunch-Kaufman, ldlt_bk.hip): hiopamd_linsolver_set_pivoting
+  bool pivoted = false;
+  hiopamd_ldlt_bk* bk = nullptr;
   bool factored = false;
   int inertia[3] = {0, 0, 0};
   double flops_fact = 0.0, flops_triu = 0.0;   // hiopLinSolStats::flopsFact / flopsTriuSolves (cumulative)
@@ -3156,6 +3172,7 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->df.wq);
   (void)hipFree(ls->df.wfirst);
   (void)hipFree(ls->df.wf);
+  (void)hiopamd_ldlt_bk_destroy(ls->bk);
   delete ls;
   return HIOPAMD_OK;
 }
@@ -3244,6 +3261,20 @@ int hiopamd_linsolver_set_safe_mode(hiopamd_linsolver* ls, int enable, int n_pos
   }
   return HIOPAMD_OK;
 }
+// Pivoted mode: matrixChanged / solve run the Bunch-Kaufman factorisation of ldlt_bk.hip (the reference's safe solver) instead of the
+// no-pivot dataflow LDL^T; takes precedence over the regularise-and-refine safe mode.  Exact inertia for any symmetric matrix, at
+// the price of ~ 3 n latency-bound launches per factorisation.
+int hiopamd_linsolver_set_pivoting(hiopamd_linsolver* ls, int enable)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  ls->factored = false;
+  if(enable && !ls->bk) {
+    const int rc = hiopamd_ldlt_bk_create(&ls->bk, ls->ctx, ls->n);
+    if(rc != HIOPAMD_OK) return rc;
+  }
+  ls->pivoted = enable != 0;
+  return HIOPAMD_OK;
+}
 int hiopamd_linsolver_safe_mode_info(const hiopamd_linsolver* ls, int* refinements_host, double* residual_rel_host)
 {
   if(!ls) return HIOPAMD_ERR_ARG;
@@ -3313,6 +3344,22 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
     }
   }
   const int n = ls->n;
+  if(ls->pivoted) {
+    // the reference's safe solver: Bunch-Kaufman (hiopLinSolverSymDenseMagma.cpp:120-250 / hiopLinSolverSymDenseLapack.hpp:75-170):
+    // -1 for INFO > 0 or a null pivot, the number of negative eigenvalues otherwise
+    SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_FACT);
+    ls->flops_fact += (double)n * n * n / 3.0;
+    int info = 0;
+    const int rc = hiopamd_ldlt_bk_factor(ls->bk, ls->M, n, ls->inertia, &info);
+    if(rc != HIOPAMD_OK) return rc;
+    if(info > 0 || ls->inertia[2] > 0) {
+      *n_neg_host = -1;
+      return HIOPAMD_OK;
+    }
+    ls->factored = true;
+    *n_neg_host = ls->inertia[1];
+    return HIOPAMD_OK;
+  }
   auto regularise = [&]() -> int {   // safe mode: M <- K + delta diag(+I, -I) (upper triangle), K kept in Msave
     const double delta = ls->safe_delta_rel * ls->safe_anorm;
     int rs = HIOPAMD_OK;
@@ -3457,6 +3504,7 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs)
   if(!ls->factored) return HIOPAMD_ERR_STATE;
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_TRIU_SOLVES);   // :173-195 (tmTriuSolves; flopsTriuSolves = 2 n^2 per rhs)
   ls->flops_triu += 2.0 * (double)ls->n * ls->n * nrhs;
+  if(ls->pivoted) return hiopamd_ldlt_bk_solve(ls->bk, ls->M, ls->n, rhs_inout, nrhs);
   if(!ls->safe_mode) return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd, ls);
   for(int q = 0; q < nrhs; ++q) {
     bool ok = false;

@@ -73,6 +73,10 @@ class LinSolverSymDense:
         check(rc, "hiopamd_linsolver_solve")
         return True
 
+    def set_pivoting(self, enable: bool):
+        """Bunch-Kaufman mode (the reference's safe solver, csrc/ldlt_bk.hip): exact inertia for any symmetric matrix"""
+        check(self._L.hiopamd_linsolver_set_pivoting(self.h, 1 if enable else 0), "hiopamd_linsolver_set_pivoting")
+
     def set_safe_mode(self, enable: bool, n_pos_block: int):
         """static quasi-definite regularisation + iterative refinement (the reference's safe mode = Bunch-Kaufman solver)"""
         check(self._L.hiopamd_linsolver_set_safe_mode(self.h, 1 if enable else 0, n_pos_block), "hiopamd_linsolver_set_safe_mode")

@@ -498,6 +498,24 @@ int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable);
  * the condensed KKT).  hiopamd_linsolver_growth: max |u_ij| and the extreme |d_i| of the last factorisation, the signal a
  * caller uses to decide that the fast path misbehaves. */
 int hiopamd_linsolver_set_safe_mode(hiopamd_linsolver* ls, int enable, int n_pos_block);
+/* Pivoted mode -- the reference's safe solver itself: Bunch-Kaufman partial pivoting (hiopLinSolverSymDenseMagmaBuKa,
+ * hiopLinSolverSymDenseMagma.cpp:120-250; hiopLinSolverSymDenseLapack.hpp:75-195 = LAPACK DSYTRF / DSYTRS).  matrixChanged returns
+ * -1 for a singular matrix (DSYTRF INFO > 0 or a null pivot by the reference's 1e-14 rule) and the exact number of negative
+ * eigenvalues otherwise, for ANY symmetric matrix; solve is DSYTRS.  Takes precedence over set_safe_mode.  Cost: ~ 3 n
+ * latency-bound launches per factorisation (0.1-0.2 s at n = 8192) -- the exceptional path, as in the reference. */
+int hiopamd_linsolver_set_pivoting(hiopamd_linsolver* ls, int enable);
+
+/* The pivoted factorisation on its own (csrc/ldlt_bk.hip): P A P^T = L D L^T, A n x n row-major with its UPPER triangle populated
+ * (= LAPACK's UPLO = 'L' on the same memory), overwritten by L (strictly below the diagonal in the column-major reading), the diagonal
+ * of D; the off-diagonals of the 2 x 2 blocks are kept in the object.  inertia3_host = (pos, neg, null) by the reference's rule
+ * (hiopLinSolverSymDenseLapack.hpp:127-167); info_host = DSYTRF's INFO.  Pivots and D equal LAPACK's; the row interchanges are applied
+ * to all previous columns at once (one permutation), so L differs from DSYTRF's by row order only. */
+typedef struct hiopamd_ldlt_bk hiopamd_ldlt_bk;
+int hiopamd_ldlt_bk_create(hiopamd_ldlt_bk** out, hiopamd_ctx* ctx, int n);
+int hiopamd_ldlt_bk_destroy(hiopamd_ldlt_bk* b);
+int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* b, double* A, int64_t lda, int* inertia3_host, int* info_host);
+int hiopamd_ldlt_bk_solve(hiopamd_ldlt_bk* b, const double* A, int64_t lda, double* x_inout, int nrhs);
+int hiopamd_ldlt_bk_pivots(hiopamd_ldlt_bk* b, int* ipiv_host, int* perm_host, double* e_host);
 int hiopamd_linsolver_safe_mode_info(const hiopamd_linsolver* ls, int* refinements_host, double* residual_rel_host);
 int hiopamd_linsolver_growth(hiopamd_linsolver* ls, double* max_abs_u_host, double* min_abs_d_host, double* max_abs_d_host);
 /* The factorisation runs as a dataflow of two persistent kernels (csrc/ldlt_dataflow.hpp) when the CU-masked streams are
@@ -584,7 +602,8 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
 int hiopamd_kkt_mds_solve_status(hiopamd_kkt_mds* k, int sync, int* ok_host);
 /* only the log-barrier diagonals change (hiopKKTLinSysCompressedXYcYd::update, hiopKKTLinSys.cpp:562-572) */
 int hiopamd_kkt_mds_set_diagonals(hiopamd_kkt_mds* k, const double* Dx, const double* Dd);
-/* safe_mode_ of hiopKKTLinSysCompressedMDSXYcYd (:145, :408-430): see hiopamd_linsolver_set_safe_mode */
+/* safe_mode_ of hiopKKTLinSysCompressedMDSXYcYd (:145, :408-430): enable = 1 regularise-and-refine (hiopamd_linsolver_set_safe_mode),
+ * enable = 2 the pivoted Bunch-Kaufman solver (hiopamd_linsolver_set_pivoting: what the reference's safe mode runs), 0 off */
 int hiopamd_kkt_mds_set_safe_mode(hiopamd_kkt_mds* k, int enable);
 int hiopamd_kkt_mds_dims(const hiopamd_kkt_mds* k, int* dims4_host /* nxs, nxd, neq, nineq */);
 /* the MDS matrices' products, on the values of the last set_values
