@@ -2,10 +2,11 @@
 
 namespace hiop
 {
-hiopLinSolverSymDenseHipNative::hiopLinSolverSymDenseHipNative(int n, hiopNlpFormulation* nlp)
+hiopLinSolverSymDenseHipNative::hiopLinSolverSymDenseHipNative(int n, hiopNlpFormulation* nlp, bool pivoted)
     : hiopLinSolverSymDense(n, nlp), ctx_(hiopamd_default_ctx()), ls_(nullptr), n_(n)
 {
   hiopamd_ok(hiopamd_linsolver_create(&ls_, ctx_, n));
+  if(pivoted) hiopamd_ok(hiopamd_linsolver_set_pivoting(ls_, 1));
   // the base class allocated a system matrix through the LinAlg factory; the KKT classes must write into the solver's own
   // storage instead, so M_ becomes a non-owning view of it (the base destructor deletes the view, not the storage)
   delete M_;

@@ -14,7 +14,8 @@ namespace hiop
 class hiopLinSolverSymDenseHipNative : public hiopLinSolverSymDense
 {
 public:
-  hiopLinSolverSymDenseHipNative(int n, hiopNlpFormulation* nlp);
+  /// pivoted = true: the Bunch-Kaufman factorisation (hiopamd_linsolver_set_pivoting) instead of the no-pivot one
+  hiopLinSolverSymDenseHipNative(int n, hiopNlpFormulation* nlp, bool pivoted = false);
   virtual ~hiopLinSolverSymDenseHipNative();
 
   int matrixChanged() override;
@@ -29,5 +30,14 @@ private:
   hiopamd_ctx* ctx_;
   hiopamd_linsolver* ls_;
   int n_;
+};
+
+// The safe solver: plays the role of hiopLinSolverSymDenseMagmaBuKa (src/LinAlg/hiopLinSolverSymDenseMagma.hpp:60-140, .cpp:120-250) --
+// what hiopKKTLinSysCompressedMDSXYcYd::determineAndCreateLinsys creates when safe_mode_ is on (hiopKKTLinSysMDS.cpp:446-456).
+// Same object, pivoted mode: LAPACK DSYTRF's pivots on the device (csrc/ldlt_bk.hip), exact inertia, DSYTRS solves.
+class hiopLinSolverSymDenseHipNativeBuKa : public hiopLinSolverSymDenseHipNative
+{
+public:
+  hiopLinSolverSymDenseHipNativeBuKa(int n, hiopNlpFormulation* nlp) : hiopLinSolverSymDenseHipNative(n, nlp, true) {}
 };
 }  // namespace hiop
