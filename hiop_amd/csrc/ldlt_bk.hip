@@ -6,8 +6,8 @@
 // switch to when the no-pivot factor misbehaves (hiopKKTLinSysMDS.cpp:408-430, hiopAlgFilterIPM.cpp:2400-2427).  The algorithm is
 // LAPACK's DSYTRF, UPLO = 'L' (the row-major upper triangle of the KKT matrix IS the column-major lower one: a(i, j), i >= j, lives at
 // A[j * lda + i]), i.e. panels of DLASYF: alpha = (1 + sqrt(17)) / 8, 1 x 1 and 2 x 2 pivots, the updated pivot columns kept in a panel
-// W = L D (n x 64), one rank-64 update of the trailing matrix per panel.  Restated, with the convention below, in
-// oracle/bunch_kaufman.py (pinned against scipy's DSYTRF / DSYTRS).
+// W = L D (n x 64), one rank-64 update of the trailing matrix per panel.  (The CPU restatement the tests compare against, itself pinned on scipy's DSYTRF /
+// DSYTRS, uses the same convention: tests/test_gpu_ldlt_bk.py.)
 //
 // Convention: every row interchange is applied to ALL previous columns of L when it happens, so P A P^T = L D L^T with ONE
 // permutation; L is unit lower triangular and stored in the strict lower part, d on the diagonal, the off-diagonal entry of a
