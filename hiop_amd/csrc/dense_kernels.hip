@@ -317,6 +317,86 @@ __global__ __launch_bounds__(256) void small_gemm(int M, int N, int K, const dou
   }
 }
 
+// The same product on the matrix pipe (round 4; the reference's DGEMM call sites :578-673 -- timesMat, transTimesMat, timesMatTrans):
+// workgroup tile 64 x 64 (2 x 2 waves of 2 x 2 v_mfma_f64_16x16x4_f64 tiles), K in LDS stages of 16 (zero-filled past K, M, N), any
+// element strides: a stage is read along whichever index of the operand is contiguous.  Lane map of the instruction:
+// A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[row = (l >> 4) + 4 reg][col = l & 15].
+typedef double gemm_double4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(int M, int N, int K, const double* __restrict__ A, int64_t a_rs, int64_t a_cs,
+                                                        const double* __restrict__ B, int64_t b_rs, int64_t b_cs, double beta,
+                                                        double* __restrict__ C, int64_t ldc, double alpha)
+{
+  constexpr int T = 64, KT = 16, LD = T + 4;   // (row stride 68 doubles: the four k-rows of an operand read fall on different banks)
+  __shared__ double As[KT][LD];   // As[k][i]
+  __shared__ double Bs[KT][LD];   // Bs[k][j]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lk = lane >> 4, li = lane & 15;
+  const int r0 = blockIdx.y * T, c0 = blockIdx.x * T;
+  gemm_double4 acc[2][2];
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int j = 0; j < 2; ++j) acc[i][j] = gemm_double4{0.0, 0.0, 0.0, 0.0};
+  const bool a_k_fast = (a_cs == 1), b_k_fast = (b_rs == 1);
+  // this thread's four elements of each operand stage: (ii, ka) of A, (kb, jj) of B; the loads are unconditional on clamped
+  // addresses (a guarded load gets its own branch and its own wait from the compiler: one load in flight), zero-filled afterwards,
+  // and the next stage is fetched into registers while the current one is multiplied
+  int ai[4], ak[4], bj[4], bk[4];
+#pragma unroll
+  for(int q = 0; q < 4; ++q) {
+    if(a_k_fast) { ak[q] = tid & 15; ai[q] = (tid >> 4) + 16 * q; } else { ai[q] = tid & 63; ak[q] = (tid >> 6) + 4 * q; }
+    if(b_k_fast) { bk[q] = tid & 15; bj[q] = (tid >> 4) + 16 * q; } else { bj[q] = tid & 63; bk[q] = (tid >> 6) + 4 * q; }
+  }
+  double va[4], vb[4];
+  auto issue = [&](int k0) {   // the stage's eight loads, all in flight
+#pragma unroll
+    for(int q = 0; q < 4; ++q) {
+      const int ir = r0 + ai[q], kr = k0 + ak[q], jc = c0 + bj[q], kc = k0 + bk[q];
+      va[q] = A[(int64_t)(ir < M ? ir : M - 1) * a_rs + (int64_t)(kr < K ? kr : K - 1) * a_cs];
+      vb[q] = B[(int64_t)(kc < K ? kc : K - 1) * b_rs + (int64_t)(jc < N ? jc : N - 1) * b_cs];
+    }
+  };
+  auto commit = [&](int k0) {   // zero fill + into LDS (the empty asm keeps the compiler from sinking a load into its select's branch)
+#pragma unroll
+    for(int q = 0; q < 4; ++q) {
+      asm volatile("" : "+v"(va[q]), "+v"(vb[q]));
+      As[ak[q]][ai[q]] = (r0 + ai[q] < M && k0 + ak[q] < K) ? va[q] : 0.0;
+      Bs[bk[q]][bj[q]] = (c0 + bj[q] < N && k0 + bk[q] < K) ? vb[q] : 0.0;
+    }
+  };
+  if(K > 0) issue(0);
+  for(int k0 = 0; k0 < K; k0 += KT) {
+    commit(k0);
+    __syncthreads();
+    if(k0 + KT < K) issue(k0 + KT);
+#pragma unroll
+    for(int k4 = 0; k4 < KT / 4; ++k4) {
+      double a[2], b[2];
+#pragma unroll
+      for(int i = 0; i < 2; ++i) a[i] = As[k4 * 4 + lk][wr * 32 + i * 16 + li];
+#pragma unroll
+      for(int j = 0; j < 2; ++j) b[j] = Bs[k4 * 4 + lk][wc * 32 + j * 16 + li];
+#pragma unroll
+      for(int i = 0; i < 2; ++i)
+#pragma unroll
+        for(int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for(int i = 0; i < 2; ++i)
+#pragma unroll
+    for(int j = 0; j < 2; ++j)
+#pragma unroll
+      for(int reg = 0; reg < 4; ++reg) {
+        const int row = r0 + wr * 32 + i * 16 + lk + 4 * reg, col = c0 + wc * 32 + j * 16 + li;
+        if(row < M && col < N) {
+          double* c = C + (int64_t)row * ldc + col;
+          *c = (beta == 0.0 ? 0.0 : beta * (*c)) + alpha * acc[i][j][reg];
+        }
+      }
+}
+
 // ------------------------------------------------------------------------------------------
 // assembly kernels
 // ------------------------------------------------------------------------------------------
@@ -505,8 +585,13 @@ static int launch_small_gemm(hiopamd_ctx* ctx, int M, int N, int K, const double
 {
   if(M < 0 || N < 0 || K < 0) return HIOPAMD_ERR_ARG;
   if(M == 0 || N == 0) return HIOPAMD_OK;
-  hipLaunchKernelGGL(small_gemm, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, ctx->stream, M, N, K, A, a_rs, a_cs,
-                     B, b_rs, b_cs, beta, C, ldc, alpha);
+  static const bool scalar_only = std::getenv("HIOPAMD_GEMM") && std::atoi(std::getenv("HIOPAMD_GEMM")) == 0;   // A/B aid
+  if(M >= 32 && N >= 32 && !scalar_only)   // fp64 MFMA tiles; outputs narrower than half a tile stay on the scalar kernel
+    hipLaunchKernelGGL(gemm_mfma_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, ctx->stream, M, N, K, A, a_rs, a_cs, B, b_rs,
+                       b_cs, beta, C, ldc, alpha);
+  else
+    hipLaunchKernelGGL(small_gemm, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, ctx->stream, M, N, K, A, a_rs, a_cs,
+                       B, b_rs, b_cs, beta, C, ldc, alpha);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
 }

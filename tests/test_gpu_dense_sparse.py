@@ -70,7 +70,8 @@ def test_leading_dimension(ctx):
     np.testing.assert_allclose(xd.cpu().numpy(), big[:, 101:600].T @ y, rtol=1e-12)
 
 
-@pytest.mark.parametrize("m,n,k", [(50, 100, 500), (12, 12, 12), (3, 200, 7), (65, 33, 129)])
+@pytest.mark.parametrize("m,n,k", [(50, 100, 500), (12, 12, 12), (3, 200, 7), (65, 33, 129), (200, 12, 200), (300, 257, 70), (64, 64, 64),
+                                   (1000, 130, 513)])   # outputs of 32 x 32 and more run on fp64 MFMA tiles (ragged tiles, K not a multiple of 16)
 def test_small_gemm_family(ctx, m, n, k):
     r = rng(m + n + k)
     A = r.uniform(-1, 1, (m, n)); X = r.uniform(-1, 1, (n, k)); W = r.uniform(-1, 1, (m, k))
