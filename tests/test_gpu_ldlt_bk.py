@@ -49,7 +49,7 @@ class DevBK:
         self.L.hiopamd_ldlt_bk_destroy(self.h)
 
 
-CASES = [("rand", 1), ("rand", 2), ("rand", 7), ("rand", 63), ("rand", 64), ("rand", 65), ("rand", 130), ("rand", 257), ("rand", 700),
+CASES = [("rand", 1), ("rand", 2), ("rand", 7), ("rand", 63), ("rand", 64), ("rand", 65), ("rand", 130), ("rand", 257), ("rand", 700), ("rand", 2500),
          ("kkt", 96), ("kkt", 200), ("kkt", 1100), ("zero_diag", 50), ("zero_diag", 150), ("arrow", 90), ("arrow", 1500), ("graded", 120)]
 
 
