@@ -195,6 +195,9 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1_v1(int m, int64_t n, con
   }
 }
 
+// (Folding in the LAST stage-1 workgroup of a row tile to arrive -- one launch instead of two -- was measured in round 4 and is slower:
+// with a release fence per workgroup 0.54 ms instead of 0.33 at 200 x 1.25e6 (every fence walks the L2), with agent-scope relaxed atomics
+// for partials and counter 0.343 against 0.333, the dense step 5.69 against 5.60 ms; scripts/r04_gpu_18.sh.)
 __global__ __launch_bounds__(kBlock) void gemv_n_stage2(int m, int nchunks, const double* __restrict__ part,
                                                         double beta, double* __restrict__ y, double alpha)
 {
