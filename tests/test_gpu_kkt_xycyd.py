@@ -122,11 +122,21 @@ def test_max_refactorizations_reports_failure(ctx):
     assert fg.deltas() == fo.perturb.deltas()
 
 
+@pytest.mark.parametrize("pivoted", [False, True])
 @pytest.mark.parametrize("nx,neq,nineq,nonconvex", [(12, 3, 4, False), (70, 9, 30, True), (33, 0, 5, False)])
-def test_dense_xycyd_build_and_directions(ctx, nx, neq, nineq, nonconvex):
+def test_dense_xycyd_build_and_directions(ctx, nx, neq, nineq, nonconvex, pivoted):
+    """pivoted: the back-end's linear solver in Bunch-Kaufman mode (hiopamd_linsolver_set_pivoting on hiopamd_kkt_xycyd_linsolver) -- what
+    the reference's dense KKT classes run with compute_mode = cpu (hiopKKTLinSysDense.hpp:100-119: hiopLinSolverSymDenseLapack); the
+    inertia-correction sequence of the non-convex case must be the oracle's (which factors with LAPACK DSYTRF) either way."""
     from hiop_amd.kkt import KKTLinSysXYcYd
+    from hiop_amd._lib import lib
     (H, Jc, Jd, ixl, ixu, idl, idu), fo, it = cases.dense_case(nx, neq, nineq, seed=nx, nonconvex=nonconvex)
     fg = KKTLinSysXYcYd(ctx, None, D(ixl), D(ixu), D(idl), D(idu), dense_dims=(nx, neq, nineq))
+    if pivoted:
+        L = lib()
+        import ctypes as C
+        L.hiopamd_kkt_xycyd_linsolver.restype = C.c_void_p
+        assert L.hiopamd_linsolver_set_pivoting(C.c_void_p(L.hiopamd_kkt_xycyd_linsolver(fg.h)), 1) == 0
     fg.set_matrices(D(H), D(Jc), D(Jd))
     it_g = fg.pack(it, kf.ITER_PARTS)
     assert fo.update(it) and fg.update(it_g)
