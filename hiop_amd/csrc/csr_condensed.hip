@@ -48,7 +48,9 @@ struct hiopamd_csr_condensed {
       (void)hipFree(long_row); (void)hipFree(long_first); (void)hipFree(chunk_beg); (void)hipFree(chunk_end); (void)hipFree(chunk_part);
     }
   };
-  Long lM, lJt;
+  Long lM, lJt, lJ;
+  int* j_rowptr = nullptr;      // Jd (m rows) as CSR over the caller's row-sorted triplets: row pointers (null: the triplets were not row-sorted)
+  double avg_row_J = 0.0;
   // Jd^T in CSR (n rows): row pointers and column indices (= constraint rows); values are Jt_val (refreshed by the numeric phase).
   // The transposed product Jd^T y runs as a CSR product — no floating-point atomics (the COO scatter form serialises a million
   // atomic adds on y[0] for the dense column of the SparseEx2 pattern: 12 ms per call), results bit-reproducible.
@@ -82,7 +84,8 @@ int hiopamd_csr_condensed_destroy(hiopamd_csr_condensed* c)
   (void)hipFree(c->hpos_l); (void)hipFree(c->dpos);
   c->lM.free_all();
   c->lJt.free_all();
-  (void)hipFree(c->jt_rowptr); (void)hipFree(c->jt_colidx);
+  c->lJ.free_all();
+  (void)hipFree(c->jt_rowptr); (void)hipFree(c->jt_colidx); (void)hipFree(c->j_rowptr);
   delete c;
   return HIOPAMD_OK;
 }
@@ -185,6 +188,19 @@ int hiopamd_csr_condensed_create(hiopamd_csr_condensed** out, hiopamd_ctx* ctx, 
     if(rc == HIOPAMD_OK) rc = up(&c->jt_rowptr, trp);
     if(rc == HIOPAMD_OK) rc = up(&c->jt_colidx, tj);
     if(rc == HIOPAMD_OK) rc = build_long(trp, n, c->lJt);
+    // Jd itself: the caller's triplets are row-sorted by the reference's convention (hiopMatrixSparseTriplet): their row pointers make
+    // them a CSR matrix, and y = Jd x gets the same short-row / long-row treatment as the other two products (a wave per row of two
+    // entries was 0.67 ms for 1e6 rows: two thirds of a solveCompressed of the SparseEx2-shaped bench case)
+    bool sorted = true;
+    for(int k = 1; k < nnzJ && sorted; ++k) sorted = iJ_host[k - 1] <= iJ_host[k];
+    if(sorted && m > 0) {
+      std::vector<int> jrp((size_t)m + 1, 0);
+      for(int k = 0; k < nnzJ; ++k) jrp[(size_t)iJ_host[k] + 1] += 1;
+      for(int i = 0; i < m; ++i) jrp[(size_t)i + 1] += jrp[i];
+      if(rc == HIOPAMD_OK) rc = up(&c->j_rowptr, jrp);
+      if(rc == HIOPAMD_OK) rc = build_long(jrp, m, c->lJ);
+      c->avg_row_J = (double)nnzJ / m;
+    }
     c->avg_row_M = n ? (double)c->nnzM / n : 0.0;
     c->avg_row_Jt = n ? (double)nnzJ / n : 0.0;
   }
@@ -423,6 +439,16 @@ int hiopamd_csr_condensed_jac_trans_times_vec(hiopamd_csr_condensed* c, double b
 {
   if(!c) return HIOPAMD_ERR_ARG;
   return csr_apply_long(c->ctx, c->n, c->jt_rowptr, c->jt_colidx, c->Jt_val, c->lJt, c->avg_row_Jt, beta, y, alpha, x);
+}
+// y (m) = beta y + alpha Jd x (n) on the caller's own (row-sorted) triplet arrays: jJ_dev = their column indices, J_val their values;
+// HIOPAMD_ERR_STATE when the triplets given at creation were not row-sorted (the caller then uses hiopamd_sp_times_vec)
+int hiopamd_csr_condensed_jac_times_vec(hiopamd_csr_condensed* c, const int* jJ_dev, const double* J_val, double beta, double* y,
+                                        double alpha, const double* x)
+{
+  if(!c || (c->nnzJ && (!jJ_dev || !J_val))) return HIOPAMD_ERR_ARG;
+  if(c->m == 0) return HIOPAMD_OK;
+  if(!c->j_rowptr) return HIOPAMD_ERR_STATE;
+  return csr_apply_long(c->ctx, c->m, c->j_rowptr, jJ_dev, J_val, c->lJ, c->avg_row_J, beta, y, alpha, x);
 }
 // diag(M) through the diagonal positions found at creation (hiopamd_csr_extract_diagonal scans a row per thread: a million
 // sequential loads for the dense row of an arrowhead)

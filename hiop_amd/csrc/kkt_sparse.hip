@@ -297,7 +297,11 @@ int hiopamd_kkt_sparse_condensed_solve_compressed(hiopamd_kkt_sparse_condensed* 
       if(i < nd) dd[i] = ryd[i];
     }));
   }
-  RC(hiopamd_sp_times_vec(ctx, nd, nx, k->nnzJ, k->iJ, k->jJ, k->J_val, -1.0, dd, 1.0, dx));   // dd = Jd dx - ryd  (:392)
+  {   // dd = Jd dx - ryd  (:392)
+    int rj = hiopamd_csr_condensed_jac_times_vec(k->csr, k->jJ, k->J_val, -1.0, dd, 1.0, dx);
+    if(rj == HIOPAMD_ERR_STATE) rj = hiopamd_sp_times_vec(ctx, nd, nx, k->nnzJ, k->iJ, k->jJ, k->J_val, -1.0, dd, 1.0, dx);
+    RC(rj);
+  }
   {   // dyd = Hd .* dd - rd  (:394-396)
     const double* Hd = k->Hd;
     RC(launch_ew(ctx, nd, [=] __device__(int64_t i) { dyd[i] = Hd[i] * dd[i] - rd[i]; }));
@@ -349,6 +353,8 @@ int hiopamd_kkt_sparse_condensed_hess_times_vec(hiopamd_kkt_sparse_condensed* k,
 int hiopamd_kkt_sparse_condensed_jac_times_vec(hiopamd_kkt_sparse_condensed* k, double beta, double* y, double alpha, const double* x)
 {
   if(!k || !k->J_val) return HIOPAMD_ERR_STATE;
+  const int rj = hiopamd_csr_condensed_jac_times_vec(k->csr, k->jJ, k->J_val, beta, y, alpha, x);
+  if(rj != HIOPAMD_ERR_STATE) return rj;
   return hiopamd_sp_times_vec(k->ctx, k->nineq, k->nx, k->nnzJ, k->iJ, k->jJ, k->J_val, beta, y, alpha, x);
 }
 int hiopamd_kkt_sparse_condensed_jac_trans_times_vec(hiopamd_kkt_sparse_condensed* k, double beta, double* y, double alpha, const double* x)

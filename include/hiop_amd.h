@@ -400,6 +400,10 @@ int hiopamd_csr_condensed_apply(void* user, const double* x_dev, double* y_dev);
 int hiopamd_csr_condensed_refresh_jt(hiopamd_csr_condensed* c, const double* J_val);   /* new Jacobian values for the Jd^T copy */
 /* y (n) = beta y + alpha Jd^T x (m), Jd^T kept in CSR by the object (values of the last numeric phase): no floating-point atomics */
 int hiopamd_csr_condensed_jac_trans_times_vec(hiopamd_csr_condensed* c, double beta, double* y, double alpha, const double* x);
+/* y (m) = beta y + alpha Jd x on the caller's own row-sorted triplet arrays (device column indices and values): rows of a few entries one
+ * thread each, long rows in chunks; HIOPAMD_ERR_STATE if the triplets given at creation were not row-sorted */
+int hiopamd_csr_condensed_jac_times_vec(hiopamd_csr_condensed* c, const int* jJ_dev, const double* J_val, double beta, double* y,
+                                        double alpha, const double* x);
 int hiopamd_csr_condensed_diagonal(hiopamd_csr_condensed* c, double* diag_dev);   /* diag(M), device, n */
 int hiopamd_csr_condensed_jacobi(void* user, const double* x_dev, double* y_dev);
 /* generic CSR kernels (int32 row pointers / column indices on the device) */
