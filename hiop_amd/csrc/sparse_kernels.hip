@@ -55,18 +55,19 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_rows(int nrows, int nnz, cons
 }
 
 // few-row matrices (e.g. the 3 inequality rows of MdsEx1, one of them with n_s/2 entries): every row is cut
-// into SPMV_SPLIT slices, one workgroup per (row, slice); the slice sums are folded in slice order.
-constexpr int SPMV_SPLIT = 16;
+// into `split` slices (16, or more when the rows are very long: one slice per ~16K entries of the average row -- the border rows of
+// the bordered-diagonal solver hold 1e6 entries), one workgroup per (row, slice); the slice sums are folded in slice order.
+constexpr int SPMV_SPLIT = 16, SPMV_SPLIT_MAX = 1024;
 __global__ __launch_bounds__(kBlock) void coo_spmv_rows_split(int nrows, int nnz, const int* __restrict__ iRow,
                                                               const int* __restrict__ jCol,
                                                               const double* __restrict__ val,
-                                                              const double* __restrict__ x, double* __restrict__ part)
+                                                              const double* __restrict__ x, double* __restrict__ part, int split)
 {
-  const int row = blockIdx.x / SPMV_SPLIT, sl = blockIdx.x % SPMV_SPLIT;
+  const int row = blockIdx.x / split, sl = blockIdx.x % split;
   const int start = wave_lower_bound(iRow, 0, nnz, row, threadIdx.x & 63);       // every wave of the workgroup: same result
   const int end = wave_lower_bound(iRow, start, nnz, row + 1, threadIdx.x & 63);
   const int len = end - start;
-  const int chunk = (len + SPMV_SPLIT - 1) / SPMV_SPLIT;
+  const int chunk = (len + split - 1) / split;
   const int b0 = start + sl * chunk;
   int b1 = b0 + chunk;
   if(b1 > end) b1 = end;
@@ -79,12 +80,12 @@ __global__ __launch_bounds__(kBlock) void coo_spmv_rows_split(int nrows, int nnz
   if(threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 __global__ void coo_spmv_fold(int nrows, const double* __restrict__ part, double beta, double* __restrict__ y,
-                              double alpha, double* __restrict__ y2)
+                              double alpha, double* __restrict__ y2, int split)
 {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if(row >= nrows) return;
   double s = 0.0;
-  for(int q = 0; q < SPMV_SPLIT; ++q) s += part[row * SPMV_SPLIT + q];
+  for(int q = 0; q < split; ++q) s += part[(int64_t)row * split + q];
   const double r = (beta == 0.0 ? 0.0 : beta * y[row]) + alpha * s;
   y[row] = r;
   if(y2) y2[row] = r;
@@ -411,10 +412,12 @@ int hiopamd_sp_times_vec_copy(hiopamd_ctx* ctx, int nrows, int ncols, int nnz, c
   if(nrows < 0 || nnz < 0) return HIOPAMD_ERR_ARG;
   if(nrows == 0) return HIOPAMD_OK;
   if(nrows <= 256 && nnz > 64 * nrows) {
-    double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nrows * SPMV_SPLIT);
-    hipLaunchKernelGGL(coo_spmv_rows_split, dim3(nrows * SPMV_SPLIT), dim3(kBlock), 0, ctx->stream, nrows, nnz, iRow,
-                       jCol, val, x, part);
-    hipLaunchKernelGGL(coo_spmv_fold, dim3((nrows + 63) / 64), dim3(64), 0, ctx->stream, nrows, part, beta, y, alpha, y2);
+    int split = SPMV_SPLIT;
+    while(split < SPMV_SPLIT_MAX && (int64_t)nnz / nrows > (int64_t)split * 16384) split *= 2;
+    double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nrows * split);
+    hipLaunchKernelGGL(coo_spmv_rows_split, dim3(nrows * split), dim3(kBlock), 0, ctx->stream, nrows, nnz, iRow,
+                       jCol, val, x, part, split);
+    hipLaunchKernelGGL(coo_spmv_fold, dim3((nrows + 63) / 64), dim3(64), 0, ctx->stream, nrows, part, beta, y, alpha, y2, split);
     HIOPAMD_CHECK(hipGetLastError());
     return HIOPAMD_OK;
   }
