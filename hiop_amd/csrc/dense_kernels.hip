@@ -88,6 +88,27 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
         }
       }
     } else {
+      // the 8-byte form (odd leading dimension or unaligned operands -- the stock MdsEx1 at n_dense = 4097): interior blocks unguarded
+      // as well, half the rows at a time (8 + 32 loads in flight); same order of the multiply-adds as the guarded form
+      if(r0 + GEMV_ROWS <= m && c0 + (int64_t)kBlock * GEMV_COLS_PER_THREAD <= n) {
+        const double* xb = x + c0 + threadIdx.x;
+        const double* Ab = A + (int64_t)r0 * lda + c0 + threadIdx.x;
+        double xs[GEMV_COLS_PER_THREAD], as[GEMV_ROWS / 2][GEMV_COLS_PER_THREAD];
+#pragma unroll
+        for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) xs[u] = xb[u * kBlock];
+#pragma unroll
+        for(int rh = 0; rh < GEMV_ROWS; rh += GEMV_ROWS / 2) {
+#pragma unroll
+          for(int r = 0; r < GEMV_ROWS / 2; ++r)
+#pragma unroll
+            for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) as[r][u] = __builtin_nontemporal_load(Ab + (int64_t)(rh + r) * lda + u * kBlock);
+#pragma unroll
+          for(int r = 0; r < GEMV_ROWS / 2; ++r)
+#pragma unroll
+            for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) acc[rh + r] = fma(as[r][u], xs[u], acc[rh + r]);
+        }
+        continue;
+      }
       double xv[GEMV_COLS_PER_THREAD];
 #pragma unroll
       for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) {
@@ -259,9 +280,27 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const 
         const int64_t j0 = jb + (int64_t)p * 2 * kBlock;
         if(j0 >= n) continue;
         const double* Ap = A + (int64_t)rb * lda + j0;
-        for(int r = 0; r < rc; ++r) {
-          a0[p] = fma(Ap[(int64_t)r * lda], xs[r], a0[p]);
-          if(j0 + 1 < n) a1[p] = fma(Ap[(int64_t)r * lda + 1], xs[r], a1[p]);
+        if(j0 + 1 < n) {   // both columns inside: eight rows = sixteen 8-byte loads in flight (odd leading dimension: no 16-byte loads)
+          int r = 0;
+          for(; r + 8 <= rc; r += 8) {
+            double u0[8], u1[8];
+#pragma unroll
+            for(int q = 0; q < 8; ++q) {
+              u0[q] = Ap[(int64_t)(r + q) * lda];
+              u1[q] = Ap[(int64_t)(r + q) * lda + 1];
+            }
+#pragma unroll
+            for(int q = 0; q < 8; ++q) {
+              a0[p] = fma(u0[q], xs[r + q], a0[p]);
+              a1[p] = fma(u1[q], xs[r + q], a1[p]);
+            }
+          }
+          for(; r < rc; ++r) {
+            a0[p] = fma(Ap[(int64_t)r * lda], xs[r], a0[p]);
+            a1[p] = fma(Ap[(int64_t)r * lda + 1], xs[r], a1[p]);
+          }
+        } else {
+          for(int r = 0; r < rc; ++r) a0[p] = fma(Ap[(int64_t)r * lda], xs[r], a0[p]);
         }
       }
     }
