@@ -1,0 +1,207 @@
+"""CPU replay of the device protocol of the pivoted factorisation (hiop_amd/csrc/ldlt_bk.hip), thread by thread.
+
+The HIP file claims that none of its three launches per column has an internal ordering requirement: "everything a thread writes
+depends only on its own row plus a handful of scalars the deciding workgroup saved".  This test restates the three kernels at the
+granularity of one thread = one Python call that reads and writes the SHARED arrays in place, and runs the threads of a launch in
+RANDOM order.  If a thread read a location another thread of the same launch writes, the result would depend on the order; it must
+instead equal the oracle's factor (oracle/bunch_kaufman.py: pivots, permutation, L, D) for every order tried.  The saved scalars, the
+"last workgroup decides" points and the two index spaces of the apply launch (rows i >= k, previous columns j < k) are those of the
+HIP code, in the same places."""
+import numpy as np
+import pytest
+
+from oracle import bunch_kaufman as bk
+from tests.test_oracle_bunch_kaufman import make
+
+ALPHA = bk.ALPHA
+NB = 64
+
+
+class State:
+    def __init__(self):
+        self.next_k = 0
+        self.info = 0
+
+
+def column_launch(a, W, st, n, k, k0, second, order):
+    """bk_column_kernel<SECOND>: one call of `thread(i)` per row i >= k, in the given order; then the deciding block."""
+    if st.next_k != k or (second and not st.need2):
+        return
+    kw = k - k0
+    col = kw + 1 if second else kw
+    src = st.imax if second else k
+    coef = W[src, :kw].copy()                      # (loaded into LDS before any thread writes column `col`: columns < kw only)
+    best, bidx = -1.0, 1 << 30
+
+    def thread(i):
+        nonlocal best, bidx
+        v = a[i, src] if (not second or i >= src) else a[src, i]
+        for p in range(kw):
+            v -= a[i, k0 + p] * coef[p]
+        W[i, col] = v
+        cand = (i != src) if second else (i > k)
+        if cand:
+            av = abs(v)
+            if av > best or (av == best and i < bidx):
+                best, bidx = av, i
+
+    for i in order:
+        thread(i)
+    # ---- the last workgroup decides (reads what the others wrote: behind the fence + counter of the HIP code)
+    if not second:
+        wkk = W[k, kw]
+        st.absakk, st.colmax = abs(wkk), (best if best >= 0 else 0.0)
+        st.imax = bidx if best >= 0 else k
+        st.c0_k = wkk
+        st.need2 = False
+        if not (max(st.absakk, st.colmax) > 0.0):
+            if st.info == 0:
+                st.info = k + 1
+        elif not (st.absakk >= ALPHA * st.colmax):
+            st.need2 = True
+        if not st.need2:
+            st.kp, st.kstep, st.use_c1 = k, 1, False
+            st.c0_kk = st.c0_kp = wkk
+            st.c1_kk = st.c1_kp = 0.0
+            st.akk_old = a[k, k]
+    else:
+        imax, rowmax = src, (best if best >= 0 else 0.0)
+        wii = abs(W[imax, kw + 1])
+        st.use_c1 = False
+        if st.absakk >= ALPHA * st.colmax * (st.colmax / rowmax):
+            st.kp, st.kstep = k, 1
+        elif wii >= ALPHA * rowmax:
+            st.kp, st.kstep, st.use_c1 = imax, 1, True
+        else:
+            st.kp, st.kstep = imax, 2
+        kk = k + st.kstep - 1
+        st.c0_kk, st.c0_kp = W[kk, kw], W[st.kp, kw]
+        st.c1_kk, st.c1_kp = W[kk, kw + 1], W[st.kp, kw + 1]
+        st.akk_old = a[kk, kk]
+        st.need2 = False
+
+
+def apply_launch(a, W, e, ipiv, perm, st, n, k, k0, order):
+    """bk_apply_kernel: thread t owns row i = k + t of the trailing part AND previous column j = t (and panel column t of W)."""
+    if st.next_k != k:
+        return
+    kp, kstep, use_c1 = st.kp, st.kstep, st.use_c1
+    kk, kw = k + kstep - 1, k - k0
+    swp = kp != kk
+
+    def thread(t):
+        if swp:
+            if t < k:
+                a[kk, t], a[kp, t] = a[kp, t], a[kk, t]
+            if t < kw:
+                W[kk, t], W[kp, t] = W[kp, t], W[kk, t]
+        i = k + t
+        if i >= n:
+            return
+        is_kk, is_kp = swp and i == kk, swp and i == kp
+        w1 = 0.0
+        if is_kk:
+            w0, w1 = (st.c1_kp if use_c1 else st.c0_kp), st.c1_kp
+        elif is_kp:
+            w0, w1 = (st.c1_kk if use_c1 else st.c0_kk), st.c1_kk
+        else:
+            w0 = W[i, kw + 1] if use_c1 else W[i, kw]
+            if kstep == 2:
+                w1 = W[i, kw + 1]
+        if use_c1 or is_kk or is_kp:
+            W[i, kw] = w0
+        if kstep == 2 and (is_kk or is_kp):
+            W[i, kw + 1] = w1
+        if swp:
+            if i == kp:
+                a[kp, kp] = st.akk_old
+            elif kk < i < kp:
+                a[kp, i] = a[i, kk]
+            elif i > kp:
+                a[i, kp] = a[i, kk]
+        if kstep == 1:
+            dk = ((st.c1_kp if use_c1 else st.c0_kp) if swp else st.c0_k)
+            if i == k:
+                a[k, k] = dk
+            else:
+                a[i, k] = w0 * (1.0 / dk) if dk != 0.0 else w0
+        else:
+            wk0 = st.c0_k
+            wk10 = st.c0_kp if swp else st.c0_kk
+            wk11 = st.c1_kp if swp else st.c1_kk
+            if i == k:
+                a[k, k] = wk0
+            elif i == k + 1:
+                a[k + 1, k] = 0.0
+                e[k] = wk10
+                a[k + 1, k + 1] = wk11
+            else:
+                d21 = wk10
+                d11, d22 = wk11 / d21, wk0 / d21
+                tt = 1.0 / (d11 * d22 - 1.0)
+                d21 = tt / d21
+                a[i, k] = d21 * (d11 * w0 - w1)
+                a[i, k + 1] = d21 * (d22 * w1 - w0)
+
+    for t in order:
+        thread(t)
+    # ---- the last workgroup
+    if kstep == 1:
+        ipiv[k] = kp + 1
+    else:
+        ipiv[k] = ipiv[k + 1] = -(kp + 1)
+    if swp:
+        perm[kk], perm[kp] = perm[kp], perm[kk]
+    st.next_k = k + kstep
+
+
+def replay(A, rng):
+    n = A.shape[0]
+    a = np.tril(np.array(A, dtype=np.float64))      # a[i, j], i >= j: what the device addresses as A[j * lda + i]
+    a[np.triu_indices(n, 1)] = np.nan                # the other triangle is never read
+    e, ipiv, perm = np.zeros(n + 1), np.zeros(n, dtype=np.int64), np.arange(n)
+    st = State()
+    k0 = 0
+    while k0 < n:
+        last = (n - k0) <= NB
+        kcap = n if last else k0 + NB - 1
+        W = np.full((n, NB), np.nan)
+        for k in range(k0, kcap):
+            rows = np.arange(k, n)
+            column_launch(a, W, st, n, k, k0, False, rng.permutation(rows))
+            column_launch(a, W, st, n, k, k0, True, rng.permutation(rows))
+            apply_launch(a, W, e, ipiv, perm, st, n, k, k0, rng.permutation(max(n - k, k)))
+        kend = st.next_k
+        if last:
+            assert kend == n
+            break
+        kb = kend - k0
+        assert kcap <= kend <= k0 + NB
+        upd = a[kend:, k0:kend] @ W[kend:, :kb].T       # ldlt_rankk_update: a(c, r) -= sum_p a(c, k0 + p) W(r, p), c >= r >= kend
+        a[kend:, kend:] -= np.tril(upd)
+        k0 = kend
+    return a, e[:n], ipiv, perm, st.info
+
+
+@pytest.mark.parametrize("kind,n", [("rand", 1), ("rand", 2), ("rand", 9), ("rand", 64), ("rand", 65), ("rand", 150), ("zero_diag", 70),
+                                    ("kkt", 96), ("arrow", 90), ("graded", 100)])
+def test_threads_in_any_order_give_the_oracle_factor(kind, n):
+    A = make(kind, n)
+    fo = bk.factor(A)
+    for seed in range(3):
+        a, e, ipiv, perm, info = replay(A, np.random.default_rng(seed))
+        assert info == 0
+        np.testing.assert_array_equal(ipiv, fo.ipiv)
+        np.testing.assert_array_equal(perm, fo.perm)
+        L = np.tril(a, -1) + np.eye(n)
+        g = max(1.0, np.abs(fo.L).max())
+        np.testing.assert_allclose(np.diag(a), fo.d, rtol=1e-10, atol=1e-12 * np.abs(A).max() * g * g)
+        np.testing.assert_allclose(e, fo.e, rtol=1e-10, atol=1e-12 * np.abs(A).max() * g * g)
+        np.testing.assert_allclose(L, fo.L, rtol=1e-9, atol=1e-11 * g * g)
+
+
+def test_exactly_zero_column_sets_info_and_goes_on():
+    A = np.zeros((6, 6))
+    A[0, 0] = 2.0
+    a, e, ipiv, perm, info = replay(A, np.random.default_rng(0))
+    assert info == 2 == bk.factor(A).info
