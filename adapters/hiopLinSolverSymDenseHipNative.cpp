@@ -40,15 +40,24 @@ int hiopLinSolverSymDenseHipNative::matrixChanged()
     // of negative eigenvalues or -1 (hiopLinSolver.hpp:117-130; the LAPACK class returns -1 for info != 0 as well,
     // hiopLinSolverSymDenseLapack.hpp:103-117) — so this is reported on stderr and answered with -1: the IPM's inertia-correction
     // loop re-assembles and calls again (hiopKKTLinSys.cpp:316-372), and gives up in its own way if the failure persists.
-    std::fprintf(stderr, "hiop_amd: hiopamd_linsolver_matrix_changed failed with status %d; reporting -1 to the caller\n", rc);
+    // What the -1 must NOT do is pass for "singular matrix" silently: the failure is counted, every message says DEVICE FAILURE, and while
+    // the count is non-zero solve() returns false (the reference's callers stop on a failed solve with "linear solver error" instead of
+    // taking a direction computed from a factorisation that never happened).  A later successful factorisation clears the count.
+    ++device_failures_;
+    std::fprintf(stderr,
+                 "hiop_amd: DEVICE FAILURE in hiopamd_linsolver_matrix_changed (status %d, %d in a row) -- this is not a singular matrix; "
+                 "reporting -1 to the caller, solve() will return false until a factorisation succeeds\n",
+                 rc, device_failures_);
     return -1;
   }
+  device_failures_ = 0;
   return n_neg;   // -1: zero / non-finite pivot (or, in safe mode, a probe solve that did not converge): the reference's "singular" answer
 }
 
 bool hiopLinSolverSymDenseHipNative::solve(hiopVector& x)
 {
   assert(x.get_size() == n_);
+  if(device_failures_ > 0) return false;   // the last factorisation failed in the device layer (see matrixChanged)
   if(nlp_) nlp_->runStats.linsolv.tmTriuSolves.start();
   const int rc = hiopamd_linsolver_solve(ls_, x.local_data(), 1);
   int ok = 1;
@@ -61,6 +70,7 @@ bool hiopLinSolverSymDenseHipNative::solve(hiopMatrix& x_)
 {
   auto& x = dynamic_cast<hiopMatrixDenseHipNative&>(x_);
   assert(x.n() == n_);
+  if(device_failures_ > 0) return false;
   const int rc = hiopamd_linsolver_solve(ls_, x.local_data(), x.m());
   int ok = 1;
   const int rc2 = hiopamd_linsolver_solve_status(ls_, &ok);

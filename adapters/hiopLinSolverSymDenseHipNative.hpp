@@ -29,6 +29,7 @@ public:
 private:
   hiopamd_ctx* ctx_;
   hiopamd_linsolver* ls_;
+  int device_failures_ = 0;   // consecutive matrixChanged() calls that failed in the device layer (not: singular matrix); solve() refuses while > 0
   int n_;
 };
 

@@ -169,53 +169,6 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
   }
 }
 
-constexpr int GEMV1_COLS_PER_THREAD = 8;
-constexpr int GEMV1_COLS = kBlock * GEMV1_COLS_PER_THREAD;
-// A/B aid (HIOPAMD_GEMV=1): round 2's stage 1 (one column chunk per block, full shuffle tree per row)
-__global__ __launch_bounds__(kBlock) void gemv_n_stage1_v1(int m, int64_t n, const double* __restrict__ A, int64_t lda,
-                                                        const double* __restrict__ x, double* __restrict__ part)
-{
-  const int64_t c0 = (int64_t)blockIdx.x * GEMV1_COLS;
-  const int r0 = blockIdx.y * GEMV_ROWS;
-  double xv[GEMV1_COLS_PER_THREAD];
-#pragma unroll
-  for(int u = 0; u < GEMV1_COLS_PER_THREAD; ++u) {
-    int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
-    xv[u] = (j < n) ? x[j] : 0.0;
-  }
-  double acc[GEMV_ROWS];
-#pragma unroll
-  for(int r = 0; r < GEMV_ROWS; ++r) {
-    acc[r] = 0.0;
-    const int row = r0 + r;
-    if(row < m) {
-      const double* Ar = A + (int64_t)row * lda;
-#pragma unroll
-      for(int u = 0; u < GEMV1_COLS_PER_THREAD; ++u) {
-        int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
-        if(j < n) acc[r] = fma(Ar[j], xv[u], acc[r]);
-      }
-    }
-  }
-  // block reduce the 8 accumulators
-  __shared__ double sm[GEMV_ROWS][kBlock / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for(int r = 0; r < GEMV_ROWS; ++r) {
-    double v = acc[r];
-    for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if(lane == 0) sm[r][wave] = v;
-  }
-  __syncthreads();
-  if(threadIdx.x < GEMV_ROWS) {
-    const int row = r0 + threadIdx.x;
-    if(row < m) {
-      double v = ((sm[threadIdx.x][0] + sm[threadIdx.x][1]) + sm[threadIdx.x][2]) + sm[threadIdx.x][3];
-      part[(int64_t)blockIdx.x * m + row] = v;
-    }
-  }
-}
-
 // (Folding in the LAST stage-1 workgroup of a row tile to arrive -- one launch instead of two -- was measured in round 4 and is slower:
 // with a release fence per workgroup 0.54 ms instead of 0.33 at 200 x 1.25e6 (every fence walks the L2), with agent-scope relaxed atomics
 // for partials and counter 0.343 against 0.333, the dense step 5.69 against 5.60 ms; scripts/r04_gpu_18.sh.)
@@ -565,20 +518,18 @@ int hiopamd_mat_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, i
   if(m < 0 || n < 0) return HIOPAMD_ERR_ARG;
   if(m == 0) return HIOPAMD_OK;
   if(n == 0) return hiopamd_vec_scale(ctx, m, y, beta);
-  static const bool v1 = std::getenv("HIOPAMD_GEMV") && std::atoi(std::getenv("HIOPAMD_GEMV")) == 1;
   // column chunks one block walks before it reduces: 4 for the tall-skinny Jacobians (k >= 100 rows: thousands of blocks anyway), fewer
   // when there are few row tiles (the l x n secant blocks, l <= 8: ONE row tile -- 153 blocks at n = 1.25e6 with 4 chunks, 611 with 1)
   const int rtiles = (m + GEMV_ROWS - 1) / GEMV_ROWS;
   int chunks = GEMV_CHUNKS;
   while(chunks > 1 && (int64_t)rtiles * ((n + (int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks - 1) / ((int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks)) < 2048)
     chunks >>= 1;
-  const int64_t cols = v1 ? GEMV1_COLS : (int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks;
+  const int64_t cols = (int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks;
   const int nchunks = (int)((n + cols - 1) / cols);
   double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nchunks * m);
   const bool vec = (lda % 2 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)x % 16 == 0);
   const dim3 g1(nchunks, rtiles), b1(kBlock);
-  if(v1) hipLaunchKernelGGL(gemv_n_stage1_v1, g1, b1, 0, ctx->stream, m, n, A, lda, x, part);
-  else if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks);
+  if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks);
   else hipLaunchKernelGGL(gemv_n_stage1<false>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks);
   const int waves_per_block = kBlock / 64;
   hipLaunchKernelGGL(gemv_n_stage2, dim3((m + waves_per_block - 1) / waves_per_block), dim3(kBlock), 0, ctx->stream, m,
@@ -627,8 +578,7 @@ static int launch_small_gemm(hiopamd_ctx* ctx, int M, int N, int K, const double
 {
   if(M < 0 || N < 0 || K < 0) return HIOPAMD_ERR_ARG;
   if(M == 0 || N == 0) return HIOPAMD_OK;
-  static const bool scalar_only = std::getenv("HIOPAMD_GEMM") && std::atoi(std::getenv("HIOPAMD_GEMM")) == 0;   // A/B aid
-  if(M >= 32 && N >= 32 && !scalar_only)   // fp64 MFMA tiles; outputs narrower than half a tile stay on the scalar kernel
+  if(M >= 32 && N >= 32)   // fp64 MFMA tiles; outputs narrower than half a tile stay on the scalar kernel
     hipLaunchKernelGGL(gemm_mfma_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, ctx->stream, M, N, K, A, a_rs, a_cs, B, b_rs,
                        b_cs, beta, C, ldc, alpha);
   else

@@ -318,175 +318,8 @@ struct GramStripTiles2 {
   unsigned char tj[WAVES][TPW];
   unsigned char cnt[WAVES];
 };
-template <int WAVES, int TPW, int ROWS, bool VEC>
-__device__ __forceinline__ void gram_strip2_body(int ma, int mb, int64_t n, const GramRows& X, const double* __restrict__ d,
-                                                 int64_t kchunk, int tiles_b, int ntiles, const GramStripTiles2<WAVES, TPW>& tl,
-                                                 double* __restrict__ partial, double* __restrict__ Xs, double (*ds)[GS_KT])
-{
-  // LDS layout of a stage buffer (round 3, after PMC showed SQ_LDS_BANK_CONFLICT = 48 % of the LDS cycles with the padded row-major
-  // layout: ds_read_b128 is served in four fixed 16-lane groups, each mixing TWO k-slots lk with complementary row sets, and
-  // conflict-free means 16 distinct 16-byte slots of a 256-byte bank row per group — MI355X_MICROARCH.md §LDS):
-  //   four PLANES, one per k-slot lk = k % 4; inside a plane row r holds its 8 k-values of that slot as four 16-byte pairs
-  //   (k = 8 g + lk, k + 4), pair g stored at position g ^ ((r >> 2) & 3)  (64 bytes per row, no padding).
-  // Slot of lane (li, lk) for pair g: 4 (li & 3) + (g ^ (li >> 2)) + plane shift — within a lane group the two k-slots own rows with
-  // li >> 2 in {0, 3} and {1, 2}: disjoint, whatever g.  Planes 2, 3 start 64 bytes later (mod 128) than planes 0, 1 so that the
-  // 8-byte staging stores of a 16-lane group (k-slots {0, 2} or {1, 3}) fall on 16 distinct bank pairs as well.
-  constexpr int GS_PLANE = ROWS * 8;                  // doubles per plane
-  constexpr int GS_BUF = 4 * GS_PLANE + 16;           // doubles per stage buffer
-  auto plane = [](int lk) { return lk * GS_PLANE + (lk >> 1) * 8; };
-  constexpr int NT = 64 * WAVES;
-  constexpr int RPP = NT / 16;          // rows per staging pass
-  constexpr int NP = ROWS / RPP;        // staging passes
-  constexpr int TB = (TPW >= 8) ? 4 : TPW;   // tiles per operand batch (registers: 8 per tile)
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lk = lane >> 4, li = lane & 15;
-  const int split = blockIdx.x;
-  const int64_t kbeg = (int64_t)split * kchunk;
-  int64_t kend = kbeg + kchunk;
-  if(kend > n) kend = n;
-  const int npa = __builtin_amdgcn_readfirstlane((((mb + 15) / 16) * 16 + RPP - 1) / RPP);   // staging passes with live rows
-  const int ntw = tl.cnt[wave];
-  const int srow = tid >> 4, skk = (tid & 15) * 2;
-  // staging store offsets of k = skk and k + 1 (same group of 8: skk is even) for row srow (+ 8 ps RPP doubles per pass: RPP is a
-  // multiple of 16, so (row >> 2) & 3 does not depend on the pass)
-  const int sg = skk >> 3, sq = (srow >> 2) & 3;
-  const int p0 = plane(skk & 3) + srow * 8 + ((sg ^ sq) << 1) + ((skk >> 2) & 1);
-  const int p1 = plane((skk + 1) & 3) + srow * 8 + ((sg ^ sq) << 1) + (((skk + 1) >> 2) & 1);
-  // Staging without a branch or a wait inside: the row pointers are resolved once (segment look-ups are dependent loads), a
-  // row outside the matrix is clamped to the last row and masked when it is written to LDS, a k outside the chunk likewise;
-  // all loads of a stage are issued back to back one stage ahead, the masks are applied at the LDS store.
-  const double* rp[NP];
-  bool rok[NP];
-#pragma unroll
-  for(int ps = 0; ps < NP; ++ps) {
-    const int r = ps * RPP + srow;
-    const int rc = (r < mb) ? r : (mb - 1);
-    const int seg = (rc < X.rows[0]) ? 0 : ((rc < X.rows[1]) ? 1 : 2);
-    const int base = (seg == 0) ? 0 : ((seg == 1) ? X.rows[0] : X.rows[1]);
-    const double* p = (seg == 0) ? X.p[0] : ((seg == 1) ? X.p[1] : X.p[2]);
-    const int64_t ld = (seg == 0) ? X.ld[0] : ((seg == 1) ? X.ld[1] : X.ld[2]);
-    rp[ps] = p + (int64_t)(rc - base) * ld;
-    rok[ps] = r < mb;
-  }
-  double v0[NP], v1[NP];
-  double dreg = 0.0;
-  bool m0 = false, m1 = false, md = false;   // k / k + 1 (/ the weight's k) of the stage in flight inside the chunk
-  const double* dsrc = d ? d : X.p[0];
-  auto gload = [&](int64_t k0) {
-    const int64_t k = k0 + skk;
-    m0 = k < kend;
-    m1 = k + 1 < kend;
-    if constexpr(VEC) {
-      // 16-byte loads (rows and leading dimensions 16-byte aligned): k is even; at the ragged end of the chunk the pair is
-      // clamped to the last even position, which is inside the row (an odd n has at least one padding element: ld is even)
-      const int64_t kc = m0 ? k : ((kend - 1) & ~(int64_t)1);
-#pragma unroll
-      for(int ps = 0; ps < NP; ++ps) {
-        const double2 t = *reinterpret_cast<const double2*>(rp[ps] + kc);
-        v0[ps] = t.x;
-        v1[ps] = t.y;
-      }
-    } else {
-      const int64_t kc0 = m0 ? k : (kend - 1), kc1 = m1 ? (k + 1) : (kend - 1);
-#pragma unroll
-      for(int ps = 0; ps < NP; ++ps) {
-        v0[ps] = rp[ps][kc0];
-        v1[ps] = rp[ps][kc1];
-      }
-    }
-    // the weight: always a load (from the matrix itself when there is no weight vector), value and mask applied at the LDS store —
-    // a select on the loaded value here would put a vmcnt(0) right behind the stage's loads
-    const int64_t kd = k0 + (tid & (GS_KT - 1));
-    md = kd < kend;
-    dreg = dsrc[md ? kd : (kend - 1)];
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for(int ps = 0; ps < NP; ++ps) {
-      if(ps < npa) {   // scalar; nothing waits inside
-        Xs[buf * GS_BUF + ps * RPP * 8 + p0] = (rok[ps] && m0) ? v0[ps] : 0.0;
-        Xs[buf * GS_BUF + ps * RPP * 8 + p1] = (rok[ps] && m1) ? v1[ps] : 0.0;
-      }
-    }
-    if(tid < GS_KT) ds[buf][tid] = md ? (d ? dreg : 1.0) : 0.0;
-  };
-  double4_t acc[TPW];
-#pragma unroll
-  for(int t = 0; t < TPW; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-  // LDS offset of each tile's operands (wave-uniform: scalar registers); a padding slot repeats tile 0
-  int aoff[TPW], boff[TPW];
-#pragma unroll
-  for(int t = 0; t < TPW; ++t) {
-    const int tt = (t < ntw) ? t : 0;
-    aoff[t] = __builtin_amdgcn_readfirstlane(16 * 8 * (int)tl.ti[wave][tt]);
-    boff[t] = __builtin_amdgcn_readfirstlane(16 * 8 * (int)tl.tj[wave][tt]);
-  }
-  const int lane_off = plane(lk) + li * 8, lq = li >> 2;
-  if(kbeg < kend) {
-    gload(kbeg);
-    lstore(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for(int64_t k0 = kbeg; k0 < kend; k0 += GS_KT) {
-    const bool more = k0 + GS_KT < kend;
-    if(more) gload(k0 + GS_KT);
-#pragma unroll
-    for(int g8 = 0; g8 < GS_KT / 8; ++g8) {
-      const double w0 = ds[buf][8 * g8 + lk], w1 = ds[buf][8 * g8 + 4 + lk];
-      const double* xb = Xs + buf * GS_BUF + lane_off + ((g8 ^ lq) << 1);
-#pragma unroll
-      for(int tb0 = 0; tb0 < TPW; tb0 += TB) {
-        gs_double2 av[TB], bv[TB];
-#pragma unroll
-        for(int q = 0; q < TB; ++q)
-          if(tb0 + q < TPW) {
-            av[q] = *reinterpret_cast<const gs_double2*>(xb + aoff[tb0 + q]);
-            bv[q] = *reinterpret_cast<const gs_double2*>(xb + boff[tb0 + q]);
-          }
-#pragma unroll
-        for(int q = 0; q < TB; ++q)
-          if(tb0 + q < TPW) {
-            av[q].x *= w0;
-            av[q].y *= w1;
-          }
-#pragma unroll
-        for(int q = 0; q < TB; ++q)
-          if(tb0 + q < TPW) acc[tb0 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q].x, bv[q].x, acc[tb0 + q], 0, 0, 0);
-#pragma unroll
-        for(int q = 0; q < TB; ++q)
-          if(tb0 + q < TPW) acc[tb0 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q].y, bv[q].y, acc[tb0 + q], 0, 0, 0);
-      }
-    }
-    if(more) lstore(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-#pragma unroll
-  for(int t = 0; t < TPW; ++t) {
-    if(t < ntw) {
-      const int tile = tl.ti[wave][t] * tiles_b + tl.tj[wave][t];
-      double* P = partial + ((int64_t)split * ntiles + tile) * 256;
-#pragma unroll
-      for(int reg = 0; reg < 4; ++reg) P[(lk + 4 * reg) * 16 + li] = acc[t][reg];
-    }
-  }
-}
-
-template <int WAVES, int TPW, int ROWS>
-__global__ __launch_bounds__(64 * WAVES, (ROWS <= 128) ? 2 : 1) void gram_strip2_kernel(int ma, int mb, int64_t n, const GramRows X,
-                                                                                       int vec_ok, const double* __restrict__ d,
-                                                                                       int64_t kchunk, int tiles_b, int ntiles,
-                                                                                       const GramStripTiles2<WAVES, TPW> tl,
-                                                                                       double* __restrict__ partial)
-{
-  __shared__ __attribute__((aligned(256))) double Xs[2 * (4 * ROWS * 8 + 16)];
-  __shared__ double ds[2][GS_KT];
-  if(vec_ok) gram_strip2_body<WAVES, TPW, ROWS, true>(ma, mb, n, X, d, kchunk, tiles_b, ntiles, tl, partial, Xs, ds);
-  else gram_strip2_body<WAVES, TPW, ROWS, false>(ma, mb, n, X, d, kchunk, tiles_b, ntiles, tl, partial, Xs, ds);
-}
-
-// The stage buffer with rows padded to 34 doubles (48 % bank-conflict cycles, still the faster one: see gram_strip2_launch)
+// The stage buffer: rows padded to 34 doubles (48 % bank-conflict cycles and still faster than the conflict-free plane layout measured
+// in round 3: 1.27 vs 1.36 ms at k = 200 — the kernel is not LDS-bound; that variant lives in scripts/probes/retired/)
 template <int WAVES, int TPW, int ROWS, bool VEC>
 __device__ __forceinline__ void gram_strip2_body_rm(int ma, int mb, int64_t n, const GramRows& X, const double* __restrict__ d,
                                                  int64_t kchunk, int tiles_b, int ntiles, const GramStripTiles2<WAVES, TPW>& tl,
@@ -655,17 +488,8 @@ static void gram_strip2_launch(hiopamd_ctx* ctx, const std::vector<std::pair<int
     tl.tj[w][t] = (unsigned char)need[q].second;
     tl.cnt[w] = (unsigned char)(t + 1);
   }
-  // HIOPAMD_GRAM_LDS=1: the conflict-free stage buffer (one plane per k-slot, XOR-swizzled pairs: SQ_LDS_BANK_CONFLICT 48 % -> 0).
-  // Measured A/B on one box (scripts/r03_gpu_13.sh): 1.36 vs 1.27 ms at k = 200, 0.50 vs 0.48 at k = 100 — SLOWER although the LDS
-  // cycles halve: the kernel is not LDS-bound (MFMA pipe 74 % busy), and the plane layout splits a lane's two staged values over
-  // two planes and adds an XOR per k-group to every operand address.  Default: rows padded to 34 doubles.
-  static const bool planes = std::getenv("HIOPAMD_GRAM_LDS") && std::atoi(std::getenv("HIOPAMD_GRAM_LDS")) == 1;
-  if(planes)
-    hipLaunchKernelGGL((gram_strip2_kernel<WAVES, TPW, ROWS>), dim3(nsplit), dim3(64 * WAVES), 0, ctx->stream, ma, mb, n, B, vec, d, kchunk,
-                       tb_n, ntiles16, tl, partial);
-  else
-    hipLaunchKernelGGL((gram_strip2_kernel_rm<WAVES, TPW, ROWS>), dim3(nsplit), dim3(64 * WAVES), 0, ctx->stream, ma, mb, n, B, vec, d,
-                       kchunk, tb_n, ntiles16, tl, partial);
+  hipLaunchKernelGGL((gram_strip2_kernel_rm<WAVES, TPW, ROWS>), dim3(nsplit), dim3(64 * WAVES), 0, ctx->stream, ma, mb, n, B, vec, d,
+                     kchunk, tb_n, ntiles16, tl, partial);
 }
 
 template <int T>
@@ -898,6 +722,69 @@ __global__ __launch_bounds__(64) void gram_quad_fold(int l, int nsplit, const do
   if(sym && j > i) W[j * l + i] = v;
 }
 
+// The same four blocks for a secant memory longer than GS_M pairs (the reference's secant_memory_len goes up to 256; hiopamd_hess_lowrank
+// accepts l_max <= 32): the l x l blocks are cut in GS_M x GS_M sub-blocks, blockIdx.y = sub-block (bi, bj); rows beyond l read as zero.
+// Partials: [split][sub-block][4][GS_M * GS_M].  S and Y are re-read once per sub-block column (L2 hits mostly): the rare shape.
+__global__ __launch_bounds__(kBlock) void gram_quad_partial_blk(int l, int nb, int64_t n, const double* __restrict__ S,
+                                                                const double* __restrict__ Y, int64_t ld, const double* __restrict__ dh,
+                                                                double sigma, int64_t kchunk, double* __restrict__ partial)
+{
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bi = blockIdx.y / nb, bj = blockIdx.y % nb;
+  const int64_t kbeg = (int64_t)blockIdx.x * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if(kend > n) kend = n;
+  const double* __restrict__ A = (q == 0) ? Y : S;
+  const double* __restrict__ B = (q <= 1) ? Y : S;
+  double acc[GS_M][GS_M];
+#pragma unroll
+  for(int i = 0; i < GS_M; ++i)
+#pragma unroll
+    for(int j = 0; j < GS_M; ++j) acc[i][j] = 0.0;
+  for(int64_t k = kbeg + lane; k < kend; k += 64) {
+    double a[GS_M], b[GS_M];
+    const double d = (q == 3) ? 1.0 : dh[k];
+    const double w = (q == 0) ? d : (q == 1) ? d * sigma : (q == 2) ? (d * sigma - 1.0) * sigma : 1.0;
+#pragma unroll
+    for(int i = 0; i < GS_M; ++i) a[i] = (GS_M * bi + i < l) ? A[(int64_t)(GS_M * bi + i) * ld + k] * w : 0.0;
+#pragma unroll
+    for(int j = 0; j < GS_M; ++j) b[j] = (GS_M * bj + j < l) ? B[(int64_t)(GS_M * bj + j) * ld + k] : 0.0;
+#pragma unroll
+    for(int i = 0; i < GS_M; ++i)
+#pragma unroll
+      for(int j = 0; j < GS_M; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  }
+  double* out = partial + (((int64_t)blockIdx.x * (nb * nb) + blockIdx.y) * 4 + q) * (GS_M * GS_M);
+#pragma unroll
+  for(int i = 0; i < GS_M; ++i)
+#pragma unroll
+    for(int j = 0; j < GS_M; ++j) {
+      double v = acc[i][j];
+      for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if(lane == 0) out[i * GS_M + j] = v;
+    }
+}
+
+// one wave per entry (q, i, j) of the four l x l blocks, splits summed lane-strided + shuffle tree like gram_quad_fold; the symmetric
+// blocks take their lower triangle from the upper one
+__global__ __launch_bounds__(64) void gram_quad_fold_blk(int l, int nb, int nsplit, const double* __restrict__ partial, double sigma,
+                                                         double* __restrict__ G)
+{
+  const int q = blockIdx.x / (l * l), e = blockIdx.x % (l * l);
+  const int i = e / l, j = e % l;
+  const bool sym = q != 1;
+  if(sym && j < i) return;
+  const int sb = (i / GS_M) * nb + (j / GS_M), es = (i % GS_M) * GS_M + (j % GS_M);
+  double s = 0.0;
+  for(int sp = threadIdx.x; sp < nsplit; sp += 64) s += partial[(((int64_t)sp * (nb * nb) + sb) * 4 + q) * (GS_M * GS_M) + es];
+  for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if(threadIdx.x != 0) return;
+  const double v = (q == 3) ? sigma * s : s;
+  double* W = G + (int64_t)q * l * l;
+  W[i * l + j] = v;
+  if(sym && j > i) W[j * l + i] = v;
+}
+
 }  // namespace hiopamd
 
 using namespace hiopamd;
@@ -931,10 +818,8 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
     return HIOPAMD_OK;
   }
   // strip form: A = the leading rows of the (stacked) right factor, everything fits one workgroup's tile budget
-  static int strip_env = -1;
-  if(strip_env < 0) strip_env = std::getenv("HIOPAMD_GRAM_STRIP") ? std::atoi(std::getenv("HIOPAMD_GRAM_STRIP")) : 2;   // 0: 128-tile kernel, 1: first strip form, 2: second
   const bool a_leads_b = (sym_cols == ma && sym_cols > 0) || (symm != 0);
-  if(strip_env && a_leads_b && ma <= mb && mb <= GS_ROWS && n >= 64 * GS_KT) {
+  if(a_leads_b && ma <= mb && mb <= GS_ROWS && n >= 64 * GS_KT) {
     const int ta_n = (ma + 15) / 16, tb_n = (mb + 15) / 16;
     const int scols = symm ? ma : sym_cols;
     std::vector<std::pair<int, int>> need;
@@ -946,7 +831,7 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
     if((int)need.size() <= GS_WAVES * GS_TPW) {
       const int ntiles16 = ta_n * tb_n;
       const int rows_pad = tb_n * 16;
-      const bool small = strip_env >= 2 && (int)need.size() <= 32 && rows_pad <= 128;   // 4 waves, two workgroups per CU
+      const bool small = (int)need.size() <= 32 && rows_pad <= 128;   // 4 waves, two workgroups per CU
       int nsplit = small ? 512 : 256;
       int64_t kchunk = (n + nsplit - 1) / nsplit;
       kchunk = ((kchunk + GS_KT - 1) / GS_KT) * GS_KT;
@@ -955,7 +840,7 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
       double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * ntiles16 * 256);
       const int vec = seg_vec_ok(B, nsegB) ? 1 : 0;
       const int per2 = ((int)need.size() + (small ? 4 : 8) - 1) / (small ? 4 : 8);
-      if(strip_env >= 2 && per2 <= 13) {   // (14-16 tiles per wave would spill: first form)
+      if(per2 <= 13) {   // (14-16 tiles per wave would spill: first form)
         // second form: branch-free tile loop, (waves, tiles per wave, rows) by the tile count
         const int per = per2;
         if(small) {
@@ -987,11 +872,8 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
       return HIOPAMD_OK;
     }
   }
-  // HIOPAMD_GRAM_T = 128: 128 x 128 tiles, 4 x 4 MFMA tiles per wave, two workgroups per CU; 64 (default): 64 x 64 tiles,
-  // 2 x 2 MFMA tiles per wave, four workgroups per CU
-  static int gt = -1;
-  if(gt < 0) gt = std::getenv("HIOPAMD_GRAM_T") ? std::atoi(std::getenv("HIOPAMD_GRAM_T")) : 128;
-  const int T = (gt == 64) ? 64 : 128;   // 1284: 128 x 128 tiles with 8 waves (4 x 2 MFMA tiles per wave)
+  // other shapes: 128 x 128 tiles, 4 x 4 MFMA tiles per wave, two workgroups per CU
+  constexpr int T = 128;
   const int tiles_a = (ma + T - 1) / T, tiles_b = (mb + T - 1) / T;
   const int ntiles = tiles_a * tiles_b;
   // K split: aim at one round of workgroups over the tiles that are actually computed (symmetric / mirrored ones return at
@@ -1004,7 +886,7 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
       ++live_tiles;
     }
   if(live_tiles < 1) live_tiles = 1;
-  int nsplit = ((T == 128) ? 480 : 960) / live_tiles;
+  int nsplit = 480 / live_tiles;
   if(nsplit < 1) nsplit = 1;
   int64_t kchunk = (n + nsplit - 1) / nsplit;
   kchunk = ((kchunk + GR_KT - 1) / GR_KT) * GR_KT;
@@ -1015,22 +897,10 @@ static int gram_launch(hiopamd_ctx* ctx, int ma, int mb, int64_t n, const GramRo
   const int vec_all = (seg_vec_ok(A, nsegA) && seg_vec_ok(B, nsegB)) ? 1 : 0;
   const int64_t tot = (int64_t)ma * mb;
   const dim3 fgrid((unsigned)((tot + kBlock - 1) / kBlock));
-  if(gt == 1284) {
-    hipLaunchKernelGGL((gram_partial_kernel<128, 4>), dim3(nsplit, ntiles), dim3(512), 0, ctx->stream, ma, mb, n, A, B,
-                       same_ab ? 1 : 0, vec_all, d, kchunk, tiles_b, symm, sym_cols, partial);
-    hipLaunchKernelGGL(gram_fold_kernel<128>, fgrid, dim3(kBlock), 0, ctx->stream, ma, mb, nsplit, ntiles, tiles_b, symm,
-                       sym_cols, partial, beta, W, ldw, alpha);
-  } else if(T == 128) {
-    hipLaunchKernelGGL(gram_partial_kernel<128>, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, B,
-                       same_ab ? 1 : 0, vec_all, d, kchunk, tiles_b, symm, sym_cols, partial);
-    hipLaunchKernelGGL(gram_fold_kernel<128>, fgrid, dim3(kBlock), 0, ctx->stream, ma, mb, nsplit, ntiles, tiles_b, symm,
-                       sym_cols, partial, beta, W, ldw, alpha);
-  } else {
-    hipLaunchKernelGGL(gram_partial_kernel<64>, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, B,
-                       same_ab ? 1 : 0, vec_all, d, kchunk, tiles_b, symm, sym_cols, partial);
-    hipLaunchKernelGGL(gram_fold_kernel<64>, fgrid, dim3(kBlock), 0, ctx->stream, ma, mb, nsplit, ntiles, tiles_b, symm,
-                       sym_cols, partial, beta, W, ldw, alpha);
-  }
+  hipLaunchKernelGGL(gram_partial_kernel<128>, dim3(nsplit, ntiles), dim3(kBlock), 0, ctx->stream, ma, mb, n, A, B, same_ab ? 1 : 0, vec_all,
+                     d, kchunk, tiles_b, symm, sym_cols, partial);
+  hipLaunchKernelGGL(gram_fold_kernel<128>, fgrid, dim3(kBlock), 0, ctx->stream, ma, mb, nsplit, ntiles, tiles_b, symm, sym_cols, partial,
+                     beta, W, ldw, alpha);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
 }
@@ -1066,13 +936,29 @@ extern "C" int hiopamd_gram_weighted_stacked(hiopamd_ctx* ctx, int ma, int64_t n
 extern "C" int hiopamd_gram_lowrank_blocks(hiopamd_ctx* ctx, int l, int64_t n, const double* St, const double* Yt, int64_t ld,
                                            const double* DhInv, double sigma, double* G)
 {
-  if(!ctx || l < 0 || l > GS_M || n < 0 || (l > 0 && (!St || !Yt || !DhInv || !G))) return HIOPAMD_ERR_ARG;
+  if(!ctx || l < 0 || l > 256 || n < 0 || (l > 0 && (!St || !Yt || !DhInv || !G))) return HIOPAMD_ERR_ARG;
   if(l == 0) return HIOPAMD_OK;
   if(n == 0) return hiopamd_vec_set_to_constant(ctx, 4 * (int64_t)l * l, G, 0.0);
   int nsplit = 512;
   int64_t kchunk = (n + nsplit - 1) / nsplit;
   if(kchunk < 16 * 64) kchunk = 16 * 64;
   nsplit = (int)((n + kchunk - 1) / kchunk);
+  if(l > GS_M) {   // a secant memory beyond GS_M pairs: the blocks in GS_M x GS_M sub-blocks (same weights, same fold)
+    const int nb = (l + GS_M - 1) / GS_M;
+    if(nb * nb > 128) {   // (keeps the partial buffer small; l <= 88 stays with 512 splits)
+      nsplit = 64;
+      kchunk = (n + nsplit - 1) / nsplit;
+      if(kchunk < 16 * 64) kchunk = 16 * 64;
+      nsplit = (int)((n + kchunk - 1) / kchunk);
+    }
+    double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * nb * nb * 4 * GS_M * GS_M);
+    if(!partial) return HIOPAMD_ERR_HIP;
+    hipLaunchKernelGGL(gram_quad_partial_blk, dim3(nsplit, nb * nb), dim3(kBlock), 0, ctx->stream, l, nb, n, St, Yt, ld, DhInv, sigma,
+                       kchunk, partial);
+    hipLaunchKernelGGL(gram_quad_fold_blk, dim3(4 * l * l), dim3(64), 0, ctx->stream, l, nb, nsplit, partial, sigma, G);
+    HIOPAMD_CHECK(hipGetLastError());
+    return HIOPAMD_OK;
+  }
   double* partial = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * 4 * GS_M * GS_M);
   const dim3 g(nsplit), b(kBlock);
   switch(l) {

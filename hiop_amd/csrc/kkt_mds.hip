@@ -368,9 +368,11 @@ int hiopamd_kkt_mds_solve_compressed(hiopamd_kkt_mds* k, const double* rx, const
     int id;
     ~SpanGuard() { if(id >= 0) span_end(c, id); }
   } guard{ctx, HIOPAMD_SPAN_KKT_SOLVE_RHS_MANIP};
-  // HIOPAMD_MDS_FUSED=0: the unfused sequence (A/B timing, and the fall-back when a column of Jcs / Jds holds more than 64 entries)
-  static const bool fused_env = !(std::getenv("HIOPAMD_MDS_FUSED") && std::atoi(std::getenv("HIOPAMD_MDS_FUSED")) == 0);
-  const bool fused = fused_env && k->tplan_c->max_len <= 64 && k->tplan_d->max_len <= 64;
+  // the unfused sequence below is the fall-back when a column of Jcs / Jds holds more than 64 entries
+  // ... and when Jcs is "few long rows" (hiopamd_sp_times_vec's split shape: nrows <= 256 && nnz > 64 nrows), where the fused kernel's
+  // one-wave-per-row product would neither be bitwise equal to the unfused call nor have its parallelism
+  const bool jcs_split_shape = neq <= 256 && (int64_t)s.nnz_Jcs > 64 * (int64_t)neq;
+  const bool fused = !jcs_split_shape && k->tplan_c->max_len <= 64 && k->tplan_d->max_len <= 64;
   if(fused) {
     const int64_t new_ = (nxs > nxd) ? nxs : nxd;
     const int blocks_ew = (int)((new_ + kBlock - 1) / kBlock);

@@ -960,11 +960,14 @@ constexpr int UD_LD = UD_T + 16;      // LDS row stride (doubles)
 // A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4 reg][col = l&15].
 // ------------------------------------------------------------------------------------------
 // Wave tile = (16 WI) x (16 WJ), workgroup tile = (32 WI) x (32 WJ) (2 x 2 waves).
-template <int WI, int WJ, int KTx = LD_KT>
+// KMASK (the pivoted factorisation's panels): only the first `kreal` of the K rows of U exist — the rows behind them are rows of A that
+// the same launch updates and are read as zero instead (K is padded to the stage depth; a padded row must not depend on what the V
+// buffer holds there: 0 * Inf from a not-yet-factored column would poison the whole trailing matrix).
+template <int WI, int WJ, int KTx = LD_KT, bool KMASK = false>
 __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __restrict__ A, int64_t lda, int N,
                                                                   const double* __restrict__ V, int64_t ldv, int vrow0,
                                                                   int urow0, int K, int s, int row_end, int col_end,
-                                                                  int skip_diag, double* __restrict__ Cnext)
+                                                                  int skip_diag, double* __restrict__ Cnext, int kreal = 0)
 {
   constexpr int TMx = 32 * WI, TNx = 32 * WJ;
   const int ti = blockIdx.y, tj = blockIdx.x;   // ti in units of TMx rows, tj in units of TNx columns
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
 #pragma unroll
   for(int q = 0; q < VL; ++q) vreg[q] = vr_ok ? Vp[(int64_t)(VPR * q) * ldv] : 0.0;
 #pragma unroll
-  for(int q = 0; q < UL; ++q) ureg[q] = uc_ok ? Up[(int64_t)(UPR * q) * lda] : 0.0;
+  for(int q = 0; q < UL; ++q) ureg[q] = (uc_ok && (!KMASK || UPR * q + urw < kreal)) ? Up[(int64_t)(UPR * q) * lda] : 0.0;
   for(int kt = 0; kt < K; kt += KTx) {
     __syncthreads();
 #pragma unroll
@@ -1007,7 +1010,8 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
 #pragma unroll
       for(int q = 0; q < VL; ++q) vreg[q] = vr_ok ? Vp[(int64_t)(kt + KTx + VPR * q) * ldv] : 0.0;
 #pragma unroll
-      for(int q = 0; q < UL; ++q) ureg[q] = uc_ok ? Up[(int64_t)(kt + KTx + UPR * q) * lda] : 0.0;
+      for(int q = 0; q < UL; ++q)
+        ureg[q] = (uc_ok && (!KMASK || kt + KTx + UPR * q + urw < kreal)) ? Up[(int64_t)(kt + KTx + UPR * q) * lda] : 0.0;
     }
 #pragma unroll
     for(int kk = 0; kk < KTx / 4; ++kk) {
@@ -1057,13 +1061,14 @@ __global__ __launch_bounds__(kBlock, 2) void ldlt_update_kernel_t(double* __rest
 
 // The same kernel for the pivoted factorisation (ldlt_bk.hip): A[r][c] -= sum_{k<K} V[k][r] * A[urow0+k][c] for c >= r >= s, K a
 // multiple of 8 (V = the panel W = L D, the A rows = the panel's columns of L in the column-major-lower reading of the storage)
-int ldlt_rankk_update(hiopamd_ctx* ctx, double* A, int64_t lda, int N, const double* V, int64_t ldv, int urow0, int K, int s)
+// kreal <= K: the rows of U that exist (the panel's true width); rows kreal..K-1 are read as zero (see KMASK)
+int ldlt_rankk_update(hiopamd_ctx* ctx, double* A, int64_t lda, int N, const double* V, int64_t ldv, int urow0, int K, int s, int kreal)
 {
   if(K <= 0 || s >= N) return HIOPAMD_OK;
-  if(K % 8 != 0) return HIOPAMD_ERR_ARG;
+  if(K % 8 != 0 || kreal < 0 || kreal > K) return HIOPAMD_ERR_ARG;
   const int t = (N - s + 127) / 128;
-  hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8>), dim3(2 * t, 2 * t), dim3(kBlock), 0, ctx->stream, A, lda, N, V, ldv, 0, urow0, K, s, N,
-                     N, 0, (double*)nullptr);
+  hipLaunchKernelGGL((ldlt_update_kernel_t<2, 2, 8, true>), dim3(2 * t, 2 * t), dim3(kBlock), 0, ctx->stream, A, lda, N, V, ldv, 0, urow0, K, s,
+                     N, N, 0, (double*)nullptr, kreal);
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;
 }
@@ -1983,19 +1988,10 @@ struct DfDeviceLock {
   }
 };
 
-// HIOPAMD_F16=0: the 16 x 16 sub-block factor in its v_readlane form (A/B timing aid; default: rank-1 MFMA updates)
-static bool f16_mfma()
-{
-  static const bool on = !(std::getenv("HIOPAMD_F16") && std::atoi(std::getenv("HIOPAMD_F16")) == 0);
-  return on;
-}
-// HIOPAMD_DF_SPINE: bit 0 = tile-solve publish deferred to the next spine step, bit 1 = next tiles prefetched into LDS while
-// the last sub-block is factored, bit 2 = F published under the tile solve (default 7; 0 = round-2 schedule; timing aid)
-static int df_spine_opt()
-{
-  static const int v = std::getenv("HIOPAMD_DF_SPINE") ? std::atoi(std::getenv("HIOPAMD_DF_SPINE")) : 7;
-  return v;
-}
+// latency cuts of the spine step (df_spine_step): bit 0 = tile-solve publish deferred to the next spine step, bit 1 = next tiles
+// prefetched into LDS while the last sub-block is factored, bit 2 = F published under the tile solve.  All on (each was measured on its
+// own in round 2, profiles/r02_probes; the run-time switch is gone).
+constexpr int DF_SPINE_OPT = 7;
 // optional per-launch timing of the MFMA update kernel (HIP events on the launch stream)
 struct LdltProfile {
   bool enabled = false;
@@ -2042,7 +2038,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 {
   std::vector<std::vector<int4>> by_role(DF_ROLES);
   const int cmax = has_next ? 7 : 3;
-  static const bool rsplit = !(std::getenv("HIOPAMD_DF_RSPLIT") && std::atoi(std::getenv("HIOPAMD_DF_RSPLIT")) == 0);
+  constexpr bool rsplit = true;   // the companion step split over roles 1 and 2 (the unsplit form was an A/B aid of round 2)
   auto nn_index = [](int a, int b) {   // upper-triangular tile (a, b) of the 4 x 4 next diagonal block -> 0..9
     int t = 0;
     for(int r = 0; r < a; ++r) t += 4 - r;
@@ -2051,7 +2047,7 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
   for(int p = 0; p < 4; ++p) {
     // the spine: S(p) = F(p) -> T(p, p+1) -> U(p; p+1, p+1) fused in one task, data carried in LDS (z = 1: with the T / U part);
     // its companion: R(p) = T(p, p+2) -> U(p; p+1, p+2) -> U(p; p+2, p+2)
-    // (HIOPAMD_DF_RSPLIT != 0, the default: U(p; p+2, p+2) is a task of role 2 instead — R(p) z = 1 — so that the two updates
+    // (U(p; p+2, p+2) is a task of role 2 instead — R(p) z = 1 — so that the two updates
     //  the next spine step waits for run side by side; as one task they were 20 us in a row against the spine's 20 us period)
     by_role[0].push_back(make_int4(DF_S, p, (p + 1 <= cmax) ? 1 : 0, 0));
     if(p + 2 <= cmax) {
@@ -2100,34 +2096,17 @@ static void df_chain_tasks(bool has_next, std::vector<int4>& out)
 
 struct DfPlan {
   int N = 0, nsp = 0, nt = 0, nchain = 0, last_has_next = 0, nwide = 0;
-  int form = 4;            // the wide kernel's form for this order (df_form)
-  bool has_far = false;    // a FAR update list exists (HIOPAMD_DF_SPLIT=1)
+  bool has_far = false;    // a FAR update list exists (never in the shipped plan: one update list per super-panel)
   int64_t off_chain = 0, off_tr = 0, off_ver = 0, off_trb = 0, off_cu = 0, off_wg = 0, off_snap = 0, off_where = 0, off_shadow = 0, off_run = 0, nflags = 0;
   std::vector<int4> ctasks, wtasks;
   std::vector<unsigned> upcnt, wfirst;
   std::vector<int4> wq, wf;
   double up_flops = 0.0;   // algorithmic flops of the UP tasks (2 K per updated element)
 };
-// Which form of the wide kernel factorises order N (HIOPAMD_DF_FORM; the task lists are the same for both):
-//   4  (default) the four-wave kernel (ldlt_wide_kernel), ONE workgroup per CU of the wide stream: 73.7 KB of LDS and 256 registers
-//      per lane, so a CU could hold two of them — the only configuration that never froze in a soak (every
-//      configuration that fills its CUs exactly — two four-wave workgroups per CU, one eight-wave workgroup with 147 KB of LDS —
-//      froze once per 5 000 - 16 000 factorisations).  HIOPAMD_DF_WGS=480 puts two on a CU (timing aid; never the default);
-//   8  eight waves, one workgroup per CU, operands by LDS-DMA, selection ahead (ldlt_wide8_kernel): measured at the same tile-loop
-//      pace, slower overall and not free of the freeze; kept for A/B.  Needs the 16-byte tile accesses (even N).
-// The one-dispatch form of the counter passes (HIOPAMD_DF_ONE=1) is form 4.
-static int df_form(int N)
-{
-  static const int form_env = std::getenv("HIOPAMD_DF_FORM") ? std::atoi(std::getenv("HIOPAMD_DF_FORM")) : 4;
-  static const bool one_env = std::getenv("HIOPAMD_DF_ONE") && std::atoi(std::getenv("HIOPAMD_DF_ONE")) != 0;
-  if(one_env || (N % 2) != 0 || N < 2 * UD_T) return 4;
-  return form_env == 8 ? 8 : 4;
-}
 static DfPlan df_build_plan(int N)
 {
   DfPlan P;
   P.N = N;
-  P.form = df_form(N);
   P.nsp = (N + LD_NB - 1) / LD_NB;
   P.nt = (N + UD_T - 1) / UD_T;
   const int nfull = N / LD_NB;
@@ -2166,12 +2145,11 @@ static DfPlan df_build_plan(int N)
   std::vector<int4> trq, nearq, farq;
   std::vector<int4> wq((size_t)P.nwide + 1, make_int4(0, 0, 0, 0)), wf((size_t)P.nwide + 1, make_int4(0, 0, -1, 0));
   P.wfirst.assign((size_t)P.nwide + 1, 0u);
-  // HIOPAMD_DF_UPH=0: the head tiles as ordinary update tasks (A/B timing aid)
-  static const bool uph = !(std::getenv("HIOPAMD_DF_UPH") && std::atoi(std::getenv("HIOPAMD_DF_UPH")) == 0);
-  // HIOPAMD_DF_SPLIT=1: separate NEAR / FAR update lists, NEAR served first (built and measured in round 3: 5.27-5.47 ms against
-  // 5.17-5.30 with the single list per super-panel — the near tiles do jump the queue, but the far tiles they depend on through
-  // `ver` then run later and the chain waits for those instead).  Default: one list per super-panel, everything NEAR, round 2's order.
-  static const bool split = std::getenv("HIOPAMD_DF_SPLIT") && std::atoi(std::getenv("HIOPAMD_DF_SPLIT")) != 0;
+  constexpr bool uph = true;     // head tiles gated per block row (DF_UPH)
+  // One update list per super-panel, everything NEAR (round 2's order).  Separate NEAR / FAR lists with NEAR served first were built and
+  // measured in round 3 (5.27-5.47 ms against 5.17-5.30: the near tiles do jump the queue, but the far tiles they depend on through `ver`
+  // then run later and the chain waits for those instead); the kernels still understand FAR lists, the plan never makes one.
+  constexpr bool split = false;
   auto emit_tile = [&](std::vector<int4>& q, int kind, int j, int I, int J) {
     q.push_back(make_int4(kind, j, I, J));
     P.upcnt[j] += 1u;
@@ -2188,10 +2166,10 @@ static DfPlan df_build_plan(int N)
   };
   // K = 512 (DF_UP2): super-panels e (even) and e + 1 are applied together to the tile rows behind super-panel e + 2
   // (I >= 2 e + 6) by FAR tasks of queue e + 1; queue e keeps the rows of super-panels e + 1 and e + 2 (what the next two chains
-  // and substitution rounds wait for).  HIOPAMD_DF_K512 = number of leading super-panels that may be paired (0: off); default: the
-  // update-bound first half (measured at N = 8192: 5.32-5.36 ms unpaired, 5.19-5.27 with 16 of 31, 5.38 with 24 — in the
-  // chain-bound second half a fused task only adds latency).
-  const int k512 = std::getenv("HIOPAMD_DF_K512") ? std::atoi(std::getenv("HIOPAMD_DF_K512")) : (P.nwide + 1) / 2;
+  // and substitution rounds wait for).  k512 = number of leading super-panels that may be paired: the update-bound first half
+  // (measured at N = 8192: 5.32-5.36 ms unpaired, 5.19-5.27 with 16 of 31, 5.38 with 24 — in the chain-bound second half a fused
+  // task only adds latency).
+  const int k512 = (P.nwide + 1) / 2;
   auto paired_first = [&](int j) { return (j % 2 == 0) && j + 1 < P.nwide && j + 1 < k512; };
   std::vector<int> near_first((size_t)P.nwide + 1, 0), near_cnt((size_t)P.nwide + 1, 0), far_first((size_t)P.nwide + 1, 0),
       far_cnt((size_t)P.nwide + 1, 0), near_maxrow((size_t)P.nwide + 1, -1);
@@ -2252,13 +2230,11 @@ static DfPlan df_build_plan(int N)
   return P;
 }
 
-// row-panel workspaces for order n: DF_NVB_MIN = 4 (three + one for the fused update tasks, which hold a buffer one super-panel
-// longer).  HIOPAMD_DF_NVB raises it up to one per super-panel (measured in round 3: 32 buffers instead of 4 at N = 8192 change
-// nothing, 5.30 vs 5.35 ms: the buffers are not what the chain waits for once there are four).
+// row-panel workspaces for order n: at least DF_NVB_MIN = 4 (three + one for the fused update tasks, which hold a buffer one super-panel
+// longer)
 static int df_nvb_for(int n)
 {
   const int nsp = (n + LD_NB - 1) / LD_NB;
-  if(const char* e = std::getenv("HIOPAMD_DF_NVB")) return std::max(DF_NVB_MIN, std::min(std::atoi(e), std::max(nsp, DF_NVB_MIN)));
   // One workspace per super-panel while that costs at most 2 GB (N <= 16384): no buffer is ever reused, so nothing — neither the chain
   // kernel nor the idle workgroups of the wide kernel — polls the "updates of super-panel j - nvb complete" counters, which ~1500 tasks
   // increment (polling a word that is being incremented from everywhere is what delayed flag updates).
@@ -2282,9 +2258,6 @@ struct DfDevice {
   // (no successful dataflow factorisation in between) switch the object to the stepwise kernels for good
   bool skip_once = false;
   int strikes = 0;
-  // workgroups of the four-wave wide kernel (0: one per CU of the wide stream, the default of both forms since round 4: in round 3's soaks
-  // every freeze happened with two 73.7 KB workgroups sharing a CU, none in 41 600 factorisations with one, scripts/r03_gpu_53.sh)
-  int wide_wgs = 0;
 };
 
 struct hiopamd_linsolver {
@@ -2414,12 +2387,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   auto superdiag = [&](int jp, hipStream_t stream) {
     const Panel p = panel(jp);
     // the kernel works on the compact copy of its block: matrix pointer = Cj, ld = 256, origin 0
-    if(f16_mfma())
-      hipLaunchKernelGGL(ldlt_superdiag_kernel<true>, dim3(1), dim3(kBlock), 0, stream, p.Cj, (int64_t)LD_NB, 0, p.kbs, p.Vb, ldv,
-                         dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, (long long*)nullptr);
-    else
-      hipLaunchKernelGGL(ldlt_superdiag_kernel<false>, dim3(1), dim3(kBlock), 0, stream, p.Cj, (int64_t)LD_NB, 0, p.kbs, p.Vb, ldv,
-                         dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, (long long*)nullptr);
+    hipLaunchKernelGGL(ldlt_superdiag_kernel<true>, dim3(1), dim3(kBlock), 0, stream, p.Cj, (int64_t)LD_NB, 0, p.kbs, p.Vb, ldv,
+                       dinv + p.K0, p.Dk_sp, p.Li_sp, d_info, (long long*)nullptr);
   };
   auto trsm = [&](int jp, hipStream_t stream, int col_ofs, int ncols) {
     if(ncols <= 0) return;
@@ -2468,12 +2437,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     int rc = dep(st, su);
     if(rc == HIOPAMD_OK) rc = dep(st, sd);
     if(rc != HIOPAMD_OK) return rc;
-    a.spine_opt = df_spine_opt();
-    a.pipe = 0;
-    a.jpipe = 0;
+    a.spine_opt = DF_SPINE_OPT;
     a.has_far = P.has_far ? 1 : 0;
-    a.sel_lead = 9;
-    a.exp = std::getenv("HIOPAMD_DF_EXP") ? std::atoi(std::getenv("HIOPAMD_DF_EXP")) : 0;
     a.dbg = std::getenv("HIOPAMD_DF_STAMPS") ? std::max(1, std::atoi(std::getenv("HIOPAMD_DF_STAMPS"))) : 0;   // profiling aid (1: all panels; 2 + j: phase sums of super-panel j only): per-super-panel time stamps, printed after the call
     a.off_ts = P.off_ver + (int64_t)P.nt * P.nt;
     a.off_ph = a.off_ts + 8 * (int64_t)(P.nsp + 1);
@@ -2492,15 +2457,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.off_run = df_check ? P.off_run : 0;
     static const bool df_debug_sh = std::getenv("HIOPAMD_DF_DEBUG") && std::atoi(std::getenv("HIOPAMD_DF_DEBUG")) != 0;
     a.off_shadow = df_debug_sh ? P.off_shadow : 0;
-    // In the chain-bound second half the wide kernel's tasks are latency (substitution, head tiles): a workgroup alone on its CU runs
-    // them 1.6x faster than next to a partner, and idle partners poll the same flag words the chain hands over through — measured at
-    // N = 8192 (scripts/r03_gpu_24.sh): 94 us per super-panel with 240 workgroups against 117 with 480, while the update-bound first
-    // half needs the 480 (3.63 ms against 3.90).  So every workgroup that is not the first on its CU leaves when its queue pointers
-    // reach super-panel jretire (default: where the K = 512 pairing ends; HIOPAMD_DF_RETIRE=<j>, a value >= nsp keeps all).
-    {
-      static const int retire_env = std::getenv("HIOPAMD_DF_RETIRE") ? std::atoi(std::getenv("HIOPAMD_DF_RETIRE")) : -1;
-      a.jretire = retire_env >= 0 ? retire_env : (P.nwide + 1) / 2;
-    }
+    // ONE workgroup of the wide kernel per CU: nobody "retires" (rounds 2-3 ran two per CU and let the second ones leave in the chain-bound
+    // half; that shape froze once per ~1.6e4 factorisations and is gone)
+    a.jretire = P.nwide;
     // HIOPAMD_DF_ONE=1 (measurement aid): chain + wide as ONE dispatch on the wide stream, one workgroup per CU — the form the
     // rocprofv3 counter passes can profile (see ldlt_df_one_kernel); needs the 16-byte tile form
     static const bool df_one = std::getenv("HIOPAMD_DF_ONE") && std::atoi(std::getenv("HIOPAMD_DF_ONE")) != 0;
@@ -2519,33 +2478,15 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
     if(a.nwtasks > 0) {
       if(timed) (void)hipEventRecord(prof->get(), su);
-      // ONE workgroup of the wide kernel per CU of the wide stream (ctx->wide_cus, 240 on MI355X with two reserved CUs per XCD).
-      // HIOPAMD_DF_WGS: timing aid — with the four-wave form a value above the number of CUs puts two workgroups on a CU, the faster
-      // and, once in ~1.6e4 factorisations, freezing shape of rounds 2-3; never the default.
-      static const int wgs_env = std::getenv("HIOPAMD_DF_WGS") ? std::atoi(std::getenv("HIOPAMD_DF_WGS")) : 0;
-      if(P.form != 4) {
-        const int wmax = wgs_env > 0 ? std::min(wgs_env, ctx->wide_cus) : ctx->wide_cus;
-        const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
-        a.jretire = P.nwide;   // (nobody retires: there is no second workgroup on a CU)
-        static const int pipe_env = std::getenv("HIOPAMD_DF_PIPE") ? std::atoi(std::getenv("HIOPAMD_DF_PIPE")) : 3;
-        static const int pipej_env = std::getenv("HIOPAMD_DF_PIPEJ") ? std::atoi(std::getenv("HIOPAMD_DF_PIPEJ")) : -1;
-        a.pipe = pipe_env;
-        a.jpipe = pipej_env >= 0 ? pipej_env : (P.nwide + 1) / 2;
-        static const int lead_env = std::getenv("HIOPAMD_DF_SELLEAD") ? std::atoi(std::getenv("HIOPAMD_DF_SELLEAD")) : 9;
-        a.sel_lead = std::max(6, std::min(lead_env, 15));
-        if(a.dbg) hipLaunchKernelGGL((ldlt_wide8_kernel<true>), dim3(grid), dim3(W8_THREADS), 0, su, a);
-        else hipLaunchKernelGGL((ldlt_wide8_kernel<false>), dim3(grid), dim3(W8_THREADS), 0, su, a);
-      } else {
-      const int wmax = wgs_env > 0 ? std::min(wgs_env, ctx->wide_cus * DF_WIDE_WG_PER_CU) : (df->wide_wgs > 0 ? df->wide_wgs : ctx->wide_cus);
-      if(wmax <= ctx->wide_cus) a.jretire = P.nwide;
+      // ONE workgroup of the wide kernel per CU of the wide stream (ctx->wide_cus, 240 on MI355X with two reserved CUs per XCD): 73.7 KB of
+      // LDS and one wave per SIMD, i.e. every CU could take a second one — the only shape that never froze in a soak
+      const int wmax = ctx->wide_cus;
       const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
-      // 16-byte accesses need even N, lda, ldv (ldv = N); HIOPAMD_DF_TILE=1 forces the 8-byte form (A/B timing)
-      static const int tile_env = std::getenv("HIOPAMD_DF_TILE") ? std::atoi(std::getenv("HIOPAMD_DF_TILE")) : 2;
-      const bool form2 = tile_env != 1 && (N % 2 == 0) && (lda % 2 == 0) && (ldv % 2 == 0) && N >= 2 * UD_T;
+      // 16-byte accesses need even N, lda, ldv (ldv = N); otherwise the 8-byte tile form
+      const bool form2 = (N % 2 == 0) && (lda % 2 == 0) && (ldv % 2 == 0) && N >= 2 * UD_T;
       if(form2 && a.dbg) hipLaunchKernelGGL((ldlt_wide_kernel<2, true>), dim3(grid), dim3(kBlock), 0, su, a);
       else if(form2) hipLaunchKernelGGL((ldlt_wide_kernel<2, false>), dim3(grid), dim3(kBlock), 0, su, a);
       else hipLaunchKernelGGL((ldlt_wide_kernel<1, false>), dim3(grid), dim3(kBlock), 0, su, a);
-      }
       if(timed) {
         (void)hipEventRecord(prof->get(), su);
         prof->flops += P.up_flops;
@@ -3080,14 +3021,13 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
   HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
   {
     // dataflow solve: inverted diagonal blocks, product slots, flags, and the task list in issue order
-    // block size of the task graph: 512 for orders that are multiples of 512 (HIOPAMD_SOLVE_B=256 forces 256: A/B timing)
-    static const int b_env = std::getenv("HIOPAMD_SOLVE_B") ? std::atoi(std::getenv("HIOPAMD_SOLVE_B")) : 512;
-    const int FB = (b_env == 512 && n >= 2048 && n % 512 == 0) ? 512 : SV_B;
+    // block size of the task graph: 512 for orders that are multiples of 512 (half the serial block steps), 256 otherwise
+    const int FB = (n >= 2048 && n % 512 == 0) ? 512 : SV_B;
     const int FR = FB / 64;
     const int nb = (int)((nn + FB - 1) / FB);
     ls->fl_B = FB;
     ls->fl_nb = nb;
-    ls->fl_lead = std::getenv("HIOPAMD_SOLVE_LEAD") ? std::atoi(std::getenv("HIOPAMD_SOLVE_LEAD")) : (FB == 512 ? 2 : FL_LEAD);
+    ls->fl_lead = (FB == 512 ? 2 : FL_LEAD);
     HIOPAMD_CHECK(hipMalloc((void**)&ls->W, sizeof(double) * (size_t)FB * FB * nb));
     if(FB == 512) {
       HIOPAMD_CHECK(hipMemsetAsync(ls->W, 0, sizeof(double) * (size_t)FB * FB * nb, ctx->stream));   // the lower-left quadrants stay zero
@@ -3596,7 +3536,6 @@ int hiopamd_ldlt_dataflow_queues(int n, int* queues_host, int cap_panels)
 }
 
 int hiopamd_ldlt_dataflow_nvb(int n) { return df_nvb_for(n); }
-int hiopamd_ldlt_dataflow_form(int n) { return df_form(n); }
 
 int hiopamd_ldlt_dataflow_far_queues(int n, int* far_host, int cap_panels)
 {

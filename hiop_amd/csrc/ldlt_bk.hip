@@ -35,7 +35,7 @@
 
 namespace hiopamd {
 
-int ldlt_rankk_update(hiopamd_ctx* ctx, double* A, int64_t lda, int N, const double* V, int64_t ldv, int urow0, int K, int s);   // ldlt.hip
+int ldlt_rankk_update(hiopamd_ctx* ctx, double* A, int64_t lda, int N, const double* V, int64_t ldv, int urow0, int K, int s, int kreal);   // ldlt.hip
 
 constexpr int BK_NB = 64;                  // panel width (columns of W)
 constexpr int BK_RPT = 4;                  // rows per thread of the column kernels
@@ -465,7 +465,7 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
     const int kpad = ((kb + 7) / 8) * 8;   // the update kernel walks K in steps of 8: the rows of W past kb are zero
     if(kpad > kb) HIOPAMD_CHECK(hipMemsetAsync(B->Wb + (int64_t)kb * ldw, 0, sizeof(double) * (size_t)(kpad - kb) * ldw, s));
     // A22 -= L21 D L21^T = L21 W21^T:   a(c, r) -= sum_p a(c, k0 + p) W(r, p),  c >= r >= kend
-    const int rc = ldlt_rankk_update(ctx, A, lda, n, B->Wb, ldw, k0, kpad, kend);
+    const int rc = ldlt_rankk_update(ctx, A, lda, n, B->Wb, ldw, k0, kpad, kend, kb);   // (U rows kb..kpad-1 are masked: they alias columns this launch updates)
     if(rc != HIOPAMD_OK) return rc;
     k0 = kend;
   }

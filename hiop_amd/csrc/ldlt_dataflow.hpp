@@ -88,11 +88,7 @@ struct DfArgs {
   int64_t off_where;       // 2 words per workgroup of the wide kernel: (XCC, SE, CU) it ran on when it took its current task / when it published it
   int64_t off_snap;        // 1024 words: copy of the state words taken by the waiter whose wait expired, at that moment
   int64_t off_wg;          // 2 words per workgroup of the wide kernel: what it holds right now (see df_wg_state) — read by the host after a time-out
-  int pipe;                // eight-wave wide kernel: bit 0 = the next task is selected during the last stages of an update tile, bit 1 = its first loads are issued before the current tile's stores are drained (ldlt_wide8.hpp)
-  int jpipe;               // ... for the update tiles of queues j < jpipe (the update-bound part of the factorisation)
   int has_far;             // some super-panel has a FAR update list (HIOPAMD_DF_SPLIT=1)
-  int sel_lead;            // stages before the end of a tile at which the selection ahead starts (>= 6)
-  int exp;                 // HIOPAMD_DF_EXP: timing experiments of the profiling instantiation (ldlt_wide8.hpp)
 };
 
 #ifndef HIOPAMD_DF_FLAG_SCOPE
@@ -1405,8 +1401,6 @@ __global__ __launch_bounds__(kBlock, DF_WIDE_WG_PER_CU) void ldlt_wide_kernel(co
   __shared__ int4 sh_task;
 #include "ldlt_wide_body.inc"
 }
-
-#include "ldlt_wide8.hpp"
 
 // Both roles in ONE dispatch (HIOPAMD_DF_ONE=1; measurement aid): workgroups 0 .. DF_ROLES-1 run the chain, the others the
 // wide task loop.  Every workgroup carries the chain's LDS (one workgroup per CU), so the wide part runs with ONE workgroup

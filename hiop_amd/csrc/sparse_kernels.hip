@@ -294,15 +294,17 @@ __global__ __launch_bounds__(kBlock) void spsym_diag_to_vec(int nnz, const int* 
                                                             int num_elems)
 {
   // The triplets are ordered by (row, column) (hiopMatrixSparseTriplet::checkIndexesAreOrdered), so repeated entries of one (i, j)
-  // are neighbours: the FIRST entry of such a run owns the destination and adds the run in storage order — no atomics, one fixed
-  // order of additions (a sym-sparse matrix normally holds one entry per (i, j): the run has length 1).
+  // are neighbours: the FIRST entry of such a run sums the run in storage order in a register and adds it to the destination with ONE
+  // atomic add — with ordered triplets that is the only add the destination receives (one fixed order of additions: bitwise
+  // reproducible; a sym-sparse matrix normally holds one entry per (i, j): the run has length 1); with unordered input that repeats an
+  // (i, j) in non-adjacent places every run still arrives (only the order of those few adds is then not fixed).
   for(int k = blockIdx.x * kBlock + threadIdx.x; k < nnz; k += gridDim.x * kBlock) {
     const int r = iRow[k];
     if(r == jCol[k] && r >= diag_src_start && r < diag_src_start + num_elems) {
       if(k > 0 && iRow[k - 1] == r && jCol[k - 1] == r) continue;   // not the first of its run
-      double acc = y[vec_start + r];
-      for(int q = k; q < nnz && iRow[q] == r && jCol[q] == r; ++q) acc += alpha * val[q];
-      y[vec_start + r] = acc;
+      double acc = alpha * val[k];
+      for(int q = k + 1; q < nnz && iRow[q] == r && jCol[q] == r; ++q) acc += alpha * val[q];
+      atomicAdd(&y[vec_start + r], acc);
     }
   }
 }
@@ -316,10 +318,9 @@ __global__ __launch_bounds__(kBlock) void spsym_add_upper(int nnz, const int* __
     const int r = iRow[k], c = jCol[k];
     if(r <= c) {
       if(k > 0 && iRow[k - 1] == r && jCol[k - 1] == c) continue;
-      double* w = &W[(int64_t)(diag_start + r) * ldw + (diag_start + c)];
-      double acc = *w;
-      for(int q = k; q < nnz && iRow[q] == r && jCol[q] == c; ++q) acc += alpha * val[q];
-      *w = acc;
+      double acc = alpha * val[k];
+      for(int q = k + 1; q < nnz && iRow[q] == r && jCol[q] == c; ++q) acc += alpha * val[q];
+      atomicAdd(&W[(int64_t)(diag_start + r) * ldw + (diag_start + c)], acc);
     }
   }
 }

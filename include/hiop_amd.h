@@ -537,9 +537,6 @@ int hiopamd_linsolver_set_retry_copy(hiopamd_linsolver* ls, int enable);
 int hiopamd_linsolver_timeouts(const hiopamd_linsolver* ls, int64_t* count_host);
 /* static schedule of the dataflow factorisation for order n (host only): see csrc/ldlt.hip */
 int hiopamd_ldlt_dataflow_plan(int n, int* dims8_host, int* chain_tasks_host, int* wide_tasks_host, int64_t wide_cap);
-/* which form of the wide kernel factorises order n: 4 = four waves, one workgroup per CU (the default), 8 = eight waves with LDS-DMA
- * operand staging and selection ahead (HIOPAMD_DF_FORM=8; csrc/ldlt_wide8.hpp) */
-int hiopamd_ldlt_dataflow_form(int n);
 /* the wide kernel's task queues for order n (host only): per super-panel {first TR task, TR tasks, first NEAR update task,
  * NEAR update tasks, NEAR tasks of the first two tile rows} as indices into the wide task list of hiopamd_ldlt_dataflow_plan;
  * _far_queues: per super-panel {first FAR update task, FAR tasks, the super-panel whose FAR list feeds this NEAR list (-1: none),

@@ -108,37 +108,3 @@ def test_every_task_of_the_wide_kernel_is_handed_out_and_completed_exactly_once(
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "CHECKED" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "HIOPAMD_DF_CHECK" not in r.stderr, r.stderr[-4000:]
-
-
-FORM8_CHILD = textwrap.dedent('''
-    import sys
-    import torch
-    sys.path.insert(0, ".")
-    from hiop_amd.runtime import Context
-    from hiop_amd.kkt import LinSolverSymDense
-    from hiop_amd._lib import lib
-    ctx = Context(0)
-    g = torch.Generator(device="cuda"); g.manual_seed(11)
-    for N in (8192, 2304, 1026):
-        assert lib().hiopamd_ldlt_dataflow_form(N) == 8
-        M = torch.rand(N, N, generator=g, device="cuda", dtype=torch.float64) * 1e-3
-        M = M + M.T + torch.diag(torch.cat([torch.full((N // 2,), 10.0), torch.full((N - N // 2,), -10.0)]).to("cuda").double())
-        b = torch.rand(N, generator=g, device="cuda", dtype=torch.float64)
-        ls = LinSolverSymDense(ctx, N)
-        for rep in range(3):
-            ls.set_sys_matrix(M); ctx.sync()
-            assert ls.matrix_changed() == N - N // 2
-            x = b.clone(); ls.solve(x); ctx.sync()
-            assert float((M @ x - b).abs().max() / b.abs().max()) < 1e-12
-    print("FORM8 ok")
-''')
-
-
-def test_eight_wave_form_of_the_wide_kernel_factorises_correctly(ctx):
-    """HIOPAMD_DF_FORM=8 (csrc/ldlt_wide8.hpp: eight waves, one workgroup per CU, operands by LDS-DMA, selection ahead, hand-out
-    check on) — not the default (it fills the CU and is not free of the freeze, profiles/r04_probes), kept measurable and correct."""
-    env = dict(os.environ, HIOPAMD_DF_FORM="8", HIOPAMD_DF_CHECK="1")
-    r = subprocess.run([sys.executable, "-c", FORM8_CHILD], capture_output=True, text=True, env=env, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "FORM8 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "HIOPAMD_DF_CHECK" not in r.stderr, r.stderr[-4000:]

@@ -53,6 +53,8 @@ def drive(ctx, n, me, mi, l_max, nupd, strategy, seed=0):
     (5001, 2, 2, 6, 10, "sty"),           # odd n (unaligned double2 path), Dense Ex2 shape (m=4)
     (20000, 60, 40, 4, 7, "sty_inv"),
     (777, 0, 3, 2, 6, "sty_srnm_ynrm"),
+    (4000, 2, 3, 12, 16, "sty"),          # secant memory beyond 8 pairs (blocked form of the four l x l Gram blocks), growing then shifting
+    (1500, 1, 1, 20, 14, "sigma0"),       # ... still growing at 13 pairs
 ])
 def test_hessian_lowrank_against_oracle(ctx, n, me, mi, l_max, nupd, strategy):
     Ho, Hg, (Jc, Jd), r, stored = drive(ctx, n, me, mi, l_max, nupd, strategy, seed=n)
