@@ -484,7 +484,7 @@ def main():
     achieved = (flops_per_launch / (ms_per_launch * 1e-3)) / 1e12 if ms_per_launch > 0 else 0.0
     # HBM-side traffic of that kernel per launch: PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc
     # passes with --kernel-trace only) of the SAME task graph run as one dispatch (HIOPAMD_DF_ONE=1: rocprofv3 serialises
-    # dispatches, and the production form is a pair of kernels that wait for each other) — scripts/r03_gpu_1.sh, committed
+    # dispatches, and the production form is a pair of kernels that wait for each other) — scripts/calls/r03_gpu_1.sh, committed
     # summary profiles/r03_pmc/summary.json.  Algorithmic bytes of the same launch: every trailing tile read + written once
     # per super-panel, the two operand row panels read once, the row-panel substitution (read A, write V and U).
     traffic, traffic_src, alg_bytes = None, "n/a (no committed PMC summary found)", None

@@ -97,7 +97,10 @@ inline bool ctx_cu_split(hiopamd_ctx* ctx)
   int dev = 0;
   if(hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
   const int ncu = prop.multiProcessorCount;
-  if(ncu != 256) return false;   // the mapping above was verified for the 8 x 32 CU layout only
+  if(ncu != 256) {   // the mapping above was verified for the 8 x 32 CU layout only
+    std::fprintf(stderr, "[hiop_amd] device reports %d CUs (not 256): no CU-masked streams, the LDL^T runs its stepwise kernels instead of the dataflow pair\n", ncu);
+    return false;
+  }
   // HIOPAMD_SD_CUS = reserved CUs per XCD for the chain stream (default 2; bits 0..8k-1 of the mask = CUs 0..k-1 of every XCD).
   // Measured at N = 8192: 1 -> 9.53 ms per step, 2 -> 9.38 (the head substitution's 16 four-wave workgroups and the 10 tiles of
   // the diagonal-block update get a CU each), 3 -> 9.42; the update's time does not move with 8 or 16 CUs fewer.

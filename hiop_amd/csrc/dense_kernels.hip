@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
 
 // (Folding in the LAST stage-1 workgroup of a row tile to arrive -- one launch instead of two -- was measured in round 4 and is slower:
 // with a release fence per workgroup 0.54 ms instead of 0.33 at 200 x 1.25e6 (every fence walks the L2), with agent-scope relaxed atomics
-// for partials and counter 0.343 against 0.333, the dense step 5.69 against 5.60 ms; scripts/r04_gpu_18.sh.)
+// for partials and counter 0.343 against 0.333, the dense step 5.69 against 5.60 ms; scripts/calls/r04_gpu_18.sh.)
 __global__ __launch_bounds__(kBlock) void gemv_n_stage2(int m, int nchunks, const double* __restrict__ part,
                                                         double beta, double* __restrict__ y, double alpha)
 {
@@ -544,7 +544,7 @@ int hiopamd_mat_trans_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double
   if(m < 0 || n < 0) return HIOPAMD_ERR_ARG;
   if(n == 0) return HIOPAMD_OK;
   if(m == 0) return hiopamd_vec_scale(ctx, n, y, beta);
-  constexpr int cp = 1;   // column pairs per thread (two: 0.41 vs 0.36 ms at k = 200, n = 1.25e6 -- scripts/r04_gpu_13.sh)
+  constexpr int cp = 1;   // column pairs per thread (two: 0.41 vs 0.36 ms at k = 200, n = 1.25e6 -- scripts/calls/r04_gpu_13.sh)
   const int gx = (int)((n + 2 * kBlock * cp - 1) / (2 * kBlock * cp));
   // split rows so that the launch has >= ~1024 workgroups when the matrix is not tall-skinny
   int nsplit = 1;

@@ -110,7 +110,7 @@ struct MdsSolver {
   // ([equalities; inequalities] in the solver's order), decided at the user's starting point (hiopNlpFormulation.cpp:671-714)
   bool scaled = false;
   double s_f = 1.0;
-  bool solved_once = false;   // hiop_*_solve_problem ran (a second call is refused)
+  bool solved_once = false;   // hiop_*_solve_problem ran: the next call starts over from the user's data (resolve_from_scratch)
   DevBuf<double> d_scal;   // neq + nineq
   double scaling_min_grad = 1e-8;
   DevBuf<int> d_eq_map, d_ineq_map, d_jc_src, d_jd_src, d_Jcs_i, d_Jcs_j, d_Jds_i, d_Jds_j, d_Hss_i, d_Hss_j;
@@ -921,6 +921,26 @@ int MdsSolver::run()
 MdsSolver* solver_of(const cHiopMDSProblem* p) { return p ? static_cast<MdsSolver*>(p->refcppHiop) : nullptr; }
 MdsSolver* solver_of(const cHiopDenseProblem* p) { return p ? static_cast<MdsSolver*>(p->refcppHiop) : nullptr; }
 
+// A second hiop_*_solve_problem on one problem object.  The reference builds a fresh hiopAlgFilterIPM* per call (chiopInterface.cpp:79-87,
+// :141-150) whose run() re-initialises from the user's data (starting point, bounds), so a binding may solve twice and gets the same
+// answer twice.  The solver state here scales its bounds and right-hand sides in place and moves them with the slacks; instead of
+// keeping pristine copies of every such array the state is dropped and rebuilt from the callbacks: what survives is what the caller set
+// between create and solve (options, callback memory space, secant memory), exactly what survives in the reference's nlp object.
+MdsSolver* resolve_from_scratch(MdsSolver* old)
+{
+  MdsSolver* s = new(std::nothrow) MdsSolver();
+  if(!s) return nullptr;
+  s->prob = old->prob;
+  s->dprob = old->dprob;
+  s->o = old->o;
+  s->dev_cb = old->dev_cb;
+  s->secant_memory_len = old->secant_memory_len;
+  s->sigma0 = old->sigma0;
+  s->scaling_min_grad = old->scaling_min_grad;
+  delete old;   // (device memory of the first solve goes back before the second allocates)
+  return s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -943,12 +963,10 @@ int hiop_mds_solve_problem(cHiopMDSProblem* problem)
 {
   MdsSolver* s = solver_of(problem);
   if(!s) return HIOPAMD_ERR_ARG;
-  // One solve per problem object.  The reference re-runs finalizeInitialization on every run() and so starts a second solve from the
-  // user's data; this object has by then scaled its bounds and right-hand sides in place and moved them with the slacks: a second
-  // solve is refused instead of being computed from that state — destroy the problem and create it again.
-  if(s->solved_once) {
-    std::fprintf(stderr, "hiop_amd: this problem object was already solved; destroy it and create a new one to solve again\n");
-    return HIOPAMD_ERR_STATE;
+  if(s->solved_once) {   // solve again: from the user's data, like the reference (see resolve_from_scratch)
+    s = resolve_from_scratch(s);
+    problem->refcppHiop = s;
+    if(!s) return HIOPAMD_ERR_HIP;
   }
   s->solved_once = true;
   if(!s->full) {
@@ -989,12 +1007,10 @@ int hiop_dense_solve_problem(cHiopDenseProblem* problem)
 {
   MdsSolver* s = solver_of(problem);
   if(!s) return HIOPAMD_ERR_ARG;
-  // One solve per problem object.  The reference re-runs finalizeInitialization on every run() and so starts a second solve from the
-  // user's data; this object has by then scaled its bounds and right-hand sides in place and moved them with the slacks: a second
-  // solve is refused instead of being computed from that state — destroy the problem and create it again.
-  if(s->solved_once) {
-    std::fprintf(stderr, "hiop_amd: this problem object was already solved; destroy it and create a new one to solve again\n");
-    return HIOPAMD_ERR_STATE;
+  if(s->solved_once) {   // solve again: from the user's data, like the reference (see resolve_from_scratch)
+    s = resolve_from_scratch(s);
+    problem->refcppHiop = s;
+    if(!s) return HIOPAMD_ERR_HIP;
   }
   s->solved_once = true;
   if(!s->full) {

@@ -110,6 +110,7 @@ struct hiopamd_kkt_xycyd {
   double* dvec[4] = {nullptr, nullptr, nullptr, nullptr};   // delta_wx [nx], delta_wd [nd], delta_cc [nyc], delta_cd [nyd]
   uint64_t reg_seed = 0x9E3779B97F4A7C15ull, reg_draw = 0;
   int n_required_neg = 0;
+  int bicg_ref_exit = 1;   // BiCGStab 'tol is too small' exit: 1 = the reference's (closing comparison against the overwritten right-hand side, hiopKrylovSolver.cpp:563,641), 0 = against the original one
   int num_refact = 0;
   int acceptor = 0;   // 0: hiopFactAcceptorIC, 1: hiopFactAcceptorInertiaFreeDWD
   bool is_xd() const { return kind == KIND_DENSE_XDYCYD || kind == KIND_SPARSE_CONDENSED; }
@@ -800,6 +801,13 @@ int hiopamd_kkt_xycyd_set_required_neg_eig(hiopamd_kkt_xycyd* h, int n_required)
   return HIOPAMD_OK;
 }
 
+int hiopamd_kkt_xycyd_set_bicgstab_exit_mode(hiopamd_kkt_xycyd* h, int reference)
+{
+  if(!h) return HIOPAMD_ERR_ARG;
+  h->bicg_ref_exit = reference != 0;
+  return HIOPAMD_OK;
+}
+
 int hiopamd_kkt_xycyd_update(hiopamd_kkt_xycyd* h, const double* iter, int* ok_host)
 {
   if(!h || !iter || !ok_host) return HIOPAMD_ERR_ARG;
@@ -962,6 +970,10 @@ int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double
   RC(hiopamd_vec_copy(ctx, n, rt, res));
   double normrmin = normr, rho = 1.0, omega = 1.0, alpha = 0.0, rho1;
   int stagsteps = 0, moresteps = 0;
+  // the reference's 'tol is too small' exits overwrite the right-hand side with xk before the closing comparison of the minimal-residual
+  // iterate (hiopKrylovSolver.cpp:561-566, :639-644, :671-688); the caller's right-hand side slab is left alone here, the comparison below
+  // is made against xk instead when this is set (default; hiopamd_kkt_xycyd_set_bicgstab_exit_mode(h, 0): against the original b)
+  bool b_is_xk = false;
   const double eps = std::numeric_limits<double>::epsilon();
   const int maxmsteps = 100, maxstagsteps = 3;
   int ok_prec = 1;
@@ -1030,6 +1042,7 @@ int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double
       if(stagsteps >= maxstagsteps && moresteps == 0) stagsteps = 0;
       moresteps++;
       if(moresteps >= maxmsteps) {
+        b_is_xk = h->bicg_ref_exit != 0;   // :563 b->copyFrom(*xk_)
         flag = 3;
         iter = ii + 1 - 0.5;
         break;
@@ -1089,6 +1102,7 @@ int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double
       if(stagsteps >= maxstagsteps && moresteps == 0) stagsteps = 0;
       moresteps++;
       if(moresteps >= maxmsteps) {
+        b_is_xk = h->bicg_ref_exit != 0;   // :641
         flag = 3;
         iter = ii + 1;
         break;
@@ -1111,7 +1125,7 @@ int hiopamd_kkt_xycyd_compute_directions_w_IR(hiopamd_kkt_xycyd* h, const double
     RC(hiopamd_vec_copy(ctx, n, dir, xk));
     conv = 1;
   } else {                                                 // :671-688
-    RC(residual_into(h, res, b, xmin));
+    RC(residual_into(h, res, b_is_xk ? xk : b, xmin));
     double normr_comp = 0.0;
     RC(slab_norm(h, res, &normr_comp));
     if(normr_comp <= abs_resid) {

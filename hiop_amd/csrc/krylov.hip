@@ -25,6 +25,11 @@ struct hiopamd_krylov {
   double iter = -1.0, abs_resid = -1.0, rel_resid = -1.0;
   int flag = -1;
   double* w[9] = {nullptr};   // x0 + 8 work vectors
+  // BiCGStab, 'tol is too small' exit (moresteps >= maxmsteps): the reference executes b->copyFrom(*xk_) before it breaks
+  // (hiopKrylovSolver.cpp:561-566, :639-644), so its closing comparison of the minimal-residual iterate (:671-688) is made against an
+  // OVERWRITTEN right-hand side and in practice hands back the last iterate.  1 (default): exactly that; 0: the comparison against the
+  // original right-hand side (hiopamd_krylov_set_exit_mode).  PCG does not overwrite (:300-306) and is not affected.
+  int ref_exit = 1;
 };
 
 namespace {
@@ -261,6 +266,7 @@ bool bicgstab_solve(hiopamd_krylov* k, double* b)
       if(stagsteps >= maxstagsteps && moresteps == 0) stagsteps = 0;
       moresteps++;
       if(moresteps >= maxmsteps) {
+        if(k->ref_exit) V.copy(b, xk);   // :563 (the reference's closing comparison then runs against this vector)
         k->flag = 3;
         k->iter = ii + 1 - 0.5;
         break;
@@ -307,6 +313,7 @@ bool bicgstab_solve(hiopamd_krylov* k, double* b)
       if(stagsteps >= maxstagsteps && moresteps == 0) stagsteps = 0;
       moresteps++;
       if(moresteps >= maxmsteps) {
+        if(k->ref_exit) V.copy(b, xk);   // :641
         k->flag = 3;
         k->iter = ii + 1;
         break;
@@ -413,6 +420,12 @@ int hiopamd_krylov_solve(hiopamd_krylov* k, double* b_inout, int* converged_host
 }
 
 int hiopamd_krylov_get_convergence_flag(const hiopamd_krylov* k) { return k ? k->flag : -1; }
+int hiopamd_krylov_set_exit_mode(hiopamd_krylov* k, int reference)
+{
+  if(!k) return HIOPAMD_ERR_ARG;
+  k->ref_exit = reference != 0;
+  return HIOPAMD_OK;
+}
 double hiopamd_krylov_get_sol_num_iter(const hiopamd_krylov* k) { return k ? k->iter : -1.0; }
 double hiopamd_krylov_get_sol_abs_resid(const hiopamd_krylov* k) { return k ? k->abs_resid : -1.0; }
 double hiopamd_krylov_get_sol_rel_resid(const hiopamd_krylov* k) { return k ? k->rel_resid : -1.0; }

@@ -2408,7 +2408,14 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   bool use_df = df && df->enabled && df->flags && lookahead && lda == N && df->plan.N == N && df->plan.nchain >= 3 && ctx->chain_cus >= DF_ROLES &&
                 ctx->wide_cus >= 8;
   DfDeviceLock df_lock;   // released when this call returns (it synchronises the stream first)
-  if(use_df && !df_lock.try_acquire()) use_df = false;   // another process factorises on this device right now: stepwise kernels
+  if(use_df && !df_lock.try_acquire()) {   // another process factorises on this device right now: stepwise kernels
+    use_df = false;
+    static bool told = false;
+    if(!told) {
+      told = true;
+      std::fprintf(stderr, "[hiop_amd] another process holds this device's dataflow-LDL^T lock: this factorisation (and any other that finds the lock taken) runs the stepwise kernels\n");
+    }
+  }
   {
     const Panel p0 = panel(0);
     hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, A, lda, p0.K0, p0.kbs, p0.Cj);

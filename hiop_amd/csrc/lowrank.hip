@@ -493,9 +493,9 @@ int hiopamd_hess_lowrank_update(hiopamd_hess_lowrank* h, const double* x, const 
   // save_prev() would do anyway.
   //   y_new += (Jc - Jc_prev)^T yc + (Jd - Jd_prev)^T yd                      (:293-299)
   {
-    // (two column pairs per thread -- 8 KB of a row per workgroup -- measured slower: 5.84 vs 5.56 ms per step, scripts/r04_gpu_13.sh;
-    //  software-pipelining the batches changed nothing: 1.17 vs 1.09-1.17 ms for the two launches, scripts/r04_gpu_14.sh;
-    //  non-temporal stores of J_prev: no change either, scripts/r04_gpu_18.sh)
+    // (two column pairs per thread -- 8 KB of a row per workgroup -- measured slower: 5.84 vs 5.56 ms per step, scripts/calls/r04_gpu_13.sh;
+    //  software-pipelining the batches changed nothing: 1.17 vs 1.09-1.17 ms for the two launches, scripts/calls/r04_gpu_14.sh;
+    //  non-temporal stores of J_prev: no change either, scripts/calls/r04_gpu_18.sh)
     const unsigned gx = (unsigned)((n + 2 * (int64_t)kBlock - 1) / (2 * (int64_t)kBlock));
     if(me > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel<1>, dim3(gx), dim3(kBlock), 0, ctx->stream, me, n, Jc, h->Jc_prev, yc, y_new);
     if(mi > 0 && n > 0) hipLaunchKernelGGL(secant_jac_kernel<1>, dim3(gx), dim3(kBlock), 0, ctx->stream, mi, n, Jd, h->Jd_prev, yd, y_new);

@@ -53,6 +53,11 @@ class KrylovSolver:
     def set_max_num_iter(self, maxit: int):
         check(self._L.hiopamd_krylov_set_max_num_iter(self.h, maxit), "set_max_num_iter")
 
+    def set_exit_mode(self, reference: bool):
+        """BiCGStab 'tol is too small' exit: True (default) = the reference's closing comparison against the overwritten right-hand
+        side (hiopKrylovSolver.cpp:561-566, :639-644), False = against the original one."""
+        check(self._L.hiopamd_krylov_set_exit_mode(self.h, 1 if reference else 0), "set_exit_mode")
+
     def set_x0(self, xval: float):
         check(self._L.hiopamd_krylov_set_x0(self.h, xval), "set_x0")
 

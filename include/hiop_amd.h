@@ -734,6 +734,8 @@ int hiopamd_kkt_xycyd_set_regularization(hiopamd_kkt_xycyd* h, int dual_first, i
 int hiopamd_kkt_xycyd_delta_vectors(hiopamd_kkt_xycyd* h, const double** delta_wx, const double** delta_wd,
                                     const double** delta_cc, const double** delta_cd);
 int hiopamd_kkt_xycyd_set_required_neg_eig(hiopamd_kkt_xycyd* h, int n_required); /* default neq+nineq (hiopAlgFilterIPM.cpp:2096) */
+/* the same choice as hiopamd_krylov_set_exit_mode for the BiCGStab of compute_directions_w_IR (default: the reference's behaviour) */
+int hiopamd_kkt_xycyd_set_bicgstab_exit_mode(hiopamd_kkt_xycyd* h, int reference);
 /* update (:543): barrier diagonals from the iterate, then factorize (:316): build + factor + inertia-correction
  * loop (<= 10 re-factorizations).  *ok_host = the reference's bool return. */
 int hiopamd_kkt_xycyd_update(hiopamd_kkt_xycyd* h, const double* iter, int* ok_host);
@@ -840,6 +842,11 @@ int hiopamd_krylov_set_x0(hiopamd_krylov* k, double xval);                 /* :9
 double* hiopamd_krylov_x0(hiopamd_krylov* k);                              /* device pointer of the start vector */
 int hiopamd_krylov_solve(hiopamd_krylov* k, double* b_inout, int* converged_host);
 int hiopamd_krylov_get_convergence_flag(const hiopamd_krylov* k);          /* :125 */
+/* BiCGStab's 'tol is too small' exit (100 extra steps without reaching the tolerance).  reference != 0 (default): the reference's
+ * behaviour — it copies the current iterate over the right-hand side BEFORE the closing comparison of the minimal-residual iterate
+ * (hiopKrylovSolver.cpp:561-566, :639-644, :671-688), which therefore runs against the overwritten vector and in practice returns the
+ * last iterate.  0: the comparison against the original right-hand side (what the code's comment intends).  PCG is not affected. */
+int hiopamd_krylov_set_exit_mode(hiopamd_krylov* k, int reference);
 double hiopamd_krylov_get_sol_num_iter(const hiopamd_krylov* k);           /* :116 */
 double hiopamd_krylov_get_sol_abs_resid(const hiopamd_krylov* k);          /* :110 */
 double hiopamd_krylov_get_sol_rel_resid(const hiopamd_krylov* k);          /* :113 */

@@ -61,8 +61,8 @@ typedef struct cHiopMDSProblem {
 } cHiopMDSProblem;
 
 /* chiopInterface.cpp:64-95.  Return 0 on success; a negative hiopamd status otherwise (the reference asserts).
- * ONE solve per problem object: a second hiop_mds_solve_problem on the same object returns HIOPAMD_ERR_STATE (-5) — destroy and create
- * again (the reference re-initialises from the user's data on every run; this object scales and moves its bounds in place). */
+ * A problem object may be solved again (chiopInterface.cpp:79-87 builds a fresh solver per call): every hiop_mds_solve_problem starts from
+ * the user's data (sizes, bounds, starting point are queried again), with the options set so far; options may be changed between solves. */
 int hiop_mds_create_problem(cHiopMDSProblem* problem);
 int hiop_mds_solve_problem(cHiopMDSProblem* problem);
 int hiop_mds_destroy_problem(cHiopMDSProblem* problem);

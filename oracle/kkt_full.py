@@ -526,9 +526,11 @@ class LowRankProvider:
 # ---------------------------------------------------------------------------------------------------------
 # BiCGStab (hiopKrylovSolver.cpp:390-700) on flat numpy vectors
 # ---------------------------------------------------------------------------------------------------------
-def bicgstab(A, ML, b, tol, maxit, dot=None, MR=None, x0=None):
+def bicgstab(A, ML, b, tol, maxit, dot=None, MR=None, x0=None, ref_exit=True):
     """Returns (x, converged, flag, iter, abs_resid, rel_resid).  A, ML, MR: callables v -> matrix*v; the preconditioned
-    direction is MR(ML(v)) (hiopKrylovSolver.cpp:504-511).  x0: start vector (default 0)."""
+    direction is MR(ML(v)) (hiopKrylovSolver.cpp:504-511).  x0: start vector (default 0).
+    ref_exit (default): the reference's 'tol is too small' exits copy xk over b BEFORE breaking (:561-566, :639-644), so the closing
+    comparison of the minimal-residual iterate (:671-688) runs against that overwritten vector; False: against the original b."""
     if MR is not None:
         ML0 = ML
         ML = (lambda v: MR(ML0(v))) if ML0 is not None else MR
@@ -600,6 +602,8 @@ def bicgstab(A, ML, b, tol, maxit, dot=None, MR=None, x0=None):
                 stagsteps = 0
             moresteps += 1
             if moresteps >= maxmsteps:
+                if ref_exit:
+                    b = xk.copy()                                      # :563 b->copyFrom(*xk_)
                 flag, it = 3, ii + 1 - 0.5
                 break
         if stagsteps >= maxstagsteps:
@@ -637,6 +641,8 @@ def bicgstab(A, ML, b, tol, maxit, dot=None, MR=None, x0=None):
                 stagsteps = 0
             moresteps += 1
             if moresteps >= maxmsteps:
+                if ref_exit:
+                    b = xk.copy()                                      # :641
                 flag, it = 3, ii + 1
                 break
         if abs_resid < normrmin:

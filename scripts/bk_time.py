@@ -1,4 +1,4 @@
-"""Time the pivoted (Bunch-Kaufman) factorisation and solve at the headline order (scripts/r04_gpu_15.sh)."""
+"""Time the pivoted (Bunch-Kaufman) factorisation and solve at the headline order (scripts/calls/r04_gpu_15.sh)."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -10,4 +10,4 @@ for form in 1 2; do
   HIOPAMD_DF_TILE=$form timeout -s KILL 120 python -u scripts/df_stamps.py > gpurun_out/stamps_form$form.txt 2>&1
   echo "form $form: $(grep matrixChanged gpurun_out/stamps_form$form.txt)"
 done
-DO_PROF=${DO_PROF:-1} bash scripts/r02_gpu_full.sh
+DO_PROF=${DO_PROF:-1} bash scripts/calls/r02_gpu_full.sh

@@ -1,6 +1,6 @@
 #!/bin/bash
 # full pass + PMC passes of the bench (dominant kernel = ldlt_wide_kernel)
 set -u
-bash scripts/r02_gpu_full.sh
+bash scripts/calls/r02_gpu_full.sh
 echo "=== PMC ==="
 bash scripts/gpu_pmc.sh 2>&1 | tail -30

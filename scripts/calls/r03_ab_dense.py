@@ -1,5 +1,5 @@
 """A/B timing of the dense step's kernels on ONE box: Gram strip kernel (HIOPAMD_GRAM_LDS) and GEMV stage 1 (HIOPAMD_GEMV) variants are
-chosen per PROCESS (the switches are read once), so this script is run once per setting by scripts/r03_gpu_13.sh."""
+chosen per PROCESS (the switches are read once), so this script is run once per setting by scripts/calls/r03_gpu_13.sh."""
 import os, sys, time
 import torch
 sys.path.insert(0, ".")

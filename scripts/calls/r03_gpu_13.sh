@@ -4,6 +4,6 @@ set -u
 export TMPDIR=/tmp
 for rep in 1 2; do
 for cfg in "HIOPAMD_GRAM_LDS=1 HIOPAMD_GEMV=0" "HIOPAMD_GRAM_LDS=0 HIOPAMD_GEMV=1"; do
-  echo "=== $cfg"; env $cfg timeout 300 python scripts/r03_ab_dense.py 2>&1 | tail -1
+  echo "=== $cfg"; env $cfg timeout 300 python scripts/calls/r03_ab_dense.py 2>&1 | tail -1
 done
 done

@@ -26,7 +26,7 @@ echo "=== rocprofv3 kernel-trace of the same command ==="
 (cd /tmp && timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/bench_under_rocprof.json 2> $R/$O/prof.err); echo "rocprof exit: $?"
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv && cut -c1-150 "$f" | head -8
 rm -rf $O/prof
-bash scripts/r04_pmc_ldlt.sh 2>&1 | tail -30
+bash scripts/calls/r04_pmc_ldlt.sh 2>&1 | tail -30
 echo "=== pivoted factorisation and MFMA GEMM: timing ==="
 timeout -s KILL 300 python scripts/bk_time.py 2048 8192 2>&1 | grep -v amdgpu.ids | tee $O/bk_time.log
 timeout -s KILL 120 python scripts/gemm_time.py 2>&1 | grep -v amdgpu.ids | tee $O/gemm_time.log

@@ -1,5 +1,5 @@
 """Time the dense low-rank KKT step of bench.py alone (BASELINE configs[3] shard: n_local = 1.25e6, m = 200; configs[1]: n = 1e6,
-m = 100) with the roofline kernels beside it -- the A/B harness of round 4's dense-step work (scripts/r04_gpu_10.sh)."""
+m = 100) with the roofline kernels beside it -- the A/B harness of round 4's dense-step work (scripts/calls/r04_gpu_10.sh)."""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1,4 +1,4 @@
-"""Summarise one step of the dense low-rank KKT bench from a rocprofv3 kernel trace (scripts/r04_gpu_12.sh): kernel time by name,
+"""Summarise one step of the dense low-rank KKT bench from a rocprofv3 kernel trace (scripts/calls/r04_gpu_12.sh): kernel time by name,
 idle time between kernels.  usage: dense_trace_summary.py <kernel_trace.csv> [step index of the first config]"""
 import csv, collections, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

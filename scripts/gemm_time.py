@@ -1,5 +1,5 @@
 """timesMat on the matrix pipe against the scalar LDS kernel (HIOPAMD_GEMM=0), 2000 x 2000 x 2000, HIP events on the context's stream
-(scripts/r04_gpu_16.sh)."""
+(scripts/calls/r04_gpu_16.sh)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -122,7 +122,19 @@ int main(int argc, char** argv)
     if(fabs(prob.solution[i] - want) > dev) dev = fabs(prob.solution[i] - want);
   }
   printf("obj=%.15e iters=%d status=%d maxdev=%.3e rc=%d\n", prob.obj_value, prob.niters, prob.status, dev, rc);
+  int ret = rc != 0;
+  if(getenv("HIOPAMD_TEST_RESOLVE")) {
+    /* solve the SAME problem object again (the reference allows it: chiopInterface.cpp:141-150 builds a fresh solver per call) */
+    const double obj1 = prob.obj_value;
+    const int it1 = prob.niters;
+    const double x2 = prob.solution[2];
+    for(int i = 0; i < P.n; ++i) prob.solution[i] = -7.0;
+    const int rc2 = hiop_dense_solve_problem(&prob);
+    printf("resolve: obj=%.15e iters=%d status=%d rc=%d same_obj=%d same_iters=%d same_x=%d\n", prob.obj_value, prob.niters, prob.status, rc2,
+           prob.obj_value == obj1, prob.niters == it1, prob.solution[2] == x2);
+    if(rc2 != 0 || prob.obj_value != obj1 || prob.niters != it1 || prob.solution[2] != x2) ret = 1;
+  }
   hiop_dense_destroy_problem(&prob);
   free(prob.solution);
-  return rc != 0;
+  return ret;
 }

@@ -271,6 +271,20 @@ int main(int argc, char** argv)
     printf("objective mismatch for MDS Ex1 C interface problem with 400 sparse variables and 100 dense variables\n");
     ret = 1;
   }
+  if(getenv("HIOPAMD_TEST_RESOLVE")) {
+    /* solve the SAME problem object again (the reference allows it: chiopInterface.cpp:79-87 builds a fresh solver per call) */
+    const double obj1 = prob.obj_value;
+    const int it1 = iters;
+    for(int i = 0; i < n; ++i) prob.solution[i] = -7.0;
+    const int rc2 = hiop_mds_solve_problem(&prob);
+    int st2 = 0, it2 = 0, nf2 = 0;
+    hiopamd_mds_get_solve_info(&prob, &st2, &it2, &nf2);
+    double xsum2 = 0.0;
+    for(int i = 0; i < n; ++i) xsum2 += prob.solution[i];
+    printf("resolve: obj=%.15e iters=%d status=%d rc=%d same_obj=%d same_iters=%d same_x=%d\n", prob.obj_value, it2, st2, rc2, prob.obj_value == obj1,
+           it2 == it1, xsum2 == xsum);
+    if(rc2 != 0 || prob.obj_value != obj1 || it2 != it1 || xsum2 != xsum) ret = 1;
+  }
   hiop_mds_destroy_problem(&prob);
   if(device) {
     hiopamd_mdsex1_destroy(P.dev);

@@ -323,3 +323,23 @@ def test_gradient_scaling_factors_follow_the_reference_formulas():
     np.testing.assert_allclose(s_d, [0.4, 1.0, 0.1], rtol=0, atol=0)            # 1 / max(1, rowmax / 100), row by row
     s_f, _, s_d = gradient_scaling(np.array([1e12]), np.zeros((0, 1)), np.array([[1e11]]))
     assert s_f == 1e-8 and s_d[0] == 1e-8                                       # the scaling_min_grad floor
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["mds-host", "mds-device", "dense"])
+def test_a_problem_object_can_be_solved_twice(tmp_path, which):
+    """chiopInterface.cpp:79-87 / :141-150: every hiop_*_solve_problem builds a fresh solver over the same problem object, so a binding may
+    call it twice and gets the same answer twice.  Here: the second call on the same object starts over from the user's data and must
+    return rc 0 with the same iteration count, the bit-identical objective and solution (the device path is deterministic)."""
+    env = dict(os.environ, HIOPAMD_TEST_RESOLVE="1")
+    if which == "dense":
+        exe = _compile(tmp_path, DENSE_SRC)
+        r = subprocess.run([str(exe), "500"], capture_output=True, text=True, timeout=600, env=env)
+    else:
+        exe = _compile(tmp_path)
+        r = subprocess.run([str(exe), which.split("-")[1]], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("resolve:")]
+    assert len(line) == 1, r.stdout[-2000:]
+    assert "rc=0" in line[0] and "same_obj=1" in line[0] and "same_iters=1" in line[0] and "same_x=1" in line[0], line[0]
+    assert "already solved" not in r.stderr

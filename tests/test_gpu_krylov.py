@@ -119,3 +119,43 @@ def test_right_preconditioner_warm_start_and_exit_paths(ctx):
     assert not sn.solve(bn) and sn.get_convergence_flag() == 4
     for k in (sl, sr, sb, s, sn):
         k.close()
+
+
+@pytest.mark.parametrize("reference", [True, False])
+def test_bicgstab_tolerance_too_small_exit(ctx, reference):
+    """hiopKrylovSolver.cpp:561-566 / :639-644 / :671-688: the 'tol is too small' exit.  Default = the reference's behaviour (closing
+    comparison against the right-hand side it has just overwritten with xk: the last iterate is returned), set_exit_mode(False) = the
+    comparison against the original right-hand side (the minimal-residual iterate).  The operator is a dense product through the library's
+    own GEMV (tests/test_oracle_krylov.py::hard_system: an indefinite matrix on which the method reaches ~1e-11 and then drifts for the
+    100 extra half steps).  Which iterate is returned depends on rounding late in a 700-iteration run, so device and oracle are compared
+    on what the mode guarantees: flag 3, not converged, an accurate solution whose reported residual is its true residual, and — the
+    difference between the modes — the returned iterate is the LAST one (reference) or an EARLIER one with a smaller residual."""
+    from hiop_amd.krylov import KrylovSolver
+    from tests.test_oracle_krylov import hard_system
+    Amat, bh = hard_system()
+    n = len(bh)
+    Ad = torch.tensor(Amat, dtype=torch.float64, device="cuda")
+
+    def A(x, y):
+        ctx.call("hiopamd_mat_times_vec", n, n, Ad, n, 0.0, y, 1.0, x)
+    s = KrylovSolver(ctx, KrylovSolver.BICGSTAB, n, A, None, None)
+    s.set_tol(1e-16); s.set_max_num_iter(2000)
+    if not reference:
+        s.set_exit_mode(False)
+    b = torch.tensor(bh, dtype=torch.float64, device="cuda")
+    ok = s.solve(b); ctx.sync()
+    x = b.cpu().numpy()
+    xo, ok_o, flag_o, it_o, ares_o, _ = kr.bicgstab(lambda v: Amat @ v, None, bh, 1e-16, 2000, ref_exit=reference)
+    assert (ok, s.get_convergence_flag()) == (ok_o, flag_o) == (False, 3)
+    r = np.linalg.norm(bh - Amat @ x)
+    assert r < 1e-9 * np.linalg.norm(bh) and s.get_sol_abs_resid() == pytest.approx(r, rel=1e-3)
+    np.testing.assert_allclose(x, xo, rtol=1e-6, atol=1e-9 * np.abs(xo).max())
+    s.close()
+    # the two modes on the device: the corrected one returns an earlier iterate with a residual no larger
+    if reference:
+        s2 = KrylovSolver(ctx, KrylovSolver.BICGSTAB, n, A, None, None)
+        s2.set_tol(1e-16); s2.set_max_num_iter(2000); s2.set_exit_mode(False)
+        b2 = torch.tensor(bh, dtype=torch.float64, device="cuda")
+        s2.solve(b2); ctx.sync()
+        assert s2.get_sol_abs_resid() <= r * (1 + 1e-9)
+        s2.close()

@@ -87,3 +87,31 @@ def test_bicgstab_on_the_reference_test_matrix(n):
     xa = kr.bicgstab(A, M, b, 1e-9, 6)[0]
     xb = kr.bicgstab(A, None, b, 1e-9, 6, MR=M)[0]
     np.testing.assert_allclose(xa, xb, rtol=1e-14)
+
+
+def hard_system(n=40, cond=1e4, seed=0):
+    """an indefinite symmetric matrix with a log-spaced spectrum: BiCGStab reaches ~1e-11 relative residual and then drifts"""
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    d = np.logspace(0, np.log10(cond), n) * np.where(np.arange(n) % 3 == 0, -1, 1)
+    return (Q * d) @ Q.T, rng.standard_normal(n)
+
+
+def test_bicgstab_tolerance_too_small_exit_follows_the_reference():
+    """hiopKrylovSolver.cpp:561-566 / :639-644: after 100 extra (half) steps that do not reach the tolerance the reference copies xk over b
+    and breaks with flag 3; its closing comparison of the minimal-residual iterate (:671-688) then runs against that overwritten vector:
+    ||K xmin - xk|| is of the size of ||xk||, not of a residual, so the comparison fails and the LAST iterate is returned with its own
+    iteration index.  The restatement does the same by default (ref_exit=True); ref_exit=False compares against the original b and returns
+    the minimal-residual iterate.  (On well-conditioned systems the exit is not reachable: the method breaks down, flag 4, or stagnates
+    first — e.g. the reference's own test matrix with tol = 1e-17.)"""
+    A, M, dense = _setup(50)
+    assert kr.bicgstab(A, M, np.ones(50), 1e-17, 400)[2] == 4
+    Amat, b = hard_system()
+    op = lambda v: Amat @ v
+    xr, okr, flagr, itr, aresr, _ = kr.bicgstab(op, None, b, 1e-16, 2000)
+    xf, okf, flagf, itf, aresf, _ = kr.bicgstab(op, None, b, 1e-16, 2000, ref_exit=False)
+    assert (okr, flagr) == (False, 3) and (okf, flagf) == (False, 3)
+    assert itf < itr                                                                    # the minimal-residual iterate is an earlier one
+    rr, rf = np.linalg.norm(b - Amat @ xr), np.linalg.norm(b - Amat @ xf)
+    assert rf < rr < 1e-9 * np.linalg.norm(b)                                           # both accurate, the reference's choice slightly less
+    assert aresr == pytest.approx(rr, rel=1e-6) and aresf == pytest.approx(rf, rel=1e-6)
