@@ -208,6 +208,21 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if _fake_multi() else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    coll = None
+    if hooked:
+        # a second pass of the same steps with the hook's calls counted and bracketed by HIP events on the context's stream (not the
+        # timed pass: the events cost a few microseconds per collective): how many collectives a step makes and what they cost
+        import ctypes as C2
+        Lc = ctx._L
+        with torch.cuda.stream(ctx.torch_stream):
+            Lc.hiopamd_ctx_collective_stats_begin(ctx.h, 1)
+            for i in range(a.steps):
+                step(8 + a.warmup + a.steps + i)
+            cnt, cms, nr = C2.c_int64(0), C2.c_double(0.0), C2.c_int(0)
+            Lc.hiopamd_ctx_collective_stats_read(ctx.h, C2.byref(cnt), C2.byref(cms))
+            Lc.hiopamd_ctx_rccl_ranks(ctx.h, C2.byref(nr))
+            barrier()
+        coll = dict(collectives_per_step=cnt.value / a.steps, collective_ms_per_step=cms.value / a.steps, rccl_ranks=nr.value)
     k = me + mi
     out = dict(value=a.steps / dt, unit="KKT iterations/s", ms_per_step=1e3 * dt / a.steps, scaling="weak",
                workload=f"NlpDenseCons quasi-Newton low-rank KKT, n_local={n} per GPU (n={n * world}), m={k}, l={l}; "
@@ -218,6 +233,10 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
                             else "RCCL all-reduce (ncclAllReduce on the context stream), %d ranks") % world) if hooked
                else "none (single rank, no hook)",
                hbm_gb_J_per_gpu=8.0 * k * n / 1e9)
+    if coll is not None:
+        # rccl_ranks = ncclCommCount of the communicator behind the hook (0 in the host-staged rehearsal); collective_ms_per_step = device
+        # time between HIP events around every hook call of a step, summed (max over ranks is NOT taken: rank 0's view)
+        out.update(coll)
     if rooflines:
         # the two kernels that carry the step, timed alone with HIP events on the context's stream (20 calls each):
         #  * weighted stacked Gram  G = J DhInv [J; S; Y]^T  (fp64 MFMA): algorithmic flops = the unique entries only,

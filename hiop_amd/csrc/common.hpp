@@ -66,6 +66,11 @@ struct hiopamd_ctx {
   void* allreduce_user = nullptr;
   int comm_rank = 0;
   int comm_size = 1;
+  // collective statistics (hiopamd_ctx_collective_stats_*): every call of the hook goes through ctx_allreduce below
+  long long coll_count = 0;
+  bool coll_timed = false;
+  std::vector<hipEvent_t> coll_ev;   // start / stop pairs on the context's stream (timing mode only)
+  size_t coll_used = 0;
   // CU-masked streams + events for intra-operation concurrency (the LDL^T look-ahead); created lazily, always joined back
   // into `stream` before the operation returns
   hipStream_t diag_stream = nullptr;   // CU-masked: the reserved CUs (serial chain; its 1-workgroup kernel needs a whole CU's LDS)
@@ -147,6 +152,28 @@ inline hipEvent_t ctx_event(hiopamd_ctx* ctx, int i)
     ctx->n_events++;
   }
   return ctx->ev_pool[i];
+}
+// THE call of the all-reduce hook (RCCL, or whatever hiopamd_ctx_set_allreduce installed): counted, and in timing mode bracketed by a
+// pair of HIP events on the context's stream.  0 on success.  Callers test ctx->allreduce themselves where "no hook" changes the algorithm.
+inline int ctx_allreduce(hiopamd_ctx* ctx, double* buf, size_t count, int op)
+{
+  if(!ctx->allreduce) return 0;
+  ctx->coll_count += 1;
+  const bool timed = ctx->coll_timed;
+  if(timed) {
+    while(ctx->coll_ev.size() < ctx->coll_used + 2) {
+      hipEvent_t e = nullptr;
+      if(hipEventCreate(&e) != hipSuccess) return -1;
+      ctx->coll_ev.push_back(e);
+    }
+    (void)hipEventRecord(ctx->coll_ev[ctx->coll_used], ctx->stream);
+  }
+  const int rc = ctx->allreduce(ctx->allreduce_user, buf, count, op, (void*)ctx->stream);
+  if(timed) {
+    (void)hipEventRecord(ctx->coll_ev[ctx->coll_used + 1], ctx->stream);
+    ctx->coll_used += 2;
+  }
+  return rc;
 }
 // grow-only workspace (never shrinks; freed with the context)
 inline void* ctx_workspace(hiopamd_ctx* ctx, size_t bytes)

@@ -212,6 +212,7 @@ int hiopamd_ctx_destroy(hiopamd_ctx* c)
     hipStreamDestroy(c->upd_stream);
   }
   for(int i = 0; i < c->n_events; ++i) hipEventDestroy(c->ev_pool[i]);
+  for(hipEvent_t e : c->coll_ev) hipEventDestroy(e);
   if(c->spans) {
     hiopamd::SpanState* st = static_cast<hiopamd::SpanState*>(c->spans);
     for(hipEvent_t e : st->pool) (void)hipEventDestroy(e);
@@ -266,6 +267,44 @@ int hiopamd_ctx_set_allreduce(hiopamd_ctx* c, hiopamd_allreduce_fn fn, void* use
   c->allreduce_user = user;
   c->comm_rank = rank;
   c->comm_size = size;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ctx_collective_stats_begin(hiopamd_ctx* c, int timed)
+{
+  if(!c) return HIOPAMD_ERR_ARG;
+  HIOPAMD_CHECK(hipStreamSynchronize(c->stream));
+  c->coll_count = 0;
+  c->coll_used = 0;
+  c->coll_timed = timed != 0;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ctx_collective_stats_read(hiopamd_ctx* c, int64_t* count_host, double* ms_host)
+{
+  if(!c) return HIOPAMD_ERR_ARG;
+  HIOPAMD_CHECK(hipStreamSynchronize(c->stream));
+  double ms = 0.0;
+  for(size_t i = 0; i + 1 < c->coll_used; i += 2) {
+    float t = 0.f;
+    if(hipEventElapsedTime(&t, c->coll_ev[i], c->coll_ev[i + 1]) == hipSuccess) ms += t;
+  }
+  if(count_host) *count_host = (int64_t)c->coll_count;
+  if(ms_host) *ms_host = c->coll_timed ? ms : -1.0;
+  c->coll_used = 0;
+  c->coll_timed = false;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ctx_rccl_ranks(const hiopamd_ctx* c, int* ranks_host)
+{
+  if(!c || !ranks_host) return HIOPAMD_ERR_ARG;
+  *ranks_host = 0;
+  if(c->allreduce == rccl_allreduce && c->allreduce_user) {
+    const RcclState* st = static_cast<const RcclState*>(c->allreduce_user);
+    int n = 0;
+    if(st->comm && ncclCommCount(st->comm, &n) == ncclSuccess) *ranks_host = n;
+  }
   return HIOPAMD_OK;
 }
 

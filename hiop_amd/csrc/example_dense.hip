@@ -187,7 +187,7 @@ static int denseex2_reduce(hiopamd_denseex2* p, const double* x)
   hiopamd_ctx* ctx = p->ctx;
   hipLaunchKernelGGL(denseex2_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->c1 - p->c0, p->c0, x, p->red);
   HIOPAMD_CHECK(hipGetLastError());
-  if(ctx->allreduce && ctx->allreduce(ctx->allreduce_user, p->red, (size_t)5, HIOPAMD_SUM, (void*)ctx->stream) != 0)
+  if(ctx->allreduce && ctx_allreduce(ctx, p->red, (size_t)5, HIOPAMD_SUM) != 0)
     return HIOPAMD_ERR_HIP;
   return HIOPAMD_OK;
 }

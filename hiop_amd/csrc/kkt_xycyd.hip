@@ -316,7 +316,7 @@ int backend_jac_times_vec(hiopamd_kkt_xycyd* h, double* ycd, const double* x)
   if(h->kind == KIND_LOWRANK) {
     const int k = h->nyc + h->nyd;
     RC(hiopamd_mat_times_vec(ctx, k, h->nx, hiopamd_kkt_lowrank_J(h->lr), h->nx, 0.0, ycd, 1.0, x));
-    if(ctx->allreduce && ctx->allreduce(ctx->allreduce_user, ycd, (size_t)k, HIOPAMD_SUM, (void*)ctx->stream) != 0)
+    if(ctx->allreduce && ctx_allreduce(ctx, ycd, (size_t)k, HIOPAMD_SUM) != 0)
       return HIOPAMD_ERR_HIP;
     return HIOPAMD_OK;
   }
@@ -356,7 +356,7 @@ int slab_dot(hiopamd_kkt_xycyd* h, const double* a, const double* b, double* out
   RC(launch_reduce<dot2_t>(ctx, h->dim, OpSlabDot2{a, b, h->off[1], h->off[4], h->off[6], h->off[8], h->off[10]}, &r));
   HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, &r.dist, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
-  if(ctx->allreduce(ctx->allreduce_user, h->dsmall, 1, HIOPAMD_SUM, (void*)ctx->stream) != 0) return HIOPAMD_ERR_HIP;
+  if(ctx_allreduce(ctx, h->dsmall, 1, HIOPAMD_SUM) != 0) return HIOPAMD_ERR_HIP;
   HIOPAMD_CHECK(hipMemcpyAsync(&r.dist, h->dsmall, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
   *out = r.dist + r.repl;
@@ -882,7 +882,7 @@ int hiopamd_kkt_xycyd_test_direction(hiopamd_kkt_xycyd* h, const double* dir, do
   if(h->kind == KIND_LOWRANK && ctx->allreduce) {
     HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, &sx, sizeof(sx), hipMemcpyHostToDevice, ctx->stream));
     HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
-    if(ctx->allreduce(ctx->allreduce_user, h->dsmall, 2, HIOPAMD_SUM, (void*)ctx->stream) != 0) return HIOPAMD_ERR_HIP;
+    if(ctx_allreduce(ctx, h->dsmall, 2, HIOPAMD_SUM) != 0) return HIOPAMD_ERR_HIP;
     HIOPAMD_CHECK(hipMemcpyAsync(&sx, h->dsmall, sizeof(sx), hipMemcpyDeviceToHost, ctx->stream));
     HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
   }
@@ -1198,9 +1198,9 @@ int xpart_allreduce(hiopamd_kkt_xycyd* h, red4_t* r, int nmax)
   if(!(h->kind == KIND_LOWRANK && ctx->allreduce)) return HIOPAMD_OK;
   HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, r->v, 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
-  if(nmax > 0 && ctx->allreduce(ctx->allreduce_user, h->dsmall, (size_t)nmax, HIOPAMD_MAX, (void*)ctx->stream) != 0)
+  if(nmax > 0 && ctx_allreduce(ctx, h->dsmall, (size_t)nmax, HIOPAMD_MAX) != 0)
     return HIOPAMD_ERR_HIP;
-  if(nmax < 4 && ctx->allreduce(ctx->allreduce_user, h->dsmall + nmax, (size_t)(4 - nmax), HIOPAMD_SUM, (void*)ctx->stream) != 0)
+  if(nmax < 4 && ctx_allreduce(ctx, h->dsmall + nmax, (size_t)(4 - nmax), HIOPAMD_SUM) != 0)
     return HIOPAMD_ERR_HIP;
   HIOPAMD_CHECK(hipMemcpyAsync(r->v, h->dsmall, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1364,7 +1364,7 @@ int hiopamd_iterate_fraction_to_the_bdry(hiopamd_kkt_xycyd* h, const double* it,
     double buf[2] = {-ap, -ad};
     HIOPAMD_CHECK(hipMemcpyAsync(h->dsmall, buf, sizeof(buf), hipMemcpyHostToDevice, ctx->stream));
     HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
-    if(ctx->allreduce(ctx->allreduce_user, h->dsmall, 2, HIOPAMD_MAX, (void*)ctx->stream) != 0) return HIOPAMD_ERR_HIP;
+    if(ctx_allreduce(ctx, h->dsmall, 2, HIOPAMD_MAX) != 0) return HIOPAMD_ERR_HIP;
     HIOPAMD_CHECK(hipMemcpyAsync(buf, h->dsmall, sizeof(buf), hipMemcpyDeviceToHost, ctx->stream));
     HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
     ap = -buf[0];
@@ -1598,7 +1598,7 @@ int hiopamd_duals_lsq_update(hiopamd_kkt_xycyd* h, double* iter, const double* g
     if(me > 0 && mi > 0) RC(hiopamd_gram_weighted(ctx, me, mi, nx, Jc, nx, Jd, nx, nullptr, 0.0, M + me, m, 1.0, 0));
     if(mi > 0) RC(hiopamd_gram_weighted(ctx, mi, mi, nx, Jd, nx, Jd, nx, nullptr, 0.0, M + (int64_t)me * m + me, m, 1.0, 1));
     if(h->kind == KIND_LOWRANK && ctx->allreduce &&
-       ctx->allreduce(ctx->allreduce_user, M, mm, HIOPAMD_SUM, (void*)ctx->stream) != 0)
+       ctx_allreduce(ctx, M, mm, HIOPAMD_SUM) != 0)
       return HIOPAMD_ERR_HIP;
   }
   RC(hiopamd_mat_add_sub_diagonal_const(ctx, M, m, me, mi, 1.0));   // mixmi->addDiagonal(1.0)  (:256)

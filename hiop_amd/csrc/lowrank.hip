@@ -346,7 +346,7 @@ static int allreduce_dev(hiopamd_ctx* ctx, double* buf, size_t count, int op)
 {
   // a hook installed on a 1-rank partition is still called (lets the RCCL path run on a single GPU)
   if(!ctx->allreduce) return HIOPAMD_OK;
-  return ctx->allreduce(ctx->allreduce_user, buf, count, op, (void*)ctx->stream) == 0 ? HIOPAMD_OK : HIOPAMD_ERR_HIP;
+  return ctx_allreduce(ctx, buf, count, op) == 0 ? HIOPAMD_OK : HIOPAMD_ERR_HIP;
 }
 static int to_host(hiopamd_ctx* ctx, void* dst, const void* src, size_t bytes)
 {

@@ -93,6 +93,14 @@ int hiopamd_ctx_comm(const hiopamd_ctx* ctx, int* rank_host, int* size_host);
  * hiopamd_rccl_unique_id on rank 0 and broadcast by the host side. */
 int hiopamd_rccl_unique_id(unsigned char* unique_id_128_host);
 int hiopamd_ctx_init_rccl(hiopamd_ctx* ctx, const unsigned char* unique_id_128_host, int rank, int size);
+/* ranks of the RCCL communicator behind the context's hook (ncclCommCount); 0 when the hook is not the RCCL one */
+int hiopamd_ctx_rccl_ranks(const hiopamd_ctx* ctx, int* ranks_host);
+/* collective statistics: _begin zeroes the call counter of the all-reduce hook (timed != 0: every call is bracketed by HIP events on the
+ * context's stream from now on); _read synchronises the stream and returns the number of hook calls since _begin and, in timed mode, the
+ * summed device time between the brackets in ms (-1 otherwise), then leaves timed mode.  The replacement of the reference's MPI_Allreduce
+ * count (hiopHessianLowRank.cpp:459,590-591; hiopMatrixDenseRowMajor.cpp:466-487) made visible to a benchmark. */
+int hiopamd_ctx_collective_stats_begin(hiopamd_ctx* ctx, int timed);
+int hiopamd_ctx_collective_stats_read(hiopamd_ctx* ctx, int64_t* count_host, double* ms_host);
 const char* hiopamd_version(void);
 int hiopamd_device_info(char* name_host, size_t name_len, int* cu_count_host, size_t* hbm_bytes_host);
 

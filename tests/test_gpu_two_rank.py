@@ -185,4 +185,9 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     ds = d["dense_sharded"]
     assert ds["n_ranks"] == 2 and ds["ms_per_step"] > 0 and "2 ranks" in ds["collective"]
+    # the N > 1 line explains itself: collectives per step counted at the hook (2 in the secant update, 1 for the l x l blocks, 1 for N,
+    # 1 per solveCompressed: 4 + solves; the first steps after a memory shift may differ by the update that was skipped), their device
+    # time between HIP events, the communicator's size (0 here: the rehearsal's hook is host-staged gloo, not RCCL), one rank alone
+    assert 4 <= ds["collectives_per_step"] <= 4 + 3 + 1 and ds["collective_ms_per_step"] > 0 and ds["rccl_ranks"] == 0
+    assert ds["single_rank_ms_per_step"] > 0
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
