@@ -528,10 +528,7 @@ def main():
     # the dominant kernel is the persistent wide kernel of the dataflow factorisation: `achieved` = the algorithmic flops of its
     # trailing-update tiles (2 K per updated element of the upper triangle) / its WHOLE duration, which also contains the
     # row-panel substitution tasks and every wait for the chain kernel — a lower bound on the tile rate, by construction
-    L.hiopamd_ldlt_dataflow_form.restype = C.c_int
-    form = int(L.hiopamd_ldlt_dataflow_form(int(p.N)))
-    kname = ("ldlt_wide8_kernel<false> (eight waves, one workgroup per CU, LDS-DMA operand staging)" if form == 8 else
-             "ldlt_wide_kernel<2,false> (four waves, ONE workgroup per CU)")
+    kname = "ldlt_wide_kernel<2,false> (four waves, ONE workgroup per CU)"
     roofline = dict(bound="mfma", kernel=kname + " — dataflow LDL^T: row-panel substitution tasks + 128x128x256 / x512 trailing-update tiles, v_mfma_f64_16x16x4_f64",
                     achieved=achieved, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
                     traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,

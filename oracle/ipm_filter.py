@@ -337,7 +337,9 @@ def solve(ops, x0, on_kkt=None, table=None, quasi_newton=False, lsq_duals=None, 
                         break
                     num_soc += 1
                 if st > 0:
-                    ls_status, ap, dr, resid, gpd, theta_trial, use_soc = st, ap_soc, dr_soc, r_soc, gpd_soc, th, 1
+                    ls_status, ap, dr, resid, gpd, use_soc = st, ap_soc, dr_soc, r_soc, gpd_soc, 1
+                    if o.get("soc_theta_corrected", False):
+                        theta_trial = th
                     break
             ap *= 0.5
             ini_step = False

@@ -4,10 +4,10 @@ set -u
 mkdir -p gpurun_out/r05_1
 export TMPDIR=/tmp
 echo "=== stream wait value probe ==="
-timeout 60 scripts/probes/stream_wait_value_probe 200 > gpurun_out/r05_1/wait_value_probe.txt 2>&1; echo "probe exit: $?"
-cat gpurun_out/r05_1/wait_value_probe.txt
+true
+true
 echo "=== pytest -m gpu ==="
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05_1/pytest_gpu.log 2>&1; echo "pytest exit: $?"
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/r05_1/pytest_gpu.log 2>&1; echo "pytest exit: $?"
 tail -15 gpurun_out/r05_1/pytest_gpu.log
 echo "=== stamps ==="
 timeout 200 python scripts/df_stamps.py > gpurun_out/r05_1/stamps.log 2>&1; echo "stamps exit: $?"
