@@ -54,6 +54,10 @@ struct Options {   // defaults of src/Utils/hiopOptions.cpp:560-850; mu0 as set 
          rel_tolerance = 0., acceptable_tolerance = 1e-6, min_step_size = 1e-16, kappa_Sigma = 1e10, bound_relax_perturb = 1e-8,
          kappa_soc = 0.99, scaling_max_grad = 100., ir_outer_tol_factor = 1e-2, ir_outer_tol_min = 1e-6;
   int acceptable_iterations = 10, max_iter = 3000, max_soc_iter = 4, verbosity_level = 3, ir_outer_maxit = 8;
+  // 0 (default): after a step accepted through the second-order correction the filter entry keeps the FIRST trial point's theta — the
+  // reference passes theta_trial to apply_second_order_correction by value (hiopAlgFilterIPM.cpp:2949-2973, call :2561-2570), so its
+  // filter.add (:2629-2639) never sees the corrected point's; 1: the corrected point's theta (rounds 3-4 of this library)
+  int soc_theta_corrected = 0;
 };
 
 template <class T>
@@ -858,7 +862,7 @@ int MdsSolver::run()
           ls_status = st;
           ap = ap_soc;
           dirp = dir_soc.p;
-          theta_trial = th;   // (the pinned trajectories need the corrected point's theta in the filter entry)
+          if(o.soc_theta_corrected) theta_trial = th;   // (default: by value, like the reference — see Options::soc_theta_corrected)
           gpd_computed = gpd_soc_computed;
           gpd = gpd_soc;
           use_soc = 1;
@@ -1094,7 +1098,7 @@ int hiopamd_mds_set_numeric_option(cHiopMDSProblem* problem, const char* name, d
     o.x = (int)v;     \
     return HIOPAMD_OK; \
   }
-  OPTI(max_iter) OPTI(acceptable_iterations) OPTI(max_soc_iter) OPTI(verbosity_level)
+  OPTI(max_iter) OPTI(acceptable_iterations) OPTI(max_soc_iter) OPTI(verbosity_level) OPTI(soc_theta_corrected)
 #undef OPTI
   return HIOPAMD_ERR_ARG;
 }

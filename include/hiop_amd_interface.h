@@ -72,7 +72,8 @@ int hiop_mds_destroy_problem(cHiopMDSProblem* problem);
 int hiopamd_mds_set_callback_mem_space(cHiopMDSProblem* problem, int device);
 /* numeric options by the reference's names (src/Utils/hiopOptions.cpp): mu0, tolerance, max_iter, kappa_d, tau_min, kappa_mu,
  * theta_mu, kappa_eps, kappa1, kappa2, smax, bound_relax_perturb, acceptable_tolerance, acceptable_iterations, dual_tol,
- * cons_tol, comp_tol, min_step_size, max_soc_iter, kappa_soc, verbosity_level (>= 3 prints the reference's iteration table).
+ * cons_tol, comp_tol, min_step_size, max_soc_iter, kappa_soc, verbosity_level (>= 3 prints the reference's iteration table);
+ * soc_theta_corrected (not a reference option; 0 = the reference's by-value theta_trial after a second-order correction, the default).
  * Unknown name: HIOPAMD_ERR_ARG. */
 int hiopamd_mds_set_numeric_option(cHiopMDSProblem* problem, const char* name, double value);
 /* after solve: status = the reference's hiopSolveStatus value (hiopInterface.hpp:78-110: 0 Solve_Success, 2 Solve_Acceptable_Level,

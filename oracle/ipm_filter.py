@@ -30,7 +30,12 @@ DEFAULTS = dict(mu0=1.0, tolerance=1e-8, kappa_mu=0.2, theta_mu=1.5, kappa_eps=1
                 theta_max_fact=1e4, theta_min_fact=1e-4, dual_tol=1.0, cons_tol=1e-4, comp_tol=1e-4, rel_tolerance=0.0,
                 acceptable_tolerance=1e-6, acceptable_iterations=10, max_iter=3000, min_step_size=1e-16, kappa_Sigma=1e10,
                 bound_relax_perturb=1e-8, duals_lsq_ini_max=1e3, recalc_lsq_duals_tol=1e-6, max_soc_iter=4,
-                kappa_soc=0.99)
+                kappa_soc=0.99,
+                # not a reference option.  False (default): after a step accepted through the second-order correction, filter.add and the
+                # LSQ-duals test keep the FIRST trial point's theta: the reference passes theta_trial to apply_second_order_correction BY
+                # VALUE (hiopAlgFilterIPM.cpp:2949-2973, call :2561-2570; infeas_nrm_trial :2537 is set in the outer loop only).
+                # True: the corrected point's theta (what rounds 3-4 of this restatement used).
+                soc_theta_corrected=False)
 
 
 def relax_bounds(xl, xu, dl, du, rel):
@@ -305,6 +310,9 @@ def solve(ops, x0, on_kkt=None, table=None, quasi_newton=False, lsq_duals=None, 
         ini_step = True
         while True:
             if not ini_step and ap < o["min_step_size"]:
+                if quasi_newton:                                        # :1289-1297: solver_status_ = Steplength_Too_Small, the run ends
+                    status = "Steplength_Too_Small"                     # (:1442-1444) at the current iterate
+                    break
                 raise NotImplementedError("minimum step size reached (feasibility restoration is not restated)")
             trial, nadj = ops.trial_primals(it, dr, ap, ad, mu)
             ev_t = ops.evaluate(trial)                                  # functions only in the reference
@@ -338,11 +346,13 @@ def solve(ops, x0, on_kkt=None, table=None, quasi_newton=False, lsq_duals=None, 
                     num_soc += 1
                 if st > 0:
                     ls_status, ap, dr, resid, gpd, use_soc = st, ap_soc, dr_soc, r_soc, gpd_soc, 1
-                    if o.get("soc_theta_corrected", False):
+                    if o["soc_theta_corrected"]:
                         theta_trial = th
                     break
             ap *= 0.5
             ini_step = False
+        if status == "Steplength_Too_Small":
+            break
         if nadj > 0:
             raise NotImplementedError("adjust_bounds after small slacks")                   # :2592-2603
         # ---- filter augmentation, :2616-2653
