@@ -200,6 +200,93 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
       if(Li_lds) Li_lds[sb * 256 + r * 16 + li] = xm[reg];
     }
   };
+  // (i'') FOUR pivots per pass (round 5; full sub-blocks only).  The rank-1 form above is one dependent chain per pivot — MFMA (76
+  // cycles), two v_readlane pairs, the next pivot and its reciprocal, the operand: ~300 cycles, 2.4 us per 16 x 16 sub-block, 40 % of every
+  // spine step.  Here the 4 x 4 diagonal block of pivots k0..k0+3 (10 entries of register k0/4, one v_readlane pair each) is factored
+  // in UNIFORM registers (every lane the same 4 x 4 LDL^T: four reciprocals, ~20 fused multiply-adds, no cross-lane traffic), the four
+  // pivot rows R (register k0/4 of the four lane groups) become U = Linv4 R by ONE MFMA whose A operand holds Linv4 in lanes (i, k),
+  // i < 4 — the result rows 0..3 are register 0 of lane group = row, i.e. every lane receives its own entry back —, and the rows below
+  // get the rank-4 update x[r][:] -= sum_q (U_q[r] / d_q) U_q[:] by ONE MFMA (A operand: own entry times -1/d of the lane's group, masked
+  // to r > k0 + 3; B operand: own entry).  The same two MFMAs applied to the inverse being built.  Per 4 pivots: 20 v_readlane, the
+  // uniform 4 x 4 factor, 2 + 2 MFMAs — ~110 cycles per pivot instead of ~300.
+  auto factor16r = [&](int sb) {
+    const int o = sb * LD_SB;
+    double4_t xa, xm;
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      xa[reg] = S[o + g + 4 * reg][o + li];   // zeros below the diagonal
+      xm[reg] = (g + 4 * reg == li) ? 1.0 : 0.0;
+    }
+    double dis[LD_SB];
+    const double4_t zero4 = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int s4 = 0; s4 < 4; ++s4) {
+      const int k0 = 4 * s4;
+      // the 4 x 4 diagonal block: entry (q, p), p >= q, lives in lane 16 q + k0 + p, register s4
+      const double p00 = bcast_lane(xa[s4], k0), p01 = bcast_lane(xa[s4], k0 + 1), p02 = bcast_lane(xa[s4], k0 + 2),
+                   p03 = bcast_lane(xa[s4], k0 + 3);
+      const double p11 = bcast_lane(xa[s4], 16 + k0 + 1), p12 = bcast_lane(xa[s4], 16 + k0 + 2), p13 = bcast_lane(xa[s4], 16 + k0 + 3);
+      const double p22 = bcast_lane(xa[s4], 32 + k0 + 2), p23 = bcast_lane(xa[s4], 32 + k0 + 3);
+      const double p33 = bcast_lane(xa[s4], 48 + k0 + 3);
+      // its LDL^T, uniform (q.. = the block after the earlier pivots of this pass)
+      const double r0 = fast_rcp(p00);
+      const double l10 = p01 * r0, l20 = p02 * r0, l30 = p03 * r0;
+      const double q11 = fma(-l10, p01, p11), q12 = fma(-l10, p02, p12), q13 = fma(-l10, p03, p13);
+      const double r1 = fast_rcp(q11);
+      const double l21 = q12 * r1, l31 = q13 * r1;
+      const double q22 = fma(-l21, q12, fma(-l20, p02, p22)), q23 = fma(-l21, q13, fma(-l20, p03, p23));
+      const double r2 = fast_rcp(q22);
+      const double l32 = q23 * r2;
+      const double q33 = fma(-l32, q23, fma(-l31, q13, fma(-l30, p03, p33)));
+      const double r3 = fast_rcp(q33);
+      dis[k0] = r0;
+      dis[k0 + 1] = r1;
+      dis[k0 + 2] = r2;
+      dis[k0 + 3] = r3;
+      // inverse of the unit lower factor (column by column: L c = e)
+      const double c10 = -l10, c21 = -l21, c32 = -l32;
+      const double c20 = fma(-l21, c10, -l20);
+      const double c30 = fma(-l32, c20, fma(-l31, c10, -l30));
+      const double c31 = fma(-l32, c21, -l31);
+      // A operand of the in-block transform: lane (li, g) <- Linv4[li][g]
+      double al = (li < 4 && li == g) ? 1.0 : 0.0;
+      al = (li == 1 && g == 0) ? c10 : al;
+      al = (li == 2 && g == 0) ? c20 : al;
+      al = (li == 3 && g == 0) ? c30 : al;
+      al = (li == 2 && g == 1) ? c21 : al;
+      al = (li == 3 && g == 1) ? c31 : al;
+      al = (li == 3 && g == 2) ? c32 : al;
+      const double rg = (g == 0) ? r0 : (g == 1) ? r1 : (g == 2) ? r2 : r3;
+      const double4_t u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(al, xa[s4], zero4, 0, 0, 0);
+      const double4_t m4 = __builtin_amdgcn_mfma_f64_16x16x4f64(al, xm[s4], zero4, 0, 0, 0);
+      const double u = u4[0], mv = m4[0];   // this lane's entry of the finished pivot row of its group / of the same row of the inverse
+      if(s4 < 3) {
+        const double aop = (li > k0 + 3) ? u * (-rg) : 0.0;
+        xa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, u, xa, 0, 0, 0);
+        xm = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, mv, xm, 0, 0, 0);
+      }
+      xa[s4] = u;
+      xm[s4] = mv;
+    }
+    int bad = 0;
+#pragma unroll
+    for(int k = LD_SB - 1; k >= 0; --k)
+      if(!isfinite(dis[k])) bad = k + 1;   // the FIRST one (everything after it is NaN as well)
+    if(tid == 0) {
+#pragma unroll
+      for(int k = 0; k < LD_SB; ++k) sdinv[o + k] = dis[k];
+      if(bad) atomicCAS(info, 0, k0 + o + bad);
+    }
+#pragma unroll
+    for(int reg = 0; reg < 4; ++reg) {
+      const int r = g + 4 * reg;
+      if(li >= r) S[o + r][o + li] = xa[reg];
+      Lv[r][li] = xm[reg];
+      if constexpr(SC1) stg_sc1(Li + sb * 256 + r * 16 + li, xm[reg]);
+      else Li[sb * 256 + r * 16 + li] = xm[reg];
+      if(Li_lds) Li_lds[sb * 256 + r * 16 + li] = xm[reg];
+    }
+  };
   // (i) for sub-block sb, by wave 0 (call with tid < 64): in-register 16x16 Gauss-Jordan; a padded sub-block (o >= kb)
   // just gets the identity as its inverse
   auto factor16v = [&](int sb) {
@@ -269,8 +356,10 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
   };
   auto factor16 = [&](int sb) {
     const unsigned t0 = prof ? (unsigned)wall_clock64() : 0u;   // (profiling runs only: time spent in the sub-block factors)
-    if constexpr(MF) factor16m(sb);
-    else factor16v(sb);
+    if constexpr(MF) {
+      if(sb * LD_SB + LD_SB <= kb) factor16r(sb);   // (uniform) a full sub-block: four pivots per pass
+      else factor16m(sb);
+    } else factor16v(sb);
     if(prof && tid == 0) atomicAdd(prof, (unsigned)wall_clock64() - t0);
   };
   // one 16x16 tile of (iii): C -= V^T D^-1 V, (ti, tj) = 0:(0,0) 1:(0,1) 2:(0,2) 3:(1,1) 4:(1,2) 5:(2,2)
