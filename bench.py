@@ -327,7 +327,8 @@ def sparse_condensed_bench(ctx, a, n=1_000_000):
     nnzJ = int(p.Jd_v.size)
     kind = K.inner_kind()
     inner = {"bordered": "bordered-diagonal direct LDL^T (diagonal + a border of <= 32 variables: exact inertia, no iteration)",
-             "pcg": "PCG + Jacobi, tol 1e-12", "dense": "dense LDL^T of the expanded matrix"}[kind]
+             "pcg": "PCG + Jacobi, tol 1e-12", "dense": "dense LDL^T of the expanded matrix",
+             "sparse_ldl": "sparse LDL^T: nested dissection, multifrontal by tree levels, dense root (exact inertia)"}[kind]
     out = dict(value=a.steps / dt, unit="KKT iterations/s", ms_per_step=1e3 * dt / a.steps,
                workload=f"NlpSparse condensed KKT (SparseEx2 pattern, inequality-only form): n={n}, m={p.nineq}, nnz(Jd)={nnzJ}; step = "
                         f"build (CSR J^T D J + H + Dx, numeric) + factorize + {a.solves} solveCompressed ({inner})",

@@ -26,6 +26,7 @@ SOURCES = [
     "sparse_assembly.hip",
     "csr_condensed.hip",
     "arrow_ldl.hip",
+    "sparse_ldl.hip",
     "kkt_sparse.hip",
     "gram.hip",
     "ldlt.hip",

@@ -32,6 +32,9 @@ struct hiopamd_kkt_sparse_condensed {
   // SPARSE direct inner solver for bordered-diagonal patterns of any order (csrc/arrow_ldl.hip: the arrowhead of the reference's
   // sparse examples): exact LDL^T with exact inertia.  HIOPAMD_SPARSE_ARROW=0 switches it off (the Krylov path stays testable).
   hiopamd_arrow_ldl* arrow = nullptr;
+  // GENERAL sparse direct inner solver (csrc/sparse_ldl.hip: nested dissection, multifrontal by tree levels, dense root) for the patterns
+  // the two above do not take: exact LDL^T, exact inertia.  Patterns whose dense root would exceed its limit keep PCG + Jacobi.
+  hiopamd_sparse_ldl* sldl = nullptr;
   // sparsity (device copies of the triplet index arrays: the SpMVs of the right-hand side / recovery and of the operator)
   int *iJ = nullptr, *jJ = nullptr, *iH = nullptr, *jH = nullptr;
   // current values (borrowed)
@@ -119,6 +122,7 @@ int hiopamd_kkt_sparse_condensed_destroy(hiopamd_kkt_sparse_condensed* k)
   if(k->pcg) hiopamd_krylov_destroy(k->pcg);
   if(k->dls) hiopamd_linsolver_destroy(k->dls);
   if(k->arrow) hiopamd_arrow_ldl_destroy(k->arrow);
+  if(k->sldl) hiopamd_sparse_ldl_destroy(k->sldl);
   if(k->csr) hiopamd_csr_condensed_destroy(k->csr);
   (void)hipFree(k->iJ); (void)hipFree(k->jJ); (void)hipFree(k->iH); (void)hipFree(k->jH);
   (void)hipFree(k->Hd); (void)hipFree(k->Dxp); (void)hipFree(k->rhs);
@@ -161,6 +165,10 @@ int hiopamd_kkt_sparse_condensed_create(hiopamd_kkt_sparse_condensed** out, hiop
     if(rc == HIOPAMD_OK) {
       const int ra = hiopamd_arrow_ldl_create(&k->arrow, ctx, nx, rp.data(), ci.data());
       if(ra != HIOPAMD_OK && ra != HIOPAMD_ERR_STATE) rc = ra;
+      if(rc == HIOPAMD_OK && !k->arrow) {   // not a bordered diagonal with a small border: the general sparse LDL^T, if its root fits
+        const int rs = hiopamd_sparse_ldl_create(&k->sldl, ctx, nx, rp.data(), ci.data());
+        if(rs != HIOPAMD_OK && rs != HIOPAMD_ERR_STATE) rc = rs;
+      }
     }
   }
   if(rc == HIOPAMD_OK) rc = hiopamd_krylov_set_tol(k->pcg, k->tol);
@@ -230,6 +238,12 @@ int hiopamd_kkt_sparse_condensed_factorize(hiopamd_kkt_sparse_condensed* k, int*
     *n_neg_host = (nneg != 0 || nzero != 0) ? -1 : 0;
     return HIOPAMD_OK;
   }
+  if(k->sldl) {   // exact as well: P M P^T = L D L^T with positive pivots iff M is positive definite
+    int nneg = 0, nzero = 0;
+    RC(hiopamd_sparse_ldl_factorize(k->sldl, hiopamd_csr_condensed_values(k->csr), &nneg, &nzero));
+    *n_neg_host = (nneg != 0 || nzero != 0) ? -1 : 0;
+    return HIOPAMD_OK;
+  }
   double* diag = k->rhs;
   RC(hiopamd_csr_condensed_diagonal(k->csr, diag));
   int64_t nonpos = 0;
@@ -276,6 +290,14 @@ int hiopamd_kkt_sparse_condensed_solve_compressed(hiopamd_kkt_sparse_condensed* 
     const int ra = hiopamd_arrow_ldl_solve(k->arrow, k->rhs);
     if(ra != HIOPAMD_OK && ra != HIOPAMD_ERR_STATE) return ra;
     conv = ra == HIOPAMD_OK ? 1 : 0;   // (ERR_STATE: the last factorisation found M singular / was never run: the reference returns false)
+    k->last_flag = conv ? 0 : 4;
+    k->last_iters = 0.0;
+    k->last_rel = 0.0;
+  } else if(k->sldl) {
+    SpanScope span(ctx, HIOPAMD_SPAN_KKT_SOLVE_INNER);
+    const int rs = hiopamd_sparse_ldl_solve(k->sldl, k->rhs);
+    if(rs != HIOPAMD_OK && rs != HIOPAMD_ERR_STATE) return rs;
+    conv = rs == HIOPAMD_OK ? 1 : 0;   // (ERR_STATE: the last factorisation met a zero pivot / was never run: the reference returns false)
     k->last_flag = conv ? 0 : 4;
     k->last_iters = 0.0;
     k->last_rel = 0.0;
@@ -334,11 +356,12 @@ int hiopamd_kkt_sparse_condensed_dims(const hiopamd_kkt_sparse_condensed* k, int
   dims4_host[0] = k->nx; dims4_host[1] = k->nineq; dims4_host[2] = k->nnzJ; dims4_host[3] = k->nnzH;
   return HIOPAMD_OK;
 }
-// which inner solver the object runs: 0 dense LDL^T of the expanded matrix, 1 bordered-diagonal direct solver, 2 PCG + Jacobi
+// which inner solver the object runs: 0 dense LDL^T of the expanded matrix, 1 bordered-diagonal direct solver, 2 PCG + Jacobi,
+// 3 general sparse LDL^T (nested dissection + multifrontal + dense root)
 int hiopamd_kkt_sparse_condensed_inner_kind(const hiopamd_kkt_sparse_condensed* k)
 {
   if(!k) return HIOPAMD_ERR_ARG;
-  return k->dls ? 0 : (k->arrow ? 1 : 2);
+  return k->dls ? 0 : (k->arrow ? 1 : (k->sldl ? 3 : 2));
 }
 hiopamd_csr_condensed* hiopamd_kkt_sparse_condensed_matrix(hiopamd_kkt_sparse_condensed* k) { return k ? k->csr : nullptr; }
 double* hiopamd_kkt_sparse_condensed_Hd(hiopamd_kkt_sparse_condensed* k) { return k ? k->Hd : nullptr; }

@@ -219,6 +219,11 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
     }
     double dis[LD_SB];
     const double4_t zero4 = double4_t{0.0, 0.0, 0.0, 0.0};
+    // 0/1 weights of lane (li, g) for the entries of Linv4 it holds as A operand (wdg: the unit diagonal), and its lane group
+    const double wdg = (li < 4 && li == g) ? 1.0 : 0.0, w10 = (li == 1 && g == 0) ? 1.0 : 0.0, w20 = (li == 2 && g == 0) ? 1.0 : 0.0,
+                 w30 = (li == 3 && g == 0) ? 1.0 : 0.0, w21 = (li == 2 && g == 1) ? 1.0 : 0.0, w31 = (li == 3 && g == 1) ? 1.0 : 0.0,
+                 w32 = (li == 3 && g == 2) ? 1.0 : 0.0;
+    const bool is_g1 = g == 1, is_g2 = g == 2, is_g3 = g == 3;
 #pragma unroll
     for(int s4 = 0; s4 < 4; ++s4) {
       const int k0 = 4 * s4;
@@ -248,15 +253,13 @@ __device__ __forceinline__ void diag_factor_lds(double (*S)[LD_nb + 1], double* 
       const double c20 = fma(-l21, c10, -l20);
       const double c30 = fma(-l32, c20, fma(-l31, c10, -l30));
       const double c31 = fma(-l32, c21, -l31);
-      // A operand of the in-block transform: lane (li, g) <- Linv4[li][g]
-      double al = (li < 4 && li == g) ? 1.0 : 0.0;
-      al = (li == 1 && g == 0) ? c10 : al;
-      al = (li == 2 && g == 0) ? c20 : al;
-      al = (li == 3 && g == 0) ? c30 : al;
-      al = (li == 2 && g == 1) ? c21 : al;
-      al = (li == 3 && g == 1) ? c31 : al;
-      al = (li == 3 && g == 2) ? c32 : al;
-      const double rg = (g == 0) ? r0 : (g == 1) ? r1 : (g == 2) ? r2 : r3;
+      // A operand of the in-block transform: lane (li, g) <- Linv4[li][g].  At most one of the 0/1 lane weights is set per lane, so the
+      // sum is a selection; written as a tree of fused multiply-adds (depth 3) instead of a chain of twelve dependent v_cndmask
+      const double al = (fma(w10, c10, wdg) + fma(w20, c20, w30 * c30)) + (fma(w21, c21, w31 * c31) + w32 * c32);
+      double rg = r0;
+      rg = is_g1 ? r1 : rg;
+      rg = is_g2 ? r2 : rg;
+      rg = is_g3 ? r3 : rg;
       const double4_t u4 = __builtin_amdgcn_mfma_f64_16x16x4f64(al, xa[s4], zero4, 0, 0, 0);
       const double4_t m4 = __builtin_amdgcn_mfma_f64_16x16x4f64(al, xm[s4], zero4, 0, 0, 0);
       const double u = u4[0], mv = m4[0];   // this lane's entry of the finished pivot row of its group / of the same row of the inverse

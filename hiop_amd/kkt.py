@@ -390,8 +390,9 @@ class KKTLinSysSparseCondensed:
         return bool(ok.value)
 
     def inner_kind(self) -> str:
-        """'dense' (LDL^T of the expanded matrix), 'bordered' (bordered-diagonal direct solver) or 'pcg'"""
-        return ("dense", "bordered", "pcg")[self.ctx._L.hiopamd_kkt_sparse_condensed_inner_kind(self.h)]
+        """'dense' (LDL^T of the expanded matrix), 'bordered' (bordered-diagonal direct solver), 'pcg' or 'sparse_ldl' (nested
+        dissection + multifrontal LDL^T + dense root)"""
+        return ("dense", "bordered", "pcg", "sparse_ldl")[self.ctx._L.hiopamd_kkt_sparse_condensed_inner_kind(self.h)]
 
     def set_inner_solver(self, tol, max_iter):
         check(self._L.hiopamd_kkt_sparse_condensed_set_inner_solver(self.h, C.c_double(tol), int(max_iter)), "set_inner_solver")

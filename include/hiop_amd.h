@@ -397,6 +397,27 @@ int hiopamd_arrow_ldl_destroy(hiopamd_arrow_ldl* s);
 int hiopamd_arrow_ldl_border(const hiopamd_arrow_ldl* s, int* p_host, int* border_host);
 int hiopamd_arrow_ldl_factorize(hiopamd_arrow_ldl* s, const double* csr_values, int* n_neg_host, int* n_zero_host);
 int hiopamd_arrow_ldl_solve(hiopamd_arrow_ldl* s, double* x_inout);
+
+/* General sparse symmetric direct solver M = P^T L D L^T P (csrc/sparse_ldl.hip; the sparse-Cholesky role of
+ * hiopKKTLinSysSparseCondensed.cpp:469-496 for patterns that are neither small nor bordered diagonals): nested-dissection ordering,
+ * supernodal multifrontal factorisation by tree levels on the device (fronts of <= 128 rows in LDS), the top of the tree as ONE dense
+ * root factored by hiopamd_linsolver.  No numerical pivoting: n_neg / n_zero are the counts of pivots below -1e-14 / of magnitude below
+ * 1e-14, M is positive definite <=> both are 0 — a verdict that does not depend on any right-hand side.
+ * Pattern = full symmetric CSR on the host, columns ascending inside a row, diagonal structurally full; values = device array aligned
+ * with it.  create returns HIOPAMD_ERR_STATE when the dense root would exceed 20480 (large patterns without small separators).
+ * _analyse / _plan are host-only (no device): the ordering and the gather plans, for tests that replay the numeric phase. */
+typedef struct hiopamd_sparse_ldl hiopamd_sparse_ldl;
+int hiopamd_sparse_ldl_create(hiopamd_sparse_ldl** out, hiopamd_ctx* ctx, int n, const int* rowptr_host, const int* colidx_host);
+int hiopamd_sparse_ldl_destroy(hiopamd_sparse_ldl* s);
+int hiopamd_sparse_ldl_info(const hiopamd_sparse_ldl* s, int64_t* info8_host);   /* supernodes, fronts, levels, root order, nnz(L) */
+int hiopamd_sparse_ldl_factorize(hiopamd_sparse_ldl* s, const double* csr_values, int* n_neg_host, int* n_zero_host);
+int hiopamd_sparse_ldl_solve(hiopamd_sparse_ldl* s, double* x_inout);
+int hiopamd_sparse_ldl_analyse(int n, const int* rowptr_host, const int* colidx_host, int64_t* info8_host, int* perm_host);
+int hiopamd_sparse_ldl_plan(int n, const int* rowptr_host, const int* colidx_host, int64_t* sizes16, int* level_ptr, int* f_nc, int* f_nr,
+                            int64_t* f_lofs, int64_t* f_uofs, int64_t* f_vofs, int64_t* f_iofs, int* fidx, int* mat_dest, int64_t* mat_ptr,
+                            int64_t* mat_src, int64_t* mat_front, int* vec_dest, int64_t* vec_ptr, int64_t* vec_src, int64_t* vec_front,
+                            int* rmat_dest, int64_t* rmat_ptr, int64_t* rmat_src, int* rvec_dest, int64_t* rvec_ptr, int64_t* rvec_src,
+                            int* root_old);
 int hiopamd_csr_condensed_pattern(const hiopamd_csr_condensed* c, int* rowptr_host, int* colidx_host);
 const int* hiopamd_csr_condensed_rowptr(const hiopamd_csr_condensed* c);   /* device */
 const int* hiopamd_csr_condensed_colidx(const hiopamd_csr_condensed* c);   /* device */
@@ -458,7 +479,9 @@ int hiopamd_kkt_sparse_condensed_set_inner_solver(hiopamd_kkt_sparse_condensed* 
 int hiopamd_kkt_sparse_condensed_last_solve(const hiopamd_kkt_sparse_condensed* k, int* flag_host, double* iters_host,
                                             double* rel_resid_host);
 int hiopamd_kkt_sparse_condensed_dims(const hiopamd_kkt_sparse_condensed* k, int* dims4_host /* nx, nineq, nnzJ, nnzH */);
-/* the inner solver in use: 0 dense LDL^T of the expanded matrix (nx <= 4096), 1 bordered-diagonal direct solver, 2 PCG + Jacobi */
+/* the inner solver in use: 0 dense LDL^T of the expanded matrix (nx <= 4096), 1 bordered-diagonal direct solver (border <= 32),
+ * 3 general sparse LDL^T (hiopamd_sparse_ldl: nested dissection + multifrontal + dense root), 2 PCG + Jacobi (only when the sparse LDL^T's
+ * dense root would exceed its limit) */
 int hiopamd_kkt_sparse_condensed_inner_kind(const hiopamd_kkt_sparse_condensed* k);
 hiopamd_csr_condensed* hiopamd_kkt_sparse_condensed_matrix(hiopamd_kkt_sparse_condensed* k);
 double* hiopamd_kkt_sparse_condensed_Hd(hiopamd_kkt_sparse_condensed* k);
