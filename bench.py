@@ -461,14 +461,26 @@ def main():
     L = lib()
     expected_neg = p.neq + p.nineq
 
+    # The step calls the C ABI the way a C++ caller (the HiOp-side adapter) does: raw device addresses resolved ONCE — every operand is a
+    # persistent buffer written before the timed region and synchronised —, one ctypes call per entry point.  (The test wrappers of
+    # hiop_amd/kkt.py re-resolve every tensor per call and order the context's stream behind torch's current stream each time: six event
+    # records + waits per solveCompressed, ~0.15 ms of harness per step that is not part of the path being measured.)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    p_rx, p_ryc, p_ryd, p_ryd0, p_dx, p_dyc, p_dyd = P(rx), P(ryc), P(ryd), P(ryd0), P(dx), P(dyc), P(dyd)
+    nbytes_ryd = ryd.numel() * 8
+    n_neg = C.c_int(0)
+    z = C.c_double(0.0)
+
     def step():
-        kg.build_kkt_matrix(0.0, 0.0, 0.0, 0.0)
-        nneg = kg.factorize_with_curv_check()
-        if nneg != expected_neg:
-            raise RuntimeError(f"wrong inertia {nneg} != {expected_neg}")
+        rc = L.hiopamd_kkt_mds_build(kg.h, z, z, z, z)
+        rc = rc or L.hiopamd_kkt_mds_factorize(kg.h, C.byref(n_neg))
+        if rc != 0 or n_neg.value != expected_neg:
+            raise RuntimeError(f"status {rc}, inertia {n_neg.value} != {expected_neg}")
         for _ in range(a.solves):
-            L.hiopamd_copy_d2d(ctx.h, C.c_void_p(ryd.data_ptr()), C.c_void_p(ryd0.data_ptr()), ryd.numel() * 8)
-            kg.solve_compressed(rx, ryc, ryd, dx, dyc, dyd)
+            rc = L.hiopamd_copy_d2d(ctx.h, p_ryd, p_ryd0, nbytes_ryd)
+            rc = rc or L.hiopamd_kkt_mds_solve_compressed(kg.h, p_rx, p_ryc, p_ryd, p_dx, p_dyc, p_dyd)
+            if rc != 0:
+                raise RuntimeError(f"solve_compressed status {rc}")
 
     def barrier():
         ctx.sync()

@@ -248,6 +248,7 @@ int hiopamd_kkt_sparse_condensed_factorize(hiopamd_kkt_sparse_condensed* k, int*
   RC(hiopamd_csr_condensed_diagonal(k->csr, diag));
   int64_t nonpos = 0;
   int finite = 1;
+  ReduceNow now(k->ctx);   // the values are used right below: not to be parked in a caller's reduction bracket
   RC(hiopamd_vec_num_elems_less_than(k->ctx, k->nx, diag, std::numeric_limits<double>::min(), &nonpos));
   RC(hiopamd_vec_isfinite(k->ctx, k->nx, diag, &finite));
   *n_neg_host = (nonpos > 0 || !finite) ? -1 : 0;

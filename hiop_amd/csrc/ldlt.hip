@@ -1172,8 +1172,10 @@ int ldlt_rankk_update(hiopamd_ctx* ctx, double* A, int64_t lda, int N, const dou
 __global__ __launch_bounds__(kBlock) void ldlt_inertia_kernel(int N, const double* __restrict__ A, int64_t lda,
                                                               int* __restrict__ out3)
 {
+  // one diagonal entry per thread, N / 256 workgroups, integer atomics onto the three (zeroed) counters: the entries are 8 (lda + 1)
+  // bytes apart — one memory round trip each —, and a single workgroup walking all of them took 18 us at N = 8192
   int pos = 0, neg = 0, nul = 0;
-  for(int i = threadIdx.x; i < N; i += kBlock) {
+  for(int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
     const double d = A[(int64_t)i * lda + i];
     if(d < -1e-14) ++neg;
     else if(d < 1e-14) ++nul;   // includes NaN? no: NaN compares false twice -> counted below
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(kBlock) void ldlt_inertia_kernel(int N, const doubl
   if(threadIdx.x < 3) {
     int v = 0;
     for(int w = 0; w < kBlock / 64; ++w) v += sm[threadIdx.x][w];
-    out3[threadIdx.x] = v;
+    if(v) atomicAdd(out3 + threadIdx.x, v);
   }
 }
 
@@ -2430,7 +2432,6 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     return HIOPAMD_OK;
   }
   hipStream_t st = ctx->stream;
-  HIOPAMD_CHECK(hipMemsetAsync(d_info, 0, 4 * sizeof(int), st));
   const int64_t ldv = N;
   // LOOK-AHEAD on two CU-masked streams (ctx_cu_split): `sd` owns the reserved CUs (two per XCD by default) and runs the serial chain
   // of the factorisation without ever leaving its stream; `su` owns the other CUs (240 with the default of two reserved CUs per XCD) and runs the wide work.
@@ -2508,7 +2509,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       std::fprintf(stderr, "[hiop_amd] another process holds this device's dataflow-LDL^T lock: this factorisation (and any other that finds the lock taken) runs the stepwise kernels\n");
     }
   }
-  {
+  if(!use_df) {   // (the dataflow path does both in its one preparation launch, ldlt_df_prep_kernel)
+    HIOPAMD_CHECK(hipMemsetAsync(d_info, 0, 4 * sizeof(int), st));
     const Panel p0 = panel(0);
     hipLaunchKernelGGL(ldlt_pack_diag_kernel, dim3(LD_NB), dim3(kBlock), 0, st, A, lda, p0.K0, p0.kbs, p0.Cj);
   }
@@ -2531,8 +2533,10 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.off_wg = P.off_wg;       // (the init kernel publishes these two offsets in the flags' header: set before its launch)
     a.off_snap = P.off_snap;
     a.off_where = P.off_where;
-    HIOPAMD_CHECK(hipMemsetAsync(df->flags, 0, sizeof(unsigned) * (size_t)P.nflags, st));
-    hipLaunchKernelGGL(ldlt_df_init_kernel, dim3(1), dim3(kBlock), 0, st, a);
+    {
+      const int nzb = (int)(((int64_t)P.nflags + (int64_t)kBlock * 16 - 1) / ((int64_t)kBlock * 16));
+      hipLaunchKernelGGL(ldlt_df_prep_kernel, dim3(LD_NB + nzb), dim3(kBlock), 0, st, a, (int64_t)P.nflags, panel(0).kbs);
+    }
     int rc = dep(st, su);
     if(rc == HIOPAMD_OK) rc = dep(st, sd);
     if(rc != HIOPAMD_OK) return rc;
@@ -2657,7 +2661,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   }
   hipLaunchKernelGGL(ldlt_unpack_diag_kernel, dim3(64, nsp), dim3(kBlock), 0, st, Cd, A, lda, N, Cd + cdt_ofs);
   span_begin(ctx, HIOPAMD_SPAN_LINSOLV_INERTIA);   // :127-167 (tmInertiaComp)
-  hipLaunchKernelGGL(ldlt_inertia_kernel, dim3(1), dim3(kBlock), 0, st, N, A, lda, d_info + 1);
+  hipLaunchKernelGGL(ldlt_inertia_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, N, A, lda, d_info + 1);   // (d_info was zeroed at the start)
   span_end(ctx, HIOPAMD_SPAN_LINSOLV_INERTIA);
   if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv, wB);
   if(Winv && wB == 512 && Wt) {

@@ -241,7 +241,7 @@ __device__ __forceinline__ bool df_wait(unsigned* flags, const DfWait& w, int* s
                 df_st(flags + 10, (unsigned)(w.f[q] - flags));
                 df_st(flags + 11, (unsigned)((now - t_wait) >> 4));    // how long this wait lasted, 160 ns units
                 // what every workgroup / role holds NOW (before anybody reacts to the abort word): flags[14] = offset of the state words,
-                // flags[15] = offset of the snapshot area (both written by ldlt_df_init_kernel; 0: no snapshot)
+                // flags[15] = offset of the snapshot area (both written by ldlt_df_prep_kernel; 0: no snapshot)
                 if(const unsigned ow = df_ld(flags + 14), os = df_ld(flags + 15); ow != 0u && os != 0u)
                   for(unsigned q2 = 0; q2 < 1024u; ++q2) df_st(flags + os + q2, df_ld(flags + ow + q2));
               }
@@ -1431,12 +1431,31 @@ __global__ __launch_bounds__(kBlock, 1) void ldlt_df_one_kernel(const DfArgs a)
   }
 }
 
-// compact copy of diagonal block 0 + the pre-credits of super-panel 0's tile versions
-__global__ __launch_bounds__(kBlock) void ldlt_df_init_kernel(const DfArgs a)
+// Everything a dataflow factorisation needs before its two kernels start, in ONE launch (round 5; before: memset of the info words, the
+// pack kernel, a memset of the flags — two fill kernels —, this kernel: five dependent launches, ~45 us of launch gaps per factorisation):
+//   blocks 0 .. 255                 row blockIdx.x of the compact copy of diagonal block 0 (ldlt_pack_diag_kernel's work)
+//   blocks 256 .. 256 + nzb - 1     zero the flag words (kBlock * 16 per block), with the pre-credits of super-panel 0's tile versions
+//                                   (cv = 4) and the two header words (offsets of the state words / of the snapshot area) in place;
+//                                   block 256 also zeroes the four info words
+__global__ __launch_bounds__(kBlock) void ldlt_df_prep_kernel(const DfArgs a, int64_t nflags, int kbs0)
 {
-  if(blockIdx.x == 0 && threadIdx.x < 16) a.flags[a.off_chain + DF_CV + threadIdx.x] = 4u;
-  if(blockIdx.x == 0 && threadIdx.x == 16) {
-    a.flags[14] = (unsigned)a.off_wg;
-    a.flags[15] = (unsigned)a.off_snap;
+  if(blockIdx.x < (unsigned)LD_NB) {
+    const int r = blockIdx.x, c = threadIdx.x;
+    a.Cd[r * LD_NB + c] = (r < kbs0 && c < kbs0 && c >= r) ? a.A[(int64_t)r * a.lda + c] : 0.0;
+    return;
+  }
+  const int64_t b = (int64_t)(blockIdx.x - LD_NB);
+  if(b == 0 && threadIdx.x < 4) a.info[threadIdx.x] = 0;
+  const int64_t cv0 = a.off_chain + DF_CV;
+#pragma unroll 4
+  for(int q = 0; q < 16; ++q) {
+    const int64_t w = (b * 16 + q) * kBlock + threadIdx.x;
+    if(w < nflags) {
+      unsigned v = 0u;
+      if(w >= cv0 && w < cv0 + 16) v = 4u;
+      else if(w == 14) v = (unsigned)a.off_wg;
+      else if(w == 15) v = (unsigned)a.off_snap;
+      a.flags[w] = v;
+    }
   }
 }

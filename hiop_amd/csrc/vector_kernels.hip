@@ -540,19 +540,14 @@ int hiopamd_vec_isinf(hiopamd_ctx* ctx, int64_t n, const double* x, int* out)
   *out = (c > 0.0) ? 1 : 0;
   return st;
 }
+// (deferrable: inside hiopamd_ctx_reduce_begin / _end, or a ReduceBatch of the library, *out is written when the bracket is closed)
 int hiopamd_vec_num_elems_less_than(hiopamd_ctx* ctx, int64_t n, const double* x, double val, int64_t* out)
 {
-  double c = 0.0;
-  int st = count_pred(ctx, n, PredLess{x, val}, &c);
-  *out = (int64_t)c;
-  return st;
+  return launch_reduce_fin<double>(ctx, n, OpCount<PredLess>{PredLess{x, val}}, [out](const double& c) { *out = (int64_t)c; }, true);
 }
 int hiopamd_vec_num_elems_abs_less_than(hiopamd_ctx* ctx, int64_t n, const double* x, double val, int64_t* out)
 {
-  double c = 0.0;
-  int st = count_pred(ctx, n, PredAbsLess{x, val}, &c);
-  *out = (int64_t)c;
-  return st;
+  return launch_reduce_fin<double>(ctx, n, OpCount<PredAbsLess>{PredAbsLess{x, val}}, [out](const double& c) { *out = (int64_t)c; }, true);
 }
 
 // ---- order-preserving pattern compaction ----
