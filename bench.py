@@ -176,6 +176,16 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
     xs = [x.clone(), x.clone()]           # the iterate alternates between two buffers (no allocation inside the step)
     g = torch.empty_like(x)
 
+    # the C ABI called like a C++ caller does: device addresses resolved once (persistent buffers), one ctypes call per entry point
+    # (see the same remark at the MDS step below)
+    Lh = ctx._L
+    PP = lambda t: C.c_void_p(t.data_ptr())
+    p_xs = [PP(xs[0]), PP(xs[1])]
+    p_g, p_Jc, p_Jd, p_yc, p_yd, p_Dx, p_Dd = PP(g), PP(Jc), PP(Jd) if mi > 0 else C.c_void_p(0), PP(yc), PP(yd), PP(Dx), PP(Dd)
+    p_rx, p_rx0, p_ryc, p_ryd, p_dx, p_dyc, p_dyd = PP(rx), PP(rx0), PP(ryc), PP(ryd), PP(dx), PP(dyc), PP(dyd)
+    stored, okc = C.c_int(0), C.c_int(0)
+    nbytes_rx = rx.numel() * 8
+
     def step(i):
         # the stand-in for the NLP side (new iterate, its gradient) runs on the CONTEXT's stream like everything else: no
         # cross-stream hand-off, no host synchronisation besides the ones the reference's API implies (update() returns
@@ -183,12 +193,13 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
         xn, xo = xs[(i + 1) & 1], xs[i & 1]
         torch.add(xo, steps_x[i % 4], out=xn)
         torch.mul(q, xn, out=g)
-        H.update(xn, g, Jc, Jd, yc, yd)
-        K.update_diag(Dx, Dd, Jc, Jd)
+        rc = Lh.hiopamd_hess_lowrank_update(H.h, p_xs[(i + 1) & 1], p_g, p_Jc, p_Jd, p_yc, p_yd, C.byref(stored))
+        rc = rc or Lh.hiopamd_kkt_lowrank_update_diag(K.h, p_Dx, p_Dd, p_Jc, p_Jd)
         for _ in range(a.solves):
-            rx.copy_(rx0)
-            if not K.solve_compressed(rx, ryc, ryd, dx, dyc, dyd):
-                raise RuntimeError("reduced system not SPD")
+            rc = rc or Lh.hiopamd_copy_d2d(ctx.h, p_rx, p_rx0, nbytes_rx)
+            rc = rc or Lh.hiopamd_kkt_lowrank_solve_compressed(K.h, p_rx, p_ryc, p_ryd, p_dx, p_dyc, p_dyd, C.byref(okc))
+            if rc != 0 or not okc.value:
+                raise RuntimeError(f"status {rc}; reduced system SPD: {okc.value}")
 
     def barrier():
         ctx.sync(); torch.cuda.synchronize()
@@ -281,7 +292,7 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
     return out
 
 
-def sparse_condensed_bench(ctx, a, n=1_000_000):
+def sparse_condensed_bench(ctx, a, n=1_000_000, pattern="sparse_ex2"):
     """BASELINE configs[4] (sparse condensed KKT + Krylov, the SpMV path): hiopKKTLinSysCondensedSparse on the SparseEx2 pattern
     (hiop_amd/problems.py::sparse_ex2_ineq: n variables, n - 1 two-entry inequality rows, diagonal Hessian), n = 1e6.
     One step = new barrier diagonals -> build_kkt_matrix (CSR J^T D J + H + Dx, numeric phase on the cached symbolic analysis) ->
@@ -293,7 +304,8 @@ def sparse_condensed_bench(ctx, a, n=1_000_000):
     from hiop_amd.kkt import KKTLinSysSparseCondensed
     from hiop_amd.runtime import dev
     rng = np.random.Generator(np.random.PCG64(5))
-    p = pr.sparse_ex2_ineq(n, x=rng.uniform(0.5, 2.0, n))
+    # pattern "chain": a banded condensed matrix (hiop_amd/problems.py::sparse_chain_ineq) — the general sparse LDL^T's case
+    p = pr.sparse_ex2_ineq(n, x=rng.uniform(0.5, 2.0, n)) if pattern == "sparse_ex2" else pr.sparse_chain_ineq(n, couple=3)
     t0 = time.perf_counter()
     K = KKTLinSysSparseCondensed(ctx, p.nx, p.nineq, p.Jd_i, p.Jd_j, p.H_i, p.H_j)
     t_symbolic = time.perf_counter() - t0
@@ -305,15 +317,28 @@ def sparse_condensed_bench(ctx, a, n=1_000_000):
     torch.cuda.synchronize()
     its = []
 
+    # direct C ABI calls on resolved addresses (see the remark at the MDS step)
+    import ctypes as C
+    Ls = ctx._L
+    PP = lambda t: C.c_void_p(t.data_ptr())
+    p_Jv, p_Hv, p_Dxs, p_Dds = PP(Jv), PP(Hv), [PP(t) for t in Dxs], [PP(t) for t in Dds]
+    p_rx, p_rd, p_ryd, p_dx, p_dd, p_dyd = PP(rx), PP(rd), PP(ryd), PP(dx), PP(dd), PP(dyd)
+    nneg, okc, flag = C.c_int(0), C.c_int(0), C.c_int(0)
+    itd, reld = C.c_double(0.0), C.c_double(0.0)
+    z = C.c_double(0.0)
+
     def step(i):
-        K.set_values(Jv, Hv, Dxs[i & 1], Dds[i & 1])
-        K.build_kkt_matrix(0.0, 0.0)
-        if K.factorize() != 0:
-            raise RuntimeError("condensed matrix not positive definite")
+        rc = Ls.hiopamd_kkt_sparse_condensed_set_values(K.h, p_Jv, p_Hv, p_Dxs[i & 1], p_Dds[i & 1])
+        rc = rc or Ls.hiopamd_kkt_sparse_condensed_build(K.h, z, z)
+        rc = rc or Ls.hiopamd_kkt_sparse_condensed_factorize(K.h, C.byref(nneg))
+        if rc != 0 or nneg.value != 0:
+            raise RuntimeError(f"status {rc}; condensed matrix positive definite: {nneg.value == 0}")
         for _ in range(a.solves):
-            if not K.solve_compressed(rx, rd, ryd, dx, dd, dyd):
+            rc = Ls.hiopamd_kkt_sparse_condensed_solve_compressed(K.h, p_rx, p_rd, p_ryd, p_dx, p_dd, p_dyd, C.byref(okc))
+            if rc != 0 or not okc.value:
                 raise RuntimeError("inner solve failed")
-            its.append(K.last_solve()[1])
+            Ls.hiopamd_kkt_sparse_condensed_last_solve(K.h, C.byref(flag), C.byref(itd), C.byref(reld))
+            its.append(itd.value)
 
     for i in range(max(a.warmup, 1)):
         step(i)
@@ -330,12 +355,13 @@ def sparse_condensed_bench(ctx, a, n=1_000_000):
              "pcg": "PCG + Jacobi, tol 1e-12", "dense": "dense LDL^T of the expanded matrix",
              "sparse_ldl": "sparse LDL^T: nested dissection, multifrontal by tree levels, dense root (exact inertia)"}[kind]
     out = dict(value=a.steps / dt, unit="KKT iterations/s", ms_per_step=1e3 * dt / a.steps,
-               workload=f"NlpSparse condensed KKT (SparseEx2 pattern, inequality-only form): n={n}, m={p.nineq}, nnz(Jd)={nnzJ}; step = "
+               workload=f"NlpSparse condensed KKT ({'SparseEx2 pattern' if pattern == 'sparse_ex2' else 'chain constraints of 3 variables: banded condensed matrix'}, inequality-only form): n={n}, m={p.nineq}, nnz(Jd)={nnzJ}; step = "
                         f"build (CSR J^T D J + H + Dx, numeric) + factorize + {a.solves} solveCompressed ({inner})",
                inner_solver=kind, pcg_iterations_per_solve=float(np.mean(its)) if its else None, symbolic_analysis_s=t_symbolic,
                note="the sparse DIRECT solver of the reference's condensed path (MA57 / cuSOLVER Cholesky) is not in the image and not in the "
-                    "reference tree (SURVEY 8c); its role is taken by the bordered-diagonal factorisation for patterns like this one and by "
-                    "PCG for general patterns — a measured number, not a parity claim")
+                    "reference tree (SURVEY 8c); its role is taken by the bordered-diagonal factorisation for arrowhead patterns, by the general sparse "
+                    "LDL^T (nested dissection + multifrontal + dense root, csrc/sparse_ldl.hip) for other patterns, and by PCG only when "
+                    "that solver's dense root would exceed its limit — a measured number, not a parity claim")
     K.close()
     return out
 
@@ -599,11 +625,16 @@ def main():
             dense_c2 = dense_lowrank_bench(ctx, world, rank, a2, dist, rooflines=True)
 
     sparse_c5 = None
+    sparse_banded = None
     if world == 1 and not a.no_dense:
         try:
             sparse_c5 = sparse_condensed_bench(ctx, a)
         except Exception as e:      # an auxiliary entry must not take the headline line down
             sparse_c5 = {"error": repr(e)}
+        try:
+            sparse_banded = sparse_condensed_bench(ctx, a, pattern="chain")
+        except Exception as e:
+            sparse_banded = {"error": repr(e)}
 
     ipm_e2e = None
     if world == 1 and not a.no_dense:
@@ -634,6 +665,8 @@ def main():
             out["dense_n1e6_m100"] = dense_c2
         if sparse_c5 is not None:
             out["sparse_condensed_n1e6"] = sparse_c5
+        if sparse_banded is not None:
+            out["sparse_condensed_banded_n1e6"] = sparse_banded
         if ipm_e2e is not None:
             out["ipm_end_to_end_N8192"] = ipm_e2e
         if world == 1 and not a.no_cpu_baseline:

@@ -238,6 +238,18 @@ def sparse_ex2_ineq(n: int, x: np.ndarray | None = None, scal: float = 1.0) -> S
     return SparseIneqProblem(n, m, np.array(Ji, np.int32), np.array(Jj, np.int32), np.array(Jv), Hi, Hi.copy(), Hv)
 
 
+def sparse_chain_ineq(n: int, couple: int = 2, seed: int = 7) -> SparseIneqProblem:
+    """A sparse inequality-only problem whose condensed matrix is BANDED (synthetic; the reference's sparse examples are all arrowheads):
+    rows d_i = sum_{q < couple} a_iq x_{i+q}, i = 0 .. n - couple, diagonal Hessian — M = H + Dx + Jd^T Dd Jd has bandwidth couple - 1.
+    The pattern the general sparse LDL^T (csrc/sparse_ldl.hip) is for."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    m = n - couple + 1
+    Ji = np.repeat(np.arange(m), couple).astype(np.int32)
+    Jj = (Ji + np.tile(np.arange(couple), m)).astype(np.int32)
+    Hi = np.arange(n, dtype=np.int32)
+    return SparseIneqProblem(n, m, Ji, Jj, r.uniform(0.5, 1.5, Ji.size), Hi, Hi.copy(), r.uniform(0.5, 2.0, n))
+
+
 def sparse_ex2_nlp(n: int, convex_obj: bool = False, rankdefic_eq: bool = True, rankdefic_ineq: bool = True, scal_neg_obj: float = 0.1):
     """The reference's SparseEx2 as a whole NLP (src/Drivers/Sparse/NlpSparseEx2.{hpp,cpp}: objective :126-143, constraints :156-186,
     bounds :52-110, start :319-326), with the driver's settings as defaults (NlpSparseEx2Driver.cpp:219-222):
