@@ -13,21 +13,20 @@
 // permutation; L is unit lower triangular and stored in the strict lower part, d on the diagonal, the off-diagonal entry of a
 // 2 x 2 block in e[k] (the matrix position a(k+1, k) is zeroed).  Pivots (LAPACK's IPIV) and D are LAPACK's.
 //
-// Device mapping.  A column step is three launches on the context's stream; the decisions stay on the device (BkState) and the host
-// never waits for them -- a launch whose column turned out to be the second half of a 2 x 2 pivot returns at once:
-//   bk_column_kernel<false>  updated column k into W(:, kw), |.| maximum below the diagonal per workgroup; the LAST workgroup to finish
-//                            folds the partial maxima and takes the first decision (1 x 1 without interchange, or "look at row imax")
-//   bk_column_kernel<true>   (if asked for) updated column imax of the symmetric matrix into W(:, kw + 1), its off-diagonal maximum,
-//                            the final decision: pivot position kp, 1 x 1 or 2 x 2
-//   bk_apply_kernel          interchange kk <-> kp (rows of L in all previous columns, rows of W, the not yet updated column kk of A to
-//                            position kp), the column(s) of L and the block of D from W; the last workgroup records IPIV / P and moves
-//                            to the next column
-// Everything a thread writes depends only on its own row plus a handful of scalars the deciding workgroup saved in BkState, so no
-// launch has an internal ordering requirement.  Once per panel the host reads the panel's end (it depends on where 2 x 2 pivots
-// fell) and launches the trailing update: the stepwise LDL^T's fp64-MFMA rank-K kernel (ldlt.hip) with V = W, U = the L rows.
-// Cost at N = 8192: ~ 3 x 8192 small launches (latency-bound, ~ 0.1-0.2 s) + 2 N^3 / 3 flops of MFMA updates; a solve is 2 x N / 64
-// block steps (one-wave 64 x 64 triangular solve + a skinny GEMV).  This is the exceptional path: the fast path stays the no-pivot
-// dataflow factorisation.
+// Device mapping (round 5).  A panel of 64 columns is ONE launch of <= 32 workgroups (bk_panel_kernel); a column step is three PHASES
+// separated by grid barriers, and the decisions never leave the device:
+//   phase A   updated column k into W(:, kw), |.| maximum below the diagonal per workgroup; behind the barrier every workgroup folds the
+//             partial maxima and takes the first decision (1 x 1 without interchange, or "look at row imax")
+//   phase B   (if asked for) updated column imax of the symmetric matrix into W(:, kw + 1), its off-diagonal maximum, the final
+//             decision: pivot position kp, 1 x 1 or 2 x 2
+//   phase C   interchange kk <-> kp (rows of L in all previous columns, rows of W, the not yet updated column kk of A to position kp),
+//             the column(s) of L and the block of D from W; workgroup 0 records IPIV / P
+// Everything a thread writes in a phase depends only on its own row plus the decision's handful of scalars, so no phase has an internal
+// ordering requirement (tests/test_ldlt_bk_protocol.py replays the phases one thread at a time in random order).  Once per panel the
+// host reads the panel's end (it depends on where 2 x 2 pivots fell) and launches the trailing update: the stepwise LDL^T's fp64-MFMA
+// rank-K kernel (ldlt.hip) with V = W, U = the L rows.  Rounds 1-4 ran the three phases as three LAUNCHES per column (3 x 8192 launches
+// at N = 8192: 173 ms; scripts/probes/retired/ldlt_bk_three_launch_kernels.hip.txt).  A solve is 2 x N / 64 block steps (one-wave
+// 64 x 64 triangular solve + a skinny GEMV).  This is the exceptional path: the fast path stays the no-pivot dataflow factorisation.
 #include "device_utils.hpp"
 
 #include <climits>
@@ -65,228 +64,282 @@ __device__ __forceinline__ void bk_argmax_combine(double& v, int& i, double v2, 
   }
 }
 
-// W(k:n, col) = [column src of the symmetric matrix](k:n) - A(k:n, k0:k-1) W(src, 0:kw-1)^T;  col = kw (src = k) or kw + 1 (src = imax)
-template <bool SECOND>
-__global__ __launch_bounds__(kBlock) void bk_column_kernel(int n, int k, int k0, const double* __restrict__ A, int64_t lda,
-                                                           double* __restrict__ Wb, int64_t ldw, BkState* __restrict__ st,
-                                                           double* __restrict__ pval, int* __restrict__ pidx)
-{
-  __shared__ double coef[BK_NB];
-  __shared__ int sh_go, sh_src, sh_last;
-  __shared__ double rv[kBlock / 64];
-  __shared__ int ri[kBlock / 64];
-  const int tid = threadIdx.x;
-  if(tid == 0) {
-    sh_go = (st->next_k == k) && (!SECOND || st->need2);
-    sh_src = SECOND ? st->imax : k;
-  }
-  __syncthreads();
-  if(!sh_go) return;
-  const int kw = k - k0, col = SECOND ? kw + 1 : kw, src = sh_src;
-  for(int p = tid; p < kw; p += kBlock) coef[p] = Wb[(int64_t)p * ldw + src];
-  __syncthreads();
-  double best = -1.0;
-  int bidx = INT_MAX;
-#pragma unroll
-  for(int q = 0; q < BK_RPT; ++q) {
-    const int i = k + blockIdx.x * BK_ROWS + q * kBlock + tid;
-    if(i < n) {
-      double v = (!SECOND || i >= src) ? A[(int64_t)src * lda + i] : A[(int64_t)i * lda + src];
-      const double* Ap = A + (int64_t)k0 * lda + i;
-      for(int p = 0; p < kw; ++p) v -= Ap[(int64_t)p * lda] * coef[p];
-      Wb[(int64_t)col * ldw + i] = v;
-      const bool cand = SECOND ? (i != src) : (i > k);
-      if(cand) bk_argmax_combine(best, bidx, fabs(v), i);
-    }
-  }
-  for(int off = 32; off > 0; off >>= 1) {
-    const double v2 = __shfl_down(best, off, 64);
-    const int i2 = __shfl_down(bidx, off, 64);
-    bk_argmax_combine(best, bidx, v2, i2);
-  }
-  if((tid & 63) == 0) {
-    rv[tid >> 6] = best;
-    ri[tid >> 6] = bidx;
-  }
-  __syncthreads();
-  if(tid == 0) {
-    for(int w = 1; w < kBlock / 64; ++w) bk_argmax_combine(best, bidx, rv[w], ri[w]);
-    pval[blockIdx.x] = best;
-    pidx[blockIdx.x] = bidx;
-    __threadfence();
-    sh_last = (atomicAdd(&st->cnt[SECOND ? 1 : 0], 1) == (int)gridDim.x - 1);
-  }
-  __syncthreads();
-  if(!sh_last || tid != 0) return;
-  // ---- the last workgroup decides ----
-  __threadfence();
-  st->cnt[SECOND ? 1 : 0] = 0;
-  best = -1.0;
-  bidx = INT_MAX;
-  for(int b = 0; b < (int)gridDim.x; ++b) bk_argmax_combine(best, bidx, __builtin_nontemporal_load(pval + b), __builtin_nontemporal_load(pidx + b));
-  if(!SECOND) {
-    const double wkk = __builtin_nontemporal_load(Wb + (int64_t)kw * ldw + k);
-    const double absakk = fabs(wkk);
-    const double colmax = (best >= 0.0) ? best : 0.0;
-    const int imax = (best >= 0.0) ? bidx : k;
-    st->absakk = absakk;
-    st->colmax = colmax;
-    st->imax = imax;
-    st->c0_k = wkk;
-    int need2 = 0;
-    if(!(fmax(absakk, colmax) > 0.0)) {   // exactly zero column (or NaN): DSYTRF's INFO = k + 1, no interchange
-      if(st->info == 0) st->info = k + 1;
-    } else if(!(absakk >= BK_ALPHA * colmax)) {
-      need2 = 1;
-    }
-    st->need2 = need2;
-    if(!need2) {
-      st->kp = k;
-      st->kstep = 1;
-      st->use_c1 = 0;
-      st->c0_kk = st->c0_kp = wkk;
-      st->c1_kk = st->c1_kp = 0.0;
-      st->akk_old = A[(int64_t)k * lda + k];
-    }
-  } else {
-    const int imax = src;
-    const double rowmax = (best >= 0.0) ? best : 0.0;
-    const double absakk = st->absakk, colmax = st->colmax;
-    const double wii = fabs(__builtin_nontemporal_load(Wb + (int64_t)(kw + 1) * ldw + imax));
-    int kp, kstep, use_c1 = 0;
-    if(absakk >= BK_ALPHA * colmax * (colmax / rowmax)) {
-      kp = k;
-      kstep = 1;
-    } else if(wii >= BK_ALPHA * rowmax) {
-      kp = imax;
-      kstep = 1;
-      use_c1 = 1;
-    } else {
-      kp = imax;
-      kstep = 2;
-    }
-    const int kk = k + kstep - 1;
-    st->kp = kp;
-    st->kstep = kstep;
-    st->use_c1 = use_c1;
-    st->c0_kk = __builtin_nontemporal_load(Wb + (int64_t)kw * ldw + kk);
-    st->c0_kp = __builtin_nontemporal_load(Wb + (int64_t)kw * ldw + kp);
-    st->c1_kk = __builtin_nontemporal_load(Wb + (int64_t)(kw + 1) * ldw + kk);
-    st->c1_kp = __builtin_nontemporal_load(Wb + (int64_t)(kw + 1) * ldw + kp);
-    st->akk_old = A[(int64_t)kk * lda + kk];
-    st->need2 = 0;
-  }
-}
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the whole panel in ONE launch.  The three launches per column above were the cost of the pivoted mode (3 x 8192 launches of
+// ~7 us at N = 8192: 173 ms); this kernel runs the same three phases for every column of a panel with grid barriers in between:
+//   G <= 8 workgroups of 1024 threads, all resident (a bounded wait turns anything else into an error, never a hang); a row i of the matrix is owned by
+//   workgroup (i / 1024) % G, thread i % 1024, for the whole panel; every global access is an agent-scope relaxed atomic (sc1: coherent
+//   across the XCDs' L2s without cache maintenance), a barrier = s_waitcnt vmcnt(0) + workgroup barrier + one counter increment + poll.
+//   Phase A  updated column k into W(:, kw), one partial |.|-maximum per workgroup            | barrier | EVERY workgroup folds the G
+//   Phase B  (only if the first decision asks for it) column imax into W(:, kw + 1), maxima   | barrier | partials and takes the same
+//   Phase C  interchange, the column(s) of L, the block of D                                  | barrier | decision (no broadcast needed)
+// The decisions, the pivots and the factor are the three-launch form's (= LAPACK's) bit for bit: the per-row arithmetic is the same text
+// and the maxima are folded with the same "first index among equals" rule, which does not depend on the order of folding.
+// Measured at N = 8192 on a random symmetric matrix (scripts/bk_time.py; 5229 column steps, 4746 of them with phase B): 157 ms against
+// 173 ms with three launches per column; per step phase A 3.3 + barrier 4.7 (incl. the wait for the slowest workgroup), phase B 5.0 +
+// two barriers 8.6, phase C 5.6 + barrier 1.6 us.  Tried and not kept (profiles/r05_probes/README.md): 32 workgroups of 256 threads
+// (186 ms: a barrier costs one atomic per workgroup on one word), the rows of the panel's L columns kept in registers (spills: 215 ms)
+// or in LDS (needs 32 workgroups again: 176 ms).
+constexpr int BK_G = 8;        // workgroups of the panel kernel: a barrier costs one atomic per workgroup on ONE word (32: 22 us per column)
+constexpr int BK_T = 1024;     // threads per workgroup: one row per thread up to n = 8192
+constexpr long long BK_BAR_TIMEOUT = 200000000ll;   // 2 s of the 100 MHz clock
 
-// interchange + the column(s) of L and the block of D; thread t owns row i = k + t of the trailing part and previous column j = t
-__global__ __launch_bounds__(kBlock) void bk_apply_kernel(int n, int k, int k0, double* __restrict__ A, int64_t lda,
-                                                          double* __restrict__ Wb, int64_t ldw, BkState* __restrict__ st,
-                                                          int* __restrict__ ipiv, int* __restrict__ perm, double* __restrict__ e)
+__device__ __forceinline__ double bk_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bk_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int bk_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bk_sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// false: the wait expired (some workgroup of the grid is not running): every workgroup leaves, the host reports an error
+__device__ __forceinline__ bool bk_grid_barrier(unsigned* bar, unsigned& target, unsigned G, int* sh_ok)
 {
-  __shared__ int sh_go, sh_kp, sh_kstep, sh_use_c1, sh_last;
-  __shared__ double sh_s[6];
-  const int tid = threadIdx.x;
-  if(tid == 0) {
-    sh_go = (st->next_k == k);
-    sh_kp = st->kp;
-    sh_kstep = st->kstep;
-    sh_use_c1 = st->use_c1;
-    sh_s[0] = st->c0_kk;
-    sh_s[1] = st->c0_kp;
-    sh_s[2] = st->c1_kk;
-    sh_s[3] = st->c1_kp;
-    sh_s[4] = st->c0_k;
-    sh_s[5] = st->akk_old;
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if(!sh_go) return;
-  const int kp = sh_kp, kstep = sh_kstep, use_c1 = sh_use_c1, kk = k + kstep - 1, kw = k - k0;
-  const double c0_kk = sh_s[0], c0_kp = sh_s[1], c1_kk = sh_s[2], c1_kp = sh_s[3], c0_k = sh_s[4], akk_old = sh_s[5];
-  const bool swp = kp != kk;
-  const int64_t t = (int64_t)blockIdx.x * kBlock + tid;
-  if(swp) {
-    if(t < k) {   // rows kk and kp of L, ALL previous columns
-      double* pa = A + t * lda;
-      const double u = pa[kk];
-      pa[kk] = pa[kp];
-      pa[kp] = u;
-    }
-    if(t < kw) {   // rows kk and kp of W, the panel's previous columns
-      double* pw = Wb + t * ldw;
-      const double u = pw[kk];
-      pw[kk] = pw[kp];
-      pw[kp] = u;
-    }
-  }
-  const int64_t i = (int64_t)k + t;
-  if(i < n) {
-    // values of the pivot column(s) at row i AFTER the interchange
-    const bool is_kk = swp && i == kk, is_kp = swp && i == kp;
-    double w0, w1 = 0.0;
-    if(is_kk) {          // gets what row kp held
-      w0 = use_c1 ? c1_kp : c0_kp;
-      w1 = c1_kp;
-    } else if(is_kp) {   // gets what row kk held
-      w0 = use_c1 ? c1_kk : c0_kk;
-      w1 = c1_kk;
-    } else {
-      w0 = use_c1 ? Wb[(int64_t)(kw + 1) * ldw + i] : Wb[(int64_t)kw * ldw + i];
-      if(kstep == 2) w1 = Wb[(int64_t)(kw + 1) * ldw + i];
-    }
-    if(use_c1 || is_kk || is_kp) Wb[(int64_t)kw * ldw + i] = w0;
-    if(kstep == 2 && (is_kk || is_kp)) Wb[(int64_t)(kw + 1) * ldw + i] = w1;
-    // the not yet updated column kk of A moves to position kp (its updated form is in W)
-    if(swp) {
-      if(i == kp) A[(int64_t)kp * lda + kp] = akk_old;
-      else if(i > kk && i < kp) A[i * lda + kp] = A[(int64_t)kk * lda + i];
-      else if(i > kp) A[(int64_t)kp * lda + i] = A[(int64_t)kk * lda + i];
-    }
-    if(kstep == 1) {
-      // row k after the interchange: kk == k
-      const double dk = swp ? (use_c1 ? c1_kp : c0_kp) : c0_k;
-      if(i == k) A[(int64_t)k * lda + k] = dk;
-      else A[(int64_t)k * lda + i] = (dk != 0.0) ? w0 * (1.0 / dk) : w0;
-    } else {
-      // D = [[W(k,kw), .], [W(k+1,kw), W(k+1,kw+1)]] after the interchange (row k is not part of it: kk = k + 1)
-      const double wk0 = c0_k;
-      const double wk10 = swp ? c0_kp : c0_kk;
-      const double wk11 = swp ? c1_kp : c1_kk;
-      if(i == k) {
-        A[(int64_t)k * lda + k] = wk0;
-      } else if(i == k + 1) {
-        A[(int64_t)k * lda + k + 1] = 0.0;   // (LAPACK keeps the off-diagonal of D here; it goes to e)
-        e[k] = wk10;
-        A[(int64_t)(k + 1) * lda + k + 1] = wk11;
-      } else {
-        double d21 = wk10;
-        const double d11 = wk11 / d21, d22 = wk0 / d21;
-        const double tt = 1.0 / (d11 * d22 - 1.0);
-        d21 = tt / d21;
-        A[(int64_t)k * lda + i] = d21 * (d11 * w0 - w1);
-        A[(int64_t)(k + 1) * lda + i] = d21 * (d22 * w1 - w0);
+  if(threadIdx.x == 0) {
+    target += G;
+    (void)__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    unsigned spins = 0;
+    long long t0 = 0;
+    while(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if((++spins & 1023u) == 0) {
+        const long long now = (long long)wall_clock64();
+        if(t0 == 0) t0 = now;
+        if(now - t0 > BK_BAR_TIMEOUT || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
       }
     }
+    *sh_ok = ok;
   }
   __syncthreads();
-  if(tid == 0) {
-    __threadfence();
-    sh_last = (atomicAdd(&st->cnt[2], 1) == (int)gridDim.x - 1);
+  return *sh_ok != 0;
+}
+
+__global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap, double* __restrict__ A, int64_t lda, double* __restrict__ Wb,
+                                                          int64_t ldw, BkState* __restrict__ st, double* __restrict__ pval,
+                                                          int* __restrict__ pidx, int* __restrict__ ipiv, int* __restrict__ perm,
+                                                          double* __restrict__ e, unsigned* __restrict__ bar)
+{
+  __shared__ double coef[BK_NB];
+  __shared__ double rv[BK_T / 64];
+  __shared__ int ri[BK_T / 64];
+  __shared__ int sh_ok;
+  // the decision of the current column, identical in every workgroup
+  __shared__ int d_need2, d_imax, d_kp, d_kstep, d_use_c1;
+  __shared__ double d_absakk, d_colmax, d_c0_k, d_c0_kk, d_c0_kp, d_c1_kk, d_c1_kp, d_akk_old;
+  const int tid = threadIdx.x;
+  const unsigned G = gridDim.x, g = blockIdx.x;
+  unsigned target = 0u;
+  int k = st->next_k;   // (written before this launch)
+  // one phase of the column kernels for the rows this workgroup owns; the workgroup's partial maximum goes to pval / pidx [g]
+  auto column_phase = [&](bool second, int src) {
+    const int kw = k - k0, col = second ? kw + 1 : kw;
+    __syncthreads();
+    for(int p = tid; p < kw; p += BK_T) coef[p] = bk_ld(Wb + (int64_t)p * ldw + src);
+    __syncthreads();
+    double best = -1.0;
+    int bidx = INT_MAX;
+    for(int blk = k / BK_T; blk * BK_T < n; ++blk) {
+      if((unsigned)blk % G != g) continue;
+      const int i = blk * BK_T + tid;
+      if(i >= k && i < n) {
+        double v = (!second || i >= src) ? bk_ld(A + (int64_t)src * lda + i) : bk_ld(A + (int64_t)i * lda + src);
+        const double* Ap = A + (int64_t)k0 * lda + i;
+        // eight loads in flight at a time (the compiler keeps atomic loads in program order and would otherwise wait for each one
+        // before the multiply-add that consumes it: up to 63 dependent round trips per row)
+        int p = 0;
+        for(; p + 8 <= kw; p += 8) {
+          double t8[8];
+#pragma unroll
+          for(int q = 0; q < 8; ++q) t8[q] = bk_ld(Ap + (int64_t)(p + q) * lda);
+#pragma unroll
+          for(int q = 0; q < 8; ++q) v -= t8[q] * coef[p + q];
+        }
+        for(; p < kw; ++p) v -= bk_ld(Ap + (int64_t)p * lda) * coef[p];
+        bk_st(Wb + (int64_t)col * ldw + i, v);
+        const bool cand = second ? (i != src) : (i > k);
+        if(cand) bk_argmax_combine(best, bidx, fabs(v), i);
+      }
+    }
+    for(int off = 32; off > 0; off >>= 1) {
+      const double v2 = __shfl_down(best, off, 64);
+      const int i2 = __shfl_down(bidx, off, 64);
+      bk_argmax_combine(best, bidx, v2, i2);
+    }
+    if((tid & 63) == 0) {
+      rv[tid >> 6] = best;
+      ri[tid >> 6] = bidx;
+    }
+    __syncthreads();
+    if(tid == 0) {
+      for(int w = 1; w < BK_T / 64; ++w) bk_argmax_combine(best, bidx, rv[w], ri[w]);
+      bk_st(pval + g, best);
+      bk_sti(pidx + g, bidx);
+    }
+  };
+  auto fold = [&](double& best, int& bidx) {
+    best = -1.0;
+    bidx = INT_MAX;
+    for(unsigned b = 0; b < G; ++b) bk_argmax_combine(best, bidx, bk_ld(pval + b), bk_ldi(pidx + b));
+  };
+  while(k < kcap) {
+    const int kw = k - k0;
+    // ---- phase A
+    column_phase(false, k);
+    if(!bk_grid_barrier(bar, target, G, &sh_ok)) return;
+    if(tid == 0) {
+      double best;
+      int bidx;
+      fold(best, bidx);
+      const double wkk = bk_ld(Wb + (int64_t)kw * ldw + k);
+      const double absakk = fabs(wkk);
+      const double colmax = (best >= 0.0) ? best : 0.0;
+      d_imax = (best >= 0.0) ? bidx : k;
+      d_absakk = absakk;
+      d_colmax = colmax;
+      d_c0_k = wkk;
+      int need2 = 0;
+      if(!(fmax(absakk, colmax) > 0.0)) {   // exactly zero column (or NaN): DSYTRF's INFO = k + 1, no interchange
+        if(g == 0 && st->info == 0) st->info = k + 1;
+      } else if(!(absakk >= BK_ALPHA * colmax)) {
+        need2 = 1;
+      }
+      d_need2 = need2;
+      if(!need2) {
+        d_kp = k;
+        d_kstep = 1;
+        d_use_c1 = 0;
+        d_c0_kk = d_c0_kp = wkk;
+        d_c1_kk = d_c1_kp = 0.0;
+        d_akk_old = bk_ld(A + (int64_t)k * lda + k);
+      }
+    }
+    __syncthreads();
+    // ---- phase B
+    if(d_need2) {
+      const int imax = d_imax;
+      column_phase(true, imax);
+      if(!bk_grid_barrier(bar, target, G, &sh_ok)) return;
+      if(tid == 0) {
+        double best;
+        int bidx;
+        fold(best, bidx);
+        const double rowmax = (best >= 0.0) ? best : 0.0;
+        const double absakk = d_absakk, colmax = d_colmax;
+        const double wii = fabs(bk_ld(Wb + (int64_t)(kw + 1) * ldw + imax));
+        int kp, kstep, use_c1 = 0;
+        if(absakk >= BK_ALPHA * colmax * (colmax / rowmax)) {
+          kp = k;
+          kstep = 1;
+        } else if(wii >= BK_ALPHA * rowmax) {
+          kp = imax;
+          kstep = 1;
+          use_c1 = 1;
+        } else {
+          kp = imax;
+          kstep = 2;
+        }
+        const int kk2 = k + kstep - 1;
+        d_kp = kp;
+        d_kstep = kstep;
+        d_use_c1 = use_c1;
+        d_c0_kk = bk_ld(Wb + (int64_t)kw * ldw + kk2);
+        d_c0_kp = bk_ld(Wb + (int64_t)kw * ldw + kp);
+        d_c1_kk = bk_ld(Wb + (int64_t)(kw + 1) * ldw + kk2);
+        d_c1_kp = bk_ld(Wb + (int64_t)(kw + 1) * ldw + kp);
+        d_akk_old = bk_ld(A + (int64_t)kk2 * lda + kk2);
+      }
+      __syncthreads();
+      // (every workgroup has read what it needs of W(kk / kp, .) BEFORE phase C overwrites those rows: a barrier between the reads above
+      //  and the interchange below)
+      if(!bk_grid_barrier(bar, target, G, &sh_ok)) return;
+    }
+    // ---- phase C
+    const int kp = d_kp, kstep = d_kstep, use_c1 = d_use_c1, kk = k + kstep - 1;
+    const double c0_kk = d_c0_kk, c0_kp = d_c0_kp, c1_kk = d_c1_kk, c1_kp = d_c1_kp, c0_k = d_c0_k, akk_old = d_akk_old;
+    const bool swp = kp != kk;
+    for(int blk = 0; blk * BK_T < n; ++blk) {
+      if((unsigned)blk % G != g) continue;
+      const int64_t j = (int64_t)blk * BK_T + tid;
+      if(j >= n) continue;
+      if(swp && j < k) {   // rows kk and kp of L, ALL previous columns
+        double* pa = A + j * lda;
+        const double u = bk_ld(pa + kk);
+        bk_st(pa + kk, bk_ld(pa + kp));
+        bk_st(pa + kp, u);
+      }
+      if(swp && j < kw) {   // rows kk and kp of W, the panel's previous columns
+        double* pw = Wb + j * ldw;
+        const double u = bk_ld(pw + kk);
+        bk_st(pw + kk, bk_ld(pw + kp));
+        bk_st(pw + kp, u);
+      }
+      const int64_t i = j;
+      if(i >= k) {
+        const bool is_kk = swp && i == kk, is_kp = swp && i == kp;
+        double w0, w1 = 0.0;
+        if(is_kk) {
+          w0 = use_c1 ? c1_kp : c0_kp;
+          w1 = c1_kp;
+        } else if(is_kp) {
+          w0 = use_c1 ? c1_kk : c0_kk;
+          w1 = c1_kk;
+        } else {
+          w0 = use_c1 ? bk_ld(Wb + (int64_t)(kw + 1) * ldw + i) : bk_ld(Wb + (int64_t)kw * ldw + i);
+          if(kstep == 2) w1 = bk_ld(Wb + (int64_t)(kw + 1) * ldw + i);
+        }
+        if(use_c1 || is_kk || is_kp) bk_st(Wb + (int64_t)kw * ldw + i, w0);
+        if(kstep == 2 && (is_kk || is_kp)) bk_st(Wb + (int64_t)(kw + 1) * ldw + i, w1);
+        if(swp) {
+          if(i == kp) bk_st(A + (int64_t)kp * lda + kp, akk_old);
+          else if(i > kk && i < kp) bk_st(A + i * lda + kp, bk_ld(A + (int64_t)kk * lda + i));
+          else if(i > kp) bk_st(A + (int64_t)kp * lda + i, bk_ld(A + (int64_t)kk * lda + i));
+        }
+        if(kstep == 1) {
+          const double dk = swp ? (use_c1 ? c1_kp : c0_kp) : c0_k;
+          if(i == k) bk_st(A + (int64_t)k * lda + k, dk);
+          else bk_st(A + (int64_t)k * lda + i, (dk != 0.0) ? w0 * (1.0 / dk) : w0);
+        } else {
+          const double wk0 = c0_k;
+          const double wk10 = swp ? c0_kp : c0_kk;
+          const double wk11 = swp ? c1_kp : c1_kk;
+          if(i == k) {
+            bk_st(A + (int64_t)k * lda + k, wk0);
+          } else if(i == k + 1) {
+            bk_st(A + (int64_t)k * lda + k + 1, 0.0);
+            bk_st(e + k, wk10);
+            bk_st(A + (int64_t)(k + 1) * lda + k + 1, wk11);
+          } else {
+            double d21 = wk10;
+            const double d11 = wk11 / d21, d22 = wk0 / d21;
+            const double tt = 1.0 / (d11 * d22 - 1.0);
+            d21 = tt / d21;
+            bk_st(A + (int64_t)k * lda + i, d21 * (d11 * w0 - w1));
+            bk_st(A + (int64_t)(k + 1) * lda + i, d21 * (d22 * w1 - w0));
+          }
+        }
+      }
+    }
+    if(g == 0 && tid == 0) {
+      if(kstep == 1) {
+        bk_sti(ipiv + k, kp + 1);
+      } else {
+        bk_sti(ipiv + k, -(kp + 1));
+        bk_sti(ipiv + k + 1, -(kp + 1));
+      }
+      if(swp) {
+        const int u = bk_ldi(perm + kk);
+        bk_sti(perm + kk, bk_ldi(perm + kp));
+        bk_sti(perm + kp, u);
+      }
+    }
+    if(!bk_grid_barrier(bar, target, G, &sh_ok)) return;
+    k += kstep;
   }
-  __syncthreads();
-  if(!sh_last || tid != 0) return;
-  st->cnt[2] = 0;
-  if(kstep == 1) {
-    ipiv[k] = kp + 1;
-  } else {
-    ipiv[k] = ipiv[k + 1] = -(kp + 1);
-  }
-  if(swp) {
-    const int u = perm[kk];
-    perm[kk] = perm[kp];
-    perm[kp] = u;
-  }
-  __threadfence();
-  st->next_k = k + kstep;
+  if(g == 0 && tid == 0) st->next_k = k;
 }
 
 __global__ __launch_bounds__(kBlock) void bk_iota_kernel(int n, int* __restrict__ perm)
@@ -385,6 +438,7 @@ struct hiopamd_ldlt_bk {
   int* ipiv = nullptr;       // n: LAPACK's IPIV (1-based, negative for 2 x 2)
   int* perm = nullptr;       // n: (P A P^T)[i][j] = A[perm[i]][perm[j]]
   BkState* st = nullptr;
+  unsigned* bar = nullptr;   // grid-barrier counter + abort word of the panel kernel
   bool factored = false;
 };
 
@@ -397,7 +451,7 @@ int hiopamd_ldlt_bk_create(hiopamd_ldlt_bk** out, hiopamd_ctx* ctx, int n)
   B->ctx = ctx;
   B->n = n;
   const size_t nn = (size_t)(n > 0 ? n : 1);
-  const size_t nblk = (nn + BK_ROWS - 1) / BK_ROWS;
+  const size_t nblk = std::max<size_t>((nn + BK_ROWS - 1) / BK_ROWS, 64);   // (>= the panel kernel's workgroups: one partial maximum each)
   bool ok = hipMalloc((void**)&B->Wb, sizeof(double) * nn * BK_NB) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->e, sizeof(double) * (nn + 1)) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->tmp, sizeof(double) * nn) == hipSuccess;
@@ -406,6 +460,7 @@ int hiopamd_ldlt_bk_create(hiopamd_ldlt_bk** out, hiopamd_ctx* ctx, int n)
   ok = ok && hipMalloc((void**)&B->ipiv, sizeof(int) * nn) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->perm, sizeof(int) * nn) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->st, sizeof(BkState)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&B->bar, 4 * sizeof(unsigned)) == hipSuccess;
   if(!ok) {
     hiopamd_ldlt_bk_destroy(B);
     return HIOPAMD_ERR_HIP;
@@ -418,7 +473,7 @@ int hiopamd_ldlt_bk_destroy(hiopamd_ldlt_bk* B)
 {
   if(!B) return HIOPAMD_OK;
   (void)hipStreamSynchronize(B->ctx->stream);
-  void* ps[] = {B->Wb, B->e, B->tmp, B->pval, B->pidx, B->ipiv, B->perm, B->st};
+  void* ps[] = {B->Wb, B->e, B->tmp, B->pval, B->pidx, B->ipiv, B->perm, B->st, B->bar};
   for(void* p : ps) (void)hipFree(p);
   delete B;
   return HIOPAMD_OK;
@@ -447,19 +502,26 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
   while(k0 < n) {
     const bool last = (n - k0) <= BK_NB;   // (DSYTRF factors the last block unblocked: the same recurrence with an empty trailing update)
     const int kcap = last ? n : k0 + BK_NB - 1;
-    for(int k = k0; k < kcap; ++k) {
-      const unsigned g = (unsigned)((n - k + BK_ROWS - 1) / BK_ROWS);
-      const int span = (n - k > k) ? (n - k) : k;
-      const unsigned ga = (unsigned)((span + kBlock - 1) / kBlock);
-      hipLaunchKernelGGL(bk_column_kernel<false>, dim3(g), dim3(kBlock), 0, s, n, k, k0, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx);
-      hipLaunchKernelGGL(bk_column_kernel<true>, dim3(g), dim3(kBlock), 0, s, n, k, k0, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx);
-      hipLaunchKernelGGL(bk_apply_kernel, dim3(ga), dim3(kBlock), 0, s, n, k, k0, A, lda, B->Wb, ldw, B->st, B->ipiv, B->perm, B->e);
+    {
+      // the panel's columns in ONE launch (bk_panel_kernel): its three phases per column, separated by grid barriers, are what
+      // tests/test_ldlt_bk_protocol.py replays thread by thread in random order
+      const unsigned G = (unsigned)std::min(BK_G, (n + BK_T - 1) / BK_T);
+      HIOPAMD_CHECK(hipMemsetAsync(B->bar, 0, 2 * sizeof(unsigned), s));
+      hipLaunchKernelGGL(bk_panel_kernel, dim3(G), dim3(BK_T), 0, s, n, k0, kcap, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx, B->ipiv,
+                         B->perm, B->e, B->bar);
     }
     HIOPAMD_CHECK(hipGetLastError());
-    if(last) break;
-    int kend = 0;   // where the panel ended: k0 + 63 or k0 + 64, depending on where the 2 x 2 pivots fell
+    int kend = 0;   // where the panel ended: k0 + 63 or k0 + 64, depending on where the 2 x 2 pivots fell (the last panel: n)
+    unsigned aborted[2] = {0u, 0u};
     HIOPAMD_CHECK(hipMemcpyAsync(&kend, &B->st->next_k, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIOPAMD_CHECK(hipMemcpyAsync(aborted, B->bar, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIOPAMD_CHECK(hipStreamSynchronize(s));
+    if(aborted[1] != 0u) {
+      std::fprintf(stderr, "[hiop_amd] pivoted LDL^T: a grid barrier of the panel kernel expired (its %d workgroups were not all running)\n",
+                   std::min(BK_G, (n + BK_T - 1) / BK_T));
+      return HIOPAMD_ERR_TIMEOUT;
+    }
+    if(last) break;
     if(kend < kcap || kend > k0 + BK_NB) return HIOPAMD_ERR_STATE;
     const int kb = kend - k0;
     const int kpad = ((kb + 7) / 8) * 8;   // the update kernel walks K in steps of 8: the rows of W past kb are zero
