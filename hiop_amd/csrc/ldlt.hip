@@ -2560,9 +2560,13 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     a.off_run = df_check ? P.off_run : 0;
     static const bool df_debug_sh = std::getenv("HIOPAMD_DF_DEBUG") && std::atoi(std::getenv("HIOPAMD_DF_DEBUG")) != 0;
     a.off_shadow = df_debug_sh ? P.off_shadow : 0;
-    // ONE workgroup of the wide kernel per CU: nobody "retires" (rounds 2-3 ran two per CU and let the second ones leave in the chain-bound
-    // half; that shape froze once per ~1.6e4 factorisations and is gone)
-    a.jretire = P.nwide;
+    // ONE workgroup of the wide kernel per CU — enforced (round 5).  A grid of exactly wide_cus workgroups is NOT dealt one per CU: the
+    // rank-on-CU counters of 117 factorisations showed anything from 240 CUs with one workgroup each to 224 CUs used and 16 of them
+    // carrying two for the whole factorisation (profiles/r05_probes/README.md) — idle CUs in the update-bound half, and the two-per-CU
+    // residency the one-per-CU shape was chosen to avoid.  So TWICE as many workgroups are launched (two fit a CU) and every workgroup
+    // that is not the first on its CU leaves at once (jretire = 0: the kernel's rank test, csrc/ldlt_wide_body.inc): 240 of 240 CUs carry
+    // exactly one working workgroup in every sample, linsolv.tmFactTime 5.27-5.32 ms against 5.35-5.51.
+    a.jretire = 0;
     // HIOPAMD_DF_ONE=1 (measurement aid): chain + wide as ONE dispatch on the wide stream, one workgroup per CU — the form the
     // rocprofv3 counter passes can profile (see ldlt_df_one_kernel); needs the 16-byte tile form
     static const bool df_one = std::getenv("HIOPAMD_DF_ONE") && std::atoi(std::getenv("HIOPAMD_DF_ONE")) != 0;
@@ -2581,9 +2585,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
     hipLaunchKernelGGL(ldlt_chain_kernel, dim3(DF_ROLES), dim3(kBlock), 0, sd, a);
     if(a.nwtasks > 0) {
       if(timed) (void)hipEventRecord(prof->get(), su);
-      // ONE workgroup of the wide kernel per CU of the wide stream (ctx->wide_cus, 240 on MI355X with two reserved CUs per XCD): 73.7 KB of
-      // LDS and one wave per SIMD, i.e. every CU could take a second one — the only shape that never froze in a soak
-      const int wmax = ctx->wide_cus;
+      // ONE working workgroup of the wide kernel per CU of the wide stream (ctx->wide_cus, 240 on MI355X with two reserved CUs per XCD):
+      // 73.7 KB of LDS and one wave per SIMD, i.e. every CU could take a second one — the only shape that never froze in a soak
+      const int wmax = 2 * ctx->wide_cus;   // (the second workgroup of every CU leaves at once: see jretire above)
       const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
       // 16-byte accesses need even N, lda, ldv (ldv = N); otherwise the 8-byte tile form
       const bool form2 = (N % 2 == 0) && (lda % 2 == 0) && (ldv % 2 == 0) && N >= 2 * UD_T;

@@ -1,0 +1,8 @@
+for r in 1 2 3; do
+for v in base wide2x; do
+if [ $v = wide2x ]; then export HIOPAMD_DEV_WIDE2X=1; else unset HIOPAMD_DEV_WIDE2X; fi
+echo "--- $v"
+HIOPAMD_DEV_CUCOUNT=1 timeout 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-dense 2> /tmp/err.txt | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.2f it/s fact %.3f wide %.3f' % (d['value'], d['kkt_spans']['linsolv.tmFactTime']['ms_per_step'], d['roofline']['avg_launch_ms']))"
+grep "DEV cu" /tmp/err.txt | sort | uniq -c | sort -rn | head -3
+done
+done
