@@ -274,19 +274,29 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
         t_gram, t_gemv, t_gemvt = time_on_ctx_stream(ctx, gram), time_on_ctx_stream(ctx, gemv), time_on_ctx_stream(ctx, gemvt)
         gram_flops = 2.0 * n * (k * (k + 1) / 2 + 2 * lc * k)
         gemv_bytes = 8.0 * n * (k + 1) + 8.0 * k
+        # HBM-side bytes per launch of the three kernels at THIS shape: committed PMC summary (scripts/calls/r05_pmc.sh part 2: the
+        # kernels alone at bench.py's two shapes, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, separate passes); null for any other shape
+        tr, tr_src = {}, None
+        try:
+            pd = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_dense", "summary.json")))
+            tr = {kk: vv.get("hbm_bytes_per_launch") for kk, vv in pd.get(f"k{k}_n{n}", {}).items()}
+            tr_src = f"profiles/r05_pmc_dense/summary.json [k{k}_n{n}]" if tr else None
+        except Exception:
+            pass
         out["roofline"] = [
             dict(kernel="gram_weighted_stacked (J DhInv [J;S;Y]^T, v_mfma_f64_16x16x4_f64)", bound="mfma",
                  achieved=gram_flops / (t_gram * 1e-3) / 1e12, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s",
                  frac=gram_flops / (t_gram * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS, avg_launch_ms=t_gram,
-                 algorithmic_flops_per_launch=gram_flops, hbm_gbs=8.0 * n * (kw + 1) / (t_gram * 1e-3) / 1e9, traffic=None),
+                 algorithmic_flops_per_launch=gram_flops, algorithmic_bytes_per_launch=8.0 * n * (kw + 1), hbm_gbs=8.0 * n * (kw + 1) / (t_gram * 1e-3) / 1e9,
+                 traffic=tr.get("gram_weighted_stacked"), traffic_source=tr_src),
             dict(kernel="mat_times_vec (y = J x, row-major k x n_local)", bound="hbm",
                  achieved=gemv_bytes / (t_gemv * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
                  frac=gemv_bytes / (t_gemv * 1e-3) / 1e9 / PEAK_HBM_GBS, avg_launch_ms=t_gemv,
-                 algorithmic_bytes_per_launch=gemv_bytes, traffic=None),
+                 algorithmic_bytes_per_launch=gemv_bytes, traffic=tr.get("mat_times_vec"), traffic_source=tr_src),
             dict(kernel="mat_trans_times_vec (x = J^T y)", bound="hbm",
                  achieved=gemv_bytes / (t_gemvt * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
                  frac=gemv_bytes / (t_gemvt * 1e-3) / 1e9 / PEAK_HBM_GBS, avg_launch_ms=t_gemvt,
-                 algorithmic_bytes_per_launch=gemv_bytes, traffic=None),
+                 algorithmic_bytes_per_launch=gemv_bytes, traffic=tr.get("mat_trans_times_vec"), traffic_source=tr_src),
         ]
     K.close(); H.close()
     return out
@@ -542,11 +552,11 @@ def main():
     achieved = (flops_per_launch / (ms_per_launch * 1e-3)) / 1e12 if ms_per_launch > 0 else 0.0
     # HBM-side traffic of that kernel per launch: PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc
     # passes with --kernel-trace only) of the SAME task graph run as one dispatch (HIOPAMD_DF_ONE=1: rocprofv3 serialises
-    # dispatches, and the production form is a pair of kernels that wait for each other) — scripts/calls/r03_gpu_1.sh, committed
-    # summary profiles/r03_pmc/summary.json.  Algorithmic bytes of the same launch: every trailing tile read + written once
+    # dispatches, and the production form is a pair of kernels that wait for each other) — scripts/calls/r05_pmc.sh, committed
+    # summary profiles/r05_pmc/summary.json (older rounds' summaries as fall-back).  Algorithmic bytes of the same launch: every trailing tile read + written once
     # per super-panel, the two operand row panels read once, the row-panel substitution (read A, write V and U).
     traffic, traffic_src, alg_bytes = None, "n/a (no committed PMC summary found)", None
-    for pmc_dir in ("r04_pmc", "r03_pmc"):
+    for pmc_dir in ("r05_pmc", "r04_pmc", "r03_pmc"):
         try:
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_dir, "summary.json")))
             if p.N == 8192:
