@@ -86,21 +86,28 @@ constexpr long long BK_BAR_TIMEOUT = 200000000ll;   // 2 s of the 100 MHz clock
 
 __device__ __forceinline__ double bk_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void bk_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// XCD-local forms (bk_panel_kernel<true>: every participating workgroup runs on ONE XCD, established at run time): a store that stays in
+// that XCD's L2 (no sc1: the line is kept, MI355X_MICROARCH.md "stores of each flavour") — the readers' sc1 loads bypass their L1 and are
+// served by the same L2 —, and read-modify-write atomics executed in that L2 instead of at the memory side.
+__device__ __forceinline__ void bk_st_l2(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void bk_sti_l2(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int bk_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void bk_sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // false: the wait expired (some workgroup of the grid is not running): every workgroup leaves, the host reports an error
+template <bool LOCAL>
 __device__ __forceinline__ bool bk_grid_barrier(unsigned* bar, unsigned& target, unsigned G, int* sh_ok)
 {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if(threadIdx.x == 0) {
     target += G;
-    (void)__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned before = LOCAL ? __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                  : __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
     unsigned spins = 0;
     long long t0 = 0;
-    while(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while(before + 1u < target && __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // (the last one to arrive does not poll)
       __builtin_amdgcn_s_sleep(2);
       if((++spins & 1023u) == 0) {
         const long long now = (long long)wall_clock64();
@@ -118,6 +125,13 @@ __device__ __forceinline__ bool bk_grid_barrier(unsigned* bar, unsigned& target,
   return *sh_ok != 0;
 }
 
+// LOCAL (the form the host launches for n > BK_T): 8 x as many workgroups as the panel needs are launched; each one reports the XCD it runs on
+// (s_getreg XCC_ID), all wait for each other ONCE, and the (up to BK_G) workgroups of the XCD that got the most — the dispatcher deals a
+// grid round-robin over the eight XCDs, so normally 8 of 64 — do the panel while the others leave.  Whatever the dispatcher did, the
+// participants are on one XCD by construction, which is what allows the L2-resident stores and L2-executed atomics above: every
+// cross-workgroup dependency of a column step then costs an L2 round trip instead of one to the memory side.
+// bar[0] barrier counter, bar[1] abort, bar[2] arrivals of the rendezvous, bar[4 + x] workgroups that reported XCD x.
+template <bool LOCAL>
 __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap, double* __restrict__ A, int64_t lda, double* __restrict__ Wb,
                                                           int64_t ldw, BkState* __restrict__ st, double* __restrict__ pval,
                                                           int* __restrict__ pidx, int* __restrict__ ipiv, int* __restrict__ perm,
@@ -127,16 +141,81 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
   __shared__ double rv[BK_T / 64];
   __shared__ int ri[BK_T / 64];
   __shared__ int sh_ok;
+  __shared__ int sh_rank, sh_G;
   // the decision of the current column, identical in every workgroup
   __shared__ int d_need2, d_imax, d_kp, d_kstep, d_use_c1;
   __shared__ double d_absakk, d_colmax, d_c0_k, d_c0_kk, d_c0_kp, d_c1_kk, d_c1_kp, d_akk_old;
   const int tid = threadIdx.x;
-  const unsigned G = gridDim.x, g = blockIdx.x;
+  unsigned G = gridDim.x, g = blockIdx.x;
+  if constexpr(LOCAL) {
+    if(tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 7u;
+      const unsigned mine = __hip_atomic_fetch_add(bar + 4 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the count above is at the memory side before the arrival is)
+      (void)__hip_atomic_fetch_add(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int rank = -1, Gact = 0;
+      unsigned spins = 0;
+      long long t0 = 0;
+      bool ok = true;
+      while(__hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(2);
+        if((++spins & 1023u) == 0) {
+          const long long now = (long long)wall_clock64();
+          if(t0 == 0) t0 = now;
+          if(now - t0 > BK_BAR_TIMEOUT || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = false;
+            break;
+          }
+        }
+      }
+      if(ok) {
+        unsigned cnt[8];
+#pragma unroll
+        for(int x = 0; x < 8; ++x) cnt[x] = __hip_atomic_load(bar + 4 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned xs = 0;
+#pragma unroll
+        for(unsigned x = 1; x < 8; ++x)
+          if(cnt[x] > cnt[xs]) xs = x;
+        Gact = (int)(cnt[xs] < (unsigned)BK_G ? cnt[xs] : (unsigned)BK_G);
+        rank = (xcc == xs && mine < (unsigned)Gact) ? (int)mine : -1;
+      }
+      sh_rank = rank;
+      sh_G = Gact;
+    }
+    __syncthreads();
+    if(sh_rank < 0) return;   // not on the chosen XCD (or the rendezvous expired: the abort word is set)
+    g = (unsigned)sh_rank;
+    G = (unsigned)sh_G;
+  }
+  // stores of everything another workgroup of the panel reads
+  auto pst = [&](double* p, double v) {
+    if constexpr(LOCAL) bk_st_l2(p, v);
+    else bk_st(p, v);
+  };
+  auto psti = [&](int* p, int v) {
+    if constexpr(LOCAL) bk_sti_l2(p, v);
+    else bk_sti(p, v);
+  };
   unsigned target = 0u;
   int k = st->next_k;   // (written before this launch)
-  // one phase of the column kernels for the rows this workgroup owns; the workgroup's partial maximum goes to pval / pidx [g]
+  // Scalars that cross workgroups, all in `pval` / `pidx` (64 entries each), addressed by the PARITY of the column step so that no slot is
+  // rewritten before every workgroup has passed a barrier behind its last read of it (a slot of parity s is written in step s and again in
+  // step s + 2; every step ends with a barrier):
+  //   [(2 par + phase) * 8 + g]   partial maximum of workgroup g in phase A (0) / B (1)
+  //   [32 + 8 par + q]            published by the OWNERS of the rows in question, read by every workgroup's deciding wave:
+  //                               q = 0 W(k, kw)   1 W(k+1, kw)   2 W(imax, kw)   3 W(k, kw+1)   4 W(k+1, kw+1)   5 W(imax, kw+1)
+  //                                   6 a(k, k)    7 a(k+1, k+1)
+  // Phase C overwrites W(kk / kp, .) and the two diagonal entries; with the published copies no workgroup reads those locations after
+  // the barrier behind phase B, so the barrier the first form of this kernel had between the second decision and phase C is gone.
+  int step = 0;
+  // one phase of the column kernels for the rows this workgroup owns; the workgroup's partial maximum goes to its slot
   auto column_phase = [&](bool second, int src) {
     const int kw = k - k0, col = second ? kw + 1 : kw;
+    const int par = step & 1;
+    double* pub = pval + 32 + 8 * par;
     __syncthreads();
     for(int p = tid; p < kw; p += BK_T) coef[p] = bk_ld(Wb + (int64_t)p * ldw + src);
     __syncthreads();
@@ -147,19 +226,50 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
       const int i = blk * BK_T + tid;
       if(i >= k && i < n) {
         double v = (!second || i >= src) ? bk_ld(A + (int64_t)src * lda + i) : bk_ld(A + (int64_t)i * lda + src);
+        const bool special = i == k || i == k + 1 || (second && i == src);
+        double diag = 0.0, c0own = 0.0;
+        if(special) {   // (three threads of the grid)
+          if(!second) diag = bk_ld(A + (int64_t)i * lda + i);
+          else c0own = bk_ld(Wb + (int64_t)kw * ldw + i);   // this thread's own result of phase A
+        }
         const double* Ap = A + (int64_t)k0 * lda + i;
-        // eight loads in flight at a time (the compiler keeps atomic loads in program order and would otherwise wait for each one
+        // sixteen loads in flight at a time (the compiler keeps atomic loads in program order and would otherwise wait for each one
         // before the multiply-add that consumes it: up to 63 dependent round trips per row)
         int p = 0;
-        for(; p + 8 <= kw; p += 8) {
-          double t8[8];
+        for(; p + 16 <= kw; p += 16) {
+          double t16[16];
 #pragma unroll
-          for(int q = 0; q < 8; ++q) t8[q] = bk_ld(Ap + (int64_t)(p + q) * lda);
+          for(int q = 0; q < 16; ++q) t16[q] = bk_ld(Ap + (int64_t)(p + q) * lda);
 #pragma unroll
-          for(int q = 0; q < 8; ++q) v -= t8[q] * coef[p + q];
+          for(int q = 0; q < 16; ++q) v -= t16[q] * coef[p + q];
         }
-        for(; p < kw; ++p) v -= bk_ld(Ap + (int64_t)p * lda) * coef[p];
-        bk_st(Wb + (int64_t)col * ldw + i, v);
+        if(p < kw) {
+          double t16[16];
+#pragma unroll
+          for(int q = 0; q < 16; ++q) t16[q] = (p + q < kw) ? bk_ld(Ap + (int64_t)(p + q) * lda) : 0.0;
+#pragma unroll
+          for(int q = 0; q < 16; ++q) v -= (p + q < kw) ? t16[q] * coef[p + q] : 0.0;
+        }
+        pst(Wb + (int64_t)col * ldw + i, v);
+        if(special) {
+          if(!second) {
+            if(i == k) {
+              pst(pub + 0, v);
+              pst(pub + 6, diag);
+            }
+            if(i == k + 1) {
+              pst(pub + 1, v);
+              pst(pub + 7, diag);
+            }
+          } else {
+            if(i == k) pst(pub + 3, v);
+            if(i == k + 1) pst(pub + 4, v);
+            if(i == src) {
+              pst(pub + 2, c0own);
+              pst(pub + 5, v);
+            }
+          }
+        }
         const bool cand = second ? (i != src) : (i > k);
         if(cand) bk_argmax_combine(best, bidx, fabs(v), i);
       }
@@ -176,45 +286,65 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
     __syncthreads();
     if(tid == 0) {
       for(int w = 1; w < BK_T / 64; ++w) bk_argmax_combine(best, bidx, rv[w], ri[w]);
-      bk_st(pval + g, best);
-      bk_sti(pidx + g, bidx);
+      const int slot = (2 * par + (second ? 1 : 0)) * 8 + (int)g;
+      pst(pval + slot, best);
+      psti(pidx + slot, bidx);
     }
   };
-  auto fold = [&](double& best, int& bidx) {
+  // the deciding wave (wave 0 of every workgroup): lanes 0 .. G-1 fetch the partial maxima, lanes 8 .. 15 the published scalars — ONE
+  // memory round trip —, then a wave reduction; every lane returns with the folded maximum, `pubv(q)` hands out scalar q
+  double dw_pub = 0.0;
+  auto fold = [&](bool second, double& best, int& bidx) {
+    const int lane = tid & 63, par = step & 1;
+    const int slot = (2 * par + (second ? 1 : 0)) * 8;
     best = -1.0;
     bidx = INT_MAX;
-    for(unsigned b = 0; b < G; ++b) bk_argmax_combine(best, bidx, bk_ld(pval + b), bk_ldi(pidx + b));
+    if(lane < (int)G) {
+      best = bk_ld(pval + slot + lane);
+      bidx = bk_ldi(pidx + slot + lane);
+    }
+    dw_pub = (lane >= 8 && lane < 16) ? bk_ld(pval + 32 + 8 * par + (lane - 8)) : 0.0;
+    for(int off = 4; off > 0; off >>= 1) {   // (G <= 8)
+      const double v2 = __shfl_down(best, off, 64);
+      const int i2 = __shfl_down(bidx, off, 64);
+      bk_argmax_combine(best, bidx, v2, i2);
+    }
+    best = __shfl(best, 0, 64);
+    bidx = __shfl(bidx, 0, 64);
   };
+  auto pubv = [&](int q) { return __shfl(dw_pub, 8 + q, 64); };
   while(k < kcap) {
     const int kw = k - k0;
     // ---- phase A
     column_phase(false, k);
-    if(!bk_grid_barrier(bar, target, G, &sh_ok)) return;
-    if(tid == 0) {
+    if(!bk_grid_barrier<LOCAL>(bar, target, G, &sh_ok)) return;
+    if(tid < 64) {
       double best;
       int bidx;
-      fold(best, bidx);
-      const double wkk = bk_ld(Wb + (int64_t)kw * ldw + k);
-      const double absakk = fabs(wkk);
-      const double colmax = (best >= 0.0) ? best : 0.0;
-      d_imax = (best >= 0.0) ? bidx : k;
-      d_absakk = absakk;
-      d_colmax = colmax;
-      d_c0_k = wkk;
-      int need2 = 0;
-      if(!(fmax(absakk, colmax) > 0.0)) {   // exactly zero column (or NaN): DSYTRF's INFO = k + 1, no interchange
-        if(g == 0 && st->info == 0) st->info = k + 1;
-      } else if(!(absakk >= BK_ALPHA * colmax)) {
-        need2 = 1;
-      }
-      d_need2 = need2;
-      if(!need2) {
-        d_kp = k;
-        d_kstep = 1;
-        d_use_c1 = 0;
-        d_c0_kk = d_c0_kp = wkk;
-        d_c1_kk = d_c1_kp = 0.0;
-        d_akk_old = bk_ld(A + (int64_t)k * lda + k);
+      fold(false, best, bidx);
+      const double wkk = pubv(0), akk = pubv(6);
+      if(tid == 0) {
+        const double absakk = fabs(wkk);
+        const double colmax = (best >= 0.0) ? best : 0.0;
+        d_imax = (best >= 0.0) ? bidx : k;
+        d_absakk = absakk;
+        d_colmax = colmax;
+        d_c0_k = wkk;
+        int need2 = 0;
+        if(!(fmax(absakk, colmax) > 0.0)) {   // exactly zero column (or NaN): DSYTRF's INFO = k + 1, no interchange
+          if(g == 0 && st->info == 0) st->info = k + 1;
+        } else if(!(absakk >= BK_ALPHA * colmax)) {
+          need2 = 1;
+        }
+        d_need2 = need2;
+        if(!need2) {
+          d_kp = k;
+          d_kstep = 1;
+          d_use_c1 = 0;
+          d_c0_kk = d_c0_kp = wkk;
+          d_c1_kk = d_c1_kp = 0.0;
+          d_akk_old = akk;
+        }
       }
     }
     __syncthreads();
@@ -222,40 +352,41 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
     if(d_need2) {
       const int imax = d_imax;
       column_phase(true, imax);
-      if(!bk_grid_barrier(bar, target, G, &sh_ok)) return;
-      if(tid == 0) {
+      if(!bk_grid_barrier<LOCAL>(bar, target, G, &sh_ok)) return;
+      if(tid < 64) {
         double best;
         int bidx;
-        fold(best, bidx);
-        const double rowmax = (best >= 0.0) ? best : 0.0;
-        const double absakk = d_absakk, colmax = d_colmax;
-        const double wii = fabs(bk_ld(Wb + (int64_t)(kw + 1) * ldw + imax));
-        int kp, kstep, use_c1 = 0;
-        if(absakk >= BK_ALPHA * colmax * (colmax / rowmax)) {
-          kp = k;
-          kstep = 1;
-        } else if(wii >= BK_ALPHA * rowmax) {
-          kp = imax;
-          kstep = 1;
-          use_c1 = 1;
-        } else {
-          kp = imax;
-          kstep = 2;
+        fold(true, best, bidx);
+        const double c0_k = pubv(0), c0_k1 = pubv(1), c0_im = pubv(2), c1_k = pubv(3), c1_k1 = pubv(4), c1_im = pubv(5), a_k = pubv(6),
+                     a_k1 = pubv(7);
+        if(tid == 0) {
+          const double rowmax = (best >= 0.0) ? best : 0.0;
+          const double absakk = d_absakk, colmax = d_colmax;
+          const double wii = fabs(c1_im);
+          int kp, kstep, use_c1 = 0;
+          if(absakk >= BK_ALPHA * colmax * (colmax / rowmax)) {
+            kp = k;
+            kstep = 1;
+          } else if(wii >= BK_ALPHA * rowmax) {
+            kp = imax;
+            kstep = 1;
+            use_c1 = 1;
+          } else {
+            kp = imax;
+            kstep = 2;
+          }
+          // row kk = k (kstep 1) or k + 1 (kstep 2); row kp = k or imax (imax may be k + 1: then both published copies are the same row's)
+          d_kp = kp;
+          d_kstep = kstep;
+          d_use_c1 = use_c1;
+          d_c0_kk = (kstep == 2) ? c0_k1 : c0_k;
+          d_c1_kk = (kstep == 2) ? c1_k1 : c1_k;
+          d_c0_kp = (kp == k) ? c0_k : c0_im;
+          d_c1_kp = (kp == k) ? c1_k : c1_im;
+          d_akk_old = (kstep == 2) ? a_k1 : a_k;
         }
-        const int kk2 = k + kstep - 1;
-        d_kp = kp;
-        d_kstep = kstep;
-        d_use_c1 = use_c1;
-        d_c0_kk = bk_ld(Wb + (int64_t)kw * ldw + kk2);
-        d_c0_kp = bk_ld(Wb + (int64_t)kw * ldw + kp);
-        d_c1_kk = bk_ld(Wb + (int64_t)(kw + 1) * ldw + kk2);
-        d_c1_kp = bk_ld(Wb + (int64_t)(kw + 1) * ldw + kp);
-        d_akk_old = bk_ld(A + (int64_t)kk2 * lda + kk2);
       }
       __syncthreads();
-      // (every workgroup has read what it needs of W(kk / kp, .) BEFORE phase C overwrites those rows: a barrier between the reads above
-      //  and the interchange below)
-      if(!bk_grid_barrier(bar, target, G, &sh_ok)) return;
     }
     // ---- phase C
     const int kp = d_kp, kstep = d_kstep, use_c1 = d_use_c1, kk = k + kstep - 1;
@@ -268,18 +399,24 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
       if(swp && j < k) {   // rows kk and kp of L, ALL previous columns
         double* pa = A + j * lda;
         const double u = bk_ld(pa + kk);
-        bk_st(pa + kk, bk_ld(pa + kp));
-        bk_st(pa + kp, u);
+        pst(pa + kk, bk_ld(pa + kp));
+        pst(pa + kp, u);
       }
       if(swp && j < kw) {   // rows kk and kp of W, the panel's previous columns
         double* pw = Wb + j * ldw;
         const double u = bk_ld(pw + kk);
-        bk_st(pw + kk, bk_ld(pw + kp));
-        bk_st(pw + kp, u);
+        pst(pw + kk, bk_ld(pw + kp));
+        pst(pw + kp, u);
       }
       const int64_t i = j;
       if(i >= k) {
         const bool is_kk = swp && i == kk, is_kp = swp && i == kp;
+        // everything this row reads, in flight together (one memory round trip; the loads are this thread's own row of W and its entry of
+        // column kk, which nobody else writes in this phase)
+        const bool need1 = use_c1 || kstep == 2;   // (uniform)
+        const double wc0 = bk_ld(Wb + (int64_t)kw * ldw + i);
+        const double wc1 = need1 ? bk_ld(Wb + (int64_t)(kw + 1) * ldw + i) : 0.0;
+        const double akki = (swp && i > kk && i != kp) ? bk_ld(A + (int64_t)kk * lda + i) : 0.0;
         double w0, w1 = 0.0;
         if(is_kk) {
           w0 = use_c1 ? c1_kp : c0_kp;
@@ -288,56 +425,57 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
           w0 = use_c1 ? c1_kk : c0_kk;
           w1 = c1_kk;
         } else {
-          w0 = use_c1 ? bk_ld(Wb + (int64_t)(kw + 1) * ldw + i) : bk_ld(Wb + (int64_t)kw * ldw + i);
-          if(kstep == 2) w1 = bk_ld(Wb + (int64_t)(kw + 1) * ldw + i);
+          w0 = use_c1 ? wc1 : wc0;
+          if(kstep == 2) w1 = wc1;
         }
-        if(use_c1 || is_kk || is_kp) bk_st(Wb + (int64_t)kw * ldw + i, w0);
-        if(kstep == 2 && (is_kk || is_kp)) bk_st(Wb + (int64_t)(kw + 1) * ldw + i, w1);
+        if(use_c1 || is_kk || is_kp) pst(Wb + (int64_t)kw * ldw + i, w0);
+        if(kstep == 2 && (is_kk || is_kp)) pst(Wb + (int64_t)(kw + 1) * ldw + i, w1);
         if(swp) {
-          if(i == kp) bk_st(A + (int64_t)kp * lda + kp, akk_old);
-          else if(i > kk && i < kp) bk_st(A + i * lda + kp, bk_ld(A + (int64_t)kk * lda + i));
-          else if(i > kp) bk_st(A + (int64_t)kp * lda + i, bk_ld(A + (int64_t)kk * lda + i));
+          if(i == kp) pst(A + (int64_t)kp * lda + kp, akk_old);
+          else if(i > kk && i < kp) pst(A + i * lda + kp, akki);
+          else if(i > kp) pst(A + (int64_t)kp * lda + i, akki);
         }
         if(kstep == 1) {
           const double dk = swp ? (use_c1 ? c1_kp : c0_kp) : c0_k;
-          if(i == k) bk_st(A + (int64_t)k * lda + k, dk);
-          else bk_st(A + (int64_t)k * lda + i, (dk != 0.0) ? w0 * (1.0 / dk) : w0);
+          if(i == k) pst(A + (int64_t)k * lda + k, dk);
+          else pst(A + (int64_t)k * lda + i, (dk != 0.0) ? w0 * (1.0 / dk) : w0);
         } else {
           const double wk0 = c0_k;
           const double wk10 = swp ? c0_kp : c0_kk;
           const double wk11 = swp ? c1_kp : c1_kk;
           if(i == k) {
-            bk_st(A + (int64_t)k * lda + k, wk0);
+            pst(A + (int64_t)k * lda + k, wk0);
           } else if(i == k + 1) {
-            bk_st(A + (int64_t)k * lda + k + 1, 0.0);
-            bk_st(e + k, wk10);
-            bk_st(A + (int64_t)(k + 1) * lda + k + 1, wk11);
+            pst(A + (int64_t)k * lda + k + 1, 0.0);
+            pst(e + k, wk10);
+            pst(A + (int64_t)(k + 1) * lda + k + 1, wk11);
           } else {
             double d21 = wk10;
             const double d11 = wk11 / d21, d22 = wk0 / d21;
             const double tt = 1.0 / (d11 * d22 - 1.0);
             d21 = tt / d21;
-            bk_st(A + (int64_t)k * lda + i, d21 * (d11 * w0 - w1));
-            bk_st(A + (int64_t)(k + 1) * lda + i, d21 * (d22 * w1 - w0));
+            pst(A + (int64_t)k * lda + i, d21 * (d11 * w0 - w1));
+            pst(A + (int64_t)(k + 1) * lda + i, d21 * (d22 * w1 - w0));
           }
         }
       }
     }
     if(g == 0 && tid == 0) {
       if(kstep == 1) {
-        bk_sti(ipiv + k, kp + 1);
+        psti(ipiv + k, kp + 1);
       } else {
-        bk_sti(ipiv + k, -(kp + 1));
-        bk_sti(ipiv + k + 1, -(kp + 1));
+        psti(ipiv + k, -(kp + 1));
+        psti(ipiv + k + 1, -(kp + 1));
       }
       if(swp) {
         const int u = bk_ldi(perm + kk);
-        bk_sti(perm + kk, bk_ldi(perm + kp));
-        bk_sti(perm + kp, u);
+        psti(perm + kk, bk_ldi(perm + kp));
+        psti(perm + kp, u);
       }
     }
-    if(!bk_grid_barrier(bar, target, G, &sh_ok)) return;
+    if(!bk_grid_barrier<LOCAL>(bar, target, G, &sh_ok)) return;
     k += kstep;
+    ++step;
   }
   if(g == 0 && tid == 0) st->next_k = k;
 }
@@ -460,7 +598,7 @@ int hiopamd_ldlt_bk_create(hiopamd_ldlt_bk** out, hiopamd_ctx* ctx, int n)
   ok = ok && hipMalloc((void**)&B->ipiv, sizeof(int) * nn) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->perm, sizeof(int) * nn) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->st, sizeof(BkState)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&B->bar, 4 * sizeof(unsigned)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&B->bar, 16 * sizeof(unsigned)) == hipSuccess;
   if(!ok) {
     hiopamd_ldlt_bk_destroy(B);
     return HIOPAMD_ERR_HIP;
@@ -506,9 +644,14 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
       // the panel's columns in ONE launch (bk_panel_kernel): its three phases per column, separated by grid barriers, are what
       // tests/test_ldlt_bk_protocol.py replays thread by thread in random order
       const unsigned G = (unsigned)std::min(BK_G, (n + BK_T - 1) / BK_T);
-      HIOPAMD_CHECK(hipMemsetAsync(B->bar, 0, 2 * sizeof(unsigned), s));
-      hipLaunchKernelGGL(bk_panel_kernel, dim3(G), dim3(BK_T), 0, s, n, k0, kcap, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx, B->ipiv,
-                         B->perm, B->e, B->bar);
+      HIOPAMD_CHECK(hipMemsetAsync(B->bar, 0, 16 * sizeof(unsigned), s));
+      static const bool local = !(std::getenv("HIOPAMD_BK_LOCAL") && std::atoi(std::getenv("HIOPAMD_BK_LOCAL")) == 0);
+      if(G >= 2 && local)   // eight times the workgroups: those that land on one XCD do the panel (see bk_panel_kernel)
+        hipLaunchKernelGGL(bk_panel_kernel<true>, dim3(8 * G), dim3(BK_T), 0, s, n, k0, kcap, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx,
+                           B->ipiv, B->perm, B->e, B->bar);
+      else
+        hipLaunchKernelGGL(bk_panel_kernel<false>, dim3(G), dim3(BK_T), 0, s, n, k0, kcap, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx,
+                           B->ipiv, B->perm, B->e, B->bar);
     }
     HIOPAMD_CHECK(hipGetLastError());
     int kend = 0;   // where the panel ended: k0 + 63 or k0 + 64, depending on where the 2 x 2 pivots fell (the last panel: n)

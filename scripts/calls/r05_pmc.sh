@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=gpurun_out/r05_pmc
 mkdir -p $O gpurun_out/r05_pmc_dense
+if [ "${1:-all}" != dense_only ]; then
 echo "=== PMC passes on the one-dispatch factorisation ==="
 run() {  # name, counters...
   name=$1; shift
@@ -47,6 +48,7 @@ print(json.dumps(out, indent=1))
 PY
 find $O -type f ! -name "summary.json" ! -name "*.err" -delete
 find $O -type d -empty -delete
+fi
 
 echo "=== PMC passes on the dense low-rank kernels ==="
 O=gpurun_out/r05_pmc_dense

@@ -205,3 +205,251 @@ def test_exactly_zero_column_sets_info_and_goes_on():
     A[0, 0] = 2.0
     a, e, ipiv, perm, info = replay(A, np.random.default_rng(0))
     assert info == 2 == bk.factor(A).info
+
+
+# ---- the panel kernel (round 5): G workgroups, grid barriers, scalars that cross workgroups ----------------------------------------------
+# bk_panel_kernel runs the three phases of every column of a panel inside ONE launch.  What the launches' boundaries used to order is now
+# ordered by grid barriers, and only by them: between two barriers the workgroups run at their own pace.  The model below runs G
+# workgroups as coroutines that yield at every point where the device code lets another workgroup overtake (a barrier, and the gaps
+# between a decision and the next phase); a random scheduler picks who goes next.  Every workgroup keeps its OWN copy of the decision
+# (the d_* words in LDS); what crosses workgroups goes through `pval` / `pidx` exactly as in the HIP file: partial maxima in slots
+# (2 par + phase) * 8 + g, the published scalars of rows k, k + 1, imax and the two diagonal entries in 32 + 8 par + q, par = parity of
+# the column step.  There is NO barrier between the second decision and phase C: a workgroup may overwrite W(kk / kp, .) and the diagonal
+# while another one has not decided yet — the published copies are what make that safe, and removing them (publish=False: the deciding
+# wave reads W and a directly, as the first form of the kernel did) must be caught by some interleaving.
+def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True):
+    pval, pidx = np.full(64, np.nan), np.zeros(64, dtype=np.int64)
+    arrived = [0]
+
+    def rows_of(g, lo):
+        return [i for i in range(lo, n) if (i // T) % G == g]
+
+    def workgroup(g):
+        k, step = st.next_k, 0
+        d = State()
+        while k < kcap:
+            kw, par = k - k0, step & 1
+            pub = 32 + 8 * par
+
+            def column_phase(second, src):
+                col = kw + 1 if second else kw
+                coef = W[src, :kw].copy()
+                best, bidx = -1.0, 1 << 30
+                for i in rng.permutation(rows_of(g, k)):
+                    v = a[i, src] if (not second or i >= src) else a[src, i]
+                    c0own = W[i, kw] if second else None
+                    for p in range(kw):
+                        v -= a[i, k0 + p] * coef[p]
+                    W[i, col] = v
+                    if not second:
+                        if i == k:
+                            pval[pub + 0], pval[pub + 6] = v, a[i, i]
+                        if i == k + 1:
+                            pval[pub + 1], pval[pub + 7] = v, a[i, i]
+                    else:
+                        if i == k:
+                            pval[pub + 3] = v
+                        if i == k + 1:
+                            pval[pub + 4] = v
+                        if i == src:
+                            pval[pub + 2], pval[pub + 5] = c0own, v
+                    if (i != src) if second else (i > k):
+                        av = abs(v)
+                        if av > best or (av == best and i < bidx):
+                            best, bidx = av, i
+                slot = (2 * par + (1 if second else 0)) * 8 + g
+                pval[slot], pidx[slot] = best, bidx
+
+            def fold(second):
+                slot = (2 * par + (1 if second else 0)) * 8
+                best, bidx = -1.0, 1 << 30
+                for b in range(G):
+                    if pval[slot + b] > best or (pval[slot + b] == best and pidx[slot + b] < bidx):
+                        best, bidx = pval[slot + b], int(pidx[slot + b])
+                return best, bidx
+
+            column_phase(False, k)
+            yield "barrier"
+            best, bidx = fold(False)
+            wkk = pval[pub + 0] if publish else W[k, kw]
+            d.absakk, d.colmax = abs(wkk), (best if best >= 0 else 0.0)
+            d.imax = bidx if best >= 0 else k
+            d.c0_k, d.need2 = wkk, False
+            if not (max(d.absakk, d.colmax) > 0.0):
+                if g == 0 and st.info == 0:
+                    st.info = k + 1
+            elif not (d.absakk >= ALPHA * d.colmax):
+                d.need2 = True
+            if not d.need2:
+                d.kp, d.kstep, d.use_c1 = k, 1, False
+                d.c0_kk = d.c0_kp = wkk
+                d.c1_kk = d.c1_kp = 0.0
+                d.akk_old = pval[pub + 6] if publish else a[k, k]
+            yield "run"
+            if d.need2:
+                imax = d.imax
+                column_phase(True, imax)
+                yield "barrier"
+                best, bidx = fold(True)
+                rowmax = best if best >= 0 else 0.0
+                if publish:
+                    c0_k, c0_k1, c0_im, c1_k, c1_k1, c1_im, a_k, a_k1 = (pval[pub + q] for q in range(8))
+                else:
+                    k1 = min(k + 1, n - 1)
+                    c0_k, c0_k1, c0_im, c1_k, c1_k1, c1_im, a_k, a_k1 = (W[k, kw], W[k1, kw], W[imax, kw], W[k, kw + 1], W[k1, kw + 1],
+                                                                         W[imax, kw + 1], a[k, k], a[k1, k1])
+                wii = abs(c1_im)
+                d.use_c1 = False
+                if d.absakk >= ALPHA * d.colmax * (d.colmax / rowmax):
+                    d.kp, d.kstep = k, 1
+                elif wii >= ALPHA * rowmax:
+                    d.kp, d.kstep, d.use_c1 = imax, 1, True
+                else:
+                    d.kp, d.kstep = imax, 2
+                two = d.kstep == 2
+                d.c0_kk, d.c1_kk = (c0_k1, c1_k1) if two else (c0_k, c1_k)
+                d.c0_kp, d.c1_kp = (c0_k, c1_k) if d.kp == k else (c0_im, c1_im)
+                d.akk_old = a_k1 if two else a_k
+                yield "run"        # (no barrier here any more)
+            # ---- phase C: thread j owns previous column j, panel column j of W and row i = j
+            kp, kstep, use_c1 = d.kp, d.kstep, d.use_c1
+            kk = k + kstep - 1
+            swp = kp != kk
+            for j in rng.permutation(rows_of(g, 0)):
+                if swp and j < k:
+                    a[kk, j], a[kp, j] = a[kp, j], a[kk, j]
+                if swp and j < kw:
+                    W[kk, j], W[kp, j] = W[kp, j], W[kk, j]
+                i = j
+                if i < k:
+                    continue
+                is_kk, is_kp = swp and i == kk, swp and i == kp
+                w1 = 0.0
+                if is_kk:
+                    w0, w1 = (d.c1_kp if use_c1 else d.c0_kp), d.c1_kp
+                elif is_kp:
+                    w0, w1 = (d.c1_kk if use_c1 else d.c0_kk), d.c1_kk
+                else:
+                    w0 = W[i, kw + 1] if use_c1 else W[i, kw]
+                    if kstep == 2:
+                        w1 = W[i, kw + 1]
+                if use_c1 or is_kk or is_kp:
+                    W[i, kw] = w0
+                if kstep == 2 and (is_kk or is_kp):
+                    W[i, kw + 1] = w1
+                if swp:
+                    if i == kp:
+                        a[kp, kp] = d.akk_old
+                    elif kk < i < kp:
+                        a[kp, i] = a[i, kk]
+                    elif i > kp:
+                        a[i, kp] = a[i, kk]
+                if kstep == 1:
+                    dk = ((d.c1_kp if use_c1 else d.c0_kp) if swp else d.c0_k)
+                    if i == k:
+                        a[k, k] = dk
+                    else:
+                        a[i, k] = w0 * (1.0 / dk) if dk != 0.0 else w0
+                else:
+                    wk0, wk10, wk11 = d.c0_k, (d.c0_kp if swp else d.c0_kk), (d.c1_kp if swp else d.c1_kk)
+                    if i == k:
+                        a[k, k] = wk0
+                    elif i == k + 1:
+                        a[k + 1, k] = 0.0
+                        e[k] = wk10
+                        a[k + 1, k + 1] = wk11
+                    else:
+                        d21 = wk10
+                        d11, d22 = wk11 / d21, wk0 / d21
+                        tt = 1.0 / (d11 * d22 - 1.0)
+                        d21 = tt / d21
+                        a[i, k] = d21 * (d11 * w0 - w1)
+                        a[i, k + 1] = d21 * (d22 * w1 - w0)
+            if g == 0:
+                if kstep == 1:
+                    ipiv[k] = kp + 1
+                else:
+                    ipiv[k] = ipiv[k + 1] = -(kp + 1)
+                if swp:
+                    perm[kk], perm[kp] = perm[kp], perm[kk]
+            yield "barrier"
+            k += kstep
+            step += 1
+        if g == 0:
+            st.next_k = k
+
+    progs = [workgroup(g) for g in range(G)]
+    waiting, done = set(), set()
+    while len(done) < G:
+        runnable = [g for g in range(G) if g not in waiting and g not in done]
+        if not runnable:                      # everybody is at the barrier: it opens
+            assert len(waiting) + len(done) == G and waiting
+            waiting.clear()
+            arrived[0] += 1
+            continue
+        g = int(rng.choice(runnable))
+        try:
+            if next(progs[g]) == "barrier":
+                waiting.add(g)
+        except StopIteration:
+            done.add(g)
+            assert not waiting, "a workgroup left the kernel while others wait at a barrier"
+
+
+def replay_panels(A, rng, T, Gmax, publish=True):
+    n = A.shape[0]
+    a = np.tril(np.array(A, dtype=np.float64))
+    a[np.triu_indices(n, 1)] = np.nan
+    e, ipiv, perm = np.zeros(n + 1), np.zeros(n, dtype=np.int64), np.arange(n)
+    st = State()
+    k0 = 0
+    while k0 < n:
+        last = (n - k0) <= NB
+        kcap = n if last else k0 + NB - 1
+        W = np.full((n, NB), np.nan)
+        panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, min(Gmax, (n + T - 1) // T), T, rng, publish)
+        kend = st.next_k
+        if last:
+            assert kend == n
+            break
+        kb = kend - k0
+        assert kcap <= kend <= k0 + NB
+        upd = a[kend:, k0:kend] @ W[kend:, :kb].T
+        a[kend:, kend:] -= np.tril(upd)
+        k0 = kend
+    return a, e[:n], ipiv, perm, st.info
+
+
+def matches_oracle(A, out):
+    n = A.shape[0]
+    fo = bk.factor(A)
+    a, e, ipiv, perm, info = out
+    if info != fo.info or not np.array_equal(ipiv, fo.ipiv) or not np.array_equal(perm, fo.perm):
+        return False
+    L = np.tril(a, -1) + np.eye(n)
+    g = max(1.0, np.abs(fo.L).max())
+    with np.errstate(invalid="ignore"):
+        return bool(np.allclose(np.diag(a), fo.d, rtol=1e-10, atol=1e-12 * np.abs(A).max() * g * g) and
+                    np.allclose(e, fo.e, rtol=1e-10, atol=1e-12 * np.abs(A).max() * g * g) and np.allclose(L, fo.L, rtol=1e-9, atol=1e-11 * g * g))
+
+
+@pytest.mark.parametrize("kind,n,T,G", [("rand", 1, 4, 8), ("rand", 2, 1, 8), ("rand", 9, 2, 3), ("rand", 65, 4, 8), ("rand", 150, 8, 8),
+                                        ("zero_diag", 70, 4, 5), ("kkt", 96, 4, 8), ("arrow", 90, 16, 4), ("graded", 100, 8, 2)])
+def test_panel_kernel_workgroups_at_their_own_pace_give_the_oracle_factor(kind, n, T, G):
+    A = make(kind, n)
+    for seed in range(3):
+        assert matches_oracle(A, replay_panels(A, np.random.default_rng(seed), T, G))
+
+
+def test_panel_kernel_without_the_published_scalars_is_caught():
+    """the same schedule with the deciding waves reading W / a directly (no barrier in front of phase C): some interleaving lets a
+    workgroup decide on values another one has already interchanged — the model must notice, otherwise it proves nothing"""
+    A = make("rand", 65)
+    bad = 0
+    for seed in range(12):
+        try:
+            ok = matches_oracle(A, replay_panels(A, np.random.default_rng(seed), 4, 8, publish=False))
+        except (AssertionError, ZeroDivisionError, FloatingPointError, IndexError):
+            ok = False
+        bad += 0 if ok else 1
+    assert bad > 0
