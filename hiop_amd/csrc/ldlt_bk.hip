@@ -80,6 +80,9 @@ __device__ __forceinline__ void bk_argmax_combine(double& v, int& i, double v2, 
 // two barriers 8.6, phase C 5.6 + barrier 1.6 us.  Tried and not kept (profiles/r05_probes/README.md): 32 workgroups of 256 threads
 // (186 ms: a barrier costs one atomic per workgroup on one word), the rows of the panel's L columns kept in registers (spills: 215 ms)
 // or in LDS (needs 32 workgroups again: 176 ms).
+#ifndef HIOPAMD_BK_TIMING
+#define HIOPAMD_BK_TIMING 0
+#endif
 constexpr int BK_G = 8;        // workgroups of the panel kernel: a barrier costs one atomic per workgroup on ONE word (32: 22 us per column)
 constexpr int BK_T = 1024;     // threads per workgroup: one row per thread up to n = 8192
 constexpr long long BK_BAR_TIMEOUT = 200000000ll;   // 2 s of the 100 MHz clock
@@ -135,7 +138,8 @@ template <bool LOCAL>
 __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap, double* __restrict__ A, int64_t lda, double* __restrict__ Wb,
                                                           int64_t ldw, BkState* __restrict__ st, double* __restrict__ pval,
                                                           int* __restrict__ pidx, int* __restrict__ ipiv, int* __restrict__ perm,
-                                                          double* __restrict__ e, unsigned* __restrict__ bar)
+                                                          double* __restrict__ e, unsigned* __restrict__ bar,
+                                                          unsigned long long* __restrict__ gran)
 {
   __shared__ double coef[BK_NB];
   __shared__ double rv[BK_T / 64];
@@ -201,21 +205,33 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
   };
   unsigned target = 0u;
   int k = st->next_k;   // (written before this launch)
-  // Scalars that cross workgroups, all in `pval` / `pidx` (64 entries each), addressed by the PARITY of the column step so that no slot is
-  // rewritten before every workgroup has passed a barrier behind its last read of it (a slot of parity s is written in step s and again in
-  // step s + 2; every step ends with a barrier):
-  //   [(2 par + phase) * 8 + g]   partial maximum of workgroup g in phase A (0) / B (1)
-  //   [32 + 8 par + q]            published by the OWNERS of the rows in question, read by every workgroup's deciding wave:
-  //                               q = 0 W(k, kw)   1 W(k+1, kw)   2 W(imax, kw)   3 W(k, kw+1)   4 W(k+1, kw+1)   5 W(imax, kw+1)
-  //                                   6 a(k, k)    7 a(k+1, k+1)
-  // Phase C overwrites W(kk / kp, .) and the two diagonal entries; with the published copies no workgroup reads those locations after
-  // the barrier behind phase B, so the barrier the first form of this kernel had between the second decision and phase C is gone.
-  int step = 0;
-  // one phase of the column kernels for the rows this workgroup owns; the workgroup's partial maximum goes to its slot
+  // Scalars that cross workgroups travel as GRANULES: naturally aligned 8-byte words {32-bit payload, 32-bit tag} written by one store each
+  // (never torn), zeroed before the launch; a value is complete for a reader when every one of its granules carries the tag it expects,
+  // whatever the order in which the stores arrive.  tag = 4 k + 1 for what phase A of column k publishes, 4 k + 2 for phase B (k only
+  // grows inside a launch, 0 is never a tag).
+  //   gran[(phase * 8 + g) * 3 + {0, 1, 2}]   partial maximum of workgroup g: low word, high word of the value, row index
+  //   gran[48 + 2 q + {0, 1}]                 published by the OWNERS of the rows in question (low, high word):
+  //                                           q = 0 W(k, kw)   1 W(k+1, kw)   6 a(k, k)   7 a(k+1, k+1)              (phase A)
+  //                                               2 W(imax, kw)   3 W(k, kw+1)   4 W(k+1, kw+1)   5 W(imax, kw+1)    (phase B)
+  // The deciding wave of every workgroup polls the granules it needs — that IS the synchronisation behind phases A and B: nothing phase B
+  // or C reads of another workgroup's rows was written in phase A or B of the same column (a row's panel entries, the rows of W and the
+  // interchanges all date from earlier columns), only the decision depends on everybody.  So a column step has ONE grid barrier, at its
+  // end (phase C's interchanges write rows that other workgroups' threads read in the next column).  A granule is rewritten one column
+  // later at the earliest, i.e. behind that barrier, which every reader of the old value has passed.
+  auto gput = [&](int idx, unsigned payload, unsigned tag) {
+    const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)payload;
+    if constexpr(LOCAL) __hip_atomic_store(gran + idx, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(gran + idx, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto gput_f64 = [&](int idx, double v, unsigned tag) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    gput(idx, (unsigned)(b & 0xffffffffull), tag);
+    gput(idx + 1, (unsigned)(b >> 32), tag);
+  };
+  // one phase of the column kernels for the rows this workgroup owns; the workgroup's partial maximum goes to its granules
   auto column_phase = [&](bool second, int src) {
     const int kw = k - k0, col = second ? kw + 1 : kw;
-    const int par = step & 1;
-    double* pub = pval + 32 + 8 * par;
+    const unsigned tag = 4u * (unsigned)k + (second ? 2u : 1u);
     __syncthreads();
     for(int p = tid; p < kw; p += BK_T) coef[p] = bk_ld(Wb + (int64_t)p * ldw + src);
     __syncthreads();
@@ -254,19 +270,19 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
         if(special) {
           if(!second) {
             if(i == k) {
-              pst(pub + 0, v);
-              pst(pub + 6, diag);
+              gput_f64(48 + 2 * 0, v, tag);
+              gput_f64(48 + 2 * 6, diag, tag);
             }
             if(i == k + 1) {
-              pst(pub + 1, v);
-              pst(pub + 7, diag);
+              gput_f64(48 + 2 * 1, v, tag);
+              gput_f64(48 + 2 * 7, diag, tag);
             }
           } else {
-            if(i == k) pst(pub + 3, v);
-            if(i == k + 1) pst(pub + 4, v);
+            if(i == k) gput_f64(48 + 2 * 3, v, tag);
+            if(i == k + 1) gput_f64(48 + 2 * 4, v, tag);
             if(i == src) {
-              pst(pub + 2, c0own);
-              pst(pub + 5, v);
+              gput_f64(48 + 2 * 2, c0own, tag);
+              gput_f64(48 + 2 * 5, v, tag);
             }
           }
         }
@@ -286,24 +302,62 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
     __syncthreads();
     if(tid == 0) {
       for(int w = 1; w < BK_T / 64; ++w) bk_argmax_combine(best, bidx, rv[w], ri[w]);
-      const int slot = (2 * par + (second ? 1 : 0)) * 8 + (int)g;
-      pst(pval + slot, best);
-      psti(pidx + slot, bidx);
+      const int base = ((second ? 8 : 0) + (int)g) * 3;
+      gput_f64(base, best, tag);
+      gput(base + 2, (unsigned)bidx, tag);
     }
   };
-  // the deciding wave (wave 0 of every workgroup): lanes 0 .. G-1 fetch the partial maxima, lanes 8 .. 15 the published scalars — ONE
-  // memory round trip —, then a wave reduction; every lane returns with the folded maximum, `pubv(q)` hands out scalar q
-  double dw_pub = 0.0;
-  auto fold = [&](bool second, double& best, int& bidx) {
-    const int lane = tid & 63, par = step & 1;
-    const int slot = (2 * par + (second ? 1 : 0)) * 8;
+  // the deciding wave (wave 0 of every workgroup): lane L < 3 G polls granule L of the phase's partial maxima, lanes 24 .. 39 the sixteen
+  // granules of the published scalars; when every needed granule carries its tag the wave folds the maxima.  Every lane returns with the
+  // folded maximum, `pubv(q)` hands out scalar q.  false: the wait expired (abort word set, every workgroup leaves).
+  unsigned dw_pl = 0u;
+  auto fold = [&](bool second, double& best, int& bidx) -> bool {
+    const int lane = tid & 63;
+    const unsigned tagA = 4u * (unsigned)k + 1u, tagB = tagA + 1u;
+    int idx = -1;
+    unsigned want = 0u;
+    if(lane < 3 * (int)G) {
+      idx = (second ? 24 : 0) + lane;
+      want = second ? tagB : tagA;
+    } else if(lane >= 24 && lane < 40) {
+      const int q = (lane - 24) >> 1;
+      const bool fromA = q == 0 || q == 1 || q == 6 || q == 7;
+      // phase A's decision reads scalars 0 and 6 only (row k + 1 may not exist; when it does not, no second phase follows)
+      const bool needed = second ? true : (q == 0 || q == 6);
+      if(needed) {
+        idx = 48 + (lane - 24);
+        want = fromA ? tagA : tagB;
+      }
+    }
+    unsigned spins = 0;
+    long long t0 = 0;
+    bool ok = true;
+    for(;;) {
+      unsigned long long w = 0ull;
+      if(idx >= 0) w = __hip_atomic_load(gran + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool have = idx < 0 || (unsigned)(w >> 32) == want;
+      dw_pl = (unsigned)(w & 0xffffffffull);
+      if(__all(have)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if((++spins & 1023u) == 0) {
+        const long long now = (long long)wall_clock64();
+        if(t0 == 0) t0 = now;
+        if(now - t0 > BK_BAR_TIMEOUT || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if(lane == 0) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = false;
+          break;
+        }
+      }
+    }
+    // lane j < G: workgroup j's partial maximum from granules 3 j, 3 j + 1, 3 j + 2
+    const int j3 = (lane < (int)G) ? 3 * lane : 0;
+    const unsigned lo = __shfl(dw_pl, j3, 64), hi = __shfl(dw_pl, j3 + 1, 64), ix = __shfl(dw_pl, j3 + 2, 64);
     best = -1.0;
     bidx = INT_MAX;
     if(lane < (int)G) {
-      best = bk_ld(pval + slot + lane);
-      bidx = bk_ldi(pidx + slot + lane);
+      best = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+      bidx = (int)ix;
     }
-    dw_pub = (lane >= 8 && lane < 16) ? bk_ld(pval + 32 + 8 * par + (lane - 8)) : 0.0;
     for(int off = 4; off > 0; off >>= 1) {   // (G <= 8)
       const double v2 = __shfl_down(best, off, 64);
       const int i2 = __shfl_down(bidx, off, 64);
@@ -311,19 +365,35 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
     }
     best = __shfl(best, 0, 64);
     bidx = __shfl(bidx, 0, 64);
+    return ok;
   };
-  auto pubv = [&](int q) { return __shfl(dw_pub, 8 + q, 64); };
+  auto pubv = [&](int q) {
+    const unsigned lo = __shfl(dw_pl, 24 + 2 * q, 64), hi = __shfl(dw_pl, 25 + 2 * q, 64);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+  };
+#if HIOPAMD_BK_TIMING
+  long long tm_last = (long long)wall_clock64(), tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BK_LAP(q)                                   \
+  if(tid == 0) {                                    \
+    const long long now__ = (long long)wall_clock64(); \
+    tm_acc[q] += now__ - tm_last;                   \
+    tm_last = now__;                                \
+  }
+#else
+#define BK_LAP(q)
+#endif
   while(k < kcap) {
     const int kw = k - k0;
     // ---- phase A
     column_phase(false, k);
-    if(!bk_grid_barrier<LOCAL>(bar, target, G, &sh_ok)) return;
+    BK_LAP(0)
     if(tid < 64) {
       double best;
       int bidx;
-      fold(false, best, bidx);
+      const bool ok = fold(false, best, bidx);
       const double wkk = pubv(0), akk = pubv(6);
       if(tid == 0) {
+        sh_ok = ok ? 1 : 0;
         const double absakk = fabs(wkk);
         const double colmax = (best >= 0.0) ? best : 0.0;
         d_imax = (best >= 0.0) ? bidx : k;
@@ -348,18 +418,21 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
       }
     }
     __syncthreads();
+    if(!sh_ok) return;
+    BK_LAP(1)
     // ---- phase B
     if(d_need2) {
       const int imax = d_imax;
       column_phase(true, imax);
-      if(!bk_grid_barrier<LOCAL>(bar, target, G, &sh_ok)) return;
+      BK_LAP(2)
       if(tid < 64) {
         double best;
         int bidx;
-        fold(true, best, bidx);
+        const bool ok = fold(true, best, bidx);
         const double c0_k = pubv(0), c0_k1 = pubv(1), c0_im = pubv(2), c1_k = pubv(3), c1_k1 = pubv(4), c1_im = pubv(5), a_k = pubv(6),
                      a_k1 = pubv(7);
         if(tid == 0) {
+          sh_ok = ok ? 1 : 0;
           const double rowmax = (best >= 0.0) ? best : 0.0;
           const double absakk = d_absakk, colmax = d_colmax;
           const double wii = fabs(c1_im);
@@ -387,6 +460,8 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
         }
       }
       __syncthreads();
+      if(!sh_ok) return;
+      BK_LAP(3)
     }
     // ---- phase C
     const int kp = d_kp, kstep = d_kstep, use_c1 = d_use_c1, kk = k + kstep - 1;
@@ -473,11 +548,17 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
         psti(perm + kp, u);
       }
     }
+    __syncthreads();
+    BK_LAP(4)
     if(!bk_grid_barrier<LOCAL>(bar, target, G, &sh_ok)) return;
+    BK_LAP(5)
     k += kstep;
-    ++step;
   }
   if(g == 0 && tid == 0) st->next_k = k;
+#if HIOPAMD_BK_TIMING
+  if(g == 0 && tid == 0)
+    for(int q = 0; q < 6; ++q) atomicAdd(gran + 64 + q, (unsigned long long)tm_acc[q]);
+#endif
 }
 
 __global__ __launch_bounds__(kBlock) void bk_iota_kernel(int n, int* __restrict__ perm)
@@ -577,6 +658,7 @@ struct hiopamd_ldlt_bk {
   int* perm = nullptr;       // n: (P A P^T)[i][j] = A[perm[i]][perm[j]]
   BkState* st = nullptr;
   unsigned* bar = nullptr;   // grid-barrier counter + abort word of the panel kernel
+  unsigned long long* gran = nullptr;   // 64 tagged granules of the panel kernel (partial maxima, published scalars)
   bool factored = false;
 };
 
@@ -599,6 +681,8 @@ int hiopamd_ldlt_bk_create(hiopamd_ldlt_bk** out, hiopamd_ctx* ctx, int n)
   ok = ok && hipMalloc((void**)&B->perm, sizeof(int) * nn) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->st, sizeof(BkState)) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->bar, 16 * sizeof(unsigned)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&B->gran, 80 * sizeof(unsigned long long)) == hipSuccess;
+  if(ok) (void)hipMemset(B->gran, 0, 80 * sizeof(unsigned long long));
   if(!ok) {
     hiopamd_ldlt_bk_destroy(B);
     return HIOPAMD_ERR_HIP;
@@ -611,7 +695,7 @@ int hiopamd_ldlt_bk_destroy(hiopamd_ldlt_bk* B)
 {
   if(!B) return HIOPAMD_OK;
   (void)hipStreamSynchronize(B->ctx->stream);
-  void* ps[] = {B->Wb, B->e, B->tmp, B->pval, B->pidx, B->ipiv, B->perm, B->st, B->bar};
+  void* ps[] = {B->Wb, B->e, B->tmp, B->pval, B->pidx, B->ipiv, B->perm, B->st, B->bar, B->gran};
   for(void* p : ps) (void)hipFree(p);
   delete B;
   return HIOPAMD_OK;
@@ -645,13 +729,14 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
       // tests/test_ldlt_bk_protocol.py replays thread by thread in random order
       const unsigned G = (unsigned)std::min(BK_G, (n + BK_T - 1) / BK_T);
       HIOPAMD_CHECK(hipMemsetAsync(B->bar, 0, 16 * sizeof(unsigned), s));
+      HIOPAMD_CHECK(hipMemsetAsync(B->gran, 0, 64 * sizeof(unsigned long long), s));
       static const bool local = !(std::getenv("HIOPAMD_BK_LOCAL") && std::atoi(std::getenv("HIOPAMD_BK_LOCAL")) == 0);
       if(G >= 2 && local)   // eight times the workgroups: those that land on one XCD do the panel (see bk_panel_kernel)
         hipLaunchKernelGGL(bk_panel_kernel<true>, dim3(8 * G), dim3(BK_T), 0, s, n, k0, kcap, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx,
-                           B->ipiv, B->perm, B->e, B->bar);
+                           B->ipiv, B->perm, B->e, B->bar, B->gran);
       else
         hipLaunchKernelGGL(bk_panel_kernel<false>, dim3(G), dim3(BK_T), 0, s, n, k0, kcap, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx,
-                           B->ipiv, B->perm, B->e, B->bar);
+                           B->ipiv, B->perm, B->e, B->bar, B->gran);
     }
     HIOPAMD_CHECK(hipGetLastError());
     int kend = 0;   // where the panel ended: k0 + 63 or k0 + 64, depending on where the 2 x 2 pivots fell (the last panel: n)
@@ -679,6 +764,15 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
   BkState h;
   HIOPAMD_CHECK(hipMemcpyAsync(&h, B->st, sizeof(BkState), hipMemcpyDeviceToHost, s));
   HIOPAMD_CHECK(hipStreamSynchronize(s));
+#if HIOPAMD_BK_TIMING
+  {
+    unsigned long long tm[6];
+    (void)hipMemcpy(tm, B->gran + 64, sizeof(tm), hipMemcpyDeviceToHost);
+    (void)hipMemset(B->gran + 64, 0, sizeof(tm));
+    std::fprintf(stderr, "[hiop_amd] pivoted panels, workgroup 0, ms: phase A %.2f | wait+decide A %.2f | phase B %.2f | wait+decide B %.2f | phase C %.2f | end barrier %.2f\n",
+                 tm[0] * 1e-5, tm[1] * 1e-5, tm[2] * 1e-5, tm[3] * 1e-5, tm[4] * 1e-5, tm[5] * 1e-5);
+  }
+#endif
   if(h.next_k != n) return HIOPAMD_ERR_STATE;
   if(inertia3_host) {
     inertia3_host[0] = h.inertia[0];

@@ -207,32 +207,51 @@ def test_exactly_zero_column_sets_info_and_goes_on():
     assert info == 2 == bk.factor(A).info
 
 
-# ---- the panel kernel (round 5): G workgroups, grid barriers, scalars that cross workgroups ----------------------------------------------
+# ---- the panel kernel (round 5): G workgroups, ONE grid barrier per column, tagged granules for what crosses workgroups -------------------
 # bk_panel_kernel runs the three phases of every column of a panel inside ONE launch.  What the launches' boundaries used to order is now
-# ordered by grid barriers, and only by them: between two barriers the workgroups run at their own pace.  The model below runs G
-# workgroups as coroutines that yield at every point where the device code lets another workgroup overtake (a barrier, and the gaps
-# between a decision and the next phase); a random scheduler picks who goes next.  Every workgroup keeps its OWN copy of the decision
-# (the d_* words in LDS); what crosses workgroups goes through `pval` / `pidx` exactly as in the HIP file: partial maxima in slots
-# (2 par + phase) * 8 + g, the published scalars of rows k, k + 1, imax and the two diagonal entries in 32 + 8 par + q, par = parity of
-# the column step.  There is NO barrier between the second decision and phase C: a workgroup may overwrite W(kk / kp, .) and the diagonal
-# while another one has not decided yet — the published copies are what make that safe, and removing them (publish=False: the deciding
-# wave reads W and a directly, as the first form of the kernel did) must be caught by some interleaving.
-def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True):
-    pval, pidx = np.full(64, np.nan), np.zeros(64, dtype=np.int64)
-    arrived = [0]
+# ordered by (a) a grid barrier at the END of every column step and (b) tagged granules: every scalar that crosses workgroups — the partial
+# maxima of phases A and B, the values W(k / k+1 / imax, kw / kw+1) and the two diagonal entries, published by the threads that own those
+# rows — is written as 8-byte words {32-bit payload, 32-bit tag}, tag = 4 k + 1 (phase A of column k) or 4 k + 2 (phase B); the deciding
+# wave of a workgroup waits until every granule it needs carries the expected tag.  Nothing else orders phases A, B and C of a column.
+# The model runs G workgroups as coroutines that yield wherever the device code lets another workgroup overtake (between any two granule
+# stores, at a wait, at the barrier) under a random scheduler; every workgroup keeps its OWN copy of the decision (the d_* words in
+# LDS).  Two sabotaged variants must be caught, otherwise the model proves nothing: `publish=False` (the deciding wave reads W and a
+# directly, as the first form of the kernel did behind a barrier that no longer exists) and `check_all_tags=False` (the reader looks at
+# the tag of ONE granule of a multi-granule value).
+def _halves(v):
+    b = int(np.float64(v).view(np.uint64))
+    return b & 0xffffffff, b >> 32
+
+
+def _join(lo, hi):
+    return float(np.uint64((int(hi) << 32) | int(lo)).view(np.float64))
+
+
+def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, check_all_tags=True):
+    gp, gt = np.zeros(64, dtype=np.uint64), np.zeros(64, dtype=np.int64)     # granules: payload, tag (zeroed before the launch)
 
     def rows_of(g, lo):
         return [i for i in range(lo, n) if (i // T) % G == g]
 
+    def gput_f64(idx, v, tag):
+        lo, hi = _halves(v)
+        gp[idx], gt[idx] = lo, tag
+        yield "run"
+        gp[idx + 1], gt[idx + 1] = hi, tag
+
+    def gget_f64(idx):
+        return _join(gp[idx], gp[idx + 1])
+
     def workgroup(g):
-        k, step = st.next_k, 0
+        k = st.next_k
         d = State()
         while k < kcap:
-            kw, par = k - k0, step & 1
-            pub = 32 + 8 * par
+            kw = k - k0
+            tagA, tagB = 4 * k + 1, 4 * k + 2
 
             def column_phase(second, src):
                 col = kw + 1 if second else kw
+                tag = tagB if second else tagA
                 coef = W[src, :kw].copy()
                 best, bidx = -1.0, 1 << 30
                 for i in rng.permutation(rows_of(g, k)):
@@ -243,35 +262,54 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True):
                     W[i, col] = v
                     if not second:
                         if i == k:
-                            pval[pub + 0], pval[pub + 6] = v, a[i, i]
+                            yield from gput_f64(48 + 0, v, tag)
+                            yield from gput_f64(48 + 12, a[i, i], tag)
                         if i == k + 1:
-                            pval[pub + 1], pval[pub + 7] = v, a[i, i]
+                            yield from gput_f64(48 + 2, v, tag)
+                            yield from gput_f64(48 + 14, a[i, i], tag)
                     else:
                         if i == k:
-                            pval[pub + 3] = v
+                            yield from gput_f64(48 + 6, v, tag)
                         if i == k + 1:
-                            pval[pub + 4] = v
+                            yield from gput_f64(48 + 8, v, tag)
                         if i == src:
-                            pval[pub + 2], pval[pub + 5] = c0own, v
+                            yield from gput_f64(48 + 4, c0own, tag)
+                            yield from gput_f64(48 + 10, v, tag)
                     if (i != src) if second else (i > k):
                         av = abs(v)
                         if av > best or (av == best and i < bidx):
                             best, bidx = av, i
-                slot = (2 * par + (1 if second else 0)) * 8 + g
-                pval[slot], pidx[slot] = best, bidx
+                base = ((8 if second else 0) + g) * 3
+                yield from gput_f64(base, best, tag)
+                yield "run"
+                gp[base + 2], gt[base + 2] = bidx, tag
+
+            def needed(second):
+                idx = [((8 if second else 0) * 3 + q, tagB if second else tagA) for q in range(3 * G)]
+                for q in ((0, 1, 2, 3, 4, 5, 6, 7) if second else (0, 6)):
+                    t = tagA if q in (0, 1, 6, 7) else tagB
+                    idx += [(48 + 2 * q, t), (48 + 2 * q + 1, t)]
+                if not check_all_tags:      # sabotage: one granule per value
+                    idx = [x for x in idx if (x[0] < 48 and x[0] % 3 == 0) or (x[0] >= 48 and x[0] % 2 == 0)]
+                return idx
+
+            def ready(second):
+                want = needed(second)
+                return lambda: all(gt[i] == t for i, t in want)
 
             def fold(second):
-                slot = (2 * par + (1 if second else 0)) * 8
                 best, bidx = -1.0, 1 << 30
                 for b in range(G):
-                    if pval[slot + b] > best or (pval[slot + b] == best and pidx[slot + b] < bidx):
-                        best, bidx = pval[slot + b], int(pidx[slot + b])
+                    base = ((8 if second else 0) + b) * 3
+                    v, ix = gget_f64(base), int(gp[base + 2])
+                    if v > best or (v == best and ix < bidx):
+                        best, bidx = v, ix
                 return best, bidx
 
-            column_phase(False, k)
-            yield "barrier"
+            yield from column_phase(False, k)
+            yield ("wait", ready(False))
             best, bidx = fold(False)
-            wkk = pval[pub + 0] if publish else W[k, kw]
+            wkk = gget_f64(48) if publish else W[k, kw]
             d.absakk, d.colmax = abs(wkk), (best if best >= 0 else 0.0)
             d.imax = bidx if best >= 0 else k
             d.c0_k, d.need2 = wkk, False
@@ -284,16 +322,16 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True):
                 d.kp, d.kstep, d.use_c1 = k, 1, False
                 d.c0_kk = d.c0_kp = wkk
                 d.c1_kk = d.c1_kp = 0.0
-                d.akk_old = pval[pub + 6] if publish else a[k, k]
+                d.akk_old = gget_f64(48 + 12) if publish else a[k, k]
             yield "run"
             if d.need2:
                 imax = d.imax
-                column_phase(True, imax)
-                yield "barrier"
+                yield from column_phase(True, imax)
+                yield ("wait", ready(True))
                 best, bidx = fold(True)
                 rowmax = best if best >= 0 else 0.0
                 if publish:
-                    c0_k, c0_k1, c0_im, c1_k, c1_k1, c1_im, a_k, a_k1 = (pval[pub + q] for q in range(8))
+                    c0_k, c0_k1, c0_im, c1_k, c1_k1, c1_im, a_k, a_k1 = (gget_f64(48 + 2 * q) for q in range(8))
                 else:
                     k1 = min(k + 1, n - 1)
                     c0_k, c0_k1, c0_im, c1_k, c1_k1, c1_im, a_k, a_k1 = (W[k, kw], W[k1, kw], W[imax, kw], W[k, kw + 1], W[k1, kw + 1],
@@ -310,7 +348,7 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True):
                 d.c0_kk, d.c1_kk = (c0_k1, c1_k1) if two else (c0_k, c1_k)
                 d.c0_kp, d.c1_kp = (c0_k, c1_k) if d.kp == k else (c0_im, c1_im)
                 d.akk_old = a_k1 if two else a_k
-                yield "run"        # (no barrier here any more)
+                yield "run"
             # ---- phase C: thread j owns previous column j, panel column j of W and row i = j
             kp, kstep, use_c1 = d.kp, d.kstep, d.use_c1
             kk = k + kstep - 1
@@ -324,15 +362,17 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True):
                 if i < k:
                     continue
                 is_kk, is_kp = swp and i == kk, swp and i == kp
+                wc0, wc1 = W[i, kw], (W[i, kw + 1] if (use_c1 or kstep == 2) else 0.0)
+                akki = a[i, kk] if (swp and i > kk and i != kp) else 0.0
                 w1 = 0.0
                 if is_kk:
                     w0, w1 = (d.c1_kp if use_c1 else d.c0_kp), d.c1_kp
                 elif is_kp:
                     w0, w1 = (d.c1_kk if use_c1 else d.c0_kk), d.c1_kk
                 else:
-                    w0 = W[i, kw + 1] if use_c1 else W[i, kw]
+                    w0 = wc1 if use_c1 else wc0
                     if kstep == 2:
-                        w1 = W[i, kw + 1]
+                        w1 = wc1
                 if use_c1 or is_kk or is_kp:
                     W[i, kw] = w0
                 if kstep == 2 and (is_kk or is_kp):
@@ -341,9 +381,9 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True):
                     if i == kp:
                         a[kp, kp] = d.akk_old
                     elif kk < i < kp:
-                        a[kp, i] = a[i, kk]
+                        a[kp, i] = akki
                     elif i > kp:
-                        a[i, kp] = a[i, kk]
+                        a[i, kp] = akki
                 if kstep == 1:
                     dk = ((d.c1_kp if use_c1 else d.c0_kp) if swp else d.c0_k)
                     if i == k:
@@ -374,29 +414,33 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True):
                     perm[kk], perm[kp] = perm[kp], perm[kk]
             yield "barrier"
             k += kstep
-            step += 1
         if g == 0:
             st.next_k = k
 
     progs = [workgroup(g) for g in range(G)]
-    waiting, done = set(), set()
+    at_barrier, done, waits = set(), set(), {}
     while len(done) < G:
-        runnable = [g for g in range(G) if g not in waiting and g not in done]
-        if not runnable:                      # everybody is at the barrier: it opens
-            assert len(waiting) + len(done) == G and waiting
-            waiting.clear()
-            arrived[0] += 1
+        runnable = [g for g in range(G) if g not in at_barrier and g not in done and (g not in waits or waits[g]())]
+        if not runnable:
+            blocked = [g for g in range(G) if g in waits and g not in at_barrier and g not in done]
+            assert not blocked, "deadlock: a workgroup waits for granules nobody will write"
+            assert len(at_barrier) + len(done) == G and at_barrier     # everybody is at the barrier: it opens
+            at_barrier.clear()
             continue
         g = int(rng.choice(runnable))
+        waits.pop(g, None)
         try:
-            if next(progs[g]) == "barrier":
-                waiting.add(g)
+            what = next(progs[g])
+            if what == "barrier":
+                at_barrier.add(g)
+            elif isinstance(what, tuple):
+                waits[g] = what[1]
         except StopIteration:
             done.add(g)
-            assert not waiting, "a workgroup left the kernel while others wait at a barrier"
+            assert not at_barrier, "a workgroup left the kernel while others wait at a barrier"
 
 
-def replay_panels(A, rng, T, Gmax, publish=True):
+def replay_panels(A, rng, T, Gmax, publish=True, check_all_tags=True):
     n = A.shape[0]
     a = np.tril(np.array(A, dtype=np.float64))
     a[np.triu_indices(n, 1)] = np.nan
@@ -407,7 +451,7 @@ def replay_panels(A, rng, T, Gmax, publish=True):
         last = (n - k0) <= NB
         kcap = n if last else k0 + NB - 1
         W = np.full((n, NB), np.nan)
-        panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, min(Gmax, (n + T - 1) // T), T, rng, publish)
+        panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, min(Gmax, (n + T - 1) // T), T, rng, publish, check_all_tags)
         kend = st.next_k
         if last:
             assert kend == n
@@ -441,15 +485,25 @@ def test_panel_kernel_workgroups_at_their_own_pace_give_the_oracle_factor(kind, 
         assert matches_oracle(A, replay_panels(A, np.random.default_rng(seed), T, G))
 
 
-def test_panel_kernel_without_the_published_scalars_is_caught():
-    """the same schedule with the deciding waves reading W / a directly (no barrier in front of phase C): some interleaving lets a
-    workgroup decide on values another one has already interchanged — the model must notice, otherwise it proves nothing"""
+def _caught(**kw):
     A = make("rand", 65)
     bad = 0
     for seed in range(12):
         try:
-            ok = matches_oracle(A, replay_panels(A, np.random.default_rng(seed), 4, 8, publish=False))
-        except (AssertionError, ZeroDivisionError, FloatingPointError, IndexError):
+            ok = matches_oracle(A, replay_panels(A, np.random.default_rng(seed), 4, 8, **kw))
+        except (AssertionError, ZeroDivisionError, FloatingPointError, IndexError, OverflowError):
             ok = False
         bad += 0 if ok else 1
-    assert bad > 0
+    return bad
+
+
+def test_panel_kernel_without_the_published_scalars_is_caught():
+    """the deciding waves read W / a directly (nothing orders that against another workgroup's phase C any more): some interleaving lets
+    a workgroup decide on values another one has already interchanged — the model must notice, otherwise it proves nothing"""
+    assert _caught(publish=False) > 0
+
+
+def test_panel_kernel_reader_that_checks_one_tag_per_value_is_caught():
+    """a value of two or three granules is complete only when ALL of them carry the tag: a reader that looks at the first one combines
+    the new low word with an old high word (or an old row index) under some interleaving"""
+    assert _caught(check_all_tags=False) > 0
