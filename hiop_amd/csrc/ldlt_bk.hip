@@ -13,20 +13,23 @@
 // permutation; L is unit lower triangular and stored in the strict lower part, d on the diagonal, the off-diagonal entry of a
 // 2 x 2 block in e[k] (the matrix position a(k+1, k) is zeroed).  Pivots (LAPACK's IPIV) and D are LAPACK's.
 //
-// Device mapping (round 5).  A panel of 64 columns is ONE launch of <= 32 workgroups (bk_panel_kernel); a column step is three PHASES
-// separated by grid barriers, and the decisions never leave the device:
-//   phase A   updated column k into W(:, kw), |.| maximum below the diagonal per workgroup; behind the barrier every workgroup folds the
-//             partial maxima and takes the first decision (1 x 1 without interchange, or "look at row imax")
+// Device mapping (round 5).  A panel of 64 columns is ONE launch (bk_panel_kernel: up to 8 workgroups of 1024 threads, a row of the matrix
+// owned by one thread for the whole panel); a column step is three PHASES and the decisions never leave the device:
+//   phase A   updated column k into W(:, kw), |.| maximum below the diagonal per workgroup; every workgroup folds the partial maxima and
+//             takes the first decision (1 x 1 without interchange, or "look at row imax")
 //   phase B   (if asked for) updated column imax of the symmetric matrix into W(:, kw + 1), its off-diagonal maximum, the final
 //             decision: pivot position kp, 1 x 1 or 2 x 2
-//   phase C   interchange kk <-> kp (rows of L in all previous columns, rows of W, the not yet updated column kk of A to position kp),
-//             the column(s) of L and the block of D from W; workgroup 0 records IPIV / P
-// Everything a thread writes in a phase depends only on its own row plus the decision's handful of scalars, so no phase has an internal
-// ordering requirement (tests/test_ldlt_bk_protocol.py replays the phases one thread at a time in random order).  Once per panel the
-// host reads the panel's end (it depends on where 2 x 2 pivots fell) and launches the trailing update: the stepwise LDL^T's fp64-MFMA
-// rank-K kernel (ldlt.hip) with V = W, U = the L rows.  Rounds 1-4 ran the three phases as three LAUNCHES per column (3 x 8192 launches
-// at N = 8192: 173 ms; scripts/probes/retired/ldlt_bk_three_launch_kernels.hip.txt).  A solve is 2 x N / 64 block steps (one-wave
-// 64 x 64 triangular solve + a skinny GEMV).  This is the exceptional path: the fast path stays the no-pivot dataflow factorisation.
+//   phase C   interchange kk <-> kp (rows of L in the panel's previous columns, rows of W, the not yet updated column kk of A to position
+//             kp), the column(s) of L and the block of D from W; workgroup 0 records IPIV / P; then the step's ONE grid barrier
+// What crosses workgroups inside a step (partial maxima, the handful of scalars a decision needs) travels as tagged 8-byte granules that
+// the deciding wave of every workgroup polls — see the comment in the kernel; the rows kk / kp of the columns IN FRONT of the panel are
+// interchanged once per panel (bk_defer_swaps_kernel).  Everything a thread writes in a phase depends only on its own row plus the
+// decision's scalars (tests/test_ldlt_bk_protocol.py replays the phases one thread at a time in random order, and the panel kernel as
+// workgroups that run at their own pace between barriers).  Once per panel the host reads the panel's end (it depends on where 2 x 2
+// pivots fell) and launches the trailing update: the stepwise LDL^T's fp64-MFMA rank-K kernel (ldlt.hip) with V = W, U = the L rows.
+// Rounds 1-4 ran the three phases as three LAUNCHES per column (3 x 8192 launches at N = 8192: 173 ms;
+// scripts/probes/retired/ldlt_bk_three_launch_kernels.hip.txt).  A solve is 2 x N / 64 block steps (one-wave 64 x 64 triangular solve +
+// a skinny GEMV).  This is the exceptional path: the fast path stays the no-pivot dataflow factorisation.
 #include "device_utils.hpp"
 
 #include <climits>
@@ -65,25 +68,22 @@ __device__ __forceinline__ void bk_argmax_combine(double& v, int& i, double v2, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Round 5: the whole panel in ONE launch.  The three launches per column above were the cost of the pivoted mode (3 x 8192 launches of
-// ~7 us at N = 8192: 173 ms); this kernel runs the same three phases for every column of a panel with grid barriers in between:
-//   G <= 8 workgroups of 1024 threads, all resident (a bounded wait turns anything else into an error, never a hang); a row i of the matrix is owned by
-//   workgroup (i / 1024) % G, thread i % 1024, for the whole panel; every global access is an agent-scope relaxed atomic (sc1: coherent
-//   across the XCDs' L2s without cache maintenance), a barrier = s_waitcnt vmcnt(0) + workgroup barrier + one counter increment + poll.
-//   Phase A  updated column k into W(:, kw), one partial |.|-maximum per workgroup            | barrier | EVERY workgroup folds the G
-//   Phase B  (only if the first decision asks for it) column imax into W(:, kw + 1), maxima   | barrier | partials and takes the same
-//   Phase C  interchange, the column(s) of L, the block of D                                  | barrier | decision (no broadcast needed)
-// The decisions, the pivots and the factor are the three-launch form's (= LAPACK's) bit for bit: the per-row arithmetic is the same text
-// and the maxima are folded with the same "first index among equals" rule, which does not depend on the order of folding.
-// Measured at N = 8192 on a random symmetric matrix (scripts/bk_time.py; 5229 column steps, 4746 of them with phase B): 157 ms against
-// 173 ms with three launches per column; per step phase A 3.3 + barrier 4.7 (incl. the wait for the slowest workgroup), phase B 5.0 +
-// two barriers 8.6, phase C 5.6 + barrier 1.6 us.  Tried and not kept (profiles/r05_probes/README.md): 32 workgroups of 256 threads
-// (186 ms: a barrier costs one atomic per workgroup on one word), the rows of the panel's L columns kept in registers (spills: 215 ms)
-// or in LDS (needs 32 workgroups again: 176 ms).
+// Round 5: the whole panel in ONE launch.  History of the form, N = 8192, random symmetric matrix (scripts/bk_time.py; 5229 column steps,
+// 4746 of them with phase B; profiles/r05_probes/README.md):
+//   173 ms  three launches per column (rounds 1-4)
+//   157 ms  one launch per panel, grid barriers behind every phase (4 per two-phase step), decisions loaded by one lane
+//   136 ms  decision scalars published by the rows' owners and fetched in one round trip by the deciding wave; 3 barriers per step
+//   128 ms  participants chosen at run time on ONE XCD, stores kept in that XCD's L2
+//   121 ms  tagged granules instead of the barriers behind phases A and B: one barrier per step
+//   117 ms  interchanges of the columns in front of the panel once per panel
+// Per column step now (workgroup 0's clock, HIOPAMD_BK_TIMING build): phase A 3.2 + wait / decide 4.2, phase B 3.4 + 4.9, phase C +
+// barrier 4.4 us; what is left is ~12 dependent L2 round trips per step.  Tried and not kept: 32 workgroups of 256 threads (a barrier
+// costs one atomic per workgroup on one word), the rows of the panel's L columns kept in registers (spills) or in LDS (needs 32
+// workgroups again).
 #ifndef HIOPAMD_BK_TIMING
 #define HIOPAMD_BK_TIMING 0
 #endif
-constexpr int BK_G = 8;        // workgroups of the panel kernel: a barrier costs one atomic per workgroup on ONE word (32: 22 us per column)
+constexpr int BK_G = 8;        // workgroups of the panel kernel (the granule layout and the deciding wave's lane map assume <= 8)
 constexpr int BK_T = 1024;     // threads per workgroup: one row per thread up to n = 8192
 constexpr long long BK_BAR_TIMEOUT = 200000000ll;   // 2 s of the 100 MHz clock
 
@@ -471,7 +471,8 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
       if((unsigned)blk % G != g) continue;
       const int64_t j = (int64_t)blk * BK_T + tid;
       if(j >= n) continue;
-      if(swp && j < k) {   // rows kk and kp of L, ALL previous columns
+      if(swp && j >= k0 && j < k) {   // rows kk and kp of L, the panel's previous columns (the columns in front of the panel: once per
+                                      // panel, bk_defer_swaps_kernel)
         double* pa = A + j * lda;
         const double u = bk_ld(pa + kk);
         pst(pa + kk, bk_ld(pa + kp));
@@ -559,6 +560,88 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
   if(g == 0 && tid == 0)
     for(int q = 0; q < 6; ++q) atomicAdd(gran + 64 + q, (unsigned long long)tm_acc[q]);
 #endif
+}
+
+// The row interchanges of the panel [k0, kend) applied to the columns IN FRONT of the panel (j < k0), once per panel.  DLASYF interchanges
+// rows kk and kp of all earlier columns in every column step; the columns in front of the panel are neither read nor written while the
+// panel is factored, so applying the same interchanges in the same order afterwards gives the same matrix — and takes ~k uncoalesced
+// two-line accesses out of every column step (they were what phase C waited for: 4.8 of a step's 21.5 us at N = 8192).
+// One thread per column, 64 per workgroup: the column's entries in the panel's 64 rows and in the (at most 64) rows further down that an
+// interchange names are gathered into LDS, interchanged there in pivot order, and written back: ~8 batches of loads per panel instead of
+// a dependent round trip per interchange.
+constexpr int BK_DS_PITCH = 2 * BK_NB + 1;
+__global__ __launch_bounds__(64) void bk_defer_swaps_kernel(int n, int k0, int kend, double* __restrict__ A, int64_t lda,
+                                                            const int* __restrict__ ipiv)
+{
+  extern __shared__ double ds_buf[];   // 64 x BK_DS_PITCH
+  __shared__ int s_kk[BK_NB], s_kp[BK_NB], s_b[BK_NB], s_far[BK_NB];
+  __shared__ int s_m, s_nfar;
+  const int tid = threadIdx.x;
+  if(tid == 0) {   // the panel's interchanges in pivot order
+    int m = 0;
+    for(int k = k0; k < kend;) {
+      const int pv = ipiv[k];
+      const int kstep = pv > 0 ? 1 : 2;
+      const int kp = (pv > 0 ? pv : -pv) - 1, kk = k + kstep - 1;
+      if(kp != kk) {
+        s_kk[m] = kk;
+        s_kp[m] = kp;
+        ++m;
+      }
+      k += kstep;
+    }
+    s_m = m;
+  }
+  __syncthreads();
+  const int m = s_m;
+  if(m == 0) return;
+  // slot of row kp: inside the panel's 64 rows its offset, otherwise 64 + (first interchange that names the same row)
+  if(tid < m) {
+    const int kp = s_kp[tid];
+    int slot = kp - k0;
+    if(slot >= BK_NB) {
+      int first = tid;
+      for(int t = 0; t < tid; ++t)
+        if(s_kp[t] == kp) {
+          first = t;
+          break;
+        }
+      slot = BK_NB + first;
+    }
+    s_b[tid] = slot;
+    s_far[tid] = (slot == BK_NB + tid) ? kp : -1;   // this interchange owns far slot 64 + tid
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 64 + tid;
+  if(j >= k0) return;
+  double* col = A + (int64_t)j * lda;
+  double* buf = ds_buf + (size_t)tid * BK_DS_PITCH;
+  const int nrow = (n - k0 < BK_NB) ? n - k0 : BK_NB;   // (all 64 rows behind k0: an interchange may name row k0 + 63 of a 63-column panel)
+#pragma unroll 4
+  for(int r0 = 0; r0 < BK_NB; r0 += 16) {
+    double t16[16];
+#pragma unroll
+    for(int q = 0; q < 16; ++q) t16[q] = (r0 + q < nrow) ? col[k0 + r0 + q] : 0.0;
+#pragma unroll
+    for(int q = 0; q < 16; ++q) buf[r0 + q] = t16[q];
+  }
+  for(int r0 = 0; r0 < m; r0 += 16) {
+    double t16[16];
+#pragma unroll
+    for(int q = 0; q < 16; ++q) t16[q] = (r0 + q < m && s_far[r0 + q] >= 0) ? col[s_far[r0 + q]] : 0.0;
+#pragma unroll
+    for(int q = 0; q < 16; ++q)
+      if(r0 + q < m) buf[BK_NB + r0 + q] = t16[q];
+  }
+  for(int t = 0; t < m; ++t) {
+    const int a = s_kk[t] - k0, b = s_b[t];
+    const double u = buf[a];
+    buf[a] = buf[b];
+    buf[b] = u;
+  }
+  for(int r = 0; r < nrow; ++r) col[k0 + r] = buf[r];
+  for(int t = 0; t < m; ++t)
+    if(s_far[t] >= 0) col[s_far[t]] = buf[BK_NB + t];
 }
 
 __global__ __launch_bounds__(kBlock) void bk_iota_kernel(int n, int* __restrict__ perm)
@@ -730,8 +813,7 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
       const unsigned G = (unsigned)std::min(BK_G, (n + BK_T - 1) / BK_T);
       HIOPAMD_CHECK(hipMemsetAsync(B->bar, 0, 16 * sizeof(unsigned), s));
       HIOPAMD_CHECK(hipMemsetAsync(B->gran, 0, 64 * sizeof(unsigned long long), s));
-      static const bool local = !(std::getenv("HIOPAMD_BK_LOCAL") && std::atoi(std::getenv("HIOPAMD_BK_LOCAL")) == 0);
-      if(G >= 2 && local)   // eight times the workgroups: those that land on one XCD do the panel (see bk_panel_kernel)
+      if(G >= 2)   // eight times the workgroups: those that land on one XCD do the panel (see bk_panel_kernel)
         hipLaunchKernelGGL(bk_panel_kernel<true>, dim3(8 * G), dim3(BK_T), 0, s, n, k0, kcap, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx,
                            B->ipiv, B->perm, B->e, B->bar, B->gran);
       else
@@ -748,6 +830,12 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
       std::fprintf(stderr, "[hiop_amd] pivoted LDL^T: a grid barrier of the panel kernel expired (its %d workgroups were not all running)\n",
                    std::min(BK_G, (n + BK_T - 1) / BK_T));
       return HIOPAMD_ERR_TIMEOUT;
+    }
+    if(k0 > 0 && kend > k0) {
+      static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(bk_defer_swaps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(sizeof(double) * 64 * BK_DS_PITCH)) == hipSuccess;
+      if(!lds_ok) return HIOPAMD_ERR_HIP;
+      hipLaunchKernelGGL(bk_defer_swaps_kernel, dim3((k0 + 63) / 64), dim3(64), sizeof(double) * 64 * BK_DS_PITCH, s, n, k0, kend, A, lda, B->ipiv);
     }
     if(last) break;
     if(kend < kcap || kend > k0 + BK_NB) return HIOPAMD_ERR_STATE;

@@ -354,7 +354,7 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, 
             kk = k + kstep - 1
             swp = kp != kk
             for j in rng.permutation(rows_of(g, 0)):
-                if swp and j < k:
+                if swp and k0 <= j < k:          # (the columns in front of the panel: once per panel, defer_swaps below)
                     a[kk, j], a[kp, j] = a[kp, j], a[kk, j]
                 if swp and j < kw:
                     W[kk, j], W[kp, j] = W[kp, j], W[kk, j]
@@ -440,6 +440,42 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, 
             assert not at_barrier, "a workgroup left the kernel while others wait at a barrier"
 
 
+def defer_swaps(a, ipiv, n, k0, kend, rng):
+    """bk_defer_swaps_kernel: one thread per column j < k0; the panel's interchanges, read back from ipiv in pivot order, applied to the
+    column's entries gathered in a private buffer (64 panel rows + one slot per distinct row further down)"""
+    swaps, k = [], k0
+    while k < kend:
+        pv = int(ipiv[k])
+        kstep = 1 if pv > 0 else 2
+        kp, kk = abs(pv) - 1, k + kstep - 1
+        if kp != kk:
+            swaps.append((kk, kp))
+        k += kstep
+    if not swaps:
+        return
+    slot = []
+    for t, (kk, kp) in enumerate(swaps):
+        sl = kp - k0
+        if sl >= NB:
+            first = next(u for u in range(t + 1) if swaps[u][1] == kp)
+            sl = NB + first
+        slot.append(sl)
+    nrow = min(NB, n - k0)
+    for j in rng.permutation(k0):
+        buf = np.full(2 * NB, np.nan)
+        buf[:nrow] = a[k0:k0 + nrow, j]
+        for t, (kk, kp) in enumerate(swaps):
+            if slot[t] == NB + t:
+                buf[NB + t] = a[kp, j]
+        for t, (kk, kp) in enumerate(swaps):
+            x, y = kk - k0, slot[t]
+            buf[x], buf[y] = buf[y], buf[x]
+        a[k0:k0 + nrow, j] = buf[:nrow]
+        for t, (kk, kp) in enumerate(swaps):
+            if slot[t] == NB + t:
+                a[kp, j] = buf[NB + t]
+
+
 def replay_panels(A, rng, T, Gmax, publish=True, check_all_tags=True):
     n = A.shape[0]
     a = np.tril(np.array(A, dtype=np.float64))
@@ -453,6 +489,8 @@ def replay_panels(A, rng, T, Gmax, publish=True, check_all_tags=True):
         W = np.full((n, NB), np.nan)
         panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, min(Gmax, (n + T - 1) // T), T, rng, publish, check_all_tags)
         kend = st.next_k
+        if k0 > 0 and kend > k0:
+            defer_swaps(a, ipiv, n, k0, kend, rng)
         if last:
             assert kend == n
             break
