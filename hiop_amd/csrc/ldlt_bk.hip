@@ -13,7 +13,7 @@
 // permutation; L is unit lower triangular and stored in the strict lower part, d on the diagonal, the off-diagonal entry of a
 // 2 x 2 block in e[k] (the matrix position a(k+1, k) is zeroed).  Pivots (LAPACK's IPIV) and D are LAPACK's.
 //
-// Device mapping (round 5).  A panel of 64 columns is ONE launch (bk_panel_kernel: up to 8 workgroups of 1024 threads, a row of the matrix
+// Device mapping (round 5).  A panel of 64 columns is ONE launch (bk_panel_kernel: up to 16 workgroups of 512 threads, a row of the matrix
 // owned by one thread for the whole panel); a column step is three PHASES and the decisions never leave the device:
 //   phase A   updated column k into W(:, kw), |.| maximum below the diagonal per workgroup; every workgroup folds the partial maxima and
 //             takes the first decision (1 x 1 without interchange, or "look at row imax")
@@ -76,6 +76,8 @@ __device__ __forceinline__ void bk_argmax_combine(double& v, int& i, double v2, 
 //   128 ms  participants chosen at run time on ONE XCD, stores kept in that XCD's L2
 //   121 ms  tagged granules instead of the barriers behind phases A and B: one barrier per step
 //   117 ms  interchanges of the columns in front of the panel once per panel
+//    94 ms  16 workgroups of 512 threads instead of 8 x 1024 (shorter workgroup barriers and reductions; 32 row entries in flight instead
+//           of 16 is slower again: 102 ms)
 // Per column step now (workgroup 0's clock, HIOPAMD_BK_TIMING build): phase A 3.2 + wait / decide 4.2, phase B 3.4 + 4.9, phase C +
 // barrier 4.4 us; what is left is ~12 dependent L2 round trips per step.  Tried and not kept: 32 workgroups of 256 threads (a barrier
 // costs one atomic per workgroup on one word), the rows of the panel's L columns kept in registers (spills) or in LDS (needs 32
@@ -83,8 +85,17 @@ __device__ __forceinline__ void bk_argmax_combine(double& v, int& i, double v2, 
 #ifndef HIOPAMD_BK_TIMING
 #define HIOPAMD_BK_TIMING 0
 #endif
-constexpr int BK_G = 8;        // workgroups of the panel kernel (the granule layout and the deciding wave's lane map assume <= 8)
-constexpr int BK_T = 1024;     // threads per workgroup: one row per thread up to n = 8192
+#ifndef HIOPAMD_BK_G
+#define HIOPAMD_BK_G 16
+#define HIOPAMD_BK_T 512
+#define HIOPAMD_BK_DEPTH 16
+#endif
+constexpr int BK_G = HIOPAMD_BK_G;        // workgroups of the panel kernel (<= 16: the deciding wave polls 3 BK_G + 16 granules, one per lane)
+constexpr int BK_T = HIOPAMD_BK_T;        // threads per workgroup: one row per thread up to n = BK_G * BK_T
+constexpr int BK_DEPTH = HIOPAMD_BK_DEPTH;   // row entries in flight per thread in the column phases
+constexpr int BK_GR_PUB = 6 * BK_G;       // first granule of the published scalars (behind 2 phases x BK_G workgroups x 3 granules)
+constexpr int BK_GR_N = BK_GR_PUB + 16;   // granules
+static_assert(3 * BK_G + 16 <= 64, "the deciding wave has one lane per granule");
 constexpr long long BK_BAR_TIMEOUT = 200000000ll;   // 2 s of the 100 MHz clock
 
 __device__ __forceinline__ double bk_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -209,8 +220,8 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
   // (never torn), zeroed before the launch; a value is complete for a reader when every one of its granules carries the tag it expects,
   // whatever the order in which the stores arrive.  tag = 4 k + 1 for what phase A of column k publishes, 4 k + 2 for phase B (k only
   // grows inside a launch, 0 is never a tag).
-  //   gran[(phase * 8 + g) * 3 + {0, 1, 2}]   partial maximum of workgroup g: low word, high word of the value, row index
-  //   gran[48 + 2 q + {0, 1}]                 published by the OWNERS of the rows in question (low, high word):
+  //   gran[(phase * BK_G + g) * 3 + {0, 1, 2}]   partial maximum of workgroup g: low word, high word of the value, row index
+  //   gran[6 BK_G + 2 q + {0, 1}]                 published by the OWNERS of the rows in question (low, high word):
   //                                           q = 0 W(k, kw)   1 W(k+1, kw)   6 a(k, k)   7 a(k+1, k+1)              (phase A)
   //                                               2 W(imax, kw)   3 W(k, kw+1)   4 W(k+1, kw+1)   5 W(imax, kw+1)    (phase B)
   // The deciding wave of every workgroup polls the granules it needs — that IS the synchronisation behind phases A and B: nothing phase B
@@ -249,40 +260,40 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
           else c0own = bk_ld(Wb + (int64_t)kw * ldw + i);   // this thread's own result of phase A
         }
         const double* Ap = A + (int64_t)k0 * lda + i;
-        // sixteen loads in flight at a time (the compiler keeps atomic loads in program order and would otherwise wait for each one
+        // BK_DEPTH loads in flight at a time (the compiler keeps atomic loads in program order and would otherwise wait for each one
         // before the multiply-add that consumes it: up to 63 dependent round trips per row)
         int p = 0;
-        for(; p + 16 <= kw; p += 16) {
-          double t16[16];
+        for(; p + BK_DEPTH <= kw; p += BK_DEPTH) {
+          double t16[BK_DEPTH];
 #pragma unroll
-          for(int q = 0; q < 16; ++q) t16[q] = bk_ld(Ap + (int64_t)(p + q) * lda);
+          for(int q = 0; q < BK_DEPTH; ++q) t16[q] = bk_ld(Ap + (int64_t)(p + q) * lda);
 #pragma unroll
-          for(int q = 0; q < 16; ++q) v -= t16[q] * coef[p + q];
+          for(int q = 0; q < BK_DEPTH; ++q) v -= t16[q] * coef[p + q];
         }
-        if(p < kw) {
-          double t16[16];
+        if(p < kw) {   // the rest, padded with zero products: the same fused multiply-adds as above, whatever BK_DEPTH is
+          double t16[BK_DEPTH];
 #pragma unroll
-          for(int q = 0; q < 16; ++q) t16[q] = (p + q < kw) ? bk_ld(Ap + (int64_t)(p + q) * lda) : 0.0;
+          for(int q = 0; q < BK_DEPTH; ++q) t16[q] = (p + q < kw) ? bk_ld(Ap + (int64_t)(p + q) * lda) : 0.0;
 #pragma unroll
-          for(int q = 0; q < 16; ++q) v -= (p + q < kw) ? t16[q] * coef[p + q] : 0.0;
+          for(int q = 0; q < BK_DEPTH; ++q) v -= t16[q] * ((p + q < kw) ? coef[p + q] : 0.0);
         }
         pst(Wb + (int64_t)col * ldw + i, v);
         if(special) {
           if(!second) {
             if(i == k) {
-              gput_f64(48 + 2 * 0, v, tag);
-              gput_f64(48 + 2 * 6, diag, tag);
+              gput_f64(BK_GR_PUB + 2 * 0, v, tag);
+              gput_f64(BK_GR_PUB + 2 * 6, diag, tag);
             }
             if(i == k + 1) {
-              gput_f64(48 + 2 * 1, v, tag);
-              gput_f64(48 + 2 * 7, diag, tag);
+              gput_f64(BK_GR_PUB + 2 * 1, v, tag);
+              gput_f64(BK_GR_PUB + 2 * 7, diag, tag);
             }
           } else {
-            if(i == k) gput_f64(48 + 2 * 3, v, tag);
-            if(i == k + 1) gput_f64(48 + 2 * 4, v, tag);
+            if(i == k) gput_f64(BK_GR_PUB + 2 * 3, v, tag);
+            if(i == k + 1) gput_f64(BK_GR_PUB + 2 * 4, v, tag);
             if(i == src) {
-              gput_f64(48 + 2 * 2, c0own, tag);
-              gput_f64(48 + 2 * 5, v, tag);
+              gput_f64(BK_GR_PUB + 2 * 2, c0own, tag);
+              gput_f64(BK_GR_PUB + 2 * 5, v, tag);
             }
           }
         }
@@ -302,12 +313,12 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
     __syncthreads();
     if(tid == 0) {
       for(int w = 1; w < BK_T / 64; ++w) bk_argmax_combine(best, bidx, rv[w], ri[w]);
-      const int base = ((second ? 8 : 0) + (int)g) * 3;
+      const int base = ((second ? BK_G : 0) + (int)g) * 3;
       gput_f64(base, best, tag);
       gput(base + 2, (unsigned)bidx, tag);
     }
   };
-  // the deciding wave (wave 0 of every workgroup): lane L < 3 G polls granule L of the phase's partial maxima, lanes 24 .. 39 the sixteen
+  // the deciding wave (wave 0 of every workgroup): lane L < 3 G polls granule L of the phase's partial maxima, lanes 3 BK_G .. 3 BK_G + 15 the sixteen
   // granules of the published scalars; when every needed granule carries its tag the wave folds the maxima.  Every lane returns with the
   // folded maximum, `pubv(q)` hands out scalar q.  false: the wait expired (abort word set, every workgroup leaves).
   unsigned dw_pl = 0u;
@@ -317,15 +328,15 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
     int idx = -1;
     unsigned want = 0u;
     if(lane < 3 * (int)G) {
-      idx = (second ? 24 : 0) + lane;
+      idx = (second ? 3 * BK_G : 0) + lane;
       want = second ? tagB : tagA;
-    } else if(lane >= 24 && lane < 40) {
-      const int q = (lane - 24) >> 1;
+    } else if(lane >= 3 * BK_G && lane < 3 * BK_G + 16) {
+      const int q = (lane - 3 * BK_G) >> 1;
       const bool fromA = q == 0 || q == 1 || q == 6 || q == 7;
       // phase A's decision reads scalars 0 and 6 only (row k + 1 may not exist; when it does not, no second phase follows)
       const bool needed = second ? true : (q == 0 || q == 6);
       if(needed) {
-        idx = 48 + (lane - 24);
+        idx = BK_GR_PUB + (lane - 3 * BK_G);
         want = fromA ? tagA : tagB;
       }
     }
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
       best = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
       bidx = (int)ix;
     }
-    for(int off = 4; off > 0; off >>= 1) {   // (G <= 8)
+    for(int off = 8; off > 0; off >>= 1) {   // (G <= 16)
       const double v2 = __shfl_down(best, off, 64);
       const int i2 = __shfl_down(bidx, off, 64);
       bk_argmax_combine(best, bidx, v2, i2);
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
     return ok;
   };
   auto pubv = [&](int q) {
-    const unsigned lo = __shfl(dw_pl, 24 + 2 * q, 64), hi = __shfl(dw_pl, 25 + 2 * q, 64);
+    const unsigned lo = __shfl(dw_pl, 3 * BK_G + 2 * q, 64), hi = __shfl(dw_pl, 3 * BK_G + 1 + 2 * q, 64);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
   };
 #if HIOPAMD_BK_TIMING
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(BK_T) void bk_panel_kernel(int n, int k0, int kcap,
   if(g == 0 && tid == 0) st->next_k = k;
 #if HIOPAMD_BK_TIMING
   if(g == 0 && tid == 0)
-    for(int q = 0; q < 6; ++q) atomicAdd(gran + 64 + q, (unsigned long long)tm_acc[q]);
+    for(int q = 0; q < 6; ++q) atomicAdd(gran + BK_GR_N + q, (unsigned long long)tm_acc[q]);
 #endif
 }
 
@@ -764,8 +775,8 @@ int hiopamd_ldlt_bk_create(hiopamd_ldlt_bk** out, hiopamd_ctx* ctx, int n)
   ok = ok && hipMalloc((void**)&B->perm, sizeof(int) * nn) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->st, sizeof(BkState)) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->bar, 16 * sizeof(unsigned)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&B->gran, 80 * sizeof(unsigned long long)) == hipSuccess;
-  if(ok) (void)hipMemset(B->gran, 0, 80 * sizeof(unsigned long long));
+  ok = ok && hipMalloc((void**)&B->gran, (BK_GR_N + 8) * sizeof(unsigned long long)) == hipSuccess;
+  if(ok) (void)hipMemset(B->gran, 0, (BK_GR_N + 8) * sizeof(unsigned long long));
   if(!ok) {
     hiopamd_ldlt_bk_destroy(B);
     return HIOPAMD_ERR_HIP;
@@ -812,7 +823,7 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
       // tests/test_ldlt_bk_protocol.py replays thread by thread in random order
       const unsigned G = (unsigned)std::min(BK_G, (n + BK_T - 1) / BK_T);
       HIOPAMD_CHECK(hipMemsetAsync(B->bar, 0, 16 * sizeof(unsigned), s));
-      HIOPAMD_CHECK(hipMemsetAsync(B->gran, 0, 64 * sizeof(unsigned long long), s));
+      HIOPAMD_CHECK(hipMemsetAsync(B->gran, 0, BK_GR_N * sizeof(unsigned long long), s));
       if(G >= 2)   // eight times the workgroups: those that land on one XCD do the panel (see bk_panel_kernel)
         hipLaunchKernelGGL(bk_panel_kernel<true>, dim3(8 * G), dim3(BK_T), 0, s, n, k0, kcap, A, lda, B->Wb, ldw, B->st, B->pval, B->pidx,
                            B->ipiv, B->perm, B->e, B->bar, B->gran);
@@ -855,7 +866,7 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
 #if HIOPAMD_BK_TIMING
   {
     unsigned long long tm[6];
-    (void)hipMemcpy(tm, B->gran + 64, sizeof(tm), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(tm, B->gran + BK_GR_N, sizeof(tm), hipMemcpyDeviceToHost);
     (void)hipMemset(B->gran + 64, 0, sizeof(tm));
     std::fprintf(stderr, "[hiop_amd] pivoted panels, workgroup 0, ms: phase A %.2f | wait+decide A %.2f | phase B %.2f | wait+decide B %.2f | phase C %.2f | end barrier %.2f\n",
                  tm[0] * 1e-5, tm[1] * 1e-5, tm[2] * 1e-5, tm[3] * 1e-5, tm[4] * 1e-5, tm[5] * 1e-5);

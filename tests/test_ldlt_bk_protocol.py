@@ -218,6 +218,9 @@ def test_exactly_zero_column_sets_info_and_goes_on():
 # LDS).  Two sabotaged variants must be caught, otherwise the model proves nothing: `publish=False` (the deciding wave reads W and a
 # directly, as the first form of the kernel did behind a barrier that no longer exists) and `check_all_tags=False` (the reader looks at
 # the tag of ONE granule of a multi-granule value).
+GMAX = 16          # BK_G of the HIP file: the granule layout is sized for it whatever the number of workgroups of a launch
+
+
 def _halves(v):
     b = int(np.float64(v).view(np.uint64))
     return b & 0xffffffff, b >> 32
@@ -228,7 +231,7 @@ def _join(lo, hi):
 
 
 def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, check_all_tags=True):
-    gp, gt = np.zeros(64, dtype=np.uint64), np.zeros(64, dtype=np.int64)     # granules: payload, tag (zeroed before the launch)
+    gp, gt = np.zeros(6 * GMAX + 16, dtype=np.uint64), np.zeros(6 * GMAX + 16, dtype=np.int64)     # granules: payload, tag (zeroed before the launch)
 
     def rows_of(g, lo):
         return [i for i in range(lo, n) if (i // T) % G == g]
@@ -241,6 +244,8 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, 
 
     def gget_f64(idx):
         return _join(gp[idx], gp[idx + 1])
+
+    PUB = 6 * GMAX
 
     def workgroup(g):
         k = st.next_k
@@ -262,35 +267,35 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, 
                     W[i, col] = v
                     if not second:
                         if i == k:
-                            yield from gput_f64(48 + 0, v, tag)
-                            yield from gput_f64(48 + 12, a[i, i], tag)
+                            yield from gput_f64(PUB + 0, v, tag)
+                            yield from gput_f64(PUB + 12, a[i, i], tag)
                         if i == k + 1:
-                            yield from gput_f64(48 + 2, v, tag)
-                            yield from gput_f64(48 + 14, a[i, i], tag)
+                            yield from gput_f64(PUB + 2, v, tag)
+                            yield from gput_f64(PUB + 14, a[i, i], tag)
                     else:
                         if i == k:
-                            yield from gput_f64(48 + 6, v, tag)
+                            yield from gput_f64(PUB + 6, v, tag)
                         if i == k + 1:
-                            yield from gput_f64(48 + 8, v, tag)
+                            yield from gput_f64(PUB + 8, v, tag)
                         if i == src:
-                            yield from gput_f64(48 + 4, c0own, tag)
-                            yield from gput_f64(48 + 10, v, tag)
+                            yield from gput_f64(PUB + 4, c0own, tag)
+                            yield from gput_f64(PUB + 10, v, tag)
                     if (i != src) if second else (i > k):
                         av = abs(v)
                         if av > best or (av == best and i < bidx):
                             best, bidx = av, i
-                base = ((8 if second else 0) + g) * 3
+                base = ((GMAX if second else 0) + g) * 3
                 yield from gput_f64(base, best, tag)
                 yield "run"
                 gp[base + 2], gt[base + 2] = bidx, tag
 
             def needed(second):
-                idx = [((8 if second else 0) * 3 + q, tagB if second else tagA) for q in range(3 * G)]
+                idx = [((GMAX if second else 0) * 3 + q, tagB if second else tagA) for q in range(3 * G)]
                 for q in ((0, 1, 2, 3, 4, 5, 6, 7) if second else (0, 6)):
                     t = tagA if q in (0, 1, 6, 7) else tagB
-                    idx += [(48 + 2 * q, t), (48 + 2 * q + 1, t)]
+                    idx += [(PUB + 2 * q, t), (PUB + 2 * q + 1, t)]
                 if not check_all_tags:      # sabotage: one granule per value
-                    idx = [x for x in idx if (x[0] < 48 and x[0] % 3 == 0) or (x[0] >= 48 and x[0] % 2 == 0)]
+                    idx = [x for x in idx if (x[0] < PUB and x[0] % 3 == 0) or (x[0] >= PUB and x[0] % 2 == 0)]
                 return idx
 
             def ready(second):
@@ -300,7 +305,7 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, 
             def fold(second):
                 best, bidx = -1.0, 1 << 30
                 for b in range(G):
-                    base = ((8 if second else 0) + b) * 3
+                    base = ((GMAX if second else 0) + b) * 3
                     v, ix = gget_f64(base), int(gp[base + 2])
                     if v > best or (v == best and ix < bidx):
                         best, bidx = v, ix
@@ -309,7 +314,7 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, 
             yield from column_phase(False, k)
             yield ("wait", ready(False))
             best, bidx = fold(False)
-            wkk = gget_f64(48) if publish else W[k, kw]
+            wkk = gget_f64(PUB) if publish else W[k, kw]
             d.absakk, d.colmax = abs(wkk), (best if best >= 0 else 0.0)
             d.imax = bidx if best >= 0 else k
             d.c0_k, d.need2 = wkk, False
@@ -322,7 +327,7 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, 
                 d.kp, d.kstep, d.use_c1 = k, 1, False
                 d.c0_kk = d.c0_kp = wkk
                 d.c1_kk = d.c1_kp = 0.0
-                d.akk_old = gget_f64(48 + 12) if publish else a[k, k]
+                d.akk_old = gget_f64(PUB + 12) if publish else a[k, k]
             yield "run"
             if d.need2:
                 imax = d.imax
@@ -331,7 +336,7 @@ def panel_kernel(a, W, e, ipiv, perm, st, n, k0, kcap, G, T, rng, publish=True, 
                 best, bidx = fold(True)
                 rowmax = best if best >= 0 else 0.0
                 if publish:
-                    c0_k, c0_k1, c0_im, c1_k, c1_k1, c1_im, a_k, a_k1 = (gget_f64(48 + 2 * q) for q in range(8))
+                    c0_k, c0_k1, c0_im, c1_k, c1_k1, c1_im, a_k, a_k1 = (gget_f64(PUB + 2 * q) for q in range(8))
                 else:
                     k1 = min(k + 1, n - 1)
                     c0_k, c0_k1, c0_im, c1_k, c1_k1, c1_im, a_k, a_k1 = (W[k, kw], W[k1, kw], W[imax, kw], W[k, kw + 1], W[k1, kw + 1],
@@ -515,7 +520,7 @@ def matches_oracle(A, out):
                     np.allclose(e, fo.e, rtol=1e-10, atol=1e-12 * np.abs(A).max() * g * g) and np.allclose(L, fo.L, rtol=1e-9, atol=1e-11 * g * g))
 
 
-@pytest.mark.parametrize("kind,n,T,G", [("rand", 1, 4, 8), ("rand", 2, 1, 8), ("rand", 9, 2, 3), ("rand", 65, 4, 8), ("rand", 150, 8, 8),
+@pytest.mark.parametrize("kind,n,T,G", [("rand", 1, 4, 8), ("rand", 2, 1, 8), ("rand", 9, 2, 3), ("rand", 65, 4, 16), ("rand", 150, 8, 8), ("rand", 130, 2, 16),
                                         ("zero_diag", 70, 4, 5), ("kkt", 96, 4, 8), ("arrow", 90, 16, 4), ("graded", 100, 8, 2)])
 def test_panel_kernel_workgroups_at_their_own_pace_give_the_oracle_factor(kind, n, T, G):
     A = make(kind, n)
