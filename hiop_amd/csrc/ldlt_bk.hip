@@ -28,8 +28,8 @@
 // workgroups that run at their own pace between barriers).  Once per panel the host reads the panel's end (it depends on where 2 x 2
 // pivots fell) and launches the trailing update: the stepwise LDL^T's fp64-MFMA rank-K kernel (ldlt.hip) with V = W, U = the L rows.
 // Rounds 1-4 ran the three phases as three LAUNCHES per column (3 x 8192 launches at N = 8192: 173 ms;
-// scripts/probes/retired/ldlt_bk_three_launch_kernels.hip.txt).  A solve is 2 x N / 64 block steps (one-wave 64 x 64 triangular solve +
-// a skinny GEMV).  This is the exceptional path: the fast path stays the no-pivot dataflow factorisation.
+// scripts/probes/retired/ldlt_bk_three_launch_kernels.hip.txt).  A solve is 2 x N / 256 block steps of two GEMVs each, on pre-inverted diagonal
+// blocks, replayed as a HIP graph.  This is the exceptional path: the fast path stays the no-pivot dataflow factorisation.
 #include "device_utils.hpp"
 
 #include <climits>
@@ -693,29 +693,6 @@ __global__ __launch_bounds__(kBlock) void bk_gather_kernel(int n, const int* __r
   else y[i] = x[perm[i]];
 }
 
-// one wave: the unit lower triangular 64 x 64 diagonal block of L at (jb, jb), forward (L y = v) or backward (L^T x = v), in place
-template <bool BWD>
-__global__ __launch_bounds__(64) void bk_block_solve_kernel(const double* __restrict__ A, int64_t lda, int jb, int bs, double* __restrict__ v)
-{
-  __shared__ double Ls[64][65];   // Ls[j][i] = L(jb + i, jb + j), i > j
-  const int lane = threadIdx.x;
-  for(int j = 0; j < bs; ++j) Ls[j][lane] = (lane < bs && lane > j) ? A[(int64_t)(jb + j) * lda + jb + lane] : 0.0;
-  double x = (lane < bs) ? v[jb + lane] : 0.0;
-  __syncthreads();
-  if(!BWD) {
-    for(int j = 0; j < bs; ++j) {
-      const double yj = __shfl(x, j, 64);
-      if(lane > j) x -= Ls[j][lane] * yj;
-    }
-  } else {
-    for(int i = bs - 1; i >= 0; --i) {
-      const double xi = __shfl(x, i, 64);
-      if(lane < i) x -= Ls[lane][i] * xi;
-    }
-  }
-  if(lane < bs) v[jb + lane] = x;
-}
-
 // z = D^-1 y with the 2 x 2 formula of DSYTRS (dsytrs.f, lower branch)
 __global__ __launch_bounds__(kBlock) void bk_dsolve_kernel(int n, const double* __restrict__ A, int64_t lda, const double* __restrict__ e,
                                                            double* __restrict__ y)
@@ -740,12 +717,71 @@ __global__ __launch_bounds__(kBlock) void bk_dsolve_kernel(int n, const double* 
 
 using namespace hiopamd;
 
+// The solve works on 256-row block steps with PRE-INVERTED diagonal blocks (round 5; before: 2 x n / 64 steps of a one-wave 64 x 64
+// triangular solve + a skinny GEMV — 1024 kernels of ~8 us at n = 8192, 8.7 ms per solve, and a HIP graph of them still 8.0: the kernels
+// themselves are latency).  X_J = L_JJ^-1 (unit lower triangular, 256 x 256) is built once per factorisation, column by column by
+// forward substitution on e_c, into M_J[c][i] = X_J(i, c) (column c of the inverse contiguous, zero above the diagonal); a block step is
+// then two GEMVs of shapes the library is fast at: y_J = M_J^T v_J and v_rest -= L(rest, J) y_J.
+constexpr int BK_SB = 256;
+constexpr int BK_INV_PITCH = BK_SB + 1;
+// grid = 4 x (number of diagonal blocks), one wave each: lane c of strip q owns column 64 q + c of the block's inverse and keeps it in
+// LDS (64 x 257 doubles).  Right-looking: eight columns of L at a time are staged into LDS (contiguous in memory: coalesced, one round
+// trip per eight columns), then for each of them every lane subtracts L(i, k) x(k) from the rest of its column — the same (i, k) for
+// every lane (entries above a column's diagonal are zeros that are multiplied along), so the staged column is an LDS broadcast.
+// (The first form — one thread per column, the column in global memory — took 4.5 ms at n = 8192: a dependent L2 round trip per term.)
+constexpr int BK_INV_NC = 8;
+__global__ __launch_bounds__(64) void bk_invert_diag_kernel(int n, const double* __restrict__ A, int64_t lda, double* __restrict__ Minv)
+{
+  extern __shared__ double bk_inv_lds[];   // 64 x BK_INV_PITCH (the lanes' columns) + BK_INV_NC x BK_SB (staged columns of L)
+  const int blk = blockIdx.x >> 2, c0 = (blockIdx.x & 3) * 64, lane = threadIdx.x, c = c0 + lane;
+  const int J0 = blk * BK_SB;
+  const int bs = (n - J0 < BK_SB) ? (n - J0) : BK_SB;
+  if(c0 >= bs) return;
+  double* x = bk_inv_lds + lane * BK_INV_PITCH;
+  double* Ls = bk_inv_lds + 64 * BK_INV_PITCH;
+  for(int i = c0; i < bs; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+  const double* L = A + (int64_t)J0 * lda + J0;   // L(J0 + i, J0 + k) = L[k * lda + i]
+  for(int k0 = c0; k0 < bs; k0 += BK_INV_NC) {
+    __syncthreads();   // (one wave: orders the LDS traffic of the previous round against the staging below)
+#pragma unroll
+    for(int q = 0; q < BK_INV_NC; ++q) {
+      const int k = k0 + q;
+      for(int i = k0 + lane; i < bs; i += 64) Ls[q * BK_SB + i] = (k < bs && i > k) ? L[(int64_t)k * lda + i] : 0.0;
+    }
+    __syncthreads();
+    for(int q = 0; q < BK_INV_NC; ++q) {
+      const int k = k0 + q;
+      if(k >= bs) break;
+      const double xk = x[k];   // final: every earlier column has been applied (0 for the lanes whose column starts below k)
+      const double* lq = Ls + q * BK_SB;
+      int i = k + 1;
+      for(; i + 8 <= bs; i += 8) {   // (reads first, writes last: the compiler cannot know that x and the staged column do not overlap)
+        double l8[8], x8[8];
+#pragma unroll
+        for(int u = 0; u < 8; ++u) {
+          l8[u] = lq[i + u];
+          x8[u] = x[i + u];
+        }
+#pragma unroll
+        for(int u = 0; u < 8; ++u) x[i + u] = x8[u] - l8[u] * xk;
+      }
+      for(; i < bs; ++i) x[i] -= lq[i] * xk;
+    }
+  }
+  if(c < bs) {
+    double* col = Minv + (int64_t)blk * BK_SB * BK_SB + (int64_t)c * BK_SB;   // M[c][i] = X(i, c)
+    for(int i = c; i < bs; ++i) col[i] = x[i];
+  }
+}
+
 struct hiopamd_ldlt_bk {
   hiopamd_ctx* ctx = nullptr;
   int n = 0;
   double* Wb = nullptr;      // 64 x n panel W = L D (column p of the panel contiguous)
   double* e = nullptr;       // n: off-diagonals of the 2 x 2 blocks of D
   double* tmp = nullptr;     // n: permuted right-hand side
+  double* tmp2 = nullptr;    // n: second vector of the sweeps
+  double* Minv = nullptr;    // ceil(n / 256) inverted diagonal blocks of L, 256 x 256 each (bk_invert_diag_kernel)
   double* pval = nullptr;    // partial maxima of the column kernels
   int* pidx = nullptr;
   int* ipiv = nullptr;       // n: LAPACK's IPIV (1-based, negative for 2 x 2)
@@ -754,7 +790,44 @@ struct hiopamd_ldlt_bk {
   unsigned* bar = nullptr;   // grid-barrier counter + abort word of the panel kernel
   unsigned long long* gran = nullptr;   // 64 tagged granules of the panel kernel (partial maxima, published scalars)
   bool factored = false;
+  // the two triangular sweeps of a solve as an instantiated HIP graph (~260 short kernels at n = 8192): captured on the second
+  // solve with the same matrix address (the first one runs eagerly and sizes the context's workspace), replayed from then on
+  hipGraphExec_t sweeps = nullptr;
+  const double* sw_A = nullptr;
+  int64_t sw_lda = 0;
+  void* sw_work = nullptr;     // the context's workspace at capture time (the GEMV partial sums live there)
+  bool sw_warm = false;
 };
+
+// L y = v, D z = y, L^T w = z with v = B->tmp on entry and on exit (y, z in B->tmp2): 2 x n / 256 block steps, every one two GEMVs
+static int bk_enqueue_sweeps(hiopamd_ldlt_bk* B, const double* A, int64_t lda)
+{
+  hiopamd_ctx* ctx = B->ctx;
+  const int n = B->n;
+  hipStream_t s = ctx->stream;
+  double *v = B->tmp, *y = B->tmp2;
+  const dim3 gn((n + kBlock - 1) / kBlock), bn(kBlock);
+  for(int jb = 0; jb < n; jb += BK_SB) {   // L y = P b
+    const int bs = (n - jb < BK_SB) ? (n - jb) : BK_SB;
+    const double* M = B->Minv + (int64_t)(jb / BK_SB) * BK_SB * BK_SB;
+    int rc = hiopamd_mat_trans_times_vec(ctx, bs, bs, M, BK_SB, 0.0, y + jb, 1.0, v + jb);   // y_J = X_J v_J = M_J^T v_J
+    const int rest = n - jb - bs;
+    if(rc == HIOPAMD_OK && rest > 0)
+      rc = hiopamd_mat_trans_times_vec(ctx, bs, rest, A + (int64_t)jb * lda + jb + bs, lda, 1.0, v + jb + bs, -1.0, y + jb);
+    if(rc != HIOPAMD_OK) return rc;
+  }
+  hipLaunchKernelGGL(bk_dsolve_kernel, gn, bn, 0, s, n, A, lda, B->e, y);
+  for(int jb = ((n - 1) / BK_SB) * BK_SB; jb >= 0; jb -= BK_SB) {   // L^T w = z, w into v
+    const int bs = (n - jb < BK_SB) ? (n - jb) : BK_SB;
+    const double* M = B->Minv + (int64_t)(jb / BK_SB) * BK_SB * BK_SB;
+    const int rest = n - jb - bs;
+    int rc = HIOPAMD_OK;
+    if(rest > 0) rc = hiopamd_mat_times_vec(ctx, bs, rest, A + (int64_t)jb * lda + jb + bs, lda, 1.0, y + jb, -1.0, v + jb + bs);
+    if(rc == HIOPAMD_OK) rc = hiopamd_mat_times_vec(ctx, bs, bs, M, BK_SB, 0.0, v + jb, 1.0, y + jb);   // w_J = X_J^T z_J = M_J z_J
+    if(rc != HIOPAMD_OK) return rc;
+  }
+  return HIOPAMD_OK;
+}
 
 extern "C" {
 
@@ -769,6 +842,12 @@ int hiopamd_ldlt_bk_create(hiopamd_ldlt_bk** out, hiopamd_ctx* ctx, int n)
   bool ok = hipMalloc((void**)&B->Wb, sizeof(double) * nn * BK_NB) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->e, sizeof(double) * (nn + 1)) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->tmp, sizeof(double) * nn) == hipSuccess;
+  ok = ok && hipMalloc((void**)&B->tmp2, sizeof(double) * nn) == hipSuccess;
+  {
+    const size_t mb = sizeof(double) * ((nn + BK_SB - 1) / BK_SB) * BK_SB * BK_SB;
+    ok = ok && hipMalloc((void**)&B->Minv, mb) == hipSuccess;
+    if(ok) ok = hipMemset(B->Minv, 0, mb) == hipSuccess;   // (the part above the diagonal of every block stays zero)
+  }
   ok = ok && hipMalloc((void**)&B->pval, sizeof(double) * nblk) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->pidx, sizeof(int) * nblk) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->ipiv, sizeof(int) * nn) == hipSuccess;
@@ -789,7 +868,8 @@ int hiopamd_ldlt_bk_destroy(hiopamd_ldlt_bk* B)
 {
   if(!B) return HIOPAMD_OK;
   (void)hipStreamSynchronize(B->ctx->stream);
-  void* ps[] = {B->Wb, B->e, B->tmp, B->pval, B->pidx, B->ipiv, B->perm, B->st, B->bar, B->gran};
+  if(B->sweeps) (void)hipGraphExecDestroy(B->sweeps);
+  void* ps[] = {B->Wb, B->e, B->tmp, B->tmp2, B->Minv, B->pval, B->pidx, B->ipiv, B->perm, B->st, B->bar, B->gran};
   for(void* p : ps) (void)hipFree(p);
   delete B;
   return HIOPAMD_OK;
@@ -858,6 +938,13 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
     if(rc != HIOPAMD_OK) return rc;
     k0 = kend;
   }
+  {
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(bk_invert_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(sizeof(double) * (64 * BK_INV_PITCH + BK_INV_NC * BK_SB))) == hipSuccess;
+    if(!lds_ok) return HIOPAMD_ERR_HIP;
+    hipLaunchKernelGGL(bk_invert_diag_kernel, dim3(4 * ((n + BK_SB - 1) / BK_SB)), dim3(64), sizeof(double) * (64 * BK_INV_PITCH + BK_INV_NC * BK_SB), s, n,
+                       A, lda, B->Minv);
+  }
   hipLaunchKernelGGL(bk_inertia_kernel, dim3(1), dim3(kBlock), 0, s, n, A, lda, B->e, B->st);
   HIOPAMD_CHECK(hipGetLastError());
   BkState h;
@@ -897,24 +984,45 @@ int hiopamd_ldlt_bk_solve(hiopamd_ldlt_bk* B, const double* A, int64_t lda, doub
     double* x = x_inout + (int64_t)q * n;
     double* v = B->tmp;
     hipLaunchKernelGGL(bk_gather_kernel, gn, bn, 0, s, n, B->perm, x, v, 0);
-    for(int jb = 0; jb < n; jb += 64) {   // L y = P b
-      const int bs = (n - jb < 64) ? (n - jb) : 64;
-      hipLaunchKernelGGL(bk_block_solve_kernel<false>, dim3(1), dim3(64), 0, s, A, lda, jb, bs, v);
-      const int rest = n - jb - bs;
-      if(rest > 0) {
-        const int rc = hiopamd_mat_trans_times_vec(ctx, bs, rest, A + (int64_t)jb * lda + jb + bs, lda, 1.0, v + jb + bs, -1.0, v + jb);
-        if(rc != HIOPAMD_OK) return rc;
+    const bool same = B->sw_A == A && B->sw_lda == lda && B->sw_work == ctx->d_work;
+    if(n < 1024) {   // a few dozen launches: not worth a graph
+      const int rc = bk_enqueue_sweeps(B, A, lda);
+      if(rc != HIOPAMD_OK) return rc;
+    } else if(B->sweeps && same) {
+      HIOPAMD_CHECK(hipGraphLaunch(B->sweeps, s));
+    } else if(B->sw_warm && same) {
+      // second solve on this matrix address: capture the launch sequence (nothing executes), instantiate, replay
+      if(B->sweeps) {
+        (void)hipGraphExecDestroy(B->sweeps);
+        B->sweeps = nullptr;
       }
-    }
-    hipLaunchKernelGGL(bk_dsolve_kernel, gn, bn, 0, s, n, A, lda, B->e, v);
-    for(int jb = ((n - 1) / 64) * 64; jb >= 0; jb -= 64) {   // L^T w = z
-      const int bs = (n - jb < 64) ? (n - jb) : 64;
-      const int rest = n - jb - bs;
-      if(rest > 0) {
-        const int rc = hiopamd_mat_times_vec(ctx, bs, rest, A + (int64_t)jb * lda + jb + bs, lda, 1.0, v + jb, -1.0, v + jb + bs);
-        if(rc != HIOPAMD_OK) return rc;
+      hipGraph_t g = nullptr;
+      HIOPAMD_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      const int rc = bk_enqueue_sweeps(B, A, lda);
+      const hipError_t ec = hipStreamEndCapture(s, &g);
+      if(rc != HIOPAMD_OK || ec != hipSuccess || !g) {
+        if(g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return rc != HIOPAMD_OK ? rc : HIOPAMD_ERR_HIP;
       }
-      hipLaunchKernelGGL(bk_block_solve_kernel<true>, dim3(1), dim3(64), 0, s, A, lda, jb, bs, v);
+      const hipError_t ei = hipGraphInstantiate(&B->sweeps, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if(ei != hipSuccess) {
+        B->sweeps = nullptr;
+        return HIOPAMD_ERR_HIP;
+      }
+      HIOPAMD_CHECK(hipGraphLaunch(B->sweeps, s));
+    } else {
+      if(B->sweeps) {
+        (void)hipGraphExecDestroy(B->sweeps);
+        B->sweeps = nullptr;
+      }
+      const int rc = bk_enqueue_sweeps(B, A, lda);
+      if(rc != HIOPAMD_OK) return rc;
+      B->sw_A = A;
+      B->sw_lda = lda;
+      B->sw_work = ctx->d_work;   // (read AFTER the eager run: it has grown the workspace to what the sweeps need)
+      B->sw_warm = true;
     }
     hipLaunchKernelGGL(bk_gather_kernel, gn, bn, 0, s, n, B->perm, v, x, 1);
   }

@@ -90,6 +90,40 @@ def test_factor_equals_oracle_and_lapack(ctx, kind, n):
     dev.close()
 
 
+@pytest.mark.parametrize("n", [1024, 1300, 2500])
+def test_repeated_solves_replay_a_graph_and_survive_a_new_factorisation(ctx, n):
+    """from n = 1024 on the two sweeps of a solve are a HIP graph: the first solve with a matrix address runs eagerly, the second captures,
+    later ones replay.  All of them must give the bits of the first; a new factorisation in the same storage (other values, other
+    pivots, other inverted diagonal blocks) is picked up by the replayed graph; a matrix at ANOTHER address drops the graph."""
+    A = make("rand", n)
+    dev = DevBK(ctx, n)
+    dev.factor(A)
+    b = rng(n).uniform(-1, 1, n)
+    x0 = dev.solve(b)
+    assert np.abs(A @ x0 - b).max() <= 1e-11 * n * np.abs(A).max() * np.abs(x0).max()
+    for _ in range(4):
+        assert np.array_equal(dev.solve(b), x0)
+    # same storage, new values: copy into the tensor the graph's kernels point at
+    A2 = make("kkt", n)
+    M = dev.M
+    M.copy_(D(np.triu(A2)))
+    ine, info = (C.c_int * 3)(), C.c_int(0)
+    torch.cuda.synchronize()
+    assert dev.L.hiopamd_ldlt_bk_factor(dev.h, C.c_void_p(M.data_ptr()), n, ine, C.byref(info)) == 0 and info.value == 0
+    x2 = dev.solve(b)
+    ldu, ipiv_l, _ = lapack.dsytrf(A2, lower=1)
+    xl, _ = lapack.dsytrs(ldu, ipiv_l, b, lower=1)
+    assert np.abs(A2 @ x2 - b).max() <= 1e-11 * n * np.abs(A2).max() * np.abs(x2).max()
+    np.testing.assert_allclose(x2, xl, rtol=0, atol=1e-8 * np.abs(xl).max() * max(1.0, np.linalg.cond(A2) * 1e-8))
+    assert np.array_equal(dev.solve(b), x2)
+    # another address
+    dev.factor(A)            # (allocates a new tensor)
+    assert dev.M.data_ptr() != M.data_ptr()
+    for _ in range(3):
+        assert np.array_equal(dev.solve(b), x0)
+    dev.close()
+
+
 def test_singular_matrices(ctx):
     A = np.zeros((70, 70))
     A[0, 0] = 1.0
