@@ -27,14 +27,24 @@ constexpr int GEMV_COLS = kBlock * GEMV_COLS_PER_THREAD * GEMV_CHUNKS;  // 8192 
 // then 1 / 1: 4 + 2 + 1 + 3 exchanges instead of 48).
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const double* __restrict__ A, int64_t lda,
-                                                        const double* __restrict__ x, double* __restrict__ part, int chunks)
+                                                        const double* __restrict__ x, double* __restrict__ part, int chunks, int nchunks,
+                                                        int rtiles)
 {
-  const int r0 = blockIdx.y * GEMV_ROWS;
+  // Block -> (column chunk group bx, row tile by), XCD-aware (round 5).  x is read by every row tile: with the grid (chunk groups, row
+  // tiles) of rounds 2-4 the k / 8 row tiles of one chunk group ran far apart in time and each re-fetched its 64 KB of x — 250 MB of
+  // 2 250 at k = 200, n = 1.25e6 (PMC: 1.12 x the algorithmic bytes, profiles/r05_pmc_dense/summary.json).  The dispatcher deals
+  // consecutive workgroups round-robin over the 8 XCDs; here XCD q takes the chunk groups == q (mod 8) and walks the row tiles of one
+  // chunk group back to back, so that piece of x is fetched once per XCD-resident pass and hit in L2 by the other row tiles.  The partial
+  // sums and their order are those of the old grid: same bits.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bx = (slot / rtiles) * 8 + xcd, by = slot % rtiles;
+  if(bx >= nchunks) return;
+  const int r0 = by * GEMV_ROWS;
   double acc[GEMV_ROWS];
 #pragma unroll
   for(int r = 0; r < GEMV_ROWS; ++r) acc[r] = 0.0;
   for(int ch = 0; ch < chunks; ++ch) {
-    const int64_t c0 = ((int64_t)blockIdx.x * chunks + ch) * (kBlock * GEMV_COLS_PER_THREAD);
+    const int64_t c0 = ((int64_t)bx * chunks + ch) * (kBlock * GEMV_COLS_PER_THREAD);
     if(c0 >= n) break;
     if constexpr(VEC) {
       // Interior blocks (all GEMV_ROWS rows, a full chunk of columns): no guards, so the 4 + 32 sixteen-byte loads of a chunk are
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
     const int row = r0 + threadIdx.x;
     if(row < m) {
       double v = ((sm[threadIdx.x][0] + sm[threadIdx.x][1]) + sm[threadIdx.x][2]) + sm[threadIdx.x][3];
-      part[(int64_t)blockIdx.x * m + row] = v;
+      part[(int64_t)bx * m + row] = v;
     }
   }
 }
@@ -528,9 +538,9 @@ int hiopamd_mat_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, i
   const int nchunks = (int)((n + cols - 1) / cols);
   double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nchunks * m);
   const bool vec = (lda % 2 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)x % 16 == 0);
-  const dim3 g1(nchunks, rtiles), b1(kBlock);
-  if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks);
-  else hipLaunchKernelGGL(gemv_n_stage1<false>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks);
+  const dim3 g1((unsigned)(8 * ((nchunks + 7) / 8)) * (unsigned)rtiles), b1(kBlock);   // (see the block map in the kernel)
+  if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks, nchunks, rtiles);
+  else hipLaunchKernelGGL(gemv_n_stage1<false>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks, nchunks, rtiles);
   const int waves_per_block = kBlock / 64;
   hipLaunchKernelGGL(gemv_n_stage2, dim3((m + waves_per_block - 1) / waves_per_block), dim3(kBlock), 0, ctx->stream, m,
                      nchunks, part, beta, y, alpha);
