@@ -371,7 +371,6 @@ struct SlHostLayout {
   std::vector<int64_t> f_iofs;          // offset into fidx
   std::vector<int> fidx;                // per front: ORIGINAL indices of its f variables (columns, then rows)
   std::vector<int> fmax_level;          // largest front per level
-  std::vector<int> pmax_level;          // largest L panel ((nc + nr) * nc doubles) per level: LDS of the solve kernels
   int64_t lsize = 0, usize = 0, vsize = 0;
   SlPlanHost mat, vec;                  // fronts
   SlPlanHost rmat, rvec;                // root (one "front")
@@ -406,7 +405,6 @@ int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHos
   std::vector<int> front_of((size_t)Y.ns, -1);
   H.level_ptr.assign((size_t)Y.nlevels + 1, 0);
   H.fmax_level.assign((size_t)std::max(Y.nlevels, 1), 0);
-  H.pmax_level.assign((size_t)std::max(Y.nlevels, 1), 0);
   for(int q = 0; q < nf; ++q) {
     front_of[(size_t)order[(size_t)q]] = q;
     H.level_ptr[(size_t)Y.slevel[(size_t)order[(size_t)q]] + 1] += 1;
@@ -425,7 +423,6 @@ int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHos
     for(int k = 0; k < nc; ++k) H.fidx.push_back(Y.perm[(size_t)(Y.sfirst[(size_t)s] + k)]);
     for(int t = Y.srow_ptr[(size_t)s]; t < Y.srow_ptr[(size_t)s + 1]; ++t) H.fidx.push_back(Y.perm[(size_t)Y.srows[(size_t)t]]);
     H.fmax_level[(size_t)Y.slevel[(size_t)s]] = std::max(H.fmax_level[(size_t)Y.slevel[(size_t)s]], nc + nr);
-    H.pmax_level[(size_t)Y.slevel[(size_t)s]] = std::max(H.pmax_level[(size_t)Y.slevel[(size_t)s]], (nc + nr) * nc);
   }
   if(H.usize > (int64_t)1 << 40) return HIOPAMD_ERR_STATE;
   H.root_old.resize((size_t)Y.r);
@@ -640,21 +637,15 @@ __global__ __launch_bounds__(64) void sl_fwd_level_kernel(int q0, const int* __r
                                                           const double* __restrict__ lpool, double* __restrict__ vpool, double* __restrict__ b)
 {
   __shared__ double w[SL_T];
-  extern __shared__ double sl_panel[];   // the front's L panel, (nc + nr) x nc: staged in ONE batch of loads — read from memory inside the
-                                         // column loop it was a dependent round trip per pivot column (15 us per level at n = 1e6)
   const int q = q0 + blockIdx.x;
   const int nc = f_nc[q], nr = f_nr[q], f = nc + nr;
   const int lane = threadIdx.x;
   const int* idx = fidx + f_iofs[q];
-  {
-    const double* Lg = lpool + f_lofs[q];
-    for(int e = lane; e < f * nc; e += 64) sl_panel[e] = Lg[e];
-  }
   for(int i = lane; i < f; i += 64) w[i] = (i < nc) ? b[idx[i]] : 0.0;
   __syncthreads();
   for(int64_t t = front_run[q] + lane; t < front_run[q + 1]; t += 64) w[run_dest[t]] += sl_gather(srcs, run_ptr[t], run_ptr[t + 1], vpool, vpool);
   __syncthreads();
-  const double* L = sl_panel;
+  const double* L = lpool + f_lofs[q];
   for(int k = 0; k < nc; ++k) {
     const double yk = w[k];
     __syncthreads();
@@ -691,17 +682,11 @@ __global__ __launch_bounds__(64) void sl_bwd_level_kernel(int q0, const int* __r
                                                           const int* __restrict__ fidx, const double* __restrict__ lpool, double* __restrict__ x)
 {
   __shared__ double w[SL_T];
-  extern __shared__ double sl_panel[];   // (see sl_fwd_level_kernel)
   const int q = q0 + blockIdx.x;
   const int nc = f_nc[q], nr = f_nr[q], f = nc + nr;
   const int lane = threadIdx.x;
   const int* idx = fidx + f_iofs[q];
-  {
-    const double* Lg = lpool + f_lofs[q];
-    for(int e = lane; e < f * nc; e += 64) sl_panel[e] = Lg[e];
-  }
-  __syncthreads();
-  const double* L = sl_panel;
+  const double* L = lpool + f_lofs[q];
   for(int i = lane; i < f; i += 64) {
     const double v = x[idx[i]];
     w[i] = (i < nc) ? v / L[(int64_t)i * nc + i] : v;
@@ -925,7 +910,7 @@ int hiopamd_sparse_ldl_solve(hiopamd_sparse_ldl* s, double* x)
   for(int l = 0; l < s->Y.nlevels; ++l) {
     const int q0 = H.level_ptr[(size_t)l], cnt = H.level_ptr[(size_t)l + 1] - q0;
     if(cnt <= 0) continue;
-    hipLaunchKernelGGL(sl_fwd_level_kernel, dim3((unsigned)cnt), dim3(64), sizeof(double) * (size_t)H.pmax_level[(size_t)l], ctx->stream, q0, s->f_nc, s->f_nr, s->f_lofs, s->f_vofs, s->f_iofs,
+    hipLaunchKernelGGL(sl_fwd_level_kernel, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, q0, s->f_nc, s->f_nr, s->f_lofs, s->f_vofs, s->f_iofs,
                        s->fidx, s->vec.run_dest, s->vec.run_ptr, s->vec.src, s->vec.front_run, s->lpool, s->vpool, x);
   }
   const int r = s->Y.r;
@@ -942,7 +927,7 @@ int hiopamd_sparse_ldl_solve(hiopamd_sparse_ldl* s, double* x)
   for(int l = s->Y.nlevels - 1; l >= 0; --l) {
     const int q0 = H.level_ptr[(size_t)l], cnt = H.level_ptr[(size_t)l + 1] - q0;
     if(cnt <= 0) continue;
-    hipLaunchKernelGGL(sl_bwd_level_kernel, dim3((unsigned)cnt), dim3(64), sizeof(double) * (size_t)H.pmax_level[(size_t)l], ctx->stream, q0, s->f_nc, s->f_nr, s->f_lofs, s->f_iofs, s->fidx,
+    hipLaunchKernelGGL(sl_bwd_level_kernel, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, q0, s->f_nc, s->f_nr, s->f_lofs, s->f_iofs, s->fidx,
                        s->lpool, x);
   }
   HIOPAMD_CHECK(hipGetLastError());
