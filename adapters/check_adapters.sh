@@ -36,6 +36,7 @@ CXX="${CXX:-g++}"
 FLAGS=(-std=c++14 -fPIC -O1 -Wall -Wextra -Wno-unused-parameter -Woverloaded-virtual -Werror=overloaded-virtual)
 
 SRCS=(hiopVectorHipNative.cpp hiopVectorIntHipNative.cpp hiopMatrixDenseHipNative.cpp hiopMatrixSparseTripletHipNative.cpp hiopLinSolverSymDenseHipNative.cpp
+      hiopLinSolverSymSparseHipNative.cpp
       MdsEx1HipNative.cpp DenseConsEx2HipNative.cpp LinAlgFactoryHipNative.cpp)
 OBJS=()
 for s in "${SRCS[@]}"; do
@@ -64,6 +65,7 @@ cat > "$TMP/instantiate.cpp" <<'EOF'
 #include "hiopMatrixDenseHipNative.hpp"
 #include "hiopMatrixSparseTripletHipNative.hpp"
 #include "hiopLinSolverSymDenseHipNative.hpp"
+#include "hiopLinSolverSymSparseHipNative.hpp"
 #include "MdsEx1HipNative.hpp"
 #include "DenseConsEx2HipNative.hpp"
 using namespace hiop;
@@ -75,9 +77,11 @@ void* instantiate_all(hiopNlpFormulation* nlp)
   auto* S = new hiopMatrixSparseTripletHipNative(4, 8, 6);
   auto* Y = new hiopMatrixSymSparseTripletHipNative(8, 6);
   auto* L = new hiopLinSolverSymDenseHipNative(8, nlp);
+  auto* LS = new hiopLinSolverSymSparseHipNative(8, 6, nlp);   // (compile / link check: never executed)
+  auto* LS2 = new hiopLinSolverSymSparseHipNative(Y, nlp);
   hiopInterfaceMDS* E = new MdsEx1HipNative(40, 12);   // the user-problem side: hiopInterfaceMDS on device pointers
   hiopInterfaceDenseConstraints* E2 = new DenseConsEx2HipNative(1000);
-  static void* all[] = {v, vi, M, S, Y, L, E, E2};
+  static void* all[] = {v, vi, M, S, Y, L, LS, LS2, E, E2};
   return all;
 }
 EOF

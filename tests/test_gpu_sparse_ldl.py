@@ -148,6 +148,48 @@ def test_zero_pivot_is_reported_and_solve_refuses(ctx):
     S.close()
 
 
+def test_the_recipe_of_the_sparse_solver_adapter(ctx):
+    """adapters/hiopLinSolverSymSparseHipNative.cpp cannot run here (it needs libhiop); this is its sequence of C-ABI calls, restated:
+    the reference's symmetric TRIPLET (one triangle, unique entries, row-sorted) -> both triangles as CSR + a gather map CSR position ->
+    triplet entry (host, once) -> per factorisation: gather the values on the device, factorise, solve."""
+    n = 30000
+    A = quasi_definite(banded(n, 4, seed=2), n // 4, seed=5)
+    U = sp.triu(A).tocoo()
+    order = np.lexsort((U.col, U.row))
+    ti, tj, tv = U.row[order].astype(np.int32), U.col[order].astype(np.int32), U.data[order]
+    # first_call(): symmetrise, sort by (row, column), refuse duplicates
+    r = np.concatenate([ti, tj[ti != tj]])
+    c = np.concatenate([tj, ti[ti != tj]])
+    t = np.concatenate([np.arange(ti.size), np.arange(ti.size)[ti != tj]])
+    o = np.lexsort((c, r))
+    r, c, t = r[o], c[o], t[o].astype(np.int32)
+    assert not np.any((r[1:] == r[:-1]) & (c[1:] == c[:-1]))
+    rp = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(rp, r + 1, 1)
+    rp = np.cumsum(rp).astype(np.int32)
+    ci = c.astype(np.int32)
+    L = ctx._L
+    h = C.c_void_p()
+    assert L.hiopamd_sparse_ldl_create(C.byref(h), ctx.h, n, rp.ctypes.data, ci.ctypes.data) == 0
+    gather = torch.as_tensor(t).cuda()
+    csr_vals = torch.zeros(t.size, dtype=torch.float64, device="cuda")
+    b = np.random.default_rng(1).uniform(-1, 1, n)
+    for scale in (1.0, 2.5):              # two "IPM iterations": same pattern, new values
+        tvals = D(tv * scale)
+        torch.cuda.synchronize()
+        assert L.hiopamd_vec_copy_from_indexes(ctx.h, t.size, C.c_void_p(csr_vals.data_ptr()), C.c_void_p(tvals.data_ptr()),
+                                               C.c_void_p(gather.data_ptr())) == 0
+        nneg, nzero = C.c_int(-7), C.c_int(-7)
+        assert L.hiopamd_sparse_ldl_factorize(h, C.c_void_p(csr_vals.data_ptr()), C.byref(nneg), C.byref(nzero)) == 0
+        assert (nneg.value, nzero.value) == (n_negative_diagonal(A), 0)        # matrixChanged() would return nneg
+        x = D(b)
+        torch.cuda.synchronize()
+        assert L.hiopamd_sparse_ldl_solve(h, C.c_void_p(x.data_ptr())) == 0
+        ctx.sync()
+        assert np.abs(scale * (A @ x.cpu().numpy()) - b).max() <= 1e-10
+    L.hiopamd_sparse_ldl_destroy(h)
+
+
 # ---- behind the condensed sparse KKT -------------------------------------------------------------------------------------------------
 def chain_problem(n, seed, couple=2):
     """inequalities d_i = sum_{q < couple} a_iq x_{i+q} (i = 0 .. n - couple), diagonal Hessian: M = H + Dx + Jd^T Dd Jd is banded"""
