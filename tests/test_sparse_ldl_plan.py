@@ -184,6 +184,9 @@ CASES = [
     ("block-arrow-200", lambda: block_arrow(30, 8, 200, 5)),
     ("random-fill", lambda: random_fill(500, 2.2, 6)),
     ("diagonal", lambda: sp.diags(np.linspace(1, 2, 300)).tocsr()),
+    ("one-by-one", lambda: sp.csr_matrix(np.array([[3.0]]))),
+    ("two-components", lambda: sp.block_diag([banded(130, 3, 11), banded(75, 2, 12)]).tocsr()),
+    ("many-tiny-components", lambda: sp.block_diag([banded(3, 1, 20 + q) for q in range(90)] + [sp.csr_matrix(np.array([[2.0 + q]])) for q in range(40)]).tocsr()),
     ("banded-indefinite", lambda: quasi_definite(banded(800, 5, 7), 300, 8)),
     ("arrow-indefinite", lambda: quasi_definite(block_arrow(25, 6, 40, 9), 60, 10)),
 ]
