@@ -78,6 +78,8 @@ struct hiopamd_ctx {
   int cu_split_state = 0;              // 0 not tried, 1 masked streams available, -1 unavailable
   int chain_cus = 0, wide_cus = 0;     // CUs behind diag_stream / upd_stream (from hipDeviceProp_t::multiProcessorCount and the reservation)
   hipEvent_t ev_pool[160] = {nullptr};
+  hipEvent_t ev_info = nullptr;      // behind the read-back of a factorisation's info words (the host waits for THIS, not for the whole stream)
+  hipEvent_t ev_pending = nullptr;   // behind the last deferred reduction (reduce_flush waits for this)
   int n_events = 0;
   void* spans = nullptr;               // hiopamd::SpanState (context.hip): KKT / linear-solver run-stats spans
   // deferred reductions (hiopamd_ctx_reduce_begin / _end): the reductions launched inside the bracket write their results to consecutive
@@ -145,6 +147,11 @@ struct SpanScope {
   SpanScope& operator=(const SpanScope&) = delete;
 };
 
+inline hipEvent_t ctx_named_event(hipEvent_t& e)
+{
+  if(!e) HIOPAMD_CHECK_ABORT(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
 inline hipEvent_t ctx_event(hiopamd_ctx* ctx, int i)
 {
   while(ctx->n_events <= i) {
@@ -192,7 +199,10 @@ inline void* ctx_workspace(hiopamd_ctx* ctx, size_t bytes)
 static inline int reduce_flush(hiopamd_ctx* ctx)
 {
   if(ctx->n_pending == 0) return HIOPAMD_OK;
-  HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
+  // wait for the LAST deferred reduction, not for whatever was queued behind it (a factorisation's epilogue kernels, for one): every
+  // deferred launch re-records this event (device_utils.hpp, launch_reduce_fin)
+  if(ctx->ev_pending) HIOPAMD_CHECK(hipEventSynchronize(ctx->ev_pending));
+  else HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));
   for(auto& f : ctx->pending) f();
   ctx->pending.clear();
   ctx->n_pending = 0;

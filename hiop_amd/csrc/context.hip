@@ -212,6 +212,8 @@ int hiopamd_ctx_destroy(hiopamd_ctx* c)
     hipStreamDestroy(c->upd_stream);
   }
   for(int i = 0; i < c->n_events; ++i) hipEventDestroy(c->ev_pool[i]);
+  if(c->ev_info) hipEventDestroy(c->ev_info);
+  if(c->ev_pending) hipEventDestroy(c->ev_pending);
   for(hipEvent_t e : c->coll_ev) hipEventDestroy(e);
   if(c->spans) {
     hiopamd::SpanState* st = static_cast<hiopamd::SpanState*>(c->spans);

@@ -132,6 +132,7 @@ static inline int launch_reduce_fin(hiopamd_ctx* ctx, int64_t n, Op op, Fin fin,
   if(may_defer && ctx->defer_depth > 0) {
     ctx->pending.emplace_back([out_host, fin]() { fin(*out_host); });
     ctx->n_pending += 1;
+    HIOPAMD_CHECK(hipEventRecord(ctx_named_event(ctx->ev_pending), ctx->stream));
     return HIOPAMD_OK;
   }
   HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));

@@ -2667,17 +2667,6 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   span_begin(ctx, HIOPAMD_SPAN_LINSOLV_INERTIA);   // :127-167 (tmInertiaComp)
   hipLaunchKernelGGL(ldlt_inertia_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, N, A, lda, d_info + 1);   // (d_info was zeroed at the start)
   span_end(ctx, HIOPAMD_SPAN_LINSOLV_INERTIA);
-  if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv, wB);
-  if(Winv && wB == 512 && Wt) {
-    // T = U_ab W_b, then the upper-right quadrant = -W_a T   (N is a multiple of 512 here; U_ab = A[rows of a, columns of b])
-    const int np2 = N / 512;
-    const int64_t w2 = 512 * 512;
-    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(64, np2), dim3(kBlock), 0, st, A + LD_NB, (int64_t)512 * lda + 512, lda,
-                       Winv + (int64_t)LD_NB * 512 + LD_NB, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB, (int64_t)LD_NB, 1.0);
-    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(64, np2), dim3(kBlock), 0, st, Winv, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB,
-                       (int64_t)LD_NB, Winv + LD_NB, w2, (int64_t)512, -1.0);
-  }
-  HIOPAMD_CHECK(hipGetLastError());
   // The results come back through a PINNED host buffer (one per thread, allocated once): these copies are enqueued while the dataflow
   // kernels are still running, and a copy into pageable memory can make the runtime map / pin pages at that moment — a change of the
   // process's GPU mappings, for which the kernel driver may preempt and restore the process's queues.  Persistent kernels whose
@@ -2689,7 +2678,21 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   for(int q = 0; q < 16; ++q) dfw[q] = 0u;
   HIOPAMD_CHECK(hipMemcpyAsync(h, d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   if(use_df) HIOPAMD_CHECK(hipMemcpyAsync(dfw, df->flags, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  HIOPAMD_CHECK(hipStreamSynchronize(st));
+  HIOPAMD_CHECK(hipEventRecord(ctx_named_event(ctx->ev_info), st));
+  if(Winv) hipLaunchKernelGGL(ldlt_inv_diag_kernel, dim3(16, nsp), dim3(64), 0, st, N, Cd, Dblk, Li, Winv, wB);
+  if(Winv && wB == 512 && Wt) {
+    // T = U_ab W_b, then the upper-right quadrant = -W_a T   (N is a multiple of 512 here; U_ab = A[rows of a, columns of b])
+    const int np2 = N / 512;
+    const int64_t w2 = 512 * 512;
+    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(64, np2), dim3(kBlock), 0, st, A + LD_NB, (int64_t)512 * lda + 512, lda,
+                       Winv + (int64_t)LD_NB * 512 + LD_NB, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB, (int64_t)LD_NB, 1.0);
+    hipLaunchKernelGGL(ldlt_w512_mm_kernel, dim3(64, np2), dim3(kBlock), 0, st, Winv, w2, (int64_t)512, Wt, (int64_t)LD_NB * LD_NB,
+                       (int64_t)LD_NB, Winv + LD_NB, w2, (int64_t)512, -1.0);
+  }
+  HIOPAMD_CHECK(hipGetLastError());
+  // The host waits for the info words' read-back, NOT for the stream: the kernels above (inverted diagonal blocks, 512-block products: ~0.14 ms)
+  // only feed the next solve, which is queued behind them on the same stream — meanwhile the caller has its inertia and goes on enqueueing.
+  HIOPAMD_CHECK(hipEventSynchronize(ctx->ev_info));
   if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
     const DfPlan& P = df->plan;
     std::vector<unsigned> ts((size_t)8 * (P.nsp + 1));
