@@ -250,3 +250,80 @@ def test_missing_diagonal_is_refused():
     L = _lib()
     ip = lambda a: a.ctypes.data_as(C.c_void_p)
     assert L.hiopamd_sparse_ldl_analyse(3, ip(rp), ip(ci), ip(info), C.c_void_p(0)) == -5
+
+
+# ---- a seeded sweep over pattern families the fixed cases do not have -----------------------------------------------------------
+def _random_structure(seed):
+    """one of: grid (2-D 5-point, narrow), tree-like (random recursive tree + a few chords), star-of-chains (a hub row), block chain with
+    dense coupling blocks, banded with random gaps + isolated vertices, union of two banded matrices under a random permutation;
+    strictly diagonally dominant with a random sign pattern on the diagonal (quasi-definite: the inertia is the diagonal's)"""
+    rng = np.random.default_rng(seed)
+    kind = seed % 6
+    n = int(rng.integers(40, 420))
+    rows, cols = [], []
+
+    def edge(i, j):
+        if i != j:
+            rows.append(i); cols.append(j)
+
+    if kind == 0:                                   # grid w x h, w small (separators of size w)
+        w = int(rng.integers(3, 9)); h = max(2, n // w); n = w * h
+        for y in range(h):
+            for x in range(w):
+                if x + 1 < w: edge(y * w + x, y * w + x + 1)
+                if y + 1 < h: edge(y * w + x, (y + 1) * w + x)
+    elif kind == 1:                                 # random recursive tree + chords
+        for i in range(1, n): edge(i, int(rng.integers(0, i)))
+        for _ in range(n // 10): edge(int(rng.integers(0, n)), int(rng.integers(0, n)))
+    elif kind == 2:                                 # chains hanging off one hub (a dense row)
+        for i in range(1, n):
+            edge(i, 0)
+            if i % 7: edge(i, i - 1)
+    elif kind == 3:                                 # chain of dense blocks with dense couplings
+        bs = int(rng.integers(3, 10)); nb = max(2, n // bs); n = nb * bs
+        for b in range(nb):
+            for i in range(bs):
+                for j in range(i):
+                    edge(b * bs + i, b * bs + j)
+                if b + 1 < nb:
+                    for j in range(bs):
+                        if rng.random() < 0.6: edge(b * bs + i, (b + 1) * bs + j)
+    elif kind == 4:                                 # banded with gaps, some isolated vertices
+        bw = int(rng.integers(1, 6))
+        for i in range(n):
+            if i % 11 == 5: continue                # isolated
+            for k in range(1, bw + 1):
+                if i + k < n and (i + k) % 11 != 5 and rng.random() < 0.8: edge(i, i + k)
+    else:                                           # two banded matrices on a shuffled numbering
+        p = rng.permutation(n)
+        for i in range(n - 1): edge(int(p[i]), int(p[i + 1]))
+        q = rng.permutation(n)
+        for i in range(0, n - 3, 2): edge(int(q[i]), int(q[i + 3]))
+    v = rng.uniform(-1, 1, len(rows))
+    A = sp.coo_matrix((v, (rows, cols)), shape=(n, n)).tocsr()
+    A = A + A.T
+    d = np.asarray(abs(A).sum(axis=1)).ravel() + rng.uniform(0.5, 2.0, n)
+    sign = np.where(rng.random(n) < 0.3, -1.0, 1.0)
+    return (A + sp.diags(d * sign)).tocsr(), int((sign < 0).sum())
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_seeded_sweep_of_pattern_families(seed):
+    A, nneg_expected = _random_structure(seed)
+    n = A.shape[0]
+    rp, ci, vals = csr_full(A)
+    rc, P = get_plan(n, rp, ci)
+    assert rc == 0
+    # every variable is eliminated exactly once: the fronts' pivot columns and the root partition 0 .. n-1
+    piv = []
+    for q in range(P["nf"]):
+        piv += list(P["fidx"][P["f_iofs"][q]:P["f_iofs"][q] + P["f_nc"][q]])
+    piv += list(P["root_old"][:P["r"]])
+    assert sorted(int(i) for i in piv) == list(range(n))
+    lpool, R, nneg, nzero = replay_factor(P, vals)
+    Rs = np.triu(R) + np.triu(R, 1).T
+    ev_root = np.linalg.eigvalsh(Rs) if P["r"] else np.zeros(0)
+    assert nzero == 0 and nneg + int((ev_root < 0).sum()) == nneg_expected
+    b = np.random.default_rng(seed + 1000).uniform(-1, 1, n)
+    x = replay_solve(P, lpool, R, b)
+    assert np.abs(A @ x - b).max() <= 1e-10 * max(1.0, np.abs(x).max())
