@@ -593,10 +593,19 @@ __global__ void sl_factor_level_kernel(int q0, const int* __restrict__ f_nc, con
     __syncthreads();
     // F[i][j] -= lk[i] * vk[j],  f > i >= j > k: rows dealt to threads in interleaved pairs (row i and row f - 1 - (i - k - 1)) would balance
     // better; the plain row-cyclic form is enough for fronts of <= 128 rows
-    const int m = f - k - 1;
-    for(int e = tid; e < m * m; e += nt) {
-      const int ii = e / m, jj = e % m;
-      if(jj <= ii) F[(k + 1 + ii) * ldf + (k + 1 + jj)] -= lk[k + 1 + ii] * vk[k + 1 + jj];
+    // (rows dealt to threads, the threads of a row split its columns: no integer division per element — the element-per-thread form
+    //  spent more time on e / m, e % m than on the update, and half its elements were above the diagonal)
+    {
+      const int m = f - k - 1;
+      const int tpr = (nt >= 2 * m) ? (nt / m < 8 ? nt / m : 8) : 1;   // threads per row
+      const int rgrp = nt / tpr;                                       // rows in flight
+      const int sub = tid % tpr, r0 = tid / tpr;
+      if(r0 < rgrp)
+        for(int ii = r0; ii < m; ii += rgrp) {
+          const double li = lk[k + 1 + ii];
+          double* Fr = F + (k + 1 + ii) * ldf + (k + 1);
+          for(int jj = sub; jj <= ii; jj += tpr) Fr[jj] -= li * vk[k + 1 + jj];
+        }
     }
     for(int i = k + 1 + tid; i < f; i += nt) F[i * ldf + k] = lk[i];
     __syncthreads();
@@ -605,9 +614,12 @@ __global__ void sl_factor_level_kernel(int q0, const int* __restrict__ f_nc, con
     if(nneg) atomicAdd(counts, nneg);
     if(nzero) atomicAdd(counts + 1, nzero);
   }
+  // the L panel COLUMN by column (column k contiguous: L[k * f + i]): the solve sweeps walk a column with consecutive lanes.  (Row by
+  // row, as first written, every column step of a sweep touched one 64-byte sector per row for 8 bytes of it: 8 x the panel's bytes from L2
+  // per sweep — the leaf level of the n = 1e6 banded case took 159 / 150 of the forward / backward sweep's 275 / 241 us.)
   double* L = lpool + f_lofs[q];
   for(int e = tid; e < f * nc; e += nt) {
-    const int i = e / nc, k = e % nc;
+    const int k = e / f, i = e % f;
     L[e] = (i >= k) ? F[i * ldf + k] : 0.0;   // diagonal: d_k; below: L; above (inside the pivot block): unused
   }
   double* U = upool + f_uofs[q];
@@ -649,7 +661,7 @@ __global__ __launch_bounds__(64) void sl_fwd_level_kernel(int q0, const int* __r
   for(int k = 0; k < nc; ++k) {
     const double yk = w[k];
     __syncthreads();
-    for(int i = k + 1 + lane; i < f; i += 64) w[i] -= L[(int64_t)i * nc + k] * yk;
+    for(int i = k + 1 + lane; i < f; i += 64) w[i] -= L[(int64_t)k * f + i] * yk;
     __syncthreads();
   }
   for(int i = lane; i < f; i += 64) {
@@ -689,12 +701,12 @@ __global__ __launch_bounds__(64) void sl_bwd_level_kernel(int q0, const int* __r
   const double* L = lpool + f_lofs[q];
   for(int i = lane; i < f; i += 64) {
     const double v = x[idx[i]];
-    w[i] = (i < nc) ? v / L[(int64_t)i * nc + i] : v;
+    w[i] = (i < nc) ? v / L[(int64_t)i * f + i] : v;
   }
   __syncthreads();
   for(int k = nc - 1; k >= 0; --k) {
     double s = 0.0;
-    for(int i = k + 1 + lane; i < f; i += 64) s += L[(int64_t)i * nc + k] * w[i];
+    for(int i = k + 1 + lane; i < f; i += 64) s += L[(int64_t)k * f + i] * w[i];
     for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if(lane == 0) w[k] -= s;
     __syncthreads();
