@@ -658,15 +658,37 @@ __global__ __launch_bounds__(64) void sl_fwd_level_kernel(int q0, const int* __r
   for(int64_t t = front_run[q] + lane; t < front_run[q + 1]; t += 64) w[run_dest[t]] += sl_gather(srcs, run_ptr[t], run_ptr[t + 1], vpool, vpool);
   __syncthreads();
   const double* L = lpool + f_lofs[q];
-  for(int k = 0; k < nc; ++k) {
-    const double yk = w[k];
-    __syncthreads();
-    for(int i = k + 1 + lane; i < f; i += 64) w[i] -= L[(int64_t)k * f + i] * yk;
-    __syncthreads();
+  // the column sweep in REGISTERS: rows lane and lane + 64 of the front's vector live in this lane (f <= 128), the pivot entry of a step is
+  // broadcast by a shuffle (nc <= 48 < 64: always in the first register) — no LDS round trip and no barrier per column
+  double w0 = (lane < f) ? w[lane] : 0.0, w1 = (lane + 64 < f) ? w[lane + 64] : 0.0;
+  // (sixteen columns' entries are requested together: the loop itself is a chain of dependent steps, and one load per step would put a
+  //  memory round trip into each of them)
+  const bool two = f > 64;   // uniform
+  for(int k0 = 0; k0 < nc; k0 += 16) {
+    double l0[16], l1[16];
+#pragma unroll
+    for(int u = 0; u < 16; ++u) {
+      const int k = k0 + u;
+      l0[u] = (k < nc && lane > k && lane < f) ? L[(int64_t)k * f + lane] : 0.0;
+      l1[u] = (two && k < nc && lane + 64 < f) ? L[(int64_t)k * f + lane + 64] : 0.0;
+    }
+#pragma unroll
+    for(int u = 0; u < 16; ++u) {
+      const int k = k0 + u;
+      if(k < nc) {   // uniform
+        const double yk = __shfl(w0, k, 64);
+        w0 -= l0[u] * yk;      // (zero for the rows at or above the pivot)
+        if(two) w1 -= l1[u] * yk;
+      }
+    }
   }
-  for(int i = lane; i < f; i += 64) {
-    if(i < nc) b[idx[i]] = w[i];
-    else vpool[f_vofs[q] + (i - nc)] = w[i];
+  if(lane < f) {
+    if(lane < nc) b[idx[lane]] = w0;
+    else vpool[f_vofs[q] + (lane - nc)] = w0;
+  }
+  if(lane + 64 < f) {
+    if(lane + 64 < nc) b[idx[lane + 64]] = w1;
+    else vpool[f_vofs[q] + (lane + 64 - nc)] = w1;
   }
 }
 
@@ -693,25 +715,41 @@ __global__ __launch_bounds__(64) void sl_bwd_level_kernel(int q0, const int* __r
                                                           const int64_t* __restrict__ f_lofs, const int64_t* __restrict__ f_iofs,
                                                           const int* __restrict__ fidx, const double* __restrict__ lpool, double* __restrict__ x)
 {
-  __shared__ double w[SL_T];
   const int q = q0 + blockIdx.x;
   const int nc = f_nc[q], nr = f_nr[q], f = nc + nr;
   const int lane = threadIdx.x;
   const int* idx = fidx + f_iofs[q];
   const double* L = lpool + f_lofs[q];
-  for(int i = lane; i < f; i += 64) {
-    const double v = x[idx[i]];
-    w[i] = (i < nc) ? v / L[(int64_t)i * f + i] : v;
+  // rows lane and lane + 64 of the front's vector in registers (f <= 128; the pivot rows, nc <= 48, in the first one): a column step is a
+  // dot product folded by shuffles (a fixed tree: reproducible run to run) and one lane's update — no LDS, no barrier
+  double w0 = 0.0, w1 = 0.0;
+  if(lane < f) {
+    const double v = x[idx[lane]];
+    w0 = (lane < nc) ? v / L[(int64_t)lane * f + lane] : v;
   }
-  __syncthreads();
-  for(int k = nc - 1; k >= 0; --k) {
-    double s = 0.0;
-    for(int i = k + 1 + lane; i < f; i += 64) s += L[(int64_t)k * f + i] * w[i];
-    for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if(lane == 0) w[k] -= s;
-    __syncthreads();
+  if(lane + 64 < f) w1 = x[idx[lane + 64]];
+  const bool two = f > 64;   // uniform
+  for(int k0 = ((nc - 1) / 16) * 16; k0 >= 0; k0 -= 16) {   // sixteen columns' entries requested together (see sl_fwd_level_kernel)
+    double l0[16], l1[16];
+#pragma unroll
+    for(int u = 0; u < 16; ++u) {
+      const int k = k0 + u;
+      l0[u] = (k < nc && lane > k && lane < f) ? L[(int64_t)k * f + lane] : 0.0;
+      l1[u] = (two && k < nc && lane + 64 < f) ? L[(int64_t)k * f + lane + 64] : 0.0;
+    }
+#pragma unroll
+    for(int u = 15; u >= 0; --u) {
+      const int k = k0 + u;
+      if(k < nc) {   // uniform
+        double s = l0[u] * w0;
+        if(two) s += l1[u] * w1;
+        for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        const double tot = __shfl(s, 0, 64);
+        if(lane == k) w0 -= tot;
+      }
+    }
   }
-  for(int i = lane; i < nc; i += 64) x[idx[i]] = w[i];
+  if(lane < nc) x[idx[lane]] = w0;
 }
 
 }  // namespace
