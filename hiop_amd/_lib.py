@@ -12,7 +12,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 HEADER = ROOT.parent / "include" / "hiop_amd.h"
-LIBPATH = ROOT / "lib" / "libhiopamd.so"
+import os as _os
+_VARIANT = _os.environ.get("HIOPAMD_BUILD_VARIANT", "")          # a test build of hiop_amd/build.py (e.g. "poison"); default: the shipped one
+LIBPATH = ROOT / ("lib" if not _VARIANT else f"lib_{_VARIANT}") / "libhiopamd.so"
 
 _OPAQUE = {"hiopamd_ctx", "hiopamd_sp_plan", "hiopamd_linsolver", "hiopamd_kkt_mds", "hiopamd_kkt_lowrank",
            "hiopamd_hess_lowrank"}

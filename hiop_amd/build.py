@@ -14,9 +14,18 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
-LIBDIR = ROOT / "lib"
+
+# HIOPAMD_BUILD_VARIANT selects a TEST build next to the shipped one (own object and library directories; hiop_amd/_lib.py loads the same
+# variant).  "poison": every device allocation of the library is filled with 0xFF bytes (NaN / -1) — the GPU suite under it finds reads of
+# memory nobody wrote (csrc/common.hpp, HIOPAMD_POISON_ALLOC).
+VARIANTS = {"": [], "poison": ["-DHIOPAMD_POISON_ALLOC"]}
+VARIANT = os.environ.get("HIOPAMD_BUILD_VARIANT", "")
+if VARIANT not in VARIANTS:
+    raise RuntimeError(f"unknown HIOPAMD_BUILD_VARIANT {VARIANT!r} (known: {sorted(VARIANTS)})")
+LIBDIR = ROOT / ("lib" if not VARIANT else f"lib_{VARIANT}")
 LIB = LIBDIR / "libhiopamd.so"
-OBJDIR = ROOT / "build"
+STAMP = LIBDIR / "libhiopamd.stamp"
+OBJDIR = ROOT / ("build" if not VARIANT else f"build_{VARIANT}")
 
 SOURCES = [
     "context.hip",
@@ -69,6 +78,20 @@ def _deps() -> list[Path]:
     return hdrs
 
 
+def _fingerprint() -> str:
+    """Hash of everything the library is made of: sources, headers, this file (flags).  Written next to the library; a library whose
+    stamp matches is up to date wherever it was built — the objects do not travel to the GPU box (.gpurunignore) and file times need
+    not survive the copy, so neither can decide that."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted([CSRC / s for s in SOURCES] + _deps() + [Path(__file__)]):
+        if p.exists():
+            h.update(p.name.encode())
+            h.update(p.read_bytes())
+    h.update(VARIANT.encode())
+    return h.hexdigest()
+
+
 def _needs(obj: Path, src: Path) -> bool:
     if not obj.exists():
         return True
@@ -77,6 +100,9 @@ def _needs(obj: Path, src: Path) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
+    fp = _fingerprint()
+    if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == fp:
+        return LIB
     hipcc = _hipcc()
     OBJDIR.mkdir(exist_ok=True)
     LIBDIR.mkdir(exist_ok=True)
@@ -89,7 +115,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc, *CXXFLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *CXXFLAGS, *VARIANTS[VARIANT], *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr[-4000:]}")
@@ -109,6 +135,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
         if verbose:
             print(f"[hiop_amd.build] linked {LIB}", file=sys.stderr)
+    STAMP.write_text(fp + "\n")
     return LIB
 
 

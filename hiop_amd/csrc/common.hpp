@@ -35,6 +35,20 @@ namespace hiopamd {
     }                                                                                         \
   } while(0)
 
+#ifdef HIOPAMD_POISON_ALLOC
+// Test build (scripts/build_poison.sh, never the shipped library): every hipMalloc of the library is filled with 0xFF bytes — quiet
+// NaNs as doubles, -1 as ints — so that a kernel that reads memory nobody wrote (0 x uninitialised in a padded tile, a flag word taken
+// as initialised) fails in every run instead of only on a box whose fresh HBM happens to hold such a pattern.
+inline hipError_t poison_malloc(void** p, size_t bytes)
+{
+  hipError_t e = hipMalloc(p, bytes);
+  if(e == hipSuccess && bytes > 0) e = hipMemset(*p, 0xFF, bytes);
+  if(e == hipSuccess) e = hipDeviceSynchronize();
+  return e;
+}
+#define hipMalloc(p, bytes) ::hiopamd::poison_malloc((void**)(p), (bytes))
+#endif
+
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kMaxGrid = 2048;       // 256 CUs x 8 blocks; grid-stride beyond
 constexpr int kPartials = kMaxGrid;  // reduction partial slots

@@ -795,6 +795,25 @@ int MdsSolver::run()
       status = Err_Step_Computation;
       break;
     }
+    {
+      // A direction with a NaN or an Inf in it is a FAILED direction (the reference's compute_search_direction would hand the line search
+      // nothing else either, hiopAlgFilterIPM.cpp:3335-3390): said here, with the place, instead of fifty-three halvings of alpha and a
+      // "step length too small" that blames the model for what the linear algebra delivered.
+      int finite = 1;
+      RC(hiopamd_vec_isfinite(ctx, dim, dir.p, &finite));
+      if(!finite) {
+        static const char* const names[12] = {"x", "d", "yc", "yd", "sxl", "sxu", "sdl", "sdu", "zl", "zu", "vl", "vu"};
+        std::fprintf(stderr, "hiop_amd: the search direction of iteration %d is not finite (parts:", iter_num);
+        for(int p = 0; p < 12; ++p) {
+          int fp = 1;
+          if(off[p + 1] > off[p]) RC(hiopamd_vec_isfinite(ctx, off[p + 1] - off[p], dir.p + off[p], &fp));
+          if(!fp) std::fprintf(stderr, " %s", names[p]);
+        }
+        std::fprintf(stderr, "): Err_Step_Computation\n");
+        status = Err_Step_Computation;
+        break;
+      }
+    }
     t_kkt += std::chrono::duration<double>(clk::now() - t_k0).count();   // end_optimiz_iteration (:2461); the call above synchronised
     // ---- backtracking line search, :2477-2588
     RC(hiopamd_iterate_fraction_to_the_bdry(full, it.p, dir.p, tau, &ap, &ad));
@@ -875,6 +894,8 @@ int MdsSolver::run()
     if(status == Err_Step_Computation) break;
     if(small_step) {
       std::fprintf(stderr, "hiop_amd: minimum step size reached at iteration %d; feasibility restoration is not implemented\n", iter_num);
+      std::fprintf(stderr, "hiop_amd:   last trial point: theta %.6e (current %.6e), barrier objective %.6e (current %.6e), %d trial points\n",
+                   theta_trial, theta, f_logbar_trial, f_logbar, ls_num);
       status = Steplength_Too_Small;
       break;
     }

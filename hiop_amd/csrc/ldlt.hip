@@ -518,7 +518,14 @@ __device__ __forceinline__ void block_row_solve(const double* A, int64_t lda, in
       for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
         for(int kk = 0; kk < 4; ++kk)
-          Lop[I][Jq][kk] = -ld_batch(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (64 * P + 16 * I + li));
+        {
+          // IDENT (the inverse of a diagonal block, possibly the ragged last one): columns of the compact block at and behind kbs are
+          // padding nobody writes for the blocks the trailing update fills (it stores the entries that exist) — they are rows of the
+          // result that do not exist, but a NaN there reaches the rows that do through 0 x NaN in the 16-row substitution below
+          const int cpad = 64 * P + 16 * I + li;
+          const double lv = ld_batch(Cd + (64 * q + 16 * Jq + 4 * kk + g) * LD_NB + (IDENT ? (cpad < kbs ? cpad : 0) : cpad));
+          Lop[I][Jq][kk] = (IDENT && cpad >= kbs) ? 0.0 : -lv;
+        }
 #pragma unroll
     for(int Jq = 0; Jq < 4; ++Jq)
 #pragma unroll
@@ -3128,6 +3135,10 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
   HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb)));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB)));   // blocks + transposes
+  // The compact blocks are filled by the kernels that produce them with the entries that EXIST (upper triangle, rows and columns below
+  // the order): the padding of a ragged last block is defined here, once — zero, and no kernel writes it afterwards (round 6: it was
+  // whatever the allocation held, and the block inversion read it; see DESIGN.md 3.1, "the round-5 gate failure")
+  HIOPAMD_CHECK(hipMemsetAsync(ls->Cd, 0, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB), ctx->stream));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
   {
     // dataflow solve: inverted diagonal blocks, product slots, flags, and the task list in issue order
