@@ -50,6 +50,9 @@ int hiopLinSolverSymDenseHipNative::matrixChanged()
                  rc, device_failures_);
     return -1;
   }
+  // the reference's callers own sysMatrix() between calls and may write it by any means (other streams, blocking copies): nothing of
+  // this call may still be reading it when it returns (hiop_amd.h, "STREAM CONTRACT" of hiopamd_linsolver_matrix_changed)
+  hiopamd_ctx_sync(ctx_);
   device_failures_ = 0;
   return n_neg;   // -1: zero / non-finite pivot (or, in safe mode, a probe solve that did not converge): the reference's "singular" answer
 }

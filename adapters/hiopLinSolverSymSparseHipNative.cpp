@@ -62,6 +62,14 @@ int hiopLinSolverSymSparseHipNative::first_call()
   rc = hiopamd_alloc((void**)&csr_vals_, sizeof(double) * es.size());
   if(rc == HIOPAMD_OK) rc = hiopamd_alloc((void**)&gather_, sizeof(int) * es.size());
   if(rc == HIOPAMD_OK) rc = hiopamd_copy_h2d(ctx_, gather_, src.data(), sizeof(int) * es.size());
+  if(rc != HIOPAMD_OK) {   // all or nothing: a half-built object must not look initialised to the next matrixChanged()
+    hiopamd_sparse_ldl_destroy(ldl_);
+    ldl_ = nullptr;
+    if(csr_vals_) hiopamd_free(csr_vals_);
+    if(gather_) hiopamd_free(gather_);
+    csr_vals_ = nullptr;
+    gather_ = nullptr;
+  }
   return rc;
 }
 
@@ -70,7 +78,16 @@ int hiopLinSolverSymSparseHipNative::matrixChanged()
   assert(M_ && M_->m() == M_->n() && (int)M_->m() == n_);
   if(nlp_) nlp_->runStats.linsolv.tmFactTime.start();
   int rc = HIOPAMD_OK;
-  if(!ldl_) rc = first_call();
+  if(pattern_status_ != HIOPAMD_OK) {
+    rc = pattern_status_;   // the pattern was rejected once (malformed triplets, root beyond the solver's limit): it will not change — fail fast
+  } else if(!ldl_) {
+    rc = first_call();
+    if(rc == HIOPAMD_ERR_ARG || rc == HIOPAMD_ERR_STATE) {
+      pattern_status_ = rc;
+      std::fprintf(stderr, "hiop_amd: hiopLinSolverSymSparseHipNative: this sparsity pattern is not accepted (%s); every later matrixChanged() fails at once\n",
+                   rc == HIOPAMD_ERR_ARG ? "out-of-range or duplicate triplets" : "the dense root of the elimination tree exceeds the solver's limit");
+    }
+  }
   if(rc == HIOPAMD_OK) rc = hiopamd_vec_copy_from_indexes(ctx_, nnz_csr_, csr_vals_, static_cast<const hiopMatrixSparse*>(M_)->M(), gather_);
   if(rc == HIOPAMD_OK) rc = hiopamd_sparse_ldl_factorize(ldl_, csr_vals_, &n_neg_, &n_zero_);
   if(nlp_) nlp_->runStats.linsolv.tmFactTime.stop();

@@ -44,6 +44,7 @@ private:
   int* gather_ = nullptr;        // device: CSR position -> triplet entry
   int n_neg_ = 0, n_zero_ = 0;
   bool factored_ = false;
+  int pattern_status_ = 0;       // != 0: first_call() rejected the pattern for good (HIOPAMD_ERR_ARG / _STATE); matrixChanged() fails fast
   int device_failures_ = 0;      // as in hiopLinSolverSymDenseHipNative: a failed device call is not "singular matrix"; solve() refuses while > 0
 };
 }  // namespace hiop

@@ -95,10 +95,20 @@ struct MdsSolver {
   hiopamd_hess_lowrank* hess = nullptr;
   hiopamd_kkt_lowrank* klr = nullptr;
   DevBuf<double> d_Jall, d_J;           // dense variant: the user's m x n Jacobian, and [Jc; Jd] in one block
-  int secant_memory_len = 6;
-  double sigma0 = 1.0;
-  Options o;
-  bool dev_cb = false;
+  // Everything the caller can SET between create and solve lives in this one struct: a second solve on the same problem object rebuilds
+  // the solver state from the callbacks and carries `user` over wholesale (resolve_from_scratch) — a setter added later cannot be forgotten there.
+  struct UserSettings {
+    Options o;
+    bool dev_cb = false;
+    int secant_memory_len = 6;
+    double sigma0 = 1.0;
+    double scaling_min_grad = 1e-8;
+  } user;
+  Options& o = user.o;
+  bool& dev_cb = user.dev_cb;
+  int& secant_memory_len = user.secant_memory_len;
+  double& sigma0 = user.sigma0;
+  double& scaling_min_grad = user.scaling_min_grad;
   hiopamd_ctx* ctx = nullptr;
   hiopamd_kkt_mds* kkt = nullptr;
   hiopamd_kkt_xycyd* full = nullptr;
@@ -116,7 +126,6 @@ struct MdsSolver {
   double s_f = 1.0;
   bool solved_once = false;   // hiop_*_solve_problem ran: the next call starts over from the user's data (resolve_from_scratch)
   DevBuf<double> d_scal;   // neq + nineq
-  double scaling_min_grad = 1e-8;
   DevBuf<int> d_eq_map, d_ineq_map, d_jc_src, d_jd_src, d_Jcs_i, d_Jcs_j, d_Jds_i, d_Jds_j, d_Hss_i, d_Hss_j;
   std::vector<int> h_Jcs_i, h_Jcs_j, h_Jds_i, h_Jds_j;
   // device: values of the current iterate (what hiopamd_kkt_mds_set_values borrows)
@@ -957,11 +966,7 @@ MdsSolver* resolve_from_scratch(MdsSolver* old)
   if(!s) return nullptr;
   s->prob = old->prob;
   s->dprob = old->dprob;
-  s->o = old->o;
-  s->dev_cb = old->dev_cb;
-  s->secant_memory_len = old->secant_memory_len;
-  s->sigma0 = old->sigma0;
-  s->scaling_min_grad = old->scaling_min_grad;
+  s->user = old->user;
   delete old;   // (device memory of the first solve goes back before the second allocates)
   return s;
 }
@@ -1058,7 +1063,10 @@ int hiop_dense_destroy_problem(cHiopDenseProblem* problem)
 int hiopamd_dense_set_callback_mem_space(cHiopDenseProblem* problem, int device)
 {
   MdsSolver* s = solver_of(problem);
-  if(!s || s->full) return s ? HIOPAMD_ERR_STATE : HIOPAMD_ERR_ARG;
+  if(!s) return HIOPAMD_ERR_ARG;
+  // before the first solve, or between solves (the next solve rebuilds the state from the callbacks anyway); not while a set-up state
+  // that was never run exists
+  if(s->full && !s->solved_once) return HIOPAMD_ERR_STATE;
   s->dev_cb = device != 0;
   return HIOPAMD_OK;
 }
@@ -1094,7 +1102,10 @@ int hiopamd_dense_get_solve_info(const cHiopDenseProblem* problem, int* status, 
 int hiopamd_mds_set_callback_mem_space(cHiopMDSProblem* problem, int device)
 {
   MdsSolver* s = solver_of(problem);
-  if(!s || s->full) return s ? HIOPAMD_ERR_STATE : HIOPAMD_ERR_ARG;
+  if(!s) return HIOPAMD_ERR_ARG;
+  // before the first solve, or between solves (the next solve rebuilds the state from the callbacks anyway); not while a set-up state
+  // that was never run exists
+  if(s->full && !s->solved_once) return HIOPAMD_ERR_STATE;
   s->dev_cb = device != 0;
   return HIOPAMD_OK;
 }

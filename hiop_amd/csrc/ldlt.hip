@@ -2507,7 +2507,7 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   // (the chain kernel's DF_ROLES workgroups wait for each other: each needs a reserved CU of its own)
   bool use_df = df && df->enabled && df->flags && lookahead && lda == N && df->plan.N == N && df->plan.nchain >= 3 && ctx->chain_cus >= DF_ROLES &&
                 ctx->wide_cus >= 8;
-  DfDeviceLock df_lock;   // released when this call returns (it synchronises the stream first)
+  DfDeviceLock df_lock;   // released when this call returns: the host has then waited for the info words' read-back, which is queued behind both dataflow kernels
   if(use_df && !df_lock.try_acquire()) {   // another process factorises on this device right now: stepwise kernels
     use_df = false;
     static bool told = false;

@@ -797,6 +797,11 @@ struct hiopamd_ldlt_bk {
   int64_t sw_lda = 0;
   void* sw_work = nullptr;     // the context's workspace at capture time (the GEMV partial sums live there)
   bool sw_warm = false;
+  // The multi-workgroup panel kernel needs its workgroups resident TOGETHER (one rendezvous, one grid barrier per column).  When a
+  // barrier expires once (a shared or busy device), this object factors with ONE workgroup from then on: no other workgroup to wait for,
+  // so nothing can expire — slow (one CU walks every column) but it always finishes.  The call that timed out still returns
+  // HIOPAMD_ERR_TIMEOUT (the matrix is partly overwritten: the caller re-assembles and calls again, as for the dataflow LDL^T).
+  bool single_workgroup = false;
 };
 
 // L y = v, D z = y, L^T w = z with v = B->tmp on entry and on exit (y, z in B->tmp2): 2 x n / 256 block steps, every one two GEMVs
@@ -901,7 +906,7 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
     {
       // the panel's columns in ONE launch (bk_panel_kernel): its three phases per column, separated by grid barriers, are what
       // tests/test_ldlt_bk_protocol.py replays thread by thread in random order
-      const unsigned G = (unsigned)std::min(BK_G, (n + BK_T - 1) / BK_T);
+      const unsigned G = B->single_workgroup ? 1u : (unsigned)std::min(BK_G, (n + BK_T - 1) / BK_T);
       HIOPAMD_CHECK(hipMemsetAsync(B->bar, 0, 16 * sizeof(unsigned), s));
       HIOPAMD_CHECK(hipMemsetAsync(B->gran, 0, BK_GR_N * sizeof(unsigned long long), s));
       if(G >= 2)   // eight times the workgroups: those that land on one XCD do the panel (see bk_panel_kernel)
@@ -918,8 +923,10 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
     HIOPAMD_CHECK(hipMemcpyAsync(aborted, B->bar, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIOPAMD_CHECK(hipStreamSynchronize(s));
     if(aborted[1] != 0u) {
-      std::fprintf(stderr, "[hiop_amd] pivoted LDL^T: a grid barrier of the panel kernel expired (its %d workgroups were not all running)\n",
+      std::fprintf(stderr, "[hiop_amd] pivoted LDL^T: a grid barrier of the panel kernel expired (its %d workgroups were not all running); the matrix "
+                           "is partly overwritten — re-assemble and call again: this solver object uses the one-workgroup panel kernel from now on\n",
                    std::min(BK_G, (n + BK_T - 1) / BK_T));
+      B->single_workgroup = true;
       return HIOPAMD_ERR_TIMEOUT;
     }
     if(k0 > 0 && kend > k0) {
@@ -967,6 +974,13 @@ int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* B, double* A, int64_t lda, int* iner
   }
   if(info_host) *info_host = h.info;
   B->factored = true;
+  return HIOPAMD_OK;
+}
+
+int hiopamd_ldlt_bk_set_single_workgroup(hiopamd_ldlt_bk* B, int enable)
+{
+  if(!B) return HIOPAMD_ERR_ARG;
+  B->single_workgroup = enable != 0;
   return HIOPAMD_OK;
 }
 

@@ -595,8 +595,8 @@ __global__ void sl_factor_level_kernel(int q0, const int* __restrict__ f_nc, con
     // better; the plain row-cyclic form is enough for fronts of <= 128 rows
     // (rows dealt to threads, the threads of a row split its columns: no integer division per element — the element-per-thread form
     //  spent more time on e / m, e % m than on the update, and half its elements were above the diagonal)
-    {
-      const int m = f - k - 1;
+    const int m = f - k - 1;   // rows below the pivot (0 at the last pivot of a front without rows: nothing to update, and no nt / m)
+    if(m > 0) {
       const int tpr = (nt >= 2 * m) ? (nt / m < 8 ? nt / m : 8) : 1;   // threads per row
       const int rgrp = nt / tpr;                                       // rows in flight
       const int sub = tid % tpr, r0 = tid / tpr;

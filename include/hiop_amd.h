@@ -504,7 +504,12 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls);
 double* hiopamd_linsolver_sys_matrix(hiopamd_linsolver* ls);
 int hiopamd_linsolver_n(const hiopamd_linsolver* ls);
 /* matrixChanged(): factorise in place; *n_neg_host = number of negative pivots, or -1 if a pivot is
- * (numerically) zero / non-finite -- the reference's "singular" return. */
+ * (numerically) zero / non-finite -- the reference's "singular" return.
+ * STREAM CONTRACT: the call returns when the pivot flags and the inertia have reached the host; kernels that only prepare the next
+ * solve (inverted diagonal blocks, ~0.1 ms) may still be running on the context's stream and still READ the matrix.  Everything this
+ * library does next is queued behind them on that stream.  A caller that touches sys_matrix() by other means — another stream, a
+ * blocking hipMemcpy (the context's own stream is non-blocking: the null stream does not wait for it) — calls hiopamd_ctx_sync first;
+ * the C++ adapter's matrixChanged() does (adapters/hiopLinSolverSymDenseHipNative.cpp). */
 int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host);
 /* solve(): rhs (device, length n * nrhs, column after column) overwritten by the solution */
 int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs);
@@ -553,6 +558,11 @@ int hiopamd_ldlt_bk_destroy(hiopamd_ldlt_bk* b);
 int hiopamd_ldlt_bk_factor(hiopamd_ldlt_bk* b, double* A, int64_t lda, int* inertia3_host, int* info_host);
 int hiopamd_ldlt_bk_solve(hiopamd_ldlt_bk* b, const double* A, int64_t lda, double* x_inout, int nrhs);
 int hiopamd_ldlt_bk_pivots(hiopamd_ldlt_bk* b, int* ipiv_host, int* perm_host, double* e_host);
+/* The panel kernel runs on up to 16 workgroups that wait for each other (one grid barrier per column): they must be resident together.
+ * If a barrier expires (a shared or busy device) _factor returns HIOPAMD_ERR_TIMEOUT with the matrix partly overwritten — re-assemble
+ * and call again — and the object factors with ONE workgroup from then on: nobody to wait for, same pivots, same factor, slower.
+ * _set_single_workgroup selects that form by hand (tests; a device known to be shared). */
+int hiopamd_ldlt_bk_set_single_workgroup(hiopamd_ldlt_bk* b, int enable);
 int hiopamd_linsolver_safe_mode_info(const hiopamd_linsolver* ls, int* refinements_host, double* residual_rel_host);
 int hiopamd_linsolver_growth(hiopamd_linsolver* ls, double* max_abs_u_host, double* min_abs_d_host, double* max_abs_d_host);
 /* The factorisation runs as a dataflow of two persistent kernels (csrc/ldlt_dataflow.hpp) when the CU-masked streams are

@@ -90,6 +90,28 @@ def test_factor_equals_oracle_and_lapack(ctx, kind, n):
     dev.close()
 
 
+@pytest.mark.parametrize("kind,n", [("rand", 700), ("kkt", 1100), ("arrow", 1500)])
+def test_one_workgroup_panel_kernel_is_the_same_factorisation(ctx, kind, n):
+    """The fallback a solver object switches to after a grid barrier of the multi-workgroup panel kernel expired (advisor, round 5: the
+    pivoted mode is the SAFE solver and must not be the path that can hard-fail on a busy device): one workgroup, nobody to wait for.
+    Same pivots as LAPACK, same bits as the multi-workgroup form (the decisions and the arithmetic of a row do not depend on who owns it)."""
+    A = make(kind, n)
+    dev = DevBK(ctx, n)
+    f16 = dev.factor(A)
+    assert dev.L.hiopamd_ldlt_bk_set_single_workgroup(dev.h, 1) == 0
+    f1 = dev.factor(A)
+    _, ipiv_l, info_l = lapack.dsytrf(A, lower=1)
+    assert f1["info"] == 0 and info_l == 0
+    np.testing.assert_array_equal(f1["ipiv"], ipiv_l)
+    np.testing.assert_array_equal(f1["perm"], f16["perm"])
+    assert np.array_equal(f1["d"], f16["d"]) and np.array_equal(f1["e"], f16["e"]) and np.array_equal(f1["L"], f16["L"])
+    assert f1["inertia"] == f16["inertia"]
+    b = rng(n + 5).uniform(-1, 1, n)
+    x = dev.solve(b)
+    assert np.abs(A @ x - b).max() <= 1e-11 * n * np.abs(A).max() * max(1.0, np.abs(x).max())
+    dev.close()
+
+
 @pytest.mark.parametrize("n", [1024, 1300, 2500])
 def test_repeated_solves_replay_a_graph_and_survive_a_new_factorisation(ctx, n):
     """from n = 1024 on the two sweeps of a solve are a HIP graph: the first solve with a matrix address runs eagerly, the second captures,
