@@ -60,6 +60,60 @@ def starting_at_copy_to_starting_at_w_pattern(src, start_src, dest, start_dest, 
     dest[idx] = src[start_src:start_src + idx.size]
 
 
+def copy_from_indexes(y, src, idx):                    # :194-206
+    y[:] = src[idx]
+
+
+def copy_from_starting(y, start_in_y, v):              # :222-237 (both overloads: a buffer of nv entries, a whole vector)
+    assert start_in_y + v.size <= y.size
+    y[start_in_y:start_in_y + v.size] = v
+
+
+def starting_at_copy_from_starting_at(dest, start_dest, src, start_src):   # :241-251: everything left of `dest` is overwritten
+    n = dest.size - start_dest
+    assert n >= 0
+    dest[start_dest:] = src[start_src:start_src + n]
+
+
+def copy_to_starting(x, dest, start_in_dest):          # :295-316 (non-distributed case)
+    assert start_in_dest + x.size <= dest.size
+    if x.size > 0:
+        dest[start_in_dest:start_in_dest + x.size] = x
+
+
+def copy_from_two_vec_w_pattern(y, c, c_map, d, d_map):   # :338-359
+    assert c.size + d.size == y.size
+    y[c_map] = c
+    y[d_map] = d
+
+
+def copy_to_two_vec_w_pattern(y, c, c_map, d, d_map):     # :366-387
+    assert c.size + d.size == y.size
+    c[:] = y[c_map]
+    d[:] = y[d_map]
+
+
+def starting_at_copy_to_starting_at(src, start_src, dest, start_dest, num_elems=-1):   # :395-428
+    assert 0 <= start_src <= src.size and 0 <= start_dest <= dest.size
+    if num_elems < 0:
+        num_elems = min(src.size - start_src, dest.size - start_dest)
+    else:
+        num_elems = min(num_elems, src.size - start_src, dest.size - start_dest)
+    dest[start_dest:start_dest + num_elems] = src[start_src:start_src + num_elems]
+
+
+def isnan_local(x):                                    # :1167-1171  (exists e: isnan(e))
+    return int(np.any(np.isnan(x)))
+
+
+def isinf_local(x):                                    # :1173-1177
+    return int(np.any(np.isinf(x)))
+
+
+def isfinite_local(x):                                 # :1179-1183  (for all e: isfinite(e))
+    return int(np.all(np.isfinite(x)))
+
+
 def component_div_w_pattern(y, x, select):             # :580
     with np.errstate(divide="ignore", invalid="ignore"):
         y[:] = np.where(select == 0.0, 0.0, y / x)

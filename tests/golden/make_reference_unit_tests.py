@@ -243,6 +243,89 @@ case("spsym_addUpperTriangleToSymDenseMatrixUpperTriangle", f"{SS}:128",
      {"A": ss, "diag_start": Wd0, "alpha": half, "W": Mx(ssn + Wd0, ssn + Wd0, one)},
      {"W": Mx(ssn + Wd0, ssn + Wd0, one, [(Wd0 + r_, Wd0 + c_, one + half * half) for r_, c_ in zip(ss["iRow"], ss["jCol"])])})
 
+# ---- round 6: the copy family, the is* predicates, the remaining dense row / triangle methods -------------------------------
+# driver sizes (tests/testVector.cpp:235-262): v has Nlocal = 1000 entries, v_smaller / v2_smaller Mlocal = 500
+Ms_ = 500
+
+
+def VR(fill, ranges, n=N):
+    """vector with constant ranges: [[lo, hi, val], ...] (hi exclusive)"""
+    return {"n": n, "fill": fill, "set": [], "range": [list(r) for r in ranges]}
+
+
+def LIN(n, i0, di=1):
+    return {"n": n, "i0": i0, "di": di}
+
+
+case("setToZero", f"{VT}:98", {"y": V(one)}, {"y": V(zero)})
+# v = 3 (size M), from = 1 with from[M-1] = 2 (size N), idxs = 0, 1, ..., M-1: v becomes the first M entries of from
+case("copy_from_indexes", f"{VT}:221", {"y": V(three, n=Ms_), "src": V(one, [(Ms_ - 1, two)]), "idx": LIN(Ms_, 0)},
+     {"y": V(one, [(-1, two)], n=Ms_)})
+case("copyFromStarting", f"{VT}:274", {"y": V(two), "start": 1, "src": V(one, n=N - 1)}, {"y": V(one, [(0, two)])})
+case("copyFromStarting", f"{VT}:284", {"y": V(two), "start": N - Ms_, "src": V(one, n=Ms_)}, {"y": VR(two, [(N - Ms_, N, one)])})
+case("copyFromStarting", f"{VT}:293", {"y": V(two), "start": 1, "src": V(one, n=Ms_)}, {"y": VR(two, [(1, Ms_ + 1, one)])})
+case("copyFromStarting", f"{VT}:301", {"y": V(two), "start": 0, "src": V(one, n=0)}, {"y": V(two)})
+# dest = 1 (size M), src = 2 (size N): one element (start_dest = M - 1, start_src = N / 2), then all of dest from src's tail
+case("startingAtCopyFromStartingAt", f"{VT}:346", {"y": V(one, n=Ms_), "start_dest": Ms_ - 1, "src": V(two), "start_src": N // 2},
+     {"y": V(one, [(-1, two)], n=Ms_)})
+case("startingAtCopyFromStartingAt", f"{VT}:358", {"y": V(one, n=Ms_), "start_dest": 0, "src": V(two), "start_src": N - Ms_},
+     {"y": V(two, n=Ms_)})
+case("copyTo", f"{VT}:373", {"x": V(two), "dest": V(one)}, {"dest": V(two)})
+case("copyToStarting", f"{VT}:397", {"x": V(one, n=Ms_), "dest": V(two), "start": N - Ms_}, {"dest": VR(two, [(N - Ms_, N, one)])})
+case("copyToStarting", f"{VT}:430", {"x": V(one, n=0), "dest": V(two), "start": 0}, {"dest": V(two)})
+# from = 1 with 3 at both ends, pattern = 0 with 1 at both ends: the two selected entries land at start, start + 1
+case("copyToStartingAt_w_pattern", f"{VT}:449",
+     {"x": V(one, [(0, three), (-1, three)], n=Ms_), "dest": V(two), "start": N - Ms_, "select": V(zero, [(0, one), (-1, one)], n=Ms_)},
+     {"dest": V(two, [(N - Ms_, three), (N - Ms_ + 1, three)]), "nnz": 2})
+case("copy_from_two_vec_w_pattern", f"{VT}:496",
+     {"y": V(zero), "c": V(one, n=Ms_), "c_map": LIN(Ms_, 0), "d": V(two, n=Ms_), "d_map": LIN(Ms_, Ms_)}, {"y": VR(one, [(Ms_, N, two)])})
+case("copy_to_two_vec_w_pattern", f"{VT}:540",
+     {"y": V(two), "c": V(zero, n=Ms_), "c_map": LIN(Ms_, 0), "d": V(zero, n=Ms_), "d_map": LIN(Ms_, Ms_)},
+     {"c": V(two, n=Ms_), "d": V(two, n=Ms_)})
+# startingAtCopyToStartingAt (from = 1, size M; to = 2, size N): the edge cases of :580-745 in the test's order
+SA = f"{VT}:580"
+case("startingAtCopyToStartingAt", SA, {"src": V(one, n=0), "start_src": 0, "dest": V(two), "start_dest": 0, "num": -1}, {"dest": V(two)})
+case("startingAtCopyToStartingAt", SA, {"src": V(one, n=Ms_), "start_src": 0, "dest": V(two), "start_dest": 0, "num": 0}, {"dest": V(two)})
+case("startingAtCopyToStartingAt", SA, {"src": V(one, n=Ms_), "start_src": 0, "dest": V(two), "start_dest": 0, "num": Ms_},
+     {"dest": VR(two, [(0, Ms_, one)])})
+case("startingAtCopyToStartingAt", SA, {"src": V(one, n=Ms_), "start_src": 0, "dest": V(two), "start_dest": N - Ms_, "num": Ms_},
+     {"dest": VR(two, [(N - Ms_, N, one)])})
+case("startingAtCopyToStartingAt", SA, {"src": V(one, n=Ms_), "start_src": 0, "dest": V(two), "start_dest": N - Ms_, "num": Ms_ // 2},
+     {"dest": VR(two, [(N - Ms_, N - Ms_ + Ms_ // 2, one)])})
+case("startingAtCopyToStartingAt", SA, {"src": V(one, n=Ms_), "start_src": 0, "dest": V(two), "start_dest": N - Ms_, "num": -1},
+     {"dest": VR(two, [(N - Ms_, N, one)])})
+case("startingAtCopyToStartingAt", SA, {"src": V(one, n=Ms_), "start_src": 0, "dest": V(two), "start_dest": N, "num": -1}, {"dest": V(two)})
+# the predicates (:1951-2036): 0, 1/0, 0/0, and a single special value at the end of a vector of ones
+case("isnan", f"{VT}:1955", {"x": V(zero)}, {"value": 0})
+case("isnan", f"{VT}:1959", {"x": V("inf")}, {"value": 0})
+case("isnan", f"{VT}:1963", {"x": V("nan")}, {"value": 1})
+case("isnan", f"{VT}:1967", {"x": V(one, [(-1, "nan")])}, {"value": 1})
+case("isinf", f"{VT}:1986", {"x": V(zero)}, {"value": 0})
+case("isinf", f"{VT}:1990", {"x": V("nan")}, {"value": 0})
+case("isinf", f"{VT}:1994", {"x": V("inf")}, {"value": 1})
+case("isinf", f"{VT}:1998", {"x": V(one, [(-1, "inf")])}, {"value": 1})
+case("isfinite", f"{VT}:2017", {"x": V(zero)}, {"value": 1})
+case("isfinite", f"{VT}:2021", {"x": V("nan")}, {"value": 0})
+case("isfinite", f"{VT}:2025", {"x": V(one, [(-1, "inf")])}, {"value": 0})
+# ---- dense, the rest (matrixTestsDense.hpp)
+case("mat_setToZero", f"{MD}:99", {"A": Mx(M_, Nn, one)}, {"A": Mx(M_, Nn, zero)})
+case("mat_setToConstant", f"{MD}:108", {"A": Mx(M_, Nn, zero), "c": one}, {"A": Mx(M_, Nn, one)})
+case("mat_copyFrom", f"{MD}:118", {"dst": Mx(M_, Nn, zero), "src": Mx(M_, Nn, one)}, {"dst": Mx(M_, Nn, one)})
+case("mat_copy_to", f"{MD}:147", {"src": Mx(M_, Nn, one), "dst": Mx(M_, Nn, zero)}, {"dst": Mx(M_, Nn, one)})
+# appendRow: A = 1 with room for one more row, vec = 2: the new last row is the vector, the row count grows by one
+case("mat_appendRow", f"{MD}:736", {"A": Mx(M_, Nn, one), "vec": V(two, n=Nn)},
+     {"A": Mx(M_ + 1, Nn, one, [(M_, j, two) for j in range(Nn)]), "m": M_ + 1})
+case("mat_replaceRow", f"{MD}:1027", {"A": Mx(M_, Nn, one), "row": M_ - 1, "vec": V(two, [(1, zero)], n=Nn)},
+     {"A": Mx(M_, Nn, one, [(M_ - 1, j, (zero if j == 1 else two)) for j in range(Nn)])})
+case("mat_getRow", f"{MD}:1068", {"A": Mx(M_, Nn, one, [(M_ - 1, Nn - 1, zero)]), "row": M_ - 1, "vec": V(two, n=Nn)},
+     {"vec": V(one, [(-1, zero)], n=Nn)})
+# rows set to their index (A[i][j] = i), then one triangle copied over the other (:1169, :1189)
+rowidx = [(i, j, float(i)) for i in range(M_) for j in range(M_)]
+case("mat_overwriteUpperTriangleWithLower", f"{MD}:1169", {"A": Mx(M_, M_, zero, rowidx)},
+     {"A": Mx(M_, M_, zero, [(i, j, float(i if j <= i else j)) for i in range(M_) for j in range(M_)])})
+case("mat_overwriteLowerTriangleWithUpper", f"{MD}:1189", {"A": Mx(M_, M_, zero, rowidx)},
+     {"A": Mx(M_, M_, zero, [(i, j, float(j if j < i else i)) for i in range(M_) for j in range(M_)])})
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_unit_tests.json")
 with open(out, "w") as f:
     json.dump({"source": "LLNL/hiop v1.1.0 tests/LinAlg (transcribed constants and expected values)", "cases": cases}, f, indent=0)

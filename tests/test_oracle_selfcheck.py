@@ -21,7 +21,10 @@ def test_mds_ex1_selfcheck_objective_is_reproduced_by_the_oracle_kkt_path():
     p = pr.mds_ex1(*g["args"])
     r = ipm.solve_mds(p, mu0=g["driver_mu0"], tol=g["driver_tolerance"])
     assert r["err"] < g["driver_tolerance"]
-    assert abs(r["obj"] - g["objective"]) < 1e-4
+    # six digits relative, the form the reference's drivers use for their stored values (NlpDenseConsEx1Driver.cpp:139-140:
+    # |saved - obj| / (1 + |saved|) <= 1e-6); the restated filter IPM itself arrives within 1e-8 ABSOLUTE
+    # (tests/test_oracle_reference_trajectory.py::test_mds_ex1_400_100_takes_the_reference_iterations_to_the_selfcheck_objective)
+    assert abs(r["obj"] - g["objective"]) / (1.0 + abs(g["objective"])) <= 1e-6
     tight = ipm.solve_mds(p, mu0=g["driver_mu0"], tol=1e-9)
     assert tight["err"] < 1e-9
     assert -3e-4 < tight["obj"] - g["objective"] < 0.0     # the true optimum is slightly below the early-terminated value
@@ -61,7 +64,7 @@ def test_mds_ex1_selfcheck_objective_through_the_full_space_layer():
     ops = ipm_full.OracleOps(full, bounds, model)
     r = ipm_full.solve(ops, it0, mu0=g["driver_mu0"], tol=g["driver_tolerance"])
     assert r["err"] < g["driver_tolerance"]
-    assert abs(r["obj"] - g["objective"]) < 2e-4
+    assert abs(r["obj"] - g["objective"]) / (1.0 + abs(g["objective"])) <= 1e-6    # (was 2e-4 absolute until round 6)
     assert r["iters"] < 40
 
 
@@ -101,7 +104,7 @@ def test_dense_ex2_selfcheck_objective_newton_through_the_dense_xycyd_backend():
     # the exact optimum is 1/64 (x_3 = 1.5 on its bound, every other x_i = 1); the reference's quasi-Newton run stops
     # 1.0e-7 above it (6.5e-6 relative), this converged run 1e-9 above it
     assert 0.0 <= r["obj"] - 1.0 / 64 < 1e-8
-    assert r["obj"] == pytest.approx(g["objective"][0], rel=1e-5)
+    assert r["obj"] == pytest.approx(g["objective"][0], rel=7e-6)   # the stored value itself lies 6.5e-6 (relative) above the exact optimum 1/64: no converged run can be closer
 
 
 def test_dense_ex2_selfcheck_objective_quasi_newton_through_the_lowrank_backend():
@@ -124,7 +127,7 @@ def test_dense_ex2_selfcheck_objective_quasi_newton_through_the_lowrank_backend(
     r = ipm_full.solve(Ops(full, bounds, model), it0, mu0=0.1, tol=1e-7, max_iter=400)
     assert r["err"] < 1e-7
     assert 0.0 <= r["obj"] - 1.0 / 64 < 2e-7
-    assert r["obj"] == pytest.approx(g["objective"][0], rel=1e-5)
+    assert r["obj"] == pytest.approx(g["objective"][0], rel=7e-6)   # the stored value itself lies 6.5e-6 (relative) above the exact optimum 1/64: no converged run can be closer
 
 
 def test_iteration_table_fixtures_are_reproducible_and_match_the_reference_iteration_count():
