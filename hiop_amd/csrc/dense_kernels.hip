@@ -7,6 +7,7 @@
 // reference's: row-major, rows contiguous, so every kernel walks a row with consecutive lanes
 // (512 B / wave / instruction) and tiles rows so the x / y vector is re-used from registers/L2.
 #include "device_utils.hpp"
+#include "dense_internal.hpp"
 
 namespace hiopamd {
 
@@ -25,9 +26,17 @@ constexpr int GEMV_COLS = kBlock * GEMV_COLS_PER_THREAD * GEMV_CHUNKS;  // 8192 
 // 64 loads.  Now a block walks GEMV_CHUNKS column chunks before it reduces, rows are read with 16-byte loads when the layout
 // allows, and the wave reduction halves the number of live sums at every step (lanes l and l ^ 32 split the 8 rows 4 / 4, then 2 / 2,
 // then 1 / 1: 4 + 2 + 1 + 3 exchanges instead of 48).
-template <bool VEC>
-__global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const double* __restrict__ A, int64_t lda,
-                                                        const double* __restrict__ x, double* __restrict__ part, int chunks, int nchunks,
+// Row groups of one launch (dense_internal.hpp, gemv_n_groups): group g owns the row tiles [tile0[g], tile0[g+1]) and the rows
+// row0[g] .. row0[g] + m[g] - 1 of the result.  hiopamd_mat_times_vec is the one-group case.
+struct GemvGroups {
+  const double* A[3];
+  int m[3], tile0[3], row0[3];
+  int ngroups, m_total;
+};
+// XS: x is multiplied by a second vector on its way in (the product is rounded like the stored vector it replaces)
+template <bool VEC, bool XS>
+__global__ __launch_bounds__(kBlock) void gemv_n_stage1(const GemvGroups G, int64_t n, int64_t lda, const double* __restrict__ x,
+                                                        const double* __restrict__ xscale, double* __restrict__ part, int chunks, int nchunks,
                                                         int rtiles)
 {
   // Block -> (column chunk group bx, row tile by), XCD-aware (round 5).  x is read by every row tile: with the grid (chunk groups, row
@@ -39,7 +48,12 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bx = (slot / rtiles) * 8 + xcd, by = slot % rtiles;
   if(bx >= nchunks) return;
-  const int r0 = by * GEMV_ROWS;
+  int g = 0;
+  if(G.ngroups > 1 && by >= G.tile0[1]) g = 1;
+  if(G.ngroups > 2 && by >= G.tile0[2]) g = 2;
+  const double* __restrict__ A = G.A[g];
+  const int m = G.m[g];
+  const int r0 = (by - G.tile0[g]) * GEMV_ROWS;
   double acc[GEMV_ROWS];
 #pragma unroll
   for(int r = 0; r < GEMV_ROWS; ++r) acc[r] = 0.0;
@@ -51,18 +65,32 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
       // issued back to back and are all in flight together.  (Round 4: with the guarded form below the compiler put every load in
       // its own exec-masked branch with an `s_waitcnt vmcnt(0)` behind it -- ONE load in flight per lane; 5.0 TB/s at k = 200,
       // n = 1.25e6 came from occupancy alone.)
-      if(r0 + GEMV_ROWS <= m && c0 + (int64_t)kBlock * GEMV_COLS_PER_THREAD <= n) {
+      // (Round 6: a row tile at the end of its group with fewer than GEMV_ROWS rows takes this path as well — the missing rows are read
+      //  from the group's last row and their sums are never stored — instead of the guarded form below: the l <= 8 rows of the secant
+      //  blocks are ONE such tile.)
+      if(c0 + (int64_t)kBlock * GEMV_COLS_PER_THREAD <= n) {
         const double* xb = x + c0 + 2 * threadIdx.x;
         const double* Ab = A + (int64_t)r0 * lda + c0 + 2 * threadIdx.x;
+        const int rlast = m - 1 - r0;   // >= 0: the tile has at least one row
         typedef double d2v __attribute__((ext_vector_type(2)));
         d2v xv[GEMV_COLS_PER_THREAD / 2], av[GEMV_ROWS][GEMV_COLS_PER_THREAD / 2];
 #pragma unroll
         for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u) xv[u] = *reinterpret_cast<const d2v*>(xb + u * 2 * kBlock);
+        if constexpr(XS) {
+          const double* sb = xscale + c0 + 2 * threadIdx.x;
 #pragma unroll
-        for(int r = 0; r < GEMV_ROWS; ++r)
+          for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u) {
+            const d2v sv = *reinterpret_cast<const d2v*>(sb + u * 2 * kBlock);
+            xv[u] = xv[u] * sv;
+          }
+        }
+#pragma unroll
+        for(int r = 0; r < GEMV_ROWS; ++r) {
+          const int rr = (r <= rlast) ? r : rlast;
 #pragma unroll
           for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u)   // A is read once: non-temporal, out of the way of x in L2 (0.353 -> 0.334 ms)
-            av[r][u] = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(Ab + (int64_t)r * lda + u * 2 * kBlock));
+            av[r][u] = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(Ab + (int64_t)rr * lda + u * 2 * kBlock));
+        }
 #pragma unroll
         for(int r = 0; r < GEMV_ROWS; ++r)
 #pragma unroll
@@ -78,6 +106,11 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
       for(int u = 0; u < GEMV_COLS_PER_THREAD / 2; ++u) {
         const int64_t j = c0 + 2 * threadIdx.x + (int64_t)u * 2 * kBlock;
         xv[u] = (j + 1 < n) ? *reinterpret_cast<const double2*>(x + j) : double2{(j < n) ? x[j] : 0.0, 0.0};
+        if constexpr(XS) {
+          const double2 sv = (j + 1 < n) ? *reinterpret_cast<const double2*>(xscale + j) : double2{(j < n) ? xscale[j] : 0.0, 0.0};
+          xv[u].x = xv[u].x * sv.x;
+          xv[u].y = xv[u].y * sv.y;
+        }
       }
 #pragma unroll
       for(int r = 0; r < GEMV_ROWS; ++r) {
@@ -100,18 +133,28 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
     } else {
       // the 8-byte form (odd leading dimension or unaligned operands -- the stock MdsEx1 at n_dense = 4097): interior blocks unguarded
       // as well, half the rows at a time (8 + 32 loads in flight); same order of the multiply-adds as the guarded form
-      if(r0 + GEMV_ROWS <= m && c0 + (int64_t)kBlock * GEMV_COLS_PER_THREAD <= n) {
+      if(c0 + (int64_t)kBlock * GEMV_COLS_PER_THREAD <= n) {
         const double* xb = x + c0 + threadIdx.x;
         const double* Ab = A + (int64_t)r0 * lda + c0 + threadIdx.x;
+        const int rlast = m - 1 - r0;
         double xs[GEMV_COLS_PER_THREAD], as[GEMV_ROWS / 2][GEMV_COLS_PER_THREAD];
 #pragma unroll
         for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) xs[u] = xb[u * kBlock];
+        if constexpr(XS) {
+#pragma unroll
+          for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) {
+            const double sv = xscale[c0 + threadIdx.x + u * kBlock];
+            xs[u] = xs[u] * sv;
+          }
+        }
 #pragma unroll
         for(int rh = 0; rh < GEMV_ROWS; rh += GEMV_ROWS / 2) {
 #pragma unroll
-          for(int r = 0; r < GEMV_ROWS / 2; ++r)
+          for(int r = 0; r < GEMV_ROWS / 2; ++r) {
+            const int rr = (rh + r <= rlast) ? (rh + r) : rlast;
 #pragma unroll
-            for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) as[r][u] = __builtin_nontemporal_load(Ab + (int64_t)(rh + r) * lda + u * kBlock);
+            for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) as[r][u] = __builtin_nontemporal_load(Ab + (int64_t)rr * lda + u * kBlock);
+          }
 #pragma unroll
           for(int r = 0; r < GEMV_ROWS / 2; ++r)
 #pragma unroll
@@ -124,6 +167,10 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
       for(int u = 0; u < GEMV_COLS_PER_THREAD; ++u) {
         const int64_t j = c0 + threadIdx.x + (int64_t)u * kBlock;
         xv[u] = (j < n) ? x[j] : 0.0;
+        if constexpr(XS) {
+          const double sv = (j < n) ? xscale[j] : 0.0;
+          xv[u] = xv[u] * sv;
+        }
       }
 #pragma unroll
       for(int r = 0; r < GEMV_ROWS; ++r) {
@@ -174,8 +221,30 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage1(int m, int64_t n, const 
     const int row = r0 + threadIdx.x;
     if(row < m) {
       double v = ((sm[threadIdx.x][0] + sm[threadIdx.x][1]) + sm[threadIdx.x][2]) + sm[threadIdx.x][3];
-      part[(int64_t)bx * m + row] = v;
+      part[(int64_t)bx * G.m_total + G.row0[g] + row] = v;
     }
+  }
+}
+
+// stage 2 of gemv_n_groups: one wave per row of the stacked result (see dense_internal.hpp for what it writes)
+__global__ __launch_bounds__(kBlock) void gemv_n_stage2_groups(const GemvGroups G, int nchunks, const double* __restrict__ part,
+                                                               double* __restrict__ y, double a0, double a1, double a2,
+                                                               const double* __restrict__ sub0, int nsub0, const double* __restrict__ sub1)
+{
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if(wave >= G.m_total) return;
+  double v = 0.0;
+  for(int c = lane; c < nchunks; c += 64) v += part[(int64_t)c * G.m_total + wave];
+  for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if(lane == 0) {
+    int g = 0;
+    if(G.ngroups > 1 && wave >= G.row0[1]) g = 1;
+    if(G.ngroups > 2 && wave >= G.row0[2]) g = 2;
+    const double alpha = (g == 0) ? a0 : (g == 1) ? a1 : a2;
+    double out = alpha * v;
+    if(g == 0 && sub0) out = out - ((wave < nsub0) ? sub0[wave] : sub1[wave - nsub0]);
+    y[wave] = out;
   }
 }
 
@@ -205,12 +274,30 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage2(int m, int nchunks, cons
 constexpr int GEMVT_ROWCHUNK = 64;
 
 // CP: column pairs per thread (pair p of thread t = columns base + 512 p + 2 t, +1)
-template <int CP>
+// the per-column epilogue of gemv_t_tail (dense_internal.hpp): yj is the finished y_j; sy_sh = the 2 l coefficients in LDS
+__device__ __forceinline__ void gemvt_tail_store(const GemvtTail& T, const double* sy_sh, int64_t j, double yj)
+{
+  double s1 = 0.0, s2 = 0.0;
+  for(int q = 0; q < T.l; ++q) s1 = fma(T.S[(int64_t)q * T.ld + j], sy_sh[q], s1);
+  for(int q = 0; q < T.l; ++q) s2 = fma(T.Y[(int64_t)q * T.ld + j], sy_sh[T.l + q], s2);
+  double res = T.sigma * s1;
+  res = res + s2;
+  const double di = T.DhInv[j];
+  const double a = yj * di, b = res * di;
+  T.dx[j] = a - b;
+}
+
+template <int CP, bool TAIL = false>
 __global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const double* __restrict__ A, int64_t lda,
                                                         const double* __restrict__ x, int rows_per_split,
                                                         double* __restrict__ out, int64_t out_stride, double beta,
-                                                        double alpha, int direct)
+                                                        double alpha, int direct, const GemvtTail T = GemvtTail())
 {
+  __shared__ double sy_sh[TAIL ? 128 : 1];
+  if constexpr(TAIL) {
+    if(threadIdx.x < 2 * T.l) sy_sh[threadIdx.x] = T.sy[threadIdx.x];
+    // (visible behind the first __syncthreads() of the row loop below: m > 0 on this path)
+  }
   const int r_begin = blockIdx.y * rows_per_split;
   int r_end = r_begin + rows_per_split;
   if(r_end > m) r_end = m;
@@ -273,8 +360,14 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const 
     const int64_t j0 = jb + (int64_t)p * 2 * kBlock;
     if(j0 >= n) continue;
     if(direct) {
-      out[j0] = (beta == 0.0 ? 0.0 : beta * out[j0]) + alpha * a0[p];
-      if(j0 + 1 < n) out[j0 + 1] = (beta == 0.0 ? 0.0 : beta * out[j0 + 1]) + alpha * a1[p];
+      const double v0 = (beta == 0.0 ? 0.0 : beta * out[j0]) + alpha * a0[p];
+      out[j0] = v0;
+      if constexpr(TAIL) gemvt_tail_store(T, sy_sh, j0, v0);
+      if(j0 + 1 < n) {
+        const double v1 = (beta == 0.0 ? 0.0 : beta * out[j0 + 1]) + alpha * a1[p];
+        out[j0 + 1] = v1;
+        if constexpr(TAIL) gemvt_tail_store(T, sy_sh, j0 + 1, v1);
+      }
     } else {
       double* o = out + (int64_t)blockIdx.y * out_stride;
       o[j0] = a0[p];
@@ -283,14 +376,23 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const 
   }
 }
 
+template <bool TAIL = false>
 __global__ __launch_bounds__(kBlock) void gemv_t_fold(int64_t n, int nsplit, const double* __restrict__ part,
-                                                      int64_t stride, double beta, double* __restrict__ y, double alpha)
+                                                      int64_t stride, double beta, double* __restrict__ y, double alpha,
+                                                      const GemvtTail T = GemvtTail())
 {
+  __shared__ double sy_sh[TAIL ? 128 : 1];
+  if constexpr(TAIL) {
+    if(threadIdx.x < 2 * T.l) sy_sh[threadIdx.x] = T.sy[threadIdx.x];
+    __syncthreads();
+  }
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if(j >= n) return;
   double v = 0.0;
   for(int s = 0; s < nsplit; ++s) v += part[(int64_t)s * stride + j];
-  y[j] = (beta == 0.0 ? 0.0 : beta * y[j]) + alpha * v;
+  const double yj = (beta == 0.0 ? 0.0 : beta * y[j]) + alpha * v;
+  y[j] = yj;
+  if constexpr(TAIL) gemvt_tail_store(T, sy_sh, j, yj);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -539,8 +641,15 @@ int hiopamd_mat_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, i
   double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nchunks * m);
   const bool vec = (lda % 2 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)x % 16 == 0);
   const dim3 g1((unsigned)(8 * ((nchunks + 7) / 8)) * (unsigned)rtiles), b1(kBlock);   // (see the block map in the kernel)
-  if(vec) hipLaunchKernelGGL(gemv_n_stage1<true>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks, nchunks, rtiles);
-  else hipLaunchKernelGGL(gemv_n_stage1<false>, g1, b1, 0, ctx->stream, m, n, A, lda, x, part, chunks, nchunks, rtiles);
+  GemvGroups G;
+  G.A[0] = A; G.A[1] = G.A[2] = nullptr;
+  G.m[0] = m; G.m[1] = G.m[2] = 0;
+  G.tile0[0] = G.tile0[1] = G.tile0[2] = 0;
+  G.row0[0] = G.row0[1] = G.row0[2] = 0;
+  G.ngroups = 1;
+  G.m_total = m;
+  if(vec) hipLaunchKernelGGL((gemv_n_stage1<true, false>), g1, b1, 0, ctx->stream, G, n, lda, x, (const double*)nullptr, part, chunks, nchunks, rtiles);
+  else hipLaunchKernelGGL((gemv_n_stage1<false, false>), g1, b1, 0, ctx->stream, G, n, lda, x, (const double*)nullptr, part, chunks, nchunks, rtiles);
   const int waves_per_block = kBlock / 64;
   hipLaunchKernelGGL(gemv_n_stage2, dim3((m + waves_per_block - 1) / waves_per_block), dim3(kBlock), 0, ctx->stream, m,
                      nchunks, part, beta, y, alpha);
@@ -548,12 +657,73 @@ int hiopamd_mat_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, i
   return HIOPAMD_OK;
 }
 
+static int gemv_t_impl(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, double beta, double* y, double alpha, const double* x,
+                      const GemvtTail* tail);
+
 int hiopamd_mat_trans_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, double beta,
                                 double* y, double alpha, const double* x)
 {
   if(m < 0 || n < 0) return HIOPAMD_ERR_ARG;
   if(n == 0) return HIOPAMD_OK;
   if(m == 0) return hiopamd_vec_scale(ctx, n, y, beta);
+  return gemv_t_impl(ctx, m, n, A, lda, beta, y, alpha, x, nullptr);
+}
+
+}  // extern "C"  (the two library-internal forms below have C++ linkage)
+
+namespace hiopamd {
+int gemv_t_tail(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, double* y, double alpha, const double* x, const GemvtTail& tail)
+{
+  if(m <= 0 || n < 0 || tail.l < 0 || 2 * tail.l > 128) return HIOPAMD_ERR_ARG;
+  if(n == 0) return HIOPAMD_OK;
+  return gemv_t_impl(ctx, m, n, A, lda, 1.0, y, alpha, x, &tail);
+}
+
+int gemv_n_groups(hiopamd_ctx* ctx, int64_t n, int64_t lda, int ngroups, const double* const* A, const int* m, const double* x,
+                  const double* xscale, double* y, const double* alpha, const double* sub0, int nsub0, const double* sub1)
+{
+  if(ngroups < 1 || ngroups > 3 || n <= 0) return HIOPAMD_ERR_ARG;
+  GemvGroups G;
+  int rtiles = 0, mt = 0;
+  bool vec = (lda % 2 == 0) && ((uintptr_t)x % 16 == 0) && (!xscale || (uintptr_t)xscale % 16 == 0);
+  for(int g = 0; g < 3; ++g) {
+    G.A[g] = (g < ngroups) ? A[g] : nullptr;
+    G.m[g] = (g < ngroups) ? m[g] : 0;
+    G.tile0[g] = rtiles;
+    G.row0[g] = mt;
+    if(g < ngroups) {
+      if(m[g] <= 0) return HIOPAMD_ERR_ARG;   // (callers leave empty groups out)
+      rtiles += (m[g] + GEMV_ROWS - 1) / GEMV_ROWS;
+      mt += m[g];
+      vec = vec && ((uintptr_t)A[g] % 16 == 0);
+    }
+  }
+  G.ngroups = ngroups;
+  G.m_total = mt;
+  int chunks = GEMV_CHUNKS;
+  while(chunks > 1 && (int64_t)rtiles * ((n + (int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks - 1) / ((int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks)) < 2048)
+    chunks >>= 1;
+  const int64_t cols = (int64_t)kBlock * GEMV_COLS_PER_THREAD * chunks;
+  const int nchunks = (int)((n + cols - 1) / cols);
+  double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nchunks * mt);
+  const dim3 g1((unsigned)(8 * ((nchunks + 7) / 8)) * (unsigned)rtiles), b1(kBlock);
+  if(vec && xscale) hipLaunchKernelGGL((gemv_n_stage1<true, true>), g1, b1, 0, ctx->stream, G, n, lda, x, xscale, part, chunks, nchunks, rtiles);
+  else if(vec) hipLaunchKernelGGL((gemv_n_stage1<true, false>), g1, b1, 0, ctx->stream, G, n, lda, x, xscale, part, chunks, nchunks, rtiles);
+  else if(xscale) hipLaunchKernelGGL((gemv_n_stage1<false, true>), g1, b1, 0, ctx->stream, G, n, lda, x, xscale, part, chunks, nchunks, rtiles);
+  else hipLaunchKernelGGL((gemv_n_stage1<false, false>), g1, b1, 0, ctx->stream, G, n, lda, x, xscale, part, chunks, nchunks, rtiles);
+  const int waves_per_block = kBlock / 64;
+  hipLaunchKernelGGL(gemv_n_stage2_groups, dim3((mt + waves_per_block - 1) / waves_per_block), dim3(kBlock), 0, ctx->stream, G, nchunks, part, y,
+                     alpha[0], ngroups > 1 ? alpha[1] : 0.0, ngroups > 2 ? alpha[2] : 0.0, sub0, nsub0, sub1);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+}  // namespace hiopamd
+
+extern "C" {
+
+static int gemv_t_impl(hiopamd_ctx* ctx, int m, int64_t n, const double* A, int64_t lda, double beta, double* y, double alpha, const double* x,
+                      const GemvtTail* tail)
+{
   constexpr int cp = 1;   // column pairs per thread (two: 0.41 vs 0.36 ms at k = 200, n = 1.25e6 -- scripts/calls/r04_gpu_13.sh)
   const int gx = (int)((n + 2 * kBlock * cp - 1) / (2 * kBlock * cp));
   // split rows so that the launch has >= ~1024 workgroups when the matrix is not tall-skinny
@@ -567,16 +737,20 @@ int hiopamd_mat_trans_times_vec(hiopamd_ctx* ctx, int m, int64_t n, const double
   int rows_per_split = (m + nsplit - 1) / nsplit;
   rows_per_split = ((rows_per_split + GEMVT_ROWCHUNK - 1) / GEMVT_ROWCHUNK) * GEMVT_ROWCHUNK;
   nsplit = (m + rows_per_split - 1) / rows_per_split;
-  auto kern = gemv_t_kernel<cp>;
+  auto kern = gemv_t_kernel<cp, false>;
   if(nsplit == 1) {
-    hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split, y,
-                       (int64_t)0, beta, alpha, 1);
+    if(tail) hipLaunchKernelGGL((gemv_t_kernel<cp, true>), dim3(gx, 1), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split, y,
+                                (int64_t)0, beta, alpha, 1, *tail);
+    else hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split, y,
+                            (int64_t)0, beta, alpha, 1, GemvtTail());
   } else {
     double* part = (double*)ctx_workspace(ctx, sizeof(double) * (size_t)nsplit * n);
     hipLaunchKernelGGL(kern, dim3(gx, nsplit), dim3(kBlock), 0, ctx->stream, m, n, A, lda, x, rows_per_split,
-                       part, n, 0.0, 1.0, 0);
-    hipLaunchKernelGGL(gemv_t_fold, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, nsplit,
-                       part, n, beta, y, alpha);
+                       part, n, 0.0, 1.0, 0, GemvtTail());
+    if(tail) hipLaunchKernelGGL(gemv_t_fold<true>, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, nsplit,
+                                part, n, beta, y, alpha, *tail);
+    else hipLaunchKernelGGL(gemv_t_fold<false>, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, nsplit,
+                            part, n, beta, y, alpha, GemvtTail());
   }
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;

@@ -2594,7 +2594,9 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
       if(timed) (void)hipEventRecord(prof->get(), su);
       // ONE working workgroup of the wide kernel per CU of the wide stream (ctx->wide_cus, 240 on MI355X with two reserved CUs per XCD):
       // 73.7 KB of LDS and one wave per SIMD, i.e. every CU could take a second one — the only shape that never froze in a soak
-      const int wmax = 2 * ctx->wide_cus;   // (the second workgroup of every CU leaves at once: see jretire above)
+      // (DF_WIDE_WG_PER_CU = 2: the second workgroup of every CU leaves at once, see jretire above; = 1: the kernel is compiled for one
+      //  wave per SIMD and uses more than 256 registers per lane, so a CU CANNOT hold a second workgroup: a grid of wide_cus is one per CU)
+      const int wmax = DF_WIDE_WG_PER_CU * ctx->wide_cus;
       const int grid = a.nwtasks < wmax ? a.nwtasks : wmax;
       // 16-byte accesses need even N, lda, ldv (ldv = N); otherwise the 8-byte tile form
       const bool form2 = (N % 2 == 0) && (lda % 2 == 0) && (ldv % 2 == 0) && N >= 2 * UD_T;
@@ -3676,6 +3678,8 @@ int hiopamd_linsolver_flops(const hiopamd_linsolver* ls, double* flops_fact_host
   if(flops_triu_solves_host) *flops_triu_solves_host = ls->flops_triu;
   return HIOPAMD_OK;
 }
+
+int hiopamd_linsolver_factored(const hiopamd_linsolver* ls) { return (ls && ls->factored) ? 1 : 0; }
 
 int hiopamd_linsolver_inertia(const hiopamd_linsolver* ls, int* pos, int* neg, int* zero)
 {

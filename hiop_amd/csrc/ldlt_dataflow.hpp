@@ -1373,7 +1373,10 @@ __device__ __forceinline__ bool df_task_tile2(const DfArgs& a, int j, int I, int
   return gate_ok;
 }
 
-constexpr int DF_WIDE_WG_PER_CU = 2;   // (register budget of the wide kernel: 256 per lane, so that a CU could hold a second workgroup — see DESIGN.md 3.1 on exactly-filled CUs)
+#ifndef HIOPAMD_DF_WIDE_WG_PER_CU
+#define HIOPAMD_DF_WIDE_WG_PER_CU 2
+#endif
+constexpr int DF_WIDE_WG_PER_CU = HIOPAMD_DF_WIDE_WG_PER_CU;   // (register budget of the wide kernel: 256 per lane, so that a CU could hold a second workgroup — see DESIGN.md 3.1 on exactly-filled CUs)
 constexpr int DF_TRQ = 40, DF_UPQ = 41, DF_UPQF = 42;   // per super-panel: TR / NEAR update / FAR update tasks of its queues handed out so far
 
 // Two task queues per super-panel instead of one ticket list.  A ticket list must put TR(j+1, .) somewhere inside UP(j, .),

@@ -20,6 +20,7 @@
 //    the reference's DSYTRF/DSYTRS on the host — no D2H round trip;
 //  * only the scalars the IPM branches on (||s||, s^T y, ...) cross to the host.
 #include "device_utils.hpp"
+#include "dense_internal.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -728,7 +729,173 @@ struct hiopamd_kkt_lowrank {
   bool N_valid = false;
   unsigned long long N_version = 0;
   int N_info = 0;
+  // Round 6, the fused solve (k <= kFusedMaxK): the equilibrated N is factored by a solver object of order k (its solve is ONE launch of
+  // the dataflow solve), and what surrounds that solve runs in three one-workgroup kernels (lowrank_mid_*): 8 launches and one host
+  // round trip per solveCompressed instead of ~38 launches.  nvec = [sc | b0 | xs | r | c0 | c1 | xu0 | xu1] (k each) + two 64-bit words (the residual maximum, the arrival counter); h_nrm: pinned, written by the device.
+  hiopamd_linsolver* nls = nullptr;
+  double* nvec = nullptr;
+  double* h_nrm = nullptr;
+  double* h_nrm_dev = nullptr;
 };
+constexpr int kFusedMaxK = 1024;   // the one-workgroup kernels keep a k-vector in LDS
+
+// ---- the fused solveCompressed (round 6) -----------------------------------------------------------------------------------------
+// The small algebra of one solveCompressed (reference hiopKKTLinSys.cpp:1110-1187; the formulas are in the comment of
+// hiopamd_kkt_lowrank_solve_compressed) as three one-workgroup kernels around ONE launch of the order-k solver's solve.
+namespace {
+// x <- V^-1 x for the 2l x 2l middle matrix (factors of small_lu_factor_kernel) by ONE WAVE (call with every lane of wave 0): lane i
+// holds x_i, a solved entry is broadcast by a shuffle and the lanes below / above subtract their multiple of it — nv dependent steps of
+// (shuffle, LDS read, fused multiply-add) instead of nv^2 / 2 dependent memory reads by one thread.  LUs: the factors in LDS, row-major
+// nv x nv (unit lower below the diagonal, upper on and above); piv: the row exchanges in the order they were made.  nv <= kMaxV <= 64.
+// Returns x_lane (lanes >= nv: 0).  The subtractions of a row happen in the order of small_lu_apply_kernel (c ascending / descending).
+__device__ inline double lu_apply_wave(int nv, const double* LUs, const int* __restrict__ piv, double xv, int lane)
+{
+  for(int k = 0; k < nv; ++k) {   // partial pivoting's exchanges: x_k <-> x_p
+    const int p = piv[k];
+    const double xk = __shfl(xv, k, 64), xp = __shfl(xv, p, 64);
+    xv = (lane == k) ? xp : (lane == p) ? xk : xv;
+  }
+  for(int c = 0; c + 1 < nv; ++c) {   // unit lower
+    const double xc = __shfl(xv, c, 64);
+    if(lane > c && lane < nv) xv -= LUs[lane * nv + c] * xc;
+  }
+  for(int c = nv - 1; c >= 0; --c) {   // upper
+    const double d = LUs[c * nv + c];
+    const double xc = __shfl(xv, c, 64) / d;
+    if(lane == c) xv = xc;
+    if(lane < c) xv -= LUs[lane * nv + c] * xc;
+  }
+  return (lane < nv) ? xv : 0.0;
+}
+
+// sc_i = 1 / sqrt(N_ii);  M = upper(diag(sc) N diag(sc)) into the solver object's matrix (both in one pass: the factor of the
+// EQUILIBRATED matrix is what DPOSVX-style refinement works with, hiopKKTLinSys.cpp:1192-1330)
+__global__ __launch_bounds__(kBlock) void lowrank_equilibrate_kernel(int k, const double* __restrict__ Nm, int64_t ldn, double* __restrict__ sc,
+                                                                     double* __restrict__ M)
+{
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if(e >= (int64_t)k * k) return;
+  const int64_t i = e / k, j = e - i * k;
+  const double si = 1.0 / sqrt(Nm[i * ldn + i]), sj = 1.0 / sqrt(Nm[j * ldn + j]);
+  if(i == j) sc[i] = si;
+  M[e] = (j >= i) ? Nm[i * ldn + j] * si * sj : 0.0;
+}
+
+// z = V^-1 sy;  rhs = t - S1Y1 z;  b0 = rhs;  x = rhs .* sc     (nv = 2 l, may be 0)
+__global__ __launch_bounds__(kBlock) void lowrank_mid_pre_kernel(int k, int nv, const double* __restrict__ LU, const int* __restrict__ piv,
+                                                                 const double* __restrict__ S1Y1, int64_t kw, const double* __restrict__ t,
+                                                                 const double* __restrict__ sy, double* __restrict__ z,
+                                                                 const double* __restrict__ sc, double* __restrict__ b0, double* __restrict__ x)
+{
+  __shared__ double zs[kMaxV];
+  __shared__ double LUs[kMaxV * kMaxV];
+  const int tid = threadIdx.x;
+  if(nv > 0) {
+    for(int e = tid; e < nv * nv; e += kBlock) LUs[e] = LU[e];
+    __syncthreads();
+    if(tid < 64) {
+      const double v = lu_apply_wave(nv, LUs, piv, (tid < nv) ? sy[tid] : 0.0, tid);
+      if(tid < nv) {
+        zs[tid] = v;
+        z[tid] = v;
+      }
+    }
+    __syncthreads();
+  }
+  for(int i = tid; i < k; i += kBlock) {
+    double v = 0.0;
+    for(int q = 0; q < nv; ++q) v = fma(S1Y1[(int64_t)i * kw + q], zs[q], v);
+    const double r = t[i] - v;
+    b0[i] = r;
+    x[i] = r * sc[i];
+  }
+}
+
+// xu = xs .* sc (the solver's answer in the unscaled variables; refine != 0: xu = xu_prev + xs .* sc, xs = the solver's answer for the
+// last residual);  r = b0 - N xu (upper triangle of N referenced), c = r .* sc (right-hand side of a refinement step, should the host
+// ask for one);  *nrm = max |r_i|.  One wave per row (like sym_upper_residual), kBlock / 64 rows per workgroup; every workgroup forms xu in
+// its own LDS from read-only inputs, workgroup 0 also writes it out (to a buffer nobody reads in this launch); the maximum goes through
+// an integer atomic on the bit pattern (non-negative doubles order like their bits; a NaN's pattern is above every number's, so it reaches
+// the host), and the LAST workgroup to arrive hands it to the pinned word and re-arms the two words for the next launch.
+__global__ __launch_bounds__(kBlock) void lowrank_mid_post_kernel(int k, const double* __restrict__ Nm, int64_t ldn, const double* __restrict__ sc,
+                                                                  const double* __restrict__ b0, const double* __restrict__ xs,
+                                                                  const double* __restrict__ xu_prev, double* __restrict__ xu,
+                                                                  double* __restrict__ r, double* __restrict__ c,
+                                                                  unsigned long long* __restrict__ acc2, double* __restrict__ nrm_out, int refine)
+{
+  __shared__ double xl[kFusedMaxK];
+  __shared__ unsigned long long wmax[kBlock / 64];
+  __shared__ int last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for(int i = tid; i < k; i += kBlock) {
+    const double v = refine ? (xu_prev[i] + xs[i] * sc[i]) : (xs[i] * sc[i]);
+    xl[i] = v;
+    if(blockIdx.x == 0) xu[i] = v;
+  }
+  __syncthreads();
+  unsigned long long mx = 0ull;
+  const int row = blockIdx.x * (kBlock / 64) + wave;
+  if(row < k) {
+    double acc = 0.0;
+    for(int j = lane; j < k; j += 64) {
+      const double a = (j >= row) ? Nm[(int64_t)row * ldn + j] : Nm[(int64_t)j * ldn + row];
+      acc = fma(a, xl[j], acc);
+    }
+    for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if(lane == 0) {
+      const double rv = b0[row] - acc;
+      r[row] = rv;
+      c[row] = rv * sc[row];
+      mx = (unsigned long long)__double_as_longlong(fabs(rv));
+    }
+  }
+  if(lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  if(tid == 0) {
+    unsigned long long m = wmax[0];
+    for(int w = 1; w < kBlock / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
+    (void)atomicMax(acc2, m);
+    __threadfence();
+    last = (atomicAdd(acc2 + 1, 1ull) == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+    if(last) {
+      __threadfence();
+      const unsigned long long tot = atomicExch(acc2, 0ull);   // (read and re-arm)
+      (void)atomicExch(acc2 + 1, 0ull);
+      *nrm_out = __longlong_as_double((long long)tot);
+    }
+  }
+}
+
+// t = dy = x; dyc / dyd;  sy <- V^-1 (sy - S1Y1^T dy)
+__global__ __launch_bounds__(kBlock) void lowrank_mid_tail_kernel(int k, int me, int nv, const double* __restrict__ LU, const int* __restrict__ piv,
+                                                                  const double* __restrict__ S1Y1, int64_t kw, const double* __restrict__ x,
+                                                                  double* __restrict__ t, double* __restrict__ dyc, double* __restrict__ dyd,
+                                                                  double* __restrict__ sy)
+{
+  __shared__ double ss[kMaxV];
+  __shared__ double LUs[kMaxV * kMaxV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for(int i = tid; i < k; i += kBlock) {
+    const double v = x[i];
+    t[i] = v;
+    if(i < me) dyc[i] = v;
+    else dyd[i - me] = v;
+  }
+  if(nv <= 0) return;
+  for(int q = wave; q < nv; q += kBlock / 64) {
+    double acc = 0.0;
+    for(int i = lane; i < k; i += 64) acc = fma(S1Y1[(int64_t)i * kw + q], x[i], acc);
+    for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if(lane == 0) ss[q] = sy[q] - acc;
+  }
+  for(int e = tid; e < nv * nv; e += kBlock) LUs[e] = LU[e];
+  __syncthreads();
+  if(tid < 64) {
+    const double v = lu_apply_wave(nv, LUs, piv, (tid < nv) ? ss[tid] : 0.0, tid);
+    if(tid < nv) sy[tid] = v;
+  }
+}
+}  // namespace
 
 static int lowrank_set_J(hiopamd_kkt_lowrank* K, const double* Jc, const double* Jd);
 namespace hiopamd {
@@ -757,6 +924,18 @@ int hiopamd_kkt_lowrank_create(hiopamd_kkt_lowrank** out, hiopamd_ctx* ctx, hiop
     hiopamd_kkt_lowrank_destroy(K);
     return HIOPAMD_ERR_HIP;
   }
+  if(k > 0 && k <= (size_t)kFusedMaxK) {
+    bool ok = hiopamd_linsolver_create(&K->nls, ctx, (int)k) == HIOPAMD_OK;
+    ok = ok && A(&K->nvec, 8 * k + 2);
+    ok = ok && hipMemsetAsync(K->nvec, 0, sizeof(double) * (8 * k + 2), ctx->stream) == hipSuccess;   // (the two words start at zero; the kernel re-arms them)
+    ok = ok && hipHostMalloc((void**)&K->h_nrm, 4 * sizeof(double), hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void**)&K->h_nrm_dev, K->h_nrm, 0) == hipSuccess;
+    if(!ok) {
+      hiopamd_kkt_lowrank_destroy(K);
+      return HIOPAMD_ERR_HIP;
+    }
+    (void)hiopamd_linsolver_set_retry_copy(K->nls, 0);   // (N is rebuilt by this object if a factorisation has to be repeated)
+  }
   *out = K;
   return HIOPAMD_OK;
 }
@@ -765,8 +944,10 @@ int hiopamd_kkt_lowrank_destroy(hiopamd_kkt_lowrank* K)
 {
   if(!K) return HIOPAMD_OK;
   (void)hipStreamSynchronize(K->ctx->stream);
-  double* ps[] = {K->J, K->N, K->Dd_inv, K->Dx, K->rhs, K->tsy, K->work};
+  double* ps[] = {K->J, K->N, K->Dd_inv, K->Dx, K->rhs, K->tsy, K->work, K->nvec};
   for(double* p : ps) (void)hipFree(p);
+  if(K->nls) (void)hiopamd_linsolver_destroy(K->nls);
+  if(K->h_nrm) (void)hipHostFree(K->h_nrm);
   delete K;
   return HIOPAMD_OK;
 }
@@ -892,6 +1073,75 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
   double* t = K->tsy;                         // [t (k) ; sy (2l)] contiguous: one buffer for the collective
   double* sy = t + k;
   double* z = sy + 2 * (size_t)H->l_max;
+  if(K->nls && n > 0 && 2 * l <= kMaxV) {
+    // ---- round 6: the same algebra in 8 launches and one host round trip
+    //  (1, 2)  [t; sy] = [J; sigma S; Y] (DhInv .* rx) - [ry; 0]: ONE pass over J and the secant rows, DhInv applied on the way in
+    const double* Ag[3] = {K->Jcur, H->St, H->Yt};
+    const int mg[3] = {k, l, l};
+    const double ag[3] = {1.0, sigma, 1.0};
+    const bool sub = ctx->comm_rank == 0;   // only rank 0 subtracts ry, then all-reduce (:466, :1157)
+    RC(gemv_n_groups(ctx, n, n, l > 0 ? 3 : 1, Ag, mg, rx, DhInv, t, ag, sub ? (me > 0 ? ryc : ryd) : nullptr, sub ? (me > 0 ? me : mi) : 0, ryd));
+    RC(allreduce_dev(ctx, t, (size_t)k + 2 * (size_t)l, HIOPAMD_SUM));
+    // scale, rhs, solver's vector, residual, correction (two copies: a launch reads the solver's answer in one and writes the next
+    // right-hand side into the other), solution (two copies for the same reason)
+    double *sc = K->nvec, *b0 = sc + k, *xk = b0 + k, *rk = xk + k, *c0 = rk + k, *c1 = c0 + k, *xu0 = c1 + k, *xu1 = xu0 + k;
+    unsigned long long* acc2 = reinterpret_cast<unsigned long long*>(xu1 + k);
+    double* xsol = xu0;   // where the current solution is
+    if(!reuse) {
+      //  the equilibrated N into the solver object, factored there (once per rebuilt N)
+      int info = 0;
+      for(int attempt = 0; attempt < 2; ++attempt) {
+        hipLaunchKernelGGL(lowrank_equilibrate_kernel, dim3((unsigned)(((int64_t)k * k + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, k, K->N,
+                           (int64_t)k, sc, hiopamd_linsolver_sys_matrix(K->nls));
+        int nneg = 0;
+        const int rcf = hiopamd_linsolver_matrix_changed(K->nls, &nneg);
+        if(rcf == HIOPAMD_ERR_TIMEOUT && attempt == 0) continue;   // (dataflow factorisation of a large k gave up: once more, stepwise kernels)
+        if(rcf != HIOPAMD_OK) return rcf;
+        info = (nneg != 0) ? 1 : 0;                                 // not (numerically) positive definite: DPOSVX INFO > 0
+        if(!hiopamd_linsolver_factored(K->nls)) info = 2;           // singular: nothing to solve with
+        break;
+      }
+      K->N_info = info;
+    }
+    K->N_version = K->H->version;
+    K->N_valid = true;
+    if(K->N_info != 0 && ok_host) *ok_host = 0;
+    double resid = 0.0;
+    if(K->N_info != 2) {
+      //  (3) z = V^-1 sy, rhs = t - S1Y1 z, scaled   (4) the solve   (5) unscale, residual, its norm to the host
+      hipLaunchKernelGGL(lowrank_mid_pre_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, k, 2 * l, H->dVlu, H->dVpiv, S1Y1, (int64_t)kw, t, sy, z, sc, b0, xk);
+      RC(hiopamd_linsolver_solve(K->nls, xk, 1));
+      const int MAX_ITER_REFIN = 3;
+      for(int it = 0;; ++it) {
+        double* xnew = (it & 1) ? xu1 : xu0;
+        double* cin = (it & 1) ? c0 : c1;    // (it > 0) the solver's answer for the previous residual
+        double* cout = (it & 1) ? c1 : c0;
+        hipLaunchKernelGGL(lowrank_mid_post_kernel, dim3((unsigned)((k + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, ctx->stream, k, K->N, (int64_t)k, sc, b0,
+                           it > 0 ? cin : xk, xsol, xnew, rk, cout, acc2, K->h_nrm_dev, it > 0 ? 1 : 0);
+        xsol = xnew;
+        HIOPAMD_CHECK(hipGetLastError());
+        // ONE host round trip: the solver's status read-back (the error word of its dataflow solve) synchronises the stream, the norm
+        // written by the kernel above has then arrived as well
+        int oks = 1;
+        RC(hiopamd_linsolver_solve_status(K->nls, &oks));
+        HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));   // (no-op behind the status read-back; the wait itself when the solve was stepwise)
+        if(!oks) return HIOPAMD_ERR_SOLVE;
+        resid = K->h_nrm[0];
+        if(resid < 1e-8 || it >= MAX_ITER_REFIN) break;
+        RC(hiopamd_linsolver_solve(K->nls, cout, 1));   // cout holds r .* sc; the correction comes back in place and is read as `cin` next
+      }
+    } else {
+      RC(hiopamd_vec_copy(ctx, k, xsol, t));   // (the old path left the right-hand side in place for a singular N)
+    }
+    K->last_resid = resid;
+    //  (6) dy out, sy' = V^-1 (sy - S1Y1^T dy)
+    hipLaunchKernelGGL(lowrank_mid_tail_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, k, me, 2 * l, H->dVlu, H->dVpiv, S1Y1, (int64_t)kw, xsol, t, dyc, dyd, sy);
+    //  (7, 8) rx -= J^T dy and, per column, dx = DhInv (rx - [sigma S, Y]^T sy')
+    GemvtTail tail{H->St, H->Yt, l, n, sigma, sy, DhInv, dx};
+    RC(gemv_t_tail(ctx, k, n, K->Jcur, n, rx, -1.0, t, tail));
+    HIOPAMD_CHECK(hipGetLastError());
+    return HIOPAMD_OK;
+  }
   RC(launch_ew(ctx, n, [=] __device__(int64_t i) { dx[i] = rx[i] * DhInv[i]; }));   // w lives in dx until the end
   if(ctx->comm_rank == 0) {   // only rank 0 subtracts ry, then all-reduce (:466, :1157)
     RC(launch_ew(ctx, k, [=] __device__(int64_t i) { t[i] = (i < me) ? ryc[i] : ryd[i - me]; }));

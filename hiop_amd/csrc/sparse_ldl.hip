@@ -41,7 +41,10 @@
 
 using namespace hiopamd;
 
-constexpr int SL_LEAF = 48;          // columns per supernode (leaf regions, separator chunks)
+#ifndef HIOPAMD_SL_LEAF
+#define HIOPAMD_SL_LEAF 48
+#endif
+constexpr int SL_LEAF = HIOPAMD_SL_LEAF;   // columns per supernode (leaf regions, separator chunks); < 64: a front's pivot rows fit one register per lane
 constexpr int SL_PACK = 8;           // columns of a supernode that packs several tiny independent components
 constexpr int SL_T = 128;            // rows of a front that is eliminated in LDS (128 x 129 doubles = 132 KB)
 constexpr int SL_ROOT_MAX = 20480;   // order of the dense root (3.4 GB)
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(kBlock) void sl_root_scatter_kernel(int r, const in
   for(int t = blockIdx.x * kBlock + threadIdx.x; t < r; t += gridDim.x * kBlock) x[root_old[t]] = xr[t];
 }
 
-// backward: z = y ./ d; L11^T x_c = z - L21^T x_r; one wave per front
+// backward: z = y ./ d; L11^T x_c = z - L21^T x_r; one wave per front (row-by-row axpy form, see below)
 __global__ __launch_bounds__(64) void sl_bwd_level_kernel(int q0, const int* __restrict__ f_nc, const int* __restrict__ f_nr,
                                                           const int64_t* __restrict__ f_lofs, const int64_t* __restrict__ f_iofs,
                                                           const int* __restrict__ fidx, const double* __restrict__ lpool, double* __restrict__ x)
@@ -720,32 +723,32 @@ __global__ __launch_bounds__(64) void sl_bwd_level_kernel(int q0, const int* __r
   const int lane = threadIdx.x;
   const int* idx = fidx + f_iofs[q];
   const double* L = lpool + f_lofs[q];
-  // rows lane and lane + 64 of the front's vector in registers (f <= 128; the pivot rows, nc <= 48, in the first one): a column step is a
-  // dot product folded by shuffles (a fixed tree: reproducible run to run) and one lane's update — no LDS, no barrier
+  // Rows lane and lane + 64 of the front's vector in registers (f <= 128; the pivot rows, nc <= 48, in the first one).  Round 6: the sweep
+  // runs in AXPY form over the ROWS of L, from the last row up: when x_i is final (every row below it has been applied) it is broadcast by
+  // ONE shuffle and lane k < min(i, nc) subtracts L_ik x_i from its own entry — no reduction.  (Rounds 4-5 took the columns from the last
+  // pivot down: a dot product over the lanes per pivot, six dependent shuffles + a broadcast each, 140 us for the 32 768 leaf fronts of the
+  // banded n = 1e6 case against 62 us for the forward sweep, which always was an axpy.)  Lane k reads ITS OWN column k of the panel
+  // (contiguous, column-major storage) at row i: sixteen rows' entries are requested together.
   double w0 = 0.0, w1 = 0.0;
   if(lane < f) {
     const double v = x[idx[lane]];
     w0 = (lane < nc) ? v / L[(int64_t)lane * f + lane] : v;
   }
   if(lane + 64 < f) w1 = x[idx[lane + 64]];
-  const bool two = f > 64;   // uniform
-  for(int k0 = ((nc - 1) / 16) * 16; k0 >= 0; k0 -= 16) {   // sixteen columns' entries requested together (see sl_fwd_level_kernel)
-    double l0[16], l1[16];
+  const double* Lk = L + (int64_t)((lane < nc) ? lane : 0) * f;   // this lane's column (lanes >= nc hold no pivot: their entries are masked)
+  for(int i0 = f - 1; i0 >= 1; i0 -= 16) {
+    double lv[16];
 #pragma unroll
     for(int u = 0; u < 16; ++u) {
-      const int k = k0 + u;
-      l0[u] = (k < nc && lane > k && lane < f) ? L[(int64_t)k * f + lane] : 0.0;
-      l1[u] = (two && k < nc && lane + 64 < f) ? L[(int64_t)k * f + lane + 64] : 0.0;
+      const int i = i0 - u;
+      lv[u] = (i >= 1 && lane < nc && i > lane) ? Lk[i] : 0.0;
     }
 #pragma unroll
-    for(int u = 15; u >= 0; --u) {
-      const int k = k0 + u;
-      if(k < nc) {   // uniform
-        double s = l0[u] * w0;
-        if(two) s += l1[u] * w1;
-        for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        const double tot = __shfl(s, 0, 64);
-        if(lane == k) w0 -= tot;
+    for(int u = 0; u < 16; ++u) {
+      const int i = i0 - u;
+      if(i >= 1) {   // uniform
+        const double xi = (i < 64) ? __shfl(w0, i, 64) : __shfl(w1, i - 64, 64);
+        w0 -= lv[u] * xi;      // (zero for the rows at or below the lane's pivot and for the non-pivot lanes)
       }
     }
   }

@@ -511,6 +511,9 @@ int hiopamd_linsolver_n(const hiopamd_linsolver* ls);
  * blocking hipMemcpy (the context's own stream is non-blocking: the null stream does not wait for it) — calls hiopamd_ctx_sync first;
  * the C++ adapter's matrixChanged() does (adapters/hiopLinSolverSymDenseHipNative.cpp). */
 int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host);
+/* 1 when the last matrixChanged() left a factor solve() can use (also with negative or tiny pivots: the answer -1 for a null pivot by
+ * the reference's threshold does not mean there is no factor), 0 after an exactly zero / non-finite pivot or before the first call */
+int hiopamd_linsolver_factored(const hiopamd_linsolver* ls);
 /* solve(): rhs (device, length n * nrhs, column after column) overwritten by the solution */
 int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs);
 /* last factorisation: pos/neg/zero pivot counts (magmablas_ddiinertia equivalent) */

@@ -2,7 +2,7 @@
 and the same phases back to back without the syncs.  DENSE_N (1000000), DENSE_K (100)."""
 import os, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hiop_amd.runtime import Context
 from hiop_amd.kkt import HessianLowRank, KKTLinSysLowRank
 n = int(os.environ.get("DENSE_N", "1000000")); k = int(os.environ.get("DENSE_K", "100")); l = 6

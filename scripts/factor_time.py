@@ -1,6 +1,6 @@
 """Wall time of hiopamd_linsolver_matrix_changed (factorisation incl. the final inertia read-back) and of one solve."""
-import sys, time, torch
-sys.path.insert(0, ".")
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hiop_amd.runtime import Context
 from hiop_amd.kkt import LinSolverSymDense
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
