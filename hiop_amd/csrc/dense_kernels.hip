@@ -274,17 +274,64 @@ __global__ __launch_bounds__(kBlock) void gemv_n_stage2(int m, int nchunks, cons
 constexpr int GEMVT_ROWCHUNK = 64;
 
 // CP: column pairs per thread (pair p of thread t = columns base + 512 p + 2 t, +1)
-// the per-column epilogue of gemv_t_tail (dense_internal.hpp): yj is the finished y_j; sy_sh = the 2 l coefficients in LDS
+// the per-column epilogue of gemv_t_tail (dense_internal.hpp): yj is the finished y_j; sy_sh = the 2 l coefficients in LDS.  The 2 l
+// entries of the secant rows are requested eight rows at a time (a loop over a run-time l keeps ONE load in flight per lane: the tail then
+// cost 55 us of a 350 us pass at n = 1.25e6, l = 6).
 __device__ __forceinline__ void gemvt_tail_store(const GemvtTail& T, const double* sy_sh, int64_t j, double yj)
 {
   double s1 = 0.0, s2 = 0.0;
-  for(int q = 0; q < T.l; ++q) s1 = fma(T.S[(int64_t)q * T.ld + j], sy_sh[q], s1);
-  for(int q = 0; q < T.l; ++q) s2 = fma(T.Y[(int64_t)q * T.ld + j], sy_sh[T.l + q], s2);
+  for(int q0 = 0; q0 < T.l; q0 += 8) {
+    double sv[8], yv[8];
+#pragma unroll
+    for(int u = 0; u < 8; ++u) {
+      const int q = (q0 + u < T.l) ? (q0 + u) : (T.l - 1);   // (clamped: the loads stay unconditional, the extra ones are not used)
+      sv[u] = T.S[(int64_t)q * T.ld + j];
+      yv[u] = T.Y[(int64_t)q * T.ld + j];
+    }
+#pragma unroll
+    for(int u = 0; u < 8; ++u)
+      if(q0 + u < T.l) s1 = fma(sv[u], sy_sh[q0 + u], s1);
+#pragma unroll
+    for(int u = 0; u < 8; ++u)
+      if(q0 + u < T.l) s2 = fma(yv[u], sy_sh[T.l + q0 + u], s2);
+  }
   double res = T.sigma * s1;
   res = res + s2;
   const double di = T.DhInv[j];
   const double a = yj * di, b = res * di;
   T.dx[j] = a - b;
+}
+// two adjacent columns j, j + 1 (j even, every row 16-byte aligned): one 16-byte load per secant row
+__device__ __forceinline__ void gemvt_tail_store2(const GemvtTail& T, const double* sy_sh, int64_t j, double y0, double y1)
+{
+  double s10 = 0.0, s11 = 0.0, s20 = 0.0, s21 = 0.0;
+  for(int q0 = 0; q0 < T.l; q0 += 8) {
+    double2 sv[8], yv[8];
+#pragma unroll
+    for(int u = 0; u < 8; ++u) {
+      const int q = (q0 + u < T.l) ? (q0 + u) : (T.l - 1);
+      sv[u] = *reinterpret_cast<const double2*>(T.S + (int64_t)q * T.ld + j);
+      yv[u] = *reinterpret_cast<const double2*>(T.Y + (int64_t)q * T.ld + j);
+    }
+#pragma unroll
+    for(int u = 0; u < 8; ++u)
+      if(q0 + u < T.l) {
+        s10 = fma(sv[u].x, sy_sh[q0 + u], s10);
+        s11 = fma(sv[u].y, sy_sh[q0 + u], s11);
+      }
+#pragma unroll
+    for(int u = 0; u < 8; ++u)
+      if(q0 + u < T.l) {
+        s20 = fma(yv[u].x, sy_sh[T.l + q0 + u], s20);
+        s21 = fma(yv[u].y, sy_sh[T.l + q0 + u], s21);
+      }
+  }
+  const double2 di = *reinterpret_cast<const double2*>(T.DhInv + j);
+  double r0 = T.sigma * s10, r1 = T.sigma * s11;
+  r0 = r0 + s20;
+  r1 = r1 + s21;
+  const double a0 = y0 * di.x, b0 = r0 * di.x, a1 = y1 * di.y, b1 = r1 * di.y;
+  *reinterpret_cast<double2*>(T.dx + j) = double2{a0 - b0, a1 - b1};
 }
 
 template <int CP, bool TAIL = false>
@@ -298,6 +345,8 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const 
     if(threadIdx.x < 2 * T.l) sy_sh[threadIdx.x] = T.sy[threadIdx.x];
     // (visible behind the first __syncthreads() of the row loop below: m > 0 on this path)
   }
+  // 16-byte accesses to the secant rows, DhInv and dx (the columns of a pair are j0 = even, j0 + 1)
+  const bool tail_vec = TAIL && ((T.ld & 1) == 0) && ((((uintptr_t)T.S) | ((uintptr_t)T.Y) | ((uintptr_t)T.DhInv) | ((uintptr_t)T.dx)) & 15) == 0;
   const int r_begin = blockIdx.y * rows_per_split;
   int r_end = r_begin + rows_per_split;
   if(r_end > m) r_end = m;
@@ -362,11 +411,18 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(int m, int64_t n, const 
     if(direct) {
       const double v0 = (beta == 0.0 ? 0.0 : beta * out[j0]) + alpha * a0[p];
       out[j0] = v0;
-      if constexpr(TAIL) gemvt_tail_store(T, sy_sh, j0, v0);
+      double v1 = 0.0;
       if(j0 + 1 < n) {
-        const double v1 = (beta == 0.0 ? 0.0 : beta * out[j0 + 1]) + alpha * a1[p];
+        v1 = (beta == 0.0 ? 0.0 : beta * out[j0 + 1]) + alpha * a1[p];
         out[j0 + 1] = v1;
-        if constexpr(TAIL) gemvt_tail_store(T, sy_sh, j0 + 1, v1);
+      }
+      if constexpr(TAIL) {
+        if(tail_vec && j0 + 1 < n) {
+          gemvt_tail_store2(T, sy_sh, j0, v0, v1);
+        } else {
+          gemvt_tail_store(T, sy_sh, j0, v0);
+          if(j0 + 1 < n) gemvt_tail_store(T, sy_sh, j0 + 1, v1);
+        }
       }
     } else {
       double* o = out + (int64_t)blockIdx.y * out_stride;

@@ -784,7 +784,7 @@ __global__ __launch_bounds__(kBlock) void lowrank_equilibrate_kernel(int k, cons
 // z = V^-1 sy;  rhs = t - S1Y1 z;  b0 = rhs;  x = rhs .* sc     (nv = 2 l, may be 0)
 __global__ __launch_bounds__(kBlock) void lowrank_mid_pre_kernel(int k, int nv, const double* __restrict__ LU, const int* __restrict__ piv,
                                                                  const double* __restrict__ S1Y1, int64_t kw, const double* __restrict__ t,
-                                                                 const double* __restrict__ sy, double* __restrict__ z,
+                                                                 const double* __restrict__ sy,
                                                                  const double* __restrict__ sc, double* __restrict__ b0, double* __restrict__ x)
 {
   __shared__ double zs[kMaxV];
@@ -795,10 +795,7 @@ __global__ __launch_bounds__(kBlock) void lowrank_mid_pre_kernel(int k, int nv, 
     __syncthreads();
     if(tid < 64) {
       const double v = lu_apply_wave(nv, LUs, piv, (tid < nv) ? sy[tid] : 0.0, tid);
-      if(tid < nv) {
-        zs[tid] = v;
-        z[tid] = v;
-      }
+      if(tid < nv) zs[tid] = v;
     }
     __syncthreads();
   }
@@ -866,11 +863,11 @@ __global__ __launch_bounds__(kBlock) void lowrank_mid_post_kernel(int k, const d
   }
 }
 
-// t = dy = x; dyc / dyd;  sy <- V^-1 (sy - S1Y1^T dy)
+// t = dy = x; dyc / dyd;  syp = V^-1 (sy - S1Y1^T dy)
 __global__ __launch_bounds__(kBlock) void lowrank_mid_tail_kernel(int k, int me, int nv, const double* __restrict__ LU, const int* __restrict__ piv,
                                                                   const double* __restrict__ S1Y1, int64_t kw, const double* __restrict__ x,
                                                                   double* __restrict__ t, double* __restrict__ dyc, double* __restrict__ dyd,
-                                                                  double* __restrict__ sy)
+                                                                  const double* __restrict__ sy, double* __restrict__ syp)
 {
   __shared__ double ss[kMaxV];
   __shared__ double LUs[kMaxV * kMaxV];
@@ -892,7 +889,7 @@ __global__ __launch_bounds__(kBlock) void lowrank_mid_tail_kernel(int k, int me,
   __syncthreads();
   if(tid < 64) {
     const double v = lu_apply_wave(nv, LUs, piv, (tid < nv) ? ss[tid] : 0.0, tid);
-    if(tid < nv) sy[tid] = v;
+    if(tid < nv) syp[tid] = v;
   }
 }
 }  // namespace
@@ -1086,7 +1083,6 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
     // right-hand side into the other), solution (two copies for the same reason)
     double *sc = K->nvec, *b0 = sc + k, *xk = b0 + k, *rk = xk + k, *c0 = rk + k, *c1 = c0 + k, *xu0 = c1 + k, *xu1 = xu0 + k;
     unsigned long long* acc2 = reinterpret_cast<unsigned long long*>(xu1 + k);
-    double* xsol = xu0;   // where the current solution is
     if(!reuse) {
       //  the equilibrated N into the solver object, factored there (once per rebuilt N)
       int info = 0;
@@ -1107,38 +1103,58 @@ int hiopamd_kkt_lowrank_solve_compressed(hiopamd_kkt_lowrank* K, double* rx, con
     K->N_valid = true;
     if(K->N_info != 0 && ok_host) *ok_host = 0;
     double resid = 0.0;
+    double* syp = z;   // sy' = V^-1 (sy - S1Y1^T dy) goes here: sy itself survives (a refinement repeats the end of the call from it)
+    auto finish = [&](const double* xs_) -> int {
+      //  (6) dy out, sy' = V^-1 (sy - S1Y1^T dy)
+      hipLaunchKernelGGL(lowrank_mid_tail_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, k, me, 2 * l, H->dVlu, H->dVpiv, S1Y1, (int64_t)kw, xs_, t, dyc, dyd, sy, syp);
+      //  (7, 8) rx -= J^T dy and, per column, dx = DhInv (rx - [sigma S, Y]^T sy')
+      GemvtTail tail{H->St, H->Yt, l, n, sigma, syp, DhInv, dx};
+      return gemv_t_tail(ctx, k, n, K->Jcur, n, rx, -1.0, t, tail);
+    };
     if(K->N_info != 2) {
       //  (3) z = V^-1 sy, rhs = t - S1Y1 z, scaled   (4) the solve   (5) unscale, residual, its norm to the host
-      hipLaunchKernelGGL(lowrank_mid_pre_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, k, 2 * l, H->dVlu, H->dVpiv, S1Y1, (int64_t)kw, t, sy, z, sc, b0, xk);
+      hipLaunchKernelGGL(lowrank_mid_pre_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, k, 2 * l, H->dVlu, H->dVpiv, S1Y1, (int64_t)kw, t, sy, sc, b0, xk);
       RC(hiopamd_linsolver_solve(K->nls, xk, 1));
-      const int MAX_ITER_REFIN = 3;
-      for(int it = 0;; ++it) {
-        double* xnew = (it & 1) ? xu1 : xu0;
-        double* cin = (it & 1) ? c0 : c1;    // (it > 0) the solver's answer for the previous residual
-        double* cout = (it & 1) ? c1 : c0;
-        hipLaunchKernelGGL(lowrank_mid_post_kernel, dim3((unsigned)((k + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, ctx->stream, k, K->N, (int64_t)k, sc, b0,
-                           it > 0 ? cin : xk, xsol, xnew, rk, cout, acc2, K->h_nrm_dev, it > 0 ? 1 : 0);
-        xsol = xnew;
+      const unsigned gpost = (unsigned)((k + kBlock / 64 - 1) / (kBlock / 64));
+      hipLaunchKernelGGL(lowrank_mid_post_kernel, dim3(gpost), dim3(kBlock), 0, ctx->stream, k, K->N, (int64_t)k, sc, b0, xk, xu0, xu0, rk, c0, acc2, K->h_nrm_dev, 0);
+      // The rest of the call is queued at once, on the expectation that this residual passes (it does unless N is badly conditioned):
+      // the J^T pass runs while the host waits for the norm, instead of after it.
+      RC(finish(xu0));
+      // ONE host round trip: the solver's status read-back (the error word of its dataflow solve) synchronises the stream, the norm has
+      // then arrived as well
+      auto wait_norm = [&](double* out) -> int {
         HIOPAMD_CHECK(hipGetLastError());
-        // ONE host round trip: the solver's status read-back (the error word of its dataflow solve) synchronises the stream, the norm
-        // written by the kernel above has then arrived as well
         int oks = 1;
         RC(hiopamd_linsolver_solve_status(K->nls, &oks));
         HIOPAMD_CHECK(hipStreamSynchronize(ctx->stream));   // (no-op behind the status read-back; the wait itself when the solve was stepwise)
         if(!oks) return HIOPAMD_ERR_SOLVE;
-        resid = K->h_nrm[0];
-        if(resid < 1e-8 || it >= MAX_ITER_REFIN) break;
-        RC(hiopamd_linsolver_solve(K->nls, cout, 1));   // cout holds r .* sc; the correction comes back in place and is read as `cin` next
+        *out = K->h_nrm[0];
+        return HIOPAMD_OK;
+      };
+      RC(wait_norm(&resid));
+      const int MAX_ITER_REFIN = 3;
+      if(!(resid < 1e-8)) {
+        // refinement (hiopKKTLinSys.cpp:1192-1330, up to three steps), then the end of the call once more: what the expectation above
+        // already applied to rx is taken back first (t still holds that dy)
+        RC(hiopamd_mat_trans_times_vec(ctx, k, n, K->Jcur, n, 1.0, rx, 1.0, t));
+        double* xsol = xu0;
+        for(int it = 1; it <= MAX_ITER_REFIN; ++it) {
+          double* cin = (it & 1) ? c0 : c1;    // the right-hand side r .* sc of this step, answered in place
+          double* cout = (it & 1) ? c1 : c0;
+          double* xnew = (it & 1) ? xu1 : xu0;
+          RC(hiopamd_linsolver_solve(K->nls, cin, 1));
+          hipLaunchKernelGGL(lowrank_mid_post_kernel, dim3(gpost), dim3(kBlock), 0, ctx->stream, k, K->N, (int64_t)k, sc, b0, cin, xsol, xnew, rk, cout, acc2, K->h_nrm_dev, 1);
+          xsol = xnew;
+          RC(wait_norm(&resid));
+          if(resid < 1e-8) break;
+        }
+        RC(finish(xsol));
       }
     } else {
-      RC(hiopamd_vec_copy(ctx, k, xsol, t));   // (the old path left the right-hand side in place for a singular N)
+      RC(hiopamd_vec_copy(ctx, k, xu0, t));   // (the old path left the right-hand side in place for a singular N)
+      RC(finish(xu0));
     }
     K->last_resid = resid;
-    //  (6) dy out, sy' = V^-1 (sy - S1Y1^T dy)
-    hipLaunchKernelGGL(lowrank_mid_tail_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, k, me, 2 * l, H->dVlu, H->dVpiv, S1Y1, (int64_t)kw, xsol, t, dyc, dyd, sy);
-    //  (7, 8) rx -= J^T dy and, per column, dx = DhInv (rx - [sigma S, Y]^T sy')
-    GemvtTail tail{H->St, H->Yt, l, n, sigma, sy, DhInv, dx};
-    RC(gemv_t_tail(ctx, k, n, K->Jcur, n, rx, -1.0, t, tail));
     HIOPAMD_CHECK(hipGetLastError());
     return HIOPAMD_OK;
   }

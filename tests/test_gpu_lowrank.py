@@ -139,6 +139,39 @@ def test_kkt_lowrank_solve_compressed(ctx, n, me, mi):
     Kg.close(); Hg.close()
 
 
+def test_kkt_lowrank_solve_compressed_takes_the_refinement_path(ctx):
+    """The solve of N dy = rhs is followed by the reference's residual loop (inf-norm 1e-8 ABSOLUTE, up to three refinement steps,
+    hiopKKTLinSys.cpp:1192-1330).  The device queues the end of solveCompressed before it knows the first residual and, when that
+    residual does not pass, takes back what it applied to rx, refines and repeats the end of the call.  Right-hand sides of 1e9 make
+    eps |N| |dy| exceed 1e-8, so the loop runs (and cannot succeed: the three steps are all taken).  The answer must still be the
+    oracle's, rx must come out as rx - J^T dy of the FINAL dy, and a second, well-scaled solve on the same object must be unaffected."""
+    import ctypes as C
+    from hiop_amd.kkt import KKTLinSysLowRank
+    n, me, mi = 3000, 20, 30
+    Ho, Hg, (Jc, Jd), r, _ = drive(ctx, n, me, mi, 6, 9, "sigma0", seed=77)
+    Dx = r.uniform(0.1, 2, n); Dd = r.uniform(0.5, 2, mi)
+    Ko = ho.KKTLinSysLowRank(Ho, me, mi)
+    Ko.update(Dx, Dd, Jc, Jd)
+    Kg = KKTLinSysLowRank(ctx, Hg)
+    Kg.update_diag(D(Dx), D(Dd), D(Jc), D(Jd))
+    ctx._L.hiopamd_kkt_lowrank_last_residual.restype = C.c_double
+    for scale, expect_refine in ((1e9, True), (1.0, False)):
+        rx, ryc, ryd = r.uniform(-1, 1, n), scale * r.uniform(-1, 1, me), scale * r.uniform(-1, 1, mi)
+        ok_o, dx_o, dyc_o, dyd_o = Ko.solve_compressed(rx.copy(), ryc, ryd)
+        rxd, dx, dyc, dyd = D(rx), D(np.zeros(n)), D(np.zeros(me)), D(np.zeros(mi))
+        torch.cuda.synchronize()
+        assert Kg.solve_compressed(rxd, D(ryc), D(ryd), dx, dyc, dyd); ctx.sync()
+        resid = ctx._L.hiopamd_kkt_lowrank_last_residual(Kg.h)
+        assert (resid >= 1e-8) == expect_refine, resid
+        dxg, dycg, dydg = dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy()
+        for a, b in ((dxg, dx_o), (dycg, dyc_o), (dydg, dyd_o)):
+            assert np.abs(a - b).max() / max(np.abs(b).max(), 1e-300) < 1e-7
+        # rx is left as rx - J^T dy (reference :1178), with the dy that was returned
+        want = rx - Jc.T @ dycg - Jd.T @ dydg
+        assert np.abs(rxd.cpu().numpy() - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+    Kg.close(); Hg.close()
+
+
 def test_posv_refine(ctx):
     import ctypes as C
     r = rng(5)
