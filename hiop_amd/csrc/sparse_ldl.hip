@@ -569,19 +569,24 @@ __global__ void sl_factor_level_kernel(int q0, const int* __restrict__ f_nc, con
   const int q = q0 + blockIdx.x;
   const int nc = f_nc[q], nr = f_nr[q], f = nc + nr;
   const int tid = threadIdx.x, nt = blockDim.x;
-  double* F = sl_lds;               // f rows of stride ldf (odd: conflict-free column walks)
-  double* lk = F + (size_t)ldf * ldf;   // multipliers of the current pivot
-  double* vk = lk + ldf;            // the unscaled column of the current pivot
-  for(int e = tid; e < f * ldf; e += nt) F[e] = 0.0;
+  // The front's LOWER TRIANGLE, packed by rows: entry (i, j), j <= i, at i (i + 1) / 2 + j.  (Rounds 4-5 kept the full f x f square at an
+  // odd pitch: 28 KB for the 58-row fronts of the banded n = 1e6 case, i.e. five fronts per CU — the leaf level, 32 768 fronts of ~15 us
+  // of dependent pivot steps each, took 26 rounds of resident workgroups.  Half the LDS is twice the fronts in flight.)
+  double* F = sl_lds;
+  double* lk = F + (size_t)ldf * (ldf + 1) / 2;   // multipliers of the current pivot
+  double* vk = lk + ldf;                          // the unscaled column of the current pivot
+#define SL_TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+  for(int e = tid; e < f * (f + 1) / 2; e += nt) F[e] = 0.0;
   __syncthreads();
   for(int64_t t = front_run[q] + tid; t < front_run[q + 1]; t += nt) {
     const int d = run_dest[t];
-    F[(d / f) * ldf + (d % f)] = sl_gather(srcs, run_ptr[t], run_ptr[t + 1], vals, upool);
+    const int di = d / f, dj = d % f;
+    F[(di >= dj) ? SL_TRI(di, dj) : SL_TRI(dj, di)] = sl_gather(srcs, run_ptr[t], run_ptr[t + 1], vals, upool);
   }
   __syncthreads();
   int nneg = 0, nzero = 0;
   for(int k = 0; k < nc; ++k) {
-    const double d = F[k * ldf + k];
+    const double d = F[SL_TRI(k, k)];
     const bool bad = !(fabs(d) >= 1e-14) || !isfinite(d);   // thresholds of the reference's dense solver class (hiopLinSolverSymDenseLapack.hpp:154-161)
     if(tid == 0) {
       nzero += bad ? 1 : 0;
@@ -589,7 +594,7 @@ __global__ void sl_factor_level_kernel(int q0, const int* __restrict__ f_nc, con
     }
     const double di = bad ? 0.0 : 1.0 / d;   // a zero pivot: the column is dropped (the verdict is "not factorisable" anyway)
     for(int i = k + 1 + tid; i < f; i += nt) {
-      const double v = F[i * ldf + k];
+      const double v = F[SL_TRI(i, k)];
       vk[i] = v;
       lk[i] = v * di;
     }
@@ -606,11 +611,11 @@ __global__ void sl_factor_level_kernel(int q0, const int* __restrict__ f_nc, con
       if(r0 < rgrp)
         for(int ii = r0; ii < m; ii += rgrp) {
           const double li = lk[k + 1 + ii];
-          double* Fr = F + (k + 1 + ii) * ldf + (k + 1);
+          double* Fr = F + SL_TRI(k + 1 + ii, k + 1);
           for(int jj = sub; jj <= ii; jj += tpr) Fr[jj] -= li * vk[k + 1 + jj];
         }
     }
-    for(int i = k + 1 + tid; i < f; i += nt) F[i * ldf + k] = lk[i];
+    for(int i = k + 1 + tid; i < f; i += nt) F[SL_TRI(i, k)] = lk[i];
     __syncthreads();
   }
   if(tid == 0 && (nneg || nzero)) {
@@ -623,12 +628,12 @@ __global__ void sl_factor_level_kernel(int q0, const int* __restrict__ f_nc, con
   double* L = lpool + f_lofs[q];
   for(int e = tid; e < f * nc; e += nt) {
     const int k = e / f, i = e % f;
-    L[e] = (i >= k) ? F[i * ldf + k] : 0.0;   // diagonal: d_k; below: L; above (inside the pivot block): unused
+    L[e] = (i >= k) ? F[SL_TRI(i, k)] : 0.0;   // diagonal: d_k; below: L; above (inside the pivot block): unused
   }
   double* U = upool + f_uofs[q];
   for(int e = tid; e < nr * nr; e += nt) {
     const int i = e / nr, j = e % nr;
-    U[e] = (j <= i) ? F[(nc + i) * ldf + (nc + j)] : 0.0;
+    U[e] = (j <= i) ? F[SL_TRI(nc + i, nc + j)] : 0.0;
   }
 }
 
@@ -919,9 +924,12 @@ int hiopamd_sparse_ldl_factorize(hiopamd_sparse_ldl* s, const double* vals, int*
     const int q0 = H.level_ptr[(size_t)l], cnt = H.level_ptr[(size_t)l + 1] - q0;
     if(cnt <= 0) continue;
     const int fmax = H.fmax_level[(size_t)l];
-    const int ldf = fmax | 1;
-    const size_t lds = sizeof(double) * ((size_t)ldf * ldf + 2 * (size_t)ldf);
-    const int threads = fmax <= 16 ? 64 : (fmax <= 48 ? 128 : 256);
+    const int ldf = fmax;   // (rows of the largest front of the level: the packed triangle has ldf (ldf + 1) / 2 entries)
+    const size_t lds = sizeof(double) * ((size_t)ldf * (ldf + 1) / 2 + 2 * (size_t)ldf);
+#ifndef HIOPAMD_SL_T128
+#define HIOPAMD_SL_T128 48
+#endif
+    const int threads = fmax <= 16 ? 64 : (fmax <= HIOPAMD_SL_T128 ? 128 : 256);
     if(lds > 64 * 1024) HIOPAMD_CHECK(hipFuncSetAttribute((const void*)sl_factor_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(sl_factor_level_kernel, dim3((unsigned)cnt), dim3(threads), lds, ctx->stream, q0, s->f_nc, s->f_nr, s->f_lofs, s->f_uofs,
                        s->mat.run_dest, s->mat.run_ptr, s->mat.src, s->mat.front_run, vals, s->upool, s->lpool, s->counts, ldf);
