@@ -372,6 +372,20 @@ def sparse_condensed_bench(ctx, a, n=1_000_000, pattern="sparse_ex2"):
                     "reference tree (SURVEY 8c); its role is taken by the bordered-diagonal factorisation for arrowhead patterns, by the general sparse "
                     "LDL^T (nested dissection + multifrontal + dense root, csrc/sparse_ldl.hip) for other patterns, and by PCG only when "
                     "that solver's dense root would exceed its limit — a measured number, not a parity claim")
+    if kind == "sparse_ldl":
+        # what bounds it: the L panels are written once per factorisation and read twice per solve (forward, backward sweep) — HBM bytes —
+        # but the kernels that do it are one launch per level of the supernode tree (16 levels: 16 + 3 x 32 launches per step) with a
+        # dependent chain of pivot steps inside every front: the entry is latency / launch bound, and the fraction says so
+        i8 = (C.c_int64 * 8)()
+        if Ls.hiopamd_kkt_sparse_condensed_ldl_info(K.h, i8) == 0:
+            nnzL = int(i8[4])
+            bytes_step = 8.0 * nnzL * (1 + 2 * a.solves)
+            out["roofline"] = dict(bound="hbm", kernel="sl_factor_level / sl_fwd_level / sl_bwd_level (one launch per tree level)",
+                                   achieved=bytes_step / (dt / a.steps) / 1e9, peak=8000.0, unit="GB/s",
+                                   frac=bytes_step / (dt / a.steps) / 8e12, algorithmic_bytes_per_step=bytes_step,
+                                   nnz_L=nnzL, supernodes=int(i8[0]), levels=int(i8[2]), root_order=int(i8[3]), traffic=None,
+                                   note="algorithmic bytes = 8 nnz(L) (1 write + 2 reads per solve); whole step time, launches and host "
+                                        "round trip of the inertia included")
     K.close()
     return out
 

@@ -359,6 +359,13 @@ int hiopamd_kkt_sparse_condensed_dims(const hiopamd_kkt_sparse_condensed* k, int
 }
 // which inner solver the object runs: 0 dense LDL^T of the expanded matrix, 1 bordered-diagonal direct solver, 2 PCG + Jacobi,
 // 3 general sparse LDL^T (nested dissection + multifrontal + dense root)
+int hiopamd_kkt_sparse_condensed_ldl_info(const hiopamd_kkt_sparse_condensed* k, int64_t* info8_host)
+{
+  if(!k || !info8_host) return HIOPAMD_ERR_ARG;
+  if(!k->sldl) return HIOPAMD_ERR_STATE;
+  return hiopamd_sparse_ldl_info(k->sldl, info8_host);
+}
+
 int hiopamd_kkt_sparse_condensed_inner_kind(const hiopamd_kkt_sparse_condensed* k)
 {
   if(!k) return HIOPAMD_ERR_ARG;

@@ -2702,252 +2702,8 @@ static int ldlt_factor_impl(hiopamd_ctx* ctx, int N, double* A, int64_t lda, dou
   // The host waits for the info words' read-back, NOT for the stream: the kernels above (inverted diagonal blocks, 512-block products: ~0.14 ms)
   // only feed the next solve, which is queued behind them on the same stream — meanwhile the caller has its inertia and goes on enqueueing.
   HIOPAMD_CHECK(hipEventSynchronize(ctx->ev_info));
-  if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
-    const DfPlan& P = df->plan;
-    std::vector<unsigned> ts((size_t)8 * (P.nsp + 1));
-    const int64_t off_ts = P.off_ver + (int64_t)P.nt * P.nt;
-    (void)hipMemcpy(ts.data(), df->flags + off_ts, sizeof(unsigned) * ts.size(), hipMemcpyDeviceToHost);
-    const unsigned t0 = 0xffffffffu - ts[0];
-    std::fprintf(stderr, "[hiop_amd] df stamps (us since F(0) of panel 0): panel | F0 start, F3 done | last head T | TR first start, last done | UP first start, last done\n");
-    for(int j = 0; j < P.nsp; ++j) {
-      auto us = [&](int k) { const unsigned v = ts[(size_t)8 * j + k]; return v == 0 ? -1.0 : ((k & 1) ? (double)(v - t0) : (double)((0xffffffffu - v) - t0)) * 0.01; };
-      std::fprintf(stderr, "  %2d | %8.1f %8.1f | %8.1f | %8.1f %8.1f | %8.1f %8.1f\n", j, us(0), us(1), us(3), us(4), us(5), us(6), us(7));
-    }
-  }
-  if(use_df && std::getenv("HIOPAMD_DF_STAMPS")) {
-    const DfPlan& P = df->plan;
-    unsigned ph[48];
-    (void)hipMemcpy(ph, df->flags + P.off_ver + (int64_t)P.nt * P.nt + 8 * (int64_t)(P.nsp + 1), sizeof(ph), hipMemcpyDeviceToHost);
-    const double nup = ph[7] ? ph[7] : 1, ntr = ph[8] ? ph[8] : 1, ntask = nup + ntr;
-    std::fprintf(stderr,
-                 "[hiop_amd] wide kernel phases, mean us per task: ticket+decode %.2f | TR(%u): wait %.2f body %.2f publish %.2f | "
-                 "UP(%u): wait %.2f body %.2f [prologue %.2f stages %.2f epilogue %.2f] publish %.2f\n",
-                 ph[0] * 0.01 / ntask, ph[8], ph[1] * 0.01 / ntr, ph[2] * 0.01 / ntr, ph[3] * 0.01 / ntr, ph[7], ph[4] * 0.01 / nup,
-                 ph[5] * 0.01 / nup, ph[9] * 0.01 / nup, ph[10] * 0.01 / nup, (ph[5] - ph[9] - ph[10]) * 0.01 / nup, ph[6] * 0.01 / nup);
-    if(ph[11] && ph[10]) std::fprintf(stderr, "[hiop_amd]   shader clock inside the stage loops: %.3f GHz\n", (double)ph[11] * 256.0 / ((double)ph[10] * 10.0));
-    if(ph[15])
-      std::fprintf(stderr, "[hiop_amd] spine steps (%u), mean us: F + publish %.2f | wait for the older updates of (p,p+1), (p+1,p+1) %.2f | T + U %.2f\n",
-                   ph[15], ph[12] * 0.01 / ph[15], ph[13] * 0.01 / ph[15], ph[14] * 0.01 / ph[15]);
-    if(ph[15])
-      std::fprintf(stderr, "[hiop_amd]   spine wait in the second half of the super-panels, mean us by pivot p = 0..3: %.1f %.1f %.1f %.1f\n",
-                   ph[18] * 0.01 / (P.nchain - P.nchain / 2), ph[19] * 0.01 / (P.nchain - P.nchain / 2),
-                   ph[20] * 0.01 / (P.nchain - P.nchain / 2), ph[21] * 0.01 / (P.nchain - P.nchain / 2));
-    if(ph[15])
-      std::fprintf(stderr, "[hiop_amd]   at p = 3 (second half): after F's publish, H tile (3,4) ready after %.1f us, then next-diagonal tile (4,4) after another %.1f us\n",
-                   ph[22] * 0.01 / (P.nchain - P.nchain / 2), ph[23] * 0.01 / (P.nchain - P.nchain / 2));
-    if(ph[15]) {
-      const double nl = P.nchain - P.nchain / 2;
-      std::fprintf(stderr, "[hiop_amd]   first H column, mean us since F(0) start (second half): F(p) published at %.0f %.0f %.0f %.0f\n", ph[40] * 0.01 / nl,
-                   ph[41] * 0.01 / nl, ph[42] * 0.01 / nl, ph[43] * 0.01 / nl);
-      for(int r = 0; r < 4; ++r)
-        std::fprintf(stderr, "[hiop_amd]     tile (%d,4): updates by pivots 0,1,2 published at %.0f %.0f %.0f | T(%d,4) published at %.0f\n", r,
-                     ph[24 + 4 * r] * 0.01 / nl, ph[25 + 4 * r] * 0.01 / nl, ph[26 + 4 * r] * 0.01 / nl, r, ph[27 + 4 * r] * 0.01 / nl);
-    }
-    if(ph[15])
-      std::fprintf(stderr, "[hiop_amd]   inside F: set-up %.2f | 64x64 factor in LDS %.2f (of which the four 16x16 sub-block factors %.2f) | emit + rest %.2f\n",
-                   ph[16] * 0.01 / 127.0, ph[17] * 0.01 / 127.0, ph[44] * 0.01 / 127.0, (ph[12] - ph[16] - ph[17]) * 0.01 / ph[15]);
-  }
-  if(use_df && std::getenv("HIOPAMD_DF_CHECK") && std::atoi(std::getenv("HIOPAMD_DF_CHECK")) != 0) {
-    const DfPlan& P = df->plan;
-    std::vector<unsigned> run(2 * P.wtasks.size());
-    (void)hipMemcpy(run.data(), df->flags + P.off_run, sizeof(unsigned) * run.size(), hipMemcpyDeviceToHost);
-    int bad = 0, jmax = 0;
-    const size_t nt_ = P.wtasks.size();
-    for(size_t t = 0; t < nt_; ++t)
-      if(run[2 * t] != 0u) jmax = std::max(jmax, P.wtasks[t].y);
-    for(size_t t = 0; t < nt_; ++t) {
-      const unsigned h = run[2 * t], c = run[2 * t + 1];
-      const bool early_q = P.wtasks[t].y < jmax - 1;
-      if((h > 1u || c > 1u || (!dfw[DF_ABORT] && (h != 1u || c != 1u)) || (dfw[DF_ABORT] && early_q && (h != 1u || c != 1u))) && bad++ < 24)
-        std::fprintf(stderr, "[hiop_amd] HIOPAMD_DF_CHECK: task %zu (kind %d, super-panel %d, %d %d): handed out %u times, completed %u times\n", t, P.wtasks[t].x, P.wtasks[t].y,
-                     P.wtasks[t].z, P.wtasks[t].w, h, c);
-    }
-    if(bad) std::fprintf(stderr, "[hiop_amd] HIOPAMD_DF_CHECK: %d of %zu tasks not handed out / completed exactly once%s\n", bad, nt_, dfw[DF_ABORT] ? " (aborted run; later queues not listed)" : "");
-  }
-  if(dfw[DF_ABORT]) {
-    std::fprintf(stderr,
-                 "[hiop_amd] dataflow LDL^T: a bounded wait timed out, factorisation aborted.  waiter %u (1 = TR, 2 = UP, 100+r = "
-                 "chain role r) args %u %u %u %u, condition slot %u: flag word %u is %u, needs >= %u; tickets taken %u\n",
-                 dfw[2], dfw[3], dfw[4], dfw[5], dfw[6], dfw[7], dfw[10], dfw[9], dfw[8], dfw[DF_TICKET]);
-    std::fprintf(stderr, "[hiop_amd]   that wait had lasted %.3f ms on the waiter's clock\n", dfw[11] * 160e-6);
-    static const bool df_debug = std::getenv("HIOPAMD_DF_DEBUG") && std::atoi(std::getenv("HIOPAMD_DF_DEBUG")) != 0;
-    if(df_debug) {   // what every workgroup of the wide kernel held when the kernels gave up
-      const DfPlan& P = df->plan;
-      std::vector<unsigned> wg(2 * 512);
-      (void)hipMemcpy(wg.data(), df->flags + P.off_snap, sizeof(unsigned) * wg.size(), hipMemcpyDeviceToHost);   // the state AT the time-out
-      int shown = 0;
-      for(int r = 0; r < 16; ++r) {
-        const unsigned v = wg[2 * (496 + r)];
-        std::fprintf(stderr, "[hiop_amd]   chain role %d: last task kind %u (1 F, 2 T, 3 U, 4 S, 5 R, 6 C) super-panel %u fields %u %u %u\n", r, v >> 28, (v >> 16) & 255u,
-                     (v >> 8) & 15u, (v >> 4) & 15u, v & 15u);
-      }
-      {   // did a workgroup finish a task on another CU than the one it took it on?  (final state: after the kernels ended)
-        std::vector<unsigned> wh(2 * 512);
-        (void)hipMemcpy(wh.data(), df->flags + P.off_where, sizeof(unsigned) * wh.size(), hipMemcpyDeviceToHost);
-        int moved = 0;
-        for(int w = 0; w < 480; ++w)
-          if((wh[2 * w] & 0x80000000u) && (wh[2 * w + 1] & 0x80000000u) && wh[2 * w] != wh[2 * w + 1] && moved++ < 8)
-            std::fprintf(stderr, "[hiop_amd]   workgroup %d took its last task on (xcc %u, se %u, cu %u) and published it on (xcc %u, se %u, cu %u)\n", w, (wh[2 * w] >> 6) & 7u,
-                         (wh[2 * w] >> 4) & 3u, wh[2 * w] & 15u, (wh[2 * w + 1] >> 6) & 7u, (wh[2 * w + 1] >> 4) & 3u, wh[2 * w + 1] & 15u);
-        std::fprintf(stderr, "[hiop_amd]   %d workgroups published their last task on another CU than they took it on\n", moved);
-      }
-      int looking = 0, left = 0, never = 0, between = 0;
-      for(int w = 0; w < 480; ++w) {
-        if(wg[2 * w] == 0u) ++never;
-        if(wg[2 * w] == 0xF0000000u) ++between;
-      }
-      std::fprintf(stderr, "[hiop_amd]   wide kernel: %d of 480 workgroups never started, %d started and nothing else\n", never, between);
-      for(int w = 0; w < 496; ++w) {
-        if((wg[2 * w] >> 24) == 0xF1u) ++looking;
-        if((wg[2 * w] >> 24) == 0xF2u && ((wg[2 * w] >> 16) & 255u) != 1u && ((wg[2 * w] >> 16) & 255u) != 2u) ++left;
-      }
-      std::fprintf(stderr, "[hiop_amd]   wide kernel: %d workgroups were looking for a task, %d had left (queues exhausted / retired / aborted)\n", looking, left);
-      // substitution tasks one by one (others wait for them), update tasks as a histogram by (kind, super-panel, phase)
-      int hist[5][256][6] = {};
-      std::vector<unsigned> fl;
-      std::map<std::string, int> missing;   // unsatisfied input -> number of waiting tasks
-      for(int w = 0; w < 496; ++w) {
-        const unsigned v = wg[2 * w];
-        if(v == 0u || (v >> 24) == 0xF1u || (v >> 24) == 0xF0u) continue;
-        if((v >> 24) == 0xF3u) {
-          std::fprintf(stderr, "[hiop_amd]   workgroup %d finished a task and did not get to the next selection\n", w);
-          continue;
-        }
-        if((v >> 24) == 0xF2u) {
-          const unsigned k = (v >> 16) & 255u;
-          if(k == 1u || k == 2u)
-            std::fprintf(stderr, "[hiop_amd]   workgroup %d took a task (kind %u, super-panel %u) and did not get past the barriers behind the selection\n", w, k, v & 0xffffu);
-          continue;
-        }
-        const unsigned kind = v >> 28, ph = (v >> 24) & 15u, jj = (v >> 16) & 255u;
-        if(ph == 1u) {   // which of its inputs is this waiting task missing?  (the conditions of ldlt_wide_body.inc)
-          if(fl.empty()) {
-            fl.resize((size_t)P.nflags);
-            (void)hipMemcpy(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost);
-          }
-          // (the state words are a snapshot taken while the workgroups run: the second word of a workgroup that has just taken a task may
-          //  still be the previous task's stage marker — every index is range-checked, an inconsistent pair is skipped)
-          auto in_t = [&](int t) { return t >= 0 && t < P.nt; };
-          auto verw = [&](int I, int J) { return (in_t(I) && in_t(J)) ? fl[(size_t)(P.off_ver + (int64_t)I * P.nt + J)] : 0xffffffffu; };
-          auto trw = [&](int jq, int B) { return (jq >= 0 && jq < P.nsp && in_t(B)) ? fl[(size_t)(P.off_tr + (int64_t)jq * P.nt + B)] : 0xffffffffu; };
-          auto grp = [&](int B) { const int rem = N - 128 * B; return (unsigned)(rem >= 128 ? 8 : (rem + 15) / 16); };
-          auto miss = [&](const char* what, int x, int y, unsigned is, unsigned needs) {
-            if(is < needs) {
-              char key[96];
-              std::snprintf(key, sizeof(key), "%s[%d][%d] is %u, needed >= %u", what, x, y, is, needs);
-              missing[key] += 1;
-            }
-          };
-          const int j = (int)jj;
-          if(kind == 1u) {
-            const int J = (int)(v & 0xffffu) / 128;
-            miss("ver", 2 * j, J, verw(2 * j, J), (unsigned)j);
-            miss("ver", 2 * j + 1, J, verw(2 * j + 1, J), (unsigned)j);
-          } else {
-            const int I = (int)(v & 0xffffu), J = (int)(wg[2 * w + 1] & 0xffffu);   // (low half: tile column, also inside a stage marker)
-            const bool fusedt = kind == 4u;
-            const int jb = fusedt ? j - 1 : j;
-            miss("ver", I, J, verw(I, J), (unsigned)jb);
-            if(fusedt) {
-              miss("tr", jb, I, trw(jb, I), grp(I));
-              miss("tr", jb, J, trw(jb, J), grp(J));
-              miss("tr", j, I, trw(j, I), grp(I));
-              miss("tr", j, J, trw(j, J), grp(J));
-            } else {
-              if(I < 2 * j + 4) miss("hdone", j, 0, (j >= 0 && j <= P.nsp) ? fl[(size_t)(P.off_chain + (int64_t)j * DF_CH + DF_HDONE)] : 0xffffffffu, 16u);
-              else miss("tr", j, I, trw(j, I), grp(I));
-              miss("tr", j, J, trw(j, J), grp(J));
-            }
-          }
-        }
-        if(kind == 1u)
-          std::fprintf(stderr, "[hiop_amd]   workgroup %d holds substitution task of super-panel %u, columns from %u, list index %d (-1: early), phase %u (1 waits for its inputs, 2 running, 3 draining its stores, 4 publishing)\n", w, jj,
-                       v & 0xffffu, (int)wg[2 * w + 1], ph);
-        else if(kind < 5u && ph < 6u) {
-          hist[kind][jj][ph] += 1;
-          if(ph == 2u) {   // in the tile loop: where?
-            const unsigned w1 = wg[2 * w + 1];
-            if(w1 & 0x80000000u) {
-              unsigned wh0 = 0u;   // where it took that task (final state of the word: a workgroup does not take another one while it is in this one)
-              (void)hipMemcpy(&wh0, df->flags + P.off_where + 2 * (int64_t)w, sizeof(unsigned), hipMemcpyDeviceToHost);
-              std::fprintf(stderr, "[hiop_amd]   workgroup %d (xcc %u, se %u, cu %u): update task kind %u of queue %u, tile (%u, %u), in the tile loop at stage %u (100 prologue, 101 epilogue)\n", w,
-                           (wh0 >> 6) & 7u, (wh0 >> 4) & 3u, wh0 & 15u, kind, jj, v & 0xffffu, w1 & 0xffffu, (w1 >> 16) & 0x7fffu);
-            }
-          }
-        }
-      }
-      if(fl.empty()) {
-        fl.resize((size_t)P.nflags);
-        (void)hipMemcpy(fl.data(), df->flags, sizeof(unsigned) * fl.size(), hipMemcpyDeviceToHost);
-      }
-      {
-        int shown_m = 0;
-        for(const auto& kv : missing)
-          if(shown_m++ < 80) std::fprintf(stderr, "[hiop_amd]   %3d waiting tasks miss %s\n", kv.second, kv.first.c_str());
-      }
-      {   // the shadow copies against the real words
-        int nd = 0;
-        for(int jq = 0; jq < P.nsp; ++jq)
-          for(int B = 0; B < P.nt; ++B) {
-            const unsigned r = fl[(size_t)(P.off_tr + (int64_t)jq * P.nt + B)], sh = fl[(size_t)(P.off_shadow + (int64_t)jq * P.nt + B)];
-            if(r != sh && nd++ < 12) std::fprintf(stderr, "[hiop_amd]   substitution counter tr[%d][%d] = %u, its shadow copy = %u\n", jq, B, r, sh);
-          }
-        for(int I = 0; I < P.nt; ++I)
-          for(int B = 0; B < P.nt; ++B) {
-            const unsigned r = fl[(size_t)(P.off_ver + (int64_t)I * P.nt + B)], sh = fl[(size_t)(P.off_shadow + (int64_t)P.nsp * P.nt + (int64_t)I * P.nt + B)];
-            if(r != sh && nd++ < 24) std::fprintf(stderr, "[hiop_amd]   version word ver[%d][%d] = %u, its shadow copy = %u\n", I, B, r, sh);
-          }
-        std::fprintf(stderr, "[hiop_amd]   %d flag words differ from their shadow copies\n", nd);
-        // every task of the lists against the number of times a task with ITS (super-panel, tile) published
-        const int64_t ex_tr = P.off_shadow + (int64_t)P.nsp * P.nt + 2 * (int64_t)P.nt * P.nt, ex_up = ex_tr + (int64_t)P.nsp * 256;
-        int ndup = 0, nnever = 0;
-        for(size_t t = 0; t < P.wtasks.size(); ++t) {
-          const int4 q = P.wtasks[t];
-          const unsigned ex = q.x == DF_TR ? fl[(size_t)(ex_tr + (int64_t)q.y * 256 + q.z / DF_TRW)] : fl[(size_t)(ex_up + ((int64_t)q.y * P.nt + q.z) * P.nt + q.w)];
-          if(ex > 1u && ndup++ < 16) std::fprintf(stderr, "[hiop_amd]   task %zu (kind %d, super-panel %d, %d %d) published %u times\n", t, q.x, q.y, q.z, q.w, ex);
-          if(ex == 0u) ++nnever;
-        }
-        std::fprintf(stderr, "[hiop_amd]   %d tasks published more than once, %d not (yet) at all\n", ndup, nnever);
-        // for every missing input: which tasks write that word, and how often each of them has published
-        int shown_r = 0;
-        for(const auto& kv : missing) {
-          if(shown_r++ >= 12) break;
-          int x = 0, y = 0;
-          std::string line;
-          if(std::sscanf(kv.first.c_str(), "ver[%d][%d]", &x, &y) == 2) {
-            for(size_t t = 0; t < P.wtasks.size(); ++t) {
-              const int4 q = P.wtasks[t];
-              if(q.x != DF_TR && q.z == x && q.w == y) {
-                char buf[64];
-                std::snprintf(buf, sizeof(buf), " (kind %d, queue %d): %u", q.x, q.y, fl[(size_t)(ex_up + ((int64_t)q.y * P.nt + q.z) * P.nt + q.w)]);
-                line += buf;
-              }
-            }
-          } else if(std::sscanf(kv.first.c_str(), "tr[%d][%d]", &x, &y) == 2) {
-            for(int c = 128 * y; c < 128 * y + 128; c += DF_TRW) {
-              char buf[64];
-              std::snprintf(buf, sizeof(buf), " (columns %d): %u", c, fl[(size_t)(ex_tr + (int64_t)x * 256 + c / DF_TRW)]);
-              line += buf;
-            }
-          }
-          if(!line.empty()) std::fprintf(stderr, "[hiop_amd]   writers of %s and their publications:%s\n", kv.first.substr(0, kv.first.find(" is")).c_str(), line.c_str());
-        }
-      }
-      for(int jq = 0, shown_q = 0; jq < P.nwide && shown_q < 10; ++jq) {   // super-panels whose update is not complete although its tickets are out
-        const unsigned* cq = fl.data() + P.off_chain + (int64_t)jq * DF_CH;
-        if(cq[DF_UPQ] == 0u || cq[DF_UPDONE] >= P.upcnt[jq]) continue;
-        std::fprintf(stderr, "[hiop_amd]   super-panel %d: update tasks done %u of %u | tickets: substitution %u of %d, update %u of %d | chain cdone %u hdone %u\n", jq, cq[DF_UPDONE],
-                     P.upcnt[jq], cq[DF_TRQ], P.wq[jq].y, cq[DF_UPQ], P.wq[jq].w, cq[DF_CDONE], cq[DF_HDONE]);
-        ++shown_q;
-      }
-      for(int k = 2; k < 5; ++k)
-        for(int jj = 0; jj < 256; ++jj)
-          if(hist[k][jj][1] || hist[k][jj][2] || hist[k][jj][3] || hist[k][jj][4])
-            std::fprintf(stderr, "[hiop_amd]   update tasks of kind %d (2 UP, 3 UPH, 4 UP2), queue %d: %d wait for their inputs, %d in the tile loop, %d draining their stores, %d publishing\n", k, jj,
-                         hist[k][jj][1], hist[k][jj][2], hist[k][jj][3], hist[k][jj][4]);
-    }
-    return HIOPAMD_ERR_TIMEOUT;
-  }
+  // (profiling time lines, the HIOPAMD_DF_CHECK verification and the diagnostics + HIOPAMD_ERR_TIMEOUT return of an expired wait)
+#include "ldlt_df_report.inc"
   if(timed) prof->collect();
   if(inertia3_host) {
     inertia3_host[0] = h[1];

@@ -483,6 +483,9 @@ int hiopamd_kkt_sparse_condensed_dims(const hiopamd_kkt_sparse_condensed* k, int
  * 3 general sparse LDL^T (hiopamd_sparse_ldl: nested dissection + multifrontal + dense root), 2 PCG + Jacobi (only when the sparse LDL^T's
  * dense root would exceed its limit) */
 int hiopamd_kkt_sparse_condensed_inner_kind(const hiopamd_kkt_sparse_condensed* k);
+/* the analysis of the general sparse LDL^T when that is the inner solver (hiopamd_sparse_ldl_info: supernodes, fronts, levels, root order,
+ * nnz(L), 0, 0, 0); HIOPAMD_ERR_STATE for the other inner solvers */
+int hiopamd_kkt_sparse_condensed_ldl_info(const hiopamd_kkt_sparse_condensed* k, int64_t* info8_host);
 hiopamd_csr_condensed* hiopamd_kkt_sparse_condensed_matrix(hiopamd_kkt_sparse_condensed* k);
 double* hiopamd_kkt_sparse_condensed_Hd(hiopamd_kkt_sparse_condensed* k);
 /* y = beta y + alpha Hess x ; y = beta y + alpha Jd x ; y = beta y + alpha Jd^T x  on the values of the last set_values */
