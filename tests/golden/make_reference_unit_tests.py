@@ -326,6 +326,82 @@ case("mat_overwriteUpperTriangleWithLower", f"{MD}:1169", {"A": Mx(M_, M_, zero,
 case("mat_overwriteLowerTriangleWithUpper", f"{MD}:1189", {"A": Mx(M_, M_, zero, rowidx)},
      {"A": Mx(M_, M_, zero, [(i, j, float(j if j < i else i)) for i in range(M_) for j in range(M_)])})
 
+# ---- sparse triplet, the assembly surface (matrixTestsSparse.hpp; driver arguments of tests/testMatrixSparse.cpp:150-215) ----------
+# test matrices: initializeMatrix (matrixTestsSparseTriplet.cpp:303-330): `epr` entries per row at columns 0, n/epr, 2n/epr, ..., the
+# last one in column n - 1
+def pattern(m, n, epr, val):
+    iR, jC = [], []
+    for r_ in range(m):
+        for e_ in range(epr - 1):
+            iR.append(r_); jC.append(e_ * (n // epr))
+        iR.append(r_); jC.append(n - 1)
+    return {"m": m, "n": n, "iRow": iR, "jCol": jC, "val": [val] * len(iR)}
+
+
+def image_rule(A, nnz_st, nnz_cp, A_val, B_entries, B_val):
+    """The expected dense copy as the reference's tests state it (e.g. :1100-1125): an entry that is both in the part of A that was not
+    replaced and among the new entries shows their sum, one that is only among the new entries the new value, one that is only in A
+    A's value, everything else zero."""
+    kept = set(zip(A["iRow"][:nnz_st], A["jCol"][:nnz_st])) | set(zip(A["iRow"][nnz_st + nnz_cp:], A["jCol"][nnz_st + nnz_cp:]))
+    out = {}
+    for ij in kept | set(B_entries):
+        in_kept, in_B = ij in kept, ij in B_entries
+        out[ij] = (B_val + A_val) if (in_kept and in_B) else (B_val if in_B else A_val)
+    return [(i, j, v) for (i, j), v in sorted(out.items())]
+
+
+mxn = pattern(sm, sn, 5, one)                      # 5 x 50
+m2xn = pattern(2 * sm, sn, 5, two)                 # 10 x 50
+n4 = 2 * sm + sn                                   # 60
+nnz1, nnz4 = sm * 5, n4 * 5
+# copyRowsFrom (:939): row i of A = row 2 i of B; A = 1, B = 2 -> every value of A is 2, its pattern is unchanged (the rows share it)
+case("sp_copyRowsFrom", f"{MS}:939", {"A": mxn, "B": m2xn, "select": [2 * i for i in range(sm)]},
+     {"val": V(two, n=nnz1), "iRow": mxn["iRow"], "jCol": mxn["jCol"], "nnz": nnz1})
+# copyRowsBlockFrom (:1009; driver :179-180): row 0 of the source becomes row M - 1 of the destination at nnz position nnz - 5
+case("sp_copyRowsBlockFrom", f"{MS}:1009", {"dest": dict(m2xn, val=[half] * (2 * nnz1)), "src": mxn, "src_row_st": 0, "n_rows": 1,
+                                             "dest_row_st": sm - 1, "dest_nnz_st": nnz1 - 5},
+     {"val": VR(half, [(nnz1 - 5, nnz1, one)], n=2 * nnz1)})
+case("sp_copyRowsBlockFrom", f"{MS}:1009", {"dest": dict(m2xn, val=[half] * (2 * nnz1)), "src": pattern(sm, sn, 5, one) | {"iRow": [], "jCol": [], "val": []},
+                                             "src_row_st": 0, "n_rows": 1, "dest_row_st": sm - 1, "dest_nnz_st": nnz1},
+     {"val": V(half, n=2 * nnz1)})
+# copySubmatrixFrom / Trans (:1070, :1147; driver :188-193): B = the 5 x 50 matrix (value 2) into the 60 x 60 one (value 1) at (M, 2M),
+# written over the last nnz(B) entries
+A4 = pattern(n4, n4, 5, one)
+Bsub = dict(mxn, val=[two] * nnz1)
+Bent = {(sm + i, 2 * sm + j) for i, j in zip(Bsub["iRow"], Bsub["jCol"])}
+case("sp_copySubmatrixFrom", f"{MS}:1070", {"A": A4, "B": Bsub, "row_st": sm, "col_st": 2 * sm, "nnz_st": nnz4 - nnz1, "trans": 0},
+     {"W": Mx(n4, n4, zero, image_rule(A4, nnz4 - nnz1, nnz1, one, Bent, two))})
+BentT = {(sm + j, 2 * sm + i) for i, j in zip(Bsub["iRow"], Bsub["jCol"])}
+case("sp_copySubmatrixFrom", f"{MS}:1147", {"A": A4, "B": Bsub, "row_st": sm, "col_st": 2 * sm, "nnz_st": nnz4 - nnz1, "trans": 1},
+     {"W": Mx(n4, n4, zero, image_rule(A4, nnz4 - nnz1, nnz1, one, BentT, two))})
+# copyDiagMatrixToSubblock (:1256; driver :201): 2 I of order nnz(B) = 25 at (M, 2M) over the entries [nnz4 - 2 nnz, nnz4 - nnz); A = 1/2
+A4h = pattern(n4, n4, 5, half)
+Dent = {(sm + e, 2 * sm + e) for e in range(nnz1)}
+case("sp_copyDiagMatrixToSubblock", f"{MS}:1256", {"A": A4h, "src_val": two, "row_st": sm, "col_st": 2 * sm, "nnz_st": nnz4 - 2 * nnz1, "nnz_to_copy": nnz1},
+     {"W": Mx(n4, n4, zero, image_rule(A4h, nnz4 - 2 * nnz1, nnz1, half, Dent, two))})
+# ..._w_pattern (:1327; driver :205): D = 2 (length N = 50), the LAST M entries of the pattern selected: M diagonal entries
+patt = V(zero, [(sn - 1 - i, one) for i in range(sm)], n=sn)
+Dent5 = {(sm + e, 2 * sm + e) for e in range(sm)}
+case("sp_copyDiagMatrixToSubblock_w_pattern", f"{MS}:1327",
+     {"A": A4h, "D": V(two, n=sn), "pattern": patt, "row_st": sm, "col_st": 2 * sm, "nnz_st": nnz4 - 2 * nnz1, "nnz_to_copy": sm},
+     {"W": Mx(n4, n4, zero, image_rule(A4h, nnz4 - 2 * nnz1, sm, half, Dent5, two))})
+# setSubmatrixToConstantDiag_w_colpattern / _rowpattern (:1408, :1492; driver :209-210): entry q of the pattern (q = N - 5 .. N - 1 set)
+# gives (row_st + q, col_st + found) / (row_st + found, col_st + q)
+colent = {(sm + (sn - sm + f), 2 * sm + f) for f in range(sm)}
+rowent = {(sm + f, 2 * sm + (sn - sm + f)) for f in range(sm)}
+case("sp_setSubmatrixToConstantDiag_w_pattern", f"{MS}:1408",
+     {"A": A4h, "scalar": two, "pattern": patt, "row_st": sm, "col_st": 2 * sm, "nnz_st": nnz4 - 2 * nnz1, "nnz_to_copy": sm, "rowpattern": 0},
+     {"W": Mx(n4, n4, zero, image_rule(A4h, nnz4 - 2 * nnz1, sm, half, colent, two))})
+case("sp_setSubmatrixToConstantDiag_w_pattern", f"{MS}:1492",
+     {"A": A4h, "scalar": two, "pattern": patt, "row_st": sm, "col_st": 2 * sm, "nnz_st": nnz4 - 2 * nnz1, "nnz_to_copy": sm, "rowpattern": 1},
+     {"W": Mx(n4, n4, zero, image_rule(A4h, nnz4 - 2 * nnz1, sm, half, rowent, two))})
+# transAddToSymDenseMatrixUpperTriangle (:846; driver :139): W (100 x 100) = 1, A (5 x 50) = 1/2, alpha = 1/2 at (0, 100 - 5):
+# W[j][95 + i] += alpha A[i][j] for the entries of A (all inside the upper triangle)
+Wn = sn + 10 * sm
+case("sp_transAddToSymDenseMatrixUpperTriangle", f"{MS}:846",
+     {"A": dict(mxn, val=[half] * nnz1), "row_st": 0, "col_st": Wn - sm, "alpha": half, "W": Mx(Wn, Wn, one)},
+     {"W": Mx(Wn, Wn, one, [(j, Wn - sm + i, one + half * half) for i, j in zip(mxn["iRow"], mxn["jCol"])])})
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_unit_tests.json")
 with open(out, "w") as f:
     json.dump({"source": "LLNL/hiop v1.1.0 tests/LinAlg (transcribed constants and expected values)", "cases": cases}, f, indent=0)

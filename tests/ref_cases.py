@@ -57,10 +57,99 @@ def check(case, out):
             assert close(out[k], e), (case["op"], case["ref"], k, out[k], e)
         elif k == "y_first4":
             assert close(out["y"][:4], e), (case["op"], case["ref"], out["y"][:4], e)
+        elif isinstance(e, list):
+            assert np.array_equal(np.asarray(out[k]), np.asarray(e)), (case["op"], case["ref"], k)
         elif isinstance(e, dict) and "m" in e:
             assert close(out[k], mat(e)), (case["op"], case["ref"], k)
         else:
             assert close(out[k], vec(e)), (case["op"], case["ref"], k, out[k][:5], vec(e)[:5])
+
+
+# ------------------------------------------------------------------ sparse assembly (both sides)
+_SP_ASSEMBLY = ("sp_copyRowsFrom", "sp_copyRowsBlockFrom", "sp_copySubmatrixFrom", "sp_copyDiagMatrixToSubblock",
+                "sp_copyDiagMatrixToSubblock_w_pattern", "sp_setSubmatrixToConstantDiag_w_pattern", "sp_transAddToSymDenseMatrixUpperTriangle")
+
+
+def _trip(d):
+    i, j, v, m, n = coo(d)
+    return [i.copy(), j.copy(), v.copy()], m, n
+
+
+def _sp_assembly_oracle(op, a):
+    from oracle import hiop_oracle as ho
+    if op == "sp_copyRowsFrom":
+        T, m, n = _trip(a["A"]); S, _, _ = _trip(a["B"])
+        nnz = ho.sp_copy_rows_from(T, S, np.array(a["select"], np.int32))
+        return {"val": T[2], "iRow": T[0], "jCol": T[1], "nnz": nnz}
+    if op == "sp_copyRowsBlockFrom":
+        T, m, n = _trip(a["dest"]); S, _, _ = _trip(a["src"])
+        ho.sp_copy_rows_block_from(T, S, a["src_row_st"], a["n_rows"], a["dest_row_st"], a["dest_nnz_st"])
+        return {"val": T[2]}
+    if op == "sp_transAddToSymDenseMatrixUpperTriangle":
+        i, j, v, m, n = coo(a["A"]); W = mat(a["W"])
+        ho.sp_trans_add_to_sym_upper(i, j, v, a["row_st"], a["col_st"], a["alpha"], W)
+        return {"W": W}
+    T, m, n = _trip(a["A"])
+    if op == "sp_copySubmatrixFrom":
+        S, _, _ = _trip(a["B"])
+        ho.sp_copy_submatrix_from(T, S, a["row_st"], a["col_st"], a["nnz_st"], False, bool(a["trans"]))
+    elif op == "sp_copyDiagMatrixToSubblock":
+        ho.sp_copy_diag_matrix_to_subblock(T, a["src_val"], a["row_st"], a["col_st"], a["nnz_st"], a["nnz_to_copy"])
+    elif op == "sp_copyDiagMatrixToSubblock_w_pattern":
+        assert ho.sp_copy_diag_matrix_to_subblock_w_pattern(T, vec(a["D"]), a["row_st"], a["col_st"], a["nnz_st"], vec(a["pattern"])) == a["nnz_to_copy"]
+    else:
+        assert ho.sp_set_submatrix_to_constant_diag_w_pattern(T, a["scalar"], a["row_st"], a["col_st"], a["nnz_st"], vec(a["pattern"]),
+                                                              bool(a["rowpattern"])) == a["nnz_to_copy"]
+    return {"W": ho.sp_copy_to_dense(m, n, T[0], T[1], T[2])}     # copy_to: duplicates add up (what the tests' "B_val + A_val" relies on)
+
+
+def _sp_assembly_gpu(ctx, op, a):
+    import torch
+    D = lambda arr, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(arr)).to(dt).cuda()
+    I32 = lambda arr: D(arr, torch.int32)
+    P = lambda t: C.c_void_p(t.data_ptr() if t.numel() else 0)
+
+    def dev_trip(d):
+        i, j, v, m, n = coo(d)
+        return [I32(i), I32(j), D(v)], m, n
+
+    def run(name, *args):
+        torch.cuda.synchronize(); ctx.call(name, *args); ctx.sync()
+
+    def image(T, m, n):
+        W = D(np.full((m, n), 7.0))
+        run("hiopamd_sp_copy_to_dense", m, n, T[2].numel(), T[0], T[1], T[2], W, n)
+        return W.cpu().numpy()
+    if op == "sp_copyRowsFrom":
+        T, m, n = dev_trip(a["A"]); S, _, _ = dev_trip(a["B"])
+        run("hiopamd_sp_copy_rows_from", T[0], T[1], T[2], S[2].numel(), S[0], S[1], S[2], I32(np.array(a["select"], np.int32)), len(a["select"]))
+        return {"val": T[2].cpu().numpy(), "iRow": T[0].cpu().numpy(), "jCol": T[1].cpu().numpy(), "nnz": T[2].numel()}
+    if op == "sp_copyRowsBlockFrom":
+        T, m, n = dev_trip(a["dest"]); S, _, _ = dev_trip(a["src"])
+        run("hiopamd_sp_copy_rows_block_from", T[0], T[1], T[2], S[2].numel(), P(S[0]), P(S[1]), P(S[2]), a["src_row_st"], a["n_rows"], a["dest_row_st"],
+            a["dest_nnz_st"])
+        return {"val": T[2].cpu().numpy()}
+    if op == "sp_transAddToSymDenseMatrixUpperTriangle":
+        T, m, n = dev_trip(a["A"]); W = D(mat(a["W"]))
+        run("hiopamd_sp_trans_add_to_sym_upper", T[2].numel(), T[0], T[1], T[2], a["row_st"], a["col_st"], a["alpha"], W, W.shape[1])
+        return {"W": W.cpu().numpy()}
+    T, m, n = dev_trip(a["A"])
+    if op == "sp_copySubmatrixFrom":
+        S, _, _ = dev_trip(a["B"])
+        run("hiopamd_sp_copy_submatrix_from", T[0], T[1], T[2], S[2].numel(), S[0], S[1], S[2], a["row_st"], a["col_st"], a["nnz_st"], 0, a["trans"])
+    elif op == "sp_copyDiagMatrixToSubblock":
+        run("hiopamd_sp_copy_diag_matrix_to_subblock", T[0], T[1], T[2], a["src_val"], a["row_st"], a["col_st"], a["nnz_st"], a["nnz_to_copy"])
+    elif op == "sp_copyDiagMatrixToSubblock_w_pattern":
+        found = C.c_int(-1); patt = vec(a["pattern"])
+        run("hiopamd_sp_copy_diag_matrix_to_subblock_w_pattern", T[0], T[1], T[2], D(vec(a["D"])), a["row_st"], a["col_st"], a["nnz_st"], patt.size, D(patt),
+            C.byref(found))
+        assert found.value == a["nnz_to_copy"]
+    else:
+        found = C.c_int(-1); patt = vec(a["pattern"])
+        run("hiopamd_sp_set_submatrix_to_constant_diag_w_pattern", T[0], T[1], T[2], a["scalar"], a["row_st"], a["col_st"], a["nnz_st"], patt.size, D(patt),
+            a["rowpattern"], C.byref(found))
+        assert found.value == a["nnz_to_copy"]
+    return {"W": image(T, m, n)}
 
 
 # ------------------------------------------------------------------ oracle
@@ -240,6 +329,8 @@ def run_oracle(case):
         A = mat(a["A"]); ho.shift_rows(A, a["shift"]); return {"A": A}
     if op == "mat_symmetrize":
         A = mat(a["A"]); ho.symmetrize(A); return {"A": A}
+    if op in _SP_ASSEMBLY:
+        return _sp_assembly_oracle(op, a)
     if op == "sp_maxAbsValue":
         return {"value": float(np.max(np.abs(coo(a["A"])[2])))}
     if op == "sp_row_max_abs_value":
@@ -475,6 +566,8 @@ def run_gpu(ctx, case):
         A = D(mat(a["A"])); run("hiopamd_mat_shift_rows", A.shape[0], A.shape[1], A, A.shape[1], a["shift"]); return {"A": A.cpu().numpy()}
     if op == "mat_symmetrize":
         A = D(mat(a["A"])); run("hiopamd_mat_symmetrize", A.shape[0], A, A.shape[1]); return {"A": A.cpu().numpy()}
+    if op in _SP_ASSEMBLY:
+        return _sp_assembly_gpu(ctx, op, a)
     if op.startswith("sp"):
         i, j, v, m, n = coo(a["A"])
         id_, jd, vd = D(i, torch.int32), D(j, torch.int32), D(v)
