@@ -277,12 +277,14 @@ def dense_lowrank_bench(ctx, world, rank, a, dist, hooked=True, rooflines=False)
         # HBM-side bytes per launch of the three kernels at THIS shape: committed PMC summary (scripts/calls/r05_pmc.sh part 2: the
         # kernels alone at bench.py's two shapes, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, separate passes); null for any other shape
         tr, tr_src = {}, None
-        try:
-            pd = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_dense", "summary.json")))
-            tr = {kk: vv.get("hbm_bytes_per_launch") for kk, vv in pd.get(f"k{k}_n{n}", {}).items()}
-            tr_src = f"profiles/r05_pmc_dense/summary.json [k{k}_n{n}]" if tr else None
-        except Exception:
-            pass
+        for pmc_dir in ("r06_pmc_dense", "r05_pmc_dense"):   # (the newest committed summary)
+            try:
+                pd = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_dir, "summary.json")))
+                tr = {kk: vv.get("hbm_bytes_per_launch") for kk, vv in pd.get(f"k{k}_n{n}", {}).items() if isinstance(vv, dict)}
+                tr_src = f"profiles/{pmc_dir}/summary.json [k{k}_n{n}]" if tr else None
+                break
+            except Exception:
+                continue
         out["roofline"] = [
             dict(kernel="gram_weighted_stacked (J DhInv [J;S;Y]^T, v_mfma_f64_16x16x4_f64)", bound="mfma",
                  achieved=gram_flops / (t_gram * 1e-3) / 1e12, peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s",
@@ -566,11 +568,11 @@ def main():
     achieved = (flops_per_launch / (ms_per_launch * 1e-3)) / 1e12 if ms_per_launch > 0 else 0.0
     # HBM-side traffic of that kernel per launch: PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc
     # passes with --kernel-trace only) of the SAME task graph run as one dispatch (HIOPAMD_DF_ONE=1: rocprofv3 serialises
-    # dispatches, and the production form is a pair of kernels that wait for each other) — scripts/calls/r05_pmc.sh, committed
-    # summary profiles/r05_pmc/summary.json (older rounds' summaries as fall-back).  Algorithmic bytes of the same launch: every trailing tile read + written once
+    # dispatches, and the production form is a pair of kernels that wait for each other) — scripts/calls/r06_pmc.sh, committed
+    # summary profiles/r06_pmc/summary.json (older rounds' summaries as fall-back).  Algorithmic bytes of the same launch: every trailing tile read + written once
     # per super-panel, the two operand row panels read once, the row-panel substitution (read A, write V and U).
     traffic, traffic_src, alg_bytes = None, "n/a (no committed PMC summary found)", None
-    for pmc_dir in ("r05_pmc", "r04_pmc", "r03_pmc"):
+    for pmc_dir in ("r06_pmc", "r05_pmc", "r04_pmc", "r03_pmc"):
         try:
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_dir, "summary.json")))
             if p.N == 8192:
