@@ -30,7 +30,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <future>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #define RC(x)                         \
@@ -40,6 +43,23 @@
   } while(0)
 
 using namespace hiopamd;
+
+#include <chrono>
+namespace {
+int sl_host_threads(int64_t work_items);   // (below, with the gather plans)
+// HIOPAMD_SL_TIMING=1: wall time of the phases of the symbolic analysis on stderr (host code; profiling aid)
+struct SlStopwatch {
+  const bool on = std::getenv("HIOPAMD_SL_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what)
+  {
+    if(!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[hiop_amd] sparse analysis: %-34s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+    t = now;
+  }
+};
+}  // namespace
 
 #ifndef HIOPAMD_SL_LEAF
 #define HIOPAMD_SL_LEAF 48
@@ -68,14 +88,25 @@ struct SlSymbolic {
 namespace {
 
 // ---- nested dissection ------------------------------------------------------------------------------------------------------
+// Round 6: the two sides of a cut are independent sub-problems (no edge joins them once the separator is out), so the top levels of the
+// recursion run on separate host threads: a sub-dissector shares the vertex-indexed work arrays (`mark`, `level`: the sets are disjoint)
+// and owns its queue, its output and a RANGE of set ids (ids are only ever compared for equality).  Its output is spliced into the
+// parent's in the order the sequential recursion would have produced it (side A, side B, separator last): the ordering — and with it
+// every plan, every sum, every bit of the factor — does not depend on the number of threads or on their timing.
 struct Dissector {
   int n;
   const int* rp;
   const int* ci;
   std::vector<char> removed;        // dense rows
-  std::vector<int> mark, level, queue, order;   // order: new -> old, filled in elimination order
+  std::vector<int> mark_store, level_store;   // (owned by the top-level dissector only)
+  int* mark = nullptr;
+  int* level = nullptr;
+  std::vector<int> queue, order;    // order: new -> old, filled in elimination order
   std::vector<int> sn_first, sn_nc;
   int stamp = 0;
+  std::atomic<int>* next_stamp = nullptr;   // where sub-dissectors get their id ranges
+  int par_depth = 0;                        // levels of the recursion that may still fork
+  static constexpr int PAR_MIN = 20000;     // vertices on a side below which forking is not worth a thread
 
   void emit_supernodes(const std::vector<int>& verts)
   {
@@ -228,6 +259,31 @@ struct Dissector {
         else S.push_back(v);
       }
       stack.push_back({std::move(S), true, false});    // emitted last
+      if(par_depth > 0 && next_stamp && (int)A.size() >= PAR_MIN && (int)B.size() >= PAR_MIN) {
+        // both sides at once; their supernodes go in front of whatever this dissector emits next (S is on top of the stack)
+        auto sub = [this](std::vector<int> verts) {
+          Dissector d;
+          d.n = n; d.rp = rp; d.ci = ci;
+          d.mark = mark; d.level = level;
+          d.next_stamp = next_stamp;
+          d.par_depth = par_depth - 1;
+          d.stamp = next_stamp->fetch_add(4 * (int)verts.size() + 64);   // (a set of m vertices uses at most ~2 m ids: components + cuts)
+          d.dissect(std::move(verts));
+          return d;
+        };
+        std::future<Dissector> fa = std::async(std::launch::async, sub, std::move(A));
+        Dissector db = sub(std::move(B));
+        Dissector da = fa.get();
+        for(const Dissector* d : {&da, &db}) {
+          const int base = (int)order.size();
+          for(size_t q = 0; q < d->sn_first.size(); ++q) {
+            sn_first.push_back(base + d->sn_first[q]);
+            sn_nc.push_back(d->sn_nc[q]);
+          }
+          order.insert(order.end(), d->order.begin(), d->order.end());
+        }
+        continue;
+      }
       stack.push_back({std::move(B), false, false});
       stack.push_back({std::move(A), false, false});
     }
@@ -250,8 +306,18 @@ int symbolic_analysis(int n, const int* rp, const int* ci, SlSymbolic& Y)
   D.rp = rp;
   D.ci = ci;
   D.removed.assign((size_t)n, 0);
-  D.mark.assign((size_t)n, 0);
-  D.level.assign((size_t)n, 0);
+  D.mark_store.assign((size_t)n, 0);
+  D.level_store.assign((size_t)n, 0);
+  D.mark = D.mark_store.data();
+  D.level = D.level_store.data();
+  // ids 1 .. 4 n + 64 belong to the top-level dissector, sub-dissectors take theirs from the counter (4 |set| + 64 each; the sets of one
+  // level of the recursion are disjoint, PAR_LEVELS levels fork: < 2^31 for every n this solver takes)
+  std::atomic<int> next_stamp(4 * n + 65);
+  constexpr int PAR_LEVELS = 3;
+  if(sl_host_threads(n) > 1 && (int64_t)n * 4 * (PAR_LEVELS + 2) < (int64_t)2000000000) {
+    D.next_stamp = &next_stamp;
+    D.par_depth = PAR_LEVELS;
+  }
   const int dense_thr = sl_dense_threshold(n, rp);
   std::vector<int> keep, dense;
   for(int v = 0; v < n; ++v) {
@@ -268,8 +334,10 @@ int symbolic_analysis(int n, const int* rp, const int* ci, SlSymbolic& Y)
     } else keep.push_back(v);
   }
   // the dissector only walks vertices whose mark equals the id of the current set: dense rows never get one
+  SlStopwatch sw;
   D.order.reserve((size_t)n);
   D.dissect(std::move(keep));
+  sw.lap("nested dissection");
   const int n_sparse_cols = (int)D.order.size();
   if(!dense.empty()) D.emit_supernodes(dense);
   if((int)D.order.size() != n) return HIOPAMD_ERR_STATE;
@@ -313,6 +381,7 @@ int symbolic_analysis(int n, const int* rp, const int* ci, SlSymbolic& Y)
     }
     (void)n_sparse_cols;
   }
+  sw.lap("row structures");
   // ---- sparse fronts / root
   Y.sroot.assign((size_t)Y.ns, 0);
   Y.slevel.assign((size_t)Y.ns, 0);
@@ -351,6 +420,7 @@ int symbolic_analysis(int n, const int* rp, const int* ci, SlSymbolic& Y)
   for(int s = 0; s < Y.ns; ++s) Y.srow_ptr[(size_t)s + 1] = Y.srow_ptr[(size_t)s] + (int)rows[(size_t)s].size();
   Y.srows.resize((size_t)Y.srow_ptr[(size_t)Y.ns]);
   for(int s = 0; s < Y.ns; ++s) std::copy(rows[(size_t)s].begin(), rows[(size_t)s].end(), Y.srows.begin() + Y.srow_ptr[(size_t)s]);
+  sw.lap("levels, root, copies");
   if(Y.r > SL_ROOT_MAX) return HIOPAMD_ERR_STATE;
   return HIOPAMD_OK;
 }
@@ -384,9 +454,46 @@ struct Contribution {
   int64_t dest;
   int64_t src;
 };
-void build_runs(std::vector<Contribution>& C, SlPlanHost& P)
+void sort_contributions(std::vector<Contribution>& C)
 {
   std::stable_sort(C.begin(), C.end(), [](const Contribution& a, const Contribution& b) { return a.dest < b.dest; });
+}
+// threads of the host-side analysis (round 6: it was single-threaded, 0.67 s at n = 1e6): the hardware's, at most 16; 1 for small patterns
+int sl_host_threads(int64_t work_items)
+{
+  if(work_items < 100000) return 1;
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
+}
+// f(q) for q in [0, count), dealt to the threads in contiguous blocks of about equal WEIGHT (weight(q): e.g. the entries to sort)
+template <class W, class F>
+void sl_parallel_for(int count, int threads, W weight, F f)
+{
+  if(threads <= 1 || count < 2 * threads) {
+    for(int q = 0; q < count; ++q) f(q);
+    return;
+  }
+  double total = 0.0;
+  for(int q = 0; q < count; ++q) total += (double)weight(q) + 1.0;
+  std::vector<int> cut((size_t)threads + 1, count);
+  cut[0] = 0;
+  double acc = 0.0;
+  int t = 1;
+  for(int q = 0; q < count && t < threads; ++q) {
+    acc += (double)weight(q) + 1.0;
+    if(acc >= total * t / threads) cut[(size_t)t++] = q + 1;
+  }
+  std::vector<std::thread> pool;
+  for(int w = 1; w < threads; ++w)
+    pool.emplace_back([&, w]() {
+      for(int q = cut[(size_t)w]; q < cut[(size_t)w + 1]; ++q) f(q);
+    });
+  for(int q = cut[0]; q < cut[1]; ++q) f(q);
+  for(auto& th : pool) th.join();
+}
+// (C sorted by destination: sort_contributions)
+void build_runs(std::vector<Contribution>& C, SlPlanHost& P)
+{
   for(size_t q = 0; q < C.size(); ++q) {
     if(q == 0 || C[q].dest != C[q - 1].dest) {
       P.run_dest.push_back((int)C[q].dest);
@@ -398,6 +505,7 @@ void build_runs(std::vector<Contribution>& C, SlPlanHost& P)
 
 int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHostLayout& H)
 {
+  SlStopwatch sw;
   // fronts by level
   std::vector<int> order;
   for(int s = 0; s < Y.ns; ++s)
@@ -445,6 +553,7 @@ int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHos
     for(int k = 0; k < Y.snc[(size_t)s]; ++k) sn_of[(size_t)(Y.sfirst[(size_t)s] + k)] = s;
   // contributions per sparse front / root: (1) entries of M whose EARLIER index (new numbering) is a column of the front,
   // (2) the update matrices of the children
+  sw.lap("layout: offsets, index lists");
   std::vector<std::vector<Contribution>> Cm((size_t)nf), Cv((size_t)nf);
   std::vector<Contribution> Rm, Rv;
   for(int v = 0; v < n; ++v) {
@@ -466,6 +575,7 @@ int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHos
       }
     }
   }
+  sw.lap("layout: matrix entries");
   for(int q = 0; q < nf; ++q) {   // child q -> its parent (front or root); children are visited in front order: a fixed order of additions
     const int s = order[(size_t)q];
     const int nr = H.f_nr[(size_t)q];
@@ -499,8 +609,27 @@ int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHos
       }
     }
   }
+  sw.lap("layout: children's updates");
   H.mat.front_run.assign(1, 0);
   H.vec.front_run.assign(1, 0);
+  {
+    // the sorts (by destination, stable: the order of the additions inside a destination is the order of the lists above) are independent
+    // per front: all host threads; the runs are then appended front by front in one sequential pass
+    int64_t ncontrib = 0;
+    for(int q = 0; q < nf; ++q) ncontrib += (int64_t)Cm[(size_t)q].size() + (int64_t)Cv[(size_t)q].size();
+    sl_parallel_for(nf, sl_host_threads(ncontrib), [&](int q) { return Cm[(size_t)q].size() + Cv[(size_t)q].size(); },
+                    [&](int q) {
+                      sort_contributions(Cm[(size_t)q]);
+                      sort_contributions(Cv[(size_t)q]);
+                    });
+    int64_t nm = 0, nv = 0;
+    for(int q = 0; q < nf; ++q) {
+      nm += (int64_t)Cm[(size_t)q].size();
+      nv += (int64_t)Cv[(size_t)q].size();
+    }
+    H.mat.src.reserve((size_t)nm); H.mat.run_dest.reserve((size_t)nm); H.mat.run_ptr.reserve((size_t)nm + 1);
+    H.vec.src.reserve((size_t)nv); H.vec.run_dest.reserve((size_t)nv); H.vec.run_ptr.reserve((size_t)nv + 1);
+  }
   for(int q = 0; q < nf; ++q) {
     build_runs(Cm[(size_t)q], H.mat);
     H.mat.front_run.push_back((int64_t)H.mat.run_dest.size());
@@ -510,10 +639,13 @@ int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHos
   }
   H.mat.run_ptr.push_back((int64_t)H.mat.src.size());
   H.vec.run_ptr.push_back((int64_t)H.vec.src.size());
+  sort_contributions(Rm);
+  sort_contributions(Rv);
   build_runs(Rm, H.rmat);
   H.rmat.run_ptr.push_back((int64_t)H.rmat.src.size());
   build_runs(Rv, H.rvec);
   H.rvec.run_ptr.push_back((int64_t)H.rvec.src.size());
+  sw.lap("layout: runs");
   return HIOPAMD_OK;
 }
 
