@@ -462,6 +462,8 @@ void sort_contributions(std::vector<Contribution>& C)
 int sl_host_threads(int64_t work_items)
 {
   if(work_items < 100000) return 1;
+  // HIOPAMD_HOST_THREADS caps it (1: the sequential analysis; the result is the same by construction — tests/test_sparse_ldl_plan.py checks)
+  if(const char* e = std::getenv("HIOPAMD_HOST_THREADS")) return std::max(1, std::min(std::atoi(e), 64));
   const unsigned hw = std::thread::hardware_concurrency();
   return (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
 }

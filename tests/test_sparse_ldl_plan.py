@@ -327,3 +327,29 @@ def test_seeded_sweep_of_pattern_families(seed):
     b = np.random.default_rng(seed + 1000).uniform(-1, 1, n)
     x = replay_solve(P, lpool, R, b)
     assert np.abs(A @ x - b).max() <= 1e-10 * max(1.0, np.abs(x).max())
+
+
+def test_the_analysis_does_not_depend_on_the_number_of_host_threads():
+    """Round 6: the nested dissection forks at its top levels and the plan lists are sorted on several threads.  The ordering, the
+    supernodes and every gather plan must be what the sequential analysis produces (so that every sum of the numeric phase — and every bit
+    of the factor — is independent of the host the analysis ran on).  n = 3e5 banded: sides of >= 20 000 vertices fork three levels deep."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_sparse_ldl_plan import banded, csr_full, get_plan\n"
+        "A = banded(300000, 4, seed=11); rp, ci, v = csr_full(A)\n"
+        "rc, P = get_plan(300000, rp, ci); assert rc == 0\n"
+        "h = hashlib.sha256()\n"
+        "for k in sorted(P):\n"
+        "    h.update(k.encode()); h.update(np.ascontiguousarray(P[k]).tobytes() if isinstance(P[k], np.ndarray) else str(P[k]).encode())\n"
+        "print(h.hexdigest())\n"
+    ) % (str(__import__("pathlib").Path(__file__).resolve().parent.parent), str(__import__("pathlib").Path(__file__).resolve().parent))
+    digests = []
+    for threads in ("1", "8"):
+        env = dict(os.environ, HIOPAMD_HOST_THREADS=threads)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append(r.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
