@@ -36,7 +36,7 @@ def poison_lib():
 
 @pytest.mark.parametrize("files", [
     ["tests/test_c_interface.py"],
-    ["tests/test_gpu_ldlt_kkt.py"],
+    ["tests/test_gpu_ldlt_kkt.py", "tests/test_ldlt_exact_closed_form.py"],
     ["tests/test_gpu_ldlt_bk.py", "tests/test_gpu_sparse_ldl.py"],
     ["tests/test_gpu_kkt_xycyd.py", "tests/test_gpu_lowrank.py"],
 ], ids=["c_interface", "ldlt_kkt", "ldlt_bk+sparse_ldl", "kkt_xycyd+lowrank"])
