@@ -3,7 +3,7 @@ exception with the library's diagnostic record on stderr.  DF_N (8192), DF_REPS 
 factor and check the residual."""
 import os, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hiop_amd.runtime import Context
 from hiop_amd.kkt import LinSolverSymDense
 N = int(os.environ.get("DF_N", "8192")); reps = int(os.environ.get("DF_REPS", "300")); nobj = int(os.environ.get("DF_OBJECTS", "4"))
