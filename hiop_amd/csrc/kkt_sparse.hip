@@ -168,6 +168,10 @@ int hiopamd_kkt_sparse_condensed_create(hiopamd_kkt_sparse_condensed** out, hiop
       if(rc == HIOPAMD_OK && !k->arrow) {   // not a bordered diagonal with a small border: the general sparse LDL^T, if its root fits
         const int rs = hiopamd_sparse_ldl_create(&k->sldl, ctx, nx, rp.data(), ci.data());
         if(rs != HIOPAMD_OK && rs != HIOPAMD_ERR_STATE) rc = rs;
+        if(rs == HIOPAMD_ERR_STATE)   // said once per object: the caller should know that factorize()'s verdict is now a Krylov probe's
+          std::fprintf(stderr, "[hiop_amd] condensed sparse KKT (n = %d): the sparse LDL^T does not take this pattern (its dense root would exceed the limit — a mesh-like "
+                               "pattern — or a diagonal entry is structurally zero); inner solver = PCG + Jacobi: factorize() then answers from a Krylov probe (necessary, not sufficient, for positive definiteness), "
+                               "hiopamd_kkt_sparse_condensed_inner_kind() = 2\n", nx);
       }
     }
   }

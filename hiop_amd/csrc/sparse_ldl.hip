@@ -769,6 +769,7 @@ __global__ void sl_factor_level_kernel(int q0, const int* __restrict__ f_nc, con
     const int i = e / nr, j = e % nr;
     U[e] = (j <= i) ? F[SL_TRI(nc + i, nc + j)] : 0.0;
   }
+#undef SL_TRI
 }
 
 __global__ __launch_bounds__(kBlock) void sl_root_gather_kernel(int64_t nruns, int r, int64_t lda, const int* __restrict__ run_dest,
