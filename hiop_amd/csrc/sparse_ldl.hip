@@ -20,7 +20,8 @@
 //     * gather plans: every entry of a front (and of the root) is the sum, in a FIXED order, of entries of M and of entries of its
 //       children's update matrices — no atomics, bitwise reproducible.
 //   numeric (device): one launch per level of the supernode tree, one workgroup per front: gather the front into LDS (lower triangle),
-//     right-looking LDL^T of its pivot columns, store the L panel and the update matrix; then gather + factor the root.
+//     right-looking LDL^T of its pivot columns, store the L panel and the update matrix; then gather + factor the root.  Round 6: levels
+//     of small fronts with many pivots (<= 40 rows: the leaves of a banded pattern) by ONE WAVE per front with the front in registers.
 //     Non-positive pivots are COUNTED (integer atomics), the factorisation goes on: inertia = (#negative, #zero) of the sparse fronts +
 //     the root's, exact by Sylvester's law whenever no pivot is zero (no pivoting: a matrix that is not quasi-definite may break down —
 //     reported as n_zero > 0, which the caller treats like the reference treats a failed Cholesky).
@@ -444,6 +445,7 @@ struct SlHostLayout {
   std::vector<int64_t> f_iofs;          // offset into fidx
   std::vector<int> fidx;                // per front: ORIGINAL indices of its f variables (columns, then rows)
   std::vector<int> fmax_level;          // largest front per level
+  std::vector<int> ncsum_level;         // pivot columns per level (which factor kernel a level gets)
   int64_t lsize = 0, usize = 0, vsize = 0;
   SlPlanHost mat, vec;                  // fronts
   SlPlanHost rmat, rvec;                // root (one "front")
@@ -518,6 +520,7 @@ int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHos
   std::vector<int> front_of((size_t)Y.ns, -1);
   H.level_ptr.assign((size_t)Y.nlevels + 1, 0);
   H.fmax_level.assign((size_t)std::max(Y.nlevels, 1), 0);
+  H.ncsum_level.assign((size_t)std::max(Y.nlevels, 1), 0);
   for(int q = 0; q < nf; ++q) {
     front_of[(size_t)order[(size_t)q]] = q;
     H.level_ptr[(size_t)Y.slevel[(size_t)order[(size_t)q]] + 1] += 1;
@@ -536,6 +539,7 @@ int build_layout(int n, const int* rp, const int* ci, const SlSymbolic& Y, SlHos
     for(int k = 0; k < nc; ++k) H.fidx.push_back(Y.perm[(size_t)(Y.sfirst[(size_t)s] + k)]);
     for(int t = Y.srow_ptr[(size_t)s]; t < Y.srow_ptr[(size_t)s + 1]; ++t) H.fidx.push_back(Y.perm[(size_t)Y.srows[(size_t)t]]);
     H.fmax_level[(size_t)Y.slevel[(size_t)s]] = std::max(H.fmax_level[(size_t)Y.slevel[(size_t)s]], nc + nr);
+    H.ncsum_level[(size_t)Y.slevel[(size_t)s]] += nc;
   }
   if(H.usize > (int64_t)1 << 40) return HIOPAMD_ERR_STATE;
   H.root_old.resize((size_t)Y.r);
@@ -783,29 +787,51 @@ __global__ __launch_bounds__(kBlock) void sl_root_gather_kernel(int64_t nruns, i
   }
 }
 
-// forward: w = [b(cols); 0] + children; L11 y = w_c; w_r -= L21 y; y -> b(cols); w_r -> vector pool.  One wave per front.
-__global__ __launch_bounds__(64) void sl_fwd_level_kernel(int q0, const int* __restrict__ f_nc, const int* __restrict__ f_nr,
-                                                          const int64_t* __restrict__ f_lofs, const int64_t* __restrict__ f_vofs,
-                                                          const int64_t* __restrict__ f_iofs, const int* __restrict__ fidx,
-                                                          const int* __restrict__ run_dest, const int64_t* __restrict__ run_ptr,
-                                                          const int64_t* __restrict__ srcs, const int64_t* __restrict__ front_run,
-                                                          const double* __restrict__ lpool, double* __restrict__ vpool, double* __restrict__ b)
+// ---- one wave per front (the sweeps; round 6: the factorisation of the levels with small fronts and many pivots) ------------------------
+// Measured and NOT kept in round 6 (profiles/r06_probes/call15-17_*): several levels in ONE launch — a workgroup per subtree, a wave per
+// front, a workgroup barrier between the levels.  With device-scope fences at the hand-over a solve took 8.7 ms instead of 0.34 (every
+// fence writes back and invalidates the XCD's L2); with the workgroup-scope hand-over that is sufficient (the waves of a workgroup share
+// their CU's L1) the five widest levels took 227 us in one launch against 135 us in five (a workgroup idles through the upper steps of its
+// subtree while the wide levels need every CU's full occupancy), and the narrow levels cost 4.3 / 6 us per step inside a workgroup against
+// 4.7 / 7 us per launch: a level of few fronts is a chain of ~8 dependent memory round trips per front, not launch overhead, and the
+// look-up of the front list adds two more.  Requesting every independent load of a front up front (48 loads in flight, 144-224
+// registers) made the wide levels slower (occupancy) and the narrow ones no faster.
+struct SlFronts {
+  const int *nc, *nr;
+  const int64_t *lofs, *uofs, *vofs, *iofs;
+  const int* idx;
+};
+struct SlRuns {
+  const int* dest;
+  const int64_t *ptr, *src, *front;
+};
+// value of lane `src` (wave-uniform) in every lane: two v_readlane_b32 — the pivot-by-pivot chains of the sweeps broadcast one value per
+// step, and __shfl is a ds_bpermute (an LDS round trip on the critical path of every step)
+__device__ __forceinline__ double sl_bcast(double v, int src)
 {
-  __shared__ double w[SL_T];
-  const int q = q0 + blockIdx.x;
-  const int nc = f_nc[q], nr = f_nr[q], f = nc + nr;
-  const int lane = threadIdx.x;
-  const int* idx = fidx + f_iofs[q];
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// forward: w = [b(cols); 0] + children; L11 y = w_c; w_r -= L21 y; y -> b(cols); w_r -> vector pool.  One wave per front; w: SL_T doubles
+// of LDS owned by the wave (LDS operations of one wave are executed in order: no barrier between its phases).
+__device__ __forceinline__ void sl_fwd_front(int q, int lane, double* __restrict__ w, const SlFronts F, const SlRuns R,
+                                             const double* __restrict__ lpool, double* __restrict__ vpool, double* __restrict__ b)
+{
+  const int nc = F.nc[q], nr = F.nr[q], f = nc + nr;
+  const int* idx = F.idx + F.iofs[q];
   for(int i = lane; i < f; i += 64) w[i] = (i < nc) ? b[idx[i]] : 0.0;
-  __syncthreads();
-  for(int64_t t = front_run[q] + lane; t < front_run[q + 1]; t += 64) w[run_dest[t]] += sl_gather(srcs, run_ptr[t], run_ptr[t + 1], vpool, vpool);
-  __syncthreads();
-  const double* L = lpool + f_lofs[q];
+  __builtin_amdgcn_wave_barrier();
+  for(int64_t t = R.front[q] + lane; t < R.front[q + 1]; t += 64) w[R.dest[t]] += sl_gather(R.src, R.ptr[t], R.ptr[t + 1], vpool, vpool);
+  __builtin_amdgcn_wave_barrier();
+  const double* L = lpool + F.lofs[q];
   // the column sweep in REGISTERS: rows lane and lane + 64 of the front's vector live in this lane (f <= 128), the pivot entry of a step is
-  // broadcast by a shuffle (nc <= 48 < 64: always in the first register) — no LDS round trip and no barrier per column
+  // broadcast from the first register (nc <= 48 < 64) — no LDS round trip and no barrier per column
   double w0 = (lane < f) ? w[lane] : 0.0, w1 = (lane + 64 < f) ? w[lane + 64] : 0.0;
   // (sixteen columns' entries are requested together: the loop itself is a chain of dependent steps, and one load per step would put a
-  //  memory round trip into each of them)
+  //  memory round trip into each of them.  Requesting ALL of a front's columns — and its index list and plan entries — before anything is
+  //  used was measured in round 6: 48 loads in flight cost 144 registers, the leaf level of the banded n = 1e6 pattern, which is bound by
+  //  HBM and needs the occupancy, went from 68 to 73 us and level 1 from 32 to 44, and the narrow levels did not get faster at all.)
   const bool two = f > 64;   // uniform
   for(int k0 = 0; k0 < nc; k0 += 16) {
     double l0[16], l1[16];
@@ -819,7 +845,7 @@ __global__ __launch_bounds__(64) void sl_fwd_level_kernel(int q0, const int* __r
     for(int u = 0; u < 16; ++u) {
       const int k = k0 + u;
       if(k < nc) {   // uniform
-        const double yk = __shfl(w0, k, 64);
+        const double yk = sl_bcast(w0, k);
         w0 -= l0[u] * yk;      // (zero for the rows at or above the pivot)
         if(two) w1 -= l1[u] * yk;
       }
@@ -827,12 +853,19 @@ __global__ __launch_bounds__(64) void sl_fwd_level_kernel(int q0, const int* __r
   }
   if(lane < f) {
     if(lane < nc) b[idx[lane]] = w0;
-    else vpool[f_vofs[q] + (lane - nc)] = w0;
+    else vpool[F.vofs[q] + (lane - nc)] = w0;
   }
   if(lane + 64 < f) {
     if(lane + 64 < nc) b[idx[lane + 64]] = w1;
-    else vpool[f_vofs[q] + (lane + 64 - nc)] = w1;
+    else vpool[F.vofs[q] + (lane + 64 - nc)] = w1;
   }
+  __builtin_amdgcn_wave_barrier();   // (the wave's next front reuses w)
+}
+__global__ __launch_bounds__(64) void sl_fwd_level_kernel(int q0, const SlFronts F, const SlRuns R, const double* __restrict__ lpool,
+                                                          double* __restrict__ vpool, double* __restrict__ b)
+{
+  __shared__ double w[SL_T];
+  sl_fwd_front(q0 + blockIdx.x, threadIdx.x, w, F, R, lpool, vpool, b);
 }
 
 __global__ __launch_bounds__(kBlock) void sl_root_rhs_kernel(int r, const int* __restrict__ root_old, int64_t nruns, const int* __restrict__ run_dest,
@@ -853,22 +886,18 @@ __global__ __launch_bounds__(kBlock) void sl_root_scatter_kernel(int r, const in
   for(int t = blockIdx.x * kBlock + threadIdx.x; t < r; t += gridDim.x * kBlock) x[root_old[t]] = xr[t];
 }
 
-// backward: z = y ./ d; L11^T x_c = z - L21^T x_r; one wave per front (row-by-row axpy form, see below)
-__global__ __launch_bounds__(64) void sl_bwd_level_kernel(int q0, const int* __restrict__ f_nc, const int* __restrict__ f_nr,
-                                                          const int64_t* __restrict__ f_lofs, const int64_t* __restrict__ f_iofs,
-                                                          const int* __restrict__ fidx, const double* __restrict__ lpool, double* __restrict__ x)
+// backward: z = y ./ d; L11^T x_c = z - L21^T x_r; one wave per front
+__device__ __forceinline__ void sl_bwd_front(int q, int lane, const SlFronts F, const double* __restrict__ lpool, double* __restrict__ x)
 {
-  const int q = q0 + blockIdx.x;
-  const int nc = f_nc[q], nr = f_nr[q], f = nc + nr;
-  const int lane = threadIdx.x;
-  const int* idx = fidx + f_iofs[q];
-  const double* L = lpool + f_lofs[q];
+  const int nc = F.nc[q], nr = F.nr[q], f = nc + nr;
+  const int* idx = F.idx + F.iofs[q];
+  const double* L = lpool + F.lofs[q];
   // Rows lane and lane + 64 of the front's vector in registers (f <= 128; the pivot rows, nc <= 48, in the first one).  Round 6: the sweep
-  // runs in AXPY form over the ROWS of L, from the last row up: when x_i is final (every row below it has been applied) it is broadcast by
-  // ONE shuffle and lane k < min(i, nc) subtracts L_ik x_i from its own entry — no reduction.  (Rounds 4-5 took the columns from the last
-  // pivot down: a dot product over the lanes per pivot, six dependent shuffles + a broadcast each, 140 us for the 32 768 leaf fronts of the
-  // banded n = 1e6 case against 62 us for the forward sweep, which always was an axpy.)  Lane k reads ITS OWN column k of the panel
-  // (contiguous, column-major storage) at row i: sixteen rows' entries are requested together.
+  // runs in AXPY form over the ROWS of L, from the last row up: when x_i is final (every row below it has been applied) it is broadcast
+  // and lane k < min(i, nc) subtracts L_ik x_i from its own entry — no reduction.  (Rounds 4-5 took the columns from the last pivot down:
+  // a dot product over the lanes per pivot, six dependent shuffles + a broadcast each, 140 us for the 32 768 leaf fronts of the banded
+  // n = 1e6 case against 62 us for the forward sweep, which always was an axpy.)  Lane k reads ITS OWN column k of the panel (contiguous,
+  // column-major storage) at row i: sixteen rows' entries are requested together.
   double w0 = 0.0, w1 = 0.0;
   if(lane < f) {
     const double v = x[idx[lane]];
@@ -887,12 +916,107 @@ __global__ __launch_bounds__(64) void sl_bwd_level_kernel(int q0, const int* __r
     for(int u = 0; u < 16; ++u) {
       const int i = i0 - u;
       if(i >= 1) {   // uniform
-        const double xi = (i < 64) ? __shfl(w0, i, 64) : __shfl(w1, i - 64, 64);
+        const double xi = (i < 64) ? sl_bcast(w0, i) : sl_bcast(w1, i - 64);
         w0 -= lv[u] * xi;      // (zero for the rows at or below the lane's pivot and for the non-pivot lanes)
       }
     }
   }
   if(lane < nc) x[idx[lane]] = w0;
+}
+__global__ __launch_bounds__(64) void sl_bwd_level_kernel(int q0, const SlFronts F, const double* __restrict__ lpool, double* __restrict__ x)
+{
+  sl_bwd_front(q0 + blockIdx.x, threadIdx.x, F, lpool, x);
+}
+
+// The factorisation of a front of at most FMAX rows by ONE wave with the front in REGISTERS: lane i holds row i of the lower triangle
+// (a[j] = F_ij, j <= i), the pivot loop is unrolled so that every register index is static.  Pivot k: its column — entry a[k] of every
+// lane — goes to 64 doubles of LDS, every lane reads it back as broadcasts (all lanes one address: no bank conflicts) and updates its row
+// with one fused multiply-add per entry: no barrier, no LDS traffic for the front itself, no integer arithmetic.  The LDS form of rounds
+// 4-5 (sl_factor_level_kernel, still used above FMAX rows) spent two workgroup barriers and three dependent LDS phases per pivot and held
+// 14 KB of LDS per 58-row front: the leaf level of the banded n = 1e6 pattern (32 768 fronts of ~30 pivots) took 450 of the
+// factorisation's 610 us.  Fw: staging for the gather and for the update matrix (f (f + 1) / 2 doubles), col: 64 doubles; both the wave's own.
+constexpr int SL_REGS_F = 40;
+#ifndef HIOPAMD_SL_BCAST_SPLIT
+#define HIOPAMD_SL_BCAST_SPLIT 1
+#endif
+#define SL_TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+template <int FMAX>
+__device__ __forceinline__ void sl_factor_front_regs(int q, int lane, double* __restrict__ Fw, double* __restrict__ col, const SlFronts F,
+                                                     const SlRuns R, const double* __restrict__ vals, double* __restrict__ upool,
+                                                     double* __restrict__ lpool, int* __restrict__ counts)
+{
+  constexpr int KMAX = FMAX < SL_LEAF ? FMAX : SL_LEAF;
+  const int nc = F.nc[q], nr = F.nr[q], f = nc + nr;
+  const int ntri = f * (f + 1) / 2;
+  for(int e = lane; e < ntri; e += 64) Fw[e] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  const float rf = 1.0f / (float)f;   // d / f for d < 4096, f <= 64: (d + 0.5) / f is at least 0.5 / 64 away from an integer, the float error is < 1e-5
+  for(int64_t t = R.front[q] + lane; t < R.front[q + 1]; t += 64) {
+    const int d = R.dest[t];
+    const int di = (int)(((float)d + 0.5f) * rf), dj = d - di * f;
+    Fw[(di >= dj) ? SL_TRI(di, dj) : SL_TRI(dj, di)] = sl_gather(R.src, R.ptr[t], R.ptr[t + 1], vals, upool);
+  }
+  __builtin_amdgcn_wave_barrier();
+  double a[FMAX];
+  const int rowbase = lane * (lane + 1) / 2;
+#pragma unroll
+  for(int j = 0; j < FMAX; ++j) a[j] = (j <= lane && lane < f) ? Fw[rowbase + j] : 0.0;
+  int nneg = 0, nzero = 0;
+#pragma unroll
+  for(int k = 0; k < KMAX; ++k) {
+    if(k < nc) {   // uniform
+      const double d = __shfl(a[k], k, 64);
+      const bool bad = !(fabs(d) >= 1e-14) || !isfinite(d);   // thresholds of the reference's dense solver class (hiopLinSolverSymDenseLapack.hpp:154-161)
+      nzero += bad ? 1 : 0;
+      nneg += (!bad && d < 0.0) ? 1 : 0;
+      const double di = bad ? 0.0 : 1.0 / d;   // a zero pivot: the column is dropped (the verdict is "not factorisable" anyway)
+      col[lane] = a[k];                        // column k, unscaled (zero in the lanes above the pivot and in the lanes behind the front)
+      __builtin_amdgcn_wave_barrier();
+      const double ak = a[k];
+      const double l = (lane > k) ? ak * di : 0.0;
+      // (the entries right of the diagonal get the symmetric value: never stored.)  The broadcast of column k is what bounds this loop:
+      // through LDS it moves 64 x 8 bytes per entry into the wave's registers, and the CU's waves share one 128-byte-per-clock LDS
+      // pipe; every other pair of entries therefore comes as a wave-uniform value from the vector unit (two v_readlane_b32) instead.
+#pragma unroll
+      for(int j = k + 1; j < FMAX; ++j) {
+        if(HIOPAMD_SL_BCAST_SPLIT == 2 || (HIOPAMD_SL_BCAST_SPLIT == 1 && ((j >> 1) & 1))) a[j] -= l * sl_bcast(ak, j);
+        else a[j] -= l * col[j];
+      }
+      if(lane > k) a[k] = l;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if(lane == 0 && (nneg || nzero)) {
+    if(nneg) atomicAdd(counts, nneg);
+    if(nzero) atomicAdd(counts + 1, nzero);
+  }
+  // the L panel column by column (column k contiguous: L[k * f + i], diagonal: d_k, above it inside the pivot block: zero)
+  double* L = lpool + F.lofs[q];
+#pragma unroll
+  for(int k = 0; k < KMAX; ++k)
+    if(k < nc && lane < f) L[(int64_t)k * f + lane] = (lane >= k) ? a[k] : 0.0;
+  // the update matrix: rows / columns behind the pivots, row-major nr x nr with zeros right of the diagonal — through the staging triangle
+  if(nr > 0) {
+#pragma unroll
+    for(int c = 0; c < FMAX; ++c)
+      if(c >= nc && lane >= c && lane < f) Fw[SL_TRI(lane - nc, c - nc)] = a[c];
+    __builtin_amdgcn_wave_barrier();
+    double* U = upool + F.uofs[q];
+    const float rn = 1.0f / (float)nr;
+    for(int e = lane; e < nr * nr; e += 64) {
+      const int i = (int)(((float)e + 0.5f) * rn), j = e - i * nr;
+      U[e] = (j <= i) ? Fw[SL_TRI(i, j)] : 0.0;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();   // (the wave's next front reuses Fw / col)
+}
+#undef SL_TRI
+template <int FMAX>
+__global__ __launch_bounds__(64) void sl_factor_regs_kernel(int q0, const SlFronts F, const SlRuns R, const double* __restrict__ vals,
+                                                            double* __restrict__ upool, double* __restrict__ lpool, int* __restrict__ counts)
+{
+  extern __shared__ double sl_lds[];   // the level's largest triangle + 64
+  sl_factor_front_regs<FMAX>(q0 + blockIdx.x, threadIdx.x, sl_lds + 64, sl_lds, F, R, vals, upool, lpool, counts);
 }
 
 }  // namespace
@@ -906,11 +1030,14 @@ struct hiopamd_sparse_ldl {
   int *f_nc = nullptr, *f_nr = nullptr, *fidx = nullptr, *root_old = nullptr, *counts = nullptr;
   int64_t *f_lofs = nullptr, *f_uofs = nullptr, *f_vofs = nullptr, *f_iofs = nullptr;
   SlPlanDev mat, vec, rmat, rvec;
+  bool reg_fronts = true;   // levels of small fronts with many pivots: one wave per front, the front in registers (HIOPAMD_SL_REGS=0: the LDS kernel everywhere)
   double *lpool = nullptr, *upool = nullptr, *vpool = nullptr, *xr = nullptr;
   hiopamd_linsolver* root = nullptr;
   int n_neg = 0, n_zero = 0;
   bool factored = false;
 };
+
+static SlFronts sl_fronts(const hiopamd_sparse_ldl* s) { return {s->f_nc, s->f_nr, s->f_lofs, s->f_uofs, s->f_vofs, s->f_iofs, s->fidx}; }
 
 extern "C" {
 
@@ -1005,6 +1132,7 @@ int hiopamd_sparse_ldl_create(hiopamd_sparse_ldl** out, hiopamd_ctx* ctx, int n,
   if(rc == HIOPAMD_OK) rc = up_plan(s->vec, H.vec);
   if(rc == HIOPAMD_OK) rc = up_plan(s->rmat, H.rmat);
   if(rc == HIOPAMD_OK) rc = up_plan(s->rvec, H.rvec);
+  if(const char* e = std::getenv("HIOPAMD_SL_REGS")) s->reg_fronts = std::atoi(e) != 0;
   auto dalloc = [](double** p, int64_t cnt) { return hipMalloc((void**)p, sizeof(double) * (size_t)std::max<int64_t>(cnt, 1)) == hipSuccess ? HIOPAMD_OK : HIOPAMD_ERR_HIP; };
   if(rc == HIOPAMD_OK) rc = dalloc(&s->lpool, H.lsize);
   if(rc == HIOPAMD_OK) rc = dalloc(&s->upool, H.usize);
@@ -1024,12 +1152,26 @@ int hiopamd_sparse_ldl_create(hiopamd_sparse_ldl** out, hiopamd_ctx* ctx, int n,
   return HIOPAMD_OK;
 }
 
-// {supernodes, sparse fronts, levels, root order, nnz(L), 0, 0, 0}
+// Which factor kernel a level gets: fronts of at most 40 rows with many pivot columns — the leaves of a banded pattern — one wave each
+// with the front in registers (sl_factor_regs_kernel; the banded n = 1e6 leaf level: 265 us against 391); fronts with few pivots —
+// separators — and larger fronts in LDS by a workgroup each (the register form's cost follows the template's row count, not the pivots:
+// 80 against 39 us on level 1 of that pattern).  A 64-row instantiation was measured as well: no gain on the 62-row leaves of bandwidth 7,
+// 1.02 against 0.90 ms on the 20-column separators of the n = 2e5, bandwidth 20 pattern — not built.
+static bool sl_level_in_registers(const hiopamd_sparse_ldl* s, int l)
+{
+  const SlHostLayout& H = s->H;
+  const int cnt = H.level_ptr[(size_t)l + 1] - H.level_ptr[(size_t)l];
+  return s->reg_fronts && cnt > 0 && H.fmax_level[(size_t)l] <= SL_REGS_F && (int64_t)H.ncsum_level[(size_t)l] >= 16 * (int64_t)cnt;
+}
+
+// {supernodes, sparse fronts, levels, root order, nnz(L), levels factored in registers, 0, 0}
 int hiopamd_sparse_ldl_info(const hiopamd_sparse_ldl* s, int64_t* info8_host)
 {
   if(!s || !info8_host) return HIOPAMD_ERR_ARG;
   info8_host[0] = s->Y.ns; info8_host[1] = s->nf; info8_host[2] = s->Y.nlevels; info8_host[3] = s->Y.r; info8_host[4] = s->Y.nnzL;
-  info8_host[5] = info8_host[6] = info8_host[7] = 0;
+  info8_host[5] = 0;   // levels whose fronts are factored in registers (one wave per front; see hiopamd_sparse_ldl_factorize)
+  for(int l = 0; l < s->Y.nlevels; ++l) info8_host[5] += sl_level_in_registers(s, l) ? 1 : 0;
+  info8_host[6] = info8_host[7] = 0;
   return HIOPAMD_OK;
 }
 
@@ -1055,10 +1197,19 @@ int hiopamd_sparse_ldl_factorize(hiopamd_sparse_ldl* s, const double* vals, int*
   s->factored = false;
   HIOPAMD_CHECK(hipMemsetAsync(s->counts, 0, 4 * sizeof(int), ctx->stream));
   const SlHostLayout& H = s->H;
+  const SlFronts F = sl_fronts(s);
+  const SlRuns R = {s->mat.run_dest, s->mat.run_ptr, s->mat.src, s->mat.front_run};
   for(int l = 0; l < s->Y.nlevels; ++l) {
     const int q0 = H.level_ptr[(size_t)l], cnt = H.level_ptr[(size_t)l + 1] - q0;
     if(cnt <= 0) continue;
     const int fmax = H.fmax_level[(size_t)l];
+    if(sl_level_in_registers(s, l)) {
+      const size_t lds = sizeof(double) * ((size_t)fmax * (fmax + 1) / 2 + 64);
+      hipLaunchKernelGGL(sl_factor_regs_kernel<SL_REGS_F>, dim3((unsigned)cnt), dim3(64), lds, ctx->stream, q0, F, R, vals, s->upool, s->lpool,
+                         s->counts);
+      HIOPAMD_CHECK(hipGetLastError());
+      continue;
+    }
     const int ldf = fmax;   // (rows of the largest front of the level: the packed triangle has ldf (ldf + 1) / 2 entries)
     const size_t lds = sizeof(double) * ((size_t)ldf * (ldf + 1) / 2 + 2 * (size_t)ldf);
 #ifndef HIOPAMD_SL_T128
@@ -1103,11 +1254,12 @@ int hiopamd_sparse_ldl_solve(hiopamd_sparse_ldl* s, double* x)
   if(!s->factored) return HIOPAMD_ERR_STATE;
   hiopamd_ctx* ctx = s->ctx;
   const SlHostLayout& H = s->H;
+  const SlFronts F = sl_fronts(s);
+  const SlRuns R = {s->vec.run_dest, s->vec.run_ptr, s->vec.src, s->vec.front_run};
   for(int l = 0; l < s->Y.nlevels; ++l) {
     const int q0 = H.level_ptr[(size_t)l], cnt = H.level_ptr[(size_t)l + 1] - q0;
     if(cnt <= 0) continue;
-    hipLaunchKernelGGL(sl_fwd_level_kernel, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, q0, s->f_nc, s->f_nr, s->f_lofs, s->f_vofs, s->f_iofs,
-                       s->fidx, s->vec.run_dest, s->vec.run_ptr, s->vec.src, s->vec.front_run, s->lpool, s->vpool, x);
+    hipLaunchKernelGGL(sl_fwd_level_kernel, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, q0, F, R, s->lpool, s->vpool, x);
   }
   const int r = s->Y.r;
   if(s->root) {
@@ -1123,8 +1275,7 @@ int hiopamd_sparse_ldl_solve(hiopamd_sparse_ldl* s, double* x)
   for(int l = s->Y.nlevels - 1; l >= 0; --l) {
     const int q0 = H.level_ptr[(size_t)l], cnt = H.level_ptr[(size_t)l + 1] - q0;
     if(cnt <= 0) continue;
-    hipLaunchKernelGGL(sl_bwd_level_kernel, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, q0, s->f_nc, s->f_nr, s->f_lofs, s->f_iofs, s->fidx,
-                       s->lpool, x);
+    hipLaunchKernelGGL(sl_bwd_level_kernel, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, q0, F, s->lpool, x);
   }
   HIOPAMD_CHECK(hipGetLastError());
   return HIOPAMD_OK;

@@ -409,7 +409,7 @@ int hiopamd_arrow_ldl_solve(hiopamd_arrow_ldl* s, double* x_inout);
 typedef struct hiopamd_sparse_ldl hiopamd_sparse_ldl;
 int hiopamd_sparse_ldl_create(hiopamd_sparse_ldl** out, hiopamd_ctx* ctx, int n, const int* rowptr_host, const int* colidx_host);
 int hiopamd_sparse_ldl_destroy(hiopamd_sparse_ldl* s);
-int hiopamd_sparse_ldl_info(const hiopamd_sparse_ldl* s, int64_t* info8_host);   /* supernodes, fronts, levels, root order, nnz(L) */
+int hiopamd_sparse_ldl_info(const hiopamd_sparse_ldl* s, int64_t* info8_host);   /* supernodes, fronts, levels, root order, nnz(L), levels factored with the front in registers */
 int hiopamd_sparse_ldl_factorize(hiopamd_sparse_ldl* s, const double* csr_values, int* n_neg_host, int* n_zero_host);
 int hiopamd_sparse_ldl_solve(hiopamd_sparse_ldl* s, double* x_inout);
 int hiopamd_sparse_ldl_analyse(int n, const int* rowptr_host, const int* colidx_host, int64_t* info8_host, int* perm_host);

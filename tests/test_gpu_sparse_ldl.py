@@ -36,7 +36,7 @@ class SparseLdl:
     def info(self):
         i8 = np.zeros(8, dtype=np.int64)
         assert self.L.hiopamd_sparse_ldl_info(self.h, i8.ctypes.data) == 0
-        return dict(supernodes=int(i8[0]), fronts=int(i8[1]), levels=int(i8[2]), root=int(i8[3]), nnzL=int(i8[4]))
+        return dict(supernodes=int(i8[0]), fronts=int(i8[1]), levels=int(i8[2]), root=int(i8[3]), nnzL=int(i8[4]), reg_levels=int(i8[5]))
 
     def factorize(self, vals=None):
         nneg, nzero = C.c_int(-7), C.c_int(-7)
@@ -98,6 +98,33 @@ def test_banded(ctx, n, bw):
     Ai = quasi_definite(A, n // 3, seed=3) if n <= 200000 else None     # (lil_matrix edits are slow beyond that)
     if Ai is not None:
         check(ctx, Ai, n_negative_diagonal(Ai))
+
+
+@pytest.mark.parametrize("n,bw,indef", [(30000, 3, False), (200000, 5, False), (60000, 5, True), (40000, 2, True)])
+def test_register_resident_fronts_against_the_lds_kernel(ctx, n, bw, indef, monkeypatch):
+    """Round 6: the levels with small fronts and many pivots (the leaves of a banded pattern) are factored by one wave per front with the
+    front in registers (sl_factor_regs_kernel); HIOPAMD_SL_REGS=0 (read when the object is created) keeps the LDS kernel of rounds 4-5
+    everywhere.  Same inertia, same solution to rounding, and the register kernel is really the one in use."""
+    A = banded(n, bw, seed=11)
+    if indef:
+        A = quasi_definite(A, n // 4, seed=5)
+    b = np.random.default_rng(8).uniform(-1, 1, n)
+    out = {}
+    for regs in ("1", "0"):
+        monkeypatch.setenv("HIOPAMD_SL_REGS", regs)
+        S = SparseLdl(ctx, A)
+        assert S.rc == 0
+        inf = S.info()
+        assert (inf["reg_levels"] >= 1) == (regs == "1"), inf
+        inertia = S.factorize()
+        rc, x = S.solve(b)
+        assert rc == 0
+        out[regs] = (inertia, x)
+        S.close()
+    assert out["1"][0] == out["0"][0] == ((n_negative_diagonal(A), 0) if indef else (0, 0))
+    x1, x0 = out["1"][1], out["0"][1]
+    assert np.abs(A @ x1 - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    assert np.abs(x1 - x0).max() <= 1e-11 * max(1.0, np.abs(x0).max())
 
 
 @pytest.mark.parametrize("nblocks,bs,border", [(2000, 6, 33), (20000, 5, 128), (60000, 4, 512)])
