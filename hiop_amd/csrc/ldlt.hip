@@ -40,6 +40,7 @@ namespace hiopamd {
 
 constexpr int LD_NB = 256;   // super-panel rows (K of the trailing update)
 constexpr int LD_nb = 64;    // panel rows
+constexpr int LD_PAD_MIN = 1024;   // odd orders from here on are factored as the even order n + 1 (hiopamd_linsolver::npad)
 constexpr int LD_TM = 128;   // update tile
 constexpr int LD_TN = 128;
 constexpr int LD_KT = 16;    // k-depth staged in LDS per step
@@ -2034,6 +2035,23 @@ __global__ __launch_bounds__(kBlock) void ldlt_triu_copy_kernel(int N, const dou
   }
 }
 
+// the same tiles between two pitches (8 bytes per lane: one of the pitches is odd) — an ODD order is factored as the even order N + 1
+// (hiopamd_linsolver::npad): `unit` also writes the decoupled last column of the padded copy, zeros and a one on the diagonal
+__global__ __launch_bounds__(kBlock) void ldlt_triu_repitch_kernel(int N, const double* __restrict__ src, int64_t lds, double* __restrict__ dst,
+                                                                   int64_t ldd, int unit)
+{
+  const int I = blockIdx.y, J = blockIdx.x;
+  if(J < I) return;
+  const int r0 = 128 * I, c0 = 128 * J;
+  const int c = threadIdx.x & 127, rq = threadIdx.x >> 7;
+  if(c0 + c < N)
+    for(int r = rq; r < 128; r += 2)
+      if(r0 + r < N) dst[(int64_t)(r0 + r) * ldd + c0 + c] = src[(int64_t)(r0 + r) * lds + c0 + c];
+  if(unit && J == (int)gridDim.x - 1)
+    for(int r = threadIdx.x; r < 128; r += kBlock)
+      if(r0 + r <= N) dst[(int64_t)(r0 + r) * ldd + N] = (r0 + r == N) ? 1.0 : 0.0;
+}
+
 }  // namespace hiopamd
 
 using namespace hiopamd;
@@ -2401,6 +2419,13 @@ struct hiopamd_linsolver {
   // the callers of the reference's matrixChanged() cannot re-assemble; the native KKT objects re-assemble themselves and switch it off)
   bool retry_copy = true;
   double* Mretry = nullptr;   // n x n, upper 128 x 128 tiles used; allocated on first use
+  // Odd orders (round 6): the 16-byte tile form of the dataflow kernels needs an even order and pitch — N = 8191 took 9.2 ms against
+  // 5.6 ms for 8192 in the 8-byte form.  An odd n >= LD_PAD_MIN is factored as diag(M, 1) of order npad = n + 1 in Mpad (upper triangle
+  // copied in, factor copied back: 2 x 0.13 ms; M itself stays as assembled until the factorisation has succeeded, so it is also the
+  // retry copy); every workspace of the factorisation is sized for npad, the solves work on M with n as before (the inverse of the
+  // last diagonal block of diag(M, 1) is diag(inverse, 1): its leading part is what the solve reads).
+  int npad = 0;               // order the dataflow factorisation runs at (n or n + 1)
+  double* Mpad = nullptr;     // npad x npad, allocated on first use
   long df_timeouts = 0;       // bounded waits that expired over the object's life (hiopamd_linsolver_timeouts)
   // pivoted mode (Bunch-Kaufman, ldlt_bk.hip): hiopamd_linsolver_set_pivoting
   bool pivoted = false;
@@ -2884,19 +2909,22 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
 {
   ls->ctx = ctx;
   ls->n = n;
+  const bool pad_off = std::getenv("HIOPAMD_LDLT_PAD") && std::atoi(std::getenv("HIOPAMD_LDLT_PAD")) == 0;   // (timing comparisons)
+  ls->npad = (n % 2 == 1 && n >= LD_PAD_MIN && !pad_off) ? n + 1 : n;
   const size_t nn = (size_t)(n > 0 ? n : 1);
+  const size_t nf = (size_t)(ls->npad > 0 ? ls->npad : 1);   // the factorisation's workspaces: the padded order
   HIOPAMD_CHECK(hipMalloc((void**)&ls->M, sizeof(double) * nn * nn));
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->dinv, sizeof(double) * nn));
-  ls->nvb = df_nvb_for(n);
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->dinv, sizeof(double) * nf));
+  ls->nvb = df_nvb_for(ls->npad);
   ls->df.nvb = ls->nvb;
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nn * LD_NB * (size_t)ls->nvb));   // row panels of nvb consecutive super-panels
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nf * LD_NB * (size_t)ls->nvb));   // row panels of nvb consecutive super-panels
   HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nn + LD_nb - 1) / LD_nb)));
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB)));   // blocks + transposes
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nf + LD_nb - 1) / LD_nb)));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nf + LD_NB - 1) / LD_NB)));   // blocks + transposes
   // The compact blocks are filled by the kernels that produce them with the entries that EXIST (upper triangle, rows and columns below
   // the order): the padding of a ragged last block is defined here, once — zero, and no kernel writes it afterwards (round 6: it was
   // whatever the allocation held, and the block inversion read it; see DESIGN.md 3.1, "the round-5 gate failure")
-  HIOPAMD_CHECK(hipMemsetAsync(ls->Cd, 0, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nn + LD_NB - 1) / LD_NB), ctx->stream));
+  HIOPAMD_CHECK(hipMemsetAsync(ls->Cd, 0, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nf + LD_NB - 1) / LD_NB), ctx->stream));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->d_info, 64));
   {
     // dataflow solve: inverted diagonal blocks, product slots, flags, and the task list in issue order
@@ -2941,7 +2969,7 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
   {
     // dataflow factorisation: task tables and flags (HIOPAMD_DF=0 in the environment selects the stepwise kernels)
     DfDevice& df = ls->df;
-    df.plan = df_build_plan(n);
+    df.plan = df_build_plan(ls->npad);
     df.enabled = !(std::getenv("HIOPAMD_DF") && std::atoi(std::getenv("HIOPAMD_DF")) == 0);
     const DfPlan& P = df.plan;
     if(P.nchain >= 3) {
@@ -2975,6 +3003,7 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->ybuf);
   (void)hipFree(ls->Msave);
   (void)hipFree(ls->Mretry);
+  (void)hipFree(ls->Mpad);
   (void)hipFree(ls->rbuf);
   (void)hipFree(ls->Dblk);
   (void)hipFree(ls->Cd);
@@ -3200,13 +3229,32 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
   }
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_FACT);   // hiopLinSolverSymDenseLapack.hpp:80-125 (tmFactTime; flopsFact = n^3/3)
   ls->flops_fact += (double)n * n * n / 3.0;
-  auto factor_once = [&]() {
+  const dim3 tgrid((unsigned)((n + 127) / 128), (unsigned)((n + 127) / 128));
+  const bool padded = ls->npad > n;
+  auto factor_once = [&]() -> int {
     // (see DfDevice::skip_once)
     const bool df_was = ls->df.enabled;
     const bool df_this = df_was && !ls->df.skip_once;
     ls->df.enabled = df_this;
     ls->df.skip_once = false;
-    const int r = ldlt_factor_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+    int r;
+    if(df_this && padded) {
+      // the even order n + 1: diag(M, 1), upper triangle; the factor comes back into M (which is untouched if the kernels give up)
+      const int np = ls->npad;
+      if(!ls->Mpad) {
+        // (the lower triangle is never assembled, but the diagonal tiles are read and written as whole tiles: defined once, like a caller's matrix)
+        HIOPAMD_CHECK(hipMalloc((void**)&ls->Mpad, sizeof(double) * (size_t)np * np));
+        HIOPAMD_CHECK(hipMemsetAsync(ls->Mpad, 0, sizeof(double) * (size_t)np * np, ls->ctx->stream));
+      }
+      hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->M, (int64_t)n, ls->Mpad, (int64_t)np, 1);
+      r = ldlt_factor_impl(ls->ctx, np, ls->Mpad, np, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+      if(r == HIOPAMD_OK || r == HIOPAMD_ERR_SINGULAR) {
+        hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mpad, (int64_t)np, ls->M, (int64_t)n, 0);
+        ls->inertia[0] -= 1;   // the unit pivot
+      }
+    } else {
+      r = ldlt_factor_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
+    }
     ls->df.enabled = df_was;
     if(df_this && r == HIOPAMD_ERR_TIMEOUT) {
       ls->df.skip_once = true;
@@ -3222,8 +3270,7 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
   // the retry copy: only when this call will run the dataflow kernels (the stepwise kernels have no bounded waits) and no other copy
   // of the matrix exists (safe mode keeps Msave)
   const bool df_next = ls->df.enabled && !ls->df.skip_once && ls->df.flags && ls->df.plan.nchain >= 3;
-  const bool use_retry = ls->retry_copy && !ls->safe_mode && df_next && n > 0;
-  const dim3 tgrid((unsigned)((n + 127) / 128), (unsigned)((n + 127) / 128));
+  const bool use_retry = ls->retry_copy && !ls->safe_mode && df_next && n > 0 && !padded;   // (padded: M is not written before the factorisation has succeeded)
   if(use_retry) {
     if(!ls->Mretry) HIOPAMD_CHECK(hipMalloc((void**)&ls->Mretry, sizeof(double) * (size_t)n * n));
     hipLaunchKernelGGL(ldlt_triu_copy_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->M, ls->Mretry, (int64_t)n);
@@ -3244,6 +3291,8 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
     } else if(use_retry) {
       hipLaunchKernelGGL(ldlt_triu_copy_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mretry, ls->M, (int64_t)n);
       rc = factor_once();   // (skip_once is set: the stepwise kernels)
+    } else if(padded && ls->retry_copy) {
+      rc = factor_once();   // (M is intact; skip_once is set: the stepwise kernels, on M itself)
     }
   }
   if(rc == HIOPAMD_ERR_SINGULAR) {

@@ -22,3 +22,12 @@ x = b.clone(); ls.solve(x); ctx.sync()
 Mf = M + torch.triu(M, 1).T
 r = (Mf @ x - b).abs().max().item() / b.abs().max().item()
 print(f"N={N} factor ms: " + " ".join(f"{t*1e3:.3f}" for t in ts) + f"  nneg={nneg} resid={r:.1e}")
+ss = []
+for rep in range(6):
+    x = b.clone(); ctx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ls.solve(x)
+    ctx.sync()
+    ss.append((time.perf_counter() - t0) / 3)
+print(f"N={N} solve ms (of 3 in a row): " + " ".join(f"{t*1e3:.3f}" for t in ss))

@@ -100,7 +100,8 @@ def test_banded(ctx, n, bw):
         check(ctx, Ai, n_negative_diagonal(Ai))
 
 
-@pytest.mark.parametrize("n,bw,indef", [(30000, 3, False), (200000, 5, False), (60000, 5, True), (40000, 2, True)])
+# (orders of 30 x a power of two: the balanced dissection ends in leaves of ~25-28 columns + 2 bw rows, inside the register kernel's 40 rows)
+@pytest.mark.parametrize("n,bw,indef", [(30 * 1024, 3, False), (30 * 4096, 5, False), (30 * 2048, 5, True), (28 * 1024, 2, True)])
 def test_register_resident_fronts_against_the_lds_kernel(ctx, n, bw, indef, monkeypatch):
     """Round 6: the levels with small fronts and many pivots (the leaves of a banded pattern) are factored by one wave per front with the
     front in registers (sl_factor_regs_kernel); HIOPAMD_SL_REGS=0 (read when the object is created) keeps the LDS kernel of rounds 4-5
