@@ -2052,6 +2052,13 @@ __global__ __launch_bounds__(kBlock) void ldlt_triu_repitch_kernel(int N, const 
       if(r0 + r <= N) dst[(int64_t)(r0 + r) * ldd + N] = (r0 + r == N) ? 1.0 : 0.0;
 }
 
+// dst[0, cnt) = src[0, n) followed by zeros (a right-hand side into / out of the padded order)
+__global__ __launch_bounds__(kBlock) void ldlt_vec_pad_kernel(int n, const double* __restrict__ src, double* __restrict__ dst, int cnt)
+{
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if(i < cnt) dst[i] = (i < n) ? src[i] : 0.0;
+}
+
 }  // namespace hiopamd
 
 using namespace hiopamd;
@@ -2420,12 +2427,14 @@ struct hiopamd_linsolver {
   bool retry_copy = true;
   double* Mretry = nullptr;   // n x n, upper 128 x 128 tiles used; allocated on first use
   // Odd orders (round 6): the 16-byte tile form of the dataflow kernels needs an even order and pitch — N = 8191 took 9.2 ms against
-  // 5.6 ms for 8192 in the 8-byte form.  An odd n >= LD_PAD_MIN is factored as diag(M, 1) of order npad = n + 1 in Mpad (upper triangle
-  // copied in, factor copied back: 2 x 0.13 ms; M itself stays as assembled until the factorisation has succeeded, so it is also the
-  // retry copy); every workspace of the factorisation is sized for npad, the solves work on M with n as before (the inverse of the
-  // last diagonal block of diag(M, 1) is diag(inverse, 1): its leading part is what the solve reads).
-  int npad = 0;               // order the dataflow factorisation runs at (n or n + 1)
+  // 5.6 ms for 8192 in the 8-byte form, and its solves 0.36 ms against 0.18 (256-row blocks at an odd pitch instead of 512-row blocks).
+  // An odd n >= LD_PAD_MIN is factored and solved as diag(M, 1) of order npad = n + 1 in Mpad: the upper triangle is copied in and the
+  // factor copied back into M (2 x 0.13 ms; what the caller reads through sys_matrix is the factor, as for an even order), a right-hand
+  // side goes through xpad.  M itself stays as assembled until the factorisation has succeeded, so it is also the retry copy.  Every
+  // workspace and task table of the object is built for npad; the pivoted mode has its own storage and works on M.
+  int npad = 0;               // order the factorisation and the solves run at (n or n + 1)
   double* Mpad = nullptr;     // npad x npad, allocated on first use
+  double* xpad = nullptr;     // npad
   long df_timeouts = 0;       // bounded waits that expired over the object's life (hiopamd_linsolver_timeouts)
   // pivoted mode (Bunch-Kaufman, ldlt_bk.hip): hiopamd_linsolver_set_pivoting
   bool pivoted = false;
@@ -2918,7 +2927,8 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
   ls->nvb = df_nvb_for(ls->npad);
   ls->df.nvb = ls->nvb;
   HIOPAMD_CHECK(hipMalloc((void**)&ls->V, sizeof(double) * nf * LD_NB * (size_t)ls->nvb));   // row panels of nvb consecutive super-panels
-  HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nn));
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->ybuf, sizeof(double) * nf));
+  if(ls->npad > n) HIOPAMD_CHECK(hipMalloc((void**)&ls->xpad, sizeof(double) * nf));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Dblk, sizeof(double) * (LD_nb * LD_nb + 4 * LD_SB * LD_SB) * ((nf + LD_nb - 1) / LD_nb)));
   HIOPAMD_CHECK(hipMalloc((void**)&ls->Cd, sizeof(double) * 2 * (size_t)LD_NB * LD_NB * ((nf + LD_NB - 1) / LD_NB)));   // blocks + transposes
   // The compact blocks are filled by the kernels that produce them with the entries that EXIST (upper triangle, rows and columns below
@@ -2929,9 +2939,9 @@ static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
   {
     // dataflow solve: inverted diagonal blocks, product slots, flags, and the task list in issue order
     // block size of the task graph: 512 for orders that are multiples of 512 (half the serial block steps), 256 otherwise
-    const int FB = (n >= 2048 && n % 512 == 0) ? 512 : SV_B;
+    const int FB = (ls->npad >= 2048 && ls->npad % 512 == 0) ? 512 : SV_B;
     const int FR = FB / 64;
-    const int nb = (int)((nn + FB - 1) / FB);
+    const int nb = (int)((nf + FB - 1) / FB);
     ls->fl_B = FB;
     ls->fl_nb = nb;
     ls->fl_lead = (FB == 512 ? 2 : FL_LEAD);
@@ -3004,6 +3014,7 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
   (void)hipFree(ls->Msave);
   (void)hipFree(ls->Mretry);
   (void)hipFree(ls->Mpad);
+  (void)hipFree(ls->xpad);
   (void)hipFree(ls->rbuf);
   (void)hipFree(ls->Dblk);
   (void)hipFree(ls->Cd);
@@ -3238,8 +3249,9 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
     ls->df.enabled = df_this;
     ls->df.skip_once = false;
     int r;
-    if(df_this && padded) {
-      // the even order n + 1: diag(M, 1), upper triangle; the factor comes back into M (which is untouched if the kernels give up)
+    if(padded) {
+      // the even order n + 1: diag(M, 1), upper triangle (dataflow or stepwise kernels alike: the solves' tables are built for that
+      // order); the factor comes back into M, which is untouched if the kernels give up
       const int np = ls->npad;
       if(!ls->Mpad) {
         // (the lower triangle is never assembled, but the diagonal tiles are read and written as whole tiles: defined once, like a caller's matrix)
@@ -3292,7 +3304,7 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
       hipLaunchKernelGGL(ldlt_triu_copy_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mretry, ls->M, (int64_t)n);
       rc = factor_once();   // (skip_once is set: the stepwise kernels)
     } else if(padded && ls->retry_copy) {
-      rc = factor_once();   // (M is intact; skip_once is set: the stepwise kernels, on M itself)
+      rc = factor_once();   // (M is intact; skip_once is set: the stepwise kernels)
     }
   }
   if(rc == HIOPAMD_ERR_SINGULAR) {
@@ -3323,6 +3335,22 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
   return HIOPAMD_OK;
 }
 
+// x <- (U^T D U)^-1 x with the object's factor, at the order the object works at
+static int linsolver_solve_factor(hiopamd_linsolver* ls, double* x, int nrhs)
+{
+  const int n = ls->n, np = ls->npad;
+  if(np == n) return ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, x, nrhs, ls->Cd, ls);
+  for(int q = 0; q < nrhs; ++q) {
+    double* xq = x + (int64_t)q * n;
+    hipLaunchKernelGGL(ldlt_vec_pad_kernel, dim3(grid_for(np)), dim3(kBlock), 0, ls->ctx->stream, n, xq, ls->xpad, np);
+    const int rc = ldlt_solve_impl(ls->ctx, np, ls->Mpad, np, ls->dinv, ls->ybuf, ls->xpad, 1, ls->Cd, ls);
+    if(rc != HIOPAMD_OK) return rc;
+    hipLaunchKernelGGL(ldlt_vec_pad_kernel, dim3(grid_for(n)), dim3(kBlock), 0, ls->ctx->stream, n, ls->xpad, xq, n);
+  }
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
+
 // safe mode: x <- K_delta^-1 x, then refined against the saved K (see hiopamd_linsolver_set_safe_mode); *ok = 0 when the
 // refinement did not reach 1e-13 (||K|| ||x|| + ||b||) in 10 steps
 static int safe_refined_solve(hiopamd_linsolver* ls, double* x, bool* ok_out)
@@ -3336,7 +3364,7 @@ static int safe_refined_solve(hiopamd_linsolver* ls, double* x, bool* ok_out)
   double bn = 0.0;
   rc = hiopamd_vec_infnorm(ls->ctx, n, b, &bn);
   if(rc != HIOPAMD_OK) return rc;
-  rc = ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, x, 1, ls->Cd, ls);
+  rc = linsolver_solve_factor(ls, x, 1);
   if(rc != HIOPAMD_OK) return rc;
   int it = 0;
   double rel = 0.0;
@@ -3356,7 +3384,7 @@ static int safe_refined_solve(hiopamd_linsolver* ls, double* x, bool* ok_out)
       break;
     }
     if(it == 10) break;
-    rc = ldlt_solve_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->ybuf, r, 1, ls->Cd, ls);     // dx = K_delta^-1 r
+    rc = linsolver_solve_factor(ls, r, 1);                                                // dx = K_delta^-1 r
     if(rc == HIOPAMD_OK) rc = hiopamd_vec_axpy(ls->ctx, n, x, 1.0, r);
     if(rc != HIOPAMD_OK) return rc;
   }
@@ -3373,7 +3401,7 @@ int hiopamd_linsolver_solve(hiopamd_linsolver* ls, double* rhs_inout, int nrhs)
   SpanScope span(ls->ctx, HIOPAMD_SPAN_LINSOLV_TRIU_SOLVES);   // :173-195 (tmTriuSolves; flopsTriuSolves = 2 n^2 per rhs)
   ls->flops_triu += 2.0 * (double)ls->n * ls->n * nrhs;
   if(ls->pivoted) return hiopamd_ldlt_bk_solve(ls->bk, ls->M, ls->n, rhs_inout, nrhs);
-  if(!ls->safe_mode) return ldlt_solve_impl(ls->ctx, ls->n, ls->M, ls->n, ls->dinv, ls->ybuf, rhs_inout, nrhs, ls->Cd, ls);
+  if(!ls->safe_mode) return linsolver_solve_factor(ls, rhs_inout, nrhs);
   for(int q = 0; q < nrhs; ++q) {
     bool ok = false;
     const int rc = safe_refined_solve(ls, rhs_inout + (int64_t)q * ls->n, &ok);

@@ -23,7 +23,7 @@ CHILD = textwrap.dedent('''
     from hiop_amd.runtime import Context
     from hiop_amd.kkt import LinSolverSymDense
     from hiop_amd._lib import HiopAmdError
-    N = 1536
+    N = int(sys.argv[1])
     ctx = Context(0)
     g = torch.Generator(device="cuda"); g.manual_seed(3)
     M = torch.rand(N, N, generator=g, device="cuda", dtype=torch.float64) * 1e-3
@@ -60,9 +60,11 @@ CHILD = textwrap.dedent('''
 ''')
 
 
-def test_timeout_recovery_sequence(ctx):
+# (1537: an odd order — factored and solved as the even order 1538 in a padded copy, the caller's matrix being the retry copy)
+@pytest.mark.parametrize("N", [1536, 1537])
+def test_timeout_recovery_sequence(ctx, N):
     env = dict(os.environ, HIOPAMD_DF_TIMEOUT_MS="0.001")
-    r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=600,
+    r = subprocess.run([sys.executable, "-c", CHILD, str(N)], capture_output=True, text=True, env=env, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     bare = [l for l in r.stdout.splitlines() if l.startswith("BARE")][0].split()[1:]
@@ -88,7 +90,7 @@ CHECK_CHILD = textwrap.dedent('''
     from hiop_amd.kkt import LinSolverSymDense
     ctx = Context(0)
     g = torch.Generator(device="cuda"); g.manual_seed(5)
-    for N in (8192, 2049, 1536):
+    for N in (8192, 2049, 1536, 4097):
         M = torch.rand(N, N, generator=g, device="cuda", dtype=torch.float64) * 1e-3
         M = M + M.T + torch.eye(N, device="cuda", dtype=torch.float64) * 10.0
         ls = LinSolverSymDense(ctx, N)
