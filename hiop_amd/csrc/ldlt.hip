@@ -40,7 +40,7 @@ namespace hiopamd {
 
 constexpr int LD_NB = 256;   // super-panel rows (K of the trailing update)
 constexpr int LD_nb = 64;    // panel rows
-constexpr int LD_PAD_MIN = 1024;   // odd orders from here on are factored as the even order n + 1 (hiopamd_linsolver::npad)
+constexpr int LD_PAD_MIN = 1024;   // orders from here on may be factored at a padded order (hiopamd_linsolver::npad, ldlt_padded_order)
 constexpr int LD_TM = 128;   // update tile
 constexpr int LD_TN = 128;
 constexpr int LD_KT = 16;    // k-depth staged in LDS per step
@@ -2035,10 +2035,10 @@ __global__ __launch_bounds__(kBlock) void ldlt_triu_copy_kernel(int N, const dou
   }
 }
 
-// the same tiles between two pitches (8 bytes per lane: one of the pitches is odd) — an ODD order is factored as the even order N + 1
-// (hiopamd_linsolver::npad): `unit` also writes the decoupled last column of the padded copy, zeros and a one on the diagonal
+// the same tiles between two pitches (8 bytes per lane: either pitch may be odd) — the solver object factors an order that the kernels'
+// fast forms do not take as a larger one, diag(M, I), in a padded copy (hiopamd_linsolver::npad)
 __global__ __launch_bounds__(kBlock) void ldlt_triu_repitch_kernel(int N, const double* __restrict__ src, int64_t lds, double* __restrict__ dst,
-                                                                   int64_t ldd, int unit)
+                                                                   int64_t ldd)
 {
   const int I = blockIdx.y, J = blockIdx.x;
   if(J < I) return;
@@ -2047,9 +2047,13 @@ __global__ __launch_bounds__(kBlock) void ldlt_triu_repitch_kernel(int N, const 
   if(c0 + c < N)
     for(int r = rq; r < 128; r += 2)
       if(r0 + r < N) dst[(int64_t)(r0 + r) * ldd + c0 + c] = src[(int64_t)(r0 + r) * lds + c0 + c];
-  if(unit && J == (int)gridDim.x - 1)
-    for(int r = threadIdx.x; r < 128; r += kBlock)
-      if(r0 + r <= N) dst[(int64_t)(r0 + r) * ldd + N] = (r0 + r == N) ? 1.0 : 0.0;
+}
+// ... and the decoupled columns N .. NP - 1 of that copy: zeros, ones on the diagonal (one workgroup per row, upper triangle)
+__global__ __launch_bounds__(kBlock) void ldlt_pad_tail_kernel(int N, int NP, double* __restrict__ dst, int64_t ldd)
+{
+  const int r = blockIdx.x;
+  for(int c = N + threadIdx.x; c < NP; c += kBlock)
+    if(c >= r) dst[(int64_t)r * ldd + c] = (c == r) ? 1.0 : 0.0;
 }
 
 // dst[0, cnt) = src[0, n) followed by zeros (a right-hand side into / out of the padded order)
@@ -2426,13 +2430,15 @@ struct hiopamd_linsolver {
   // the callers of the reference's matrixChanged() cannot re-assemble; the native KKT objects re-assemble themselves and switch it off)
   bool retry_copy = true;
   double* Mretry = nullptr;   // n x n, upper 128 x 128 tiles used; allocated on first use
-  // Odd orders (round 6): the 16-byte tile form of the dataflow kernels needs an even order and pitch — N = 8191 took 9.2 ms against
-  // 5.6 ms for 8192 in the 8-byte form, and its solves 0.36 ms against 0.18 (256-row blocks at an odd pitch instead of 512-row blocks).
-  // An odd n >= LD_PAD_MIN is factored and solved as diag(M, 1) of order npad = n + 1 in Mpad: the upper triangle is copied in and the
-  // factor copied back into M (2 x 0.13 ms; what the caller reads through sys_matrix is the factor, as for an even order), a right-hand
-  // side goes through xpad.  M itself stays as assembled until the factorisation has succeeded, so it is also the retry copy.  Every
-  // workspace and task table of the object is built for npad; the pivoted mode has its own storage and works on M.
-  int npad = 0;               // order the factorisation and the solves run at (n or n + 1)
+  // Padded orders (round 6).  The kernels have fast forms for SOME orders: the 16-byte tile form of the dataflow kernels needs an even
+  // order and pitch (N = 8191 took 8.9 ms against 5.2 ms for 8192 in the 8-byte form); an order that is not a multiple of 256 leaves
+  // its last two super-panels to the stepwise kernels (8193 -> 8194: 5.9 ms); the solve runs on 512-row blocks only for multiples of
+  // 512 (0.18 ms against 0.36 on 256-row blocks at N ~ 8192).  An order n >= LD_PAD_MIN is therefore factored and solved as
+  // diag(M, I) of order npad >= n in Mpad, npad chosen by ldlt_padded_order(): the upper triangle is copied in and the factor copied
+  // back into M (2 x 0.13 ms at 8192; what the caller reads through sys_matrix is the factor, as ever), a right-hand side goes through
+  // xpad.  M itself stays as assembled until the factorisation has succeeded, so it is also the retry copy.  Every workspace and task
+  // table of the object is built for npad; the pivoted mode has its own storage and works on M.
+  int npad = 0;               // order the factorisation and the solves run at (>= n)
   double* Mpad = nullptr;     // npad x npad, allocated on first use
   double* xpad = nullptr;     // npad
   long df_timeouts = 0;       // bounded waits that expired over the object's life (hiopamd_linsolver_timeouts)
@@ -2914,12 +2920,41 @@ int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
   return HIOPAMD_OK;
 }
 
+// The order a solver object of order n works at (hiopamd_linsolver::npad): n itself, n made even, the next multiple of 256 or the next
+// multiple of 512 — the larger ones only when a cost model of one factorisation + three solves + the copies calls them at least 5 %
+// cheaper than the even order.  The model's constants are this machine's measurements (ms; scripts/factor_time.py,
+// profiles/r06_probes/call20-24_*), x = order / 8192: the dataflow factorisation max(5.2 x^3, 0.1 per super-panel) — throughput above
+// ~6000, the chain's latency below —, x 1.7 in the 8-byte tile form of an odd order, + 0.15 + 0.5 x^2 for the stepwise tail of an order
+// that is not a multiple of 256; a solve = 11 us per block step (512-row blocks for multiples of 512 from 2048 on, else 256) + 0.05 x^2;
+// copying the triangle in and out 0.27 x^2 (against 0.13 x^2 for the retry copy of an unpadded order).
+// HIOPAMD_LDLT_PAD=0: never pad, =1: parity only (timing comparisons).
+static int ldlt_padded_order(int n)
+{
+  if(n < LD_PAD_MIN) return n;
+  int mode = 2;
+  if(const char* e = std::getenv("HIOPAMD_LDLT_PAD")) mode = std::atoi(e);
+  if(mode <= 0) return n;
+  auto cost = [&](int c) {
+    const double x = c / 8192.0;
+    double t = std::max(5.2 * x * x * x, 0.1 * c / LD_NB) * ((c & 1) ? 1.7 : 1.0) + ((c % LD_NB) ? 0.15 + 0.5 * x * x : 0.0);
+    const int FB = (c >= 2048 && c % 512 == 0) ? 512 : 256;
+    t += 3.0 * (0.011 * ((c + FB - 1) / FB) + 0.05 * x * x);
+    t += (c != n ? 0.27 : 0.13) * x * x;
+    return t;
+  };
+  const int even = n + (n & 1);
+  int best = even;
+  if(mode >= 2)
+    for(int c : {(n + 255) / 256 * 256, (n + 511) / 512 * 512})
+      if(cost(c) < 0.95 * cost(even) && cost(c) < cost(best)) best = c;
+  return best;
+}
+
 static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n)
 {
   ls->ctx = ctx;
   ls->n = n;
-  const bool pad_off = std::getenv("HIOPAMD_LDLT_PAD") && std::atoi(std::getenv("HIOPAMD_LDLT_PAD")) == 0;   // (timing comparisons)
-  ls->npad = (n % 2 == 1 && n >= LD_PAD_MIN && !pad_off) ? n + 1 : n;
+  ls->npad = ldlt_padded_order(n);
   const size_t nn = (size_t)(n > 0 ? n : 1);
   const size_t nf = (size_t)(ls->npad > 0 ? ls->npad : 1);   // the factorisation's workspaces: the padded order
   HIOPAMD_CHECK(hipMalloc((void**)&ls->M, sizeof(double) * nn * nn));
@@ -3250,7 +3285,7 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
     ls->df.skip_once = false;
     int r;
     if(padded) {
-      // the even order n + 1: diag(M, 1), upper triangle (dataflow or stepwise kernels alike: the solves' tables are built for that
+      // the padded order: diag(M, I), upper triangle (dataflow or stepwise kernels alike: the solves' tables are built for that
       // order); the factor comes back into M, which is untouched if the kernels give up
       const int np = ls->npad;
       if(!ls->Mpad) {
@@ -3258,11 +3293,12 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
         HIOPAMD_CHECK(hipMalloc((void**)&ls->Mpad, sizeof(double) * (size_t)np * np));
         HIOPAMD_CHECK(hipMemsetAsync(ls->Mpad, 0, sizeof(double) * (size_t)np * np, ls->ctx->stream));
       }
-      hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->M, (int64_t)n, ls->Mpad, (int64_t)np, 1);
+      hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->M, (int64_t)n, ls->Mpad, (int64_t)np);
+      hipLaunchKernelGGL(ldlt_pad_tail_kernel, dim3((unsigned)np), dim3(kBlock), 0, ls->ctx->stream, n, np, ls->Mpad, (int64_t)np);
       r = ldlt_factor_impl(ls->ctx, np, ls->Mpad, np, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
       if(r == HIOPAMD_OK || r == HIOPAMD_ERR_SINGULAR) {
-        hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mpad, (int64_t)np, ls->M, (int64_t)n, 0);
-        ls->inertia[0] -= 1;   // the unit pivot
+        hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mpad, (int64_t)np, ls->M, (int64_t)n);
+        ls->inertia[0] -= np - n;   // the unit pivots
       }
     } else {
       r = ldlt_factor_impl(ls->ctx, n, ls->M, n, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);

@@ -504,10 +504,10 @@ typedef struct hiopamd_linsolver hiopamd_linsolver;
 int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n);
 int hiopamd_linsolver_destroy(hiopamd_linsolver* ls);
 /* device pointer of the n x n row-major system matrix (ld = n); the KKT class writes its upper triangle.  After a successful
- * hiopamd_linsolver_matrix_changed it holds the factor (U above the diagonal, D on it).  An odd order n >= 1024 is factored and solved
- * internally as the even order n + 1 in a padded copy (the kernels' 16-byte accesses need an even pitch: 5.3 instead of 8.9 ms at
- * n = 8191); the caller sees no difference — same matrix view, same factor in it, same inertia — except that the matrix is not
- * written before the factorisation has succeeded. */
+ * hiopamd_linsolver_matrix_changed it holds the factor (U above the diagonal, D on it).  An order n >= 1024 that the kernels' fast
+ * forms do not take (odd; not a multiple of 256 / 512) is factored and solved internally as diag(M, I) of a larger order in a padded
+ * copy (n = 8191: 5.3 instead of 8.9 ms; n = 8000: 5.8 instead of 6.2 ms per factorisation + 3 solves); the caller sees no difference —
+ * same matrix view, same factor in it, same inertia — except that the matrix is not written before the factorisation has succeeded. */
 double* hiopamd_linsolver_sys_matrix(hiopamd_linsolver* ls);
 int hiopamd_linsolver_n(const hiopamd_linsolver* ls);
 /* matrixChanged(): factorise in place; *n_neg_host = number of negative pivots, or -1 if a pivot is
