@@ -63,9 +63,14 @@ struct SlStopwatch {
 }  // namespace
 
 #ifndef HIOPAMD_SL_LEAF
-#define HIOPAMD_SL_LEAF 48
+#define HIOPAMD_SL_LEAF 32
 #endif
-constexpr int SL_LEAF = HIOPAMD_SL_LEAF;   // columns per supernode (leaf regions, separator chunks); < 64: a front's pivot rows fit one register per lane
+// columns per supernode (leaf regions, separator chunks); < 64: a front's pivot rows fit one register per lane.  32 since round 6 (48
+// before): a leaf of a narrow-band pattern then has at most 32 + 2 x bandwidth rows and is factored in registers (sl_factor_regs_kernel,
+// <= 40 rows) whatever the order — with 48 the leaves of n = 2e5 / 7e5, bandwidth 5 came out at 53 rows (LDS kernel: 0.31 / 0.67 ms per
+// factorisation against 0.21 / 0.40), those of n = 1e6 at 39 by luck; the solves pay 0-5 % for the extra level
+// (profiles/r06_probes/call25_*).
+constexpr int SL_LEAF = HIOPAMD_SL_LEAF;
 constexpr int SL_PACK = 8;           // columns of a supernode that packs several tiny independent components
 constexpr int SL_T = 128;            // rows of a front that is eliminated in LDS (128 x 129 doubles = 132 KB)
 constexpr int SL_ROOT_MAX = 20480;   // order of the dense root (3.4 GB)
