@@ -392,6 +392,60 @@ def sparse_condensed_bench(ctx, a, n=1_000_000, pattern="sparse_ex2"):
     return out
 
 
+def mds_other_orders_bench(ctx, a, dims=((4000, 4000), (4096, 4092), (3500, 3000))):
+    """The headline step — assemble + factor + `solves` solveCompressed of the MDS condensed KKT — at orders N = nd + neq + 3 that are
+    NOT the headline's 8192 (which is even, a multiple of 256 and of 512: the best case of the tile form, of the dataflow's task graph and
+    of the solve's block size at once).  The solver object factors and solves such an order at a padded one ("orders the
+    fast forms do not take"); round 5 ran N = 8003 at 99 it/s and 8191 at 98 against 165 at 8192."""
+    import ctypes as C
+    import torch
+    from hiop_amd.runtime import dev
+    from hiop_amd.kkt import mds_from_problem
+    from hiop_amd._lib import lib
+    from hiop_amd import problems as pr
+    L = lib()
+    out = []
+    for nd, neq in dims:
+        p = pr.mds_ex1_g(a.ns, nd, neq)
+        Dx, Dd = pr.barrier_diagonals(p)
+        rhs = pr.random_rhs(p)
+        kg, dv = mds_from_problem(ctx, p)
+        dv["Dx"], dv["Dd"] = dev(Dx), dev(Dd)
+        kg.set_values(dv["Jcs_v"], dv["Jds_v"], dv["Hss_v"], dv["Jcd"], dv["Jdd"], dv["Hdd"], dv["Dx"], dv["Dd"])
+        rx, ryc, ryd0 = dev(rhs[0]), dev(rhs[1]), dev(rhs[2])
+        ryd = ryd0.clone()
+        dx, dyc, dyd = torch.zeros_like(rx), torch.zeros_like(ryc), torch.zeros_like(ryd)
+        torch.cuda.synchronize()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        n_neg, z = C.c_int(0), C.c_double(0.0)
+        expected_neg = p.neq + p.nineq
+
+        def step():
+            rc = L.hiopamd_kkt_mds_build(kg.h, z, z, z, z)
+            rc = rc or L.hiopamd_kkt_mds_factorize(kg.h, C.byref(n_neg))
+            if rc != 0 or n_neg.value != expected_neg:
+                raise RuntimeError(f"status {rc}, inertia {n_neg.value} != {expected_neg}")
+            for _ in range(a.solves):
+                rc = L.hiopamd_copy_d2d(ctx.h, P(ryd), P(ryd0), ryd.numel() * 8)
+                rc = rc or L.hiopamd_kkt_mds_solve_compressed(kg.h, P(rx), P(ryc), P(ryd), P(dx), P(dyc), P(dyd))
+                if rc != 0:
+                    raise RuntimeError(f"solve_compressed status {rc}")
+
+        for _ in range(a.warmup):
+            step()
+        ctx.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        ctx.sync(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out.append({"N": p.N, "n_dense": p.nxd, "m": p.neq + p.nineq, "value": a.steps / dt, "unit": "KKT iterations/s",
+                    "ms_per_step": 1e3 * dt / a.steps})
+        kg.close()
+    return {"workload": "the headline step at other orders (same n_sparse, other n_dense / m): assemble + factor + "
+                        f"{a.solves} solveCompressed; the solver object works at a padded order", "orders": out}
+
+
 def ipm_end_to_end_bench(ns=4092, nd=4097):
     """The reference's metric measured the reference's way: a REAL interior-point run — hiop_mds_create/solve/destroy_problem of this
     library (include/hiop_amd_interface.h) on the stock MdsEx1 problem at the headline order (ns = 4092 sparse pairs, nd = 4097 dense
@@ -662,6 +716,13 @@ def main():
         except Exception as e:
             sparse_banded = {"error": repr(e)}
 
+    other_orders = None
+    if world == 1 and not a.no_dense and p.N == 8192:
+        try:
+            other_orders = mds_other_orders_bench(ctx, a)
+        except Exception as e:
+            other_orders = {"error": repr(e)}
+
     ipm_e2e = None
     if world == 1 and not a.no_dense:
         try:
@@ -693,6 +754,8 @@ def main():
             out["sparse_condensed_n1e6"] = sparse_c5
         if sparse_banded is not None:
             out["sparse_condensed_banded_n1e6"] = sparse_banded
+        if other_orders is not None:
+            out["mds_other_orders"] = other_orders
         if ipm_e2e is not None:
             out["ipm_end_to_end_N8192"] = ipm_e2e
         if world == 1 and not a.no_cpu_baseline:
