@@ -410,7 +410,8 @@ def test_dataflow_solve_block_boundaries_multi_rhs_and_repeats(ctx, n):
     assert torch.equal(first, X[1])
 
 
-@pytest.mark.parametrize("n1,n2", [(300, 200), (700, 324)])
+# ((900, 437): order 1337 — odd and not a multiple of 256: the object factors and solves it at a padded order, two right-hand sides)
+@pytest.mark.parametrize("n1,n2", [(300, 200), (700, 324), (900, 437)])
 def test_safe_mode_tiny_leading_pivot(ctx, n1, n2):
     """Safe mode (the reference's switch to the Bunch-Kaufman solver, hiopKKTLinSysMDS.cpp:408-430): a quasi-definite matrix
     whose leading pivot is 1e-13 ||A||.  The plain no-pivot factor has element growth ~1e13 — reported by the growth
