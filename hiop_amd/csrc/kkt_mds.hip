@@ -270,8 +270,10 @@ static int kkt_mds_build_impl(hiopamd_kkt_mds* k, MdsDelta dwx, MdsDelta dwd, Md
   const hiopamd_mds_structure& s = k->s;
   const int nxs = s.nxs, nxd = s.nxd, neq = s.neq, nineq = s.nineq;
   const int N = nxd + neq + nineq;
-  double* M = hiopamd_linsolver_sys_matrix(k->ls);
-  const int64_t ld = N;
+  // (an order the solver object works at a padded order is assembled straight into the padded copy, at its pitch)
+  double* M = nullptr;
+  int64_t ld = N;
+  RC(hiopamd_linsolver_assembly_matrix(k->ls, &M, &ld));
   SpanScope span(ctx, HIOPAMD_SPAN_KKT_UPDATE_LINSYS);   // :193-294
 
   // Hxs = Dxs + delta_wx + diag(Hss)                                         (:223-231)
@@ -560,7 +562,14 @@ int hiopamd_kkt_mds_jac_jac_trans(hiopamd_kkt_mds* k, double* W, int64_t ldw)
 }
 
 double* hiopamd_kkt_mds_Dd_inv(hiopamd_kkt_mds* k) { return k ? k->Dd_inv : nullptr; }
-double* hiopamd_kkt_mds_sys_matrix(hiopamd_kkt_mds* k) { return k ? hiopamd_linsolver_sys_matrix(k->ls) : nullptr; }
+// (the N x N view, pitch N: brought up to date first when the object assembles into the solver's padded copy; asynchronous on the
+//  context's stream, like the assembly itself)
+double* hiopamd_kkt_mds_sys_matrix(hiopamd_kkt_mds* k)
+{
+  if(!k) return nullptr;
+  (void)hiopamd_linsolver_sys_matrix_sync(k->ls);
+  return hiopamd_linsolver_sys_matrix(k->ls);
+}
 double* hiopamd_kkt_mds_Hxs(hiopamd_kkt_mds* k) { return k ? k->Hxs : nullptr; }
 hiopamd_linsolver* hiopamd_kkt_mds_linsolver(hiopamd_kkt_mds* k) { return k ? k->ls : nullptr; }
 

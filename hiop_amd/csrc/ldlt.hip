@@ -2441,6 +2441,10 @@ struct hiopamd_linsolver {
   int npad = 0;               // order the factorisation and the solves run at (>= n)
   double* Mpad = nullptr;     // npad x npad, allocated on first use
   double* xpad = nullptr;     // npad
+  // hiopamd_linsolver_assembly_matrix: a caller that assembles at any pitch (the native KKT objects) writes the padded copy itself — the
+  // next matrixChanged factors it where it is (no copy in, no copy back: 2 x 0.13 ms at 8192)
+  bool direct_armed = false;   // the next matrixChanged finds its matrix in Mpad
+  bool factor_in_pad = false;  // the last factorisation was of that kind: M does not show the factor (hiopamd_linsolver_sys_matrix_sync)
   long df_timeouts = 0;       // bounded waits that expired over the object's life (hiopamd_linsolver_timeouts)
   // pivoted mode (Bunch-Kaufman, ldlt_bk.hip): hiopamd_linsolver_set_pivoting
   bool pivoted = false;
@@ -2905,6 +2909,7 @@ int hiopamd_ldlt_solve(hiopamd_ctx* ctx, int n, const double* A, int64_t lda, co
 }
 
 static int linsolver_create_impl(hiopamd_linsolver* ls, hiopamd_ctx* ctx, int n);
+static int linsolver_ensure_pad(hiopamd_linsolver* ls);
 
 int hiopamd_linsolver_create(hiopamd_linsolver** out, hiopamd_ctx* ctx, int n)
 {
@@ -3072,6 +3077,43 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls)
 }
 
 double* hiopamd_linsolver_sys_matrix(hiopamd_linsolver* ls) { return ls ? ls->M : nullptr; }
+
+// Where a caller that can assemble at ANY pitch should write the upper triangle of the next matrix: for an object that works at a
+// padded order, the padded copy itself (*ld_out = that order) — the next hiopamd_linsolver_matrix_changed then factors it where it is.
+// For every other object (and in safe / pivoted mode) the n x n matrix of hiopamd_linsolver_sys_matrix, *ld_out = n.  To be called
+// before every such assembly (it arms ONE matrixChanged).  After a factorisation of this kind hiopamd_linsolver_sys_matrix does not show
+// the factor (hiopamd_linsolver_sys_matrix_sync copies it there), the assembled matrix is overwritten and there is no retry copy: an
+// expired wait is reported as HIOPAMD_ERR_TIMEOUT and the caller assembles again — what the native KKT objects do anyway.
+int hiopamd_linsolver_assembly_matrix(hiopamd_linsolver* ls, double** M_out, int64_t* ld_out)
+{
+  if(!ls || !M_out || !ld_out) return HIOPAMD_ERR_ARG;
+  if(ls->npad > ls->n && !ls->safe_mode && !ls->pivoted) {
+    const int rc = linsolver_ensure_pad(ls);
+    if(rc != HIOPAMD_OK) return rc;
+    ls->direct_armed = true;
+    *M_out = ls->Mpad;
+    *ld_out = ls->npad;
+    return HIOPAMD_OK;
+  }
+  ls->direct_armed = false;
+  *M_out = ls->M;
+  *ld_out = ls->n;
+  return HIOPAMD_OK;
+}
+
+// the n x n view of hiopamd_linsolver_sys_matrix brought up to date with the padded copy (upper triangle): the matrix as assembled
+// through hiopamd_linsolver_assembly_matrix, or — after matrixChanged — its factor.  A no-op for every other object.  Asynchronous on
+// the context's stream.
+int hiopamd_linsolver_sys_matrix_sync(hiopamd_linsolver* ls)
+{
+  if(!ls) return HIOPAMD_ERR_ARG;
+  if(!(ls->Mpad && (ls->direct_armed || ls->factor_in_pad))) return HIOPAMD_OK;
+  const int n = ls->n;
+  const dim3 tgrid((unsigned)((n + 127) / 128), (unsigned)((n + 127) / 128));
+  hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mpad, (int64_t)ls->npad, ls->M, (int64_t)n);
+  HIOPAMD_CHECK(hipGetLastError());
+  return HIOPAMD_OK;
+}
 int hiopamd_linsolver_n(const hiopamd_linsolver* ls) { return ls ? ls->n : -1; }
 
 // Synchronises the context's stream and looks at the dataflow solve's error word (a bounded wait timed out).  On error the
@@ -3143,9 +3185,23 @@ int hiopamd_linsolver_set_solve_dataflow(hiopamd_linsolver* ls, int enable)
 // ||r||_inf <= 1e-13 (||K|| ||x|| + ||b||) or gives up after 10 steps (solve_status then reports failure: the reference's
 // "-1 / solve failed" answer, never a silently wrong direction).
 // ------------------------------------------------------------------------------------------------------------------
+// (a matrix assembled into the padded copy and not factored yet — hiopamd_linsolver_assembly_matrix — is brought into M before the
+//  object switches to a mode that works on M)
+static int linsolver_disarm_direct(hiopamd_linsolver* ls)
+{
+  if(!ls->direct_armed) return HIOPAMD_OK;
+  const int rc = hiopamd_linsolver_sys_matrix_sync(ls);
+  ls->direct_armed = false;
+  return rc;
+}
+
 int hiopamd_linsolver_set_safe_mode(hiopamd_linsolver* ls, int enable, int n_pos_block)
 {
   if(!ls || n_pos_block < 0 || n_pos_block > ls->n) return HIOPAMD_ERR_ARG;
+  if(enable) {
+    const int rd = linsolver_disarm_direct(ls);
+    if(rd != HIOPAMD_OK) return rd;
+  }
   ls->safe_mode = enable != 0;
   ls->safe_npos = n_pos_block;
   ls->factored = false;
@@ -3161,6 +3217,10 @@ int hiopamd_linsolver_set_safe_mode(hiopamd_linsolver* ls, int enable, int n_pos
 int hiopamd_linsolver_set_pivoting(hiopamd_linsolver* ls, int enable)
 {
   if(!ls) return HIOPAMD_ERR_ARG;
+  if(enable) {
+    const int rd = linsolver_disarm_direct(ls);
+    if(rd != HIOPAMD_OK) return rd;
+  }
   ls->factored = false;
   if(enable && !ls->bk) {
     const int rc = hiopamd_ldlt_bk_create(&ls->bk, ls->ctx, ls->n);
@@ -3184,36 +3244,38 @@ int hiopamd_linsolver_growth(hiopamd_linsolver* ls, double* max_abs_u_host, doub
   if(!ls) return HIOPAMD_ERR_ARG;
   if(!ls->factored) return HIOPAMD_ERR_STATE;
   const int n = ls->n;
-  const double* M = ls->M;
+  const double* M = ls->factor_in_pad ? ls->Mpad : ls->M;
+  const int64_t ld = ls->factor_in_pad ? ls->npad : n;
   struct OpU {
     const double* M;
     int n;
+    int64_t ld;
     __device__ double identity() const { return 0.0; }
     __device__ double map(int64_t e) const
     {
       const int64_t r = e / n, c = e - r * n;
-      return c > r ? fabs(M[e]) : 0.0;
+      return c > r ? fabs(M[r * ld + c]) : 0.0;
     }
     __device__ double combine(double a, double b) const { return fmax(a, b); }
   };
   struct OpDmin {
     const double* M;
-    int n;
+    int64_t n;   // (the pitch)
     __device__ double identity() const { return DBL_MAX; }
-    __device__ double map(int64_t i) const { return fabs(M[i * (int64_t)n + i]); }
+    __device__ double map(int64_t i) const { return fabs(M[i * n + i]); }
     __device__ double combine(double a, double b) const { return fmin(a, b); }
   };
   struct OpDmax {
     const double* M;
-    int n;
+    int64_t n;   // (the pitch)
     __device__ double identity() const { return 0.0; }
-    __device__ double map(int64_t i) const { return fabs(M[i * (int64_t)n + i]); }
+    __device__ double map(int64_t i) const { return fabs(M[i * n + i]); }
     __device__ double combine(double a, double b) const { return fmax(a, b); }
   };
   double u = 0.0, dmin = 0.0, dmax = 0.0;
-  int rc = hiopamd::launch_reduce<double>(ls->ctx, (int64_t)n * n, OpU{M, n}, &u);
-  if(rc == HIOPAMD_OK) rc = hiopamd::launch_reduce<double>(ls->ctx, n, OpDmin{M, n}, &dmin);
-  if(rc == HIOPAMD_OK) rc = hiopamd::launch_reduce<double>(ls->ctx, n, OpDmax{M, n}, &dmax);
+  int rc = hiopamd::launch_reduce<double>(ls->ctx, (int64_t)n * n, OpU{M, n, ld}, &u);
+  if(rc == HIOPAMD_OK) rc = hiopamd::launch_reduce<double>(ls->ctx, n, OpDmin{M, ld}, &dmin);
+  if(rc == HIOPAMD_OK) rc = hiopamd::launch_reduce<double>(ls->ctx, n, OpDmax{M, ld}, &dmax);
   if(max_abs_u_host) *max_abs_u_host = u;
   if(min_abs_d_host) *min_abs_d_host = dmin;
   if(max_abs_d_host) *max_abs_d_host = dmax;
@@ -3277,6 +3339,10 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
   ls->flops_fact += (double)n * n * n / 3.0;
   const dim3 tgrid((unsigned)((n + 127) / 128), (unsigned)((n + 127) / 128));
   const bool padded = ls->npad > n;
+  // (the caller assembled the padded copy itself: hiopamd_linsolver_assembly_matrix.  Not in safe mode, which works on M and its copy.)
+  const bool direct = padded && ls->direct_armed && !ls->safe_mode;
+  ls->direct_armed = false;
+  ls->factor_in_pad = false;
   auto factor_once = [&]() -> int {
     // (see DfDevice::skip_once)
     const bool df_was = ls->df.enabled;
@@ -3288,16 +3354,14 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
       // the padded order: diag(M, I), upper triangle (dataflow or stepwise kernels alike: the solves' tables are built for that
       // order); the factor comes back into M, which is untouched if the kernels give up
       const int np = ls->npad;
-      if(!ls->Mpad) {
-        // (the lower triangle is never assembled, but the diagonal tiles are read and written as whole tiles: defined once, like a caller's matrix)
-        HIOPAMD_CHECK(hipMalloc((void**)&ls->Mpad, sizeof(double) * (size_t)np * np));
-        HIOPAMD_CHECK(hipMemsetAsync(ls->Mpad, 0, sizeof(double) * (size_t)np * np, ls->ctx->stream));
-      }
-      hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->M, (int64_t)n, ls->Mpad, (int64_t)np);
+      const int re = linsolver_ensure_pad(ls);
+      if(re != HIOPAMD_OK) return re;
+      if(!direct) hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->M, (int64_t)n, ls->Mpad, (int64_t)np);
       hipLaunchKernelGGL(ldlt_pad_tail_kernel, dim3((unsigned)np), dim3(kBlock), 0, ls->ctx->stream, n, np, ls->Mpad, (int64_t)np);
       r = ldlt_factor_impl(ls->ctx, np, ls->Mpad, np, ls->dinv, ls->V, ls->Dblk, ls->Cd, ls->d_info, ls->inertia, &ls->prof, ls->W, &ls->df, ls->fl_B, ls->Wt);
       if(r == HIOPAMD_OK || r == HIOPAMD_ERR_SINGULAR) {
-        hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mpad, (int64_t)np, ls->M, (int64_t)n);
+        if(!direct) hipLaunchKernelGGL(ldlt_triu_repitch_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mpad, (int64_t)np, ls->M, (int64_t)n);
+        ls->factor_in_pad = direct;
         ls->inertia[0] -= np - n;   // the unit pivots
       }
     } else {
@@ -3339,9 +3403,9 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
     } else if(use_retry) {
       hipLaunchKernelGGL(ldlt_triu_copy_kernel, tgrid, dim3(kBlock), 0, ls->ctx->stream, n, ls->Mretry, ls->M, (int64_t)n);
       rc = factor_once();   // (skip_once is set: the stepwise kernels)
-    } else if(padded && ls->retry_copy) {
+    } else if(padded && ls->retry_copy && !direct) {
       rc = factor_once();   // (M is intact; skip_once is set: the stepwise kernels)
-    }
+    }   // (direct: the caller's assembly is overwritten, like an unpadded matrix without a retry copy — it re-assembles and calls again)
   }
   if(rc == HIOPAMD_ERR_SINGULAR) {
     // reference: "entry in the factorization's diagonal is exactly zero" -> matrixChanged() returns -1
@@ -3368,6 +3432,17 @@ int hiopamd_linsolver_matrix_changed(hiopamd_linsolver* ls, int* n_neg_host)
       *n_neg_host = -1;
     }
   }
+  return HIOPAMD_OK;
+}
+
+// the padded copy: allocated on first use; the lower triangle is never assembled, but the diagonal tiles are read and written as whole
+// tiles: defined once, like a caller's matrix
+static int linsolver_ensure_pad(hiopamd_linsolver* ls)
+{
+  if(ls->Mpad || ls->npad <= ls->n) return HIOPAMD_OK;
+  const int np = ls->npad;
+  HIOPAMD_CHECK(hipMalloc((void**)&ls->Mpad, sizeof(double) * (size_t)np * np));
+  HIOPAMD_CHECK(hipMemsetAsync(ls->Mpad, 0, sizeof(double) * (size_t)np * np, ls->ctx->stream));
   return HIOPAMD_OK;
 }
 
@@ -3528,6 +3603,9 @@ int hiopamd_ldlt_dataflow_queues(int n, int* queues_host, int cap_panels)
 }
 
 int hiopamd_ldlt_dataflow_nvb(int n) { return df_nvb_for(n); }
+
+// host only: the order a solver object of order n works at (ldlt_padded_order; the environment's HIOPAMD_LDLT_PAD applies)
+int hiopamd_ldlt_padded_order(int n) { return n < 0 ? -1 : ldlt_padded_order(n); }
 
 int hiopamd_ldlt_dataflow_far_queues(int n, int* far_host, int cap_panels)
 {

@@ -509,6 +509,18 @@ int hiopamd_linsolver_destroy(hiopamd_linsolver* ls);
  * copy (n = 8191: 5.3 instead of 8.9 ms; n = 8000: 5.8 instead of 6.2 ms per factorisation + 3 solves); the caller sees no difference —
  * same matrix view, same factor in it, same inertia — except that the matrix is not written before the factorisation has succeeded. */
 double* hiopamd_linsolver_sys_matrix(hiopamd_linsolver* ls);
+/* For callers that can assemble at ANY pitch (the native KKT objects of this library): where to write the upper triangle of the next
+ * matrix — for an object that works at a padded order, the padded copy itself (*ld_out = that order), and the next
+ * hiopamd_linsolver_matrix_changed factors it where it is (no copy in, no copy back).  Call it before every such assembly: it arms ONE
+ * matrixChanged.  After a factorisation of this kind hiopamd_linsolver_sys_matrix does not show the factor until
+ * hiopamd_linsolver_sys_matrix_sync has been called, the assembled matrix is overwritten, and an expired wait is reported as
+ * HIOPAMD_ERR_TIMEOUT (assemble again and call again).  Every other object / safe mode / pivoted mode: the matrix of
+ * hiopamd_linsolver_sys_matrix, *ld_out = n, nothing changes. */
+int hiopamd_linsolver_assembly_matrix(hiopamd_linsolver* ls, double** M_out, int64_t* ld_out);
+int hiopamd_linsolver_sys_matrix_sync(hiopamd_linsolver* ls);
+/* host only: the order a solver object of order n works at — n, n made even, or the next multiple of 256 / 512 (a cost model of one
+ * factorisation + three solves + the copies; n < 1024: n) */
+int hiopamd_ldlt_padded_order(int n);
 int hiopamd_linsolver_n(const hiopamd_linsolver* ls);
 /* matrixChanged(): factorise in place; *n_neg_host = number of negative pivots, or -1 if a pivot is
  * (numerically) zero / non-finite -- the reference's "singular" return.

@@ -185,6 +185,7 @@ PROBLEMS = [
     lambda: pr.mds_ex1(40, 12, empty_sp_row=True),
     lambda: pr.mds_ex1(400, 100),
     lambda: pr.mds_ex1_g(600, 130, 257),
+    lambda: pr.mds_ex1_g(900, 700, 500),   # N = 1203: the solver object works at a padded order, the KKT object assembles into its padded copy
 ]
 
 
