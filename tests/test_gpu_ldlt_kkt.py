@@ -283,6 +283,49 @@ def test_kkt_mds_inertia_correction_signal(ctx):
     kg.close()
 
 
+def test_kkt_mds_mode_switches_between_assembly_and_factorisation_at_a_padded_order(ctx):
+    """N = 1203: the solver object works at a padded order and the KKT object assembles straight into its padded copy
+    (hiopamd_linsolver_assembly_matrix).  Safe mode and the pivoted solver work on the N x N matrix instead: switching one of them on
+    AFTER an assembly and BEFORE its factorisation must carry the assembled matrix over; switching back must return to the padded copy."""
+    p = pr.mds_ex1_g(900, 700, 500)
+    ko, kg, dv = _kkt_pair(ctx, p)
+    deltas = (1e-4, 1e-4, 1e-8, 1e-8)
+    ko.build_kkt_matrix(*deltas)
+    n_o = ko.factorize_with_curv_check()
+    rx, ryc, ryd = pr.random_rhs(p)
+    ok, dx_o, dyc_o, dyd_o = ko.solve_compressed(rx, ryc, ryd)
+    assert ok and n_o == p.neq + p.nineq
+    scale = max(np.abs(dx_o).max(), np.abs(dyc_o).max(), np.abs(dyd_o).max())
+    L = kg._L
+
+    def solve():
+        dx, dyc, dyd = D(np.zeros_like(rx)), D(np.zeros_like(ryc)), D(np.zeros_like(ryd))
+        rxd, rycd, rydd = D(rx), D(ryc), D(ryd)
+        torch.cuda.synchronize()
+        kg.solve_compressed(rxd, rycd, rydd, dx, dyc, dyd)
+        ctx.sync()
+        return dx.cpu().numpy(), dyc.cpu().numpy(), dyd.cpu().numpy()
+
+    for mode in (1, 2, 0, 1, 0):          # regularise-and-refine, Bunch-Kaufman, plain (padded copy), and again
+        # the control: the mode set BEFORE the assembly (which then writes the N x N matrix for modes 1 and 2)
+        assert L.hiopamd_kkt_mds_set_safe_mode(kg.h, mode) == 0
+        kg.build_kkt_matrix(*deltas)
+        assert kg.factorize_with_curv_check() == n_o, mode
+        want = solve()
+        # the case: assembled in plain mode (into the padded copy), the mode switched on afterwards
+        assert L.hiopamd_kkt_mds_set_safe_mode(kg.h, 0) == 0
+        kg.build_kkt_matrix(*deltas)
+        assert L.hiopamd_kkt_mds_set_safe_mode(kg.h, mode) == 0
+        assert kg.factorize_with_curv_check() == n_o, mode
+        got = solve()
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), mode      # the same matrix through the same kernels: the same bits
+        res = ho.kkt_mds_full_residual(ko, deltas, rx, ryc, ryd, *got)
+        assert max(res) < (1e-9 if mode == 1 else 1e-11), (mode, res)   # (safe mode refines to 1e-13 (||K|| ||x|| + ||b||), not componentwise)
+        assert np.abs(got[0] - dx_o).max() / scale < (1e-5 if mode == 1 else 1e-8), mode   # (forward error of the refined solve: x cond(K))
+    kg.close()
+
+
 def test_kkt_mds_full_size_roundtrip(ctx):
     """BASELINE config 3 (n_sparse=1e5, n_dense=4096, m=4096 -> N=8192): assemble -> factor -> solve, checked
     by the size-independent property 'residual of the uncondensed KKT system' (sparse mat-vecs on host)."""
