@@ -382,7 +382,7 @@ def sparse_condensed_bench(ctx, a, n=1_000_000, pattern="sparse_ex2"):
         if Ls.hiopamd_kkt_sparse_condensed_ldl_info(K.h, i8) == 0:
             nnzL = int(i8[4])
             bytes_step = 8.0 * nnzL * (1 + 2 * a.solves)
-            out["roofline"] = dict(bound="hbm", kernel="sl_factor_level / sl_fwd_level / sl_bwd_level (one launch per tree level)",
+            out["roofline"] = dict(bound="hbm", kernel="sl_factor_regs (leaf-like levels: one wave per front, the front in registers) / sl_factor_level / sl_fwd_level / sl_bwd_level (one launch per tree level)",
                                    achieved=bytes_step / (dt / a.steps) / 1e9, peak=8000.0, unit="GB/s",
                                    frac=bytes_step / (dt / a.steps) / 8e12, algorithmic_bytes_per_step=bytes_step,
                                    nnz_L=nnzL, supernodes=int(i8[0]), levels=int(i8[2]), root_order=int(i8[3]), traffic=None,
