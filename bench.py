@@ -388,6 +388,18 @@ def sparse_condensed_bench(ctx, a, n=1_000_000, pattern="sparse_ex2"):
                                    nnz_L=nnzL, supernodes=int(i8[0]), levels=int(i8[2]), root_order=int(i8[3]), traffic=None,
                                    note="algorithmic bytes = 8 nnz(L) (1 write + 2 reads per solve); whole step time, launches and host "
                                         "round trip of the inertia included")
+            # HBM-side traffic of the level kernels of one step (PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes), measured on
+            # THIS pattern (banded n = 1e6): scripts/calls/r06_pmc_sparse.sh -> profiles/r06_pmc_sparse/summary.json
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_sparse", "summary.json")))["per_step"]
+                if pattern == "chain" and n == 1_000_000:
+                    tr = pmc["factor_fetch_bytes"] + pmc["factor_write_bytes"] + a.solves * (pmc["solve_fetch_bytes"] + pmc["solve_write_bytes"])
+                    out["roofline"].update(traffic=tr, traffic_over_algorithmic=tr / bytes_step,
+                                           traffic_source="profiles/r06_pmc_sparse/summary.json: the level kernels of 1 factorisation + "
+                                                          f"{a.solves} solves; the L panels are stored as full nc x f rectangles (zeros above the "
+                                                          "diagonal of the pivot block) and the sweeps also read index lists and gather plans")
+            except Exception:
+                pass
     K.close()
     return out
 
